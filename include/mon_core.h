@@ -1,0 +1,147 @@
+/*
+ * mon_core.h -- C ABI of libmon_core.so, the MI355X-native Multi-Object-NeRF core.
+ *
+ * This is the drop-in boundary for the one hot path of XiaoHan-Git/RO-MAP: the per-object NeRF
+ * inside dependencies/Multi-Object-NeRF/Core (libMON.so).  The reference exposes a C++ ABI
+ * (namespace nerf, Eigen / cv::Mat types); every entry point below cites the reference member it
+ * replaces.  CORE = /root/reference/dependencies/Multi-Object-NeRF/Core.  The C++ shim that
+ * reproduces the reference's class names on top of this ABI is shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns an int status
+ * (MON_OK == 0); matrices are 4x4 float, column-major (Eigen::Matrix4f memory order); images are
+ * row-major HxW.  A handle may be used from one thread at a time; different handles are
+ * independent (the reference runs one std::thread per object, CORE/src/nerf_manager.cu:89,259).
+ * There is NO CPU fallback: every compute entry point fails with MON_ERR_NO_DEVICE when no gfx950
+ * device is visible.
+ */
+#ifndef MON_CORE_H
+#define MON_CORE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MON_OK              0
+#define MON_ERR_ARG         1   /* bad argument                                        */
+#define MON_ERR_NO_DEVICE   2   /* no HIP device (reference: cerr + exit(0), nerf_manager.cu:21-25) */
+#define MON_ERR_HIP         3   /* HIP runtime error (reference: CUDA_CHECK_THROW)     */
+#define MON_ERR_IO          4   /* file / parse error                                  */
+#define MON_ERR_STATE       5   /* call not valid in the current state                 */
+#define MON_ERR_NO_RAYS     6   /* a training step found zero rays inside the 3-D box (reference: i % 0 UB, nerf_model.cu:287) */
+
+/* Network / training configuration.  Fields follow CORE/configs/base.json (tcnn JSON schema) and
+ * the compile-time constants of CORE/include/nerf_model.h:145,166,172-175 promoted to runtime. */
+typedef struct mon_config {
+    int32_t  n_levels;             /* encoding.n_levels (16)                                 */
+    int32_t  n_features;           /* encoding.n_features_per_level; must be 2               */
+    int32_t  log2_hashmap_size;    /* encoding.log2_hashmap_size (16)                        */
+    int32_t  base_resolution;      /* encoding.base_resolution (16)                          */
+    float    per_level_scale;      /* encoding.per_level_scale; tcnn default 2.0             */
+    int32_t  n_neurons;            /* network.n_neurons: 32 or 64                            */
+    int32_t  n_hidden_layers;      /* network.n_hidden_layers: 1 or 2                        */
+    int32_t  rays_per_batch;       /* mnRaysPerBatch (4096); multiple of 64                  */
+    int32_t  n_samples;            /* mnSampleNum (32); render uses 2x (mnRenderSampleNum)   */
+    float    loss_scale;           /* mLoss_Scale (128)                                      */
+    float    learning_rate;        /* optimizer...nested.nested.learning_rate (1e-2)         */
+    float    beta1, beta2, epsilon, l2_reg;
+    float    ema_decay;            /* optimizer.decay (0.95)                                 */
+    int32_t  decay_start, decay_interval;
+    float    decay_base;
+    uint32_t param_seed;           /* m_seed (1337)                                          */
+    uint32_t reserved0;
+    uint64_t sample_seed;          /* counter-RNG key replacing the cuRAND XORWOW stream     */
+    int32_t  use_depth;            /* NeRF_Model::mbUseDepth                                 */
+    int32_t  reserved1;
+} mon_config;
+
+/* CORE/include/common.h:18-23 (note: h before w). */
+typedef struct mon_frame_bbox { uint32_t FrameId, x, y, h, w; } mon_frame_bbox;
+
+typedef struct mon_dataset mon_dataset;   /* nerf::NeRF_Dataset, one per device (nerf_data.h:19-71)   */
+typedef struct mon_object  mon_object;    /* nerf::NeRF + nerf::NeRF_Model (nerf.h:19-89, nerf_model.h:92-184) */
+
+typedef struct mon_object_info {
+    uint32_t n_params, n_mlp_params, n_grid_params, encoded_width;
+    uint32_t train_step;           /* mnTrainingStep                                        */
+    uint32_t n_boxes;              /* mnBbox                                                */
+    uint32_t last_n_valid;         /* rays inside the 3-D box in the last batch             */
+    int32_t  device;               /* mGPUid                                                */
+    float    last_loss;            /* mfPerTrainLoss                                        */
+    float    learning_rate;        /* after ExponentialDecay                                */
+} mon_object_info;
+
+/* Kernel classes timed with HIP events on the object's train stream when profiling is on. */
+enum { MON_K_BATCH = 0, MON_K_FWDBWD = 1, MON_K_OPTIM = 2, MON_K_RENDER = 3, MON_K_COUNT = 8 };
+typedef struct mon_profile { double ms[MON_K_COUNT]; uint64_t launches[MON_K_COUNT]; } mon_profile;
+
+const char* mon_last_error(void);                 /* thread-local message for the last non-OK status */
+int mon_version(void);
+
+/* NerfManager{Offline,Online}::Init -- device discovery (nerf_manager.cu:16-38, :136-158). */
+int mon_device_count(int* n_devices);
+
+/* NeRF_Model::ReadNetworkConfig (nerf_model.cu:1272-1284): tcnn JSON with comments. */
+int mon_config_default(mon_config* cfg);                       /* CORE/configs/base.json values */
+int mon_config_from_json(const char* path, mon_config* cfg);
+
+/* NerfManagerOnline::DatasetInit / NeRF_Dataset::InitDataToGPU (nerf_manager.cu:160-187, nerf_data.cu:237-271):
+ * intrinsics + capacity for max_frames frames resident in HBM on `device`. */
+int mon_dataset_create(int device, int H, int W, float fx, float fy, float cx, float cy,
+                       uint32_t max_frames, int use_depth, mon_dataset** out);
+/* NerfManagerOnline::NewFrameToDataset / NeRF_Dataset::FrameDataToGPU (nerf_manager.cu:189-218,
+ * nerf_data.cu:273-339) and the per-image body of DataToGPU (nerf_data.cu:151-221).
+ * rgb: HxWxchannels 8-bit (channels 3 or 4), is_bgr as delivered by cv::imread / the SLAM frontend;
+ * instance: HxW 8-bit instance ids (0 = background); depth: HxW float metres (z-depth, 0 = none) or NULL;
+ * Twc16: camera-to-world pose. */
+int mon_dataset_add_frame(mon_dataset* ds, uint32_t frame_id, const uint8_t* rgb, int channels, int is_bgr,
+                          const uint8_t* instance, const float* depth, const float* Twc16);
+int mon_dataset_n_frames(const mon_dataset* ds, uint32_t* n);
+int mon_dataset_destroy(mon_dataset* ds);
+
+/* NerfManagerOnline::CreateNeRF / NeRF::SetAttributes + CreateModelOnline + ResetNetwork
+ * (nerf_manager.cu:237-261, nerf.cu:155-185, nerf_model.cu:1259-1342) and NerfManagerOffline::CreateNeRF
+ * (nerf_manager.cu:64-92).  class_id doubles as the instance id (nerf.cu:75,158).  The 1.1x/1.2x box
+ * inflation of SetAttributes is the caller's business (the shim applies it); aabb is used as given. */
+int mon_object_create(mon_dataset* ds, const mon_config* cfg, int class_id, const float* Tow16,
+                      const float* aabb_min3, const float* aabb_max3, mon_object** out);
+/* NeRF_Model::UpdateFrameIdAndBbox / UpdateFrameIdAndBboxOnline (nerf_model.cu:1609-1628): append. */
+int mon_object_add_boxes(mon_object* obj, const mon_frame_bbox* boxes, size_t n);
+/* NeRF_Model::Train_Step / Train_Step_Online (nerf_model.cu:1630-1699): `iters` iterations of
+ * GenerateBatch -> Step_No_Compacted -> optimizer_step; returns after the train stream drained.
+ * *loss (may be NULL) = mean per-ray loss of the last iteration (mfPerTrainLoss). */
+int mon_object_train(mon_object* obj, int iters, float* loss);
+/* NeRF_Model::Render (nerf_model.cu:1702-1830; pose_is_Toc=0, pose=Twc) and one pose of RenderVideo
+ * (:1916-1976; pose_is_Toc=1).  Outputs box.h x box.w: rgb[3*h*w] float RGB, depth, mask; host
+ * pointers unless dst_on_device != 0 (then device pointers on the object's device). */
+int mon_object_render(mon_object* obj, mon_frame_bbox box, const float* pose16, int pose_is_Toc,
+                      float* rgb, float* depth, float* mask, int dst_on_device);
+/* NeRF_Model::GetDensityOnGrid (nerf_model.cu:2007-2048): raw density channel on an rx*ry*rz lattice. */
+int mon_object_density_grid(mon_object* obj, int rx, int ry, int rz, float* out_host);
+
+int mon_object_info_get(mon_object* obj, mon_object_info* info);
+/* Parameter I/O (the reference has none; needed for fixtures/checkpoints).
+ * which: 0 fp32 master, 1 fp16 working copy, 2 fp16 EMA (inference) copy. */
+int mon_object_get_params(mon_object* obj, int which, void* dst, size_t bytes);
+int mon_object_set_params(mon_object* obj, const float* master, size_t n);
+/* Test hooks: split one iteration so intermediate buffers can be compared with the oracle.
+ * stage bits: 1 GenerateBatch, 2 forward+backward, 4 optimizer_step(+step counter). */
+int mon_object_train_stages(mon_object* obj, int stage_bits);
+/* Backend selector for forward/backward: 0 = unfused reference kernels, 1 = fused MFMA kernel. */
+int mon_object_set_backend(mon_object* obj, int backend);
+/* Copy an internal device buffer to the host; ids in ro-map_amd/csrc/model.h (MON_BUF_*). */
+int mon_object_debug_read(mon_object* obj, int which, void* dst, size_t bytes);
+int mon_object_set_profiling(mon_object* obj, int enable);
+int mon_object_get_profile(mon_object* obj, mon_profile* out, int reset);
+int mon_object_destroy(mon_object* obj);
+
+/* Whole-device helpers used by bench.py. */
+int mon_device_synchronize(int device);
+/* MFMA fragment-layout self-test (tests only): D[32x32] = A[32x16] * B[16x32], fp16 in / fp32 out. */
+int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MON_CORE_H */

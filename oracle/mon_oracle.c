@@ -1,0 +1,649 @@
+/*
+ * mon_oracle.c -- CPU restatement of the RO-MAP Multi-Object-NeRF hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under ro-map_amd/ may include, link or call
+ * this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it
+ * (as the checker / the timed CPU baseline, never as the thing shipped).
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path
+ * and cannot be built here (CUDA-only; tiny-cuda-nn submodule absent; Eigen/OpenCV/GLEW
+ * absent).  This file restates
+ *   (a) the reference's own kernels, citing CORE/src/nerf_model.cu file:line
+ *       (CORE = /root/reference/dependencies/Multi-Object-NeRF/Core), and
+ *   (b) the published algorithm of the un-vendored dependency NVlabs/tiny-cuda-nn
+ *       (v1.6 era, late 2022; pinned commit not recoverable) for the
+ *       hash-grid encoding, fully fused MLP, Adam / ExponentialDecay / EMA optimizers.
+ * It is pinned by this repo's own known-answer tests (tests/test_oracle_*.py): closed-form
+ * composite, finite-difference / torch-autograd checks of the hand-derived gradient,
+ * closed-form Adam/EMA step, hash-index KATs.
+ *
+ * Numeric model (rounding points; "h()" = round-to-nearest-even to IEEE fp16):
+ *   table/weights  fp16 working copy of fp32 master           (tcnn: half params + fp32 master)
+ *   encode         fp32 fmaf chain over the 8 corners, h() once per feature
+ *                  (tcnn accumulates the 8 products in half; <= 4 half-ulp apart)
+ *   MLP            fp16 in, fp16 weights, fp32 fmaf chain over k, h() per activation
+ *   composite      fp32                                       (nerf_model.cu:735-815)
+ *   dL/dO          fp32 math, h() on store                    (nerf_model.cu:917-945)
+ *   MLP backward   dh, dE: fp32 chain then h(); dW accumulated in fp32 (tcnn: fp16 GEMM out)
+ *   grid backward  each contribution h(w * dE) as in tcnn; accumulated in fp32 here
+ *                  (tcnn: atomicAdd(__half2), order-dependent) then h() before Adam
+ *   Adam/EMA       fp32, as tcnn
+ * All geometry uses explicit fmaf chains; build with -ffp-contract=off so that the HIP
+ * path (same chains) is bit-comparable up to expf/powf implementation differences.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#if defined(__F16C__)
+#include <immintrin.h>
+#endif
+
+#define ORC_MAX_LEVELS 32
+#define ORC_OUT 4          /* rgb + density (nerf_model.cu:1318: NetworkWithInputEncoding(3,4,..)) */
+#define ORC_OUT_PAD 16     /* tcnn pads the MLP output to a multiple of 16 */
+
+/* ---- configuration; layout mirrors include/mon_core.h:mon_config on purpose so one
+ *      ctypes.Structure serves both (declared independently, not shared code). ---- */
+typedef struct {
+    int32_t n_levels;            /* base.json encoding.n_levels            */
+    int32_t n_features;          /* must be 2 (base.json:25)               */
+    int32_t log2_hashmap_size;   /* base.json:26                           */
+    int32_t base_resolution;     /* base.json:27                           */
+    float   per_level_scale;     /* tcnn default 2.0 (TCNN-A1; nerf_model.cu:1305-1313 only prints its own) */
+    int32_t n_neurons;           /* base.json:34                           */
+    int32_t n_hidden_layers;     /* base.json:35                           */
+    int32_t rays_per_batch;      /* nerf_model.h:173 (4096)                */
+    int32_t n_samples;           /* common.h:12 SampleNum 32; render uses 2x (nerf_model.h:175) */
+    float   loss_scale;          /* nerf_model.h:166 (128)                 */
+    float   learning_rate;       /* base.json:16                           */
+    float   beta1, beta2, epsilon, l2_reg;   /* base.json:17-20            */
+    float   ema_decay;           /* base.json:7                            */
+    int32_t decay_start, decay_interval;     /* base.json:10-11            */
+    float   decay_base;          /* base.json:12                           */
+    uint32_t param_seed;         /* nerf_model.h:145 (1337)                */
+    uint32_t reserved0;
+    uint64_t sample_seed;        /* cuRAND XORWOW stream parity is not attempted; counter RNG below */
+    int32_t use_depth;           /* NeRF_Model::mbUseDepth                 */
+    int32_t grid_grad_half_accum;/* oracle-only: 1 = accumulate grid grads sequentially in fp16 */
+} orc_config;
+
+typedef struct { uint32_t FrameId, x, y, h, w; } orc_bbox;   /* common.h:18-23 (h before w) */
+
+/* ------------------------------------------------------------------ fp16 */
+static inline uint16_t f2h(float f) {
+#if defined(__F16C__)
+    return (uint16_t)_cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+#else
+    uint32_t x; memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u; x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((x > 0x7f800000u) ? 0x200u : 0));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);          /* rounds to inf */
+    if (x < 0x33000001u) return (uint16_t)sign;                       /* rounds to zero */
+    int e = (int)(x >> 23) - 127; uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    int shift = (e < -14) ? (13 + (-14 - e)) : 13; int he = (e < -14) ? 0 : e + 15;
+    uint32_t hm = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (hm & 1))) hm++;
+    uint32_t r = (e < -14) ? hm : (((uint32_t)he << 10) + (hm - 0x400u));
+    return (uint16_t)(sign | r);
+#endif
+}
+static inline float h2f(uint16_t h) {
+#if defined(__F16C__)
+    return _cvtsh_ss(h);
+#else
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ffu, x;
+    if (e == 0) { if (!m) x = sign; else { int s = 0; while (!(m & 0x400u)) { m <<= 1; s++; } m &= 0x3ffu; x = sign | ((uint32_t)(113 - s) << 23) | (m << 13); } }
+    else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f; memcpy(&f, &x, 4); return f;
+#endif
+}
+uint16_t orc_f2h(float f) { return f2h(f); }
+float orc_h2f(uint16_t h) { return h2f(h); }
+
+/* ------------------------------------------------------------------ RNG
+ * Sampling stream: counter-based splitmix64 finaliser; u in [0,1).  Replaces the three
+ * curandGenerateUniform calls (nerf_model.cu:1432,1434,1468; XORWOW, default seed).
+ * streams: 0 SampleXY[2R], 1 RandColors[3R], 2 RandDt[S*R], 3 render RandDt. */
+static inline float rand01(uint64_t seed, uint32_t stream, uint32_t step, uint32_t idx) {
+    uint64_t ctr = ((uint64_t)stream << 60) | ((uint64_t)step << 28) | (uint64_t)(idx & 0x0fffffffu);
+    uint64_t z = ctr + seed * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+}
+float orc_rand01(uint64_t seed, uint32_t stream, uint32_t step, uint32_t idx) { return rand01(seed, stream, step, idx); }
+
+/* Parameter-init stream: pcg32 as used by tcnn::default_rng_t (public-domain PCG, Jakob's
+ * pcg32.h): seed(initstate, initseq=1).  Element k of the parameter vector takes the k-th
+ * draw (tcnn's generate_random_uniform interleaves draws per thread; not reproduced). */
+typedef struct { uint64_t state, inc; } pcg32;
+static uint32_t pcg_next(pcg32* r) {
+    uint64_t old = r->state; r->state = old * 0x5851f42d4c957f2dull + r->inc;
+    uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u);
+    return (xs >> rot) | (xs << ((~rot + 1u) & 31));
+}
+static void pcg_seed(pcg32* r, uint64_t initstate, uint64_t initseq) {
+    r->state = 0; r->inc = (initseq << 1u) | 1u; pcg_next(r); r->state += initstate; pcg_next(r);
+}
+static float pcg_float(pcg32* r) { uint32_t u = (pcg_next(r) >> 9) | 0x3f800000u; float f; memcpy(&f, &u, 4); return f - 1.0f; }
+
+/* ------------------------------------------------------------------ grid geometry (tcnn grid.h) */
+static inline uint32_t next_multiple(uint32_t v, uint32_t d) { return ((v + d - 1) / d) * d; }
+
+/* TCNN-A1/A2/A4: scale_l = 2^(l*log2 b) * Nmin - 1 ; res = ceil(scale)+1 ;
+ * entries = min(round_up(res^3, 8), 2^T). offsets has n_levels+1 entries. Returns E_pad. */
+int orc_level_table(const orc_config* c, uint32_t* offsets, float* scales, uint32_t* res) {
+    uint32_t off = 0; float l2 = log2f(c->per_level_scale);
+    for (int l = 0; l < c->n_levels; ++l) {
+        float s = exp2f((float)l * l2) * (float)c->base_resolution - 1.0f;
+        uint32_t r = (uint32_t)ceilf(s) + 1u;
+        uint64_t dense = (uint64_t)r * r * r; uint32_t maxp = 0xffffffffu / 2;
+        uint32_t n = dense > maxp ? maxp : (uint32_t)dense;
+        n = next_multiple(n, 8u);
+        uint32_t cap = 1u << c->log2_hashmap_size; if (n > cap) n = cap;
+        offsets[l] = off; scales[l] = s; res[l] = r; off += n;
+    }
+    offsets[c->n_levels] = off;
+    return (int)next_multiple((uint32_t)(c->n_levels * c->n_features), 16u);
+}
+
+/* TCNN-A3: dense index with overflow guard, else coherent-prime hash; then % size. */
+static inline uint32_t grid_index(uint32_t size, uint32_t res, uint32_t x, uint32_t y, uint32_t z) {
+    uint32_t stride = 1, index = 0; const uint32_t p[3] = { x, y, z };
+    for (int d = 0; d < 3 && stride <= size; ++d) { index += p[d] * stride; stride *= res; }
+    if (size < stride) index = (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);
+    return index % size;
+}
+uint32_t orc_grid_index(uint32_t size, uint32_t res, uint32_t x, uint32_t y, uint32_t z) { return grid_index(size, res, x, y, z); }
+
+/* ------------------------------------------------------------------ model */
+typedef struct {
+    orc_config cfg;
+    int L, W, NH, Epad, R, S;
+    uint32_t off[ORC_MAX_LEVELS + 1], res[ORC_MAX_LEVELS]; float scale[ORC_MAX_LEVELS];
+    uint32_t n_mlp, n_grid, n_params;
+    /* parameters, tcnn layout: [MLP matrices row-major (out x in) | grid entries x F] */
+    float* master; uint16_t* half; uint16_t* ema; float* m1; float* m2; uint32_t* steps;
+    float* gmlp;            /* fp32 dW (n_mlp) */
+    float* ggrid;           /* fp32 accumulated grid gradient (n_grid) */
+    float* ggrid_abs;       /* sum |contribution| per entry, for tolerance bounds */
+    uint16_t* ggrid_h;      /* h() of the above = what Adam consumes */
+    uint32_t step;          /* optimizer steps taken */
+    uint32_t iter;          /* batches generated: RNG counter, advances even when a batch is skipped */
+    float lr; int has_ema;
+    /* dataset (host copies) */
+    int H, Wimg, n_frames, use_depth; float fx, fy, cx, cy;
+    const uint8_t* rgba;    /* [n][H][W][4]: r,g,b,instance (caller owned) */
+    const float* depth;     /* [n][H][W] metres or NULL */
+    const float* poses;     /* [n][16] Twc column-major */
+    /* object */
+    float Tow[16]; float amin[3], amax[3]; uint8_t inst;
+    orc_bbox* boxes; size_t n_boxes;
+    /* last batch (kept for the tests) */
+    uint32_t n_valid; uint8_t* valid; uint32_t* sel;
+    float *ray_o, *ray_d, *ray_dn, *ray_tmin, *ray_tmax, *target, *target_depth, *bgcol; uint8_t* ray_flag;
+    float *pts, *tdist; uint16_t *E, *Hid, *O, *dO, *dHid, *dE;
+    float *rgb_ray, *depth_ray, *mask_ray, *loss_ray; float loss;
+} orc_model;
+
+static uint32_t mlp_params(int W, int NH, int Epad) { return (uint32_t)(W * Epad + (NH - 1) * W * W + ORC_OUT_PAD * W); }
+
+orc_model* orc_create(const orc_config* c) {
+    orc_model* m = (orc_model*)calloc(1, sizeof(orc_model));
+    m->cfg = *c; m->L = c->n_levels; m->W = c->n_neurons; m->NH = c->n_hidden_layers; m->R = c->rays_per_batch; m->S = c->n_samples;
+    m->Epad = orc_level_table(c, m->off, m->scale, m->res);
+    m->n_mlp = mlp_params(m->W, m->NH, m->Epad); m->n_grid = m->off[m->L] * 2u; m->n_params = m->n_mlp + m->n_grid;
+    size_t n = m->n_params;
+    m->master = (float*)calloc(n, 4); m->half = (uint16_t*)calloc(n, 2); m->ema = (uint16_t*)calloc(n, 2);
+    m->m1 = (float*)calloc(n, 4); m->m2 = (float*)calloc(n, 4); m->steps = (uint32_t*)calloc(n, 4);
+    m->gmlp = (float*)calloc(m->n_mlp, 4); m->ggrid = (float*)calloc(m->n_grid, 4); m->ggrid_abs = (float*)calloc(m->n_grid, 4);
+    m->ggrid_h = (uint16_t*)calloc(m->n_grid, 2);
+    m->lr = c->learning_rate;
+    /* TCNN-A5: MLP Xavier-uniform per matrix, grid U(-1e-4,1e-4); network params first. */
+    pcg32 rng; pcg_seed(&rng, c->param_seed, 1u);
+    uint32_t k = 0;
+    for (int layer = 0; layer <= m->NH; ++layer) {
+        int rows = (layer == m->NH) ? ORC_OUT_PAD : m->W, cols = (layer == 0) ? m->Epad : m->W;
+        float sc = sqrtf(6.0f / (float)(rows + cols));
+        for (int i = 0; i < rows * cols; ++i, ++k) m->master[k] = pcg_float(&rng) * (2.0f * sc) - sc;
+    }
+    for (; k < m->n_params; ++k) m->master[k] = pcg_float(&rng) * 2e-4f - 1e-4f;
+    for (k = 0; k < m->n_params; ++k) m->half[k] = f2h(m->master[k]);
+    size_t R = (size_t)m->R, B = R * (size_t)m->S;
+    m->valid = (uint8_t*)calloc(R, 1); m->sel = (uint32_t*)calloc(R, 4);
+    m->ray_o = (float*)calloc(R * 3, 4); m->ray_d = (float*)calloc(R * 3, 4); m->ray_dn = (float*)calloc(R, 4);
+    m->ray_tmin = (float*)calloc(R, 4); m->ray_tmax = (float*)calloc(R, 4); m->target = (float*)calloc(R * 3, 4);
+    m->target_depth = (float*)calloc(R, 4); m->bgcol = (float*)calloc(R * 3, 4); m->ray_flag = (uint8_t*)calloc(R, 1);
+    m->pts = (float*)calloc(B * 3, 4); m->tdist = (float*)calloc(B, 4);
+    m->E = (uint16_t*)calloc(B * m->Epad, 2); m->Hid = (uint16_t*)calloc(B * m->W * m->NH, 2); m->O = (uint16_t*)calloc(B * ORC_OUT, 2);
+    m->dO = (uint16_t*)calloc(B * ORC_OUT, 2); m->dHid = (uint16_t*)calloc(B * m->W * m->NH, 2); m->dE = (uint16_t*)calloc(B * m->Epad, 2);
+    m->rgb_ray = (float*)calloc(R * 3, 4); m->depth_ray = (float*)calloc(R, 4); m->mask_ray = (float*)calloc(R, 4); m->loss_ray = (float*)calloc(R, 4);
+    return m;
+}
+void orc_destroy(orc_model* m) {
+    if (!m) return;
+    void* p[] = { m->master, m->half, m->ema, m->m1, m->m2, m->steps, m->gmlp, m->ggrid, m->ggrid_abs, m->ggrid_h, m->boxes, m->valid, m->sel,
+        m->ray_o, m->ray_d, m->ray_dn, m->ray_tmin, m->ray_tmax, m->target, m->target_depth, m->bgcol, m->ray_flag, m->pts, m->tdist,
+        m->E, m->Hid, m->O, m->dO, m->dHid, m->dE, m->rgb_ray, m->depth_ray, m->mask_ray, m->loss_ray };
+    for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); ++i) free(p[i]);
+    free(m);
+}
+uint32_t orc_n_params(const orc_model* m) { return m->n_params; }
+uint32_t orc_n_mlp_params(const orc_model* m) { return m->n_mlp; }
+uint32_t orc_step(const orc_model* m) { return m->step; }
+uint32_t orc_n_valid(const orc_model* m) { return m->n_valid; }
+float orc_loss(const orc_model* m) { return m->loss; }
+int orc_epad(const orc_model* m) { return m->Epad; }
+
+/* which: 0 master f32, 1 half u16, 2 ema u16, 3 m1, 4 m2, 5 steps, 6 gmlp f32, 7 ggrid f32, 8 ggrid_abs f32, 9 ggrid_h u16,
+ * 10 pts, 11 tdist, 12 E, 13 Hid, 14 O, 15 dO, 16 dHid, 17 dE, 18 rgb_ray, 19 depth_ray, 20 mask_ray, 21 loss_ray,
+ * 22 ray_o, 23 ray_d, 24 ray_tmin, 25 ray_tmax, 26 target, 27 target_depth, 28 bgcol, 29 ray_flag, 30 sel, 31 ray_dn */
+const void* orc_buffer(const orc_model* m, int which) {
+    const void* t[] = { m->master, m->half, m->ema, m->m1, m->m2, m->steps, m->gmlp, m->ggrid, m->ggrid_abs, m->ggrid_h,
+        m->pts, m->tdist, m->E, m->Hid, m->O, m->dO, m->dHid, m->dE, m->rgb_ray, m->depth_ray, m->mask_ray, m->loss_ray,
+        m->ray_o, m->ray_d, m->ray_tmin, m->ray_tmax, m->target, m->target_depth, m->bgcol, m->ray_flag, m->sel, m->ray_dn };
+    if (which < 0 || which >= (int)(sizeof(t) / sizeof(t[0]))) return NULL;
+    return t[which];
+}
+void orc_set_params(orc_model* m, const float* master) {
+    memcpy(m->master, master, (size_t)m->n_params * 4);
+    for (uint32_t k = 0; k < m->n_params; ++k) m->half[k] = f2h(m->master[k]);
+}
+void orc_set_dataset(orc_model* m, int H, int W, int n_frames, float fx, float fy, float cx, float cy,
+                     const uint8_t* rgba, const float* depth, const float* poses) {
+    m->H = H; m->Wimg = W; m->n_frames = n_frames; m->fx = fx; m->fy = fy; m->cx = cx; m->cy = cy;
+    m->rgba = rgba; m->depth = depth; m->poses = poses; m->use_depth = (depth != NULL) && m->cfg.use_depth;
+}
+void orc_set_object(orc_model* m, const float* Tow16, const float* amin, const float* amax, int instance_id) {
+    memcpy(m->Tow, Tow16, 64); memcpy(m->amin, amin, 12); memcpy(m->amax, amax, 12); m->inst = (uint8_t)instance_id;
+}
+void orc_add_boxes(orc_model* m, const orc_bbox* b, size_t n) {   /* nerf_model.cu:1609-1628 */
+    m->boxes = (orc_bbox*)realloc(m->boxes, (m->n_boxes + n) * sizeof(orc_bbox));
+    memcpy(m->boxes + m->n_boxes, b, n * sizeof(orc_bbox)); m->n_boxes += n;
+}
+
+/* ------------------------------------------------------------------ geometry */
+/* column-major 4x4: M(r,c) = m[c*4+r].  rot(M) * v with fmaf chains. */
+static inline void rot3(const float* M, const float* v, float* o) {
+    for (int r = 0; r < 3; ++r) o[r] = fmaf(M[8 + r], v[2], fmaf(M[4 + r], v[1], M[r] * v[0]));
+}
+/* nerf_model.cu:87-138 slab test; returns 0 on miss. No special-casing of dir==0 (inf arithmetic). */
+static int ray_intersect(const float* bmin, const float* bmax, const float* o, const float* d, float* t0, float* t1) {
+    float tmin = (bmin[0] - o[0]) / d[0], tmax = (bmax[0] - o[0]) / d[0], t;
+    if (tmin > tmax) { t = tmin; tmin = tmax; tmax = t; }
+    float tymin = (bmin[1] - o[1]) / d[1], tymax = (bmax[1] - o[1]) / d[1];
+    if (tymin > tymax) { t = tymin; tymin = tymax; tymax = t; }
+    if (tmin > tymax || tymin > tmax) return 0;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = (bmin[2] - o[2]) / d[2], tzmax = (bmax[2] - o[2]) / d[2];
+    if (tzmin > tzmax) { t = tzmin; tzmin = tzmax; tzmax = t; }
+    if (tmin > tzmax || tzmin > tmax) return 0;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    *t0 = tmin; *t1 = tmax; return 1;
+}
+/* pixel -> object-frame ray.  nerf_model.cu:403-413 (train), :467-477 (render), :511-518 (video: Tow==NULL). */
+static void pixel_ray(const orc_model* m, float px, float py, const float* Twc, const float* Tow, float* o, float* d, float* dn) {
+    float dc[3] = { (px - m->cx) / m->fx, (py - m->cy) / m->fy, 1.0f };
+    float n = sqrtf(fmaf(dc[2], dc[2], fmaf(dc[1], dc[1], dc[0] * dc[0])));
+    float dnrm[3] = { dc[0] / n, dc[1] / n, dc[2] / n }, dw[3];
+    rot3(Twc, dnrm, dw);
+    if (Tow) { rot3(Tow, dw, d); float ow[3] = { Twc[12], Twc[13], Twc[14] }, t[3]; rot3(Tow, ow, t); for (int r = 0; r < 3; ++r) o[r] = t[r] + Tow[12 + r]; }
+    else { for (int r = 0; r < 3; ++r) { d[r] = dw[r]; o[r] = Twc[12 + r]; } }
+    *dn = n;
+}
+
+/* ------------------------------------------------------------------ GenerateBatch
+ * nerf_model.cu:1429-1502 = GenerateRays (:369-446) + fill_rollover_rays (:280-294) +
+ * GenerateInputPoints (:536-566).  The atomicAdd compaction order of the reference is
+ * unspecified; this restatement (and the HIP path) use the stable candidate order. */
+static void generate_batch(orc_model* m) {
+    const orc_config* c = &m->cfg; const int R = m->R, S = m->S; const uint32_t step = m->iter;
+    float *co = (float*)malloc((size_t)R * 3 * 4), *cd = (float*)malloc((size_t)R * 3 * 4), *cdn = (float*)malloc((size_t)R * 4),
+          *ct0 = (float*)malloc((size_t)R * 4), *ct1 = (float*)malloc((size_t)R * 4), *ctg = (float*)malloc((size_t)R * 3 * 4), *ctd = (float*)malloc((size_t)R * 4);
+    uint8_t* cfl = (uint8_t*)malloc((size_t)R);
+    uint32_t nv = 0;
+    for (int i = 0; i < R; ++i) {
+        m->valid[i] = 0;
+        const orc_bbox* b = &m->boxes[(size_t)i % m->n_boxes];
+        float u0 = rand01(c->sample_seed, 0, step, 2u * i), u1 = rand01(c->sample_seed, 0, step, 2u * i + 1u);
+        uint32_t x = b->x + (uint32_t)(u0 * (float)(int)b->w), y = b->y + (uint32_t)(u1 * (float)(int)b->h);
+        size_t pix = ((size_t)b->FrameId * m->H + y) * m->Wimg + x;
+        uint8_t inst = m->rgba[pix * 4 + 3];
+        if (inst != 0 && inst != m->inst) continue;                            /* occlusion :398-401 */
+        float o[3], d[3], dn, t0, t1;
+        pixel_ray(m, (float)x, (float)y, m->poses + (size_t)b->FrameId * 16, m->Tow, o, d, &dn);
+        if (!ray_intersect(m->amin, m->amax, o, d, &t0, &t1)) continue;
+        m->valid[i] = 1; m->sel[nv++] = (uint32_t)i;
+        memcpy(co + 3 * i, o, 12); memcpy(cd + 3 * i, d, 12); cdn[i] = dn; ct0[i] = fmaxf(t0, 0.0f); ct1[i] = t1;
+        if (inst != 0) {
+            for (int k = 0; k < 3; ++k) ctg[3 * i + k] = (float)m->rgba[pix * 4 + k] / 255.0f;   /* nerf_data.cu:169 convertTo(1/255) */
+            ctd[i] = m->use_depth ? m->depth[pix] * dn : 0.0f; cfl[i] = 1;
+        } else { ctd[i] = 0.0f; cfl[i] = 0; }
+    }
+    m->n_valid = nv;
+    if (nv == 0) goto done;     /* reference: i % 0 UB (:287,:760); here the step is skipped */
+    for (int j = 0; j < R; ++j) {
+        uint32_t k = (uint32_t)j % nv, i = m->sel[k];
+        for (int a = 0; a < 3; ++a) m->bgcol[3 * j + a] = rand01(c->sample_seed, 1, step, 3u * k + a);     /* :760 RandomColor[(i % n)*3] */
+        memcpy(m->ray_o + 3 * j, co + 3 * i, 12); memcpy(m->ray_d + 3 * j, cd + 3 * i, 12);
+        m->ray_dn[j] = cdn[i]; m->ray_tmin[j] = ct0[i]; m->ray_tmax[j] = ct1[i]; m->ray_flag[j] = cfl[i]; m->target_depth[j] = ctd[i];
+        for (int a = 0; a < 3; ++a) m->target[3 * j + a] = cfl[i] ? ctg[3 * i + a] : m->bgcol[3 * j + a];     /* :438-441 */
+        float dt = (ct1[i] - ct0[i]) / (float)S;
+        for (int n = 0; n < S; ++n) {                                           /* :553-566 */
+            float t = fmaf(dt, (float)n + rand01(c->sample_seed, 2, step, (uint32_t)(j * S + n)), ct0[i]);
+            size_t s = (size_t)j * S + n;
+            for (int a = 0; a < 3; ++a) { float p = fmaf(t, cd[3 * i + a], co[3 * i + a]); m->pts[3 * s + a] = (p - m->amin[a]) / (m->amax[a] - m->amin[a]); }
+            m->tdist[s] = t;
+        }
+    }
+done:
+    free(co); free(cd); free(cdn); free(ct0); free(ct1); free(ctg); free(ctd); free(cfl);
+}
+
+/* ------------------------------------------------------------------ hash-grid encode (tcnn kernel_grid) */
+typedef struct { uint32_t idx[8]; float w[8]; } corners;
+static inline void level_corners(const orc_model* m, int l, const float* x, corners* c) {
+    float pos[3]; uint32_t pg[3];
+    for (int d = 0; d < 3; ++d) { float p = fmaf(m->scale[l], x[d], 0.5f), fl = floorf(p); pg[d] = (uint32_t)(int32_t)fl; pos[d] = p - fl; }
+    uint32_t size = m->off[l + 1] - m->off[l];
+    for (int k = 0; k < 8; ++k) {
+        float w = 1.0f; uint32_t q[3];
+        for (int d = 0; d < 3; ++d) { if (k & (1 << d)) { w *= pos[d]; q[d] = pg[d] + 1u; } else { w *= 1.0f - pos[d]; q[d] = pg[d]; } }
+        c->w[k] = w; c->idx[k] = m->off[l] + grid_index(size, m->res[l], q[0], q[1], q[2]);
+    }
+}
+static void encode_one(const orc_model* m, const uint16_t* table /* grid part, [entry][2] */, const float* x, uint16_t* E) {
+    for (int l = 0; l < m->L; ++l) {
+        corners c; level_corners(m, l, x, &c); float a0 = 0.0f, a1 = 0.0f;
+        for (int k = 0; k < 8; ++k) { a0 = fmaf(c.w[k], h2f(table[2 * c.idx[k]]), a0); a1 = fmaf(c.w[k], h2f(table[2 * c.idx[k] + 1]), a1); }
+        E[2 * l] = f2h(a0); E[2 * l + 1] = f2h(a1);
+    }
+    for (int k = 2 * m->L; k < m->Epad; ++k) E[k] = 0;       /* TCNN-A9 zero padding */
+}
+/* fully-fused MLP forward (tcnn; no biases, ReLU hidden, linear output; TCNN-A10) */
+static void mlp_forward_one(const orc_model* m, const uint16_t* w, const uint16_t* E, uint16_t* hid /* NH*W */, uint16_t* out /* 4 */) {
+    const int W = m->W; const uint16_t* in = E; int nin = m->Epad;
+    for (int layer = 0; layer < m->NH; ++layer) {
+        for (int u = 0; u < W; ++u) { float a = 0.0f; for (int k = 0; k < nin; ++k) a = fmaf(h2f(w[u * nin + k]), h2f(in[k]), a); hid[layer * W + u] = f2h(a > 0.0f ? a : 0.0f); }
+        w += W * nin; in = hid + layer * W; nin = W;
+    }
+    for (int o = 0; o < ORC_OUT; ++o) { float a = 0.0f; for (int k = 0; k < W; ++k) a = fmaf(h2f(w[o * W + k]), h2f(in[k]), a); out[o] = f2h(a); }
+}
+/* stand-alone stage entry points (tests): params = fp16 parameter vector [n_params] */
+void orc_encode(const orc_model* m, const uint16_t* params, const float* x, size_t n, uint16_t* E) {
+    #pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; ++i) encode_one(m, params + m->n_mlp, x + 3 * i, E + (size_t)i * m->Epad);
+}
+void orc_mlp_forward(const orc_model* m, const uint16_t* params, const uint16_t* E, size_t n, uint16_t* hid, uint16_t* out) {
+    #pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; ++i) mlp_forward_one(m, params, E + (size_t)i * m->Epad, hid + (size_t)i * m->W * m->NH, out + (size_t)i * ORC_OUT);
+}
+
+/* ------------------------------------------------------------------ activations nerf_model.cu:22-64 */
+static inline float logistic(float x) { return 1.0f / (1.0f + expf(-x)); }
+static inline float clampf(float x, float a, float b) { return x < a ? a : (x > b ? b : x); }
+
+/* VolumeRender nerf_model.cu:735-815 (one ray).  out4: fp16 [S][4]; t: [S]. */
+static void composite_ray(const uint16_t* out4, const float* t, int S, const float* bg, float* rgb, float* depth, float* mask) {
+    float T = 1.0f, r[3] = { 0, 0, 0 }, dep = 0.0f, last = 0.0f;          /* :770 last_distance = 0 (first dt measured from the origin) */
+    for (int n = 0; n < S; ++n) {
+        if (T < 1e-4f) break;
+        float c0 = logistic(h2f(out4[4 * n])), c1 = logistic(h2f(out4[4 * n + 1])), c2 = logistic(h2f(out4[4 * n + 2]));
+        float cur = t[n], dt = cur - last, sigma = expf(h2f(out4[4 * n + 3]));        /* :49 unclamped */
+        float alpha = 1.0f - expf(-sigma * dt), w = alpha * T;
+        r[0] += w * c0; r[1] += w * c1; r[2] += w * c2; dep += w * cur; T *= (1.0f - alpha); last = cur;
+    }
+    rgb[0] = r[0] + T * bg[0]; rgb[1] = r[1] + T * bg[1]; rgb[2] = r[2] + T * bg[2]; *depth = dep; *mask = 1.0f - T;
+}
+/* VolumeRenderGradient_No_Compacted nerf_model.cu:817-954 (one ray).  dO pre-zeroed (:1578). */
+static float gradient_ray(const uint16_t* out4, const float* t, int S, int nRays, float loss_scale, int is_obj,
+                          const float* target, float target_depth, const float* rgb_ray, float depth_ray, float mask_ray, uint16_t* dO) {
+    float g[3], lsum = 0.0f;
+    for (int k = 0; k < 3; ++k) { float d = rgb_ray[k] - target[k]; lsum += d * d; g[k] = 2.0f * d; }       /* :78-84 */
+    float mean_loss = lsum / 3.0f, dl_dd = 0.0f;
+    if (target_depth > 0.0f) dl_dd = 0.5f * ((depth_ray - target_depth >= 0.0f) ? 1.0f : -1.0f);          /* :869-871 */
+    float loss = is_obj ? mean_loss + dl_dd * (depth_ray - target_depth) + (1.0f - mask_ray) : mean_loss + mask_ray;  /* :877-880 */
+    float ls = loss_scale / (float)nRays, T = 1.0f, r2[3] = { 0, 0, 0 }, d2 = 0.0f, last = 0.0f;
+    for (int n = 0; n < S; ++n) {
+        if (T < 1e-4f) break;
+        float v[4]; for (int k = 0; k < 4; ++k) v[k] = h2f(out4[4 * n + k]);
+        float c[3] = { logistic(v[0]), logistic(v[1]), logistic(v[2]) };
+        float cur = t[n], dt = cur - last, sigma = expf(v[3]);
+        float alpha = 1.0f - expf(-sigma * dt), w = alpha * T;
+        for (int k = 0; k < 3; ++k) r2[k] += w * c[k];
+        d2 += w * cur; T *= (1.0f - alpha);
+        float suf[3] = { rgb_ray[0] - r2[0], rgb_ray[1] - r2[1], rgb_ray[2] - r2[2] };
+        for (int k = 0; k < 3; ++k) dO[4 * n + k] = f2h(ls * ((w * g[k]) * (c[k] * (1.0f - c[k]))));        /* :916-920 */
+        float dsig = expf(clampf(v[3], -15.0f, 15.0f));                                                   /* :60 */
+        float depth_sup = dl_dd * (T * cur - (depth_ray - d2));                                            /* :924-925 */
+        float dmask = 1.0f - mask_ray, dl;
+        if (is_obj) {
+            float dlm = 0.5f * (mask_ray >= 1.0f ? 1.0f : -1.0f);                                          /* :928 */
+            float dot = g[0] * (T * c[0] - suf[0]) + g[1] * (T * c[1] - suf[1]) + g[2] * (T * c[2] - suf[2]);
+            dl = dsig * dt * (dot + depth_sup + dlm * dmask);                                              /* :933-934 */
+        } else {
+            float dlm = 0.5f * (mask_ray >= 0.0f ? 1.0f : -1.0f);                                          /* :938 */
+            dl = dsig * dt * dlm * dmask + dsig * 0.01f;                                                   /* :940 */
+        }
+        dO[4 * n + 3] = f2h(ls * dl); last = cur;
+    }
+    return loss;
+}
+/* stage entry points for KATs */
+void orc_composite(const uint16_t* out4, const float* t, int S, const float* bg, float* rgb, float* depth, float* mask) { composite_ray(out4, t, S, bg, rgb, depth, mask); }
+float orc_gradient(const uint16_t* out4, const float* t, int S, int nRays, float loss_scale, int is_obj, const float* target, float target_depth,
+                   const float* rgb_ray, float depth_ray, float mask_ray, uint16_t* dO) {
+    memset(dO, 0, (size_t)S * 4 * 2);
+    return gradient_ray(out4, t, S, nRays, loss_scale, is_obj, target, target_depth, rgb_ray, depth_ray, mask_ray, dO);
+}
+
+/* ------------------------------------------------------------------ Step_No_Compacted nerf_model.cu:1552-1607 */
+static void forward_backward(orc_model* m) {
+    const int R = m->R, S = m->S, W = m->W, NH = m->NH, Ep = m->Epad; const size_t B = (size_t)R * S;
+    const uint16_t* wt = m->half; const uint16_t* table = m->half + m->n_mlp;
+    #pragma omp parallel for schedule(static)
+    for (long s = 0; s < (long)B; ++s) {
+        encode_one(m, table, m->pts + 3 * s, m->E + (size_t)s * Ep);
+        mlp_forward_one(m, wt, m->E + (size_t)s * Ep, m->Hid + (size_t)s * W * NH, m->O + (size_t)s * 4);
+    }
+    memset(m->dO, 0, B * 4 * 2);                                                 /* :1578 */
+    #pragma omp parallel for schedule(static)
+    for (long j = 0; j < R; ++j) {
+        const uint16_t* o4 = m->O + (size_t)j * S * 4; const float* t = m->tdist + (size_t)j * S;
+        composite_ray(o4, t, S, m->bgcol + 3 * j, m->rgb_ray + 3 * j, m->depth_ray + j, m->mask_ray + j);
+        m->loss_ray[j] = gradient_ray(o4, t, S, R, m->cfg.loss_scale, m->ray_flag[j], m->target + 3 * j, m->target_depth[j],
+                                      m->rgb_ray + 3 * j, m->depth_ray[j], m->mask_ray[j], m->dO + (size_t)j * S * 4);
+    }
+    double ls = 0; for (int j = 0; j < R; ++j) ls += m->loss_ray[j];             /* SumLoss :1231-1253 + :1650-1658 */
+    m->loss = (float)(ls / R);
+    /* tcnn backward (EGradientMode::Overwrite): dh, dE per sample */
+    #pragma omp parallel for schedule(static)
+    for (long s = 0; s < (long)B; ++s) {
+        const uint16_t* dO = m->dO + (size_t)s * 4; const uint16_t* hid = m->Hid + (size_t)s * W * NH;
+        uint16_t* dh = m->dHid + (size_t)s * W * NH; uint16_t* dE = m->dE + (size_t)s * Ep;
+        const uint16_t* wout = wt + (size_t)W * Ep + (size_t)(NH - 1) * W * W;
+        for (int u = 0; u < W; ++u) {
+            float a = 0.0f; for (int c = 0; c < ORC_OUT; ++c) a = fmaf(h2f(wout[c * W + u]), h2f(dO[c]), a);
+            dh[(NH - 1) * W + u] = f2h(h2f(hid[(NH - 1) * W + u]) > 0.0f ? a : 0.0f);
+        }
+        for (int layer = NH - 1; layer >= 1; --layer) {
+            const uint16_t* wl = wt + (size_t)W * Ep + (size_t)(layer - 1) * W * W;   /* maps layer-1 -> layer */
+            for (int k = 0; k < W; ++k) {
+                float a = 0.0f; for (int u = 0; u < W; ++u) a = fmaf(h2f(wl[u * W + k]), h2f(dh[layer * W + u]), a);
+                dh[(layer - 1) * W + k] = f2h(h2f(hid[(layer - 1) * W + k]) > 0.0f ? a : 0.0f);
+            }
+        }
+        for (int k = 0; k < Ep; ++k) { float a = 0.0f; for (int u = 0; u < W; ++u) a = fmaf(h2f(wt[u * Ep + k]), h2f(dh[u]), a); dE[k] = f2h(a); }
+    }
+    /* weight gradients dW = sum_s d(out) x in^T, fp32, sample order */
+    memset(m->gmlp, 0, (size_t)m->n_mlp * 4);
+    {
+        int nthreads = 1;
+        #ifdef _OPENMP
+        nthreads = omp_get_max_threads();
+        #endif
+        float* part = (float*)calloc((size_t)nthreads * m->n_mlp, 4);
+        #pragma omp parallel
+        {
+            int tid = 0;
+            #ifdef _OPENMP
+            tid = omp_get_thread_num();
+            #endif
+            float* g = part + (size_t)tid * m->n_mlp;
+            #pragma omp for schedule(static)
+            for (long s = 0; s < (long)B; ++s) {
+                const uint16_t* E = m->E + (size_t)s * Ep; const uint16_t* hid = m->Hid + (size_t)s * W * NH;
+                const uint16_t* dh = m->dHid + (size_t)s * W * NH; const uint16_t* dO = m->dO + (size_t)s * 4;
+                float* g0 = g;
+                for (int u = 0; u < W; ++u) { float d = h2f(dh[u]); if (d != 0.0f) for (int k = 0; k < Ep; ++k) g0[u * Ep + k] += d * h2f(E[k]); }
+                for (int layer = 1; layer < NH; ++layer) {
+                    float* gl = g + (size_t)W * Ep + (size_t)(layer - 1) * W * W;
+                    for (int u = 0; u < W; ++u) { float d = h2f(dh[layer * W + u]); if (d != 0.0f) for (int k = 0; k < W; ++k) gl[u * W + k] += d * h2f(hid[(layer - 1) * W + k]); }
+                }
+                float* go = g + (size_t)W * Ep + (size_t)(NH - 1) * W * W;
+                for (int c = 0; c < ORC_OUT; ++c) { float d = h2f(dO[c]); if (d != 0.0f) for (int k = 0; k < W; ++k) go[c * W + k] += d * h2f(hid[(NH - 1) * W + k]); }
+            }
+        }
+        for (int t = 0; t < nthreads; ++t) for (uint32_t k = 0; k < m->n_mlp; ++k) m->gmlp[k] += part[(size_t)t * m->n_mlp + k];
+        free(part);
+    }
+    /* grid backward (tcnn kernel_grid_backward): contribution = h(w * dE) per corner; serial for determinism */
+    memset(m->ggrid, 0, (size_t)m->n_grid * 4); memset(m->ggrid_abs, 0, (size_t)m->n_grid * 4);
+    if (m->cfg.grid_grad_half_accum) memset(m->ggrid_h, 0, (size_t)m->n_grid * 2);
+    for (size_t s = 0; s < B; ++s) {
+        const uint16_t* dE = m->dE + s * Ep;
+        for (int l = 0; l < m->L; ++l) {
+            float g0 = h2f(dE[2 * l]), g1 = h2f(dE[2 * l + 1]);
+            if (g0 == 0.0f && g1 == 0.0f) continue;
+            corners c; level_corners(m, l, m->pts + 3 * s, &c);
+            for (int k = 0; k < 8; ++k) {
+                float c0 = h2f(f2h(c.w[k] * g0)), c1 = h2f(f2h(c.w[k] * g1)); size_t e = 2 * (size_t)c.idx[k];
+                m->ggrid[e] += c0; m->ggrid[e + 1] += c1; m->ggrid_abs[e] += fabsf(c0); m->ggrid_abs[e + 1] += fabsf(c1);
+                if (m->cfg.grid_grad_half_accum) { m->ggrid_h[e] = f2h(h2f(m->ggrid_h[e]) + c0); m->ggrid_h[e + 1] = f2h(h2f(m->ggrid_h[e + 1]) + c1); }
+            }
+        }
+    }
+    if (!m->cfg.grid_grad_half_accum) for (uint32_t k = 0; k < m->n_grid; ++k) m->ggrid_h[k] = f2h(m->ggrid[k]);
+}
+
+/* ------------------------------------------------------------------ Trainer::optimizer_step (tcnn), nerf_model.cu:1644
+ * Ema(0.95){ ExponentialDecay{ Adam } }  base.json:5-22.  TCNN-A6/A7/A8. */
+static void adam_one(orc_model* m, uint32_t i, float gradient, int is_matrix) {
+    const orc_config* c = &m->cfg;
+    if (!is_matrix && gradient == 0.0f) return;                         /* grid entries with zero gradient are skipped entirely */
+    float w = m->master[i];
+    if (is_matrix) gradient += c->l2_reg * w;                           /* L2 only on matrix weights */
+    float gsq = gradient * gradient;
+    float fm = m->m1[i] = c->beta1 * m->m1[i] + (1.0f - c->beta1) * gradient;
+    float sm = m->m2[i] = c->beta2 * m->m2[i] + (1.0f - c->beta2) * gsq;
+    uint32_t cs = ++m->steps[i];                                        /* per-parameter step counter */
+    float lr = m->lr * sqrtf(1.0f - powf(c->beta2, (float)cs)) / (1.0f - powf(c->beta1, (float)cs));
+    float eff = lr / (sqrtf(sm) + c->epsilon);
+    float nw = w - eff * fm;
+    m->master[i] = nw; m->half[i] = f2h(nw);
+}
+static void optimizer_step(orc_model* m) {
+    const orc_config* c = &m->cfg; const float inv_ls = c->loss_scale;
+    #pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)m->n_mlp; ++i) adam_one(m, (uint32_t)i, m->gmlp[i] / inv_ls, 1);
+    #pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)m->n_grid; ++i) adam_one(m, m->n_mlp + (uint32_t)i, h2f(m->ggrid_h[i]) / inv_ls, 0);
+    uint32_t cur = m->step + 1;                                          /* nested optimizer's step() after increment */
+    if ((int32_t)cur >= c->decay_start && c->decay_interval > 0 && ((int32_t)cur - c->decay_start) % c->decay_interval == 0) m->lr *= c->decay_base;
+    float d = c->ema_decay;
+    float deb_old = 1.0f - (float)pow((double)d, (double)(cur - 1)), deb_new = 1.0f / (1.0f - (float)pow((double)d, (double)cur));
+    #pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)m->n_params; ++i)
+        m->ema[i] = f2h(((h2f(m->ema[i]) * d) * deb_old + h2f(m->half[i]) * (1.0f - d)) * deb_new);
+    m->has_ema = 1;
+}
+/* closed-form KAT hooks: run the optimizer on externally supplied gradients */
+void orc_optimizer_step_with(orc_model* m, const float* gmlp, const uint16_t* ggrid_h) {
+    memcpy(m->gmlp, gmlp, (size_t)m->n_mlp * 4); memcpy(m->ggrid_h, ggrid_h, (size_t)m->n_grid * 2);
+    optimizer_step(m); m->step++;
+}
+
+/* NeRF_Model::Train_Step body, nerf_model.cu:1635-1648 (one iteration). Returns n_valid. */
+uint32_t orc_train_step(orc_model* m) {
+    generate_batch(m);
+    m->iter++;
+    if (m->n_valid == 0) return 0;
+    forward_backward(m);
+    optimizer_step(m);
+    m->step++;
+    return m->n_valid;
+}
+float orc_train(orc_model* m, int iters) { for (int i = 0; i < iters; ++i) orc_train_step(m); return m->loss; }
+/* forward+backward only on the current batch (tests compare gradients without touching params) */
+void orc_generate_batch(orc_model* m) { generate_batch(m); }   /* does not advance iter */
+void orc_advance_iter(orc_model* m) { m->iter++; }
+void orc_forward_backward(orc_model* m) { forward_backward(m); }
+
+/* ------------------------------------------------------------------ Render nerf_model.cu:1702-1830 / RenderVideo :1832-1991
+ * GenerateRender(Video)Rays :448-534, GenerateRenderInputPoints :593-626 (2S samples, jittered; the
+ * reference re-creates the generator per call => identical jitter every call), inference with the
+ * EMA weights (TCNN-A8; fp16 compute, output widened to fp32), VolumeRender_Render :1134-1229.
+ * pose_is_Toc: 0 -> Twc with the object's Tow; 1 -> pose given directly in the object frame. */
+void orc_render(const orc_model* m, orc_bbox box, const float* pose16, int pose_is_Toc, int use_ema, float* rgb, float* depth, float* mask) {
+    const int S = 2 * m->S; const long n = (long)box.w * box.h;
+    const uint16_t* prm = (use_ema && m->has_ema) ? m->ema : m->half;
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (long i = 0; i < n; ++i) {
+        int x = (int)box.x + (int)(i % box.w), y = (int)box.y + (int)(i / box.w);
+        float o[3], d[3], dn, t0, t1;
+        pixel_ray(m, (float)x, (float)y, pose16, pose_is_Toc ? NULL : m->Tow, o, d, &dn);
+        if (!ray_intersect(m->amin, m->amax, o, d, &t0, &t1)) { rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = 1.0f; depth[i] = 0.0f; mask[i] = 0.0f; continue; }
+        t0 = fmaxf(t0, 0.0f);
+        float dt = (t1 - t0) / (float)S, T = 1.0f, r[3] = { 0, 0, 0 }, dep = 0.0f, last = 0.0f;
+        uint16_t E[2 * ORC_MAX_LEVELS + 16], hid[256], out[4];
+        for (int k = 0; k < S; ++k) {
+            if (T < 1e-4f) break;
+            float t = fmaf(dt, (float)k + rand01(m->cfg.sample_seed, 3, 0, (uint32_t)(i * S + k)), t0), p[3];
+            for (int a = 0; a < 3; ++a) { float q = fmaf(t, d[a], o[a]); p[a] = (q - m->amin[a]) / (m->amax[a] - m->amin[a]); }
+            encode_one(m, prm + m->n_mlp, p, E); mlp_forward_one(m, prm, E, hid, out);
+            float c0 = logistic(h2f(out[0])), c1 = logistic(h2f(out[1])), c2 = logistic(h2f(out[2]));
+            float ddt = t - last, sigma = expf(h2f(out[3])), alpha = 1.0f - expf(-sigma * ddt), w = alpha * T;
+            r[0] += w * c0; r[1] += w * c1; r[2] += w * c2; dep += w * t; T *= (1.0f - alpha); last = t;
+        }
+        if (1.0f - T > 0.5f) { rgb[3 * i] = r[0] + T; rgb[3 * i + 1] = r[1] + T; rgb[3 * i + 2] = r[2] + T; depth[i] = dep / dn; mask[i] = 1.0f; }
+        else { rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = 1.0f; depth[i] = 0.0f; mask[i] = 0.0f; }
+    }
+}
+
+/* GetDensityOnGrid nerf_model.cu:2007-2048: raw (pre-activation) channel 3 on a res^3 lattice of the unit cube
+ * (generate_grid_samples_nerf_uniform :296-309, x fastest), inference weights. */
+void orc_density_grid(const orc_model* m, int rx, int ry, int rz, int use_ema, float* out) {
+    const uint16_t* prm = (use_ema && m->has_ema) ? m->ema : m->half;
+    #pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)rx * ry * rz; ++i) {
+        int x = (int)(i % rx), y = (int)((i / rx) % ry), z = (int)(i / ((long)rx * ry));
+        float p[3] = { (float)x / (float)(rx - 1), (float)y / (float)(ry - 1), (float)z / (float)(rz - 1) };
+        uint16_t E[2 * ORC_MAX_LEVELS + 16], hid[256], o4[4];
+        encode_one(m, prm + m->n_mlp, p, E); mlp_forward_one(m, prm, E, hid, o4); out[i] = h2f(o4[3]);
+    }
+}
+
+/* inference throughput probe for the CPU baseline: encode + MLP + composite over given points */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

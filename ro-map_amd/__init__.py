@@ -1,0 +1,8 @@
+"""ro-map_amd: MI355X-native Multi-Object-NeRF core for RO-MAP (host mirror + ctypes view of the C ABI).
+
+The product is the C-ABI shared library `libmon_core.so` (include/mon_core.h); this Python package is a
+thin ctypes view used by tests, bench.py and tools.  The directory name contains a hyphen, so load it
+with `__graft_entry__.load_package()` (importlib) rather than `import`.
+"""
+from .binding import (MonConfig, MonBBox, MonError, Dataset, ObjectNeRF, default_config, config_from_json, device_count, lib, lib_path,  # noqa: F401
+                      exported_symbols, BUF, selftest_mfma)

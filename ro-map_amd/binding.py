@@ -1,0 +1,221 @@
+"""ctypes binding of libmon_core.so.  Mirrors the reference's manager/object interface
+(CORE/include/nerf_manager.h, nerf.h) one call per C-ABI entry point; no compute happens in Python and
+there is no CPU fallback: every compute call raises MonError when the HIP library or a device is missing."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class MonError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mon_core error %d: %s" % (code, msg)); self.code = code
+
+
+class MonConfig(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("n_features", C.c_int32), ("log2_hashmap_size", C.c_int32), ("base_resolution", C.c_int32),
+                ("per_level_scale", C.c_float), ("n_neurons", C.c_int32), ("n_hidden_layers", C.c_int32), ("rays_per_batch", C.c_int32),
+                ("n_samples", C.c_int32), ("loss_scale", C.c_float), ("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("epsilon", C.c_float), ("l2_reg", C.c_float), ("ema_decay", C.c_float), ("decay_start", C.c_int32), ("decay_interval", C.c_int32),
+                ("decay_base", C.c_float), ("param_seed", C.c_uint32), ("reserved0", C.c_uint32), ("sample_seed", C.c_uint64),
+                ("use_depth", C.c_int32), ("reserved1", C.c_int32)]
+
+
+class MonBBox(C.Structure):
+    _fields_ = [("FrameId", C.c_uint32), ("x", C.c_uint32), ("y", C.c_uint32), ("h", C.c_uint32), ("w", C.c_uint32)]
+
+
+class MonInfo(C.Structure):
+    _fields_ = [("n_params", C.c_uint32), ("n_mlp_params", C.c_uint32), ("n_grid_params", C.c_uint32), ("encoded_width", C.c_uint32),
+                ("train_step", C.c_uint32), ("n_boxes", C.c_uint32), ("last_n_valid", C.c_uint32), ("device", C.c_int32),
+                ("last_loss", C.c_float), ("learning_rate", C.c_float)]
+
+
+class MonProfile(C.Structure):
+    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8)]
+
+
+K_BATCH, K_FWDBWD, K_OPTIM, K_RENDER = 0, 1, 2, 3
+
+# every symbol include/mon_core.h declares (checked by tests/test_abi.py against the header text)
+_SIGS = {
+    "mon_last_error": (C.c_char_p, []),
+    "mon_version": (C.c_int, []),
+    "mon_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mon_config_default": (C.c_int, [C.POINTER(MonConfig)]),
+    "mon_config_from_json": (C.c_int, [C.c_char_p, C.POINTER(MonConfig)]),
+    "mon_dataset_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
+    "mon_dataset_add_frame": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mon_dataset_n_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "mon_dataset_destroy": (C.c_int, [C.c_void_p]),
+    "mon_object_create": (C.c_int, [C.c_void_p, C.POINTER(MonConfig), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mon_object_add_boxes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mon_object_train": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "mon_object_render": (C.c_int, [C.c_void_p, MonBBox, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "mon_object_density_grid": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mon_object_info_get": (C.c_int, [C.c_void_p, C.POINTER(MonInfo)]),
+    "mon_object_get_params": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "mon_object_set_params": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mon_object_train_stages": (C.c_int, [C.c_void_p, C.c_int]),
+    "mon_object_set_backend": (C.c_int, [C.c_void_p, C.c_int]),
+    "mon_object_debug_read": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "mon_object_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "mon_object_get_profile": (C.c_int, [C.c_void_p, C.POINTER(MonProfile), C.c_int]),
+    "mon_object_destroy": (C.c_int, [C.c_void_p]),
+    "mon_device_synchronize": (C.c_int, [C.c_int]),
+    "mon_selftest_mfma": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def lib_path():
+    return os.path.join(_HERE, "libmon_core.so")
+
+
+_lib = None
+
+
+def lib():
+    """Loads libmon_core.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise MonError(-1, "libmon_core.so not built (run python -c 'import __graft_entry__ as g; g.build()')")
+        L = C.CDLL(p)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name); fn.restype = res; fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise MonError(rc, lib().mon_last_error().decode("utf-8", "replace"))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().mon_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def default_config(**kw):
+    c = MonConfig(); _check(lib().mon_config_default(C.byref(c)))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def config_from_json(path):
+    c = MonConfig(); _check(lib().mon_config_from_json(path.encode(), C.byref(c))); return c
+
+
+def selftest_mfma(A_h, B_h, device=0):
+    A = np.ascontiguousarray(A_h, np.uint16); B = np.ascontiguousarray(B_h, np.uint16); D = np.empty((32, 32), np.float32)
+    _check(lib().mon_selftest_mfma(device, _p(A), _p(B), _p(D))); return D
+
+
+class Dataset:
+    """nerf::NeRF_Dataset on one device (frames resident in HBM)."""
+
+    def __init__(self, device, H, W, fx, fy, cx, cy, max_frames, use_depth=False):
+        self.h = C.c_void_p(); self.H, self.W = H, W
+        _check(lib().mon_dataset_create(device, H, W, fx, fy, cx, cy, max_frames, int(use_depth), C.byref(self.h)))
+
+    def add_frame(self, frame_id, rgb_u8, instance_u8, Twc16, depth=None, is_bgr=False):
+        rgb = np.ascontiguousarray(rgb_u8, np.uint8); inst = np.ascontiguousarray(instance_u8, np.uint8)
+        pose = np.ascontiguousarray(Twc16, np.float32); d = None if depth is None else np.ascontiguousarray(depth, np.float32)
+        assert rgb.shape[:2] == (self.H, self.W) and inst.shape == (self.H, self.W) and pose.size == 16
+        _check(lib().mon_dataset_add_frame(self.h, frame_id, _p(rgb), rgb.shape[2], int(is_bgr), _p(inst), _p(d), _p(pose)))
+
+    @property
+    def n_frames(self):
+        n = C.c_uint32(0); _check(lib().mon_dataset_n_frames(self.h, C.byref(n))); return n.value
+
+    def close(self):
+        if self.h:
+            lib().mon_dataset_destroy(self.h); self.h = None
+
+
+# debug buffer ids (ro-map_amd/csrc/model.h MON_BUF_*): name -> (id, dtype, elements as f(R, B, info))
+BUF = dict(master=0, half=1, ema=2, m1=3, m2=4, steps=5, gmlp=6, ggrid_h=9, pts=10, tdist=11, E=12, Hid=13, O=14, dO=15, dHid=16, dE=17,
+           rgb_ray=18, depth_ray=19, mask_ray=20, loss_ray=21, ray_o=22, ray_d=23, ray_t0=24, ray_t1=25, target=26, target_depth=27, bgcol=28,
+           ray_flag=29, ray_dn=31, mask=32, state=33)
+
+
+class ObjectNeRF:
+    """nerf::NeRF + nerf::NeRF_Model for one object."""
+
+    def __init__(self, dataset, cfg, class_id, Tow16, aabb_min, aabb_max):
+        self.h = C.c_void_p(); self.cfg = cfg; self.ds = dataset
+        a, b, c = (np.ascontiguousarray(v, np.float32) for v in (Tow16, aabb_min, aabb_max))
+        _check(lib().mon_object_create(dataset.h, C.byref(cfg), int(class_id), _p(a), _p(b), _p(c), C.byref(self.h)))
+        self.R, self.S = cfg.rays_per_batch, cfg.n_samples
+
+    def close(self):
+        if self.h:
+            lib().mon_object_destroy(self.h); self.h = None
+
+    def add_boxes(self, boxes):
+        b = np.ascontiguousarray(boxes, np.uint32).reshape(-1, 5)
+        _check(lib().mon_object_add_boxes(self.h, _p(b), b.shape[0]))
+
+    def train(self, iters):
+        loss = C.c_float(0); _check(lib().mon_object_train(self.h, iters, C.byref(loss))); return loss.value
+
+    def train_stages(self, bits):
+        _check(lib().mon_object_train_stages(self.h, bits))
+
+    def set_backend(self, backend):
+        _check(lib().mon_object_set_backend(self.h, backend))
+
+    def info(self):
+        i = MonInfo(); _check(lib().mon_object_info_get(self.h, C.byref(i))); return i
+
+    def render(self, box, pose16, pose_is_Toc=False):
+        FrameId, x, y, h, w = (int(v) for v in box)
+        rgb = np.empty((h, w, 3), np.float32); depth = np.empty((h, w), np.float32); mask = np.empty((h, w), np.float32)
+        pose = np.ascontiguousarray(pose16, np.float32)
+        _check(lib().mon_object_render(self.h, MonBBox(FrameId, x, y, h, w), _p(pose), int(pose_is_Toc), _p(rgb), _p(depth), _p(mask), 0))
+        return rgb, depth, mask
+
+    def density_grid(self, rx, ry, rz):
+        out = np.empty(rx * ry * rz, np.float32); _check(lib().mon_object_density_grid(self.h, rx, ry, rz, _p(out))); return out
+
+    def get_params(self, which=0):
+        n = self.info().n_params
+        out = np.empty(n, np.float32 if which == 0 else np.uint16)
+        _check(lib().mon_object_get_params(self.h, which, _p(out), out.nbytes)); return out
+
+    def set_params(self, master):
+        m = np.ascontiguousarray(master, np.float32); _check(lib().mon_object_set_params(self.h, _p(m), m.size))
+
+    def buffer(self, name):
+        i = self.info(); R, B, n = self.R, self.R * self.S, i.n_params
+        W, NH, Ep = self.cfg.n_neurons, self.cfg.n_hidden_layers, i.encoded_width
+        shapes = dict(master=(np.float32, n), half=(np.uint16, n), ema=(np.uint16, n), m1=(np.float32, n), m2=(np.float32, n), steps=(np.uint32, n),
+                      gmlp=(np.float32, i.n_mlp_params), ggrid_h=(np.uint16, i.n_grid_params), pts=(np.float32, B * 3), tdist=(np.float32, B),
+                      E=(np.uint16, B * Ep), Hid=(np.uint16, B * W * NH), O=(np.uint16, B * 4), dO=(np.uint16, B * 4), dHid=(np.uint16, B * W * NH),
+                      dE=(np.uint16, B * Ep), rgb_ray=(np.float32, R * 3), depth_ray=(np.float32, R), mask_ray=(np.float32, R), loss_ray=(np.float32, R),
+                      ray_o=(np.float32, R * 3), ray_d=(np.float32, R * 3), ray_t0=(np.float32, R), ray_t1=(np.float32, R), target=(np.float32, R * 3),
+                      target_depth=(np.float32, R), bgcol=(np.float32, R * 3), ray_flag=(np.uint8, R), ray_dn=(np.float32, R), mask=(np.uint64, R // 64),
+                      state=(np.uint32, 8))
+        dt, cnt = shapes[name]; out = np.empty(cnt, dt)
+        _check(lib().mon_object_debug_read(self.h, BUF[name], _p(out), out.nbytes)); return out
+
+    def set_profiling(self, on):
+        _check(lib().mon_object_set_profiling(self.h, int(on)))
+
+    def profile(self, reset=True):
+        p = MonProfile(); _check(lib().mon_object_get_profile(self.h, C.byref(p), int(reset)))
+        return {"ms": list(p.ms), "launches": list(p.launches)}

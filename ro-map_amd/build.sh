@@ -1,0 +1,20 @@
+#!/usr/bin/env bash
+# Builds ro-map_amd/libmon_core.so for gfx950 (cross-compiles without a GPU).
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+OBJ="$HERE/build"; mkdir -p "$OBJ"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -ffp-contract=off -fno-math-errno -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result)
+SRCS=(config.cpp model.cpp c_api.cpp kernels_batch.hip kernels_net.hip kernels_composite.hip kernels_optim.hip kernels_fused.hip)
+pids=()
+for s in "${SRCS[@]}"; do
+  o="$OBJ/${s%.*}.o"
+  if [[ ! -f "$o" || "$HERE/csrc/$s" -nt "$o" || "$HERE/csrc/model.h" -nt "$o" || "$HERE/csrc/device_common.h" -nt "$o" || "$HERE/../include/mon_core.h" -nt "$o" ]]; then
+    "$HIPCC" "${FLAGS[@]}" -c "$HERE/csrc/$s" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
+objs=(); for s in "${SRCS[@]}"; do objs+=("$OBJ/${s%.*}.o"); done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$HERE/libmon_core.so" "${objs[@]}"
+echo "built $HERE/libmon_core.so"

@@ -1,0 +1,90 @@
+// c_api.cpp -- extern "C" surface declared in include/mon_core.h.
+#include <cstring>
+#include "model.h"
+
+namespace mon {
+void set_error(const char* fmt, ...);
+const char* last_error();
+int device_count(int* n);
+void config_default(mon_config& c);
+int config_from_json(const char* path, mon_config& c);
+int dataset_create(int device, int H, int W, float fx, float fy, float cx, float cy, uint32_t max_frames, int use_depth, Dataset** out);
+int dataset_add_frame(Dataset* d, uint32_t id, const uint8_t* rgb, int ch, int is_bgr, const uint8_t* inst, const float* depth, const float* Twc);
+int dataset_destroy(Dataset* d);
+int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* Tow, const float* amin, const float* amax, Model** out);
+int model_destroy(Model* m);
+int model_add_boxes(Model& m, const mon_frame_bbox* boxes, size_t n);
+int model_train(Model& m, int iters, float* loss, int stages);
+int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, int dst_on_device);
+int model_density_grid(Model& m, int rx, int ry, int rz, float* out_host);
+int model_get_params(Model& m, int which, void* dst, size_t bytes);
+int model_set_params(Model& m, const float* master, size_t n);
+int model_debug_read(Model& m, int which, void* dst, size_t bytes);
+}  // namespace mon
+
+using namespace mon;
+
+struct mon_dataset { Dataset* d; };
+struct mon_object { Model* m; };
+
+#define REQUIRE(p, what) do { if (!(p)) { set_error("%s: null %s", __func__, what); return MON_ERR_ARG; } } while (0)
+
+extern "C" {
+
+const char* mon_last_error(void) { return last_error(); }
+int mon_version(void) { return 100; }
+int mon_device_count(int* n) { REQUIRE(n, "n_devices"); return device_count(n); }
+int mon_config_default(mon_config* cfg) { REQUIRE(cfg, "cfg"); config_default(*cfg); return MON_OK; }
+int mon_config_from_json(const char* path, mon_config* cfg) { REQUIRE(path, "path"); REQUIRE(cfg, "cfg"); return config_from_json(path, *cfg); }
+
+int mon_dataset_create(int device, int H, int W, float fx, float fy, float cx, float cy, uint32_t max_frames, int use_depth, mon_dataset** out) {
+    REQUIRE(out, "out"); Dataset* d = nullptr;
+    int rc = dataset_create(device, H, W, fx, fy, cx, cy, max_frames, use_depth, &d); if (rc) return rc;
+    *out = new mon_dataset{ d }; return MON_OK;
+}
+int mon_dataset_add_frame(mon_dataset* ds, uint32_t frame_id, const uint8_t* rgb, int channels, int is_bgr, const uint8_t* instance, const float* depth, const float* Twc16) {
+    REQUIRE(ds, "dataset"); return dataset_add_frame(ds->d, frame_id, rgb, channels, is_bgr, instance, depth, Twc16);
+}
+int mon_dataset_n_frames(const mon_dataset* ds, uint32_t* n) { REQUIRE(ds, "dataset"); REQUIRE(n, "n"); *n = ds->d->n_frames; return MON_OK; }
+int mon_dataset_destroy(mon_dataset* ds) { if (!ds) return MON_OK; dataset_destroy(ds->d); delete ds; return MON_OK; }
+
+int mon_object_create(mon_dataset* ds, const mon_config* cfg, int class_id, const float* Tow16, const float* aabb_min3, const float* aabb_max3, mon_object** out) {
+    REQUIRE(ds, "dataset"); REQUIRE(cfg, "cfg"); REQUIRE(out, "out"); Model* m = nullptr;
+    int rc = model_create(ds->d, *cfg, class_id, Tow16, aabb_min3, aabb_max3, &m); if (rc) return rc;
+    *out = new mon_object{ m }; return MON_OK;
+}
+int mon_object_add_boxes(mon_object* o, const mon_frame_bbox* boxes, size_t n) { REQUIRE(o, "object"); return model_add_boxes(*o->m, boxes, n); }
+int mon_object_train(mon_object* o, int iters, float* loss) { REQUIRE(o, "object"); return model_train(*o->m, iters, loss, 7); }
+int mon_object_train_stages(mon_object* o, int stage_bits) { REQUIRE(o, "object"); return model_train(*o->m, 1, nullptr, stage_bits & 7); }
+int mon_object_render(mon_object* o, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, int dst_on_device) {
+    REQUIRE(o, "object"); return model_render(*o->m, box, pose16, pose_is_Toc, rgb, depth, mask, dst_on_device);
+}
+int mon_object_density_grid(mon_object* o, int rx, int ry, int rz, float* out_host) { REQUIRE(o, "object"); return model_density_grid(*o->m, rx, ry, rz, out_host); }
+int mon_object_info_get(mon_object* o, mon_object_info* info) {
+    REQUIRE(o, "object"); REQUIRE(info, "info"); Model& m = *o->m;
+    info->n_params = m.n_params; info->n_mlp_params = m.nd.n_mlp; info->n_grid_params = m.n_grid; info->encoded_width = (uint32_t)m.nd.Epad;
+    info->train_step = m.h_state.step; info->n_boxes = m.n_boxes; info->last_n_valid = m.h_state.n_valid; info->device = m.device;
+    info->last_loss = m.h_state.loss_sum / (float)m.oc.R; info->learning_rate = m.h_state.lr; return MON_OK;
+}
+int mon_object_get_params(mon_object* o, int which, void* dst, size_t bytes) { REQUIRE(o, "object"); return model_get_params(*o->m, which, dst, bytes); }
+int mon_object_set_params(mon_object* o, const float* master, size_t n) { REQUIRE(o, "object"); return model_set_params(*o->m, master, n); }
+int mon_object_set_backend(mon_object* o, int backend) {
+    REQUIRE(o, "object");
+    if (backend == 1 && !fused_supported(o->m->nd, o->m->oc.S)) { set_error("fused backend does not support this network shape"); return MON_ERR_ARG; }
+    if (backend != 0 && backend != 1) { set_error("backend must be 0 or 1"); return MON_ERR_ARG; }
+    o->m->backend = backend; return MON_OK;
+}
+int mon_object_debug_read(mon_object* o, int which, void* dst, size_t bytes) { REQUIRE(o, "object"); return model_debug_read(*o->m, which, dst, bytes); }
+int mon_object_set_profiling(mon_object* o, int enable) { REQUIRE(o, "object"); o->m->profiling = enable != 0; return MON_OK; }
+int mon_object_get_profile(mon_object* o, mon_profile* out, int reset) {
+    REQUIRE(o, "object"); REQUIRE(out, "out"); *out = o->m->prof; if (reset) std::memset(&o->m->prof, 0, sizeof(mon_profile)); return MON_OK;
+}
+int mon_object_destroy(mon_object* o) { if (!o) return MON_OK; model_destroy(o->m); delete o; return MON_OK; }
+
+int mon_device_synchronize(int device) {
+    if (hipSetDevice(device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { set_error("device synchronize failed"); return MON_ERR_HIP; }
+    return MON_OK;
+}
+int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D) { REQUIRE(A, "A"); REQUIRE(B, "B"); REQUIRE(D, "D"); return selftest_mfma(device, A, B, D); }
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// device_common.h -- shared host/device definitions for the gfx950 Multi-Object-NeRF core.
+// Arithmetic follows SURVEY.md 8(a) rows a5-a31; reference = CORE/src/nerf_model.cu (cited per function).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mon {
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+constexpr int kMaxLevels = 16;
+constexpr int kOut = 4;        // rgb + density (nerf_model.cu:1318)
+constexpr int kOutPad = 16;    // tcnn pads the output layer to 16 rows
+constexpr float kTransmittanceEps = 1e-4f;   // nerf_model.cu:763
+
+// Per-level geometry of the multiresolution hash grid (tcnn grid.h; SURVEY TCNN-A1..A4).
+struct LevelTable {
+    uint32_t offset[kMaxLevels + 1];   // entry offsets, offset[L] = total entries
+    uint32_t res[kMaxLevels];
+    float scale[kMaxLevels];
+};
+
+// Static shape of one object's network; passed by value to kernels.
+struct NetDims {
+    int L;          // hash levels
+    int Epad;       // encoded width padded to 16
+    int W;          // hidden width (32 / 64)
+    int NH;         // hidden layers (1 / 2)
+    uint32_t n_mlp; // MLP parameter count; grid params follow in the flat parameter vector
+};
+
+struct Aabb { float mn[3]; float mx[3]; };
+struct Mat4 { float m[16]; };   // column-major: M(r,c) = m[c*4+r]
+struct Intrinsics { float fx, fy, cx, cy; int H, W; };
+
+// ---------------------------------------------------------------- counter RNG (bit-exact host/device)
+// Replaces the three curandGenerateUniform streams of GenerateBatch (nerf_model.cu:1432,1434,1468).
+enum { kStreamXY = 0, kStreamColor = 1, kStreamDt = 2, kStreamRender = 3 };
+__host__ __device__ inline float rand01(uint64_t seed, uint32_t stream, uint32_t step, uint32_t idx) {
+    uint64_t ctr = ((uint64_t)stream << 60) | ((uint64_t)step << 28) | (uint64_t)(idx & 0x0fffffffu);
+    uint64_t z = ctr + seed * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// ---------------------------------------------------------------- hash grid index (tcnn grid_index / grid_hash)
+__host__ __device__ inline uint32_t grid_index(uint32_t size, uint32_t res, uint32_t x, uint32_t y, uint32_t z) {
+    uint32_t stride = 1, index = 0;
+    if (stride <= size) { index += x * stride; stride *= res; }
+    if (stride <= size) { index += y * stride; stride *= res; }
+    if (stride <= size) { index += z * stride; stride *= res; }
+    if (size < stride) index = x ^ (y * 2654435761u) ^ (z * 805459861u);
+    return index % size;
+}
+
+// ---------------------------------------------------------------- geometry
+__host__ __device__ inline void rot3(const float* M, const float* v, float* o) {
+    o[0] = fmaf(M[8], v[2], fmaf(M[4], v[1], M[0] * v[0]));
+    o[1] = fmaf(M[9], v[2], fmaf(M[5], v[1], M[1] * v[0]));
+    o[2] = fmaf(M[10], v[2], fmaf(M[6], v[1], M[2] * v[0]));
+}
+// Slab test, nerf_model.cu:87-138. Returns false on a miss.
+__host__ __device__ inline bool ray_intersect(const Aabb& b, const float* o, const float* d, float& t0, float& t1) {
+    float tmin = (b.mn[0] - o[0]) / d[0], tmax = (b.mx[0] - o[0]) / d[0], t;
+    if (tmin > tmax) { t = tmin; tmin = tmax; tmax = t; }
+    float tymin = (b.mn[1] - o[1]) / d[1], tymax = (b.mx[1] - o[1]) / d[1];
+    if (tymin > tymax) { t = tymin; tymin = tymax; tymax = t; }
+    if (tmin > tymax || tymin > tmax) return false;
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = (b.mn[2] - o[2]) / d[2], tzmax = (b.mx[2] - o[2]) / d[2];
+    if (tzmin > tzmax) { t = tzmin; tzmin = tzmax; tzmax = t; }
+    if (tmin > tzmax || tzmin > tmax) return false;
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    t0 = tmin; t1 = tmax;
+    return true;
+}
+// Pixel -> ray in the object frame (nerf_model.cu:403-413 train, :467-477 render, :511-518 video).
+__host__ __device__ inline void pixel_ray(const Intrinsics& K, float px, float py, const float* Twc, const float* Tow,
+                                          bool pose_is_Toc, float* o, float* d, float& dnorm) {
+    float dc[3] = { (px - K.cx) / K.fx, (py - K.cy) / K.fy, 1.0f };
+    float n = sqrtf(fmaf(dc[2], dc[2], fmaf(dc[1], dc[1], dc[0] * dc[0])));
+    float dn[3] = { dc[0] / n, dc[1] / n, dc[2] / n }, dw[3];
+    rot3(Twc, dn, dw);
+    if (!pose_is_Toc) {
+        rot3(Tow, dw, d);
+        float ow[3] = { Twc[12], Twc[13], Twc[14] }, t[3];
+        rot3(Tow, ow, t);
+        o[0] = t[0] + Tow[12]; o[1] = t[1] + Tow[13]; o[2] = t[2] + Tow[14];
+    } else {
+        d[0] = dw[0]; d[1] = dw[1]; d[2] = dw[2];
+        o[0] = Twc[12]; o[1] = Twc[13]; o[2] = Twc[14];
+    }
+    dnorm = n;
+}
+
+// ---------------------------------------------------------------- activations, nerf_model.cu:22-64
+__device__ inline float logistic_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ inline float clamp_f(float x, float a, float b) { return fminf(fmaxf(x, a), b); }
+
+}  // namespace mon

@@ -1,0 +1,44 @@
+// kernels_fused.hip -- fused MFMA forward/backward path (backend 1).  PLACEHOLDER STAGE:
+// only the MFMA fragment-layout self-test is live; fused_supported() reports false so the
+// unfused kernels (kernels_net.hip / kernels_composite.hip) run.
+#include "device_common.h"
+#include "model.h"
+
+namespace mon {
+
+void set_error(const char* fmt, ...);
+
+// D[32x32] = A[32x16] * B[16x32] with v_mfma_f32_32x32x16_f16, using the fragment layout this
+// code base assumes: A lane l -> row l&31, k = 8*(l>>5)+j ; B lane l -> col l&31, k = 8*(l>>5)+j ;
+// D lane l, reg r -> col l&31, row (r&3) + 8*(r>>2) + 4*(l>>5).   A, B, D row-major.
+__global__ void __launch_bounds__(64) k_selftest_mfma(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, float* __restrict__ D) {
+    const int l = threadIdx.x, i = l & 31, hk = l >> 5;
+    half8_t a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        a[j] = reinterpret_cast<const half_t*>(A)[i * 16 + 8 * hk + j];
+        b[j] = reinterpret_cast<const half_t*>(B)[(8 * hk + j) * 32 + i];
+    }
+    float16_t c = { 0 };
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * hk) * 32 + i] = c[r];
+}
+
+int selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D) {
+    if (hipSetDevice(device) != hipSuccess) { set_error("selftest: no device"); return MON_ERR_NO_DEVICE; }
+    uint16_t *dA = nullptr, *dB = nullptr; float* dD = nullptr;
+    if (hipMalloc((void**)&dA, 32 * 16 * 2) != hipSuccess || hipMalloc((void**)&dB, 16 * 32 * 2) != hipSuccess || hipMalloc((void**)&dD, 32 * 32 * 4) != hipSuccess) { set_error("selftest: hipMalloc failed"); return MON_ERR_HIP; }
+    hipMemcpy(dA, A, 32 * 16 * 2, hipMemcpyHostToDevice); hipMemcpy(dB, B, 16 * 32 * 2, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+    const hipError_t e = hipMemcpy(D, dD, 32 * 32 * 4, hipMemcpyDeviceToHost);
+    hipFree(dA); hipFree(dB); hipFree(dD);
+    if (e != hipSuccess) { set_error("selftest: %s", hipGetErrorString(e)); return MON_ERR_HIP; }
+    return MON_OK;
+}
+
+bool fused_supported(const NetDims&, uint32_t) { return false; }
+void launch_fused_train(hipStream_t, const LevelTable&, const NetDims&, const ParamPtrs&, const BatchPtrs&, const ObjectConst&, DevState*, float*, int) {}
+void launch_fused_render(hipStream_t, const LevelTable&, const NetDims&, const uint16_t*, const BatchPtrs&, const ObjectConst&, uint32_t, uint32_t, float*, float*, float*) {}
+
+}  // namespace mon

@@ -1,0 +1,365 @@
+// model.cpp -- host side of one object NeRF on one gfx950 device.
+// Mirrors nerf::NeRF_Model (CORE/src/nerf_model.cu:1259-1830) and nerf::NeRF_Dataset
+// (CORE/src/nerf_data.cu:123-339) without Eigen/OpenCV/tcnn types.  Differences by design:
+//   * the whole iteration is enqueued on one HIP stream with no host synchronisation (the
+//     reference syncs 3x per iteration: nerf_model.cu:1459,1469,1645); counters live in DevState;
+//   * an iteration can be replayed as a hipGraph;
+//   * the dataset is one packed RGBA8+instance slab per device instead of per-frame float buffers.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "model.h"
+
+namespace mon {
+
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+    char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap); g_err = buf;
+}
+const char* last_error() { return g_err.c_str(); }
+
+#define HIPCHECK(expr)                                                                                         \
+    do { hipError_t _e = (expr); if (_e != hipSuccess) {                                                       \
+        set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return MON_ERR_HIP; } } while (0)
+
+void config_default(mon_config& c);
+int config_from_json(const char* path, mon_config& c);
+
+int device_count(int* n) {
+    int c = 0; hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess || c < 1) { *n = 0; set_error("Can not Detect GPU: %s", hipGetErrorString(e)); return MON_ERR_NO_DEVICE; }
+    *n = c; return MON_OK;
+}
+
+// ------------------------------------------------------------------ dataset
+int dataset_create(int device, int H, int W, float fx, float fy, float cx, float cy, uint32_t max_frames, int use_depth, Dataset** out) {
+    int n = 0; int rc = device_count(&n); if (rc) return rc;
+    if (device < 0 || device >= n || H <= 0 || W <= 0 || max_frames == 0) { set_error("dataset_create: bad argument"); return MON_ERR_ARG; }
+    HIPCHECK(hipSetDevice(device));
+    Dataset* d = new Dataset();
+    d->device = device; d->K = Intrinsics{ fx, fy, cx, cy, H, W }; d->max_frames = max_frames; d->use_depth = use_depth != 0;
+    const size_t px = (size_t)H * W;
+    HIPCHECK(hipMalloc((void**)&d->d_rgba, px * 4 * max_frames));
+    if (d->use_depth) HIPCHECK(hipMalloc((void**)&d->d_depth, px * 4 * max_frames));
+    HIPCHECK(hipMalloc((void**)&d->d_poses, 64 * (size_t)max_frames));
+    HIPCHECK(hipMemset(d->d_poses, 0, 64 * (size_t)max_frames));
+    d->staging.resize(px);
+    *out = d; return MON_OK;
+}
+int dataset_add_frame(Dataset* d, uint32_t id, const uint8_t* rgb, int ch, int is_bgr, const uint8_t* inst, const float* depth, const float* Twc) {
+    if (!d || !rgb || !inst || !Twc || (ch != 3 && ch != 4)) { set_error("dataset_add_frame: bad argument"); return MON_ERR_ARG; }
+    if (id >= d->max_frames) { set_error("dataset_add_frame: frame id %u >= capacity %u", id, d->max_frames); return MON_ERR_ARG; }
+    if (d->use_depth && !depth) { set_error("depth img error: dataset was created with use_depth"); return MON_ERR_ARG; }      // nerf_data.cu:296-300
+    HIPCHECK(hipSetDevice(d->device));
+    const size_t px = (size_t)d->K.H * d->K.W;
+    const int ri = is_bgr ? 2 : 0, bi = is_bgr ? 0 : 2;             // cv::COLOR_BGR2RGB, nerf_data.cu:167,286
+    for (size_t i = 0; i < px; ++i)
+        d->staging[i] = (uint32_t)rgb[i * ch + ri] | ((uint32_t)rgb[i * ch + 1] << 8) | ((uint32_t)rgb[i * ch + bi] << 16) | ((uint32_t)inst[i] << 24);
+    HIPCHECK(hipMemcpy(d->d_rgba + px * id, d->staging.data(), px * 4, hipMemcpyHostToDevice));
+    if (d->use_depth) HIPCHECK(hipMemcpy(d->d_depth + px * id, depth, px * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(d->d_poses + 16 * (size_t)id, Twc, 64, hipMemcpyHostToDevice));
+    if (id + 1 > d->n_frames) d->n_frames = id + 1;                 // mFrameDataNum, nerf_data.cu:338
+    return MON_OK;
+}
+int dataset_destroy(Dataset* d) {
+    if (!d) return MON_OK;
+    hipSetDevice(d->device);
+    if (d->d_rgba) hipFree(d->d_rgba);
+    if (d->d_depth) hipFree(d->d_depth);
+    if (d->d_poses) hipFree(d->d_poses);
+    delete d; return MON_OK;
+}
+
+// ------------------------------------------------------------------ model
+template <class T> static int dev_alloc(Model& m, T*& p, size_t n, bool zero = true) {
+    void* q = nullptr; const size_t bytes = (n ? n : 1) * sizeof(T);
+    HIPCHECK(hipMalloc(&q, bytes));
+    if (zero) HIPCHECK(hipMemset(q, 0, bytes));
+    m.allocs.push_back(q); p = (T*)q; return MON_OK;
+}
+
+static constexpr uint32_t kRenderChunkRays = 16384;   // rays per render pass (x 2S samples)
+
+int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* Tow, const float* amin, const float* amax, Model** out) {
+    if (!ds || !Tow || !amin || !amax) { set_error("object_create: bad argument"); return MON_ERR_ARG; }
+    if (cfg.rays_per_batch < 64 || (cfg.rays_per_batch % 64) != 0 || cfg.n_samples < 1 || cfg.n_samples > 64) { set_error("rays_per_batch must be a multiple of 64, n_samples 1..64"); return MON_ERR_ARG; }
+    Model* mp = new Model(); Model& m = *mp;
+    m.ds = ds; m.cfg = cfg; m.device = ds->device;
+    int rc = level_table_build(cfg, m.lt, m.nd, m.n_grid);
+    if (rc) { delete mp; return rc; }
+    m.n_params = m.nd.n_mlp + m.n_grid;
+    HIPCHECK(hipSetDevice(m.device));
+    std::memcpy(m.oc.Tow.m, Tow, 64);
+    for (int a = 0; a < 3; ++a) { m.oc.aabb.mn[a] = amin[a]; m.oc.aabb.mx[a] = amax[a]; }
+    m.oc.instance_id = (uint32_t)(uint8_t)class_id;                 // nerf.cu:75,158
+    m.oc.R = (uint32_t)cfg.rays_per_batch; m.oc.S = (uint32_t)cfg.n_samples; m.oc.use_depth = cfg.use_depth && ds->use_depth;
+    m.oc.sample_seed = cfg.sample_seed; m.oc.loss_scale = cfg.loss_scale;
+    m.opt = OptimConst{ cfg.beta1, cfg.beta2, cfg.epsilon, cfg.l2_reg, cfg.ema_decay, cfg.loss_scale, cfg.decay_base, cfg.decay_start, cfg.decay_interval, m.nd.n_mlp, m.n_params };
+    HIPCHECK(hipStreamCreateWithFlags(&m.train_stream, hipStreamNonBlocking));       // mpTrainStream, nerf_model.cu:1268
+    HIPCHECK(hipStreamCreateWithFlags(&m.infer_stream, hipStreamNonBlocking));       // mpInferenceStream :1269
+    // ---- parameters (ResetNetwork :1286-1342; Trainer init)
+    const size_t n = m.n_params;
+    if ((rc = dev_alloc(m, m.P.master, n, false)) || (rc = dev_alloc(m, m.P.half, n, false)) || (rc = dev_alloc(m, m.P.ema, n)) ||
+        (rc = dev_alloc(m, m.P.m1, n)) || (rc = dev_alloc(m, m.P.m2, n)) || (rc = dev_alloc(m, m.P.steps, n)) ||
+        (rc = dev_alloc(m, m.P.gmlp, m.nd.n_mlp)) || (rc = dev_alloc(m, m.P.ggrid, m.n_grid))) return rc;
+    {
+        std::vector<float> master; init_params_host(cfg, m.nd, m.n_params, master);
+        std::vector<uint16_t> half(n);
+        for (size_t i = 0; i < n; ++i) { const _Float16 h = (_Float16)master[i]; std::memcpy(&half[i], &h, 2); }
+        HIPCHECK(hipMemcpy(m.P.master, master.data(), n * 4, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(m.P.half, half.data(), n * 2, hipMemcpyHostToDevice));
+    }
+    // ---- workspace (AllocateBatchWorkspace :1344-1427), sized for max(train batch, render chunk)
+    const uint32_t R = m.oc.R, S = m.oc.S;
+    m.ws_rays = R > kRenderChunkRays ? R : kRenderChunkRays;
+    const uint32_t Btrain = R * S, Brender = kRenderChunkRays * 2 * S;
+    m.ws_samples = Btrain > Brender ? Btrain : Brender;
+    BatchPtrs& B = m.B;
+    if ((rc = dev_alloc(m, B.cand_o, 3 * (size_t)R)) || (rc = dev_alloc(m, B.cand_d, 3 * (size_t)R)) || (rc = dev_alloc(m, B.cand_dn, R)) ||
+        (rc = dev_alloc(m, B.cand_t0, R)) || (rc = dev_alloc(m, B.cand_t1, R)) || (rc = dev_alloc(m, B.cand_depth, R)) ||
+        (rc = dev_alloc(m, B.cand_rgba, R)) || (rc = dev_alloc(m, B.mask, (R + 63) / 64 + 64)) ||
+        (rc = dev_alloc(m, B.ray_o, 3 * (size_t)m.ws_rays)) || (rc = dev_alloc(m, B.ray_d, 3 * (size_t)m.ws_rays)) || (rc = dev_alloc(m, B.ray_dn, m.ws_rays)) ||
+        (rc = dev_alloc(m, B.ray_t0, m.ws_rays)) || (rc = dev_alloc(m, B.ray_t1, m.ws_rays)) || (rc = dev_alloc(m, B.target, 3 * (size_t)R)) ||
+        (rc = dev_alloc(m, B.target_depth, R)) || (rc = dev_alloc(m, B.bgcol, 3 * (size_t)R)) || (rc = dev_alloc(m, B.ray_flag, m.ws_rays)) ||
+        (rc = dev_alloc(m, B.pts, 3 * (size_t)m.ws_samples)) || (rc = dev_alloc(m, B.tdist, m.ws_samples)) ||
+        (rc = dev_alloc(m, B.E, (size_t)m.ws_samples * m.nd.Epad)) || (rc = dev_alloc(m, B.O, (size_t)m.ws_samples * kOut)) ||
+        (rc = dev_alloc(m, B.Hid, (size_t)Btrain * m.nd.W * m.nd.NH)) || (rc = dev_alloc(m, B.dO, (size_t)Btrain * kOut)) ||
+        (rc = dev_alloc(m, B.dHid, (size_t)Btrain * m.nd.W * m.nd.NH)) || (rc = dev_alloc(m, B.dE, (size_t)Btrain * m.nd.Epad)) ||
+        (rc = dev_alloc(m, B.rgb_ray, 3 * (size_t)R)) || (rc = dev_alloc(m, B.depth_ray, R)) || (rc = dev_alloc(m, B.mask_ray, R)) || (rc = dev_alloc(m, B.loss_ray, R)) ||
+        (rc = dev_alloc(m, m.d_state, 1)) || (rc = dev_alloc(m, m.d_dw_partials, (size_t)m.nd.n_mlp * 1024)) ||
+        (rc = dev_alloc(m, m.d_out_rgb, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_depth, kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_mask, kRenderChunkRays))) return rc;
+    m.boxes_cap = 1024;
+    if ((rc = dev_alloc(m, m.d_boxes, m.boxes_cap))) return rc;
+    B.boxes = m.d_boxes;
+    m.h_state = DevState{}; m.h_state.lr = cfg.learning_rate;
+    HIPCHECK(hipMemcpy(m.d_state, &m.h_state, sizeof(DevState), hipMemcpyHostToDevice));
+    m.backend = fused_supported(m.nd, S) ? 1 : 0;
+    if (const char* e = std::getenv("MON_BACKEND")) m.backend = std::atoi(e) ? (fused_supported(m.nd, S) ? 1 : 0) : 0;
+    HIPCHECK(hipDeviceSynchronize());
+    *out = mp; return MON_OK;
+}
+
+static void drop_graph(Model& m) { if (m.graph_exec) { hipGraphExecDestroy(m.graph_exec); m.graph_exec = nullptr; m.graph_backend = -1; } }
+
+int model_destroy(Model* mp) {
+    if (!mp) return MON_OK;
+    Model& m = *mp; hipSetDevice(m.device);
+    if (m.train_stream) hipStreamSynchronize(m.train_stream);
+    drop_graph(m);
+    for (auto& e : m.ev_pool) hipEventDestroy(e);
+    for (void* p : m.allocs) hipFree(p);
+    if (m.train_stream) hipStreamDestroy(m.train_stream);
+    if (m.infer_stream) hipStreamDestroy(m.infer_stream);
+    delete mp; return MON_OK;
+}
+
+int model_add_boxes(Model& m, const mon_frame_bbox* boxes, size_t n) {
+    if (!boxes || n == 0) { set_error("add_boxes: empty"); return MON_ERR_ARG; }
+    HIPCHECK(hipSetDevice(m.device));
+    for (size_t i = 0; i < n; ++i) {
+        const mon_frame_bbox& b = boxes[i];
+        if (b.FrameId >= m.ds->max_frames || b.w == 0 || b.h == 0 || b.x + b.w > (uint32_t)m.ds->K.W || b.y + b.h > (uint32_t)m.ds->K.H) {
+            set_error("add_boxes: box %zu (frame %u, x %u y %u h %u w %u) outside the %dx%d image / dataset capacity", i, b.FrameId, b.x, b.y, b.h, b.w, m.ds->K.W, m.ds->K.H);
+            return MON_ERR_ARG;
+        }
+    }
+    HIPCHECK(hipStreamSynchronize(m.train_stream));
+    if (m.n_boxes + n > m.boxes_cap) {
+        uint32_t cap = m.boxes_cap; while (cap < m.n_boxes + n) cap *= 2;
+        mon_frame_bbox* nb = nullptr; int rc = dev_alloc(m, nb, cap); if (rc) return rc;
+        HIPCHECK(hipMemcpy(nb, m.d_boxes, sizeof(mon_frame_bbox) * m.n_boxes, hipMemcpyDeviceToDevice));
+        m.d_boxes = nb; m.B.boxes = nb; m.boxes_cap = cap; drop_graph(m);       // old buffer stays in allocs until destroy
+    }
+    HIPCHECK(hipMemcpy(m.d_boxes + m.n_boxes, boxes, sizeof(mon_frame_bbox) * n, hipMemcpyHostToDevice));   // nerf_model.cu:1625
+    m.n_boxes += (uint32_t)n;
+    HIPCHECK(hipMemcpy(&m.d_state->n_boxes, &m.n_boxes, 4, hipMemcpyHostToDevice));
+    return MON_OK;
+}
+
+// ---- profiling helpers: HIP events on the train stream around each kernel class
+static hipEvent_t get_event(Model& m) {
+    if (!m.ev_pool.empty()) { hipEvent_t e = m.ev_pool.back(); m.ev_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+struct ProfScope {
+    Model& m; int cls; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(Model& mm, int c) : m(mm), cls(c) { if (m.profiling) { a = get_event(m); b = get_event(m); hipEventRecord(a, m.train_stream); } }
+    ~ProfScope() { if (m.profiling) { hipEventRecord(b, m.train_stream); m.ev_pending.push_back({ cls, { a, b } }); } }
+};
+static void collect_profile(Model& m) {
+    for (auto& p : m.ev_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) { m.prof.ms[p.first] += ms; m.prof.launches[p.first] += 1; }
+        m.ev_pool.push_back(p.second.first); m.ev_pool.push_back(p.second.second);
+    }
+    m.ev_pending.clear();
+}
+
+// One iteration of Train_Step's loop body (nerf_model.cu:1637-1646), enqueued without host syncs.
+static void enqueue_iteration(Model& m, int stages) {
+    hipStream_t s = m.train_stream; const uint32_t B = m.oc.R * m.oc.S;
+    if (stages & 1) {      // GenerateBatch :1429-1502
+        ProfScope ps(m, MON_K_BATCH);
+        launch_gen_candidates(s, m.B, m.ds->ptrs(), m.oc, m.d_state);
+        launch_build_rays(s, m.B, m.oc, m.d_state);
+        if (m.backend == 0) launch_gen_samples(s, m.B, m.oc, m.d_state, m.oc.S, B, kStreamDt, 0u, 0);
+    }
+    if (stages & 2) {      // Step_No_Compacted :1552-1607
+        ProfScope ps(m, MON_K_FWDBWD);
+        if (m.backend == 0) {
+            launch_encode(s, m.lt, m.nd, m.P.half, m.B.pts, m.B.E, B, m.d_state);
+            launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);
+            launch_composite_grad(s, m.B, m.oc, m.d_state);
+            launch_mlp_backward(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state);
+            launch_weight_grads(s, m.nd, m.B.E, m.B.Hid, m.B.dHid, m.B.dO, m.P.gmlp, B, m.d_state);
+            launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
+        } else {
+            launch_fused_train(s, m.lt, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, std::getenv("MON_FUSED_DUMP") ? 1 : 0);
+        }
+    }
+    if (stages & 4) {      // Trainer::optimizer_step :1644
+        ProfScope ps(m, MON_K_OPTIM);
+        launch_optimizer(s, m.P, m.opt, m.d_state);
+    }
+}
+
+static int sync_state(Model& m) {
+    HIPCHECK(hipStreamSynchronize(m.train_stream));            // :1645 (once per call instead of once per iteration)
+    HIPCHECK(hipMemcpy(&m.h_state, m.d_state, sizeof(DevState), hipMemcpyDeviceToHost));
+    collect_profile(m);
+    return MON_OK;
+}
+
+int model_train(Model& m, int iters, float* loss, int stages) {
+    if (iters < 0) { set_error("train: negative iteration count"); return MON_ERR_ARG; }
+    if (m.n_boxes == 0) { set_error("train: no 2-D boxes (UpdateFrameIdAndBbox was never called)"); return MON_ERR_STATE; }
+    HIPCHECK(hipSetDevice(m.device));
+    static const bool use_graph_env = std::getenv("MON_USE_GRAPH") && std::atoi(std::getenv("MON_USE_GRAPH")) != 0;
+    const bool use_graph = use_graph_env && !m.profiling && stages == 7 && iters >= 2;
+    if (use_graph) {
+        if (!m.graph_exec || m.graph_backend != m.backend) {
+            drop_graph(m);
+            hipGraph_t g = nullptr;
+            HIPCHECK(hipStreamBeginCapture(m.train_stream, hipStreamCaptureModeThreadLocal));
+            enqueue_iteration(m, 7);
+            HIPCHECK(hipStreamEndCapture(m.train_stream, &g));
+            HIPCHECK(hipGraphInstantiate(&m.graph_exec, g, nullptr, nullptr, 0));
+            hipGraphDestroy(g); m.graph_backend = m.backend;
+        }
+        for (int i = 0; i < iters; ++i) HIPCHECK(hipGraphLaunch(m.graph_exec, m.train_stream));
+    } else {
+        for (int i = 0; i < iters; ++i) enqueue_iteration(m, stages);
+    }
+    HIPCHECK(hipGetLastError());
+    int rc = sync_state(m); if (rc) return rc;
+    if (loss) *loss = m.h_state.loss_sum / (float)m.oc.R;       // :1650-1658
+    return MON_OK;
+}
+
+// Render / RenderVideo body :1768-1828, chunked; inference (EMA) weights once training has run.
+int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, int dst_on_device) {
+    if (!pose16 || !rgb || !depth || !mask || box.w == 0 || box.h == 0) { set_error("render: bad argument"); return MON_ERR_ARG; }
+    HIPCHECK(hipSetDevice(m.device));
+    hipStream_t s = m.train_stream;
+    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(hipMemcpy(&m.h_state, m.d_state, sizeof(DevState), hipMemcpyDeviceToHost));
+    const uint16_t* prm = (m.h_state.step > 0) ? m.P.ema : m.P.half;
+    Mat4 pose; std::memcpy(pose.m, pose16, 64);
+    const uint32_t n_pix = box.w * box.h, S2 = 2 * m.oc.S;
+    const hipMemcpyKind kind = dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    for (uint32_t p0 = 0; p0 < n_pix; p0 += kRenderChunkRays) {
+        const uint32_t n = (n_pix - p0) < kRenderChunkRays ? (n_pix - p0) : kRenderChunkRays;
+        {
+            ProfScope ps(m, MON_K_RENDER);
+            launch_render_rays(s, m.B, m.ds->K, m.oc, box, pose, pose_is_Toc, p0, n);
+            if (m.backend == 0) {
+                launch_gen_samples(s, m.B, m.oc, m.d_state, S2, n * S2, kStreamRender, p0 * S2, 1);
+                launch_encode(s, m.lt, m.nd, prm, m.B.pts, m.B.E, n * S2, nullptr);
+                launch_mlp_forward(s, m.nd, prm, m.B.E, nullptr, m.B.O, n * S2, nullptr);
+                launch_composite_render(s, m.B, S2, n, m.d_out_rgb, m.d_out_depth, m.d_out_mask);
+            } else {
+                launch_fused_render(s, m.lt, m.nd, prm, m.B, m.oc, n, p0 * S2, m.d_out_rgb, m.d_out_depth, m.d_out_mask);
+            }
+        }
+        HIPCHECK(hipMemcpyAsync(rgb + 3 * (size_t)p0, m.d_out_rgb, 12 * (size_t)n, kind, s));
+        HIPCHECK(hipMemcpyAsync(depth + p0, m.d_out_depth, 4 * (size_t)n, kind, s));
+        HIPCHECK(hipMemcpyAsync(mask + p0, m.d_out_mask, 4 * (size_t)n, kind, s));
+        HIPCHECK(hipStreamSynchronize(s));
+    }
+    HIPCHECK(hipGetLastError());
+    collect_profile(m);
+    return MON_OK;
+}
+
+// GetDensityOnGrid :2007-2048
+int model_density_grid(Model& m, int rx, int ry, int rz, float* out_host) {
+    if (rx < 2 || ry < 2 || rz < 2 || !out_host) { set_error("density_grid: bad argument"); return MON_ERR_ARG; }
+    HIPCHECK(hipSetDevice(m.device));
+    hipStream_t s = m.train_stream;
+    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(hipMemcpy(&m.h_state, m.d_state, sizeof(DevState), hipMemcpyDeviceToHost));
+    const uint16_t* prm = (m.h_state.step > 0) ? m.P.ema : m.P.half;
+    const uint32_t total = (uint32_t)rx * ry * rz, chunk = m.ws_samples;
+    for (uint32_t p0 = 0; p0 < total; p0 += chunk) {
+        const uint32_t n = (total - p0) < chunk ? (total - p0) : chunk;
+        launch_grid_points(s, m.B.pts, rx, ry, rz, p0, n);
+        launch_encode(s, m.lt, m.nd, prm, m.B.pts, m.B.E, n, nullptr);
+        launch_mlp_forward(s, m.nd, prm, m.B.E, nullptr, m.B.O, n, nullptr);
+        launch_extract_density(s, m.B.O, m.B.tdist, n);
+        HIPCHECK(hipMemcpyAsync(out_host + p0, m.B.tdist, 4 * (size_t)n, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+    }
+    return MON_OK;
+}
+
+int model_get_params(Model& m, int which, void* dst, size_t bytes) {
+    const void* src = nullptr; size_t need = 0;
+    switch (which) { case 0: src = m.P.master; need = (size_t)m.n_params * 4; break; case 1: src = m.P.half; need = (size_t)m.n_params * 2; break;
+                     case 2: src = m.P.ema; need = (size_t)m.n_params * 2; break; default: set_error("get_params: which must be 0..2"); return MON_ERR_ARG; }
+    if (!dst || bytes < need) { set_error("get_params: buffer too small (%zu < %zu)", bytes, need); return MON_ERR_ARG; }
+    HIPCHECK(hipSetDevice(m.device)); HIPCHECK(hipStreamSynchronize(m.train_stream));
+    HIPCHECK(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost)); return MON_OK;
+}
+int model_set_params(Model& m, const float* master, size_t n) {
+    if (!master || n != m.n_params) { set_error("set_params: expected %u values", m.n_params); return MON_ERR_ARG; }
+    HIPCHECK(hipSetDevice(m.device)); HIPCHECK(hipStreamSynchronize(m.train_stream));
+    std::vector<uint16_t> half(n);
+    for (size_t i = 0; i < n; ++i) { const _Float16 h = (_Float16)master[i]; std::memcpy(&half[i], &h, 2); }
+    HIPCHECK(hipMemcpy(m.P.master, master, n * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(m.P.half, half.data(), n * 2, hipMemcpyHostToDevice));
+    return MON_OK;
+}
+
+int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
+    const size_t R = m.oc.R, B = R * m.oc.S, n = m.n_params; const void* src = nullptr; size_t sz = 0;
+    switch (which) {
+        case MON_BUF_MASTER: src = m.P.master; sz = n * 4; break;       case MON_BUF_HALF: src = m.P.half; sz = n * 2; break;
+        case MON_BUF_EMA: src = m.P.ema; sz = n * 2; break;             case MON_BUF_M1: src = m.P.m1; sz = n * 4; break;
+        case MON_BUF_M2: src = m.P.m2; sz = n * 4; break;               case MON_BUF_STEPS: src = m.P.steps; sz = n * 4; break;
+        case MON_BUF_GMLP: src = m.P.gmlp; sz = (size_t)m.nd.n_mlp * 4; break;
+        case MON_BUF_GGRID_H: src = m.P.ggrid; sz = (size_t)m.n_grid * 2; break;
+        case MON_BUF_PTS: src = m.B.pts; sz = B * 12; break;            case MON_BUF_TDIST: src = m.B.tdist; sz = B * 4; break;
+        case MON_BUF_E: src = m.B.E; sz = B * m.nd.Epad * 2; break;     case MON_BUF_HID: src = m.B.Hid; sz = B * m.nd.W * m.nd.NH * 2; break;
+        case MON_BUF_O: src = m.B.O; sz = B * 8; break;                 case MON_BUF_DO: src = m.B.dO; sz = B * 8; break;
+        case MON_BUF_DHID: src = m.B.dHid; sz = B * m.nd.W * m.nd.NH * 2; break;
+        case MON_BUF_DE: src = m.B.dE; sz = B * m.nd.Epad * 2; break;
+        case MON_BUF_RGB_RAY: src = m.B.rgb_ray; sz = R * 12; break;    case MON_BUF_DEPTH_RAY: src = m.B.depth_ray; sz = R * 4; break;
+        case MON_BUF_MASK_RAY: src = m.B.mask_ray; sz = R * 4; break;   case MON_BUF_LOSS_RAY: src = m.B.loss_ray; sz = R * 4; break;
+        case MON_BUF_RAY_O: src = m.B.ray_o; sz = R * 12; break;        case MON_BUF_RAY_D: src = m.B.ray_d; sz = R * 12; break;
+        case MON_BUF_RAY_T0: src = m.B.ray_t0; sz = R * 4; break;       case MON_BUF_RAY_T1: src = m.B.ray_t1; sz = R * 4; break;
+        case MON_BUF_TARGET: src = m.B.target; sz = R * 12; break;      case MON_BUF_TARGET_DEPTH: src = m.B.target_depth; sz = R * 4; break;
+        case MON_BUF_BGCOL: src = m.B.bgcol; sz = R * 12; break;        case MON_BUF_RAY_FLAG: src = m.B.ray_flag; sz = R; break;
+        case MON_BUF_RAY_DN: src = m.B.ray_dn; sz = R * 4; break;       case MON_BUF_MASK: src = m.B.mask; sz = (R / 64) * 8; break;
+        case MON_BUF_STATE: src = m.d_state; sz = sizeof(DevState); break;
+        default: set_error("debug_read: unknown buffer id %d", which); return MON_ERR_ARG;
+    }
+    if (!dst || bytes < sz) { set_error("debug_read: buffer too small (%zu < %zu)", bytes, sz); return MON_ERR_ARG; }
+    HIPCHECK(hipSetDevice(m.device)); HIPCHECK(hipStreamSynchronize(m.train_stream));
+    HIPCHECK(hipMemcpy(dst, src, sz, hipMemcpyDeviceToHost)); return MON_OK;
+}
+
+}  // namespace mon

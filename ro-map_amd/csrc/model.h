@@ -1,0 +1,129 @@
+// model.h -- host-side mirror of nerf::NeRF_Model / nerf::NeRF_Dataset for gfx950.
+// Reference: CORE/include/nerf_model.h:92-184, CORE/include/nerf_data.h:19-71.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/mon_core.h"
+#include "device_common.h"
+
+namespace mon {
+
+// ---- device-resident per-object state updated by kernels (no host round trips inside an iteration)
+struct DevState {
+    uint32_t step;       // optimizer steps taken (mnTrainingStep)
+    uint32_t iter;       // batches generated (RNG counter); advances even when a batch is skipped
+    uint32_t n_valid;    // rays of the current batch inside the 3-D box
+    uint32_t n_boxes;    // mnBbox
+    float lr;            // Adam learning rate after ExponentialDecay
+    float loss_sum;      // sum of per-ray losses of the current batch (SumLoss, nerf_model.cu:1231-1253)
+    uint32_t ticket;     // last-block-done counter of the optimizer kernel
+    uint32_t skipped;    // batches skipped because n_valid == 0
+};
+
+// ---- dataset pointers (HBM layout: one slab per kind, frame-major)
+struct DatasetPtrs {
+    const uint32_t* rgba;    // [frames][H*W]  r | g<<8 | b<<16 | instance<<24  (4 B/pixel; the reference keeps 13 B/pixel)
+    const float* depth;      // [frames][H*W]  metres, or nullptr
+    const float* poses;      // [frames][16]   Twc column-major
+    Intrinsics K;
+};
+
+struct ObjectConst {
+    Mat4 Tow; Aabb aabb;
+    uint32_t instance_id; uint32_t R; uint32_t S; int use_depth;
+    uint64_t sample_seed;
+    float loss_scale;
+};
+
+struct BatchPtrs {
+    const mon_frame_bbox* boxes;
+    // candidates (un-compacted), R entries
+    float *cand_o, *cand_d, *cand_dn, *cand_t0, *cand_t1, *cand_depth; uint32_t* cand_rgba; unsigned long long* mask;
+    // training / render rays
+    float *ray_o, *ray_d, *ray_dn, *ray_t0, *ray_t1, *target, *target_depth, *bgcol; uint8_t* ray_flag;
+    // samples
+    float *pts, *tdist;
+    // network activations (unfused backend only) -- fp16
+    uint16_t *E, *Hid, *O, *dO, *dHid, *dE;
+    // per-ray results
+    float *rgb_ray, *depth_ray, *mask_ray, *loss_ray;
+};
+
+struct ParamPtrs {
+    float* master; uint16_t* half; uint16_t* ema; float* m1; float* m2; uint32_t* steps;
+    float* gmlp;        // fp32 dW [n_mlp]
+    uint16_t* ggrid;    // fp16 grid gradient [n_grid], accumulated with global_atomic_pk_add_f16
+};
+
+struct OptimConst {
+    float beta1, beta2, epsilon, l2_reg, ema_decay, loss_scale, decay_base;
+    int decay_start, decay_interval;
+    uint32_t n_mlp, n_params;
+};
+
+// debug buffer ids for mon_object_debug_read (stable numbering, see binding.py BUF)
+enum {
+    MON_BUF_MASTER = 0, MON_BUF_HALF = 1, MON_BUF_EMA = 2, MON_BUF_M1 = 3, MON_BUF_M2 = 4, MON_BUF_STEPS = 5,
+    MON_BUF_GMLP = 6, MON_BUF_GGRID_H = 9, MON_BUF_PTS = 10, MON_BUF_TDIST = 11, MON_BUF_E = 12, MON_BUF_HID = 13,
+    MON_BUF_O = 14, MON_BUF_DO = 15, MON_BUF_DHID = 16, MON_BUF_DE = 17, MON_BUF_RGB_RAY = 18, MON_BUF_DEPTH_RAY = 19,
+    MON_BUF_MASK_RAY = 20, MON_BUF_LOSS_RAY = 21, MON_BUF_RAY_O = 22, MON_BUF_RAY_D = 23, MON_BUF_RAY_T0 = 24,
+    MON_BUF_RAY_T1 = 25, MON_BUF_TARGET = 26, MON_BUF_TARGET_DEPTH = 27, MON_BUF_BGCOL = 28, MON_BUF_RAY_FLAG = 29,
+    MON_BUF_RAY_DN = 31, MON_BUF_MASK = 32, MON_BUF_STATE = 33
+};
+
+// ---- kernel launchers (kernels_*.hip)
+void launch_gen_candidates(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st);
+void launch_build_rays(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st);
+void launch_gen_samples(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, const DevState* st, uint32_t S, uint32_t n_samples, uint32_t stream_id, uint32_t idx_base, int render);
+void launch_render_rays(hipStream_t s, const BatchPtrs& b, const Intrinsics& K, const ObjectConst& oc, mon_frame_bbox box, const Mat4& pose, int pose_is_Toc, uint32_t pix0, uint32_t n);
+void launch_grid_points(hipStream_t s, float* pts, int rx, int ry, int rz, uint32_t p0, uint32_t n);
+
+// unfused network path (kernels_net.hip)
+void launch_encode(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* params, const float* pts, uint16_t* E, uint32_t n, const DevState* st_or_null);
+void launch_mlp_forward(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid_or_null, uint16_t* O, uint32_t n, const DevState* st_or_null);
+void launch_mlp_backward(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE, uint32_t n, const DevState* st);
+void launch_weight_grads(hipStream_t s, const NetDims& nd, const uint16_t* E, const uint16_t* Hid, const uint16_t* dHid, const uint16_t* dO, float* gmlp, uint32_t n, const DevState* st);
+void launch_grid_backward(hipStream_t s, const LevelTable& lt, const NetDims& nd, const float* pts, const uint16_t* dE, uint16_t* ggrid, uint32_t n, const DevState* st);
+
+// composite / loss gradient (kernels_composite.hip)
+void launch_composite_grad(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st);
+void launch_composite_render(hipStream_t s, const BatchPtrs& b, uint32_t S, uint32_t n_rays, float* rgb, float* depth, float* mask);
+void launch_extract_density(hipStream_t s, const uint16_t* O, float* out, uint32_t n);
+
+// optimizer (kernels_optim.hip)
+void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st);
+
+// fused MFMA path (kernels_fused.hip)
+bool fused_supported(const NetDims& nd, uint32_t S);
+void launch_fused_train(hipStream_t s, const LevelTable& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump);
+void launch_fused_render(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask);
+int selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
+
+// ---- host classes
+struct Dataset {
+    int device = 0; Intrinsics K{}; uint32_t max_frames = 0, n_frames = 0; bool use_depth = false;
+    uint32_t* d_rgba = nullptr; float* d_depth = nullptr; float* d_poses = nullptr;
+    std::vector<uint32_t> staging;
+    DatasetPtrs ptrs() const { return DatasetPtrs{ d_rgba, d_depth, d_poses, K }; }
+};
+
+struct Model {
+    Dataset* ds = nullptr; mon_config cfg{}; int device = 0;
+    LevelTable lt{}; NetDims nd{}; ObjectConst oc{}; OptimConst opt{};
+    uint32_t n_grid = 0, n_params = 0;
+    hipStream_t train_stream = nullptr, infer_stream = nullptr;
+    ParamPtrs P{}; BatchPtrs B{}; DevState* d_state = nullptr; mon_frame_bbox* d_boxes = nullptr;
+    uint32_t boxes_cap = 0, n_boxes = 0; uint32_t ws_samples = 0, ws_rays = 0;
+    float* d_dw_partials = nullptr; float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr;
+    std::vector<void*> allocs;
+    DevState h_state{}; int backend = 0; bool profiling = false;
+    mon_profile prof{}; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pending;
+    hipGraphExec_t graph_exec = nullptr; int graph_backend = -1;
+};
+
+int level_table_build(const mon_config& c, LevelTable& lt, NetDims& nd, uint32_t& n_grid);
+void init_params_host(const mon_config& c, const NetDims& nd, uint32_t n_params, std::vector<float>& master);
+
+}  // namespace mon
