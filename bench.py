@@ -1,0 +1,147 @@
+#!/usr/bin/env python
+"""bench.py -- ray-samples/s through hash-encode -> MLP -> composite (train step = fwd + bwd + optimizer) for
+per-object NeRFs, one process per GPU.  Contract: see the round brief; prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json configs[1]): OfflineNeRF-style training of one object NeRF per GPU with the reference's
+base.json defaults (hash L=16 F=2 T=2^16, MLP 64x1, R=4096 rays x S=32 samples = 131072 ray-samples per step) on a
+synthetic 'room'-like sequence (40 views, 640x480) that is resident in HBM before the timed region starts.
+A "step" is one iteration of NeRF_Model::Train_Step's loop (GenerateBatch -> forward -> composite -> loss
+gradient -> backward -> Adam/EMA), nerf_model.cu:1637-1646.  N > 1: objects shard one per rank, no data-path
+collective while training; the final render is gathered over RCCL (torch.distributed backend "nccl").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per ray-sample of one training step, SURVEY.md 8(d): 52 + 96*L  (L hash levels, F=2, fp16 table)
+def train_bytes_per_sample(L):
+    return 52 + 96 * L
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--backend", type=int, default=-1, help="-1 library default, 0 unfused, 1 fused MFMA")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--views", type=int, default=40)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    import __graft_entry__ as ge
+    pkg = ge.load_package(); ss = ge.load_tools()
+    if pkg.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible (the HIP path has no CPU fallback)")
+    device = local_rank
+
+    # ---- workload: resident in HBM before timing
+    sc = ss.make_scene(n_views=args.views, H=480, W=640, f=525.0, seed=0)
+    cfg_kw = dict(sample_seed=2024 + rank)            # every rank trains its own object NeRF (independent units)
+    ds, obj = ge.make_problem(pkg, sc, cfg_kw, device=device)
+    if args.backend >= 0:
+        obj.set_backend(args.backend)
+    cfg = obj.cfg; L = cfg.n_levels; B = cfg.rays_per_batch * cfg.n_samples
+
+    def sync():
+        pkg.lib().mon_device_synchronize(device)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    obj.train(args.warmup)
+    barrier(); sync()
+    t0 = time.perf_counter()
+    obj.train(args.steps)              # K iterations enqueued on the object's HIP stream, one sync at the end
+    sync(); barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    value = world * args.steps * B / dt
+
+    # ---- roofline of the dominant kernel (forward+backward), HIP events on the kernel's own stream
+    obj.set_profiling(True); obj.profile(reset=True)
+    obj.train(args.steps); prof = obj.profile(reset=True); obj.set_profiling(False)
+    fb_ms = prof["ms"][1] / max(1, prof["launches"][1])
+    alg_bytes = train_bytes_per_sample(L) * B
+    achieved = alg_bytes / (fb_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("fwdbwd_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                "kernel": "fused_train" if obj_backend(pkg, obj) == 1 else "unfused fwd+bwd kernel group",
+                "avg_launch_ms": round(fb_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                "batch_ms": round(prof["ms"][0] / max(1, prof["launches"][0]), 4), "optim_ms": round(prof["ms"][2] / max(1, prof["launches"][2]), 4)}
+
+    # ---- quality: PSNR of a rendered crop vs the synthetic ground truth after (2W + 2K) steps; gathered over RCCL when N > 1
+    box = sc.objects[0]["boxes"][0]; v, x, y, h, w = (int(q) for q in box)
+    rgb, depth, mask = obj.render(box, ss.colmajor(sc.Twc[v]))
+    gm = sc.instance[v, y:y + h, x:x + w] > 0
+    gt = np.where(gm[..., None], sc.rgb[v, y:y + h, x:x + w] / 255.0, 1.0)
+    my_psnr = float(-10 * np.log10(max(1e-12, ((rgb - gt) ** 2).mean())))
+    psnrs = [my_psnr]
+    if dist is not None:
+        crop = torch.from_numpy(np.concatenate([rgb.reshape(-1), depth.reshape(-1), mask.reshape(-1)]).astype(np.float32)).cuda()
+        gathered = [torch.empty_like(crop) for _ in range(world)]
+        dist.all_gather(gathered, crop)             # RCCL over xGMI: the only collective on the path (final render)
+        if rank == 0:
+            psnrs = [float(-10 * np.log10(max(1e-12, ((g[: rgb.size].cpu().numpy().reshape(rgb.shape) - gt) ** 2).mean()))) for g in gathered]
+
+    # ---- CPU baseline: the oracle (port of the same algorithm), bounded sample, rank 0 at N=1 only
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        orc = ge.load_oracle()
+        ref = ge.make_oracle(orc, sc, {})
+        ref.train(1)
+        t1 = time.perf_counter(); n = 0
+        while time.perf_counter() - t1 < args.cpu_seconds:
+            ref.train(1); n += 1
+        cdt = time.perf_counter() - t1
+        cpu = {"value": round(n * B / cdt, 1), "unit": "ray-samples/s", "cores": orc.lib().orc_max_threads(), "kind": "port",
+               "sample": "%d full training steps (R=4096 x S=32, base.json network) of oracle/mon_oracle.c with OpenMP in %.1f s" % (n, cdt)}
+        ref.close()
+
+    if rank == 0:
+        out = {"metric": "ray-samples/sec (train: hash-encode->MLP->composite fwd+bwd+optimizer) per object-NeRF", "value": round(value, 1),
+               "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16 params/activations, fp32 accumulate + fp32 master",
+               "data": "synthetic",
+               "config": {"workload": "OfflineNeRF-style training, 1 synthetic 'room'-like object per GPU, base.json defaults (hash L=16 F=2 T=2^16, MLP 64x1), "
+                                      "R=4096 rays x S=32 samples/step, %d views 640x480 resident in HBM" % args.views,
+                          "objects": world, "rays_per_step": cfg.rays_per_batch, "samples_per_ray": cfg.n_samples, "backend": obj_backend(pkg, obj),
+                          "parallelism": "object-per-GPU (no training collective; RCCL all_gather of the final render)"},
+               "roofline": roofline, "cpu_baseline": cpu,
+               "psnr_db": [round(p, 2) for p in psnrs], "train_steps_before_render": args.warmup + 2 * args.steps,
+               "final_loss": round(obj.info().last_loss, 5)}
+        print(json.dumps(out))
+    obj.close(); ds.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def obj_backend(pkg, obj):
+    return int(obj.info().backend)
+
+
+if __name__ == "__main__":
+    main()

@@ -70,6 +70,8 @@ typedef struct mon_object_info {
     int32_t  device;               /* mGPUid                                                */
     float    last_loss;            /* mfPerTrainLoss                                        */
     float    learning_rate;        /* after ExponentialDecay                                */
+    int32_t  backend;              /* 0 unfused kernels, 1 fused MFMA kernel                */
+    uint32_t skipped_batches;      /* iterations skipped because no ray hit the 3-D box     */
 } mon_object_info;
 
 /* Kernel classes timed with HIP events on the object's train stream when profiling is on. */

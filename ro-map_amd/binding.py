@@ -30,7 +30,7 @@ class MonBBox(C.Structure):
 class MonInfo(C.Structure):
     _fields_ = [("n_params", C.c_uint32), ("n_mlp_params", C.c_uint32), ("n_grid_params", C.c_uint32), ("encoded_width", C.c_uint32),
                 ("train_step", C.c_uint32), ("n_boxes", C.c_uint32), ("last_n_valid", C.c_uint32), ("device", C.c_int32),
-                ("last_loss", C.c_float), ("learning_rate", C.c_float)]
+                ("last_loss", C.c_float), ("learning_rate", C.c_float), ("backend", C.c_int32), ("skipped_batches", C.c_uint32)]
 
 
 class MonProfile(C.Structure):

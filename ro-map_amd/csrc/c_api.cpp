@@ -64,7 +64,7 @@ int mon_object_info_get(mon_object* o, mon_object_info* info) {
     REQUIRE(o, "object"); REQUIRE(info, "info"); Model& m = *o->m;
     info->n_params = m.n_params; info->n_mlp_params = m.nd.n_mlp; info->n_grid_params = m.n_grid; info->encoded_width = (uint32_t)m.nd.Epad;
     info->train_step = m.h_state.step; info->n_boxes = m.n_boxes; info->last_n_valid = m.h_state.n_valid; info->device = m.device;
-    info->last_loss = m.h_state.loss_sum / (float)m.oc.R; info->learning_rate = m.h_state.lr; return MON_OK;
+    info->last_loss = m.h_state.loss_sum / (float)m.oc.R; info->learning_rate = m.h_state.lr; info->backend = m.backend; info->skipped_batches = m.h_state.skipped; return MON_OK;
 }
 int mon_object_get_params(mon_object* o, int which, void* dst, size_t bytes) { REQUIRE(o, "object"); return model_get_params(*o->m, which, dst, bytes); }
 int mon_object_set_params(mon_object* o, const float* master, size_t n) { REQUIRE(o, "object"); return model_set_params(*o->m, master, n); }
