@@ -140,6 +140,10 @@ int mon_object_destroy(mon_object* obj);
 
 /* Whole-device helpers used by bench.py. */
 int mon_device_synchronize(int device);
+/* Diagnostic: write intermediate activations of the fused backend into the debug buffers (slower). */
+int mon_object_set_debug_dump(mon_object* obj, int enable);
+/* Diagnostic micro-benchmarks of scatter strategies (ro-map_amd/csrc/microbench.hip); *ms = best of 3 runs. */
+int mon_microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms);
 /* MFMA fragment-layout self-test (tests only): D[32x32] = A[32x16] * B[16x32], fp16 in / fp32 out. */
 int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
 

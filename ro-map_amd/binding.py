@@ -61,6 +61,8 @@ _SIGS = {
     "mon_object_train_stages": (C.c_int, [C.c_void_p, C.c_int]),
     "mon_object_set_backend": (C.c_int, [C.c_void_p, C.c_int]),
     "mon_object_debug_read": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "mon_object_set_debug_dump": (C.c_int, [C.c_void_p, C.c_int]),
+    "mon_microbench": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
     "mon_object_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mon_object_get_profile": (C.c_int, [C.c_void_p, C.POINTER(MonProfile), C.c_int]),
     "mon_object_destroy": (C.c_int, [C.c_void_p]),
@@ -123,6 +125,10 @@ def config_from_json(path):
 def selftest_mfma(A_h, B_h, device=0):
     A = np.ascontiguousarray(A_h, np.uint16); B = np.ascontiguousarray(B_h, np.uint16); D = np.empty((32, 32), np.float32)
     _check(lib().mon_selftest_mfma(device, _p(A), _p(B), _p(D))); return D
+
+
+def microbench(mode, pattern, n_entries, n_ops, device=0):
+    ms = C.c_float(0); _check(lib().mon_microbench(device, mode, pattern, n_entries, n_ops, C.byref(ms))); return ms.value
 
 
 class Dataset:
@@ -212,6 +218,9 @@ class ObjectNeRF:
                       state=(np.uint32, 8))
         dt, cnt = shapes[name]; out = np.empty(cnt, dt)
         _check(lib().mon_object_debug_read(self.h, BUF[name], _p(out), out.nbytes)); return out
+
+    def set_debug_dump(self, on):
+        _check(lib().mon_object_set_debug_dump(self.h, int(on)))
 
     def set_profiling(self, on):
         _check(lib().mon_object_set_profiling(self.h, int(on)))

@@ -20,6 +20,7 @@ int model_density_grid(Model& m, int rx, int ry, int rz, float* out_host);
 int model_get_params(Model& m, int which, void* dst, size_t bytes);
 int model_set_params(Model& m, const float* master, size_t n);
 int model_debug_read(Model& m, int which, void* dst, size_t bytes);
+int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms_out);
 }  // namespace mon
 
 using namespace mon;
@@ -74,6 +75,8 @@ int mon_object_set_backend(mon_object* o, int backend) {
     if (backend != 0 && backend != 1) { set_error("backend must be 0 or 1"); return MON_ERR_ARG; }
     o->m->backend = backend; return MON_OK;
 }
+int mon_object_set_debug_dump(mon_object* o, int enable) { REQUIRE(o, "object"); o->m->fused_dump = enable != 0; o->m->graph_backend = -1; return MON_OK; }
+int mon_microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms) { REQUIRE(ms, "ms"); return microbench(device, mode, pattern, n_entries, n_ops, ms); }
 int mon_object_debug_read(mon_object* o, int which, void* dst, size_t bytes) { REQUIRE(o, "object"); return model_debug_read(*o->m, which, dst, bytes); }
 int mon_object_set_profiling(mon_object* o, int enable) { REQUIRE(o, "object"); o->m->profiling = enable != 0; return MON_OK; }
 int mon_object_get_profile(mon_object* o, mon_profile* out, int reset) {

@@ -1,6 +1,29 @@
-// kernels_fused.hip -- fused MFMA forward/backward path (backend 1).  PLACEHOLDER STAGE:
-// only the MFMA fragment-layout self-test is live; fused_supported() reports false so the
-// unfused kernels (kernels_net.hip / kernels_composite.hip) run.
+// kernels_fused.hip -- fused forward + backward of one object NeRF for gfx950 (backend 1).
+//
+// One kernel does what Step_No_Compacted (CORE/src/nerf_model.cu:1552-1607) spreads over
+// GenerateInputPoints + tcnn forward (2 kernels) + VolumeRender + memset + VolumeRenderGradient +
+// SumLoss + tcnn backward (fused MLP backward, split-k GEMMs, grid scatter):
+//   sample points -> hash-grid encode -> MLP (MFMA) -> composite (wave scans) -> dL/dO ->
+//   MLP backward (MFMA) -> dW (MFMA, accumulated in registers) -> grid scatter (packed-f16 atomics)
+// Nothing between the ray record and the gradient tables touches HBM: E, h, dh, dE stay in
+// registers / LDS (the reference spills 8+16+8+16 MB per step at base.json sizes).
+//
+// Mapping (wave64, v_mfma_f32_32x32x16_f16, "samples on N, weights on M"):
+//   * one wavefront = one ray = 32 samples; lane l: sample n = l & 31, half h = l >> 5;
+//   * the two half-waves split the hash levels: half h owns levels [h*LPH, h*LPH+LPH), LPH = ceil(L/2);
+//     its encoded features ARE its MFMA B-operand K-slots (k = 8h + j), so the encode feeds the MLP
+//     with no cross-lane movement;
+//   * every layer is computed transposed, Out^T[units x samples] = W[units x K] * In^T[K x samples];
+//     the C/D fragment (lane = sample, registers = units rho(h,r) = (r&3) + 8(r>>2) + 4h) is directly
+//     the next layer's B fragment; weight matrices are pre-permuted into A fragments in LDS once per
+//     workgroup so that K-slot order matches;
+//   * W0^T's rows are permuted so dE lands in the half-wave that owns the level (grid backward reuses
+//     the lane's own sample position);
+//   * composite / loss gradient: lanes 0-31 are the ray's samples in order; transmittance is an
+//     exclusive multiplicative wave scan, colour/depth suffix sums are additive scans;
+//   * weight gradients need samples on K: activations are transposed through a per-wave LDS scratch
+//     ([unit][sample] fp16) and accumulated in MFMA accumulators across the wave's rays, then reduced
+//     across the workgroup in LDS and written as one fp32 partial per workgroup (summed by the optimizer).
 #include "device_common.h"
 #include "model.h"
 
@@ -8,8 +31,8 @@ namespace mon {
 
 void set_error(const char* fmt, ...);
 
-// D[32x32] = A[32x16] * B[16x32] with v_mfma_f32_32x32x16_f16, using the fragment layout this
-// code base assumes: A lane l -> row l&31, k = 8*(l>>5)+j ; B lane l -> col l&31, k = 8*(l>>5)+j ;
+// ------------------------------------------------------------------ MFMA fragment-layout self-test
+// D[32x32] = A[32x16] * B[16x32]: A lane l -> row l&31, k = 8*(l>>5)+j ; B lane l -> col l&31, same k ;
 // D lane l, reg r -> col l&31, row (r&3) + 8*(r>>2) + 4*(l>>5).   A, B, D row-major.
 __global__ void __launch_bounds__(64) k_selftest_mfma(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, float* __restrict__ D) {
     const int l = threadIdx.x, i = l & 31, hk = l >> 5;
@@ -26,7 +49,8 @@ __global__ void __launch_bounds__(64) k_selftest_mfma(const uint16_t* __restrict
 }
 
 int selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D) {
-    if (hipSetDevice(device) != hipSuccess) { set_error("selftest: no device"); return MON_ERR_NO_DEVICE; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || hipSetDevice(device) != hipSuccess) { set_error("selftest: no HIP device"); return MON_ERR_NO_DEVICE; }
     uint16_t *dA = nullptr, *dB = nullptr; float* dD = nullptr;
     if (hipMalloc((void**)&dA, 32 * 16 * 2) != hipSuccess || hipMalloc((void**)&dB, 16 * 32 * 2) != hipSuccess || hipMalloc((void**)&dD, 32 * 32 * 4) != hipSuccess) { set_error("selftest: hipMalloc failed"); return MON_ERR_HIP; }
     hipMemcpy(dA, A, 32 * 16 * 2, hipMemcpyHostToDevice); hipMemcpy(dB, B, 16 * 32 * 2, hipMemcpyHostToDevice);
@@ -37,8 +61,557 @@ int selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D) {
     return MON_OK;
 }
 
-bool fused_supported(const NetDims&, uint32_t) { return false; }
-void launch_fused_train(hipStream_t, const LevelTable&, const NetDims&, const ParamPtrs&, const BatchPtrs&, const ObjectConst&, DevState*, float*, int) {}
-void launch_fused_render(hipStream_t, const LevelTable&, const NetDims&, const uint16_t*, const BatchPtrs&, const ObjectConst&, uint32_t, uint32_t, float*, float*, float*) {}
+// ------------------------------------------------------------------ shared pieces
+__device__ __forceinline__ int rho(int h, int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// hidden unit carried by K-slot (k-step s, half h, element j) of a W-wide activation in C/D layout
+__device__ __forceinline__ int unit_of_slot(int s, int h, int j) { return 32 * (s >> 1) + rho(h, 8 * (s & 1) + j); }
+
+struct LevelLds { uint32_t offset[kMaxLevels + 1]; uint32_t res[kMaxLevels]; float scale[kMaxLevels]; };
+
+// Corner walk of one level for one position: calls f(k, table_index, weight) for the 8 corners.
+template <class F>
+__device__ __forceinline__ void level_corners(const LevelLds& lt, int level, const float x[3], F&& f) {
+    const float scale = lt.scale[level]; const uint32_t res = lt.res[level], off = lt.offset[level], size = lt.offset[level + 1] - off;
+    float pos[3]; uint32_t pg[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { const float p = fmaf(scale, x[d], 0.5f), fl = floorf(p); pg[d] = (uint32_t)(int32_t)fl; pos[d] = p - fl; }
+    const bool pow2 = (size & (size - 1u)) == 0u;
+    // strides of the dense index, with tcnn's overflow guard
+    const bool s1 = res <= size; const uint32_t r2 = res * res; const bool s2 = s1 && r2 <= size; const bool hashed = !(s2) || (uint64_t)r2 * res > size;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float w = 1.f; uint32_t q[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { if (k & (1 << d)) { w *= pos[d]; q[d] = pg[d] + 1u; } else { w *= 1.f - pos[d]; q[d] = pg[d]; } }
+        uint32_t idx = hashed ? (q[0] ^ (q[1] * 2654435761u) ^ (q[2] * 805459861u)) : (q[0] + q[1] * res + q[2] * r2);
+        idx = pow2 ? (idx & (size - 1u)) : (idx % size);
+        f(k, off + idx, w);
+    }
+}
+
+template <int EPAD, int W, int NH> struct FusedShape {
+    static constexpr int MB = W / 32;            // 32-row M blocks of a hidden layer
+    static constexpr int KS0 = EPAD / 16;        // k-steps over the encoded input
+    static constexpr int KSW = W / 16;           // k-steps over a hidden activation
+    static constexpr int LLV = EPAD / 4;         // max local levels per half-wave (2 features each, EPAD/2 features per half)
+    // A-fragment table (units of 512 halves = 64 lanes x 8)
+    static constexpr int F_W0 = 0;                                   // [MB][KS0]
+    static constexpr int F_W1 = F_W0 + MB * KS0;                     // [MB][KSW]      (NH == 2)
+    static constexpr int F_WO = F_W1 + (NH == 2 ? MB * KSW : 0);     // [KSW]
+    static constexpr int F_WOT = F_WO + KSW;                         // [MB]
+    static constexpr int F_W1T = F_WOT + MB;                         // [MB][KSW]      (NH == 2)
+    static constexpr int F_W0T = F_W1T + (NH == 2 ? MB * KSW : 0);   // [KSW]
+    static constexpr int N_FRAGS = F_W0T + KSW;
+    static constexpr int FRAG_BYTES = N_FRAGS * 1024;
+    static constexpr int LT_BYTES = 256;                             // LevelLds (49 words)
+    // per-wave transpose scratch, fp16 [row][32 samples]
+    static constexpr int SCR_E = 0;                                  // EPAD rows
+    static constexpr int SCR_HA = SCR_E + EPAD * 32;                 // W rows: last hidden layer / its gradient
+    static constexpr int SCR_HB = SCR_HA + W * 32;                   // W rows: first hidden layer (NH == 2)
+    static constexpr int SCR_DO = SCR_HB + (NH == 2 ? W * 32 : 0);   // 4 rows
+    static constexpr int SCR_HALVES = SCR_DO + 4 * 32;
+    static constexpr int SCR_BYTES = SCR_HALVES * 2;
+    static constexpr int N_MLP = W * EPAD + (NH - 1) * W * W + kOutPad * W;
+    static constexpr int OFF_W1 = W * EPAD;
+    static constexpr int OFF_WO = W * EPAD + (NH - 1) * W * W;
+    static constexpr int RED_BYTES = (N_MLP + 64) * 4;
+    static constexpr int WAVES = 4;
+    static constexpr int SMEM_BYTES = FRAG_BYTES + LT_BYTES + ((WAVES * SCR_BYTES > RED_BYTES) ? WAVES * SCR_BYTES : RED_BYTES);
+};
+
+struct FusedArgs {
+    LevelTable lt; NetDims nd; ObjectConst oc; BatchPtrs b;
+    const uint16_t* params;     // fp16 parameter vector (MLP matrices then grid)
+    uint16_t* ggrid;            // fp16 grid gradient table
+    float* partials;            // [gridDim.x][N_MLP + 64] fp32: dW partial sums, slot N_MLP = loss partial
+    const DevState* st;
+};
+
+// Builds the A fragments (weights pre-permuted to K-slot order) and the level table in LDS.
+template <int EPAD, int W, int NH>
+__device__ __forceinline__ void build_fragments(half_t* frags, LevelLds* llt, const FusedArgs& a, bool backward) {
+    using S = FusedShape<EPAD, W, NH>;
+    const half_t* w = reinterpret_cast<const half_t*>(a.params);
+    const int L = a.nd.L, LPH = (L + 1) >> 1;
+    for (int i = threadIdx.x; i <= kMaxLevels; i += blockDim.x) { llt->offset[i] = a.lt.offset[i]; if (i < kMaxLevels) { llt->res[i] = a.lt.res[i]; llt->scale[i] = a.lt.scale[i]; } }
+    const int total = (backward ? S::N_FRAGS : S::F_WOT) * 512;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int frag = idx >> 9, lane = (idx >> 3) & 63, j = idx & 7, m = lane & 31, h = lane >> 5;
+        half_t v = (half_t)0.f;
+        if (frag < S::F_W1) {                                   // W0: rows = units, K slots = encoded features of the owning half
+            const int mb = (frag - S::F_W0) / S::KS0, s = (frag - S::F_W0) % S::KS0;
+            const int il = 4 * s + (j >> 1), level = h * LPH + il;
+            if (il < LPH && level < L) v = w[(32 * mb + m) * EPAD + 2 * level + (j & 1)];
+        } else if (NH == 2 && frag < S::F_WO) {                 // W1: rows = units of layer 1, K slots = units of layer 0
+            const int mb = (frag - S::F_W1) / S::KSW, s = (frag - S::F_W1) % S::KSW;
+            v = w[S::OFF_W1 + (32 * mb + m) * W + unit_of_slot(s, h, j)];
+        } else if (frag < S::F_WOT) {                           // Wout: 4 real rows of 32
+            const int s = frag - S::F_WO;
+            if (m < kOut) v = w[S::OFF_WO + m * W + unit_of_slot(s, h, j)];
+        } else if (frag < S::F_W1T) {                           // Wout^T: rows = units, K slots 0..3 = output channels
+            const int mb = frag - S::F_WOT, c = 8 * h + j;
+            if (c < kOut) v = w[S::OFF_WO + c * W + 32 * mb + m];
+        } else if (NH == 2 && frag < S::F_W0T) {                // W1^T: rows = units of layer 0, K slots = units of layer 1
+            const int mb = (frag - S::F_W1T) / S::KSW, s = (frag - S::F_W1T) % S::KSW;
+            v = w[S::OFF_W1 + unit_of_slot(s, h, j) * W + 32 * mb + m];
+        } else {                                                // W0^T: row m = (half hh, reg r) <-> local feature r of half hh
+            const int s = frag - S::F_W0T;
+            const int hh = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3), il = r >> 1, level = hh * LPH + il;
+            if (il < LPH && level < L && r < EPAD / 2) v = w[unit_of_slot(s, h, j) * EPAD + 2 * level + (r & 1)];
+        }
+        frags[idx] = v;
+    }
+}
+
+__device__ __forceinline__ half8_t lds_frag(const half_t* frags, int frag, int lane) { return *reinterpret_cast<const half8_t*>(frags + frag * 512 + lane * 8); }
+
+// relu + round to fp16 of one 32x32 C/D fragment -> two B fragments (registers 0..7, 8..15)
+__device__ __forceinline__ void relu_pack(const float16_t& acc, half8_t& lo, half8_t& hi) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { lo[j] = (half_t)fmaxf(acc[j], 0.f); hi[j] = (half_t)fmaxf(acc[8 + j], 0.f); }
+}
+__device__ __forceinline__ void mask_pack(const float16_t& acc, const half8_t& flo, const half8_t& fhi, half8_t& lo, half8_t& hi) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { lo[j] = (half_t)(((float)flo[j] > 0.f) ? acc[j] : 0.f); hi[j] = (half_t)(((float)fhi[j] > 0.f) ? acc[8 + j] : 0.f); }
+}
+// store one packed C/D fragment pair transposed into the scratch: scr[unit][sample]
+__device__ __forceinline__ void scratch_store_units(half_t* scr, int mb, int n, int h, const half8_t& lo, const half8_t& hi) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { scr[(32 * mb + rho(h, j)) * 32 + n] = lo[j]; scr[(32 * mb + rho(h, 8 + j)) * 32 + n] = hi[j]; }
+}
+
+// Forward pass of one 32-sample tile.  Leaves: ef (local encoded features), hp* (hidden activations as
+// packed B fragments), out4 (raw network outputs of sample n, valid in half-wave 0).
+template <int EPAD, int W, int NH>
+struct TileState {
+    using S = FusedShape<EPAD, W, NH>;
+    half_t ef[EPAD / 2];
+    half8_t h0[S::MB][2];
+    half8_t h1[NH == 2 ? S::MB : 1][2];
+    float out4[4];
+};
+
+template <int EPAD, int W, int NH>
+__device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const half_t* frags, const LevelLds& llt, const half2_t* __restrict__ table,
+                                             int L, const float x[3], int lane) {
+    using S = FusedShape<EPAD, W, NH>;
+    const int h = lane >> 5, LPH = (L + 1) >> 1;
+    // ---- hash-grid encode of the levels this half-wave owns (tcnn kernel_grid; fp32 fmaf chain, one rounding)
+#pragma unroll
+    for (int il = 0; il < S::LLV; ++il) {
+        const int level = h * LPH + il;
+        float a0 = 0.f, a1 = 0.f;
+        if (il < LPH && level < L) {
+            level_corners(llt, level, x, [&](int, uint32_t idx, float wgt) { const half2_t v = table[idx]; a0 = fmaf(wgt, (float)v.x, a0); a1 = fmaf(wgt, (float)v.y, a1); });
+        }
+        ts.ef[2 * il] = (half_t)a0; ts.ef[2 * il + 1] = (half_t)a1;
+    }
+    // ---- layer 0
+    float16_t acc[S::MB];
+#pragma unroll
+    for (int mb = 0; mb < S::MB; ++mb) {
+        acc[mb] = float16_t{ 0 };
+#pragma unroll
+        for (int s = 0; s < S::KS0; ++s) {
+            half8_t bf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bf[j] = ts.ef[8 * s + j];
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(frags, S::F_W0 + mb * S::KS0 + s, lane), bf, acc[mb], 0, 0, 0);
+        }
+        relu_pack(acc[mb], ts.h0[mb][0], ts.h0[mb][1]);
+    }
+    if constexpr (NH == 2) {
+#pragma unroll
+        for (int mb = 0; mb < S::MB; ++mb) {
+            float16_t a1 = float16_t{ 0 };
+#pragma unroll
+            for (int s = 0; s < S::KSW; ++s) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(frags, S::F_W1 + mb * S::KSW + s, lane), ts.h0[s >> 1][s & 1], a1, 0, 0, 0);
+            relu_pack(a1, ts.h1[mb][0], ts.h1[mb][1]);
+        }
+    }
+    // ---- output layer (rows 0..3 real)
+    float16_t ao = float16_t{ 0 };
+#pragma unroll
+    for (int s = 0; s < S::KSW; ++s) {
+        half8_t bf;
+        if constexpr (NH == 2) bf = ts.h1[s >> 1][s & 1]; else bf = ts.h0[s >> 1][s & 1];
+        ao = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(frags, S::F_WO + s, lane), bf, ao, 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ts.out4[c] = (float)(half_t)ao[c];        // network output is fp16 (tcnn network_precision_t)
+}
+
+// 32-lane inclusive scans (each half-wave scans independently)
+__device__ __forceinline__ float scan_mul32(float v, int n) {
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) { const float o = __shfl_up(v, d, 32); if (n >= d) v *= o; }
+    return v;
+}
+__device__ __forceinline__ float scan_add32(float v, int n) {
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) { const float o = __shfl_up(v, d, 32); if (n >= d) v += o; }
+    return v;
+}
+
+// ------------------------------------------------------------------ fused training kernel
+template <int EPAD, int W, int NH, bool DUMP>
+__global__ void __launch_bounds__(256) k_fused_train(FusedArgs a) {
+    using S = FusedShape<EPAD, W, NH>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (a.st->n_valid == 0u) return;                                   // batch skipped (uniform)
+    half_t* frags = reinterpret_cast<half_t*>(smem);
+    LevelLds* llt = reinterpret_cast<LevelLds*>(smem + S::FRAG_BYTES);
+    unsigned char* dyn = smem + S::FRAG_BYTES + S::LT_BYTES;
+    build_fragments<EPAD, W, NH>(frags, llt, a, true);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+    half_t* scr = reinterpret_cast<half_t*>(dyn + wave * S::SCR_BYTES);
+    for (int i = lane; i < S::SCR_HALVES; i += 64) scr[i] = (half_t)0.f;           // pad feature rows must stay zero
+    __syncthreads();
+
+    const int L = a.nd.L, LPH = (L + 1) >> 1;
+    const uint32_t R = a.oc.R, iter = a.st->iter, nvalid = a.st->n_valid;
+    const half2_t* table = reinterpret_cast<const half2_t*>(a.params + a.nd.n_mlp);
+    typedef __attribute__((address_space(1))) half2_t gh2;
+    gh2* gtable = (gh2*)reinterpret_cast<half2_t*>(a.ggrid);
+    const float ls = a.oc.loss_scale / (float)R;
+
+    float16_t dW0[S::MB], dWo[S::MB], dW1[NH == 2 ? S::MB : 1][NH == 2 ? S::MB : 1];
+#pragma unroll
+    for (int mb = 0; mb < S::MB; ++mb) { dW0[mb] = float16_t{ 0 }; dWo[mb] = float16_t{ 0 }; }
+    if constexpr (NH == 2) {
+#pragma unroll
+        for (int mb = 0; mb < S::MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < S::MB; ++nb) dW1[mb][nb] = float16_t{ 0 };
+    }
+    float loss_acc = 0.f;
+
+    for (uint32_t ray = blockIdx.x * S::WAVES + wave; ray < R; ray += gridDim.x * S::WAVES) {
+        // ---- sample position (GenerateInputPoints, nerf_model.cu:553-566)
+        const float t0 = a.b.ray_t0[ray], t1 = a.b.ray_t1[ray];
+        const float dtr = (t1 - t0) / 32.0f;
+        const uint32_t s_idx = ray * 32u + (uint32_t)n;
+        const float t = fmaf(dtr, (float)n + rand01(a.oc.sample_seed, kStreamDt, iter, s_idx), t0);
+        float x[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { const float p = fmaf(t, a.b.ray_d[3 * ray + d], a.b.ray_o[3 * ray + d]); x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
+
+        TileState<EPAD, W, NH> ts;
+        tile_forward<EPAD, W, NH>(ts, frags, *llt, table, L, x, lane);
+
+        // ---- transposes needed by the weight gradients
+#pragma unroll
+        for (int il = 0; il < S::LLV; ++il) {
+            const int level = h * LPH + il;
+            if (il < LPH && level < L) { scr[S::SCR_E + (2 * level) * 32 + n] = ts.ef[2 * il]; scr[S::SCR_E + (2 * level + 1) * 32 + n] = ts.ef[2 * il + 1]; }
+        }
+#pragma unroll
+        for (int mb = 0; mb < S::MB; ++mb) {
+            if constexpr (NH == 2) { scratch_store_units(scr + S::SCR_HB, mb, n, h, ts.h0[mb][0], ts.h0[mb][1]); scratch_store_units(scr + S::SCR_HA, mb, n, h, ts.h1[mb][0], ts.h1[mb][1]); }
+            else scratch_store_units(scr + S::SCR_HA, mb, n, h, ts.h0[mb][0], ts.h0[mb][1]);
+        }
+
+        // ---- composite (VolumeRender :762-813) as wave scans over lanes 0..31
+        const float v0 = ts.out4[0], v1 = ts.out4[1], v2 = ts.out4[2], v3 = ts.out4[3];
+        const float c0 = logistic_f(v0), c1 = logistic_f(v1), c2 = logistic_f(v2), sigma = __expf(v3);
+        float tprev = __shfl_up(t, 1, 32); if (n == 0) tprev = 0.f;                      // :770 last_distance = 0
+        const float dt = t - tprev;
+        const float alpha = 1.f - __expf(-sigma * dt), om = 1.f - alpha;
+        const float tincl = scan_mul32(om, n);                                            // T after this sample
+        float T = __shfl_up(tincl, 1, 32); if (n == 0) T = 1.f;                           // T before this sample
+        const bool active = T >= kTransmittanceEps;                                        // :774 early-out (T is non-increasing)
+        const int nact = __popc((uint32_t)__ballot(active));                               // lanes 0..31 = the ray's samples
+        const float Tfin = __shfl(tincl, nact - 1, 64);                                    // broadcast from half-wave 0
+        const float wgt = active ? alpha * T : 0.f;
+        const float p0 = scan_add32(wgt * c0, n), p1 = scan_add32(wgt * c1, n), p2 = scan_add32(wgt * c2, n), pd = scan_add32(wgt * t, n);
+        const float bg0 = a.b.bgcol[3 * ray], bg1 = a.b.bgcol[3 * ray + 1], bg2 = a.b.bgcol[3 * ray + 2];
+        const float rgb0 = __shfl(p0, 31, 64) + Tfin * bg0, rgb1 = __shfl(p1, 31, 64) + Tfin * bg1, rgb2 = __shfl(p2, 31, 64) + Tfin * bg2;
+        const float dep = __shfl(pd, 31, 64), mask = 1.f - Tfin;
+        // ---- loss + dL/dO (VolumeRenderGradient_No_Compacted :853-953)
+        const float e0 = rgb0 - a.b.target[3 * ray], e1 = rgb1 - a.b.target[3 * ray + 1], e2 = rgb2 - a.b.target[3 * ray + 2];
+        const float g0 = 2.f * e0, g1 = 2.f * e1, g2 = 2.f * e2;
+        const float tdp = a.b.target_depth[ray];
+        float dl_dd = 0.f; if (tdp > 0.f) dl_dd = 0.5f * ((dep - tdp >= 0.f) ? 1.f : -1.f);
+        const bool is_obj = a.b.ray_flag[ray] == 1;
+        const float mean_loss = (e0 * e0 + e1 * e1 + e2 * e2) / 3.f;
+        const float loss = is_obj ? mean_loss + dl_dd * (dep - tdp) + (1.f - mask) : mean_loss + mask;
+        half8_t bdo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bdo[j] = (half_t)0.f;
+        if (active && h == 0) {
+            const float Tn = tincl;                                                       // T after the update (:912)
+            const float s0 = rgb0 - p0, s1 = rgb1 - p1, s2 = rgb2 - p2;                   // suffix :915
+            bdo[0] = (half_t)(ls * ((wgt * g0) * (c0 * (1.f - c0))));
+            bdo[1] = (half_t)(ls * ((wgt * g1) * (c1 * (1.f - c1))));
+            bdo[2] = (half_t)(ls * ((wgt * g2) * (c2 * (1.f - c2))));
+            const float dsig = __expf(clamp_f(v3, -15.f, 15.f));
+            const float depth_sup = dl_dd * (Tn * t - (dep - pd));
+            const float dmask = 1.f - mask;
+            float dl;
+            if (is_obj) {
+                const float dlm = 0.5f * (mask >= 1.f ? 1.f : -1.f);
+                const float dot = g0 * (Tn * c0 - s0) + g1 * (Tn * c1 - s1) + g2 * (Tn * c2 - s2);
+                dl = dsig * dt * (dot + depth_sup + dlm * dmask);
+            } else {
+                const float dlm = 0.5f * (mask >= 0.f ? 1.f : -1.f);
+                dl = dsig * dt * dlm * dmask + dsig * 0.01f;
+            }
+            bdo[3] = (half_t)(ls * dl);
+        }
+        if (h == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) scr[S::SCR_DO + c * 32 + n] = bdo[c];
+        }
+        if (lane == 0) {
+            loss_acc += loss;
+            a.b.rgb_ray[3 * ray] = rgb0; a.b.rgb_ray[3 * ray + 1] = rgb1; a.b.rgb_ray[3 * ray + 2] = rgb2;
+            a.b.depth_ray[ray] = dep; a.b.mask_ray[ray] = mask; a.b.loss_ray[ray] = loss;
+        }
+        if (DUMP) {
+            if (h == 0) {
+                a.b.pts[3 * s_idx] = x[0]; a.b.pts[3 * s_idx + 1] = x[1]; a.b.pts[3 * s_idx + 2] = x[2]; a.b.tdist[s_idx] = t;
+                half4_t o4 = { (half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3 }; reinterpret_cast<half4_t*>(a.b.O)[s_idx] = o4;
+                half4_t d4 = { bdo[0], bdo[1], bdo[2], bdo[3] }; reinterpret_cast<half4_t*>(a.b.dO)[s_idx] = d4;
+            }
+            half_t* Eo = reinterpret_cast<half_t*>(a.b.E) + (size_t)s_idx * EPAD;
+#pragma unroll
+            for (int il = 0; il < S::LLV; ++il) { const int level = h * LPH + il; if (il < LPH && level < L) { Eo[2 * level] = ts.ef[2 * il]; Eo[2 * level + 1] = ts.ef[2 * il + 1]; } }
+            half_t* Ho = reinterpret_cast<half_t*>(a.b.Hid) + (size_t)s_idx * W * NH;
+#pragma unroll
+            for (int mb = 0; mb < S::MB; ++mb)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    Ho[32 * mb + rho(h, j)] = ts.h0[mb][0][j]; Ho[32 * mb + rho(h, 8 + j)] = ts.h0[mb][1][j];
+                    if constexpr (NH == 2) { Ho[W + 32 * mb + rho(h, j)] = ts.h1[mb][0][j]; Ho[W + 32 * mb + rho(h, 8 + j)] = ts.h1[mb][1][j]; }
+                }
+        }
+
+        // ---- backward: dWout += H_last^T-side outer products (K = samples, via the LDS transposes)
+        const int m = n;     // A-fragment row / B-fragment column of this lane
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            half8_t bcol;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bcol[j] = (half_t)0.f;
+            if (m < kOut) bcol = *reinterpret_cast<const half8_t*>(scr + S::SCR_DO + m * 32 + 16 * s + 8 * h);
+#pragma unroll
+            for (int mb = 0; mb < S::MB; ++mb) {
+                const half8_t arow = *reinterpret_cast<const half8_t*>(scr + S::SCR_HA + (32 * mb + m) * 32 + 16 * s + 8 * h);
+                dWo[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(arow, bcol, dWo[mb], 0, 0, 0);
+            }
+        }
+        // ---- dH of the last hidden layer = relu' * (Wout^T dO)
+        half8_t dhl[S::MB][2];
+#pragma unroll
+        for (int mb = 0; mb < S::MB; ++mb) {
+            float16_t acc = float16_t{ 0 };
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(frags, S::F_WOT + mb, lane), bdo, acc, 0, 0, 0);
+            if constexpr (NH == 2) mask_pack(acc, ts.h1[mb][0], ts.h1[mb][1], dhl[mb][0], dhl[mb][1]);
+            else mask_pack(acc, ts.h0[mb][0], ts.h0[mb][1], dhl[mb][0], dhl[mb][1]);
+            scratch_store_units(scr + S::SCR_HA, mb, n, h, dhl[mb][0], dhl[mb][1]);       // H_last no longer needed: reuse as dH_last
+        }
+        half8_t dh0[S::MB][2];
+        if constexpr (NH == 2) {
+            // dW1[u2][u1] += dH1[u2][n] * H0[n][u1]
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int nb = 0; nb < S::MB; ++nb) {
+                    const half8_t bcol = *reinterpret_cast<const half8_t*>(scr + S::SCR_HB + (32 * nb + m) * 32 + 16 * s + 8 * h);
+#pragma unroll
+                    for (int mb = 0; mb < S::MB; ++mb) {
+                        const half8_t arow = *reinterpret_cast<const half8_t*>(scr + S::SCR_HA + (32 * mb + m) * 32 + 16 * s + 8 * h);
+                        dW1[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(arow, bcol, dW1[mb][nb], 0, 0, 0);
+                    }
+                }
+            // dH0 = relu' * (W1^T dH1)
+#pragma unroll
+            for (int mb = 0; mb < S::MB; ++mb) {
+                float16_t acc = float16_t{ 0 };
+#pragma unroll
+                for (int s = 0; s < S::KSW; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(frags, S::F_W1T + mb * S::KSW + s, lane), dhl[s >> 1][s & 1], acc, 0, 0, 0);
+                mask_pack(acc, ts.h0[mb][0], ts.h0[mb][1], dh0[mb][0], dh0[mb][1]);
+                scratch_store_units(scr + S::SCR_HB, mb, n, h, dh0[mb][0], dh0[mb][1]);   // H0 no longer needed: reuse as dH0
+            }
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < S::MB; ++mb) { dh0[mb][0] = dhl[mb][0]; dh0[mb][1] = dhl[mb][1]; }
+        }
+        // ---- dW0[u][f] += dH0[u][n] * E[n][f]
+        {
+            const half_t* dh0_scr = scr + (NH == 2 ? S::SCR_HB : S::SCR_HA);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const half8_t bcol = *reinterpret_cast<const half8_t*>(scr + S::SCR_E + (m & (EPAD - 1)) * 32 + 16 * s + 8 * h);
+#pragma unroll
+                for (int mb = 0; mb < S::MB; ++mb) {
+                    const half8_t arow = *reinterpret_cast<const half8_t*>(dh0_scr + (32 * mb + m) * 32 + 16 * s + 8 * h);
+                    dW0[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(arow, bcol, dW0[mb], 0, 0, 0);
+                }
+            }
+        }
+        // ---- dE = W0^T dH0, rows permuted so register r of half h is local feature r of that half
+        float16_t de = float16_t{ 0 };
+#pragma unroll
+        for (int s = 0; s < S::KSW; ++s) de = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(frags, S::F_W0T + s, lane), dh0[s >> 1][s & 1], de, 0, 0, 0);
+        if (DUMP) {
+            half_t* dEo = reinterpret_cast<half_t*>(a.b.dE) + (size_t)s_idx * EPAD;
+            half_t* dHo = reinterpret_cast<half_t*>(a.b.dHid) + (size_t)s_idx * W * NH;
+#pragma unroll
+            for (int il = 0; il < S::LLV; ++il) { const int level = h * LPH + il; if (il < LPH && level < L) { dEo[2 * level] = (half_t)de[2 * il]; dEo[2 * level + 1] = (half_t)de[2 * il + 1]; } }
+#pragma unroll
+            for (int mb = 0; mb < S::MB; ++mb)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    dHo[(NH - 1) * W + 32 * mb + rho(h, j)] = dhl[mb][0][j]; dHo[(NH - 1) * W + 32 * mb + rho(h, 8 + j)] = dhl[mb][1][j];
+                    if constexpr (NH == 2) { dHo[32 * mb + rho(h, j)] = dh0[mb][0][j]; dHo[32 * mb + rho(h, 8 + j)] = dh0[mb][1][j]; }
+                }
+        }
+        // ---- grid backward (tcnn kernel_grid_backward): 8 packed-f16 atomics per owned level
+#pragma unroll
+        for (int il = 0; il < S::LLV; ++il) {
+            const int level = h * LPH + il;
+            if (il < LPH && level < L) {
+                const float gq0 = (float)(half_t)de[2 * il], gq1 = (float)(half_t)de[2 * il + 1];
+                if (gq0 != 0.f || gq1 != 0.f) {
+                    level_corners(*llt, level, x, [&](int, uint32_t idx, float wgt2) {
+                        __builtin_amdgcn_global_atomic_fadd_v2f16(gtable + idx, half2_t{ (half_t)(wgt2 * gq0), (half_t)(wgt2 * gq1) });
+                    });
+                }
+            }
+        }
+    }
+
+    // ---- reduce the weight-gradient accumulators over the workgroup's waves, write one fp32 partial
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(dyn);
+    for (int i = threadIdx.x; i < S::N_MLP + 64; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    const int col = n;
+    for (int wv = 0; wv < S::WAVES; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int mb = 0; mb < S::MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int u = 32 * mb + rho(h, r);
+                    if (col < EPAD) red[u * EPAD + col] += dW0[mb][r];
+                    if (col < kOut) red[S::OFF_WO + col * W + u] += dWo[mb][r];
+                    if constexpr (NH == 2) {
+#pragma unroll
+                        for (int nb = 0; nb < S::MB; ++nb) red[S::OFF_W1 + u * W + 32 * nb + col] += dW1[mb][nb][r];
+                    }
+                }
+            if (lane == 0) red[S::N_MLP] += loss_acc;
+        }
+        __syncthreads();
+    }
+    float* dst = a.partials + (size_t)blockIdx.x * (S::N_MLP + 64);
+    for (int i = threadIdx.x; i < S::N_MLP + 1; i += blockDim.x) dst[i] = red[i];
+}
+
+// ------------------------------------------------------------------ fused render kernel
+// One wavefront per pixel ray, 2S = 64 samples as two 32-sample tiles with a carried transmittance;
+// rays that miss the box and tiles behind an opaque prefix are skipped (wave-uniform).
+// GenerateRenderInputPoints :593-626 + inference + VolumeRender_Render :1134-1229.
+template <int EPAD, int W, int NH>
+__global__ void __launch_bounds__(256) k_fused_render(FusedArgs a, uint32_t n_rays, uint32_t idx_base, float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ mask) {
+    using S = FusedShape<EPAD, W, NH>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half_t* frags = reinterpret_cast<half_t*>(smem);
+    LevelLds* llt = reinterpret_cast<LevelLds*>(smem + S::FRAG_BYTES);
+    build_fragments<EPAD, W, NH>(frags, llt, a, false);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31;
+    const int L = a.nd.L; const uint32_t S2 = 2u * a.oc.S;      // 64
+    const half2_t* table = reinterpret_cast<const half2_t*>(a.params + a.nd.n_mlp);
+    for (uint32_t ray = blockIdx.x * S::WAVES + wave; ray < n_rays; ray += gridDim.x * S::WAVES) {
+        float o0 = 1.f, o1 = 1.f, o2 = 1.f, od = 0.f, om_ = 0.f;
+        if (a.b.ray_flag[ray]) {
+            const float t0 = a.b.ray_t0[ray], t1 = a.b.ray_t1[ray], dtr = (t1 - t0) / (float)S2;
+            float Tc = 1.f, r0 = 0.f, r1 = 0.f, r2 = 0.f, dep = 0.f, tlast = 0.f;
+            for (uint32_t tile = 0; tile < 2u; ++tile) {
+                if (Tc < kTransmittanceEps) break;
+                const uint32_t k = tile * 32u + (uint32_t)n;
+                const float t = fmaf(dtr, (float)k + rand01(a.oc.sample_seed, kStreamRender, 0u, idx_base + ray * S2 + k), t0);
+                float x[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { const float p = fmaf(t, a.b.ray_d[3 * ray + d], a.b.ray_o[3 * ray + d]); x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
+                TileState<EPAD, W, NH> ts;
+                tile_forward<EPAD, W, NH>(ts, frags, *llt, table, L, x, lane);
+                const float c0 = logistic_f(ts.out4[0]), c1 = logistic_f(ts.out4[1]), c2 = logistic_f(ts.out4[2]), sigma = __expf(ts.out4[3]);
+                float tprev = __shfl_up(t, 1, 32); if (n == 0) tprev = tlast;
+                const float alpha = 1.f - __expf(-sigma * (t - tprev)), omv = 1.f - alpha;
+                const float tincl = scan_mul32(omv, n) * Tc;
+                float T = __shfl_up(tincl, 1, 32); if (n == 0) T = Tc;
+                const bool active = T >= kTransmittanceEps;
+                const int nact = __popc((uint32_t)__ballot(active));
+                const float wgt = active ? alpha * T : 0.f;
+                r0 += __shfl(scan_add32(wgt * c0, n), 31, 64); r1 += __shfl(scan_add32(wgt * c1, n), 31, 64); r2 += __shfl(scan_add32(wgt * c2, n), 31, 64);
+                dep += __shfl(scan_add32(wgt * t, n), 31, 64);
+                Tc = (nact > 0) ? __shfl(tincl, nact - 1, 64) : Tc;      // all 64 lanes carry half-wave 0's state (uniform control flow)
+                tlast = __shfl(t, 31, 64);
+            }
+            if (1.f - Tc > 0.5f) { o0 = r0 + Tc; o1 = r1 + Tc; o2 = r2 + Tc; od = dep / a.b.ray_dn[ray]; om_ = 1.f; }      // :1213-1220
+        }
+        if (lane == 0) { rgb[3 * ray] = o0; rgb[3 * ray + 1] = o1; rgb[3 * ray + 2] = o2; depth[ray] = od; mask[ray] = om_; }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+bool fused_supported(const NetDims& nd, uint32_t S) {
+    return S == 32 && nd.L >= 1 && nd.L <= kMaxLevels && (nd.Epad == 16 || nd.Epad == 32) && (nd.W == 32 || nd.W == 64) && (nd.NH == 1 || nd.NH == 2);
+}
+
+uint32_t fused_train_grid(const NetDims&, uint32_t R) {
+    const uint32_t want = (R + 3) / 4;            // one ray per wavefront when it fits
+    return want < 512u ? want : 512u;
+}
+
+template <int EPAD, int W, int NH>
+static void fused_train_t(hipStream_t s, const FusedArgs& a, uint32_t grid, int dump) {
+    using S = FusedShape<EPAD, W, NH>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
+        attr_done = true;
+    }
+    if (dump) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
+    else hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
+}
+template <int EPAD, int W, int NH>
+static void fused_render_t(hipStream_t s, const FusedArgs& a, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask) {
+    using S = FusedShape<EPAD, W, NH>;
+    const uint32_t smem = S::FRAG_BYTES + S::LT_BYTES;
+    uint32_t grid = (n_rays + 3) / 4; if (grid > 2048u) grid = 2048u;
+    hipLaunchKernelGGL((k_fused_render<EPAD, W, NH>), dim3(grid), dim3(256), smem, s, a, n_rays, idx_base, rgb, depth, mask);
+}
+
+#define MON_FUSED_DISPATCH(FN, ...)                                                            \
+    do {                                                                                       \
+        const int key = nd.Epad * 1000 + nd.W * 10 + nd.NH;                                    \
+        switch (key) {                                                                         \
+            case 16 * 1000 + 32 * 10 + 1: FN<16, 32, 1>(__VA_ARGS__); break;                   \
+            case 16 * 1000 + 32 * 10 + 2: FN<16, 32, 2>(__VA_ARGS__); break;                   \
+            case 16 * 1000 + 64 * 10 + 1: FN<16, 64, 1>(__VA_ARGS__); break;                   \
+            case 16 * 1000 + 64 * 10 + 2: FN<16, 64, 2>(__VA_ARGS__); break;                   \
+            case 32 * 1000 + 32 * 10 + 1: FN<32, 32, 1>(__VA_ARGS__); break;                   \
+            case 32 * 1000 + 32 * 10 + 2: FN<32, 32, 2>(__VA_ARGS__); break;                   \
+            case 32 * 1000 + 64 * 10 + 1: FN<32, 64, 1>(__VA_ARGS__); break;                   \
+            case 32 * 1000 + 64 * 10 + 2: FN<32, 64, 2>(__VA_ARGS__); break;                   \
+            default: break;                                                                    \
+        }                                                                                      \
+    } while (0)
+
+void launch_fused_train(hipStream_t s, const LevelTable& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump) {
+    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st };
+    const uint32_t grid = fused_train_grid(nd, oc.R);
+    MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);
+}
+void launch_fused_render(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask) {
+    FusedArgs a{ lt, nd, oc, b, params, nullptr, nullptr, nullptr };
+    MON_FUSED_DISPATCH(fused_render_t, s, a, n_rays, idx_base, rgb, depth, mask);
+}
 
 }  // namespace mon

@@ -1,63 +1,91 @@
 // kernels_optim.hip -- tcnn Trainer::optimizer_step for Ema{ ExponentialDecay{ Adam } }
 // (call site CORE/src/nerf_model.cu:1644,1681; hyper-parameters CORE/configs/base.json:5-22).
-// One fused pass over the flat parameter vector: gradient read + reset (replaces the Overwrite
-// memset of tcnn's backward), Adam on fp32 master weights, fp16 working copy, EMA shadow copy.
-// SURVEY TCNN-A6/A7/A8: grid entries with zero gradient are skipped by Adam (not by the EMA),
-// L2 regularisation only on the MLP matrices, per-parameter step counters, debiased EMA.
-// The last block to finish advances the device-resident step / iteration counters and applies
-// the exponential LR decay, so a whole training run needs no host synchronisation.
+// One fused, grid-stride, 8-parameters-per-thread pass over the flat parameter vector: gradient read +
+// reset (replaces the Overwrite memset of tcnn's backward), Adam on fp32 master weights, fp16 working
+// copy, EMA shadow copy.  SURVEY TCNN-A6/A7/A8: grid entries with zero gradient are skipped by Adam (not
+// by the EMA), L2 regularisation only on the MLP matrices, per-parameter step counters, debiased EMA.
+// Untouched grid chunks cost 64 B per 8 parameters (fp16 grad, weight, EMA read + EMA write).
+// The last block to finish advances the device-resident step / iteration counters and applies the
+// exponential LR decay, so a whole training run needs no host synchronisation.
 #include "device_common.h"
 #include "model.h"
 
 namespace mon {
 
+__device__ __forceinline__ float adam_update(float g, float w, float& m1, float& m2, uint32_t& steps, float lr0, const OptimConst& oc) {
+    const float gsq = g * g;
+    m1 = oc.beta1 * m1 + (1.f - oc.beta1) * g;
+    m2 = oc.beta2 * m2 + (1.f - oc.beta2) * gsq;
+    const uint32_t cs = ++steps;
+    const float lr = lr0 * sqrtf(1.f - powf(oc.beta2, (float)cs)) / (1.f - powf(oc.beta1, (float)cs));
+    const float eff = lr / (sqrtf(m2) + oc.epsilon);
+    return w - eff * m1;
+}
+
 __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, DevState* __restrict__ st) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_valid = st->n_valid, step = st->step;
     const float lr0 = st->lr;
-    __shared__ float s_deb[2];
-    if (threadIdx.x == 0) {     // EMA debias factors from the global step after increment (double pow once per block)
-        const uint32_t cur = step + 1u;
-        s_deb[0] = 1.f - (float)pow((double)oc.ema_decay, (double)(cur - 1u));
-        s_deb[1] = 1.f / (1.f - (float)pow((double)oc.ema_decay, (double)cur));
-    }
-    __syncthreads();
-    if (n_valid != 0u && i < oc.n_params) {
-        const bool is_matrix = i < oc.n_mlp;
-        float g;
-        if (is_matrix) { g = p.gmlp[i] / oc.loss_scale; p.gmlp[i] = 0.f; }
-        else {
-            half_t* gp = reinterpret_cast<half_t*>(p.ggrid) + (i - oc.n_mlp);
-            const half_t gh = *gp;
-            g = (float)gh / oc.loss_scale;
-            if ((float)gh != 0.f) *gp = (half_t)0.f;
+    // EMA debias factors from the global step after increment (ema_step_half_precision); wave-uniform scalars
+    const uint32_t cur = step + 1u;
+    const float d = oc.ema_decay;
+    const float deb_old = 1.f - (float)pow((double)d, (double)(cur - 1u));
+    const float deb_new = 1.f / (1.f - (float)pow((double)d, (double)cur));
+    if (n_valid != 0u) {
+        const uint32_t n_chunks = oc.n_params >> 3;
+        for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += gridDim.x * blockDim.x) {
+            const uint32_t i0 = c << 3;
+            const bool is_matrix = i0 < oc.n_mlp;                     // n_mlp is a multiple of 8: uniform per chunk
+            float g[8]; bool any = false;
+            if (is_matrix) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t i = i0 + j;
+                    const float gs = p.gmlp[i]; p.gmlp[i] = 0.f;
+                    g[j] = gs / oc.loss_scale;
+                }
+                any = true;
+            } else {
+                half8_t* gp = reinterpret_cast<half8_t*>(p.ggrid + (i0 - oc.n_mlp));
+                const half8_t gh = *gp;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { g[j] = (float)gh[j] / oc.loss_scale; any |= (float)gh[j] != 0.f; }
+                if (any) { half8_t z;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) z[j] = (half_t)0.f;
+                    *gp = z; }
+            }
+            half8_t wh = *reinterpret_cast<const half8_t*>(p.half + i0);
+            if (any) {
+                float4_t w0 = *reinterpret_cast<const float4_t*>(p.master + i0), w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
+                float4_t a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0), a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
+                float4_t b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0), b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
+                uint4 s0 = *reinterpret_cast<const uint4*>(p.steps + i0), s1 = *reinterpret_cast<const uint4*>(p.steps + i0 + 4);
+                float w[8] = { w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3] };
+                float m1[8] = { a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3] };
+                float m2[8] = { b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3] };
+                uint32_t sc[8] = { s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w };
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float gj = g[j];
+                    if (is_matrix) gj += oc.l2_reg * w[j];                            // L2 only on matrix weights
+                    else if (gj == 0.f) continue;                                     // untouched grid entry: skipped entirely
+                    w[j] = adam_update(gj, w[j], m1[j], m2[j], sc[j], lr0, oc);
+                    wh[j] = (half_t)w[j];
+                }
+                *reinterpret_cast<float4_t*>(p.master + i0) = float4_t{ w[0], w[1], w[2], w[3] }; *reinterpret_cast<float4_t*>(p.master + i0 + 4) = float4_t{ w[4], w[5], w[6], w[7] };
+                *reinterpret_cast<float4_t*>(p.m1 + i0) = float4_t{ m1[0], m1[1], m1[2], m1[3] }; *reinterpret_cast<float4_t*>(p.m1 + i0 + 4) = float4_t{ m1[4], m1[5], m1[6], m1[7] };
+                *reinterpret_cast<float4_t*>(p.m2 + i0) = float4_t{ m2[0], m2[1], m2[2], m2[3] }; *reinterpret_cast<float4_t*>(p.m2 + i0 + 4) = float4_t{ m2[4], m2[5], m2[6], m2[7] };
+                *reinterpret_cast<uint4*>(p.steps + i0) = make_uint4(sc[0], sc[1], sc[2], sc[3]); *reinterpret_cast<uint4*>(p.steps + i0 + 4) = make_uint4(sc[4], sc[5], sc[6], sc[7]);
+                *reinterpret_cast<half8_t*>(p.half + i0) = wh;
+            }
+            half8_t* ep = reinterpret_cast<half8_t*>(p.ema + i0);
+            half8_t e = *ep;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = (half_t)((((float)e[j] * d) * deb_old + (float)wh[j] * (1.f - d)) * deb_new);
+            *ep = e;
         }
-        float w_half;
-        if (is_matrix || g != 0.f) {
-            const float w = p.master[i];
-            if (is_matrix) g += oc.l2_reg * w;
-            const float gsq = g * g;
-            const float fm = oc.beta1 * p.m1[i] + (1.f - oc.beta1) * g;
-            const float sm = oc.beta2 * p.m2[i] + (1.f - oc.beta2) * gsq;
-            p.m1[i] = fm; p.m2[i] = sm;
-            const uint32_t cs = p.steps[i] + 1u; p.steps[i] = cs;
-            const float lr = lr0 * sqrtf(1.f - powf(oc.beta2, (float)cs)) / (1.f - powf(oc.beta1, (float)cs));
-            const float eff = lr / (sqrtf(sm) + oc.epsilon);
-            const float nw = w - eff * fm;
-            p.master[i] = nw;
-            const half_t nh = (half_t)nw;
-            reinterpret_cast<half_t*>(p.half)[i] = nh;
-            w_half = (float)nh;
-        } else {
-            w_half = (float)reinterpret_cast<const half_t*>(p.half)[i];
-        }
-        // EMA (ema_step_half_precision)
-        const float d = oc.ema_decay;
-        const float deb_old = s_deb[0], deb_new = s_deb[1];
-        half_t* ep = reinterpret_cast<half_t*>(p.ema) + i;
-        *ep = (half_t)((((float)*ep * d) * deb_old + w_half * (1.f - d)) * deb_new);
     }
-    // ---- last block advances the counters
+    // ---- last block advances the counters (one ticket per block; the grid is capped at 512 blocks)
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
@@ -66,7 +94,6 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
             st->ticket = 0u;
             st->iter = st->iter + 1u;
             if (n_valid != 0u) {
-                const uint32_t cur = step + 1u;
                 st->step = cur;
                 if ((int)cur >= oc.decay_start && oc.decay_interval > 0 && ((int)cur - oc.decay_start) % oc.decay_interval == 0) st->lr = lr0 * oc.decay_base;
             } else {
@@ -77,8 +104,33 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
     }
 }
 
+// Fused backend: sums the per-workgroup fp32 weight-gradient partials (and loss partials) written by
+// k_fused_train into gmlp / DevState::loss_sum.  16 parameters x 16 partial subsets per block.
+__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ partials, uint32_t n_partials, uint32_t stride, uint32_t n_mlp,
+                                                         float* __restrict__ gmlp, DevState* __restrict__ st) {
+    if (st->n_valid == 0u) return;
+    __shared__ float red[256];
+    const uint32_t pi = blockIdx.x * 16u + (threadIdx.x & 15u), sub = threadIdx.x >> 4;
+    float s0 = 0.f, s1 = 0.f;
+    if (pi <= n_mlp) {                      // slot n_mlp of each row is the loss partial
+        uint32_t k = sub;
+        for (; k + 16u < n_partials; k += 32u) { s0 += partials[(size_t)k * stride + pi]; s1 += partials[(size_t)(k + 16u) * stride + pi]; }
+        if (k < n_partials) s0 += partials[(size_t)k * stride + pi];
+    }
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    for (int off = 128; off >= 16; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x < 16u) { if (pi < n_mlp) gmlp[pi] = red[threadIdx.x]; else if (pi == n_mlp) st->loss_sum = red[threadIdx.x]; }
+}
+
+void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_partials, uint32_t stride, uint32_t n_mlp, float* gmlp, DevState* st) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3((n_mlp + 1 + 15) / 16), dim3(256), 0, s, partials, n_partials, stride, n_mlp, gmlp, st);
+}
+
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st) {
-    hipLaunchKernelGGL(k_optimizer, dim3((oc.n_params + 255) / 256), dim3(256), 0, s, p, oc, st);
+    const uint32_t chunks = oc.n_params >> 3;
+    uint32_t blocks = (chunks + 255) / 256; if (blocks > 512u) blocks = 512u; if (blocks < 1u) blocks = 1u;
+    hipLaunchKernelGGL(k_optimizer, dim3(blocks), dim3(256), 0, s, p, oc, st);
 }
 
 }  // namespace mon

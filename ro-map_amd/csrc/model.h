@@ -94,9 +94,11 @@ void launch_extract_density(hipStream_t s, const uint16_t* O, float* out, uint32
 
 // optimizer (kernels_optim.hip)
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st);
+void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_partials, uint32_t stride, uint32_t n_mlp, float* gmlp, DevState* st);
 
 // fused MFMA path (kernels_fused.hip)
 bool fused_supported(const NetDims& nd, uint32_t S);
+uint32_t fused_train_grid(const NetDims& nd, uint32_t R);
 void launch_fused_train(hipStream_t s, const LevelTable& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump);
 void launch_fused_render(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask);
 int selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
@@ -118,7 +120,7 @@ struct Model {
     uint32_t boxes_cap = 0, n_boxes = 0; uint32_t ws_samples = 0, ws_rays = 0;
     float* d_dw_partials = nullptr; float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr;
     std::vector<void*> allocs;
-    DevState h_state{}; int backend = 0; bool profiling = false;
+    DevState h_state{}; int backend = 0; bool profiling = false; int fused_dump = 0;
     mon_profile prof{}; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pending;
     hipGraphExec_t graph_exec = nullptr; int graph_backend = -1;
 };

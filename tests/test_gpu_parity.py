@@ -24,6 +24,8 @@ def _pair(pkg, orc, sc, kw, backend, use_depth=False):
         obj.set_backend(backend)
     except pkg.MonError:
         obj.close(); ds.close(); pytest.skip("fused backend not available for this shape")
+    if backend == 1:
+        obj.set_debug_dump(True)          # also write E / h / O / dO / dE of the fused kernel for comparison
     ref = ge.make_oracle(orc, sc, kw, use_depth=use_depth)
     return ds, obj, ref
 
@@ -66,7 +68,7 @@ def test_forward_backward_matches_oracle_and_golden(pkg, orc, ss, name, backend)
     obj.train_stages(1 | 2); ref.generate_batch(); ref.forward_backward()
     assert int(obj.buffer("state")[2]) == ref.n_valid == int(g["n_valid"])
     B, Ep = ref.R * ref.S, ref.Epad
-    if backend == 0:                      # intermediate activations exist only in the unfused path
+    if True:                              # backend 1 dumps its on-chip intermediates in debug mode
         assert np.array_equal(obj.buffer("E"), ref.buffer("E")), "hash-grid encode must be bit-exact"
         assert np.array_equal(obj.buffer("E")[:g["E"].size], g["E"])
         ex = close_half(obj.buffer("Hid"), ref.buffer("Hid"), "hidden activations")
