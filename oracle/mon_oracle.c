@@ -446,6 +446,9 @@ float orc_gradient(const uint16_t* out4, const float* t, int S, int nRays, float
     return gradient_ray(out4, t, S, nRays, loss_scale, is_obj, target, target_depth, rgb_ray, depth_ray, mask_ray, dO);
 }
 
+static int g_parallel_scatter = 0;
+void orc_set_parallel_scatter(int on) { g_parallel_scatter = on; }
+
 /* ------------------------------------------------------------------ Step_No_Compacted nerf_model.cu:1552-1607 */
 static void forward_backward(orc_model* m) {
     const int R = m->R, S = m->S, W = m->W, NH = m->NH, Ep = m->Epad; const size_t B = (size_t)R * S;
@@ -519,6 +522,25 @@ static void forward_backward(orc_model* m) {
     /* grid backward (tcnn kernel_grid_backward): contribution = h(w * dE) per corner; serial for determinism */
     memset(m->ggrid, 0, (size_t)m->n_grid * 4); memset(m->ggrid_abs, 0, (size_t)m->n_grid * 4);
     if (m->cfg.grid_grad_half_accum) memset(m->ggrid_h, 0, (size_t)m->n_grid * 2);
+    if (g_parallel_scatter && !m->cfg.grid_grad_half_accum) {
+        /* CPU-baseline mode (bench.py): same contributions, accumulated with fp32 atomics in thread order */
+        #pragma omp parallel for schedule(static)
+        for (long s = 0; s < (long)B; ++s) {
+            const uint16_t* dE = m->dE + (size_t)s * Ep;
+            for (int l = 0; l < m->L; ++l) {
+                float g0 = h2f(dE[2 * l]), g1 = h2f(dE[2 * l + 1]);
+                if (g0 == 0.0f && g1 == 0.0f) continue;
+                corners c; level_corners(m, l, m->pts + 3 * s, &c);
+                for (int k = 0; k < 8; ++k) {
+                    float c0 = h2f(f2h(c.w[k] * g0)), c1 = h2f(f2h(c.w[k] * g1)); size_t e = 2 * (size_t)c.idx[k];
+                    #pragma omp atomic
+                    m->ggrid[e] += c0;
+                    #pragma omp atomic
+                    m->ggrid[e + 1] += c1;
+                }
+            }
+        }
+    } else
     for (size_t s = 0; s < B; ++s) {
         const uint16_t* dE = m->dE + s * Ep;
         for (int l = 0; l < m->L; ++l) {

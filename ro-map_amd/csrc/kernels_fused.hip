@@ -68,10 +68,10 @@ __device__ __forceinline__ int unit_of_slot(int s, int h, int j) { return 32 * (
 
 struct LevelLds { uint32_t offset[kMaxLevels + 1]; uint32_t res[kMaxLevels]; float scale[kMaxLevels]; };
 
-// Corner walk of one level for one position: calls f(k, table_index, weight) for the 8 corners.
+// Corner walk of one level for one position: calls f(k, index_within_level, weight) for the 8 corners.
 template <class F>
 __device__ __forceinline__ void level_corners(const LevelLds& lt, int level, const float x[3], F&& f) {
-    const float scale = lt.scale[level]; const uint32_t res = lt.res[level], off = lt.offset[level], size = lt.offset[level + 1] - off;
+    const float scale = lt.scale[level]; const uint32_t res = lt.res[level], size = lt.offset[level + 1] - lt.offset[level];
     float pos[3]; uint32_t pg[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) { const float p = fmaf(scale, x[d], 0.5f), fl = floorf(p); pg[d] = (uint32_t)(int32_t)fl; pos[d] = p - fl; }
@@ -85,7 +85,7 @@ __device__ __forceinline__ void level_corners(const LevelLds& lt, int level, con
         for (int d = 0; d < 3; ++d) { if (k & (1 << d)) { w *= pos[d]; q[d] = pg[d] + 1u; } else { w *= 1.f - pos[d]; q[d] = pg[d]; } }
         uint32_t idx = hashed ? (q[0] ^ (q[1] * 2654435761u) ^ (q[2] * 805459861u)) : (q[0] + q[1] * res + q[2] * r2);
         idx = pow2 ? (idx & (size - 1u)) : (idx % size);
-        f(k, off + idx, w);
+        f(k, idx, w);
     }
 }
 
@@ -125,6 +125,9 @@ struct FusedArgs {
     uint16_t* ggrid;            // fp16 grid gradient table
     float* partials;            // [gridDim.x][N_MLP + 64] fp32: dW partial sums, slot N_MLP = loss partial
     const DevState* st;
+    half2_t* de_soa;            // [L][B] dL/dE of the levels scattered through LDS (k_grid_scatter), or nullptr
+    float* x_soa;               // [3][B] warped sample positions for k_grid_scatter
+    uint32_t lds_level_mask;    // bit l set: level l goes through k_grid_scatter instead of global atomics
 };
 
 // Builds the A fragments (weights pre-permuted to K-slot order) and the level table in LDS.
@@ -202,7 +205,8 @@ __device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const h
         const int level = h * LPH + il;
         float a0 = 0.f, a1 = 0.f;
         if (il < LPH && level < L) {
-            level_corners(llt, level, x, [&](int, uint32_t idx, float wgt) { const half2_t v = table[idx]; a0 = fmaf(wgt, (float)v.x, a0); a1 = fmaf(wgt, (float)v.y, a1); });
+            const half2_t* tl = table + llt.offset[level];
+            level_corners(llt, level, x, [&](int, uint32_t idx, float wgt) { const half2_t v = tl[idx]; a0 = fmaf(wgt, (float)v.x, a0); a1 = fmaf(wgt, (float)v.y, a1); });
         }
         ts.ef[2 * il] = (half_t)a0; ts.ef[2 * il + 1] = (half_t)a1;
     }
@@ -254,8 +258,8 @@ __device__ __forceinline__ float scan_add32(float v, int n) {
 }
 
 // ------------------------------------------------------------------ fused training kernel
-template <int EPAD, int W, int NH, bool DUMP>
-__global__ void __launch_bounds__(256) k_fused_train(FusedArgs a) {
+template <int EPAD, int W, int NH, bool DUMP, bool ATOMIC_LEVELS>
+__global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_train(FusedArgs a) {
     using S = FusedShape<EPAD, W, NH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (a.st->n_valid == 0u) return;                                   // batch skipped (uniform)
@@ -467,16 +471,26 @@ __global__ void __launch_bounds__(256) k_fused_train(FusedArgs a) {
                     if constexpr (NH == 2) { dHo[32 * mb + rho(h, j)] = dh0[mb][0][j]; dHo[32 * mb + rho(h, 8 + j)] = dh0[mb][1][j]; }
                 }
         }
-        // ---- grid backward (tcnn kernel_grid_backward): 8 packed-f16 atomics per owned level
+        // ---- grid backward (tcnn kernel_grid_backward).  Levels small enough for an LDS tile hand dL/dE to
+        //      k_grid_scatter (global packed-f16 atomics sustain only ~21 Gop/s on gfx950, ~12x below the gather
+        //      rate: profiles/); larger levels scatter here with 8 global_atomic_pk_add_f16 per level.
+        const uint32_t Btot = R * 32u;
+        if (a.lds_level_mask && h == 0) { a.x_soa[s_idx] = x[0]; a.x_soa[Btot + s_idx] = x[1]; a.x_soa[2u * Btot + s_idx] = x[2]; }
 #pragma unroll
         for (int il = 0; il < S::LLV; ++il) {
             const int level = h * LPH + il;
             if (il < LPH && level < L) {
-                const float gq0 = (float)(half_t)de[2 * il], gq1 = (float)(half_t)de[2 * il + 1];
-                if (gq0 != 0.f || gq1 != 0.f) {
-                    level_corners(*llt, level, x, [&](int, uint32_t idx, float wgt2) {
-                        __builtin_amdgcn_global_atomic_fadd_v2f16(gtable + idx, half2_t{ (half_t)(wgt2 * gq0), (half_t)(wgt2 * gq1) });
-                    });
+                const half_t q0 = (half_t)de[2 * il], q1 = (half_t)de[2 * il + 1];
+                if (!ATOMIC_LEVELS || ((a.lds_level_mask >> level) & 1u)) {
+                    a.de_soa[(size_t)level * Btot + s_idx] = half2_t{ q0, q1 };
+                } else if constexpr (ATOMIC_LEVELS) {
+                    const float gq0 = (float)q0, gq1 = (float)q1;
+                    if (gq0 != 0.f || gq1 != 0.f) {
+                        gh2* gl = gtable + llt->offset[level];
+                        level_corners(*llt, level, x, [&](int, uint32_t idx, float wgt2) {
+                            __builtin_amdgcn_global_atomic_fadd_v2f16(gl + idx, half2_t{ (half_t)(wgt2 * gq0), (half_t)(wgt2 * gq1) });
+                        });
+                    }
                 }
             }
         }
@@ -508,6 +522,77 @@ __global__ void __launch_bounds__(256) k_fused_train(FusedArgs a) {
     }
     float* dst = a.partials + (size_t)blockIdx.x * (S::N_MLP + 64);
     for (int i = threadIdx.x; i < S::N_MLP + 1; i += blockDim.x) dst[i] = red[i];
+}
+
+// ------------------------------------------------------------------ LDS grid scatter
+// One workgroup = (level, 32768-entry part of that level, sample partition).  The part's gradient tile lives in
+// LDS as half2 (128 KB); contributions h(w * dE) are accumulated with ds_pk_add_f16 (same arithmetic as tcnn's
+// atomicAdd(__half2), but at LDS rate), then the tile is written densely to partial table `p`.  The optimizer
+// sums the P partial tables.  No global atomics, no memset: every tile is fully rewritten each step.
+struct ScatterUnits { uint8_t level[32]; uint8_t part[32]; uint32_t n_units; uint32_t P; };
+constexpr uint32_t kScatterTile = 32768;
+
+__global__ void __launch_bounds__(1024) k_grid_scatter(LevelTable lt, ScatterUnits su, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa,
+                                                       uint32_t B, half2_t* __restrict__ gpart, uint32_t part_stride, const DevState* __restrict__ st) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (st->n_valid == 0u) return;
+    half2_t* tab = reinterpret_cast<half2_t*>(smem);
+    const uint32_t unit = blockIdx.x / su.P, p = blockIdx.x - unit * su.P;
+    const int level = su.level[unit]; const uint32_t part = su.part[unit];
+    const uint32_t off = lt.offset[level], size = lt.offset[level + 1] - off, res = lt.res[level];
+    const float scale = lt.scale[level];
+    const uint32_t base = part * kScatterTile, tile = min(kScatterTile, size - base);
+    for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) tab[i] = half2_t{ (half_t)0.f, (half_t)0.f };
+    __syncthreads();
+    typedef __attribute__((address_space(3))) half2_t lh2;
+    const bool pow2 = (size & (size - 1u)) == 0u;
+    const bool s1 = res <= size; const uint32_t r2 = res * res; const bool s2 = s1 && r2 <= size; const bool hashed = !(s2) || (uint64_t)r2 * res > size;
+    const uint32_t per = (B + su.P - 1) / su.P, s_begin = p * per, s_end = min(B, s_begin + per);
+    const half2_t* de = de_soa + (size_t)level * B;
+    for (uint32_t s = s_begin + threadIdx.x; s < s_end; s += blockDim.x) {
+        const half2_t g = de[s];
+        const float g0 = (float)g.x, g1 = (float)g.y;
+        if (g0 == 0.f && g1 == 0.f) continue;
+        float pos[3]; uint32_t pg[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, x_soa[(size_t)d * B + s], 0.5f), fl = floorf(q); pg[d] = (uint32_t)(int32_t)fl; pos[d] = q - fl; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float w = 1.f; uint32_t q[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { if (k & (1 << d)) { w *= pos[d]; q[d] = pg[d] + 1u; } else { w *= 1.f - pos[d]; q[d] = pg[d]; } }
+            uint32_t idx = hashed ? (q[0] ^ (q[1] * 2654435761u) ^ (q[2] * 805459861u)) : (q[0] + q[1] * res + q[2] * r2);
+            idx = pow2 ? (idx & (size - 1u)) : (idx % size);
+            const uint32_t local = idx - base;
+            if (local < tile) __builtin_amdgcn_ds_atomic_fadd_v2f16((lh2*)(tab + local), half2_t{ (half_t)(w * g0), (half_t)(w * g1) });
+        }
+    }
+    __syncthreads();
+    half2_t* dst = gpart + (size_t)p * part_stride + off + base;
+    for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) dst[i] = tab[i];
+}
+
+// Host: which levels go through the LDS scatter, and the (level, part) unit list.
+uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterUnits& su) {
+    uint32_t mask = 0; su.n_units = 0;
+    for (int l = 0; l < nd.L; ++l) {
+        const uint32_t size = lt.offset[l + 1] - lt.offset[l];
+        const uint32_t parts = (size + kScatterTile - 1) / kScatterTile;
+        if (parts <= 2 && su.n_units + parts <= 32) { mask |= 1u << l; for (uint32_t q = 0; q < parts; ++q) { su.level[su.n_units] = (uint8_t)l; su.part[su.n_units] = (uint8_t)q; ++su.n_units; } }
+    }
+    su.P = 1;
+    if (su.n_units) { uint32_t P = 256u / su.n_units; if (P < 1u) P = 1u; if (P > 16u) P = 16u; su.P = P; }
+    return mask;
+}
+uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd) { ScatterUnits su; return scatter_plan(lt, nd, su); }
+uint32_t scatter_partitions(const LevelTable& lt, const NetDims& nd) { ScatterUnits su; return scatter_plan(lt, nd, su) ? su.P : 0u; }
+
+void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, const DevState* st) {
+    ScatterUnits su; if (!scatter_plan(lt, nd, su)) return;
+    static bool attr_done = false;
+    if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, kScatterTile * 4); attr_done = true; }
+    hipLaunchKernelGGL(k_grid_scatter, dim3(su.n_units * su.P), dim3(1024), kScatterTile * 4, s, lt, su, reinterpret_cast<const half2_t*>(de_soa), x_soa, B,
+                       reinterpret_cast<half2_t*>(gpart), part_stride_entries, st);
 }
 
 // ------------------------------------------------------------------ fused render kernel
@@ -573,12 +658,15 @@ static void fused_train_t(hipStream_t s, const FusedArgs& a, uint32_t grid, int 
     using S = FusedShape<EPAD, W, NH>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         attr_done = true;
     }
-    if (dump) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
-    else hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
+    const bool all_lds = a.lds_level_mask != 0u && (a.lds_level_mask == ((a.nd.L >= 32) ? 0xffffffffu : ((1u << a.nd.L) - 1u)));
+    if (dump) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
+    else if (all_lds) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
+    else hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
 }
 template <int EPAD, int W, int NH>
 static void fused_render_t(hipStream_t s, const FusedArgs& a, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask) {
@@ -604,13 +692,14 @@ static void fused_render_t(hipStream_t s, const FusedArgs& a, uint32_t n_rays, u
         }                                                                                      \
     } while (0)
 
-void launch_fused_train(hipStream_t s, const LevelTable& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump) {
-    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st };
+void launch_fused_train(hipStream_t s, const LevelTable& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
+                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask) {
+    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask };
     const uint32_t grid = fused_train_grid(nd, oc.R);
     MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);
 }
 void launch_fused_render(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask) {
-    FusedArgs a{ lt, nd, oc, b, params, nullptr, nullptr, nullptr };
+    FusedArgs a{ lt, nd, oc, b, params, nullptr, nullptr, nullptr, nullptr, nullptr, 0u };
     MON_FUSED_DISPATCH(fused_render_t, s, a, n_rays, idx_base, rgb, depth, mask);
 }
 

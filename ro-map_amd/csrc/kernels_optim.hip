@@ -47,12 +47,20 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
             } else {
                 half8_t* gp = reinterpret_cast<half8_t*>(p.ggrid + (i0 - oc.n_mlp));
                 const half8_t gh = *gp;
+                bool anyg = false;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { g[j] = (float)gh[j] / oc.loss_scale; any |= (float)gh[j] != 0.f; }
-                if (any) { half8_t z;
+                for (int j = 0; j < 8; ++j) { g[j] = (float)gh[j]; anyg |= (float)gh[j] != 0.f; }
+                if (anyg) { half8_t z;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) z[j] = (half_t)0.f;
                     *gp = z; }
+                for (uint32_t q = 0; q < p.n_part; ++q) {            // dense partial tables of k_grid_scatter (fused backend)
+                    const half8_t ph = *reinterpret_cast<const half8_t*>(p.gpart + (size_t)q * p.part_stride + (i0 - oc.n_mlp));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] += (float)ph[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { any |= g[j] != 0.f; g[j] = g[j] / oc.loss_scale; }
             }
             half8_t wh = *reinterpret_cast<const half8_t*>(p.half + i0);
             if (any) {

@@ -132,6 +132,12 @@ int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* 
         (rc = dev_alloc(m, B.rgb_ray, 3 * (size_t)R)) || (rc = dev_alloc(m, B.depth_ray, R)) || (rc = dev_alloc(m, B.mask_ray, R)) || (rc = dev_alloc(m, B.loss_ray, R)) ||
         (rc = dev_alloc(m, m.d_state, 1)) || (rc = dev_alloc(m, m.d_dw_partials, (size_t)(m.nd.n_mlp + 64) * 512)) ||
         (rc = dev_alloc(m, m.d_out_rgb, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_depth, kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_mask, kRenderChunkRays))) return rc;
+    if (fused_supported(m.nd, S)) {
+        m.lds_mask = scatter_level_mask(m.lt, m.nd); m.scatter_P = scatter_partitions(m.lt, m.nd);
+        if (const char* e = std::getenv("MON_LDS_SCATTER")) if (!std::atoi(e)) { m.lds_mask = 0; m.scatter_P = 0; }
+        if (m.lds_mask && ((rc = dev_alloc(m, m.d_de_soa, (size_t)m.nd.L * Btrain * 2)) || (rc = dev_alloc(m, m.d_x_soa, 3 * (size_t)Btrain)) ||
+                           (rc = dev_alloc(m, m.d_gpart, (size_t)m.scatter_P * m.n_grid)))) return rc;
+    }
     m.boxes_cap = 1024;
     if ((rc = dev_alloc(m, m.d_boxes, m.boxes_cap))) return rc;
     B.boxes = m.d_boxes;
@@ -218,13 +224,16 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_weight_grads(s, m.nd, m.B.E, m.B.Hid, m.B.dHid, m.B.dO, m.P.gmlp, B, m.d_state);
             launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
         } else {
-            launch_fused_train(s, m.lt, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump);
+            launch_fused_train(s, m.lt, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask);
+            if (m.lds_mask) launch_grid_scatter(s, m.lt, m.nd, m.d_de_soa, m.d_x_soa, B, m.d_gpart, m.n_grid / 2, m.d_state);
             launch_reduce_partials(s, m.d_dw_partials, fused_train_grid(m.nd, m.oc.R), m.nd.n_mlp + 64, m.nd.n_mlp, m.P.gmlp, m.d_state);
         }
     }
     if (stages & 4) {      // Trainer::optimizer_step :1644
         ProfScope ps(m, MON_K_OPTIM);
-        launch_optimizer(s, m.P, m.opt, m.d_state);
+        ParamPtrs P = m.P;
+        if (m.backend == 1 && m.lds_mask) { P.gpart = m.d_gpart; P.n_part = m.scatter_P; P.part_stride = m.n_grid; }
+        launch_optimizer(s, P, m.opt, m.d_state);
     }
 }
 
@@ -360,7 +369,18 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
     }
     if (!dst || bytes < sz) { set_error("debug_read: buffer too small (%zu < %zu)", bytes, sz); return MON_ERR_ARG; }
     HIPCHECK(hipSetDevice(m.device)); HIPCHECK(hipStreamSynchronize(m.train_stream));
-    HIPCHECK(hipMemcpy(dst, src, sz, hipMemcpyDeviceToHost)); return MON_OK;
+    HIPCHECK(hipMemcpy(dst, src, sz, hipMemcpyDeviceToHost));
+    if (which == MON_BUF_GGRID_H && m.backend == 1 && m.lds_mask) {        // total gradient = atomic table + sum of the scatter partials
+        std::vector<uint16_t> part(m.n_grid); std::vector<float> acc(m.n_grid);
+        uint16_t* out = reinterpret_cast<uint16_t*>(dst);
+        for (uint32_t i = 0; i < m.n_grid; ++i) { _Float16 h; std::memcpy(&h, &out[i], 2); acc[i] = (float)h; }
+        for (uint32_t q = 0; q < m.scatter_P; ++q) {
+            HIPCHECK(hipMemcpy(part.data(), m.d_gpart + (size_t)q * m.n_grid, (size_t)m.n_grid * 2, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < m.n_grid; ++i) { _Float16 h; std::memcpy(&h, &part[i], 2); acc[i] += (float)h; }
+        }
+        for (uint32_t i = 0; i < m.n_grid; ++i) { const _Float16 h = (_Float16)acc[i]; std::memcpy(&out[i], &h, 2); }
+    }
+    return MON_OK;
 }
 
 }  // namespace mon
