@@ -111,7 +111,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         orc = ge.load_oracle()
-        orc.lib().orc_set_parallel_scatter(1)       # use every host core for the scatter too (fp32 atomics)
+        orc.lib().orc_set_parallel_scatter(1)       # parallel scatter too (fp32 atomics)
+        orc.lib().orc_set_threads(int(os.environ.get("MON_CPU_BASELINE_THREADS", min(64, os.cpu_count() or 1))))
         ref = ge.make_oracle(orc, sc, {})
         ref.train(1)
         t1 = time.perf_counter(); n = 0

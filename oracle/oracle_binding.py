@@ -79,6 +79,9 @@ def lib():
         L.orc_f2h.restype = C.c_uint16; L.orc_f2h.argtypes = [C.c_float]
         L.orc_h2f.restype = C.c_float; L.orc_h2f.argtypes = [C.c_uint16]
         L.orc_set_threads.argtypes = [C.c_int]; L.orc_max_threads.restype = C.c_int
+        L.orc_set_parallel_scatter.argtypes = [C.c_int]; L.orc_advance_iter.argtypes = [C.c_void_p]
+        # the checker's loops are small: a modest team beats one thread per hardware thread on a 256-thread host
+        L.orc_set_threads(int(os.environ.get("MON_ORACLE_THREADS", min(16, os.cpu_count() or 1))))
         _lib = L
     return _lib
 

@@ -24,6 +24,7 @@
 //   * weight gradients need samples on K: activations are transposed through a per-wave LDS scratch
 //     ([unit][sample] fp16) and accumulated in MFMA accumulators across the wave's rays, then reduced
 //     across the workgroup in LDS and written as one fp32 partial per workgroup (summed by the optimizer).
+#include <cstdlib>
 #include "device_common.h"
 #include "model.h"
 
@@ -581,7 +582,12 @@ uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterUnits& su)
         if (parts <= 2 && su.n_units + parts <= 32) { mask |= 1u << l; for (uint32_t q = 0; q < parts; ++q) { su.level[su.n_units] = (uint8_t)l; su.part[su.n_units] = (uint8_t)q; ++su.n_units; } }
     }
     su.P = 1;
-    if (su.n_units) { uint32_t P = 256u / su.n_units; if (P < 1u) P = 1u; if (P > 16u) P = 16u; su.P = P; }
+    if (su.n_units) {
+        uint32_t P = 256u / su.n_units; if (P < 1u) P = 1u; if (P > 16u) P = 16u;
+        static const int envP = std::getenv("MON_SCATTER_P") ? std::atoi(std::getenv("MON_SCATTER_P")) : 0;
+        if (envP >= 1 && envP <= 16) P = (uint32_t)envP;
+        su.P = P;
+    }
     return mask;
 }
 uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd) { ScatterUnits su; return scatter_plan(lt, nd, su); }

@@ -33,6 +33,30 @@ __global__ void __launch_bounds__(256) k_ub(int mode, int pattern, uint32_t n_en
     if (acc == 123.456f) sink[0] = acc;
 }
 
+// LDS atomics on a 128 KB tile, 1024 threads per workgroup, one workgroup per CU.
+// mode 10: ds_pk_add_f16 random   11: ds_add_f32 random   12: ds_add_u32 random
+// mode 13: ds_pk_add_f16, lane pairs share an address   14: ds_write_b32 random (no atomic)   15: ds_pk_add_f16, 4 lanes share
+__global__ void __launch_bounds__(1024) k_ub_lds(int mode, uint32_t ops_per_thread, float* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
+    for (uint32_t i = threadIdx.x; i < 32768u; i += blockDim.x) tab[i] = 0u;
+    __syncthreads();
+    typedef __attribute__((address_space(3))) half2_t lh2;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t i = 0; i < ops_per_thread; ++i) {
+        uint32_t key = gid;
+        if (mode == 13) key = gid >> 1; else if (mode == 15) key = gid >> 2;
+        const uint32_t idx = mix32(key * 0x9E3779B9u + i * 0x85EBCA6Bu + 777u) & 32767u;
+        const half2_t v = { (half_t)1e-3f, (half_t)-1e-3f };
+        if (mode == 10 || mode == 13 || mode == 15) __builtin_amdgcn_ds_atomic_fadd_v2f16((lh2*)reinterpret_cast<half2_t*>(tab) + idx, v);
+        else if (mode == 11) atomicAdd(reinterpret_cast<float*>(tab) + idx, 1e-3f);
+        else if (mode == 12) atomicAdd(tab + idx, 1u);
+        else tab[idx] = i;
+    }
+    __syncthreads();
+    if (tab[threadIdx.x] == 0x12345678u) sink[0] = 1.f;
+}
+
 int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms_out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || hipSetDevice(device) != hipSuccess) { set_error("microbench: no HIP device"); return MON_ERR_NO_DEVICE; }
@@ -43,9 +67,11 @@ int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n
     const uint32_t ops_per_thread = 64, threads = n_ops / ops_per_thread, blocks = (threads + 255) / 256;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
+    if (mode >= 10) hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ub_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k_ub, dim3(blocks), dim3(256), 0, 0, mode, pattern, n_entries, ops_per_thread, table, sink);
+        if (mode >= 10) hipLaunchKernelGGL(k_ub_lds, dim3(256), dim3(1024), 131072, 0, mode, n_ops / (256u * 1024u), sink);
+        else hipLaunchKernelGGL(k_ub, dim3(blocks), dim3(256), 0, 0, mode, pattern, n_entries, ops_per_thread, table, sink);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms = 0.f; hipEventElapsedTime(&ms, e0, e1); if (rep > 0 && ms < best) best = ms;
     }

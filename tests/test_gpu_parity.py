@@ -78,7 +78,8 @@ def test_forward_backward_matches_oracle_and_golden(pkg, orc, ss, name, backend)
         close_half(obj.buffer("O")[:g["O"].size], g["O"], "network output vs golden", frac_ok=fr)
         close_half(obj.buffer("dO"), ref.buffer("dO"), "dL/dO", ulps=4, frac_ok=0.999)
         close_half(obj.buffer("dHid"), ref.buffer("dHid"), "dL/dh", ulps=4, frac_ok=0.999)
-        close_half(obj.buffer("dE"), ref.buffer("dE"), "dL/dE", ulps=4, frac_ok=0.999)
+        nf = 2 * ref.cfg.n_levels                  # compare the real features; dL/dE of the zero-padded inputs is never used
+        close_half(obj.buffer("dE").reshape(B, Ep)[:, :nf], ref.buffer("dE").reshape(B, Ep)[:, :nf], "dL/dE", ulps=4, frac_ok=0.999)
         assert ex > 0.9
     close_f32(obj.buffer("rgb_ray"), ref.buffer("rgb_ray"), "rgb_ray", 2e-3)
     close_f32(obj.buffer("rgb_ray")[:g["rgb_ray"].size], g["rgb_ray"], "rgb_ray vs golden", 2e-3)

@@ -14,3 +14,8 @@ for n in (4096, 65536, 1 << 20, 1 << 24):
     for mode in (3, 0, 1):
         ms = pkg.microbench(mode, 0, n, OPS)
         print("uniform over %9d entries  mode %d  %-40s %8.3f ms  %7.1f Gop/s" % (n, mode, names[mode], ms, OPS / ms / 1e6), flush=True)
+
+lds = {10: "ds_pk_add_f16 random", 11: "ds_add_f32 random", 12: "ds_add_u32 random", 13: "ds_pk_add_f16 lane pairs share", 15: "ds_pk_add_f16 4 lanes share", 14: "ds_write_b32 random"}
+for mode, nm in lds.items():
+    ms = pkg.microbench(mode, 0, N, OPS)
+    print("LDS 128KB tile x 256 WGs  mode %d  %-34s %8.3f ms  %8.1f Gop/s (chip)  %6.2f op/clk/CU @2.1GHz" % (mode, nm, ms, OPS / ms / 1e6, OPS / ms / 1e6 / 256 / 2.1), flush=True)
