@@ -526,29 +526,38 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
 }
 
 // ------------------------------------------------------------------ LDS grid scatter
-// One workgroup = (level, 32768-entry part of that level, sample partition).  The part's gradient tile lives in
-// LDS as half2 (128 KB); contributions h(w * dE) are accumulated with ds_pk_add_f16 (same arithmetic as tcnn's
-// atomicAdd(__half2), but at LDS rate), then the tile is written densely to partial table `p`.  The optimizer
-// sums the P partial tables.  No global atomics, no memset: every tile is fully rewritten each step.
-struct ScatterUnits { uint8_t level[32]; uint8_t part[32]; uint32_t n_units; uint32_t P; };
-constexpr uint32_t kScatterTile = 32768;
+// Measured on MI355X (profiles/microbench_r01.md): global_atomic_pk_add_f16 sustains ~21 Gop/s chip-wide, LDS
+// floating-point atomics (ds_pk_add_f16, ds_add_f32) ~0.35 op/clk/CU, LDS integer atomics (ds_add_u32) ~2.4
+// op/clk/CU.  So the scatter accumulates in LDS in int32 FIXED POINT with scale 2^24: every fp16 value is an
+// exact multiple of 2^-24, so each contribution h(w * dE) converts exactly, integer addition is exact and
+// order-independent, and the tile sum equals the exact sum of tcnn's fp16 contributions (valid while
+// |sum| < 128 in loss-scaled units) -- deterministic, unlike atomicAdd(__half2).
+// One workgroup = (level, 16384-entry part of that level, sample partition).  Every level gets 16 workgroups:
+// parts_l = ceil(entries_l / 16384) parts x P_l = 16 / parts_l sample partitions, which balances the
+// in-range atomics per workgroup.  The tile is written densely (as half2) to partial table p of that level; the
+// optimizer sums the P_l partial tables.  No global atomics, no memset: every tile is fully rewritten each step.
+constexpr uint32_t kScatterTile = 16384;          // entries per LDS tile: 2 x int32 per entry = 128 KB
+constexpr uint32_t kScatterWgPerLevel = 16;
+constexpr float kFixScale = 16777216.0f;          // 2^24
 
-__global__ void __launch_bounds__(1024) k_grid_scatter(LevelTable lt, ScatterUnits su, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa,
+__global__ void __launch_bounds__(1024) k_grid_scatter(LevelTable lt, ScatterLevels sl, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa,
                                                        uint32_t B, half2_t* __restrict__ gpart, uint32_t part_stride, const DevState* __restrict__ st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (st->n_valid == 0u) return;
-    half2_t* tab = reinterpret_cast<half2_t*>(smem);
-    const uint32_t unit = blockIdx.x / su.P, p = blockIdx.x - unit * su.P;
-    const int level = su.level[unit]; const uint32_t part = su.part[unit];
+    int* tab = reinterpret_cast<int*>(smem);
+    const uint32_t slot = blockIdx.x / kScatterWgPerLevel, j = blockIdx.x - slot * kScatterWgPerLevel;
+    const int level = sl.level[slot]; const uint32_t P = sl.P[level];
+    const uint32_t part = j / P, p = j - part * P;
     const uint32_t off = lt.offset[level], size = lt.offset[level + 1] - off, res = lt.res[level];
     const float scale = lt.scale[level];
-    const uint32_t base = part * kScatterTile, tile = min(kScatterTile, size - base);
-    for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) tab[i] = half2_t{ (half_t)0.f, (half_t)0.f };
+    const uint32_t base = part * kScatterTile;
+    if (base >= size) return;                                   // levels whose part count does not divide 16
+    const uint32_t tile = min(kScatterTile, size - base);
+    for (uint32_t i = threadIdx.x; i < 2u * tile; i += blockDim.x) tab[i] = 0;
     __syncthreads();
-    typedef __attribute__((address_space(3))) half2_t lh2;
     const bool pow2 = (size & (size - 1u)) == 0u;
     const bool s1 = res <= size; const uint32_t r2 = res * res; const bool s2 = s1 && r2 <= size; const bool hashed = !(s2) || (uint64_t)r2 * res > size;
-    const uint32_t per = (B + su.P - 1) / su.P, s_begin = p * per, s_end = min(B, s_begin + per);
+    const uint32_t per = (B + P - 1) / P, s_begin = p * per, s_end = min(B, s_begin + per);
     const half2_t* de = de_soa + (size_t)level * B;
     for (uint32_t s = s_begin + threadIdx.x; s < s_end; s += blockDim.x) {
         const half2_t g = de[s];
@@ -565,39 +574,44 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelTable lt, ScatterUni
             uint32_t idx = hashed ? (q[0] ^ (q[1] * 2654435761u) ^ (q[2] * 805459861u)) : (q[0] + q[1] * res + q[2] * r2);
             idx = pow2 ? (idx & (size - 1u)) : (idx % size);
             const uint32_t local = idx - base;
-            if (local < tile) __builtin_amdgcn_ds_atomic_fadd_v2f16((lh2*)(tab + local), half2_t{ (half_t)(w * g0), (half_t)(w * g1) });
+            if (local < tile) {
+                const float c0 = clamp_f((float)(half_t)(w * g0), -100.f, 100.f), c1 = clamp_f((float)(half_t)(w * g1), -100.f, 100.f);   // tcnn: (T)(weight * grad)
+                const int f0 = (int)(c0 * kFixScale), f1 = (int)(c1 * kFixScale);                                                       // exact: fp16 values are multiples of 2^-24
+                if (f0) atomicAdd(tab + 2u * local, f0);
+                if (f1) atomicAdd(tab + 2u * local + 1u, f1);
+            }
         }
     }
     __syncthreads();
     half2_t* dst = gpart + (size_t)p * part_stride + off + base;
-    for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) dst[i] = tab[i];
+    for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x)
+        dst[i] = half2_t{ (half_t)((float)tab[2u * i] * (1.0f / kFixScale)), (half_t)((float)tab[2u * i + 1u] * (1.0f / kFixScale)) };
 }
 
-// Host: which levels go through the LDS scatter, and the (level, part) unit list.
-uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterUnits& su) {
-    uint32_t mask = 0; su.n_units = 0;
+// Host: which levels go through the LDS scatter, with how many sample partitions each.
+uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl) {
+    uint32_t mask = 0; sl.n_levels = 0; sl.max_P = 0;
+    for (int l = 0; l < kMaxLevels; ++l) { sl.P[l] = 0; sl.level[l] = 0; sl.entry_offset[l] = lt.offset[l]; }
+    sl.entry_offset[kMaxLevels] = lt.offset[kMaxLevels];
+    static const int env_on = std::getenv("MON_LDS_SCATTER") ? std::atoi(std::getenv("MON_LDS_SCATTER")) : 1;
+    if (!env_on) return 0u;
     for (int l = 0; l < nd.L; ++l) {
         const uint32_t size = lt.offset[l + 1] - lt.offset[l];
         const uint32_t parts = (size + kScatterTile - 1) / kScatterTile;
-        if (parts <= 2 && su.n_units + parts <= 32) { mask |= 1u << l; for (uint32_t q = 0; q < parts; ++q) { su.level[su.n_units] = (uint8_t)l; su.part[su.n_units] = (uint8_t)q; ++su.n_units; } }
-    }
-    su.P = 1;
-    if (su.n_units) {
-        uint32_t P = 256u / su.n_units; if (P < 1u) P = 1u; if (P > 16u) P = 16u;
-        static const int envP = std::getenv("MON_SCATTER_P") ? std::atoi(std::getenv("MON_SCATTER_P")) : 0;
-        if (envP >= 1 && envP <= 16) P = (uint32_t)envP;
-        su.P = P;
+        if (parts <= kScatterWgPerLevel) {
+            mask |= 1u << l; sl.level[sl.n_levels++] = (uint8_t)l;
+            sl.P[l] = (uint8_t)(kScatterWgPerLevel / parts); if (sl.P[l] > sl.max_P) sl.max_P = sl.P[l];
+        }
     }
     return mask;
 }
-uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd) { ScatterUnits su; return scatter_plan(lt, nd, su); }
-uint32_t scatter_partitions(const LevelTable& lt, const NetDims& nd) { ScatterUnits su; return scatter_plan(lt, nd, su) ? su.P : 0u; }
+uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd) { ScatterLevels sl; return scatter_plan(lt, nd, sl); }
 
 void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, const DevState* st) {
-    ScatterUnits su; if (!scatter_plan(lt, nd, su)) return;
+    ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return;
     static bool attr_done = false;
-    if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, kScatterTile * 4); attr_done = true; }
-    hipLaunchKernelGGL(k_grid_scatter, dim3(su.n_units * su.P), dim3(1024), kScatterTile * 4, s, lt, su, reinterpret_cast<const half2_t*>(de_soa), x_soa, B,
+    if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, kScatterTile * 8); attr_done = true; }
+    hipLaunchKernelGGL(k_grid_scatter, dim3(sl.n_levels * kScatterWgPerLevel), dim3(1024), kScatterTile * 8, s, lt, sl, reinterpret_cast<const half2_t*>(de_soa), x_soa, B,
                        reinterpret_cast<half2_t*>(gpart), part_stride_entries, st);
 }
 

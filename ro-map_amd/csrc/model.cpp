@@ -98,7 +98,7 @@ int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* 
     m.oc.instance_id = (uint32_t)(uint8_t)class_id;                 // nerf.cu:75,158
     m.oc.R = (uint32_t)cfg.rays_per_batch; m.oc.S = (uint32_t)cfg.n_samples; m.oc.use_depth = cfg.use_depth && ds->use_depth;
     m.oc.sample_seed = cfg.sample_seed; m.oc.loss_scale = cfg.loss_scale;
-    m.opt = OptimConst{ cfg.beta1, cfg.beta2, cfg.epsilon, cfg.l2_reg, cfg.ema_decay, cfg.loss_scale, cfg.decay_base, cfg.decay_start, cfg.decay_interval, m.nd.n_mlp, m.n_params };
+    m.opt = OptimConst{ cfg.beta1, cfg.beta2, cfg.epsilon, cfg.l2_reg, cfg.ema_decay, cfg.loss_scale, cfg.decay_base, std::log2(cfg.beta1), std::log2(cfg.beta2), cfg.decay_start, cfg.decay_interval, m.nd.n_mlp, m.n_params };
     HIPCHECK(hipStreamCreateWithFlags(&m.train_stream, hipStreamNonBlocking));       // mpTrainStream, nerf_model.cu:1268
     HIPCHECK(hipStreamCreateWithFlags(&m.infer_stream, hipStreamNonBlocking));       // mpInferenceStream :1269
     // ---- parameters (ResetNetwork :1286-1342; Trainer init)
@@ -133,10 +133,9 @@ int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* 
         (rc = dev_alloc(m, m.d_state, 1)) || (rc = dev_alloc(m, m.d_dw_partials, (size_t)(m.nd.n_mlp + 64) * 512)) ||
         (rc = dev_alloc(m, m.d_out_rgb, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_depth, kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_mask, kRenderChunkRays))) return rc;
     if (fused_supported(m.nd, S)) {
-        m.lds_mask = scatter_level_mask(m.lt, m.nd); m.scatter_P = scatter_partitions(m.lt, m.nd);
-        if (const char* e = std::getenv("MON_LDS_SCATTER")) if (!std::atoi(e)) { m.lds_mask = 0; m.scatter_P = 0; }
+        m.lds_mask = scatter_plan(m.lt, m.nd, m.scatter);
         if (m.lds_mask && ((rc = dev_alloc(m, m.d_de_soa, (size_t)m.nd.L * Btrain * 2)) || (rc = dev_alloc(m, m.d_x_soa, 3 * (size_t)Btrain)) ||
-                           (rc = dev_alloc(m, m.d_gpart, (size_t)m.scatter_P * m.n_grid)))) return rc;
+                           (rc = dev_alloc(m, m.d_gpart, (size_t)m.scatter.max_P * m.n_grid)))) return rc;
     }
     m.boxes_cap = 1024;
     if ((rc = dev_alloc(m, m.d_boxes, m.boxes_cap))) return rc;
@@ -232,7 +231,7 @@ static void enqueue_iteration(Model& m, int stages) {
     if (stages & 4) {      // Trainer::optimizer_step :1644
         ProfScope ps(m, MON_K_OPTIM);
         ParamPtrs P = m.P;
-        if (m.backend == 1 && m.lds_mask) { P.gpart = m.d_gpart; P.n_part = m.scatter_P; P.part_stride = m.n_grid; }
+        if (m.backend == 1 && m.lds_mask) { P.gpart = m.d_gpart; P.part_stride = m.n_grid; P.sl = m.scatter; }
         launch_optimizer(s, P, m.opt, m.d_state);
     }
 }
@@ -374,7 +373,7 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
         std::vector<uint16_t> part(m.n_grid); std::vector<float> acc(m.n_grid);
         uint16_t* out = reinterpret_cast<uint16_t*>(dst);
         for (uint32_t i = 0; i < m.n_grid; ++i) { _Float16 h; std::memcpy(&h, &out[i], 2); acc[i] = (float)h; }
-        for (uint32_t q = 0; q < m.scatter_P; ++q) {
+        for (uint32_t q = 0; q < m.scatter.max_P; ++q) {
             HIPCHECK(hipMemcpy(part.data(), m.d_gpart + (size_t)q * m.n_grid, (size_t)m.n_grid * 2, hipMemcpyDeviceToHost));
             for (uint32_t i = 0; i < m.n_grid; ++i) { _Float16 h; std::memcpy(&h, &part[i], 2); acc[i] += (float)h; }
         }

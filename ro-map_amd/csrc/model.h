@@ -51,15 +51,19 @@ struct BatchPtrs {
     float *rgb_ray, *depth_ray, *mask_ray, *loss_ray;
 };
 
+// LDS scatter plan: levels handled by k_grid_scatter and their sample-partition counts (partial tables per level)
+struct ScatterLevels { uint32_t entry_offset[kMaxLevels + 1]; uint8_t P[kMaxLevels]; uint8_t level[kMaxLevels]; uint32_t n_levels; uint32_t max_P; };
+
 struct ParamPtrs {
     float* master; uint16_t* half; uint16_t* ema; float* m1; float* m2; uint32_t* steps;
     float* gmlp;        // fp32 dW [n_mlp]
     uint16_t* ggrid;    // fp16 grid gradient [n_grid], accumulated with global_atomic_pk_add_f16
-    const uint16_t* gpart; uint32_t n_part; uint32_t part_stride;   // fused backend: P dense fp16 partial gradient tables from k_grid_scatter (stride in halves)
+    const uint16_t* gpart; uint32_t part_stride;                    // fused backend: dense fp16 partial gradient tables from k_grid_scatter (stride in halves); nullptr = unused
+    ScatterLevels sl;                                               // per-level partial-table counts
 };
 
 struct OptimConst {
-    float beta1, beta2, epsilon, l2_reg, ema_decay, loss_scale, decay_base;
+    float beta1, beta2, epsilon, l2_reg, ema_decay, loss_scale, decay_base, log2_beta1, log2_beta2;
     int decay_start, decay_interval;
     uint32_t n_mlp, n_params;
 };
@@ -102,9 +106,7 @@ bool fused_supported(const NetDims& nd, uint32_t S);
 uint32_t fused_train_grid(const NetDims& nd, uint32_t R);
 void launch_fused_train(hipStream_t s, const LevelTable& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
                         uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask);
-struct ScatterUnits;
-uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterUnits& su);
-uint32_t scatter_partitions(const LevelTable& lt, const NetDims& nd);
+uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl);
 uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd);
 void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, const DevState* st);
 void launch_fused_render(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask);
@@ -125,7 +127,7 @@ struct Model {
     hipStream_t train_stream = nullptr, infer_stream = nullptr;
     ParamPtrs P{}; BatchPtrs B{}; DevState* d_state = nullptr; mon_frame_bbox* d_boxes = nullptr;
     uint32_t boxes_cap = 0, n_boxes = 0; uint32_t ws_samples = 0, ws_rays = 0;
-    float* d_dw_partials = nullptr; uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr; uint16_t* d_gpart = nullptr; uint32_t scatter_P = 0, lds_mask = 0; float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr;
+    float* d_dw_partials = nullptr; uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr; uint16_t* d_gpart = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0; float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr;
     std::vector<void*> allocs;
     DevState h_state{}; int backend = 0; bool profiling = false; int fused_dump = 0;
     mon_profile prof{}; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pending;
