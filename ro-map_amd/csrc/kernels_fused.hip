@@ -129,6 +129,7 @@ struct FusedArgs {
     half2_t* de_soa;            // [L][B] dL/dE of the levels scattered through LDS (k_grid_scatter), or nullptr
     float* x_soa;               // [3][B] warped sample positions for k_grid_scatter
     uint32_t lds_level_mask;    // bit l set: level l goes through k_grid_scatter instead of global atomics
+    uint32_t ablate;            // timing experiments only (MON_FUSED_ABLATE): 1 no table gathers, 2 no dW, 4 no dE/x stores, 8 no composite scans
 };
 
 // Builds the A fragments (weights pre-permuted to K-slot order) and the level table in LDS.
@@ -197,7 +198,7 @@ struct TileState {
 
 template <int EPAD, int W, int NH>
 __device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const half_t* frags, const LevelLds& llt, const half2_t* __restrict__ table,
-                                             int L, const float x[3], int lane) {
+                                             int L, const float x[3], int lane, bool no_gather = false) {
     using S = FusedShape<EPAD, W, NH>;
     const int h = lane >> 5, LPH = (L + 1) >> 1;
     // ---- hash-grid encode of the levels this half-wave owns (tcnn kernel_grid; fp32 fmaf chain, one rounding)
@@ -207,7 +208,7 @@ __device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const h
         float a0 = 0.f, a1 = 0.f;
         if (il < LPH && level < L) {
             const half2_t* tl = table + llt.offset[level];
-            level_corners(llt, level, x, [&](int, uint32_t idx, float wgt) { const half2_t v = tl[idx]; a0 = fmaf(wgt, (float)v.x, a0); a1 = fmaf(wgt, (float)v.y, a1); });
+            level_corners(llt, level, x, [&](int, uint32_t idx, float wgt) { const half2_t v = no_gather ? half2_t{ (half_t)(float)(idx & 7u), (half_t)1.f } : tl[idx]; a0 = fmaf(wgt, (float)v.x, a0); a1 = fmaf(wgt, (float)v.y, a1); });
         }
         ts.ef[2 * il] = (half_t)a0; ts.ef[2 * il + 1] = (half_t)a1;
     }
@@ -302,9 +303,11 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         for (int d = 0; d < 3; ++d) { const float p = fmaf(t, a.b.ray_d[3 * ray + d], a.b.ray_o[3 * ray + d]); x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
 
         TileState<EPAD, W, NH> ts;
-        tile_forward<EPAD, W, NH>(ts, frags, *llt, table, L, x, lane);
+        tile_forward<EPAD, W, NH>(ts, frags, *llt, table, L, x, lane, (a.ablate & 1u) != 0u);
+        const bool do_dw = (a.ablate & 2u) == 0u;
 
         // ---- transposes needed by the weight gradients
+        if (do_dw) {
 #pragma unroll
         for (int il = 0; il < S::LLV; ++il) {
             const int level = h * LPH + il;
@@ -314,6 +317,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         for (int mb = 0; mb < S::MB; ++mb) {
             if constexpr (NH == 2) { scratch_store_units(scr + S::SCR_HB, mb, n, h, ts.h0[mb][0], ts.h0[mb][1]); scratch_store_units(scr + S::SCR_HA, mb, n, h, ts.h1[mb][0], ts.h1[mb][1]); }
             else scratch_store_units(scr + S::SCR_HA, mb, n, h, ts.h0[mb][0], ts.h0[mb][1]);
+        }
         }
 
         // ---- composite (VolumeRender :762-813) as wave scans over lanes 0..31
@@ -393,6 +397,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
 
         // ---- backward: dWout += H_last^T-side outer products (K = samples, via the LDS transposes)
         const int m = n;     // A-fragment row / B-fragment column of this lane
+        if (do_dw) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             half8_t bcol;
@@ -405,6 +410,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
                 dWo[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(arow, bcol, dWo[mb], 0, 0, 0);
             }
         }
+        }
         // ---- dH of the last hidden layer = relu' * (Wout^T dO)
         half8_t dhl[S::MB][2];
 #pragma unroll
@@ -413,7 +419,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(frags, S::F_WOT + mb, lane), bdo, acc, 0, 0, 0);
             if constexpr (NH == 2) mask_pack(acc, ts.h1[mb][0], ts.h1[mb][1], dhl[mb][0], dhl[mb][1]);
             else mask_pack(acc, ts.h0[mb][0], ts.h0[mb][1], dhl[mb][0], dhl[mb][1]);
-            scratch_store_units(scr + S::SCR_HA, mb, n, h, dhl[mb][0], dhl[mb][1]);       // H_last no longer needed: reuse as dH_last
+            if (do_dw) scratch_store_units(scr + S::SCR_HA, mb, n, h, dhl[mb][0], dhl[mb][1]);       // H_last no longer needed: reuse as dH_last
         }
         half8_t dh0[S::MB][2];
         if constexpr (NH == 2) {
@@ -443,7 +449,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
             for (int mb = 0; mb < S::MB; ++mb) { dh0[mb][0] = dhl[mb][0]; dh0[mb][1] = dhl[mb][1]; }
         }
         // ---- dW0[u][f] += dH0[u][n] * E[n][f]
-        {
+        if (do_dw) {
             const half_t* dh0_scr = scr + (NH == 2 ? S::SCR_HB : S::SCR_HA);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -476,14 +482,15 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         //      k_grid_scatter (global packed-f16 atomics sustain only ~21 Gop/s on gfx950, ~12x below the gather
         //      rate: profiles/); larger levels scatter here with 8 global_atomic_pk_add_f16 per level.
         const uint32_t Btot = R * 32u;
-        if (a.lds_level_mask && h == 0) { a.x_soa[s_idx] = x[0]; a.x_soa[Btot + s_idx] = x[1]; a.x_soa[2u * Btot + s_idx] = x[2]; }
+        const bool do_store = (a.ablate & 4u) == 0u;
+        if (a.lds_level_mask && h == 0 && do_store) { a.x_soa[s_idx] = x[0]; a.x_soa[Btot + s_idx] = x[1]; a.x_soa[2u * Btot + s_idx] = x[2]; }
 #pragma unroll
         for (int il = 0; il < S::LLV; ++il) {
             const int level = h * LPH + il;
             if (il < LPH && level < L) {
                 const half_t q0 = (half_t)de[2 * il], q1 = (half_t)de[2 * il + 1];
                 if (!ATOMIC_LEVELS || ((a.lds_level_mask >> level) & 1u)) {
-                    a.de_soa[(size_t)level * Btot + s_idx] = half2_t{ q0, q1 };
+                    if (do_store) a.de_soa[(size_t)level * Btot + s_idx] = half2_t{ q0, q1 };
                 } else if constexpr (ATOMIC_LEVELS) {
                     const float gq0 = (float)q0, gq1 = (float)q1;
                     if (gq0 != 0.f || gq1 != 0.f) {
@@ -559,26 +566,38 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelTable lt, ScatterLev
     const bool s1 = res <= size; const uint32_t r2 = res * res; const bool s2 = s1 && r2 <= size; const bool hashed = !(s2) || (uint64_t)r2 * res > size;
     const uint32_t per = (B + P - 1) / P, s_begin = p * per, s_end = min(B, s_begin + per);
     const half2_t* de = de_soa + (size_t)level * B;
-    for (uint32_t s = s_begin + threadIdx.x; s < s_end; s += blockDim.x) {
-        const half2_t g = de[s];
-        const float g0 = (float)g.x, g1 = (float)g.y;
-        if (g0 == 0.f && g1 == 0.f) continue;
-        float pos[3]; uint32_t pg[3];
+    // The loop is latency-bound if run one sample at a time (dependent loads, 16 waves per CU): fetch a batch
+    // of kBatch samples per thread with independent loads first, then do the index math + LDS atomics.
+    constexpr int kBatch = 8;
+    for (uint32_t s0 = s_begin + threadIdx.x; s0 < s_end; s0 += blockDim.x * kBatch) {
+        half2_t g[kBatch]; float xs[kBatch][3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, x_soa[(size_t)d * B + s], 0.5f), fl = floorf(q); pg[d] = (uint32_t)(int32_t)fl; pos[d] = q - fl; }
+        for (int u = 0; u < kBatch; ++u) {
+            const uint32_t s = s0 + u * blockDim.x; const bool in = s < s_end; const uint32_t sc = in ? s : s_begin;
+            g[u] = de[sc]; if (!in) g[u] = half2_t{ (half_t)0.f, (half_t)0.f };
+            xs[u][0] = x_soa[sc]; xs[u][1] = x_soa[(size_t)B + sc]; xs[u][2] = x_soa[2 * (size_t)B + sc];
+        }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float w = 1.f; uint32_t q[3];
+        for (int u = 0; u < kBatch; ++u) {
+            const float g0 = (float)g[u].x, g1 = (float)g[u].y;
+            if (g0 == 0.f && g1 == 0.f) continue;
+            float pos[3]; uint32_t pg[3];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) { if (k & (1 << d)) { w *= pos[d]; q[d] = pg[d] + 1u; } else { w *= 1.f - pos[d]; q[d] = pg[d]; } }
-            uint32_t idx = hashed ? (q[0] ^ (q[1] * 2654435761u) ^ (q[2] * 805459861u)) : (q[0] + q[1] * res + q[2] * r2);
-            idx = pow2 ? (idx & (size - 1u)) : (idx % size);
-            const uint32_t local = idx - base;
-            if (local < tile) {
-                const float c0 = clamp_f((float)(half_t)(w * g0), -100.f, 100.f), c1 = clamp_f((float)(half_t)(w * g1), -100.f, 100.f);   // tcnn: (T)(weight * grad)
-                const int f0 = (int)(c0 * kFixScale), f1 = (int)(c1 * kFixScale);                                                       // exact: fp16 values are multiples of 2^-24
-                if (f0) atomicAdd(tab + 2u * local, f0);
-                if (f1) atomicAdd(tab + 2u * local + 1u, f1);
+            for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, xs[u][d], 0.5f), fl = floorf(q); pg[d] = (uint32_t)(int32_t)fl; pos[d] = q - fl; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float w = 1.f; uint32_t q[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { if (k & (1 << d)) { w *= pos[d]; q[d] = pg[d] + 1u; } else { w *= 1.f - pos[d]; q[d] = pg[d]; } }
+                uint32_t idx = hashed ? (q[0] ^ (q[1] * 2654435761u) ^ (q[2] * 805459861u)) : (q[0] + q[1] * res + q[2] * r2);
+                idx = pow2 ? (idx & (size - 1u)) : (idx % size);
+                const uint32_t local = idx - base;
+                if (local < tile) {
+                    const float c0 = clamp_f((float)(half_t)(w * g0), -100.f, 100.f), c1 = clamp_f((float)(half_t)(w * g1), -100.f, 100.f);   // tcnn: (T)(weight * grad)
+                    const int f0 = (int)(c0 * kFixScale), f1 = (int)(c1 * kFixScale);                                                       // exact: fp16 values are multiples of 2^-24
+                    if (f0) atomicAdd(tab + 2u * local, f0);
+                    if (f1) atomicAdd(tab + 2u * local + 1u, f1);
+                }
             }
         }
     }
@@ -714,12 +733,13 @@ static void fused_render_t(hipStream_t s, const FusedArgs& a, uint32_t n_rays, u
 
 void launch_fused_train(hipStream_t s, const LevelTable& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
                         uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask) {
-    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask };
+    static const uint32_t ablate = std::getenv("MON_FUSED_ABLATE") ? (uint32_t)std::atoi(std::getenv("MON_FUSED_ABLATE")) : 0u;
+    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, ablate };
     const uint32_t grid = fused_train_grid(nd, oc.R);
     MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);
 }
 void launch_fused_render(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask) {
-    FusedArgs a{ lt, nd, oc, b, params, nullptr, nullptr, nullptr, nullptr, nullptr, 0u };
+    FusedArgs a{ lt, nd, oc, b, params, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u };
     MON_FUSED_DISPATCH(fused_render_t, s, a, n_rays, idx_base, rgb, depth, mask);
 }
 
