@@ -70,23 +70,34 @@ __device__ __forceinline__ int unit_of_slot(int s, int h, int j) { return 32 * (
 struct LevelLds { uint32_t offset[kMaxLevels + 1]; uint32_t res[kMaxLevels]; float scale[kMaxLevels]; };
 
 // Corner walk of one level for one position: calls f(k, index_within_level, weight) for the 8 corners.
+// Same arithmetic as tcnn's grid_index / grid_hash (weights multiply in x, y, z order; see k_encode), restructured
+// for instruction count -- this kernel is VALU-issue bound, not gather bound:
+//   * tcnn's table sizes leave two cases only: dense (size = round_up(res^3, 8) >= res^3, linear index, can exceed
+//     size only by the +1 boundary corner, so `% size` is one conditional subtract) and hashed (size = 2^T, `%` is a mask);
+//   * the 8 corners share the per-axis terms (2 integer multiplies per level instead of 16), both index forms are
+//     computed and selected per lane (the two half-waves may sit on a dense and a hashed level at the same time).
 template <class F>
 __device__ __forceinline__ void level_corners(const LevelLds& lt, int level, const float x[3], F&& f) {
     const float scale = lt.scale[level]; const uint32_t res = lt.res[level], size = lt.offset[level + 1] - lt.offset[level];
     float pos[3]; uint32_t pg[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) { const float p = fmaf(scale, x[d], 0.5f), fl = floorf(p); pg[d] = (uint32_t)(int32_t)fl; pos[d] = p - fl; }
-    const bool pow2 = (size & (size - 1u)) == 0u;
-    // strides of the dense index, with tcnn's overflow guard
-    const bool s1 = res <= size; const uint32_t r2 = res * res; const bool s2 = s1 && r2 <= size; const bool hashed = !(s2) || (uint64_t)r2 * res > size;
+    const uint32_t r2 = res * res;
+    const bool hashed = (uint64_t)r2 * res > (uint64_t)size;            // else dense: res^3 <= size
+    const uint32_t mask = hashed ? (size - 1u) : 0xffffffffu;
+    const uint32_t my = hashed ? 2654435761u : res, mz = hashed ? 805459861u : r2;
+    const uint32_t ax[2] = { pg[0], pg[0] + 1u };
+    const uint32_t y0 = pg[1] * my, z0 = pg[2] * mz;
+    const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
+    const float wx[2] = { 1.f - pos[0], pos[0] }, wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        float w = 1.f; uint32_t q[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { if (k & (1 << d)) { w *= pos[d]; q[d] = pg[d] + 1u; } else { w *= 1.f - pos[d]; q[d] = pg[d]; } }
-        uint32_t idx = hashed ? (q[0] ^ (q[1] * 2654435761u) ^ (q[2] * 805459861u)) : (q[0] + q[1] * res + q[2] * r2);
-        idx = pow2 ? (idx & (size - 1u)) : (idx % size);
-        f(k, idx, w);
+        const int ix = k & 1, iy = (k >> 1) & 1, iz = k >> 2;
+        const uint32_t ih = (ax[ix] ^ ay[iy] ^ az[iz]) & mask, id = ax[ix] + ay[iy] + az[iz];
+        uint32_t idx = hashed ? ih : id;
+        idx -= (idx >= size) ? size : 0u;                               // dense boundary corner aliases (tcnn: index % size)
+        idx = min(idx, size - 1u);                                      // memory safety for positions far outside [0,1]^3 (never produced by the sampler)
+        f(k, idx, (wx[ix] * wy[iy]) * wz[iz]);                          // same product order as the reference walk: ((1 * wx) * wy) * wz
     }
 }
 
@@ -129,7 +140,7 @@ struct FusedArgs {
     half2_t* de_soa;            // [L][B] dL/dE of the levels scattered through LDS (k_grid_scatter), or nullptr
     float* x_soa;               // [3][B] warped sample positions for k_grid_scatter
     uint32_t lds_level_mask;    // bit l set: level l goes through k_grid_scatter instead of global atomics
-    uint32_t ablate;            // timing experiments only (MON_FUSED_ABLATE): 1 no table gathers, 2 no dW, 4 no dE/x stores, 8 no composite scans
+    uint32_t ablate;            // timing experiments only (MON_FUSED_ABLATE): 2 no dW, 4 no dE/x stores
 };
 
 // Builds the A fragments (weights pre-permuted to K-slot order) and the level table in LDS.
@@ -198,7 +209,7 @@ struct TileState {
 
 template <int EPAD, int W, int NH>
 __device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const half_t* frags, const LevelLds& llt, const half2_t* __restrict__ table,
-                                             int L, const float x[3], int lane, bool no_gather = false) {
+                                             int L, const float x[3], int lane) {
     using S = FusedShape<EPAD, W, NH>;
     const int h = lane >> 5, LPH = (L + 1) >> 1;
     // ---- hash-grid encode of the levels this half-wave owns (tcnn kernel_grid; fp32 fmaf chain, one rounding)
@@ -208,7 +219,7 @@ __device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const h
         float a0 = 0.f, a1 = 0.f;
         if (il < LPH && level < L) {
             const half2_t* tl = table + llt.offset[level];
-            level_corners(llt, level, x, [&](int, uint32_t idx, float wgt) { const half2_t v = no_gather ? half2_t{ (half_t)(float)(idx & 7u), (half_t)1.f } : tl[idx]; a0 = fmaf(wgt, (float)v.x, a0); a1 = fmaf(wgt, (float)v.y, a1); });
+            level_corners(llt, level, x, [&](int, uint32_t idx, float wgt) { const half2_t v = tl[idx]; a0 = fmaf(wgt, (float)v.x, a0); a1 = fmaf(wgt, (float)v.y, a1); });
         }
         ts.ef[2 * il] = (half_t)a0; ts.ef[2 * il + 1] = (half_t)a1;
     }
@@ -303,7 +314,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         for (int d = 0; d < 3; ++d) { const float p = fmaf(t, a.b.ray_d[3 * ray + d], a.b.ray_o[3 * ray + d]); x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
 
         TileState<EPAD, W, NH> ts;
-        tile_forward<EPAD, W, NH>(ts, frags, *llt, table, L, x, lane, (a.ablate & 1u) != 0u);
+        tile_forward<EPAD, W, NH>(ts, frags, *llt, table, L, x, lane);
         const bool do_dw = (a.ablate & 2u) == 0u;
 
         // ---- transposes needed by the weight gradients
@@ -562,8 +573,8 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelTable lt, ScatterLev
     const uint32_t tile = min(kScatterTile, size - base);
     for (uint32_t i = threadIdx.x; i < 2u * tile; i += blockDim.x) tab[i] = 0;
     __syncthreads();
-    const bool pow2 = (size & (size - 1u)) == 0u;
-    const bool s1 = res <= size; const uint32_t r2 = res * res; const bool s2 = s1 && r2 <= size; const bool hashed = !(s2) || (uint64_t)r2 * res > size;
+    const uint32_t r2 = res * res; const bool hashed = (uint64_t)r2 * res > (uint64_t)size;
+    const uint32_t my = hashed ? 2654435761u : res, mz = hashed ? 805459861u : r2;
     const uint32_t per = (B + P - 1) / P, s_begin = p * per, s_end = min(B, s_begin + per);
     const half2_t* de = de_soa + (size_t)level * B;
     // The loop is latency-bound if run one sample at a time (dependent loads, 16 waves per CU): fetch a batch
@@ -584,13 +595,13 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelTable lt, ScatterLev
             float pos[3]; uint32_t pg[3];
 #pragma unroll
             for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, xs[u][d], 0.5f), fl = floorf(q); pg[d] = (uint32_t)(int32_t)fl; pos[d] = q - fl; }
+            const uint32_t ax[2] = { pg[0], pg[0] + 1u }, y0 = pg[1] * my, z0 = pg[2] * mz, ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
+            const float wx[2] = { 1.f - pos[0], pos[0] }, wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                float w = 1.f; uint32_t q[3];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) { if (k & (1 << d)) { w *= pos[d]; q[d] = pg[d] + 1u; } else { w *= 1.f - pos[d]; q[d] = pg[d]; } }
-                uint32_t idx = hashed ? (q[0] ^ (q[1] * 2654435761u) ^ (q[2] * 805459861u)) : (q[0] + q[1] * res + q[2] * r2);
-                idx = pow2 ? (idx & (size - 1u)) : (idx % size);
+                const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
+                uint32_t idx = hashed ? ((ax[k & 1] ^ ay[(k >> 1) & 1] ^ az[k >> 2]) & (size - 1u)) : (ax[k & 1] + ay[(k >> 1) & 1] + az[k >> 2]);
+                idx -= (idx >= size) ? size : 0u; idx = min(idx, size - 1u);
                 const uint32_t local = idx - base;
                 if (local < tile) {
                     const float c0 = clamp_f((float)(half_t)(w * g0), -100.f, 100.f), c1 = clamp_f((float)(half_t)(w * g1), -100.f, 100.f);   // tcnn: (T)(weight * grad)

@@ -67,8 +67,16 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                     for (int l = 1; l < kMaxLevels; ++l) lvl += (e0 >= p.sl.entry_offset[l]) ? 1 : 0;
                     n_part = p.sl.P[lvl];
                 }
-                for (uint32_t q = 0; q < n_part; ++q) {              // dense partial tables of k_grid_scatter (fused backend)
-                    const half8_t ph = *reinterpret_cast<const half8_t*>(p.gpart + (size_t)q * p.part_stride + (i0 - oc.n_mlp));
+                const uint16_t* pp = p.gpart + (i0 - oc.n_mlp);         // dense partial tables of k_grid_scatter (fused backend)
+                uint32_t q = 0;
+                for (; q + 4 <= n_part; q += 4) {                       // 4 independent 16-byte loads in flight
+                    const half8_t h0 = *reinterpret_cast<const half8_t*>(pp + (size_t)q * p.part_stride), h1 = *reinterpret_cast<const half8_t*>(pp + (size_t)(q + 1) * p.part_stride);
+                    const half8_t h2 = *reinterpret_cast<const half8_t*>(pp + (size_t)(q + 2) * p.part_stride), h3 = *reinterpret_cast<const half8_t*>(pp + (size_t)(q + 3) * p.part_stride);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] += ((float)h0[j] + (float)h1[j]) + ((float)h2[j] + (float)h3[j]);
+                }
+                for (; q < n_part; ++q) {
+                    const half8_t ph = *reinterpret_cast<const half8_t*>(pp + (size_t)q * p.part_stride);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) g[j] += (float)ph[j];
                 }
@@ -106,7 +114,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
             *ep = e;
         }
     }
-    // ---- last block advances the counters (one ticket per block; the grid is capped at 512 blocks)
+    // ---- last block advances the counters (one ticket per block)
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
@@ -150,7 +158,7 @@ void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_par
 
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st) {
     const uint32_t chunks = oc.n_params >> 3;
-    uint32_t blocks = (chunks + 255) / 256; if (blocks > 512u) blocks = 512u; if (blocks < 1u) blocks = 1u;
+    uint32_t blocks = (chunks + 255) / 256; if (blocks > 2048u) blocks = 2048u; if (blocks < 1u) blocks = 1u;     // one chunk per thread up to 4 M parameters
     hipLaunchKernelGGL(k_optimizer, dim3(blocks), dim3(256), 0, s, p, oc, st);
 }
 
