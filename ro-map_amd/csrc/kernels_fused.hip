@@ -83,7 +83,7 @@ __device__ __forceinline__ void level_corners(const LevelLds& lt, int level, con
 #pragma unroll
     for (int d = 0; d < 3; ++d) { const float p = fmaf(scale, x[d], 0.5f), fl = floorf(p); pg[d] = (uint32_t)(int32_t)fl; pos[d] = p - fl; }
     const uint32_t r2 = res * res;
-    const bool hashed = (uint64_t)r2 * res > (uint64_t)size;            // else dense: res^3 <= size
+    const bool hashed = (uint64_t)res * res * res > (uint64_t)size;     // 64-bit: res^2 overflows 32 bits on fine levels; else dense: res^3 <= size
     const uint32_t mask = hashed ? (size - 1u) : 0xffffffffu;
     const uint32_t my = hashed ? 2654435761u : res, mz = hashed ? 805459861u : r2;
     const uint32_t ax[2] = { pg[0], pg[0] + 1u };
@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelTable lt, ScatterLev
     const uint32_t tile = min(kScatterTile, size - base);
     for (uint32_t i = threadIdx.x; i < 2u * tile; i += blockDim.x) tab[i] = 0;
     __syncthreads();
-    const uint32_t r2 = res * res; const bool hashed = (uint64_t)r2 * res > (uint64_t)size;
+    const uint32_t r2 = res * res; const bool hashed = (uint64_t)res * res * res > (uint64_t)size;
     const uint32_t my = hashed ? 2654435761u : res, mz = hashed ? 805459861u : r2;
     const uint32_t per = (B + P - 1) / P, s_begin = p * per, s_end = min(B, s_begin + per);
     const half2_t* de = de_soa + (size_t)level * B;
