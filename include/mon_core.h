@@ -144,6 +144,9 @@ int mon_device_synchronize(int device);
 int mon_object_set_debug_dump(mon_object* obj, int enable);
 /* Diagnostic micro-benchmarks of scatter strategies (ro-map_amd/csrc/microbench.hip); *ms = best of 3 runs. */
 int mon_microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms);
+/* Host-side check hook: corner index of the fused kernels' closed form (device_common.h:fast_grid_index) for level `level`
+ * of configuration cfg; *size = entries of that level.  No device needed. */
+int mon_debug_fast_index(const mon_config* cfg, int level, uint32_t x, uint32_t y, uint32_t z, uint32_t* index, uint32_t* size);
 /* MFMA fragment-layout self-test (tests only): D[32x32] = A[32x16] * B[16x32], fp16 in / fp32 out. */
 int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
 

@@ -67,6 +67,7 @@ _SIGS = {
     "mon_object_get_profile": (C.c_int, [C.c_void_p, C.POINTER(MonProfile), C.c_int]),
     "mon_object_destroy": (C.c_int, [C.c_void_p]),
     "mon_device_synchronize": (C.c_int, [C.c_int]),
+    "mon_debug_fast_index": (C.c_int, [C.POINTER(MonConfig), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mon_selftest_mfma": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
@@ -125,6 +126,10 @@ def config_from_json(path):
 def selftest_mfma(A_h, B_h, device=0):
     A = np.ascontiguousarray(A_h, np.uint16); B = np.ascontiguousarray(B_h, np.uint16); D = np.empty((32, 32), np.float32)
     _check(lib().mon_selftest_mfma(device, _p(A), _p(B), _p(D))); return D
+
+
+def fast_index(cfg, level, x, y, z):
+    i = C.c_uint32(0); n = C.c_uint32(0); _check(lib().mon_debug_fast_index(C.byref(cfg), level, x, y, z, C.byref(i), C.byref(n))); return i.value, n.value
 
 
 def microbench(mode, pattern, n_entries, n_ops, device=0):

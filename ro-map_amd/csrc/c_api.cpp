@@ -88,6 +88,13 @@ int mon_device_synchronize(int device) {
     if (hipSetDevice(device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { set_error("device synchronize failed"); return MON_ERR_HIP; }
     return MON_OK;
 }
+int mon_debug_fast_index(const mon_config* cfg, int level, uint32_t x, uint32_t y, uint32_t z, uint32_t* index, uint32_t* size) {
+    REQUIRE(cfg, "cfg"); REQUIRE(index, "index"); REQUIRE(size, "size");
+    LevelTable lt{}; NetDims nd{}; uint32_t n_grid = 0; int rc = level_table_build(*cfg, lt, nd, n_grid); if (rc) return rc;
+    if (level < 0 || level >= nd.L) { set_error("level out of range"); return MON_ERR_ARG; }
+    LevelFast lf{}; level_fast_build(lt, nd, lf);
+    *index = fast_grid_index(lf, level, x, y, z); *size = lf.size[level]; return MON_OK;
+}
 int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D) { REQUIRE(A, "A"); REQUIRE(B, "B"); REQUIRE(D, "D"); return selftest_mfma(device, A, B, D); }
 
 }  // extern "C"

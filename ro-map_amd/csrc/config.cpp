@@ -163,6 +163,21 @@ int level_table_build(const mon_config& c, LevelTable& lt, NetDims& nd, uint32_t
     return MON_OK;
 }
 
+// Closed-form per-level index constants (device_common.h:LevelFast) = tcnn's stride loop replayed in uint32.
+void level_fast_build(const LevelTable& lt, const NetDims& nd, LevelFast& lf) {
+    for (int l = 0; l < kMaxLevels; ++l) { lf.scale[l] = 0.f; lf.size[l] = 1; lf.my[l] = lf.mz[l] = 0; lf.mask[l] = 0; lf.hashed[l] = 0; lf.offset[l] = lt.offset[l]; }
+    lf.offset[kMaxLevels] = lt.offset[kMaxLevels];
+    for (int l = 0; l < nd.L; ++l) {
+        const uint32_t size = lt.offset[l + 1] - lt.offset[l], res = lt.res[l];
+        uint32_t stride = 1, mult[3] = { 0, 0, 0 };
+        for (int d = 0; d < 3 && stride <= size; ++d) { mult[d] = stride; stride *= res; }      // uint32 wrap-around on purpose
+        const bool hashed = size < stride;
+        lf.scale[l] = lt.scale[l]; lf.size[l] = size; lf.hashed[l] = hashed ? 1u : 0u;
+        lf.my[l] = hashed ? 2654435761u : mult[1]; lf.mz[l] = hashed ? 805459861u : mult[2];
+        lf.mask[l] = ((size & (size - 1u)) == 0u) ? size - 1u : 0xffffffffu;
+    }
+}
+
 // ------------------------------------------------------------------ parameter init (SURVEY TCNN-A5)
 // pcg32 (tcnn::default_rng_t, seed 1337): MLP Xavier-uniform per matrix, then grid U(-1e-4, 1e-4).
 namespace {

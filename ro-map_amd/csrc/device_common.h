@@ -25,6 +25,22 @@ struct LevelTable {
     float scale[kMaxLevels];
 };
 
+// Per-level constants of the closed-form corner index used by the fused kernels.  Built on the host by replaying
+// tcnn's grid_index stride loop in uint32 arithmetic (including its wrap-around: with base 16, scale 2, T=16 the
+// level with res = 65536 gets strides {1, 65536, 0} and is NOT hashed -- the quirk is kept for parity):
+//   index = hashed ? (x ^ y*my ^ z*mz) : (x + y*my + z*mz);  index &= mask;  if (index >= size) index -= size;
+// mask = size-1 for power-of-two sizes (exact modulo), else ~0 with the conditional subtract (dense, index < 2*size).
+struct LevelFast {
+    float scale[kMaxLevels];
+    uint32_t size[kMaxLevels], my[kMaxLevels], mz[kMaxLevels], mask[kMaxLevels], hashed[kMaxLevels], offset[kMaxLevels + 1];
+};
+
+__host__ __device__ inline uint32_t fast_grid_index(const LevelFast& lf, int l, uint32_t x, uint32_t y, uint32_t z) {
+    uint32_t idx = (lf.hashed[l] ? (x ^ (y * lf.my[l]) ^ (z * lf.mz[l])) : (x + y * lf.my[l] + z * lf.mz[l])) & lf.mask[l];
+    idx -= (idx >= lf.size[l]) ? lf.size[l] : 0u;
+    return idx < lf.size[l] ? idx : lf.size[l] - 1u;
+}
+
 // Static shape of one object's network; passed by value to kernels.
 struct NetDims {
     int L;          // hash levels

@@ -67,7 +67,7 @@ __device__ __forceinline__ int rho(int h, int r) { return (r & 3) + 8 * (r >> 2)
 // hidden unit carried by K-slot (k-step s, half h, element j) of a W-wide activation in C/D layout
 __device__ __forceinline__ int unit_of_slot(int s, int h, int j) { return 32 * (s >> 1) + rho(h, 8 * (s & 1) + j); }
 
-struct LevelLds { uint32_t offset[kMaxLevels + 1]; uint32_t res[kMaxLevels]; float scale[kMaxLevels]; };
+typedef LevelFast LevelLds;      // copied into LDS once per workgroup
 
 // Corner walk of one level for one position: calls f(k, index_within_level, weight) for the 8 corners.
 // Same arithmetic as tcnn's grid_index / grid_hash (weights multiply in x, y, z order; see k_encode), restructured
@@ -78,14 +78,12 @@ struct LevelLds { uint32_t offset[kMaxLevels + 1]; uint32_t res[kMaxLevels]; flo
 //     computed and selected per lane (the two half-waves may sit on a dense and a hashed level at the same time).
 template <class F>
 __device__ __forceinline__ void level_corners(const LevelLds& lt, int level, const float x[3], F&& f) {
-    const float scale = lt.scale[level]; const uint32_t res = lt.res[level], size = lt.offset[level + 1] - lt.offset[level];
+    const float scale = lt.scale[level];
+    const uint32_t size = lt.size[level], my = lt.my[level], mz = lt.mz[level], mask = lt.mask[level];
+    const bool hashed = lt.hashed[level] != 0u;
     float pos[3]; uint32_t pg[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) { const float p = fmaf(scale, x[d], 0.5f), fl = floorf(p); pg[d] = (uint32_t)(int32_t)fl; pos[d] = p - fl; }
-    const uint32_t r2 = res * res;
-    const bool hashed = (uint64_t)res * res * res > (uint64_t)size;     // 64-bit: res^2 overflows 32 bits on fine levels; else dense: res^3 <= size
-    const uint32_t mask = hashed ? (size - 1u) : 0xffffffffu;
-    const uint32_t my = hashed ? 2654435761u : res, mz = hashed ? 805459861u : r2;
     const uint32_t ax[2] = { pg[0], pg[0] + 1u };
     const uint32_t y0 = pg[1] * my, z0 = pg[2] * mz;
     const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
@@ -93,9 +91,9 @@ __device__ __forceinline__ void level_corners(const LevelLds& lt, int level, con
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int ix = k & 1, iy = (k >> 1) & 1, iz = k >> 2;
-        const uint32_t ih = (ax[ix] ^ ay[iy] ^ az[iz]) & mask, id = ax[ix] + ay[iy] + az[iz];
-        uint32_t idx = hashed ? ih : id;
-        idx -= (idx >= size) ? size : 0u;                               // dense boundary corner aliases (tcnn: index % size)
+        const uint32_t ih = ax[ix] ^ ay[iy] ^ az[iz], id = ax[ix] + ay[iy] + az[iz];
+        uint32_t idx = (hashed ? ih : id) & mask;
+        idx -= (idx >= size) ? size : 0u;                               // non-power-of-two (dense) sizes: index < 2*size, so % size is one subtract
         idx = min(idx, size - 1u);                                      // memory safety for positions far outside [0,1]^3 (never produced by the sampler)
         f(k, idx, (wx[ix] * wy[iy]) * wz[iz]);                          // same product order as the reference walk: ((1 * wx) * wy) * wz
     }
@@ -115,7 +113,7 @@ template <int EPAD, int W, int NH> struct FusedShape {
     static constexpr int F_W0T = F_W1T + (NH == 2 ? MB * KSW : 0);   // [KSW]
     static constexpr int N_FRAGS = F_W0T + KSW;
     static constexpr int FRAG_BYTES = N_FRAGS * 1024;
-    static constexpr int LT_BYTES = 256;                             // LevelLds (49 words)
+    static constexpr int LT_BYTES = 512;                             // LevelLds (113 words)
     // per-wave transpose scratch, fp16 [row][32 samples]
     static constexpr int SCR_E = 0;                                  // EPAD rows
     static constexpr int SCR_HA = SCR_E + EPAD * 32;                 // W rows: last hidden layer / its gradient
@@ -132,7 +130,7 @@ template <int EPAD, int W, int NH> struct FusedShape {
 };
 
 struct FusedArgs {
-    LevelTable lt; NetDims nd; ObjectConst oc; BatchPtrs b;
+    LevelFast lt; NetDims nd; ObjectConst oc; BatchPtrs b;
     const uint16_t* params;     // fp16 parameter vector (MLP matrices then grid)
     uint16_t* ggrid;            // fp16 grid gradient table
     float* partials;            // [gridDim.x][N_MLP + 64] fp32: dW partial sums, slot N_MLP = loss partial
@@ -149,7 +147,10 @@ __device__ __forceinline__ void build_fragments(half_t* frags, LevelLds* llt, co
     using S = FusedShape<EPAD, W, NH>;
     const half_t* w = reinterpret_cast<const half_t*>(a.params);
     const int L = a.nd.L, LPH = (L + 1) >> 1;
-    for (int i = threadIdx.x; i <= kMaxLevels; i += blockDim.x) { llt->offset[i] = a.lt.offset[i]; if (i < kMaxLevels) { llt->res[i] = a.lt.res[i]; llt->scale[i] = a.lt.scale[i]; } }
+    for (int i = threadIdx.x; i <= kMaxLevels; i += blockDim.x) {
+        llt->offset[i] = a.lt.offset[i];
+        if (i < kMaxLevels) { llt->scale[i] = a.lt.scale[i]; llt->size[i] = a.lt.size[i]; llt->my[i] = a.lt.my[i]; llt->mz[i] = a.lt.mz[i]; llt->mask[i] = a.lt.mask[i]; llt->hashed[i] = a.lt.hashed[i]; }
+    }
     const int total = (backward ? S::N_FRAGS : S::F_WOT) * 512;
     for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
         const int frag = idx >> 9, lane = (idx >> 3) & 63, j = idx & 7, m = lane & 31, h = lane >> 5;
@@ -558,7 +559,7 @@ constexpr uint32_t kScatterTile = 16384;          // entries per LDS tile: 2 x i
 constexpr uint32_t kScatterWgPerLevel = 16;
 constexpr float kFixScale = 16777216.0f;          // 2^24
 
-__global__ void __launch_bounds__(1024) k_grid_scatter(LevelTable lt, ScatterLevels sl, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa,
+__global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLevels sl, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa,
                                                        uint32_t B, half2_t* __restrict__ gpart, uint32_t part_stride, const DevState* __restrict__ st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (st->n_valid == 0u) return;
@@ -566,15 +567,14 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelTable lt, ScatterLev
     const uint32_t slot = blockIdx.x / kScatterWgPerLevel, j = blockIdx.x - slot * kScatterWgPerLevel;
     const int level = sl.level[slot]; const uint32_t P = sl.P[level];
     const uint32_t part = j / P, p = j - part * P;
-    const uint32_t off = lt.offset[level], size = lt.offset[level + 1] - off, res = lt.res[level];
+    const uint32_t off = lt.offset[level], size = lt.size[level], my = lt.my[level], mz = lt.mz[level], mask = lt.mask[level];
+    const bool hashed = lt.hashed[level] != 0u;
     const float scale = lt.scale[level];
     const uint32_t base = part * kScatterTile;
     if (base >= size) return;                                   // levels whose part count does not divide 16
     const uint32_t tile = min(kScatterTile, size - base);
     for (uint32_t i = threadIdx.x; i < 2u * tile; i += blockDim.x) tab[i] = 0;
     __syncthreads();
-    const uint32_t r2 = res * res; const bool hashed = (uint64_t)res * res * res > (uint64_t)size;
-    const uint32_t my = hashed ? 2654435761u : res, mz = hashed ? 805459861u : r2;
     const uint32_t per = (B + P - 1) / P, s_begin = p * per, s_end = min(B, s_begin + per);
     const half2_t* de = de_soa + (size_t)level * B;
     // The loop is latency-bound if run one sample at a time (dependent loads, 16 waves per CU): fetch a batch
@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelTable lt, ScatterLev
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
-                uint32_t idx = hashed ? ((ax[k & 1] ^ ay[(k >> 1) & 1] ^ az[k >> 2]) & (size - 1u)) : (ax[k & 1] + ay[(k >> 1) & 1] + az[k >> 2]);
+                uint32_t idx = (hashed ? (ax[k & 1] ^ ay[(k >> 1) & 1] ^ az[k >> 2]) : (ax[k & 1] + ay[(k >> 1) & 1] + az[k >> 2])) & mask;
                 idx -= (idx >= size) ? size : 0u; idx = min(idx, size - 1u);
                 const uint32_t local = idx - base;
                 if (local < tile) {
@@ -637,11 +637,11 @@ uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl
 }
 uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd) { ScatterLevels sl; return scatter_plan(lt, nd, sl); }
 
-void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, const DevState* st) {
+void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, const DevState* st) {
     ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return;
     static bool attr_done = false;
     if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, kScatterTile * 8); attr_done = true; }
-    hipLaunchKernelGGL(k_grid_scatter, dim3(sl.n_levels * kScatterWgPerLevel), dim3(1024), kScatterTile * 8, s, lt, sl, reinterpret_cast<const half2_t*>(de_soa), x_soa, B,
+    hipLaunchKernelGGL(k_grid_scatter, dim3(sl.n_levels * kScatterWgPerLevel), dim3(1024), kScatterTile * 8, s, lf, sl, reinterpret_cast<const half2_t*>(de_soa), x_soa, B,
                        reinterpret_cast<half2_t*>(gpart), part_stride_entries, st);
 }
 
@@ -742,14 +742,14 @@ static void fused_render_t(hipStream_t s, const FusedArgs& a, uint32_t n_rays, u
         }                                                                                      \
     } while (0)
 
-void launch_fused_train(hipStream_t s, const LevelTable& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
+void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
                         uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask) {
     static const uint32_t ablate = std::getenv("MON_FUSED_ABLATE") ? (uint32_t)std::atoi(std::getenv("MON_FUSED_ABLATE")) : 0u;
     FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, ablate };
     const uint32_t grid = fused_train_grid(nd, oc.R);
     MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);
 }
-void launch_fused_render(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask) {
+void launch_fused_render(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask) {
     FusedArgs a{ lt, nd, oc, b, params, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u };
     MON_FUSED_DISPATCH(fused_render_t, s, a, n_rays, idx_base, rgb, depth, mask);
 }

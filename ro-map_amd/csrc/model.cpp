@@ -92,6 +92,7 @@ int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* 
     int rc = level_table_build(cfg, m.lt, m.nd, m.n_grid);
     if (rc) { delete mp; return rc; }
     m.n_params = m.nd.n_mlp + m.n_grid;
+    level_fast_build(m.lt, m.nd, m.lf);
     HIPCHECK(hipSetDevice(m.device));
     std::memcpy(m.oc.Tow.m, Tow, 64);
     for (int a = 0; a < 3; ++a) { m.oc.aabb.mn[a] = amin[a]; m.oc.aabb.mx[a] = amax[a]; }
@@ -223,8 +224,8 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_weight_grads(s, m.nd, m.B.E, m.B.Hid, m.B.dHid, m.B.dO, m.P.gmlp, B, m.d_state);
             launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
         } else {
-            launch_fused_train(s, m.lt, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask);
-            if (m.lds_mask) launch_grid_scatter(s, m.lt, m.nd, m.d_de_soa, m.d_x_soa, B, m.d_gpart, m.n_grid / 2, m.d_state);
+            launch_fused_train(s, m.lf, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask);
+            if (m.lds_mask) launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.d_gpart, m.n_grid / 2, m.d_state);
             launch_reduce_partials(s, m.d_dw_partials, fused_train_grid(m.nd, m.oc.R), m.nd.n_mlp + 64, m.nd.n_mlp, m.P.gmlp, m.d_state);
         }
     }
@@ -291,7 +292,7 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
                 launch_mlp_forward(s, m.nd, prm, m.B.E, nullptr, m.B.O, n * S2, nullptr);
                 launch_composite_render(s, m.B, S2, n, m.d_out_rgb, m.d_out_depth, m.d_out_mask);
             } else {
-                launch_fused_render(s, m.lt, m.nd, prm, m.B, m.oc, n, p0 * S2, m.d_out_rgb, m.d_out_depth, m.d_out_mask);
+                launch_fused_render(s, m.lf, m.nd, prm, m.B, m.oc, n, p0 * S2, m.d_out_rgb, m.d_out_depth, m.d_out_mask);
             }
         }
         HIPCHECK(hipMemcpyAsync(rgb + 3 * (size_t)p0, m.d_out_rgb, 12 * (size_t)n, kind, s));

@@ -104,12 +104,12 @@ void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_par
 // fused MFMA path (kernels_fused.hip)
 bool fused_supported(const NetDims& nd, uint32_t S);
 uint32_t fused_train_grid(const NetDims& nd, uint32_t R);
-void launch_fused_train(hipStream_t s, const LevelTable& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
+void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
                         uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask);
 uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl);
 uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd);
-void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, const DevState* st);
-void launch_fused_render(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask);
+void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, const DevState* st);
+void launch_fused_render(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask);
 int selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
 
 // ---- host classes
@@ -122,7 +122,7 @@ struct Dataset {
 
 struct Model {
     Dataset* ds = nullptr; mon_config cfg{}; int device = 0;
-    LevelTable lt{}; NetDims nd{}; ObjectConst oc{}; OptimConst opt{};
+    LevelTable lt{}; LevelFast lf{}; NetDims nd{}; ObjectConst oc{}; OptimConst opt{};
     uint32_t n_grid = 0, n_params = 0;
     hipStream_t train_stream = nullptr, infer_stream = nullptr;
     ParamPtrs P{}; BatchPtrs B{}; DevState* d_state = nullptr; mon_frame_bbox* d_boxes = nullptr;
@@ -135,6 +135,7 @@ struct Model {
 };
 
 int level_table_build(const mon_config& c, LevelTable& lt, NetDims& nd, uint32_t& n_grid);
+void level_fast_build(const LevelTable& lt, const NetDims& nd, LevelFast& lf);
 void init_params_host(const mon_config& c, const NetDims& nd, uint32_t n_params, std::vector<float>& master);
 
 }  // namespace mon

@@ -78,3 +78,22 @@ def test_product_does_not_reference_the_oracle():
     assert not bad, bad
     out = os.popen("ldd %s" % os.path.join(ROOT, "ro-map_amd", "libmon_core.so")).read()
     assert "oracle" not in out
+
+
+def test_closed_form_corner_index_matches_tcnn_loop(pkg, orc):
+    """The fused kernels' per-level index constants (built on the host) against the oracle's restatement of tcnn's
+    grid_index loop, for every level of several configurations -- including the uint32 stride wrap-around at res = 2^16."""
+    import ctypes as C
+    import numpy as np
+    rs = np.random.RandomState(0)
+    for kw in (dict(), dict(log2_hashmap_size=19), dict(log2_hashmap_size=22), dict(base_resolution=20, n_levels=8), dict(n_levels=4),
+               dict(base_resolution=24, per_level_scale=1.5, n_levels=12, log2_hashmap_size=15)):
+        cfg = pkg.default_config(**kw); ocfg = orc.default_config(**kw)
+        off = np.zeros(33, np.uint32); sc = np.zeros(32, np.float32); res = np.zeros(32, np.uint32)
+        orc.lib().orc_level_table(C.byref(ocfg), off.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p))
+        for l in range(cfg.n_levels):
+            size = int(off[l + 1] - off[l]); r = int(res[l])
+            pts = [tuple(int(v) for v in rs.randint(0, r + 1, 3)) for _ in range(200)] + [(0, 0, 0), (r, r, r), (r, 0, 0), (0, r, 0), (0, 0, r), (r - 1, r, r)]
+            for (x, y, z) in pts:
+                got, n = pkg.fast_index(cfg, l, x, y, z)
+                assert n == size and got == orc.lib().orc_grid_index(size, r, x, y, z), (kw, l, r, size, x, y, z)
