@@ -559,26 +559,11 @@ constexpr uint32_t kScatterTile = 16384;          // entries per LDS tile: 2 x i
 constexpr uint32_t kScatterWgPerLevel = 16;
 constexpr float kFixScale = 16777216.0f;          // 2^24
 
-__global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLevels sl, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa,
-                                                       uint32_t B, half2_t* __restrict__ gpart, uint32_t part_stride, const DevState* __restrict__ st) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (st->n_valid == 0u) return;
-    int* tab = reinterpret_cast<int*>(smem);
-    const uint32_t slot = blockIdx.x / kScatterWgPerLevel, j = blockIdx.x - slot * kScatterWgPerLevel;
-    const int level = sl.level[slot]; const uint32_t P = sl.P[level];
-    const uint32_t part = j / P, p = j - part * P;
-    const uint32_t off = lt.offset[level], size = lt.size[level], my = lt.my[level], mz = lt.mz[level], mask = lt.mask[level];
-    const bool hashed = lt.hashed[level] != 0u;
-    const float scale = lt.scale[level];
-    const uint32_t base = part * kScatterTile;
-    if (base >= size) return;                                   // levels whose part count does not divide 16
-    const uint32_t tile = min(kScatterTile, size - base);
-    for (uint32_t i = threadIdx.x; i < 2u * tile; i += blockDim.x) tab[i] = 0;
-    __syncthreads();
-    const uint32_t per = (B + P - 1) / P, s_begin = p * per, s_end = min(B, s_begin + per);
-    const half2_t* de = de_soa + (size_t)level * B;
-    // The loop is latency-bound if run one sample at a time (dependent loads, 16 waves per CU): fetch a batch
-    // of kBatch samples per thread with independent loads first, then do the index math + LDS atomics.
+template <bool HASHED, bool POW2>
+__device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restrict__ de, const float* __restrict__ x_soa, uint32_t B, uint32_t s_begin, uint32_t s_end,
+                                                float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask, uint32_t base, uint32_t tile) {
+    // The loop is latency-bound if run one sample at a time: fetch a batch of kBatch samples per thread with independent
+    // loads first, then do the index math + LDS integer atomics.  Out-of-tile corners cost 4 instructions.
     constexpr int kBatch = 8;
     for (uint32_t s0 = s_begin + threadIdx.x; s0 < s_end; s0 += blockDim.x * kBatch) {
         half2_t g[kBatch]; float xs[kBatch][3];
@@ -590,28 +575,55 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
         }
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
-            const float g0 = (float)g[u].x, g1 = (float)g[u].y;
+            float g0 = (float)g[u].x, g1 = (float)g[u].y;
             if (g0 == 0.f && g1 == 0.f) continue;
+            g0 = clamp_f(g0, -100.f, 100.f); g1 = clamp_f(g1, -100.f, 100.f);          // keeps |contribution| * 2^24 inside int32
             float pos[3]; uint32_t pg[3];
 #pragma unroll
             for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, xs[u][d], 0.5f), fl = floorf(q); pg[d] = (uint32_t)(int32_t)fl; pos[d] = q - fl; }
             const uint32_t ax[2] = { pg[0], pg[0] + 1u }, y0 = pg[1] * my, z0 = pg[2] * mz, ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
+            uint32_t ayz[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ayz[j] = HASHED ? (ay[j & 1] ^ az[j >> 1]) : (ay[j & 1] + az[j >> 1]);
             const float wx[2] = { 1.f - pos[0], pos[0] }, wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
-                uint32_t idx = (hashed ? (ax[k & 1] ^ ay[(k >> 1) & 1] ^ az[k >> 2]) : (ax[k & 1] + ay[(k >> 1) & 1] + az[k >> 2])) & mask;
-                idx -= (idx >= size) ? size : 0u; idx = min(idx, size - 1u);
+                uint32_t idx = (HASHED ? (ax[k & 1] ^ ayz[k >> 1]) : (ax[k & 1] + ayz[k >> 1])) & mask;
+                if (!POW2) { idx -= (idx >= size) ? size : 0u; idx = min(idx, size - 1u); }
                 const uint32_t local = idx - base;
                 if (local < tile) {
-                    const float c0 = clamp_f((float)(half_t)(w * g0), -100.f, 100.f), c1 = clamp_f((float)(half_t)(w * g1), -100.f, 100.f);   // tcnn: (T)(weight * grad)
-                    const int f0 = (int)(c0 * kFixScale), f1 = (int)(c1 * kFixScale);                                                       // exact: fp16 values are multiples of 2^-24
+                    const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
+                    const int f0 = (int)((float)(half_t)(w * g0) * kFixScale), f1 = (int)((float)(half_t)(w * g1) * kFixScale);   // tcnn: (T)(weight * grad); exact in 2^-24 units
                     if (f0) atomicAdd(tab + 2u * local, f0);
                     if (f1) atomicAdd(tab + 2u * local + 1u, f1);
                 }
             }
         }
     }
+}
+
+__global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLevels sl, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa,
+                                                       uint32_t B, half2_t* __restrict__ gpart, uint32_t part_stride, const DevState* __restrict__ st) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (st->n_valid == 0u) return;
+    int* tab = reinterpret_cast<int*>(smem);
+    const uint32_t slot = blockIdx.x / kScatterWgPerLevel, j = blockIdx.x - slot * kScatterWgPerLevel;
+    const int level = sl.level[slot]; const uint32_t P = sl.P[level];
+    const uint32_t part = j / P, p = j - part * P;
+    const uint32_t off = lt.offset[level], size = lt.size[level], my = lt.my[level], mz = lt.mz[level], mask = lt.mask[level];
+    const bool hashed = lt.hashed[level] != 0u, pow2 = mask != 0xffffffffu;
+    const float scale = lt.scale[level];
+    const uint32_t base = part * kScatterTile;
+    if (base >= size) return;                                   // levels whose part count does not divide 16
+    const uint32_t tile = min(kScatterTile, size - base);
+    for (uint32_t i = threadIdx.x; i < 2u * tile; i += blockDim.x) tab[i] = 0;
+    __syncthreads();
+    const uint32_t per = (B + P - 1) / P, s_begin = p * per, s_end = min(B, s_begin + per);
+    const half2_t* de = de_soa + (size_t)level * B;
+    if (hashed) { if (pow2) scatter_samples<true, true>(tab, de, x_soa, B, s_begin, s_end, scale, size, my, mz, mask, base, tile);
+                  else scatter_samples<true, false>(tab, de, x_soa, B, s_begin, s_end, scale, size, my, mz, mask, base, tile); }
+    else { if (pow2) scatter_samples<false, true>(tab, de, x_soa, B, s_begin, s_end, scale, size, my, mz, mask, base, tile);
+           else scatter_samples<false, false>(tab, de, x_soa, B, s_begin, s_end, scale, size, my, mz, mask, base, tile); }
     __syncthreads();
     half2_t* dst = gpart + (size_t)p * part_stride + off + base;
     for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x)

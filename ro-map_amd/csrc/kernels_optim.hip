@@ -114,10 +114,10 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
             *ep = e;
         }
     }
-    // ---- last block advances the counters (one ticket per block)
+    // ---- last block advances the counters (one ticket per block).  No fence: the other blocks only READ the state
+    //      (at kernel entry, before their ticket), and a __threadfence() here costs an L2 write-back per block.
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
         const uint32_t t = atomicAdd(&st->ticket, 1u);
         if (t == gridDim.x - 1u) {
             st->ticket = 0u;
@@ -128,7 +128,6 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
             } else {
                 st->skipped = st->skipped + 1u;
             }
-            __threadfence();
         }
     }
 }
@@ -158,7 +157,7 @@ void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_par
 
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st) {
     const uint32_t chunks = oc.n_params >> 3;
-    uint32_t blocks = (chunks + 255) / 256; if (blocks > 2048u) blocks = 2048u; if (blocks < 1u) blocks = 1u;     // one chunk per thread up to 4 M parameters
+    uint32_t blocks = (chunks + 255) / 256; if (blocks > 1024u) blocks = 1024u; if (blocks < 1u) blocks = 1u;     // one chunk per thread up to 4 M parameters
     hipLaunchKernelGGL(k_optimizer, dim3(blocks), dim3(256), 0, s, p, oc, st);
 }
 
