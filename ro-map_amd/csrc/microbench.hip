@@ -28,14 +28,16 @@ __global__ void __launch_bounds__(256) k_ub(int mode, int pattern, uint32_t n_en
         else if (mode == 1) __builtin_amdgcn_global_atomic_fadd_v2f16(t16 + (size_t)xcc * n_entries + idx, v);
         else if (mode == 2) atomicAdd(reinterpret_cast<float*>(table) + idx, 1e-3f);
         else if (mode == 3) { const half2_t g = reinterpret_cast<const half2_t*>(table)[idx]; acc += (float)g.x + (float)g.y; }
-        else { const uint32_t b = (idx & ~7u) + ((idx + (i & 7u)) & 7u); __builtin_amdgcn_global_atomic_fadd_v2f16(t16 + b, v); }
+        else if (mode == 4) { const uint32_t b = (idx & ~7u) + ((idx + (i & 7u)) & 7u); __builtin_amdgcn_global_atomic_fadd_v2f16(t16 + b, v); }
+        else if (mode == 5) { const uint4 g = reinterpret_cast<const uint4*>(table)[idx >> 2]; acc += __uint_as_float(g.x ^ g.y ^ g.z ^ g.w); }      // 16-byte aligned quad gather
+        else { const uint2 g = reinterpret_cast<const uint2*>(table)[idx >> 1]; acc += __uint_as_float(g.x ^ g.y); }                          // mode 6: 8-byte pair gather
     }
     if (acc == 123.456f) sink[0] = acc;
 }
 
 // LDS atomics on a 128 KB tile, 1024 threads per workgroup, one workgroup per CU.
 // mode 10: ds_pk_add_f16 random   11: ds_add_f32 random   12: ds_add_u32 random
-// mode 13: ds_pk_add_f16, lane pairs share an address   14: ds_write_b32 random (no atomic)   15: ds_pk_add_f16, 4 lanes share
+// mode 13: ds_pk_add_f16, lane pairs share an address   14: ds_write_b32 random (no atomic)   15: ds_pk_add_f16, 4 lanes share   16: ds_add_u64 random
 __global__ void __launch_bounds__(1024) k_ub_lds(int mode, uint32_t ops_per_thread, float* __restrict__ sink) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
@@ -51,6 +53,7 @@ __global__ void __launch_bounds__(1024) k_ub_lds(int mode, uint32_t ops_per_thre
         if (mode == 10 || mode == 13 || mode == 15) __builtin_amdgcn_ds_atomic_fadd_v2f16((lh2*)reinterpret_cast<half2_t*>(tab) + idx, v);
         else if (mode == 11) atomicAdd(reinterpret_cast<float*>(tab) + idx, 1e-3f);
         else if (mode == 12) atomicAdd(tab + idx, 1u);
+        else if (mode == 16) atomicAdd(reinterpret_cast<unsigned long long*>(tab) + (idx >> 1), 0x0000000100000001ull);
         else tab[idx] = i;
     }
     __syncthreads();
