@@ -219,39 +219,8 @@ __device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const h
         const int level = h * LPH + il;
         float a0 = 0.f, a1 = 0.f;
         if (il < LPH && level < L) {
-            // The gather is bound by the L2 REQUEST rate (~280 G requests/s chip-wide, the same for 4-, 8- and 16-byte
-            // accesses: profiles/r01_microbench.md).  The two x-neighbours of a corner pair usually sit in one aligned
-            // group of four entries (hashed: idx ^ (x+1) flips only bits 0..1 unless x % 4 == 3; dense: idx + 1), so one
-            // 16-byte load serves both and only ~25 % of the lanes issue a second (4-byte) load: ~5 requests per level
-            // instead of 8.  Accumulation order (k = 0..7, x fastest) is unchanged.
-            const uint32_t* tl = reinterpret_cast<const uint32_t*>(table + llt.offset[level]);
-            const float scale = llt.scale[level];
-            const uint32_t size = llt.size[level], my = llt.my[level], mz = llt.mz[level], mask = llt.mask[level];
-            const bool hashed = llt.hashed[level] != 0u;
-            float pos[3]; uint32_t pg[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { const float p = fmaf(scale, x[d], 0.5f), fl = floorf(p); pg[d] = (uint32_t)(int32_t)fl; pos[d] = p - fl; }
-            const uint32_t y0 = pg[1] * my, z0 = pg[2] * mz;
-            const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
-            const float wx0 = 1.f - pos[0], wx1 = pos[0];
-            const float wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t t = hashed ? (ay[j & 1] ^ az[j >> 1]) : (ay[j & 1] + az[j >> 1]);
-                uint32_t i0 = (hashed ? (pg[0] ^ t) : (pg[0] + t)) & mask, i1 = (hashed ? ((pg[0] + 1u) ^ t) : (pg[0] + 1u + t)) & mask;
-                i0 -= (i0 >= size) ? size : 0u; i0 = min(i0, size - 1u);
-                i1 -= (i1 >= size) ? size : 0u; i1 = min(i1, size - 1u);
-                const uint4 q = *reinterpret_cast<const uint4*>(tl + (i0 & ~3u));
-                const uint32_t k0 = i0 & 3u, k1 = i1 & 3u;
-                const uint32_t u0 = k0 == 0u ? q.x : (k0 == 1u ? q.y : (k0 == 2u ? q.z : q.w));
-                uint32_t u1 = k1 == 0u ? q.x : (k1 == 1u ? q.y : (k1 == 2u ? q.z : q.w));
-                if ((i0 >> 2) != (i1 >> 2)) u1 = tl[i1];
-                const half2_t v0 = __builtin_bit_cast(half2_t, u0), v1 = __builtin_bit_cast(half2_t, u1);
-                const float wyz_lo = wx0 * wy[j & 1], wyz_hi = wx1 * wy[j & 1];       // ((1 * wx) * wy) * wz, as in the reference walk
-                const float w0 = wyz_lo * wz[j >> 1], w1 = wyz_hi * wz[j >> 1];
-                a0 = fmaf(w0, (float)v0.x, a0); a1 = fmaf(w0, (float)v0.y, a1);
-                a0 = fmaf(w1, (float)v1.x, a0); a1 = fmaf(w1, (float)v1.y, a1);
-            }
+            const half2_t* tl = table + llt.offset[level];
+            level_corners(llt, level, x, [&](int, uint32_t idx, float wgt) { const half2_t v = tl[idx]; a0 = fmaf(wgt, (float)v.x, a0); a1 = fmaf(wgt, (float)v.y, a1); });
         }
         ts.ef[2 * il] = (half_t)a0; ts.ef[2 * il + 1] = (half_t)a1;
     }
@@ -591,7 +560,7 @@ constexpr uint32_t kScatterWgPerLevel = 16;
 constexpr float kFixScale = 16777216.0f;          // 2^24
 
 template <bool HASHED, bool POW2>
-__device__ __forceinline__ void scatter_samples(unsigned long long* tab, const half2_t* __restrict__ de, const float* __restrict__ x_soa, uint32_t B, uint32_t s_begin, uint32_t s_end,
+__device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restrict__ de, const float* __restrict__ x_soa, uint32_t B, uint32_t s_begin, uint32_t s_end,
                                                 float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask, uint32_t base, uint32_t tile) {
     // The loop is latency-bound if run one sample at a time: fetch a batch of kBatch samples per thread with independent
     // loads first, then do the index math + LDS integer atomics.  Out-of-tile corners cost 4 instructions.
@@ -625,10 +594,8 @@ __device__ __forceinline__ void scatter_samples(unsigned long long* tab, const h
                 if (local < tile) {
                     const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
                     const int f0 = (int)((float)(half_t)(w * g0) * kFixScale), f1 = (int)((float)(half_t)(w * g1) * kFixScale);   // tcnn: (T)(weight * grad); exact in 2^-24 units
-                    // both features in ONE 64-bit LDS atomic: value = f1 * 2^32 + f0 with f0 sign-extended, i.e. exact integer
-                    // arithmetic in base 2^32 with a signed low digit (ds_add_u64 runs at the ds_add_u32 rate: profiles/r01_microbench.md)
-                    const long long v = (long long)((unsigned long long)(unsigned)f1 << 32) + (long long)f0;
-                    if (v) atomicAdd(tab + local, (unsigned long long)v);
+                    if (f0) atomicAdd(tab + 2u * local, f0);
+                    if (f1) atomicAdd(tab + 2u * local + 1u, f1);
                 }
             }
         }
@@ -639,7 +606,7 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
                                                        uint32_t B, half2_t* __restrict__ gpart, uint32_t part_stride, const DevState* __restrict__ st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (st->n_valid == 0u) return;
-    unsigned long long* tab = reinterpret_cast<unsigned long long*>(smem);
+    int* tab = reinterpret_cast<int*>(smem);
     const uint32_t slot = blockIdx.x / kScatterWgPerLevel, j = blockIdx.x - slot * kScatterWgPerLevel;
     const int level = sl.level[slot]; const uint32_t P = sl.P[level];
     const uint32_t part = j / P, p = j - part * P;
@@ -649,7 +616,7 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
     const uint32_t base = part * kScatterTile;
     if (base >= size) return;                                   // levels whose part count does not divide 16
     const uint32_t tile = min(kScatterTile, size - base);
-    for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) tab[i] = 0ull;
+    for (uint32_t i = threadIdx.x; i < 2u * tile; i += blockDim.x) tab[i] = 0;
     __syncthreads();
     const uint32_t per = (B + P - 1) / P, s_begin = p * per, s_end = min(B, s_begin + per);
     const half2_t* de = de_soa + (size_t)level * B;
@@ -659,12 +626,8 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
            else scatter_samples<false, false>(tab, de, x_soa, B, s_begin, s_end, scale, size, my, mz, mask, base, tile); }
     __syncthreads();
     half2_t* dst = gpart + (size_t)p * part_stride + off + base;
-    for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) {
-        const long long tot = (long long)tab[i];
-        const int s0 = (int)(unsigned)(unsigned long long)tot;                 // signed low digit
-        const int s1 = (int)((tot - (long long)s0) >> 32);                      // high digit after removing the borrow
-        dst[i] = half2_t{ (half_t)((float)s0 * (1.0f / kFixScale)), (half_t)((float)s1 * (1.0f / kFixScale)) };
-    }
+    for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x)
+        dst[i] = half2_t{ (half_t)((float)tab[2u * i] * (1.0f / kFixScale)), (half_t)((float)tab[2u * i + 1u] * (1.0f / kFixScale)) };
 }
 
 // Host: which levels go through the LDS scatter, with how many sample partitions each.
