@@ -138,46 +138,62 @@ struct FusedArgs {
     half2_t* de_soa;            // [L][B] dL/dE of the levels scattered through LDS (k_grid_scatter), or nullptr
     float* x_soa;               // [3][B] warped sample positions for k_grid_scatter
     uint32_t lds_level_mask;    // bit l set: level l goes through k_grid_scatter instead of global atomics
-    uint32_t ablate;            // timing experiments only (MON_FUSED_ABLATE): 2 no dW, 4 no dE/x stores
+    const uint16_t* frag_image; // A fragments in LDS layout (k_build_frag_image), N_FRAGS x 512 halves
+    uint32_t ablate;            // timing experiments only (MON_FUSED_ABLATE): 2 no dW, 4 no dE/x stores, 8 no rays (prologue + epilogue only)
 };
 
-// Builds the A fragments (weights pre-permuted to K-slot order) and the level table in LDS.
+// A fragments: the weight matrices pre-permuted to K-slot order (see the header).  They depend only on the weights,
+// so they are built ONCE per step by k_build_frag_image into a global image that every workgroup of the fused
+// kernels copies into LDS with 16-byte loads (building them per workgroup cost ~28 dependent 2-byte loads per thread).
+template <int EPAD, int W, int NH>
+__device__ __forceinline__ half_t frag_element(const half_t* __restrict__ w, int L, int idx) {
+    using S = FusedShape<EPAD, W, NH>;
+    const int LPH = (L + 1) >> 1;
+    const int frag = idx >> 9, lane = (idx >> 3) & 63, j = idx & 7, m = lane & 31, h = lane >> 5;
+    half_t v = (half_t)0.f;
+    if (frag < S::F_W1) {                                   // W0: rows = units, K slots = encoded features of the owning half
+        const int mb = (frag - S::F_W0) / S::KS0, s = (frag - S::F_W0) % S::KS0;
+        const int il = 4 * s + (j >> 1), level = h * LPH + il;
+        if (il < LPH && level < L) v = w[(32 * mb + m) * EPAD + 2 * level + (j & 1)];
+    } else if (NH == 2 && frag < S::F_WO) {                 // W1: rows = units of layer 1, K slots = units of layer 0
+        const int mb = (frag - S::F_W1) / S::KSW, s = (frag - S::F_W1) % S::KSW;
+        v = w[S::OFF_W1 + (32 * mb + m) * W + unit_of_slot(s, h, j)];
+    } else if (frag < S::F_WOT) {                           // Wout: 4 real rows of 32
+        const int s = frag - S::F_WO;
+        if (m < kOut) v = w[S::OFF_WO + m * W + unit_of_slot(s, h, j)];
+    } else if (frag < S::F_W1T) {                           // Wout^T: rows = units, K slots 0..3 = output channels
+        const int mb = frag - S::F_WOT, c = 8 * h + j;
+        if (c < kOut) v = w[S::OFF_WO + c * W + 32 * mb + m];
+    } else if (NH == 2 && frag < S::F_W0T) {                // W1^T: rows = units of layer 0, K slots = units of layer 1
+        const int mb = (frag - S::F_W1T) / S::KSW, s = (frag - S::F_W1T) % S::KSW;
+        v = w[S::OFF_W1 + unit_of_slot(s, h, j) * W + 32 * mb + m];
+    } else {                                                // W0^T: row m = (half hh, reg r) <-> local feature r of half hh
+        const int s = frag - S::F_W0T;
+        const int hh = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3), il = r >> 1, level = hh * LPH + il;
+        if (il < LPH && level < L && r < EPAD / 2) v = w[unit_of_slot(s, h, j) * EPAD + 2 * level + (r & 1)];
+    }
+    return v;
+}
+
+template <int EPAD, int W, int NH>
+__global__ void __launch_bounds__(256) k_build_frag_image(const uint16_t* __restrict__ params, int L, uint16_t* __restrict__ image, const DevState* __restrict__ st) {
+    using S = FusedShape<EPAD, W, NH>;
+    if (st && st->n_valid == 0u) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < S::N_FRAGS * 512) reinterpret_cast<half_t*>(image)[idx] = frag_element<EPAD, W, NH>(reinterpret_cast<const half_t*>(params), L, idx);
+}
+
+// Workgroup prologue: fragment image + level constants -> LDS.
 template <int EPAD, int W, int NH>
 __device__ __forceinline__ void build_fragments(half_t* frags, LevelLds* llt, const FusedArgs& a, bool backward) {
     using S = FusedShape<EPAD, W, NH>;
-    const half_t* w = reinterpret_cast<const half_t*>(a.params);
-    const int L = a.nd.L, LPH = (L + 1) >> 1;
     for (int i = threadIdx.x; i <= kMaxLevels; i += blockDim.x) {
         llt->offset[i] = a.lt.offset[i];
         if (i < kMaxLevels) { llt->scale[i] = a.lt.scale[i]; llt->size[i] = a.lt.size[i]; llt->my[i] = a.lt.my[i]; llt->mz[i] = a.lt.mz[i]; llt->mask[i] = a.lt.mask[i]; llt->hashed[i] = a.lt.hashed[i]; }
     }
-    const int total = (backward ? S::N_FRAGS : S::F_WOT) * 512;
-    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-        const int frag = idx >> 9, lane = (idx >> 3) & 63, j = idx & 7, m = lane & 31, h = lane >> 5;
-        half_t v = (half_t)0.f;
-        if (frag < S::F_W1) {                                   // W0: rows = units, K slots = encoded features of the owning half
-            const int mb = (frag - S::F_W0) / S::KS0, s = (frag - S::F_W0) % S::KS0;
-            const int il = 4 * s + (j >> 1), level = h * LPH + il;
-            if (il < LPH && level < L) v = w[(32 * mb + m) * EPAD + 2 * level + (j & 1)];
-        } else if (NH == 2 && frag < S::F_WO) {                 // W1: rows = units of layer 1, K slots = units of layer 0
-            const int mb = (frag - S::F_W1) / S::KSW, s = (frag - S::F_W1) % S::KSW;
-            v = w[S::OFF_W1 + (32 * mb + m) * W + unit_of_slot(s, h, j)];
-        } else if (frag < S::F_WOT) {                           // Wout: 4 real rows of 32
-            const int s = frag - S::F_WO;
-            if (m < kOut) v = w[S::OFF_WO + m * W + unit_of_slot(s, h, j)];
-        } else if (frag < S::F_W1T) {                           // Wout^T: rows = units, K slots 0..3 = output channels
-            const int mb = frag - S::F_WOT, c = 8 * h + j;
-            if (c < kOut) v = w[S::OFF_WO + c * W + 32 * mb + m];
-        } else if (NH == 2 && frag < S::F_W0T) {                // W1^T: rows = units of layer 0, K slots = units of layer 1
-            const int mb = (frag - S::F_W1T) / S::KSW, s = (frag - S::F_W1T) % S::KSW;
-            v = w[S::OFF_W1 + unit_of_slot(s, h, j) * W + 32 * mb + m];
-        } else {                                                // W0^T: row m = (half hh, reg r) <-> local feature r of half hh
-            const int s = frag - S::F_W0T;
-            const int hh = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3), il = r >> 1, level = hh * LPH + il;
-            if (il < LPH && level < L && r < EPAD / 2) v = w[unit_of_slot(s, h, j) * EPAD + 2 * level + (r & 1)];
-        }
-        frags[idx] = v;
-    }
+    const int total16 = (backward ? S::N_FRAGS : S::F_WOT) * 64;            // 16-byte pieces
+    const uint4* src = reinterpret_cast<const uint4*>(a.frag_image); uint4* dst = reinterpret_cast<uint4*>(frags);
+    for (int i = threadIdx.x; i < total16; i += blockDim.x) dst[i] = src[i];
 }
 
 __device__ __forceinline__ half8_t lds_frag(const half_t* frags, int frag, int lane) { return *reinterpret_cast<const half8_t*>(frags + frag * 512 + lane * 8); }
@@ -287,7 +303,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     __syncthreads();
 
     const int L = a.nd.L, LPH = (L + 1) >> 1;
-    const uint32_t R = a.oc.R, iter = a.st->iter, nvalid = a.st->n_valid;
+    const uint32_t R = (a.ablate & 8u) ? 0u : a.oc.R, iter = a.st->iter;
     const half2_t* table = reinterpret_cast<const half2_t*>(a.params + a.nd.n_mlp);
     typedef __attribute__((address_space(1))) half2_t gh2;
     gh2* gtable = (gh2*)reinterpret_cast<half2_t*>(a.ggrid);
@@ -725,6 +741,7 @@ static void fused_train_t(hipStream_t s, const FusedArgs& a, uint32_t grid, int 
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         attr_done = true;
     }
+    hipLaunchKernelGGL((k_build_frag_image<EPAD, W, NH>), dim3((S::N_FRAGS * 512 + 255) / 256), dim3(256), 0, s, a.params, a.nd.L, const_cast<uint16_t*>(a.frag_image), a.st);
     const bool all_lds = a.lds_level_mask != 0u && (a.lds_level_mask == ((a.nd.L >= 32) ? 0xffffffffu : ((1u << a.nd.L) - 1u)));
     if (dump) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
     else if (all_lds) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
@@ -735,6 +752,7 @@ static void fused_render_t(hipStream_t s, const FusedArgs& a, uint32_t n_rays, u
     using S = FusedShape<EPAD, W, NH>;
     const uint32_t smem = S::FRAG_BYTES + S::LT_BYTES;
     uint32_t grid = (n_rays + 3) / 4; if (grid > 2048u) grid = 2048u;
+    hipLaunchKernelGGL((k_build_frag_image<EPAD, W, NH>), dim3((S::F_WOT * 512 + 255) / 256), dim3(256), 0, s, a.params, a.nd.L, const_cast<uint16_t*>(a.frag_image), (const DevState*)nullptr);
     hipLaunchKernelGGL((k_fused_render<EPAD, W, NH>), dim3(grid), dim3(256), smem, s, a, n_rays, idx_base, rgb, depth, mask);
 }
 
@@ -755,14 +773,14 @@ static void fused_render_t(hipStream_t s, const FusedArgs& a, uint32_t n_rays, u
     } while (0)
 
 void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
-                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask) {
+                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image) {
     static const uint32_t ablate = std::getenv("MON_FUSED_ABLATE") ? (uint32_t)std::atoi(std::getenv("MON_FUSED_ABLATE")) : 0u;
-    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, ablate };
+    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate };
     const uint32_t grid = fused_train_grid(nd, oc.R);
     MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);
 }
-void launch_fused_render(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask) {
-    FusedArgs a{ lt, nd, oc, b, params, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u };
+void launch_fused_render(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask, uint16_t* frag_image) {
+    FusedArgs a{ lt, nd, oc, b, params, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, frag_image, 0u };
     MON_FUSED_DISPATCH(fused_render_t, s, a, n_rays, idx_base, rgb, depth, mask);
 }
 

@@ -134,6 +134,7 @@ int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* 
         (rc = dev_alloc(m, m.d_state, 1)) || (rc = dev_alloc(m, m.d_dw_partials, (size_t)(m.nd.n_mlp + 64) * 512)) ||
         (rc = dev_alloc(m, m.d_out_rgb, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_depth, kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_mask, kRenderChunkRays))) return rc;
     if (fused_supported(m.nd, S)) {
+        if ((rc = dev_alloc(m, m.d_frag_train, 64 * 512)) || (rc = dev_alloc(m, m.d_frag_render, 64 * 512))) return rc;       // <= 30 fragments of 512 halves
         m.lds_mask = scatter_plan(m.lt, m.nd, m.scatter);
         if (m.lds_mask && ((rc = dev_alloc(m, m.d_de_soa, (size_t)m.nd.L * Btrain * 2)) || (rc = dev_alloc(m, m.d_x_soa, 3 * (size_t)Btrain)) ||
                            (rc = dev_alloc(m, m.d_gpart, (size_t)m.scatter.max_P * m.n_grid)))) return rc;
@@ -224,7 +225,7 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_weight_grads(s, m.nd, m.B.E, m.B.Hid, m.B.dHid, m.B.dO, m.P.gmlp, B, m.d_state);
             launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
         } else {
-            launch_fused_train(s, m.lf, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask);
+            launch_fused_train(s, m.lf, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask, m.d_frag_train);
             if (m.lds_mask) launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.d_gpart, m.n_grid / 2, m.d_state);
             launch_reduce_partials(s, m.d_dw_partials, fused_train_grid(m.nd, m.oc.R), m.nd.n_mlp + 64, m.nd.n_mlp, m.P.gmlp, m.d_state);
         }
@@ -292,7 +293,7 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
                 launch_mlp_forward(s, m.nd, prm, m.B.E, nullptr, m.B.O, n * S2, nullptr);
                 launch_composite_render(s, m.B, S2, n, m.d_out_rgb, m.d_out_depth, m.d_out_mask);
             } else {
-                launch_fused_render(s, m.lf, m.nd, prm, m.B, m.oc, n, p0 * S2, m.d_out_rgb, m.d_out_depth, m.d_out_mask);
+                launch_fused_render(s, m.lf, m.nd, prm, m.B, m.oc, n, p0 * S2, m.d_out_rgb, m.d_out_depth, m.d_out_mask, m.d_frag_render);
             }
         }
         HIPCHECK(hipMemcpyAsync(rgb + 3 * (size_t)p0, m.d_out_rgb, 12 * (size_t)n, kind, s));
