@@ -124,8 +124,8 @@ template <int EPAD, int W, int NH> struct FusedShape {
     static constexpr int N_MLP = W * EPAD + (NH - 1) * W * W + kOutPad * W;
     static constexpr int OFF_W1 = W * EPAD;
     static constexpr int OFF_WO = W * EPAD + (NH - 1) * W * W;
-    static constexpr int RED_BYTES = (N_MLP + 64) * 4;
     static constexpr int WAVES = 4;
+    static constexpr int RED_BYTES = (N_MLP + 64) * 4 * WAVES;      // one private fp32 copy per wave
     static constexpr int SMEM_BYTES = FRAG_BYTES + LT_BYTES + ((WAVES * SCR_BYTES > RED_BYTES) ? WAVES * SCR_BYTES : RED_BYTES);
 };
 
@@ -532,32 +532,34 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         }
     }
 
-    // ---- reduce the weight-gradient accumulators over the workgroup's waves, write one fp32 partial
+    // ---- reduce the weight-gradient accumulators over the workgroup's waves, write one fp32 partial row.
+    //      Each wave stores its accumulators to a private LDS copy (independent plain stores; read-modify-write
+    //      rounds serialise on LDS latency), then all threads sum the four copies element-wise.
     __syncthreads();
-    float* red = reinterpret_cast<float*>(dyn);
-    for (int i = threadIdx.x; i < S::N_MLP + 64; i += blockDim.x) red[i] = 0.f;
-    __syncthreads();
+    float* red = reinterpret_cast<float*>(dyn) + (size_t)wave * (S::N_MLP + 64);
     const int col = n;
-    for (int wv = 0; wv < S::WAVES; ++wv) {
-        if (wave == wv) {
 #pragma unroll
-            for (int mb = 0; mb < S::MB; ++mb)
+    for (int mb = 0; mb < S::MB; ++mb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int u = 32 * mb + rho(h, r);
-                    if (col < EPAD) red[u * EPAD + col] += dW0[mb][r];
-                    if (col < kOut) red[S::OFF_WO + col * W + u] += dWo[mb][r];
-                    if constexpr (NH == 2) {
+        for (int r = 0; r < 16; ++r) {
+            const int u = 32 * mb + rho(h, r);
+            if (col < EPAD) red[u * EPAD + col] = dW0[mb][r];
+            if (col < kOut) red[S::OFF_WO + col * W + u] = dWo[mb][r];
+            if constexpr (NH == 2) {
 #pragma unroll
-                        for (int nb = 0; nb < S::MB; ++nb) red[S::OFF_W1 + u * W + 32 * nb + col] += dW1[mb][nb][r];
-                    }
-                }
-            if (lane == 0) red[S::N_MLP] += loss_acc;
+                for (int nb = 0; nb < S::MB; ++nb) red[S::OFF_W1 + u * W + 32 * nb + col] = dW1[mb][nb][r];
+            }
         }
-        __syncthreads();
-    }
+    if (lane == 0) red[S::N_MLP] = loss_acc;
+    __syncthreads();
+    const float* r0 = reinterpret_cast<const float*>(dyn);
     float* dst = a.partials + (size_t)blockIdx.x * (S::N_MLP + 64);
-    for (int i = threadIdx.x; i < S::N_MLP + 1; i += blockDim.x) dst[i] = red[i];
+    for (int i = threadIdx.x; i < S::N_MLP + 1; i += blockDim.x) {
+        const bool dead = i >= S::OFF_WO + kOut * W && i < S::N_MLP;             // rows 4..15 of the padded output layer: no gradient
+        float v = 0.f;
+        if (!dead) v = (r0[i] + r0[(S::N_MLP + 64) + i]) + (r0[2 * (S::N_MLP + 64) + i] + r0[3 * (S::N_MLP + 64) + i]);
+        dst[i] = v;
+    }
 }
 
 // ------------------------------------------------------------------ LDS grid scatter

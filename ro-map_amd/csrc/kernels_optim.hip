@@ -133,22 +133,26 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
 }
 
 // Fused backend: sums the per-workgroup fp32 weight-gradient partials (and loss partials) written by
-// k_fused_train into gmlp / DevState::loss_sum.  16 parameters x 16 partial subsets per block.
+// k_fused_train into gmlp / DevState::loss_sum.  One block = 16 parameters (4 float4 columns) x 64 row subsets,
+// so every thread has only n_partials/64 independent 16-byte loads in flight (the kernel is latency bound).
 __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ partials, uint32_t n_partials, uint32_t stride, uint32_t n_mlp,
                                                          float* __restrict__ gmlp, DevState* __restrict__ st) {
     if (st->n_valid == 0u) return;
-    __shared__ float red[256];
-    const uint32_t pi = blockIdx.x * 16u + (threadIdx.x & 15u), sub = threadIdx.x >> 4;
-    float s0 = 0.f, s1 = 0.f;
-    if (pi <= n_mlp) {                      // slot n_mlp of each row is the loss partial
-        uint32_t k = sub;
-        for (; k + 16u < n_partials; k += 32u) { s0 += partials[(size_t)k * stride + pi]; s1 += partials[(size_t)(k + 16u) * stride + pi]; }
-        if (k < n_partials) s0 += partials[(size_t)k * stride + pi];
+    __shared__ float4_t red[256];
+    const uint32_t c4 = threadIdx.x & 3u, sub = threadIdx.x >> 2;              // column group, row subset (0..63)
+    const uint32_t p0 = blockIdx.x * 16u + c4 * 4u;
+    float4_t acc = { 0.f, 0.f, 0.f, 0.f };
+    if (p0 < n_mlp + 4u) {                                                      // rows are padded to n_mlp + 64 floats: in-bounds
+        for (uint32_t k = sub; k < n_partials; k += 64u) acc += *reinterpret_cast<const float4_t*>(partials + (size_t)k * stride + p0);
     }
-    red[threadIdx.x] = s0 + s1;
+    red[threadIdx.x] = acc;
     __syncthreads();
-    for (int off = 128; off >= 16; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
-    if (threadIdx.x < 16u) { if (pi < n_mlp) gmlp[pi] = red[threadIdx.x]; else if (pi == n_mlp) st->loss_sum = red[threadIdx.x]; }
+    for (int off = 128; off >= 4; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x < 4u) {
+        const float4_t v = red[threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t pi = p0 + j; if (pi < n_mlp) gmlp[pi] = v[j]; else if (pi == n_mlp) st->loss_sum = v[j]; }
+    }
 }
 
 void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_partials, uint32_t stride, uint32_t n_mlp, float* gmlp, DevState* st) {
