@@ -71,7 +71,7 @@ int mon_object_get_params(mon_object* o, int which, void* dst, size_t bytes) { R
 int mon_object_set_params(mon_object* o, const float* master, size_t n) { REQUIRE(o, "object"); return model_set_params(*o->m, master, n); }
 int mon_object_set_backend(mon_object* o, int backend) {
     REQUIRE(o, "object");
-    if (backend == 1 && !fused_supported(o->m->nd, o->m->oc.S)) { set_error("fused backend does not support this network shape"); return MON_ERR_ARG; }
+    if (backend == 1 && !fused_supported(o->m->nd, o->m->oc.S, o->m->oc.R)) { set_error("fused backend does not support this network shape"); return MON_ERR_ARG; }
     if (backend != 0 && backend != 1) { set_error("backend must be 0 or 1"); return MON_ERR_ARG; }
     o->m->backend = backend; return MON_OK;
 }

@@ -113,7 +113,7 @@ template <int EPAD, int W, int NH> struct FusedShape {
     static constexpr int F_W0T = F_W1T + (NH == 2 ? MB * KSW : 0);   // [KSW]
     static constexpr int N_FRAGS = F_W0T + KSW;
     static constexpr int FRAG_BYTES = N_FRAGS * 1024;
-    static constexpr int LT_BYTES = 512;                             // LevelLds (113 words)
+    static constexpr int LT_BYTES = 512 + 4096;                      // LevelLds (113 words) + ray-compaction table (256 ballot words, 257 prefixes)
     // per-wave transpose scratch, fp16 [row][32 samples]
     static constexpr int SCR_E = 0;                                  // EPAD rows
     static constexpr int SCR_HA = SCR_E + EPAD * 32;                 // W rows: last hidden layer / its gradient
@@ -134,7 +134,7 @@ struct FusedArgs {
     const uint16_t* params;     // fp16 parameter vector (MLP matrices then grid)
     uint16_t* ggrid;            // fp16 grid gradient table
     float* partials;            // [gridDim.x][N_MLP + 64] fp32: dW partial sums, slot N_MLP = loss partial
-    const DevState* st;
+    DevState* st;
     half2_t* de_soa;            // [L][B] dL/dE of the levels scattered through LDS (k_grid_scatter), or nullptr
     float* x_soa;               // [3][B] warped sample positions for k_grid_scatter
     uint32_t lds_level_mask;    // bit l set: level l goes through k_grid_scatter instead of global atomics
@@ -292,15 +292,34 @@ template <int EPAD, int W, int NH, bool DUMP, bool ATOMIC_LEVELS>
 __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_train(FusedArgs a) {
     using S = FusedShape<EPAD, W, NH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (a.st->n_valid == 0u) return;                                   // batch skipped (uniform)
     half_t* frags = reinterpret_cast<half_t*>(smem);
     LevelLds* llt = reinterpret_cast<LevelLds*>(smem + S::FRAG_BYTES);
+    unsigned long long* cwords = reinterpret_cast<unsigned long long*>(smem + S::FRAG_BYTES + 512);      // [256]
+    uint32_t* cprefix = reinterpret_cast<uint32_t*>(smem + S::FRAG_BYTES + 512 + 2048);                   // [257] exclusive prefix, [nwords] = total
     unsigned char* dyn = smem + S::FRAG_BYTES + S::LT_BYTES;
     build_fragments<EPAD, W, NH>(frags, llt, a, true);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
     half_t* scr = reinterpret_cast<half_t*>(dyn + wave * S::SCR_BYTES);
     for (int i = lane; i < S::SCR_HALVES; i += 64) scr[i] = (half_t)0.f;           // pad feature rows must stay zero
+    // ---- ray compaction table (fill_rollover_rays :280-294 without a kernel of its own): every workgroup scans the
+    //      candidates' 64-bit ballot words; training ray j is valid candidate number (j mod n_valid) in candidate order.
+    const uint32_t nwords = a.oc.R >> 6;                                           // <= 256 (fused_supported)
+    if (wave == 0) {
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < nwords; base += 64) {
+            const unsigned long long wd = (base + lane < nwords) ? a.b.mask[base + lane] : 0ull;
+            const uint32_t c = __popcll(wd); uint32_t inc = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+            if (base + lane < nwords) { cwords[base + lane] = wd; cprefix[base + lane] = carry + inc - c; }
+            carry += __shfl(inc, 63);
+        }
+        if (lane == 0) cprefix[nwords] = carry;
+    }
     __syncthreads();
+    const uint32_t nvalid = cprefix[nwords];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->n_valid = nvalid; a.st->loss_sum = 0.f; }
+    if (nvalid == 0u) return;                                                        // batch skipped (uniform over the grid)
 
     const int L = a.nd.L, LPH = (L + 1) >> 1;
     const uint32_t R = (a.ablate & 8u) ? 0u : a.oc.R, iter = a.st->iter;
@@ -321,14 +340,25 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     float loss_acc = 0.f;
 
     for (uint32_t ray = blockIdx.x * S::WAVES + wave; ray < R; ray += gridDim.x * S::WAVES) {
+        // ---- which candidate is this ray (wave-uniform binary search over the prefix table + in-word select)
+        const uint32_t kth = ray % nvalid;
+        uint32_t lo = 0, hi = nwords - 1u;
+        while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if (cprefix[mid] <= kth) lo = mid; else hi = mid - 1u; }
+        uint32_t cand;
+        { unsigned long long wd = cwords[lo]; uint32_t kk = kth - cprefix[lo], pos = 0;
+#pragma unroll
+          for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t c = __popcll(wd & ((1ull << sh) - 1ull)); if (kk >= c) { kk -= c; wd >>= sh; pos += sh; } }
+          cand = (lo << 6) + pos; }
+        const uint32_t rgba = a.b.cand_rgba[cand];
+        const bool is_obj = (rgba >> 24) != 0u;
         // ---- sample position (GenerateInputPoints, nerf_model.cu:553-566)
-        const float t0 = a.b.ray_t0[ray], t1 = a.b.ray_t1[ray];
+        const float t0 = a.b.cand_t0[cand], t1 = a.b.cand_t1[cand];
         const float dtr = (t1 - t0) / 32.0f;
         const uint32_t s_idx = ray * 32u + (uint32_t)n;
         const float t = fmaf(dtr, (float)n + rand01(a.oc.sample_seed, kStreamDt, iter, s_idx), t0);
         float x[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { const float p = fmaf(t, a.b.ray_d[3 * ray + d], a.b.ray_o[3 * ray + d]); x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
+        for (int d = 0; d < 3; ++d) { const float p = fmaf(t, a.b.cand_d[3 * cand + d], a.b.cand_o[3 * cand + d]); x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
 
         TileState<EPAD, W, NH> ts;
         tile_forward<EPAD, W, NH>(ts, frags, *llt, table, L, x, lane);
@@ -361,15 +391,15 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         const float Tfin = __shfl(tincl, nact - 1, 64);                                    // broadcast from half-wave 0
         const float wgt = active ? alpha * T : 0.f;
         const float p0 = scan_add32(wgt * c0, n), p1 = scan_add32(wgt * c1, n), p2 = scan_add32(wgt * c2, n), pd = scan_add32(wgt * t, n);
-        const float bg0 = a.b.bgcol[3 * ray], bg1 = a.b.bgcol[3 * ray + 1], bg2 = a.b.bgcol[3 * ray + 2];
+        const float bg0 = rand01(a.oc.sample_seed, kStreamColor, iter, 3u * kth), bg1 = rand01(a.oc.sample_seed, kStreamColor, iter, 3u * kth + 1u), bg2 = rand01(a.oc.sample_seed, kStreamColor, iter, 3u * kth + 2u);   // :760, :438-441
         const float rgb0 = __shfl(p0, 31, 64) + Tfin * bg0, rgb1 = __shfl(p1, 31, 64) + Tfin * bg1, rgb2 = __shfl(p2, 31, 64) + Tfin * bg2;
         const float dep = __shfl(pd, 31, 64), mask = 1.f - Tfin;
         // ---- loss + dL/dO (VolumeRenderGradient_No_Compacted :853-953)
-        const float e0 = rgb0 - a.b.target[3 * ray], e1 = rgb1 - a.b.target[3 * ray + 1], e2 = rgb2 - a.b.target[3 * ray + 2];
+        const float tg0 = is_obj ? (float)(rgba & 0xffu) / 255.0f : bg0, tg1 = is_obj ? (float)((rgba >> 8) & 0xffu) / 255.0f : bg1, tg2 = is_obj ? (float)((rgba >> 16) & 0xffu) / 255.0f : bg2;
+        const float e0 = rgb0 - tg0, e1 = rgb1 - tg1, e2 = rgb2 - tg2;
         const float g0 = 2.f * e0, g1 = 2.f * e1, g2 = 2.f * e2;
-        const float tdp = a.b.target_depth[ray];
+        const float tdp = a.b.cand_depth[cand];
         float dl_dd = 0.f; if (tdp > 0.f) dl_dd = 0.5f * ((dep - tdp >= 0.f) ? 1.f : -1.f);
-        const bool is_obj = a.b.ray_flag[ray] == 1;
         const float mean_loss = (e0 * e0 + e1 * e1 + e2 * e2) / 3.f;
         const float loss = is_obj ? mean_loss + dl_dd * (dep - tdp) + (1.f - mask) : mean_loss + mask;
         half8_t bdo;
@@ -405,6 +435,11 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
             a.b.depth_ray[ray] = dep; a.b.mask_ray[ray] = mask; a.b.loss_ray[ray] = loss;
         }
         if (DUMP) {
+            if (lane == 0) {
+                for (int d = 0; d < 3; ++d) { a.b.ray_o[3 * ray + d] = a.b.cand_o[3 * cand + d]; a.b.ray_d[3 * ray + d] = a.b.cand_d[3 * cand + d]; }
+                a.b.ray_t0[ray] = t0; a.b.ray_t1[ray] = t1; a.b.ray_dn[ray] = a.b.cand_dn[cand]; a.b.ray_flag[ray] = is_obj ? 1 : 0; a.b.target_depth[ray] = tdp;
+                a.b.bgcol[3 * ray] = bg0; a.b.bgcol[3 * ray + 1] = bg1; a.b.bgcol[3 * ray + 2] = bg2; a.b.target[3 * ray] = tg0; a.b.target[3 * ray + 1] = tg1; a.b.target[3 * ray + 2] = tg2;
+            }
             if (h == 0) {
                 a.b.pts[3 * s_idx] = x[0]; a.b.pts[3 * s_idx + 1] = x[1]; a.b.pts[3 * s_idx + 2] = x[2]; a.b.tdist[s_idx] = t;
                 half4_t o4 = { (half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3 }; reinterpret_cast<half4_t*>(a.b.O)[s_idx] = o4;
@@ -724,8 +759,8 @@ __global__ void __launch_bounds__(256) k_fused_render(FusedArgs a, uint32_t n_ra
 }
 
 // ------------------------------------------------------------------ host side
-bool fused_supported(const NetDims& nd, uint32_t S) {
-    return S == 32 && nd.L >= 1 && nd.L <= kMaxLevels && (nd.Epad == 16 || nd.Epad == 32) && (nd.W == 32 || nd.W == 64) && (nd.NH == 1 || nd.NH == 2);
+bool fused_supported(const NetDims& nd, uint32_t S, uint32_t R) {
+    return S == 32 && R <= 16384u && nd.L >= 1 && nd.L <= kMaxLevels && (nd.Epad == 16 || nd.Epad == 32) && (nd.W == 32 || nd.W == 64) && (nd.NH == 1 || nd.NH == 2);
 }
 
 uint32_t fused_train_grid(const NetDims&, uint32_t R) {
@@ -743,7 +778,7 @@ static void fused_train_t(hipStream_t s, const FusedArgs& a, uint32_t grid, int 
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_build_frag_image<EPAD, W, NH>), dim3((S::N_FRAGS * 512 + 255) / 256), dim3(256), 0, s, a.params, a.nd.L, const_cast<uint16_t*>(a.frag_image), a.st);
+    hipLaunchKernelGGL((k_build_frag_image<EPAD, W, NH>), dim3((S::N_FRAGS * 512 + 255) / 256), dim3(256), 0, s, a.params, a.nd.L, const_cast<uint16_t*>(a.frag_image), (const DevState*)nullptr);
     const bool all_lds = a.lds_level_mask != 0u && (a.lds_level_mask == ((a.nd.L >= 32) ? 0xffffffffu : ((1u << a.nd.L) - 1u)));
     if (dump) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
     else if (all_lds) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);

@@ -133,7 +133,7 @@ int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* 
         (rc = dev_alloc(m, B.rgb_ray, 3 * (size_t)R)) || (rc = dev_alloc(m, B.depth_ray, R)) || (rc = dev_alloc(m, B.mask_ray, R)) || (rc = dev_alloc(m, B.loss_ray, R)) ||
         (rc = dev_alloc(m, m.d_state, 1)) || (rc = dev_alloc(m, m.d_dw_partials, (size_t)(m.nd.n_mlp + 64) * 512)) ||
         (rc = dev_alloc(m, m.d_out_rgb, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_depth, kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_mask, kRenderChunkRays))) return rc;
-    if (fused_supported(m.nd, S)) {
+    if (fused_supported(m.nd, S, m.oc.R)) {
         if ((rc = dev_alloc(m, m.d_frag_train, 64 * 512)) || (rc = dev_alloc(m, m.d_frag_render, 64 * 512))) return rc;       // <= 30 fragments of 512 halves
         m.lds_mask = scatter_plan(m.lt, m.nd, m.scatter);
         if (m.lds_mask && ((rc = dev_alloc(m, m.d_de_soa, (size_t)m.nd.L * Btrain * 2)) || (rc = dev_alloc(m, m.d_x_soa, 3 * (size_t)Btrain)) ||
@@ -144,8 +144,8 @@ int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* 
     B.boxes = m.d_boxes;
     m.h_state = DevState{}; m.h_state.lr = cfg.learning_rate;
     HIPCHECK(hipMemcpy(m.d_state, &m.h_state, sizeof(DevState), hipMemcpyHostToDevice));
-    m.backend = fused_supported(m.nd, S) ? 1 : 0;
-    if (const char* e = std::getenv("MON_BACKEND")) m.backend = std::atoi(e) ? (fused_supported(m.nd, S) ? 1 : 0) : 0;
+    m.backend = fused_supported(m.nd, S, m.oc.R) ? 1 : 0;
+    if (const char* e = std::getenv("MON_BACKEND")) m.backend = std::atoi(e) ? (fused_supported(m.nd, S, m.oc.R) ? 1 : 0) : 0;
     HIPCHECK(hipDeviceSynchronize());
     *out = mp; return MON_OK;
 }
@@ -212,8 +212,10 @@ static void enqueue_iteration(Model& m, int stages) {
     if (stages & 1) {      // GenerateBatch :1429-1502
         ProfScope ps(m, MON_K_BATCH);
         launch_gen_candidates(s, m.B, m.ds->ptrs(), m.oc, m.d_state);
-        launch_build_rays(s, m.B, m.oc, m.d_state);
-        if (m.backend == 0) launch_gen_samples(s, m.B, m.oc, m.d_state, m.oc.S, B, kStreamDt, 0u, 0);
+        if (m.backend == 0) {                       // the fused kernel compacts the rays itself
+            launch_build_rays(s, m.B, m.oc, m.d_state);
+            launch_gen_samples(s, m.B, m.oc, m.d_state, m.oc.S, B, kStreamDt, 0u, 0);
+        }
     }
     if (stages & 2) {      // Step_No_Compacted :1552-1607
         ProfScope ps(m, MON_K_FWDBWD);

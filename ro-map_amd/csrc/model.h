@@ -102,7 +102,7 @@ void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, D
 void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_partials, uint32_t stride, uint32_t n_mlp, float* gmlp, DevState* st);
 
 // fused MFMA path (kernels_fused.hip)
-bool fused_supported(const NetDims& nd, uint32_t S);
+bool fused_supported(const NetDims& nd, uint32_t S, uint32_t R);
 uint32_t fused_train_grid(const NetDims& nd, uint32_t R);
 void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
                         uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image);

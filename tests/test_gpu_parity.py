@@ -154,22 +154,27 @@ def test_render_matches_oracle_and_golden(pkg, orc, ss, name, backend):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_training_parity_psnr_c1(pkg, orc, ss, small_scene, backend):
-    """BASELINE configs[0]: identical schedules on both sides; mutual PSNR of the rendered crop and absolute PSNR."""
-    ds, obj, ref = _pair(pkg, orc, small_scene, C1, backend)
-    steps = 400
-    l_hip = obj.train(steps); l_ref = ref.train(steps)
-    assert l_hip < 0.05 and abs(l_hip - l_ref) < 0.5 * max(l_ref, 0.01)
-    sc = small_scene; worst_mutual = 99.0; abs_hip = []; abs_ref = []
-    for box in sc.objects[0]["boxes"][::4]:
-        v, x, y, h, w = (int(q) for q in box); pose = ss.colmajor(sc.Twc[v])
-        rgb, depth, mask = obj.render(box, pose); rrgb, rdepth, rmask = ref.render(box, pose)
-        gt = sc.rgb[v, y:y + h, x:x + w] / 255.0; gm = sc.instance[v, y:y + h, x:x + w] > 0
-        gtw = np.where(gm[..., None], gt, 1.0)
-        worst_mutual = min(worst_mutual, psnr(rgb, rrgb)); abs_hip.append(psnr(rgb, gtw)); abs_ref.append(psnr(rrgb, gtw))
-    print("mutual PSNR %.2f dB, abs HIP %.2f dB, abs oracle %.2f dB" % (worst_mutual, np.mean(abs_hip), np.mean(abs_ref)))
-    assert worst_mutual > 28.0                       # two independently-rounded trainings of the same schedule
-    assert np.mean(abs_hip) > np.mean(abs_ref) - 1.0 and np.mean(abs_hip) > 24.0      # two chaotic trajectories: +-0.5 dB run to run
-    obj.close(); ds.close(); ref.close()
+    """BASELINE configs[0]: identical schedules on both sides.  Training is chaotic (fp16 rounding, summation order), so a
+    single pair of runs differs by the run-to-run spread (measured on MI355X over 6 sampling seeds, tools/psnr_study.py:
+    absolute PSNR std 0.7-1.0 dB for the oracle and both HIP backends, per-seed HIP-oracle difference within +-0.3 dB for 4 of
+    4 seeds).  The test therefore averages 3 seeds: mean absolute PSNR within 0.8 dB of the oracle's, mutual PSNR > 28 dB."""
+    sc = small_scene; steps = 300; abs_hip, abs_ref, mutual = [], [], []
+    for seed in (11, 12, 13):
+        _need_gpu(pkg)
+        kw = dict(C1, sample_seed=seed)
+        ds, obj = ge.make_problem(pkg, sc, kw); obj.set_backend(backend); ref = ge.make_oracle(orc, sc, kw)
+        l_hip = obj.train(steps); l_ref = ref.train(steps)
+        assert l_hip < 0.05 and abs(l_hip - l_ref) < 0.5 * max(l_ref, 0.01)
+        for box in sc.objects[0]["boxes"][::4]:
+            v, x, y, h, w = (int(q) for q in box); pose = ss.colmajor(sc.Twc[v])
+            rgb, depth, mask = obj.render(box, pose); rrgb, rdepth, rmask = ref.render(box, pose)
+            gt = sc.rgb[v, y:y + h, x:x + w] / 255.0; gm = sc.instance[v, y:y + h, x:x + w] > 0
+            gtw = np.where(gm[..., None], gt, 1.0)
+            mutual.append(psnr(rgb, rrgb)); abs_hip.append(psnr(rgb, gtw)); abs_ref.append(psnr(rrgb, gtw))
+        obj.close(); ds.close(); ref.close()
+    print("backend %d: mutual PSNR min %.2f dB, abs HIP %.2f dB, abs oracle %.2f dB" % (backend, min(mutual), np.mean(abs_hip), np.mean(abs_ref)))
+    assert min(mutual) > 28.0
+    assert abs(np.mean(abs_hip) - np.mean(abs_ref)) < 0.8 and np.mean(abs_hip) > 24.0
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -183,7 +188,10 @@ def test_full_size_properties_c2(pkg, ss, backend):
     except pkg.MonError:
         obj.close(); ds.close(); pytest.skip("fused backend not available")
     i0 = obj.info(); assert i0.n_params == 3072 + 1908736 and i0.encoded_width == 32
+    if backend == 1:
+        obj.set_debug_dump(True)          # the fused kernel keeps the compacted rays on chip; dump them for the rollover check
     l0 = obj.train(1); nv = obj.info().last_n_valid
+    obj.set_debug_dump(False)
     assert 0 < nv <= 4096 and np.isfinite(l0)
     flags = obj.buffer("ray_flag"); o = obj.buffer("ray_o").reshape(-1, 3)
     assert np.array_equal(o[nv:], o[np.arange(nv, 4096) % nv]) and np.array_equal(flags[nv:], flags[np.arange(nv, 4096) % nv])
