@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include "device_common.h"
 #include "model.h"
+#include "batch_device.h"
 
 namespace mon {
 
@@ -180,6 +181,17 @@ __global__ void __launch_bounds__(256) k_build_frag_image(const uint16_t* __rest
     using S = FusedShape<EPAD, W, NH>;
     if (st && st->n_valid == 0u) return;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < S::N_FRAGS * 512) reinterpret_cast<half_t*>(image)[idx] = frag_element<EPAD, W, NH>(reinterpret_cast<const half_t*>(params), L, idx);
+}
+
+// First kernel of a fused-backend iteration: the candidate rays (GenerateRays) and the weight-fragment image are
+// independent, so they share one launch (blocks [0, cand_blocks) generate candidates, the rest build fragments).
+template <int EPAD, int W, int NH>
+__global__ void __launch_bounds__(256) k_candidates_and_frags(BatchPtrs b, DatasetPtrs ds, ObjectConst oc, const DevState* __restrict__ st, uint32_t cand_blocks,
+                                                              const uint16_t* __restrict__ params, int L, uint16_t* __restrict__ image) {
+    using S = FusedShape<EPAD, W, NH>;
+    if (blockIdx.x < cand_blocks) { gen_candidate(b, ds, oc, st, blockIdx.x * blockDim.x + threadIdx.x); return; }
+    const int idx = (blockIdx.x - cand_blocks) * blockDim.x + threadIdx.x;
     if (idx < S::N_FRAGS * 512) reinterpret_cast<half_t*>(image)[idx] = frag_element<EPAD, W, NH>(reinterpret_cast<const half_t*>(params), L, idx);
 }
 
@@ -778,7 +790,6 @@ static void fused_train_t(hipStream_t s, const FusedArgs& a, uint32_t grid, int 
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_build_frag_image<EPAD, W, NH>), dim3((S::N_FRAGS * 512 + 255) / 256), dim3(256), 0, s, a.params, a.nd.L, const_cast<uint16_t*>(a.frag_image), (const DevState*)nullptr);
     const bool all_lds = a.lds_level_mask != 0u && (a.lds_level_mask == ((a.nd.L >= 32) ? 0xffffffffu : ((1u << a.nd.L) - 1u)));
     if (dump) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
     else if (all_lds) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
@@ -791,6 +802,13 @@ static void fused_render_t(hipStream_t s, const FusedArgs& a, uint32_t n_rays, u
     uint32_t grid = (n_rays + 3) / 4; if (grid > 2048u) grid = 2048u;
     hipLaunchKernelGGL((k_build_frag_image<EPAD, W, NH>), dim3((S::F_WOT * 512 + 255) / 256), dim3(256), 0, s, a.params, a.nd.L, const_cast<uint16_t*>(a.frag_image), (const DevState*)nullptr);
     hipLaunchKernelGGL((k_fused_render<EPAD, W, NH>), dim3(grid), dim3(256), smem, s, a, n_rays, idx_base, rgb, depth, mask);
+}
+
+template <int EPAD, int W, int NH>
+static void candidates_frags_t(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st, const uint16_t* params, const NetDims& nd, uint16_t* image) {
+    using S = FusedShape<EPAD, W, NH>;
+    const uint32_t cand_blocks = (oc.R + 255) / 256, frag_blocks = (S::N_FRAGS * 512 + 255) / 256;
+    hipLaunchKernelGGL((k_candidates_and_frags<EPAD, W, NH>), dim3(cand_blocks + frag_blocks), dim3(256), 0, s, b, ds, oc, st, cand_blocks, params, nd.L, image);
 }
 
 #define MON_FUSED_DISPATCH(FN, ...)                                                            \
@@ -815,6 +833,9 @@ void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, c
     FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate };
     const uint32_t grid = fused_train_grid(nd, oc.R);
     MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);
+}
+void launch_candidates_and_frags(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st, const uint16_t* params, const NetDims& nd, uint16_t* frag_image) {
+    MON_FUSED_DISPATCH(candidates_frags_t, s, b, ds, oc, st, params, nd, frag_image);
 }
 void launch_fused_render(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask, uint16_t* frag_image) {
     FusedArgs a{ lt, nd, oc, b, params, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, frag_image, 0u };

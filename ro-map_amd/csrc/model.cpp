@@ -211,7 +211,8 @@ static void enqueue_iteration(Model& m, int stages) {
     hipStream_t s = m.train_stream; const uint32_t B = m.oc.R * m.oc.S;
     if (stages & 1) {      // GenerateBatch :1429-1502
         ProfScope ps(m, MON_K_BATCH);
-        launch_gen_candidates(s, m.B, m.ds->ptrs(), m.oc, m.d_state);
+        if (m.backend == 1) launch_candidates_and_frags(s, m.B, m.ds->ptrs(), m.oc, m.d_state, m.P.half, m.nd, m.d_frag_train);
+        else launch_gen_candidates(s, m.B, m.ds->ptrs(), m.oc, m.d_state);
         if (m.backend == 0) {                       // the fused kernel compacts the rays itself
             launch_build_rays(s, m.B, m.oc, m.d_state);
             launch_gen_samples(s, m.B, m.oc, m.d_state, m.oc.S, B, kStreamDt, 0u, 0);

@@ -238,6 +238,6 @@ def test_edge_cases(pkg, ss, small_scene):
     # occluder: pixels of another instance id never become rays (nerf_model.cu:398-401)
     sc2 = ss.make_scene(n_views=8, H=120, W=160, f=130.0, n_objects=3, seed=4)
     ds2, o4 = ge.make_problem(pkg, sc2, C1, obj_index=1)
-    o4.train_stages(1)
+    o4.train_stages(1 | 2)
     assert int(o4.buffer("state")[2]) > 0
     o4.close(); ds2.close(); ds.close()
