@@ -23,6 +23,10 @@ def train_bytes_per_sample(L):
     return 52 + 96 * L
 
 
+def train_bytes_per_sample_fused(L):          # k_fused_train's share: everything except the gradient scatter RMW (64*L)
+    return 52 + 32 * L
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,23 +79,35 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     value = world * args.steps * B / dt
 
-    # ---- roofline of the dominant kernel (forward+backward), HIP events on the kernel's own stream
+    # ---- roofline of the dominant kernel, HIP events on the kernel's own stream (the object's train stream).
+    # a training step moves 52 + 96*L algorithmic bytes per ray-sample.  The fused backend splits them over two
+    # kernels: k_fused_train = forward gathers + outputs + dL/dO (52 + 32*L), k_grid_scatter = the gradient
+    # scatter read-modify-write (64*L).  The unfused backend is one kernel group timed as a whole.
     obj.set_profiling(True); obj.profile(reset=True)
     obj.train(args.steps); prof = obj.profile(reset=True); obj.set_profiling(False)
-    fb_ms = prof["ms"][1] / max(1, prof["launches"][1])
-    alg_bytes = train_bytes_per_sample(L) * B
-    achieved = alg_bytes / (fb_ms * 1e-3) / 1e9
+    avg = lambda k: prof["ms"][k] / max(1, prof["launches"][k])
+    fused = obj_backend(pkg, obj) == 1
+    fb_ms, sc_ms, rd_ms = avg(1), avg(4), avg(5)
+    dom_bytes = (train_bytes_per_sample_fused(L) if fused else train_bytes_per_sample(L)) * B
+    achieved = dom_bytes / (fb_ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("fwdbwd_hbm_bytes_per_launch")
+            traffic = json.load(open(pmc)).get("k_fused_train_hbm_bytes_per_launch" if fused else "unfused_hbm_bytes_per_launch")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                "kernel": "fused_train" if obj_backend(pkg, obj) == 1 else "unfused fwd+bwd kernel group",
-                "avg_launch_ms": round(fb_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                "batch_ms": round(prof["ms"][0] / max(1, prof["launches"][0]), 4), "optim_ms": round(prof["ms"][2] / max(1, prof["launches"][2]), 4)}
+                "kernel": "k_fused_train" if fused else "unfused fwd+bwd kernel group",
+                "avg_launch_ms": round(fb_ms, 4), "algorithmic_bytes_per_launch": dom_bytes}
+    if fused:
+        grp_ms = fb_ms + sc_ms
+        roofline["scatter_kernel"] = {"kernel": "k_grid_scatter", "avg_launch_ms": round(sc_ms, 4), "algorithmic_bytes_per_launch": 64 * L * B,
+                                      "achieved": round(64 * L * B / (sc_ms * 1e-3) / 1e9, 2), "frac": round(64 * L * B / (sc_ms * 1e-3) / 1e9 / 8000.0, 4)}
+        roofline["fwd_bwd_pair"] = {"avg_ms": round(grp_ms, 4), "algorithmic_bytes": train_bytes_per_sample(L) * B,
+                                    "achieved": round(train_bytes_per_sample(L) * B / (grp_ms * 1e-3) / 1e9, 2),
+                                    "frac": round(train_bytes_per_sample(L) * B / (grp_ms * 1e-3) / 1e9 / 8000.0, 4)}
+    roofline["other_kernels_ms"] = {"candidates+frags": round(avg(0), 4), "reduce_partials": round(rd_ms, 4), "optimizer": round(avg(2), 4)}
 
     # ---- quality: PSNR of a rendered crop vs the synthetic ground truth after (2W + 2K) steps; gathered over RCCL when N > 1
     box = sc.objects[0]["boxes"][0]; v, x, y, h, w = (int(q) for q in box)
