@@ -41,16 +41,24 @@ def main():
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     import numpy as np
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    import importlib
     import __graft_entry__ as ge
     pkg = ge.load_package(); ss = ge.load_tools()
-    if pkg.device_count() < 1:
+    sharding = importlib.import_module("ro_map_amd.sharding")
+    ndev = pkg.device_count()
+    if ndev < 1:
         raise SystemExit("bench.py: no HIP device visible (the HIP path has no CPU fallback)")
-    device = local_rank
+    device = local_rank % ndev
+    dist = None; coll_dev = "cpu"
+    if world > 1:
+        import torch.distributed as dist
+        # "nccl" IS RCCL on ROCm (xGMI); MON_BENCH_DIST_BACKEND=gloo lets the N>1 path be exercised on a 1-GPU box
+        backend = os.environ.get("MON_BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(device); coll_dev = torch.device("cuda", device)
+            dist.init_process_group(backend="nccl", device_id=coll_dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     # ---- workload: resident in HBM before timing
     sc = ss.make_scene(n_views=args.views, H=480, W=640, f=525.0, seed=0)
@@ -76,7 +84,7 @@ def main():
     sync(); barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        dt = sharding.max_over_ranks(dist, torch, dt, coll_dev)
     value = world * args.steps * B / dt
 
     # ---- roofline of the dominant kernel, HIP events on the kernel's own stream (the object's train stream).
@@ -115,13 +123,17 @@ def main():
     gm = sc.instance[v, y:y + h, x:x + w] > 0
     gt = np.where(gm[..., None], sc.rgb[v, y:y + h, x:x + w] / 255.0, 1.0)
     my_psnr = float(-10 * np.log10(max(1e-12, ((rgb - gt) ** 2).mean())))
+    # render throughput (NeRF_Model::Render, 2S = 64 samples per pixel ray, nominal count like the reference which evaluates every pixel)
+    sync(); tr0 = time.perf_counter(); n_rep = 20
+    for _ in range(n_rep):
+        obj.render(box, ss.colmajor(sc.Twc[v]))
+    sync(); tr = (time.perf_counter() - tr0) / n_rep
+    render_info = {"crop": [h, w], "ms_per_crop_incl_d2h": round(1e3 * tr, 3), "nominal_ray_samples_per_s": round(h * w * 2 * cfg.n_samples / tr, 1)}
     psnrs = [my_psnr]
     if dist is not None:
-        crop = torch.from_numpy(np.concatenate([rgb.reshape(-1), depth.reshape(-1), mask.reshape(-1)]).astype(np.float32)).cuda()
-        gathered = [torch.empty_like(crop) for _ in range(world)]
-        dist.all_gather(gathered, crop)             # RCCL over xGMI: the only collective on the path (final render)
-        if rank == 0:
-            psnrs = [float(-10 * np.log10(max(1e-12, ((g[: rgb.size].cpu().numpy().reshape(rgb.shape) - gt) ** 2).mean()))) for g in gathered]
+        # RCCL over xGMI: the only collective on the path -- every rank's rendered crop gathered for the final image set
+        crops = sharding.gather_crops(dist, torch, [sharding.pack_crop(rgb, depth, mask)], coll_dev)
+        psnrs = [float(-10 * np.log10(max(1e-12, ((items[0][0] - gt) ** 2).mean()))) for items in crops if items]
 
     # ---- CPU baseline: the oracle (port of the same algorithm), bounded sample, rank 0 at N=1 only
     cpu = None
@@ -149,7 +161,7 @@ def main():
                           "objects": world, "rays_per_step": cfg.rays_per_batch, "samples_per_ray": cfg.n_samples, "backend": obj_backend(pkg, obj),
                           "parallelism": "object-per-GPU (no training collective; RCCL all_gather of the final render)"},
                "roofline": roofline, "cpu_baseline": cpu,
-               "psnr_db": [round(p, 2) for p in psnrs], "train_steps_before_render": args.warmup + 2 * args.steps,
+               "render": render_info, "psnr_db": [round(p, 2) for p in psnrs], "train_steps_before_render": args.warmup + 2 * args.steps,
                "final_loss": round(obj.info().last_loss, 5)}
         print(json.dumps(out))
     obj.close(); ds.close()
