@@ -139,6 +139,26 @@ int mon_object_set_profiling(mon_object* obj, int enable);
 int mon_object_get_profile(mon_object* obj, mon_profile* out, int reset);
 int mon_object_destroy(mon_object* obj);
 
+/* ---- nerf::NerfManagerOffline (CORE/include/nerf_manager.h:21-50, CORE/src/nerf_manager.cu:9-131) without OpenCV/Eigen:
+ * reads the reference's on-disk sequence layout (nerf_data.cu:27-121: config.yaml, img.txt, groundtruth.txt, rgb|depth|instance
+ * PNGs) and object files (nerf.cu:58-118), one dataset replica per device, one thread per object, object k on device k mod nGPU,
+ * 10 x 500 training iterations per object (nerf_manager.cu:89, nerf_model.cu:1635; MON_OFFLINE_OUTER / MON_OFFLINE_INNER override). */
+typedef struct mon_offline mon_offline;
+int mon_offline_create(const char* dataset_path, const char* network_config_file, int use_dense_depth, mon_offline** out);
+int mon_offline_init(mon_offline* mgr);                                   /* Init()            */
+int mon_offline_read_dataset(mon_offline* mgr);                           /* ReadDataset()     */
+int mon_offline_create_nerf(mon_offline* mgr, const char* object_file);   /* CreateNeRF(file): starts the object's training thread */
+int mon_offline_wait_threads_end(mon_offline* mgr);                       /* WaitThreadsEnd()  */
+int mon_offline_n_objects(mon_offline* mgr, int* n);
+int mon_offline_object_loss(mon_offline* mgr, int idx, float* loss, int* device);
+/* test images for the first max_views (0 = all) training boxes of object idx: <out_dir>/<id>/test_{img,depth,mask}/<stamp>.png (nerf.cu:335-349) */
+int mon_offline_render_test(mon_offline* mgr, int idx, const char* out_dir, int max_views);
+int mon_offline_destroy(mon_offline* mgr);
+/* PNG codec used for the sequence layout (8/16-bit, gray/RGB/RGBA in; gray/RGB out; 16-bit samples big-endian as in the file).
+ * pixels may be NULL to query the header only. */
+int mon_png_read(const char* path, int* width, int* height, int* channels, int* bit_depth, uint8_t* pixels, size_t capacity);
+int mon_png_write(const char* path, int width, int height, int channels, int bit_depth, const uint8_t* pixels_big_endian);
+
 /* Whole-device helpers used by bench.py. */
 int mon_device_synchronize(int device);
 /* Diagnostic: write intermediate activations of the fused backend into the debug buffers (slower). */

@@ -66,6 +66,17 @@ _SIGS = {
     "mon_object_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mon_object_get_profile": (C.c_int, [C.c_void_p, C.POINTER(MonProfile), C.c_int]),
     "mon_object_destroy": (C.c_int, [C.c_void_p]),
+    "mon_offline_create": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "mon_offline_init": (C.c_int, [C.c_void_p]),
+    "mon_offline_read_dataset": (C.c_int, [C.c_void_p]),
+    "mon_offline_create_nerf": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "mon_offline_wait_threads_end": (C.c_int, [C.c_void_p]),
+    "mon_offline_n_objects": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "mon_offline_object_loss": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "mon_offline_render_test": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
+    "mon_offline_destroy": (C.c_int, [C.c_void_p]),
+    "mon_png_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
+    "mon_png_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mon_device_synchronize": (C.c_int, [C.c_int]),
     "mon_debug_fast_index": (C.c_int, [C.POINTER(MonConfig), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mon_selftest_mfma": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -233,3 +244,54 @@ class ObjectNeRF:
     def profile(self, reset=True):
         p = MonProfile(); _check(lib().mon_object_get_profile(self.h, C.byref(p), int(reset)))
         return {"ms": list(p.ms), "launches": list(p.launches)}
+
+
+def png_read(path):
+    w, h, c, d = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    _check(lib().mon_png_read(path.encode(), C.byref(w), C.byref(h), C.byref(c), C.byref(d), None, 0))
+    buf = np.empty(w.value * h.value * c.value * d.value // 8, np.uint8)
+    _check(lib().mon_png_read(path.encode(), C.byref(w), C.byref(h), C.byref(c), C.byref(d), _p(buf), buf.nbytes))
+    if d.value == 16:
+        return buf.view(">u2").astype(np.uint16).reshape(h.value, w.value, c.value)
+    return buf.reshape(h.value, w.value, c.value)
+
+
+def png_write(path, arr):
+    a = np.asarray(arr)
+    if a.ndim == 2:
+        a = a[..., None]
+    data = np.ascontiguousarray(a.astype(">u2") if a.dtype == np.uint16 else a.astype(np.uint8))
+    _check(lib().mon_png_write(path.encode(), a.shape[1], a.shape[0], a.shape[2], 16 if arr.dtype == np.uint16 else 8, data.ctypes.data_as(C.c_void_p)))
+
+
+class OfflineManager:
+    """nerf::NerfManagerOffline: same call sequence as OfflineNeRF's main() (MON/main.cpp:322-340) minus the viewer."""
+
+    def __init__(self, dataset_path, config_path, use_dense_depth=False):
+        self.h = C.c_void_p()
+        _check(lib().mon_offline_create(dataset_path.encode(), config_path.encode(), int(use_dense_depth), C.byref(self.h)))
+
+    def init(self):
+        _check(lib().mon_offline_init(self.h))
+
+    def read_dataset(self):
+        _check(lib().mon_offline_read_dataset(self.h))
+
+    def create_nerf(self, object_file):
+        _check(lib().mon_offline_create_nerf(self.h, object_file.encode()))
+
+    def wait_threads_end(self):
+        _check(lib().mon_offline_wait_threads_end(self.h))
+
+    def n_objects(self):
+        n = C.c_int(0); _check(lib().mon_offline_n_objects(self.h, C.byref(n))); return n.value
+
+    def object_loss(self, idx):
+        l = C.c_float(0); d = C.c_int(0); _check(lib().mon_offline_object_loss(self.h, idx, C.byref(l), C.byref(d))); return l.value, d.value
+
+    def render_test(self, idx, out_dir, max_views=0):
+        _check(lib().mon_offline_render_test(self.h, idx, out_dir.encode(), max_views))
+
+    def close(self):
+        if self.h:
+            lib().mon_offline_destroy(self.h); self.h = None

@@ -5,7 +5,7 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 OBJ="$HERE/build"; mkdir -p "$OBJ"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -ffp-contract=off -fno-math-errno -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result)
-SRCS=(config.cpp model.cpp c_api.cpp kernels_batch.hip kernels_net.hip kernels_composite.hip kernels_optim.hip kernels_fused.hip microbench.hip)
+SRCS=(config.cpp model.cpp c_api.cpp manager.cpp png_io.cpp kernels_batch.hip kernels_net.hip kernels_composite.hip kernels_optim.hip kernels_fused.hip microbench.hip)
 pids=()
 for s in "${SRCS[@]}"; do
   o="$OBJ/${s%.*}.o"
@@ -16,5 +16,6 @@ for s in "${SRCS[@]}"; do
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
 objs=(); for s in "${SRCS[@]}"; do objs+=("$OBJ/${s%.*}.o"); done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$HERE/libmon_core.so" "${objs[@]}"
-echo "built $HERE/libmon_core.so"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$HERE/libmon_core.so" "${objs[@]}" -lz -lpthread
+g++ -O2 -std=c++17 "$HERE/../tools/offline_nerf.cpp" -o "$HERE/offline_nerf" -L"$HERE" -lmon_core -Wl,-rpath,'$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
+echo "built $HERE/libmon_core.so and $HERE/offline_nerf"

@@ -1,0 +1,221 @@
+// manager.cpp -- host mirror of nerf::NerfManagerOffline / nerf::NeRF (offline part) without Eigen / OpenCV:
+// CORE/src/nerf_manager.cu:9-131 (Init, ReadDataset, CreateNeRF, WaitThreadsEnd), CORE/src/nerf_data.cu:27-235
+// (sequence layout: config.yaml, img.txt, groundtruth.txt, rgb|depth|instance PNGs), CORE/src/nerf.cu:58-152
+// (object file, thread body: 10 x 500 iterations) and the test-image writer of nerf.cu:255-349.
+// One std::thread per object, object k on device k mod nGPU (nerf.cu:27-33), one dataset replica per device.
+#include <sys/stat.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+#include "model.h"
+#include "png_io.h"
+
+namespace mon {
+
+void set_error(const char* fmt, ...);
+int device_count(int* n);
+int config_from_json(const char* path, mon_config& c);
+int dataset_create(int device, int H, int W, float fx, float fy, float cx, float cy, uint32_t max_frames, int use_depth, Dataset** out);
+int dataset_add_frame(Dataset* d, uint32_t id, const uint8_t* rgb, int ch, int is_bgr, const uint8_t* inst, const float* depth, const float* Twc);
+int dataset_destroy(Dataset* d);
+int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* Tow, const float* amin, const float* amax, Model** out);
+int model_destroy(Model* m);
+int model_add_boxes(Model& m, const mon_frame_bbox* boxes, size_t n);
+int model_train(Model& m, int iters, float* loss, int stages);
+int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, int dst_on_device);
+
+// Eigen::Quaternionf(w,x,y,z).toRotationMatrix() + translation -> column-major 4x4 (nerf_data.cu:100-106)
+static void pose_from_tq(const float* t, float qx, float qy, float qz, float qw, float* M) {
+    const float n = std::sqrt(qx * qx + qy * qy + qz * qz + qw * qw); qx /= n; qy /= n; qz /= n; qw /= n;
+    const float R[9] = { 1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw),
+                         2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
+                         2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy) };      // row-major
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) M[c * 4 + r] = R[r * 3 + c];
+    M[3] = M[7] = M[11] = 0.f; M[12] = t[0]; M[13] = t[1]; M[14] = t[2]; M[15] = 1.f;
+}
+// inverse of a rigid transform (the reference calls Matrix4f::inverse() on Two, nerf.cu:89)
+static void rigid_inverse(const float* M, float* Inv) {
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Inv[c * 4 + r] = M[r * 4 + c];
+    for (int r = 0; r < 3; ++r) Inv[12 + r] = -(Inv[r] * M[12] + Inv[4 + r] * M[13] + Inv[8 + r] * M[14]);
+    Inv[3] = Inv[7] = Inv[11] = 0.f; Inv[15] = 1.f;
+}
+
+struct OfflineObject {
+    int id = 0, device = 0, cls = 0; float Tow[16]; float amin[3], amax[3];
+    std::vector<mon_frame_bbox> boxes; std::vector<std::string> stamps;
+    Model* model = nullptr; float last_loss = 0.f; int rc = 0; std::string err;
+};
+
+struct OfflineManager {
+    std::string dataset, cfg_path; bool use_depth = false; int n_dev = 0; mon_config cfg{};
+    float fx = 0, fy = 0, cx = 0, cy = 0, depth_scale = 1.f; int H = 0, W = 0;
+    std::vector<std::string> names, stamps; std::map<std::string, uint32_t> stamp_to_idx; std::vector<float> poses;   // [n][16]
+    std::vector<Dataset*> ds; std::vector<OfflineObject*> objs; std::vector<std::thread> threads;
+    int outer_iters = 10, inner_iters = 500;       // nerf_manager.cu:89, nerf_model.cu:1635
+};
+
+static bool read_yaml_number(const std::string& text, const char* key, double& v) {
+    const size_t p = text.find(key); if (p == std::string::npos) return false;
+    const size_t c = text.find(':', p); if (c == std::string::npos) return false;
+    v = std::strtod(text.c_str() + c + 1, nullptr); return true;
+}
+
+int offline_init(OfflineManager& m) {                                   // nerf_manager.cu:16-38
+    int rc = device_count(&m.n_dev); if (rc) return rc;
+    rc = config_from_json(m.cfg_path.c_str(), m.cfg); if (rc) return rc;
+    m.cfg.use_depth = m.use_depth ? 1 : 0;
+    if (const char* e = std::getenv("MON_OFFLINE_OUTER")) m.outer_iters = std::atoi(e);
+    if (const char* e = std::getenv("MON_OFFLINE_INNER")) m.inner_iters = std::atoi(e);
+    return MON_OK;
+}
+
+int offline_read_dataset(OfflineManager& m) {                           // nerf_manager.cu:40-62, nerf_data.cu:27-235
+    std::ifstream fc(m.dataset + "/config.yaml");
+    if (!fc) { set_error("Failed to open settings file at: %s/config.yaml", m.dataset.c_str()); return MON_ERR_IO; }
+    std::stringstream ss; ss << fc.rdbuf(); const std::string y = ss.str(); double v;
+    if (!read_yaml_number(y, "Camera.fx", v)) { set_error("config.yaml: Camera.fx missing"); return MON_ERR_IO; } m.fx = (float)v;
+    read_yaml_number(y, "Camera.fy", v); m.fy = (float)v; read_yaml_number(y, "Camera.cx", v); m.cx = (float)v; read_yaml_number(y, "Camera.cy", v); m.cy = (float)v;
+    read_yaml_number(y, "Camera.H", v); m.H = (int)v; read_yaml_number(y, "Camera.W", v); m.W = (int)v;
+    if (m.use_depth && read_yaml_number(y, "DepthMapFactor", v)) m.depth_scale = (float)v;
+    std::ifstream fi(m.dataset + "/img.txt"), fg(m.dataset + "/groundtruth.txt"); std::string line;
+    if (!fi || !fg) { set_error("Load dataset error: img.txt / groundtruth.txt missing in %s", m.dataset.c_str()); return MON_ERR_IO; }
+    std::getline(fi, line);                                             // skip comments
+    while (std::getline(fi, line)) { if (line.empty()) continue; std::stringstream s2(line); std::string st, nm; s2 >> st >> nm; m.stamp_to_idx[st] = (uint32_t)m.names.size(); m.names.push_back(nm); m.stamps.push_back(st); }
+    std::getline(fg, line);
+    while (std::getline(fg, line)) {
+        if (line.empty()) continue; std::stringstream s2(line); std::string st; float t[3], qx, qy, qz, qw; s2 >> st >> t[0] >> t[1] >> t[2] >> qx >> qy >> qz >> qw;
+        float M[16]; pose_from_tq(t, qx, qy, qz, qw, M); m.poses.insert(m.poses.end(), M, M + 16);
+    }
+    const size_t n = m.poses.size() / 16;
+    if (n == 0 || n != m.names.size()) { set_error("Load dataset error...No images (%zu poses, %zu image names)", n, m.names.size()); return MON_ERR_IO; }
+    const size_t px = (size_t)m.H * m.W; std::string err;
+    std::vector<uint8_t> rgb(px * 3), inst(px); std::vector<float> depth(m.use_depth ? px : 0);
+    for (int g = 0; g < m.n_dev; ++g) { Dataset* d = nullptr; int rc = dataset_create(g, m.H, m.W, m.fx, m.fy, m.cx, m.cy, (uint32_t)n, m.use_depth, &d); if (rc) return rc; m.ds.push_back(d); }
+    for (size_t i = 0; i < n; ++i) {
+        PngImage c, s, z;
+        if (!png_read(m.dataset + "/rgb/" + m.names[i], c, err) || !png_read(m.dataset + "/instance/" + m.names[i], s, err)) { set_error("%s", err.c_str()); return MON_ERR_IO; }
+        if (c.width != m.W || c.height != m.H || s.width != m.W || s.height != m.H || c.bit_depth != 8 || c.channels < 3 || s.bit_depth != 8) { set_error("image %s does not match config.yaml", m.names[i].c_str()); return MON_ERR_IO; }
+        for (size_t p = 0; p < px; ++p) { rgb[3 * p] = c.data[p * c.channels]; rgb[3 * p + 1] = c.data[p * c.channels + 1]; rgb[3 * p + 2] = c.data[p * c.channels + 2]; inst[p] = s.data[p * s.channels]; }
+        if (m.use_depth) {
+            if (!png_read(m.dataset + "/depth/" + m.names[i], z, err)) { set_error("%s", err.c_str()); return MON_ERR_IO; }
+            if (z.width != m.W || z.height != m.H || z.bit_depth != 16) { set_error("depth image %s must be 16-bit %dx%d", m.names[i].c_str(), m.W, m.H); return MON_ERR_IO; }
+            for (size_t p = 0; p < px; ++p) depth[p] = (float)((z.data[2 * p * z.channels] << 8) | z.data[2 * p * z.channels + 1]) * m.depth_scale;      // convertTo(CV_32FC1, mfDepthScale), nerf_data.cu:187
+        }
+        for (int g = 0; g < m.n_dev; ++g) {                             // PNG stores RGB; is_bgr = 0 (cv::imread would hand BGR)
+            int rc = dataset_add_frame(m.ds[g], (uint32_t)i, rgb.data(), 3, 0, inst.data(), m.use_depth ? depth.data() : nullptr, &m.poses[16 * i]); if (rc) return rc;
+        }
+    }
+    return MON_OK;
+}
+
+static void train_offline_thread(OfflineManager* m, OfflineObject* o) {  // NeRF::TrainOffline, nerf.cu:120-152
+    o->rc = model_add_boxes(*o->model, o->boxes.data(), o->boxes.size());
+    for (int i = 1; i <= m->outer_iters && o->rc == MON_OK; ++i) {
+        o->rc = model_train(*o->model, m->inner_iters, &o->last_loss, 7);
+        if (o->rc == MON_OK) std::printf("Id: %d Step: %d loss: %f\n", o->id, i * m->inner_iters, o->last_loss);
+    }
+    if (o->rc != MON_OK) o->err = "training failed";
+}
+
+int offline_create_nerf(OfflineManager& m, const char* object_file) {    // nerf_manager.cu:64-92, nerf.cu:58-118
+    std::ifstream f(object_file);
+    if (!f) { set_error("object file error... %s", object_file); return MON_ERR_IO; }
+    if (m.ds.empty()) { set_error("CreateNeRF before ReadDataset"); return MON_ERR_STATE; }
+    OfflineObject* o = new OfflineObject(); o->id = (int)m.objs.size(); o->device = o->id % m.n_dev;
+    std::string line; std::getline(f, line); std::getline(f, line); std::stringstream ss(line); float v[10]; ss >> o->cls; for (float& x : v) ss >> x;
+    float Two[16]; pose_from_tq(v, v[3], v[4], v[5], v[6], Two); rigid_inverse(Two, o->Tow);
+    for (int a = 0; a < 3; ++a) { o->amin[a] = -v[7 + a]; o->amax[a] = v[7 + a]; }
+    while (std::getline(f, line)) {
+        if (line.empty()) continue; std::stringstream s2(line); std::string st; mon_frame_bbox b{}; s2 >> st >> b.x >> b.y >> b.h >> b.w;
+        auto it = m.stamp_to_idx.find(st);
+        if (it == m.stamp_to_idx.end()) { delete o; set_error("object file %s references unknown stamp %s", object_file, st.c_str()); return MON_ERR_IO; }
+        b.FrameId = it->second; o->boxes.push_back(b); o->stamps.push_back(st);
+    }
+    int rc = model_create(m.ds[o->device], m.cfg, o->cls, o->Tow, o->amin, o->amax, &o->model);
+    if (rc) { delete o; return rc; }
+    m.objs.push_back(o);
+    m.threads.emplace_back(train_offline_thread, &m, o);                // one thread per model, nerf_manager.cu:89
+    return MON_OK;
+}
+
+int offline_wait(OfflineManager& m) {                                    // nerf_manager.cu:94-102
+    if (m.threads.empty()) { set_error("WaitThreadsEnd: no threads"); return MON_ERR_STATE; }
+    for (auto& t : m.threads) if (t.joinable()) t.join();
+    m.threads.clear();
+    for (auto* o : m.objs) if (o->rc != MON_OK) { set_error("object %d: %s", o->id, o->err.c_str()); return o->rc; }
+    return MON_OK;
+}
+
+// Test images of one object for each of its training boxes: <out>/<id>/test_img|test_depth|test_mask/<stamp>.png,
+// 8-bit colour, 16-bit depth x 20000, 8-bit mask (nerf.cu:335-349).
+int offline_render_test(OfflineManager& m, int idx, const char* out_dir, int max_views) {
+    if (idx < 0 || idx >= (int)m.objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
+    OfflineObject* o = m.objs[idx]; const std::string root = std::string(out_dir) + "/" + std::to_string(o->id);
+    for (const char* sub : { "", "/test_img", "/test_depth", "/test_mask" }) ::mkdir((root + sub).c_str(), 0755);
+    std::string err; const size_t nv = max_views > 0 && (size_t)max_views < o->boxes.size() ? (size_t)max_views : o->boxes.size();
+    for (size_t i = 0; i < nv; ++i) {
+        const mon_frame_bbox b = o->boxes[i]; const size_t n = (size_t)b.w * b.h;
+        std::vector<float> rgb(3 * n), depth(n), mask(n);
+        int rc = model_render(*o->model, b, &m.poses[16 * (size_t)b.FrameId], 0, rgb.data(), depth.data(), mask.data(), 0); if (rc) return rc;
+        std::vector<uint8_t> c8(3 * n), m8(n), d16(2 * n);
+        for (size_t p = 0; p < 3 * n; ++p) { const float q = rgb[p] * 255.f; c8[p] = (uint8_t)(q < 0.f ? 0.f : (q > 255.f ? 255.f : std::nearbyint(q))); }      // convertTo(CV_8UC3, 255)
+        for (size_t p = 0; p < n; ++p) {
+            m8[p] = (uint8_t)std::nearbyint(mask[p] * 255.f);
+            const float q = depth[p] * 20000.f; const uint32_t u = (uint32_t)(q < 0.f ? 0.f : (q > 65535.f ? 65535.f : std::nearbyint(q))); d16[2 * p] = (uint8_t)(u >> 8); d16[2 * p + 1] = (uint8_t)u;
+        }
+        if (!png_write(root + "/test_img/" + o->stamps[i] + ".png", (int)b.w, (int)b.h, 3, 8, c8.data(), err) ||
+            !png_write(root + "/test_depth/" + o->stamps[i] + ".png", (int)b.w, (int)b.h, 1, 16, d16.data(), err) ||
+            !png_write(root + "/test_mask/" + o->stamps[i] + ".png", (int)b.w, (int)b.h, 1, 8, m8.data(), err)) { set_error("%s", err.c_str()); return MON_ERR_IO; }
+    }
+    return MON_OK;
+}
+
+int offline_destroy(OfflineManager* m) {
+    if (!m) return MON_OK;
+    for (auto& t : m->threads) if (t.joinable()) t.join();
+    for (auto* o : m->objs) { if (o->model) model_destroy(o->model); delete o; }
+    for (auto* d : m->ds) dataset_destroy(d);
+    delete m; return MON_OK;
+}
+
+}  // namespace mon
+
+using namespace mon;
+struct mon_offline { OfflineManager* m; };
+#define REQ(p) do { if (!(p)) { set_error("%s: null argument", __func__); return MON_ERR_ARG; } } while (0)
+
+extern "C" {
+int mon_offline_create(const char* dataset_path, const char* network_config_file, int use_dense_depth, mon_offline** out) {   // NerfManagerOffline ctor
+    REQ(dataset_path); REQ(network_config_file); REQ(out);
+    OfflineManager* m = new OfflineManager(); m->dataset = dataset_path; m->cfg_path = network_config_file; m->use_depth = use_dense_depth != 0;
+    *out = new mon_offline{ m }; return MON_OK;
+}
+int mon_offline_init(mon_offline* h) { REQ(h); return offline_init(*h->m); }
+int mon_offline_read_dataset(mon_offline* h) { REQ(h); return offline_read_dataset(*h->m); }
+int mon_offline_create_nerf(mon_offline* h, const char* object_file) { REQ(h); REQ(object_file); return offline_create_nerf(*h->m, object_file); }
+int mon_offline_wait_threads_end(mon_offline* h) { REQ(h); return offline_wait(*h->m); }
+int mon_offline_n_objects(mon_offline* h, int* n) { REQ(h); REQ(n); *n = (int)h->m->objs.size(); return MON_OK; }
+int mon_offline_object_loss(mon_offline* h, int idx, float* loss, int* device) { REQ(h); REQ(loss); if (idx < 0 || idx >= (int)h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *loss = h->m->objs[idx]->last_loss; if (device) *device = h->m->objs[idx]->device; return MON_OK; }
+int mon_offline_render_test(mon_offline* h, int idx, const char* out_dir, int max_views) { REQ(h); REQ(out_dir); return offline_render_test(*h->m, idx, out_dir, max_views); }
+int mon_offline_destroy(mon_offline* h) { if (!h) return MON_OK; offline_destroy(h->m); delete h; return MON_OK; }
+
+int mon_png_read(const char* path, int* width, int* height, int* channels, int* bit_depth, uint8_t* pixels, size_t capacity) {
+    REQ(path); REQ(width); REQ(height); REQ(channels); REQ(bit_depth);
+    PngImage img; std::string err;
+    if (!png_read(path, img, err)) { set_error("%s", err.c_str()); return MON_ERR_IO; }
+    *width = img.width; *height = img.height; *channels = img.channels; *bit_depth = img.bit_depth;
+    if (pixels) { if (capacity < img.data.size()) { set_error("png_read: buffer too small"); return MON_ERR_ARG; } std::memcpy(pixels, img.data.data(), img.data.size()); }
+    return MON_OK;
+}
+int mon_png_write(const char* path, int width, int height, int channels, int bit_depth, const uint8_t* pixels_big_endian) {
+    REQ(path); REQ(pixels_big_endian); std::string err;
+    if (!png_write(path, width, height, channels, bit_depth, pixels_big_endian, err)) { set_error("%s", err.c_str()); return MON_ERR_IO; }
+    return MON_OK;
+}
+}

@@ -1,0 +1,89 @@
+"""Sequence-format support of the drop-in boundary: PNG codec (CPU) and the NerfManagerOffline flow (GPU)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_png_codec_against_pillow(pkg, tmp_path):
+    from PIL import Image
+    rs = np.random.RandomState(0)
+    rgb = rs.randint(0, 256, (37, 53, 3)).astype(np.uint8); gray = rs.randint(0, 256, (37, 53)).astype(np.uint8)
+    d16 = rs.randint(0, 65536, (37, 53)).astype(np.uint16); rgba = rs.randint(0, 256, (20, 31, 4)).astype(np.uint8)
+    # Pillow -> ours (all PNG filter types appear in Pillow's adaptive filtering)
+    Image.fromarray(rgb).save(tmp_path / "a.png"); Image.fromarray(gray).save(tmp_path / "b.png"); Image.fromarray(d16).save(tmp_path / "c.png")
+    Image.fromarray(rgba).save(tmp_path / "d.png")
+    smooth = (np.add.outer(np.arange(64), np.arange(80))[..., None] * np.array([1, 2, 3])).astype(np.uint8); Image.fromarray(smooth).save(tmp_path / "e.png")
+    assert np.array_equal(pkg.png_read(str(tmp_path / "a.png")), rgb)
+    assert np.array_equal(pkg.png_read(str(tmp_path / "b.png"))[..., 0], gray)
+    assert np.array_equal(pkg.png_read(str(tmp_path / "c.png"))[..., 0], d16)
+    assert np.array_equal(pkg.png_read(str(tmp_path / "d.png")), rgba)
+    assert np.array_equal(pkg.png_read(str(tmp_path / "e.png")), smooth)
+    # ours -> Pillow
+    pkg.png_write(str(tmp_path / "w1.png"), rgb); pkg.png_write(str(tmp_path / "w2.png"), gray); pkg.png_write(str(tmp_path / "w3.png"), d16)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "w1.png")), rgb)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "w2.png")), gray)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "w3.png")).astype(np.uint16), d16)
+    with pytest.raises(pkg.MonError):
+        pkg.png_read(str(tmp_path / "missing.png"))
+    (tmp_path / "bad.png").write_bytes(b"not a png at all, definitely" * 4)
+    with pytest.raises(pkg.MonError):
+        pkg.png_read(str(tmp_path / "bad.png"))
+
+
+def test_offline_manager_errors_without_dataset(pkg, tmp_path):
+    m = pkg.OfflineManager(str(tmp_path), os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json"))
+    if pkg.device_count() == 0:
+        with pytest.raises(pkg.MonError) as e:
+            m.init()
+        assert e.value.code == 2                       # no device: fails loudly, no CPU fallback
+    else:
+        m.init()
+        with pytest.raises(pkg.MonError) as e:
+            m.read_dataset()
+        assert e.value.code == 4
+    with pytest.raises(pkg.MonError):
+        m.create_nerf(str(tmp_path / "nope.txt"))
+    m.close()
+
+
+@pytest.mark.gpu
+def test_offline_nerf_flow_on_disk_sequence(pkg, ss, tmp_path):
+    """OfflineNeRF's call sequence (MON/main.cpp:322-340) on a synthetic sequence written in the reference's on-disk layout:
+    3 objects, thread per object, test images written as PNG and compared with the ground-truth frames."""
+    from PIL import Image
+    assert pkg.device_count() >= 1
+    sc = ss.make_scene(n_views=10, H=120, W=160, f=130.0, n_objects=3, seed=5)
+    seq = str(tmp_path / "seq"); ss.write_sequence(sc, seq)
+    os.environ["MON_OFFLINE_OUTER"] = "2"; os.environ["MON_OFFLINE_INNER"] = "150"
+    m = pkg.OfflineManager(seq, os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json"), use_dense_depth=True)
+    m.init(); m.read_dataset()
+    for k in range(3):
+        m.create_nerf(os.path.join(seq, "obj_offline", "%d.txt" % k))
+    m.wait_threads_end()
+    assert m.n_objects() == 3
+    out = str(tmp_path / "out"); os.makedirs(out)
+    for k in range(3):
+        loss, dev = m.object_loss(k); assert loss < 0.08 and dev == k % pkg.device_count()
+        m.render_test(k, out, 2)
+        ob = sc.objects[k]; v, x, y, h, w = (int(q) for q in ob["boxes"][0]); stamp = "%.6f" % (v * 0.1)
+        img = np.asarray(Image.open(os.path.join(out, str(k), "test_img", stamp + ".png"))).astype(np.float64) / 255.0
+        msk = np.asarray(Image.open(os.path.join(out, str(k), "test_mask", stamp + ".png"))) > 127
+        dep = np.asarray(Image.open(os.path.join(out, str(k), "test_depth", stamp + ".png"))).astype(np.float64) / 20000.0
+        gm = sc.instance[v, y:y + h, x:x + w] == ob["cls"]
+        gt = np.where(gm[..., None], sc.rgb[v, y:y + h, x:x + w] / 255.0, 1.0)
+        assert img.shape == (h, w, 3)
+        iou = (msk & gm).sum() / max(1, (msk | gm).sum())
+        psnr = -10 * np.log10(np.mean((img - gt) ** 2))
+        assert iou > 0.85 and psnr > 18.0, (k, iou, psnr)
+        both = msk & gm
+        assert np.abs(dep[both] - sc.depth[v, y:y + h, x:x + w][both]).mean() < 0.08
+    m.close()
+    # the headless executable, same sequence, 1 object
+    exe = os.path.join(ROOT, "ro-map_amd", "offline_nerf")
+    r = subprocess.run([exe, os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json"), seq, "0", "1", str(tmp_path / "out2")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Training completed" in r.stdout, r.stdout + r.stderr
+    assert os.path.exists(os.path.join(str(tmp_path / "out2"), "0", "test_img"))

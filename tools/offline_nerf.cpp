@@ -1,0 +1,35 @@
+// offline_nerf.cpp -- headless equivalent of the reference's OfflineNeRF executable (MON/main.cpp:287-343) without the
+// Pangolin viewer: OfflineNeRF <config.json> <dataset_path> <UseGTdepth 0|1> [n_objects=4] [out_dir=./output]
+// Links only against the C ABI (include/mon_core.h).
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include "../include/mon_core.h"
+
+static int fail(const char* what) { std::fprintf(stderr, "%s: %s\n", what, mon_last_error()); return 1; }
+
+int main(int argc, char** argv) {
+    std::puts("......Multi-Object NeRF Offline (MI355X core)......");
+    if (argc < 4) { std::fprintf(stderr, "param error...\n./offline_nerf ./configs/base.json dataset_path UseGTdepth [n_objects] [out_dir]\n"); return 0; }
+    const std::string cfg = argv[1], dataset = argv[2]; const int use_depth = std::atoi(argv[3]);
+    const int n_objects = argc > 4 ? std::atoi(argv[4]) : 4;                 // main.cpp:315-319 hard-codes 4
+    const std::string out = argc > 5 ? argv[5] : "./output";
+    if (use_depth != 0 && use_depth != 1) { std::fprintf(stderr, "UseGTdepth param error...\n0 or 1\n"); return 0; }
+    mon_offline* mgr = nullptr;
+    if (mon_offline_create(dataset.c_str(), cfg.c_str(), use_depth, &mgr)) return fail("create");
+    if (mon_offline_init(mgr)) return fail("Init");
+    if (mon_offline_read_dataset(mgr)) return fail("ReadDataset");
+    for (int i = 0; i < n_objects; ++i) {
+        const std::string obj = dataset + "/obj_offline/" + std::to_string(i) + ".txt";
+        if (mon_offline_create_nerf(mgr, obj.c_str())) return fail("CreateNeRF");
+    }
+    if (mon_offline_wait_threads_end(mgr)) return fail("WaitThreadsEnd");
+    for (int i = 0; i < n_objects; ++i) {
+        float loss = 0.f; int dev = 0; mon_offline_object_loss(mgr, i, &loss, &dev);
+        std::printf("object %d on device %d: final loss %f\n", i, dev, loss);
+        if (mon_offline_render_test(mgr, i, out.c_str(), 4)) return fail("render");
+    }
+    mon_offline_destroy(mgr);
+    std::puts("Training completed");
+    return 0;
+}
