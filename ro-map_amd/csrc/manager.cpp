@@ -157,6 +157,7 @@ int offline_wait(OfflineManager& m) {                                    // nerf
 int offline_render_test(OfflineManager& m, int idx, const char* out_dir, int max_views) {
     if (idx < 0 || idx >= (int)m.objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
     OfflineObject* o = m.objs[idx]; const std::string root = std::string(out_dir) + "/" + std::to_string(o->id);
+    ::mkdir(out_dir, 0755);                                              // mkdir -p of nerf.cu:258-283, one level at a time
     for (const char* sub : { "", "/test_img", "/test_depth", "/test_mask" }) ::mkdir((root + sub).c_str(), 0755);
     std::string err; const size_t nv = max_views > 0 && (size_t)max_views < o->boxes.size() ? (size_t)max_views : o->boxes.size();
     for (size_t i = 0; i < nv; ++i) {
