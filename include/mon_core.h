@@ -154,6 +154,23 @@ int mon_offline_object_loss(mon_offline* mgr, int idx, float* loss, int* device)
 /* test images for the first max_views (0 = all) training boxes of object idx: <out_dir>/<id>/test_{img,depth,mask}/<stamp>.png (nerf.cu:335-349) */
 int mon_offline_render_test(mon_offline* mgr, int idx, const char* out_dir, int max_views);
 int mon_offline_destroy(mon_offline* mgr);
+/* ---- nerf::NerfManagerOnline (CORE/include/nerf_manager.h:54-90, CORE/src/nerf_manager.cu:133-312) + the online half of nerf::NeRF
+ * (nerf.cu:155-253, 406-448): per-object training thread sleeping on a condition variable, training gated on > 10 boxes,
+ * per-object dataset mutex, finish protocol.  cv::Mat arguments become raw pointers (8-bit BGR(A), 8-bit instance, float depth). */
+typedef struct mon_online mon_online;
+int mon_online_create(const char* network_config_file, int use_sparse_depth, int train_step_iterations, mon_online** out);
+int mon_online_init(mon_online* mgr);
+int mon_online_dataset_init(mon_online* mgr, float fx, float fy, float cx, float cy, int H, int W, size_t imgs);
+int mon_online_new_frame(mon_online* mgr, uint32_t img_id, const char* timestamp, const uint8_t* bgr, int channels, const uint8_t* instance,
+                         const float* depth, const float* Twc16);                                   /* NewFrameToDataset */
+int mon_online_create_nerf(mon_online* mgr, int cls, const float* Tow16, const float* aabb_min3, const float* aabb_max3, size_t* idx_out);   /* CreateNeRF: 1.1x / 1.2x box inflation applied */
+int mon_online_update_nerf_bbox(mon_online* mgr, size_t idx, const mon_frame_bbox* boxes, size_t n, int train_step);                        /* UpdateNeRFBbox */
+int mon_online_get_frame_idx(mon_online* mgr, const char* timestamp, int* idx);                     /* GetFrameIdx (-1 if unknown) */
+int mon_online_wait_threads_end(mon_online* mgr);                                                  /* WaitThreadsEnd: request finish + join */
+int mon_online_object_info(mon_online* mgr, size_t idx, float* loss, int* train_calls, int* device, uint32_t* n_boxes);
+int mon_online_render(mon_online* mgr, size_t idx, mon_frame_bbox box, const float* Twc16, float* rgb, float* depth, float* mask);   /* one view of RenderNeRFsTest */
+int mon_online_destroy(mon_online* mgr);
+
 /* PNG codec used for the sequence layout (8/16-bit, gray/RGB/RGBA in; gray/RGB out; 16-bit samples big-endian as in the file).
  * pixels may be NULL to query the header only. */
 int mon_png_read(const char* path, int* width, int* height, int* channels, int* bit_depth, uint8_t* pixels, size_t capacity);

@@ -75,6 +75,17 @@ _SIGS = {
     "mon_offline_object_loss": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "mon_offline_render_test": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "mon_offline_destroy": (C.c_int, [C.c_void_p]),
+    "mon_online_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mon_online_init": (C.c_int, [C.c_void_p]),
+    "mon_online_dataset_init": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_size_t]),
+    "mon_online_new_frame": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mon_online_create_nerf": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]),
+    "mon_online_update_nerf_bbox": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]),
+    "mon_online_get_frame_idx": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
+    "mon_online_wait_threads_end": (C.c_int, [C.c_void_p]),
+    "mon_online_object_info": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
+    "mon_online_render": (C.c_int, [C.c_void_p, C.c_size_t, MonBBox, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mon_online_destroy": (C.c_int, [C.c_void_p]),
     "mon_png_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
     "mon_png_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mon_device_synchronize": (C.c_int, [C.c_int]),
@@ -295,3 +306,50 @@ class OfflineManager:
     def close(self):
         if self.h:
             lib().mon_offline_destroy(self.h); self.h = None
+
+
+class OnlineManager:
+    """nerf::NerfManagerOnline as the SLAM frontend drives it (REF/src/System.cc:120-138, LocalMapping.cc:1122-1270)."""
+
+    def __init__(self, config_path, use_sparse_depth=False, train_step_iterations=500):
+        self.h = C.c_void_p()
+        _check(lib().mon_online_create(config_path.encode(), int(use_sparse_depth), int(train_step_iterations), C.byref(self.h)))
+
+    def init(self):
+        _check(lib().mon_online_init(self.h))
+
+    def dataset_init(self, fx, fy, cx, cy, H, W, imgs):
+        _check(lib().mon_online_dataset_init(self.h, fx, fy, cx, cy, H, W, imgs))
+
+    def new_frame(self, img_id, stamp, bgr_u8, instance_u8, Twc16, depth=None):
+        bgr = np.ascontiguousarray(bgr_u8, np.uint8); inst = np.ascontiguousarray(instance_u8, np.uint8); pose = np.ascontiguousarray(Twc16, np.float32)
+        d = None if depth is None else np.ascontiguousarray(depth, np.float32)
+        _check(lib().mon_online_new_frame(self.h, img_id, stamp.encode(), _p(bgr), bgr.shape[2], _p(inst), _p(d), _p(pose)))
+
+    def create_nerf(self, cls, Tow16, aabb_min, aabb_max):
+        a, b, c = (np.ascontiguousarray(v, np.float32) for v in (Tow16, aabb_min, aabb_max)); idx = C.c_size_t(0)
+        _check(lib().mon_online_create_nerf(self.h, int(cls), _p(a), _p(b), _p(c), C.byref(idx))); return idx.value
+
+    def update_nerf_bbox(self, idx, boxes, train_step):
+        b = np.ascontiguousarray(boxes, np.uint32).reshape(-1, 5)
+        _check(lib().mon_online_update_nerf_bbox(self.h, idx, _p(b), b.shape[0], int(train_step)))
+
+    def get_frame_idx(self, stamp):
+        i = C.c_int(0); _check(lib().mon_online_get_frame_idx(self.h, stamp.encode(), C.byref(i))); return i.value
+
+    def wait_threads_end(self):
+        _check(lib().mon_online_wait_threads_end(self.h))
+
+    def object_info(self, idx):
+        l = C.c_float(0); t = C.c_int(0); d = C.c_int(0); n = C.c_uint32(0)
+        _check(lib().mon_online_object_info(self.h, idx, C.byref(l), C.byref(t), C.byref(d), C.byref(n))); return dict(loss=l.value, train_calls=t.value, device=d.value, n_boxes=n.value)
+
+    def render(self, idx, box, Twc16):
+        FrameId, x, y, h, w = (int(v) for v in box)
+        rgb = np.empty((h, w, 3), np.float32); depth = np.empty((h, w), np.float32); mask = np.empty((h, w), np.float32)
+        pose = np.ascontiguousarray(Twc16, np.float32)
+        _check(lib().mon_online_render(self.h, idx, MonBBox(FrameId, x, y, h, w), _p(pose), _p(rgb), _p(depth), _p(mask))); return rgb, depth, mask
+
+    def close(self):
+        if self.h:
+            lib().mon_online_destroy(self.h); self.h = None

@@ -4,8 +4,12 @@
 // (object file, thread body: 10 x 500 iterations) and the test-image writer of nerf.cu:255-349.
 // One std::thread per object, object k on device k mod nGPU (nerf.cu:27-33), one dataset replica per device.
 #include <sys/stat.h>
+#include <unistd.h>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
+#include <memory>
+#include <mutex>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -185,10 +189,69 @@ int offline_destroy(OfflineManager* m) {
     delete m; return MON_OK;
 }
 
+// ------------------------------------------------------------------ online manager
+// nerf::NerfManagerOnline + the online half of nerf::NeRF (CORE/src/nerf_manager.cu:133-312, CORE/src/nerf.cu:155-253,
+// 406-448): frames arrive one at a time from the SLAM frontend, every object has its own training thread that sleeps on a
+// condition variable until new 2-D boxes arrive, trains `train_step` x TrainStepIterations iterations once it has more than
+// 10 boxes, and does one last round when asked to finish.
+struct OnlineObject {
+    int id = 0, device = 0, cls = 0; float Tow[16]; float amin[3], amax[3];
+    std::vector<mon_frame_bbox> boxes; size_t n_boxes = 0, n_uploaded = 0; int pending_train_step = 0, iterations = 500;
+    std::mutex mu_boxes, mu_finish; std::condition_variable cond; bool finish = false;
+    std::mutex* dataset_mutex = nullptr;
+    Model* model = nullptr; float last_loss = 0.f; int train_calls = 0; int rc = 0;
+};
+
+struct OnlineManager {
+    std::string cfg_path; bool use_depth = false; int iters = 500, n_dev = 0, next_dev = 0; mon_config cfg{};
+    size_t n_images = 0; std::vector<Dataset*> ds; std::vector<std::vector<std::unique_ptr<std::mutex>>> ds_mutex;
+    std::map<std::string, uint32_t> stamp_to_idx; std::vector<OnlineObject*> objs; std::vector<std::thread> threads;
+};
+
+static bool online_check_finish(OnlineObject* o) { std::unique_lock<std::mutex> l(o->mu_finish); return o->finish; }
+
+static void train_online_thread(OnlineObject* o) {                       // NeRF::TrainOnline, nerf.cu:187-253
+    int train_step_count = 0;
+    for (;;) {
+        int train_step = 0;
+        {
+            std::unique_lock<std::mutex> lock(o->mu_boxes);
+            if (o->n_boxes == o->n_uploaded && !online_check_finish(o)) o->cond.wait(lock);          // no update: wait (:209-212)
+            if (o->n_boxes > o->n_uploaded) {
+                o->rc = model_add_boxes(*o->model, o->boxes.data() + o->n_uploaded, o->n_boxes - o->n_uploaded);   // UpdateFrameIdAndBboxOnline
+                o->n_uploaded = o->n_boxes; train_step = o->pending_train_step; o->pending_train_step = 0;
+            }
+        }
+        if (o->rc == MON_OK && o->n_uploaded > 10) {                      // :223
+            for (int i = 0; i < train_step && o->rc == MON_OK; ++i) {
+                std::unique_lock<std::mutex> dl(*o->dataset_mutex);      // GenerateBatch under the per-object dataset mutex (nerf_model.cu:1675-1678)
+                o->rc = model_train(*o->model, o->iterations, &o->last_loss, 7); ++o->train_calls; ++train_step_count;
+            }
+        }
+        if (online_check_finish(o) || o->rc != MON_OK) break;
+        ::usleep(3000);
+    }
+    if (o->rc == MON_OK && o->n_uploaded > 0) {                           // last time (:246)
+        std::unique_lock<std::mutex> dl(*o->dataset_mutex);
+        o->rc = model_train(*o->model, o->iterations, &o->last_loss, 7); ++o->train_calls;
+    }
+    std::printf("Id: %d finished! \n", o->id);
+}
+
+int online_destroy(OnlineManager* m) {
+    if (!m) return MON_OK;
+    for (auto* o : m->objs) { { std::unique_lock<std::mutex> l(o->mu_finish); o->finish = true; } o->cond.notify_all(); }
+    for (auto& t : m->threads) if (t.joinable()) t.join();
+    for (auto* o : m->objs) { if (o->model) model_destroy(o->model); delete o; }
+    for (auto* d : m->ds) dataset_destroy(d);
+    delete m; return MON_OK;
+}
+
 }  // namespace mon
 
 using namespace mon;
 struct mon_offline { OfflineManager* m; };
+struct mon_online { OnlineManager* m; };
 #define REQ(p) do { if (!(p)) { set_error("%s: null argument", __func__); return MON_ERR_ARG; } } while (0)
 
 extern "C" {
@@ -205,6 +268,81 @@ int mon_offline_n_objects(mon_offline* h, int* n) { REQ(h); REQ(n); *n = (int)h-
 int mon_offline_object_loss(mon_offline* h, int idx, float* loss, int* device) { REQ(h); REQ(loss); if (idx < 0 || idx >= (int)h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *loss = h->m->objs[idx]->last_loss; if (device) *device = h->m->objs[idx]->device; return MON_OK; }
 int mon_offline_render_test(mon_offline* h, int idx, const char* out_dir, int max_views) { REQ(h); REQ(out_dir); return offline_render_test(*h->m, idx, out_dir, max_views); }
 int mon_offline_destroy(mon_offline* h) { if (!h) return MON_OK; offline_destroy(h->m); delete h; return MON_OK; }
+
+// ---- NerfManagerOnline
+int mon_online_create(const char* network_config_file, int use_sparse_depth, int train_step_iterations, mon_online** out) {
+    REQ(network_config_file); REQ(out);
+    OnlineManager* m = new OnlineManager(); m->cfg_path = network_config_file; m->use_depth = use_sparse_depth != 0; m->iters = train_step_iterations;
+    *out = new mon_online{ m }; return MON_OK;
+}
+int mon_online_init(mon_online* h) {                                      // nerf_manager.cu:136-158
+    REQ(h); OnlineManager& m = *h->m;
+    int rc = device_count(&m.n_dev); if (rc) return rc;
+    rc = config_from_json(m.cfg_path.c_str(), m.cfg); if (rc) return rc;
+    m.cfg.use_depth = m.use_depth ? 1 : 0; return MON_OK;
+}
+int mon_online_dataset_init(mon_online* h, float fx, float fy, float cx, float cy, int H, int W, size_t imgs) {   // :160-187
+    REQ(h); OnlineManager& m = *h->m; m.n_images = imgs; m.ds_mutex.resize(m.n_dev);
+    for (int g = 0; g < m.n_dev; ++g) { Dataset* d = nullptr; int rc = dataset_create(g, H, W, fx, fy, cx, cy, (uint32_t)imgs, m.use_depth, &d); if (rc) return rc; m.ds.push_back(d); }
+    return MON_OK;
+}
+int mon_online_new_frame(mon_online* h, uint32_t img_id, const char* timestamp, const uint8_t* bgr, int channels, const uint8_t* instance, const float* depth, const float* Twc16) {   // :189-218
+    REQ(h); REQ(timestamp); OnlineManager& m = *h->m;
+    m.stamp_to_idx[timestamp] = img_id;                                   // nerf_data.cu:284
+    for (int g = 0; g < m.n_dev; ++g) {
+        for (auto& mu : m.ds_mutex[g]) mu->lock();                        // exclude every object's GenerateBatch on that device while the frame lands
+        const int rc = dataset_add_frame(m.ds[g], img_id, bgr, channels, 1, instance, m.use_depth ? depth : nullptr, Twc16);
+        for (auto& mu : m.ds_mutex[g]) mu->unlock();
+        if (rc) return rc;
+    }
+    return MON_OK;
+}
+int mon_online_create_nerf(mon_online* h, int cls, const float* Tow16, const float* aabb_min3, const float* aabb_max3, size_t* idx_out) {   // :237-261 + SetAttributes nerf.cu:155-185
+    REQ(h); REQ(Tow16); REQ(aabb_min3); REQ(aabb_max3); REQ(idx_out); OnlineManager& m = *h->m;
+    if (m.ds.empty()) { set_error("CreateNeRF before DatasetInit"); return MON_ERR_STATE; }
+    OnlineObject* o = new OnlineObject(); o->id = (int)m.objs.size(); o->device = m.next_dev; m.next_dev = (m.next_dev + 1) % m.n_dev; o->cls = cls; o->iterations = m.iters;
+    std::memcpy(o->Tow, Tow16, 64);
+    const float k = (cls == 41 || cls == 73) ? 1.2f : 1.1f;              // appropriately expand the 3-D box (nerf.cu:163-172)
+    for (int a = 0; a < 3; ++a) { o->amin[a] = k * aabb_min3[a]; o->amax[a] = k * aabb_max3[a]; }
+    o->boxes.resize(m.n_images);                                          // mFrameIdBbox.resize(maxnumBbox) :182
+    m.ds_mutex[o->device].emplace_back(new std::mutex()); o->dataset_mutex = m.ds_mutex[o->device].back().get();
+    int rc = model_create(m.ds[o->device], m.cfg, cls, o->Tow, o->amin, o->amax, &o->model);
+    if (rc) { delete o; return rc; }
+    *idx_out = m.objs.size(); m.objs.push_back(o);
+    m.threads.emplace_back(train_online_thread, o);                      // thread per object, nerf_manager.cu:259
+    return MON_OK;
+}
+int mon_online_update_nerf_bbox(mon_online* h, size_t idx, const mon_frame_bbox* boxes, size_t n, int train_step) {   // :298-303 + UpdateFrameBBox nerf.cu:406-421
+    REQ(h); if (n == 0) return MON_OK; REQ(boxes);
+    if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
+    OnlineObject* o = h->m->objs[idx];
+    std::unique_lock<std::mutex> lock(o->mu_boxes);
+    if (o->n_boxes + n > o->boxes.size()) o->boxes.resize(o->n_boxes + n);
+    for (size_t i = 0; i < n; ++i) o->boxes[o->n_boxes + i] = boxes[i];
+    o->n_boxes += n; o->pending_train_step = train_step; o->cond.notify_all();
+    return MON_OK;
+}
+int mon_online_get_frame_idx(mon_online* h, const char* timestamp, int* idx) {   // GetFrameIdx :288-296 (key = std::to_string(double) on the caller's side)
+    REQ(h); REQ(timestamp); REQ(idx); auto it = h->m->stamp_to_idx.find(timestamp); *idx = it == h->m->stamp_to_idx.end() ? -1 : (int)it->second; return MON_OK;
+}
+int mon_online_wait_threads_end(mon_online* h) {                           // :263-278
+    REQ(h); OnlineManager& m = *h->m;
+    if (m.threads.empty()) { set_error("WaitThreadsEnd: no threads"); return MON_ERR_STATE; }
+    for (auto* o : m.objs) { { std::unique_lock<std::mutex> l(o->mu_finish); o->finish = true; } o->cond.notify_all(); }     // RequestFinish nerf.cu:443-448
+    for (auto& t : m.threads) if (t.joinable()) t.join();
+    m.threads.clear(); std::puts("All NeRF threads completed ...");
+    for (auto* o : m.objs) if (o->rc != MON_OK) { set_error("object %d failed", o->id); return o->rc; }
+    return MON_OK;
+}
+int mon_online_object_info(mon_online* h, size_t idx, float* loss, int* train_calls, int* device, uint32_t* n_boxes) {
+    REQ(h); if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
+    OnlineObject* o = h->m->objs[idx]; if (loss) *loss = o->last_loss; if (train_calls) *train_calls = o->train_calls; if (device) *device = o->device; if (n_boxes) *n_boxes = (uint32_t)o->n_uploaded; return MON_OK;
+}
+int mon_online_render(mon_online* h, size_t idx, mon_frame_bbox box, const float* Twc16, float* rgb, float* depth, float* mask) {   // one view of RenderNeRFsTest :280-285
+    REQ(h); if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
+    return model_render(*h->m->objs[idx]->model, box, Twc16, 0, rgb, depth, mask, 0);
+}
+int mon_online_destroy(mon_online* h) { if (!h) return MON_OK; online_destroy(h->m); delete h; return MON_OK; }
 
 int mon_png_read(const char* path, int* width, int* height, int* channels, int* bit_depth, uint8_t* pixels, size_t capacity) {
     REQ(path); REQ(width); REQ(height); REQ(channels); REQ(bit_depth);

@@ -87,3 +87,54 @@ def test_offline_nerf_flow_on_disk_sequence(pkg, ss, tmp_path):
     r = subprocess.run([exe, os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json"), seq, "0", "1", str(tmp_path / "out2")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "Training completed" in r.stdout, r.stdout + r.stderr
     assert os.path.exists(os.path.join(str(tmp_path / "out2"), "0", "test_img"))
+
+
+def test_online_manager_errors_without_device(pkg):
+    m = pkg.OnlineManager(os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json"), False, 50)
+    if pkg.device_count() == 0:
+        with pytest.raises(pkg.MonError) as e:
+            m.init()
+        assert e.value.code == 2
+    else:
+        m.init()
+        with pytest.raises(pkg.MonError) as e:          # CreateNeRF before DatasetInit
+            m.create_nerf(1, np.eye(4, dtype=np.float32).reshape(16), [-1, -1, -1], [1, 1, 1])
+        assert e.value.code == 4
+    assert m.get_frame_idx("0.100000") == -1
+    with pytest.raises(pkg.MonError):
+        m.update_nerf_bbox(3, np.zeros((1, 5), np.uint32), 1)
+    m.close()
+
+
+@pytest.mark.gpu
+def test_online_manager_incremental_flow(pkg, ss):
+    """The SLAM-side call sequence (REF/src/LocalMapping.cc:1122-1270): frames land one by one, objects are created when first
+    seen, boxes arrive per keyframe with train_step=1, training only starts past 10 boxes, WaitThreadsEnd trains once more."""
+    sc = ss.make_scene(n_views=24, H=120, W=160, f=130.0, n_objects=2, seed=9)
+    m = pkg.OnlineManager(os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json"), True, 60)
+    m.init(); m.dataset_init(sc.fx, sc.fy, sc.cx, sc.cy, sc.H, sc.W, sc.n_views)
+    ids = {}
+    import time
+    for v in range(sc.n_views):
+        stamp = "%.6f" % (v * 0.1)
+        m.new_frame(v, stamp, sc.rgb[v][..., ::-1], sc.instance[v], ss.colmajor(sc.Twc[v]), sc.depth[v])
+        assert m.get_frame_idx(stamp) == v
+        for k, ob in enumerate(sc.objects):
+            if k not in ids:
+                ids[k] = m.create_nerf(ob["cls"], ss.colmajor(ob["Tow"]), -ob["half"] / 1.1, ob["half"] / 1.1)   # the manager inflates by 1.1
+            b = ob["boxes"][ob["boxes"][:, 0] == v]
+            m.update_nerf_bbox(ids[k], b, 1)
+        if v == 8:
+            time.sleep(0.3)
+            assert all(m.object_info(i)["train_calls"] == 0 for i in ids.values())      # <= 10 boxes: no training yet (nerf.cu:223)
+        time.sleep(0.02)
+    m.wait_threads_end()
+    for k, i in ids.items():
+        info = m.object_info(i); ob = sc.objects[k]
+        assert info["n_boxes"] == len(ob["boxes"]) and info["train_calls"] >= 3 and info["loss"] < 0.08, info
+        v, x, y, h, w = (int(q) for q in ob["boxes"][3])
+        rgb, depth, mask = m.render(i, ob["boxes"][3], ss.colmajor(sc.Twc[v]))
+        gm = sc.instance[v, y:y + h, x:x + w] == ob["cls"]
+        iou = ((mask > 0.5) & gm).sum() / max(1, ((mask > 0.5) | gm).sum())
+        assert iou > 0.8, (k, iou)
+    m.close()
