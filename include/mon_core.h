@@ -123,6 +123,23 @@ int mon_object_render(mon_object* obj, mon_frame_bbox box, const float* pose16, 
 /* NeRF_Model::GetDensityOnGrid (nerf_model.cu:2007-2048): raw density channel on an rx*ry*rz lattice. */
 int mon_object_density_grid(mon_object* obj, int rx, int ry, int rz, float* out_host);
 
+/* ---- mesh extraction: NeRF_Model::GenerateMesh + TransCPUMesh (CORE/src/nerf_model.cu:1993-2095), MarchingCubes and
+ * compute_mesh_1ring (CORE/src/marching_cubes.cu:478-509, 655-665), SaveMesh (nerf_model.cu:2181-2184 -> save_mesh :511-653).
+ * res <= 0 selects the reference's 64 (marching_cubes.h:30); the reference's threshold is 2.0 on the PRE-activation density
+ * (marching_cubes.h:31).  n_verts is rounded up to a multiple of 128 with all-zero padding vertices (marching_cubes.cu:496);
+ * vertex / face numbering is deterministic here (lattice order), the reference's is atomicAdd order.
+ * The result is kept with the object as CPUMeshData (CORE/include/common.h:32-41): verts / normals float[3n], colors u8[3n],
+ * indices u32; get_mesh with try_lock_only != 0 behaves like DrawCPUMesh's try_lock (nerf.cu:486-490). */
+int mon_object_generate_mesh(mon_object* obj, int res, float thresh, uint32_t* n_verts, uint32_t* n_indices);
+int mon_object_mesh_counts(mon_object* obj, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices);
+int mon_object_get_mesh(mon_object* obj, float* verts, float* normals, uint8_t* colors, uint32_t* indices, int try_lock_only);
+int mon_object_get_mesh_raw(mon_object* obj, float* normals_raw, float* colors_f32);      /* un-normalised normals, float colours (parity tests) */
+int mon_object_save_mesh(mon_object* obj, const char* path);                              /* ".ply" -> ASCII ply, anything else -> obj */
+/* Marching cubes + normals on a caller-supplied lattice (x fastest); buffers may be NULL to query the counts. */
+int mon_marching_cubes(int device, const float* density, int rx, int ry, int rz, float thresh, const float* aabb_min3, const float* aabb_max3,
+                       float* verts, float* normals_raw, uint32_t* indices, uint32_t cap_verts, uint32_t cap_indices,
+                       uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices);
+
 int mon_object_info_get(mon_object* obj, mon_object_info* info);
 /* Parameter I/O (the reference has none; needed for fixtures/checkpoints).
  * which: 0 fp32 master, 1 fp16 working copy, 2 fp16 EMA (inference) copy. */
@@ -153,6 +170,8 @@ int mon_offline_n_objects(mon_offline* mgr, int* n);
 int mon_offline_object_loss(mon_offline* mgr, int idx, float* loss, int* device);
 /* test images for the first max_views (0 = all) training boxes of object idx: <out_dir>/<id>/test_{img,depth,mask}/<stamp>.png (nerf.cu:335-349) */
 int mon_offline_render_test(mon_offline* mgr, int idx, const char* out_dir, int max_views);
+int mon_offline_set_output_dir(mon_offline* mgr, const char* dir);       /* where the training thread saves <id>.ply (default "./output", nerf.cu:148; "" = do not save) */
+int mon_offline_object(mon_offline* mgr, int idx, mon_object** borrowed); /* GetAllNeRF()[idx]: owned by the manager, do not destroy; only mon_object_get_mesh(try_lock) is safe while its thread trains */
 int mon_offline_destroy(mon_offline* mgr);
 /* ---- nerf::NerfManagerOnline (CORE/include/nerf_manager.h:54-90, CORE/src/nerf_manager.cu:133-312) + the online half of nerf::NeRF
  * (nerf.cu:155-253, 406-448): per-object training thread sleeping on a condition variable, training gated on > 10 boxes,
@@ -169,6 +188,7 @@ int mon_online_get_frame_idx(mon_online* mgr, const char* timestamp, int* idx); 
 int mon_online_wait_threads_end(mon_online* mgr);                                                  /* WaitThreadsEnd: request finish + join */
 int mon_online_object_info(mon_online* mgr, size_t idx, float* loss, int* train_calls, int* device, uint32_t* n_boxes);
 int mon_online_render(mon_online* mgr, size_t idx, mon_frame_bbox box, const float* Twc16, float* rgb, float* depth, float* mask);   /* one view of RenderNeRFsTest */
+int mon_online_object(mon_online* mgr, size_t idx, mon_object** borrowed);  /* DrawMesh(idx) reads this object's CPUMeshData through mon_object_get_mesh(try_lock) */
 int mon_online_destroy(mon_online* mgr);
 
 /* PNG codec used for the sequence layout (8/16-bit, gray/RGB/RGBA in; gray/RGB out; 16-bit samples big-endian as in the file).

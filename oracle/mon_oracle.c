@@ -256,6 +256,8 @@ void orc_set_params(orc_model* m, const float* master) {
     memcpy(m->master, master, (size_t)m->n_params * 4);
     for (uint32_t k = 0; k < m->n_params; ++k) m->half[k] = f2h(m->master[k]);
 }
+/* test hook: load inference (EMA) weights, fp16 bit patterns */
+void orc_set_ema(orc_model* m, const uint16_t* ema) { memcpy(m->ema, ema, (size_t)m->n_params * 2); m->has_ema = 1; }
 void orc_set_dataset(orc_model* m, int H, int W, int n_frames, float fx, float fy, float cx, float cy,
                      const uint8_t* rgba, const float* depth, const float* poses) {
     m->H = H; m->Wimg = W; m->n_frames = n_frames; m->fx = fx; m->fy = fy; m->cx = cx; m->cy = cy;
@@ -651,6 +653,18 @@ void orc_density_grid(const orc_model* m, int rx, int ry, int rz, int use_ema, f
         float p[3] = { (float)x / (float)(rx - 1), (float)y / (float)(ry - 1), (float)z / (float)(rz - 1) };
         uint16_t E[2 * ORC_MAX_LEVELS + 16], hid[256], o4[4];
         encode_one(m, prm + m->n_mlp, p, E); mlp_forward_one(m, prm, E, hid, o4); out[i] = h2f(o4[3]);
+    }
+}
+
+/* compute_mesh_vertex_colors nerf_model.cu:2050-2069: WarpPoint (:140-144) -> inference weights -> logistic rgb (:328-339) */
+void orc_mesh_colors(const orc_model* m, const float* verts, uint32_t n, int use_ema, float* colors) {
+    const uint16_t* prm = (use_ema && m->has_ema) ? m->ema : m->half;
+    #pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; ++i) {
+        float p[3]; for (int a = 0; a < 3; ++a) p[a] = (verts[3 * i + a] - m->amin[a]) / (m->amax[a] - m->amin[a]);
+        uint16_t E[2 * ORC_MAX_LEVELS + 16], hid[256], o4[4];
+        encode_one(m, prm + m->n_mlp, p, E); mlp_forward_one(m, prm, E, hid, o4);
+        for (int c = 0; c < 3; ++c) colors[3 * i + c] = logistic(h2f(o4[c]));
     }
 }
 

@@ -79,6 +79,12 @@ def lib():
         L.orc_f2h.restype = C.c_uint16; L.orc_f2h.argtypes = [C.c_float]
         L.orc_h2f.restype = C.c_float; L.orc_h2f.argtypes = [C.c_uint16]
         L.orc_set_threads.argtypes = [C.c_int]; L.orc_max_threads.restype = C.c_int
+        L.orc_set_ema.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_mc_case.restype = C.c_uint64; L.orc_mc_case.argtypes = [C.c_int]
+        L.orc_mc_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_mc_extract.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_mesh_to_cpu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_mesh_colors.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_set_parallel_scatter.argtypes = [C.c_int]; L.orc_advance_iter.argtypes = [C.c_void_p]
         # the checker's loops are small: a modest team beats one thread per hardware thread on a 256-thread host
         L.orc_set_threads(int(os.environ.get("MON_ORACLE_THREADS", min(16, os.cpu_count() or 1))))
@@ -111,9 +117,12 @@ class OracleModel:
         self._keep += [rgba, depth, poses]
         self.L.orc_set_dataset(self.h, H, W, rgba.shape[0], fx, fy, cx, cy, _p(rgba), _p(depth), _p(poses))
 
+    def set_ema(self, ema_u16):
+        e = np.ascontiguousarray(ema_u16, np.uint16); self.L.orc_set_ema(self.h, _p(e))
+
     def set_object(self, Tow16, amin, amax, inst):
         a, b, c = (np.ascontiguousarray(v, np.float32) for v in (Tow16, amin, amax))
-        self.L.orc_set_object(self.h, _p(a), _p(b), _p(c), int(inst))
+        self.L.orc_set_object(self.h, _p(a), _p(b), _p(c), int(inst)); self._amin, self._amax = b.copy(), c.copy()
 
     def add_boxes(self, boxes):
         b = np.ascontiguousarray(boxes, np.uint32).reshape(-1, 5)
@@ -172,6 +181,40 @@ class OracleModel:
         out = np.empty(rx * ry * rz, np.float32)
         self.L.orc_density_grid(self.h, rx, ry, rz, int(use_ema), _p(out))
         return out
+
+    def mesh_colors(self, verts, use_ema=True):
+        v = np.ascontiguousarray(verts, np.float32); col = np.empty_like(v)
+        self.L.orc_mesh_colors(self.h, _p(v), v.shape[0], int(use_ema), _p(col)); return col
+
+    def generate_mesh(self, res=64, thresh=2.0, use_ema=True):
+        """GenerateMesh + TransCPUMesh (nerf_model.cu:1993-2095)."""
+        dens = self.density_grid(res, res, res, use_ema)
+        mesh = marching_cubes(dens, (res, res, res), thresh, self._amin, self._amax)
+        n = mesh["verts"].shape[0]; col = np.empty((n, 3), np.float32)
+        self.L.orc_mesh_colors(self.h, _p(mesh["verts"]), n, int(use_ema), _p(col))
+        mesh["colors_f32"] = col; mesh["density"] = dens
+        mesh["normals"], mesh["colors"] = mesh_to_cpu(mesh["normals_raw"], col)
+        return mesh
+
+
+def marching_cubes(density, res3, thresh, amin, amax):
+    """MarchingCubes + compute_mesh_1ring (marching_cubes.cu:478-509, 655-665) in the fixed order of mon_mesh_oracle.c."""
+    L = lib(); rx, ry, rz = (int(v) for v in res3)
+    d = np.ascontiguousarray(density, np.float32).reshape(-1); assert d.size == rx * ry * rz
+    nv = C.c_uint32(0); ni = C.c_uint32(0)
+    L.orc_mc_count(_p(d), rx, ry, rz, float(thresh), C.byref(nv), C.byref(ni))
+    npad = (nv.value + 127) & ~127
+    verts = np.zeros((npad, 3), np.float32); nraw = np.zeros((npad, 3), np.float32); idx = np.zeros(ni.value, np.uint32)
+    vgrid = np.zeros(3 * d.size, np.int32)
+    a0 = np.ascontiguousarray(amin, np.float32); a1 = np.ascontiguousarray(amax, np.float32)
+    L.orc_mc_extract(_p(d), rx, ry, rz, float(thresh), _p(a0), _p(a1), _p(verts), _p(vgrid), _p(idx), _p(nraw), npad)
+    return dict(verts=verts, normals_raw=nraw, indices=idx, n_verts_real=nv.value, vertidx=vgrid)
+
+
+def mesh_to_cpu(normals_raw, colors):
+    n = normals_raw.shape[0]; nrm = np.empty((n, 3), np.float32); c8 = np.empty((n, 3), np.uint8)
+    lib().orc_mesh_to_cpu(_p(np.ascontiguousarray(normals_raw, np.float32)), _p(np.ascontiguousarray(colors, np.float32)), n, _p(nrm), _p(c8))
+    return nrm, c8
 
 
 def h2f(a):

@@ -75,6 +75,16 @@ _SIGS = {
     "mon_offline_object_loss": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "mon_offline_render_test": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "mon_offline_destroy": (C.c_int, [C.c_void_p]),
+    "mon_object_generate_mesh": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "mon_object_mesh_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "mon_object_get_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "mon_object_get_mesh_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mon_object_save_mesh": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "mon_marching_cubes": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                     C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "mon_offline_set_output_dir": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "mon_offline_object": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "mon_online_object": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "mon_online_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mon_online_init": (C.c_int, [C.c_void_p]),
     "mon_online_dataset_init": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_size_t]),
@@ -222,6 +232,26 @@ class ObjectNeRF:
         _check(lib().mon_object_render(self.h, MonBBox(FrameId, x, y, h, w), _p(pose), int(pose_is_Toc), _p(rgb), _p(depth), _p(mask), 0))
         return rgb, depth, mask
 
+    def generate_mesh(self, res=64, thresh=2.0):
+        """GenerateMesh + TransCPUMesh (nerf_model.cu:1993-2095); returns (n_verts incl. padding, n_indices)."""
+        nv = C.c_uint32(0); ni = C.c_uint32(0)
+        _check(lib().mon_object_generate_mesh(self.h, int(res), float(thresh), C.byref(nv), C.byref(ni))); return nv.value, ni.value
+
+    def get_mesh(self, try_lock=False, raw=False):
+        """CPUMeshData (common.h:32-41) as a dict of numpy arrays."""
+        nv = C.c_uint32(0); nr = C.c_uint32(0); ni = C.c_uint32(0)
+        _check(lib().mon_object_mesh_counts(self.h, C.byref(nv), C.byref(nr), C.byref(ni)))
+        out = dict(verts=np.empty((nv.value, 3), np.float32), normals=np.empty((nv.value, 3), np.float32), colors=np.empty((nv.value, 3), np.uint8),
+                   indices=np.empty(ni.value, np.uint32), n_verts_real=nr.value)
+        _check(lib().mon_object_get_mesh(self.h, _p(out["verts"]), _p(out["normals"]), _p(out["colors"]), _p(out["indices"]), int(try_lock)))
+        if raw:
+            out["normals_raw"] = np.empty((nv.value, 3), np.float32); out["colors_f32"] = np.empty((nv.value, 3), np.float32)
+            _check(lib().mon_object_get_mesh_raw(self.h, _p(out["normals_raw"]), _p(out["colors_f32"])))
+        return out
+
+    def save_mesh(self, path):
+        _check(lib().mon_object_save_mesh(self.h, path.encode()))
+
     def density_grid(self, rx, ry, rz):
         out = np.empty(rx * ry * rz, np.float32); _check(lib().mon_object_density_grid(self.h, rx, ry, rz, _p(out))); return out
 
@@ -300,6 +330,13 @@ class OfflineManager:
     def object_loss(self, idx):
         l = C.c_float(0); d = C.c_int(0); _check(lib().mon_offline_object_loss(self.h, idx, C.byref(l), C.byref(d))); return l.value, d.value
 
+    def set_output_dir(self, path):
+        _check(lib().mon_offline_set_output_dir(self.h, path.encode()))
+
+    def object(self, idx):
+        """Borrowed handle of object idx (GetAllNeRF()[idx]); owned by the manager."""
+        h = C.c_void_p(); _check(lib().mon_offline_object(self.h, idx, C.byref(h))); return _borrowed_object(h)
+
     def render_test(self, idx, out_dir, max_views=0):
         _check(lib().mon_offline_render_test(self.h, idx, out_dir.encode(), max_views))
 
@@ -340,6 +377,9 @@ class OnlineManager:
     def wait_threads_end(self):
         _check(lib().mon_online_wait_threads_end(self.h))
 
+    def object(self, idx):
+        h = C.c_void_p(); _check(lib().mon_online_object(self.h, idx, C.byref(h))); return _borrowed_object(h)
+
     def object_info(self, idx):
         l = C.c_float(0); t = C.c_int(0); d = C.c_int(0); n = C.c_uint32(0)
         _check(lib().mon_online_object_info(self.h, idx, C.byref(l), C.byref(t), C.byref(d), C.byref(n))); return dict(loss=l.value, train_calls=t.value, device=d.value, n_boxes=n.value)
@@ -353,3 +393,21 @@ class OnlineManager:
     def close(self):
         if self.h:
             lib().mon_online_destroy(self.h); self.h = None
+
+
+def _borrowed_object(handle):
+    o = ObjectNeRF.__new__(ObjectNeRF); o.h = handle; o.cfg = None; o.ds = None
+    o.close = lambda: None                     # the manager owns it
+    return o
+
+
+def marching_cubes(density, res3, thresh, aabb_min, aabb_max, device=0):
+    """MarchingCubes + compute_mesh_1ring (marching_cubes.cu:478-509, 655-665) on a caller-supplied lattice (x fastest)."""
+    rx, ry, rz = (int(v) for v in res3)
+    d = np.ascontiguousarray(density, np.float32).reshape(-1); assert d.size == rx * ry * rz
+    a0 = np.ascontiguousarray(aabb_min, np.float32); a1 = np.ascontiguousarray(aabb_max, np.float32)
+    nv = C.c_uint32(0); nr = C.c_uint32(0); ni = C.c_uint32(0)
+    _check(lib().mon_marching_cubes(device, _p(d), rx, ry, rz, float(thresh), _p(a0), _p(a1), None, None, None, 0, 0, C.byref(nv), C.byref(nr), C.byref(ni)))
+    verts = np.empty((nv.value, 3), np.float32); nraw = np.empty((nv.value, 3), np.float32); idx = np.empty(ni.value, np.uint32)
+    _check(lib().mon_marching_cubes(device, _p(d), rx, ry, rz, float(thresh), _p(a0), _p(a1), _p(verts), _p(nraw), _p(idx), nv.value, ni.value, C.byref(nv), C.byref(nr), C.byref(ni)))
+    return dict(verts=verts, normals_raw=nraw, indices=idx, n_verts_real=nr.value)

@@ -20,13 +20,17 @@ int model_density_grid(Model& m, int rx, int ry, int rz, float* out_host);
 int model_get_params(Model& m, int which, void* dst, size_t bytes);
 int model_set_params(Model& m, const float* master, size_t n);
 int model_debug_read(Model& m, int which, void* dst, size_t bytes);
+int model_generate_mesh(Model& m, int res, float thresh, uint32_t* n_verts, uint32_t* n_indices);
+int model_mesh_counts(Model& m, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices);
+int model_get_mesh(Model& m, float* verts, float* normals, uint8_t* colors, uint32_t* indices, float* normals_raw, float* colors_f32, int try_only);
+int model_save_mesh(Model& m, const char* path);
+int marching_cubes_host(int device, const float* density, int rx, int ry, int rz, float thresh, const float* amin, const float* amax,
+                        float* verts, float* normals_raw, uint32_t* indices, uint32_t cap_verts, uint32_t cap_indices, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices);
 int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms_out);
 }  // namespace mon
 
 using namespace mon;
 
-struct mon_dataset { Dataset* d; };
-struct mon_object { Model* m; };
 
 #define REQUIRE(p, what) do { if (!(p)) { set_error("%s: null %s", __func__, what); return MON_ERR_ARG; } } while (0)
 
@@ -59,6 +63,15 @@ int mon_object_train(mon_object* o, int iters, float* loss) { REQUIRE(o, "object
 int mon_object_train_stages(mon_object* o, int stage_bits) { REQUIRE(o, "object"); return model_train(*o->m, 1, nullptr, stage_bits & 7); }
 int mon_object_render(mon_object* o, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, int dst_on_device) {
     REQUIRE(o, "object"); return model_render(*o->m, box, pose16, pose_is_Toc, rgb, depth, mask, dst_on_device);
+}
+int mon_object_generate_mesh(mon_object* o, int res, float thresh, uint32_t* n_verts, uint32_t* n_indices) { REQUIRE(o, "object"); return model_generate_mesh(*o->m, res, thresh, n_verts, n_indices); }
+int mon_object_mesh_counts(mon_object* o, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices) { REQUIRE(o, "object"); return model_mesh_counts(*o->m, n_verts, n_verts_real, n_indices); }
+int mon_object_get_mesh(mon_object* o, float* verts, float* normals, uint8_t* colors, uint32_t* indices, int try_lock_only) { REQUIRE(o, "object"); return model_get_mesh(*o->m, verts, normals, colors, indices, nullptr, nullptr, try_lock_only); }
+int mon_object_get_mesh_raw(mon_object* o, float* normals_raw, float* colors_f32) { REQUIRE(o, "object"); return model_get_mesh(*o->m, nullptr, nullptr, nullptr, nullptr, normals_raw, colors_f32, 0); }
+int mon_object_save_mesh(mon_object* o, const char* path) { REQUIRE(o, "object"); REQUIRE(path, "path"); return model_save_mesh(*o->m, path); }
+int mon_marching_cubes(int device, const float* density, int rx, int ry, int rz, float thresh, const float* aabb_min3, const float* aabb_max3,
+                       float* verts, float* normals_raw, uint32_t* indices, uint32_t cap_verts, uint32_t cap_indices, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices) {
+    return marching_cubes_host(device, density, rx, ry, rz, thresh, aabb_min3, aabb_max3, verts, normals_raw, indices, cap_verts, cap_indices, n_verts, n_verts_real, n_indices);
 }
 int mon_object_density_grid(mon_object* o, int rx, int ry, int rz, float* out_host) { REQUIRE(o, "object"); return model_density_grid(*o->m, rx, ry, rz, out_host); }
 int mon_object_info_get(mon_object* o, mon_object_info* info) {

@@ -23,6 +23,7 @@
 namespace mon {
 
 void set_error(const char* fmt, ...);
+const char* last_error();
 int device_count(int* n);
 int config_from_json(const char* path, mon_config& c);
 int dataset_create(int device, int H, int W, float fx, float fy, float cx, float cy, uint32_t max_frames, int use_depth, Dataset** out);
@@ -31,6 +32,9 @@ int dataset_destroy(Dataset* d);
 int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* Tow, const float* amin, const float* amax, Model** out);
 int model_destroy(Model* m);
 int model_add_boxes(Model& m, const mon_frame_bbox* boxes, size_t n);
+int model_generate_mesh(Model& m, int res, float thresh, uint32_t* n_verts, uint32_t* n_indices);
+int model_save_mesh(Model& m, const char* path);
+int model_mesh_counts(Model& m, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices);
 int model_train(Model& m, int iters, float* loss, int stages);
 int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, int dst_on_device);
 
@@ -53,7 +57,7 @@ static void rigid_inverse(const float* M, float* Inv) {
 struct OfflineObject {
     int id = 0, device = 0, cls = 0; float Tow[16]; float amin[3], amax[3];
     std::vector<mon_frame_bbox> boxes; std::vector<std::string> stamps;
-    Model* model = nullptr; float last_loss = 0.f; int rc = 0; std::string err;
+    Model* model = nullptr; mon_object handle{ nullptr }; float last_loss = 0.f; int rc = 0; std::string err;
 };
 
 struct OfflineManager {
@@ -62,6 +66,8 @@ struct OfflineManager {
     std::vector<std::string> names, stamps; std::map<std::string, uint32_t> stamp_to_idx; std::vector<float> poses;   // [n][16]
     std::vector<Dataset*> ds; std::vector<OfflineObject*> objs; std::vector<std::thread> threads;
     int outer_iters = 10, inner_iters = 500;       // nerf_manager.cu:89, nerf_model.cu:1635
+    std::string mesh_dir = "./output";              // nerf.cu:148
+    int mesh_res = 64; float mesh_thresh = 2.0f;   // marching_cubes.h:30-31
 };
 
 static bool read_yaml_number(const std::string& text, const char* key, double& v) {
@@ -123,6 +129,12 @@ static void train_offline_thread(OfflineManager* m, OfflineObject* o) {  // NeRF
     for (int i = 1; i <= m->outer_iters && o->rc == MON_OK; ++i) {
         o->rc = model_train(*o->model, m->inner_iters, &o->last_loss, 7);
         if (o->rc == MON_OK) std::printf("Id: %d Step: %d loss: %f\n", o->id, i * m->inner_iters, o->last_loss);
+        if (o->rc == MON_OK && i % 2 == 0) o->rc = model_generate_mesh(*o->model, m->mesh_res, m->mesh_thresh, nullptr, nullptr);   // GenerateMesh + TransCPUMesh, nerf.cu:138-145
+    }
+    if (o->rc == MON_OK && !m->mesh_dir.empty()) {                        // SaveMesh("./output/<id>.ply"), nerf.cu:148-149
+        uint32_t nv = 0; model_mesh_counts(*o->model, &nv, nullptr, nullptr);
+        ::mkdir(m->mesh_dir.c_str(), 0755);
+        if (nv && model_save_mesh(*o->model, (m->mesh_dir + "/" + std::to_string(o->id) + ".ply").c_str()) != MON_OK) std::fprintf(stderr, "Id: %d mesh not saved: %s\n", o->id, last_error());
     }
     if (o->rc != MON_OK) o->err = "training failed";
 }
@@ -143,6 +155,7 @@ int offline_create_nerf(OfflineManager& m, const char* object_file) {    // nerf
     }
     int rc = model_create(m.ds[o->device], m.cfg, o->cls, o->Tow, o->amin, o->amax, &o->model);
     if (rc) { delete o; return rc; }
+    o->handle.m = o->model;
     m.objs.push_back(o);
     m.threads.emplace_back(train_offline_thread, &m, o);                // one thread per model, nerf_manager.cu:89
     return MON_OK;
@@ -178,6 +191,11 @@ int offline_render_test(OfflineManager& m, int idx, const char* out_dir, int max
             !png_write(root + "/test_depth/" + o->stamps[i] + ".png", (int)b.w, (int)b.h, 1, 16, d16.data(), err) ||
             !png_write(root + "/test_mask/" + o->stamps[i] + ".png", (int)b.w, (int)b.h, 1, 8, m8.data(), err)) { set_error("%s", err.c_str()); return MON_ERR_IO; }
     }
+    uint32_t n_mesh = 0; model_mesh_counts(*o->model, &n_mesh, nullptr, nullptr);
+    if (n_mesh) {                                                        // "Save Object Mesh", nerf.cu:397-403
+        int rc = model_generate_mesh(*o->model, m.mesh_res, m.mesh_thresh, nullptr, nullptr); if (rc) return rc;
+        rc = model_save_mesh(*o->model, (root + "/obj.ply").c_str()); if (rc) return rc;
+    }
     return MON_OK;
 }
 
@@ -199,7 +217,8 @@ struct OnlineObject {
     std::vector<mon_frame_bbox> boxes; size_t n_boxes = 0, n_uploaded = 0; int pending_train_step = 0, iterations = 500;
     std::mutex mu_boxes, mu_finish; std::condition_variable cond; bool finish = false;
     std::mutex* dataset_mutex = nullptr;
-    Model* model = nullptr; float last_loss = 0.f; int train_calls = 0; int rc = 0;
+    Model* model = nullptr; mon_object handle{ nullptr }; float last_loss = 0.f; int train_calls = 0; int rc = 0;
+    int mesh_res = 64; float mesh_thresh = 2.0f;
 };
 
 struct OnlineManager {
@@ -226,6 +245,8 @@ static void train_online_thread(OnlineObject* o) {                       // NeRF
             for (int i = 0; i < train_step && o->rc == MON_OK; ++i) {
                 std::unique_lock<std::mutex> dl(*o->dataset_mutex);      // GenerateBatch under the per-object dataset mutex (nerf_model.cu:1675-1678)
                 o->rc = model_train(*o->model, o->iterations, &o->last_loss, 7); ++o->train_calls; ++train_step_count;
+                dl.unlock();
+                if (o->rc == MON_OK && train_step_count % 2 == 0) o->rc = model_generate_mesh(*o->model, o->mesh_res, o->mesh_thresh, nullptr, nullptr);   // :228-236
             }
         }
         if (online_check_finish(o) || o->rc != MON_OK) break;
@@ -234,6 +255,8 @@ static void train_online_thread(OnlineObject* o) {                       // NeRF
     if (o->rc == MON_OK && o->n_uploaded > 0) {                           // last time (:246)
         std::unique_lock<std::mutex> dl(*o->dataset_mutex);
         o->rc = model_train(*o->model, o->iterations, &o->last_loss, 7); ++o->train_calls;
+        dl.unlock();
+        if (o->rc == MON_OK) o->rc = model_generate_mesh(*o->model, o->mesh_res, o->mesh_thresh, nullptr, nullptr);       // :247-249
     }
     std::printf("Id: %d finished! \n", o->id);
 }
@@ -267,6 +290,8 @@ int mon_offline_wait_threads_end(mon_offline* h) { REQ(h); return offline_wait(*
 int mon_offline_n_objects(mon_offline* h, int* n) { REQ(h); REQ(n); *n = (int)h->m->objs.size(); return MON_OK; }
 int mon_offline_object_loss(mon_offline* h, int idx, float* loss, int* device) { REQ(h); REQ(loss); if (idx < 0 || idx >= (int)h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *loss = h->m->objs[idx]->last_loss; if (device) *device = h->m->objs[idx]->device; return MON_OK; }
 int mon_offline_render_test(mon_offline* h, int idx, const char* out_dir, int max_views) { REQ(h); REQ(out_dir); return offline_render_test(*h->m, idx, out_dir, max_views); }
+int mon_offline_set_output_dir(mon_offline* h, const char* dir) { REQ(h); h->m->mesh_dir = dir ? dir : ""; return MON_OK; }
+int mon_offline_object(mon_offline* h, int idx, mon_object** borrowed) { REQ(h); REQ(borrowed); if (idx < 0 || idx >= (int)h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *borrowed = &h->m->objs[idx]->handle; return MON_OK; }
 int mon_offline_destroy(mon_offline* h) { if (!h) return MON_OK; offline_destroy(h->m); delete h; return MON_OK; }
 
 // ---- NerfManagerOnline
@@ -308,6 +333,7 @@ int mon_online_create_nerf(mon_online* h, int cls, const float* Tow16, const flo
     m.ds_mutex[o->device].emplace_back(new std::mutex()); o->dataset_mutex = m.ds_mutex[o->device].back().get();
     int rc = model_create(m.ds[o->device], m.cfg, cls, o->Tow, o->amin, o->amax, &o->model);
     if (rc) { delete o; return rc; }
+    o->handle.m = o->model;
     *idx_out = m.objs.size(); m.objs.push_back(o);
     m.threads.emplace_back(train_online_thread, o);                      // thread per object, nerf_manager.cu:259
     return MON_OK;
@@ -342,6 +368,7 @@ int mon_online_render(mon_online* h, size_t idx, mon_frame_bbox box, const float
     REQ(h); if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
     return model_render(*h->m->objs[idx]->model, box, Twc16, 0, rgb, depth, mask, 0);
 }
+int mon_online_object(mon_online* h, size_t idx, mon_object** borrowed) { REQ(h); REQ(borrowed); if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *borrowed = &h->m->objs[idx]->handle; return MON_OK; }
 int mon_online_destroy(mon_online* h) { if (!h) return MON_OK; online_destroy(h->m); delete h; return MON_OK; }
 
 int mon_png_read(const char* path, int* width, int* height, int* channels, int* bit_depth, uint8_t* pixels, size_t capacity) {

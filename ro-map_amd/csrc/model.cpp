@@ -152,9 +152,11 @@ int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* 
 
 static void drop_graph(Model& m) { if (m.graph_exec) { hipGraphExecDestroy(m.graph_exec); m.graph_exec = nullptr; m.graph_backend = -1; } }
 
+void model_mesh_free(Model& m);
 int model_destroy(Model* mp) {
     if (!mp) return MON_OK;
     Model& m = *mp; hipSetDevice(m.device);
+    model_mesh_free(m);
     if (m.train_stream) hipStreamSynchronize(m.train_stream);
     drop_graph(m);
     for (auto& e : m.ev_pool) hipEventDestroy(e);

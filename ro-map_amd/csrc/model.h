@@ -121,7 +121,10 @@ struct Dataset {
     DatasetPtrs ptrs() const { return DatasetPtrs{ d_rgba, d_depth, d_poses, K }; }
 };
 
+struct MeshState;   // mesh.cpp
+
 struct Model {
+    MeshState* mesh = nullptr;
     Dataset* ds = nullptr; mon_config cfg{}; int device = 0;
     LevelTable lt{}; LevelFast lf{}; NetDims nd{}; ObjectConst oc{}; OptimConst opt{};
     uint32_t n_grid = 0, n_params = 0;
@@ -140,3 +143,7 @@ void level_fast_build(const LevelTable& lt, const NetDims& nd, LevelFast& lf);
 void init_params_host(const mon_config& c, const NetDims& nd, uint32_t n_params, std::vector<float>& master);
 
 }  // namespace mon
+
+// opaque C handles of include/mon_core.h
+struct mon_dataset { mon::Dataset* d; };
+struct mon_object { mon::Model* m; };

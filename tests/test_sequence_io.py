@@ -61,11 +61,11 @@ def test_offline_nerf_flow_on_disk_sequence(pkg, ss, tmp_path):
     os.environ["MON_OFFLINE_OUTER"] = "2"; os.environ["MON_OFFLINE_INNER"] = "150"
     m = pkg.OfflineManager(seq, os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json"), use_dense_depth=True)
     m.init(); m.read_dataset()
+    out = str(tmp_path / "out"); os.makedirs(out); m.set_output_dir(out)
     for k in range(3):
         m.create_nerf(os.path.join(seq, "obj_offline", "%d.txt" % k))
     m.wait_threads_end()
     assert m.n_objects() == 3
-    out = str(tmp_path / "out"); os.makedirs(out)
     for k in range(3):
         loss, dev = m.object_loss(k); assert loss < 0.08 and dev == k % pkg.device_count()
         m.render_test(k, out, 2)
@@ -81,6 +81,13 @@ def test_offline_nerf_flow_on_disk_sequence(pkg, ss, tmp_path):
         assert iou > 0.85 and psnr > 18.0, (k, iou, psnr)
         both = msk & gm
         assert np.abs(dep[both] - sc.depth[v, y:y + h, x:x + w][both]).mean() < 0.08
+        # mesh: generated every 2nd outer step on the training thread, saved as <out>/<id>.ply at the end and as obj.ply by render_test
+        mesh = m.object(k).get_mesh(try_lock=True); nr = mesh["n_verts_real"]
+        assert nr > 100 and mesh["indices"].size % 3 == 0 and mesh["indices"].max() < nr
+        p_obj = mesh["verts"][:nr] / ob["radii"]
+        assert 0.75 < np.median(np.linalg.norm(p_obj, axis=1)) < 1.25
+        for ply in (os.path.join(out, "%d.ply" % k), os.path.join(out, str(k), "obj.ply")):
+            assert open(ply).readline().strip() == "ply"
     m.close()
     # the headless executable, same sequence, 1 object
     exe = os.path.join(ROOT, "ro-map_amd", "offline_nerf")
@@ -137,4 +144,6 @@ def test_online_manager_incremental_flow(pkg, ss):
         gm = sc.instance[v, y:y + h, x:x + w] == ob["cls"]
         iou = ((mask > 0.5) & gm).sum() / max(1, ((mask > 0.5) | gm).sum())
         assert iou > 0.8, (k, iou)
+        mesh = m.object(i).get_mesh(try_lock=True)                    # DrawMesh(idx)'s data
+        assert mesh["n_verts_real"] > 50 and mesh["indices"].max() < mesh["n_verts_real"]
     m.close()

@@ -19,6 +19,7 @@ int main(int argc, char** argv) {
     if (mon_offline_create(dataset.c_str(), cfg.c_str(), use_depth, &mgr)) return fail("create");
     if (mon_offline_init(mgr)) return fail("Init");
     if (mon_offline_read_dataset(mgr)) return fail("ReadDataset");
+    mon_offline_set_output_dir(mgr, out.c_str());                          // <out>/<id>.ply, the reference writes ./output/<id>.ply
     for (int i = 0; i < n_objects; ++i) {
         const std::string obj = dataset + "/obj_offline/" + std::to_string(i) + ".txt";
         if (mon_offline_create_nerf(mgr, obj.c_str())) return fail("CreateNeRF");
