@@ -17,7 +17,16 @@ static void die(const char* what) { std::cerr << what << ": " << mon_last_error(
 NeRF::~NeRF() { if (mpObject) mon_object_destroy(mpObject); }
 vector<FrameIdAndBbox> NeRF::GetFrameIdAndBBox() { return vector<FrameIdAndBbox>(mFrameIdBbox.begin(), mFrameIdBbox.begin() + mnBbox); }
 
-void NeRF::DrawCPUMesh() {                                                    // nerf.cu:484-507 (mesh extraction is a "next" row)
+void NeRF::UpdateCPUMesh() {                                                  // GenerateMesh + TransCPUMesh, nerf.cu:138-145 / 228-236
+    uint32_t nv = 0, ni = 0;
+    if (mon_object_generate_mesh(mpObject, 64, 2.0f, &nv, &ni)) die("GenerateMesh");      // marching_cubes.h:30-31
+    std::unique_lock<std::mutex> lock(mCPUMeshData.mesh_mutex);
+    mCPUMeshData.verts.resize(3 * nv); mCPUMeshData.normals.resize(3 * nv); mCPUMeshData.colors.resize(3 * nv); mCPUMeshData.indices.resize(ni);
+    mon_object_get_mesh(mpObject, mCPUMeshData.verts.data(), mCPUMeshData.normals.data(), mCPUMeshData.colors.data(), mCPUMeshData.indices.data(), 0);
+    mCPUMeshData.have_reslult = true;
+}
+
+void NeRF::DrawCPUMesh() {                                                    // nerf.cu:484-507
     std::unique_lock<std::mutex> lock(mCPUMeshData.mesh_mutex, std::try_to_lock);
     if (!lock.owns_lock() || !mCPUMeshData.have_reslult) return;
     glEnableClientState(GL_VERTEX_ARRAY); glEnableClientState(GL_NORMAL_ARRAY); glEnableClientState(GL_COLOR_ARRAY);
@@ -33,7 +42,9 @@ void NeRF::TrainOffline(const int iterations) {                               //
         float loss = 0.f;
         if (mon_object_train(mpObject, 500, &loss)) die("Train_Step");       // nerf_model.cu:1635
         std::cout << "Id: " << mId << " Step: " << i * 500 << " loss: " << loss << std::endl;
+        if (i % 2 == 0) UpdateCPUMesh();
     }
+    mon_object_save_mesh(mpObject, ("./output/" + std::to_string(mId) + ".ply").c_str());   // nerf.cu:148-149
 }
 
 void NeRF::UpdateFrameBBox(const vector<FrameIdAndBbox>& v, const int train_step) {   // nerf.cu:406-421
@@ -45,6 +56,7 @@ void NeRF::RequestFinish() { std::unique_lock<std::mutex> lock(mFinishMutex); mb
 bool NeRF::CheckFinish() { std::unique_lock<std::mutex> lock(mFinishMutex); return mbFinishRequested; }
 
 void NeRF::TrainOnline() {                                                    // nerf.cu:187-253
+    int train_step_count = 0;
     while (true) {
         int train_step = 0;
         {
@@ -58,17 +70,18 @@ void NeRF::TrainOnline() {                                                    //
         if (mnUploaded > 10)
             for (int i = 0; i < train_step; ++i) {
                 std::unique_lock<std::mutex> dl(*mpDatasetMutex);             // GenerateBatch under the dataset mutex (nerf_model.cu:1675-1678)
-                float loss = 0.f; mon_object_train(mpObject, mnIteration, &loss);
+                float loss = 0.f; mon_object_train(mpObject, mnIteration, &loss); dl.unlock();
+                if (++train_step_count % 2 == 0) UpdateCPUMesh();
             }
         if (CheckFinish()) break;
         usleep(3000);
     }
-    float loss = 0.f; mon_object_train(mpObject, mnIteration, &loss);
+    float loss = 0.f; mon_object_train(mpObject, mnIteration, &loss); UpdateCPUMesh();
     std::cout << "Id: " << mId << " finished! " << std::endl;
 }
 
 void NeRF::RenderTestImg(const string out_path, const vector<string>& stamps, const vector<Eigen::Matrix4f>& Twcs, const vector<FrameIdAndBbox>& boxes, const float) {
-    const string dir = out_path + "/" + std::to_string(mId);                  // nerf.cu:255-349 (test images; video/mesh are "next")
+    const string dir = out_path + "/" + std::to_string(mId);                  // nerf.cu:255-349 (test images + mesh; the 360 video is a "next" row)
     if (system(("mkdir -p " + dir + "/test_img " + dir + "/test_depth " + dir + "/test_mask").c_str()) != 0) throw std::runtime_error("mkdir error");
     for (size_t i = 0; i < stamps.size(); ++i) {
         const FrameIdAndBbox& b = boxes[i];
@@ -79,6 +92,7 @@ void NeRF::RenderTestImg(const string out_path, const vector<string>& stamps, co
         depth.convertTo(depth, CV_16UC1, 20000); cv::imwrite(dir + "/test_depth/" + stamps[i] + ".png", depth);
         mask.convertTo(mask, CV_8UC1, 255); cv::imwrite(dir + "/test_mask/" + stamps[i] + ".png", mask);
     }
+    if (mCPUMeshData.have_reslult) { UpdateCPUMesh(); mon_object_save_mesh(mpObject, (dir + "/obj.ply").c_str()); }   // nerf.cu:397-403
 }
 
 // ------------------------------------------------------------------ offline manager (nerf_manager.cu:9-131)

@@ -17,6 +17,7 @@ public:
     BoundingBox GetBoundingBox() { return mBoundingBox; }
     CPUMeshData& GetCPUMeshData() { return mCPUMeshData; }
     void DrawCPUMesh();
+    void UpdateCPUMesh();
     // online protocol (nerf.cu:187-253, 406-448)
     void UpdateFrameBBox(const vector<FrameIdAndBbox>& vFrameBbox, const int train_step);
     void RequestFinish();
