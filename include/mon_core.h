@@ -188,6 +188,11 @@ int mon_online_get_frame_idx(mon_online* mgr, const char* timestamp, int* idx); 
 int mon_online_wait_threads_end(mon_online* mgr);                                                  /* WaitThreadsEnd: request finish + join */
 int mon_online_object_info(mon_online* mgr, size_t idx, float* loss, int* train_calls, int* device, uint32_t* n_boxes);
 int mon_online_render(mon_online* mgr, size_t idx, mon_frame_bbox box, const float* Twc16, float* rgb, float* depth, float* mask);   /* one view of RenderNeRFsTest */
+/* RenderNeRFsTest(out_path, idx, stamps, boxes, Twcs, radius) -> NeRF::RenderTestImg (nerf.cu:255-404): test images + test.txt +
+ * train.txt + the 60-view 360-degree video (RenderVideo, nerf_model.cu:1832-1990) + obj.ply under <out_path>/<id>/ */
+int mon_online_render_nerfs_test(mon_online* mgr, const char* out_path, size_t idx, const char* const* timestamps, const mon_frame_bbox* boxes,
+                                 const float* Twcs16, size_t n, float radius);
+int mon_generate_toc(float theta_deg, float phi_deg, float radius, float* Toc16);   /* NeRF_Model::GenerateToc, nerf_model.cu:2186-2205 */
 int mon_online_object(mon_online* mgr, size_t idx, mon_object** borrowed);  /* DrawMesh(idx) reads this object's CPUMeshData through mon_object_get_mesh(try_lock) */
 int mon_online_destroy(mon_online* mgr);
 

@@ -85,6 +85,8 @@ _SIGS = {
     "mon_offline_set_output_dir": (C.c_int, [C.c_void_p, C.c_char_p]),
     "mon_offline_object": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "mon_online_object": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "mon_online_render_nerfs_test": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]),
+    "mon_generate_toc": (C.c_int, [C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mon_online_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mon_online_init": (C.c_int, [C.c_void_p]),
     "mon_online_dataset_init": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_size_t]),
@@ -380,6 +382,11 @@ class OnlineManager:
     def object(self, idx):
         h = C.c_void_p(); _check(lib().mon_online_object(self.h, idx, C.byref(h))); return _borrowed_object(h)
 
+    def render_nerfs_test(self, out_path, idx, stamps, boxes, Twcs16, radius):
+        b = np.ascontiguousarray(boxes, np.uint32).reshape(-1, 5); T = np.ascontiguousarray(Twcs16, np.float32).reshape(-1, 16)
+        arr = (C.c_char_p * len(stamps))(*[s.encode() for s in stamps])
+        _check(lib().mon_online_render_nerfs_test(self.h, out_path.encode(), idx, arr, _p(b), _p(T), len(stamps), float(radius)))
+
     def object_info(self, idx):
         l = C.c_float(0); t = C.c_int(0); d = C.c_int(0); n = C.c_uint32(0)
         _check(lib().mon_online_object_info(self.h, idx, C.byref(l), C.byref(t), C.byref(d), C.byref(n))); return dict(loss=l.value, train_calls=t.value, device=d.value, n_boxes=n.value)
@@ -411,3 +418,7 @@ def marching_cubes(density, res3, thresh, aabb_min, aabb_max, device=0):
     verts = np.empty((nv.value, 3), np.float32); nraw = np.empty((nv.value, 3), np.float32); idx = np.empty(ni.value, np.uint32)
     _check(lib().mon_marching_cubes(device, _p(d), rx, ry, rz, float(thresh), _p(a0), _p(a1), _p(verts), _p(nraw), _p(idx), nv.value, ni.value, C.byref(nv), C.byref(nr), C.byref(ni)))
     return dict(verts=verts, normals_raw=nraw, indices=idx, n_verts_real=nr.value)
+
+
+def generate_toc(theta_deg, phi_deg, radius):
+    T = np.empty(16, np.float32); _check(lib().mon_generate_toc(theta_deg, phi_deg, radius, _p(T))); return T

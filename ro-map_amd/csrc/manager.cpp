@@ -169,6 +169,65 @@ int offline_wait(OfflineManager& m) {                                    // nerf
     return MON_OK;
 }
 
+// img.convertTo(CV_8UC3, 255) / depth.convertTo(CV_16UC1, 20000) / mask.convertTo(CV_8UC1, 255) + imwrite, nerf.cu:335-349 (saturating, round half to even)
+static int write_render_pngs(const std::string& img_path, const std::string& depth_path, const std::string& mask_path, uint32_t w, uint32_t h,
+                             const float* rgb, const float* depth, const float* mask) {
+    const size_t n = (size_t)w * h; std::string err; std::vector<uint8_t> c8(3 * n), m8(n), d16(2 * n);
+    for (size_t p = 0; p < 3 * n; ++p) { const float q = rgb[p] * 255.f; c8[p] = (uint8_t)(q < 0.f ? 0.f : (q > 255.f ? 255.f : std::nearbyint(q))); }
+    for (size_t p = 0; p < n; ++p) {
+        if (mask) m8[p] = (uint8_t)std::nearbyint(mask[p] * 255.f);
+        const float q = depth[p] * 20000.f; const uint32_t u = (uint32_t)(q < 0.f ? 0.f : (q > 65535.f ? 65535.f : std::nearbyint(q))); d16[2 * p] = (uint8_t)(u >> 8); d16[2 * p + 1] = (uint8_t)u;
+    }
+    if (!png_write(img_path, (int)w, (int)h, 3, 8, c8.data(), err) || !png_write(depth_path, (int)w, (int)h, 1, 16, d16.data(), err) ||
+        (mask && !png_write(mask_path, (int)w, (int)h, 1, 8, m8.data(), err))) { set_error("%s", err.c_str()); return MON_ERR_IO; }
+    return MON_OK;
+}
+
+// NeRF_Model::GenerateToc nerf_model.cu:2186-2205: camera on a sphere of radius r around the object, looking at its centre
+void generate_toc(float theta, float phi, float r, float* Toc16) {
+    const double d2r = M_PI / 180.0;
+    const float t[3] = { (float)(r * std::cos(phi * d2r) * std::cos(theta * d2r)), (float)(r * std::cos(phi * d2r) * std::sin(theta * d2r)), (float)(r * std::sin(phi * d2r)) };
+    float z[3] = { -t[0], -t[1], -t[2] }; const float zn = std::sqrt(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]); if (zn > 0.f) for (float& v : z) v /= zn;
+    const float rv = (float)((theta + 90.0f) * d2r); float x[3] = { std::cos(rv), std::sin(rv), 0.f };
+    const float xn = std::sqrt(x[0] * x[0] + x[1] * x[1]); if (xn > 0.f) for (float& v : x) v /= xn;
+    float y[3] = { z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0] };
+    const float yn = std::sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]); if (yn > 0.f) for (float& v : y) v /= yn;
+    const float M[16] = { x[0], x[1], x[2], 0.f, y[0], y[1], y[2], 0.f, z[0], z[1], z[2], 0.f, t[0], t[1], t[2], 1.f };
+    std::memcpy(Toc16, M, 64);
+}
+
+// NeRF_Model::RenderVideo nerf_model.cu:1832-1990: 60 views (6 degree steps, 30 degree elevation), central half of the image, object-frame poses
+static int render_video(Model& m, int H, int W, float radius, const std::string& img_dir, const std::string& depth_dir) {
+    mon_frame_bbox box{ 0u, (uint32_t)(W / 4), (uint32_t)(H / 4), (uint32_t)(H / 2), (uint32_t)(W / 2) };
+    const size_t n = (size_t)box.w * box.h; std::vector<float> rgb(3 * n), depth(n), mask(n);
+    const int theta_num = 60; const float theta = 360 / (float)theta_num; float cur = 0.f;
+    for (int i = 0; i < theta_num; ++i) {
+        cur += theta; float Toc[16]; generate_toc(cur, 30.f, radius, Toc);
+        int rc = model_render(m, box, Toc, 1, rgb.data(), depth.data(), mask.data(), 0); if (rc) return rc;
+        rc = write_render_pngs(img_dir + "/" + std::to_string(i) + ".png", depth_dir + "/" + std::to_string(i) + ".png", "", box.w, box.h, rgb.data(), depth.data(), nullptr); if (rc) return rc;
+    }
+    return MON_OK;
+}
+
+// Eigen::Quaternionf(Matrix3f) for a column-major 4x4 (x y z w); trace / largest-diagonal branches
+static void quat_from_pose(const float* M, float* q) {
+    const float m00 = M[0], m11 = M[5], m22 = M[10], tr = m00 + m11 + m22;
+    if (tr > 0.f) { float t = std::sqrt(tr + 1.f); q[3] = 0.5f * t; t = 0.5f / t; q[0] = (M[6] - M[9]) * t; q[1] = (M[8] - M[2]) * t; q[2] = (M[1] - M[4]) * t; }
+    else {
+        int i = 0; if (m11 > m00) i = 1; if (m22 > (i ? m11 : m00)) i = 2; const int j = (i + 1) % 3, k = (j + 1) % 3;
+        auto R = [&](int r, int c) { return M[c * 4 + r]; };
+        float t = std::sqrt(R(i, i) - R(j, j) - R(k, k) + 1.f); q[i] = 0.5f * t; t = 0.5f / t;
+        q[3] = (R(k, j) - R(j, k)) * t; q[j] = (R(j, i) + R(i, j)) * t; q[k] = (R(k, i) + R(i, k)) * t;
+    }
+}
+static void mat4_mul(const float* A, const float* B, float* C) {       // column-major C = A * B
+    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) { float v = 0.f; for (int k = 0; k < 4; ++k) v += A[k * 4 + r] * B[c * 4 + k]; C[c * 4 + r] = v; }
+}
+static void write_pose_line(std::ofstream& f, const std::string& stamp, const mon_frame_bbox& b, const float* Tow, const float* Twc) {
+    float Toc[16], q[4]; mat4_mul(Tow, Twc, Toc); quat_from_pose(Toc, q);
+    f << stamp << " " << b.x << " " << b.y << " " << b.h << " " << b.w << " " << Toc[12] << " " << Toc[13] << " " << Toc[14] << " " << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << std::endl;
+}
+
 // Test images of one object for each of its training boxes: <out>/<id>/test_img|test_depth|test_mask/<stamp>.png,
 // 8-bit colour, 16-bit depth x 20000, 8-bit mask (nerf.cu:335-349).
 int offline_render_test(OfflineManager& m, int idx, const char* out_dir, int max_views) {
@@ -181,15 +240,8 @@ int offline_render_test(OfflineManager& m, int idx, const char* out_dir, int max
         const mon_frame_bbox b = o->boxes[i]; const size_t n = (size_t)b.w * b.h;
         std::vector<float> rgb(3 * n), depth(n), mask(n);
         int rc = model_render(*o->model, b, &m.poses[16 * (size_t)b.FrameId], 0, rgb.data(), depth.data(), mask.data(), 0); if (rc) return rc;
-        std::vector<uint8_t> c8(3 * n), m8(n), d16(2 * n);
-        for (size_t p = 0; p < 3 * n; ++p) { const float q = rgb[p] * 255.f; c8[p] = (uint8_t)(q < 0.f ? 0.f : (q > 255.f ? 255.f : std::nearbyint(q))); }      // convertTo(CV_8UC3, 255)
-        for (size_t p = 0; p < n; ++p) {
-            m8[p] = (uint8_t)std::nearbyint(mask[p] * 255.f);
-            const float q = depth[p] * 20000.f; const uint32_t u = (uint32_t)(q < 0.f ? 0.f : (q > 65535.f ? 65535.f : std::nearbyint(q))); d16[2 * p] = (uint8_t)(u >> 8); d16[2 * p + 1] = (uint8_t)u;
-        }
-        if (!png_write(root + "/test_img/" + o->stamps[i] + ".png", (int)b.w, (int)b.h, 3, 8, c8.data(), err) ||
-            !png_write(root + "/test_depth/" + o->stamps[i] + ".png", (int)b.w, (int)b.h, 1, 16, d16.data(), err) ||
-            !png_write(root + "/test_mask/" + o->stamps[i] + ".png", (int)b.w, (int)b.h, 1, 8, m8.data(), err)) { set_error("%s", err.c_str()); return MON_ERR_IO; }
+        rc = write_render_pngs(root + "/test_img/" + o->stamps[i] + ".png", root + "/test_depth/" + o->stamps[i] + ".png", root + "/test_mask/" + o->stamps[i] + ".png", b.w, b.h, rgb.data(), depth.data(), mask.data());
+        if (rc) return rc;
     }
     uint32_t n_mesh = 0; model_mesh_counts(*o->model, &n_mesh, nullptr, nullptr);
     if (n_mesh) {                                                        // "Save Object Mesh", nerf.cu:397-403
@@ -225,6 +277,7 @@ struct OnlineManager {
     std::string cfg_path; bool use_depth = false; int iters = 500, n_dev = 0, next_dev = 0; mon_config cfg{};
     size_t n_images = 0; std::vector<Dataset*> ds; std::vector<std::vector<std::unique_ptr<std::mutex>>> ds_mutex;
     std::map<std::string, uint32_t> stamp_to_idx; std::vector<OnlineObject*> objs; std::vector<std::thread> threads;
+    int H = 0, W = 0; std::map<uint32_t, std::vector<float>> poses;       // host copy of the poses for train.txt (nerf.cu:369-373 reads them back from the device)
 };
 
 static bool online_check_finish(OnlineObject* o) { std::unique_lock<std::mutex> l(o->mu_finish); return o->finish; }
@@ -307,13 +360,14 @@ int mon_online_init(mon_online* h) {                                      // ner
     m.cfg.use_depth = m.use_depth ? 1 : 0; return MON_OK;
 }
 int mon_online_dataset_init(mon_online* h, float fx, float fy, float cx, float cy, int H, int W, size_t imgs) {   // :160-187
-    REQ(h); OnlineManager& m = *h->m; m.n_images = imgs; m.ds_mutex.resize(m.n_dev);
+    REQ(h); OnlineManager& m = *h->m; m.n_images = imgs; m.ds_mutex.resize(m.n_dev); m.H = H; m.W = W;
     for (int g = 0; g < m.n_dev; ++g) { Dataset* d = nullptr; int rc = dataset_create(g, H, W, fx, fy, cx, cy, (uint32_t)imgs, m.use_depth, &d); if (rc) return rc; m.ds.push_back(d); }
     return MON_OK;
 }
 int mon_online_new_frame(mon_online* h, uint32_t img_id, const char* timestamp, const uint8_t* bgr, int channels, const uint8_t* instance, const float* depth, const float* Twc16) {   // :189-218
     REQ(h); REQ(timestamp); OnlineManager& m = *h->m;
     m.stamp_to_idx[timestamp] = img_id;                                   // nerf_data.cu:284
+    if (Twc16) m.poses[img_id].assign(Twc16, Twc16 + 16);
     for (int g = 0; g < m.n_dev; ++g) {
         for (auto& mu : m.ds_mutex[g]) mu->lock();                        // exclude every object's GenerateBatch on that device while the frame lands
         const int rc = dataset_add_frame(m.ds[g], img_id, bgr, channels, 1, instance, m.use_depth ? depth : nullptr, Twc16);
@@ -368,6 +422,49 @@ int mon_online_render(mon_online* h, size_t idx, mon_frame_bbox box, const float
     REQ(h); if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
     return model_render(*h->m->objs[idx]->model, box, Twc16, 0, rgb, depth, mask, 0);
 }
+// NerfManagerOnline::RenderNeRFsTest -> NeRF::RenderTestImg, nerf.cu:255-404: <out>/<id>/{test_img,test_depth,test_mask}/<stamp>.png,
+// test.txt, train.txt (object-centric poses), 60-view video_img / video_depth, obj.ply
+int mon_online_render_nerfs_test(mon_online* h, const char* out_path, size_t idx, const char* const* timestamps, const mon_frame_bbox* boxes, const float* Twcs16, size_t n, float radius) {
+    REQ(h); REQ(out_path); OnlineManager& m = *h->m;
+    if (m.objs.empty()) return MON_OK;                                    // nerf_manager.cu:282
+    if (idx >= m.objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
+    if (n && (!timestamps || !boxes || !Twcs16)) { set_error("RenderNeRFsTest: null argument"); return MON_ERR_ARG; }
+    OnlineObject* o = m.objs[idx]; const std::string root = std::string(out_path) + "/" + std::to_string(o->id);
+    ::mkdir(out_path, 0755);
+    for (const char* sub : { "", "/test_img", "/test_depth", "/test_mask", "/video_img", "/video_depth" }) ::mkdir((root + sub).c_str(), 0755);
+    std::ofstream f(root + "/test.txt");
+    if (!f) { set_error("mkdir error: %s", root.c_str()); return MON_ERR_IO; }
+    f << std::fixed << "#stamp  box.x  box.y  box.h  box.w  tx  ty  tz  qx  qy  qz  qw (object-centric)" << std::endl;
+    std::printf("Render Object %d test imgs to %s/test_img ... please wait...\n", o->id, root.c_str());
+    for (size_t i = 0; i < n; ++i) {
+        const mon_frame_bbox b = boxes[i]; const float* Twc = Twcs16 + 16 * i; const std::string st = timestamps[i]; const size_t px = (size_t)b.w * b.h;
+        write_pose_line(f, st, b, o->Tow, Twc);
+        std::vector<float> rgb(3 * px), depth(px), mask(px);
+        int rc = model_render(*o->model, b, Twc, 0, rgb.data(), depth.data(), mask.data(), 0); if (rc) return rc;
+        rc = write_render_pngs(root + "/test_img/" + st + ".png", root + "/test_depth/" + st + ".png", root + "/test_mask/" + st + ".png", b.w, b.h, rgb.data(), depth.data(), mask.data()); if (rc) return rc;
+    }
+    f.close();
+    f.open(root + "/train.txt");                                          // training data, nerf.cu:356-390
+    f << std::fixed << "#class Bbox" << std::endl << o->cls << " " << o->amax[0] << " " << o->amax[1] << " " << o->amax[2] << " " << std::endl;
+    f << "#stamp box.x box.y box.h box.w  tx  ty  tz  qx  qy  qz  qw (object-centric)" << std::endl;
+    for (size_t i = 0; i < o->n_uploaded; ++i) {
+        const mon_frame_bbox b = o->boxes[i]; std::string st;
+        for (const auto& kv : m.stamp_to_idx) if (kv.second == b.FrameId) { st = kv.first; break; }
+        auto it = m.poses.find(b.FrameId); if (it == m.poses.end()) continue;
+        write_pose_line(f, st, b, o->Tow, it->second.data());
+    }
+    f.close();
+    std::printf("Render Object %d 360 video imgs to %s/video_img ... please wait...\n", o->id, root.c_str());
+    int rc = render_video(*o->model, m.H, m.W, radius, root + "/video_img", root + "/video_depth"); if (rc) return rc;
+    uint32_t n_mesh = 0; model_mesh_counts(*o->model, &n_mesh, nullptr, nullptr);
+    if (n_mesh) {                                                         // "Save Object Mesh", nerf.cu:397-403
+        std::puts("Save Object Mesh ... please wait...");
+        rc = model_generate_mesh(*o->model, o->mesh_res, o->mesh_thresh, nullptr, nullptr); if (rc) return rc;
+        rc = model_save_mesh(*o->model, (root + "/obj.ply").c_str()); if (rc) return rc;
+    }
+    return MON_OK;
+}
+int mon_generate_toc(float theta_deg, float phi_deg, float radius, float* Toc16) { REQ(Toc16); generate_toc(theta_deg, phi_deg, radius, Toc16); return MON_OK; }
 int mon_online_object(mon_online* h, size_t idx, mon_object** borrowed) { REQ(h); REQ(borrowed); if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *borrowed = &h->m->objs[idx]->handle; return MON_OK; }
 int mon_online_destroy(mon_online* h) { if (!h) return MON_OK; online_destroy(h->m); delete h; return MON_OK; }
 

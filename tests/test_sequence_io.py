@@ -96,6 +96,17 @@ def test_offline_nerf_flow_on_disk_sequence(pkg, ss, tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path / "out2"), "0", "test_img"))
 
 
+def test_generate_toc_orbit_pose(pkg):
+    """GenerateToc (nerf_model.cu:2186-2205): camera at radius r, 30 degrees up, z axis through the object centre, x axis horizontal."""
+    for theta in (6.0, 90.0, 201.0, 360.0):
+        T = pkg.generate_toc(theta, 30.0, 0.8).reshape(4, 4).T
+        R, t = T[:3, :3], T[:3, 3]
+        assert np.allclose(R.T @ R, np.eye(3), atol=1e-6) and abs(np.linalg.det(R) - 1) < 1e-5
+        assert abs(np.linalg.norm(t) - 0.8) < 1e-6 and abs(t[2] - 0.8 * np.sin(np.radians(30))) < 1e-6
+        assert np.allclose(R[:, 2], -t / np.linalg.norm(t), atol=1e-6) and abs(R[2, 0]) < 1e-7
+        assert np.allclose(np.arctan2(t[1], t[0]) % (2 * np.pi), np.radians(theta) % (2 * np.pi), atol=1e-5) or theta == 360.0
+
+
 def test_online_manager_errors_without_device(pkg):
     m = pkg.OnlineManager(os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json"), False, 50)
     if pkg.device_count() == 0:
@@ -114,7 +125,7 @@ def test_online_manager_errors_without_device(pkg):
 
 
 @pytest.mark.gpu
-def test_online_manager_incremental_flow(pkg, ss):
+def test_online_manager_incremental_flow(pkg, ss, tmp_path):
     """The SLAM-side call sequence (REF/src/LocalMapping.cc:1122-1270): frames land one by one, objects are created when first
     seen, boxes arrive per keyframe with train_step=1, training only starts past 10 boxes, WaitThreadsEnd trains once more."""
     sc = ss.make_scene(n_views=24, H=120, W=160, f=130.0, n_objects=2, seed=9)
@@ -146,4 +157,28 @@ def test_online_manager_incremental_flow(pkg, ss):
         assert iou > 0.8, (k, iou)
         mesh = m.object(i).get_mesh(try_lock=True)                    # DrawMesh(idx)'s data
         assert mesh["n_verts_real"] > 50 and mesh["indices"].max() < mesh["n_verts_real"]
+    # RenderNeRFsTest (System.cc:610): test images, test.txt / train.txt, 360-degree video, obj.ply
+    from PIL import Image
+    out = str(tmp_path / "render"); ob = sc.objects[0]; sel = [2, 7]
+    stamps = ["%.6f" % (int(ob["boxes"][j][0]) * 0.1) for j in sel]
+    m.render_nerfs_test(out, ids[0], stamps, ob["boxes"][sel], np.stack([ss.colmajor(sc.Twc[int(ob["boxes"][j][0])]) for j in sel]), 0.8)
+    root = os.path.join(out, "0")
+    test_lines = open(os.path.join(root, "test.txt")).read().strip().split("\n"); train_lines = open(os.path.join(root, "train.txt")).read().strip().split("\n")
+    assert len(test_lines) == 3 and len(train_lines) == 3 + len(ob["boxes"]) and test_lines[1].split()[0] == stamps[0]
+    # object-centric pose of the first test view: Toc = Tow * Twc (nerf.cu:325-329)
+    Toc = ob["Tow"] @ sc.Twc[int(ob["boxes"][sel[0]][0])]; vals = [float(q) for q in test_lines[1].split()[5:]]
+    assert np.allclose(vals[:3], Toc[:3, 3], atol=1e-5)
+    qx, qy, qz, qw = vals[3:]; R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                                             [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                                             [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+    assert np.allclose(R, Toc[:3, :3], atol=1e-4)
+    for j in sel:
+        st = "%.6f" % (int(ob["boxes"][j][0]) * 0.1)
+        assert np.asarray(Image.open(os.path.join(root, "test_img", st + ".png"))).shape == (int(ob["boxes"][j][3]), int(ob["boxes"][j][4]), 3)
+    frames = [np.asarray(Image.open(os.path.join(root, "video_img", "%d.png" % i))) for i in (0, 29, 59)]
+    assert all(fr.shape == (sc.H // 2, sc.W // 2, 3) for fr in frames)
+    cover = [(fr.min(axis=2) < 250).mean() for fr in frames]                     # the object is in view from every orbit pose
+    assert min(cover) > 0.02, cover
+    assert np.asarray(Image.open(os.path.join(root, "video_depth", "0.png"))).max() > 255          # 16-bit depth x 20000
+    assert open(os.path.join(root, "obj.ply")).readline().strip() == "ply"
     m.close()
