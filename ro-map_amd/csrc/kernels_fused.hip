@@ -69,6 +69,10 @@ __device__ __forceinline__ int rho(int h, int r) { return (r & 3) + 8 * (r >> 2)
 __device__ __forceinline__ int unit_of_slot(int s, int h, int j) { return 32 * (s >> 1) + rho(h, 8 * (s & 1) + j); }
 
 typedef LevelFast LevelLds;      // copied into LDS once per workgroup
+#ifndef MON_ENCODE_BATCH
+#define MON_ENCODE_BATCH 4
+#endif
+constexpr int kEncodeBatch = MON_ENCODE_BATCH;
 
 // Corner walk of one level for one position: calls f(k, index_within_level, weight) for the 8 corners.
 // Same arithmetic as tcnn's grid_index / grid_hash (weights multiply in x, y, z order; see k_encode), restructured
@@ -225,6 +229,17 @@ __device__ __forceinline__ void scratch_store_units(half_t* scr, int mb, int n, 
     for (int j = 0; j < 8; ++j) { scr[(32 * mb + rho(h, j)) * 32 + n] = lo[j]; scr[(32 * mb + rho(h, 8 + j)) * 32 + n] = hi[j]; }
 }
 
+// Phase timing (tools/fused_timing.py builds a -DMON_FUSED_TIMING variant of the library): per-wave cycle totals per phase,
+// every stamp drains the memory counters first so a phase owns the latency it waits for.  Compiles to nothing otherwise.
+struct TimingCtx { float acc[16]; long long last; };
+__device__ __forceinline__ void tstamp(TimingCtx* tc, int k) {
+#ifdef MON_FUSED_TIMING
+    if (tc) { __builtin_amdgcn_s_waitcnt(0); const long long t = clock64(); tc->acc[k] += (float)(t - tc->last); tc->last = t; }
+#else
+    (void)tc; (void)k;
+#endif
+}
+
 // Forward pass of one 32-sample tile.  Leaves: ef (local encoded features), hp* (hidden activations as
 // packed B fragments), out4 (raw network outputs of sample n, valid in half-wave 0).
 template <int EPAD, int W, int NH>
@@ -237,21 +252,78 @@ struct TileState {
 };
 
 template <int EPAD, int W, int NH>
-__device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const half_t* frags, const LevelLds& llt, const half2_t* __restrict__ table,
-                                             int L, const float x[3], int lane) {
+__device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const half_t* frags, const LevelFast& klt, const half2_t* __restrict__ table,
+                                             int L, const float x[3], int lane, TimingCtx* tc = nullptr) {
     using S = FusedShape<EPAD, W, NH>;
     const int h = lane >> 5, LPH = (L + 1) >> 1;
-    // ---- hash-grid encode of the levels this half-wave owns (tcnn kernel_grid; fp32 fmaf chain, one rounding)
+    // ---- hash-grid encode (tcnn kernel_grid; fp32 fmaf chain over the 8 corners, one rounding).  Half-wave h OWNS levels
+    //      h*LPH + il (their features are its K slots), but the GATHERS are issued level by level with all 64 lanes on one
+    //      level: lane (n, c) fetches the four (y, z) corners with x-corner c of sample n.  Measured on MI355X
+    //      (tools/run_gatherbench.py): a divergent gather costs ~2.4 clk per distinct 64-byte line per instruction and nothing
+    //      more for further lanes in the same line -- and corners x, x+1 share a line 15 times out of 16, on hashed levels too
+    //      (x ^ h keeps the upper bits).  So pairing them in one instruction halves the lines per level; a
+    //      v_permlane32_swap per value then hands each half the 8 corners of the level it owns, and the interpolation runs
+    //      the same chain in the same order as before (bit-identical results).
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half2_t*>(table), 0, (int)(klt.offset[L] * 4u), 0x00020000);
+    auto half_gather = [&](int level, uint32_t (&r)[4]) {                              // `level` is wave-uniform: constants come from SGPRs
+        const float scale = klt.scale[level];
+        const uint32_t size = klt.size[level], my = klt.my[level], mz = klt.mz[level], mask = klt.mask[level], off = klt.offset[level];
+        const bool hashed = klt.hashed[level] != 0u;
+        uint32_t pg[3];
 #pragma unroll
-    for (int il = 0; il < S::LLV; ++il) {
-        const int level = h * LPH + il;
-        float a0 = 0.f, a1 = 0.f;
-        if (il < LPH && level < L) {
-            const half2_t* tl = table + llt.offset[level];
-            level_corners(llt, level, x, [&](int, uint32_t idx, float wgt) { const half2_t v = tl[idx]; a0 = fmaf(wgt, (float)v.x, a0); a1 = fmaf(wgt, (float)v.y, a1); });
+        for (int d = 0; d < 3; ++d) pg[d] = (uint32_t)(int32_t)floorf(fmaf(scale, x[d], 0.5f));
+        const uint32_t ax = pg[0] + (uint32_t)h, y0 = pg[1] * my, z0 = pg[2] * mz;
+        const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t ih = ax ^ ay[j & 1] ^ az[j >> 1], id = ax + ay[j & 1] + az[j >> 1];
+            uint32_t idx = (hashed ? ih : id) & mask;
+            idx -= (idx >= size) ? size : 0u;
+            idx = min(idx, size - 1u);
+            r[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (off + idx) * 4u, 0, 0);
         }
-        ts.ef[2 * il] = (half_t)a0; ts.ef[2 * il + 1] = (half_t)a1;
+    };
+    constexpr int EB = (S::LLV < kEncodeBatch) ? S::LLV : kEncodeBatch;              // level pairs in flight
+#pragma unroll
+    for (int b0 = 0; b0 < S::LLV; b0 += EB) {
+        uint32_t ra[EB][4], rb[EB][4];
+#pragma unroll
+        for (int ib = 0; ib < EB; ++ib) {
+            const int il = b0 + ib;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ra[ib][j] = 0u; rb[ib][j] = 0u; }
+            if (il < LPH) {                                                             // uniform
+                half_gather(il, ra[ib]);
+                if (LPH + il < L) half_gather(LPH + il, rb[ib]);
+            }
+        }
+#pragma unroll
+        for (int ib = 0; ib < EB; ++ib) {
+            const int il = b0 + ib, level = h * LPH + il;
+            float a0 = 0.f, a1 = 0.f;
+            if (il < LPH) {
+                typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                uint32_t c0[4], c1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const u2v sw = __builtin_amdgcn_permlane32_swap(ra[ib][j], rb[ib][j], false, false); c0[j] = sw.x; c1[j] = sw.y; }
+                if (level < L) {
+                    const float scale = h ? klt.scale[(LPH + il < L) ? LPH + il : il] : klt.scale[il];
+                    float pos[3];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, x[d], 0.5f); pos[d] = q - floorf(q); }
+                    const float wx[2] = { 1.f - pos[0], pos[0] }, wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const half2_t v = __builtin_bit_cast(half2_t, (k & 1) ? c1[k >> 1] : c0[k >> 1]);
+                        const float wgt = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
+                        a0 = fmaf(wgt, (float)v.x, a0); a1 = fmaf(wgt, (float)v.y, a1);
+                    }
+                }
+            }
+            ts.ef[2 * il] = (half_t)a0; ts.ef[2 * il + 1] = (half_t)a1;
+        }
     }
+    tstamp(tc, 2);
     // ---- layer 0
     float16_t acc[S::MB];
 #pragma unroll
@@ -309,6 +381,11 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     unsigned long long* cwords = reinterpret_cast<unsigned long long*>(smem + S::FRAG_BYTES + 512);      // [256]
     uint32_t* cprefix = reinterpret_cast<uint32_t*>(smem + S::FRAG_BYTES + 512 + 2048);                   // [257] exclusive prefix, [nwords] = total
     unsigned char* dyn = smem + S::FRAG_BYTES + S::LT_BYTES;
+#ifdef MON_FUSED_TIMING
+    TimingCtx tcx; for (float& v : tcx.acc) v = 0.f; tcx.last = clock64(); TimingCtx* tc = &tcx;
+#else
+    TimingCtx* tc = nullptr;
+#endif
     build_fragments<EPAD, W, NH>(frags, llt, a, true);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
     half_t* scr = reinterpret_cast<half_t*>(dyn + wave * S::SCR_BYTES);
@@ -350,6 +427,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
             for (int nb = 0; nb < S::MB; ++nb) dW1[mb][nb] = float16_t{ 0 };
     }
     float loss_acc = 0.f;
+    tstamp(tc, 0);
 
     for (uint32_t ray = blockIdx.x * S::WAVES + wave; ray < R; ray += gridDim.x * S::WAVES) {
         // ---- which candidate is this ray (wave-uniform binary search over the prefix table + in-word select)
@@ -372,8 +450,9 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
 #pragma unroll
         for (int d = 0; d < 3; ++d) { const float p = fmaf(t, a.b.cand_d[3 * cand + d], a.b.cand_o[3 * cand + d]); x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
 
+        tstamp(tc, 1);
         TileState<EPAD, W, NH> ts;
-        tile_forward<EPAD, W, NH>(ts, frags, *llt, table, L, x, lane);
+        tile_forward<EPAD, W, NH>(ts, frags, a.lt, table, L, x, lane, tc);
         const bool do_dw = (a.ablate & 2u) == 0u;
 
         // ---- transposes needed by the weight gradients
@@ -390,6 +469,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         }
         }
 
+        tstamp(tc, 4);
         // ---- composite (VolumeRender :762-813) as wave scans over lanes 0..31
         const float v0 = ts.out4[0], v1 = ts.out4[1], v2 = ts.out4[2], v3 = ts.out4[3];
         const float c0 = logistic_f(v0), c1 = logistic_f(v1), c2 = logistic_f(v2), sigma = __expf(v3);
@@ -470,6 +550,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
                 }
         }
 
+        tstamp(tc, 5);
         // ---- backward: dWout += H_last^T-side outer products (K = samples, via the LDS transposes)
         const int m = n;     // A-fragment row / B-fragment column of this lane
         if (do_dw) {
@@ -523,6 +604,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
 #pragma unroll
             for (int mb = 0; mb < S::MB; ++mb) { dh0[mb][0] = dhl[mb][0]; dh0[mb][1] = dhl[mb][1]; }
         }
+        tstamp(tc, 6);
         // ---- dW0[u][f] += dH0[u][n] * E[n][f]
         if (do_dw) {
             const half_t* dh0_scr = scr + (NH == 2 ? S::SCR_HB : S::SCR_HA);
@@ -556,6 +638,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         // ---- grid backward (tcnn kernel_grid_backward).  Levels small enough for an LDS tile hand dL/dE to
         //      k_grid_scatter (global packed-f16 atomics sustain only ~21 Gop/s on gfx950, ~12x below the gather
         //      rate: profiles/); larger levels scatter here with 8 global_atomic_pk_add_f16 per level.
+        tstamp(tc, 7);
         const uint32_t Btot = R * 32u;
         const bool do_store = (a.ablate & 4u) == 0u;
         if (a.lds_level_mask && h == 0 && do_store) { a.x_soa[s_idx] = x[0]; a.x_soa[Btot + s_idx] = x[1]; a.x_soa[2u * Btot + s_idx] = x[2]; }
@@ -577,6 +660,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
                 }
             }
         }
+        tstamp(tc, 8);
     }
 
     // ---- reduce the weight-gradient accumulators over the workgroup's waves, write one fp32 partial row.
@@ -607,6 +691,10 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         if (!dead) v = (r0[i] + r0[(S::N_MLP + 64) + i]) + (r0[2 * (S::N_MLP + 64) + i] + r0[3 * (S::N_MLP + 64) + i]);
         dst[i] = v;
     }
+#ifdef MON_FUSED_TIMING
+    tstamp(tc, 9);
+    if (lane == 0) for (int k = 0; k < 16; ++k) a.b.tdist[(blockIdx.x * S::WAVES + wave) * 16 + k] = tcx.acc[k];
+#endif
 }
 
 // ------------------------------------------------------------------ LDS grid scatter
@@ -750,7 +838,7 @@ __global__ void __launch_bounds__(256) k_fused_render(FusedArgs a, uint32_t n_ra
 #pragma unroll
                 for (int d = 0; d < 3; ++d) { const float p = fmaf(t, a.b.ray_d[3 * ray + d], a.b.ray_o[3 * ray + d]); x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
                 TileState<EPAD, W, NH> ts;
-                tile_forward<EPAD, W, NH>(ts, frags, *llt, table, L, x, lane);
+                tile_forward<EPAD, W, NH>(ts, frags, a.lt, table, L, x, lane);
                 const float c0 = logistic_f(ts.out4[0]), c1 = logistic_f(ts.out4[1]), c2 = logistic_f(ts.out4[2]), sigma = __expf(ts.out4[3]);
                 float tprev = __shfl_up(t, 1, 32); if (n == 0) tprev = tlast;
                 const float alpha = 1.f - __expf(-sigma * (t - tprev)), omv = 1.f - alpha;

@@ -19,15 +19,24 @@ __global__ void __launch_bounds__(256) k_ub(int mode, int pattern, uint32_t n_en
     typedef __attribute__((address_space(1))) half2_t gh2;
     gh2* t16 = (gh2*)reinterpret_cast<half2_t*>(table);
     float acc = 0.f;
+    // gather-sharing probes (all read-only half2 gathers, pattern as given):
+    //   mode 7: consecutive loads of one lane hit the same 64-byte line (idx, idx^1)      mode 8: lanes l and l^32 of one load share a line
+    //   mode 9: as mode 3 through buffer_load (SGPR descriptor + 32-bit offset)            mode 20: 4 lanes (l, l^16, l^32, l^48) share a line
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(table, 0, (int)(n_entries * 32u), 0x00020000);
+#pragma unroll 8
     for (uint32_t i = 0; i < ops_per_thread; ++i) {
-        uint32_t r = mix32(gid * 0x9E3779B9u + i * 0x85EBCA6Bu + 12345u), idx;
+        uint32_t key = gid, it = i;
+        if (mode == 7) it = i >> 1; else if (mode == 8) key = gid & ~32u; else if (mode == 20) key = gid & ~48u;
+        uint32_t r = mix32(key * 0x9E3779B9u + it * 0x85EBCA6Bu + 12345u), idx;
         if (pattern == 0) idx = r % n_entries;
         else { const uint32_t lvl = i & 15u; const uint32_t size = lvl == 0 ? 4096u : (lvl == 1 ? 32768u : 65536u); const uint32_t off = lvl == 0 ? 0u : (lvl == 1 ? 4096u : 36864u + (lvl - 2u) * 65536u); idx = off + (r % size); }
+        if (mode == 7) idx ^= (i & 1u); else if (mode == 8) idx ^= (gid >> 5) & 1u; else if (mode == 20) idx ^= (gid >> 4) & 3u;
         const half2_t v = { (half_t)1e-3f, (half_t)-1e-3f };
         if (mode == 0) __builtin_amdgcn_global_atomic_fadd_v2f16(t16 + idx, v);
         else if (mode == 1) __builtin_amdgcn_global_atomic_fadd_v2f16(t16 + (size_t)xcc * n_entries + idx, v);
         else if (mode == 2) atomicAdd(reinterpret_cast<float*>(table) + idx, 1e-3f);
-        else if (mode == 3) { const half2_t g = reinterpret_cast<const half2_t*>(table)[idx]; acc += (float)g.x + (float)g.y; }
+        else if (mode == 9) { acc += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, idx * 4u, 0, 0)); }
+        else if (mode == 3 || mode == 7 || mode == 8 || mode == 20) { const half2_t g = reinterpret_cast<const half2_t*>(table)[idx]; acc += (float)g.x + (float)g.y; }
         else if (mode == 4) { const uint32_t b = (idx & ~7u) + ((idx + (i & 7u)) & 7u); __builtin_amdgcn_global_atomic_fadd_v2f16(t16 + b, v); }
         else if (mode == 5) { const uint4 g = reinterpret_cast<const uint4*>(table)[idx >> 2]; acc += __uint_as_float(g.x ^ g.y ^ g.z ^ g.w); }      // 16-byte aligned quad gather
         else { const uint2 g = reinterpret_cast<const uint2*>(table)[idx >> 1]; acc += __uint_as_float(g.x ^ g.y); }                          // mode 6: 8-byte pair gather
@@ -45,6 +54,19 @@ __global__ void __launch_bounds__(1024) k_ub_lds(int mode, uint32_t ops_per_thre
     __syncthreads();
     typedef __attribute__((address_space(3))) half2_t lh2;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode >= 17 && mode <= 19) {            // minimal-ALU probes: 17 ds_read_b32 random, 18 ds_add_u32 random, 19 ds_read_b64 random (LCG index, 2 VALU per op)
+        uint32_t idx = mix32(gid * 0x9E3779B9u + 777u) & 32767u, accu = 0u;
+#pragma unroll 16
+        for (uint32_t i = 0; i < ops_per_thread; ++i) {
+            idx = (idx * 5u + 12345u) & 32767u;
+            if (mode == 17) accu += tab[idx];
+            else if (mode == 18) atomicAdd(tab + idx, 1u);
+            else { const uint2 v = *reinterpret_cast<const uint2*>(tab + (idx & ~1u)); accu += v.x ^ v.y; }
+        }
+        __syncthreads();
+        if (accu == 0x12345678u) sink[0] = 1.f;
+        return;
+    }
     for (uint32_t i = 0; i < ops_per_thread; ++i) {
         uint32_t key = gid;
         if (mode == 13) key = gid >> 1; else if (mode == 15) key = gid >> 2;

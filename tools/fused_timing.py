@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Per-phase cycle breakdown of k_fused_train (runs on the GPU box).
+
+Builds a -DMON_FUSED_TIMING variant of the library into ro-map_amd/build_timing/ (every phase boundary drains the memory
+counters and reads the shader clock, so a phase owns the latency it waits for; the sum is therefore an upper bound of the
+un-instrumented wave time), runs a few training steps of the bench workload and prints the mean cycles per wave and phase."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PH = ["prologue (frag image, compaction table)", "ray select + position", "encode (16 levels of gathers)", "MLP forward (MFMA)", "LDS transposes for dW",
+      "composite + loss + dL/dO", "dWo, dH (MFMA)", "dW0, dE (MFMA)", "dE / x stores", "epilogue (dW reduce + store)"]
+
+
+def main():
+    src = os.path.join(ROOT, "ro-map_amd"); out = os.path.join(src, "build_timing"); os.makedirs(out, exist_ok=True)
+    flags = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -ffp-contract=off -fno-math-errno -DMON_FUSED_TIMING -w".split()
+    srcs = "config.cpp model.cpp c_api.cpp manager.cpp png_io.cpp mesh.cpp kernels_batch.hip kernels_net.hip kernels_composite.hip kernels_optim.hip kernels_fused.hip kernels_mesh.hip microbench.hip".split()
+    if not os.path.exists(os.path.join(out, "libmon_core.so")) or os.environ.get("MON_TIMING_REBUILD"):
+      procs = [subprocess.Popen(["/opt/rocm/bin/hipcc"] + flags + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(src, "csrc", f), "-o", os.path.join(out, f.rsplit(".", 1)[0] + ".o")]) for f in srcs]
+      assert all(p.wait() == 0 for p in procs)
+      subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(out, "libmon_core.so")] + [os.path.join(out, f.rsplit(".", 1)[0] + ".o") for f in srcs] + ["-lz", "-lpthread"])
+    lib = os.path.join(out, "libmon_core.so")
+    if os.environ.get("MON_TIMING_BUILD_ONLY"):
+        return
+    import __graft_entry__ as ge
+    pkg = ge.load_package(); ss = ge.load_tools()
+    import importlib; binding = importlib.import_module(pkg.__name__ + ".binding")
+    binding.lib_path = lambda: lib; binding._lib = None
+    sc = ss.make_scene(n_views=40, H=480, W=640, f=525.0, seed=0)
+    ds, obj = ge.make_problem(pkg, sc, {}); obj.set_backend(1)
+    obj.train(50)
+    t = obj.buffer("tdist")[:2048 * 16].reshape(2048, 16)
+    tot = t[:, :10].sum(1).mean()
+    print("| phase | mean cycles / wave (2 rays) | share |\n|---|---|---|")
+    for k, name in enumerate(PH):
+        print("| %s | %.0f | %.1f%% |" % (name, t[:, k].mean(), 100 * t[:, k].mean() / tot))
+    print("| total | %.0f | |" % tot)
+
+
+if __name__ == "__main__":
+    main()
