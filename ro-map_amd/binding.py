@@ -111,7 +111,8 @@ def exported_symbols():
 
 
 def lib_path():
-    return os.path.join(_HERE, "libmon_core.so")
+    """In-tree library; MON_CORE_LIB points tooling at an instrumented / experimental build of the same sources (tools/variant_build.sh)."""
+    return os.environ.get("MON_CORE_LIB") or os.path.join(_HERE, "libmon_core.so")
 
 
 _lib = None

@@ -359,17 +359,35 @@ __device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const h
     for (int c = 0; c < 4; ++c) ts.out4[c] = (float)(half_t)ao[c];        // network output is fp16 (tcnn network_precision_t)
 }
 
-// 32-lane inclusive scans (each half-wave scans independently)
-__device__ __forceinline__ float scan_mul32(float v, int n) {
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) { const float o = __shfl_up(v, d, 32); if (n >= d) v *= o; }
+// Cross-lane helpers on DPP (VALU data path, a few cycles each) instead of __shfl_* (ds_bpermute through the LDS crossbar,
+// ~100 cycles of dependent latency per step; the composite is a chain of ~30 of them per ray).
+// dpp_ctrl: row_shr:n = 0x110+n (shift within a 16-lane row), row_bcast:15 = 0x142 (lane 15 of a row to the next row),
+// row_bcast:31 = 0x143, wave_shr:1 = 0x138.  Lanes without a source keep `old`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t src) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xF, false); }
+// 32-lane inclusive scans (each half-wave scans independently: rows 0-1 and rows 2-3)
+__device__ __forceinline__ float scan_mul32(float v) {
+    v *= dpp_f<0x111, 0xF>(1.f, v); v *= dpp_f<0x112, 0xF>(1.f, v); v *= dpp_f<0x114, 0xF>(1.f, v); v *= dpp_f<0x118, 0xF>(1.f, v);
+    v *= dpp_f<0x142, 0xA>(1.f, v);
     return v;
 }
-__device__ __forceinline__ float scan_add32(float v, int n) {
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) { const float o = __shfl_up(v, d, 32); if (n >= d) v += o; }
+__device__ __forceinline__ float scan_add32(float v) {
+    v += dpp_f<0x111, 0xF>(0.f, v); v += dpp_f<0x112, 0xF>(0.f, v); v += dpp_f<0x114, 0xF>(0.f, v); v += dpp_f<0x118, 0xF>(0.f, v);
+    v += dpp_f<0x142, 0xA>(0.f, v);
     return v;
 }
+__device__ __forceinline__ uint32_t scan_add64_u32(uint32_t v) {                     // whole-wave inclusive scan
+    v += dpp_u<0x111, 0xF>(0u, v); v += dpp_u<0x112, 0xF>(0u, v); v += dpp_u<0x114, 0xF>(0u, v); v += dpp_u<0x118, 0xF>(0u, v);
+    v += dpp_u<0x142, 0xA>(0u, v); v += dpp_u<0x143, 0xC>(0u, v);
+    return v;
+}
+// value of the previous lane (lane 0 keeps `fill`; callers overwrite lane 32 themselves where the halves are independent)
+__device__ __forceinline__ float lane_prev(float v, float fill) { return dpp_f<0x138, 0xF>(fill, v); }
+__device__ __forceinline__ float lane_bcast(float v, int src_lane_uniform) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane_uniform)); }
 
 // ------------------------------------------------------------------ fused training kernel
 template <int EPAD, int W, int NH, bool DUMP, bool ATOMIC_LEVELS>
@@ -389,7 +407,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     build_fragments<EPAD, W, NH>(frags, llt, a, true);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
     half_t* scr = reinterpret_cast<half_t*>(dyn + wave * S::SCR_BYTES);
-    for (int i = lane; i < S::SCR_HALVES; i += 64) scr[i] = (half_t)0.f;           // pad feature rows must stay zero
+    for (int i = 2 * a.nd.L * 32 + lane; i < EPAD * 32; i += 64) scr[S::SCR_E + i] = (half_t)0.f;   // pad feature rows stay zero; every other row is rewritten per ray before it is read
     // ---- ray compaction table (fill_rollover_rays :280-294 without a kernel of its own): every workgroup scans the
     //      candidates' 64-bit ballot words; training ray j is valid candidate number (j mod n_valid) in candidate order.
     const uint32_t nwords = a.oc.R >> 6;                                           // <= 256 (fused_supported)
@@ -397,11 +415,9 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         uint32_t carry = 0;
         for (uint32_t base = 0; base < nwords; base += 64) {
             const unsigned long long wd = (base + lane < nwords) ? a.b.mask[base + lane] : 0ull;
-            const uint32_t c = __popcll(wd); uint32_t inc = c;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+            const uint32_t c = __popcll(wd); const uint32_t inc = scan_add64_u32(c);
             if (base + lane < nwords) { cwords[base + lane] = wd; cprefix[base + lane] = carry + inc - c; }
-            carry += __shfl(inc, 63);
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
         if (lane == 0) cprefix[nwords] = carry;
     }
@@ -473,19 +489,19 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         // ---- composite (VolumeRender :762-813) as wave scans over lanes 0..31
         const float v0 = ts.out4[0], v1 = ts.out4[1], v2 = ts.out4[2], v3 = ts.out4[3];
         const float c0 = logistic_f(v0), c1 = logistic_f(v1), c2 = logistic_f(v2), sigma = __expf(v3);
-        float tprev = __shfl_up(t, 1, 32); if (n == 0) tprev = 0.f;                      // :770 last_distance = 0
+        float tprev = lane_prev(t, 0.f); if (n == 0) tprev = 0.f;                         // :770 last_distance = 0
         const float dt = t - tprev;
         const float alpha = 1.f - __expf(-sigma * dt), om = 1.f - alpha;
-        const float tincl = scan_mul32(om, n);                                            // T after this sample
-        float T = __shfl_up(tincl, 1, 32); if (n == 0) T = 1.f;                           // T before this sample
+        const float tincl = scan_mul32(om);                                               // T after this sample
+        float T = lane_prev(tincl, 1.f); if (n == 0) T = 1.f;                             // T before this sample
         const bool active = T >= kTransmittanceEps;                                        // :774 early-out (T is non-increasing)
         const int nact = __popc((uint32_t)__ballot(active));                               // lanes 0..31 = the ray's samples
-        const float Tfin = __shfl(tincl, nact - 1, 64);                                    // broadcast from half-wave 0
+        const float Tfin = lane_bcast(tincl, nact - 1);                                    // broadcast from half-wave 0 (sample 0 is always active: nact >= 1)
         const float wgt = active ? alpha * T : 0.f;
-        const float p0 = scan_add32(wgt * c0, n), p1 = scan_add32(wgt * c1, n), p2 = scan_add32(wgt * c2, n), pd = scan_add32(wgt * t, n);
+        const float p0 = scan_add32(wgt * c0), p1 = scan_add32(wgt * c1), p2 = scan_add32(wgt * c2), pd = scan_add32(wgt * t);
         const float bg0 = rand01(a.oc.sample_seed, kStreamColor, iter, 3u * kth), bg1 = rand01(a.oc.sample_seed, kStreamColor, iter, 3u * kth + 1u), bg2 = rand01(a.oc.sample_seed, kStreamColor, iter, 3u * kth + 2u);   // :760, :438-441
-        const float rgb0 = __shfl(p0, 31, 64) + Tfin * bg0, rgb1 = __shfl(p1, 31, 64) + Tfin * bg1, rgb2 = __shfl(p2, 31, 64) + Tfin * bg2;
-        const float dep = __shfl(pd, 31, 64), mask = 1.f - Tfin;
+        const float rgb0 = lane_bcast(p0, 31) + Tfin * bg0, rgb1 = lane_bcast(p1, 31) + Tfin * bg1, rgb2 = lane_bcast(p2, 31) + Tfin * bg2;
+        const float dep = lane_bcast(pd, 31), mask = 1.f - Tfin;
         // ---- loss + dL/dO (VolumeRenderGradient_No_Compacted :853-953)
         const float tg0 = is_obj ? (float)(rgba & 0xffu) / 255.0f : bg0, tg1 = is_obj ? (float)((rgba >> 8) & 0xffu) / 255.0f : bg1, tg2 = is_obj ? (float)((rgba >> 16) & 0xffu) / 255.0f : bg2;
         const float e0 = rgb0 - tg0, e1 = rgb1 - tg1, e2 = rgb2 - tg2;
@@ -517,7 +533,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
             }
             bdo[3] = (half_t)(ls * dl);
         }
-        if (h == 0) {
+        if (h == 0 && do_dw) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) scr[S::SCR_DO + c * 32 + n] = bdo[c];
         }
@@ -840,17 +856,17 @@ __global__ void __launch_bounds__(256) k_fused_render(FusedArgs a, uint32_t n_ra
                 TileState<EPAD, W, NH> ts;
                 tile_forward<EPAD, W, NH>(ts, frags, a.lt, table, L, x, lane);
                 const float c0 = logistic_f(ts.out4[0]), c1 = logistic_f(ts.out4[1]), c2 = logistic_f(ts.out4[2]), sigma = __expf(ts.out4[3]);
-                float tprev = __shfl_up(t, 1, 32); if (n == 0) tprev = tlast;
+                float tprev = lane_prev(t, tlast); if (n == 0) tprev = tlast;
                 const float alpha = 1.f - __expf(-sigma * (t - tprev)), omv = 1.f - alpha;
-                const float tincl = scan_mul32(omv, n) * Tc;
-                float T = __shfl_up(tincl, 1, 32); if (n == 0) T = Tc;
+                const float tincl = scan_mul32(omv) * Tc;
+                float T = lane_prev(tincl, Tc); if (n == 0) T = Tc;
                 const bool active = T >= kTransmittanceEps;
                 const int nact = __popc((uint32_t)__ballot(active));
                 const float wgt = active ? alpha * T : 0.f;
-                r0 += __shfl(scan_add32(wgt * c0, n), 31, 64); r1 += __shfl(scan_add32(wgt * c1, n), 31, 64); r2 += __shfl(scan_add32(wgt * c2, n), 31, 64);
-                dep += __shfl(scan_add32(wgt * t, n), 31, 64);
-                Tc = (nact > 0) ? __shfl(tincl, nact - 1, 64) : Tc;      // all 64 lanes carry half-wave 0's state (uniform control flow)
-                tlast = __shfl(t, 31, 64);
+                r0 += lane_bcast(scan_add32(wgt * c0), 31); r1 += lane_bcast(scan_add32(wgt * c1), 31); r2 += lane_bcast(scan_add32(wgt * c2), 31);
+                dep += lane_bcast(scan_add32(wgt * t), 31);
+                Tc = (nact > 0) ? lane_bcast(tincl, nact > 0 ? nact - 1 : 0) : Tc;      // all 64 lanes carry half-wave 0's state (uniform control flow)
+                tlast = lane_bcast(t, 31);
             }
             if (1.f - Tc > 0.5f) { o0 = r0 + Tc; o1 = r1 + Tc; o2 = r2 + Tc; od = dep / a.b.ray_dn[ray]; om_ = 1.f; }      // :1213-1220
         }
@@ -865,7 +881,8 @@ bool fused_supported(const NetDims& nd, uint32_t S, uint32_t R) {
 
 uint32_t fused_train_grid(const NetDims&, uint32_t R) {
     const uint32_t want = (R + 3) / 4;            // one ray per wavefront when it fits
-    return want < 512u ? want : 512u;
+    static const uint32_t cap = std::getenv("MON_FUSED_GRID") ? (uint32_t)std::atoi(std::getenv("MON_FUSED_GRID")) : 512u;
+    return want < cap ? want : cap;
 }
 
 template <int EPAD, int W, int NH>
