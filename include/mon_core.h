@@ -211,6 +211,10 @@ int mon_microbench(int device, int mode, int pattern, uint32_t n_entries, uint32
  * of configuration cfg; *size = entries of that level.  No device needed. */
 int mon_debug_fast_index(const mon_config* cfg, int level, uint32_t x, uint32_t y, uint32_t z, uint32_t* index, uint32_t* size);
 /* MFMA fragment-layout self-test (tests only): D[32x32] = A[32x16] * B[16x32], fp16 in / fp32 out. */
+/* Layout of the MFMA A-fragment image of the fused kernels (ro-map_amd/csrc/frag_layout.h), both directions, for the layout test:
+ * source[n_image] = MLP parameter index held by each image element (-1 = structural zero); slots[2 * n_mlp] = the (<= 2) image elements
+ * each parameter feeds (-1 = none).  Either pointer may be NULL. */
+int mon_debug_frag_layout(int encoded_width_padded, int n_neurons, int n_hidden_layers, int n_levels, int* source, int* slots, int* n_image, int* n_mlp);
 int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
 
 #ifdef __cplusplus

@@ -135,6 +135,9 @@ class OracleModel:
     def train(self, iters):
         return self.L.orc_train(self.h, iters)
 
+    def advance_iter(self):
+        self.L.orc_advance_iter(self.h)
+
     def generate_batch(self):
         self.L.orc_generate_batch(self.h)
 

@@ -87,6 +87,7 @@ _SIGS = {
     "mon_online_object": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "mon_online_render_nerfs_test": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]),
     "mon_generate_toc": (C.c_int, [C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "mon_debug_frag_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mon_online_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mon_online_init": (C.c_int, [C.c_void_p]),
     "mon_online_dataset_init": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_size_t]),
@@ -196,7 +197,7 @@ class Dataset:
 # debug buffer ids (ro-map_amd/csrc/model.h MON_BUF_*): name -> (id, dtype, elements as f(R, B, info))
 BUF = dict(master=0, half=1, ema=2, m1=3, m2=4, steps=5, gmlp=6, ggrid_h=9, pts=10, tdist=11, E=12, Hid=13, O=14, dO=15, dHid=16, dE=17,
            rgb_ray=18, depth_ray=19, mask_ray=20, loss_ray=21, ray_o=22, ray_d=23, ray_t0=24, ray_t1=25, target=26, target_depth=27, bgcol=28,
-           ray_flag=29, ray_dn=31, mask=32, state=33)
+           ray_flag=29, ray_dn=31, mask=32, state=33, frag_train=34, frag_ref=35)
 
 
 class ObjectNeRF:
@@ -275,7 +276,7 @@ class ObjectNeRF:
                       dE=(np.uint16, B * Ep), rgb_ray=(np.float32, R * 3), depth_ray=(np.float32, R), mask_ray=(np.float32, R), loss_ray=(np.float32, R),
                       ray_o=(np.float32, R * 3), ray_d=(np.float32, R * 3), ray_t0=(np.float32, R), ray_t1=(np.float32, R), target=(np.float32, R * 3),
                       target_depth=(np.float32, R), bgcol=(np.float32, R * 3), ray_flag=(np.uint8, R), ray_dn=(np.float32, R), mask=(np.uint64, R // 64),
-                      state=(np.uint32, 8))
+                      state=(np.uint32, 8), frag_train=(np.uint16, 64 * 512), frag_ref=(np.uint16, 64 * 512))
         dt, cnt = shapes[name]; out = np.empty(cnt, dt)
         _check(lib().mon_object_debug_read(self.h, BUF[name], _p(out), out.nbytes)); return out
 
@@ -423,3 +424,11 @@ def marching_cubes(density, res3, thresh, aabb_min, aabb_max, device=0):
 
 def generate_toc(theta_deg, phi_deg, radius):
     T = np.empty(16, np.float32); _check(lib().mon_generate_toc(theta_deg, phi_deg, radius, _p(T))); return T
+
+
+def frag_layout(epad, W, NH, L):
+    """(source[n_image], slots[n_mlp, 2]) of the fused kernels' A-fragment image (frag_layout.h)."""
+    ni = C.c_int(0); nm = C.c_int(0)
+    _check(lib().mon_debug_frag_layout(epad, W, NH, L, None, None, C.byref(ni), C.byref(nm)))
+    src = np.empty(ni.value, np.int32); sl = np.empty((nm.value, 2), np.int32)
+    _check(lib().mon_debug_frag_layout(epad, W, NH, L, _p(src), _p(sl), C.byref(ni), C.byref(nm))); return src, sl

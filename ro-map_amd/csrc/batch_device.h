@@ -8,11 +8,10 @@ namespace mon {
 
 // One thread per candidate ray (GenerateRays, CORE/src/nerf_model.cu:369-446).  Candidate data is written un-compacted at
 // index i; the validity bit goes into mask[i/64] via a wave ballot (wave64: one 64-bit word per wavefront, no atomics).
-__device__ __forceinline__ void gen_candidate(const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* __restrict__ st, uint32_t i) {
+__device__ __forceinline__ void gen_candidate(const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, uint32_t nb, uint32_t iter, uint32_t i) {
     const uint32_t R = oc.R;
     bool ok = false;
     if (i < R) {
-        const uint32_t nb = st->n_boxes, iter = st->iter;
         const mon_frame_bbox box = b.boxes[i % nb];
         const float u0 = rand01(oc.sample_seed, kStreamXY, iter, 2u * i), u1 = rand01(oc.sample_seed, kStreamXY, iter, 2u * i + 1u);
         uint32_t x = box.x + (uint32_t)(u0 * (float)(int)box.w);          // :395

@@ -1,6 +1,7 @@
 // c_api.cpp -- extern "C" surface declared in include/mon_core.h.
 #include <cstring>
 #include "model.h"
+#include "frag_layout.h"
 
 namespace mon {
 void set_error(const char* fmt, ...);
@@ -86,7 +87,7 @@ int mon_object_set_backend(mon_object* o, int backend) {
     REQUIRE(o, "object");
     if (backend == 1 && !fused_supported(o->m->nd, o->m->oc.S, o->m->oc.R)) { set_error("fused backend does not support this network shape"); return MON_ERR_ARG; }
     if (backend != 0 && backend != 1) { set_error("backend must be 0 or 1"); return MON_ERR_ARG; }
-    o->m->backend = backend; return MON_OK;
+    o->m->backend = backend; o->m->next_ready = false; return MON_OK;
 }
 int mon_object_set_debug_dump(mon_object* o, int enable) { REQUIRE(o, "object"); o->m->fused_dump = enable != 0; o->m->graph_backend = -1; return MON_OK; }
 int mon_microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms) { REQUIRE(ms, "ms"); return microbench(device, mode, pattern, n_entries, n_ops, ms); }
@@ -107,6 +108,15 @@ int mon_debug_fast_index(const mon_config* cfg, int level, uint32_t x, uint32_t 
     if (level < 0 || level >= nd.L) { set_error("level out of range"); return MON_ERR_ARG; }
     LevelFast lf{}; level_fast_build(lt, nd, lf);
     *index = fast_grid_index(lf, level, x, y, z); *size = lf.size[level]; return MON_OK;
+}
+int mon_debug_frag_layout(int epad, int W, int NH, int L, int* source, int* slots, int* n_image, int* n_mlp) {
+    if (!(epad == 16 || epad == 32) || !(W == 32 || W == 64) || !(NH == 1 || NH == 2) || L < 1 || 2 * L > epad) { set_error("frag_layout: unsupported shape"); return MON_ERR_ARG; }
+    const FragDims d{ epad, W, NH, L };
+    if (n_image) *n_image = d.N_FRAGS() * 512;
+    if (n_mlp) *n_mlp = d.N_MLP();
+    if (source) for (int i = 0; i < d.N_FRAGS() * 512; ++i) source[i] = frag_source(d, i);
+    if (slots) for (int p = 0; p < d.N_MLP(); ++p) { int o[2] = { -1, -1 }; const int n = frag_slots(d, p, o); slots[2 * p] = n > 0 ? o[0] : -1; slots[2 * p + 1] = n > 1 ? o[1] : -1; }
+    return MON_OK;
 }
 int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D) { REQUIRE(A, "A"); REQUIRE(B, "B"); REQUIRE(D, "D"); return selftest_mfma(device, A, B, D); }
 

@@ -15,7 +15,7 @@ namespace mon {
 
 // One thread per candidate ray; body in batch_device.h.
 __global__ void __launch_bounds__(256) k_gen_candidates(BatchPtrs b, DatasetPtrs ds, ObjectConst oc, const DevState* __restrict__ st) {
-    gen_candidate(b, ds, oc, st, blockIdx.x * blockDim.x + threadIdx.x);
+    gen_candidate(b, ds, oc, st->n_boxes, st->iter, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // k-th set bit of a 64-bit word (k < popcount).

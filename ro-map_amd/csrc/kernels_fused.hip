@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include "device_common.h"
 #include "model.h"
+#include "frag_layout.h"
 #include "batch_device.h"
 
 namespace mon {
@@ -152,32 +153,8 @@ struct FusedArgs {
 // kernels copies into LDS with 16-byte loads (building them per workgroup cost ~28 dependent 2-byte loads per thread).
 template <int EPAD, int W, int NH>
 __device__ __forceinline__ half_t frag_element(const half_t* __restrict__ w, int L, int idx) {
-    using S = FusedShape<EPAD, W, NH>;
-    const int LPH = (L + 1) >> 1;
-    const int frag = idx >> 9, lane = (idx >> 3) & 63, j = idx & 7, m = lane & 31, h = lane >> 5;
-    half_t v = (half_t)0.f;
-    if (frag < S::F_W1) {                                   // W0: rows = units, K slots = encoded features of the owning half
-        const int mb = (frag - S::F_W0) / S::KS0, s = (frag - S::F_W0) % S::KS0;
-        const int il = 4 * s + (j >> 1), level = h * LPH + il;
-        if (il < LPH && level < L) v = w[(32 * mb + m) * EPAD + 2 * level + (j & 1)];
-    } else if (NH == 2 && frag < S::F_WO) {                 // W1: rows = units of layer 1, K slots = units of layer 0
-        const int mb = (frag - S::F_W1) / S::KSW, s = (frag - S::F_W1) % S::KSW;
-        v = w[S::OFF_W1 + (32 * mb + m) * W + unit_of_slot(s, h, j)];
-    } else if (frag < S::F_WOT) {                           // Wout: 4 real rows of 32
-        const int s = frag - S::F_WO;
-        if (m < kOut) v = w[S::OFF_WO + m * W + unit_of_slot(s, h, j)];
-    } else if (frag < S::F_W1T) {                           // Wout^T: rows = units, K slots 0..3 = output channels
-        const int mb = frag - S::F_WOT, c = 8 * h + j;
-        if (c < kOut) v = w[S::OFF_WO + c * W + 32 * mb + m];
-    } else if (NH == 2 && frag < S::F_W0T) {                // W1^T: rows = units of layer 0, K slots = units of layer 1
-        const int mb = (frag - S::F_W1T) / S::KSW, s = (frag - S::F_W1T) % S::KSW;
-        v = w[S::OFF_W1 + unit_of_slot(s, h, j) * W + 32 * mb + m];
-    } else {                                                // W0^T: row m = (half hh, reg r) <-> local feature r of half hh
-        const int s = frag - S::F_W0T;
-        const int hh = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3), il = r >> 1, level = hh * LPH + il;
-        if (il < LPH && level < L && r < EPAD / 2) v = w[unit_of_slot(s, h, j) * EPAD + 2 * level + (r & 1)];
-    }
-    return v;
+    const int p = frag_source(FragDims{ EPAD, W, NH, L }, idx);      // frag_layout.h: the one table both directions come from
+    return p < 0 ? (half_t)0.f : w[p];
 }
 
 template <int EPAD, int W, int NH>
@@ -194,7 +171,7 @@ template <int EPAD, int W, int NH>
 __global__ void __launch_bounds__(256) k_candidates_and_frags(BatchPtrs b, DatasetPtrs ds, ObjectConst oc, const DevState* __restrict__ st, uint32_t cand_blocks,
                                                               const uint16_t* __restrict__ params, int L, uint16_t* __restrict__ image) {
     using S = FusedShape<EPAD, W, NH>;
-    if (blockIdx.x < cand_blocks) { gen_candidate(b, ds, oc, st, blockIdx.x * blockDim.x + threadIdx.x); return; }
+    if (blockIdx.x < cand_blocks) { gen_candidate(b, ds, oc, st->n_boxes, st->iter, blockIdx.x * blockDim.x + threadIdx.x); return; }
     const int idx = (blockIdx.x - cand_blocks) * blockDim.x + threadIdx.x;
     if (idx < S::N_FRAGS * 512) reinterpret_cast<half_t*>(image)[idx] = frag_element<EPAD, W, NH>(reinterpret_cast<const half_t*>(params), L, idx);
 }
@@ -939,6 +916,13 @@ void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, c
     const uint32_t grid = fused_train_grid(nd, oc.R);
     MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);
 }
+template <int EPAD, int W, int NH>
+static void build_frag_image_t(hipStream_t s, const uint16_t* params, const NetDims& nd, uint16_t* image) {
+    using S = FusedShape<EPAD, W, NH>;
+    hipLaunchKernelGGL((k_build_frag_image<EPAD, W, NH>), dim3((S::N_FRAGS * 512 + 255) / 256), dim3(256), 0, s, params, nd.L, image, (const DevState*)nullptr);
+}
+void launch_build_frag_image(hipStream_t s, const uint16_t* params, const NetDims& nd, uint16_t* image) { MON_FUSED_DISPATCH(build_frag_image_t, s, params, nd, image); }
+
 void launch_candidates_and_frags(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st, const uint16_t* params, const NetDims& nd, uint16_t* frag_image) {
     MON_FUSED_DISPATCH(candidates_frags_t, s, b, ds, oc, st, params, nd, frag_image);
 }

@@ -7,8 +7,14 @@
 // Untouched grid chunks cost 64 B per 8 parameters (fp16 grad, weight, EMA read + EMA write).
 // The last block to finish advances the device-resident step / iteration counters and applies the
 // exponential LR decay, so a whole training run needs no host synchronisation.
+// Fused backend: the same launch also prepares the NEXT iteration -- the blocks that update the MLP matrices write the new
+// fp16 weights straight into the MFMA A-fragment image (frag_layout.h), and `cand_blocks` extra blocks generate the next
+// iteration's candidate rays (they depend on the iteration counter and the dataset only), so the steady-state loop is
+// k_fused_train -> k_grid_scatter -> k_reduce_partials -> k_optimizer with no batch-generation launch.
 #include "device_common.h"
 #include "model.h"
+#include "frag_layout.h"
+#include "batch_device.h"
 
 namespace mon {
 
@@ -23,8 +29,11 @@ __device__ __forceinline__ float adam_update(float g, float w, float& m1, float&
     return w - eff * m1;
 }
 
-__global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, DevState* __restrict__ st) {
+__global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, DevState* __restrict__ st, OptimNext nx) {
     const uint32_t n_valid = st->n_valid, step = st->step;
+    const bool cand_block = blockIdx.x < nx.cand_blocks;            // GenerateRays of iteration iter + 1 (every block reads the state before its ticket)
+    if (cand_block) gen_candidate(nx.b, nx.ds, nx.oc, st->n_boxes, st->iter + 1u, blockIdx.x * blockDim.x + threadIdx.x);
+    const uint32_t bid = blockIdx.x - nx.cand_blocks, nblk = gridDim.x - nx.cand_blocks;
     const float lr0 = st->lr;
     // EMA debias factors from the global step after increment (ema_step_half_precision); wave-uniform scalars
     const uint32_t cur = step + 1u;
@@ -36,9 +45,9 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
     }
     __syncthreads();
     const float deb_old = s_deb[0], deb_new = s_deb[1];
-    if (n_valid != 0u) {
+    if (n_valid != 0u && !cand_block) {
         const uint32_t n_chunks = oc.n_params >> 3;
-        for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += gridDim.x * blockDim.x) {
+        for (uint32_t c = bid * blockDim.x + threadIdx.x; c < n_chunks; c += nblk * blockDim.x) {
             const uint32_t i0 = c << 3;
             const bool is_matrix = i0 < oc.n_mlp;                     // n_mlp is a multiple of 8: uniform per chunk
             float g[8]; bool any = false;
@@ -106,6 +115,10 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                 *reinterpret_cast<float4_t*>(p.m2 + i0) = float4_t{ m2[0], m2[1], m2[2], m2[3] }; *reinterpret_cast<float4_t*>(p.m2 + i0 + 4) = float4_t{ m2[4], m2[5], m2[6], m2[7] };
                 *reinterpret_cast<uint4*>(p.steps + i0) = make_uint4(sc[0], sc[1], sc[2], sc[3]); *reinterpret_cast<uint4*>(p.steps + i0 + 4) = make_uint4(sc[4], sc[5], sc[6], sc[7]);
                 *reinterpret_cast<half8_t*>(p.half + i0) = wh;
+                if (is_matrix && nx.frag_image) {                                     // next iteration's A fragments
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { int sl[2]; const int ns = frag_slots(nx.fd, (int)(i0 + j), sl); for (int q = 0; q < ns; ++q) reinterpret_cast<half_t*>(nx.frag_image)[sl[q]] = wh[j]; }
+                }
             }
             half8_t* ep = reinterpret_cast<half8_t*>(p.ema + i0);
             half8_t e = *ep;
@@ -159,10 +172,10 @@ void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_par
     hipLaunchKernelGGL(k_reduce_partials, dim3((n_mlp + 1 + 15) / 16), dim3(256), 0, s, partials, n_partials, stride, n_mlp, gmlp, st);
 }
 
-void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st) {
+void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx) {
     const uint32_t chunks = oc.n_params >> 3;
     uint32_t blocks = (chunks + 255) / 256; if (blocks > 1024u) blocks = 1024u; if (blocks < 1u) blocks = 1u;     // one chunk per thread up to 4 M parameters
-    hipLaunchKernelGGL(k_optimizer, dim3(blocks), dim3(256), 0, s, p, oc, st);
+    hipLaunchKernelGGL(k_optimizer, dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx);
 }
 
 }  // namespace mon

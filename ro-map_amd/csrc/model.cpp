@@ -186,6 +186,7 @@ int model_add_boxes(Model& m, const mon_frame_bbox* boxes, size_t n) {
     HIPCHECK(hipMemcpy(m.d_boxes + m.n_boxes, boxes, sizeof(mon_frame_bbox) * n, hipMemcpyHostToDevice));   // nerf_model.cu:1625
     m.n_boxes += (uint32_t)n;
     HIPCHECK(hipMemcpy(&m.d_state->n_boxes, &m.n_boxes, 4, hipMemcpyHostToDevice));
+    m.next_ready = false;                                   // candidates pre-generated for the next iteration used the old box list
     return MON_OK;
 }
 
@@ -213,7 +214,7 @@ static void enqueue_iteration(Model& m, int stages) {
     hipStream_t s = m.train_stream; const uint32_t B = m.oc.R * m.oc.S;
     if (stages & 1) {      // GenerateBatch :1429-1502
         ProfScope ps(m, MON_K_BATCH);
-        if (m.backend == 1) launch_candidates_and_frags(s, m.B, m.ds->ptrs(), m.oc, m.d_state, m.P.half, m.nd, m.d_frag_train);
+        if (m.backend == 1) { if (!m.next_ready) launch_candidates_and_frags(s, m.B, m.ds->ptrs(), m.oc, m.d_state, m.P.half, m.nd, m.d_frag_train); }   // otherwise the last k_optimizer already did both
         else launch_gen_candidates(s, m.B, m.ds->ptrs(), m.oc, m.d_state);
         if (m.backend == 0) {                       // the fused kernel compacts the rays itself
             launch_build_rays(s, m.B, m.oc, m.d_state);
@@ -241,7 +242,14 @@ static void enqueue_iteration(Model& m, int stages) {
         ProfScope ps(m, MON_K_OPTIM);
         ParamPtrs P = m.P;
         if (m.backend == 1 && m.lds_mask) { P.gpart = m.d_gpart; P.part_stride = m.n_grid; P.sl = m.scatter; }
-        launch_optimizer(s, P, m.opt, m.d_state);
+        OptimNext nx{};
+        static const bool fold = !(std::getenv("MON_FOLD_NEXT") && std::atoi(std::getenv("MON_FOLD_NEXT")) == 0);
+        if (m.backend == 1 && fold) {
+            nx.cand_blocks = (m.oc.R + 255) / 256; nx.frag_image = m.d_frag_train; nx.fd = FragDims{ m.nd.Epad, m.nd.W, m.nd.NH, m.nd.L };
+            nx.b = m.B; nx.ds = m.ds->ptrs(); nx.oc = m.oc;
+        }
+        launch_optimizer(s, P, m.opt, m.d_state, nx);
+        m.next_ready = (m.backend == 1 && fold);
     }
 }
 
@@ -263,6 +271,7 @@ int model_train(Model& m, int iters, float* loss, int stages) {
             drop_graph(m);
             hipGraph_t g = nullptr;
             HIPCHECK(hipStreamBeginCapture(m.train_stream, hipStreamCaptureModeThreadLocal));
+            m.next_ready = false;                           // the captured iteration is self-contained
             enqueue_iteration(m, 7);
             HIPCHECK(hipStreamEndCapture(m.train_stream, &g));
             HIPCHECK(hipGraphInstantiate(&m.graph_exec, g, nullptr, nullptr, 0));
@@ -349,6 +358,7 @@ int model_set_params(Model& m, const float* master, size_t n) {
     for (size_t i = 0; i < n; ++i) { const _Float16 h = (_Float16)master[i]; std::memcpy(&half[i], &h, 2); }
     HIPCHECK(hipMemcpy(m.P.master, master, n * 4, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(m.P.half, half.data(), n * 2, hipMemcpyHostToDevice));
+    m.next_ready = false;                                   // the fragment image no longer matches the weights
     return MON_OK;
 }
 
@@ -373,6 +383,11 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
         case MON_BUF_BGCOL: src = m.B.bgcol; sz = R * 12; break;        case MON_BUF_RAY_FLAG: src = m.B.ray_flag; sz = R; break;
         case MON_BUF_RAY_DN: src = m.B.ray_dn; sz = R * 4; break;       case MON_BUF_MASK: src = m.B.mask; sz = (R / 64) * 8; break;
         case MON_BUF_STATE: src = m.d_state; sz = sizeof(DevState); break;
+        case MON_BUF_FRAG_TRAIN: src = m.d_frag_train; sz = 64 * 512 * 2; break;
+        case MON_BUF_FRAG_REF:
+            if (!m.d_frag_render) { set_error("debug_read: fused backend not available"); return MON_ERR_STATE; }
+            HIPCHECK(hipSetDevice(m.device)); HIPCHECK(hipMemsetAsync(m.d_frag_render, 0, 64 * 512 * 2, m.train_stream));
+            launch_build_frag_image(m.train_stream, m.P.half, m.nd, m.d_frag_render); src = m.d_frag_render; sz = 64 * 512 * 2; break;
         default: set_error("debug_read: unknown buffer id %d", which); return MON_ERR_ARG;
     }
     if (!dst || bytes < sz) { set_error("debug_read: buffer too small (%zu < %zu)", bytes, sz); return MON_ERR_ARG; }

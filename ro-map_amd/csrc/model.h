@@ -7,6 +7,7 @@
 #include <vector>
 #include "../../include/mon_core.h"
 #include "device_common.h"
+#include "frag_layout.h"
 
 namespace mon {
 
@@ -68,6 +69,9 @@ struct OptimConst {
     uint32_t n_mlp, n_params;
 };
 
+// What k_optimizer prepares for the next iteration of the fused backend (all zero = nothing): candidate rays and the A-fragment image.
+struct OptimNext { uint32_t cand_blocks; uint16_t* frag_image; FragDims fd; BatchPtrs b; DatasetPtrs ds; ObjectConst oc; };
+
 // debug buffer ids for mon_object_debug_read (stable numbering, see binding.py BUF)
 enum {
     MON_BUF_MASTER = 0, MON_BUF_HALF = 1, MON_BUF_EMA = 2, MON_BUF_M1 = 3, MON_BUF_M2 = 4, MON_BUF_STEPS = 5,
@@ -75,7 +79,9 @@ enum {
     MON_BUF_O = 14, MON_BUF_DO = 15, MON_BUF_DHID = 16, MON_BUF_DE = 17, MON_BUF_RGB_RAY = 18, MON_BUF_DEPTH_RAY = 19,
     MON_BUF_MASK_RAY = 20, MON_BUF_LOSS_RAY = 21, MON_BUF_RAY_O = 22, MON_BUF_RAY_D = 23, MON_BUF_RAY_T0 = 24,
     MON_BUF_RAY_T1 = 25, MON_BUF_TARGET = 26, MON_BUF_TARGET_DEPTH = 27, MON_BUF_BGCOL = 28, MON_BUF_RAY_FLAG = 29,
-    MON_BUF_RAY_DN = 31, MON_BUF_MASK = 32, MON_BUF_STATE = 33
+    MON_BUF_RAY_DN = 31, MON_BUF_MASK = 32, MON_BUF_STATE = 33,
+    MON_BUF_FRAG_TRAIN = 34,    // the A-fragment image the next fused iteration will use (64 x 512 halves)
+    MON_BUF_FRAG_REF = 35       // the same image rebuilt from the current fp16 weights by k_build_frag_image (layout test)
 };
 
 // ---- kernel launchers (kernels_*.hip)
@@ -98,7 +104,7 @@ void launch_composite_render(hipStream_t s, const BatchPtrs& b, uint32_t S, uint
 void launch_extract_density(hipStream_t s, const uint16_t* O, float* out, uint32_t n);
 
 // optimizer (kernels_optim.hip)
-void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st);
+void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx);
 void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_partials, uint32_t stride, uint32_t n_mlp, float* gmlp, DevState* st);
 
 // fused MFMA path (kernels_fused.hip)
@@ -110,6 +116,7 @@ uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl
 uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd);
 void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, const DevState* st);
 void launch_fused_render(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask, uint16_t* frag_image);
+void launch_build_frag_image(hipStream_t s, const uint16_t* params, const NetDims& nd, uint16_t* image);
 void launch_candidates_and_frags(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st, const uint16_t* params, const NetDims& nd, uint16_t* frag_image);
 int selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
 
@@ -134,6 +141,7 @@ struct Model {
     float* d_dw_partials = nullptr; uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr; uint16_t* d_gpart = nullptr; uint16_t* d_frag_train = nullptr; uint16_t* d_frag_render = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0; float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr;
     std::vector<void*> allocs;
     DevState h_state{}; int backend = 0; bool profiling = false; int fused_dump = 0;
+    bool next_ready = false;     // fused backend: candidates + fragment image of the coming iteration were already produced by the last k_optimizer
     mon_profile prof{}; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pending;
     hipGraphExec_t graph_exec = nullptr; int graph_backend = -1;
 };

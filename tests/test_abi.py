@@ -1,5 +1,6 @@
 """CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/mon_core.h
 declares, parses the reference's config schema, and fails loudly (no CPU fallback) without a device."""
+import numpy as np
 import ctypes
 import os
 import re
@@ -97,3 +98,25 @@ def test_closed_form_corner_index_matches_tcnn_loop(pkg, orc):
             for (x, y, z) in pts:
                 got, n = pkg.fast_index(cfg, l, x, y, z)
                 assert n == size and got == orc.lib().orc_grid_index(size, r, x, y, z), (kw, l, r, size, x, y, z)
+
+
+@pytest.mark.parametrize("shape", [(32, 64, 1, 16), (16, 32, 2, 4), (32, 64, 2, 13), (16, 64, 1, 7), (32, 32, 2, 16)])
+def test_fragment_layout_maps_are_inverse(pkg, shape):
+    """frag_layout.h: every image element names the parameter whose slot list contains it, and the other way round
+    (the optimizer writes the image through frag_slots, k_build_frag_image reads through frag_source)."""
+    epad, W, NH, L = shape
+    src, slots = pkg.frag_layout(epad, W, NH, L)
+    used = np.nonzero(src >= 0)[0]
+    assert used.size > 0 and src.max() < slots.shape[0]
+    hit = (slots[src[used], 0] == used) | (slots[src[used], 1] == used)
+    assert hit.all()
+    ps = np.repeat(np.arange(slots.shape[0]), 2); flat = slots.reshape(-1); ok = flat >= 0
+    assert (src[flat[ok]] == ps[ok]).all()
+    assert np.unique(flat[ok]).size == ok.sum() == used.size           # a bijection between used image elements and slots
+    # every real weight is present: W0 columns of real features, W1, the 4 real output rows
+    real = np.zeros(slots.shape[0], bool)
+    real[: W * epad] = (np.arange(W * epad) % epad) < 2 * L
+    if NH == 2:
+        real[W * epad: W * epad + W * W] = True
+    off_wo = W * epad + (NH - 1) * W * W; real[off_wo: off_wo + 4 * W] = True
+    assert ((slots[:, 0] >= 0) == real).all() and ((slots[:, 1] >= 0) == real).all()

@@ -241,3 +241,29 @@ def test_edge_cases(pkg, ss, small_scene):
     o4.train_stages(1 | 2)
     assert int(o4.buffer("state")[2]) > 0
     o4.close(); ds2.close(); ds.close()
+
+
+@pytest.mark.parametrize("kw", [C1, C2, dict(rays_per_batch=512, n_levels=13, n_neurons=64, n_hidden_layers=2)], ids=["c1", "c2", "l13w64x2"])
+def test_optimizer_prepares_the_next_iteration(pkg, orc, small_scene, kw):
+    """Fused backend: k_optimizer writes the MFMA fragment image while it updates the weights and generates the next iteration's
+    candidate rays; both must equal what the stand-alone kernels produce (image from the new weights, GenerateRays of iter + 1)."""
+    ds, obj, ref = _pair(pkg, orc, small_scene, kw, 1)
+    obj.set_debug_dump(False)
+    obj.train(3)
+    assert np.array_equal(obj.buffer("frag_train"), obj.buffer("frag_ref"))          # image == rebuilt from the current fp16 weights
+    pre = {b: obj.buffer(b).copy() for b in ("mask",)}
+    it = int(obj.buffer("state")[1])
+    ref.set_params(obj.get_params(0))
+    for _ in range(it):
+        ref.advance_iter()
+    ref.generate_batch()
+    nv = int(sum(bin(int(w)).count("1") for w in pre["mask"]))
+    assert nv == ref.n_valid and nv > 0                                               # candidates of iteration `it` already sit in the buffers
+    obj.train_stages(1)                                                               # a no-op now: nothing to regenerate
+    assert np.array_equal(obj.buffer("mask"), pre["mask"])
+    obj.add_boxes(small_scene.objects[0]["boxes"][:2]); ref.add_boxes(small_scene.objects[0]["boxes"][:2])   # invalidates the pre-generated batch
+    obj.train_stages(1); ref.generate_batch()
+    assert int(sum(bin(int(w)).count("1") for w in obj.buffer("mask"))) == ref.n_valid
+    l0 = obj.train(5); assert np.isfinite(l0)
+    assert np.array_equal(obj.buffer("frag_train"), obj.buffer("frag_ref"))
+    obj.close(); ds.close(); ref.close()
