@@ -748,10 +748,40 @@ __device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restr
     }
 }
 
+// The weight-gradient partial rows of k_fused_train (one per workgroup) are summed here as well: every scatter workgroup
+// takes a few float4 column groups before it touches its tile (128 row subsets x 8 groups per pass, LDS tree), so the
+// latency-bound stand-alone reduction kernel disappears from the critical path (k_reduce_partials remains for networks
+// whose levels all go through global atomics).
+struct PartialsArgs { const float* partials; uint32_t n_partials, stride, n_mlp; float* gmlp; DevState* st; };
+
+__device__ __forceinline__ void reduce_partials_slice(const PartialsArgs& pa, float* red) {
+    // thread = (column group gs of 8, row subset sub of 128); the 64 subsets of a wave are summed with DPP, the two waves of a group through LDS
+    const uint32_t n4 = (pa.n_mlp + 1u + 3u) / 4u, gs = threadIdx.x >> 7, sub = threadIdx.x & 127u, wave = threadIdx.x >> 6;
+    for (uint32_t g0 = blockIdx.x * 8u; g0 < n4; g0 += gridDim.x * 8u) {
+        const uint32_t g = g0 + gs; float4_t acc = { 0.f, 0.f, 0.f, 0.f };
+        if (g < n4) for (uint32_t k = sub; k < pa.n_partials; k += 128u) acc += *reinterpret_cast<const float4_t*>(pa.partials + (size_t)k * pa.stride + 4u * g);   // rows are padded to n_mlp + 64 floats
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = acc[c];
+            v += dpp_f<0x111, 0xF>(0.f, v); v += dpp_f<0x112, 0xF>(0.f, v); v += dpp_f<0x114, 0xF>(0.f, v); v += dpp_f<0x118, 0xF>(0.f, v);
+            v += dpp_f<0x142, 0xA>(0.f, v); v += dpp_f<0x143, 0xC>(0.f, v);
+            if ((threadIdx.x & 63u) == 63u) red[wave * 4u + (uint32_t)c] = v;               // lane 63 holds the wave total
+        }
+        __syncthreads();
+        if (threadIdx.x < 32u) {
+            const uint32_t gg = g0 + (threadIdx.x >> 2), c = threadIdx.x & 3u, pi = 4u * gg + c;
+            const float v = red[(2u * (threadIdx.x >> 2)) * 4u + c] + red[(2u * (threadIdx.x >> 2) + 1u) * 4u + c];
+            if (gg < n4) { if (pi < pa.n_mlp) pa.gmlp[pi] = v; else if (pi == pa.n_mlp) pa.st->loss_sum = v; }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLevels sl, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa,
-                                                       uint32_t B, half2_t* __restrict__ gpart, uint32_t part_stride, const DevState* __restrict__ st) {
+                                                       uint32_t B, half2_t* __restrict__ gpart, uint32_t part_stride, const DevState* __restrict__ st, PartialsArgs pa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (st->n_valid == 0u) return;
+    if (pa.partials) reduce_partials_slice(pa, reinterpret_cast<float*>(smem));
     int* tab = reinterpret_cast<int*>(smem);
     const uint32_t slot = blockIdx.x / kScatterWgPerLevel, j = blockIdx.x - slot * kScatterWgPerLevel;
     const int level = sl.level[slot]; const uint32_t P = sl.P[level];
@@ -795,12 +825,14 @@ uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl
 }
 uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd) { ScatterLevels sl; return scatter_plan(lt, nd, sl); }
 
-void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, const DevState* st) {
+void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
+                         const float* partials, uint32_t n_partials, float* gmlp) {
     ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return;
+    const PartialsArgs pa{ partials, n_partials, nd.n_mlp + 64u, nd.n_mlp, gmlp, st };
     static bool attr_done = false;
     if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, kScatterTile * 8); attr_done = true; }
     hipLaunchKernelGGL(k_grid_scatter, dim3(sl.n_levels * kScatterWgPerLevel), dim3(1024), kScatterTile * 8, s, lf, sl, reinterpret_cast<const half2_t*>(de_soa), x_soa, B,
-                       reinterpret_cast<half2_t*>(gpart), part_stride_entries, st);
+                       reinterpret_cast<half2_t*>(gpart), part_stride_entries, st, pa);
 }
 
 // ------------------------------------------------------------------ fused render kernel

@@ -235,8 +235,11 @@ static void enqueue_iteration(Model& m, int stages) {
         }
     }
     if ((stages & 2) && m.backend == 1) {
-        if (m.lds_mask) { ProfScope ps(m, MON_K_SCATTER); launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.d_gpart, m.n_grid / 2, m.d_state); }
-        { ProfScope ps(m, MON_K_REDUCE); launch_reduce_partials(s, m.d_dw_partials, fused_train_grid(m.nd, m.oc.R), m.nd.n_mlp + 64, m.nd.n_mlp, m.P.gmlp, m.d_state); }
+        static const bool fold_reduce = !(std::getenv("MON_FOLD_REDUCE") && std::atoi(std::getenv("MON_FOLD_REDUCE")) == 0);
+        const bool folded = m.lds_mask && fold_reduce;                 // the scatter workgroups also sum the dW partial rows
+        if (m.lds_mask) { ProfScope ps(m, MON_K_SCATTER); launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.d_gpart, m.n_grid / 2, m.d_state,
+                                                                                folded ? m.d_dw_partials : nullptr, fused_train_grid(m.nd, m.oc.R), m.P.gmlp); }
+        if (!folded) { ProfScope ps(m, MON_K_REDUCE); launch_reduce_partials(s, m.d_dw_partials, fused_train_grid(m.nd, m.oc.R), m.nd.n_mlp + 64, m.nd.n_mlp, m.P.gmlp, m.d_state); }
     }
     if (stages & 4) {      // Trainer::optimizer_step :1644
         ProfScope ps(m, MON_K_OPTIM);
