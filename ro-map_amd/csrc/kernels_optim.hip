@@ -29,28 +29,34 @@ __device__ __forceinline__ float adam_update(float g, float w, float& m1, float&
     return w - eff * m1;
 }
 
+template <bool DENSE>
 __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, DevState* __restrict__ st, OptimNext nx) {
     const uint32_t n_valid = st->n_valid, step = st->step;
     const bool cand_block = blockIdx.x < nx.cand_blocks;            // GenerateRays of iteration iter + 1 (every block reads the state before its ticket)
     if (cand_block) gen_candidate(nx.b, nx.ds, nx.oc, st->n_boxes, st->iter + 1u, blockIdx.x * blockDim.x + threadIdx.x);
     const uint32_t bid = blockIdx.x - nx.cand_blocks, nblk = gridDim.x - nx.cand_blocks;
     const float lr0 = st->lr;
-    // EMA debias factors from the global step after increment (ema_step_half_precision); wave-uniform scalars
+    // EMA debias factors of this step (ema_step_half_precision; double-precision pow like tcnn's host code): computed by the
+    // last block of the previous step, so no block waits for a software pow before it can issue its loads
     const uint32_t cur = step + 1u;
     const float d = oc.ema_decay;
-    __shared__ float s_deb[2];
-    if (threadIdx.x == 0) {                  // double-precision pow once per block, as tcnn does on the host
-        s_deb[0] = 1.f - (float)pow((double)d, (double)(cur - 1u));
-        s_deb[1] = 1.f / (1.f - (float)pow((double)d, (double)cur));
-    }
-    __syncthreads();
-    const float deb_old = s_deb[0], deb_new = s_deb[1];
+    const float deb_old = st->ema_deb_old, deb_new = st->ema_deb_new;
     if (n_valid != 0u && !cand_block) {
         const uint32_t n_chunks = oc.n_params >> 3;
         for (uint32_t c = bid * blockDim.x + threadIdx.x; c < n_chunks; c += nblk * blockDim.x) {
             const uint32_t i0 = c << 3;
             const bool is_matrix = i0 < oc.n_mlp;                     // n_mlp is a multiple of 8: uniform per chunk
             float g[8]; bool any = false;
+            // DENSE (small tables: practically every entry has a gradient each step): the optimizer state is requested together
+            // with the gradients -- one memory round trip instead of two; sparse tables keep the state loads behind the test.
+            float4_t w0, w1, a0, a1, b0, b1; uint4 s0, s1;
+            if (DENSE) {
+                w0 = *reinterpret_cast<const float4_t*>(p.master + i0); w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
+                a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0); a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
+                b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
+                s0 = *reinterpret_cast<const uint4*>(p.steps + i0); s1 = *reinterpret_cast<const uint4*>(p.steps + i0 + 4);
+            }
+            const half8_t ema_in = *reinterpret_cast<const half8_t*>(p.ema + i0);
             if (is_matrix) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -60,15 +66,19 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                 }
                 any = true;
             } else {
-                half8_t* gp = reinterpret_cast<half8_t*>(p.ggrid + (i0 - oc.n_mlp));
-                const half8_t gh = *gp;
-                bool anyg = false;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { g[j] = (float)gh[j]; anyg |= (float)gh[j] != 0.f; }
-                if (anyg) { half8_t z;
+                for (int j = 0; j < 8; ++j) g[j] = 0.f;
+                if (!DENSE) {                                            // the global-atomic table (levels too large for an LDS tile); never written when DENSE
+                    half8_t* gp = reinterpret_cast<half8_t*>(p.ggrid + (i0 - oc.n_mlp));
+                    const half8_t gh = *gp;
+                    bool anyg = false;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) z[j] = (half_t)0.f;
-                    *gp = z; }
+                    for (int j = 0; j < 8; ++j) { g[j] = (float)gh[j]; anyg |= (float)gh[j] != 0.f; }
+                    if (anyg) { half8_t z;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) z[j] = (half_t)0.f;
+                        *gp = z; }
+                }
                 uint32_t n_part = 0;
                 if (p.gpart) {                                       // which level is this chunk in -> how many partial tables it has
                     const uint32_t e0 = (i0 - oc.n_mlp) >> 1; int lvl = 0;
@@ -94,10 +104,12 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
             }
             half8_t wh = *reinterpret_cast<const half8_t*>(p.half + i0);
             if (any) {
-                float4_t w0 = *reinterpret_cast<const float4_t*>(p.master + i0), w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
-                float4_t a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0), a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
-                float4_t b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0), b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
-                uint4 s0 = *reinterpret_cast<const uint4*>(p.steps + i0), s1 = *reinterpret_cast<const uint4*>(p.steps + i0 + 4);
+                if (!DENSE) {
+                    w0 = *reinterpret_cast<const float4_t*>(p.master + i0); w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
+                    a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0); a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
+                    b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
+                    s0 = *reinterpret_cast<const uint4*>(p.steps + i0); s1 = *reinterpret_cast<const uint4*>(p.steps + i0 + 4);
+                }
                 float w[8] = { w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3] };
                 float m1[8] = { a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3] };
                 float m2[8] = { b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3] };
@@ -110,10 +122,12 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                     w[j] = adam_update(gj, w[j], m1[j], m2[j], sc[j], lr0, oc);
                     wh[j] = (half_t)w[j];
                 }
-                *reinterpret_cast<float4_t*>(p.master + i0) = float4_t{ w[0], w[1], w[2], w[3] }; *reinterpret_cast<float4_t*>(p.master + i0 + 4) = float4_t{ w[4], w[5], w[6], w[7] };
-                *reinterpret_cast<float4_t*>(p.m1 + i0) = float4_t{ m1[0], m1[1], m1[2], m1[3] }; *reinterpret_cast<float4_t*>(p.m1 + i0 + 4) = float4_t{ m1[4], m1[5], m1[6], m1[7] };
-                *reinterpret_cast<float4_t*>(p.m2 + i0) = float4_t{ m2[0], m2[1], m2[2], m2[3] }; *reinterpret_cast<float4_t*>(p.m2 + i0 + 4) = float4_t{ m2[4], m2[5], m2[6], m2[7] };
-                *reinterpret_cast<uint4*>(p.steps + i0) = make_uint4(sc[0], sc[1], sc[2], sc[3]); *reinterpret_cast<uint4*>(p.steps + i0 + 4) = make_uint4(sc[4], sc[5], sc[6], sc[7]);
+                // optimizer state is not touched again before the next step: stream it past the caches
+                __builtin_nontemporal_store(float4_t{ w[0], w[1], w[2], w[3] }, reinterpret_cast<float4_t*>(p.master + i0)); __builtin_nontemporal_store(float4_t{ w[4], w[5], w[6], w[7] }, reinterpret_cast<float4_t*>(p.master + i0 + 4));
+                __builtin_nontemporal_store(float4_t{ m1[0], m1[1], m1[2], m1[3] }, reinterpret_cast<float4_t*>(p.m1 + i0)); __builtin_nontemporal_store(float4_t{ m1[4], m1[5], m1[6], m1[7] }, reinterpret_cast<float4_t*>(p.m1 + i0 + 4));
+                __builtin_nontemporal_store(float4_t{ m2[0], m2[1], m2[2], m2[3] }, reinterpret_cast<float4_t*>(p.m2 + i0)); __builtin_nontemporal_store(float4_t{ m2[4], m2[5], m2[6], m2[7] }, reinterpret_cast<float4_t*>(p.m2 + i0 + 4));
+                typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(u4v{ sc[0], sc[1], sc[2], sc[3] }, reinterpret_cast<u4v*>(p.steps + i0)); __builtin_nontemporal_store(u4v{ sc[4], sc[5], sc[6], sc[7] }, reinterpret_cast<u4v*>(p.steps + i0 + 4));
                 *reinterpret_cast<half8_t*>(p.half + i0) = wh;
                 if (is_matrix && nx.frag_image) {                                     // next iteration's A fragments
 #pragma unroll
@@ -121,7 +135,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                 }
             }
             half8_t* ep = reinterpret_cast<half8_t*>(p.ema + i0);
-            half8_t e = *ep;
+            half8_t e = ema_in;
 #pragma unroll
             for (int j = 0; j < 8; ++j) e[j] = (half_t)((((float)e[j] * d) * deb_old + (float)wh[j] * (1.f - d)) * deb_new);
             *ep = e;
@@ -137,6 +151,8 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
             st->iter = st->iter + 1u;
             if (n_valid != 0u) {
                 st->step = cur;
+                st->ema_deb_old = 1.f - (float)pow((double)d, (double)cur);              // factors of step cur + 1
+                st->ema_deb_new = 1.f / (1.f - (float)pow((double)d, (double)(cur + 1u)));
                 if ((int)cur >= oc.decay_start && oc.decay_interval > 0 && ((int)cur - oc.decay_start) % oc.decay_interval == 0) st->lr = lr0 * oc.decay_base;
             } else {
                 st->skipped = st->skipped + 1u;
@@ -175,7 +191,9 @@ void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_par
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx) {
     const uint32_t chunks = oc.n_params >> 3;
     uint32_t blocks = (chunks + 255) / 256; if (blocks > 1024u) blocks = 1024u; if (blocks < 1u) blocks = 1u;     // one chunk per thread up to 4 M parameters
-    hipLaunchKernelGGL(k_optimizer, dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx);
+    // dense = every level goes through the LDS scatter, i.e. tables of at most 2^18 entries that a 131 072-sample batch covers
+    if (p.gpart && p.all_levels_dense) hipLaunchKernelGGL(k_optimizer<true>, dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx);
+    else hipLaunchKernelGGL(k_optimizer<false>, dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx);
 }
 
 }  // namespace mon

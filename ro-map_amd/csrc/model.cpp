@@ -143,6 +143,7 @@ int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* 
     if ((rc = dev_alloc(m, m.d_boxes, m.boxes_cap))) return rc;
     B.boxes = m.d_boxes;
     m.h_state = DevState{}; m.h_state.lr = cfg.learning_rate;
+    m.h_state.ema_deb_old = 0.0f; m.h_state.ema_deb_new = 1.0f / (1.0f - (float)std::pow((double)cfg.ema_decay, 1.0));   // step 1
     HIPCHECK(hipMemcpy(m.d_state, &m.h_state, sizeof(DevState), hipMemcpyHostToDevice));
     m.backend = fused_supported(m.nd, S, m.oc.R) ? 1 : 0;
     if (const char* e = std::getenv("MON_BACKEND")) m.backend = std::atoi(e) ? (fused_supported(m.nd, S, m.oc.R) ? 1 : 0) : 0;
@@ -244,7 +245,7 @@ static void enqueue_iteration(Model& m, int stages) {
     if (stages & 4) {      // Trainer::optimizer_step :1644
         ProfScope ps(m, MON_K_OPTIM);
         ParamPtrs P = m.P;
-        if (m.backend == 1 && m.lds_mask) { P.gpart = m.d_gpart; P.part_stride = m.n_grid; P.sl = m.scatter; }
+        if (m.backend == 1 && m.lds_mask) { P.gpart = m.d_gpart; P.part_stride = m.n_grid; P.sl = m.scatter; P.all_levels_dense = (m.lds_mask == ((1u << m.nd.L) - 1u)) ? 1 : 0; }
         OptimNext nx{};
         static const bool fold = !(std::getenv("MON_FOLD_NEXT") && std::atoi(std::getenv("MON_FOLD_NEXT")) == 0);
         if (m.backend == 1 && fold) {

@@ -21,6 +21,7 @@ struct DevState {
     float loss_sum;      // sum of per-ray losses of the current batch (SumLoss, nerf_model.cu:1231-1253)
     uint32_t ticket;     // last-block-done counter of the optimizer kernel
     uint32_t skipped;    // batches skipped because n_valid == 0
+    float ema_deb_old, ema_deb_new;   // EMA debias factors of the NEXT optimizer step (1 - d^(t-1), 1 / (1 - d^t)); the last block of a step leaves them for the following one
 };
 
 // ---- dataset pointers (HBM layout: one slab per kind, frame-major)
@@ -61,6 +62,7 @@ struct ParamPtrs {
     uint16_t* ggrid;    // fp16 grid gradient [n_grid], accumulated with global_atomic_pk_add_f16
     const uint16_t* gpart; uint32_t part_stride;                    // fused backend: dense fp16 partial gradient tables from k_grid_scatter (stride in halves); nullptr = unused
     ScatterLevels sl;                                               // per-level partial-table counts
+    int all_levels_dense;                                           // every level is LDS-scattered (no global-atomic table in use)
 };
 
 struct OptimConst {
