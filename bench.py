@@ -115,7 +115,18 @@ def main():
         roofline["fwd_bwd_pair"] = {"avg_ms": round(grp_ms, 4), "algorithmic_bytes": train_bytes_per_sample(L) * B,
                                     "achieved": round(train_bytes_per_sample(L) * B / (grp_ms * 1e-3) / 1e9, 2),
                                     "frac": round(train_bytes_per_sample(L) * B / (grp_ms * 1e-3) / 1e9 / 8000.0, 4)}
-    roofline["other_kernels_ms"] = {"candidates+frags": round(avg(0), 4), "reduce_partials": round(rd_ms, 4), "optimizer": round(avg(2), 4)}
+    roofline["other_kernels_ms"] = {"candidates+frags (folded into k_optimizer in steady state)": round(avg(0), 4),
+                                    "reduce_partials (folded into k_grid_scatter)": round(rd_ms, 4), "optimizer": round(avg(2), 4)}
+    if fused and os.path.exists(pmc):
+        # the bound that actually holds k_fused_train: its 4-byte hash-grid gathers are one L2 request per distinct 64-byte line per
+        # instruction, and the chip serves ~270 G of those per second (profiles/r01_microbench.md); requests from the PMC pass
+        try:
+            pj = json.load(open(pmc)); req = pj.get("k_fused_train_l2_read_requests_per_launch"); rate = pj.get("l2_line_request_rate_measured_per_s")
+            if req and rate:
+                roofline["l2_request_bound"] = {"requests_per_launch": req, "measured_peak_requests_per_s": rate, "min_ms": round(1e3 * req / rate, 4),
+                                                "frac_of_kernel_time": round(1e3 * req / rate / fb_ms, 4)}
+        except Exception:
+            pass
 
     # ---- quality: PSNR of a rendered crop vs the synthetic ground truth after (2W + 2K) steps; gathered over RCCL when N > 1
     box = sc.objects[0]["boxes"][0]; v, x, y, h, w = (int(q) for q in box)
