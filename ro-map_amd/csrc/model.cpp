@@ -232,7 +232,9 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_weight_grads(s, m.nd, m.B.E, m.B.Hid, m.B.dHid, m.B.dO, m.P.gmlp, B, m.d_state);
             launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
         } else {
+            if (m.scatter_pending) hipMemsetAsync(m.d_state->n_scatter, 0, sizeof(m.d_state->n_scatter), s);      // stage-wise debugging: a forward/backward without an optimizer step after it
             launch_fused_train(s, m.lf, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask, m.d_frag_train);
+            m.scatter_pending = true;
         }
     }
     if ((stages & 2) && m.backend == 1) {
@@ -252,7 +254,7 @@ static void enqueue_iteration(Model& m, int stages) {
             nx.cand_blocks = (m.oc.R + 255) / 256; nx.frag_image = m.d_frag_train; nx.fd = FragDims{ m.nd.Epad, m.nd.W, m.nd.NH, m.nd.L };
             nx.b = m.B; nx.ds = m.ds->ptrs(); nx.oc = m.oc;
         }
-        launch_optimizer(s, P, m.opt, m.d_state, nx);
+        launch_optimizer(s, P, m.opt, m.d_state, nx); m.scatter_pending = false;
         m.next_ready = (m.backend == 1 && fold);
     }
 }

@@ -21,6 +21,8 @@ struct DevState {
     float loss_sum;      // sum of per-ray losses of the current batch (SumLoss, nerf_model.cu:1231-1253)
     uint32_t ticket;     // last-block-done counter of the optimizer kernel
     uint32_t skipped;    // batches skipped because n_valid == 0
+    uint32_t n_scatter[16];   // fused backend: samples with a non-zero dL/dO handed to k_grid_scatter this iteration, per ray bin (ray & 15): slot counters, reset by the optimizer's last block
+    uint32_t n_scatter_last;  // their sum in the last completed iteration (reporting)
     float ema_deb_old, ema_deb_new;   // EMA debias factors of the NEXT optimizer step (1 - d^(t-1), 1 / (1 - d^t)); the last block of a step leaves them for the following one
 };
 
@@ -144,6 +146,7 @@ struct Model {
     float* d_dw_partials = nullptr; uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr; uint16_t* d_gpart = nullptr; uint16_t* d_frag_train = nullptr; uint16_t* d_frag_render = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0; float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr;
     std::vector<void*> allocs;
     DevState h_state{}; int backend = 0; bool profiling = false; int fused_dump = 0;
+    bool scatter_pending = false;   // a fused forward/backward was enqueued whose slot counter has not been reset by an optimizer step yet
     bool next_ready = false;     // fused backend: candidates + fragment image of the coming iteration were already produced by the last k_optimizer
     mon_profile prof{}; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pending;
     hipGraphExec_t graph_exec = nullptr; int graph_backend = -1;

@@ -1,6 +1,8 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded
 inputs, against the committed golden fixtures, and through size-independent properties at BASELINE sizes.
 Nothing here reads /root/reference.  Tolerances: tests/parity.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -270,3 +272,19 @@ def test_optimizer_prepares_the_next_iteration(pkg, orc, small_scene, kw):
     l0 = obj.train(5); assert np.isfinite(l0)
     assert np.array_equal(obj.buffer("frag_train"), obj.buffer("frag_ref"))
     obj.close(); ds.close(); ref.close()
+
+
+def test_zero_gradient_skipping_is_exact_and_deterministic():
+    """k_fused_train drops rays / samples whose fp16 dL/dO is all zeros before the backward MFMAs and the grid scatter.  The trained
+    parameters must be bit-identical to a run that keeps every sample (MON_FUSED_ABLATE=16) and identical from run to run."""
+    import subprocess, sys
+    from conftest import ROOT
+    def run(extra):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "param_crc.py"), "3", "150", "250"], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        rows = [ln.split() for ln in r.stdout.strip().split("\n") if ln.startswith("steps+")]
+        return [w[2] for w in rows], [int(w[4]) for w in rows]
+    crc_a, n_a = run({}); crc_b, n_b = run({}); crc_c, n_c = run({"MON_FUSED_ABLATE": "16"})
+    assert crc_a == crc_b == crc_c, (crc_a, crc_b, crc_c)
+    assert n_c[-1] == 4096 * 32 and n_a[-1] < n_c[-1] // 2, (n_a, n_b, n_c)            # the skipping really happened in the default run
