@@ -723,16 +723,27 @@ constexpr uint32_t kScatterWgPerLevel = 16;
 constexpr float kFixScale = 16777216.0f;          // 2^24
 
 template <bool HASHED, bool POW2>
-__device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restrict__ de, const float* __restrict__ x_soa, uint32_t B, uint32_t s_begin, uint32_t s_end,
+__device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restrict__ de, const float* __restrict__ x_soa, uint32_t B, const uint32_t* __restrict__ bin_count,
+                                                uint32_t bin0, uint32_t bin_step, uint32_t bin_cap,
                                                 float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask, uint32_t base, uint32_t tile) {
+    // This workgroup's samples are the ray bins bin0, bin0 + bin_step, ... (< 16), each a compacted run of bin_count[b] samples at
+    // b * bin_cap.  They are walked as ONE index space v = k * width + o (k-th bin, offset o < width = longest run): a loop per bin
+    // would serialise 4-16 short, latency-bound loops late in training when a bin holds a few hundred samples.
     // The loop is latency-bound if run one sample at a time: fetch a batch of kBatch samples per thread with independent
     // loads first, then do the index math + LDS integer atomics.  Out-of-tile corners cost 4 instructions.
     constexpr int kBatch = 8;
-    for (uint32_t s0 = s_begin + threadIdx.x; s0 < s_end; s0 += blockDim.x * kBatch) {
+    uint32_t nb = 0, width = 0;
+    for (uint32_t b = bin0; b < 16u; b += bin_step) { ++nb; width = max(width, min(bin_count[b], bin_cap)); }
+    if (width == 0u) return;
+    const uint32_t total = nb * width; const float inv_width = 1.0f / (float)width;
+    for (uint32_t v0 = threadIdx.x; v0 < total; v0 += blockDim.x * kBatch) {
         half2_t g[kBatch]; float xs[kBatch][3];
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
-            const uint32_t s = s0 + u * blockDim.x; const bool in = s < s_end; const uint32_t sc = in ? s : s_begin;
+            const uint32_t v = v0 + u * blockDim.x;
+            uint32_t k = (uint32_t)((float)v * inv_width); k -= (k * width > v) ? 1u : 0u; k += ((k + 1u) * width <= v) ? 1u : 0u;   // v / width
+            const uint32_t bsel = min(bin0 + k * bin_step, 15u), o = v - k * width;
+            const bool in = v < total && o < min(bin_count[bsel], bin_cap); const uint32_t sc = in ? bsel * bin_cap + o : bin0 * bin_cap;
             g[u] = de[sc]; if (!in) g[u] = half2_t{ (half_t)0.f, (half_t)0.f };
             xs[u][0] = x_soa[sc]; xs[u][1] = x_soa[(size_t)B + sc]; xs[u][2] = x_soa[2 * (size_t)B + sc];
         }
@@ -814,13 +825,10 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
     // sample partition p of this level = the ray bins b = p, p + P, ... (16 bins, compacted by k_fused_train: only samples with a non-zero gradient)
     const uint32_t bin_cap = B >> 4;
     const half2_t* de = de_soa + (size_t)level * B;
-    for (uint32_t b = p; b < 16u; b += P) {
-        const uint32_t s_begin = b * bin_cap, s_end = s_begin + min(st->n_scatter[b], bin_cap);
-        if (hashed) { if (pow2) scatter_samples<true, true>(tab, de, x_soa, B, s_begin, s_end, scale, size, my, mz, mask, base, tile);
-                      else scatter_samples<true, false>(tab, de, x_soa, B, s_begin, s_end, scale, size, my, mz, mask, base, tile); }
-        else { if (pow2) scatter_samples<false, true>(tab, de, x_soa, B, s_begin, s_end, scale, size, my, mz, mask, base, tile);
-               else scatter_samples<false, false>(tab, de, x_soa, B, s_begin, s_end, scale, size, my, mz, mask, base, tile); }
-    }
+    if (hashed) { if (pow2) scatter_samples<true, true>(tab, de, x_soa, B, st->n_scatter, p, P, bin_cap, scale, size, my, mz, mask, base, tile);
+                  else scatter_samples<true, false>(tab, de, x_soa, B, st->n_scatter, p, P, bin_cap, scale, size, my, mz, mask, base, tile); }
+    else { if (pow2) scatter_samples<false, true>(tab, de, x_soa, B, st->n_scatter, p, P, bin_cap, scale, size, my, mz, mask, base, tile);
+           else scatter_samples<false, false>(tab, de, x_soa, B, st->n_scatter, p, P, bin_cap, scale, size, my, mz, mask, base, tile); }
     __syncthreads();
     half2_t* dst = gpart + (size_t)p * part_stride + off + base;
     for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x)

@@ -11,6 +11,7 @@
 // fp16 weights straight into the MFMA A-fragment image (frag_layout.h), and `cand_blocks` extra blocks generate the next
 // iteration's candidate rays (they depend on the iteration counter and the dataset only), so the steady-state loop is
 // k_fused_train -> k_grid_scatter -> k_reduce_partials -> k_optimizer with no batch-generation launch.
+#include <cstdlib>
 #include "device_common.h"
 #include "model.h"
 #include "frag_layout.h"
@@ -191,7 +192,8 @@ void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_par
 
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx) {
     const uint32_t chunks = oc.n_params >> 3;
-    uint32_t blocks = (chunks + 255) / 256; if (blocks > 1024u) blocks = 1024u; if (blocks < 1u) blocks = 1u;     // one chunk per thread up to 4 M parameters
+    static const uint32_t cap = std::getenv("MON_OPT_BLOCKS") ? (uint32_t)std::atoi(std::getenv("MON_OPT_BLOCKS")) : 512u;
+    uint32_t blocks = (chunks + 255) / 256; if (blocks > cap) blocks = cap; if (blocks < 1u) blocks = 1u;     // ~2 chunks per thread at base.json size: measured best (256: 28.1, 512: 23.7, 1024: 26.2 us)
     // dense = every level goes through the LDS scatter, i.e. tables of at most 2^18 entries that a 131 072-sample batch covers
     if (p.gpart && p.all_levels_dense) hipLaunchKernelGGL(k_optimizer<true>, dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx);
     else hipLaunchKernelGGL(k_optimizer<false>, dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx);
