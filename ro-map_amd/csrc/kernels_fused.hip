@@ -820,7 +820,11 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
     const uint32_t base = part * kScatterTile;
     if (base >= size) return;                                   // levels whose part count does not divide 16
     const uint32_t tile = min(kScatterTile, size - base);
-    for (uint32_t i = threadIdx.x; i < 2u * tile; i += blockDim.x) tab[i] = 0;
+    {   // tile sizes are multiples of 8 entries (tcnn rounds level sizes up to 8): clear with 16-byte stores
+        typedef int int4v __attribute__((ext_vector_type(4)));
+        int4v* t4 = reinterpret_cast<int4v*>(tab);
+        for (uint32_t i = threadIdx.x; i < tile / 2u; i += blockDim.x) t4[i] = int4v{ 0, 0, 0, 0 };
+    }
     __syncthreads();
     // sample partition p of this level = the ray bins b = p, p + P, ... (16 bins, compacted by k_fused_train: only samples with a non-zero gradient)
     const uint32_t bin_cap = B >> 4;
@@ -831,8 +835,17 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
            else scatter_samples<false, false>(tab, de, x_soa, B, st->n_scatter, p, P, bin_cap, scale, size, my, mz, mask, base, tile); }
     __syncthreads();
     half2_t* dst = gpart + (size_t)p * part_stride + off + base;
-    for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x)
-        dst[i] = half2_t{ (half_t)((float)tab[2u * i] * (1.0f / kFixScale)), (half_t)((float)tab[2u * i + 1u] * (1.0f / kFixScale)) };
+    {   // 4 entries per thread and pass: 32 bytes of accumulators in, one 16-byte store of four half2 out
+        typedef int int4v __attribute__((ext_vector_type(4)));
+        const int4v* t4 = reinterpret_cast<const int4v*>(tab);
+        for (uint32_t i = threadIdx.x; i < tile / 4u; i += blockDim.x) {
+            const int4v a0 = t4[2u * i], a1 = t4[2u * i + 1u];
+            half8_t o;
+            o[0] = (half_t)((float)a0[0] * (1.0f / kFixScale)); o[1] = (half_t)((float)a0[1] * (1.0f / kFixScale)); o[2] = (half_t)((float)a0[2] * (1.0f / kFixScale)); o[3] = (half_t)((float)a0[3] * (1.0f / kFixScale));
+            o[4] = (half_t)((float)a1[0] * (1.0f / kFixScale)); o[5] = (half_t)((float)a1[1] * (1.0f / kFixScale)); o[6] = (half_t)((float)a1[2] * (1.0f / kFixScale)); o[7] = (half_t)((float)a1[3] * (1.0f / kFixScale));
+            *reinterpret_cast<half8_t*>(dst + 4u * i) = o;
+        }
+    }
 }
 
 // Host: which levels go through the LDS scatter, with how many sample partitions each.
