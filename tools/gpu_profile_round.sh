@@ -6,11 +6,11 @@ TAG="${1:-prof}"
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$REPO/gpurun_out/$TAG"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o trace -- python "$REPO/bench.py" --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/rocprof.log" 2>&1); echo "rocprof exit $?"
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o trace -- python "$REPO/bench.py" --steps 100 --warmup 10 --no-cpu-baseline --objects-per-gpu 0 > "$OUT/rocprof.log" 2>&1); echo "rocprof exit $?"
 DB=$(find "$OUT/prof" -name "*_results.db" | head -1); python "$REPO/tools/rocpd_stats.py" "$DB" "$OUT/kernel_stats.md" | head -14; rm -rf "$OUT/prof"
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCC_REQ_sum"; do
   N=$(echo $C | tr ' ' '_')
-  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $C -d "$OUT/$N" -o pmc -- python "$REPO/bench.py" --steps 30 --warmup 10 --no-cpu-baseline > "$OUT/$N.log" 2>&1); echo "pmc $C exit $?"
+  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $C -d "$OUT/$N" -o pmc -- python "$REPO/bench.py" --steps 30 --warmup 10 --no-cpu-baseline --objects-per-gpu 0 > "$OUT/$N.log" 2>&1); echo "pmc $C exit $?"
 done
 python "$REPO/tools/rocpd_pmc.py" "$OUT" > "$OUT/pmc_summary.md"; grep -E "k_fused_train|k_grid_scatter|k_optimizer" "$OUT/pmc_summary.md"
 for C in FETCH_SIZE WRITE_SIZE TCC_HIT_sum_TCC_MISS_sum TCP_TCC_READ_REQ_sum_TCC_REQ_sum; do rm -rf "$OUT/$C"; done
