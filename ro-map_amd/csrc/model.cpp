@@ -133,6 +133,7 @@ int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* 
         (rc = dev_alloc(m, B.rgb_ray, 3 * (size_t)R)) || (rc = dev_alloc(m, B.depth_ray, R)) || (rc = dev_alloc(m, B.mask_ray, R)) || (rc = dev_alloc(m, B.loss_ray, R)) ||
         (rc = dev_alloc(m, m.d_state, 1)) || (rc = dev_alloc(m, m.d_dw_partials, (size_t)(m.nd.n_mlp + 64) * 512)) ||
         (rc = dev_alloc(m, m.d_out_rgb, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_depth, kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_mask, kRenderChunkRays))) return rc;
+    m.out_cap = kRenderChunkRays;
     if (fused_supported(m.nd, S, m.oc.R)) {
         if ((rc = dev_alloc(m, m.d_frag_train, 64 * 512)) || (rc = dev_alloc(m, m.d_frag_render, 64 * 512))) return rc;       // <= 30 fragments of 512 halves
         m.lds_mask = scatter_plan(m.lt, m.nd, m.scatter);
@@ -304,25 +305,27 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
     Mat4 pose; std::memcpy(pose.m, pose16, 64);
     const uint32_t n_pix = box.w * box.h, S2 = 2 * m.oc.S;
     const hipMemcpyKind kind = dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (n_pix > m.out_cap) {                                         // whole-crop output buffers (grow-only): all chunks are enqueued back to back, one copy-out and one sync per call
+        int rc; if ((rc = dev_alloc(m, m.d_out_rgb, 3 * (size_t)n_pix, false)) || (rc = dev_alloc(m, m.d_out_depth, n_pix, false)) || (rc = dev_alloc(m, m.d_out_mask, n_pix, false))) return rc;
+        m.out_cap = n_pix;
+    }
     for (uint32_t p0 = 0; p0 < n_pix; p0 += kRenderChunkRays) {
         const uint32_t n = (n_pix - p0) < kRenderChunkRays ? (n_pix - p0) : kRenderChunkRays;
-        {
-            ProfScope ps(m, MON_K_RENDER);
-            launch_render_rays(s, m.B, m.ds->K, m.oc, box, pose, pose_is_Toc, p0, n);
-            if (m.backend == 0) {
-                launch_gen_samples(s, m.B, m.oc, m.d_state, S2, n * S2, kStreamRender, p0 * S2, 1);
-                launch_encode(s, m.lt, m.nd, prm, m.B.pts, m.B.E, n * S2, nullptr);
-                launch_mlp_forward(s, m.nd, prm, m.B.E, nullptr, m.B.O, n * S2, nullptr);
-                launch_composite_render(s, m.B, S2, n, m.d_out_rgb, m.d_out_depth, m.d_out_mask);
-            } else {
-                launch_fused_render(s, m.lf, m.nd, prm, m.B, m.oc, n, p0 * S2, m.d_out_rgb, m.d_out_depth, m.d_out_mask, m.d_frag_render);
-            }
+        ProfScope ps(m, MON_K_RENDER);
+        launch_render_rays(s, m.B, m.ds->K, m.oc, box, pose, pose_is_Toc, p0, n);
+        if (m.backend == 0) {
+            launch_gen_samples(s, m.B, m.oc, m.d_state, S2, n * S2, kStreamRender, p0 * S2, 1);
+            launch_encode(s, m.lt, m.nd, prm, m.B.pts, m.B.E, n * S2, nullptr);
+            launch_mlp_forward(s, m.nd, prm, m.B.E, nullptr, m.B.O, n * S2, nullptr);
+            launch_composite_render(s, m.B, S2, n, m.d_out_rgb + 3 * (size_t)p0, m.d_out_depth + p0, m.d_out_mask + p0);
+        } else {
+            launch_fused_render(s, m.lf, m.nd, prm, m.B, m.oc, n, p0 * S2, m.d_out_rgb + 3 * (size_t)p0, m.d_out_depth + p0, m.d_out_mask + p0, m.d_frag_render, p0 == 0u);
         }
-        HIPCHECK(hipMemcpyAsync(rgb + 3 * (size_t)p0, m.d_out_rgb, 12 * (size_t)n, kind, s));
-        HIPCHECK(hipMemcpyAsync(depth + p0, m.d_out_depth, 4 * (size_t)n, kind, s));
-        HIPCHECK(hipMemcpyAsync(mask + p0, m.d_out_mask, 4 * (size_t)n, kind, s));
-        HIPCHECK(hipStreamSynchronize(s));
     }
+    HIPCHECK(hipMemcpyAsync(rgb, m.d_out_rgb, 12 * (size_t)n_pix, kind, s));
+    HIPCHECK(hipMemcpyAsync(depth, m.d_out_depth, 4 * (size_t)n_pix, kind, s));
+    HIPCHECK(hipMemcpyAsync(mask, m.d_out_mask, 4 * (size_t)n_pix, kind, s));
+    HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipGetLastError());
     collect_profile(m);
     return MON_OK;

@@ -120,7 +120,7 @@ uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl
 uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd);
 void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
                          const float* partials_or_null, uint32_t n_partials, float* gmlp);   // partials != null: also sums the dW partial rows (k_reduce_partials folded in)
-void launch_fused_render(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask, uint16_t* frag_image);
+void launch_fused_render(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask, uint16_t* frag_image, int build_image);
 void launch_build_frag_image(hipStream_t s, const uint16_t* params, const NetDims& nd, uint16_t* image);
 void launch_candidates_and_frags(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st, const uint16_t* params, const NetDims& nd, uint16_t* frag_image);
 int selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
@@ -143,7 +143,7 @@ struct Model {
     hipStream_t train_stream = nullptr, infer_stream = nullptr;
     ParamPtrs P{}; BatchPtrs B{}; DevState* d_state = nullptr; mon_frame_bbox* d_boxes = nullptr;
     uint32_t boxes_cap = 0, n_boxes = 0; uint32_t ws_samples = 0, ws_rays = 0;
-    float* d_dw_partials = nullptr; uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr; uint16_t* d_gpart = nullptr; uint16_t* d_frag_train = nullptr; uint16_t* d_frag_render = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0; float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr;
+    float* d_dw_partials = nullptr; uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr; uint16_t* d_gpart = nullptr; uint16_t* d_frag_train = nullptr; uint16_t* d_frag_render = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0; float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr; size_t out_cap = 0;
     std::vector<void*> allocs;
     DevState h_state{}; int backend = 0; bool profiling = false; int fused_dump = 0;
     bool scatter_pending = false;   // a fused forward/backward was enqueued whose slot counter has not been reset by an optimizer step yet
