@@ -101,7 +101,6 @@ int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* 
     m.oc.sample_seed = cfg.sample_seed; m.oc.loss_scale = cfg.loss_scale;
     m.opt = OptimConst{ cfg.beta1, cfg.beta2, cfg.epsilon, cfg.l2_reg, cfg.ema_decay, cfg.loss_scale, cfg.decay_base, std::log2(cfg.beta1), std::log2(cfg.beta2), cfg.decay_start, cfg.decay_interval, m.nd.n_mlp, m.n_params };
     HIPCHECK(hipStreamCreateWithFlags(&m.train_stream, hipStreamNonBlocking));       // mpTrainStream, nerf_model.cu:1268
-    HIPCHECK(hipStreamCreateWithFlags(&m.infer_stream, hipStreamNonBlocking));       // mpInferenceStream :1269
     // ---- parameters (ResetNetwork :1286-1342; Trainer init)
     const size_t n = m.n_params;
     if ((rc = dev_alloc(m, m.P.master, n, false)) || (rc = dev_alloc(m, m.P.half, n, false)) || (rc = dev_alloc(m, m.P.ema, n)) ||
@@ -164,7 +163,6 @@ int model_destroy(Model* mp) {
     for (auto& e : m.ev_pool) hipEventDestroy(e);
     for (void* p : m.allocs) hipFree(p);
     if (m.train_stream) hipStreamDestroy(m.train_stream);
-    if (m.infer_stream) hipStreamDestroy(m.infer_stream);
     delete mp; return MON_OK;
 }
 

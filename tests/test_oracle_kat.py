@@ -89,17 +89,15 @@ def _numpy_encode(cfg, table_f64, x):
                 else:
                     w = w * (1 - fr[:, d]); q.append(g[:, d])
             qx, qy, qz = (np.asarray(v, np.uint64) & 0xffffffff for v in q)
-            if r ** 3 <= size or (r * r <= size and False):
-                pass
-            stride_ok3 = (1 <= size) and (r <= size) and (r * r <= size)
-            dense = qx + qy * r + qz * r * r
-            stride = r ** 3 if stride_ok3 else None
-            if stride is not None and size >= stride:
-                idx = dense % size
-            elif stride is not None and size < stride:
+            # tcnn grid_index: linear index while the running stride (uint32) fits the table, otherwise the prime hash
+            stride, dense = 1, np.zeros(x.shape[0], np.uint64)
+            for coord in (qx, qy, qz):
+                if stride <= size:
+                    dense = (dense + coord * stride) & 0xffffffff; stride = (stride * r) & 0xffffffff
+            if size < stride:
                 idx = ((qx ^ (qy * 2654435761 & 0xffffffff) ^ (qz * 805459861 & 0xffffffff)) & 0xffffffff) % size
             else:
-                idx = ((qx ^ (qy * 2654435761 & 0xffffffff) ^ (qz * 805459861 & 0xffffffff)) & 0xffffffff) % size
+                idx = dense % size
             idx = idx.astype(np.int64) + int(off[l])
             out[:, 2 * l] += w * table_f64[idx, 0]; out[:, 2 * l + 1] += w * table_f64[idx, 1]
     return out
