@@ -31,6 +31,31 @@ def grid_probe_indices(n_grid):
     return (np.arange(2048, dtype=np.int64) * 7919) % n_grid
 
 
+def mc_field(res3):
+    """Fixed analytic density lattice (x fastest): a wobbly sphere, threshold 0."""
+    rx, ry, rz = res3
+    z, y, x = np.meshgrid(np.linspace(-1, 1, rz), np.linspace(-1, 1, ry), np.linspace(-1, 1, rx), indexing="ij")
+    return (0.7 - np.sqrt((x - 0.05) ** 2 + (y + 0.03) ** 2 + (z - 0.02) ** 2) + 0.05 * np.sin(7 * x) * np.cos(5 * y)).astype(np.float32).reshape(-1)
+
+
+MC_RES = (21, 17, 19); MC_BOX = ([-1.0, -0.5, 0.25], [1.0, 0.75, 2.0])
+
+
+def make_mesh_golden(orc, ss):
+    """Marching cubes + normals of the analytic field, and GenerateMesh of a c1 object with the pattern parameters."""
+    out = {}
+    m = orc.marching_cubes(mc_field(MC_RES), MC_RES, 0.0, *MC_BOX)
+    out["mc_verts"] = m["verts"]; out["mc_indices"] = m["indices"]; out["mc_normals_raw"] = m["normals_raw"]; out["mc_n_real"] = np.uint32(m["n_verts_real"])
+    sc = ss.make_scene(**SCENE); mo = ge.make_oracle(orc, sc, CFGS["c1"]); mo.set_params(pattern_params(mo))
+    g = mo.generate_mesh(16, 0.0, use_ema=False)                 # the pattern grid is oscillatory: threshold 0 gives a large surface
+    for k in ("verts", "indices", "normals", "colors"):
+        out["obj_" + k] = g[k]
+    out["obj_n_real"] = np.uint32(g["n_verts_real"]); mo.close()
+    np.savez_compressed(os.path.join(HERE, "mesh.npz"), **out)
+    print("mesh: mc", m["n_verts_real"], "verts", m["indices"].size // 3, "faces; object", g["n_verts_real"], "verts", g["indices"].size // 3, "faces;",
+          os.path.getsize(os.path.join(HERE, "mesh.npz")), "bytes")
+
+
 def main():
     orc = ge.load_oracle(); ss = ge.load_tools()
     sc = ss.make_scene(**SCENE)
@@ -66,3 +91,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    make_mesh_golden(ge.load_oracle(), ge.load_tools())

@@ -26,3 +26,16 @@ def test_oracle_reproduces_golden(orc, ss, name):
     assert np.abs(rgb - g["render_rgb"].astype(np.float32)).max() < 1e-3
     assert np.array_equal(m2.density_grid(9, 9, 9, use_ema=False), g["density_probe"])
     m.close(); m2.close()
+
+
+def test_oracle_reproduces_mesh_golden(orc, ss):
+    from make_golden import MC_BOX, MC_RES, mc_field
+    g = load_golden("mesh")
+    m = orc.marching_cubes(mc_field(MC_RES), MC_RES, 0.0, *MC_BOX)
+    assert m["n_verts_real"] == int(g["mc_n_real"]) and np.array_equal(m["indices"], g["mc_indices"])
+    assert np.array_equal(m["verts"], g["mc_verts"]) and np.array_equal(m["normals_raw"], g["mc_normals_raw"])
+    sc = ss.make_scene(**SCENE); mo = ge.make_oracle(orc, sc, CFGS["c1"]); mo.set_params(pattern_params(mo))
+    o = mo.generate_mesh(16, 0.0, use_ema=False)
+    assert o["n_verts_real"] == int(g["obj_n_real"]) and np.array_equal(o["indices"], g["obj_indices"]) and np.array_equal(o["verts"], g["obj_verts"])
+    assert np.array_equal(o["normals"], g["obj_normals"]) and np.array_equal(o["colors"], g["obj_colors"])
+    mo.close()

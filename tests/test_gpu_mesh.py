@@ -87,3 +87,22 @@ def test_object_mesh_matches_oracle(pkg, orc, ss, tmp_path):
     obj.generate_mesh(32, 2.0); again = obj.get_mesh(raw=True)
     assert all(np.array_equal(again[k], got[k]) for k in ("verts", "normals", "colors", "indices"))
     obj.close(); ds.close(); ref.close()
+
+
+def test_mesh_matches_golden_fixture(pkg, ss):
+    """No live oracle: marching cubes of the fixed analytic field and GenerateMesh of a c1 object with the pattern parameters
+    against tests/golden/mesh.npz (bit-exact geometry; colours within one 8-bit level: logistic through __expf)."""
+    from parity import CFGS, SCENE, load_golden
+    from make_golden import MC_BOX, MC_RES, mc_field
+    g = load_golden("mesh")
+    m = pkg.marching_cubes(mc_field(MC_RES), MC_RES, 0.0, *MC_BOX)
+    assert m["n_verts_real"] == int(g["mc_n_real"]) and np.array_equal(m["indices"], g["mc_indices"])
+    assert np.array_equal(m["verts"].view(np.uint32), g["mc_verts"].view(np.uint32)) and np.array_equal(m["normals_raw"].view(np.uint32), g["mc_normals_raw"].view(np.uint32))
+    sc = ss.make_scene(**SCENE); ds, obj = ge.make_problem(pkg, sc, CFGS["c1"])
+    k = np.arange(obj.info().n_grid_params, dtype=np.float64); p = obj.get_params(0); p[obj.info().n_mlp_params:] = (0.5 * np.sin(0.37 * k)).astype(np.float32)   # parity.pattern_params
+    obj.set_params(p)
+    obj.generate_mesh(16, 0.0); o = obj.get_mesh()
+    assert o["n_verts_real"] == int(g["obj_n_real"]) and np.array_equal(o["indices"], g["obj_indices"])
+    assert np.array_equal(o["verts"].view(np.uint32), g["obj_verts"].view(np.uint32)) and np.array_equal(o["normals"].view(np.uint32), g["obj_normals"].view(np.uint32))
+    assert np.abs(o["colors"].astype(int) - g["obj_colors"].astype(int)).max() <= 1
+    obj.close(); ds.close()
