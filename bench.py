@@ -96,7 +96,9 @@ def main():
     # kernels: k_fused_train = forward gathers + outputs + dL/dO (52 + 32*L), k_grid_scatter = the gradient
     # scatter read-modify-write (64*L).  The unfused backend is one kernel group timed as a whole.
     obj.set_profiling(True); obj.profile(reset=True)
+    sc0 = int(obj.buffer("state")[25])
     obj.train(args.steps); prof = obj.profile(reset=True); obj.set_profiling(False)
+    scattered = ((int(obj.buffer("state")[25]) - sc0) % (1 << 32)) / float(args.steps)      # samples with a non-zero gradient per step in this window
     avg = lambda k: prof["ms"][k] / max(1, prof["launches"][k])
     fused = obj_backend(pkg, obj) == 1
     fb_ms, sc_ms, rd_ms = avg(1), avg(4), avg(5)
@@ -115,11 +117,13 @@ def main():
                 "avg_launch_ms": round(fb_ms, 4), "algorithmic_bytes_per_launch": dom_bytes}
     if fused:
         grp_ms = fb_ms + sc_ms
-        roofline["scatter_kernel"] = {"kernel": "k_grid_scatter", "avg_launch_ms": round(sc_ms, 4), "algorithmic_bytes_per_launch": 64 * L * B,
-                                      "achieved": round(64 * L * B / (sc_ms * 1e-3) / 1e9, 2), "frac": round(64 * L * B / (sc_ms * 1e-3) / 1e9 / 8000.0, 4)}
-        roofline["fwd_bwd_pair"] = {"avg_ms": round(grp_ms, 4), "algorithmic_bytes": train_bytes_per_sample(L) * B,
-                                    "achieved": round(train_bytes_per_sample(L) * B / (grp_ms * 1e-3) / 1e9, 2),
-                                    "frac": round(train_bytes_per_sample(L) * B / (grp_ms * 1e-3) / 1e9 / 8000.0, 4)}
+        sc_bytes = 64 * L * scattered                # the scatter's read-modify-write bytes of the samples that carry a gradient
+        roofline["scatter_kernel"] = {"kernel": "k_grid_scatter", "avg_launch_ms": round(sc_ms, 4), "gradient_carrying_samples_per_launch": round(scattered, 1),
+                                      "algorithmic_bytes_per_launch": int(sc_bytes), "achieved": round(sc_bytes / (sc_ms * 1e-3) / 1e9, 2),
+                                      "frac": round(sc_bytes / (sc_ms * 1e-3) / 1e9 / 8000.0, 4)}
+        pair_bytes = train_bytes_per_sample_fused(L) * B + sc_bytes
+        roofline["fwd_bwd_pair"] = {"avg_ms": round(grp_ms, 4), "algorithmic_bytes": int(pair_bytes),
+                                    "achieved": round(pair_bytes / (grp_ms * 1e-3) / 1e9, 2), "frac": round(pair_bytes / (grp_ms * 1e-3) / 1e9 / 8000.0, 4)}
     roofline["other_kernels_ms"] = {"candidates+frags (folded into k_optimizer in steady state)": round(avg(0), 4),
                                     "reduce_partials (folded into k_grid_scatter)": round(rd_ms, 4), "optimizer": round(avg(2), 4)}
     if fused and os.path.exists(pmc) and base_cfg:

@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
         if (t == gridDim.x - 1u) {
             st->ticket = 0u;
             st->iter = st->iter + 1u;
-            { uint32_t tot = 0; for (int b = 0; b < 16; ++b) { tot += st->n_scatter[b]; st->n_scatter[b] = 0u; } st->n_scatter_last = tot; }   // slot counters of k_fused_train's compacted gradient rows
+            { uint32_t tot = 0; for (int b = 0; b < 16; ++b) { tot += st->n_scatter[b]; st->n_scatter[b] = 0u; } st->n_scatter_last = tot; st->n_scatter_total += tot; }   // slot counters of k_fused_train's compacted gradient rows
             if (n_valid != 0u) {
                 st->step = cur;
                 st->ema_deb_old = 1.f - (float)pow((double)d, (double)cur);              // factors of step cur + 1

@@ -23,6 +23,7 @@ struct DevState {
     uint32_t skipped;    // batches skipped because n_valid == 0
     uint32_t n_scatter[16];   // fused backend: samples with a non-zero dL/dO handed to k_grid_scatter this iteration, per ray bin (ray & 15): slot counters, reset by the optimizer's last block
     uint32_t n_scatter_last;  // their sum in the last completed iteration (reporting)
+    uint32_t n_scatter_total; // running sum over all iterations, modulo 2^32 (reporting: differences over a measurement window)
     float ema_deb_old, ema_deb_new;   // EMA debias factors of the NEXT optimizer step (1 - d^(t-1), 1 / (1 - d^t)); the last block of a step leaves them for the following one
 };
 
