@@ -308,3 +308,29 @@ def test_large_tables_mix_lds_and_atomic_levels(pkg, orc, small_scene, kw):
     l0 = obj.train(1); l1 = obj.train(150)
     assert np.isfinite(l1) and l1 < 0.6 * l0, (l0, l1)
     obj.close(); ds.close(); ref.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_depth_supervised_gradient_matches_oracle(pkg, orc, small_scene, backend):
+    """use_depth (dense depth offline, sparse depth online: CORE/src/nerf_model.cu:431-434, 869-872): the L1 depth term of the
+    hand-derived gradient, forward/backward against the oracle."""
+    kw = dict(rays_per_batch=256, n_levels=16, n_neurons=64, n_hidden_layers=1)
+    ds, obj, ref = _pair(pkg, orc, small_scene, kw, backend, use_depth=True)
+    p = pattern_params(ref); obj.set_params(p); ref.set_params(p)
+    obj.train_stages(1 | 2); ref.generate_batch(); ref.forward_backward()
+    assert int(obj.buffer("state")[2]) == ref.n_valid and (ref.buffer("target_depth") > 0).sum() > 10
+    if backend == 0:
+        close_f32(obj.buffer("target_depth"), ref.buffer("target_depth"), "target depth", 1e-6)
+    fr = 1.0 if backend == 0 else 0.999
+    close_half(obj.buffer("O"), ref.buffer("O"), "network output", frac_ok=fr)
+    close_half(obj.buffer("dO"), ref.buffer("dO"), "dL/dO with the depth term", ulps=4, frac_ok=0.999)
+    close_f32(obj.buffer("depth_ray"), ref.buffer("depth_ray"), "depth_ray", 3e-3)
+    close_f32(obj.buffer("loss_ray"), ref.buffer("loss_ray"), "loss_ray", 5e-3)
+    gm, rm = obj.buffer("gmlp").astype(np.float64), ref.buffer("gmlp").astype(np.float64)
+    assert np.abs(gm - rm).max() < 5e-3 * np.abs(rm).max()
+    # the depth term is really in there: without depth supervision dL/dO differs
+    ds2, obj2, ref2 = _pair(pkg, orc, small_scene, kw, backend, use_depth=False)
+    obj2.set_params(p); obj2.train_stages(1 | 2)
+    assert (h2f(obj2.buffer("dO")) != h2f(obj.buffer("dO"))).mean() > 0.01
+    for o in (obj, ds, ref, obj2, ds2, ref2):
+        o.close()
