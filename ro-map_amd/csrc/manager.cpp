@@ -282,6 +282,18 @@ struct OnlineManager {
 
 static bool online_check_finish(OnlineObject* o) { std::unique_lock<std::mutex> l(o->mu_finish); return o->finish; }
 
+// Train_Step_Online takes the per-object dataset mutex around GenerateBatch of every iteration (nerf_model.cu:1675-1678), so the SLAM
+// thread's NewFrameToDataset never waits longer than one batch generation.  Here an iteration is three stream-ordered launches without
+// host involvement, so the mutex is held for slices of 64 iterations (~6 ms at base.json size) instead of per iteration.
+static int train_sliced(OnlineObject* o) {
+    int rc = MON_OK;
+    for (int done = 0; done < o->iterations && rc == MON_OK; done += 64) {
+        std::unique_lock<std::mutex> dl(*o->dataset_mutex);
+        rc = model_train(*o->model, (o->iterations - done) < 64 ? (o->iterations - done) : 64, &o->last_loss, 7);
+    }
+    return rc;
+}
+
 static void train_online_thread(OnlineObject* o) {                       // NeRF::TrainOnline, nerf.cu:187-253
     int train_step_count = 0;
     for (;;) {
@@ -296,9 +308,7 @@ static void train_online_thread(OnlineObject* o) {                       // NeRF
         }
         if (o->rc == MON_OK && o->n_uploaded > 10) {                      // :223
             for (int i = 0; i < train_step && o->rc == MON_OK; ++i) {
-                std::unique_lock<std::mutex> dl(*o->dataset_mutex);      // GenerateBatch under the per-object dataset mutex (nerf_model.cu:1675-1678)
-                o->rc = model_train(*o->model, o->iterations, &o->last_loss, 7); ++o->train_calls; ++train_step_count;
-                dl.unlock();
+                o->rc = train_sliced(o); ++o->train_calls; ++train_step_count;
                 if (o->rc == MON_OK && train_step_count % 2 == 0) o->rc = model_generate_mesh(*o->model, o->mesh_res, o->mesh_thresh, nullptr, nullptr);   // :228-236
             }
         }
@@ -306,9 +316,7 @@ static void train_online_thread(OnlineObject* o) {                       // NeRF
         ::usleep(3000);
     }
     if (o->rc == MON_OK && o->n_uploaded > 0) {                           // last time (:246)
-        std::unique_lock<std::mutex> dl(*o->dataset_mutex);
-        o->rc = model_train(*o->model, o->iterations, &o->last_loss, 7); ++o->train_calls;
-        dl.unlock();
+        o->rc = train_sliced(o); ++o->train_calls;
         if (o->rc == MON_OK) o->rc = model_generate_mesh(*o->model, o->mesh_res, o->mesh_thresh, nullptr, nullptr);       // :247-249
     }
     std::printf("Id: %d finished! \n", o->id);
