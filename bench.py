@@ -126,6 +126,13 @@ def main():
                                     "achieved": round(pair_bytes / (grp_ms * 1e-3) / 1e9, 2), "frac": round(pair_bytes / (grp_ms * 1e-3) / 1e9 / 8000.0, 4)}
     roofline["other_kernels_ms"] = {"candidates+frags (folded into k_optimizer in steady state)": round(avg(0), 4),
                                     "reduce_partials (folded into k_grid_scatter)": round(rd_ms, 4), "optimizer": round(avg(2), 4)}
+    # MFMA side of the same kernel (the tiny-GEMM of the MLP is the only matrix work): algorithmic flops = 2 * MACs of forward, input
+    # gradients and weight gradients (3 GEMMs per layer, no padding counted), against the dense fp16 peak
+    W_, NH_, F_in = cfg.n_neurons, cfg.n_hidden_layers, 2 * L
+    macs = F_in * W_ + (NH_ - 1) * W_ * W_ + W_ * 4
+    mlp_flops = 3 * 2 * macs * B
+    roofline["mfma"] = {"algorithmic_flops_per_launch": mlp_flops, "achieved": round(mlp_flops / (fb_ms * 1e-3) / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": round(mlp_flops / (fb_ms * 1e-3) / 1e12 / 2500.0, 4), "note": "the path is gather-bound; MFMA is used only for the MLP's tiny GEMMs"}
     if fused and os.path.exists(pmc) and base_cfg:
         # the bound that actually holds k_fused_train: its 4-byte hash-grid gathers are one L2 request per distinct 64-byte line per
         # instruction, and the chip serves ~270 G of those per second (profiles/r01_microbench.md); requests from the PMC pass
