@@ -287,6 +287,8 @@ def test_zero_gradient_skipping_is_exact_and_deterministic():
         return [w[2] for w in rows], [int(w[4]) for w in rows]
     crc_a, n_a = run({}); crc_b, n_b = run({}); crc_c, n_c = run({"MON_FUSED_ABLATE": "16"})
     assert crc_a == crc_b == crc_c, (crc_a, crc_b, crc_c)
+    crc_g, _ = run({"MON_USE_GRAPH": "1"})                              # hipGraph replay of the same launches
+    assert crc_g == crc_a, (crc_g, crc_a)
     assert n_c[-1] == 4096 * 32 and n_a[-1] < n_c[-1] // 2, (n_a, n_b, n_c)            # the skipping really happened in the default run
 
 
