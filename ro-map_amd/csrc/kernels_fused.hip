@@ -24,6 +24,7 @@
 //   * weight gradients need samples on K: activations are transposed through a per-wave LDS scratch
 //     ([unit][sample] fp16) and accumulated in MFMA accumulators across the wave's rays, then reduced
 //     across the workgroup in LDS and written as one fp32 partial per workgroup (summed by the optimizer).
+#include <atomic>
 #include <cstdlib>
 #include "device_common.h"
 #include "model.h"
@@ -31,6 +32,14 @@
 #include "batch_device.h"
 
 namespace mon {
+
+// true the first time the calling thread's current device is seen by this call site
+static bool first_use_on_this_device(std::atomic<uint64_t>& seen) {
+    int dev = 0; (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    return (seen.fetch_or(bit) & bit) == 0ull;
+}
+
 
 void set_error(const char* fmt, ...);
 
@@ -871,8 +880,8 @@ void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& l
                          const float* partials, uint32_t n_partials, float* gmlp) {
     ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return;
     const PartialsArgs pa{ partials, n_partials, nd.n_mlp + 64u, nd.n_mlp, gmlp, st };
-    static bool attr_done = false;
-    if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, kScatterTile * 8); attr_done = true; }
+    static std::atomic<uint64_t> attr_devices{ 0 };       // function attributes are per device: the managers run objects on every GPU of the node from one process
+    if (first_use_on_this_device(attr_devices)) hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, kScatterTile * 8);
     hipLaunchKernelGGL(k_grid_scatter, dim3(sl.n_levels * kScatterWgPerLevel), dim3(1024), kScatterTile * 8, s, lf, sl, reinterpret_cast<const half2_t*>(de_soa), x_soa, B,
                        reinterpret_cast<half2_t*>(gpart), part_stride_entries, st, pa);
 }
@@ -939,12 +948,11 @@ uint32_t fused_train_grid(const NetDims&, uint32_t R) {
 template <int EPAD, int W, int NH>
 static void fused_train_t(hipStream_t s, const FusedArgs& a, uint32_t grid, int dump) {
     using S = FusedShape<EPAD, W, NH>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<uint64_t> attr_devices{ 0 };
+    if (first_use_on_this_device(attr_devices)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
-        attr_done = true;
     }
     const bool all_lds = a.lds_level_mask != 0u && (a.lds_level_mask == ((a.nd.L >= 32) ? 0xffffffffu : ((1u << a.nd.L) - 1u)));
     if (dump) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
