@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-kernel averages of the PMC counters collected by tools/gpu_pmc.sh (rocprofv3 rocpd SQLite output)."""
+"""Per-kernel averages of the PMC counters collected by tools/gpu_profile_round.sh / tools/gpu_pmc_one.sh (rocprofv3 rocpd SQLite output)."""
 import glob
 import os
 import re
