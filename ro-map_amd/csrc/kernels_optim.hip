@@ -48,10 +48,23 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
     const float inv_scale = 1.0f / oc.loss_scale;
     auto unscale = [&](float g) { return pow2_scale ? g * inv_scale : g / oc.loss_scale; };
     if (n_valid != 0u && !cand_block) {
-        const uint32_t n_chunks = oc.n_params >> 3;
-        for (uint32_t c = bid * blockDim.x + threadIdx.x; c < n_chunks; c += nblk * blockDim.x) {
+        const uint32_t n_chunks = oc.n_params >> 3, c_stride = nblk * blockDim.x, c_first = bid * blockDim.x + threadIdx.x;
+        // sparse (!DENSE) tables: a thread walks dozens of chunks, most of them untouched; the three always-needed loads of the NEXT chunk
+        // (gradient, fp16 weight, EMA) are requested one iteration ahead so the walk is not one memory latency per chunk
+        half8_t nx_g, nx_w, nx_e;
+        auto prefetch = [&](uint32_t cn) {
+            if (!DENSE && cn < n_chunks && (cn << 3) >= oc.n_mlp) {
+                const uint32_t in0 = cn << 3;
+                nx_g = *reinterpret_cast<const half8_t*>(p.ggrid + (in0 - oc.n_mlp)); nx_w = *reinterpret_cast<const half8_t*>(p.half + in0); nx_e = *reinterpret_cast<const half8_t*>(p.ema + in0);
+            }
+        };
+        prefetch(c_first);
+        for (uint32_t c = c_first; c < n_chunks; c += c_stride) {
             const uint32_t i0 = c << 3;
             const bool is_matrix = i0 < oc.n_mlp;                     // n_mlp is a multiple of 8: uniform per chunk
+            const bool pre = !DENSE && !is_matrix;                   // this chunk's always-needed loads were issued an iteration ago
+            const half8_t cur_g = nx_g, cur_w = nx_w, cur_e = nx_e;
+            prefetch(c + c_stride);
             float g[8]; bool any = false;
             // DENSE (small tables: practically every entry has a gradient each step): the optimizer state is requested together
             // with the gradients -- one memory round trip instead of two; sparse tables keep the state loads behind the test.
@@ -62,7 +75,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                 b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
                 s0 = *reinterpret_cast<const uint4*>(p.steps + i0); s1 = *reinterpret_cast<const uint4*>(p.steps + i0 + 4);
             }
-            const half8_t ema_in = *reinterpret_cast<const half8_t*>(p.ema + i0);
+            const half8_t ema_in = pre ? cur_e : *reinterpret_cast<const half8_t*>(p.ema + i0);
             if (is_matrix) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -76,7 +89,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                 for (int j = 0; j < 8; ++j) g[j] = 0.f;
                 if (!DENSE) {                                            // the global-atomic table (levels too large for an LDS tile); never written when DENSE
                     half8_t* gp = reinterpret_cast<half8_t*>(p.ggrid + (i0 - oc.n_mlp));
-                    const half8_t gh = *gp;
+                    const half8_t gh = cur_g;
                     bool anyg = false;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { g[j] = (float)gh[j]; anyg |= (float)gh[j] != 0.f; }
@@ -108,7 +121,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { any |= g[j] != 0.f; g[j] = unscale(g[j]); }
             }
-            half8_t wh = *reinterpret_cast<const half8_t*>(p.half + i0);
+            half8_t wh = pre ? cur_w : *reinterpret_cast<const half8_t*>(p.half + i0);
             if (any) {
                 if (!DENSE) {
                     w0 = *reinterpret_cast<const float4_t*>(p.master + i0); w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
