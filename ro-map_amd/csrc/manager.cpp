@@ -280,6 +280,13 @@ struct OnlineManager {
     int H = 0, W = 0; std::map<uint32_t, std::vector<float>> poses;       // host copy of the poses for train.txt (nerf.cu:369-373 reads them back from the device)
 };
 
+// The training thread tests `finish` and then waits on `cond` under mu_boxes; passing through mu_boxes between setting the flag and
+// notifying closes the window in which the notification could fall between that test and the wait.
+static void request_finish(OnlineObject* o) {
+    { std::unique_lock<std::mutex> l(o->mu_finish); o->finish = true; }
+    { std::unique_lock<std::mutex> l(o->mu_boxes); }
+    o->cond.notify_all();
+}
 static bool online_check_finish(OnlineObject* o) { std::unique_lock<std::mutex> l(o->mu_finish); return o->finish; }
 
 // Train_Step_Online takes the per-object dataset mutex around GenerateBatch of every iteration (nerf_model.cu:1675-1678), so the SLAM
@@ -324,7 +331,7 @@ static void train_online_thread(OnlineObject* o) {                       // NeRF
 
 int online_destroy(OnlineManager* m) {
     if (!m) return MON_OK;
-    for (auto* o : m->objs) { { std::unique_lock<std::mutex> l(o->mu_finish); o->finish = true; } o->cond.notify_all(); }
+    for (auto* o : m->objs) request_finish(o);
     for (auto& t : m->threads) if (t.joinable()) t.join();
     for (auto* o : m->objs) { if (o->model) model_destroy(o->model); delete o; }
     for (auto* d : m->ds) dataset_destroy(d);
@@ -416,7 +423,7 @@ int mon_online_get_frame_idx(mon_online* h, const char* timestamp, int* idx) {  
 int mon_online_wait_threads_end(mon_online* h) {                           // :263-278
     REQ(h); OnlineManager& m = *h->m;
     if (m.threads.empty()) { set_error("WaitThreadsEnd: no threads"); return MON_ERR_STATE; }
-    for (auto* o : m.objs) { { std::unique_lock<std::mutex> l(o->mu_finish); o->finish = true; } o->cond.notify_all(); }     // RequestFinish nerf.cu:443-448
+    for (auto* o : m.objs) request_finish(o);                               // RequestFinish nerf.cu:443-448
     for (auto& t : m.threads) if (t.joinable()) t.join();
     m.threads.clear(); std::puts("All NeRF threads completed ...");
     for (auto* o : m.objs) if (o->rc != MON_OK) { set_error("object %d failed", o->id); return o->rc; }
