@@ -52,7 +52,11 @@ void NeRF::UpdateFrameBBox(const vector<FrameIdAndBbox>& v, const int train_step
     for (size_t i = 0; i < v.size(); ++i) mFrameIdBbox[mnBbox + i] = v[i];
     mnBbox += v.size(); mnTrainStep = train_step; mCond.notify_all();
 }
-void NeRF::RequestFinish() { std::unique_lock<std::mutex> lock(mFinishMutex); mbFinishRequested = true; mCond.notify_all(); }
+void NeRF::RequestFinish() {                                                 // nerf.cu:443-448; passing through mUpdateBbox keeps the notification from falling between TrainOnline's test and its wait
+    { std::unique_lock<std::mutex> lock(mFinishMutex); mbFinishRequested = true; }
+    { std::unique_lock<std::mutex> lock(mUpdateBbox); }
+    mCond.notify_all();
+}
 bool NeRF::CheckFinish() { std::unique_lock<std::mutex> lock(mFinishMutex); return mbFinishRequested; }
 
 void NeRF::TrainOnline() {                                                    // nerf.cu:187-253
@@ -61,7 +65,7 @@ void NeRF::TrainOnline() {                                                    //
         int train_step = 0;
         {
             std::unique_lock<std::mutex> lock(mUpdateBbox);
-            if (mnBbox == mnUploaded) mCond.wait(lock);
+            if (mnBbox == mnUploaded && !CheckFinish()) mCond.wait(lock);
             if (mnBbox > mnUploaded) {
                 mon_object_add_boxes(mpObject, reinterpret_cast<const mon_frame_bbox*>(mFrameIdBbox.data() + mnUploaded), mnBbox - mnUploaded);
                 mnUploaded = mnBbox; train_step = mnTrainStep; mnTrainStep = 0;
