@@ -170,6 +170,11 @@ int mon_offline_n_objects(mon_offline* mgr, int* n);
 int mon_offline_object_loss(mon_offline* mgr, int idx, float* loss, int* device);
 /* test images for the first max_views (0 = all) training boxes of object idx: <out_dir>/<id>/test_{img,depth,mask}/<stamp>.png (nerf.cu:335-349) */
 int mon_offline_render_test(mon_offline* mgr, int idx, const char* out_dir, int max_views);
+/* GetIntrinsics(), GetAllTwc() and, per object, GetObjTow() / GetBoundingBox() / GetFrameIdAndBBox() (MON/main.cpp:55,149-151,334-336: the viewer's inputs).
+ * Buffers may be NULL to query the counts. */
+int mon_offline_get_intrinsics(mon_offline* mgr, float* fx, float* fy, float* cx, float* cy, int* H, int* W);
+int mon_offline_get_poses(mon_offline* mgr, float* Twc16s, size_t capacity_frames, size_t* n_frames);
+int mon_offline_object_meta(mon_offline* mgr, int idx, int* class_id, float* Tow16, float* aabb_min3, float* aabb_max3, mon_frame_bbox* boxes, size_t capacity_boxes, size_t* n_boxes);
 int mon_offline_set_output_dir(mon_offline* mgr, const char* dir);       /* where the training thread saves <id>.ply (default "./output", nerf.cu:148; "" = do not save) */
 int mon_offline_object(mon_offline* mgr, int idx, mon_object** borrowed); /* GetAllNeRF()[idx]: owned by the manager, do not destroy; only mon_object_get_mesh(try_lock) is safe while its thread trains */
 int mon_offline_destroy(mon_offline* mgr);

@@ -82,6 +82,9 @@ _SIGS = {
     "mon_object_save_mesh": (C.c_int, [C.c_void_p, C.c_char_p]),
     "mon_marching_cubes": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "mon_offline_get_intrinsics": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_float)] * 4 + [C.POINTER(C.c_int)] * 2),
+    "mon_offline_get_poses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mon_offline_object_meta": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mon_offline_set_output_dir": (C.c_int, [C.c_void_p, C.c_char_p]),
     "mon_offline_object": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "mon_online_object": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -336,6 +339,21 @@ class OfflineManager:
 
     def set_output_dir(self, path):
         _check(lib().mon_offline_set_output_dir(self.h, path.encode()))
+
+    def intrinsics(self):
+        f = [C.c_float(0) for _ in range(4)]; hw = [C.c_int(0), C.c_int(0)]
+        _check(lib().mon_offline_get_intrinsics(self.h, *[C.byref(v) for v in f + hw])); return tuple(v.value for v in f + hw)
+
+    def poses(self):
+        n = C.c_size_t(0); _check(lib().mon_offline_get_poses(self.h, None, 0, C.byref(n)))
+        T = np.empty((n.value, 16), np.float32); _check(lib().mon_offline_get_poses(self.h, _p(T), n.value, C.byref(n))); return T
+
+    def object_meta(self, idx):
+        n = C.c_size_t(0); cls = C.c_int(0); Tow = np.empty(16, np.float32); a0 = np.empty(3, np.float32); a1 = np.empty(3, np.float32)
+        _check(lib().mon_offline_object_meta(self.h, idx, C.byref(cls), _p(Tow), _p(a0), _p(a1), None, 0, C.byref(n)))
+        boxes = np.empty((n.value, 5), np.uint32)
+        _check(lib().mon_offline_object_meta(self.h, idx, None, None, None, None, _p(boxes), n.value, C.byref(n)))
+        return dict(cls=cls.value, Tow=Tow, aabb_min=a0, aabb_max=a1, boxes=boxes)
 
     def object(self, idx):
         """Borrowed handle of object idx (GetAllNeRF()[idx]); owned by the manager."""

@@ -358,6 +358,23 @@ int mon_offline_wait_threads_end(mon_offline* h) { REQ(h); return offline_wait(*
 int mon_offline_n_objects(mon_offline* h, int* n) { REQ(h); REQ(n); *n = (int)h->m->objs.size(); return MON_OK; }
 int mon_offline_object_loss(mon_offline* h, int idx, float* loss, int* device) { REQ(h); REQ(loss); if (idx < 0 || idx >= (int)h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *loss = h->m->objs[idx]->last_loss; if (device) *device = h->m->objs[idx]->device; return MON_OK; }
 int mon_offline_render_test(mon_offline* h, int idx, const char* out_dir, int max_views) { REQ(h); REQ(out_dir); return offline_render_test(*h->m, idx, out_dir, max_views); }
+// GetIntrinsics / GetAllTwc / NeRF::GetObjTow, GetBoundingBox, GetFrameIdAndBBox -- what MON/main.cpp:55,149-151,334-336 reads for its viewer
+int mon_offline_get_intrinsics(mon_offline* h, float* fx, float* fy, float* cx, float* cy, int* H, int* W) {
+    REQ(h); OfflineManager& m = *h->m; if (fx) *fx = m.fx; if (fy) *fy = m.fy; if (cx) *cx = m.cx; if (cy) *cy = m.cy; if (H) *H = m.H; if (W) *W = m.W; return MON_OK;
+}
+int mon_offline_get_poses(mon_offline* h, float* Twc16s, size_t capacity_frames, size_t* n_frames) {
+    REQ(h); OfflineManager& m = *h->m; const size_t n = m.poses.size() / 16; if (n_frames) *n_frames = n;
+    if (Twc16s) { if (capacity_frames < n) { set_error("get_poses: buffer holds %zu of %zu frames", capacity_frames, n); return MON_ERR_ARG; } std::memcpy(Twc16s, m.poses.data(), n * 64); }
+    return MON_OK;
+}
+int mon_offline_object_meta(mon_offline* h, int idx, int* class_id, float* Tow16, float* aabb_min3, float* aabb_max3, mon_frame_bbox* boxes, size_t capacity_boxes, size_t* n_boxes) {
+    REQ(h); if (idx < 0 || idx >= (int)h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
+    OfflineObject* o = h->m->objs[idx];
+    if (class_id) *class_id = o->cls; if (Tow16) std::memcpy(Tow16, o->Tow, 64); if (aabb_min3) std::memcpy(aabb_min3, o->amin, 12); if (aabb_max3) std::memcpy(aabb_max3, o->amax, 12);
+    if (n_boxes) *n_boxes = o->boxes.size();
+    if (boxes) { if (capacity_boxes < o->boxes.size()) { set_error("object_meta: buffer holds %zu of %zu boxes", capacity_boxes, o->boxes.size()); return MON_ERR_ARG; } std::memcpy(boxes, o->boxes.data(), o->boxes.size() * sizeof(mon_frame_bbox)); }
+    return MON_OK;
+}
 int mon_offline_set_output_dir(mon_offline* h, const char* dir) { REQ(h); h->m->mesh_dir = dir ? dir : ""; return MON_OK; }
 int mon_offline_object(mon_offline* h, int idx, mon_object** borrowed) { REQ(h); REQ(borrowed); if (idx < 0 || idx >= (int)h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *borrowed = &h->m->objs[idx]->handle; return MON_OK; }
 int mon_offline_destroy(mon_offline* h) { if (!h) return MON_OK; offline_destroy(h->m); delete h; return MON_OK; }

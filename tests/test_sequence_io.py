@@ -66,6 +66,12 @@ def test_offline_nerf_flow_on_disk_sequence(pkg, ss, tmp_path):
         m.create_nerf(os.path.join(seq, "obj_offline", "%d.txt" % k))
     m.wait_threads_end()
     assert m.n_objects() == 3
+    # what the OfflineNeRF viewer reads back (MON/main.cpp:55,149-151,334-336)
+    fx, fy, cx, cy, H, W = m.intrinsics(); assert (H, W) == (sc.H, sc.W) and abs(fx - sc.fx) < 1e-4 and abs(cy - sc.cy) < 1e-4
+    T = m.poses(); assert T.shape == (sc.n_views, 16) and np.allclose(T[3].reshape(4, 4).T, sc.Twc[3], atol=1e-5)
+    meta = m.object_meta(1); ob1 = sc.objects[1]
+    assert meta["cls"] == ob1["cls"] and np.array_equal(meta["boxes"], ob1["boxes"]) and np.allclose(meta["aabb_max"], ob1["half"], atol=1e-5)
+    assert np.allclose(meta["Tow"].reshape(4, 4).T, ob1["Tow"], atol=1e-5)
     for k in range(3):
         loss, dev = m.object_loss(k); assert loss < 0.08 and dev == k % pkg.device_count()
         m.render_test(k, out, 2)
