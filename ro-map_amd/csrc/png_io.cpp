@@ -34,7 +34,8 @@ bool png_read(const std::string& path, PngImage& img, std::string& err) {
         else if (!std::memcmp(type, "IEND", 4)) break;
         pos += 12 + len;
     }
-    if (img.width <= 0 || img.height <= 0 || interlace != 0 || (img.bit_depth != 8 && img.bit_depth != 16) || !(color == 0 || color == 2 || color == 4 || color == 6)) {
+    if (img.width <= 0 || img.height <= 0 || img.width > 32768 || img.height > 32768 || (uint64_t)img.width * (uint64_t)img.height > (1ull << 26) || idat.empty() || interlace != 0 || (img.bit_depth != 8 && img.bit_depth != 16) ||
+        !(color == 0 || color == 2 || color == 4 || color == 6)) {
         err = "unsupported PNG format: " + path; return false;
     }
     img.channels = color == 0 ? 1 : (color == 2 ? 3 : (color == 4 ? 2 : 4));
@@ -45,6 +46,7 @@ bool png_read(const std::string& path, PngImage& img, std::string& err) {
     img.data.assign(stride * img.height, 0);
     for (int y = 0; y < img.height; ++y) {
         const uint8_t ft = raw[(stride + 1) * y]; const uint8_t* in = &raw[(stride + 1) * y + 1];
+        if (ft > 4) { err = "PNG: bad filter type in " + path; return false; }
         uint8_t* cur = &img.data[stride * y]; const uint8_t* up = y ? &img.data[stride * (y - 1)] : nullptr;
         for (size_t x = 0; x < stride; ++x) {
             const int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
