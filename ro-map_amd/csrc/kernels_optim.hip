@@ -30,7 +30,18 @@ __device__ __forceinline__ float adam_update(float g, float w, float& m1, float&
     return w - eff * m1;
 }
 
-template <bool DENSE>
+// EMA of `k` steps during which the weight stayed w, in one go (debiased form): e(t+k) = (d^k e(t) (1 - d^t) + (1 - d^k) w) / (1 - d^(t+k)).
+__device__ __forceinline__ void ema_catch_up(half8_t& e, const half8_t& w, uint32_t t, uint32_t k, float log2_d) {
+    const float dk = exp2f((float)k * log2_d), a = dk * (1.f - exp2f((float)t * log2_d)), b = 1.f - dk, inv = 1.f / (1.f - exp2f((float)(t + k) * log2_d));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = (half_t)(((float)e[j] * a + (float)w[j] * b) * inv);
+}
+
+// LAZY (large tables, !DENSE): a grid chunk without a gradient is left alone entirely -- not even its EMA is touched; p.ema_step[chunk]
+// remembers the optimizer step its EMA is current for, and the missing steps are applied in closed form when the chunk next receives a
+// gradient or when the inference weights are needed (k_ema_finalize).  The weights and Adam state are exactly those of the eager
+// schedule; the EMA differs from the step-by-step fp16 recurrence by rounding only.
+template <bool DENSE, bool LAZY>
 __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, DevState* __restrict__ st, OptimNext nx) {
     const uint32_t n_valid = st->n_valid, step = st->step;
     const bool cand_block = blockIdx.x < nx.cand_blocks;            // GenerateRays of iteration iter + 1 (every block reads the state before its ticket)
@@ -55,16 +66,14 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
         auto prefetch = [&](uint32_t cn) {
             if (!DENSE && cn < n_chunks && (cn << 3) >= oc.n_mlp) {
                 const uint32_t in0 = cn << 3;
-                nx_g = *reinterpret_cast<const half8_t*>(p.ggrid + (in0 - oc.n_mlp)); nx_w = *reinterpret_cast<const half8_t*>(p.half + in0); nx_e = *reinterpret_cast<const half8_t*>(p.ema + in0);
+                nx_g = *reinterpret_cast<const half8_t*>(p.ggrid + (in0 - oc.n_mlp));
+                if (!LAZY) { nx_w = *reinterpret_cast<const half8_t*>(p.half + in0); nx_e = *reinterpret_cast<const half8_t*>(p.ema + in0); }
             }
         };
-        prefetch(c_first);
-        for (uint32_t c = c_first; c < n_chunks; c += c_stride) {
+        // one 8-parameter chunk; `pre`: its always-needed loads (cur_*) were issued an iteration ago
+        auto update_chunk = [&](uint32_t c, bool pre, const half8_t& cur_g, const half8_t& cur_w, const half8_t& cur_e) {
             const uint32_t i0 = c << 3;
             const bool is_matrix = i0 < oc.n_mlp;                     // n_mlp is a multiple of 8: uniform per chunk
-            const bool pre = !DENSE && !is_matrix;                   // this chunk's always-needed loads were issued an iteration ago
-            const half8_t cur_g = nx_g, cur_w = nx_w, cur_e = nx_e;
-            prefetch(c + c_stride);
             float g[8]; bool any = false;
             // DENSE (small tables: practically every entry has a gradient each step): the optimizer state is requested together
             // with the gradients -- one memory round trip instead of two; sparse tables keep the state loads behind the test.
@@ -75,7 +84,9 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                 b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
                 s0 = *reinterpret_cast<const uint4*>(p.steps + i0); s1 = *reinterpret_cast<const uint4*>(p.steps + i0 + 4);
             }
-            const half8_t ema_in = pre ? cur_e : *reinterpret_cast<const half8_t*>(p.ema + i0);
+            const bool lazy_chunk = LAZY && !is_matrix;
+            half8_t ema_in;
+            if (!lazy_chunk) ema_in = pre ? cur_e : *reinterpret_cast<const half8_t*>(p.ema + i0);
             if (is_matrix) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -89,7 +100,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                 for (int j = 0; j < 8; ++j) g[j] = 0.f;
                 if (!DENSE) {                                            // the global-atomic table (levels too large for an LDS tile); never written when DENSE
                     half8_t* gp = reinterpret_cast<half8_t*>(p.ggrid + (i0 - oc.n_mlp));
-                    const half8_t gh = cur_g;
+                    const half8_t gh = pre ? cur_g : *reinterpret_cast<const half8_t*>(p.ggrid + (i0 - oc.n_mlp));
                     bool anyg = false;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { g[j] = (float)gh[j]; anyg |= (float)gh[j] != 0.f; }
@@ -121,7 +132,14 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { any |= g[j] != 0.f; g[j] = unscale(g[j]); }
             }
-            half8_t wh = pre ? cur_w : *reinterpret_cast<const half8_t*>(p.half + i0);
+            if (lazy_chunk && !any) return;                                            // untouched: nothing to do now (see k_ema_finalize)
+            half8_t wh = (pre && !LAZY) ? cur_w : *reinterpret_cast<const half8_t*>(p.half + i0);
+            if (lazy_chunk) {                                                        // touched again: first the steps it sat out, with the weight it had
+                ema_in = *reinterpret_cast<const half8_t*>(p.ema + i0);
+                const uint32_t last = p.ema_step[c], k = (cur - 1u) - last;
+                if (k) ema_catch_up(ema_in, wh, last, k, oc.log2_decay);
+                p.ema_step[c] = cur;
+            }
             if (any) {
                 if (!DENSE) {
                     w0 = *reinterpret_cast<const float4_t*>(p.master + i0); w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
@@ -158,6 +176,47 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
 #pragma unroll
             for (int j = 0; j < 8; ++j) e[j] = (half_t)((((float)e[j] * d) * deb_old + (float)wh[j] * (1.f - d)) * deb_new);
             *ep = e;
+        };
+        if constexpr (LAZY) {
+            // Few chunks carry a gradient, but nearly every wave has SOME lane that does in every iteration, so handling them in place makes
+            // the whole wave sit through the touched path's three dependent memory round trips ~25 times.  Instead: scan (one prefetched
+            // 16-byte load per chunk), queue the touched chunks per wave in LDS, then work the queue with full waves.
+            constexpr uint32_t kQueueCap = 2048;
+            __shared__ uint32_t queue[4][kQueueCap];
+            const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u; uint32_t qn = 0;
+            const half8_t none{};
+            prefetch(c_first);
+            for (uint32_t c0 = c_first - lane; c0 < n_chunks; c0 += c_stride) {          // wave-uniform trip count
+                const uint32_t c = c0 + lane; const bool valid = c < n_chunks;
+                const half8_t cur_g = nx_g; prefetch(c + c_stride);
+                bool direct = false, touched = false;
+                if (valid) {
+                    const uint32_t i0 = c << 3;
+                    if (i0 < oc.n_mlp) direct = true;
+                    else {
+                        const uint32_t e0 = (i0 - oc.n_mlp) >> 1; int lvl = 0;
+#pragma unroll
+                        for (int l = 1; l < kMaxLevels; ++l) lvl += (e0 >= p.sl.entry_offset[l]) ? 1 : 0;
+                        if (p.gpart && p.sl.P[lvl]) direct = true;                        // LDS-scattered level: its gradient is in the partial tables
+                        else { const uint4 gb = __builtin_bit_cast(uint4, cur_g); touched = ((gb.x | gb.y | gb.z | gb.w) & 0x7fff7fffu) != 0u; }
+                    }
+                }
+                const unsigned long long tm = __ballot(touched);
+                const uint32_t pos = qn + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull));
+                if (touched) { if (pos < kQueueCap) queue[wave][pos] = c; else direct = true; }
+                qn += (uint32_t)__popcll(tm);
+                if (direct) update_chunk(c, false, none, none, none);
+            }
+            if (qn > kQueueCap) qn = kQueueCap;
+            for (uint32_t q0 = 0; q0 < qn; q0 += 64u) if (q0 + lane < qn) update_chunk(queue[wave][q0 + lane], false, none, none, none);
+        } else {
+            prefetch(c_first);
+            for (uint32_t c = c_first; c < n_chunks; c += c_stride) {
+                const bool pre = !DENSE && (c << 3) >= oc.n_mlp;
+                const half8_t cur_g = nx_g, cur_w = nx_w, cur_e = nx_e;
+                prefetch(c + c_stride);
+                update_chunk(c, pre, cur_g, cur_w, cur_e);
+            }
         }
     }
     // ---- last block advances the counters (one ticket per block).  No fence: the other blocks only READ the state
@@ -208,6 +267,21 @@ void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_par
     hipLaunchKernelGGL(k_reduce_partials, dim3((n_mlp + 1 + 15) / 16), dim3(256), 0, s, partials, n_partials, stride, n_mlp, gmlp, st);
 }
 
+// Brings every lazily maintained EMA chunk up to the last completed optimizer step (before render / mesh / parameter read-back).
+__global__ void __launch_bounds__(256) k_ema_finalize(ParamPtrs p, OptimConst oc, const DevState* __restrict__ st) {
+    const uint32_t done = st->step, n_chunks = oc.n_params >> 3;
+    for (uint32_t c = (oc.n_mlp >> 3) + blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += gridDim.x * blockDim.x) {
+        const uint32_t last = p.ema_step[c];
+        if (last >= done) continue;
+        half8_t e = *reinterpret_cast<const half8_t*>(p.ema + (c << 3)); const half8_t w = *reinterpret_cast<const half8_t*>(p.half + (c << 3));
+        ema_catch_up(e, w, last, done - last, oc.log2_decay);
+        *reinterpret_cast<half8_t*>(p.ema + (c << 3)) = e; p.ema_step[c] = done;
+    }
+}
+void launch_ema_finalize(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, const DevState* st) {
+    hipLaunchKernelGGL(k_ema_finalize, dim3(2048), dim3(256), 0, s, p, oc, st);
+}
+
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx) {
     const uint32_t chunks = oc.n_params >> 3;
     static const uint32_t env_cap = std::getenv("MON_OPT_BLOCKS") ? (uint32_t)std::atoi(std::getenv("MON_OPT_BLOCKS")) : 0u;
@@ -215,8 +289,9 @@ void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, D
     uint32_t cap = chunks / (256u * 8u); if (cap < 512u) cap = 512u; if (cap > 2048u) cap = 2048u; if (env_cap) cap = env_cap;
     uint32_t blocks = (chunks + 255) / 256; if (blocks > cap) blocks = cap; if (blocks < 1u) blocks = 1u;     // ~2 chunks per thread at base.json size: measured best (256: 28.1, 512: 23.7, 1024: 26.2 us)
     // dense = every level goes through the LDS scatter, i.e. tables of at most 2^18 entries that a 131 072-sample batch covers
-    if (p.gpart && p.all_levels_dense) hipLaunchKernelGGL(k_optimizer<true>, dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx);
-    else hipLaunchKernelGGL(k_optimizer<false>, dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx);
+    if (p.gpart && p.all_levels_dense) hipLaunchKernelGGL((k_optimizer<true, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx);
+    else if (p.ema_step) hipLaunchKernelGGL((k_optimizer<false, true>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx);
+    else hipLaunchKernelGGL((k_optimizer<false, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx);
 }
 
 }  // namespace mon

@@ -142,6 +142,7 @@ int model_generate_mesh(Model& m, int res, float thresh, uint32_t* n_verts, uint
     MeshState& ms = *m.mesh; hipStream_t s = m.train_stream;
     const size_t res3 = (size_t)res * res * res;
     int rc = mesh_reserve_lattice(ms, res3); if (rc) return rc;
+    rc = ensure_ema_current(m); if (rc) return rc;
     HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipMemcpy(&m.h_state, m.d_state, sizeof(DevState), hipMemcpyDeviceToHost));
     const uint16_t* prm = (m.h_state.step > 0) ? m.P.ema : m.P.half;

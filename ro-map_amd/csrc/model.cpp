@@ -99,12 +99,12 @@ int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* 
     m.oc.instance_id = (uint32_t)(uint8_t)class_id;                 // nerf.cu:75,158
     m.oc.R = (uint32_t)cfg.rays_per_batch; m.oc.S = (uint32_t)cfg.n_samples; m.oc.use_depth = cfg.use_depth && ds->use_depth;
     m.oc.sample_seed = cfg.sample_seed; m.oc.loss_scale = cfg.loss_scale;
-    m.opt = OptimConst{ cfg.beta1, cfg.beta2, cfg.epsilon, cfg.l2_reg, cfg.ema_decay, cfg.loss_scale, cfg.decay_base, std::log2(cfg.beta1), std::log2(cfg.beta2), cfg.decay_start, cfg.decay_interval, m.nd.n_mlp, m.n_params };
+    m.opt = OptimConst{ cfg.beta1, cfg.beta2, cfg.epsilon, cfg.l2_reg, cfg.ema_decay, cfg.loss_scale, cfg.decay_base, std::log2(cfg.beta1), std::log2(cfg.beta2), std::log2(cfg.ema_decay), cfg.decay_start, cfg.decay_interval, m.nd.n_mlp, m.n_params };
     HIPCHECK(hipStreamCreateWithFlags(&m.train_stream, hipStreamNonBlocking));       // mpTrainStream, nerf_model.cu:1268
     // ---- parameters (ResetNetwork :1286-1342; Trainer init)
     const size_t n = m.n_params;
     if ((rc = dev_alloc(m, m.P.master, n, false)) || (rc = dev_alloc(m, m.P.half, n, false)) || (rc = dev_alloc(m, m.P.ema, n)) ||
-        (rc = dev_alloc(m, m.P.m1, n)) || (rc = dev_alloc(m, m.P.m2, n)) || (rc = dev_alloc(m, m.P.steps, n)) ||
+        (rc = dev_alloc(m, m.P.m1, n)) || (rc = dev_alloc(m, m.P.m2, n)) || (rc = dev_alloc(m, m.P.steps, n)) || (rc = dev_alloc(m, m.d_ema_step, n / 8 + 1)) ||
         (rc = dev_alloc(m, m.P.gmlp, m.nd.n_mlp)) || (rc = dev_alloc(m, m.P.ggrid, m.n_grid))) return rc;
     {
         std::vector<float> master; init_params_host(cfg, m.nd, m.n_params, master);
@@ -146,6 +146,9 @@ int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* 
     m.h_state.ema_deb_old = 0.0f; m.h_state.ema_deb_new = 1.0f / (1.0f - (float)std::pow((double)cfg.ema_decay, 1.0));   // step 1
     HIPCHECK(hipMemcpy(m.d_state, &m.h_state, sizeof(DevState), hipMemcpyHostToDevice));
     m.backend = fused_supported(m.nd, S, m.oc.R) ? 1 : 0;
+    // lazy EMA: only where the optimizer is not the dense variant anyway and the table is large (> 8 M parameters); MON_LAZY_EMA=0/1 overrides
+    m.lazy_ema = m.n_grid > (8u << 20);
+    if (const char* e = std::getenv("MON_LAZY_EMA")) m.lazy_ema = std::atoi(e) != 0;
     if (const char* e = std::getenv("MON_BACKEND")) m.backend = std::atoi(e) ? (fused_supported(m.nd, S, m.oc.R) ? 1 : 0) : 0;
     HIPCHECK(hipDeviceSynchronize());
     *out = mp; return MON_OK;
@@ -247,6 +250,8 @@ static void enqueue_iteration(Model& m, int stages) {
         ProfScope ps(m, MON_K_OPTIM);
         ParamPtrs P = m.P;
         if (m.backend == 1 && m.lds_mask) { P.gpart = m.d_gpart; P.part_stride = m.n_grid; P.sl = m.scatter; P.all_levels_dense = (m.lds_mask == ((1u << m.nd.L) - 1u)) ? 1 : 0; }
+        const bool lazy = m.lazy_ema && !(P.gpart && P.all_levels_dense);
+        P.ema_step = lazy ? m.d_ema_step : nullptr; if (lazy) m.ema_pending = true;
         OptimNext nx{};
         static const bool fold = !(std::getenv("MON_FOLD_NEXT") && std::atoi(std::getenv("MON_FOLD_NEXT")) == 0);
         if (m.backend == 1 && fold) {
@@ -293,9 +298,19 @@ int model_train(Model& m, int iters, float* loss, int stages) {
 }
 
 // Render / RenderVideo body :1768-1828, chunked; inference (EMA) weights once training has run.
+// Lazy EMA: apply the steps untouched chunks sat out before the inference weights are read.
+int ensure_ema_current(Model& m) {
+    if (!m.ema_pending) return MON_OK;
+    HIPCHECK(hipSetDevice(m.device));
+    ParamPtrs P = m.P; P.ema_step = m.d_ema_step;
+    launch_ema_finalize(m.train_stream, P, m.opt, m.d_state);
+    HIPCHECK(hipGetLastError()); m.ema_pending = false; return MON_OK;
+}
+
 int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, int dst_on_device) {
     if (!pose16 || !rgb || !depth || !mask || box.w == 0 || box.h == 0) { set_error("render: bad argument"); return MON_ERR_ARG; }
     HIPCHECK(hipSetDevice(m.device));
+    { int rc = ensure_ema_current(m); if (rc) return rc; }
     hipStream_t s = m.train_stream;
     HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipMemcpy(&m.h_state, m.d_state, sizeof(DevState), hipMemcpyDeviceToHost));
@@ -333,6 +348,7 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
 int model_density_grid(Model& m, int rx, int ry, int rz, float* out_host) {
     if (rx < 2 || ry < 2 || rz < 2 || !out_host) { set_error("density_grid: bad argument"); return MON_ERR_ARG; }
     HIPCHECK(hipSetDevice(m.device));
+    { int rc = ensure_ema_current(m); if (rc) return rc; }
     hipStream_t s = m.train_stream;
     HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipMemcpy(&m.h_state, m.d_state, sizeof(DevState), hipMemcpyDeviceToHost));
@@ -355,7 +371,9 @@ int model_get_params(Model& m, int which, void* dst, size_t bytes) {
     switch (which) { case 0: src = m.P.master; need = (size_t)m.n_params * 4; break; case 1: src = m.P.half; need = (size_t)m.n_params * 2; break;
                      case 2: src = m.P.ema; need = (size_t)m.n_params * 2; break; default: set_error("get_params: which must be 0..2"); return MON_ERR_ARG; }
     if (!dst || bytes < need) { set_error("get_params: buffer too small (%zu < %zu)", bytes, need); return MON_ERR_ARG; }
-    HIPCHECK(hipSetDevice(m.device)); HIPCHECK(hipStreamSynchronize(m.train_stream));
+    HIPCHECK(hipSetDevice(m.device));
+    if (which == 2) { int rc = ensure_ema_current(m); if (rc) return rc; }
+    HIPCHECK(hipStreamSynchronize(m.train_stream));
     HIPCHECK(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost)); return MON_OK;
 }
 int model_set_params(Model& m, const float* master, size_t n) {
@@ -370,6 +388,7 @@ int model_set_params(Model& m, const float* master, size_t n) {
 }
 
 int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
+    if (which == MON_BUF_EMA) { int rc = ensure_ema_current(m); if (rc) return rc; }
     const size_t R = m.oc.R, B = R * m.oc.S, n = m.n_params; const void* src = nullptr; size_t sz = 0;
     switch (which) {
         case MON_BUF_MASTER: src = m.P.master; sz = n * 4; break;       case MON_BUF_HALF: src = m.P.half; sz = n * 2; break;

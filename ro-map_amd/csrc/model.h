@@ -65,11 +65,12 @@ struct ParamPtrs {
     uint16_t* ggrid;    // fp16 grid gradient [n_grid], accumulated with global_atomic_pk_add_f16
     const uint16_t* gpart; uint32_t part_stride;                    // fused backend: dense fp16 partial gradient tables from k_grid_scatter (stride in halves); nullptr = unused
     ScatterLevels sl;                                               // per-level partial-table counts
+    uint32_t* ema_step;                                             // lazy EMA (large tables): per 8-parameter chunk, the optimizer step its EMA is current for; nullptr = eager EMA
     int all_levels_dense;                                           // every level is LDS-scattered (no global-atomic table in use)
 };
 
 struct OptimConst {
-    float beta1, beta2, epsilon, l2_reg, ema_decay, loss_scale, decay_base, log2_beta1, log2_beta2;
+    float beta1, beta2, epsilon, l2_reg, ema_decay, loss_scale, decay_base, log2_beta1, log2_beta2, log2_decay;
     int decay_start, decay_interval;
     uint32_t n_mlp, n_params;
 };
@@ -110,6 +111,7 @@ void launch_extract_density(hipStream_t s, const uint16_t* O, float* out, uint32
 
 // optimizer (kernels_optim.hip)
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx);
+void launch_ema_finalize(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, const DevState* st);
 void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_partials, uint32_t stride, uint32_t n_mlp, float* gmlp, DevState* st);
 
 // fused MFMA path (kernels_fused.hip)
@@ -144,15 +146,17 @@ struct Model {
     hipStream_t train_stream = nullptr;      // mpTrainStream :1268; inference (render, mesh) runs on the same stream: the reference's mpInferenceStream is only ever used from the object's own thread between training calls
     ParamPtrs P{}; BatchPtrs B{}; DevState* d_state = nullptr; mon_frame_bbox* d_boxes = nullptr;
     uint32_t boxes_cap = 0, n_boxes = 0; uint32_t ws_samples = 0, ws_rays = 0;
-    float* d_dw_partials = nullptr; uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr; uint16_t* d_gpart = nullptr; uint16_t* d_frag_train = nullptr; uint16_t* d_frag_render = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0; float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr; size_t out_cap = 0;
+    float* d_dw_partials = nullptr; uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr; uint16_t* d_gpart = nullptr; uint16_t* d_frag_train = nullptr; uint32_t* d_ema_step = nullptr; uint16_t* d_frag_render = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0; float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr; size_t out_cap = 0;
     std::vector<void*> allocs;
     DevState h_state{}; int backend = 0; bool profiling = false; int fused_dump = 0;
+    bool lazy_ema = false, ema_pending = false;   // large tables: EMA of untouched chunks is brought up to date on demand (k_ema_finalize)
     bool scatter_pending = false;   // a fused forward/backward was enqueued whose slot counter has not been reset by an optimizer step yet
     bool next_ready = false;     // fused backend: candidates + fragment image of the coming iteration were already produced by the last k_optimizer
     mon_profile prof{}; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pending;
     hipGraphExec_t graph_exec = nullptr; int graph_backend = -1;
 };
 
+int ensure_ema_current(Model& m);
 int level_table_build(const mon_config& c, LevelTable& lt, NetDims& nd, uint32_t& n_grid);
 void level_fast_build(const LevelTable& lt, const NetDims& nd, LevelFast& lf);
 void init_params_host(const mon_config& c, const NetDims& nd, uint32_t n_params, std::vector<float>& master);

@@ -336,3 +336,27 @@ def test_depth_supervised_gradient_matches_oracle(pkg, orc, small_scene, backend
     assert (h2f(obj2.buffer("dO")) != h2f(obj.buffer("dO"))).mean() > 0.01
     for o in (obj, ds, ref, obj2, ds2, ref2):
         o.close()
+
+
+def test_lazy_ema_matches_eager_on_large_tables(pkg, small_scene):
+    """Tables above 8 M parameters skip untouched chunks in the optimizer altogether and catch their EMA up in closed form when the chunk
+    is touched again or the inference weights are read.  The device's EMA is compared with the eager step-by-step fp16 recurrence
+    (tcnn ema_step_half_precision, restated here in NumPy) run on the weights the device itself produced after every step, so the
+    comparison does not depend on the arrival order of the fine levels' global atomics."""
+    _need_gpu(pkg)
+    ds, obj = ge.make_problem(pkg, small_scene, dict(rays_per_batch=512, log2_hashmap_size=19))
+    assert obj.info().n_grid_params > (8 << 20)
+    d = np.float32(0.95); e = np.zeros(obj.info().n_params, np.float32); touched_any = np.zeros(e.size, bool); w_prev = h2f(obj.get_params(1))
+    for t in range(1, 31):
+        obj.train(1); w = h2f(obj.get_params(1)); touched_any = w != w_prev; w_prev = w
+        deb_old = np.float32(1.0) - np.float32(float(d) ** (t - 1)); deb_new = np.float32(1.0) / (np.float32(1.0) - np.float32(float(d) ** t))
+        e = (((e * d) * deb_old + w * (np.float32(1.0) - d)) * deb_new).astype(np.float16).astype(np.float32)
+    got = h2f(obj.get_params(2))
+    # a few fp16 ulps of the quantities being averaged: an EMA that has cancelled to far below |w| carries the rounding of its larger past
+    # values in either schedule (grid values start at 1e-4: subnormal ulp 2^-24)
+    err = np.abs(got - e); tol = 2.0 ** -9 * (np.abs(e) + np.abs(w)) + 3 * 2.0 ** -24
+    assert (err > tol).mean() < 1e-3 and err.max() < 1e-3, (float((err > tol).mean()), float(err.max()))
+    assert 0.001 < touched_any[obj.info().n_mlp_params:].mean() < 0.9                 # the last step really left most entries alone and changed some
+    # reading the inference weights again changes nothing; training on and reading again stays consistent
+    assert np.array_equal(h2f(obj.get_params(2)), got)
+    obj.close(); ds.close()
