@@ -30,6 +30,7 @@
 #include "model.h"
 #include "frag_layout.h"
 #include "batch_device.h"
+#include "grid_walk.h"
 
 namespace mon {
 
@@ -78,41 +79,10 @@ __device__ __forceinline__ int rho(int h, int r) { return (r & 3) + 8 * (r >> 2)
 // hidden unit carried by K-slot (k-step s, half h, element j) of a W-wide activation in C/D layout
 __device__ __forceinline__ int unit_of_slot(int s, int h, int j) { return 32 * (s >> 1) + rho(h, 8 * (s & 1) + j); }
 
-typedef LevelFast LevelLds;      // copied into LDS once per workgroup
 #ifndef MON_ENCODE_BATCH
 #define MON_ENCODE_BATCH 4
 #endif
 constexpr int kEncodeBatch = MON_ENCODE_BATCH;
-
-// Corner walk of one level for one position: calls f(k, index_within_level, weight) for the 8 corners.
-// Same arithmetic as tcnn's grid_index / grid_hash (weights multiply in x, y, z order; see k_encode), restructured
-// for instruction count -- this kernel is VALU-issue bound, not gather bound:
-//   * tcnn's table sizes leave two cases only: dense (size = round_up(res^3, 8) >= res^3, linear index, can exceed
-//     size only by the +1 boundary corner, so `% size` is one conditional subtract) and hashed (size = 2^T, `%` is a mask);
-//   * the 8 corners share the per-axis terms (2 integer multiplies per level instead of 16), both index forms are
-//     computed and selected per lane (the two half-waves may sit on a dense and a hashed level at the same time).
-template <class F>
-__device__ __forceinline__ void level_corners(const LevelLds& lt, int level, const float x[3], F&& f) {
-    const float scale = lt.scale[level];
-    const uint32_t size = lt.size[level], my = lt.my[level], mz = lt.mz[level], mask = lt.mask[level];
-    const bool hashed = lt.hashed[level] != 0u;
-    float pos[3]; uint32_t pg[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { const float p = fmaf(scale, x[d], 0.5f), fl = floorf(p); pg[d] = (uint32_t)(int32_t)fl; pos[d] = p - fl; }
-    const uint32_t ax[2] = { pg[0], pg[0] + 1u };
-    const uint32_t y0 = pg[1] * my, z0 = pg[2] * mz;
-    const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
-    const float wx[2] = { 1.f - pos[0], pos[0] }, wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int ix = k & 1, iy = (k >> 1) & 1, iz = k >> 2;
-        const uint32_t ih = ax[ix] ^ ay[iy] ^ az[iz], id = ax[ix] + ay[iy] + az[iz];
-        uint32_t idx = (hashed ? ih : id) & mask;
-        idx -= (idx >= size) ? size : 0u;                               // non-power-of-two (dense) sizes: index < 2*size, so % size is one subtract
-        idx = min(idx, size - 1u);                                      // memory safety for positions far outside [0,1]^3 (never produced by the sampler)
-        f(k, idx, (wx[ix] * wy[iy]) * wz[iz]);                          // same product order as the reference walk: ((1 * wx) * wy) * wz
-    }
-}
 
 template <int EPAD, int W, int NH> struct FusedShape {
     static constexpr int MB = W / 32;            // 32-row M blocks of a hidden layer
@@ -155,6 +125,7 @@ struct FusedArgs {
     uint32_t lds_level_mask;    // bit l set: level l goes through k_grid_scatter instead of global atomics
     const uint16_t* frag_image; // A fragments in LDS layout (k_build_frag_image), N_FRAGS x 512 halves
     uint32_t ablate;            // timing experiments only (MON_FUSED_ABLATE): 2 no dW, 4 no dE/x stores, 8 no rays (prologue + epilogue only), 16 keep zero-gradient samples
+    uint32_t big_switch;        // > 0: while big_levels_binned(st, big_switch) holds, EVERY level's dE rows are stored (kernels_bigscatter.hip bins the large levels)
 };
 
 // A fragments: the weight matrices pre-permuted to K-slot order (see the header).  They depend only on the weights,
@@ -414,6 +385,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
 
     const int L = a.nd.L, LPH = (L + 1) >> 1;
     const uint32_t R = (a.ablate & 8u) ? 0u : a.oc.R, iter = a.st->iter;
+    const uint32_t lds_level_mask = (ATOMIC_LEVELS && a.big_switch != 0u && big_levels_binned(a.st->n_scatter_last, a.big_switch)) ? 0xffffffffu : a.lds_level_mask;   // wave-uniform
     const half2_t* table = reinterpret_cast<const half2_t*>(a.params + a.nd.n_mlp);
     typedef __attribute__((address_space(1))) half2_t gh2;
     gh2* gtable = (gh2*)reinterpret_cast<half2_t*>(a.ggrid);
@@ -516,7 +488,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         const uint32_t nz32 = (a.ablate & 16u) ? 0xffffffffu : (uint32_t)__ballot(h == 0 && ((bdo_bits.x | bdo_bits.y) & 0x7fff7fffu) != 0u);   // ablate 16: no skipping (A/B check)
         const uint32_t nz_cnt = __popc(nz32);
         uint32_t slot_base = 0u;
-        if (nz_cnt != 0u && lane == 0 && a.lds_level_mask) slot_base = atomicAdd(&a.st->n_scatter[ray & 15u], nz_cnt);
+        if (nz_cnt != 0u && lane == 0 && lds_level_mask) slot_base = atomicAdd(&a.st->n_scatter[ray & 15u], nz_cnt);
         if (lane == 0) {
             loss_acc += loss;
             a.b.rgb_ray[3 * ray] = rgb0; a.b.rgb_ray[3 * ray + 1] = rgb1; a.b.rgb_ray[3 * ray + 2] = rgb2;
@@ -659,13 +631,13 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         const uint32_t bin_cap = Btot >> 4, in_bin = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_base) + __popc(nz32 & ((1u << n) - 1u));
         const uint32_t slot = (ray & 15u) * bin_cap + in_bin;                              // a bin holds the samples of R/16 rays at most
         const bool do_store = (a.ablate & 4u) == 0u && mine && in_bin < bin_cap;
-        if (a.lds_level_mask && h == 0 && do_store) { a.x_soa[slot] = x[0]; a.x_soa[Btot + slot] = x[1]; a.x_soa[2u * Btot + slot] = x[2]; }
+        if (lds_level_mask && h == 0 && do_store) { a.x_soa[slot] = x[0]; a.x_soa[Btot + slot] = x[1]; a.x_soa[2u * Btot + slot] = x[2]; }
 #pragma unroll
         for (int il = 0; il < S::LLV; ++il) {
             const int level = h * LPH + il;
             if (il < LPH && level < L) {
                 const half_t q0 = (half_t)de[2 * il], q1 = (half_t)de[2 * il + 1];
-                if (!ATOMIC_LEVELS || ((a.lds_level_mask >> level) & 1u)) {
+                if (!ATOMIC_LEVELS || ((lds_level_mask >> level) & 1u)) {
                     if (do_store) a.de_soa[(size_t)level * Btot + slot] = half2_t{ q0, q1 };
                 } else if constexpr (ATOMIC_LEVELS) {
                     const float gq0 = (float)q0, gq1 = (float)q1;
@@ -864,10 +836,15 @@ uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl
     sl.entry_offset[kMaxLevels] = lt.offset[kMaxLevels];
     static const int env_on = std::getenv("MON_LDS_SCATTER") ? std::atoi(std::getenv("MON_LDS_SCATTER")) : 1;
     if (!env_on) return 0u;
+    // A level of up to 16 tiles fits the 16-workgroup plan, but with more than 4 tiles every workgroup walks all the samples of the batch
+    // for its one tile.  When the table has levels that need the large-table path anyway (kernels_bigscatter.hip), levels of 5..16
+    // tiles go there too.
+    uint32_t max_parts = kScatterWgPerLevel;
+    for (int l = 0; l < nd.L; ++l) if ((lt.offset[l + 1] - lt.offset[l] + kScatterTile - 1) / kScatterTile > kScatterWgPerLevel) max_parts = 4;
     for (int l = 0; l < nd.L; ++l) {
         const uint32_t size = lt.offset[l + 1] - lt.offset[l];
         const uint32_t parts = (size + kScatterTile - 1) / kScatterTile;
-        if (parts <= kScatterWgPerLevel) {
+        if (parts <= max_parts) {
             mask |= 1u << l; sl.level[sl.n_levels++] = (uint8_t)l;
             sl.P[l] = (uint8_t)(kScatterWgPerLevel / parts); if (sl.P[l] > sl.max_P) sl.max_P = sl.P[l];
         }
@@ -992,9 +969,9 @@ static void candidates_frags_t(hipStream_t s, const BatchPtrs& b, const DatasetP
     } while (0)
 
 void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
-                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image) {
+                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch) {
     static const uint32_t ablate = std::getenv("MON_FUSED_ABLATE") ? (uint32_t)std::atoi(std::getenv("MON_FUSED_ABLATE")) : 0u;
-    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate };
+    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate, big_switch };
     const uint32_t grid = fused_train_grid(nd, oc.R);
     MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);
 }

@@ -138,6 +138,11 @@ int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* 
         m.lds_mask = scatter_plan(m.lt, m.nd, m.scatter);
         if (m.lds_mask && ((rc = dev_alloc(m, m.d_de_soa, (size_t)m.nd.L * Btrain * 2)) || (rc = dev_alloc(m, m.d_x_soa, 3 * (size_t)Btrain)) ||
                            (rc = dev_alloc(m, m.d_gpart, (size_t)m.scatter.max_P * m.n_grid)))) return rc;
+        // Levels beyond the LDS plan (more than 2^18 entries): binned exact scatter while many samples carry a gradient (kernels_bigscatter.hip).
+        // MON_BIG_SWITCH = gradient-carrying samples below which the global-atomic path takes over (0: atomics always).
+        const size_t big_bytes = m.lds_mask ? big_scatter_workspace_bytes(m.lt, m.nd, m.lds_mask, Btrain) : 0;
+        const uint32_t big_switch = std::getenv("MON_BIG_SWITCH") ? (uint32_t)std::atoll(std::getenv("MON_BIG_SWITCH")) : 16384u;
+        if (big_bytes && big_switch) { if ((rc = dev_alloc(m, m.d_big_ws, big_bytes))) return rc; m.big_switch = big_switch; }
     }
     m.boxes_cap = 1024;
     if ((rc = dev_alloc(m, m.d_boxes, m.boxes_cap))) return rc;
@@ -235,7 +240,7 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
         } else {
             if (m.scatter_pending) hipMemsetAsync(m.d_state->n_scatter, 0, sizeof(m.d_state->n_scatter), s);      // stage-wise debugging: a forward/backward without an optimizer step after it
-            launch_fused_train(s, m.lf, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask, m.d_frag_train);
+            launch_fused_train(s, m.lf, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask, m.d_frag_train, m.big_active ? m.big_switch : 0u);
             m.scatter_pending = true;
         }
     }
@@ -244,6 +249,7 @@ static void enqueue_iteration(Model& m, int stages) {
         const bool folded = m.lds_mask && fold_reduce;                 // the scatter workgroups also sum the dW partial rows
         if (m.lds_mask) { ProfScope ps(m, MON_K_SCATTER); launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.d_gpart, m.n_grid / 2, m.d_state,
                                                                                 folded ? m.d_dw_partials : nullptr, fused_train_grid(m.nd, m.oc.R), m.P.gmlp); }
+        if (m.big_active) { ProfScope ps(m, MON_K_SCATTER); launch_big_scatter(s, m.lt, m.lf, m.nd, m.lds_mask, m.d_de_soa, m.d_x_soa, B, m.d_state, m.big_switch, m.d_big_ws, m.P.ggrid); }
         if (!folded) { ProfScope ps(m, MON_K_REDUCE); launch_reduce_partials(s, m.d_dw_partials, fused_train_grid(m.nd, m.oc.R), m.nd.n_mlp + 64, m.nd.n_mlp, m.P.gmlp, m.d_state); }
     }
     if (stages & 4) {      // Trainer::optimizer_step :1644
@@ -274,10 +280,14 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     if (iters < 0) { set_error("train: negative iteration count"); return MON_ERR_ARG; }
     if (m.n_boxes == 0) { set_error("train: no 2-D boxes (UpdateFrameIdAndBbox was never called)"); return MON_ERR_STATE; }
     HIPCHECK(hipSetDevice(m.device));
+    // Large-table scatter: the device picks binned / atomic per iteration from the previous iteration's gradient-carrying sample count;
+    // once the host has seen that count well below the switch point it stops launching the (then empty) binning kernels at all.
+    m.big_active = m.big_switch && (m.h_state.n_scatter_last == 0u || m.h_state.n_scatter_last > m.big_switch / 2u);
     static const bool use_graph_env = std::getenv("MON_USE_GRAPH") && std::atoi(std::getenv("MON_USE_GRAPH")) != 0;
     const bool use_graph = use_graph_env && !m.profiling && stages == 7 && iters >= 2;
     if (use_graph) {
-        if (!m.graph_exec || m.graph_backend != m.backend) {
+        const int graph_key = m.backend | (m.big_active ? 256 : 0);
+        if (!m.graph_exec || m.graph_backend != graph_key) {
             drop_graph(m);
             hipGraph_t g = nullptr;
             HIPCHECK(hipStreamBeginCapture(m.train_stream, hipStreamCaptureModeThreadLocal));
@@ -285,7 +295,7 @@ int model_train(Model& m, int iters, float* loss, int stages) {
             enqueue_iteration(m, 7);
             HIPCHECK(hipStreamEndCapture(m.train_stream, &g));
             HIPCHECK(hipGraphInstantiate(&m.graph_exec, g, nullptr, nullptr, 0));
-            hipGraphDestroy(g); m.graph_backend = m.backend;
+            hipGraphDestroy(g); m.graph_backend = graph_key;
         }
         for (int i = 0; i < iters; ++i) HIPCHECK(hipGraphLaunch(m.graph_exec, m.train_stream));
     } else {

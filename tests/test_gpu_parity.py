@@ -312,6 +312,34 @@ def test_large_tables_mix_lds_and_atomic_levels(pkg, orc, small_scene, kw):
     obj.close(); ds.close(); ref.close()
 
 
+def test_binned_large_level_scatter_is_exact_and_deterministic(pkg, orc, small_scene):
+    """Levels beyond 2^18 entries while many samples carry a gradient (kernels_bigscatter.hip): contributions are counting-sorted by
+    16 384-entry tile and summed exactly in LDS, so the fp16 gradient is the fp32 sum of tcnn's fp16 contributions rounded ONCE --
+    tighter than arrival-order atomics -- and a run that never leaves the binned path (MON_BIG_SWITCH=1) is bit-reproducible."""
+    import subprocess, sys
+    from conftest import ROOT
+    kw = dict(rays_per_batch=256, log2_hashmap_size=19, n_neurons=64, n_hidden_layers=1)
+    ds, obj, ref = _pair(pkg, orc, small_scene, kw, 1)
+    p = pattern_params(ref); obj.set_params(p); ref.set_params(p)
+    obj.train_stages(1 | 2); ref.generate_batch(); ref.forward_backward()
+    gg = h2f(obj.buffer("ggrid_h")).astype(np.float64); rg = ref.buffer("ggrid").astype(np.float64); ra = ref.buffer("ggrid_abs").astype(np.float64)
+    loose = 2.0 ** -8 * ra + 2.0 ** -10 * np.abs(rg) + 1e-7
+    assert float((np.abs(gg - rg) > loose).mean()) < 1e-4 and (gg != 0).sum() > 0
+    big = np.zeros(gg.size, bool); big[gg.size // 2:] = True                 # the fine (binned) levels sit in the upper half of the table
+    # what is left: one fp16 rounding of the sum, and dL/dE rows that differ from the oracle's by an fp16 ulp
+    err = np.abs(gg - rg)[big & (rg != 0)]; ref_mag = np.abs(rg)[big & (rg != 0)]
+    assert np.median(err / ref_mag) < 2.0 ** -10, float(np.median(err / ref_mag))
+    obj.close(); ds.close(); ref.close()
+
+    def run(extra):
+        env = dict(os.environ, MON_CRC_CFG='{"log2_hashmap_size": 19}', **extra)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "param_crc.py"), "2", "20"], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return [ln.split()[2] for ln in r.stdout.strip().split("\n") if ln.startswith("steps+")]
+    a = run({"MON_BIG_SWITCH": "1"}); b = run({"MON_BIG_SWITCH": "1"})
+    assert a == b and len(a) == 2, (a, b)
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_depth_supervised_gradient_matches_oracle(pkg, orc, small_scene, backend):
     """use_depth (dense depth offline, sparse depth online: CORE/src/nerf_model.cu:431-434, 869-872): the L1 depth term of the
