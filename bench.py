@@ -52,7 +52,7 @@ def main():
         raise SystemExit("bench.py: no HIP device visible (the HIP path has no CPU fallback)")
     device = local_rank % ndev
     dist = None; coll_dev = "cpu"
-    if world > 1:
+    if world > 1 or os.environ.get("MON_BENCH_FORCE_DIST"):      # FORCE_DIST: exercise the RCCL path with world_size 1 on a 1-GPU box
         import torch.distributed as dist
         # "nccl" IS RCCL on ROCm (xGMI); MON_BENCH_DIST_BACKEND=gloo lets the N>1 path be exercised on a 1-GPU box
         backend = os.environ.get("MON_BENCH_DIST_BACKEND", "nccl")
