@@ -58,6 +58,7 @@ struct OfflineObject {
     int id = 0, device = 0, cls = 0; float Tow[16]; float amin[3], amax[3];
     std::vector<mon_frame_bbox> boxes; std::vector<std::string> stamps;
     Model* model = nullptr; mon_object handle{ nullptr }; float last_loss = 0.f; int rc = 0; std::string err;
+    std::mutex mu_model;            // a Model is single-threaded: held by the training thread per train / mesh call and by every caller-side use of the model
 };
 
 struct OfflineManager {
@@ -125,12 +126,14 @@ int offline_read_dataset(OfflineManager& m) {                           // nerf_
 }
 
 static void train_offline_thread(OfflineManager* m, OfflineObject* o) {  // NeRF::TrainOffline, nerf.cu:120-152
-    o->rc = model_add_boxes(*o->model, o->boxes.data(), o->boxes.size());
+    { std::lock_guard<std::mutex> l(o->mu_model); o->rc = model_add_boxes(*o->model, o->boxes.data(), o->boxes.size()); }
     for (int i = 1; i <= m->outer_iters && o->rc == MON_OK; ++i) {
+        std::lock_guard<std::mutex> l(o->mu_model);
         o->rc = model_train(*o->model, m->inner_iters, &o->last_loss, 7);
         if (o->rc == MON_OK) std::printf("Id: %d Step: %d loss: %f\n", o->id, i * m->inner_iters, o->last_loss);
         if (o->rc == MON_OK && i % 2 == 0) o->rc = model_generate_mesh(*o->model, m->mesh_res, m->mesh_thresh, nullptr, nullptr);   // GenerateMesh + TransCPUMesh, nerf.cu:138-145
     }
+    std::lock_guard<std::mutex> l(o->mu_model);
     if (o->rc == MON_OK && !m->mesh_dir.empty()) {                        // SaveMesh("./output/<id>.ply"), nerf.cu:148-149
         uint32_t nv = 0; model_mesh_counts(*o->model, &nv, nullptr, nullptr);
         ::mkdir(m->mesh_dir.c_str(), 0755);
@@ -144,7 +147,8 @@ int offline_create_nerf(OfflineManager& m, const char* object_file) {    // nerf
     if (!f) { set_error("object file error... %s", object_file); return MON_ERR_IO; }
     if (m.ds.empty()) { set_error("CreateNeRF before ReadDataset"); return MON_ERR_STATE; }
     OfflineObject* o = new OfflineObject(); o->id = (int)m.objs.size(); o->device = o->id % m.n_dev;
-    std::string line; std::getline(f, line); std::getline(f, line); std::stringstream ss(line); float v[10]; ss >> o->cls; for (float& x : v) ss >> x;
+    std::string line; std::getline(f, line); std::getline(f, line); std::stringstream ss(line); float v[10] = {}; ss >> o->cls; for (float& x : v) ss >> x;
+    if (ss.fail()) { delete o; set_error("object file error... %s: expected 'class tx ty tz qx qy qz qw ex ey ez' on line 2", object_file); return MON_ERR_IO; }
     float Two[16]; pose_from_tq(v, v[3], v[4], v[5], v[6], Two); rigid_inverse(Two, o->Tow);
     for (int a = 0; a < 3; ++a) { o->amin[a] = -v[7 + a]; o->amax[a] = v[7 + a]; }
     while (std::getline(f, line)) {
@@ -175,7 +179,7 @@ static int write_render_pngs(const std::string& img_path, const std::string& dep
     const size_t n = (size_t)w * h; std::string err; std::vector<uint8_t> c8(3 * n), m8(n), d16(2 * n);
     for (size_t p = 0; p < 3 * n; ++p) { const float q = rgb[p] * 255.f; c8[p] = (uint8_t)(q < 0.f ? 0.f : (q > 255.f ? 255.f : std::nearbyint(q))); }
     for (size_t p = 0; p < n; ++p) {
-        if (mask) m8[p] = (uint8_t)std::nearbyint(mask[p] * 255.f);
+        if (mask) { const float q = mask[p] * 255.f; m8[p] = (uint8_t)(q > 0.f ? (q > 255.f ? 255.f : std::nearbyint(q)) : 0.f); }
         const float q = depth[p] * 20000.f; const uint32_t u = (uint32_t)(q < 0.f ? 0.f : (q > 65535.f ? 65535.f : std::nearbyint(q))); d16[2 * p] = (uint8_t)(u >> 8); d16[2 * p + 1] = (uint8_t)u;
     }
     if (!png_write(img_path, (int)w, (int)h, 3, 8, c8.data(), err) || !png_write(depth_path, (int)w, (int)h, 1, 16, d16.data(), err) ||
@@ -235,6 +239,7 @@ int offline_render_test(OfflineManager& m, int idx, const char* out_dir, int max
     OfflineObject* o = m.objs[idx]; const std::string root = std::string(out_dir) + "/" + std::to_string(o->id);
     ::mkdir(out_dir, 0755);                                              // mkdir -p of nerf.cu:258-283, one level at a time
     for (const char* sub : { "", "/test_img", "/test_depth", "/test_mask" }) ::mkdir((root + sub).c_str(), 0755);
+    std::lock_guard<std::mutex> lm(o->mu_model);                         // may be called while the object is still training
     std::string err; const size_t nv = max_views > 0 && (size_t)max_views < o->boxes.size() ? (size_t)max_views : o->boxes.size();
     for (size_t i = 0; i < nv; ++i) {
         const mon_frame_bbox b = o->boxes[i]; const size_t n = (size_t)b.w * b.h;
@@ -271,6 +276,8 @@ struct OnlineObject {
     std::mutex* dataset_mutex = nullptr;
     Model* model = nullptr; mon_object handle{ nullptr }; float last_loss = 0.f; int train_calls = 0; int rc = 0;
     int mesh_res = 64; float mesh_thresh = 2.0f;
+    std::mutex mu_model;            // a Model is single-threaded: the training thread holds it per train slice / box upload / mesh call, the SLAM-side
+                                    // calls (render, object_info, RenderNeRFsTest) while they use the model or read what the thread writes
 };
 
 struct OnlineManager {
@@ -295,7 +302,7 @@ static bool online_check_finish(OnlineObject* o) { std::unique_lock<std::mutex> 
 static int train_sliced(OnlineObject* o) {
     int rc = MON_OK;
     for (int done = 0; done < o->iterations && rc == MON_OK; done += 64) {
-        std::unique_lock<std::mutex> dl(*o->dataset_mutex);
+        std::unique_lock<std::mutex> dl(*o->dataset_mutex); std::lock_guard<std::mutex> lm(o->mu_model);
         rc = model_train(*o->model, (o->iterations - done) < 64 ? (o->iterations - done) : 64, &o->last_loss, 7);
     }
     return rc;
@@ -309,13 +316,15 @@ static void train_online_thread(OnlineObject* o) {                       // NeRF
             std::unique_lock<std::mutex> lock(o->mu_boxes);
             if (o->n_boxes == o->n_uploaded && !online_check_finish(o)) o->cond.wait(lock);          // no update: wait (:209-212)
             if (o->n_boxes > o->n_uploaded) {
+                std::lock_guard<std::mutex> lm(o->mu_model);
                 o->rc = model_add_boxes(*o->model, o->boxes.data() + o->n_uploaded, o->n_boxes - o->n_uploaded);   // UpdateFrameIdAndBboxOnline
                 o->n_uploaded = o->n_boxes; train_step = o->pending_train_step; o->pending_train_step = 0;
             }
         }
         if (o->rc == MON_OK && o->n_uploaded > 10) {                      // :223
             for (int i = 0; i < train_step && o->rc == MON_OK; ++i) {
-                o->rc = train_sliced(o); ++o->train_calls; ++train_step_count;
+                o->rc = train_sliced(o); ++train_step_count;
+                std::lock_guard<std::mutex> lm(o->mu_model); ++o->train_calls;
                 if (o->rc == MON_OK && train_step_count % 2 == 0) o->rc = model_generate_mesh(*o->model, o->mesh_res, o->mesh_thresh, nullptr, nullptr);   // :228-236
             }
         }
@@ -323,7 +332,8 @@ static void train_online_thread(OnlineObject* o) {                       // NeRF
         ::usleep(3000);
     }
     if (o->rc == MON_OK && o->n_uploaded > 0) {                           // last time (:246)
-        o->rc = train_sliced(o); ++o->train_calls;
+        o->rc = train_sliced(o);
+        std::lock_guard<std::mutex> lm(o->mu_model); ++o->train_calls;
         if (o->rc == MON_OK) o->rc = model_generate_mesh(*o->model, o->mesh_res, o->mesh_thresh, nullptr, nullptr);       // :247-249
     }
     std::printf("Id: %d finished! \n", o->id);
@@ -392,7 +402,10 @@ int mon_online_init(mon_online* h) {                                      // ner
     m.cfg.use_depth = m.use_depth ? 1 : 0; return MON_OK;
 }
 int mon_online_dataset_init(mon_online* h, float fx, float fy, float cx, float cy, int H, int W, size_t imgs) {   // :160-187
-    REQ(h); OnlineManager& m = *h->m; m.n_images = imgs; m.ds_mutex.resize(m.n_dev); m.H = H; m.W = W;
+    REQ(h); OnlineManager& m = *h->m;
+    if (m.n_dev == 0) { set_error("DatasetInit before Init"); return MON_ERR_STATE; }
+    if (!m.ds.empty()) { set_error("DatasetInit called twice"); return MON_ERR_STATE; }
+    m.n_images = imgs; m.ds_mutex.resize(m.n_dev); m.H = H; m.W = W;
     for (int g = 0; g < m.n_dev; ++g) { Dataset* d = nullptr; int rc = dataset_create(g, H, W, fx, fy, cx, cy, (uint32_t)imgs, m.use_depth, &d); if (rc) return rc; m.ds.push_back(d); }
     return MON_OK;
 }
@@ -448,10 +461,11 @@ int mon_online_wait_threads_end(mon_online* h) {                           // :2
 }
 int mon_online_object_info(mon_online* h, size_t idx, float* loss, int* train_calls, int* device, uint32_t* n_boxes) {
     REQ(h); if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
-    OnlineObject* o = h->m->objs[idx]; if (loss) *loss = o->last_loss; if (train_calls) *train_calls = o->train_calls; if (device) *device = o->device; if (n_boxes) *n_boxes = (uint32_t)o->n_uploaded; return MON_OK;
+    OnlineObject* o = h->m->objs[idx]; std::lock_guard<std::mutex> lm(o->mu_model); if (loss) *loss = o->last_loss; if (train_calls) *train_calls = o->train_calls; if (device) *device = o->device; if (n_boxes) *n_boxes = (uint32_t)o->n_uploaded; return MON_OK;
 }
 int mon_online_render(mon_online* h, size_t idx, mon_frame_bbox box, const float* Twc16, float* rgb, float* depth, float* mask) {   // one view of RenderNeRFsTest :280-285
     REQ(h); if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
+    std::lock_guard<std::mutex> lm(h->m->objs[idx]->mu_model);            // between two 64-iteration slices of a running training step
     return model_render(*h->m->objs[idx]->model, box, Twc16, 0, rgb, depth, mask, 0);
 }
 // NerfManagerOnline::RenderNeRFsTest -> NeRF::RenderTestImg, nerf.cu:255-404: <out>/<id>/{test_img,test_depth,test_mask}/<stamp>.png,
@@ -462,6 +476,9 @@ int mon_online_render_nerfs_test(mon_online* h, const char* out_path, size_t idx
     if (idx >= m.objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
     if (n && (!timestamps || !boxes || !Twcs16)) { set_error("RenderNeRFsTest: null argument"); return MON_ERR_ARG; }
     OnlineObject* o = m.objs[idx]; const std::string root = std::string(out_path) + "/" + std::to_string(o->id);
+    std::vector<mon_frame_bbox> trained;                                  // snapshot of the uploaded boxes (lock order everywhere: mu_boxes, then mu_model)
+    { std::lock_guard<std::mutex> lb(o->mu_boxes); trained.assign(o->boxes.begin(), o->boxes.begin() + (ptrdiff_t)o->n_uploaded); }
+    std::lock_guard<std::mutex> lm(o->mu_model);
     ::mkdir(out_path, 0755);
     for (const char* sub : { "", "/test_img", "/test_depth", "/test_mask", "/video_img", "/video_depth" }) ::mkdir((root + sub).c_str(), 0755);
     std::ofstream f(root + "/test.txt");
@@ -479,8 +496,8 @@ int mon_online_render_nerfs_test(mon_online* h, const char* out_path, size_t idx
     f.open(root + "/train.txt");                                          // training data, nerf.cu:356-390
     f << std::fixed << "#class Bbox" << std::endl << o->cls << " " << o->amax[0] << " " << o->amax[1] << " " << o->amax[2] << " " << std::endl;
     f << "#stamp box.x box.y box.h box.w  tx  ty  tz  qx  qy  qz  qw (object-centric)" << std::endl;
-    for (size_t i = 0; i < o->n_uploaded; ++i) {
-        const mon_frame_bbox b = o->boxes[i]; std::string st;
+    for (const mon_frame_bbox& b : trained) {
+        std::string st;
         for (const auto& kv : m.stamp_to_idx) if (kv.second == b.FrameId) { st = kv.first; break; }
         auto it = m.poses.find(b.FrameId); if (it == m.poses.end()) continue;
         write_pose_line(f, st, b, o->Tow, it->second.data());

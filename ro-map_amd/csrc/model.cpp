@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -36,6 +37,7 @@ int device_count(int* n) {
 }
 
 // ------------------------------------------------------------------ dataset
+int dataset_destroy(Dataset* d);
 int dataset_create(int device, int H, int W, float fx, float fy, float cx, float cy, uint32_t max_frames, int use_depth, Dataset** out) {
     int n = 0; int rc = device_count(&n); if (rc) return rc;
     if (device < 0 || device >= n || H <= 0 || W <= 0 || max_frames == 0) { set_error("dataset_create: bad argument"); return MON_ERR_ARG; }
@@ -43,10 +45,14 @@ int dataset_create(int device, int H, int W, float fx, float fy, float cx, float
     Dataset* d = new Dataset();
     d->device = device; d->K = Intrinsics{ fx, fy, cx, cy, H, W }; d->max_frames = max_frames; d->use_depth = use_depth != 0;
     const size_t px = (size_t)H * W;
-    HIPCHECK(hipMalloc((void**)&d->d_rgba, px * 4 * max_frames));
-    if (d->use_depth) HIPCHECK(hipMalloc((void**)&d->d_depth, px * 4 * max_frames));
-    HIPCHECK(hipMalloc((void**)&d->d_poses, 64 * (size_t)max_frames));
-    HIPCHECK(hipMemset(d->d_poses, 0, 64 * (size_t)max_frames));
+    const auto alloc = [&]() -> int {
+        HIPCHECK(hipMalloc((void**)&d->d_rgba, px * 4 * max_frames));
+        if (d->use_depth) HIPCHECK(hipMalloc((void**)&d->d_depth, px * 4 * max_frames));
+        HIPCHECK(hipMalloc((void**)&d->d_poses, 64 * (size_t)max_frames));
+        HIPCHECK(hipMemset(d->d_poses, 0, 64 * (size_t)max_frames));
+        return MON_OK;
+    };
+    if ((rc = alloc())) { dataset_destroy(d); return rc; }          // e.g. out of memory for max_frames images: free what was taken
     d->staging.resize(px);
     *out = d; return MON_OK;
 }
@@ -84,13 +90,10 @@ template <class T> static int dev_alloc(Model& m, T*& p, size_t n, bool zero = t
 
 static constexpr uint32_t kRenderChunkRays = 16384;   // rays per render pass (x 2S samples)
 
-int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* Tow, const float* amin, const float* amax, Model** out) {
-    if (!ds || !Tow || !amin || !amax) { set_error("object_create: bad argument"); return MON_ERR_ARG; }
-    if (cfg.rays_per_batch < 64 || (cfg.rays_per_batch % 64) != 0 || cfg.n_samples < 1 || cfg.n_samples > 64) { set_error("rays_per_batch must be a multiple of 64, n_samples 1..64"); return MON_ERR_ARG; }
-    Model* mp = new Model(); Model& m = *mp;
+static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id, const float* Tow, const float* amin, const float* amax) {
     m.ds = ds; m.cfg = cfg; m.device = ds->device;
     int rc = level_table_build(cfg, m.lt, m.nd, m.n_grid);
-    if (rc) { delete mp; return rc; }
+    if (rc) return rc;
     m.n_params = m.nd.n_mlp + m.n_grid;
     level_fast_build(m.lt, m.nd, m.lf);
     HIPCHECK(hipSetDevice(m.device));
@@ -156,6 +159,16 @@ int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* 
     if (const char* e = std::getenv("MON_LAZY_EMA")) m.lazy_ema = std::atoi(e) != 0;
     if (const char* e = std::getenv("MON_BACKEND")) m.backend = std::atoi(e) ? (fused_supported(m.nd, S, m.oc.R) ? 1 : 0) : 0;
     HIPCHECK(hipDeviceSynchronize());
+    return MON_OK;
+}
+
+int model_destroy(Model* mp);
+int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* Tow, const float* amin, const float* amax, Model** out) {
+    if (!ds || !Tow || !amin || !amax) { set_error("object_create: bad argument"); return MON_ERR_ARG; }
+    if (cfg.rays_per_batch < 64 || (cfg.rays_per_batch % 64) != 0 || cfg.n_samples < 1 || cfg.n_samples > 64) { set_error("rays_per_batch must be a multiple of 64, n_samples 1..64"); return MON_ERR_ARG; }
+    Model* mp = new Model();
+    const int rc = model_init(*mp, ds, cfg, class_id, Tow, amin, amax);
+    if (rc) { model_destroy(mp); return rc; }          // a failed allocation half-way must not leak what came before it
     *out = mp; return MON_OK;
 }
 
@@ -329,8 +342,9 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
     const uint32_t n_pix = box.w * box.h, S2 = 2 * m.oc.S;
     const hipMemcpyKind kind = dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (n_pix > m.out_cap) {                                         // whole-crop output buffers (grow-only): all chunks are enqueued back to back, one copy-out and one sync per call
-        int rc; if ((rc = dev_alloc(m, m.d_out_rgb, 3 * (size_t)n_pix, false)) || (rc = dev_alloc(m, m.d_out_depth, n_pix, false)) || (rc = dev_alloc(m, m.d_out_mask, n_pix, false))) return rc;
-        m.out_cap = n_pix;
+        const size_t cap = std::max<size_t>(n_pix, 2 * m.out_cap);   // doubling: the superseded buffers (freed with the object) add up to less than the live one
+        int rc; if ((rc = dev_alloc(m, m.d_out_rgb, 3 * cap, false)) || (rc = dev_alloc(m, m.d_out_depth, cap, false)) || (rc = dev_alloc(m, m.d_out_mask, cap, false))) return rc;
+        m.out_cap = cap;
     }
     for (uint32_t p0 = 0; p0 < n_pix; p0 += kRenderChunkRays) {
         const uint32_t n = (n_pix - p0) < kRenderChunkRays ? (n_pix - p0) : kRenderChunkRays;
@@ -356,7 +370,7 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
 
 // GetDensityOnGrid :2007-2048
 int model_density_grid(Model& m, int rx, int ry, int rz, float* out_host) {
-    if (rx < 2 || ry < 2 || rz < 2 || !out_host) { set_error("density_grid: bad argument"); return MON_ERR_ARG; }
+    if (rx < 2 || ry < 2 || rz < 2 || !out_host || (uint64_t)rx * (uint64_t)ry * (uint64_t)rz > (1ull << 31)) { set_error("density_grid: bad argument"); return MON_ERR_ARG; }
     HIPCHECK(hipSetDevice(m.device));
     { int rc = ensure_ema_current(m); if (rc) return rc; }
     hipStream_t s = m.train_stream;
