@@ -340,6 +340,28 @@ def test_binned_large_level_scatter_is_exact_and_deterministic(pkg, orc, small_s
     assert a == b and len(a) == 2, (a, b)
 
 
+def test_stress_configuration_t22_full_size_properties(pkg, ss):
+    """BASELINE configs[4] (T = 2^22: 105 M parameters, a 211 MB fp16 table) at the full batch: far beyond what the oracle finishes in
+    seconds, so size-independent properties -- sparse Adam touches only entries that got a gradient, the loss falls, the lazily
+    maintained EMA renders the object (mask IoU / PSNR against the synthetic ground truth), parameters stay finite."""
+    _need_gpu(pkg)
+    sc = ss.make_scene(n_views=16, H=240, W=320, f=260.0, seed=3)
+    ds, obj = ge.make_problem(pkg, sc, dict(log2_hashmap_size=22)); obj.set_backend(1)
+    n_mlp = obj.info().n_mlp_params
+    l0 = obj.train(1); st = obj.buffer("steps")
+    assert (st[:n_mlp] == 1).all() and 0 < int((st[n_mlp:] > 0).sum()) < 0.5 * (st.size - n_mlp)
+    l1 = obj.train(400)
+    assert np.isfinite(l1) and l1 < 0.35 * l0, (l0, l1)
+    st = obj.buffer("state"); assert int(st[24]) > 0                         # gradient-carrying samples of the last iteration
+    box = sc.objects[0]["boxes"][0]; v, x, y, h, w = (int(q) for q in box)
+    rgb, depth, mask = obj.render(box, ss.colmajor(sc.Twc[v]))
+    gm = sc.instance[v, y:y + h, x:x + w] > 0; gt = np.where(gm[..., None], sc.rgb[v, y:y + h, x:x + w] / 255.0, 1.0)
+    iou = (mask.astype(bool) & gm).sum() / max(1, (mask.astype(bool) | gm).sum())
+    assert iou > 0.85 and psnr(rgb, gt) > 18.0, (iou, psnr(rgb, gt))
+    assert np.isfinite(h2f(obj.get_params(2))).all()                        # the EMA weights after k_ema_finalize
+    obj.close(); ds.close()
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_depth_supervised_gradient_matches_oracle(pkg, orc, small_scene, backend):
     """use_depth (dense depth offline, sparse depth online: CORE/src/nerf_model.cu:431-434, 869-872): the L1 depth term of the
