@@ -214,6 +214,31 @@ def test_full_size_properties_c2(pkg, ss, backend):
     obj.close(); ds.close()
 
 
+@pytest.mark.parametrize("kw", [dict(rays_per_batch=64), dict(rays_per_batch=16384), dict(rays_per_batch=256, n_samples=16), dict(rays_per_batch=128, n_samples=64)],
+                         ids=["R64_min", "R16384_fused_max", "S16_unfused", "S64_unfused"])
+def test_size_limits_match_oracle(pkg, orc, small_scene, kw):
+    """Smallest / largest batch of the fused kernels (R = 64 .. 16 384 rays, S = 32) and sample counts only the layer-at-a-time kernels
+    take (S != 32 selects backend 0 by itself): one forward/backward against the oracle on the base.json network."""
+    _need_gpu(pkg)
+    ds, obj = ge.make_problem(pkg, small_scene, kw); ref = ge.make_oracle(orc, small_scene, kw)
+    assert int(obj.info().backend) == (1 if kw.get("n_samples", 32) == 32 else 0)
+    if int(obj.info().backend) == 1:
+        obj.set_debug_dump(True)
+    p = pattern_params(ref); obj.set_params(p); ref.set_params(p)
+    obj.train_stages(1 | 2); ref.generate_batch(); ref.forward_backward()
+    assert int(obj.buffer("state")[2]) == ref.n_valid > 0
+    assert np.array_equal(obj.buffer("E"), ref.buffer("E")), "hash-grid encode must be bit-exact"
+    close_f32(obj.buffer("rgb_ray"), ref.buffer("rgb_ray"), "rgb_ray", 2e-3)
+    close_f32(obj.buffer("loss_ray"), ref.buffer("loss_ray"), "loss_ray", 5e-3)
+    gm, rm = obj.buffer("gmlp").astype(np.float64), ref.buffer("gmlp").astype(np.float64)
+    assert np.abs(gm - rm).max() < 5e-3 * np.abs(rm).max(), (np.abs(gm - rm).max(), np.abs(rm).max())
+    gg = h2f(obj.buffer("ggrid_h")).astype(np.float64); rg = ref.buffer("ggrid").astype(np.float64); ra = ref.buffer("ggrid_abs").astype(np.float64)
+    assert float((np.abs(gg - rg) > 2.0 ** -8 * ra + 2.0 ** -10 * np.abs(rg) + 1e-7).mean()) < 2e-3 and (gg != 0).sum() > 0
+    obj.train_stages(4); l = obj.train(3)
+    assert np.isfinite(l) and np.isfinite(obj.get_params(0)).all()
+    obj.close(); ds.close(); ref.close()
+
+
 def test_edge_cases(pkg, ss, small_scene):
     _need_gpu(pkg)
     sc = small_scene
