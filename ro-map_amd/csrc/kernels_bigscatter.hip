@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(1024) k_big_emit(LevelFast lf, BigLevels big, 
 }
 
 __global__ void __launch_bounds__(1024) k_big_accum(LevelFast lf, BigLevels big, const DevState* __restrict__ st, uint32_t big_switch, const uint32_t* __restrict__ tile_cnt,
-                                                    const uint32_t* __restrict__ tile_off, const uint2* __restrict__ rec, uint32_t B, uint32_t* __restrict__ ggrid_h2) {
+                                                    const uint32_t* __restrict__ tile_off, const uint2* __restrict__ rec, uint32_t B, uint32_t* __restrict__ ggrid_h2, uint8_t* __restrict__ touched_grid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (st->n_valid == 0u || !big_levels_binned(st->n_scatter_last, big_switch)) return;
     int bl = 0;
@@ -112,7 +112,10 @@ __global__ void __launch_bounds__(1024) k_big_accum(LevelFast lf, BigLevels big,
     uint32_t* dst = ggrid_h2 + lf.offset[level] + base;
     for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) {
         const int a0 = tab[2u * i], a1 = tab[2u * i + 1u];
-        if (a0 | a1) dst[i] = __builtin_bit_cast(uint32_t, half2_t{ (half_t)((float)a0 * (1.0f / kBigFixScale)), (half_t)((float)a1 * (1.0f / kBigFixScale)) });
+        if (a0 | a1) {
+            dst[i] = __builtin_bit_cast(uint32_t, half2_t{ (half_t)((float)a0 * (1.0f / kBigFixScale)), (half_t)((float)a1 * (1.0f / kBigFixScale)) });
+            if (touched_grid) touched_grid[(lf.offset[level] + base + i) >> 2] = 1;          // the optimizer's chunk flag (4 entries = 8 parameters)
+        }
     }
 }
 
@@ -134,7 +137,7 @@ size_t big_scatter_workspace_bytes(const LevelTable& lt, const NetDims& nd, uint
     return (size_t)n_big * (2 * kBigBins + 2) * kBigMaxTiles * 4 + (size_t)n_big * 8u * B * 8u;
 }
 void launch_big_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, uint32_t lds_mask, const uint16_t* de_soa, const float* x_soa, uint32_t B,
-                        const DevState* st, uint32_t big_switch, void* workspace, uint16_t* ggrid) {
+                        const DevState* st, uint32_t big_switch, void* workspace, uint16_t* ggrid, uint8_t* touched_grid) {
     BigLevels big; if (big_levels_plan(lt, nd, lds_mask, big) <= 0) return;
     uint32_t* hist = reinterpret_cast<uint32_t*>(workspace); uint32_t* woff = hist + (size_t)big.n * kBigBins * kBigMaxTiles;
     uint32_t* tcnt = woff + (size_t)big.n * kBigBins * kBigMaxTiles; uint32_t* toff = tcnt + (size_t)big.n * kBigMaxTiles;
@@ -146,7 +149,7 @@ void launch_big_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf
     hipLaunchKernelGGL(k_big_hist, dim3(big.n * kBigBins), dim3(1024), 0, s, lf, big, de, x_soa, B, st, big_switch, hist);
     hipLaunchKernelGGL(k_big_scan, dim3(big.n), dim3(1024), 0, s, big, st, big_switch, hist, woff, tcnt, toff);
     hipLaunchKernelGGL(k_big_emit, dim3(big.n * kBigBins), dim3(1024), 0, s, lf, big, de, x_soa, B, st, big_switch, woff, rec);
-    hipLaunchKernelGGL(k_big_accum, dim3(big.tile_base[big.n]), dim3(1024), kBigTile * 8, s, lf, big, st, big_switch, tcnt, toff, rec, B, reinterpret_cast<uint32_t*>(ggrid));
+    hipLaunchKernelGGL(k_big_accum, dim3(big.tile_base[big.n]), dim3(1024), kBigTile * 8, s, lf, big, st, big_switch, tcnt, toff, rec, B, reinterpret_cast<uint32_t*>(ggrid), touched_grid);
 }
 
 }  // namespace mon

@@ -125,6 +125,7 @@ struct FusedArgs {
     uint32_t lds_level_mask;    // bit l set: level l goes through k_grid_scatter instead of global atomics
     const uint16_t* frag_image; // A fragments in LDS layout (k_build_frag_image), N_FRAGS x 512 halves
     uint32_t ablate;            // timing experiments only (MON_FUSED_ABLATE): 2 no dW, 4 no dE/x stores, 8 no rays (prologue + epilogue only), 16 keep zero-gradient samples
+    uint8_t* touched_grid;      // per 4 grid entries (= one 8-parameter optimizer chunk): set to 1 next to every global atomic, or nullptr (see ParamPtrs::touched)
     uint32_t big_switch;        // > 0: while big_levels_binned(st, big_switch) holds, EVERY level's dE rows are stored (kernels_bigscatter.hip bins the large levels)
 };
 
@@ -645,6 +646,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
                         gh2* gl = gtable + llt->offset[level];
                         level_corners(*llt, level, x, [&](int, uint32_t idx, float wgt2) {
                             __builtin_amdgcn_global_atomic_fadd_v2f16(gl + idx, half2_t{ (half_t)(wgt2 * gq0), (half_t)(wgt2 * gq1) });
+                            if (a.touched_grid) a.touched_grid[(llt->offset[level] + idx) >> 2] = 1;
                         });
                     }
                 }
@@ -969,9 +971,9 @@ static void candidates_frags_t(hipStream_t s, const BatchPtrs& b, const DatasetP
     } while (0)
 
 void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
-                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch) {
+                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched) {
     static const uint32_t ablate = std::getenv("MON_FUSED_ABLATE") ? (uint32_t)std::atoi(std::getenv("MON_FUSED_ABLATE")) : 0u;
-    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate, big_switch };
+    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate, touched ? touched + (nd.n_mlp >> 3) : nullptr, big_switch };
     const uint32_t grid = fused_train_grid(nd, oc.R);
     MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);
 }

@@ -185,6 +185,25 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
             __shared__ uint32_t queue[4][kQueueCap];
             const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u; uint32_t qn = 0;
             const half8_t none{};
+            if (p.touched) {
+                // Chunk flags (one byte per chunk, set next to every addition into ggrid): the scan reads 1/16 of what the gradient table
+                // itself would cost.  Chunks below first_flag_chunk (MLP matrices, LDS-scattered levels) are few and always visited.
+                for (uint32_t c = c_first; c < p.first_flag_chunk; c += c_stride) update_chunk(c, false, none, none, none);
+                const uint32_t w_end = (n_chunks + 3u) >> 2; uint32_t* flags = reinterpret_cast<uint32_t*>(p.touched);
+                for (uint32_t w0 = (p.first_flag_chunk >> 2) + c_first - lane; w0 < w_end; w0 += c_stride) {     // wave-uniform trip count
+                    const uint32_t w = w0 + lane; uint32_t f = 0u;
+                    if (w < w_end) { f = flags[w]; if (f) flags[w] = 0u; }
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) {
+                        const bool touched = ((f >> (8u * j)) & 0xffu) != 0u; const uint32_t c = 4u * w + j;
+                        const unsigned long long tm = __ballot(touched);
+                        if (tm == 0ull) continue;
+                        const uint32_t pos = qn + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull));
+                        qn += (uint32_t)__popcll(tm);
+                        if (touched) { if (pos < kQueueCap) queue[wave][pos] = c; else update_chunk(c, false, none, none, none); }
+                    }
+                }
+            } else {
             prefetch(c_first);
             for (uint32_t c0 = c_first - lane; c0 < n_chunks; c0 += c_stride) {          // wave-uniform trip count
                 const uint32_t c = c0 + lane; const bool valid = c < n_chunks;
@@ -206,6 +225,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                 if (touched) { if (pos < kQueueCap) queue[wave][pos] = c; else direct = true; }
                 qn += (uint32_t)__popcll(tm);
                 if (direct) update_chunk(c, false, none, none, none);
+            }
             }
             if (qn > kQueueCap) qn = kQueueCap;
             for (uint32_t q0 = 0; q0 < qn; q0 += 64u) if (q0 + lane < qn) update_chunk(queue[wave][q0 + lane], false, none, none, none);

@@ -136,6 +136,9 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         (rc = dev_alloc(m, m.d_state, 1)) || (rc = dev_alloc(m, m.d_dw_partials, (size_t)(m.nd.n_mlp + 64) * 512)) ||
         (rc = dev_alloc(m, m.d_out_rgb, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_depth, kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_mask, kRenderChunkRays))) return rc;
     m.out_cap = kRenderChunkRays;
+    // lazy EMA: only where the optimizer is not the dense variant anyway and the table is large (> 8 M parameters); MON_LAZY_EMA=0/1 overrides
+    m.lazy_ema = m.n_grid > (8u << 20);
+    if (const char* e = std::getenv("MON_LAZY_EMA")) m.lazy_ema = std::atoi(e) != 0;
     if (fused_supported(m.nd, S, m.oc.R)) {
         if ((rc = dev_alloc(m, m.d_frag_train, 64 * 512)) || (rc = dev_alloc(m, m.d_frag_render, 64 * 512))) return rc;       // <= 30 fragments of 512 halves
         m.lds_mask = scatter_plan(m.lt, m.nd, m.scatter);
@@ -146,6 +149,9 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         const size_t big_bytes = m.lds_mask ? big_scatter_workspace_bytes(m.lt, m.nd, m.lds_mask, Btrain) : 0;
         const uint32_t big_switch = std::getenv("MON_BIG_SWITCH") ? (uint32_t)std::atoll(std::getenv("MON_BIG_SWITCH")) : 16384u;
         if (big_bytes && big_switch) { if ((rc = dev_alloc(m, m.d_big_ws, big_bytes))) return rc; m.big_switch = big_switch; }
+        // chunk flags for the lazy optimizer (tables above 8 M parameters with levels outside the LDS plan); MON_TOUCHED_FLAGS=0: scan the gradient table
+        const bool flags_on = !(std::getenv("MON_TOUCHED_FLAGS") && std::atoi(std::getenv("MON_TOUCHED_FLAGS")) == 0);
+        if (flags_on && m.lazy_ema && m.lds_mask && m.lds_mask != ((m.nd.L >= 32) ? 0xffffffffu : ((1u << m.nd.L) - 1u)) && (rc = dev_alloc(m, m.d_touched, (m.n_params >> 3) + 16))) return rc;
     }
     m.boxes_cap = 1024;
     if ((rc = dev_alloc(m, m.d_boxes, m.boxes_cap))) return rc;
@@ -154,9 +160,6 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     m.h_state.ema_deb_old = 0.0f; m.h_state.ema_deb_new = 1.0f / (1.0f - (float)std::pow((double)cfg.ema_decay, 1.0));   // step 1
     HIPCHECK(hipMemcpy(m.d_state, &m.h_state, sizeof(DevState), hipMemcpyHostToDevice));
     m.backend = fused_supported(m.nd, S, m.oc.R) ? 1 : 0;
-    // lazy EMA: only where the optimizer is not the dense variant anyway and the table is large (> 8 M parameters); MON_LAZY_EMA=0/1 overrides
-    m.lazy_ema = m.n_grid > (8u << 20);
-    if (const char* e = std::getenv("MON_LAZY_EMA")) m.lazy_ema = std::atoi(e) != 0;
     if (const char* e = std::getenv("MON_BACKEND")) m.backend = std::atoi(e) ? (fused_supported(m.nd, S, m.oc.R) ? 1 : 0) : 0;
     HIPCHECK(hipDeviceSynchronize());
     return MON_OK;
@@ -253,7 +256,7 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
         } else {
             if (m.scatter_pending) hipMemsetAsync(m.d_state->n_scatter, 0, sizeof(m.d_state->n_scatter), s);      // stage-wise debugging: a forward/backward without an optimizer step after it
-            launch_fused_train(s, m.lf, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask, m.d_frag_train, m.big_active ? m.big_switch : 0u);
+            launch_fused_train(s, m.lf, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask, m.d_frag_train, m.big_active ? m.big_switch : 0u, m.d_touched);
             m.scatter_pending = true;
         }
     }
@@ -262,7 +265,7 @@ static void enqueue_iteration(Model& m, int stages) {
         const bool folded = m.lds_mask && fold_reduce;                 // the scatter workgroups also sum the dW partial rows
         if (m.lds_mask) { ProfScope ps(m, MON_K_SCATTER); launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.d_gpart, m.n_grid / 2, m.d_state,
                                                                                 folded ? m.d_dw_partials : nullptr, fused_train_grid(m.nd, m.oc.R), m.P.gmlp); }
-        if (m.big_active) { ProfScope ps(m, MON_K_SCATTER); launch_big_scatter(s, m.lt, m.lf, m.nd, m.lds_mask, m.d_de_soa, m.d_x_soa, B, m.d_state, m.big_switch, m.d_big_ws, m.P.ggrid); }
+        if (m.big_active) { ProfScope ps(m, MON_K_SCATTER); launch_big_scatter(s, m.lt, m.lf, m.nd, m.lds_mask, m.d_de_soa, m.d_x_soa, B, m.d_state, m.big_switch, m.d_big_ws, m.P.ggrid, m.d_touched ? m.d_touched + (m.nd.n_mlp >> 3) : nullptr); }
         if (!folded) { ProfScope ps(m, MON_K_REDUCE); launch_reduce_partials(s, m.d_dw_partials, fused_train_grid(m.nd, m.oc.R), m.nd.n_mlp + 64, m.nd.n_mlp, m.P.gmlp, m.d_state); }
     }
     if (stages & 4) {      // Trainer::optimizer_step :1644
@@ -271,6 +274,10 @@ static void enqueue_iteration(Model& m, int stages) {
         if (m.backend == 1 && m.lds_mask) { P.gpart = m.d_gpart; P.part_stride = m.n_grid; P.sl = m.scatter; P.all_levels_dense = (m.lds_mask == ((1u << m.nd.L) - 1u)) ? 1 : 0; }
         const bool lazy = m.lazy_ema && !(P.gpart && P.all_levels_dense);
         P.ema_step = lazy ? m.d_ema_step : nullptr; if (lazy) m.ema_pending = true;
+        if (lazy && m.backend == 1 && m.d_touched && (m.lds_mask & (m.lds_mask + 1u)) == 0u) {      // (the LDS-scattered levels are a prefix: sizes grow with the level)              // every writer of ggrid on the fused path sets the chunk flags; the unfused grid backward does not
+            P.touched = m.d_touched; uint32_t first_big = 0; while (first_big < (uint32_t)m.nd.L && ((m.lds_mask >> first_big) & 1u)) ++first_big;
+            P.first_flag_chunk = (m.nd.n_mlp + 2u * m.lt.offset[first_big]) >> 3;
+        }
         OptimNext nx{};
         static const bool fold = !(std::getenv("MON_FOLD_NEXT") && std::atoi(std::getenv("MON_FOLD_NEXT")) == 0);
         if (m.backend == 1 && fold) {

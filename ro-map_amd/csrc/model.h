@@ -66,6 +66,8 @@ struct ParamPtrs {
     const uint16_t* gpart; uint32_t part_stride;                    // fused backend: dense fp16 partial gradient tables from k_grid_scatter (stride in halves); nullptr = unused
     ScatterLevels sl;                                               // per-level partial-table counts
     uint32_t* ema_step;                                             // lazy EMA (large tables): per 8-parameter chunk, the optimizer step its EMA is current for; nullptr = eager EMA
+    uint8_t* touched; uint32_t first_flag_chunk;                    // lazy EMA + fused backend: one byte per 8-parameter chunk, set by whoever adds into ggrid (k_fused_train's atomics, k_big_accum),
+                                                                    // read and cleared by k_optimizer instead of scanning ggrid; chunks below first_flag_chunk (MLP, LDS-scattered levels) are always visited
     int all_levels_dense;                                           // every level is LDS-scattered (no global-atomic table in use)
 };
 
@@ -118,14 +120,14 @@ void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_par
 bool fused_supported(const NetDims& nd, uint32_t S, uint32_t R);
 uint32_t fused_train_grid(const NetDims& nd, uint32_t R);
 void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
-                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch);
+                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched);
 uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl);
 uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd);
 void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
                          const float* partials_or_null, uint32_t n_partials, float* gmlp);   // partials != null: also sums the dW partial rows (k_reduce_partials folded in)
 size_t big_scatter_workspace_bytes(const LevelTable& lt, const NetDims& nd, uint32_t lds_mask, uint32_t B);
 void launch_big_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, uint32_t lds_mask, const uint16_t* de_soa, const float* x_soa, uint32_t B,
-                        const DevState* st, uint32_t big_switch, void* workspace, uint16_t* ggrid);
+                        const DevState* st, uint32_t big_switch, void* workspace, uint16_t* ggrid, uint8_t* touched_grid);
 void launch_fused_render(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask, uint16_t* frag_image, int build_image);
 void launch_build_frag_image(hipStream_t s, const uint16_t* params, const NetDims& nd, uint16_t* image);
 void launch_candidates_and_frags(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st, const uint16_t* params, const NetDims& nd, uint16_t* frag_image);
@@ -149,7 +151,7 @@ struct Model {
     hipStream_t train_stream = nullptr;      // mpTrainStream :1268; inference (render, mesh) runs on the same stream: the reference's mpInferenceStream is only ever used from the object's own thread between training calls
     ParamPtrs P{}; BatchPtrs B{}; DevState* d_state = nullptr; mon_frame_bbox* d_boxes = nullptr;
     uint32_t boxes_cap = 0, n_boxes = 0; uint32_t ws_samples = 0, ws_rays = 0;
-    float* d_dw_partials = nullptr; uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr; uint16_t* d_gpart = nullptr; uint16_t* d_frag_train = nullptr; uint32_t* d_ema_step = nullptr; uint16_t* d_frag_render = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0; uint8_t* d_big_ws = nullptr; uint32_t big_switch = 0; bool big_active = false; float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr; size_t out_cap = 0;
+    float* d_dw_partials = nullptr; uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr; uint16_t* d_gpart = nullptr; uint16_t* d_frag_train = nullptr; uint32_t* d_ema_step = nullptr; uint8_t* d_touched = nullptr; uint16_t* d_frag_render = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0; uint8_t* d_big_ws = nullptr; uint32_t big_switch = 0; bool big_active = false; float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr; size_t out_cap = 0;
     std::vector<void*> allocs;
     DevState h_state{}; int backend = 0; bool profiling = false; int fused_dump = 0;
     bool lazy_ema = false, ema_pending = false;   // large tables: EMA of untouched chunks is brought up to date on demand (k_ema_finalize)
