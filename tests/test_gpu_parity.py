@@ -363,6 +363,10 @@ def test_binned_large_level_scatter_is_exact_and_deterministic(pkg, orc, small_s
         return [ln.split()[2] for ln in r.stdout.strip().split("\n") if ln.startswith("steps+")]
     a = run({"MON_BIG_SWITCH": "1"}); b = run({"MON_BIG_SWITCH": "1"})
     assert a == b and len(a) == 2, (a, b)
+    # the lazy optimizer finds the touched chunks through the byte flags written next to the gradient table; scanning the table itself
+    # (MON_TOUCHED_FLAGS=0) must train the same parameters bit for bit
+    c = run({"MON_BIG_SWITCH": "1", "MON_TOUCHED_FLAGS": "0"})
+    assert a == c, (a, c)
 
 
 def test_stress_configuration_t22_full_size_properties(pkg, ss):
