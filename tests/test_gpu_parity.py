@@ -369,6 +369,21 @@ def test_binned_large_level_scatter_is_exact_and_deterministic(pkg, orc, small_s
     assert a == c, (a, c)
 
 
+def test_atomic_path_marks_every_touched_chunk(pkg, small_scene, monkeypatch):
+    """tcnn-style global atomics on the large levels (MON_BIG_SWITCH=0 forces them from the first step): every addition into the
+    gradient table also sets its chunk's byte flag, so the lazy optimizer -- which only visits flagged chunks -- must leave the table
+    all zero after each step, and must have stepped some of those entries."""
+    _need_gpu(pkg)
+    monkeypatch.setenv("MON_BIG_SWITCH", "0")
+    kw = dict(rays_per_batch=256, log2_hashmap_size=19, n_neurons=64, n_hidden_layers=1)
+    ds, obj = ge.make_problem(pkg, small_scene, kw); obj.set_backend(1)
+    obj.train(6)
+    gg = obj.buffer("ggrid_h"); st = obj.buffer("steps")
+    assert not gg[gg.size // 2:].any(), "a gradient survived the optimizer: its chunk was not flagged"
+    assert (st[st.size // 2:] > 0).sum() > 1000
+    obj.close(); ds.close()
+
+
 def test_stress_configuration_t22_full_size_properties(pkg, ss):
     """BASELINE configs[4] (T = 2^22: 105 M parameters, a 211 MB fp16 table) at the full batch: far beyond what the oracle finishes in
     seconds, so size-independent properties -- sparse Adam touches only entries that got a gradient, the loss falls, the lazily
