@@ -193,14 +193,22 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                 for (uint32_t w0 = (p.first_flag_chunk >> 2) + c_first - lane; w0 < w_end; w0 += c_stride) {     // wave-uniform trip count
                     const uint32_t w = w0 + lane; uint32_t f = 0u;
                     if (w < w_end) { f = flags[w]; if (f) flags[w] = 0u; }
+                    // queue in ascending chunk order (lane-major: a lane's four chunks are neighbours, the next lane's follow), so that the
+                    // lanes working the queue touch adjacent 32-byte pieces of the state arrays where adjacent chunks are both touched
+                    uint32_t before = 0u, total = 0u;
 #pragma unroll
                     for (uint32_t j = 0; j < 4u; ++j) {
-                        const bool touched = ((f >> (8u * j)) & 0xffu) != 0u; const uint32_t c = 4u * w + j;
-                        const unsigned long long tm = __ballot(touched);
-                        if (tm == 0ull) continue;
-                        const uint32_t pos = qn + (uint32_t)__popcll(tm & ((1ull << lane) - 1ull));
-                        qn += (uint32_t)__popcll(tm);
-                        if (touched) { if (pos < kQueueCap) queue[wave][pos] = c; else update_chunk(c, false, none, none, none); }
+                        const unsigned long long tm = __ballot(((f >> (8u * j)) & 0xffu) != 0u);
+                        before += (uint32_t)__popcll(tm & ((1ull << lane) - 1ull)); total += (uint32_t)__popcll(tm);
+                    }
+                    if (total == 0u) continue;
+                    uint32_t pos = qn + before; qn += total;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) {
+                        if (((f >> (8u * j)) & 0xffu) == 0u) continue;
+                        const uint32_t c = 4u * w + j;
+                        if (pos < kQueueCap) queue[wave][pos] = c; else update_chunk(c, false, none, none, none);
+                        ++pos;
                     }
                 }
             } else {
