@@ -133,6 +133,11 @@ int mon_object_density_grid(mon_object* obj, int rx, int ry, int rz, float* out_
 int mon_object_generate_mesh(mon_object* obj, int res, float thresh, uint32_t* n_verts, uint32_t* n_indices);
 int mon_object_mesh_counts(mon_object* obj, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices);
 int mon_object_get_mesh(mon_object* obj, float* verts, float* normals, uint8_t* colors, uint32_t* indices, int try_lock_only);
+/* Counts + data under one hold of the mesh mutex, bounded by the caller's capacities (in vertices / indices): the form a viewer thread uses
+ * while the object's thread trains and republishes the mesh (counts-then-get is only safe once the threads have ended).  MON_ERR_ARG with
+ * the needed counts in n_* when a buffer is too small; MON_ERR_STATE when try_lock_only and the trainer holds the mesh, or no mesh yet. */
+int mon_object_copy_mesh(mon_object* obj, uint32_t cap_verts, uint32_t cap_indices, float* verts, float* normals, uint8_t* colors, uint32_t* indices,
+                         uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices, int try_lock_only);
 int mon_object_get_mesh_raw(mon_object* obj, float* normals_raw, float* colors_f32);      /* un-normalised normals, float colours (parity tests) */
 int mon_object_save_mesh(mon_object* obj, const char* path);                              /* ".ply" -> ASCII ply, anything else -> obj */
 /* Marching cubes + normals on a caller-supplied lattice (x fastest); buffers may be NULL to query the counts. */
@@ -176,7 +181,7 @@ int mon_offline_get_intrinsics(mon_offline* mgr, float* fx, float* fy, float* cx
 int mon_offline_get_poses(mon_offline* mgr, float* Twc16s, size_t capacity_frames, size_t* n_frames);
 int mon_offline_object_meta(mon_offline* mgr, int idx, int* class_id, float* Tow16, float* aabb_min3, float* aabb_max3, mon_frame_bbox* boxes, size_t capacity_boxes, size_t* n_boxes);
 int mon_offline_set_output_dir(mon_offline* mgr, const char* dir);       /* where the training thread saves <id>.ply (default "./output", nerf.cu:148; "" = do not save) */
-int mon_offline_object(mon_offline* mgr, int idx, mon_object** borrowed); /* GetAllNeRF()[idx]: owned by the manager, do not destroy; only mon_object_get_mesh(try_lock) is safe while its thread trains */
+int mon_offline_object(mon_offline* mgr, int idx, mon_object** borrowed); /* GetAllNeRF()[idx]: owned by the manager, do not destroy; only mon_object_copy_mesh(try_lock) is safe while its thread trains */
 int mon_offline_destroy(mon_offline* mgr);
 /* ---- nerf::NerfManagerOnline (CORE/include/nerf_manager.h:54-90, CORE/src/nerf_manager.cu:133-312) + the online half of nerf::NeRF
  * (nerf.cu:155-253, 406-448): per-object training thread sleeping on a condition variable, training gated on > 10 boxes,
@@ -198,7 +203,7 @@ int mon_online_render(mon_online* mgr, size_t idx, mon_frame_bbox box, const flo
 int mon_online_render_nerfs_test(mon_online* mgr, const char* out_path, size_t idx, const char* const* timestamps, const mon_frame_bbox* boxes,
                                  const float* Twcs16, size_t n, float radius);
 int mon_generate_toc(float theta_deg, float phi_deg, float radius, float* Toc16);   /* NeRF_Model::GenerateToc, nerf_model.cu:2186-2205 */
-int mon_online_object(mon_online* mgr, size_t idx, mon_object** borrowed);  /* DrawMesh(idx) reads this object's CPUMeshData through mon_object_get_mesh(try_lock) */
+int mon_online_object(mon_online* mgr, size_t idx, mon_object** borrowed);  /* DrawMesh(idx) reads this object's CPUMeshData through mon_object_copy_mesh(try_lock) */
 int mon_online_destroy(mon_online* mgr);
 
 /* PNG codec used for the sequence layout (8/16-bit, gray/RGB/RGBA in; gray/RGB out; 16-bit samples big-endian as in the file).

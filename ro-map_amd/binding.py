@@ -78,6 +78,7 @@ _SIGS = {
     "mon_object_generate_mesh": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mon_object_mesh_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mon_object_get_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "mon_object_copy_mesh": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "mon_object_get_mesh_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mon_object_save_mesh": (C.c_int, [C.c_void_p, C.c_char_p]),
     "mon_marching_cubes": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
@@ -245,12 +246,21 @@ class ObjectNeRF:
         _check(lib().mon_object_generate_mesh(self.h, int(res), float(thresh), C.byref(nv), C.byref(ni))); return nv.value, ni.value
 
     def get_mesh(self, try_lock=False, raw=False):
-        """CPUMeshData (common.h:32-41) as a dict of numpy arrays."""
+        """CPUMeshData (common.h:32-41) as a dict of numpy arrays.  Counts and data come from one hold of the mesh mutex
+        (mon_object_copy_mesh), so this is safe from a viewer thread while the object's thread republishes the mesh."""
         nv = C.c_uint32(0); nr = C.c_uint32(0); ni = C.c_uint32(0)
         _check(lib().mon_object_mesh_counts(self.h, C.byref(nv), C.byref(nr), C.byref(ni)))
-        out = dict(verts=np.empty((nv.value, 3), np.float32), normals=np.empty((nv.value, 3), np.float32), colors=np.empty((nv.value, 3), np.uint8),
-                   indices=np.empty(ni.value, np.uint32), n_verts_real=nr.value)
-        _check(lib().mon_object_get_mesh(self.h, _p(out["verts"]), _p(out["normals"]), _p(out["colors"]), _p(out["indices"]), int(try_lock)))
+        for _ in range(8):
+            cv, ci = nv.value, ni.value
+            out = dict(verts=np.empty((cv, 3), np.float32), normals=np.empty((cv, 3), np.float32), colors=np.empty((cv, 3), np.uint8), indices=np.empty(ci, np.uint32))
+            rc = lib().mon_object_copy_mesh(self.h, cv, ci, _p(out["verts"]), _p(out["normals"]), _p(out["colors"]), _p(out["indices"]),
+                                            C.byref(nv), C.byref(nr), C.byref(ni), int(try_lock))
+            if rc == 1 and (nv.value > cv or ni.value > ci):
+                continue                                            # the mesh grew in between: retry with the reported counts
+            _check(rc); break
+        else:
+            raise MonError(1, "get_mesh: mesh kept growing")
+        out = {k: (v[:nv.value] if k != "indices" else v[:ni.value]) for k, v in out.items()}; out["n_verts_real"] = nr.value
         if raw:
             out["normals_raw"] = np.empty((nv.value, 3), np.float32); out["colors_f32"] = np.empty((nv.value, 3), np.float32)
             _check(lib().mon_object_get_mesh_raw(self.h, _p(out["normals_raw"]), _p(out["colors_f32"])))

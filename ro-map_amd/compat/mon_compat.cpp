@@ -1,195 +1,126 @@
-// compat/mon_compat.cpp -- the reference's manager / NeRF classes implemented on the C ABI (include/mon_core.h).
-// Compiled inside the RO-MAP tree (needs Eigen, OpenCV, GLEW); see INTEGRATION.md.  Behaviour follows
-// CORE/src/nerf_manager.cu and CORE/src/nerf.cu: thread per object, round-robin device choice, fixed 10 x 500
-// offline iterations, cond-var driven online training gated on more than 10 boxes, fatal errors = cerr + exit(0).
-#include <unistd.h>
-#include <fstream>
+// compat/mon_compat.cpp -- the reference's manager / NeRF classes as a thin layer over the C ABI's manager entry points
+// (include/mon_core.h: mon_offline_*, mon_online_*, mon_object_copy_mesh).  Compiled inside the RO-MAP tree (Eigen, OpenCV core
+// for the cv::Mat signatures, GLEW for DrawCPUMesh); see INTEGRATION.md.  Threads, datasets, PNG I/O and training live in
+// libmon_core.so; fatal errors keep the reference's convention: message on cerr, exit(0) (nerf_manager.cu:21-25).
+// tests/test_compat_shim.py compiles this file against minimal stand-ins of the three third-party headers and runs the consumers'
+// call sequences (MON/main.cpp:322-340, REF/src/System.cc:120-138,567,610, LocalMapping.cc:1172-1280) on the device.
+#include <cstdlib>
+#include <cstring>
 #include <iostream>
-#include <sstream>
-#include <opencv2/imgcodecs.hpp>
-#include <opencv2/imgproc.hpp>
 #include "nerf_manager.h"
 
 namespace nerf {
 
-static void die(const char* what) { std::cerr << what << ": " << mon_last_error() << std::endl; exit(0); }   // nerf_manager.cu:21-25
+static_assert(sizeof(FrameIdAndBbox) == sizeof(mon_frame_bbox), "FrameIdAndBbox must stay layout-compatible with mon_frame_bbox");
 
-NeRF::~NeRF() { if (mpObject) mon_object_destroy(mpObject); }
-vector<FrameIdAndBbox> NeRF::GetFrameIdAndBBox() { return vector<FrameIdAndBbox>(mFrameIdBbox.begin(), mFrameIdBbox.begin() + mnBbox); }
-
-void NeRF::UpdateCPUMesh() {                                                  // GenerateMesh + TransCPUMesh, nerf.cu:138-145 / 228-236
-    uint32_t nv = 0, ni = 0;
-    if (mon_object_generate_mesh(mpObject, 64, 2.0f, &nv, &ni)) die("GenerateMesh");      // marching_cubes.h:30-31
-    std::unique_lock<std::mutex> lock(mCPUMeshData.mesh_mutex);
-    mCPUMeshData.verts.resize(3 * nv); mCPUMeshData.normals.resize(3 * nv); mCPUMeshData.colors.resize(3 * nv); mCPUMeshData.indices.resize(ni);
-    mon_object_get_mesh(mpObject, mCPUMeshData.verts.data(), mCPUMeshData.normals.data(), mCPUMeshData.colors.data(), mCPUMeshData.indices.data(), 0);
-    mCPUMeshData.have_reslult = true;
-}
+static void die(const char* what) { std::cerr << what << ": " << mon_last_error() << std::endl; exit(0); }
 
 void NeRF::DrawCPUMesh() {                                                    // nerf.cu:484-507
-    std::unique_lock<std::mutex> lock(mCPUMeshData.mesh_mutex, std::try_to_lock);
-    if (!lock.owns_lock() || !mCPUMeshData.have_reslult) return;
+    CPUMeshData& cm = mCPUMeshData;
+    std::unique_lock<std::mutex> lock(cm.mesh_mutex, std::try_to_lock);
+    if (!lock.owns_lock() || !mpObject) return;
+    // refresh the host copy if the training thread is not publishing right now (TransCPUMesh fills CPUMeshData there, nerf.cu:138-145)
+    uint32_t nv = (uint32_t)(cm.verts.size() / 3), ni = (uint32_t)cm.indices.size(), need_v = 0, need_r = 0, need_i = 0;
+    int rc = mon_object_copy_mesh(mpObject, nv, ni, cm.verts.data(), cm.normals.data(), cm.colors.data(), cm.indices.data(), &need_v, &need_r, &need_i, 1);
+    if (rc == MON_ERR_ARG && (need_v > nv || need_i > ni)) {                   // the mesh grew: make room and try once more
+        cm.verts.resize(3 * (size_t)need_v); cm.normals.resize(3 * (size_t)need_v); cm.colors.resize(3 * (size_t)need_v); cm.indices.resize(need_i);
+        rc = mon_object_copy_mesh(mpObject, need_v, need_i, cm.verts.data(), cm.normals.data(), cm.colors.data(), cm.indices.data(), &need_v, &need_r, &need_i, 1);
+    }
+    if (rc == MON_OK) {
+        cm.verts.resize(3 * (size_t)need_v); cm.normals.resize(3 * (size_t)need_v); cm.colors.resize(3 * (size_t)need_v); cm.indices.resize(need_i);
+        cm.have_reslult = true;
+    }
+    if (!cm.have_reslult || cm.indices.empty()) return;
     glEnableClientState(GL_VERTEX_ARRAY); glEnableClientState(GL_NORMAL_ARRAY); glEnableClientState(GL_COLOR_ARRAY);
-    glVertexPointer(3, GL_FLOAT, 0, mCPUMeshData.verts.data()); glColorPointer(3, GL_UNSIGNED_BYTE, 0, mCPUMeshData.colors.data());
-    glNormalPointer(GL_FLOAT, 0, mCPUMeshData.normals.data());
-    glDrawElements(GL_TRIANGLES, (GLsizei)mCPUMeshData.indices.size(), GL_UNSIGNED_INT, mCPUMeshData.indices.data());
+    glVertexPointer(3, GL_FLOAT, 0, cm.verts.data()); glColorPointer(3, GL_UNSIGNED_BYTE, 0, cm.colors.data());
+    glNormalPointer(GL_FLOAT, 0, cm.normals.data());
+    glDrawElements(GL_TRIANGLES, (GLsizei)cm.indices.size(), GL_UNSIGNED_INT, cm.indices.data());
     glDisableClientState(GL_VERTEX_ARRAY); glDisableClientState(GL_NORMAL_ARRAY); glDisableClientState(GL_COLOR_ARRAY);
-}
-
-void NeRF::TrainOffline(const int iterations) {                               // nerf.cu:120-152
-    mon_object_add_boxes(mpObject, reinterpret_cast<const mon_frame_bbox*>(mFrameIdBbox.data()), mnBbox);
-    for (int i = 1; i <= iterations; ++i) {
-        float loss = 0.f;
-        if (mon_object_train(mpObject, 500, &loss)) die("Train_Step");       // nerf_model.cu:1635
-        std::cout << "Id: " << mId << " Step: " << i * 500 << " loss: " << loss << std::endl;
-        if (i % 2 == 0) UpdateCPUMesh();
-    }
-    mon_object_save_mesh(mpObject, ("./output/" + std::to_string(mId) + ".ply").c_str());   // nerf.cu:148-149
-}
-
-void NeRF::UpdateFrameBBox(const vector<FrameIdAndBbox>& v, const int train_step) {   // nerf.cu:406-421
-    std::unique_lock<std::mutex> lock(mUpdateBbox);
-    for (size_t i = 0; i < v.size(); ++i) mFrameIdBbox[mnBbox + i] = v[i];
-    mnBbox += v.size(); mnTrainStep = train_step; mCond.notify_all();
-}
-void NeRF::RequestFinish() {                                                 // nerf.cu:443-448; passing through mUpdateBbox keeps the notification from falling between TrainOnline's test and its wait
-    { std::unique_lock<std::mutex> lock(mFinishMutex); mbFinishRequested = true; }
-    { std::unique_lock<std::mutex> lock(mUpdateBbox); }
-    mCond.notify_all();
-}
-bool NeRF::CheckFinish() { std::unique_lock<std::mutex> lock(mFinishMutex); return mbFinishRequested; }
-
-void NeRF::TrainOnline() {                                                    // nerf.cu:187-253
-    int train_step_count = 0;
-    while (true) {
-        int train_step = 0;
-        {
-            std::unique_lock<std::mutex> lock(mUpdateBbox);
-            if (mnBbox == mnUploaded && !CheckFinish()) mCond.wait(lock);
-            if (mnBbox > mnUploaded) {
-                mon_object_add_boxes(mpObject, reinterpret_cast<const mon_frame_bbox*>(mFrameIdBbox.data() + mnUploaded), mnBbox - mnUploaded);
-                mnUploaded = mnBbox; train_step = mnTrainStep; mnTrainStep = 0;
-            }
-        }
-        if (mnUploaded > 10)
-            for (int i = 0; i < train_step; ++i) {
-                std::unique_lock<std::mutex> dl(*mpDatasetMutex);             // GenerateBatch under the dataset mutex (nerf_model.cu:1675-1678)
-                float loss = 0.f; mon_object_train(mpObject, mnIteration, &loss); dl.unlock();
-                if (++train_step_count % 2 == 0) UpdateCPUMesh();
-            }
-        if (CheckFinish()) break;
-        usleep(3000);
-    }
-    float loss = 0.f; mon_object_train(mpObject, mnIteration, &loss); UpdateCPUMesh();
-    std::cout << "Id: " << mId << " finished! " << std::endl;
-}
-
-void NeRF::RenderTestImg(const string out_path, const vector<string>& stamps, const vector<Eigen::Matrix4f>& Twcs, const vector<FrameIdAndBbox>& boxes, const float) {
-    const string dir = out_path + "/" + std::to_string(mId);                  // nerf.cu:255-349 (test images + mesh; the 360 video is a "next" row)
-    if (system(("mkdir -p " + dir + "/test_img " + dir + "/test_depth " + dir + "/test_mask").c_str()) != 0) throw std::runtime_error("mkdir error");
-    for (size_t i = 0; i < stamps.size(); ++i) {
-        const FrameIdAndBbox& b = boxes[i];
-        cv::Mat img(b.h, b.w, CV_32FC3), depth(b.h, b.w, CV_32FC1), mask(b.h, b.w, CV_32FC1);
-        mon_frame_bbox mb{ b.FrameId, b.x, b.y, b.h, b.w };
-        if (mon_object_render(mpObject, mb, Twcs[i].data(), 0, img.ptr<float>(), depth.ptr<float>(), mask.ptr<float>(), 0)) die("Render");
-        cv::cvtColor(img, img, cv::COLOR_RGB2BGR); img.convertTo(img, CV_8UC3, 255); cv::imwrite(dir + "/test_img/" + stamps[i] + ".png", img);
-        depth.convertTo(depth, CV_16UC1, 20000); cv::imwrite(dir + "/test_depth/" + stamps[i] + ".png", depth);
-        mask.convertTo(mask, CV_8UC1, 255); cv::imwrite(dir + "/test_mask/" + stamps[i] + ".png", mask);
-    }
-    if (mCPUMeshData.have_reslult) { UpdateCPUMesh(); mon_object_save_mesh(mpObject, (dir + "/obj.ply").c_str()); }   // nerf.cu:397-403
 }
 
 // ------------------------------------------------------------------ offline manager (nerf_manager.cu:9-131)
 NerfManagerOffline::NerfManagerOffline(const string datasetPath, const string cfg, bool useDenseDepth)
-    : msNetworkConfigFile(cfg), msDatasetPath(datasetPath), mbUseDenseDepth(useDenseDepth) {}
-bool NerfManagerOffline::Init() {
-    if (mon_device_count(&mNumGPU)) die("Can not Detect GPU");
-    if (mon_config_from_json(msNetworkConfigFile.c_str(), &mConfig)) die("Read Network Config error");
-    mConfig.use_depth = mbUseDenseDepth; return true;
+    : msNetworkConfigFile(cfg), msDatasetPath(datasetPath), mbUseDenseDepth(useDenseDepth) {
+    if (mon_offline_create(datasetPath.c_str(), cfg.c_str(), useDenseDepth ? 1 : 0, &mpManager)) die("NerfManagerOffline");
 }
-bool NerfManagerOffline::ReadDataset() {                                      // nerf_data.cu:27-235
-    cv::FileStorage fs(msDatasetPath + "/config.yaml", cv::FileStorage::READ);
-    if (!fs.isOpened()) { std::cerr << "Failed to open settings file" << std::endl; exit(0); }
-    mfx = fs["Camera.fx"]; mfy = fs["Camera.fy"]; mcx = fs["Camera.cx"]; mcy = fs["Camera.cy"]; mH = fs["Camera.H"]; mW = fs["Camera.W"];
-    const float depthScale = mbUseDenseDepth ? (float)fs["DepthMapFactor"] : 1.f;
-    std::ifstream fi(msDatasetPath + "/img.txt"), fg(msDatasetPath + "/groundtruth.txt"); string line; vector<string> names;
-    std::getline(fi, line);
-    while (std::getline(fi, line)) { if (line.empty()) continue; std::stringstream ss(line); string st, nm; ss >> st >> nm; mStampToIdx[st] = (uint32_t)names.size(); names.push_back(nm); }
-    std::getline(fg, line);
-    while (std::getline(fg, line)) {
-        if (line.empty()) continue; std::stringstream ss(line); string st; float tx, ty, tz, qx, qy, qz, qw; ss >> st >> tx >> ty >> tz >> qx >> qy >> qz >> qw;
-        Eigen::Matrix4f T = Eigen::Matrix4f::Identity(); T.topLeftCorner(3, 3) = Eigen::Quaternionf(qw, qx, qy, qz).toRotationMatrix(); T.col(3).head<3>() = Eigen::Vector3f(tx, ty, tz);
-        mvTwc.push_back(T);
-    }
-    if (mvTwc.empty()) { std::cerr << "Load dataset error...No images..." << std::endl; return false; }
-    for (int g = 0; g < mNumGPU; ++g) {                                       // one replica per device (nerf_manager.cu:44-55)
-        mon_dataset* ds = nullptr;
-        if (mon_dataset_create(g, mH, mW, mfx, mfy, mcx, mcy, (uint32_t)mvTwc.size(), mbUseDenseDepth, &ds)) die("DataToGPU");
-        for (size_t i = 0; i < mvTwc.size(); ++i) {
-            cv::Mat bgr = cv::imread(msDatasetPath + "/rgb/" + names[i], cv::IMREAD_COLOR), inst = cv::imread(msDatasetPath + "/instance/" + names[i], cv::IMREAD_UNCHANGED), depth;
-            if (bgr.empty() || inst.empty()) { std::cerr << "Can not read image" << std::endl; exit(0); }
-            if (mbUseDenseDepth) { cv::imread(msDatasetPath + "/depth/" + names[i], cv::IMREAD_UNCHANGED).convertTo(depth, CV_32FC1, depthScale); }
-            if (mon_dataset_add_frame(ds, (uint32_t)i, bgr.data, 3, 1, inst.data, mbUseDenseDepth ? depth.ptr<float>() : nullptr, mvTwc[i].data())) die("DataToGPU");
-        }
-        mvpDataset.push_back(ds);
-    }
+NerfManagerOffline::~NerfManagerOffline() { mon_offline_destroy(mpManager); }
+bool NerfManagerOffline::Init() { if (mon_offline_init(mpManager)) die("Init"); return true; }                       // "Can not Detect GPU" / config errors are fatal (:21-25)
+bool NerfManagerOffline::ReadDataset() {                                                                              // nerf_data.cu:27-235
+    if (mon_offline_read_dataset(mpManager)) { std::cerr << "Load dataset error: " << mon_last_error() << std::endl; return false; }
     return true;
 }
-bool NerfManagerOffline::CreateNeRF(const string objectFile) {               // nerf_manager.cu:64-92, nerf.cu:58-118
-    std::ifstream f(objectFile); if (!f) { std::cerr << "object file error..." << std::endl; return false; }
-    auto n = std::make_shared<NeRF>(); n->mId = (int)mvpNeRFs.size(); n->mGPUid = n->mId % mNumGPU; mvpNeRFs.push_back(n);
-    string line; std::getline(f, line); std::getline(f, line); std::stringstream ss(line); float v[10]; ss >> n->mClass; for (float& x : v) ss >> x;
-    Eigen::Matrix4f Two = Eigen::Matrix4f::Identity(); Two.topLeftCorner(3, 3) = Eigen::Quaternionf(v[6], v[3], v[4], v[5]).toRotationMatrix(); Two.col(3).head<3>() = Eigen::Vector3f(v[0], v[1], v[2]);
-    n->mObjTow = Two.inverse(); n->mBoundingBox.min = Eigen::Vector3f(-v[7], -v[8], -v[9]); n->mBoundingBox.max = Eigen::Vector3f(v[7], v[8], v[9]);
-    while (std::getline(f, line)) { if (line.empty()) continue; std::stringstream s2(line); string st; FrameIdAndBbox b; s2 >> st >> b.x >> b.y >> b.h >> b.w; b.FrameId = mStampToIdx[st]; n->mFrameIdBbox.push_back(b); }
-    n->mnBbox = n->mFrameIdBbox.size();
-    if (mon_object_create(mvpDataset[n->mGPUid], &mConfig, n->mClass, n->mObjTow.data(), n->mBoundingBox.min.data(), n->mBoundingBox.max.data(), &n->mpObject)) die("Create NeRF error");
-    mvThreads.emplace_back(&NeRF::TrainOffline, n, 10);
+bool NerfManagerOffline::CreateNeRF(const string objectFile) {                                                        // nerf_manager.cu:64-92, nerf.cu:58-118
+    if (mon_offline_create_nerf(mpManager, objectFile.c_str())) { std::cerr << "Create NeRF error: " << mon_last_error() << std::endl; return false; }
+    auto n = std::make_shared<NeRF>(); const int idx = (int)mvpNeRFs.size(); n->mId = idx;
+    size_t nb = 0;
+    if (mon_offline_object_meta(mpManager, idx, &n->mClass, n->mObjTow.data(), n->mBoundingBox.min.data(), n->mBoundingBox.max.data(), nullptr, 0, &nb)) die("CreateNeRF");
+    n->mFrameIdBbox.resize(nb);
+    if (mon_offline_object_meta(mpManager, idx, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<mon_frame_bbox*>(n->mFrameIdBbox.data()), nb, &nb) ||
+        mon_offline_object(mpManager, idx, &n->mpObject)) die("CreateNeRF");
+    mvpNeRFs.push_back(n);
     return true;
 }
-bool NerfManagerOffline::WaitThreadsEnd() { if (mvThreads.empty()) return false; for (auto& t : mvThreads) t.join(); return true; }
+bool NerfManagerOffline::WaitThreadsEnd() {                                                                           // nerf_manager.cu:94-102
+    if (mvpNeRFs.empty()) return false;
+    if (mon_offline_wait_threads_end(mpManager)) die("WaitThreadsEnd");
+    return true;
+}
+vector<Eigen::Matrix4f> NerfManagerOffline::GetAllTwc() {
+    size_t n = 0; mon_offline_get_poses(mpManager, nullptr, 0, &n);
+    std::vector<float> flat(16 * n); vector<Eigen::Matrix4f> out(n);
+    if (n && mon_offline_get_poses(mpManager, flat.data(), n, &n)) die("GetAllTwc");
+    for (size_t i = 0; i < n; ++i) std::memcpy(out[i].data(), &flat[16 * i], 64);                                      // both sides column-major
+    return out;
+}
+void NerfManagerOffline::GetIntrinsics(float& fx, float& fy, float& cx, float& cy) { mon_offline_get_intrinsics(mpManager, &fx, &fy, &cx, &cy, nullptr, nullptr); }
 
 // ------------------------------------------------------------------ online manager (nerf_manager.cu:133-312)
-NerfManagerOnline::NerfManagerOnline(const string cfg, bool UseSparseDepth, int iters) : mNetworkConfigFile(cfg), mbUseSparseDepth(UseSparseDepth), mnTrainStepIterations(iters) {}
-bool NerfManagerOnline::Init() {
-    if (mon_device_count(&mNumGPU)) die("Can not Detect GPU");
-    if (mon_config_from_json(mNetworkConfigFile.c_str(), &mConfig)) die("Read Network Config error");
-    mConfig.use_depth = mbUseSparseDepth; return true;
+NerfManagerOnline::NerfManagerOnline(const string cfg, bool UseSparseDepth, int iters)
+    : mNetworkConfigFile(cfg), mbUseSparseDepth(UseSparseDepth), mnTrainStepIterations(iters) {
+    if (mon_online_create(cfg.c_str(), UseSparseDepth ? 1 : 0, iters, &mpManager)) die("NerfManagerOnline");
 }
+NerfManagerOnline::~NerfManagerOnline() { mon_online_destroy(mpManager); }
+bool NerfManagerOnline::Init() { if (mon_online_init(mpManager)) die("Init"); return true; }
 void NerfManagerOnline::DatasetInit(float fx, float fy, float cx, float cy, int H, int W, size_t imgs) {
-    mnImages = imgs; mvDatasetMutex.resize(mNumGPU);
-    for (int g = 0; g < mNumGPU; ++g) { mon_dataset* ds = nullptr; if (mon_dataset_create(g, H, W, fx, fy, cx, cy, (uint32_t)imgs, mbUseSparseDepth, &ds)) die("InitDataToGPU"); mvpDataset.push_back(ds); }
+    if (mon_online_dataset_init(mpManager, fx, fy, cx, cy, H, W, imgs)) die("InitDataToGPU");
 }
 void NerfManagerOnline::NewFrameToDataset(unsigned int imgId, const string stamp, cv::Mat& img, cv::Mat& instance, const cv::Mat& depth, const Eigen::Matrix4f& pose) {
-    mStampToIdx[stamp] = imgId;                                               // nerf_data.cu:284
-    for (int g = 0; g < mNumGPU; ++g) {
-        for (auto& m : mvDatasetMutex[g]) m->lock();                          // writers exclude every object's GenerateBatch on that device
-        const int rc = mon_dataset_add_frame(mvpDataset[g], imgId, img.data, img.channels(), 1, instance.data, mbUseSparseDepth ? depth.ptr<float>() : nullptr, pose.data());
-        for (auto& m : mvDatasetMutex[g]) m->unlock();
-        if (rc) die("FrameDataToGPU");
-    }
+    // 8-bit BGR(A) colour, 8-bit instance ids, CV_32FC1 z-depth in metres with 0 = no sample (nerf_data.cu:279-339; callers pass clones, LocalMapping.cc:1112-1113)
+    const cv::Mat c = img.isContinuous() ? img : img.clone(), s = instance.isContinuous() ? instance : instance.clone();
+    const cv::Mat z = (mbUseSparseDepth && !depth.isContinuous()) ? depth.clone() : depth;
+    if (mon_online_new_frame(mpManager, imgId, stamp.c_str(), c.data, c.channels(), s.data, mbUseSparseDepth ? z.ptr<float>() : nullptr, pose.data())) die("FrameDataToGPU");
 }
 size_t NerfManagerOnline::CreateNeRF(const int Class, const Eigen::Matrix4f& ObjTow, const nerf::BoundingBox& box) {
-    auto n = std::make_shared<NeRF>(); const size_t idx = mvpNeRFs.size(); mvpNeRFs.push_back(n);
-    n->mId = (int)idx; n->mGPUid = mNextGPU; mNextGPU = (mNextGPU + 1) % mNumGPU; n->mClass = Class; n->mObjTow = ObjTow; n->mnIteration = mnTrainStepIterations;
-    const float k = (Class == 41 || Class == 73) ? 1.2f : 1.1f;               // SetAttributes, nerf.cu:163-172
-    n->mBoundingBox.min = k * box.min; n->mBoundingBox.max = k * box.max; n->mFrameIdBbox.resize(mnImages);
-    mvDatasetMutex[n->mGPUid].emplace_back(new std::mutex()); n->mpDatasetMutex = mvDatasetMutex[n->mGPUid].back().get();
-    if (mon_object_create(mvpDataset[n->mGPUid], &mConfig, Class, n->mObjTow.data(), n->mBoundingBox.min.data(), n->mBoundingBox.max.data(), &n->mpObject)) die("Create NeRF error");
-    mvThreads.emplace_back(&NeRF::TrainOnline, n);
+    size_t idx = 0;                                                           // the 1.1x / 1.2x inflation of SetAttributes (nerf.cu:163-172) is applied behind the C ABI
+    if (mon_online_create_nerf(mpManager, Class, ObjTow.data(), box.min.data(), box.max.data(), &idx)) die("Create NeRF error");
+    auto n = std::make_shared<NeRF>(); n->mId = (int)idx; n->mClass = Class; n->mObjTow = ObjTow;
+    const float k = (Class == 41 || Class == 73) ? 1.2f : 1.1f;
+    for (int a = 0; a < 3; ++a) { n->mBoundingBox.min.data()[a] = k * box.min.data()[a]; n->mBoundingBox.max.data()[a] = k * box.max.data()[a]; }
+    if (mon_online_object(mpManager, idx, &n->mpObject)) die("Create NeRF error");
+    mvpNeRFs.push_back(n);
     return idx;
 }
-int NerfManagerOnline::GetFrameIdx(double t) { auto it = mStampToIdx.find(std::to_string(t)); return it == mStampToIdx.end() ? -1 : (int)it->second; }   // nerf_manager.cu:288-296
-void NerfManagerOnline::UpdateNeRFBbox(const size_t idx, const vector<nerf::FrameIdAndBbox>& v, const int train_step) { if (!v.empty()) mvpNeRFs[idx]->UpdateFrameBBox(v, train_step); }
+int NerfManagerOnline::GetFrameIdx(double t) {                                // nerf_manager.cu:288-296: the key is std::to_string(double) on both sides
+    int idx = -1; mon_online_get_frame_idx(mpManager, std::to_string(t).c_str(), &idx); return idx;
+}
+void NerfManagerOnline::UpdateNeRFBbox(const size_t idx, const vector<nerf::FrameIdAndBbox>& v, const int train_step) {
+    if (v.empty()) return;
+    if (idx < mvpNeRFs.size()) mvpNeRFs[idx]->mFrameIdBbox.insert(mvpNeRFs[idx]->mFrameIdBbox.end(), v.begin(), v.end());
+    if (mon_online_update_nerf_bbox(mpManager, idx, reinterpret_cast<const mon_frame_bbox*>(v.data()), v.size(), train_step)) die("UpdateNeRFBbox");
+}
 void NerfManagerOnline::DrawMesh(size_t idx) { if (idx < mvpNeRFs.size()) mvpNeRFs[idx]->DrawCPUMesh(); }
 bool NerfManagerOnline::WaitThreadsEnd() {
-    if (mvThreads.empty()) return false;
-    for (auto& n : mvpNeRFs) n->RequestFinish();
-    for (auto& t : mvThreads) t.join();
-    std::cout << "All NeRF threads completed ..." << std::endl; return true;
+    if (mvpNeRFs.empty()) return false;
+    if (mon_online_wait_threads_end(mpManager)) die("WaitThreadsEnd");
+    return true;
 }
-void NerfManagerOnline::RenderNeRFsTest(const string out_path, const size_t Idx, const vector<string>& ts, const vector<FrameIdAndBbox>& vb, const vector<Eigen::Matrix4f>& vT, const float radius) {
-    if (!mvpNeRFs.empty()) mvpNeRFs[Idx]->RenderTestImg(out_path, ts, vT, vb, radius);
+void NerfManagerOnline::RenderNeRFsTest(const string out_path, const size_t Idx, const vector<string>& ts, const vector<FrameIdAndBbox>& vb,
+                                        const vector<Eigen::Matrix4f>& vT, const float radius) {
+    if (mvpNeRFs.empty()) return;                                             // nerf_manager.cu:282
+    std::vector<const char*> stamps(ts.size()); std::vector<float> poses(16 * vT.size());
+    for (size_t i = 0; i < ts.size(); ++i) stamps[i] = ts[i].c_str();
+    for (size_t i = 0; i < vT.size(); ++i) std::memcpy(&poses[16 * i], vT[i].data(), 64);
+    if (mon_online_render_nerfs_test(mpManager, out_path.c_str(), Idx, stamps.data(), reinterpret_cast<const mon_frame_bbox*>(vb.data()), poses.data(), ts.size(), radius)) die("RenderNeRFsTest");
 }
 
 }  // namespace nerf

@@ -1,7 +1,6 @@
-// compat/nerf.h -- source-compatible nerf::NeRF (CORE/include/nerf.h:19-89) on top of the C ABI.
+// compat/nerf.h -- source-compatible nerf::NeRF (CORE/include/nerf.h:19-89): what the consumers of libMON touch on an object.
+// The object itself (network, training thread, mesh) lives behind the C ABI (include/mon_core.h); this class is a view on it.
 #pragma once
-#include <condition_variable>
-#include <thread>
 #include "common.h"
 #include "mon_core.h"
 
@@ -9,32 +8,19 @@ namespace nerf {
 
 class NeRF {
 public:
-    NeRF() = default;
-    ~NeRF();
-    // callers: MON/main.cpp:55,149,151,217
-    vector<FrameIdAndBbox> GetFrameIdAndBBox();
+    // callers: MON/main.cpp:55,149,151,217; REF/src/MapDrawer.cc:396 via NerfManagerOnline::DrawMesh
+    vector<FrameIdAndBbox> GetFrameIdAndBBox() { return mFrameIdBbox; }
     Eigen::Matrix4f GetObjTow() { return mObjTow; }
     BoundingBox GetBoundingBox() { return mBoundingBox; }
     CPUMeshData& GetCPUMeshData() { return mCPUMeshData; }
-    void DrawCPUMesh();
-    void UpdateCPUMesh();
-    // online protocol (nerf.cu:187-253, 406-448)
-    void UpdateFrameBBox(const vector<FrameIdAndBbox>& vFrameBbox, const int train_step);
-    void RequestFinish();
-    bool CheckFinish();
-    void TrainOffline(const int iterations);      // 10 x 500 iterations (nerf_manager.cu:89, nerf_model.cu:1635)
-    void TrainOnline();
-    void RenderTestImg(const string out_path, const vector<string>& timestamp, const vector<Eigen::Matrix4f>& testTwc,
-                       const vector<FrameIdAndBbox>& testBbox, const float radius);
+    void DrawCPUMesh();                           // nerf.cu:484-507: try_lock, draw the last mesh the training thread published
 
-    int mId = -1, mGPUid = -1, mClass = 0, mnIteration = 500, mnTrainStep = 0;
+    int mId = -1, mClass = 0;
     Eigen::Matrix4f mObjTow = Eigen::Matrix4f::Identity();
     BoundingBox mBoundingBox;
-    std::vector<FrameIdAndBbox> mFrameIdBbox; size_t mnBbox = 0, mnUploaded = 0;
-    std::mutex mUpdateBbox, mFinishMutex; std::condition_variable mCond; bool mbFinishRequested = false;
+    std::vector<FrameIdAndBbox> mFrameIdBbox;
     CPUMeshData mCPUMeshData;
-    mon_object* mpObject = nullptr;               // replaces shared_ptr<NeRF_Model>
-    std::mutex* mpDatasetMutex = nullptr;         // per-object dataset mutex (nerf_manager.cu:245-247)
+    mon_object* mpObject = nullptr;               // borrowed from the manager (mon_offline_object / mon_online_object)
 };
 
 }  // namespace nerf

@@ -25,6 +25,8 @@ int model_generate_mesh(Model& m, int res, float thresh, uint32_t* n_verts, uint
 int model_mesh_counts(Model& m, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices);
 int model_get_mesh(Model& m, float* verts, float* normals, uint8_t* colors, uint32_t* indices, float* normals_raw, float* colors_f32, int try_only);
 int model_save_mesh(Model& m, const char* path);
+int model_copy_mesh(Model& m, uint32_t cap_verts, uint32_t cap_indices, float* verts, float* normals, uint8_t* colors, uint32_t* indices,
+                    uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices, int try_only);
 int marching_cubes_host(int device, const float* density, int rx, int ry, int rz, float thresh, const float* amin, const float* amax,
                         float* verts, float* normals_raw, uint32_t* indices, uint32_t cap_verts, uint32_t cap_indices, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices);
 int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms_out);
@@ -69,6 +71,10 @@ int mon_object_generate_mesh(mon_object* o, int res, float thresh, uint32_t* n_v
 int mon_object_mesh_counts(mon_object* o, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices) { REQUIRE(o, "object"); return model_mesh_counts(*o->m, n_verts, n_verts_real, n_indices); }
 int mon_object_get_mesh(mon_object* o, float* verts, float* normals, uint8_t* colors, uint32_t* indices, int try_lock_only) { REQUIRE(o, "object"); return model_get_mesh(*o->m, verts, normals, colors, indices, nullptr, nullptr, try_lock_only); }
 int mon_object_get_mesh_raw(mon_object* o, float* normals_raw, float* colors_f32) { REQUIRE(o, "object"); return model_get_mesh(*o->m, nullptr, nullptr, nullptr, nullptr, normals_raw, colors_f32, 0); }
+int mon_object_copy_mesh(mon_object* o, uint32_t cap_verts, uint32_t cap_indices, float* verts, float* normals, uint8_t* colors, uint32_t* indices,
+                         uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices, int try_lock_only) {
+    REQUIRE(o, "object"); return model_copy_mesh(*o->m, cap_verts, cap_indices, verts, normals, colors, indices, n_verts, n_verts_real, n_indices, try_lock_only);
+}
 int mon_object_save_mesh(mon_object* o, const char* path) { REQUIRE(o, "object"); REQUIRE(path, "path"); return model_save_mesh(*o->m, path); }
 int mon_marching_cubes(int device, const float* density, int rx, int ry, int rz, float thresh, const float* aabb_min3, const float* aabb_max3,
                        float* verts, float* normals_raw, uint32_t* indices, uint32_t cap_verts, uint32_t cap_indices, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices) {

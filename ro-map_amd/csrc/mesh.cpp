@@ -138,7 +138,7 @@ int model_generate_mesh(Model& m, int res, float thresh, uint32_t* n_verts, uint
     if (res <= 0) res = 64;                                                   // marching_cubes.h:30
     if (res < 2 || res > 512) { set_error("generate_mesh: res must be in [2, 512]"); return MON_ERR_ARG; }
     HIPCHECK(hipSetDevice(m.device));
-    if (!m.mesh) m.mesh = mesh_state_create(m.device);
+    if (!m.mesh) { set_error("mesh: object has no mesh state"); return MON_ERR_STATE; }       // created with the object (no lazily published pointer for readers to race on)
     MeshState& ms = *m.mesh; hipStream_t s = m.train_stream;
     const size_t res3 = (size_t)res * res * res;
     int rc = mesh_reserve_lattice(ms, res3); if (rc) return rc;
@@ -191,6 +191,24 @@ int model_get_mesh(Model& m, float* verts, float* normals, uint8_t* colors, uint
     if (indices) std::memcpy(indices, ms.indices.data(), ms.indices.size() * 4);
     if (normals_raw) std::memcpy(normals_raw, ms.normals_raw.data(), ms.normals_raw.size() * 4);
     if (colors_f32) std::memcpy(colors_f32, ms.colors_f32.data(), ms.colors_f32.size() * 4);
+    return MON_OK;
+}
+// DrawCPUMesh-safe copy-out: counts and data under ONE hold of the mesh mutex, bounded by the caller's capacities (the training thread may
+// publish a larger mesh between a mon_object_mesh_counts call and the copy).  MON_ERR_ARG + the needed counts when a buffer is too small.
+int model_copy_mesh(Model& m, uint32_t cap_verts, uint32_t cap_indices, float* verts, float* normals, uint8_t* colors, uint32_t* indices,
+                    uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices, int try_only) {
+    if (!m.mesh) { set_error("copy_mesh: no mesh has been generated"); return MON_ERR_STATE; }
+    std::unique_lock<std::mutex> lock(m.mesh->mu, std::defer_lock);
+    if (try_only) { if (!lock.try_lock()) { set_error("copy_mesh: mesh is being updated"); return MON_ERR_STATE; } } else lock.lock();
+    MeshState& ms = *m.mesh;
+    if (!ms.have_result) { set_error("copy_mesh: no mesh has been generated"); return MON_ERR_STATE; }
+    const uint32_t nv = (uint32_t)(ms.verts.size() / 3), ni = (uint32_t)ms.indices.size();
+    if (n_verts) *n_verts = nv; if (n_verts_real) *n_verts_real = ms.cpu_n_real; if (n_indices) *n_indices = ni;
+    if (nv > cap_verts || ni > cap_indices) { set_error("copy_mesh: buffers hold %u vertices / %u indices, the mesh has %u / %u", cap_verts, cap_indices, nv, ni); return MON_ERR_ARG; }
+    if (verts) std::memcpy(verts, ms.verts.data(), ms.verts.size() * 4);
+    if (normals) std::memcpy(normals, ms.normals.data(), ms.normals.size() * 4);
+    if (colors) std::memcpy(colors, ms.colors.data(), ms.colors.size());
+    if (indices) std::memcpy(indices, ms.indices.data(), ms.indices.size() * 4);
     return MON_OK;
 }
 int model_save_mesh(Model& m, const char* path) {

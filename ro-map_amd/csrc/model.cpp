@@ -90,6 +90,7 @@ template <class T> static int dev_alloc(Model& m, T*& p, size_t n, bool zero = t
 
 static constexpr uint32_t kRenderChunkRays = 16384;   // rays per render pass (x 2S samples)
 
+MeshState* mesh_state_create(int device);
 static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id, const float* Tow, const float* amin, const float* amax) {
     m.ds = ds; m.cfg = cfg; m.device = ds->device;
     int rc = level_table_build(cfg, m.lt, m.nd, m.n_grid);
@@ -161,6 +162,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     HIPCHECK(hipMemcpy(m.d_state, &m.h_state, sizeof(DevState), hipMemcpyHostToDevice));
     m.backend = fused_supported(m.nd, S, m.oc.R) ? 1 : 0;
     if (const char* e = std::getenv("MON_BACKEND")) m.backend = std::atoi(e) ? (fused_supported(m.nd, S, m.oc.R) ? 1 : 0) : 0;
+    m.mesh = mesh_state_create(m.device);
     HIPCHECK(hipDeviceSynchronize());
     return MON_OK;
 }
