@@ -139,7 +139,7 @@ static void train_offline_thread(OfflineManager* m, OfflineObject* o) {  // NeRF
         ::mkdir(m->mesh_dir.c_str(), 0755);
         if (nv && model_save_mesh(*o->model, (m->mesh_dir + "/" + std::to_string(o->id) + ".ply").c_str()) != MON_OK) std::fprintf(stderr, "Id: %d mesh not saved: %s\n", o->id, last_error());
     }
-    if (o->rc != MON_OK) o->err = "training failed";
+    if (o->rc != MON_OK) o->err = last_error();            // the message is thread-local: hand it to whoever joins this thread
 }
 
 int offline_create_nerf(OfflineManager& m, const char* object_file) {    // nerf_manager.cu:64-92, nerf.cu:58-118
@@ -274,7 +274,7 @@ struct OnlineObject {
     std::vector<mon_frame_bbox> boxes; size_t n_boxes = 0, n_uploaded = 0; int pending_train_step = 0, iterations = 500;
     std::mutex mu_boxes, mu_finish; std::condition_variable cond; bool finish = false;
     std::mutex* dataset_mutex = nullptr;
-    Model* model = nullptr; mon_object handle{ nullptr }; float last_loss = 0.f; int train_calls = 0; int rc = 0;
+    Model* model = nullptr; mon_object handle{ nullptr }; float last_loss = 0.f; int train_calls = 0; int rc = 0; std::string err;
     int mesh_res = 64; float mesh_thresh = 2.0f;
     std::mutex mu_model;            // a Model is single-threaded: the training thread holds it per train slice / box upload / mesh call, the SLAM-side
                                     // calls (render, object_info, RenderNeRFsTest) while they use the model or read what the thread writes
@@ -336,6 +336,7 @@ static void train_online_thread(OnlineObject* o) {                       // NeRF
         std::lock_guard<std::mutex> lm(o->mu_model); ++o->train_calls;
         if (o->rc == MON_OK) o->rc = model_generate_mesh(*o->model, o->mesh_res, o->mesh_thresh, nullptr, nullptr);       // :247-249
     }
+    if (o->rc != MON_OK) o->err = last_error();
     std::printf("Id: %d finished! \n", o->id);
 }
 
@@ -456,7 +457,7 @@ int mon_online_wait_threads_end(mon_online* h) {                           // :2
     for (auto* o : m.objs) request_finish(o);                               // RequestFinish nerf.cu:443-448
     for (auto& t : m.threads) if (t.joinable()) t.join();
     m.threads.clear(); std::puts("All NeRF threads completed ...");
-    for (auto* o : m.objs) if (o->rc != MON_OK) { set_error("object %d failed", o->id); return o->rc; }
+    for (auto* o : m.objs) if (o->rc != MON_OK) { set_error("object %d: %s", o->id, o->err.c_str()); return o->rc; }
     return MON_OK;
 }
 int mon_online_object_info(mon_online* h, size_t idx, float* loss, int* train_calls, int* device, uint32_t* n_boxes) {
