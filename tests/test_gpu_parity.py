@@ -155,6 +155,25 @@ def test_render_matches_oracle_and_golden(pkg, orc, ss, name, backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_learning_rate_decay_follows_the_oracle(pkg, orc, small_scene, backend):
+    """ExponentialDecay (base.json:9-13: start 20000, interval 10000, base 0.33 -- never reached by the 5000 offline steps, reached
+    online): with the schedule pulled forward to steps 3, 5, 7 the device-side learning rate (DevState, advanced by the optimizer's last
+    block) and the MLP weights follow the oracle through 8 steps."""
+    kw = dict(C1, decay_start=3, decay_interval=2, decay_base=0.5)
+    ds, obj, ref = _pair(pkg, orc, small_scene, kw, backend)
+    p = pattern_params(ref); obj.set_params(p); ref.set_params(p)
+    lrs = []
+    for _ in range(8):
+        obj.train(1); ref.train(1); lrs.append(float(obj.info().learning_rate))
+    # the rate each step leaves behind for the next one: halved after steps 3, 5, 7
+    assert np.allclose(lrs, np.array([1, 1, 0.5, 0.5, 0.25, 0.25, 0.125, 0.125]) * 1e-2, rtol=1e-6), lrs
+    nm = ref.n_mlp; a, b = obj.get_params(0), ref.buffer("master")
+    close_f32(a[:nm], b[:nm], "MLP master weights after 8 decayed steps", 2e-3)
+    assert float((np.abs(a[nm:] - b[nm:]) > 5e-4).mean()) < 2e-2
+    obj.close(); ds.close(); ref.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_training_parity_psnr_c1(pkg, orc, ss, small_scene, backend):
     """BASELINE configs[0]: identical schedules on both sides.  Training is chaotic (fp16 rounding, summation order), so a
     single pair of runs differs by the run-to-run spread (measured on MI355X over 6 sampling seeds, tools/psnr_study.py:
