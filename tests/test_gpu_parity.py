@@ -155,6 +155,38 @@ def test_render_matches_oracle_and_golden(pkg, orc, ss, name, backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_nondefault_hyperparameters_match_oracle(pkg, orc, small_scene, backend):
+    """Everything base.json leaves at its default, moved: level geometry (base resolution 24, per-level scale 1.5: odd resolutions, dense
+    and hashed levels of other sizes), 12 levels on a 32-wide network, a loss scale that is not a power of two (the optimizer's division
+    path), Adam / L2 / EMA constants.  Forward/backward and three optimizer steps against the oracle."""
+    kw = dict(rays_per_batch=256, base_resolution=24, per_level_scale=1.5, n_levels=12, log2_hashmap_size=15, n_neurons=32, n_hidden_layers=1,
+              loss_scale=100.0, learning_rate=5e-3, beta1=0.8, beta2=0.95, epsilon=1e-8, l2_reg=1e-4, ema_decay=0.9)
+    ds, obj, ref = _pair(pkg, orc, small_scene, kw, backend)
+    p = pattern_params(ref); obj.set_params(p); ref.set_params(p)
+    obj.train_stages(1 | 2); ref.generate_batch(); ref.forward_backward()
+    assert int(obj.buffer("state")[2]) == ref.n_valid > 0
+    assert np.array_equal(obj.buffer("E"), ref.buffer("E")), "hash-grid encode must be bit-exact"
+    close_half(obj.buffer("O"), ref.buffer("O"), "network output", frac_ok=1.0 if backend == 0 else 0.999)
+    close_half(obj.buffer("dO"), ref.buffer("dO"), "dL/dO", ulps=4, frac_ok=0.999)
+    gm, rm = obj.buffer("gmlp").astype(np.float64), ref.buffer("gmlp").astype(np.float64)
+    assert np.abs(gm - rm).max() < 5e-3 * np.abs(rm).max()
+    gg = h2f(obj.buffer("ggrid_h")).astype(np.float64); rg = ref.buffer("ggrid").astype(np.float64); ra = ref.buffer("ggrid_abs").astype(np.float64)
+    assert float((np.abs(gg - rg) > 2.0 ** -8 * ra + 2.0 ** -10 * np.abs(rg) + 1e-7).mean()) < 2e-3 and (gg != 0).sum() > 0
+    obj.close(); ds.close(); ref.close()
+    ds, obj, ref = _pair(pkg, orc, small_scene, kw, backend)
+    obj.set_debug_dump(False); obj.set_params(p); ref.set_params(p)
+    for _ in range(3):
+        la = obj.train(1); ref.train(1)
+    assert abs(la - ref.loss) < 5e-3 * max(1.0, abs(ref.loss))
+    nm = ref.n_mlp; a, b = obj.get_params(0), ref.buffer("master")
+    close_f32(a[:nm], b[:nm], "MLP master weights after three steps", 1e-3)
+    assert float((np.abs(a[nm:] - b[nm:]) > 3e-4).mean()) < 1e-2
+    ea, eb = h2f(obj.get_params(2)), h2f(ref.buffer("ema"))
+    assert (np.abs(ea - eb) > 4e-3 * np.maximum(np.abs(eb), 1e-2)).mean() < 1e-2
+    obj.close(); ds.close(); ref.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_learning_rate_decay_follows_the_oracle(pkg, orc, small_scene, backend):
     """ExponentialDecay (base.json:9-13: start 20000, interval 10000, base 0.33 -- never reached by the 5000 offline steps, reached
     online): with the schedule pulled forward to steps 3, 5, 7 the device-side learning rate (DevState, advanced by the optimizer's last
