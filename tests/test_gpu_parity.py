@@ -155,6 +155,27 @@ def test_render_matches_oracle_and_golden(pkg, orc, ss, name, backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_render_crop_sizes_around_the_chunk_boundaries(pkg, orc, ss, backend):
+    """Render works in passes of 16 384 rays: a single pixel, a crop one pixel short of / one pixel past a pass, and a whole 160x120 image
+    (two passes, most rays miss the box) against the oracle; the whole-crop output buffers grow on demand."""
+    sc = ss.make_scene(**SCENE); kw = CFGS["c2s"]
+    ds, obj, ref = _pair(pkg, orc, sc, kw, backend)
+    p = pattern_params(ref); obj.set_params(p); ref.set_params(p)
+    ob = sc.objects[0]["boxes"][2]; v, cx, cy = int(ob[0]), int(ob[1] + ob[4] // 2), int(ob[2] + ob[3] // 2)
+    pose = ss.colmajor(sc.Twc[v])
+    for (x, y, h, w) in [(cx, cy, 1, 1), (0, 0, 127, 129), (0, 0, 113, 145), (0, 0, sc.H, sc.W), (sc.W - 3, sc.H - 2, 2, 3)]:     # 16 383 and 16 385 pixels
+        box = np.array([v, x, y, h, w], np.uint32)
+        rgb, depth, mask = obj.render(box, pose); rrgb, rdepth, rmask = ref.render(box, pose, use_ema=False)
+        assert rgb.shape == (h, w, 3) and mask.shape == (h, w)
+        same = mask == rmask
+        assert (~same).mean() <= 5e-3 + 1.0 / mask.size * (mask.size < 100), (h, w)
+        if same.any():
+            assert np.abs(rgb - rrgb)[same].max() < 4e-3 and np.abs(depth - rdepth)[same].max() < 4e-3, (h, w)
+    assert mask.shape == (2, 3)
+    obj.close(); ds.close(); ref.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_nondefault_hyperparameters_match_oracle(pkg, orc, small_scene, backend):
     """Everything base.json leaves at its default, moved: level geometry (base resolution 24, per-level scale 1.5: odd resolutions, dense
     and hashed levels of other sizes), 12 levels on a 32-wide network, a loss scale that is not a power of two (the optimizer's division
