@@ -5,6 +5,7 @@
 // One std::thread per object, object k on device k mod nGPU (nerf.cu:27-33), one dataset replica per device.
 #include <sys/stat.h>
 #include <unistd.h>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -278,6 +279,14 @@ struct OnlineObject {
     int mesh_res = 64; float mesh_thresh = 2.0f;
     std::mutex mu_model;            // a Model is single-threaded: the training thread holds it per train slice / box upload / mesh call, the SLAM-side
                                     // calls (render, object_info, RenderNeRFsTest) while they use the model or read what the thread writes
+    std::atomic<int> waiters{ 0 };  // callers blocked on mu_model / the dataset mutex: the training thread lets them in between two slices
+                                    // (std::mutex is not fair -- a thread that unlocks and relocks in a loop would starve them)
+};
+
+// Caller-side lock of one of an object's mutexes, announced to its training thread.
+struct AnnouncedLock {
+    std::unique_lock<std::mutex> lock;
+    AnnouncedLock(OnlineObject* o, std::mutex& mu) : lock(mu, std::defer_lock) { o->waiters.fetch_add(1); lock.lock(); o->waiters.fetch_sub(1); }
 };
 
 struct OnlineManager {
@@ -298,12 +307,15 @@ static bool online_check_finish(OnlineObject* o) { std::unique_lock<std::mutex> 
 
 // Train_Step_Online takes the per-object dataset mutex around GenerateBatch of every iteration (nerf_model.cu:1675-1678), so the SLAM
 // thread's NewFrameToDataset never waits longer than one batch generation.  Here an iteration is three stream-ordered launches without
-// host involvement, so the mutex is held for slices of 64 iterations (~6 ms at base.json size) instead of per iteration.
+// host involvement, so the mutexes are held for slices of kOnlineSlice iterations (~1.5 ms at base.json size, one host sync per slice)
+// and anybody waiting for them is let in between two slices.
+static constexpr int kOnlineSlice = 16;
 static int train_sliced(OnlineObject* o) {
     int rc = MON_OK;
-    for (int done = 0; done < o->iterations && rc == MON_OK; done += 64) {
+    for (int done = 0; done < o->iterations && rc == MON_OK; done += kOnlineSlice) {
+        while (o->waiters.load() > 0) std::this_thread::yield();
         std::unique_lock<std::mutex> dl(*o->dataset_mutex); std::lock_guard<std::mutex> lm(o->mu_model);
-        rc = model_train(*o->model, (o->iterations - done) < 64 ? (o->iterations - done) : 64, &o->last_loss, 7);
+        rc = model_train(*o->model, (o->iterations - done) < kOnlineSlice ? (o->iterations - done) : kOnlineSlice, &o->last_loss, 7);
     }
     return rc;
 }
@@ -415,9 +427,13 @@ int mon_online_new_frame(mon_online* h, uint32_t img_id, const char* timestamp, 
     m.stamp_to_idx[timestamp] = img_id;                                   // nerf_data.cu:284
     if (Twc16) m.poses[img_id].assign(Twc16, Twc16 + 16);
     for (int g = 0; g < m.n_dev; ++g) {
-        for (auto& mu : m.ds_mutex[g]) mu->lock();                        // exclude every object's GenerateBatch on that device while the frame lands
+        // The reference locks every object's dataset mutex on the device (its per-frame pointer table is rewritten, nerf_manager.cu:204-216).
+        // Here a NEW frame id lands in a slab row that no kernel can be reading -- 2-D boxes naming it only arrive afterwards
+        // (UpdateNeRFBbox) -- so training is only excluded when an id that is already in use is overwritten.
+        const bool overwrite = img_id < m.ds[g]->max_frames && m.ds[g]->present[img_id];
+        std::vector<std::unique_ptr<AnnouncedLock>> held;
+        if (overwrite) for (auto* o : m.objs) if (o->device == g) held.emplace_back(new AnnouncedLock(o, *o->dataset_mutex));
         const int rc = dataset_add_frame(m.ds[g], img_id, bgr, channels, 1, instance, m.use_depth ? depth : nullptr, Twc16);
-        for (auto& mu : m.ds_mutex[g]) mu->unlock();
         if (rc) return rc;
     }
     return MON_OK;
@@ -462,11 +478,11 @@ int mon_online_wait_threads_end(mon_online* h) {                           // :2
 }
 int mon_online_object_info(mon_online* h, size_t idx, float* loss, int* train_calls, int* device, uint32_t* n_boxes) {
     REQ(h); if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
-    OnlineObject* o = h->m->objs[idx]; std::lock_guard<std::mutex> lm(o->mu_model); if (loss) *loss = o->last_loss; if (train_calls) *train_calls = o->train_calls; if (device) *device = o->device; if (n_boxes) *n_boxes = (uint32_t)o->n_uploaded; return MON_OK;
+    OnlineObject* o = h->m->objs[idx]; AnnouncedLock lm(o, o->mu_model); if (loss) *loss = o->last_loss; if (train_calls) *train_calls = o->train_calls; if (device) *device = o->device; if (n_boxes) *n_boxes = (uint32_t)o->n_uploaded; return MON_OK;
 }
 int mon_online_render(mon_online* h, size_t idx, mon_frame_bbox box, const float* Twc16, float* rgb, float* depth, float* mask) {   // one view of RenderNeRFsTest :280-285
     REQ(h); if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
-    std::lock_guard<std::mutex> lm(h->m->objs[idx]->mu_model);            // between two 64-iteration slices of a running training step
+    AnnouncedLock lm(h->m->objs[idx], h->m->objs[idx]->mu_model);         // let in between two slices of a running training step
     return model_render(*h->m->objs[idx]->model, box, Twc16, 0, rgb, depth, mask, 0);
 }
 // NerfManagerOnline::RenderNeRFsTest -> NeRF::RenderTestImg, nerf.cu:255-404: <out>/<id>/{test_img,test_depth,test_mask}/<stamp>.png,
@@ -479,7 +495,7 @@ int mon_online_render_nerfs_test(mon_online* h, const char* out_path, size_t idx
     OnlineObject* o = m.objs[idx]; const std::string root = std::string(out_path) + "/" + std::to_string(o->id);
     std::vector<mon_frame_bbox> trained;                                  // snapshot of the uploaded boxes (lock order everywhere: mu_boxes, then mu_model)
     { std::lock_guard<std::mutex> lb(o->mu_boxes); trained.assign(o->boxes.begin(), o->boxes.begin() + (ptrdiff_t)o->n_uploaded); }
-    std::lock_guard<std::mutex> lm(o->mu_model);
+    AnnouncedLock lm(o, o->mu_model);
     ::mkdir(out_path, 0755);
     for (const char* sub : { "", "/test_img", "/test_depth", "/test_mask", "/video_img", "/video_depth" }) ::mkdir((root + sub).c_str(), 0755);
     std::ofstream f(root + "/test.txt");

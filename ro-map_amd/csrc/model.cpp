@@ -53,7 +53,7 @@ int dataset_create(int device, int H, int W, float fx, float fy, float cx, float
         return MON_OK;
     };
     if ((rc = alloc())) { dataset_destroy(d); return rc; }          // e.g. out of memory for max_frames images: free what was taken
-    d->staging.resize(px);
+    d->staging.resize(px); d->present.assign(max_frames, 0);
     *out = d; return MON_OK;
 }
 int dataset_add_frame(Dataset* d, uint32_t id, const uint8_t* rgb, int ch, int is_bgr, const uint8_t* inst, const float* depth, const float* Twc) {
@@ -69,6 +69,7 @@ int dataset_add_frame(Dataset* d, uint32_t id, const uint8_t* rgb, int ch, int i
     if (d->use_depth) HIPCHECK(hipMemcpy(d->d_depth + px * id, depth, px * 4, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(d->d_poses + 16 * (size_t)id, Twc, 64, hipMemcpyHostToDevice));
     if (id + 1 > d->n_frames) d->n_frames = id + 1;                 // mFrameDataNum, nerf_data.cu:338
+    d->present[id] = 1;
     return MON_OK;
 }
 int dataset_destroy(Dataset* d) {

@@ -137,7 +137,7 @@ int selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
 struct Dataset {
     int device = 0; Intrinsics K{}; uint32_t max_frames = 0, n_frames = 0; bool use_depth = false;
     uint32_t* d_rgba = nullptr; float* d_depth = nullptr; float* d_poses = nullptr;
-    std::vector<uint32_t> staging;
+    std::vector<uint32_t> staging; std::vector<uint8_t> present;      // present[id]: frame id has been uploaded (a new id lands in memory no kernel reads yet)
     DatasetPtrs ptrs() const { return DatasetPtrs{ d_rgba, d_depth, d_poses, K }; }
 };
 
