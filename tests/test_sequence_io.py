@@ -165,7 +165,9 @@ def test_online_manager_incremental_flow(pkg, ss, tmp_path):
         if v == 8:
             time.sleep(0.3)
             assert all(m.object_info(i)["train_calls"] == 0 for i in ids.values())      # <= 10 boxes: no training yet (nerf.cu:223)
-        if v in (14, 18, 22):                                        # a viewer reads while the training threads run (between two 64-iteration slices)
+        if v == 20:                                                  # an id that is already in use is overwritten: the one case that excludes the training threads
+            m.new_frame(3, "%.6f" % 0.3, sc.rgb[3][..., ::-1], sc.instance[3], ss.colmajor(sc.Twc[3]), sc.depth[3])
+        if v in (14, 18, 22):                                        # a viewer reads while the training threads run (let in between two slices)
             for i in ids.values():
                 bx = sc.objects[0]["boxes"][1]; r, d, k_ = m.render(i, bx, ss.colmajor(sc.Twc[int(bx[0])]))
                 assert np.isfinite(r).all() and np.isfinite(d).all() and m.object_info(i)["n_boxes"] >= 0
