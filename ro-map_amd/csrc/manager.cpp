@@ -279,6 +279,7 @@ struct OnlineObject {
     int mesh_res = 64; float mesh_thresh = 2.0f;
     std::mutex mu_model;            // a Model is single-threaded: the training thread holds it per train slice / box upload / mesh call, the SLAM-side
                                     // calls (render, object_info, RenderNeRFsTest) while they use the model or read what the thread writes
+    const std::atomic<int>* device_objects = nullptr;      // objects training on the same device (slice length, see train_sliced)
     std::atomic<int> waiters{ 0 };  // callers blocked on mu_model / the dataset mutex: the training thread lets them in between two slices
                                     // (std::mutex is not fair -- a thread that unlocks and relocks in a loop would starve them)
 };
@@ -291,7 +292,7 @@ struct AnnouncedLock {
 
 struct OnlineManager {
     std::string cfg_path; bool use_depth = false; int iters = 500, n_dev = 0, next_dev = 0; mon_config cfg{};
-    size_t n_images = 0; std::vector<Dataset*> ds; std::vector<std::vector<std::unique_ptr<std::mutex>>> ds_mutex;
+    size_t n_images = 0; std::vector<Dataset*> ds; std::vector<std::vector<std::unique_ptr<std::mutex>>> ds_mutex; std::vector<std::unique_ptr<std::atomic<int>>> dev_objects;
     std::map<std::string, uint32_t> stamp_to_idx; std::vector<OnlineObject*> objs; std::vector<std::thread> threads;
     int H = 0, W = 0; std::map<uint32_t, std::vector<float>> poses;       // host copy of the poses for train.txt (nerf.cu:369-373 reads them back from the device)
 };
@@ -307,15 +308,19 @@ static bool online_check_finish(OnlineObject* o) { std::unique_lock<std::mutex> 
 
 // Train_Step_Online takes the per-object dataset mutex around GenerateBatch of every iteration (nerf_model.cu:1675-1678), so the SLAM
 // thread's NewFrameToDataset never waits longer than one batch generation.  Here an iteration is three stream-ordered launches without
-// host involvement, so the mutexes are held for slices of kOnlineSlice iterations (~1.5 ms at base.json size, one host sync per slice)
-// and anybody waiting for them is let in between two slices.
+// host involvement, so the mutexes are held for slices of up to kOnlineSlice iterations (~1.5 ms at base.json size, one host sync per
+// slice) and anybody waiting for them is let in between two slices.  With several objects on a device the slices shrink (16 / n, at
+// least 2): the other objects' queued work keeps the GPU busy across this thread's syncs, and a frame upload or a viewer's render --
+// which share the device's few hardware queues with all those streams -- finds them shallow.
 static constexpr int kOnlineSlice = 16;
 static int train_sliced(OnlineObject* o) {
     int rc = MON_OK;
-    for (int done = 0; done < o->iterations && rc == MON_OK; done += kOnlineSlice) {
+    for (int done = 0; done < o->iterations && rc == MON_OK; ) {
         while (o->waiters.load() > 0) std::this_thread::yield();
+        const int sharing = o->device_objects ? o->device_objects->load() : 1;
+        int n = kOnlineSlice / (sharing > 0 ? sharing : 1); if (n < 2) n = 2; if (n > o->iterations - done) n = o->iterations - done;
         std::unique_lock<std::mutex> dl(*o->dataset_mutex); std::lock_guard<std::mutex> lm(o->mu_model);
-        rc = model_train(*o->model, (o->iterations - done) < kOnlineSlice ? (o->iterations - done) : kOnlineSlice, &o->last_loss, 7);
+        rc = model_train(*o->model, n, &o->last_loss, 7); done += n;
     }
     return rc;
 }
@@ -419,6 +424,7 @@ int mon_online_dataset_init(mon_online* h, float fx, float fy, float cx, float c
     if (m.n_dev == 0) { set_error("DatasetInit before Init"); return MON_ERR_STATE; }
     if (!m.ds.empty()) { set_error("DatasetInit called twice"); return MON_ERR_STATE; }
     m.n_images = imgs; m.ds_mutex.resize(m.n_dev); m.H = H; m.W = W;
+    for (int g = 0; g < m.n_dev; ++g) m.dev_objects.emplace_back(new std::atomic<int>(0));
     for (int g = 0; g < m.n_dev; ++g) { Dataset* d = nullptr; int rc = dataset_create(g, H, W, fx, fy, cx, cy, (uint32_t)imgs, m.use_depth, &d); if (rc) return rc; m.ds.push_back(d); }
     return MON_OK;
 }
@@ -449,7 +455,7 @@ int mon_online_create_nerf(mon_online* h, int cls, const float* Tow16, const flo
     m.ds_mutex[o->device].emplace_back(new std::mutex()); o->dataset_mutex = m.ds_mutex[o->device].back().get();
     int rc = model_create(m.ds[o->device], m.cfg, cls, o->Tow, o->amin, o->amax, &o->model);
     if (rc) { delete o; return rc; }
-    o->handle.m = o->model;
+    o->handle.m = o->model; o->device_objects = m.dev_objects[o->device].get(); m.dev_objects[o->device]->fetch_add(1);
     *idx_out = m.objs.size(); m.objs.push_back(o);
     m.threads.emplace_back(train_online_thread, o);                      // thread per object, nerf_manager.cu:259
     return MON_OK;
