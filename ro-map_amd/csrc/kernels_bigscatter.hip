@@ -11,8 +11,11 @@
 //   k_big_scan   (level):          tile offsets + per-(bin, tile) write offsets
 //   k_big_emit   (level, ray bin): records {index in level, h(w * dE) as half2} into the tile bins
 //   k_big_accum  (level, tile):    LDS accumulation, non-zero entries -> gradient table
-// Late in training (a few thousand samples) the per-tile fixed work outweighs ~10 us of atomics; the host switches back to the atomic
-// path of k_fused_train between training calls (model.cpp).
+// Late in training (a few thousand samples) the per-tile fixed work outweighs ~10 us of atomics: every kernel here, and k_fused_train,
+// reads the previous iteration's gradient-carrying sample count from DevState and takes the same wave-uniform decision
+// (big_levels_binned, grid_walk.h) -- binned above `big_switch` samples, tcnn's global atomics inside k_fused_train below.  Once the
+// host has seen the count well below the switch it stops launching these kernels (model.cpp).  k_big_accum also sets the lazy
+// optimizer's chunk flags (ParamPtrs::touched) next to every entry it writes.
 #include <atomic>
 #include "model.h"
 #include "grid_walk.h"
