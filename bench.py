@@ -120,7 +120,9 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "kernel": "k_fused_train" if fused else "unfused fwd+bwd kernel group",
-                "avg_launch_ms": round(fb_ms, 4), "algorithmic_bytes_per_launch": dom_bytes}
+                "avg_launch_ms": round(fb_ms, 4), "algorithmic_bytes_per_launch": dom_bytes,
+                "measured_over": "HIP events around every launch on the object's train stream during the %d steps that follow the timed region "
+                                 "(events between the launches add ~37 us per step, so the timed region itself runs without them)" % args.steps}
     if fused:
         grp_ms = fb_ms + sc_ms
         sc_bytes = 64 * L * scattered                # the scatter's read-modify-write bytes of the samples that carry a gradient
