@@ -161,6 +161,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     m.h_state = DevState{}; m.h_state.lr = cfg.learning_rate;
     m.h_state.ema_deb_old = 0.0f; m.h_state.ema_deb_new = 1.0f / (1.0f - (float)std::pow((double)cfg.ema_decay, 1.0));   // step 1
     HIPCHECK(hipMemcpy(m.d_state, &m.h_state, sizeof(DevState), hipMemcpyHostToDevice));
+    HIPCHECK(hipHostMalloc((void**)&m.h_state_pinned, sizeof(DevState), hipHostMallocDefault));
     m.backend = fused_supported(m.nd, S, m.oc.R) ? 1 : 0;
     if (const char* e = std::getenv("MON_BACKEND")) m.backend = std::atoi(e) ? (fused_supported(m.nd, S, m.oc.R) ? 1 : 0) : 0;
     m.mesh = mesh_state_create(m.device);
@@ -189,6 +190,7 @@ int model_destroy(Model* mp) {
     drop_graph(m);
     for (auto& e : m.ev_pool) hipEventDestroy(e);
     for (void* p : m.allocs) hipFree(p);
+    if (m.h_state_pinned) hipHostFree(m.h_state_pinned);
     if (m.train_stream) hipStreamDestroy(m.train_stream);
     delete mp; return MON_OK;
 }
@@ -293,8 +295,11 @@ static void enqueue_iteration(Model& m, int stages) {
 }
 
 static int sync_state(Model& m) {
-    HIPCHECK(hipStreamSynchronize(m.train_stream));            // :1645 (once per call instead of once per iteration)
-    HIPCHECK(hipMemcpy(&m.h_state, m.d_state, sizeof(DevState), hipMemcpyDeviceToHost));
+    // :1645 (once per call instead of once per iteration); the state rides the same sync in a pinned buffer -- the online manager trains
+    // in slices of a few iterations, where a second blocking copy would be a visible share of the slice
+    HIPCHECK(hipMemcpyAsync(m.h_state_pinned, m.d_state, sizeof(DevState), hipMemcpyDeviceToHost, m.train_stream));
+    HIPCHECK(hipStreamSynchronize(m.train_stream));
+    m.h_state = *m.h_state_pinned;
     collect_profile(m);
     return MON_OK;
 }
