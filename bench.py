@@ -80,7 +80,7 @@ def main():
 
     def sync():
         pkg.lib().mon_device_synchronize(device)
-        if torch.cuda.is_available():
+        if torch.cuda.device_count() > 0:      # (is_available() can answer False once another HIP user -- the library -- has initialised the device)
             torch.cuda.synchronize()
 
     def barrier():

@@ -213,6 +213,7 @@ int mon_png_write(const char* path, int width, int height, int channels, int bit
 
 /* Whole-device helpers used by bench.py. */
 int mon_device_synchronize(int device);
+int mon_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes);   /* hipMemGetInfo: sizing how many object NeRFs a device takes (base.json: 38 MB each, T = 2^22: 2.2 GB) */
 /* Diagnostic: write intermediate activations of the fused backend into the debug buffers (slower). */
 int mon_object_set_debug_dump(mon_object* obj, int enable);
 /* Diagnostic micro-benchmarks of scatter strategies (ro-map_amd/csrc/microbench.hip); *ms = best of 3 runs. */

@@ -78,6 +78,7 @@ _SIGS = {
     "mon_object_generate_mesh": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mon_object_mesh_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mon_object_get_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "mon_device_mem_info": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "mon_object_copy_mesh": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "mon_object_get_mesh_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mon_object_save_mesh": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -150,6 +151,11 @@ def device_count():
     n = C.c_int(0)
     rc = lib().mon_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+def device_mem_info(device=0):
+    """(free, total) bytes of device memory (hipMemGetInfo)."""
+    f = C.c_size_t(0); t = C.c_size_t(0); _check(lib().mon_device_mem_info(int(device), C.byref(f), C.byref(t))); return f.value, t.value
 
 
 def default_config(**kw):

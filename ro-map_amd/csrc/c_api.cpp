@@ -108,6 +108,11 @@ int mon_device_synchronize(int device) {
     if (hipSetDevice(device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { set_error("device synchronize failed"); return MON_ERR_HIP; }
     return MON_OK;
 }
+int mon_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes) {
+    REQUIRE(free_bytes, "free_bytes"); REQUIRE(total_bytes, "total_bytes");
+    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(free_bytes, total_bytes) != hipSuccess) { set_error("hipMemGetInfo failed on device %d", device); return MON_ERR_HIP; }
+    return MON_OK;
+}
 int mon_debug_fast_index(const mon_config* cfg, int level, uint32_t x, uint32_t y, uint32_t z, uint32_t* index, uint32_t* size) {
     REQUIRE(cfg, "cfg"); REQUIRE(index, "index"); REQUIRE(size, "size");
     LevelTable lt{}; NetDims nd{}; uint32_t n_grid = 0; int rc = level_table_build(*cfg, lt, nd, n_grid); if (rc) return rc;

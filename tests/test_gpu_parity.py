@@ -311,6 +311,27 @@ def test_size_limits_match_oracle(pkg, orc, small_scene, kw):
     obj.close(); ds.close(); ref.close()
 
 
+def test_create_train_render_mesh_destroy_does_not_leak(pkg, ss, small_scene):
+    """Device memory after 40 rounds of dataset + object create / train / render (growing crops) / mesh / destroy returns to where it was
+    after the first rounds (allocator caches settle); online objects come and go with the map (LocalMapping.cc:1231)."""
+    _need_gpu(pkg)
+    sc = small_scene
+
+    def round_trip(k):
+        ds, obj = ge.make_problem(pkg, sc, dict(C1, sample_seed=k)); obj.train(5)
+        for s in (8, 40, 100):                                  # whole-crop output buffers grow on demand
+            obj.render(np.array([0, 0, 0, s, s], np.uint32), ss.colmajor(sc.Twc[0]))
+        obj.generate_mesh(32, 2.0); obj.close(); ds.close()
+
+    for k in range(4):
+        round_trip(k)
+    free0, _ = pkg.device_mem_info(0)
+    for k in range(40):
+        round_trip(100 + k)
+    free1, _ = pkg.device_mem_info(0)
+    assert free0 - free1 < 64 << 20, "device memory shrank by %.1f MB over 40 create/destroy rounds" % ((free0 - free1) / 2 ** 20)
+
+
 def test_edge_cases(pkg, ss, small_scene):
     _need_gpu(pkg)
     sc = small_scene
