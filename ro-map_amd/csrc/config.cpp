@@ -28,7 +28,7 @@ struct JVal {
 };
 
 struct JParser {
-    const std::string& s; size_t i = 0; bool ok = true;
+    const std::string& s; size_t i = 0; bool ok = true; int depth = 0;          // nesting is bounded (tcnn configs are 3 deep): no stack exhaustion on hostile input
     explicit JParser(const std::string& src) : s(src) {}
     void ws() {
         for (;;) {
@@ -40,7 +40,8 @@ struct JParser {
     }
     JVal value() {
         ws(); JVal v;
-        if (i >= s.size()) { ok = false; return v; }
+        if (i >= s.size() || depth > 32) { ok = false; return v; }
+        struct Depth { int& d; explicit Depth(int& x) : d(x) { ++d; } ~Depth() { --d; } } guard(depth);
         const char c = s[i];
         if (c == '{') {
             v.kind = JVal::Obj; ++i; ws();

@@ -54,6 +54,40 @@ def test_config_errors(pkg, tmp_path):
         pkg.config_from_json(str(broken))
 
 
+def test_config_reader_survives_damaged_files(pkg, tmp_path):
+    """Truncations, byte flips and pathological nesting of base.json: a clean error or a config, never a crash; values outside what the
+    kernels support are rejected when the level table is built (mon_debug_fast_index goes through the same check)."""
+    import numpy as np
+    good = open(os.path.join(ROOT, "ro-map_amd", "configs", "base.json"), "rb").read()
+    rs = np.random.RandomState(0); f = tmp_path / "m.json"
+    for cut in range(0, len(good), 37):
+        f.write_bytes(good[:cut])
+        try:
+            pkg.config_from_json(str(f))
+        except pkg.MonError:
+            pass
+    for _ in range(300):
+        b = bytearray(good)
+        for pos in rs.randint(0, len(b), rs.randint(1, 4)):
+            b[pos] = rs.randint(32, 127)
+        f.write_bytes(bytes(b))
+        try:
+            pkg.config_from_json(str(f))
+        except pkg.MonError:
+            pass
+    f.write_text("[" * 100000)
+    with pytest.raises(pkg.MonError):
+        pkg.config_from_json(str(f))
+    f.write_text('{"encoding": {"otype": "HashGrid", "n_levels": 99, "n_features_per_level": 2, "log2_hashmap_size": 40}, "network": {"n_neurons": 64, "n_hidden_layers": 1}}')
+    try:
+        c = pkg.config_from_json(str(f))
+    except pkg.MonError:
+        c = None
+    if c is not None:
+        with pytest.raises(pkg.MonError):
+            pkg.fast_index(c, 0, 0, 0, 0)
+
+
 def test_no_silent_cpu_fallback(pkg):
     """Without a HIP device every compute entry point must fail with MON_ERR_NO_DEVICE, not run elsewhere."""
     if pkg.device_count() > 0:
