@@ -138,6 +138,7 @@ int mon_object_get_mesh(mon_object* obj, float* verts, float* normals, uint8_t* 
  * the needed counts in n_* when a buffer is too small; MON_ERR_STATE when try_lock_only and the trainer holds the mesh, or no mesh yet. */
 int mon_object_copy_mesh(mon_object* obj, uint32_t cap_verts, uint32_t cap_indices, float* verts, float* normals, uint8_t* colors, uint32_t* indices,
                          uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices, int try_lock_only);
+int mon_object_mesh_generation(mon_object* obj, uint64_t* generation);                  /* lock-free: number of meshes published so far (0 = none); a viewer copies again only when it changed */
 int mon_object_get_mesh_raw(mon_object* obj, float* normals_raw, float* colors_f32);      /* un-normalised normals, float colours (parity tests) */
 int mon_object_save_mesh(mon_object* obj, const char* path);                              /* ".ply" -> ASCII ply, anything else -> obj */
 /* Marching cubes + normals on a caller-supplied lattice (x fastest); buffers may be NULL to query the counts. */

@@ -79,6 +79,7 @@ _SIGS = {
     "mon_object_mesh_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mon_object_get_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "mon_device_mem_info": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
+    "mon_object_mesh_generation": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mon_object_copy_mesh": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "mon_object_get_mesh_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mon_object_save_mesh": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -271,6 +272,9 @@ class ObjectNeRF:
             out["normals_raw"] = np.empty((nv.value, 3), np.float32); out["colors_f32"] = np.empty((nv.value, 3), np.float32)
             _check(lib().mon_object_get_mesh_raw(self.h, _p(out["normals_raw"]), _p(out["colors_f32"])))
         return out
+
+    def mesh_generation(self):
+        g = C.c_uint64(0); _check(lib().mon_object_mesh_generation(self.h, C.byref(g))); return g.value
 
     def save_mesh(self, path):
         _check(lib().mon_object_save_mesh(self.h, path.encode()))

@@ -19,16 +19,19 @@ void NeRF::DrawCPUMesh() {                                                    //
     CPUMeshData& cm = mCPUMeshData;
     std::unique_lock<std::mutex> lock(cm.mesh_mutex, std::try_to_lock);
     if (!lock.owns_lock() || !mpObject) return;
-    // refresh the host copy if the training thread is not publishing right now (TransCPUMesh fills CPUMeshData there, nerf.cu:138-145)
-    uint32_t nv = (uint32_t)(cm.verts.size() / 3), ni = (uint32_t)cm.indices.size(), need_v = 0, need_r = 0, need_i = 0;
-    int rc = mon_object_copy_mesh(mpObject, nv, ni, cm.verts.data(), cm.normals.data(), cm.colors.data(), cm.indices.data(), &need_v, &need_r, &need_i, 1);
-    if (rc == MON_ERR_ARG && (need_v > nv || need_i > ni)) {                   // the mesh grew: make room and try once more
-        cm.verts.resize(3 * (size_t)need_v); cm.normals.resize(3 * (size_t)need_v); cm.colors.resize(3 * (size_t)need_v); cm.indices.resize(need_i);
-        rc = mon_object_copy_mesh(mpObject, need_v, need_i, cm.verts.data(), cm.normals.data(), cm.colors.data(), cm.indices.data(), &need_v, &need_r, &need_i, 1);
-    }
-    if (rc == MON_OK) {
-        cm.verts.resize(3 * (size_t)need_v); cm.normals.resize(3 * (size_t)need_v); cm.colors.resize(3 * (size_t)need_v); cm.indices.resize(need_i);
-        cm.have_reslult = true;
+    // refresh the host copy when the training thread has published a new mesh (TransCPUMesh fills CPUMeshData there, nerf.cu:138-145)
+    uint64_t gen = 0; mon_object_mesh_generation(mpObject, &gen);
+    if (gen != mMeshGeneration) {
+        uint32_t nv = (uint32_t)(cm.verts.size() / 3), ni = (uint32_t)cm.indices.size(), need_v = 0, need_r = 0, need_i = 0;
+        int rc = mon_object_copy_mesh(mpObject, nv, ni, cm.verts.data(), cm.normals.data(), cm.colors.data(), cm.indices.data(), &need_v, &need_r, &need_i, 1);
+        if (rc == MON_ERR_ARG && (need_v > nv || need_i > ni)) {                   // the mesh grew: make room and try once more
+            cm.verts.resize(3 * (size_t)need_v); cm.normals.resize(3 * (size_t)need_v); cm.colors.resize(3 * (size_t)need_v); cm.indices.resize(need_i);
+            rc = mon_object_copy_mesh(mpObject, need_v, need_i, cm.verts.data(), cm.normals.data(), cm.colors.data(), cm.indices.data(), &need_v, &need_r, &need_i, 1);
+        }
+        if (rc == MON_OK) {
+            cm.verts.resize(3 * (size_t)need_v); cm.normals.resize(3 * (size_t)need_v); cm.colors.resize(3 * (size_t)need_v); cm.indices.resize(need_i);
+            cm.have_reslult = true; mMeshGeneration = gen;
+        }
     }
     if (!cm.have_reslult || cm.indices.empty()) return;
     glEnableClientState(GL_VERTEX_ARRAY); glEnableClientState(GL_NORMAL_ARRAY); glEnableClientState(GL_COLOR_ARRAY);

@@ -19,7 +19,7 @@ public:
     Eigen::Matrix4f mObjTow = Eigen::Matrix4f::Identity();
     BoundingBox mBoundingBox;
     std::vector<FrameIdAndBbox> mFrameIdBbox;
-    CPUMeshData mCPUMeshData;
+    CPUMeshData mCPUMeshData; uint64_t mMeshGeneration = 0;   // generation of the mesh held in mCPUMeshData
     mon_object* mpObject = nullptr;               // borrowed from the manager (mon_offline_object / mon_online_object)
 };
 

@@ -25,6 +25,7 @@ int model_generate_mesh(Model& m, int res, float thresh, uint32_t* n_verts, uint
 int model_mesh_counts(Model& m, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices);
 int model_get_mesh(Model& m, float* verts, float* normals, uint8_t* colors, uint32_t* indices, float* normals_raw, float* colors_f32, int try_only);
 int model_save_mesh(Model& m, const char* path);
+int model_mesh_generation(Model& m, uint64_t* gen);
 int model_copy_mesh(Model& m, uint32_t cap_verts, uint32_t cap_indices, float* verts, float* normals, uint8_t* colors, uint32_t* indices,
                     uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices, int try_only);
 int marching_cubes_host(int device, const float* density, int rx, int ry, int rz, float thresh, const float* amin, const float* amax,
@@ -75,6 +76,7 @@ int mon_object_copy_mesh(mon_object* o, uint32_t cap_verts, uint32_t cap_indices
                          uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices, int try_lock_only) {
     REQUIRE(o, "object"); return model_copy_mesh(*o->m, cap_verts, cap_indices, verts, normals, colors, indices, n_verts, n_verts_real, n_indices, try_lock_only);
 }
+int mon_object_mesh_generation(mon_object* o, uint64_t* generation) { REQUIRE(o, "object"); REQUIRE(generation, "generation"); return model_mesh_generation(*o->m, generation); }
 int mon_object_save_mesh(mon_object* o, const char* path) { REQUIRE(o, "object"); REQUIRE(path, "path"); return model_save_mesh(*o->m, path); }
 int mon_marching_cubes(int device, const float* density, int rx, int ry, int rz, float thresh, const float* aabb_min3, const float* aabb_max3,
                        float* verts, float* normals_raw, uint32_t* indices, uint32_t cap_verts, uint32_t cap_indices, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices) {

@@ -1,6 +1,7 @@
 // mesh.cpp -- host side of mesh extraction: NeRF_Model::GenerateMesh / TransCPUMesh / SaveMesh
 // (CORE/src/nerf_model.cu:1993-2095, 2181-2184), MarchingCubes' count -> allocate -> emit flow (CORE/src/marching_cubes.cu:478-509)
 // and the ASCII ply / obj writer (marching_cubes.cu:511-653, the non-unwrapped branch).
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -30,6 +31,7 @@ struct MeshState {
     uint32_t* d_indices = nullptr; size_t cap_indices = 0;
     uint32_t n_verts = 0, n_verts_real = 0, n_indices = 0;      // device-side result (n_verts is rounded up to 128, :496)
     std::mutex mu; bool have_result = false;                    // CPUMeshData::mesh_mutex / have_reslult
+    std::atomic<uint64_t> generation{ 0 };                      // bumped whenever a new mesh is published to the host copy (viewers skip unchanged meshes)
     std::vector<float> verts, normals, normals_raw, colors_f32; std::vector<uint8_t> colors; std::vector<uint32_t> indices; uint32_t cpu_n_real = 0;
 };
 
@@ -95,7 +97,7 @@ int mesh_to_cpu(MeshState& ms, hipStream_t s, bool with_colors) {
     }
     if (ms.n_indices) HIPCHECK(hipMemcpyAsync(ms.indices.data(), ms.d_indices, (size_t)ms.n_indices * 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
-    ms.cpu_n_real = ms.n_verts_real; ms.have_result = true;
+    ms.cpu_n_real = ms.n_verts_real; ms.have_result = true; ms.generation.fetch_add(1);
     return MON_OK;
 }
 
@@ -211,6 +213,7 @@ int model_copy_mesh(Model& m, uint32_t cap_verts, uint32_t cap_indices, float* v
     if (indices) std::memcpy(indices, ms.indices.data(), ms.indices.size() * 4);
     return MON_OK;
 }
+int model_mesh_generation(Model& m, uint64_t* gen) { *gen = m.mesh ? m.mesh->generation.load() : 0; return MON_OK; }
 int model_save_mesh(Model& m, const char* path) {
     if (!m.mesh) { set_error("SaveMesh: no mesh has been generated"); return MON_ERR_STATE; }
     return mesh_save(*m.mesh, path);
