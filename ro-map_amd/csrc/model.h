@@ -148,10 +148,18 @@ struct Model {
     Dataset* ds = nullptr; mon_config cfg{}; int device = 0;
     LevelTable lt{}; LevelFast lf{}; NetDims nd{}; ObjectConst oc{}; OptimConst opt{};
     uint32_t n_grid = 0, n_params = 0;
-    hipStream_t train_stream = nullptr;      // mpTrainStream :1268; inference (render, mesh) runs on the same stream: the reference's mpInferenceStream is only ever used from the object's own thread between training calls
+    hipStream_t train_stream = nullptr;      // mpTrainStream :1268; inference (render, mesh) runs on the same stream: the reference's mpInferenceStream is only
+                                             // ever used from the object's own thread between training calls
     ParamPtrs P{}; BatchPtrs B{}; DevState* d_state = nullptr; mon_frame_bbox* d_boxes = nullptr;
     uint32_t boxes_cap = 0, n_boxes = 0; uint32_t ws_samples = 0, ws_rays = 0;
-    float* d_dw_partials = nullptr; uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr; uint16_t* d_gpart = nullptr; uint16_t* d_frag_train = nullptr; uint32_t* d_ema_step = nullptr; uint8_t* d_touched = nullptr; uint16_t* d_frag_render = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0; uint8_t* d_big_ws = nullptr; uint32_t big_switch = 0; bool big_active = false; float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr; size_t out_cap = 0;
+    // fused backend
+    float* d_dw_partials = nullptr;                               // [512][n_mlp + 64] fp32 dW partial rows of k_fused_train
+    uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr;       // compacted dL/dE rows [L][B] and positions [3][B] for the scatter kernels
+    uint16_t* d_gpart = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0;   // k_grid_scatter: partial tables, plan, levels it covers
+    uint16_t* d_frag_train = nullptr; uint16_t* d_frag_render = nullptr;           // MFMA A-fragment images (training weights / inference weights)
+    uint32_t* d_ema_step = nullptr; uint8_t* d_touched = nullptr;                  // lazy EMA bookkeeping, chunk flags (ParamPtrs)
+    uint8_t* d_big_ws = nullptr; uint32_t big_switch = 0; bool big_active = false; // kernels_bigscatter.hip: workspace, switch point, launched in this train call
+    float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr; size_t out_cap = 0;   // whole-crop render outputs (grow-only)
     std::vector<void*> allocs;
     DevState h_state{}; DevState* h_state_pinned = nullptr; int backend = 0; bool profiling = false; int fused_dump = 0;
     bool lazy_ema = false, ema_pending = false;   // large tables: EMA of untouched chunks is brought up to date on demand (k_ema_finalize)
