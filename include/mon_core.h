@@ -146,6 +146,7 @@ int mon_marching_cubes(int device, const float* density, int rx, int ry, int rz,
                        float* verts, float* normals_raw, uint32_t* indices, uint32_t cap_verts, uint32_t cap_indices,
                        uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices);
 
+int mon_object_get_config(mon_object* obj, mon_config* cfg);                               /* the configuration the object was created with (borrowed objects of the managers: base.json as read) */
 int mon_object_info_get(mon_object* obj, mon_object_info* info);
 /* Parameter I/O (the reference has none; needed for fixtures/checkpoints).
  * which: 0 fp32 master, 1 fp16 working copy, 2 fp16 EMA (inference) copy. */

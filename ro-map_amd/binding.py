@@ -80,6 +80,7 @@ _SIGS = {
     "mon_object_get_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "mon_device_mem_info": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "mon_object_mesh_generation": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mon_object_get_config": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mon_object_copy_mesh": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "mon_object_get_mesh_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mon_object_save_mesh": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -443,7 +444,8 @@ class OnlineManager:
 
 
 def _borrowed_object(handle):
-    o = ObjectNeRF.__new__(ObjectNeRF); o.h = handle; o.cfg = None; o.ds = None
+    o = ObjectNeRF.__new__(ObjectNeRF); o.h = handle; o.ds = None
+    o.cfg = MonConfig(); _check(lib().mon_object_get_config(handle, C.byref(o.cfg))); o.R, o.S = o.cfg.rays_per_batch, o.cfg.n_samples
     o.close = lambda: None                     # the manager owns it
     return o
 

@@ -83,6 +83,7 @@ int mon_marching_cubes(int device, const float* density, int rx, int ry, int rz,
     return marching_cubes_host(device, density, rx, ry, rz, thresh, aabb_min3, aabb_max3, verts, normals_raw, indices, cap_verts, cap_indices, n_verts, n_verts_real, n_indices);
 }
 int mon_object_density_grid(mon_object* o, int rx, int ry, int rz, float* out_host) { REQUIRE(o, "object"); return model_density_grid(*o->m, rx, ry, rz, out_host); }
+int mon_object_get_config(mon_object* o, mon_config* cfg) { REQUIRE(o, "object"); REQUIRE(cfg, "cfg"); *cfg = o->m->cfg; return MON_OK; }
 int mon_object_info_get(mon_object* o, mon_object_info* info) {
     REQUIRE(o, "object"); REQUIRE(info, "info"); Model& m = *o->m;
     info->n_params = m.n_params; info->n_mlp_params = m.nd.n_mlp; info->n_grid_params = m.n_grid; info->encoded_width = (uint32_t)m.nd.Epad;

@@ -182,6 +182,7 @@ def test_online_manager_incremental_flow(pkg, ss, tmp_path):
         iou = ((mask > 0.5) & gm).sum() / max(1, ((mask > 0.5) | gm).sum())
         assert iou > 0.8, (k, iou)
         mesh = m.object(i).get_mesh(try_lock=True)                    # DrawMesh(idx)'s data
+        bo = m.object(i); assert bo.cfg.rays_per_batch == 1024 and int(bo.buffer("state")[0]) == bo.info().train_step > 0 and bo.mesh_generation() >= 1   # the borrowed handle is a full object
         assert mesh["n_verts_real"] > 50 and mesh["indices"].max() < mesh["n_verts_real"]
     # RenderNeRFsTest (System.cc:610): test images, test.txt / train.txt, 360-degree video, obj.ply
     from PIL import Image
