@@ -311,6 +311,20 @@ def test_size_limits_match_oracle(pkg, orc, small_scene, kw):
     obj.close(); ds.close(); ref.close()
 
 
+def test_base_json_training_runs_on_the_fused_path_at_speed(pkg, ss):
+    """Guard against a silent fall-back to the layer-at-a-time kernels (or a lost order of magnitude): base.json at the full batch must
+    select the fused backend by itself and take well under 0.2 ms per step (measured 0.08-0.1 ms; the unfused kernels need 0.7 ms)."""
+    _need_gpu(pkg)
+    import time
+    sc = ss.make_scene(n_views=16, H=240, W=320, f=260.0, seed=2)
+    ds, obj = ge.make_problem(pkg, sc, {})
+    assert int(obj.info().backend) == 1
+    obj.train(50); pkg.lib().mon_device_synchronize(0)
+    t0 = time.perf_counter(); obj.train(400); pkg.lib().mon_device_synchronize(0); dt = (time.perf_counter() - t0) / 400
+    assert dt < 0.2e-3, "%.3f ms per step" % (1e3 * dt)
+    obj.close(); ds.close()
+
+
 def test_create_train_render_mesh_destroy_does_not_leak(pkg, ss, small_scene):
     """Device memory after 40 rounds of dataset + object create / train / render (growing crops) / mesh / destroy returns to where it was
     after the first rounds (allocator caches settle); online objects come and go with the map (LocalMapping.cc:1231)."""
