@@ -310,6 +310,15 @@ void launch_ema_finalize(hipStream_t s, const ParamPtrs& p, const OptimConst& oc
     hipLaunchKernelGGL(k_ema_finalize, dim3(2048), dim3(256), 0, s, p, oc, st);
 }
 
+// fp16 working copy of the fp32 master weights, h(master): object creation and set_params (a scalar host loop without F16C costs ~13 ms for
+// base.json's 1.9 M parameters -- time the SLAM thread spends inside CreateNeRF)
+__global__ void __launch_bounds__(256) k_master_to_half(const float* __restrict__ master, uint16_t* __restrict__ half, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const half_t h = (half_t)master[i]; half[i] = __builtin_bit_cast(uint16_t, h); }
+}
+void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, uint32_t n) {
+    hipLaunchKernelGGL(k_master_to_half, dim3(1024), dim3(256), 0, s, master, half, n);
+}
+
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx) {
     const uint32_t chunks = oc.n_params >> 3;
     static const uint32_t env_cap = std::getenv("MON_OPT_BLOCKS") ? (uint32_t)std::atoi(std::getenv("MON_OPT_BLOCKS")) : 0u;

@@ -37,6 +37,7 @@ int model_generate_mesh(Model& m, int res, float thresh, uint32_t* n_verts, uint
 int model_save_mesh(Model& m, const char* path);
 int model_mesh_counts(Model& m, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices);
 int model_train(Model& m, int iters, float* loss, int stages);
+int stream_pool_reserve(int device, int n);
 int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, int dst_on_device);
 
 // Eigen::Quaternionf(w,x,y,z).toRotationMatrix() + translation -> column-major 4x4 (nerf_data.cu:100-106)
@@ -425,6 +426,7 @@ int mon_online_dataset_init(mon_online* h, float fx, float fy, float cx, float c
     if (!m.ds.empty()) { set_error("DatasetInit called twice"); return MON_ERR_STATE; }
     m.n_images = imgs; m.ds_mutex.resize(m.n_dev); m.H = H; m.W = W;
     for (int g = 0; g < m.n_dev; ++g) m.dev_objects.emplace_back(new std::atomic<int>(0));
+    for (int g = 0; g < m.n_dev; ++g) stream_pool_reserve(g, 8);          // CreateNeRF runs on the SLAM thread later: take the ~8 ms per stream now
     for (int g = 0; g < m.n_dev; ++g) { Dataset* d = nullptr; int rc = dataset_create(g, H, W, fx, fy, cx, cy, (uint32_t)imgs, m.use_depth, &d); if (rc) return rc; m.ds.push_back(d); }
     return MON_OK;
 }

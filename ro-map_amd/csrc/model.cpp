@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "model.h"
@@ -82,6 +84,24 @@ int dataset_destroy(Dataset* d) {
 }
 
 // ------------------------------------------------------------------ model
+// hipStreamCreate costs ~8 ms (a hardware queue is set up), and CreateNeRF runs on the SLAM thread: streams of destroyed objects are
+// kept for the next object of that device, and a manager can reserve some ahead of time (mon_online_dataset_init).
+static std::mutex g_stream_mu; static std::map<int, std::vector<hipStream_t>> g_stream_pool;
+static int stream_acquire(int device, hipStream_t* out) {
+    { std::lock_guard<std::mutex> l(g_stream_mu); auto& v = g_stream_pool[device]; if (!v.empty()) { *out = v.back(); v.pop_back(); return MON_OK; } }
+    HIPCHECK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));       // mpTrainStream, nerf_model.cu:1268
+    return MON_OK;
+}
+static void stream_release(int device, hipStream_t s) { std::lock_guard<std::mutex> l(g_stream_mu); g_stream_pool[device].push_back(s); }
+int stream_pool_reserve(int device, int n) {
+    HIPCHECK(hipSetDevice(device));
+    std::vector<hipStream_t> fresh;
+    { std::lock_guard<std::mutex> l(g_stream_mu); n -= (int)g_stream_pool[device].size(); }
+    for (int i = 0; i < n; ++i) { hipStream_t s; HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); fresh.push_back(s); }
+    std::lock_guard<std::mutex> l(g_stream_mu); for (hipStream_t s : fresh) g_stream_pool[device].push_back(s);
+    return MON_OK;
+}
+
 template <class T> static int dev_alloc(Model& m, T*& p, size_t n, bool zero = true) {
     void* q = nullptr; const size_t bytes = (n ? n : 1) * sizeof(T);
     HIPCHECK(hipMalloc(&q, bytes));
@@ -105,7 +125,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     m.oc.R = (uint32_t)cfg.rays_per_batch; m.oc.S = (uint32_t)cfg.n_samples; m.oc.use_depth = cfg.use_depth && ds->use_depth;
     m.oc.sample_seed = cfg.sample_seed; m.oc.loss_scale = cfg.loss_scale;
     m.opt = OptimConst{ cfg.beta1, cfg.beta2, cfg.epsilon, cfg.l2_reg, cfg.ema_decay, cfg.loss_scale, cfg.decay_base, std::log2(cfg.beta1), std::log2(cfg.beta2), std::log2(cfg.ema_decay), cfg.decay_start, cfg.decay_interval, m.nd.n_mlp, m.n_params };
-    HIPCHECK(hipStreamCreateWithFlags(&m.train_stream, hipStreamNonBlocking));       // mpTrainStream, nerf_model.cu:1268
+    { const int rcs = stream_acquire(m.device, &m.train_stream); if (rcs) return rcs; }
     // ---- parameters (ResetNetwork :1286-1342; Trainer init)
     const size_t n = m.n_params;
     if ((rc = dev_alloc(m, m.P.master, n, false)) || (rc = dev_alloc(m, m.P.half, n, false)) || (rc = dev_alloc(m, m.P.ema, n)) ||
@@ -113,10 +133,8 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         (rc = dev_alloc(m, m.P.gmlp, m.nd.n_mlp)) || (rc = dev_alloc(m, m.P.ggrid, m.n_grid))) return rc;
     {
         std::vector<float> master; init_params_host(cfg, m.nd, m.n_params, master);
-        std::vector<uint16_t> half(n);
-        for (size_t i = 0; i < n; ++i) { const _Float16 h = (_Float16)master[i]; std::memcpy(&half[i], &h, 2); }
         HIPCHECK(hipMemcpy(m.P.master, master.data(), n * 4, hipMemcpyHostToDevice));
-        HIPCHECK(hipMemcpy(m.P.half, half.data(), n * 2, hipMemcpyHostToDevice));
+        launch_master_to_half(m.train_stream, m.P.master, m.P.half, (uint32_t)n);        // h(master), same rounding as every later update
     }
     // ---- workspace (AllocateBatchWorkspace :1344-1427), sized for max(train batch, render chunk)
     const uint32_t R = m.oc.R, S = m.oc.S;
@@ -191,7 +209,7 @@ int model_destroy(Model* mp) {
     for (auto& e : m.ev_pool) hipEventDestroy(e);
     for (void* p : m.allocs) hipFree(p);
     if (m.h_state_pinned) hipHostFree(m.h_state_pinned);
-    if (m.train_stream) hipStreamDestroy(m.train_stream);
+    if (m.train_stream) stream_release(m.device, m.train_stream);        // idle (synchronised above): the next object of this device takes it
     delete mp; return MON_OK;
 }
 
@@ -418,10 +436,9 @@ int model_get_params(Model& m, int which, void* dst, size_t bytes) {
 int model_set_params(Model& m, const float* master, size_t n) {
     if (!master || n != m.n_params) { set_error("set_params: expected %u values", m.n_params); return MON_ERR_ARG; }
     HIPCHECK(hipSetDevice(m.device)); HIPCHECK(hipStreamSynchronize(m.train_stream));
-    std::vector<uint16_t> half(n);
-    for (size_t i = 0; i < n; ++i) { const _Float16 h = (_Float16)master[i]; std::memcpy(&half[i], &h, 2); }
     HIPCHECK(hipMemcpy(m.P.master, master, n * 4, hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(m.P.half, half.data(), n * 2, hipMemcpyHostToDevice));
+    launch_master_to_half(m.train_stream, m.P.master, m.P.half, (uint32_t)n);
+    HIPCHECK(hipStreamSynchronize(m.train_stream));
     m.next_ready = false;                                   // the fragment image no longer matches the weights
     return MON_OK;
 }

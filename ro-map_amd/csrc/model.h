@@ -110,6 +110,7 @@ void launch_grid_backward(hipStream_t s, const LevelTable& lt, const NetDims& nd
 void launch_composite_grad(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st);
 void launch_composite_render(hipStream_t s, const BatchPtrs& b, uint32_t S, uint32_t n_rays, float* rgb, float* depth, float* mask);
 void launch_extract_density(hipStream_t s, const uint16_t* O, float* out, uint32_t n);
+void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, uint32_t n);
 
 // optimizer (kernels_optim.hip)
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx);
