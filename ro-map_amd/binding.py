@@ -248,6 +248,13 @@ class ObjectNeRF:
         _check(lib().mon_object_render(self.h, MonBBox(FrameId, x, y, h, w), _p(pose), int(pose_is_Toc), _p(rgb), _p(depth), _p(mask), 0))
         return rgb, depth, mask
 
+    def render_into(self, box, pose16, rgb_ptr, depth_ptr, mask_ptr, on_device, pose_is_Toc=False):
+        """NeRF_Model::Render straight into caller-owned buffers given as raw addresses (3hw + hw + hw float32); `on_device`: they are
+        HBM addresses of this object's device (e.g. a torch tensor's data_ptr() -- the final-render gather sends them over RCCL as they are)."""
+        FrameId, x, y, h, w = (int(v) for v in box)
+        pose = np.ascontiguousarray(pose16, np.float32)
+        _check(lib().mon_object_render(self.h, MonBBox(FrameId, x, y, h, w), _p(pose), int(pose_is_Toc), C.c_void_p(int(rgb_ptr)), C.c_void_p(int(depth_ptr)), C.c_void_p(int(mask_ptr)), int(bool(on_device))))
+
     def generate_mesh(self, res=64, thresh=2.0):
         """GenerateMesh + TransCPUMesh (nerf_model.cu:1993-2095); returns (n_verts incl. padding, n_indices)."""
         nv = C.c_uint32(0); ni = C.c_uint32(0)

@@ -28,19 +28,37 @@ def unpack_crop(buf):
     return rgb, depth, mask
 
 
+def render_packed(obj, box, pose16, torch, device, pose_is_Toc=False):
+    """Renders one crop of `obj` straight into a packed float32 tensor [h, w, rgb(3hw), depth(hw), mask(hw)] that lives on the
+    collective's device: HBM for RCCL (mon_object_render with dst_on_device=1 -- the crop never visits the host before the
+    gather), host memory for gloo."""
+    h, w = int(box[3]), int(box[4]); n = h * w
+    on_dev = str(device) != "cpu"
+    buf = torch.empty(2 + 5 * n, dtype=torch.float32, device=device)
+    buf[:2] = torch.tensor([float(h), float(w)], dtype=torch.float32)
+    if on_dev:
+        torch.cuda.synchronize()             # the header write runs on torch's stream, the render on the object's own
+    base = buf.data_ptr() + 8
+    obj.render_into(box, pose16, base, base + 12 * n, base + 16 * n, on_dev, pose_is_Toc)
+    return buf
+
+
 def gather_crops(dist, torch, crops, device):
-    """crops: list of packed float32 arrays rendered by this rank.  Returns, on every rank, the list (over ranks)
-    of lists of (rgb, depth, mask).  One size all_gather + one padded payload all_gather."""
+    """crops: list of packed float32 crops rendered by this rank -- numpy arrays (pack_crop) or tensors already on `device`
+    (render_packed).  Returns, on every rank, the list (over ranks) of lists of (rgb, depth, mask).  One size all_gather + one
+    padded payload all_gather; tensors given on the device stay there until the gathered payload is unpacked."""
     world = dist.get_world_size()
-    parts = [np.array([len(crops)], np.float32)]
+    f32 = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
+    parts = [f32([float(len(crops))])]
     for c in crops:
-        parts += [np.array([c.size], np.float32), c.astype(np.float32)]
-    mine = np.concatenate(parts)
-    n = torch.tensor([mine.size], dtype=torch.int64, device=device)
+        t = c.to(device) if torch.is_tensor(c) else torch.from_numpy(np.ascontiguousarray(c, np.float32)).to(device)
+        parts += [f32([float(t.numel())]), t]
+    mine = torch.cat(parts)
+    n = torch.tensor([mine.numel()], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
     cap = int(max(int(s.item()) for s in sizes))
-    pad = torch.zeros(cap, dtype=torch.float32, device=device); pad[: mine.size] = torch.from_numpy(mine).to(device)
+    pad = torch.zeros(cap, dtype=torch.float32, device=device); pad[: mine.numel()] = mine
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     out = []

@@ -32,7 +32,8 @@ def _worker(rank, world, port, q):
     for k in mine:                                   # variable crop sizes, content encodes the object id
         h, w = 3 + k, 4 + 2 * k
         rgb = np.full((h, w, 3), k + 0.25, np.float32); depth = np.full((h, w), k + 0.5, np.float32); mask = np.full((h, w), float(k % 2), np.float32)
-        crops.append(sh.pack_crop(rgb, depth, mask))
+        c = sh.pack_crop(rgb, depth, mask)
+        crops.append(torch.from_numpy(c) if k % 2 else c)          # both input kinds: host arrays and tensors already on the collective's device
     got = sh.gather_crops(dist, torch, crops, "cpu")
     tmax = sh.max_over_ranks(dist, torch, 1.0 + rank, "cpu")
     ok = True
