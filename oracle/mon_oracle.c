@@ -69,8 +69,17 @@ typedef struct {
     uint32_t reserved0;
     uint64_t sample_seed;        /* cuRAND XORWOW stream parity is not attempted; counter RNG below */
     int32_t use_depth;           /* NeRF_Model::mbUseDepth                 */
-    int32_t grid_grad_half_accum;/* oracle-only: 1 = accumulate grid grads sequentially in fp16 */
+    int32_t numerics_flags;      /* oracle-only, bit field (0 = the contract of DESIGN.md section 1):
+                                  *   ORC_NUM_GRID_HALF  accumulate grid gradients sequentially in fp16 (tcnn: atomicAdd(__half2))
+                                  *   ORC_NUM_TCNN_HALF  MODEL of tiny-cuda-nn's own accumulation (the submodule is absent; restated from
+                                  *                      its published kernels): kernel_grid sums the 8 corner products in __half
+                                  *                      (result += (T)(weight * value)); the fully fused MLP keeps __half WMMA
+                                  *                      accumulators -- modelled as one fp16 rounding per 16-wide k block, the products
+                                  *                      of a block summed in fp32 -- forward and backward; weight gradients leave the
+                                  *                      split-k GEMM as fp16.  Call sites nerf_model.cu:1557,1604,1644. */
 } orc_config;
+#define ORC_NUM_GRID_HALF 1
+#define ORC_NUM_TCNN_HALF 2
 
 typedef struct { uint32_t FrameId, x, y, h, w; } orc_bbox;   /* common.h:18-23 (h before w) */
 
@@ -364,21 +373,39 @@ static inline void level_corners(const orc_model* m, int l, const float* x, corn
     }
 }
 static void encode_one(const orc_model* m, const uint16_t* table /* grid part, [entry][2] */, const float* x, uint16_t* E) {
+    const int tcnn = m->cfg.numerics_flags & ORC_NUM_TCNN_HALF;
     for (int l = 0; l < m->L; ++l) {
         corners c; level_corners(m, l, x, &c); float a0 = 0.0f, a1 = 0.0f;
+        if (tcnn) {          /* tcnn kernel_grid: ((T*)&result)[f] += (T)(weight * (float)val[f]) with T = __half */
+            uint16_t r0 = 0, r1 = 0;
+            for (int k = 0; k < 8; ++k) { r0 = f2h(h2f(r0) + h2f(f2h(c.w[k] * h2f(table[2 * c.idx[k]])))); r1 = f2h(h2f(r1) + h2f(f2h(c.w[k] * h2f(table[2 * c.idx[k] + 1])))); }
+            E[2 * l] = r0; E[2 * l + 1] = r1; continue;
+        }
         for (int k = 0; k < 8; ++k) { a0 = fmaf(c.w[k], h2f(table[2 * c.idx[k]]), a0); a1 = fmaf(c.w[k], h2f(table[2 * c.idx[k] + 1]), a1); }
         E[2 * l] = f2h(a0); E[2 * l + 1] = f2h(a1);
     }
     for (int k = 2 * m->L; k < m->Epad; ++k) E[k] = 0;       /* TCNN-A9 zero padding */
 }
+/* dot product of two fp16 vectors (strides sa, sb).  Contract (tcnn = 0): one fp32 fmaf chain.  ORC_NUM_TCNN_HALF: the __half WMMA
+ * accumulator of tcnn's fully fused MLP -- every 16-wide k block adds its (fp32-summed) products into an fp16 running value. */
+static inline float dot_h(const uint16_t* a, int sa, const uint16_t* b, int sb, int n, int tcnn) {
+    if (!tcnn) { float acc = 0.0f; for (int k = 0; k < n; ++k) acc = fmaf(h2f(a[k * sa]), h2f(b[k * sb]), acc); return acc; }
+    uint16_t acc = 0;
+    for (int k0 = 0; k0 < n; k0 += 16) {
+        float blk = 0.0f; const int k1 = k0 + 16 < n ? k0 + 16 : n;
+        for (int k = k0; k < k1; ++k) blk = fmaf(h2f(a[k * sa]), h2f(b[k * sb]), blk);
+        acc = f2h(h2f(acc) + blk);
+    }
+    return h2f(acc);
+}
 /* fully-fused MLP forward (tcnn; no biases, ReLU hidden, linear output; TCNN-A10) */
 static void mlp_forward_one(const orc_model* m, const uint16_t* w, const uint16_t* E, uint16_t* hid /* NH*W */, uint16_t* out /* 4 */) {
-    const int W = m->W; const uint16_t* in = E; int nin = m->Epad;
+    const int W = m->W, tcnn = m->cfg.numerics_flags & ORC_NUM_TCNN_HALF; const uint16_t* in = E; int nin = m->Epad;
     for (int layer = 0; layer < m->NH; ++layer) {
-        for (int u = 0; u < W; ++u) { float a = 0.0f; for (int k = 0; k < nin; ++k) a = fmaf(h2f(w[u * nin + k]), h2f(in[k]), a); hid[layer * W + u] = f2h(a > 0.0f ? a : 0.0f); }
+        for (int u = 0; u < W; ++u) { float a = dot_h(w + u * nin, 1, in, 1, nin, tcnn); hid[layer * W + u] = f2h(a > 0.0f ? a : 0.0f); }
         w += W * nin; in = hid + layer * W; nin = W;
     }
-    for (int o = 0; o < ORC_OUT; ++o) { float a = 0.0f; for (int k = 0; k < W; ++k) a = fmaf(h2f(w[o * W + k]), h2f(in[k]), a); out[o] = f2h(a); }
+    for (int o = 0; o < ORC_OUT; ++o) out[o] = f2h(dot_h(w + o * W, 1, in, 1, W, tcnn));
 }
 /* stand-alone stage entry points (tests): params = fp16 parameter vector [n_params] */
 void orc_encode(const orc_model* m, const uint16_t* params, const float* x, size_t n, uint16_t* E) {
@@ -455,6 +482,7 @@ void orc_set_parallel_scatter(int on) { g_parallel_scatter = on; }
 static void forward_backward(orc_model* m) {
     const int R = m->R, S = m->S, W = m->W, NH = m->NH, Ep = m->Epad; const size_t B = (size_t)R * S;
     const uint16_t* wt = m->half; const uint16_t* table = m->half + m->n_mlp;
+    const int tcnn = m->cfg.numerics_flags & ORC_NUM_TCNN_HALF, grid_half = (m->cfg.numerics_flags & (ORC_NUM_GRID_HALF | ORC_NUM_TCNN_HALF)) != 0;
     #pragma omp parallel for schedule(static)
     for (long s = 0; s < (long)B; ++s) {
         encode_one(m, table, m->pts + 3 * s, m->E + (size_t)s * Ep);
@@ -477,17 +505,17 @@ static void forward_backward(orc_model* m) {
         uint16_t* dh = m->dHid + (size_t)s * W * NH; uint16_t* dE = m->dE + (size_t)s * Ep;
         const uint16_t* wout = wt + (size_t)W * Ep + (size_t)(NH - 1) * W * W;
         for (int u = 0; u < W; ++u) {
-            float a = 0.0f; for (int c = 0; c < ORC_OUT; ++c) a = fmaf(h2f(wout[c * W + u]), h2f(dO[c]), a);
+            float a = dot_h(wout + u, W, dO, 1, ORC_OUT, tcnn);      /* the 12 padded output rows carry no gradient */
             dh[(NH - 1) * W + u] = f2h(h2f(hid[(NH - 1) * W + u]) > 0.0f ? a : 0.0f);
         }
         for (int layer = NH - 1; layer >= 1; --layer) {
             const uint16_t* wl = wt + (size_t)W * Ep + (size_t)(layer - 1) * W * W;   /* maps layer-1 -> layer */
             for (int k = 0; k < W; ++k) {
-                float a = 0.0f; for (int u = 0; u < W; ++u) a = fmaf(h2f(wl[u * W + k]), h2f(dh[layer * W + u]), a);
+                float a = dot_h(wl + k, W, dh + layer * W, 1, W, tcnn);
                 dh[(layer - 1) * W + k] = f2h(h2f(hid[(layer - 1) * W + k]) > 0.0f ? a : 0.0f);
             }
         }
-        for (int k = 0; k < Ep; ++k) { float a = 0.0f; for (int u = 0; u < W; ++u) a = fmaf(h2f(wt[u * Ep + k]), h2f(dh[u]), a); dE[k] = f2h(a); }
+        for (int k = 0; k < Ep; ++k) dE[k] = f2h(dot_h(wt + k, Ep, dh, 1, W, tcnn));
     }
     /* weight gradients dW = sum_s d(out) x in^T, fp32, sample order */
     memset(m->gmlp, 0, (size_t)m->n_mlp * 4);
@@ -520,11 +548,12 @@ static void forward_backward(orc_model* m) {
         }
         for (int t = 0; t < nthreads; ++t) for (uint32_t k = 0; k < m->n_mlp; ++k) m->gmlp[k] += part[(size_t)t * m->n_mlp + k];
         free(part);
+        if (tcnn) for (uint32_t k = 0; k < m->n_mlp; ++k) m->gmlp[k] = h2f(f2h(m->gmlp[k]));      /* tcnn: the weight-gradient GEMMs write network_precision_t (fp16) */
     }
     /* grid backward (tcnn kernel_grid_backward): contribution = h(w * dE) per corner; serial for determinism */
     memset(m->ggrid, 0, (size_t)m->n_grid * 4); memset(m->ggrid_abs, 0, (size_t)m->n_grid * 4);
-    if (m->cfg.grid_grad_half_accum) memset(m->ggrid_h, 0, (size_t)m->n_grid * 2);
-    if (g_parallel_scatter && !m->cfg.grid_grad_half_accum) {
+    if (grid_half) memset(m->ggrid_h, 0, (size_t)m->n_grid * 2);
+    if (g_parallel_scatter && !grid_half) {
         /* CPU-baseline mode (bench.py): same contributions, accumulated with fp32 atomics in thread order */
         #pragma omp parallel for schedule(static)
         for (long s = 0; s < (long)B; ++s) {
@@ -552,11 +581,11 @@ static void forward_backward(orc_model* m) {
             for (int k = 0; k < 8; ++k) {
                 float c0 = h2f(f2h(c.w[k] * g0)), c1 = h2f(f2h(c.w[k] * g1)); size_t e = 2 * (size_t)c.idx[k];
                 m->ggrid[e] += c0; m->ggrid[e + 1] += c1; m->ggrid_abs[e] += fabsf(c0); m->ggrid_abs[e + 1] += fabsf(c1);
-                if (m->cfg.grid_grad_half_accum) { m->ggrid_h[e] = f2h(h2f(m->ggrid_h[e]) + c0); m->ggrid_h[e + 1] = f2h(h2f(m->ggrid_h[e + 1]) + c1); }
+                if (grid_half) { m->ggrid_h[e] = f2h(h2f(m->ggrid_h[e]) + c0); m->ggrid_h[e + 1] = f2h(h2f(m->ggrid_h[e + 1]) + c1); }
             }
         }
     }
-    if (!m->cfg.grid_grad_half_accum) for (uint32_t k = 0; k < m->n_grid; ++k) m->ggrid_h[k] = f2h(m->ggrid[k]);
+    if (!grid_half) for (uint32_t k = 0; k < m->n_grid; ++k) m->ggrid_h[k] = f2h(m->ggrid[k]);
 }
 
 /* ------------------------------------------------------------------ Trainer::optimizer_step (tcnn), nerf_model.cu:1644

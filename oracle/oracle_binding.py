@@ -14,7 +14,10 @@ class OrcConfig(C.Structure):
                 ("n_samples", C.c_int32), ("loss_scale", C.c_float), ("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("epsilon", C.c_float), ("l2_reg", C.c_float), ("ema_decay", C.c_float), ("decay_start", C.c_int32), ("decay_interval", C.c_int32),
                 ("decay_base", C.c_float), ("param_seed", C.c_uint32), ("reserved0", C.c_uint32), ("sample_seed", C.c_uint64),
-                ("use_depth", C.c_int32), ("grid_grad_half_accum", C.c_int32)]
+                ("use_depth", C.c_int32), ("numerics_flags", C.c_int32)]
+
+
+NUM_GRID_HALF, NUM_TCNN_HALF = 1, 2
 
 
 class OrcBBox(C.Structure):
@@ -25,9 +28,15 @@ def default_config(**kw):
     c = OrcConfig(n_levels=16, n_features=2, log2_hashmap_size=16, base_resolution=16, per_level_scale=2.0, n_neurons=64, n_hidden_layers=1,
                   rays_per_batch=4096, n_samples=32, loss_scale=128.0, learning_rate=1e-2, beta1=0.9, beta2=0.99, epsilon=1e-15, l2_reg=1e-6,
                   ema_decay=0.95, decay_start=20000, decay_interval=10000, decay_base=0.33, param_seed=1337, sample_seed=2024, use_depth=0,
-                  grid_grad_half_accum=0)
+                  numerics_flags=0)
+    flags = 0
+    if kw.pop("grid_grad_half_accum", 0):          # ORC_NUM_GRID_HALF: grid gradients accumulated sequentially in fp16 (tcnn: atomicAdd(__half2))
+        flags |= NUM_GRID_HALF
+    if kw.pop("tcnn_half_accum", 0):               # ORC_NUM_TCNN_HALF: model of tiny-cuda-nn's own fp16 accumulation (encode, MLP fwd/bwd, dW)
+        flags |= NUM_TCNN_HALF
     for k, v in kw.items():
         setattr(c, k, v)
+    c.numerics_flags |= flags
     return c
 
 

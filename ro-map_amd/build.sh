@@ -7,9 +7,11 @@ OBJ="$HERE/build"; mkdir -p "$OBJ"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -ffp-contract=off -fno-math-errno -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result)
 SRCS=(config.cpp model.cpp c_api.cpp manager.cpp png_io.cpp mesh.cpp kernels_batch.hip kernels_net.hip kernels_composite.hip kernels_optim.hip kernels_fused.hip kernels_bigscatter.hip kernels_mesh.hip microbench.hip)
 pids=()
+# every object depends on every header (frag_layout.h is the MFMA weight image shared by k_optimizer and k_fused_train: a partial rebuild must not mix layouts)
+newest_hdr="$HERE/../include/mon_core.h"; for h in "$HERE"/csrc/*.h; do [[ "$h" -nt "$newest_hdr" ]] && newest_hdr="$h"; done
 for s in "${SRCS[@]}"; do
   o="$OBJ/${s%.*}.o"
-  if [[ ! -f "$o" || "$HERE/csrc/$s" -nt "$o" || "$HERE/csrc/model.h" -nt "$o" || "$HERE/csrc/device_common.h" -nt "$o" || "$HERE/../include/mon_core.h" -nt "$o" ]]; then
+  if [[ ! -f "$o" || "$HERE/csrc/$s" -nt "$o" || "$newest_hdr" -nt "$o" || "$HERE/build.sh" -nt "$o" ]]; then
     "$HIPCC" "${FLAGS[@]}" -c "$HERE/csrc/$s" -o "$o" &
     pids+=($!)
   fi

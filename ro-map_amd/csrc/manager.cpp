@@ -73,10 +73,24 @@ struct OfflineManager {
     int mesh_res = 64; float mesh_thresh = 2.0f;   // marching_cubes.h:30-31
 };
 
+// cv::FileStorage looks keys up exactly (nerf_data.cu:39-46): the key must start a line (after blanks), be followed by blanks and
+// ':', and carry a number; comment lines and longer keys with the same prefix (Camera.Height vs Camera.H) do not match.
 static bool read_yaml_number(const std::string& text, const char* key, double& v) {
-    const size_t p = text.find(key); if (p == std::string::npos) return false;
-    const size_t c = text.find(':', p); if (c == std::string::npos) return false;
-    v = std::strtod(text.c_str() + c + 1, nullptr); return true;
+    const size_t klen = std::strlen(key); size_t ls = 0;
+    while (ls < text.size()) {
+        size_t le = text.find('\n', ls); if (le == std::string::npos) le = text.size();
+        size_t p = ls; while (p < le && (text[p] == ' ' || text[p] == '\t')) ++p;
+        if (p + klen <= le && text.compare(p, klen, key) == 0) {
+            size_t q = p + klen; while (q < le && (text[q] == ' ' || text[q] == '\t')) ++q;
+            if (q < le && text[q] == ':') {
+                const char* b = text.c_str() + q + 1; char* e = nullptr; const double x = std::strtod(b, &e);
+                if (e != b && e <= text.c_str() + le) { v = x; return true; }
+                return false;                                   // the key is there but carries no number
+            }
+        }
+        ls = le + 1;
+    }
+    return false;
 }
 
 int offline_init(OfflineManager& m) {                                   // nerf_manager.cu:16-38
@@ -92,10 +106,17 @@ int offline_read_dataset(OfflineManager& m) {                           // nerf_
     std::ifstream fc(m.dataset + "/config.yaml");
     if (!fc) { set_error("Failed to open settings file at: %s/config.yaml", m.dataset.c_str()); return MON_ERR_IO; }
     std::stringstream ss; ss << fc.rdbuf(); const std::string y = ss.str(); double v;
-    if (!read_yaml_number(y, "Camera.fx", v)) { set_error("config.yaml: Camera.fx missing"); return MON_ERR_IO; } m.fx = (float)v;
-    read_yaml_number(y, "Camera.fy", v); m.fy = (float)v; read_yaml_number(y, "Camera.cx", v); m.cx = (float)v; read_yaml_number(y, "Camera.cy", v); m.cy = (float)v;
-    read_yaml_number(y, "Camera.H", v); m.H = (int)v; read_yaml_number(y, "Camera.W", v); m.W = (int)v;
-    if (m.use_depth && read_yaml_number(y, "DepthMapFactor", v)) m.depth_scale = (float)v;
+    const struct { const char* key; float* f; int* i; } fields[] = { { "Camera.fx", &m.fx, nullptr }, { "Camera.fy", &m.fy, nullptr }, { "Camera.cx", &m.cx, nullptr }, { "Camera.cy", &m.cy, nullptr },
+                                                                     { "Camera.H", nullptr, &m.H }, { "Camera.W", nullptr, &m.W } };
+    for (const auto& fd : fields) {
+        if (!read_yaml_number(y, fd.key, v)) { set_error("config.yaml: %s missing or not a number", fd.key); return MON_ERR_IO; }
+        if (fd.f) *fd.f = (float)v; else *fd.i = (int)v;
+    }
+    if (m.H <= 0 || m.W <= 0 || !(m.fx > 0.f) || !(m.fy > 0.f)) { set_error("config.yaml: bad intrinsics (fx %g fy %g H %d W %d)", (double)m.fx, (double)m.fy, m.H, m.W); return MON_ERR_IO; }
+    if (m.use_depth) {
+        if (!read_yaml_number(y, "DepthMapFactor", v)) { set_error("config.yaml: DepthMapFactor missing or not a number"); return MON_ERR_IO; }
+        m.depth_scale = (float)v;
+    }
     std::ifstream fi(m.dataset + "/img.txt"), fg(m.dataset + "/groundtruth.txt"); std::string line;
     if (!fi || !fg) { set_error("Load dataset error: img.txt / groundtruth.txt missing in %s", m.dataset.c_str()); return MON_ERR_IO; }
     std::getline(fi, line);                                             // skip comments
@@ -113,8 +134,18 @@ int offline_read_dataset(OfflineManager& m) {                           // nerf_
     for (size_t i = 0; i < n; ++i) {
         PngImage c, s, z;
         if (!png_read(m.dataset + "/rgb/" + m.names[i], c, err) || !png_read(m.dataset + "/instance/" + m.names[i], s, err)) { set_error("%s", err.c_str()); return MON_ERR_IO; }
-        if (c.width != m.W || c.height != m.H || s.width != m.W || s.height != m.H || c.bit_depth != 8 || c.channels < 3 || s.bit_depth != 8) { set_error("image %s does not match config.yaml", m.names[i].c_str()); return MON_ERR_IO; }
-        for (size_t p = 0; p < px; ++p) { rgb[3 * p] = c.data[p * c.channels]; rgb[3 * p + 1] = c.data[p * c.channels + 1]; rgb[3 * p + 2] = c.data[p * c.channels + 2]; inst[p] = s.data[p * s.channels]; }
+        if (c.width != m.W || c.height != m.H || s.width != m.W || s.height != m.H || s.bit_depth != 8) { set_error("image %s does not match config.yaml", m.names[i].c_str()); return MON_ERR_IO; }
+        {   // cv::imread(IMREAD_COLOR), nerf_data.cu:158: gray is replicated to three channels, alpha dropped, 16-bit samples reduced to their high byte
+            const size_t sb = c.bit_depth == 16 ? 2 : 1, pb = (size_t)c.channels * sb; const bool gray = c.channels < 3;
+            for (size_t p = 0; p < px; ++p) {
+                const uint8_t* q = &c.data[p * pb];
+                rgb[3 * p] = q[0]; rgb[3 * p + 1] = gray ? q[0] : q[sb]; rgb[3 * p + 2] = gray ? q[0] : q[2 * sb];
+            }
+            // instance: IMREAD_UNCHANGED, first byte of every pixel (nerf_data.cu:196-207 reads the buffer as one u8 per pixel); OpenCV orders colour
+            // pixels B,G,R, so for a colour / palette mask that byte is the blue sample
+            const int ic = s.channels >= 3 ? 2 : 0;
+            for (size_t p = 0; p < px; ++p) inst[p] = s.data[p * s.channels + ic];
+        }
         if (m.use_depth) {
             if (!png_read(m.dataset + "/depth/" + m.names[i], z, err)) { set_error("%s", err.c_str()); return MON_ERR_IO; }
             if (z.width != m.W || z.height != m.H || z.bit_depth != 16) { set_error("depth image %s must be 16-bit %dx%d", m.names[i].c_str(), m.W, m.H); return MON_ERR_IO; }
@@ -426,7 +457,7 @@ int mon_online_dataset_init(mon_online* h, float fx, float fy, float cx, float c
     if (!m.ds.empty()) { set_error("DatasetInit called twice"); return MON_ERR_STATE; }
     m.n_images = imgs; m.ds_mutex.resize(m.n_dev); m.H = H; m.W = W;
     for (int g = 0; g < m.n_dev; ++g) m.dev_objects.emplace_back(new std::atomic<int>(0));
-    for (int g = 0; g < m.n_dev; ++g) stream_pool_reserve(g, 8);          // CreateNeRF runs on the SLAM thread later: take the ~8 ms per stream now
+    for (int g = 0; g < m.n_dev; ++g) { const int rcs = stream_pool_reserve(g, 8); if (rcs) return rcs; }          // CreateNeRF runs on the SLAM thread later: take the ~8 ms per stream now
     for (int g = 0; g < m.n_dev; ++g) { Dataset* d = nullptr; int rc = dataset_create(g, H, W, fx, fy, cx, cy, (uint32_t)imgs, m.use_depth, &d); if (rc) return rc; m.ds.push_back(d); }
     return MON_OK;
 }

@@ -49,7 +49,8 @@ int dataset_create(int device, int H, int W, float fx, float fy, float cx, float
     const size_t px = (size_t)H * W;
     const auto alloc = [&]() -> int {
         HIPCHECK(hipMalloc((void**)&d->d_rgba, px * 4 * max_frames));
-        if (d->use_depth) HIPCHECK(hipMalloc((void**)&d->d_depth, px * 4 * max_frames));
+        HIPCHECK(hipMemset(d->d_rgba, 0, px * 4 * max_frames));          // a frame id never uploaded reads as black / instance 0, not as whatever the allocation held
+        if (d->use_depth) { HIPCHECK(hipMalloc((void**)&d->d_depth, px * 4 * max_frames)); HIPCHECK(hipMemset(d->d_depth, 0, px * 4 * max_frames)); }
         HIPCHECK(hipMalloc((void**)&d->d_poses, 64 * (size_t)max_frames));
         HIPCHECK(hipMemset(d->d_poses, 0, 64 * (size_t)max_frames));
         return MON_OK;
@@ -97,9 +98,14 @@ int stream_pool_reserve(int device, int n) {
     HIPCHECK(hipSetDevice(device));
     std::vector<hipStream_t> fresh;
     { std::lock_guard<std::mutex> l(g_stream_mu); n -= (int)g_stream_pool[device].size(); }
-    for (int i = 0; i < n; ++i) { hipStream_t s; HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); fresh.push_back(s); }
-    std::lock_guard<std::mutex> l(g_stream_mu); for (hipStream_t s : fresh) g_stream_pool[device].push_back(s);
-    return MON_OK;
+    int rc = MON_OK;
+    for (int i = 0; i < n; ++i) {
+        hipStream_t s; const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (e != hipSuccess) { set_error("hipStreamCreateWithFlags failed: %s", hipGetErrorString(e)); rc = MON_ERR_HIP; break; }
+        fresh.push_back(s);
+    }
+    std::lock_guard<std::mutex> l(g_stream_mu); for (hipStream_t s : fresh) g_stream_pool[device].push_back(s);      // what was created is kept either way
+    return rc;
 }
 
 template <class T> static int dev_alloc(Model& m, T*& p, size_t n, bool zero = true) {
@@ -221,6 +227,10 @@ int model_add_boxes(Model& m, const mon_frame_bbox* boxes, size_t n) {
         if (b.FrameId >= m.ds->max_frames || b.w == 0 || b.h == 0 || b.x + b.w > (uint32_t)m.ds->K.W || b.y + b.h > (uint32_t)m.ds->K.H) {
             set_error("add_boxes: box %zu (frame %u, x %u y %u h %u w %u) outside the %dx%d image / dataset capacity", i, b.FrameId, b.x, b.y, b.h, b.w, m.ds->K.W, m.ds->K.H);
             return MON_ERR_ARG;
+        }
+        if (!m.ds->present[b.FrameId]) {          // the reference's callers always hand the frame over first (LocalMapping.cc:1175 before :1242); rays of an absent frame would train on nothing
+            set_error("add_boxes: box %zu names frame %u, which has not been added to the dataset", i, b.FrameId);
+            return MON_ERR_STATE;
         }
     }
     HIPCHECK(hipStreamSynchronize(m.train_stream));

@@ -226,32 +226,63 @@ def test_learning_rate_decay_follows_the_oracle(pkg, orc, small_scene, backend):
     obj.close(); ds.close(); ref.close()
 
 
+def _trained_pair_scores(pkg, orc, ss, sc, kw, backend, steps, every=4):
+    """Trains the HIP object and the oracle on identical schedules; returns (mutual PSNRs per crop, abs PSNR HIP, abs PSNR oracle, losses)."""
+    _need_gpu(pkg)
+    ds, obj = ge.make_problem(pkg, sc, kw); obj.set_backend(backend); ref = ge.make_oracle(orc, sc, kw)
+    l_hip = obj.train(steps); l_ref = ref.train(steps)
+    mutual, a_hip, a_ref = [], [], []
+    for box in sc.objects[0]["boxes"][::every]:
+        v, x, y, h, w = (int(q) for q in box); pose = ss.colmajor(sc.Twc[v])
+        rgb, depth, mask = obj.render(box, pose); rrgb, rdepth, rmask = ref.render(box, pose)
+        gt = sc.rgb[v, y:y + h, x:x + w] / 255.0; gm = sc.instance[v, y:y + h, x:x + w] > 0
+        gtw = np.where(gm[..., None], gt, 1.0)
+        mutual.append(psnr(rgb, rrgb)); a_hip.append(psnr(rgb, gtw)); a_ref.append(psnr(rrgb, gtw))
+    obj.close(); ds.close(); ref.close()
+    return mutual, a_hip, a_ref, (l_hip, l_ref)
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_training_parity_psnr_c1(pkg, orc, ss, small_scene, backend):
-    """BASELINE configs[0]: identical schedules on both sides.  Training is chaotic (fp16 rounding, summation order), so a
-    single pair of runs differs by the run-to-run spread (measured on MI355X over 6 sampling seeds, tools/psnr_study.py:
-    absolute PSNR std 0.7-1.0 dB for the oracle and both HIP backends, per-seed HIP-oracle difference within +-0.3 dB for 4 of
-    4 seeds).  The test therefore averages 3 seeds: mean absolute PSNR within 0.8 dB of the oracle's, mutual PSNR > 28 dB."""
+    """BASELINE configs[0]: identical schedules on both sides, 300 steps, three sampling seeds.  Training amplifies any last-place
+    difference (the HIP path differs from the oracle by expf / summation-order ulps from step 0), so the bar for TRAINED models is
+    derived from the committed chaos-floor fixture (tests/golden/numerics_study.json, tests/test_numerics_study.py): the oracle
+    against itself started one fp16 ulp away reaches 33.1 dB (min) mutual PSNR and differs by up to 0.84 dB in mean-of-three
+    absolute PSNR.  Required here: mutual PSNR (min over crops and seeds) above that floor minus 3 dB, mean-of-three absolute
+    PSNR within the floor's own spread of the oracle's."""
+    from test_numerics_study import trained_model_bars
+    mutual_floor, abs_tol = trained_model_bars()
     sc = small_scene; steps = 300; abs_hip, abs_ref, mutual = [], [], []
     for seed in (11, 12, 13):
-        _need_gpu(pkg)
-        kw = dict(C1, sample_seed=seed)
-        ds, obj = ge.make_problem(pkg, sc, kw); obj.set_backend(backend); ref = ge.make_oracle(orc, sc, kw)
-        l_hip = obj.train(steps); l_ref = ref.train(steps)
+        mu, ah, ar, (l_hip, l_ref) = _trained_pair_scores(pkg, orc, ss, sc, dict(C1, sample_seed=seed), backend, steps)
         assert l_hip < 0.05 and abs(l_hip - l_ref) < max(l_ref, 0.02)          # last-iteration losses of two chaotic runs on the same batch
-        for box in sc.objects[0]["boxes"][::4]:
-            v, x, y, h, w = (int(q) for q in box); pose = ss.colmajor(sc.Twc[v])
-            rgb, depth, mask = obj.render(box, pose); rrgb, rdepth, rmask = ref.render(box, pose)
-            gt = sc.rgb[v, y:y + h, x:x + w] / 255.0; gm = sc.instance[v, y:y + h, x:x + w] > 0
-            gtw = np.where(gm[..., None], gt, 1.0)
-            mutual.append(psnr(rgb, rrgb)); abs_hip.append(psnr(rgb, gtw)); abs_ref.append(psnr(rrgb, gtw))
-        obj.close(); ds.close(); ref.close()
-    print("backend %d: mutual PSNR min %.2f dB, abs HIP %.2f dB, abs oracle %.2f dB" % (backend, min(mutual), np.mean(abs_hip), np.mean(abs_ref)))
-    assert min(mutual) > 28.0
+        mutual += mu; abs_hip += ah; abs_ref += ar
+    print("backend %d: mutual PSNR min %.2f dB (bar %.2f), abs HIP %.2f dB, abs oracle %.2f dB (tol %.2f)" % (backend, min(mutual), mutual_floor, np.mean(abs_hip), np.mean(abs_ref), abs_tol))
     # backend 1 is deterministic (integer scatter); backend 0 sums the grid gradient with fp16 global atomics in arrival order, so
-    # its trained weights differ from run to run: observed mean-of-3 absolute PSNR 30.4 .. 31.3 dB against the oracle's 31.33 dB
-    tol = 0.8 if backend == 1 else 1.6
-    assert abs(np.mean(abs_hip) - np.mean(abs_ref)) < tol and np.mean(abs_hip) > 24.0
+    # its trained weights differ from run to run on top of the floor: observed mean-of-3 absolute PSNR 30.4 .. 31.3 dB against the oracle's 31.33 dB
+    assert min(mutual) > (mutual_floor if backend == 1 else mutual_floor - 2.0)
+    assert abs(np.mean(abs_hip) - np.mean(abs_ref)) < (abs_tol if backend == 1 else 2.0 * abs_tol) and np.mean(abs_hip) > 24.0
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_training_parity_psnr_c2_base_json_200_steps(pkg, orc, ss, backend):
+    """BASELINE configs[1] (base.json defaults at the full batch: R=4096 x S=32, hash L=16, MLP 64x1): 200 training steps on identical
+    schedules, HIP path against the oracle -- mutual and absolute PSNR of rendered training crops, same fixture-derived bar as C1
+    (the larger network averages more samples per step; it stays well inside it)."""
+    from test_numerics_study import trained_model_bars
+    mutual_floor, abs_tol = trained_model_bars()
+    sc = ss.make_scene(n_views=12, H=120, W=160, f=130.0, seed=0)
+    # the oracle's serial grid scatter costs ~0.1 s per full-size step: use its parallel mode (same contributions, fp32 atomics in thread
+    # order -- a summation-order difference far below the chaos floor) and a larger team for this one test
+    orc.lib().orc_set_parallel_scatter(1); orc.lib().orc_set_threads(min(32, os.cpu_count() or 1))
+    try:
+        mu, ah, ar, (l_hip, l_ref) = _trained_pair_scores(pkg, orc, ss, sc, dict(C2, sample_seed=21), backend, 200, every=3)
+    finally:
+        orc.lib().orc_set_parallel_scatter(0); orc.lib().orc_set_threads(int(os.environ.get("MON_ORACLE_THREADS", min(16, os.cpu_count() or 1))))
+    print("C2 backend %d: mutual PSNR min %.2f mean %.2f dB, abs HIP %.2f dB, abs oracle %.2f dB, loss %.5f / %.5f" % (backend, min(mu), np.mean(mu), np.mean(ah), np.mean(ar), l_hip, l_ref))
+    assert np.isfinite(l_hip) and abs(l_hip - l_ref) < max(l_ref, 0.02)
+    assert min(mu) > (mutual_floor if backend == 1 else mutual_floor - 2.0)
+    assert abs(np.mean(ah) - np.mean(ar)) < 2.0 * abs_tol and np.mean(ah) > 24.0          # single seed: twice the mean-of-three tolerance
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
