@@ -33,6 +33,9 @@ struct LevelTable {
 struct LevelFast {
     float scale[kMaxLevels];
     uint32_t size[kMaxLevels], my[kMaxLevels], mz[kMaxLevels], mask[kMaxLevels], hashed[kMaxLevels], offset[kMaxLevels + 1];
+    // fixed-point unit of the exact LDS gradient accumulation (k_grid_scatter, k_big_accum): 2^24 for loss_scale <= 128, coarser by the
+    // same power of two for larger loss scales; every contribution is clamped to +-fix_clamp first (|contribution| * fix_scale < 2^31)
+    float fix_scale, fix_clamp;
 };
 
 __host__ __device__ inline uint32_t fast_grid_index(const LevelFast& lf, int l, uint32_t x, uint32_t y, uint32_t z) {

@@ -23,7 +23,6 @@
 namespace mon {
 
 constexpr uint32_t kBigTile = 8192, kBigTileShift = 13, kBigBins = 16, kBigMaxTiles = 2048;   // 64 KB of LDS per tile (two workgroups per CU); up to 2^24 entries per level
-constexpr float kBigFixScale = 16777216.0f;
 
 struct BigLevels { int n; int level[kMaxLevels]; uint32_t tiles[kMaxLevels]; uint32_t tile_base[kMaxLevels + 1]; };
 
@@ -36,8 +35,8 @@ __device__ __forceinline__ void for_bin_samples(const LevelFast& lf, int level, 
         const half2_t g = de[s];
         float g0 = (float)g.x, g1 = (float)g.y;
         if (g0 == 0.f && g1 == 0.f) continue;
-        g0 = clamp_f(g0, -100.f, 100.f); g1 = clamp_f(g1, -100.f, 100.f);
-        const float x[3] = { x_soa[s], x_soa[(size_t)B + s], x_soa[2 * (size_t)B + s] };
+        g0 = clamp_f(g0, -lf.fix_clamp, lf.fix_clamp); g1 = clamp_f(g1, -lf.fix_clamp, lf.fix_clamp);
+        const float4_t xv = reinterpret_cast<const float4_t*>(x_soa)[s]; const float x[3] = { xv[0], xv[1], xv[2] };
         level_corners(lf, level, x, [&](int, uint32_t idx, float w) {
             const half2_t c = { (half_t)(w * g0), (half_t)(w * g1) };                      // tcnn: (T)(weight * grad)
             const uint32_t bits = __builtin_bit_cast(uint32_t, c);
@@ -107,7 +106,7 @@ __global__ void __launch_bounds__(1024) k_big_accum(LevelFast lf, BigLevels big,
     const uint2* in = rec + (size_t)bl * 8u * B + tile_off[(size_t)bl * kBigMaxTiles + t];
     for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
         const uint2 r = in[i]; const uint32_t local = r.x - base; const half2_t c = __builtin_bit_cast(half2_t, r.y);
-        const int f0 = (int)((float)c.x * kBigFixScale), f1 = (int)((float)c.y * kBigFixScale);   // exact: every fp16 value is a multiple of 2^-24
+        const int f0 = (int)((float)c.x * lf.fix_scale), f1 = (int)((float)c.y * lf.fix_scale);   // exact for loss_scale <= 128: every fp16 value is a multiple of 2^-24
         if (f0) atomicAdd(tab + 2u * local, f0);
         if (f1) atomicAdd(tab + 2u * local + 1u, f1);
     }
@@ -116,7 +115,7 @@ __global__ void __launch_bounds__(1024) k_big_accum(LevelFast lf, BigLevels big,
     for (uint32_t i = threadIdx.x; i < tile; i += blockDim.x) {
         const int a0 = tab[2u * i], a1 = tab[2u * i + 1u];
         if (a0 | a1) {
-            dst[i] = __builtin_bit_cast(uint32_t, half2_t{ (half_t)((float)a0 * (1.0f / kBigFixScale)), (half_t)((float)a1 * (1.0f / kBigFixScale)) });
+            dst[i] = __builtin_bit_cast(uint32_t, half2_t{ (half_t)((float)a0 * (1.0f / lf.fix_scale)), (half_t)((float)a1 * (1.0f / lf.fix_scale)) });
             if (touched_grid) touched_grid[(lf.offset[level] + base + i) >> 2] = 1;          // the optimizer's chunk flag (4 entries = 8 parameters)
         }
     }

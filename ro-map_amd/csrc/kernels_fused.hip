@@ -82,6 +82,22 @@ __device__ __forceinline__ int unit_of_slot(int s, int h, int j) { return 32 * (
 #ifndef MON_ENCODE_BATCH
 #define MON_ENCODE_BATCH 4
 #endif
+// experiment switches (tools/variant_build.sh -D...): MON_V_GATHER 0 = both index forms + select per corner, 1 = scalar branch on the level kind,
+// 2 = 1 + the level's table offset in the buffer load's SGPR offset; MON_V_SCALAR 1 = wave-uniform ray bookkeeping pinned to SGPRs
+#ifndef MON_V_GATHER
+#define MON_V_GATHER 1
+#endif
+#ifndef MON_V_SCALAR
+#define MON_V_SCALAR 0          // measured: -2 us with the bookkeeping left on the vector unit (100 SGPRs were already in use; the scalar version spills them into VGPR lanes)
+#endif
+#ifndef MON_V_SBATCH
+#define MON_V_SBATCH 4          // samples per thread and software-pipeline round of k_grid_scatter
+#endif
+#if MON_V_SCALAR
+#define MON_UNIFORM(x) __builtin_amdgcn_readfirstlane((int)(x))
+#else
+#define MON_UNIFORM(x) (x)
+#endif
 constexpr int kEncodeBatch = MON_ENCODE_BATCH;
 
 template <int EPAD, int W, int NH> struct FusedShape {
@@ -121,7 +137,7 @@ struct FusedArgs {
     float* partials;            // [gridDim.x][N_MLP + 64] fp32: dW partial sums, slot N_MLP = loss partial
     DevState* st;
     half2_t* de_soa;            // [L][B] dL/dE of the levels scattered through LDS (k_grid_scatter), or nullptr
-    float* x_soa;               // [3][B] warped sample positions for k_grid_scatter
+    float* x_soa;               // [B] float4 {x, y, z, 0}: warped sample positions for k_grid_scatter
     uint32_t lds_level_mask;    // bit l set: level l goes through k_grid_scatter instead of global atomics
     const uint16_t* frag_image; // A fragments in LDS layout (k_build_frag_image), N_FRAGS x 512 halves
     uint32_t ablate;            // timing experiments only (MON_FUSED_ABLATE): 2 no dW, 4 no dE/x stores, 8 no rays (prologue + epilogue only), 16 keep zero-gradient samples
@@ -223,15 +239,16 @@ __device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const h
     //      v_permlane32_swap per value then hands each half the 8 corners of the level it owns, and the interpolation runs
     //      the same chain in the same order as before (bit-identical results).
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half2_t*>(table), 0, (int)(klt.offset[L] * 4u), 0x00020000);
-    auto half_gather = [&](int level, uint32_t (&r)[4]) {                              // `level` is wave-uniform: constants come from SGPRs
+    auto half_gather = [&](int level, uint32_t (&r)[4]) {                              // `level` is wave-uniform: constants come from SGPRs, the hashed / dense choice is a scalar branch
         const float scale = klt.scale[level];
-        const uint32_t size = klt.size[level], my = klt.my[level], mz = klt.mz[level], mask = klt.mask[level], off = klt.offset[level];
-        const bool hashed = klt.hashed[level] != 0u;
+        const uint32_t size = klt.size[level], my = klt.my[level], mz = klt.mz[level], mask = klt.mask[level], off4 = klt.offset[level] * 4u;
         uint32_t pg[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) pg[d] = (uint32_t)(int32_t)floorf(fmaf(scale, x[d], 0.5f));
         const uint32_t ax = pg[0] + (uint32_t)h, y0 = pg[1] * my, z0 = pg[2] * mz;
         const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
+#if MON_V_GATHER == 0
+        const bool hashed = klt.hashed[level] != 0u; const uint32_t off = klt.offset[level];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t ih = ax ^ ay[j & 1] ^ az[j >> 1], id = ax + ay[j & 1] + az[j >> 1];
@@ -240,6 +257,31 @@ __device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const h
             idx = min(idx, size - 1u);
             r[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (off + idx) * 4u, 0, 0);
         }
+#else
+        if (klt.hashed[level] != 0u) {                                                  // hashed levels hold 2^T entries: the mask IS the modulo
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t idx = (ax ^ ay[j & 1] ^ az[j >> 1]) & mask;
+#if MON_V_GATHER == 2
+                r[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, idx << 2, off4, 0);
+#else
+                r[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (idx << 2) + off4, 0, 0);
+#endif
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t idx = (ax + ay[j & 1] + az[j >> 1]) & mask;
+                idx -= (idx >= size) ? size : 0u;                                       // dense sizes are not powers of two: index < 2 * size, so % size is one subtract
+                idx = min(idx, size - 1u);                                              // memory safety for positions far outside [0,1]^3 (never produced by the sampler)
+#if MON_V_GATHER == 2
+                r[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, idx << 2, off4, 0);
+#else
+                r[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (idx << 2) + off4, 0, 0);
+#endif
+            }
+        }
+#endif
     };
     constexpr int EB = (S::LLV < kEncodeBatch) ? S::LLV : kEncodeBatch;              // level pairs in flight
 #pragma unroll
@@ -363,7 +405,9 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     TimingCtx* tc = nullptr;
 #endif
     build_fragments<EPAD, W, NH>(frags, llt, a, true);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+    // the wave index is uniform by construction, but anything derived from threadIdx is divergent to the compiler: pin it to an SGPR so that the ray
+    // bookkeeping below (ray index, candidate search, the candidate record, the background colour's RNG) runs on the scalar unit and in scalar registers
+    const int wave = MON_UNIFORM(threadIdx.x >> 6), lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
     half_t* scr = reinterpret_cast<half_t*>(dyn + wave * S::SCR_BYTES);
     for (int i = 2 * a.nd.L * 32 + lane; i < EPAD * 32; i += 64) scr[S::SCR_E + i] = (half_t)0.f;   // pad feature rows stay zero; every other row is rewritten per ray before it is read
     // ---- ray compaction table (fill_rollover_rays :280-294 without a kernel of its own): every workgroup scans the
@@ -408,12 +452,12 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         // ---- which candidate is this ray (wave-uniform binary search over the prefix table + in-word select)
         const uint32_t kth = ray % nvalid;
         uint32_t lo = 0, hi = nwords - 1u;
-        while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if (cprefix[mid] <= kth) lo = mid; else hi = mid - 1u; }
+        while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if ((uint32_t)MON_UNIFORM(cprefix[mid]) <= kth) lo = mid; else hi = mid - 1u; }
         uint32_t cand;
         { unsigned long long wd = cwords[lo]; uint32_t kk = kth - cprefix[lo], pos = 0;
 #pragma unroll
           for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t c = __popcll(wd & ((1ull << sh) - 1ull)); if (kk >= c) { kk -= c; wd >>= sh; pos += sh; } }
-          cand = (lo << 6) + pos; }
+          cand = (uint32_t)MON_UNIFORM((lo << 6) + pos); }          // (the table lives in LDS: the reads came back in VGPRs)
         const uint32_t rgba = a.b.cand_rgba[cand];
         const bool is_obj = (rgba >> 24) != 0u;
         // ---- sample position (GenerateInputPoints, nerf_model.cu:553-566)
@@ -632,14 +676,15 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         const uint32_t bin_cap = Btot >> 4, in_bin = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_base) + __popc(nz32 & ((1u << n) - 1u));
         const uint32_t slot = (ray & 15u) * bin_cap + in_bin;                              // a bin holds the samples of R/16 rays at most
         const bool do_store = (a.ablate & 4u) == 0u && mine && in_bin < bin_cap;
-        if (lds_level_mask && h == 0 && do_store) { a.x_soa[slot] = x[0]; a.x_soa[Btot + slot] = x[1]; a.x_soa[2u * Btot + slot] = x[2]; }
+        if (lds_level_mask && h == 0 && do_store) reinterpret_cast<float4_t*>(a.x_soa)[slot] = float4_t{ x[0], x[1], x[2], 0.f };          // one 16-byte store per sample
 #pragma unroll
         for (int il = 0; il < S::LLV; ++il) {
             const int level = h * LPH + il;
             if (il < LPH && level < L) {
                 const half_t q0 = (half_t)de[2 * il], q1 = (half_t)de[2 * il + 1];
                 if (!ATOMIC_LEVELS || ((lds_level_mask >> level) & 1u)) {
-                    if (do_store) a.de_soa[(size_t)level * Btot + slot] = half2_t{ q0, q1 };
+                    // (clamped to the fixed-point range of the exact LDS accumulation, LevelFast::fix_clamp: |dL/dE| * fix_scale stays inside int32)
+                    if (do_store) a.de_soa[(size_t)level * Btot + slot] = half2_t{ (half_t)clamp_f((float)q0, -a.lt.fix_clamp, a.lt.fix_clamp), (half_t)clamp_f((float)q1, -a.lt.fix_clamp, a.lt.fix_clamp) };
                 } else if constexpr (ATOMIC_LEVELS) {
                     const float gq0 = (float)q0, gq1 = (float)q1;
                     if (gq0 != 0.f || gq1 != 0.f) {
@@ -691,89 +736,143 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
 }
 
 // ------------------------------------------------------------------ LDS grid scatter
-// Measured on MI355X (profiles/microbench_r01.md): global_atomic_pk_add_f16 sustains ~21 Gop/s chip-wide, LDS
-// floating-point atomics (ds_pk_add_f16, ds_add_f32) ~0.35 op/clk/CU, LDS integer atomics (ds_add_u32) ~2.4
-// op/clk/CU.  So the scatter accumulates in LDS in int32 FIXED POINT with scale 2^24: every fp16 value is an
-// exact multiple of 2^-24, so each contribution h(w * dE) converts exactly, integer addition is exact and
-// order-independent, and the tile sum equals the exact sum of tcnn's fp16 contributions (valid while
-// |sum| < 128 in loss-scaled units) -- deterministic, unlike atomicAdd(__half2).
-// One workgroup = (level, 16384-entry part of that level, sample partition).  Every level gets 16 workgroups:
-// parts_l = ceil(entries_l / 16384) parts x P_l = 16 / parts_l sample partitions, which balances the
-// in-range atomics per workgroup.  The tile is written densely (as half2) to partial table p of that level; the
+// Measured on MI355X (profiles/r01_microbench.md): global_atomic_pk_add_f16 sustains ~21 Gop/s chip-wide, LDS
+// floating-point atomics (ds_pk_add_f16, ds_add_f32) ~0.35 op/clk/CU, LDS integer atomics (ds_add_u32) ~4 lanes/clk/CU.
+// So the scatter accumulates in LDS in int32 FIXED POINT with scale 2^24: every fp16 value is an exact multiple of
+// 2^-24, so each contribution h(w * dE) converts exactly, integer addition is exact and order-independent, and the tile sum
+// equals the exact sum of tcnn's fp16 contributions -- deterministic, unlike atomicAdd(__half2).
+// Range: |sum| < 2^31 / scale per entry, feature and sample partition = 128 in loss-scaled units for loss_scale <= 128;
+// a larger loss scale coarsens the unit by the same factor (LevelFast::fix_scale, set by the host), which keeps the range at
+// "un-scaled gradient below 1.0" -- tcnn's own fp16 atomics would be down to 3 significant digits there.
+//
+// One workgroup = (level, 32768-entry part of that level, FEATURE, sample partition): a 128 KB tile of int32 accumulators for
+// one of the two features.  The kernel is VALU-bound (profiles/r02_*: ~4 cycles per wave instruction, the LDS array 20-30 %
+// busy), and a workgroup pays the index arithmetic of every sample of its partition for the few corners that land in its tile;
+// splitting by feature instead of into four 16384-entry parts halves the corner work inside the divergent in-tile branch and
+// doubles the share of lanes that take it (a hashed corner pair is in a given 32768-entry half of a 2^16 table with
+// probability 1/2).  Every level gets 16 workgroups: parts_l = 2 * ceil(entries_l / 32768) parts x P_l = 16 / parts_l sample
+// partitions.  Tiles are written densely as fp16 to partial table p, feature plane f of that level ([P][2][entries]); the
 // optimizer sums the P_l partial tables.  No global atomics, no memset: every tile is fully rewritten each step.
-constexpr uint32_t kScatterTile = 16384;          // entries per LDS tile: 2 x int32 per entry = 128 KB
+constexpr uint32_t kScatterTile = 32768;          // entries per LDS tile: one int32 accumulator per entry (one feature) = 128 KB
 constexpr uint32_t kScatterWgPerLevel = 16;
-constexpr float kFixScale = 16777216.0f;          // 2^24
+
+struct ScatterItem { half2_t g; float4_t x; };
+
+// fixed-point contribution of one corner and feature: tcnn's (T)(weight * grad), exact in 1 / fs units
+__device__ __forceinline__ int contrib_fix(float w, float g, float fs) { return (int)((float)(half_t)(w * g) * fs); }
 
 template <bool HASHED, bool POW2>
-__device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restrict__ de, const float* __restrict__ x_soa, uint32_t B, const uint32_t* __restrict__ bin_count,
-                                                uint32_t bin0, uint32_t bin_step, uint32_t bin_cap,
-                                                float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask, uint32_t base, uint32_t tile) {
-    // This workgroup's samples are the ray bins bin0, bin0 + bin_step, ... (< 16), each a compacted run of bin_count[b] samples at
-    // b * bin_cap.  They are walked as ONE index space v = k * width + o (k-th bin, offset o < width = longest run): a loop per bin
-    // would serialise 4-16 short, latency-bound loops late in training when a bin holds a few hundred samples.
-    // The loop is latency-bound if run one sample at a time: fetch a batch of kBatch samples per thread with independent
-    // loads first, then do the index math + LDS integer atomics.  Out-of-tile corners cost 4 instructions.
-    constexpr int kBatch = 8;
-    uint32_t nb = 0, width = 0;
-    for (uint32_t b = bin0; b < 16u; b += bin_step) { ++nb; width = max(width, min(bin_count[b], bin_cap)); }
-    if (width == 0u) return;
-    const uint32_t total = nb * width; const float inv_width = 1.0f / (float)width;
-    for (uint32_t v0 = threadIdx.x; v0 < total; v0 += blockDim.x * kBatch) {
-        half2_t g[kBatch]; float xs[kBatch][3];
+__device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bool valid, uint32_t feature, float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask, uint32_t base, uint32_t tile, float fs) {
+    const float g = (float)(feature ? it.g.y : it.g.x);          // (k_fused_train stores dL/dE already clamped to the fixed-point range)
+    if (!valid || g == 0.f) return;
+    float pos[3]; uint32_t pg[3];
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            const uint32_t v = v0 + u * blockDim.x;
-            uint32_t k = (uint32_t)((float)v * inv_width); k -= (k * width > v) ? 1u : 0u; k += ((k + 1u) * width <= v) ? 1u : 0u;   // v / width
-            const uint32_t bsel = min(bin0 + k * bin_step, 15u), o = v - k * width;
-            const bool in = v < total && o < min(bin_count[bsel], bin_cap); const uint32_t sc = in ? bsel * bin_cap + o : bin0 * bin_cap;
-            g[u] = de[sc]; if (!in) g[u] = half2_t{ (half_t)0.f, (half_t)0.f };
-            xs[u][0] = x_soa[sc]; xs[u][1] = x_soa[(size_t)B + sc]; xs[u][2] = x_soa[2 * (size_t)B + sc];
-        }
+    for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, it.x[d], 0.5f), fl = floorf(q); pg[d] = (uint32_t)(int32_t)fl; pos[d] = q - fl; }
+    // hashed levels: only the index bits below the (power-of-two) table size matter, so the 24-bit multiply (full rate) serves: positions are < 2^24
+    const uint32_t ax0 = pg[0], ax1 = pg[0] + 1u, y0 = (HASHED && POW2) ? __umul24(pg[1], my & 0xffffffu) : pg[1] * my, z0 = (HASHED && POW2) ? __umul24(pg[2], mz & 0xffffffu) : pg[2] * mz;
+    const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
+    const float wx[2] = { 1.f - pos[0], pos[0] }, wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
+    // Hashed power-of-two level: the two x corners of a (y, z) pair are idx0 and idx0 ^ dxm with dxm = (x ^ (x + 1)) & mask.  Unless x ends in 15 or
+    // more one-bits, dxm stays below the tile size, both corners fall into the same tile and ONE range test covers the pair (the rare other case --
+    // decided per wave -- takes the corner-by-corner walk below).
+    const uint32_t dxm = (ax0 ^ ax1) & mask;
+    if (HASHED && POW2 && __ballot(dxm >= kScatterTile) == 0ull) {                         // (tile bases are multiples of kScatterTile)
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            float g0 = (float)g[u].x, g1 = (float)g[u].y;
-            if (g0 == 0.f && g1 == 0.f) continue;
-            g0 = clamp_f(g0, -100.f, 100.f); g1 = clamp_f(g1, -100.f, 100.f);          // keeps |contribution| * 2^24 inside int32
-            float pos[3]; uint32_t pg[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, xs[u][d], 0.5f), fl = floorf(q); pg[d] = (uint32_t)(int32_t)fl; pos[d] = q - fl; }
-            const uint32_t ax[2] = { pg[0], pg[0] + 1u }, y0 = pg[1] * my, z0 = pg[2] * mz, ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
-            uint32_t ayz[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ayz[j] = HASHED ? (ay[j & 1] ^ az[j >> 1]) : (ay[j & 1] + az[j >> 1]);
-            const float wx[2] = { 1.f - pos[0], pos[0] }, wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                uint32_t idx = (HASHED ? (ax[k & 1] ^ ayz[k >> 1]) : (ax[k & 1] + ayz[k >> 1])) & mask;
-                if (!POW2) { idx -= (idx >= size) ? size : 0u; idx = min(idx, size - 1u); }
-                const uint32_t local = idx - base;
-                if (local < tile) {
-                    const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
-                    const int f0 = (int)((float)(half_t)(w * g0) * kFixScale), f1 = (int)((float)(half_t)(w * g1) * kFixScale);   // tcnn: (T)(weight * grad); exact in 2^-24 units
-                    if (f0) atomicAdd(tab + 2u * local, f0);
-                    if (f1) atomicAdd(tab + 2u * local + 1u, f1);
-                }
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t l0 = ((ax0 ^ ay[j & 1] ^ az[j >> 1]) & mask) - base;
+            if (l0 < tile) {
+                const float wyz0 = wx[0] * wy[j & 1], wyz1 = wx[1] * wy[j & 1];           // ((wx * wy) * wz): the reference walk's product order
+                atomicAdd(tab + l0, contrib_fix(wyz0 * wz[j >> 1], g, fs));
+                atomicAdd(tab + (l0 ^ dxm), contrib_fix(wyz1 * wz[j >> 1], g, fs));
             }
+        }
+    } else {
+        uint32_t ayz[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ayz[j] = HASHED ? (ay[j & 1] ^ az[j >> 1]) : (ay[j & 1] + az[j >> 1]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t idx = (HASHED ? ((k & 1 ? ax1 : ax0) ^ ayz[k >> 1]) : ((k & 1 ? ax1 : ax0) + ayz[k >> 1])) & mask;
+            if (!POW2) { idx -= (idx >= size) ? size : 0u; idx = min(idx, size - 1u); }
+            const uint32_t local = idx - base;
+            if (local < tile) atomicAdd(tab + local, contrib_fix((wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2], g, fs));
         }
     }
 }
 
-// The weight-gradient partial rows of k_fused_train (one per workgroup) are summed here as well: every scatter workgroup
-// takes a few float4 column groups before it touches its tile (128 row subsets x 8 groups per pass, LDS tree), so the
-// latency-bound stand-alone reduction kernel disappears from the critical path (k_reduce_partials remains for networks
-// whose levels all go through global atomics).
-struct PartialsArgs { const float* partials; uint32_t n_partials, stride, n_mlp; float* gmlp; DevState* st; };
+template <bool HASHED, bool POW2>
+__device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restrict__ de, const float4_t* __restrict__ x4, uint32_t cnt_lanes /* lane b: run length of ray bin b */,
+                                                uint32_t bin0, uint32_t bin_step, uint32_t bin_cap, uint32_t feature,
+                                                float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask, uint32_t base, uint32_t tile, float fs) {
+    // This workgroup's samples are the ray bins bin0, bin0 + bin_step, ... (< 16), each a compacted run of samples at b * bin_cap.  They are
+    // walked in STEPS: step s = (round r, k-th bin), thread t takes offset o = r * 1024 + t of that bin -- the bin is uniform per step, so its
+    // run length and base come from scalar registers (v_readlane with a scalar lane index) and a sample costs two vector instructions of
+    // bookkeeping.  NOTHING inside the loop may wait on an LDS or scalar-memory read: both share the counter (lgkmcnt) the LDS atomics are
+    // counted on, in order, so such a wait drains every atomic issued before it.
+    // Software pipeline: the kBatch steps of round r + 1 are requested before round r's index math and LDS atomics run, so the global-load
+    // latency hides behind arithmetic (all 16 waves of the workgroup start in phase; without the prefetch they also wait in phase).
+    constexpr int kBatch = MON_V_SBATCH;
+    uint32_t nb = 0, width = 0;
+    for (uint32_t b = bin0; b < 16u; b += bin_step) { ++nb; width = max(width, (uint32_t)__builtin_amdgcn_readlane((int)cnt_lanes, (int)b)); }
+    if (width == 0u) return;
+    const uint32_t rounds = (width + blockDim.x - 1u) / blockDim.x, n_steps = rounds * nb;
+    uint32_t fk = 0, fo = threadIdx.x, fb = bin0, fs_left = n_steps;          // running state of the step the next fetch serves: bin ordinal, offset, bin, steps left (all but fo uniform)
+    const auto fetch = [&](ScatterItem& it, bool& valid) {
+        const uint32_t b = min(fb, 15u);
+        const uint32_t cnt = fs_left ? (uint32_t)__builtin_amdgcn_readlane((int)cnt_lanes, (int)b) : 0u;
+        valid = fo < cnt; const uint32_t sc = b * bin_cap + (valid ? fo : 0u);
+        it.g = de[sc]; it.x = x4[sc];
+        fs_left -= fs_left ? 1u : 0u;
+        const bool wrap = fk + 1u == nb;                                         // (selects, not branches: the compiler turned conditional updates of the captured state into scratch memory)
+        fo += wrap ? blockDim.x : 0u; fb = wrap ? bin0 : fb + bin_step; fk = wrap ? 0u : fk + 1u;
+    };
+    ScatterItem nxt[kBatch]; bool nv[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) fetch(nxt[u], nv[u]);
+    for (uint32_t s0 = 0; s0 < n_steps; s0 += kBatch) {
+        ScatterItem cur[kBatch]; bool cv[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) { cur[u] = nxt[u]; cv[u] = nv[u]; }
+        if (s0 + kBatch < n_steps) {
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) fetch(nxt[u], nv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) scatter_item<HASHED, POW2>(tab, cur[u], cv[u], feature, scale, size, my, mz, mask, base, tile, fs);
+    }
+}
 
-__device__ __forceinline__ void reduce_partials_slice(const PartialsArgs& pa, float* red) {
-    // thread = (column group gs of 8, row subset sub of 128); the 64 subsets of a wave are summed with DPP, the two waves of a group through LDS
-    const uint32_t n4 = (pa.n_mlp + 1u + 3u) / 4u, gs = threadIdx.x >> 7, sub = threadIdx.x & 127u, wave = threadIdx.x >> 6;
-    for (uint32_t g0 = blockIdx.x * 8u; g0 < n4; g0 += gridDim.x * 8u) {
-        const uint32_t g = g0 + gs; float4_t acc = { 0.f, 0.f, 0.f, 0.f };
-        if (g < n4) for (uint32_t k = sub; k < pa.n_partials; k += 128u) acc += *reinterpret_cast<const float4_t*>(pa.partials + (size_t)k * pa.stride + 4u * g);   // rows are padded to n_mlp + 64 floats
+// The weight-gradient partial rows of k_fused_train (one per workgroup) are summed here as well: every scatter workgroup
+// takes a few float4 column groups (128 row subsets x 8 groups per pass).  The loads are issued at kernel entry and the sums
+// are finished (DPP + a small LDS exchange) after the tile has been written, so their latency hides behind the scatter itself
+// (k_reduce_partials remains for networks whose levels all go through global atomics).
+struct PartialsArgs { const float* partials; uint32_t n_partials, stride, n_mlp; float* gmlp; DevState* st; };
+constexpr uint32_t kPartialsMaxPasses = 2;          // column-group passes a workgroup may hold in registers (n_mlp + 1 <= 2 * 8 * 4 * gridDim.x)
+
+__device__ __forceinline__ void partials_prefetch(const PartialsArgs& pa, float4_t (&acc)[kPartialsMaxPasses]) {
+    // thread = (column group gs of 8, row subset sub of 128)
+    const uint32_t n4 = (pa.n_mlp + 1u + 3u) / 4u, gs = threadIdx.x >> 7, sub = threadIdx.x & 127u;
+#pragma unroll
+    for (uint32_t ps = 0; ps < kPartialsMaxPasses; ++ps) {
+        const uint32_t g = (blockIdx.x + ps * gridDim.x) * 8u + gs; acc[ps] = float4_t{ 0.f, 0.f, 0.f, 0.f };
+        if (g < n4) for (uint32_t k0 = sub; k0 < pa.n_partials; k0 += 512u) {                // four independent 16-byte loads per round (rows are padded to n_mlp + 64 floats)
+            float4_t v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) { const uint32_t k = k0 + 128u * u; v[u] = (k < pa.n_partials) ? *reinterpret_cast<const float4_t*>(pa.partials + (size_t)k * pa.stride + 4u * g) : float4_t{ 0.f, 0.f, 0.f, 0.f }; }
+            acc[ps] += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    }
+}
+__device__ __forceinline__ void partials_finish(const PartialsArgs& pa, const float4_t (&acc)[kPartialsMaxPasses], float* red) {
+    // the 64 subsets of a wave are summed with DPP, the two waves of a column group through LDS
+    const uint32_t n4 = (pa.n_mlp + 1u + 3u) / 4u, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (uint32_t ps = 0; ps < kPartialsMaxPasses; ++ps) {
+        const uint32_t g0 = (blockIdx.x + ps * gridDim.x) * 8u;
+        if (g0 >= n4) break;                                                               // uniform
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float v = acc[c];
+            float v = acc[ps][c];
             v += dpp_f<0x111, 0xF>(0.f, v); v += dpp_f<0x112, 0xF>(0.f, v); v += dpp_f<0x114, 0xF>(0.f, v); v += dpp_f<0x118, 0xF>(0.f, v);
             v += dpp_f<0x142, 0xA>(0.f, v); v += dpp_f<0x143, 0xC>(0.f, v);
             if ((threadIdx.x & 63u) == 63u) red[wave * 4u + (uint32_t)c] = v;               // lane 63 holds the wave total
@@ -788,47 +887,71 @@ __device__ __forceinline__ void reduce_partials_slice(const PartialsArgs& pa, fl
     }
 }
 
-__global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLevels sl, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa,
-                                                       uint32_t B, half2_t* __restrict__ gpart, uint32_t part_stride, const DevState* __restrict__ st, PartialsArgs pa) {
+__global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLevels sl, const half2_t* __restrict__ de_soa, const float4_t* __restrict__ x4,
+                                                       uint32_t B, half_t* __restrict__ gpart, uint32_t n_entries, const DevState* __restrict__ st, PartialsArgs pa, float* __restrict__ timing) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (st->n_valid == 0u) return;
-    if (pa.partials) reduce_partials_slice(pa, reinterpret_cast<float*>(smem));
+#ifdef MON_SCATTER_TIMING
+    long long tq[10]; int tn = 0;
+#define MON_ST_STAMP() do { __builtin_amdgcn_s_waitcnt(0); tq[tn++] = clock64(); } while (0)
+#else
+#define MON_ST_STAMP() do { } while (0)
+#endif
+    MON_ST_STAMP();
+    float4_t pacc[kPartialsMaxPasses];
+    if (pa.partials) partials_prefetch(pa, pacc);                                    // loads in flight while the tile is cleared and filled
     int* tab = reinterpret_cast<int*>(smem);
+    float* red = reinterpret_cast<float*>(smem + (size_t)kScatterTile * 4u);           // 256 B behind the tile
+    // run lengths of the 16 compacted ray bins, lane b of every wave holds bin b's (read back with v_readlane: no memory access in the sample loop)
+    const uint32_t cnt_lanes = min(st->n_scatter[threadIdx.x & 15u], B >> 4);
     const uint32_t slot = blockIdx.x / kScatterWgPerLevel, j = blockIdx.x - slot * kScatterWgPerLevel;
     const int level = sl.level[slot]; const uint32_t P = sl.P[level];
-    const uint32_t part = j / P, p = j - part * P;
+    const uint32_t part = j / P, p = j - part * P, feature = part & 1u;
     const uint32_t off = lt.offset[level], size = lt.size[level], my = lt.my[level], mz = lt.mz[level], mask = lt.mask[level];
     const bool hashed = lt.hashed[level] != 0u, pow2 = mask != 0xffffffffu;
-    const float scale = lt.scale[level];
-    const uint32_t base = part * kScatterTile;
-    if (base >= size) return;                                   // levels whose part count does not divide 16
-    const uint32_t tile = min(kScatterTile, size - base);
-    {   // tile sizes are multiples of 8 entries (tcnn rounds level sizes up to 8): clear with 16-byte stores
-        typedef int int4v __attribute__((ext_vector_type(4)));
-        int4v* t4 = reinterpret_cast<int4v*>(tab);
-        for (uint32_t i = threadIdx.x; i < tile / 2u; i += blockDim.x) t4[i] = int4v{ 0, 0, 0, 0 };
-    }
-    __syncthreads();
-    // sample partition p of this level = the ray bins b = p, p + P, ... (16 bins, compacted by k_fused_train: only samples with a non-zero gradient)
-    const uint32_t bin_cap = B >> 4;
-    const half2_t* de = de_soa + (size_t)level * B;
-    if (hashed) { if (pow2) scatter_samples<true, true>(tab, de, x_soa, B, st->n_scatter, p, P, bin_cap, scale, size, my, mz, mask, base, tile);
-                  else scatter_samples<true, false>(tab, de, x_soa, B, st->n_scatter, p, P, bin_cap, scale, size, my, mz, mask, base, tile); }
-    else { if (pow2) scatter_samples<false, true>(tab, de, x_soa, B, st->n_scatter, p, P, bin_cap, scale, size, my, mz, mask, base, tile);
-           else scatter_samples<false, false>(tab, de, x_soa, B, st->n_scatter, p, P, bin_cap, scale, size, my, mz, mask, base, tile); }
-    __syncthreads();
-    half2_t* dst = gpart + (size_t)p * part_stride + off + base;
-    {   // 4 entries per thread and pass: 32 bytes of accumulators in, one 16-byte store of four half2 out
-        typedef int int4v __attribute__((ext_vector_type(4)));
-        const int4v* t4 = reinterpret_cast<const int4v*>(tab);
-        for (uint32_t i = threadIdx.x; i < tile / 4u; i += blockDim.x) {
-            const int4v a0 = t4[2u * i], a1 = t4[2u * i + 1u];
-            half8_t o;
-            o[0] = (half_t)((float)a0[0] * (1.0f / kFixScale)); o[1] = (half_t)((float)a0[1] * (1.0f / kFixScale)); o[2] = (half_t)((float)a0[2] * (1.0f / kFixScale)); o[3] = (half_t)((float)a0[3] * (1.0f / kFixScale));
-            o[4] = (half_t)((float)a1[0] * (1.0f / kFixScale)); o[5] = (half_t)((float)a1[1] * (1.0f / kFixScale)); o[6] = (half_t)((float)a1[2] * (1.0f / kFixScale)); o[7] = (half_t)((float)a1[3] * (1.0f / kFixScale));
-            *reinterpret_cast<half8_t*>(dst + 4u * i) = o;
+    const float scale = lt.scale[level], fs = lt.fix_scale;
+    const uint32_t base = (part >> 1) * kScatterTile;
+    MON_ST_STAMP();
+    if (base < size) {                                                                // (levels whose part count does not divide 16 leave workgroups without a tile)
+        const uint32_t tile = min(kScatterTile, size - base);
+        {   // tile sizes are multiples of 8 entries (tcnn rounds level sizes up to 8): clear with 16-byte stores
+            typedef int int4v __attribute__((ext_vector_type(4)));
+            int4v* t4 = reinterpret_cast<int4v*>(tab);
+            for (uint32_t i = threadIdx.x; i < tile / 4u; i += blockDim.x) t4[i] = int4v{ 0, 0, 0, 0 };
+        }
+        MON_ST_STAMP();
+        __syncthreads();
+        MON_ST_STAMP();
+        // sample partition p of this level = the ray bins b = p, p + P, ... (16 bins, compacted by k_fused_train: only samples with a non-zero gradient)
+        const uint32_t bin_cap = B >> 4;
+        const half2_t* de = de_soa + (size_t)level * B;
+#define MON_SCATTER_CALL(H, PW) scatter_samples<H, PW>(tab, de, x4, cnt_lanes, p, P, bin_cap, feature, scale, size, my, mz, mask, base, tile, fs)
+        if (hashed) { if (pow2) MON_SCATTER_CALL(true, true); else MON_SCATTER_CALL(true, false); }
+        else { if (pow2) MON_SCATTER_CALL(false, true); else MON_SCATTER_CALL(false, false); }
+#undef MON_SCATTER_CALL
+        MON_ST_STAMP();
+        __syncthreads();
+        MON_ST_STAMP();
+        half_t* dst = gpart + ((size_t)p * 2u + feature) * n_entries + off + base;     // partial table p, plane `feature`
+        {   // 8 entries per thread and pass: 32 bytes of accumulators in, one 16-byte store of eight halves out
+            typedef int int4v __attribute__((ext_vector_type(4)));
+            const int4v* t4 = reinterpret_cast<const int4v*>(tab);
+            const float inv = 1.0f / fs;
+            for (uint32_t i = threadIdx.x; i < tile / 8u; i += blockDim.x) {
+                const int4v a0 = t4[2u * i], a1 = t4[2u * i + 1u];
+                half8_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = (half_t)((float)a0[e] * inv); o[4 + e] = (half_t)((float)a1[e] * inv); }
+                *reinterpret_cast<half8_t*>(dst + 8u * i) = o;
+            }
         }
     }
+    MON_ST_STAMP();
+    if (pa.partials) partials_finish(pa, pacc, red);
+    MON_ST_STAMP();
+#ifdef MON_SCATTER_TIMING
+    if (timing && (threadIdx.x & 63u) == 0u) { float* o = timing + ((size_t)blockIdx.x * 16u + (threadIdx.x >> 6)) * 8u; for (int k = 0; k + 1 < tn && k < 6; ++k) o[k] = (float)(tq[k + 1] - tq[k]); o[6] = (float)(tq[0] & 0xffffff); o[7] = (float)level; }
+#endif
 }
 
 // Host: which levels go through the LDS scatter, with how many sample partitions each.
@@ -842,10 +965,10 @@ uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl
     // for its one tile.  When the table has levels that need the large-table path anyway (kernels_bigscatter.hip), levels of 5..16
     // tiles go there too.
     uint32_t max_parts = kScatterWgPerLevel;
-    for (int l = 0; l < nd.L; ++l) if ((lt.offset[l + 1] - lt.offset[l] + kScatterTile - 1) / kScatterTile > kScatterWgPerLevel) max_parts = 4;
+    for (int l = 0; l < nd.L; ++l) if (2u * ((lt.offset[l + 1] - lt.offset[l] + kScatterTile - 1) / kScatterTile) > kScatterWgPerLevel) max_parts = 4;
     for (int l = 0; l < nd.L; ++l) {
         const uint32_t size = lt.offset[l + 1] - lt.offset[l];
-        const uint32_t parts = (size + kScatterTile - 1) / kScatterTile;
+        const uint32_t parts = 2u * ((size + kScatterTile - 1) / kScatterTile);              // entry ranges x the two features
         if (parts <= max_parts) {
             mask |= 1u << l; sl.level[sl.n_levels++] = (uint8_t)l;
             sl.P[l] = (uint8_t)(kScatterWgPerLevel / parts); if (sl.P[l] > sl.max_P) sl.max_P = sl.P[l];
@@ -855,15 +978,31 @@ uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl
 }
 uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd) { ScatterLevels sl; return scatter_plan(lt, nd, sl); }
 
+#ifdef MON_SCATTER_TIMING
+static float* g_scatter_timing_buf = nullptr;
+#endif
+bool grid_scatter_sums_partials(const LevelTable& lt, const NetDims& nd) {
+    // the scatter workgroups hold their share of the dW column groups in registers (kPartialsMaxPasses passes of 8 groups of 4 columns)
+    ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return false;
+    return nd.n_mlp + 1u <= kPartialsMaxPasses * 8u * 4u * sl.n_levels * kScatterWgPerLevel;
+}
 void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
                          const float* partials, uint32_t n_partials, float* gmlp) {
     ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return;
     const PartialsArgs pa{ partials, n_partials, nd.n_mlp + 64u, nd.n_mlp, gmlp, st };
+    constexpr uint32_t smem = kScatterTile * 4 + 256;
     static std::atomic<uint64_t> attr_devices{ 0 };       // function attributes are per device: the managers run objects on every GPU of the node from one process
-    if (first_use_on_this_device(attr_devices)) hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, kScatterTile * 8);
-    hipLaunchKernelGGL(k_grid_scatter, dim3(sl.n_levels * kScatterWgPerLevel), dim3(1024), kScatterTile * 8, s, lf, sl, reinterpret_cast<const half2_t*>(de_soa), x_soa, B,
-                       reinterpret_cast<half2_t*>(gpart), part_stride_entries, st, pa);
+    if (first_use_on_this_device(attr_devices)) hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    float* timing = nullptr;
+#ifdef MON_SCATTER_TIMING
+    static float* g_timing = nullptr; if (!g_timing) hipMalloc((void**)&g_timing, 256 * 16 * 8 * 4); timing = g_timing; g_scatter_timing_buf = g_timing;
+#endif
+    hipLaunchKernelGGL(k_grid_scatter, dim3(sl.n_levels * kScatterWgPerLevel), dim3(1024), smem, s, lf, sl, reinterpret_cast<const half2_t*>(de_soa), reinterpret_cast<const float4_t*>(x_soa), B,
+                       reinterpret_cast<half_t*>(gpart), part_stride_entries, st, pa, timing);
 }
+#ifdef MON_SCATTER_TIMING
+extern "C" int mon_debug_scatter_timing(float* out) { hipDeviceSynchronize(); return g_scatter_timing_buf ? (int)hipMemcpy(out, g_scatter_timing_buf, 256 * 16 * 8 * 4, hipMemcpyDeviceToHost) : -1; }
+#endif
 
 // ------------------------------------------------------------------ fused render kernel
 // One wavefront per pixel ray, 2S = 64 samples as two 32-sample tiles with a carried transmittance;
@@ -877,7 +1016,7 @@ __global__ void __launch_bounds__(256) k_fused_render(FusedArgs a, uint32_t n_ra
     LevelLds* llt = reinterpret_cast<LevelLds*>(smem + S::FRAG_BYTES);
     build_fragments<EPAD, W, NH>(frags, llt, a, false);
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31;
+    const int wave = MON_UNIFORM(threadIdx.x >> 6), lane = threadIdx.x & 63, n = lane & 31;
     const int L = a.nd.L; const uint32_t S2 = 2u * a.oc.S;      // 64
     const half2_t* table = reinterpret_cast<const half2_t*>(a.params + a.nd.n_mlp);
     for (uint32_t ray = blockIdx.x * S::WAVES + wave; ray < n_rays; ray += gridDim.x * S::WAVES) {

@@ -116,18 +116,20 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                     for (int l = 1; l < kMaxLevels; ++l) lvl += (e0 >= p.sl.entry_offset[l]) ? 1 : 0;
                     n_part = p.sl.P[lvl];
                 }
-                const uint16_t* pp = p.gpart + (i0 - oc.n_mlp);         // dense partial tables of k_grid_scatter (fused backend)
+                // dense partial tables of k_grid_scatter (fused backend): [partition][feature plane][entry]; this chunk = entries e0 .. e0 + 3, both features
+                const uint16_t* pp = p.gpart + ((i0 - oc.n_mlp) >> 1);
+                const size_t plane = p.part_stride >> 1;                 // entries per plane
                 uint32_t q = 0;
-                for (; q + 4 <= n_part; q += 4) {                       // 4 independent 16-byte loads in flight
-                    const half8_t h0 = *reinterpret_cast<const half8_t*>(pp + (size_t)q * p.part_stride), h1 = *reinterpret_cast<const half8_t*>(pp + (size_t)(q + 1) * p.part_stride);
-                    const half8_t h2 = *reinterpret_cast<const half8_t*>(pp + (size_t)(q + 2) * p.part_stride), h3 = *reinterpret_cast<const half8_t*>(pp + (size_t)(q + 3) * p.part_stride);
+                for (; q + 2 <= n_part; q += 2) {                       // 4 independent 8-byte loads in flight
+                    const half4_t a0 = *reinterpret_cast<const half4_t*>(pp + (size_t)(2u * q) * plane), a1 = *reinterpret_cast<const half4_t*>(pp + (size_t)(2u * q + 1u) * plane);
+                    const half4_t b0 = *reinterpret_cast<const half4_t*>(pp + (size_t)(2u * q + 2u) * plane), b1 = *reinterpret_cast<const half4_t*>(pp + (size_t)(2u * q + 3u) * plane);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) g[j] += ((float)h0[j] + (float)h1[j]) + ((float)h2[j] + (float)h3[j]);
+                    for (int e = 0; e < 4; ++e) { g[2 * e] += (float)a0[e] + (float)b0[e]; g[2 * e + 1] += (float)a1[e] + (float)b1[e]; }
                 }
                 for (; q < n_part; ++q) {
-                    const half8_t ph = *reinterpret_cast<const half8_t*>(pp + (size_t)q * p.part_stride);
+                    const half4_t a0 = *reinterpret_cast<const half4_t*>(pp + (size_t)(2u * q) * plane), a1 = *reinterpret_cast<const half4_t*>(pp + (size_t)(2u * q + 1u) * plane);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) g[j] += (float)ph[j];
+                    for (int e = 0; e < 4; ++e) { g[2 * e] += (float)a0[e]; g[2 * e + 1] += (float)a1[e]; }
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { any |= g[j] != 0.f; g[j] = unscale(g[j]); }

@@ -124,6 +124,11 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     if (rc) return rc;
     m.n_params = m.nd.n_mlp + m.n_grid;
     level_fast_build(m.lt, m.nd, m.lf);
+    {   // fixed-point unit of the exact LDS gradient accumulation: 2^-24 (every fp16 value is a multiple of it) up to the reference's loss scale of
+        // 128, coarser by the next power of two of loss_scale / 128 beyond it, so that the int32 range always spans un-scaled gradient sums below 1.0
+        int shift = 0; while (shift < 23 && 128.0f * (float)(1u << shift) < cfg.loss_scale) ++shift;
+        m.lf.fix_scale = 16777216.0f / (float)(1u << shift); m.lf.fix_clamp = 100.0f * (float)(1u << shift);
+    }
     HIPCHECK(hipSetDevice(m.device));
     std::memcpy(m.oc.Tow.m, Tow, 64);
     for (int a = 0; a < 3; ++a) { m.oc.aabb.mn[a] = amin[a]; m.oc.aabb.mx[a] = amax[a]; }
@@ -168,7 +173,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     if (fused_supported(m.nd, S, m.oc.R)) {
         if ((rc = dev_alloc(m, m.d_frag_train, 64 * 512)) || (rc = dev_alloc(m, m.d_frag_render, 64 * 512))) return rc;       // <= 30 fragments of 512 halves
         m.lds_mask = scatter_plan(m.lt, m.nd, m.scatter);
-        if (m.lds_mask && ((rc = dev_alloc(m, m.d_de_soa, (size_t)m.nd.L * Btrain * 2)) || (rc = dev_alloc(m, m.d_x_soa, 3 * (size_t)Btrain)) ||
+        if (m.lds_mask && ((rc = dev_alloc(m, m.d_de_soa, (size_t)m.nd.L * Btrain * 2)) || (rc = dev_alloc(m, m.d_x_soa, 4 * (size_t)Btrain)) ||
                            (rc = dev_alloc(m, m.d_gpart, (size_t)m.scatter.max_P * m.n_grid)))) return rc;
         // Levels beyond the LDS plan (more than 2^18 entries): binned exact scatter while many samples carry a gradient (kernels_bigscatter.hip).
         // MON_BIG_SWITCH = gradient-carrying samples below which the global-atomic path takes over (0: atomics always).
@@ -197,6 +202,7 @@ int model_destroy(Model* mp);
 int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* Tow, const float* amin, const float* amax, Model** out) {
     if (!ds || !Tow || !amin || !amax) { set_error("object_create: bad argument"); return MON_ERR_ARG; }
     if (cfg.rays_per_batch < 64 || (cfg.rays_per_batch % 64) != 0 || cfg.n_samples < 1 || cfg.n_samples > 64) { set_error("rays_per_batch must be a multiple of 64, n_samples 1..64"); return MON_ERR_ARG; }
+    if (!(cfg.loss_scale > 0.f) || !(cfg.loss_scale <= 65536.f)) { set_error("loss_scale must be in (0, 65536] (fp16 gradients; the reference uses 128)"); return MON_ERR_ARG; }
     Model* mp = new Model();
     const int rc = model_init(*mp, ds, cfg, class_id, Tow, amin, amax);
     if (rc) { model_destroy(mp); return rc; }          // a failed allocation half-way must not leak what came before it
@@ -295,7 +301,7 @@ static void enqueue_iteration(Model& m, int stages) {
     }
     if ((stages & 2) && m.backend == 1) {
         static const bool fold_reduce = !(std::getenv("MON_FOLD_REDUCE") && std::atoi(std::getenv("MON_FOLD_REDUCE")) == 0);
-        const bool folded = m.lds_mask && fold_reduce;                 // the scatter workgroups also sum the dW partial rows
+        const bool folded = m.lds_mask && fold_reduce && grid_scatter_sums_partials(m.lt, m.nd);   // the scatter workgroups also sum the dW partial rows
         if (m.lds_mask) { ProfScope ps(m, MON_K_SCATTER); launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.d_gpart, m.n_grid / 2, m.d_state,
                                                                                 folded ? m.d_dw_partials : nullptr, fused_train_grid(m.nd, m.oc.R), m.P.gmlp); }
         if (m.big_active) { ProfScope ps(m, MON_K_SCATTER); launch_big_scatter(s, m.lt, m.lf, m.nd, m.lds_mask, m.d_de_soa, m.d_x_soa, B, m.d_state, m.big_switch, m.d_big_ws, m.P.ggrid, m.d_touched ? m.d_touched + (m.nd.n_mlp >> 3) : nullptr); }
@@ -489,9 +495,13 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
         std::vector<uint16_t> part(m.n_grid); std::vector<float> acc(m.n_grid);
         uint16_t* out = reinterpret_cast<uint16_t*>(dst);
         for (uint32_t i = 0; i < m.n_grid; ++i) { _Float16 h; std::memcpy(&h, &out[i], 2); acc[i] = (float)h; }
+        const uint32_t n_ent = m.n_grid / 2;                                  // partial tables are planar: [partition][feature][entry]
         for (uint32_t q = 0; q < m.scatter.max_P; ++q) {
             HIPCHECK(hipMemcpy(part.data(), m.d_gpart + (size_t)q * m.n_grid, (size_t)m.n_grid * 2, hipMemcpyDeviceToHost));
-            for (uint32_t i = 0; i < m.n_grid; ++i) { _Float16 h; std::memcpy(&h, &part[i], 2); acc[i] += (float)h; }
+            for (int l = 0; l < m.nd.L; ++l) {
+                if (q >= m.scatter.P[l]) continue;                              // this level has fewer partial tables: the rest of the buffer is not its data
+                for (uint32_t e = m.lt.offset[l]; e < m.lt.offset[l + 1]; ++e) for (uint32_t f = 0; f < 2; ++f) { _Float16 h; std::memcpy(&h, &part[(size_t)f * n_ent + e], 2); acc[2 * e + f] += (float)h; }
+            }
         }
         for (uint32_t i = 0; i < m.n_grid; ++i) { const _Float16 h = (_Float16)acc[i]; std::memcpy(&out[i], &h, 2); }
     }

@@ -124,6 +124,7 @@ void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, c
                         uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched);
 uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl);
 uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd);
+bool grid_scatter_sums_partials(const LevelTable& lt, const NetDims& nd);
 void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
                          const float* partials_or_null, uint32_t n_partials, float* gmlp);   // partials != null: also sums the dW partial rows (k_reduce_partials folded in)
 size_t big_scatter_workspace_bytes(const LevelTable& lt, const NetDims& nd, uint32_t lds_mask, uint32_t B);
@@ -155,7 +156,7 @@ struct Model {
     uint32_t boxes_cap = 0, n_boxes = 0; uint32_t ws_samples = 0, ws_rays = 0;
     // fused backend
     float* d_dw_partials = nullptr;                               // [512][n_mlp + 64] fp32 dW partial rows of k_fused_train
-    uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr;       // compacted dL/dE rows [L][B] and positions [3][B] for the scatter kernels
+    uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr;       // compacted dL/dE rows [L][B] and positions [B] float4 for the scatter kernels
     uint16_t* d_gpart = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0;   // k_grid_scatter: partial tables, plan, levels it covers
     uint16_t* d_frag_train = nullptr; uint16_t* d_frag_render = nullptr;           // MFMA A-fragment images (training weights / inference weights)
     uint32_t* d_ema_step = nullptr; uint8_t* d_touched = nullptr;                  // lazy EMA bookkeeping, chunk flags (ParamPtrs)

@@ -72,7 +72,7 @@ static cv::Mat read_png(const std::string& path, int want_type) {
 
 static int run_online(const std::string& seq, const std::string& cfg, const std::string& out) {
     std::ifstream fc(seq + "/config.yaml"); std::stringstream ss; ss << fc.rdbuf(); const std::string y = ss.str();
-    auto num = [&](const char* key) { const size_t p = y.find(key); return std::strtod(y.c_str() + y.find(':', p) + 1, nullptr); };
+    auto num = [&](const char* key) { const std::string k = std::string("\n") + key + ":"; const size_t p = y.find(k); return p == std::string::npos ? 0.0 : std::strtod(y.c_str() + p + k.size(), nullptr); };   // exact key at line start
     std::vector<std::string> stamps, names; std::vector<Eigen::Matrix4f> twc; std::string line;
     { std::ifstream fi(seq + "/img.txt"); std::getline(fi, line); while (std::getline(fi, line)) { std::stringstream s(line); std::string a, b; s >> a >> b; if (!a.empty()) { stamps.push_back(a); names.push_back(b); } } }
     { std::ifstream fg(seq + "/groundtruth.txt"); std::getline(fg, line); while (std::getline(fg, line)) { std::stringstream s(line); std::string a; float t[3], q[4]; s >> a >> t[0] >> t[1] >> t[2] >> q[0] >> q[1] >> q[2] >> q[3]; if (!a.empty()) twc.push_back(pose_from_tq(t, q[0], q[1], q[2], q[3])); } }

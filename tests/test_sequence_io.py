@@ -48,6 +48,54 @@ def test_png_codec_against_pillow(pkg, tmp_path):
             pass
 
 
+def test_png_reader_takes_what_cv_imread_takes(pkg, tmp_path):
+    """Palette (instance masks are often written that way), 1/2/4-bit gray, palette + tRNS, gray + alpha, 16-bit RGB and Adam7-interlaced
+    files, each against Pillow's decode; a short IHDR chunk is rejected instead of over-read."""
+    import struct
+    import zlib
+    from PIL import Image
+    rs = np.random.RandomState(3); H, W = 23, 41
+    idx = rs.randint(0, 7, (H, W)).astype(np.uint8)
+    pal = Image.fromarray(idx, mode="P"); palette = rs.randint(0, 256, 7 * 3).astype(np.uint8); pal.putpalette(palette.tolist())
+    pal.save(tmp_path / "p8.png"); pal.save(tmp_path / "p4.png", bits=4)
+    got = pkg.png_read(str(tmp_path / "p8.png")); want = palette.reshape(-1, 3)[idx]
+    assert got.shape == (H, W, 3) and np.array_equal(got, want) and np.array_equal(pkg.png_read(str(tmp_path / "p4.png")), want)
+    pal.save(tmp_path / "pt.png", transparency=2)                             # tRNS: palette entry 2 fully transparent -> RGBA like libpng's expand
+    got = pkg.png_read(str(tmp_path / "pt.png")); assert got.shape == (H, W, 4) and np.array_equal(got, np.asarray(Image.open(tmp_path / "pt.png").convert("RGBA")))
+    bw = (rs.rand(H, W) > 0.5); Image.fromarray(bw).save(tmp_path / "g1.png")           # 1-bit gray
+    assert np.array_equal(pkg.png_read(str(tmp_path / "g1.png"))[..., 0], bw.astype(np.uint8) * 255)
+    # 2- and 4-bit gray, written by hand (Pillow only writes them for palettes): packed samples, filter 0
+    for bits in (2, 4):
+        v = rs.randint(0, 1 << bits, (H, W)).astype(np.uint8); rows = b""
+        for y in range(H):
+            acc = 0; nb = 0; line = bytearray()
+            for x in range(W):
+                acc = (acc << bits) | int(v[y, x]); nb += bits
+                if nb == 8: line.append(acc); acc = 0; nb = 0
+            if nb: line.append(acc << (8 - nb))
+            rows += b"\x00" + bytes(line)
+        def chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+        png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, bits, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(rows)) + chunk(b"IEND", b"")
+        (tmp_path / ("g%d.png" % bits)).write_bytes(png)
+        assert np.array_equal(pkg.png_read(str(tmp_path / ("g%d.png" % bits)))[..., 0], v * (255 // ((1 << bits) - 1)))
+        assert np.array_equal(np.asarray(Image.open(tmp_path / ("g%d.png" % bits)).convert("L")), v * (255 // ((1 << bits) - 1)))
+    la = rs.randint(0, 256, (H, W, 2)).astype(np.uint8); Image.fromarray(la, mode="LA").save(tmp_path / "la.png")
+    assert np.array_equal(pkg.png_read(str(tmp_path / "la.png")), la)
+    # Adam7: re-encode a Pillow file's pixels interlaced by hand (Pillow cannot write interlaced PNGs): 7 passes, filter 0
+    rgb = rs.randint(0, 256, (H, W, 3)).astype(np.uint8); raw = b""
+    for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = rgb[y0::dy, x0::dx]
+        if sub.size:
+            raw += b"".join(b"\x00" + sub[r].tobytes() for r in range(sub.shape[0]))
+    def chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    (tmp_path / "i.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "i.png")), rgb) and np.array_equal(pkg.png_read(str(tmp_path / "i.png")), rgb)
+    # a 12-byte IHDR (crafted) must be refused, not read past
+    (tmp_path / "short.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBB", W, H, 8, 2, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\x00" * 64)) + chunk(b"IEND", b""))
+    with pytest.raises(pkg.MonError):
+        pkg.png_read(str(tmp_path / "short.png"))
+
+
 def test_offline_manager_errors_without_dataset(pkg, tmp_path):
     m = pkg.OfflineManager(str(tmp_path), os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json"))
     if pkg.device_count() == 0:
