@@ -84,6 +84,11 @@ int mon_version(void);
 
 /* NerfManager{Offline,Online}::Init -- device discovery (nerf_manager.cu:16-38, :136-158). */
 int mon_device_count(int* n_devices);
+/* Device numbering of everything below is LOGICAL.  Default: the physical HIP devices.  n > 0: n logical devices mapped round-robin onto the
+ * physical ones (logical d -> physical d mod physical count), so the reference's object k -> device k mod nGPU placement with one dataset replica
+ * per device (nerf.cu:27-33, nerf_manager.cu:44-55) can be driven -- oversubscribed -- on a box with fewer GPUs; 0 restores the default.  Call before
+ * creating datasets / managers. */
+int mon_set_logical_devices(int n);
 
 /* NeRF_Model::ReadNetworkConfig (nerf_model.cu:1272-1284): tcnn JSON with comments. */
 int mon_config_default(mon_config* cfg);                       /* CORE/configs/base.json values */

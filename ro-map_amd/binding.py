@@ -44,6 +44,7 @@ _SIGS = {
     "mon_last_error": (C.c_char_p, []),
     "mon_version": (C.c_int, []),
     "mon_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mon_set_logical_devices": (C.c_int, [C.c_int]),
     "mon_config_default": (C.c_int, [C.POINTER(MonConfig)]),
     "mon_config_from_json": (C.c_int, [C.c_char_p, C.POINTER(MonConfig)]),
     "mon_dataset_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
@@ -153,6 +154,11 @@ def device_count():
     n = C.c_int(0)
     rc = lib().mon_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+def set_logical_devices(n):
+    """n logical devices mapped round-robin onto the physical GPUs (0 = the physical devices themselves)."""
+    _check(lib().mon_set_logical_devices(int(n)))
 
 
 def device_mem_info(device=0):

@@ -43,6 +43,7 @@ extern "C" {
 const char* mon_last_error(void) { return last_error(); }
 int mon_version(void) { return 100; }
 int mon_device_count(int* n) { REQUIRE(n, "n_devices"); return device_count(n); }
+int mon_set_logical_devices(int n) { return set_logical_devices(n); }
 int mon_config_default(mon_config* cfg) { REQUIRE(cfg, "cfg"); config_default(*cfg); return MON_OK; }
 int mon_config_from_json(const char* path, mon_config* cfg) { REQUIRE(path, "path"); REQUIRE(cfg, "cfg"); return config_from_json(path, *cfg); }
 
@@ -108,12 +109,12 @@ int mon_object_get_profile(mon_object* o, mon_profile* out, int reset) {
 int mon_object_destroy(mon_object* o) { if (!o) return MON_OK; model_destroy(o->m); delete o; return MON_OK; }
 
 int mon_device_synchronize(int device) {
-    if (hipSetDevice(device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { set_error("device synchronize failed"); return MON_ERR_HIP; }
+    if (use_device(device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { set_error("device synchronize failed"); return MON_ERR_HIP; }
     return MON_OK;
 }
 int mon_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes) {
     REQUIRE(free_bytes, "free_bytes"); REQUIRE(total_bytes, "total_bytes");
-    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(free_bytes, total_bytes) != hipSuccess) { set_error("hipMemGetInfo failed on device %d", device); return MON_ERR_HIP; }
+    if (use_device(device) != hipSuccess || hipMemGetInfo(free_bytes, total_bytes) != hipSuccess) { set_error("hipMemGetInfo failed on device %d", device); return MON_ERR_HIP; }
     return MON_OK;
 }
 int mon_debug_fast_index(const mon_config* cfg, int level, uint32_t x, uint32_t y, uint32_t z, uint32_t* index, uint32_t* size) {

@@ -46,7 +46,7 @@ template <class T> static int grow(T*& p, size_t& cap, size_t need, size_t elems
 MeshState* mesh_state_create(int device) { MeshState* ms = new MeshState(); ms->device = device; return ms; }
 void mesh_state_destroy(MeshState* ms) {
     if (!ms) return;
-    hipSetDevice(ms->device);
+    use_device(ms->device);
     for (void* p : { (void*)ms->d_density, (void*)ms->d_vertidx, (void*)ms->d_blocks, (void*)ms->d_verts, (void*)ms->d_nraw, (void*)ms->d_normals, (void*)ms->d_colf, (void*)ms->d_col8, (void*)ms->d_indices })
         if (p) hipFree(p);
     delete ms;
@@ -139,7 +139,7 @@ int mesh_save(MeshState& ms, const char* path) {
 int model_generate_mesh(Model& m, int res, float thresh, uint32_t* n_verts, uint32_t* n_indices) {
     if (res <= 0) res = 64;                                                   // marching_cubes.h:30
     if (res < 2 || res > 512) { set_error("generate_mesh: res must be in [2, 512]"); return MON_ERR_ARG; }
-    HIPCHECK(hipSetDevice(m.device));
+    HIPCHECK(use_device(m.device));
     if (!m.mesh) { set_error("mesh: object has no mesh state"); return MON_ERR_STATE; }       // created with the object (no lazily published pointer for readers to race on)
     MeshState& ms = *m.mesh; hipStream_t s = m.train_stream;
     const size_t res3 = (size_t)res * res * res;
@@ -225,7 +225,7 @@ int marching_cubes_host(int device, const float* density, int rx, int ry, int rz
                         float* verts, float* normals_raw, uint32_t* indices, uint32_t cap_verts, uint32_t cap_indices, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices) {
     if (!density || !amin || !amax || rx < 2 || ry < 2 || rz < 2) { set_error("marching_cubes: bad argument"); return MON_ERR_ARG; }
     int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available"); return MON_ERR_NO_DEVICE; }
-    HIPCHECK(hipSetDevice(device));
+    HIPCHECK(use_device(device));
     MeshState* ms = mesh_state_create(device); const size_t res3 = (size_t)rx * ry * rz;
     int rc = mesh_reserve_lattice(*ms, res3);
     if (!rc) { if (hipMemcpy(ms->d_density, density, res3 * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("marching_cubes: upload failed"); rc = MON_ERR_HIP; } }

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(1024) k_ub_lds(int mode, uint32_t ops_per_thre
 
 int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms_out) {
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || hipSetDevice(device) != hipSuccess) { set_error("microbench: no HIP device"); return MON_ERR_NO_DEVICE; }
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || use_device(device) != hipSuccess) { set_error("microbench: no HIP device"); return MON_ERR_NO_DEVICE; }
     uint32_t* table = nullptr; float* sink = nullptr;
     const size_t bytes = (size_t)n_entries * 4 * 8;
     if (hipMalloc((void**)&table, bytes) != hipSuccess || hipMalloc((void**)&sink, 64) != hipSuccess) { set_error("microbench: hipMalloc failed"); return MON_ERR_HIP; }

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -32,10 +33,24 @@ const char* last_error() { return g_err.c_str(); }
 void config_default(mon_config& c);
 int config_from_json(const char* path, mon_config& c);
 
+// Logical devices: what the managers and the C ABI number 0 .. n-1.  By default they are the physical HIP devices; mon_set_logical_devices(n)
+// maps n logical devices round-robin onto the physical ones, so the multi-device code paths (object k -> device k mod nGPU, one dataset replica and
+// one stream pool per device, CORE/src/nerf.cu:27-33, nerf_manager.cu:44-55) also run -- oversubscribed -- on a box with fewer GPUs.
+static std::atomic<int> g_logical_devices{ 0 };
+static int physical_count() { int c = 0; return (hipGetDeviceCount(&c) == hipSuccess) ? c : 0; }
+hipError_t use_device(int logical) {
+    const int phys = physical_count(); if (phys < 1) return hipErrorNoDevice;
+    const int n = g_logical_devices.load(); if (logical < 0 || logical >= (n > 0 ? n : phys)) return hipErrorInvalidDevice;
+    return hipSetDevice(logical % phys);
+}
+int set_logical_devices(int n) {
+    if (n < 0 || n > 64) { set_error("set_logical_devices: 0 (= the physical devices) .. 64"); return MON_ERR_ARG; }
+    g_logical_devices.store(n); return MON_OK;
+}
 int device_count(int* n) {
     int c = 0; hipError_t e = hipGetDeviceCount(&c);
     if (e != hipSuccess || c < 1) { *n = 0; set_error("Can not Detect GPU: %s", hipGetErrorString(e)); return MON_ERR_NO_DEVICE; }
-    *n = c; return MON_OK;
+    const int l = g_logical_devices.load(); *n = l > 0 ? l : c; return MON_OK;
 }
 
 // ------------------------------------------------------------------ dataset
@@ -43,7 +58,7 @@ int dataset_destroy(Dataset* d);
 int dataset_create(int device, int H, int W, float fx, float fy, float cx, float cy, uint32_t max_frames, int use_depth, Dataset** out) {
     int n = 0; int rc = device_count(&n); if (rc) return rc;
     if (device < 0 || device >= n || H <= 0 || W <= 0 || max_frames == 0) { set_error("dataset_create: bad argument"); return MON_ERR_ARG; }
-    HIPCHECK(hipSetDevice(device));
+    HIPCHECK(use_device(device));
     Dataset* d = new Dataset();
     d->device = device; d->K = Intrinsics{ fx, fy, cx, cy, H, W }; d->max_frames = max_frames; d->use_depth = use_depth != 0;
     const size_t px = (size_t)H * W;
@@ -63,7 +78,7 @@ int dataset_add_frame(Dataset* d, uint32_t id, const uint8_t* rgb, int ch, int i
     if (!d || !rgb || !inst || !Twc || (ch != 3 && ch != 4)) { set_error("dataset_add_frame: bad argument"); return MON_ERR_ARG; }
     if (id >= d->max_frames) { set_error("dataset_add_frame: frame id %u >= capacity %u", id, d->max_frames); return MON_ERR_ARG; }
     if (d->use_depth && !depth) { set_error("depth img error: dataset was created with use_depth"); return MON_ERR_ARG; }      // nerf_data.cu:296-300
-    HIPCHECK(hipSetDevice(d->device));
+    HIPCHECK(use_device(d->device));
     const size_t px = (size_t)d->K.H * d->K.W;
     const int ri = is_bgr ? 2 : 0, bi = is_bgr ? 0 : 2;             // cv::COLOR_BGR2RGB, nerf_data.cu:167,286
     for (size_t i = 0; i < px; ++i)
@@ -77,7 +92,7 @@ int dataset_add_frame(Dataset* d, uint32_t id, const uint8_t* rgb, int ch, int i
 }
 int dataset_destroy(Dataset* d) {
     if (!d) return MON_OK;
-    hipSetDevice(d->device);
+    use_device(d->device);
     if (d->d_rgba) hipFree(d->d_rgba);
     if (d->d_depth) hipFree(d->d_depth);
     if (d->d_poses) hipFree(d->d_poses);
@@ -95,7 +110,7 @@ static int stream_acquire(int device, hipStream_t* out) {
 }
 static void stream_release(int device, hipStream_t s) { std::lock_guard<std::mutex> l(g_stream_mu); g_stream_pool[device].push_back(s); }
 int stream_pool_reserve(int device, int n) {
-    HIPCHECK(hipSetDevice(device));
+    HIPCHECK(use_device(device));
     std::vector<hipStream_t> fresh;
     { std::lock_guard<std::mutex> l(g_stream_mu); n -= (int)g_stream_pool[device].size(); }
     int rc = MON_OK;
@@ -129,7 +144,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         int shift = 0; while (shift < 23 && 128.0f * (float)(1u << shift) < cfg.loss_scale) ++shift;
         m.lf.fix_scale = 16777216.0f / (float)(1u << shift); m.lf.fix_clamp = 100.0f * (float)(1u << shift);
     }
-    HIPCHECK(hipSetDevice(m.device));
+    HIPCHECK(use_device(m.device));
     std::memcpy(m.oc.Tow.m, Tow, 64);
     for (int a = 0; a < 3; ++a) { m.oc.aabb.mn[a] = amin[a]; m.oc.aabb.mx[a] = amax[a]; }
     m.oc.instance_id = (uint32_t)(uint8_t)class_id;                 // nerf.cu:75,158
@@ -214,7 +229,7 @@ static void drop_graph(Model& m) { if (m.graph_exec) { hipGraphExecDestroy(m.gra
 void model_mesh_free(Model& m);
 int model_destroy(Model* mp) {
     if (!mp) return MON_OK;
-    Model& m = *mp; hipSetDevice(m.device);
+    Model& m = *mp; use_device(m.device);
     model_mesh_free(m);
     if (m.train_stream) hipStreamSynchronize(m.train_stream);
     drop_graph(m);
@@ -227,7 +242,7 @@ int model_destroy(Model* mp) {
 
 int model_add_boxes(Model& m, const mon_frame_bbox* boxes, size_t n) {
     if (!boxes || n == 0) { set_error("add_boxes: empty"); return MON_ERR_ARG; }
-    HIPCHECK(hipSetDevice(m.device));
+    HIPCHECK(use_device(m.device));
     for (size_t i = 0; i < n; ++i) {
         const mon_frame_bbox& b = boxes[i];
         if (b.FrameId >= m.ds->max_frames || b.w == 0 || b.h == 0 || b.x + b.w > (uint32_t)m.ds->K.W || b.y + b.h > (uint32_t)m.ds->K.H) {
@@ -341,7 +356,7 @@ static int sync_state(Model& m) {
 int model_train(Model& m, int iters, float* loss, int stages) {
     if (iters < 0) { set_error("train: negative iteration count"); return MON_ERR_ARG; }
     if (m.n_boxes == 0) { set_error("train: no 2-D boxes (UpdateFrameIdAndBbox was never called)"); return MON_ERR_STATE; }
-    HIPCHECK(hipSetDevice(m.device));
+    HIPCHECK(use_device(m.device));
     // Large-table scatter: the device picks binned / atomic per iteration from the previous iteration's gradient-carrying sample count;
     // once the host has seen that count well below the switch point it stops launching the (then empty) binning kernels at all.
     m.big_active = m.big_switch && (m.h_state.n_scatter_last == 0u || m.h_state.n_scatter_last > m.big_switch / 2u);
@@ -373,7 +388,7 @@ int model_train(Model& m, int iters, float* loss, int stages) {
 // Lazy EMA: apply the steps untouched chunks sat out before the inference weights are read.
 int ensure_ema_current(Model& m) {
     if (!m.ema_pending) return MON_OK;
-    HIPCHECK(hipSetDevice(m.device));
+    HIPCHECK(use_device(m.device));
     ParamPtrs P = m.P; P.ema_step = m.d_ema_step;
     launch_ema_finalize(m.train_stream, P, m.opt, m.d_state);
     HIPCHECK(hipGetLastError()); m.ema_pending = false; return MON_OK;
@@ -381,7 +396,7 @@ int ensure_ema_current(Model& m) {
 
 int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, int dst_on_device) {
     if (!pose16 || !rgb || !depth || !mask || box.w == 0 || box.h == 0) { set_error("render: bad argument"); return MON_ERR_ARG; }
-    HIPCHECK(hipSetDevice(m.device));
+    HIPCHECK(use_device(m.device));
     { int rc = ensure_ema_current(m); if (rc) return rc; }
     hipStream_t s = m.train_stream;
     HIPCHECK(hipStreamSynchronize(s));
@@ -420,7 +435,7 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
 // GetDensityOnGrid :2007-2048
 int model_density_grid(Model& m, int rx, int ry, int rz, float* out_host) {
     if (rx < 2 || ry < 2 || rz < 2 || !out_host || (uint64_t)rx * (uint64_t)ry * (uint64_t)rz > (1ull << 31)) { set_error("density_grid: bad argument"); return MON_ERR_ARG; }
-    HIPCHECK(hipSetDevice(m.device));
+    HIPCHECK(use_device(m.device));
     { int rc = ensure_ema_current(m); if (rc) return rc; }
     hipStream_t s = m.train_stream;
     HIPCHECK(hipStreamSynchronize(s));
@@ -444,14 +459,14 @@ int model_get_params(Model& m, int which, void* dst, size_t bytes) {
     switch (which) { case 0: src = m.P.master; need = (size_t)m.n_params * 4; break; case 1: src = m.P.half; need = (size_t)m.n_params * 2; break;
                      case 2: src = m.P.ema; need = (size_t)m.n_params * 2; break; default: set_error("get_params: which must be 0..2"); return MON_ERR_ARG; }
     if (!dst || bytes < need) { set_error("get_params: buffer too small (%zu < %zu)", bytes, need); return MON_ERR_ARG; }
-    HIPCHECK(hipSetDevice(m.device));
+    HIPCHECK(use_device(m.device));
     if (which == 2) { int rc = ensure_ema_current(m); if (rc) return rc; }
     HIPCHECK(hipStreamSynchronize(m.train_stream));
     HIPCHECK(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost)); return MON_OK;
 }
 int model_set_params(Model& m, const float* master, size_t n) {
     if (!master || n != m.n_params) { set_error("set_params: expected %u values", m.n_params); return MON_ERR_ARG; }
-    HIPCHECK(hipSetDevice(m.device)); HIPCHECK(hipStreamSynchronize(m.train_stream));
+    HIPCHECK(use_device(m.device)); HIPCHECK(hipStreamSynchronize(m.train_stream));
     HIPCHECK(hipMemcpy(m.P.master, master, n * 4, hipMemcpyHostToDevice));
     launch_master_to_half(m.train_stream, m.P.master, m.P.half, (uint32_t)n);
     HIPCHECK(hipStreamSynchronize(m.train_stream));
@@ -484,12 +499,12 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
         case MON_BUF_FRAG_TRAIN: src = m.d_frag_train; sz = 64 * 512 * 2; break;
         case MON_BUF_FRAG_REF:
             if (!m.d_frag_render) { set_error("debug_read: fused backend not available"); return MON_ERR_STATE; }
-            HIPCHECK(hipSetDevice(m.device)); HIPCHECK(hipMemsetAsync(m.d_frag_render, 0, 64 * 512 * 2, m.train_stream));
+            HIPCHECK(use_device(m.device)); HIPCHECK(hipMemsetAsync(m.d_frag_render, 0, 64 * 512 * 2, m.train_stream));
             launch_build_frag_image(m.train_stream, m.P.half, m.nd, m.d_frag_render); src = m.d_frag_render; sz = 64 * 512 * 2; break;
         default: set_error("debug_read: unknown buffer id %d", which); return MON_ERR_ARG;
     }
     if (!dst || bytes < sz) { set_error("debug_read: buffer too small (%zu < %zu)", bytes, sz); return MON_ERR_ARG; }
-    HIPCHECK(hipSetDevice(m.device)); HIPCHECK(hipStreamSynchronize(m.train_stream));
+    HIPCHECK(use_device(m.device)); HIPCHECK(hipStreamSynchronize(m.train_stream));
     HIPCHECK(hipMemcpy(dst, src, sz, hipMemcpyDeviceToHost));
     if (which == MON_BUF_GGRID_H && m.backend == 1 && m.lds_mask) {        // total gradient = atomic table + sum of the scatter partials
         std::vector<uint16_t> part(m.n_grid); std::vector<float> acc(m.n_grid);

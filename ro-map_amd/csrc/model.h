@@ -92,6 +92,9 @@ enum {
     MON_BUF_FRAG_REF = 35       // the same image rebuilt from the current fp16 weights by k_build_frag_image (layout test)
 };
 
+hipError_t use_device(int logical_device);      // hipSetDevice through the logical-device map (model.cpp)
+int set_logical_devices(int n);
+
 // ---- kernel launchers (kernels_*.hip)
 void launch_gen_candidates(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st);
 void launch_build_rays(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st);

@@ -1,0 +1,140 @@
+"""BASELINE.json configs[3] and configs[4] at their stated shapes, as far as one GPU allows, plus the in-process multi-device placement
+(object k -> device k mod nGPU) on logical devices.
+
+configs[3]: online RO-MAP at TrainStepIterations = 500 on base.json -- the SLAM side's call sequence (LocalMapping.cc:1122-1270) replayed
+through the online manager while the object threads train: what the CALLERS wait is asserted, not only that training happens.
+configs[4]: the stress shape per GPU -- 8 object NeRFs with hash T = 2^22 (105 M parameters each) trained concurrently on one device.
+The two remaining configs need eight GPUs (configs[2] and the 64-object form of configs[4]); their per-GPU code path is what runs here."""
+import os
+import threading
+import time
+import zlib
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_online_replay_at_500_iterations_on_base_json(pkg, ss):
+    assert pkg.device_count() >= 1
+    n_obj, n_kf, period = 4, 36, 0.03
+    sc = ss.make_scene(n_views=n_kf, H=480, W=640, f=525.0, n_objects=n_obj, seed=11)
+    m = pkg.OnlineManager(os.path.join(ROOT, "ro-map_amd", "configs", "base.json"), False, 500)
+    m.init(); m.dataset_init(sc.fx, sc.fy, sc.cx, sc.cy, sc.H, sc.W, sc.n_views)
+    ids = {}; t_frame, t_box, t_render = [], [], []
+    t_start = time.perf_counter()
+    for v in range(sc.n_views):
+        t_next = t_start + (v + 1) * period
+        t0 = time.perf_counter(); m.new_frame(v, "%.6f" % (v * 0.1), sc.rgb[v][..., ::-1], sc.instance[v], ss.colmajor(sc.Twc[v])); t_frame.append(time.perf_counter() - t0)
+        for k, ob in enumerate(sc.objects):
+            if k not in ids:
+                ids[k] = m.create_nerf(ob["cls"], ss.colmajor(ob["Tow"]), -ob["half"] / 1.1, ob["half"] / 1.1)
+            b = ob["boxes"][ob["boxes"][:, 0] == v]
+            t0 = time.perf_counter(); m.update_nerf_bbox(ids[k], b, 1); t_box.append(time.perf_counter() - t0)
+        if v > 12:                                            # a viewer: a crop of object 0 every keyframe while everything trains
+            bx = sc.objects[0]["boxes"][3]
+            t0 = time.perf_counter(); m.render(ids[0], bx, ss.colmajor(sc.Twc[int(bx[0])])); t_render.append(time.perf_counter() - t0)
+        time.sleep(max(0.0, t_next - time.perf_counter()))
+    m.wait_threads_end()
+    ms = lambda a: (1e3 * float(np.mean(a)), 1e3 * float(np.max(a)))
+    print("NewFrameToDataset mean %.2f max %.2f ms; UpdateNeRFBbox mean %.3f max %.2f ms; viewer crop mean %.2f max %.2f ms" % (ms(t_frame) + ms(t_box) + ms(t_render)))
+    # the reference holds every object's dataset mutex for a whole 500-iteration Train_Step_Online around these calls (tens of ms on its own hardware)
+    assert ms(t_frame)[0] < 6.0 and ms(t_frame)[1] < 60.0
+    assert ms(t_box)[0] < 1.0 and ms(t_box)[1] < 20.0
+    assert ms(t_render)[0] < 12.0
+    for k, i in ids.items():
+        info = m.object_info(i)
+        steps_done = int(m.object(i).info().train_step)
+        assert info["train_calls"] >= 2 and steps_done == 500 * info["train_calls"]          # whole Train_Step_Online calls of 500 iterations (nerf.cu:222-227)
+        ob = sc.objects[k]; v, x, y, h, w = (int(q) for q in ob["boxes"][3])
+        rgb, depth, mask = m.render(i, ob["boxes"][3], ss.colmajor(sc.Twc[v]))
+        gm = sc.instance[v, y:y + h, x:x + w] == ob["cls"]; gt = np.where(gm[..., None], sc.rgb[v, y:y + h, x:x + w] / 255.0, 1.0)
+        assert np.isfinite(info["loss"]) and info["loss"] < 0.02 and -10 * np.log10(np.mean((rgb - gt) ** 2)) > 25.0
+    m.close()
+
+
+def test_stress_shape_eight_t22_objects_concurrently_on_one_gpu(pkg, ss):
+    assert pkg.device_count() >= 1
+    free, total = pkg.device_mem_info(0)
+    if free < 40 << 30:
+        pytest.skip("needs ~20 GB of device memory")
+    sc = ss.make_scene(n_views=16, H=240, W=320, f=260.0, seed=2)
+    K, steps = 8, 60
+    ds = None; objs = []
+    for k in range(K):
+        ds, o = ge.make_problem(pkg, sc, dict(log2_hashmap_size=22, sample_seed=500 + k), dataset=ds)
+        assert o.info().n_params == 3072 + 2 * 52727808 and int(o.info().backend) == 1
+        objs.append(o)
+    l0 = [o.train(1) for o in objs]
+    warm = 200                                                    # the first ~100 steps are optimizer-bound (most of the 13 M chunks still receive gradients: ~1 ms per object-step)
+    th = [threading.Thread(target=o.train, args=(warm,)) for o in objs]
+    [t.start() for t in th]; [t.join() for t in th]
+    pkg.lib().mon_device_synchronize(0); t0 = time.perf_counter()
+    th = [threading.Thread(target=o.train, args=(steps,)) for o in objs]
+    [t.start() for t in th]; [t.join() for t in th]
+    pkg.lib().mon_device_synchronize(0); dt = time.perf_counter() - t0
+    rate = K * steps * 4096 * 32 / dt
+    print("8 x T=2^22 objects: %.2f G ray-samples/s aggregate, %.3f ms per step per object" % (rate / 1e9, 1e3 * dt / steps))
+    assert rate > 0.35e9                                          # measured ~1.5 G at steps 200-260; one such object alone trains at 0.25-0.55 G
+    crc = []
+    for o, l in zip(objs, l0):
+        i = o.info(); assert i.train_step == warm + steps + 1 and i.skipped_batches == 0 and np.isfinite(i.last_loss) and i.last_loss < l
+        crc.append(zlib.crc32(o.get_params(1)[:3072 + 2 * 4096 + 2 * 32768].tobytes()))          # MLP + the two dense levels: cheap to read back
+    assert len(set(crc)) == K                                    # independent units: every object has its own sampling stream
+    # (tables this large scatter their fine levels with fp16 global atomics once few samples carry a gradient -- arrival order, like tcnn -- so the
+    #  bit-for-bit independence check runs on base.json objects below, whose every level takes the deterministic LDS path)
+    for o in objs:
+        o.close()
+    ds.close()
+
+
+def test_concurrent_objects_train_exactly_like_lone_ones(pkg, ss):
+    """Independent units: four base.json objects trained concurrently on one GPU (thread + stream each, as the managers do) end with
+    bit-identical parameters to the same objects trained one at a time -- no cross-object state, deterministic scatter."""
+    assert pkg.device_count() >= 1
+    sc = ss.make_scene(n_views=16, H=240, W=320, f=260.0, seed=2)
+    ds = None; objs = []
+    for k in range(4):
+        ds, o = ge.make_problem(pkg, sc, dict(sample_seed=700 + k), dataset=ds); objs.append(o)
+    th = [threading.Thread(target=o.train, args=(150,)) for o in objs]
+    [t.start() for t in th]; [t.join() for t in th]
+    together = [zlib.crc32(o.get_params(0).tobytes()) for o in objs]
+    for o in objs:
+        o.close()
+    for k in range(4):
+        _, o = ge.make_problem(pkg, sc, dict(sample_seed=700 + k), dataset=ds); o.train(150)
+        assert zlib.crc32(o.get_params(0).tobytes()) == together[k], "object %d" % k
+        o.close()
+    assert len(set(together)) == 4
+    ds.close()
+
+
+def test_object_placement_over_logical_devices(pkg, ss, tmp_path):
+    """NerfManagerOffline on a two-device node, driven on one GPU through two logical devices: one dataset replica per device, object k on
+    device k mod 2 (nerf.cu:27-33, nerf_manager.cu:44-55), all objects trained and their outputs written."""
+    assert pkg.device_count() >= 1
+    sc = ss.make_scene(n_views=10, H=120, W=160, f=130.0, n_objects=3, seed=4)
+    seq = str(tmp_path / "seq"); ss.write_sequence(sc, seq)
+    os.environ["MON_OFFLINE_OUTER"] = "2"; os.environ["MON_OFFLINE_INNER"] = "60"
+    pkg.set_logical_devices(2)
+    try:
+        assert pkg.device_count() == 2
+        m = pkg.OfflineManager(seq, os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json"))
+        m.set_output_dir(str(tmp_path / "out")); m.init(); m.read_dataset()
+        for k in range(3):
+            m.create_nerf(os.path.join(seq, "obj_offline", "%d.txt" % k))
+        m.wait_threads_end()
+        devs = [int(m.object_loss(k)[1]) for k in range(3)]
+        assert devs == [0, 1, 0] and [int(m.object(k).info().device) for k in range(3)] == devs, devs
+        for k in range(3):
+            loss = m.object_loss(k)[0]
+            assert int(m.object(k).info().train_step) == 120 and np.isfinite(loss) and loss < 0.2
+            assert os.path.exists(os.path.join(str(tmp_path / "out"), "%d.ply" % k))
+        m.close()
+    finally:
+        pkg.set_logical_devices(0); os.environ.pop("MON_OFFLINE_OUTER", None); os.environ.pop("MON_OFFLINE_INNER", None)
+    assert pkg.device_count() >= 1
