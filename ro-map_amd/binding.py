@@ -55,6 +55,7 @@ _SIGS = {
     "mon_object_add_boxes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mon_object_train": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "mon_object_render": (C.c_int, [C.c_void_p, MonBBox, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "mon_object_render_snapshot": (C.c_int, [C.c_void_p, MonBBox, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "mon_object_density_grid": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mon_object_info_get": (C.c_int, [C.c_void_p, C.POINTER(MonInfo)]),
     "mon_object_get_params": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
@@ -253,6 +254,15 @@ class ObjectNeRF:
         pose = np.ascontiguousarray(pose16, np.float32)
         _check(lib().mon_object_render(self.h, MonBBox(FrameId, x, y, h, w), _p(pose), int(pose_is_Toc), _p(rgb), _p(depth), _p(mask), 0))
         return rgb, depth, mask
+
+    def render_snapshot(self, box, pose16, pose_is_Toc=False):
+        """Viewer-side render from the last published inference weights on the inference stream (safe while another thread trains this object);
+        returns (rgb, depth, mask, optimizer steps of the weights)."""
+        FrameId, x, y, h, w = (int(v) for v in box)
+        rgb = np.empty((h, w, 3), np.float32); depth = np.empty((h, w), np.float32); mask = np.empty((h, w), np.float32); st = C.c_uint32(0)
+        pose = np.ascontiguousarray(pose16, np.float32)
+        _check(lib().mon_object_render_snapshot(self.h, MonBBox(FrameId, x, y, h, w), _p(pose), int(pose_is_Toc), _p(rgb), _p(depth), _p(mask), C.byref(st)))
+        return rgb, depth, mask, st.value
 
     def render_into(self, box, pose16, rgb_ptr, depth_ptr, mask_ptr, on_device, pose_is_Toc=False):
         """NeRF_Model::Render straight into caller-owned buffers given as raw addresses (3hw + hw + hw float32); `on_device`: they are

@@ -69,6 +69,9 @@ int mon_object_train_stages(mon_object* o, int stage_bits) { REQUIRE(o, "object"
 int mon_object_render(mon_object* o, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, int dst_on_device) {
     REQUIRE(o, "object"); return model_render(*o->m, box, pose16, pose_is_Toc, rgb, depth, mask, dst_on_device);
 }
+int mon_object_render_snapshot(mon_object* o, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, uint32_t* snapshot_step) {
+    REQUIRE(o, "object"); return model_render_snapshot(*o->m, box, pose16, pose_is_Toc, rgb, depth, mask, snapshot_step);
+}
 int mon_object_generate_mesh(mon_object* o, int res, float thresh, uint32_t* n_verts, uint32_t* n_indices) { REQUIRE(o, "object"); return model_generate_mesh(*o->m, res, thresh, n_verts, n_indices); }
 int mon_object_mesh_counts(mon_object* o, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices) { REQUIRE(o, "object"); return model_mesh_counts(*o->m, n_verts, n_verts_real, n_indices); }
 int mon_object_get_mesh(mon_object* o, float* verts, float* normals, uint8_t* colors, uint32_t* indices, int try_lock_only) { REQUIRE(o, "object"); return model_get_mesh(*o->m, verts, normals, colors, indices, nullptr, nullptr, try_lock_only); }

@@ -39,6 +39,7 @@ int model_mesh_counts(Model& m, uint32_t* n_verts, uint32_t* n_verts_real, uint3
 int model_train(Model& m, int iters, float* loss, int stages);
 int stream_pool_reserve(int device, int n);
 int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, int dst_on_device);
+int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, uint32_t* snapshot_step);
 
 // Eigen::Quaternionf(w,x,y,z).toRotationMatrix() + translation -> column-major 4x4 (nerf_data.cu:100-106)
 static void pose_from_tq(const float* t, float qx, float qy, float qz, float qw, float* M) {
@@ -521,7 +522,9 @@ int mon_online_object_info(mon_online* h, size_t idx, float* loss, int* train_ca
 }
 int mon_online_render(mon_online* h, size_t idx, mon_frame_bbox box, const float* Twc16, float* rgb, float* depth, float* mask) {   // one view of RenderNeRFsTest :280-285
     REQ(h); if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
-    AnnouncedLock lm(h->m->objs[idx], h->m->objs[idx]->mu_model);         // let in between two slices of a running training step
+    // a viewer's render: the latest published inference weights on the object's inference stream -- no model mutex, nothing queued behind training
+    if (model_render_snapshot(*h->m->objs[idx]->model, box, Twc16, 0, rgb, depth, mask, nullptr) == MON_OK) return MON_OK;
+    AnnouncedLock lm(h->m->objs[idx], h->m->objs[idx]->mu_model);         // nothing published yet / no inference side: let in between two slices of a running training step
     return model_render(*h->m->objs[idx]->model, box, Twc16, 0, rgb, depth, mask, 0);
 }
 // NerfManagerOnline::RenderNeRFsTest -> NeRF::RenderTestImg, nerf.cu:255-404: <out>/<id>/{test_img,test_depth,test_mask}/<stamp>.png,

@@ -123,6 +123,19 @@ int stream_pool_reserve(int device, int n) {
     return rc;
 }
 
+// ---- inference side of a model (the reference's second stream, nerf_model.cu:1268-1269).  The training thread PUBLISHES the inference weights
+// at the end of every train call / online slice: a device-to-device copy into one of two snapshot buffers, ordered on the train stream, with an
+// event.  A viewer thread renders from the latest published snapshot on the inference stream (created with the highest priority) and in a
+// workspace of its own: it takes no model mutex, never touches the train stream, and its kernels do not queue behind training slices.
+struct InferState {
+    hipStream_t stream = nullptr;
+    uint16_t* snap[2] = { nullptr, nullptr }; hipEvent_t ready[2] = { nullptr, nullptr }; uint32_t step_of[2] = { 0, 0 };
+    int latest = -1, readers[2] = { 0, 0 }; std::mutex mu;              // which snapshot is current, who is reading which
+    std::mutex render_mu;                                               // one snapshot render per object at a time (they share the workspace below)
+    BatchPtrs rb{}; float *out_rgb = nullptr, *out_depth = nullptr, *out_mask = nullptr; size_t out_cap = 0; uint16_t* frag = nullptr;
+    std::vector<void*> grown;                                           // superseded output buffers, freed with the object
+};
+
 template <class T> static int dev_alloc(Model& m, T*& p, size_t n, bool zero = true) {
     void* q = nullptr; const size_t bytes = (n ? n : 1) * sizeof(T);
     HIPCHECK(hipMalloc(&q, bytes));
@@ -209,7 +222,32 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     m.backend = fused_supported(m.nd, S, m.oc.R) ? 1 : 0;
     if (const char* e = std::getenv("MON_BACKEND")) m.backend = std::atoi(e) ? (fused_supported(m.nd, S, m.oc.R) ? 1 : 0) : 0;
     m.mesh = mesh_state_create(m.device);
+    if (m.backend == 1 && !m.lazy_ema) {          // (tables above 8 M parameters keep their EMA lazily and would cost 2 x 200 MB of snapshots: they render on the train stream)
+        InferState* is = new InferState(); m.infer = is;
+        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIPCHECK(hipStreamCreateWithPriority(&is->stream, hipStreamNonBlocking, hi));
+        for (int k = 0; k < 2; ++k) { if ((rc = dev_alloc(m, is->snap[k], n, false))) return rc; HIPCHECK(hipEventCreateWithFlags(&is->ready[k], hipEventDisableTiming)); }
+        is->rb = m.B;
+        if ((rc = dev_alloc(m, is->rb.ray_o, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, is->rb.ray_d, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, is->rb.ray_dn, kRenderChunkRays)) ||
+            (rc = dev_alloc(m, is->rb.ray_t0, kRenderChunkRays)) || (rc = dev_alloc(m, is->rb.ray_t1, kRenderChunkRays)) || (rc = dev_alloc(m, is->rb.ray_flag, kRenderChunkRays)) ||
+            (rc = dev_alloc(m, is->out_rgb, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, is->out_depth, kRenderChunkRays)) || (rc = dev_alloc(m, is->out_mask, kRenderChunkRays)) ||
+            (rc = dev_alloc(m, is->frag, 64 * 512))) return rc;
+        is->out_cap = kRenderChunkRays;
+    }
     HIPCHECK(hipDeviceSynchronize());
+    return MON_OK;
+}
+
+// Owner thread, after a train call's state read-back: copy the inference weights (EMA once a step has been taken) into the snapshot buffer no reader
+// holds and make it the current one.  ~4 us of device-to-device copy at base.json size, ordered on the train stream.
+static int publish_snapshot(Model& m) {
+    InferState* is = m.infer; if (!is) return MON_OK;
+    int w;
+    { std::lock_guard<std::mutex> l(is->mu); w = is->latest == 0 ? 1 : 0; if (is->readers[w] > 0) return MON_OK; }          // a render still reads the older buffer: keep the current snapshot this round
+    const uint16_t* src = (m.h_state.step > 0) ? m.P.ema : m.P.half;
+    HIPCHECK(hipMemcpyAsync(is->snap[w], src, (size_t)m.n_params * 2, hipMemcpyDeviceToDevice, m.train_stream));
+    HIPCHECK(hipEventRecord(is->ready[w], m.train_stream));
+    { std::lock_guard<std::mutex> l(is->mu); is->step_of[w] = m.h_state.step; is->latest = w; }
     return MON_OK;
 }
 
@@ -232,6 +270,12 @@ int model_destroy(Model* mp) {
     Model& m = *mp; use_device(m.device);
     model_mesh_free(m);
     if (m.train_stream) hipStreamSynchronize(m.train_stream);
+    if (m.infer) {
+        InferState* is = m.infer; if (is->stream) { hipStreamSynchronize(is->stream); hipStreamDestroy(is->stream); }
+        for (int k = 0; k < 2; ++k) if (is->ready[k]) hipEventDestroy(is->ready[k]);
+        for (void* p : is->grown) hipFree(p);
+        delete is; m.infer = nullptr;
+    }
     drop_graph(m);
     for (auto& e : m.ev_pool) hipEventDestroy(e);
     for (void* p : m.allocs) hipFree(p);
@@ -381,6 +425,42 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     HIPCHECK(hipGetLastError());
     int rc = sync_state(m); if (rc) return rc;
     if (loss) *loss = m.h_state.loss_sum / (float)m.oc.R;       // :1650-1658
+    if (stages == 7 && iters > 0) rc = publish_snapshot(m);
+    return rc;
+}
+
+// Render of the latest PUBLISHED inference weights on the inference stream: callable from any thread while the owner trains (no model mutex,
+// no train-stream work).  MON_ERR_STATE when nothing has been published yet (or the model has no inference side): the caller falls back to
+// model_render under the model mutex.
+int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, uint32_t* snapshot_step) {
+    if (!pose16 || !rgb || !depth || !mask || box.w == 0 || box.h == 0) { set_error("render: bad argument"); return MON_ERR_ARG; }
+    InferState* is = m.infer; if (!is) { set_error("render_snapshot: this object renders on its train stream"); return MON_ERR_STATE; }
+    std::lock_guard<std::mutex> one(is->render_mu);
+    int r;
+    { std::lock_guard<std::mutex> l(is->mu); r = is->latest; if (r < 0) { set_error("render_snapshot: no weights published yet"); return MON_ERR_STATE; } ++is->readers[r]; }
+    struct Release { InferState* is; int r; ~Release() { std::lock_guard<std::mutex> l(is->mu); --is->readers[r]; } } release{ is, r };
+    HIPCHECK(use_device(m.device));
+    hipStream_t s = is->stream;
+    HIPCHECK(hipStreamWaitEvent(s, is->ready[r], 0));
+    if (snapshot_step) *snapshot_step = is->step_of[r];
+    Mat4 pose; std::memcpy(pose.m, pose16, 64);
+    const uint32_t n_pix = box.w * box.h, S2 = 2 * m.oc.S;
+    if (n_pix > is->out_cap) {
+        const size_t cap = std::max<size_t>(n_pix, 2 * is->out_cap); void* q[3] = { nullptr, nullptr, nullptr };
+        HIPCHECK(hipMalloc(&q[0], 12 * cap)); HIPCHECK(hipMalloc(&q[1], 4 * cap)); HIPCHECK(hipMalloc(&q[2], 4 * cap));
+        for (void* p : q) is->grown.push_back(p);                       // (freed with the object; the superseded ones are smaller than the live one)
+        is->out_rgb = (float*)q[0]; is->out_depth = (float*)q[1]; is->out_mask = (float*)q[2]; is->out_cap = cap;
+    }
+    for (uint32_t p0 = 0; p0 < n_pix; p0 += kRenderChunkRays) {
+        const uint32_t n = (n_pix - p0) < kRenderChunkRays ? (n_pix - p0) : kRenderChunkRays;
+        launch_render_rays(s, is->rb, m.ds->K, m.oc, box, pose, pose_is_Toc, p0, n);
+        launch_fused_render(s, m.lf, m.nd, is->snap[r], is->rb, m.oc, n, p0 * S2, is->out_rgb + 3 * (size_t)p0, is->out_depth + p0, is->out_mask + p0, is->frag, p0 == 0u);
+    }
+    HIPCHECK(hipMemcpyAsync(rgb, is->out_rgb, 12 * (size_t)n_pix, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(depth, is->out_depth, 4 * (size_t)n_pix, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(mask, is->out_mask, 4 * (size_t)n_pix, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(hipGetLastError());
     return MON_OK;
 }
 
@@ -471,7 +551,7 @@ int model_set_params(Model& m, const float* master, size_t n) {
     launch_master_to_half(m.train_stream, m.P.master, m.P.half, (uint32_t)n);
     HIPCHECK(hipStreamSynchronize(m.train_stream));
     m.next_ready = false;                                   // the fragment image no longer matches the weights
-    return MON_OK;
+    return publish_snapshot(m);                             // (viewers of an untrained object see the weights just set)
 }
 
 int model_debug_read(Model& m, int which, void* dst, size_t bytes) {

@@ -147,9 +147,11 @@ struct Dataset {
 };
 
 struct MeshState;   // mesh.cpp
+struct InferState;  // model.cpp: inference stream, published weight snapshots and the render workspace of their own
 
 struct Model {
     MeshState* mesh = nullptr;
+    InferState* infer = nullptr;                // mpInferenceStream (nerf_model.cu:1269): renders for viewers that never queue behind training
     Dataset* ds = nullptr; mon_config cfg{}; int device = 0;
     LevelTable lt{}; LevelFast lf{}; NetDims nd{}; ObjectConst oc{}; OptimConst opt{};
     uint32_t n_grid = 0, n_params = 0;
@@ -175,6 +177,7 @@ struct Model {
 };
 
 int ensure_ema_current(Model& m);
+int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, uint32_t* snapshot_step);
 int level_table_build(const mon_config& c, LevelTable& lt, NetDims& nd, uint32_t& n_grid);
 void level_fast_build(const LevelTable& lt, const NetDims& nd, LevelFast& lf);
 void init_params_host(const mon_config& c, const NetDims& nd, uint32_t n_params, std::vector<float>& master);

@@ -113,6 +113,45 @@ def test_concurrent_objects_train_exactly_like_lone_ones(pkg, ss):
     ds.close()
 
 
+def test_viewer_renders_from_published_snapshots_while_the_object_trains(pkg, ss):
+    """The inference side (mpInferenceStream, nerf_model.cu:1269): a viewer thread renders the weights published at the end of every train call,
+    on a stream and in a workspace of its own, while the owner thread keeps training -- no lock shared with training.  Every render shows one
+    consistent published state (its step count is a multiple of the slice length), later renders never show older weights, and once training
+    has stopped the snapshot render equals the train-stream render bit for bit."""
+    assert pkg.device_count() >= 1
+    sc = ss.make_scene(n_views=16, H=240, W=320, f=260.0, seed=2)
+    ds, obj = ge.make_problem(pkg, sc, dict(sample_seed=31))
+    box = sc.objects[0]["boxes"][2]; pose = ss.colmajor(sc.Twc[int(box[0])])
+    with pytest.raises(pkg.MonError):
+        obj.render_snapshot(box, pose)                               # nothing published before the first train call
+    stop = threading.Event(); err = []
+
+    def trainer():
+        try:
+            while not stop.is_set():
+                obj.train(16)
+        except Exception as e:                                       # pragma: no cover
+            err.append(e)
+    th = threading.Thread(target=trainer); th.start()
+    steps, lat = [], []
+    t_end = time.perf_counter() + 1.5
+    while time.perf_counter() < t_end:
+        t0 = time.perf_counter()
+        try:
+            rgb, depth, mask, st = obj.render_snapshot(box, pose)
+        except pkg.MonError:
+            time.sleep(0.001); continue                              # the trainer has not finished its first call yet
+        lat.append(time.perf_counter() - t0); steps.append(st)
+        assert np.isfinite(rgb).all() and st % 16 == 0 and st > 0
+    stop.set(); th.join(); assert not err, err
+    assert len(steps) > 20 and steps == sorted(steps) and steps[-1] > steps[0]
+    print("snapshot renders while training: %d, mean %.2f ms, max %.2f ms; steps %d .. %d" % (len(lat), 1e3 * np.mean(lat), 1e3 * np.max(lat), steps[0], steps[-1]))
+    assert np.mean(lat) < 0.02
+    a = obj.render_snapshot(box, pose); b = obj.render(box, pose)
+    assert a[3] == obj.info().train_step and all(np.array_equal(x, y) for x, y in zip(a[:3], b))
+    obj.close(); ds.close()
+
+
 def test_object_placement_over_logical_devices(pkg, ss, tmp_path):
     """NerfManagerOffline on a two-device node, driven on one GPU through two logical devices: one dataset replica per device, object k on
     device k mod 2 (nerf.cu:27-33, nerf_manager.cu:44-55), all objects trained and their outputs written."""
