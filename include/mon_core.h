@@ -169,8 +169,6 @@ int mon_object_set_params(mon_object* obj, const float* master, size_t n);
 int mon_object_train_stages(mon_object* obj, int stage_bits);
 /* Backend selector for forward/backward: 0 = unfused reference kernels, 1 = fused MFMA kernel. */
 int mon_object_set_backend(mon_object* obj, int backend);
-/* Copy an internal device buffer to the host; ids in ro-map_amd/csrc/model.h (MON_BUF_*). */
-int mon_object_debug_read(mon_object* obj, int which, void* dst, size_t bytes);
 int mon_object_set_profiling(mon_object* obj, int enable);
 int mon_object_get_profile(mon_object* obj, mon_profile* out, int reset);
 int mon_object_destroy(mon_object* obj);
@@ -209,6 +207,12 @@ int mon_online_new_frame(mon_online* mgr, uint32_t img_id, const char* timestamp
 int mon_online_create_nerf(mon_online* mgr, int cls, const float* Tow16, const float* aabb_min3, const float* aabb_max3, size_t* idx_out);   /* CreateNeRF: 1.1x / 1.2x box inflation applied */
 int mon_online_update_nerf_bbox(mon_online* mgr, size_t idx, const mon_frame_bbox* boxes, size_t n, int train_step);                        /* UpdateNeRFBbox */
 int mon_online_get_frame_idx(mon_online* mgr, const char* timestamp, int* idx);                     /* GetFrameIdx (-1 if unknown) */
+/* NerfManagerOnline::UpdateDataset -> NeRF_Dataset::UpdateDataGPU (nerf_manager.cu:220-235, nerf_data.cu:341-353): the poses of frames
+ * [cur_id - frame_num, cur_id) are replaced on every device (bundle adjustment moved them) while every object's training is excluded.
+ * Twc16s: frame_num column-major 4x4.  The reference only calls it from commented-out code (LocalMapping.cc:1128-1150). */
+int mon_online_update_dataset(mon_online* mgr, uint32_t cur_id, uint32_t frame_num, const float* Twc16s);
+/* pose (Twc, column-major) the dataset holds for frame `frame_id` (NeRF::GetTwc reads these, nerf.cu:450-462) */
+int mon_online_get_pose(mon_online* mgr, uint32_t frame_id, float* Twc16);
 int mon_online_wait_threads_end(mon_online* mgr);                                                  /* WaitThreadsEnd: request finish + join */
 int mon_online_object_info(mon_online* mgr, size_t idx, float* loss, int* train_calls, int* device, uint32_t* n_boxes);
 int mon_online_render(mon_online* mgr, size_t idx, mon_frame_bbox box, const float* Twc16, float* rgb, float* depth, float* mask);   /* one view of RenderNeRFsTest */
@@ -225,22 +229,23 @@ int mon_online_destroy(mon_online* mgr);
 int mon_png_read(const char* path, int* width, int* height, int* channels, int* bit_depth, uint8_t* pixels, size_t capacity);
 int mon_png_write(const char* path, int width, int height, int channels, int bit_depth, const uint8_t* pixels_big_endian);
 
+/* Process-wide test and tuning switches (none is needed for normal operation; defaults are the product behaviour).  Read when an object is
+ * created or a training call is enqueued -- set them before.  Names: "backend" (-1 auto, 0 layer-at-a-time kernels, 1 fused), "use_graph" (replay
+ * an iteration as a hipGraph), "lazy_ema" (-1 auto: tables above 8 M parameters), "big_switch" (gradient-carrying samples below which the
+ * large-table levels scatter with global atomics; 0 = always), "touched_flags", "lds_scatter", "fold_reduce", "fold_next" (1 = on: the
+ * optimizer's chunk flags, the LDS scatter, the dW row sums inside k_grid_scatter, next-iteration preparation inside k_optimizer),
+ * "fused_grid", "opt_blocks" (workgroup caps, 0 = built-in), "fused_ablate" (timing ablations of k_fused_train; bit 16 = keep zero-gradient
+ * samples, used by the exactness test), "offline_outer" / "offline_inner" (NerfManagerOffline's 10 x 500 iterations, nerf_manager.cu:89).
+ * Unknown names return MON_ERR_ARG. */
+int mon_set_option(const char* name, long value);
+int mon_get_option(const char* name, long* value);
+
 /* Whole-device helpers used by bench.py. */
 int mon_device_synchronize(int device);
 int mon_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes);   /* hipMemGetInfo: sizing how many object NeRFs a device takes (base.json: 38 MB each, T = 2^22: 2.2 GB) */
-/* Diagnostic: write intermediate activations of the fused backend into the debug buffers (slower). */
+/* Staged-execution companion (tests): the fused backend also writes its intermediate activations into the debug buffers (slower);
+ * they are read back through libmon_core_diag.so (include/mon_core_diag.h). */
 int mon_object_set_debug_dump(mon_object* obj, int enable);
-/* Diagnostic micro-benchmarks of scatter strategies (ro-map_amd/csrc/microbench.hip); *ms = best of 3 runs. */
-int mon_microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms);
-/* Host-side check hook: corner index of the fused kernels' closed form (device_common.h:fast_grid_index) for level `level`
- * of configuration cfg; *size = entries of that level.  No device needed. */
-int mon_debug_fast_index(const mon_config* cfg, int level, uint32_t x, uint32_t y, uint32_t z, uint32_t* index, uint32_t* size);
-/* MFMA fragment-layout self-test (tests only): D[32x32] = A[32x16] * B[16x32], fp16 in / fp32 out. */
-/* Layout of the MFMA A-fragment image of the fused kernels (ro-map_amd/csrc/frag_layout.h), both directions, for the layout test:
- * source[n_image] = MLP parameter index held by each image element (-1 = structural zero); slots[2 * n_mlp] = the (<= 2) image elements
- * each parameter feeds (-1 = none).  Either pointer may be NULL. */
-int mon_debug_frag_layout(int encoded_width_padded, int n_neurons, int n_hidden_layers, int n_levels, int* source, int* slots, int* n_image, int* n_mlp);
-int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
 
 #ifdef __cplusplus
 }

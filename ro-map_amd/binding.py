@@ -45,6 +45,8 @@ _SIGS = {
     "mon_version": (C.c_int, []),
     "mon_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "mon_set_logical_devices": (C.c_int, [C.c_int]),
+    "mon_set_option": (C.c_int, [C.c_char_p, C.c_long]),
+    "mon_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_long)]),
     "mon_config_default": (C.c_int, [C.POINTER(MonConfig)]),
     "mon_config_from_json": (C.c_int, [C.c_char_p, C.POINTER(MonConfig)]),
     "mon_dataset_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
@@ -62,9 +64,7 @@ _SIGS = {
     "mon_object_set_params": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mon_object_train_stages": (C.c_int, [C.c_void_p, C.c_int]),
     "mon_object_set_backend": (C.c_int, [C.c_void_p, C.c_int]),
-    "mon_object_debug_read": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "mon_object_set_debug_dump": (C.c_int, [C.c_void_p, C.c_int]),
-    "mon_microbench": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
     "mon_object_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mon_object_get_profile": (C.c_int, [C.c_void_p, C.POINTER(MonProfile), C.c_int]),
     "mon_object_destroy": (C.c_int, [C.c_void_p]),
@@ -96,7 +96,6 @@ _SIGS = {
     "mon_online_object": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "mon_online_render_nerfs_test": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]),
     "mon_generate_toc": (C.c_int, [C.c_float, C.c_float, C.c_float, C.c_void_p]),
-    "mon_debug_frag_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mon_online_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mon_online_init": (C.c_int, [C.c_void_p]),
     "mon_online_dataset_init": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_size_t]),
@@ -104,6 +103,8 @@ _SIGS = {
     "mon_online_create_nerf": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]),
     "mon_online_update_nerf_bbox": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]),
     "mon_online_get_frame_idx": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
+    "mon_online_update_dataset": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "mon_online_get_pose": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "mon_online_wait_threads_end": (C.c_int, [C.c_void_p]),
     "mon_online_object_info": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "mon_online_render": (C.c_int, [C.c_void_p, C.c_size_t, MonBBox, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -111,13 +112,26 @@ _SIGS = {
     "mon_png_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
     "mon_png_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mon_device_synchronize": (C.c_int, [C.c_int]),
+}
+
+
+# every symbol include/mon_core_diag.h declares (libmon_core_diag.so: diagnostics and test scaffolding, not the product)
+_DIAG_SIGS = {
+    "mon_object_debug_read": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "mon_microbench": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
+    "mon_debug_frag_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mon_debug_fast_index": (C.c_int, [C.POINTER(MonConfig), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mon_selftest_mfma": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mon_debug_yaml_number": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_double)]),
 }
 
 
 def exported_symbols():
     return sorted(_SIGS)
+
+
+def diag_symbols():
+    return sorted(_DIAG_SIGS)
 
 
 def lib_path():
@@ -139,7 +153,47 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name); fn.restype = res; fn.argtypes = args
         _lib = L
+        # harness convenience (tools / tests that run in a subprocess): MON_OPTIONS="name=value,..." -> mon_set_option calls
+        for kv in filter(None, os.environ.get("MON_OPTIONS", "").split(",")):
+            k, v = kv.split("="); rc = L.mon_set_option(k.strip().encode(), int(v))
+            if rc != 0:
+                raise MonError(rc, L.mon_last_error().decode("utf-8", "replace"))
     return _lib
+
+
+_diag = None
+
+
+def diag_lib_path():
+    return os.path.join(os.path.dirname(lib_path()), "libmon_core_diag.so")
+
+
+def diag_lib():
+    """Loads libmon_core_diag.so (after libmon_core.so, which it links against)."""
+    global _diag
+    if _diag is None:
+        lib()
+        p = diag_lib_path()
+        if not os.path.exists(p):
+            raise MonError(-1, "libmon_core_diag.so not built")
+        L = C.CDLL(p)
+        for name, (res, args) in _DIAG_SIGS.items():
+            fn = getattr(L, name); fn.restype = res; fn.argtypes = args
+        _diag = L
+    return _diag
+
+
+def set_option(name, value):
+    """Process-wide test / tuning switch (include/mon_core.h: mon_set_option)."""
+    _check(lib().mon_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = C.c_long(0); _check(lib().mon_get_option(name.encode(), C.byref(v))); return v.value
+
+
+def yaml_number(text, key):
+    v = C.c_double(0); _check(diag_lib().mon_debug_yaml_number(text.encode(), key.encode(), C.byref(v))); return v.value
 
 
 def _check(rc):
@@ -180,15 +234,15 @@ def config_from_json(path):
 
 def selftest_mfma(A_h, B_h, device=0):
     A = np.ascontiguousarray(A_h, np.uint16); B = np.ascontiguousarray(B_h, np.uint16); D = np.empty((32, 32), np.float32)
-    _check(lib().mon_selftest_mfma(device, _p(A), _p(B), _p(D))); return D
+    _check(diag_lib().mon_selftest_mfma(device, _p(A), _p(B), _p(D))); return D
 
 
 def fast_index(cfg, level, x, y, z):
-    i = C.c_uint32(0); n = C.c_uint32(0); _check(lib().mon_debug_fast_index(C.byref(cfg), level, x, y, z, C.byref(i), C.byref(n))); return i.value, n.value
+    i = C.c_uint32(0); n = C.c_uint32(0); _check(diag_lib().mon_debug_fast_index(C.byref(cfg), level, x, y, z, C.byref(i), C.byref(n))); return i.value, n.value
 
 
 def microbench(mode, pattern, n_entries, n_ops, device=0):
-    ms = C.c_float(0); _check(lib().mon_microbench(device, mode, pattern, n_entries, n_ops, C.byref(ms))); return ms.value
+    ms = C.c_float(0); _check(diag_lib().mon_microbench(device, mode, pattern, n_entries, n_ops, C.byref(ms))); return ms.value
 
 
 class Dataset:
@@ -325,7 +379,7 @@ class ObjectNeRF:
                       target_depth=(np.float32, R), bgcol=(np.float32, R * 3), ray_flag=(np.uint8, R), ray_dn=(np.float32, R), mask=(np.uint64, R // 64),
                       state=(np.uint32, 28), frag_train=(np.uint16, 64 * 512), frag_ref=(np.uint16, 64 * 512))
         dt, cnt = shapes[name]; out = np.empty(cnt, dt)
-        _check(lib().mon_object_debug_read(self.h, BUF[name], _p(out), out.nbytes)); return out
+        _check(diag_lib().mon_object_debug_read(self.h, BUF[name], _p(out), out.nbytes)); return out
 
     def set_debug_dump(self, on):
         _check(lib().mon_object_set_debug_dump(self.h, int(on)))
@@ -437,6 +491,13 @@ class OnlineManager:
         b = np.ascontiguousarray(boxes, np.uint32).reshape(-1, 5)
         _check(lib().mon_online_update_nerf_bbox(self.h, idx, _p(b), b.shape[0], int(train_step)))
 
+    def update_dataset(self, cur_id, Twc16s):
+        """UpdateDataset: poses of the len(Twc16s) frames before cur_id replaced on every device."""
+        T = np.ascontiguousarray(Twc16s, np.float32).reshape(-1, 16); _check(lib().mon_online_update_dataset(self.h, int(cur_id), T.shape[0], _p(T)))
+
+    def get_pose(self, frame_id):
+        T = np.empty(16, np.float32); _check(lib().mon_online_get_pose(self.h, int(frame_id), _p(T))); return T
+
     def get_frame_idx(self, stamp):
         i = C.c_int(0); _check(lib().mon_online_get_frame_idx(self.h, stamp.encode(), C.byref(i))); return i.value
 
@@ -492,6 +553,6 @@ def generate_toc(theta_deg, phi_deg, radius):
 def frag_layout(epad, W, NH, L):
     """(source[n_image], slots[n_mlp, 2]) of the fused kernels' A-fragment image (frag_layout.h)."""
     ni = C.c_int(0); nm = C.c_int(0)
-    _check(lib().mon_debug_frag_layout(epad, W, NH, L, None, None, C.byref(ni), C.byref(nm)))
+    _check(diag_lib().mon_debug_frag_layout(epad, W, NH, L, None, None, C.byref(ni), C.byref(nm)))
     src = np.empty(ni.value, np.int32); sl = np.empty((nm.value, 2), np.int32)
-    _check(lib().mon_debug_frag_layout(epad, W, NH, L, _p(src), _p(sl), C.byref(ni), C.byref(nm))); return src, sl
+    _check(diag_lib().mon_debug_frag_layout(epad, W, NH, L, _p(src), _p(sl), C.byref(ni), C.byref(nm))); return src, sl

@@ -41,6 +41,18 @@ void NeRF::DrawCPUMesh() {                                                    //
     glDisableClientState(GL_VERTEX_ARRAY); glDisableClientState(GL_NORMAL_ARRAY); glDisableClientState(GL_COLOR_ARRAY);
 }
 
+vector<Eigen::Matrix4f> NeRF::GetTwc() {                                      // nerf.cu:450-462
+    vector<Eigen::Matrix4f> out;
+    if (mpOffline) {
+        size_t n = 0; mon_offline_get_poses(mpOffline, nullptr, 0, &n); std::vector<float> flat(16 * n);
+        if (n && mon_offline_get_poses(mpOffline, flat.data(), n, &n)) die("GetTwc");
+        for (const FrameIdAndBbox& b : mFrameIdBbox) { Eigen::Matrix4f T = Eigen::Matrix4f::Identity(); if (b.FrameId < n) std::memcpy(T.data(), &flat[16 * (size_t)b.FrameId], 64); out.push_back(T); }
+    } else if (mpOnline) {
+        for (const FrameIdAndBbox& b : mFrameIdBbox) { Eigen::Matrix4f T = Eigen::Matrix4f::Identity(); if (mon_online_get_pose(mpOnline, b.FrameId, T.data())) die("GetTwc"); out.push_back(T); }
+    }
+    return out;
+}
+
 // ------------------------------------------------------------------ offline manager (nerf_manager.cu:9-131)
 NerfManagerOffline::NerfManagerOffline(const string datasetPath, const string cfg, bool useDenseDepth)
     : msNetworkConfigFile(cfg), msDatasetPath(datasetPath), mbUseDenseDepth(useDenseDepth) {
@@ -54,12 +66,13 @@ bool NerfManagerOffline::ReadDataset() {                                        
 }
 bool NerfManagerOffline::CreateNeRF(const string objectFile) {                                                        // nerf_manager.cu:64-92, nerf.cu:58-118
     if (mon_offline_create_nerf(mpManager, objectFile.c_str())) { std::cerr << "Create NeRF error: " << mon_last_error() << std::endl; return false; }
-    auto n = std::make_shared<NeRF>(); const int idx = (int)mvpNeRFs.size(); n->mId = idx;
+    auto n = std::make_shared<NeRF>(); const int idx = (int)mvpNeRFs.size(); n->mId = idx; n->mpOffline = mpManager;
     size_t nb = 0;
     if (mon_offline_object_meta(mpManager, idx, &n->mClass, n->mObjTow.data(), n->mBoundingBox.min.data(), n->mBoundingBox.max.data(), nullptr, 0, &nb)) die("CreateNeRF");
     n->mFrameIdBbox.resize(nb);
     if (mon_offline_object_meta(mpManager, idx, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<mon_frame_bbox*>(n->mFrameIdBbox.data()), nb, &nb) ||
         mon_offline_object(mpManager, idx, &n->mpObject)) die("CreateNeRF");
+    n->mInstanceId = (uint8_t)n->mClass; n->mnBbox = nb;
     mvpNeRFs.push_back(n);
     return true;
 }
@@ -96,7 +109,7 @@ void NerfManagerOnline::NewFrameToDataset(unsigned int imgId, const string stamp
 size_t NerfManagerOnline::CreateNeRF(const int Class, const Eigen::Matrix4f& ObjTow, const nerf::BoundingBox& box) {
     size_t idx = 0;                                                           // the 1.1x / 1.2x inflation of SetAttributes (nerf.cu:163-172) is applied behind the C ABI
     if (mon_online_create_nerf(mpManager, Class, ObjTow.data(), box.min.data(), box.max.data(), &idx)) die("Create NeRF error");
-    auto n = std::make_shared<NeRF>(); n->mId = (int)idx; n->mClass = Class; n->mObjTow = ObjTow;
+    auto n = std::make_shared<NeRF>(); n->mId = (int)idx; n->mClass = Class; n->mInstanceId = (uint8_t)Class; n->mObjTow = ObjTow; n->mpOnline = mpManager;
     const float k = (Class == 41 || Class == 73) ? 1.2f : 1.1f;
     for (int a = 0; a < 3; ++a) { n->mBoundingBox.min.data()[a] = k * box.min.data()[a]; n->mBoundingBox.max.data()[a] = k * box.max.data()[a]; }
     if (mon_online_object(mpManager, idx, &n->mpObject)) die("Create NeRF error");
@@ -108,8 +121,14 @@ int NerfManagerOnline::GetFrameIdx(double t) {                                //
 }
 void NerfManagerOnline::UpdateNeRFBbox(const size_t idx, const vector<nerf::FrameIdAndBbox>& v, const int train_step) {
     if (v.empty()) return;
-    if (idx < mvpNeRFs.size()) mvpNeRFs[idx]->mFrameIdBbox.insert(mvpNeRFs[idx]->mFrameIdBbox.end(), v.begin(), v.end());
+    if (idx < mvpNeRFs.size()) { mvpNeRFs[idx]->mFrameIdBbox.insert(mvpNeRFs[idx]->mFrameIdBbox.end(), v.begin(), v.end()); mvpNeRFs[idx]->mnBbox = mvpNeRFs[idx]->mFrameIdBbox.size(); }
     if (mon_online_update_nerf_bbox(mpManager, idx, reinterpret_cast<const mon_frame_bbox*>(v.data()), v.size(), train_step)) die("UpdateNeRFBbox");
+}
+void NerfManagerOnline::UpdateDataset(unsigned int CurId, unsigned int FrameNum, const vector<Eigen::Matrix4f>& Poses) {      // nerf_manager.cu:220-235
+    if (FrameNum == 0 || Poses.size() < FrameNum) return;
+    std::vector<float> flat(16 * (size_t)FrameNum);
+    for (unsigned int i = 0; i < FrameNum; ++i) std::memcpy(&flat[16 * (size_t)i], Poses[i].data(), 64);
+    if (mon_online_update_dataset(mpManager, CurId, FrameNum, flat.data())) die("UpdateDataGPU");
 }
 void NerfManagerOnline::DrawMesh(size_t idx) { if (idx < mvpNeRFs.size()) mvpNeRFs[idx]->DrawCPUMesh(); }
 bool NerfManagerOnline::WaitThreadsEnd() {

@@ -14,13 +14,18 @@ public:
     BoundingBox GetBoundingBox() { return mBoundingBox; }
     CPUMeshData& GetCPUMeshData() { return mCPUMeshData; }
     void DrawCPUMesh();                           // nerf.cu:484-507: try_lock, draw the last mesh the training thread published
+    void DrawMesh() { DrawCPUMesh(); }            // nerf.cu:509-551 draws CUDA-GL interop buffers; here the same mesh from host arrays (no interop on this side)
+    vector<Eigen::Matrix4f> GetTwc();             // nerf.cu:450-462: the dataset's pose of every frame the object has a 2-D box in
 
     int mId = -1, mClass = 0;
+    uint8_t mInstanceId = 0;                      // nerf.h:59 (= class id as stored in the instance images, nerf.cu:75,158)
+    size_t mnBbox = 0;                            // nerf.h:64
     Eigen::Matrix4f mObjTow = Eigen::Matrix4f::Identity();
     BoundingBox mBoundingBox;
     std::vector<FrameIdAndBbox> mFrameIdBbox;
     CPUMeshData mCPUMeshData; uint64_t mMeshGeneration = 0;   // generation of the mesh held in mCPUMeshData
     mon_object* mpObject = nullptr;               // borrowed from the manager (mon_offline_object / mon_online_object)
+    mon_offline* mpOffline = nullptr; mon_online* mpOnline = nullptr;      // the manager that owns the dataset (GetTwc)
 };
 
 }  // namespace nerf

@@ -3,7 +3,11 @@
 // (mbUseSparseDepth, REF/src/LocalMapping.cc:1172); every method is one call into libmon_core.so's manager entry
 // points (mon_offline_* / mon_online_*, include/mon_core.h), which own the datasets, objects and training threads.
 #pragma once
+#if defined(__has_include) && __has_include(<opencv/cv.hpp>)
+#include <opencv/cv.hpp>                          // what CORE/include/nerf_manager.h:9 pulls in (OpenCV 3): consumers rely on its transitive includes
+#else
 #include <opencv2/core.hpp>
+#endif
 #include "nerf.h"
 
 namespace nerf {
@@ -36,6 +40,7 @@ public:
     size_t CreateNeRF(const int Class, const Eigen::Matrix4f& ObjTow, const nerf::BoundingBox& BoundingBox);
     int GetFrameIdx(double timastamp);
     void UpdateNeRFBbox(const size_t idx, const vector<nerf::FrameIdAndBbox>& vFrameBbox, const int train_step);
+    void UpdateDataset(unsigned int CurId, unsigned int FrameNum, const vector<Eigen::Matrix4f>& Poses);     // nerf_manager.h:66
     void DrawMesh(size_t idx);
     bool WaitThreadsEnd();
     void RenderNeRFsTest(const string out_path, const size_t Idx, const vector<string>& timestamp, const vector<FrameIdAndBbox>& vBbox,

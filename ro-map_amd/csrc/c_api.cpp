@@ -44,6 +44,8 @@ const char* mon_last_error(void) { return last_error(); }
 int mon_version(void) { return 100; }
 int mon_device_count(int* n) { REQUIRE(n, "n_devices"); return device_count(n); }
 int mon_set_logical_devices(int n) { return set_logical_devices(n); }
+int mon_set_option(const char* name, long value) { return option_set(name, value); }
+int mon_get_option(const char* name, long* value) { return option_get(name, value); }
 int mon_config_default(mon_config* cfg) { REQUIRE(cfg, "cfg"); config_default(*cfg); return MON_OK; }
 int mon_config_from_json(const char* path, mon_config* cfg) { REQUIRE(path, "path"); REQUIRE(cfg, "cfg"); return config_from_json(path, *cfg); }
 
@@ -103,8 +105,6 @@ int mon_object_set_backend(mon_object* o, int backend) {
     o->m->backend = backend; o->m->next_ready = false; return MON_OK;
 }
 int mon_object_set_debug_dump(mon_object* o, int enable) { REQUIRE(o, "object"); o->m->fused_dump = enable != 0; o->m->graph_backend = -1; return MON_OK; }
-int mon_microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms) { REQUIRE(ms, "ms"); return microbench(device, mode, pattern, n_entries, n_ops, ms); }
-int mon_object_debug_read(mon_object* o, int which, void* dst, size_t bytes) { REQUIRE(o, "object"); return model_debug_read(*o->m, which, dst, bytes); }
 int mon_object_set_profiling(mon_object* o, int enable) { REQUIRE(o, "object"); o->m->profiling = enable != 0; return MON_OK; }
 int mon_object_get_profile(mon_object* o, mon_profile* out, int reset) {
     REQUIRE(o, "object"); REQUIRE(out, "out"); *out = o->m->prof; if (reset) std::memset(&o->m->prof, 0, sizeof(mon_profile)); return MON_OK;
@@ -120,22 +120,5 @@ int mon_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes) {
     if (use_device(device) != hipSuccess || hipMemGetInfo(free_bytes, total_bytes) != hipSuccess) { set_error("hipMemGetInfo failed on device %d", device); return MON_ERR_HIP; }
     return MON_OK;
 }
-int mon_debug_fast_index(const mon_config* cfg, int level, uint32_t x, uint32_t y, uint32_t z, uint32_t* index, uint32_t* size) {
-    REQUIRE(cfg, "cfg"); REQUIRE(index, "index"); REQUIRE(size, "size");
-    LevelTable lt{}; NetDims nd{}; uint32_t n_grid = 0; int rc = level_table_build(*cfg, lt, nd, n_grid); if (rc) return rc;
-    if (level < 0 || level >= nd.L) { set_error("level out of range"); return MON_ERR_ARG; }
-    LevelFast lf{}; level_fast_build(lt, nd, lf);
-    *index = fast_grid_index(lf, level, x, y, z); *size = lf.size[level]; return MON_OK;
-}
-int mon_debug_frag_layout(int epad, int W, int NH, int L, int* source, int* slots, int* n_image, int* n_mlp) {
-    if (!(epad == 16 || epad == 32) || !(W == 32 || W == 64) || !(NH == 1 || NH == 2) || L < 1 || 2 * L > epad) { set_error("frag_layout: unsupported shape"); return MON_ERR_ARG; }
-    const FragDims d{ epad, W, NH, L };
-    if (n_image) *n_image = d.N_FRAGS() * 512;
-    if (n_mlp) *n_mlp = d.N_MLP();
-    if (source) for (int i = 0; i < d.N_FRAGS() * 512; ++i) source[i] = frag_source(d, i);
-    if (slots) for (int p = 0; p < d.N_MLP(); ++p) { int o[2] = { -1, -1 }; const int n = frag_slots(d, p, o); slots[2 * p] = n > 0 ? o[0] : -1; slots[2 * p + 1] = n > 1 ? o[1] : -1; }
-    return MON_OK;
-}
-int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D) { REQUIRE(A, "A"); REQUIRE(B, "B"); REQUIRE(D, "D"); return selftest_mfma(device, A, B, D); }
 
 }  // extern "C"

@@ -1,0 +1,101 @@
+// diag.cpp -- libmon_core_diag.so: diagnostics and test scaffolding (include/mon_core_diag.h).  Links against libmon_core.so and reads its objects
+// through the internal headers; nothing here is on the product path.
+#include <cstring>
+#include <string>
+#include <vector>
+#include "model.h"
+#include "frag_layout.h"
+#include "../../include/mon_core_diag.h"
+
+namespace mon {
+void set_error(const char* fmt, ...);
+int ensure_ema_current(Model& m);
+int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms);
+int selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
+bool read_yaml_number(const std::string& text, const char* key, double& v);
+
+#define HIPCHECK(expr)                                                                                         \
+    do { hipError_t _e = (expr); if (_e != hipSuccess) {                                                       \
+        set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return MON_ERR_HIP; } } while (0)
+
+int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
+    if (which == MON_BUF_EMA) { int rc = ensure_ema_current(m); if (rc) return rc; }
+    const size_t R = m.oc.R, B = R * m.oc.S, n = m.n_params; const void* src = nullptr; size_t sz = 0;
+    switch (which) {
+        case MON_BUF_MASTER: src = m.P.master; sz = n * 4; break;       case MON_BUF_HALF: src = m.P.half; sz = n * 2; break;
+        case MON_BUF_EMA: src = m.P.ema; sz = n * 2; break;             case MON_BUF_M1: src = m.P.m1; sz = n * 4; break;
+        case MON_BUF_M2: src = m.P.m2; sz = n * 4; break;               case MON_BUF_STEPS: src = m.P.steps; sz = n * 4; break;
+        case MON_BUF_GMLP: src = m.P.gmlp; sz = (size_t)m.nd.n_mlp * 4; break;
+        case MON_BUF_GGRID_H: src = m.P.ggrid; sz = (size_t)m.n_grid * 2; break;
+        case MON_BUF_PTS: src = m.B.pts; sz = B * 12; break;            case MON_BUF_TDIST: src = m.B.tdist; sz = B * 4; break;
+        case MON_BUF_E: src = m.B.E; sz = B * m.nd.Epad * 2; break;     case MON_BUF_HID: src = m.B.Hid; sz = B * m.nd.W * m.nd.NH * 2; break;
+        case MON_BUF_O: src = m.B.O; sz = B * 8; break;                 case MON_BUF_DO: src = m.B.dO; sz = B * 8; break;
+        case MON_BUF_DHID: src = m.B.dHid; sz = B * m.nd.W * m.nd.NH * 2; break;
+        case MON_BUF_DE: src = m.B.dE; sz = B * m.nd.Epad * 2; break;
+        case MON_BUF_RGB_RAY: src = m.B.rgb_ray; sz = R * 12; break;    case MON_BUF_DEPTH_RAY: src = m.B.depth_ray; sz = R * 4; break;
+        case MON_BUF_MASK_RAY: src = m.B.mask_ray; sz = R * 4; break;   case MON_BUF_LOSS_RAY: src = m.B.loss_ray; sz = R * 4; break;
+        case MON_BUF_RAY_O: src = m.B.ray_o; sz = R * 12; break;        case MON_BUF_RAY_D: src = m.B.ray_d; sz = R * 12; break;
+        case MON_BUF_RAY_T0: src = m.B.ray_t0; sz = R * 4; break;       case MON_BUF_RAY_T1: src = m.B.ray_t1; sz = R * 4; break;
+        case MON_BUF_TARGET: src = m.B.target; sz = R * 12; break;      case MON_BUF_TARGET_DEPTH: src = m.B.target_depth; sz = R * 4; break;
+        case MON_BUF_BGCOL: src = m.B.bgcol; sz = R * 12; break;        case MON_BUF_RAY_FLAG: src = m.B.ray_flag; sz = R; break;
+        case MON_BUF_RAY_DN: src = m.B.ray_dn; sz = R * 4; break;       case MON_BUF_MASK: src = m.B.mask; sz = (R / 64) * 8; break;
+        case MON_BUF_STATE: src = m.d_state; sz = sizeof(DevState); break;
+        case MON_BUF_FRAG_TRAIN: src = m.d_frag_train; sz = 64 * 512 * 2; break;
+        case MON_BUF_FRAG_REF:
+            if (!m.d_frag_render) { set_error("debug_read: fused backend not available"); return MON_ERR_STATE; }
+            HIPCHECK(use_device(m.device)); HIPCHECK(hipMemsetAsync(m.d_frag_render, 0, 64 * 512 * 2, m.train_stream));
+            launch_build_frag_image(m.train_stream, m.P.half, m.nd, m.d_frag_render); src = m.d_frag_render; sz = 64 * 512 * 2; break;
+        default: set_error("debug_read: unknown buffer id %d", which); return MON_ERR_ARG;
+    }
+    if (!dst || bytes < sz) { set_error("debug_read: buffer too small (%zu < %zu)", bytes, sz); return MON_ERR_ARG; }
+    HIPCHECK(use_device(m.device)); HIPCHECK(hipStreamSynchronize(m.train_stream));
+    HIPCHECK(hipMemcpy(dst, src, sz, hipMemcpyDeviceToHost));
+    if (which == MON_BUF_GGRID_H && m.backend == 1 && m.lds_mask) {        // total gradient = atomic table + sum of the scatter partials
+        std::vector<uint16_t> part(m.n_grid); std::vector<float> acc(m.n_grid);
+        uint16_t* out = reinterpret_cast<uint16_t*>(dst);
+        for (uint32_t i = 0; i < m.n_grid; ++i) { _Float16 h; std::memcpy(&h, &out[i], 2); acc[i] = (float)h; }
+        const uint32_t n_ent = m.n_grid / 2;                                  // partial tables are planar: [partition][feature][entry]
+        for (uint32_t q = 0; q < m.scatter.max_P; ++q) {
+            HIPCHECK(hipMemcpy(part.data(), m.d_gpart + (size_t)q * m.n_grid, (size_t)m.n_grid * 2, hipMemcpyDeviceToHost));
+            for (int l = 0; l < m.nd.L; ++l) {
+                if (q >= m.scatter.P[l]) continue;                              // this level has fewer partial tables: the rest of the buffer is not its data
+                for (uint32_t e = m.lt.offset[l]; e < m.lt.offset[l + 1]; ++e) for (uint32_t f = 0; f < 2; ++f) { _Float16 h; std::memcpy(&h, &part[(size_t)f * n_ent + e], 2); acc[2 * e + f] += (float)h; }
+            }
+        }
+        for (uint32_t i = 0; i < m.n_grid; ++i) { const _Float16 h = (_Float16)acc[i]; std::memcpy(&out[i], &h, 2); }
+    }
+    return MON_OK;
+}
+
+
+}  // namespace mon
+
+using namespace mon;
+#define REQUIRE(p, what) do { if (!(p)) { set_error("%s: null %s", __func__, what); return MON_ERR_ARG; } } while (0)
+
+extern "C" {
+int mon_object_debug_read(mon_object* o, int which, void* dst, size_t bytes) { REQUIRE(o, "object"); return model_debug_read(*o->m, which, dst, bytes); }
+int mon_microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms) { REQUIRE(ms, "ms"); return microbench(device, mode, pattern, n_entries, n_ops, ms); }
+int mon_debug_fast_index(const mon_config* cfg, int level, uint32_t x, uint32_t y, uint32_t z, uint32_t* index, uint32_t* size) {
+    REQUIRE(cfg, "cfg"); REQUIRE(index, "index"); REQUIRE(size, "size");
+    LevelTable lt{}; NetDims nd{}; uint32_t n_grid = 0; int rc = level_table_build(*cfg, lt, nd, n_grid); if (rc) return rc;
+    if (level < 0 || level >= nd.L) { set_error("level out of range"); return MON_ERR_ARG; }
+    LevelFast lf{}; level_fast_build(lt, nd, lf);
+    *index = fast_grid_index(lf, level, x, y, z); *size = lf.size[level]; return MON_OK;
+}
+int mon_debug_frag_layout(int epad, int W, int NH, int L, int* source, int* slots, int* n_image, int* n_mlp) {
+    if (!(epad == 16 || epad == 32) || !(W == 32 || W == 64) || !(NH == 1 || NH == 2) || L < 1 || 2 * L > epad) { set_error("frag_layout: unsupported shape"); return MON_ERR_ARG; }
+    const FragDims d{ epad, W, NH, L };
+    if (n_image) *n_image = d.N_FRAGS() * 512;
+    if (n_mlp) *n_mlp = d.N_MLP();
+    if (source) for (int i = 0; i < d.N_FRAGS() * 512; ++i) source[i] = frag_source(d, i);
+    if (slots) for (int p = 0; p < d.N_MLP(); ++p) { int o[2] = { -1, -1 }; const int n = frag_slots(d, p, o); slots[2 * p] = n > 0 ? o[0] : -1; slots[2 * p + 1] = n > 1 ? o[1] : -1; }
+    return MON_OK;
+}
+int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D) { REQUIRE(A, "A"); REQUIRE(B, "B"); REQUIRE(D, "D"); return selftest_mfma(device, A, B, D); }
+int mon_debug_yaml_number(const char* text, const char* key, double* value) {
+    REQUIRE(text, "text"); REQUIRE(key, "key"); REQUIRE(value, "value");
+    if (!read_yaml_number(text, key, *value)) { set_error("config.yaml: %s missing or not a number", key); return MON_ERR_IO; }
+    return MON_OK;
+}
+}

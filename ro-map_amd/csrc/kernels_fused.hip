@@ -44,36 +44,6 @@ static bool first_use_on_this_device(std::atomic<uint64_t>& seen) {
 
 void set_error(const char* fmt, ...);
 
-// ------------------------------------------------------------------ MFMA fragment-layout self-test
-// D[32x32] = A[32x16] * B[16x32]: A lane l -> row l&31, k = 8*(l>>5)+j ; B lane l -> col l&31, same k ;
-// D lane l, reg r -> col l&31, row (r&3) + 8*(r>>2) + 4*(l>>5).   A, B, D row-major.
-__global__ void __launch_bounds__(64) k_selftest_mfma(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, float* __restrict__ D) {
-    const int l = threadIdx.x, i = l & 31, hk = l >> 5;
-    half8_t a, b;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        a[j] = reinterpret_cast<const half_t*>(A)[i * 16 + 8 * hk + j];
-        b[j] = reinterpret_cast<const half_t*>(B)[(8 * hk + j) * 32 + i];
-    }
-    float16_t c = { 0 };
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * hk) * 32 + i] = c[r];
-}
-
-int selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D) {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || use_device(device) != hipSuccess) { set_error("selftest: no HIP device"); return MON_ERR_NO_DEVICE; }
-    uint16_t *dA = nullptr, *dB = nullptr; float* dD = nullptr;
-    if (hipMalloc((void**)&dA, 32 * 16 * 2) != hipSuccess || hipMalloc((void**)&dB, 16 * 32 * 2) != hipSuccess || hipMalloc((void**)&dD, 32 * 32 * 4) != hipSuccess) { set_error("selftest: hipMalloc failed"); return MON_ERR_HIP; }
-    hipMemcpy(dA, A, 32 * 16 * 2, hipMemcpyHostToDevice); hipMemcpy(dB, B, 16 * 32 * 2, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, 0, dA, dB, dD);
-    const hipError_t e = hipMemcpy(D, dD, 32 * 32 * 4, hipMemcpyDeviceToHost);
-    hipFree(dA); hipFree(dB); hipFree(dD);
-    if (e != hipSuccess) { set_error("selftest: %s", hipGetErrorString(e)); return MON_ERR_HIP; }
-    return MON_OK;
-}
-
 // ------------------------------------------------------------------ shared pieces
 __device__ __forceinline__ int rho(int h, int r) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 // hidden unit carried by K-slot (k-step s, half h, element j) of a W-wide activation in C/D layout
@@ -959,8 +929,7 @@ uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl
     uint32_t mask = 0; sl.n_levels = 0; sl.max_P = 0;
     for (int l = 0; l < kMaxLevels; ++l) { sl.P[l] = 0; sl.level[l] = 0; sl.entry_offset[l] = lt.offset[l]; }
     sl.entry_offset[kMaxLevels] = lt.offset[kMaxLevels];
-    static const int env_on = std::getenv("MON_LDS_SCATTER") ? std::atoi(std::getenv("MON_LDS_SCATTER")) : 1;
-    if (!env_on) return 0u;
+    if (!options().lds_scatter) return 0u;
     // A level of up to 16 tiles fits the 16-workgroup plan, but with more than 4 tiles every workgroup walks all the samples of the batch
     // for its one tile.  When the table has levels that need the large-table path anyway (kernels_bigscatter.hip), levels of 5..16
     // tiles go there too.
@@ -1059,7 +1028,7 @@ bool fused_supported(const NetDims& nd, uint32_t S, uint32_t R) {
 
 uint32_t fused_train_grid(const NetDims&, uint32_t R) {
     const uint32_t want = (R + 3) / 4;            // one ray per wavefront when it fits
-    static const uint32_t cap = std::getenv("MON_FUSED_GRID") ? (uint32_t)std::atoi(std::getenv("MON_FUSED_GRID")) : 512u;
+    const uint32_t cap = options().fused_grid > 0 ? (uint32_t)options().fused_grid : 512u;
     return want < cap ? want : cap;
 }
 
@@ -1111,7 +1080,7 @@ static void candidates_frags_t(hipStream_t s, const BatchPtrs& b, const DatasetP
 
 void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
                         uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched) {
-    static const uint32_t ablate = std::getenv("MON_FUSED_ABLATE") ? (uint32_t)std::atoi(std::getenv("MON_FUSED_ABLATE")) : 0u;
+    const uint32_t ablate = (uint32_t)options().fused_ablate;
     FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate, touched ? touched + (nd.n_mlp >> 3) : nullptr, big_switch };
     const uint32_t grid = fused_train_grid(nd, oc.R);
     MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);

@@ -323,7 +323,7 @@ void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, u
 
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx) {
     const uint32_t chunks = oc.n_params >> 3;
-    static const uint32_t env_cap = std::getenv("MON_OPT_BLOCKS") ? (uint32_t)std::atoi(std::getenv("MON_OPT_BLOCKS")) : 0u;
+    const uint32_t env_cap = (uint32_t)options().opt_blocks;
     // measured: base.json (239 k chunks) 256 / 512 / 1024 blocks = 28.1 / 23.7 / 26.2 us; T = 2^22 (13.2 M chunks) 512 / 2048 / 8192 / 32768 blocks = 368 / 244 / 251 / 406 us
     uint32_t cap = chunks / (256u * 8u); if (cap < 512u) cap = 512u; if (cap > 2048u) cap = 2048u; if (env_cap) cap = env_cap;
     uint32_t blocks = (chunks + 255) / 256; if (blocks > cap) blocks = cap; if (blocks < 1u) blocks = 1u;     // ~2 chunks per thread at base.json size: measured best (256: 28.1, 512: 23.7, 1024: 26.2 us)

@@ -38,6 +38,7 @@ int model_save_mesh(Model& m, const char* path);
 int model_mesh_counts(Model& m, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices);
 int model_train(Model& m, int iters, float* loss, int stages);
 int stream_pool_reserve(int device, int n);
+int dataset_update_poses(Dataset* d, uint32_t first, uint32_t n, const float* Twc16s);
 int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, int dst_on_device);
 int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, uint32_t* snapshot_step);
 
@@ -76,7 +77,7 @@ struct OfflineManager {
 
 // cv::FileStorage looks keys up exactly (nerf_data.cu:39-46): the key must start a line (after blanks), be followed by blanks and
 // ':', and carry a number; comment lines and longer keys with the same prefix (Camera.Height vs Camera.H) do not match.
-static bool read_yaml_number(const std::string& text, const char* key, double& v) {
+bool read_yaml_number(const std::string& text, const char* key, double& v) {
     const size_t klen = std::strlen(key); size_t ls = 0;
     while (ls < text.size()) {
         size_t le = text.find('\n', ls); if (le == std::string::npos) le = text.size();
@@ -98,8 +99,7 @@ int offline_init(OfflineManager& m) {                                   // nerf_
     int rc = device_count(&m.n_dev); if (rc) return rc;
     rc = config_from_json(m.cfg_path.c_str(), m.cfg); if (rc) return rc;
     m.cfg.use_depth = m.use_depth ? 1 : 0;
-    if (const char* e = std::getenv("MON_OFFLINE_OUTER")) m.outer_iters = std::atoi(e);
-    if (const char* e = std::getenv("MON_OFFLINE_INNER")) m.inner_iters = std::atoi(e);
+    m.outer_iters = (int)options().offline_outer; m.inner_iters = (int)options().offline_inner;       // (10 x 500 unless a test shortened the job: mon_set_option)
     return MON_OK;
 }
 
@@ -477,6 +477,27 @@ int mon_online_new_frame(mon_online* h, uint32_t img_id, const char* timestamp, 
         if (rc) return rc;
     }
     return MON_OK;
+}
+int mon_online_update_dataset(mon_online* h, uint32_t cur_id, uint32_t frame_num, const float* Twc16s) {   // :220-235
+    REQ(h); REQ(Twc16s); OnlineManager& m = *h->m;
+    if (frame_num == 0) return MON_OK;
+    if (frame_num > cur_id) { set_error("UpdateDataset: %u frames before frame %u", frame_num, cur_id); return MON_ERR_ARG; }
+    const uint32_t head = cur_id - frame_num;
+    for (int g = 0; g < m.n_dev; ++g) {
+        // every object's dataset mutex on the device (nerf_data.cu:345-347), announced so a training slice lets the update in; the candidate rays
+        // an object prepared for its next iteration used the old poses: they are regenerated
+        std::vector<std::unique_ptr<AnnouncedLock>> held, models;
+        for (auto* o : m.objs) if (o->device == g) held.emplace_back(new AnnouncedLock(o, *o->dataset_mutex));
+        const int rc = dataset_update_poses(m.ds[g], head, frame_num, Twc16s); if (rc) return rc;
+        for (auto* o : m.objs) if (o->device == g && o->model) { AnnouncedLock lm(o, o->mu_model); o->model->next_ready = false; }
+    }
+    for (uint32_t i = 0; i < frame_num; ++i) m.poses[head + i].assign(Twc16s + 16 * (size_t)i, Twc16s + 16 * (size_t)i + 16);
+    return MON_OK;
+}
+int mon_online_get_pose(mon_online* h, uint32_t frame_id, float* Twc16) {
+    REQ(h); REQ(Twc16); auto it = h->m->poses.find(frame_id);
+    if (it == h->m->poses.end()) { set_error("get_pose: frame %u has not been added", frame_id); return MON_ERR_ARG; }
+    std::memcpy(Twc16, it->second.data(), 64); return MON_OK;
 }
 int mon_online_create_nerf(mon_online* h, int cls, const float* Tow16, const float* aabb_min3, const float* aabb_max3, size_t* idx_out) {   // :237-261 + SetAttributes nerf.cu:155-185
     REQ(h); REQ(Tow16); REQ(aabb_min3); REQ(aabb_max3); REQ(idx_out); OnlineManager& m = *h->m;

@@ -30,6 +30,20 @@ const char* last_error() { return g_err.c_str(); }
     do { hipError_t _e = (expr); if (_e != hipSuccess) {                                                       \
         set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return MON_ERR_HIP; } } while (0)
 
+static Options g_options;
+Options& options() { return g_options; }
+static long* option_slot(const char* name) {
+    static const struct { const char* n; long Options::*f; } tab[] = {
+        { "backend", &Options::backend }, { "use_graph", &Options::use_graph }, { "lazy_ema", &Options::lazy_ema }, { "big_switch", &Options::big_switch },
+        { "touched_flags", &Options::touched_flags }, { "lds_scatter", &Options::lds_scatter }, { "fold_reduce", &Options::fold_reduce }, { "fold_next", &Options::fold_next },
+        { "fused_grid", &Options::fused_grid }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate },
+        { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner } };
+    for (const auto& e : tab) if (name && std::strcmp(name, e.n) == 0) return &(g_options.*(e.f));
+    return nullptr;
+}
+int option_set(const char* name, long value) { long* p = option_slot(name); if (!p) { set_error("set_option: unknown option '%s'", name ? name : "(null)"); return MON_ERR_ARG; } *p = value; return MON_OK; }
+int option_get(const char* name, long* value) { long* p = option_slot(name); if (!p || !value) { set_error("get_option: unknown option '%s'", name ? name : "(null)"); return MON_ERR_ARG; } *value = *p; return MON_OK; }
+
 void config_default(mon_config& c);
 int config_from_json(const char* path, mon_config& c);
 
@@ -88,6 +102,13 @@ int dataset_add_frame(Dataset* d, uint32_t id, const uint8_t* rgb, int ch, int i
     HIPCHECK(hipMemcpy(d->d_poses + 16 * (size_t)id, Twc, 64, hipMemcpyHostToDevice));
     if (id + 1 > d->n_frames) d->n_frames = id + 1;                 // mFrameDataNum, nerf_data.cu:338
     d->present[id] = 1;
+    return MON_OK;
+}
+// UpdateDataGPU (nerf_data.cu:341-353): overwrite the poses of n consecutive frames
+int dataset_update_poses(Dataset* d, uint32_t first, uint32_t n, const float* Twc16s) {
+    if (!d || !Twc16s || first + n > d->max_frames) { set_error("update_poses: frames %u..%u outside the dataset (%u frames)", first, first + n, d ? d->max_frames : 0u); return MON_ERR_ARG; }
+    HIPCHECK(use_device(d->device));
+    HIPCHECK(hipMemcpy(d->d_poses + 16 * (size_t)first, Twc16s, 64 * (size_t)n, hipMemcpyHostToDevice));
     return MON_OK;
 }
 int dataset_destroy(Dataset* d) {
@@ -197,7 +218,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     m.out_cap = kRenderChunkRays;
     // lazy EMA: only where the optimizer is not the dense variant anyway and the table is large (> 8 M parameters); MON_LAZY_EMA=0/1 overrides
     m.lazy_ema = m.n_grid > (8u << 20);
-    if (const char* e = std::getenv("MON_LAZY_EMA")) m.lazy_ema = std::atoi(e) != 0;
+    if (options().lazy_ema >= 0) m.lazy_ema = options().lazy_ema != 0;
     if (fused_supported(m.nd, S, m.oc.R)) {
         if ((rc = dev_alloc(m, m.d_frag_train, 64 * 512)) || (rc = dev_alloc(m, m.d_frag_render, 64 * 512))) return rc;       // <= 30 fragments of 512 halves
         m.lds_mask = scatter_plan(m.lt, m.nd, m.scatter);
@@ -206,10 +227,10 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         // Levels beyond the LDS plan (more than 2^18 entries): binned exact scatter while many samples carry a gradient (kernels_bigscatter.hip).
         // MON_BIG_SWITCH = gradient-carrying samples below which the global-atomic path takes over (0: atomics always).
         const size_t big_bytes = m.lds_mask ? big_scatter_workspace_bytes(m.lt, m.nd, m.lds_mask, Btrain) : 0;
-        const uint32_t big_switch = std::getenv("MON_BIG_SWITCH") ? (uint32_t)std::atoll(std::getenv("MON_BIG_SWITCH")) : 16384u;
+        const uint32_t big_switch = (uint32_t)options().big_switch;
         if (big_bytes && big_switch) { if ((rc = dev_alloc(m, m.d_big_ws, big_bytes))) return rc; m.big_switch = big_switch; }
         // chunk flags for the lazy optimizer (tables above 8 M parameters with levels outside the LDS plan); MON_TOUCHED_FLAGS=0: scan the gradient table
-        const bool flags_on = !(std::getenv("MON_TOUCHED_FLAGS") && std::atoi(std::getenv("MON_TOUCHED_FLAGS")) == 0);
+        const bool flags_on = options().touched_flags != 0;
         if (flags_on && m.lazy_ema && m.lds_mask && m.lds_mask != ((m.nd.L >= 32) ? 0xffffffffu : ((1u << m.nd.L) - 1u)) && (rc = dev_alloc(m, m.d_touched, (m.n_params >> 3) + 16))) return rc;
     }
     m.boxes_cap = 1024;
@@ -220,7 +241,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     HIPCHECK(hipMemcpy(m.d_state, &m.h_state, sizeof(DevState), hipMemcpyHostToDevice));
     HIPCHECK(hipHostMalloc((void**)&m.h_state_pinned, sizeof(DevState), hipHostMallocDefault));
     m.backend = fused_supported(m.nd, S, m.oc.R) ? 1 : 0;
-    if (const char* e = std::getenv("MON_BACKEND")) m.backend = std::atoi(e) ? (fused_supported(m.nd, S, m.oc.R) ? 1 : 0) : 0;
+    if (options().backend >= 0) m.backend = options().backend ? (fused_supported(m.nd, S, m.oc.R) ? 1 : 0) : 0;
     m.mesh = mesh_state_create(m.device);
     if (m.backend == 1 && !m.lazy_ema) {          // (tables above 8 M parameters keep their EMA lazily and would cost 2 x 200 MB of snapshots: they render on the train stream)
         InferState* is = new InferState(); m.infer = is;
@@ -359,7 +380,7 @@ static void enqueue_iteration(Model& m, int stages) {
         }
     }
     if ((stages & 2) && m.backend == 1) {
-        static const bool fold_reduce = !(std::getenv("MON_FOLD_REDUCE") && std::atoi(std::getenv("MON_FOLD_REDUCE")) == 0);
+        const bool fold_reduce = options().fold_reduce != 0;
         const bool folded = m.lds_mask && fold_reduce && grid_scatter_sums_partials(m.lt, m.nd);   // the scatter workgroups also sum the dW partial rows
         if (m.lds_mask) { ProfScope ps(m, MON_K_SCATTER); launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.d_gpart, m.n_grid / 2, m.d_state,
                                                                                 folded ? m.d_dw_partials : nullptr, fused_train_grid(m.nd, m.oc.R), m.P.gmlp); }
@@ -377,7 +398,7 @@ static void enqueue_iteration(Model& m, int stages) {
             P.first_flag_chunk = (m.nd.n_mlp + 2u * m.lt.offset[first_big]) >> 3;
         }
         OptimNext nx{};
-        static const bool fold = !(std::getenv("MON_FOLD_NEXT") && std::atoi(std::getenv("MON_FOLD_NEXT")) == 0);
+        const bool fold = options().fold_next != 0;
         if (m.backend == 1 && fold) {
             nx.cand_blocks = (m.oc.R + 255) / 256; nx.frag_image = m.d_frag_train; nx.fd = FragDims{ m.nd.Epad, m.nd.W, m.nd.NH, m.nd.L };
             nx.b = m.B; nx.ds = m.ds->ptrs(); nx.oc = m.oc;
@@ -404,7 +425,7 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     // Large-table scatter: the device picks binned / atomic per iteration from the previous iteration's gradient-carrying sample count;
     // once the host has seen that count well below the switch point it stops launching the (then empty) binning kernels at all.
     m.big_active = m.big_switch && (m.h_state.n_scatter_last == 0u || m.h_state.n_scatter_last > m.big_switch / 2u);
-    static const bool use_graph_env = std::getenv("MON_USE_GRAPH") && std::atoi(std::getenv("MON_USE_GRAPH")) != 0;
+    const bool use_graph_env = options().use_graph != 0;
     const bool use_graph = use_graph_env && !m.profiling && stages == 7 && iters >= 2;
     if (use_graph) {
         const int graph_key = m.backend | (m.big_active ? 256 : 0);
@@ -552,55 +573,6 @@ int model_set_params(Model& m, const float* master, size_t n) {
     HIPCHECK(hipStreamSynchronize(m.train_stream));
     m.next_ready = false;                                   // the fragment image no longer matches the weights
     return publish_snapshot(m);                             // (viewers of an untrained object see the weights just set)
-}
-
-int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
-    if (which == MON_BUF_EMA) { int rc = ensure_ema_current(m); if (rc) return rc; }
-    const size_t R = m.oc.R, B = R * m.oc.S, n = m.n_params; const void* src = nullptr; size_t sz = 0;
-    switch (which) {
-        case MON_BUF_MASTER: src = m.P.master; sz = n * 4; break;       case MON_BUF_HALF: src = m.P.half; sz = n * 2; break;
-        case MON_BUF_EMA: src = m.P.ema; sz = n * 2; break;             case MON_BUF_M1: src = m.P.m1; sz = n * 4; break;
-        case MON_BUF_M2: src = m.P.m2; sz = n * 4; break;               case MON_BUF_STEPS: src = m.P.steps; sz = n * 4; break;
-        case MON_BUF_GMLP: src = m.P.gmlp; sz = (size_t)m.nd.n_mlp * 4; break;
-        case MON_BUF_GGRID_H: src = m.P.ggrid; sz = (size_t)m.n_grid * 2; break;
-        case MON_BUF_PTS: src = m.B.pts; sz = B * 12; break;            case MON_BUF_TDIST: src = m.B.tdist; sz = B * 4; break;
-        case MON_BUF_E: src = m.B.E; sz = B * m.nd.Epad * 2; break;     case MON_BUF_HID: src = m.B.Hid; sz = B * m.nd.W * m.nd.NH * 2; break;
-        case MON_BUF_O: src = m.B.O; sz = B * 8; break;                 case MON_BUF_DO: src = m.B.dO; sz = B * 8; break;
-        case MON_BUF_DHID: src = m.B.dHid; sz = B * m.nd.W * m.nd.NH * 2; break;
-        case MON_BUF_DE: src = m.B.dE; sz = B * m.nd.Epad * 2; break;
-        case MON_BUF_RGB_RAY: src = m.B.rgb_ray; sz = R * 12; break;    case MON_BUF_DEPTH_RAY: src = m.B.depth_ray; sz = R * 4; break;
-        case MON_BUF_MASK_RAY: src = m.B.mask_ray; sz = R * 4; break;   case MON_BUF_LOSS_RAY: src = m.B.loss_ray; sz = R * 4; break;
-        case MON_BUF_RAY_O: src = m.B.ray_o; sz = R * 12; break;        case MON_BUF_RAY_D: src = m.B.ray_d; sz = R * 12; break;
-        case MON_BUF_RAY_T0: src = m.B.ray_t0; sz = R * 4; break;       case MON_BUF_RAY_T1: src = m.B.ray_t1; sz = R * 4; break;
-        case MON_BUF_TARGET: src = m.B.target; sz = R * 12; break;      case MON_BUF_TARGET_DEPTH: src = m.B.target_depth; sz = R * 4; break;
-        case MON_BUF_BGCOL: src = m.B.bgcol; sz = R * 12; break;        case MON_BUF_RAY_FLAG: src = m.B.ray_flag; sz = R; break;
-        case MON_BUF_RAY_DN: src = m.B.ray_dn; sz = R * 4; break;       case MON_BUF_MASK: src = m.B.mask; sz = (R / 64) * 8; break;
-        case MON_BUF_STATE: src = m.d_state; sz = sizeof(DevState); break;
-        case MON_BUF_FRAG_TRAIN: src = m.d_frag_train; sz = 64 * 512 * 2; break;
-        case MON_BUF_FRAG_REF:
-            if (!m.d_frag_render) { set_error("debug_read: fused backend not available"); return MON_ERR_STATE; }
-            HIPCHECK(use_device(m.device)); HIPCHECK(hipMemsetAsync(m.d_frag_render, 0, 64 * 512 * 2, m.train_stream));
-            launch_build_frag_image(m.train_stream, m.P.half, m.nd, m.d_frag_render); src = m.d_frag_render; sz = 64 * 512 * 2; break;
-        default: set_error("debug_read: unknown buffer id %d", which); return MON_ERR_ARG;
-    }
-    if (!dst || bytes < sz) { set_error("debug_read: buffer too small (%zu < %zu)", bytes, sz); return MON_ERR_ARG; }
-    HIPCHECK(use_device(m.device)); HIPCHECK(hipStreamSynchronize(m.train_stream));
-    HIPCHECK(hipMemcpy(dst, src, sz, hipMemcpyDeviceToHost));
-    if (which == MON_BUF_GGRID_H && m.backend == 1 && m.lds_mask) {        // total gradient = atomic table + sum of the scatter partials
-        std::vector<uint16_t> part(m.n_grid); std::vector<float> acc(m.n_grid);
-        uint16_t* out = reinterpret_cast<uint16_t*>(dst);
-        for (uint32_t i = 0; i < m.n_grid; ++i) { _Float16 h; std::memcpy(&h, &out[i], 2); acc[i] = (float)h; }
-        const uint32_t n_ent = m.n_grid / 2;                                  // partial tables are planar: [partition][feature][entry]
-        for (uint32_t q = 0; q < m.scatter.max_P; ++q) {
-            HIPCHECK(hipMemcpy(part.data(), m.d_gpart + (size_t)q * m.n_grid, (size_t)m.n_grid * 2, hipMemcpyDeviceToHost));
-            for (int l = 0; l < m.nd.L; ++l) {
-                if (q >= m.scatter.P[l]) continue;                              // this level has fewer partial tables: the rest of the buffer is not its data
-                for (uint32_t e = m.lt.offset[l]; e < m.lt.offset[l + 1]; ++e) for (uint32_t f = 0; f < 2; ++f) { _Float16 h; std::memcpy(&h, &part[(size_t)f * n_ent + e], 2); acc[2 * e + f] += (float)h; }
-            }
-        }
-        for (uint32_t i = 0; i < m.n_grid; ++i) { const _Float16 h = (_Float16)acc[i]; std::memcpy(&out[i], &h, 2); }
-    }
-    return MON_OK;
 }
 
 }  // namespace mon

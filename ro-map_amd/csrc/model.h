@@ -92,6 +92,15 @@ enum {
     MON_BUF_FRAG_REF = 35       // the same image rebuilt from the current fp16 weights by k_build_frag_image (layout test)
 };
 
+// Process-wide test and tuning switches (mon_set_option, include/mon_core.h); defaults are the product behaviour.
+struct Options {
+    long backend = -1, use_graph = 0, lazy_ema = -1, big_switch = 16384, touched_flags = 1, lds_scatter = 1, fold_reduce = 1, fold_next = 1,
+         fused_grid = 0, opt_blocks = 0, fused_ablate = 0, offline_outer = 10, offline_inner = 500;
+};
+Options& options();
+int option_set(const char* name, long value);
+int option_get(const char* name, long* value);
+
 hipError_t use_device(int logical_device);      // hipSetDevice through the logical-device map (model.cpp)
 int set_logical_devices(int n);
 

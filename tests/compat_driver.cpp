@@ -6,6 +6,7 @@
 #include <unistd.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -99,6 +100,11 @@ static int run_online(const std::string& seq, const std::string& cfg, const std:
         ::usleep(15000);
     }
     const int draws_during = g_draws;
+    // members no consumer calls today but the interface has (nerf_manager.h:66, nerf.h:41,47,59,64): pose refresh of the last three frames, per-object views
+    { std::vector<Eigen::Matrix4f> last3(twc.end() - 3, twc.end()); mgr->UpdateDataset((unsigned)twc.size(), 3, last3); }
+    const std::vector<Eigen::Matrix4f> obj_twc = mgr->mvpNeRFs[idx]->GetTwc();
+    std::printf("online_members n_obj_twc=%zu mnBbox=%zu instance=%d twc_last_tx=%.6f\n", obj_twc.size(), mgr->mvpNeRFs[idx]->mnBbox, (int)mgr->mvpNeRFs[idx]->mInstanceId, obj_twc.empty() ? 0.f : obj_twc.back()(0, 3));
+    mgr->mvpNeRFs[idx]->DrawMesh();
     mgr->WaitThreadsEnd();                                                                             // System.cc:567
     g_last_count = 0; mgr->DrawMesh(idx);
     std::vector<std::string> ts = { std::to_string(std::strtod(box_stamps[2].c_str(), nullptr)), std::to_string(std::strtod(box_stamps[5].c_str(), nullptr)) };
@@ -111,7 +117,15 @@ static int run_online(const std::string& seq, const std::string& cfg, const std:
     return 0;
 }
 
+// harness convenience shared with the Python binding: MON_OPTIONS="name=value,..." -> mon_set_option
+static void apply_options_from_env() {
+    const char* e = std::getenv("MON_OPTIONS"); if (!e) return;
+    std::stringstream ss(e); std::string kv;
+    while (std::getline(ss, kv, ',')) { const size_t q = kv.find('='); if (q != std::string::npos && mon_set_option(kv.substr(0, q).c_str(), std::atol(kv.c_str() + q + 1))) { std::cerr << mon_last_error() << std::endl; exit(6); } }
+}
+
 int main(int argc, char** argv) {
+    apply_options_from_env();
     if (argc != 5) { std::fprintf(stderr, "usage: %s offline|online <sequence dir> <network json> <out dir>\n", argv[0]); return 1; }
     const std::string mode = argv[1];
     return mode == "offline" ? run_offline(argv[2], argv[3], argv[4]) : run_online(argv[2], argv[3], argv[4]);

@@ -10,8 +10,8 @@ import pytest
 from conftest import ROOT
 
 
-def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "mon_core.h")).read()
+def header_symbols(name="mon_core.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(mon_[a-z_0-9]+)\s*\(", txt)))
 
@@ -154,3 +154,31 @@ def test_fragment_layout_maps_are_inverse(pkg, shape):
         real[W * epad: W * epad + W * W] = True
     off_wo = W * epad + (NH - 1) * W * W; real[off_wo: off_wo + 4 * W] = True
     assert ((slots[:, 0] >= 0) == real).all() and ((slots[:, 1] >= 0) == real).all()
+
+
+def test_diagnostics_live_in_their_own_library(pkg):
+    """libmon_core.so is the product only: the micro-benchmarks, the MFMA self-test, the debug read-back and the layout hooks are exported by
+    libmon_core_diag.so (include/mon_core_diag.h), which links against the product library -- never the other way round."""
+    import subprocess
+    diag = header_symbols("mon_core_diag.h")
+    assert len(diag) >= 6 and sorted(pkg.diag_symbols()) == diag and not set(diag) & set(header_symbols())
+    assert os.path.exists(pkg.diag_lib_path()), "run __graft_entry__.build() first"
+    core = ctypes.CDLL(pkg.lib_path()); dl = pkg.diag_lib()
+    for s in diag:
+        assert hasattr(dl, s), "libmon_core_diag.so does not export " + s
+        assert not hasattr(core, s), "diagnostic symbol %s is still exported by the product library" % s
+    defined = subprocess.run(["nm", "-D", "--defined-only", pkg.lib_path()], capture_output=True, text=True).stdout
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", pkg.lib_path()], capture_output=True, text=True).stdout
+    assert "microbench" not in defined and "selftest" not in defined and "getenv" not in undefined      # no environment knobs on the product path
+    assert pkg.yaml_number("%YAML:1.0\n# Camera.fx: 1.0\nCamera.Height_mm: 9999\n  Camera.H : 480\nCamera.fx: 525.5\n", "Camera.H") == 480.0
+    assert pkg.yaml_number("# Camera.fx: 1.0\nCamera.fx: 525.5\n", "Camera.fx") == 525.5
+    with pytest.raises(pkg.MonError):
+        pkg.yaml_number("Camera.Height: 3\nCamera.fx:\n", "Camera.H")
+
+
+def test_options_are_an_explicit_interface(pkg):
+    """Test and tuning switches go through mon_set_option / mon_get_option; the product library reads no environment variables."""
+    assert pkg.get_option("big_switch") == 16384 and pkg.get_option("backend") == -1 and pkg.get_option("offline_inner") == 500
+    pkg.set_option("fused_ablate", 16); assert pkg.get_option("fused_ablate") == 16; pkg.set_option("fused_ablate", 0)
+    with pytest.raises(pkg.MonError):
+        pkg.set_option("no_such_switch", 1)

@@ -158,7 +158,7 @@ def test_object_placement_over_logical_devices(pkg, ss, tmp_path):
     assert pkg.device_count() >= 1
     sc = ss.make_scene(n_views=10, H=120, W=160, f=130.0, n_objects=3, seed=4)
     seq = str(tmp_path / "seq"); ss.write_sequence(sc, seq)
-    os.environ["MON_OFFLINE_OUTER"] = "2"; os.environ["MON_OFFLINE_INNER"] = "60"
+    pkg.set_option("offline_outer", 2); pkg.set_option("offline_inner", 60)
     pkg.set_logical_devices(2)
     try:
         assert pkg.device_count() == 2
@@ -175,5 +175,5 @@ def test_object_placement_over_logical_devices(pkg, ss, tmp_path):
             assert os.path.exists(os.path.join(str(tmp_path / "out"), "%d.ply" % k))
         m.close()
     finally:
-        pkg.set_logical_devices(0); os.environ.pop("MON_OFFLINE_OUTER", None); os.environ.pop("MON_OFFLINE_INNER", None)
+        pkg.set_logical_devices(0); pkg.set_option("offline_outer", 10); pkg.set_option("offline_inner", 500)
     assert pkg.device_count() >= 1

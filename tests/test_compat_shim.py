@@ -42,7 +42,7 @@ def test_shim_runs_the_offline_and_online_call_sequences(pkg, ss, tmp_path):
     sc = ss.make_scene(n_views=24, H=120, W=160, f=130.0, n_objects=2, seed=9)
     seq = str(tmp_path / "seq"); ss.write_sequence(sc, seq)
     cfg = os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json")
-    env = dict(os.environ, MON_OFFLINE_OUTER="4", MON_OFFLINE_INNER="150")
+    env = dict(os.environ, MON_OPTIONS="offline_outer=4,offline_inner=150")
     out = str(tmp_path / "out_offline")
     r = subprocess.run([exe, "offline", seq, cfg, out], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -64,6 +64,9 @@ def test_shim_runs_the_offline_and_online_call_sequences(pkg, ss, tmp_path):
     o = _kv(r.stdout, "online idx=")
     assert int(o["idx"]) == 0 and int(o["unknown_frame"]) == -1 and int(o["frame5"]) == 5 and int(o["n_boxes"]) == len(sc.objects[0]["boxes"])
     assert int(o["mesh_indices"]) > 300 and int(o["gl_state_balance"]) == 0
+    mem = _kv(r.stdout, "online_members ")          # UpdateDataset / NeRF::GetTwc / mnBbox / mInstanceId / DrawMesh (interface members without a consumer today)
+    nb = len(sc.objects[0]["boxes"]); last = int(sc.objects[0]["boxes"][-1][0])
+    assert int(mem["n_obj_twc"]) == nb and int(mem["mnBbox"]) == nb and int(mem["instance"]) == sc.objects[0]["cls"] and abs(float(mem["twc_last_tx"]) - sc.Twc[last][0, 3]) < 1e-4
     root = os.path.join(out2, "0")
     assert len(open(os.path.join(root, "test.txt")).read().strip().split("\n")) == 3
     assert os.path.exists(os.path.join(root, "test_img", o["stamp0"] + ".png")) and os.path.exists(os.path.join(root, "video_img", "59.png"))

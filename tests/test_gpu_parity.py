@@ -439,7 +439,7 @@ def test_optimizer_prepares_the_next_iteration(pkg, orc, small_scene, kw):
 
 def test_zero_gradient_skipping_is_exact_and_deterministic():
     """k_fused_train drops rays / samples whose fp16 dL/dO is all zeros before the backward MFMAs and the grid scatter.  The trained
-    parameters must be bit-identical to a run that keeps every sample (MON_FUSED_ABLATE=16) and identical from run to run."""
+    parameters must be bit-identical to a run that keeps every sample (option fused_ablate = 16) and identical from run to run."""
     import subprocess, sys
     from conftest import ROOT
     def run(extra):
@@ -448,9 +448,9 @@ def test_zero_gradient_skipping_is_exact_and_deterministic():
         assert r.returncode == 0, r.stdout + r.stderr
         rows = [ln.split() for ln in r.stdout.strip().split("\n") if ln.startswith("steps+")]
         return [w[2] for w in rows], [int(w[4]) for w in rows]
-    crc_a, n_a = run({}); crc_b, n_b = run({}); crc_c, n_c = run({"MON_FUSED_ABLATE": "16"})
+    crc_a, n_a = run({}); crc_b, n_b = run({}); crc_c, n_c = run({"MON_OPTIONS": "fused_ablate=16"})
     assert crc_a == crc_b == crc_c, (crc_a, crc_b, crc_c)
-    crc_g, _ = run({"MON_USE_GRAPH": "1"})                              # hipGraph replay of the same launches
+    crc_g, _ = run({"MON_OPTIONS": "use_graph=1"})                              # hipGraph replay of the same launches
     assert crc_g == crc_a, (crc_g, crc_a)
     assert n_c[-1] == 4096 * 32 and n_a[-1] < n_c[-1] // 2, (n_a, n_b, n_c)            # the skipping really happened in the default run
 
@@ -478,7 +478,7 @@ def test_large_tables_mix_lds_and_atomic_levels(pkg, orc, small_scene, kw):
 def test_binned_large_level_scatter_is_exact_and_deterministic(pkg, orc, small_scene):
     """Levels beyond 2^18 entries while many samples carry a gradient (kernels_bigscatter.hip): contributions are counting-sorted by
     16 384-entry tile and summed exactly in LDS, so the fp16 gradient is the fp32 sum of tcnn's fp16 contributions rounded ONCE --
-    tighter than arrival-order atomics -- and a run that never leaves the binned path (MON_BIG_SWITCH=1) is bit-reproducible."""
+    tighter than arrival-order atomics -- and a run that never leaves the binned path (option big_switch = 1) is bit-reproducible."""
     import subprocess, sys
     from conftest import ROOT
     kw = dict(rays_per_batch=256, log2_hashmap_size=19, n_neurons=64, n_hidden_layers=1)
@@ -499,22 +499,25 @@ def test_binned_large_level_scatter_is_exact_and_deterministic(pkg, orc, small_s
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "param_crc.py"), "2", "20"], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         return [ln.split()[2] for ln in r.stdout.strip().split("\n") if ln.startswith("steps+")]
-    a = run({"MON_BIG_SWITCH": "1"}); b = run({"MON_BIG_SWITCH": "1"})
+    a = run({"MON_OPTIONS": "big_switch=1"}); b = run({"MON_OPTIONS": "big_switch=1"})
     assert a == b and len(a) == 2, (a, b)
     # the lazy optimizer finds the touched chunks through the byte flags written next to the gradient table; scanning the table itself
-    # (MON_TOUCHED_FLAGS=0) must train the same parameters bit for bit
-    c = run({"MON_BIG_SWITCH": "1", "MON_TOUCHED_FLAGS": "0"})
+    # (option touched_flags = 0) must train the same parameters bit for bit
+    c = run({"MON_OPTIONS": "big_switch=1,touched_flags=0"})
     assert a == c, (a, c)
 
 
 def test_atomic_path_marks_every_touched_chunk(pkg, small_scene, monkeypatch):
-    """tcnn-style global atomics on the large levels (MON_BIG_SWITCH=0 forces them from the first step): every addition into the
+    """tcnn-style global atomics on the large levels (option big_switch = 0 forces them from the first step): every addition into the
     gradient table also sets its chunk's byte flag, so the lazy optimizer -- which only visits flagged chunks -- must leave the table
     all zero after each step, and must have stepped some of those entries."""
     _need_gpu(pkg)
-    monkeypatch.setenv("MON_BIG_SWITCH", "0")
     kw = dict(rays_per_batch=256, log2_hashmap_size=19, n_neurons=64, n_hidden_layers=1)
-    ds, obj = ge.make_problem(pkg, small_scene, kw); obj.set_backend(1)
+    old = pkg.get_option("big_switch"); pkg.set_option("big_switch", 0)
+    try:
+        ds, obj = ge.make_problem(pkg, small_scene, kw); obj.set_backend(1)
+    finally:
+        pkg.set_option("big_switch", old)                       # (read when the object is created)
     obj.train(6)
     gg = obj.buffer("ggrid_h"); st = obj.buffer("steps")
     assert not gg[gg.size // 2:].any(), "a gradient survived the optimizer: its chunk was not flagged"

@@ -18,13 +18,9 @@ PH = ["prologue (frag image, compaction table)", "ray select + position", "encod
 
 
 def main():
-    src = os.path.join(ROOT, "ro-map_amd"); out = os.path.join(src, "build_timing"); os.makedirs(out, exist_ok=True)
-    flags = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -ffp-contract=off -fno-math-errno -DMON_FUSED_TIMING -w".split()
-    srcs = "config.cpp model.cpp c_api.cpp manager.cpp png_io.cpp mesh.cpp kernels_batch.hip kernels_net.hip kernels_composite.hip kernels_optim.hip kernels_fused.hip kernels_bigscatter.hip kernels_mesh.hip microbench.hip".split()
+    out = os.path.join(ROOT, "ro-map_amd", "build_timing")
     if not os.path.exists(os.path.join(out, "libmon_core.so")) or os.environ.get("MON_TIMING_REBUILD"):
-      procs = [subprocess.Popen(["/opt/rocm/bin/hipcc"] + flags + ["-I" + os.path.join(ROOT, "include"), "-c", os.path.join(src, "csrc", f), "-o", os.path.join(out, f.rsplit(".", 1)[0] + ".o")]) for f in srcs]
-      assert all(p.wait() == 0 for p in procs)
-      subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(out, "libmon_core.so")] + [os.path.join(out, f.rsplit(".", 1)[0] + ".o") for f in srcs] + ["-lz", "-lpthread"])
+        subprocess.check_call([os.path.join(ROOT, "tools", "variant_build.sh"), "timing", "-DMON_FUSED_TIMING"])
     lib = os.path.join(out, "libmon_core.so")
     if os.environ.get("MON_TIMING_BUILD_ONLY"):
         return
