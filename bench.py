@@ -223,6 +223,19 @@ def main():
             tl = sharding.max_over_ranks(dist, torch, tl, coll_dev)
         late = {"after_steps": done + extra, "ms_per_step": round(1e3 * tl / args.steps, 4), "value": round(world * args.steps * B / tl, 1), "unit": "ray-samples/s"}
 
+    # ---- extra, not the headline: the late-training window with occupancy-grid skipping switched on (mon_config::occupancy_skip -- named by
+    #      BASELINE.json's north star, absent from the reference, hence opt-in: samples in cells a 64^3 density grid marks empty are not evaluated)
+    occ = None
+    if fused and rank == 0 and world == 1:
+        try:
+            oo = new_object(dict(occupancy_skip=1)); oo.train(800); sync()
+            to0 = time.perf_counter(); oo.train(args.steps); sync(); to = time.perf_counter() - to0
+            occ = {"after_steps": 800, "ms_per_step": round(1e3 * to / args.steps, 4), "value": round(args.steps * B / to, 1), "unit": "ray-samples/s (nominal: skipped samples count)",
+                   "note": "opt-in approximation (default off; parity and the headline run without it)"}
+            oo.close()
+        except Exception as e:
+            occ = {"value": None, "note": "failed: %s" % e}
+
     # ---- quality: PSNR of a rendered crop vs the synthetic ground truth; N > 1: every rank's crop is rendered into a tensor on the
     #      collective's device (HBM for RCCL) and gathered with one padded all_gather -- the only collective on the path
     box = sc.objects[0]["boxes"][0]; v, x, y, h, w = (int(q) for q in box)
@@ -303,7 +316,7 @@ def main():
                "timed_region": "median of %d independent repeats; each repeat: fresh object, %d warm-up steps, %d timed steps from init, barrier + device sync on both sides, max over ranks" % (len(reps), args.warmup, args.steps),
                "ms_per_step_repeats": [round(1e3 * r / args.steps, 4) for r in reps], "per_rank_ray_samples_per_s": per_rank,
                "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": cpu_c1,
-               "late_training": late, "multi_object": multi,
+               "late_training": late, "late_training_with_occupancy_skipping": occ, "multi_object": multi,
                "pcie_inclusive": {"dataset_upload_ms": round(1e3 * upload_s, 2), "dataset_bytes": int(sc.n_views * sc.H * sc.W * 4),
                                   "value_for_a_5000_step_job": round(world * 5000 * B / (upload_s + 5000 * dt / args.steps), 1), "unit": "ray-samples/s",
                                   "note": "host frames -> HBM once per sequence (pack + hipMemcpy), then 5000 steps at the measured step time; never the headline value"},

@@ -53,7 +53,10 @@ typedef struct mon_config {
     uint32_t reserved0;
     uint64_t sample_seed;          /* counter-RNG key replacing the cuRAND XORWOW stream     */
     int32_t  use_depth;            /* NeRF_Model::mbUseDepth                                 */
-    int32_t  reserved1;
+    int32_t  occupancy_skip;       /* 0 (default, the reference's behaviour: every one of the 32 samples of a ray is evaluated) | 1: occupancy-grid skipping -- a 64^3
+                                    * bit grid over the object's box, refreshed from the training weights every 32 iterations after 256 warm-up iterations and dilated
+                                    * by one cell; samples in empty cells are not evaluated (no table gathers, no contribution, no gradient).  An approximation the
+                                    * reference does not have: parity runs leave it off. */
 } mon_config;
 
 /* CORE/include/common.h:18-23 (note: h before w). */

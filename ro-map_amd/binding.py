@@ -20,7 +20,7 @@ class MonConfig(C.Structure):
                 ("n_samples", C.c_int32), ("loss_scale", C.c_float), ("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("epsilon", C.c_float), ("l2_reg", C.c_float), ("ema_decay", C.c_float), ("decay_start", C.c_int32), ("decay_interval", C.c_int32),
                 ("decay_base", C.c_float), ("param_seed", C.c_uint32), ("reserved0", C.c_uint32), ("sample_seed", C.c_uint64),
-                ("use_depth", C.c_int32), ("reserved1", C.c_int32)]
+                ("use_depth", C.c_int32), ("occupancy_skip", C.c_int32)]
 
 
 class MonBBox(C.Structure):

@@ -17,6 +17,8 @@ constexpr int kMaxLevels = 16;
 constexpr int kOut = 4;        // rgb + density (nerf_model.cu:1318)
 constexpr int kOutPad = 16;    // tcnn pads the output layer to 16 rows
 constexpr float kTransmittanceEps = 1e-4f;   // nerf_model.cu:763
+constexpr int kOccRes = 64;                  // occupancy grid (opt-in forward-pass skipping): cells per axis over the object's box, one bit each
+constexpr int kOccWarmup = 256, kOccInterval = 32;   // iterations before the first refresh / between refreshes
 
 // Per-level geometry of the multiresolution hash grid (tcnn grid.h; SURVEY TCNN-A1..A4).
 struct LevelTable {

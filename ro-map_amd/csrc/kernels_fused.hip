@@ -113,6 +113,7 @@ struct FusedArgs {
     uint32_t ablate;            // timing experiments only (MON_FUSED_ABLATE): 2 no dW, 4 no dE/x stores, 8 no rays (prologue + epilogue only), 16 keep zero-gradient samples
     uint8_t* touched_grid;      // per 4 grid entries (= one 8-parameter optimizer chunk): set to 1 next to every global atomic, or nullptr (see ParamPtrs::touched)
     uint32_t big_switch;        // > 0: while big_levels_binned(st, big_switch) holds, EVERY level's dE rows are stored (kernels_bigscatter.hip bins the large levels)
+    const uint32_t* occ_bits;   // occupancy-grid skipping (mon_config::occupancy_skip, default off): kOccRes^3 bits, 1 = the cell may hold density; nullptr = evaluate every sample
 };
 
 // A fragments: the weight matrices pre-permuted to K-slot order (see the header).  They depend only on the weights,
@@ -197,9 +198,9 @@ struct TileState {
 
 template <int EPAD, int W, int NH>
 __device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const half_t* frags, const LevelFast& klt, const half2_t* __restrict__ table,
-                                             int L, const float x[3], int lane, TimingCtx* tc = nullptr) {
+                                             int L, const float x[3], int lane, TimingCtx* tc = nullptr, bool live = true) {
     using S = FusedShape<EPAD, W, NH>;
-    const int h = lane >> 5, LPH = (L + 1) >> 1;
+    const int h = lane >> 5, LPH = (L + 1) >> 1;      // `live` = false: this lane's sample sits in a cell the occupancy grid marks empty -- its gathers are not issued (features 0)
     // ---- hash-grid encode (tcnn kernel_grid; fp32 fmaf chain over the 8 corners, one rounding).  Half-wave h OWNS levels
     //      h*LPH + il (their features are its K slots), but the GATHERS are issued level by level with all 64 lanes on one
     //      level: lane (n, c) fetches the four (y, z) corners with x-corner c of sample n.  Measured on MI355X
@@ -217,6 +218,7 @@ __device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const h
         for (int d = 0; d < 3; ++d) pg[d] = (uint32_t)(int32_t)floorf(fmaf(scale, x[d], 0.5f));
         const uint32_t ax = pg[0] + (uint32_t)h, y0 = pg[1] * my, z0 = pg[2] * mz;
         const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
+        if (!live) return;                                                              // (r[] was zeroed by the caller; an exec-masked load costs no L2 request)
 #if MON_V_GATHER == 0
         const bool hashed = klt.hashed[level] != 0u; const uint32_t off = klt.offset[level];
 #pragma unroll
@@ -440,8 +442,22 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         for (int d = 0; d < 3; ++d) { const float p = fmaf(t, a.b.cand_d[3 * cand + d], a.b.cand_o[3 * cand + d]); x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
 
         tstamp(tc, 1);
+        // occupancy-grid skipping (default off): a sample whose cell the grid marks empty is not evaluated -- no gathers, alpha = 0, no gradient
+        bool live = true;
+        if (a.occ_bits) {
+            const uint32_t cx = (uint32_t)min(max((int)(x[0] * (float)kOccRes), 0), kOccRes - 1), cy = (uint32_t)min(max((int)(x[1] * (float)kOccRes), 0), kOccRes - 1), cz = (uint32_t)min(max((int)(x[2] * (float)kOccRes), 0), kOccRes - 1);
+            live = ((a.occ_bits[((cz * kOccRes + cy) * kOccRes + cx) >> 5] >> (cx & 31u)) & 1u) != 0u;
+        }
         TileState<EPAD, W, NH> ts;
-        tile_forward<EPAD, W, NH>(ts, frags, a.lt, table, L, x, lane, tc);
+        if (__ballot(live) != 0ull) tile_forward<EPAD, W, NH>(ts, frags, a.lt, table, L, x, lane, tc, live);
+        else {                                                                           // the whole ray crosses empty cells only: nothing to evaluate
+#pragma unroll
+            for (int i = 0; i < EPAD / 2; ++i) ts.ef[i] = (half_t)0.f;
+#pragma unroll
+            for (int mb = 0; mb < S::MB; ++mb) { ts.h0[mb][0] = half8_t{}; ts.h0[mb][1] = half8_t{}; if constexpr (NH == 2) { ts.h1[mb][0] = half8_t{}; ts.h1[mb][1] = half8_t{}; } }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ts.out4[c] = 0.f;
+        }
         const bool do_dw = (a.ablate & 2u) == 0u;
 
         tstamp(tc, 4);
@@ -450,7 +466,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         const float c0 = logistic_f(v0), c1 = logistic_f(v1), c2 = logistic_f(v2), sigma = __expf(v3);
         float tprev = lane_prev(t, 0.f); if (n == 0) tprev = 0.f;                         // :770 last_distance = 0
         const float dt = t - tprev;
-        const float alpha = 1.f - __expf(-sigma * dt), om = 1.f - alpha;
+        const float alpha = live ? 1.f - __expf(-sigma * dt) : 0.f, om = 1.f - alpha;
         const float tincl = scan_mul32(om);                                               // T after this sample
         float T = lane_prev(tincl, 1.f); if (n == 0) T = 1.f;                             // T before this sample
         const bool active = T >= kTransmittanceEps;                                        // :774 early-out (T is non-increasing)
@@ -472,7 +488,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         half8_t bdo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) bdo[j] = (half_t)0.f;
-        if (active && h == 0) {
+        if (active && h == 0 && live) {
             const float Tn = tincl;                                                       // T after the update (:912)
             const float s0 = rgb0 - p0, s1 = rgb1 - p1, s2 = rgb2 - p2;                   // suffix :915
             bdo[0] = (half_t)(ls * ((wgt * g0) * (c0 * (1.f - c0))));
@@ -1021,6 +1037,55 @@ __global__ void __launch_bounds__(256) k_fused_render(FusedArgs a, uint32_t n_ra
     }
 }
 
+// ------------------------------------------------------------------ occupancy grid (N1: forward-pass skipping, default off)
+// BASELINE.json's north star names occupancy-grid skipping; the reference has none (it always takes 32 uniform samples inside the box,
+// nerf_model.cu:536-566), so the feature is opt-in (mon_config::occupancy_skip) and the parity tests run without it.  A kOccRes^3 bit grid over
+// the object's box is refreshed from the CURRENT training weights every kOccInterval iterations after a warm-up: one wavefront evaluates the
+// network's raw density at the centres of 32 cells (the same tile_forward as training) and ballots "density above the threshold" into one
+// word; a second pass dilates by one cell in every direction.  k_fused_train then skips the gathers of samples in empty cells.
+template <int EPAD, int W, int NH>
+__global__ void __launch_bounds__(256) k_occ_density(FusedArgs a, float raw_threshold, uint32_t* __restrict__ bits_out) {
+    using S = FusedShape<EPAD, W, NH>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half_t* frags = reinterpret_cast<half_t*>(smem);
+    LevelLds* llt = reinterpret_cast<LevelLds*>(smem + S::FRAG_BYTES);
+    build_fragments<EPAD, W, NH>(frags, llt, a, false);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31;
+    const half2_t* table = reinterpret_cast<const half2_t*>(a.params + a.nd.n_mlp);
+    constexpr uint32_t n_words = kOccRes * kOccRes * kOccRes / 32;
+    for (uint32_t word = blockIdx.x * S::WAVES + wave; word < n_words; word += gridDim.x * S::WAVES) {
+        const uint32_t cell = word * 32u + (uint32_t)n, cx = cell % kOccRes, cy = (cell / kOccRes) % kOccRes, cz = cell / (kOccRes * kOccRes);
+        const float x[3] = { ((float)cx + 0.5f) / (float)kOccRes, ((float)cy + 0.5f) / (float)kOccRes, ((float)cz + 0.5f) / (float)kOccRes };
+        TileState<EPAD, W, NH> ts;
+        tile_forward<EPAD, W, NH>(ts, frags, a.lt, table, a.nd.L, x, lane);
+        const uint32_t occ = (uint32_t)__ballot(lane < 32 && ts.out4[3] > raw_threshold);      // raw channel 3 = log density (network_to_density = exp, nerf_model.cu:49)
+        if (lane == 0) bits_out[word] = occ;
+    }
+}
+// a cell stays live if it or any of its 26 neighbours is occupied (the network is only sampled at cell centres)
+__global__ void __launch_bounds__(256) k_occ_dilate(const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+    constexpr int WPR = kOccRes / 32;                                                   // words per x row
+    const uint32_t word = blockIdx.x * blockDim.x + threadIdx.x;
+    if (word >= (uint32_t)(kOccRes * kOccRes * WPR)) return;
+    const int wx = (int)(word % WPR), cy = (int)((word / WPR) % kOccRes), cz = (int)(word / (WPR * kOccRes));
+    uint32_t acc = 0u;
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
+        const int y = cy + dy, z = cz + dz; if (y < 0 || y >= kOccRes || z < 0 || z >= kOccRes) continue;
+        const uint32_t* row = in + ((size_t)z * kOccRes + y) * WPR;
+        const uint32_t w = row[wx], wl = wx > 0 ? row[wx - 1] : 0u, wr = wx + 1 < WPR ? row[wx + 1] : 0u;
+        acc |= w | (w << 1) | (w >> 1) | (wl >> 31) | (wr << 31);
+    }
+    out[word] = acc;
+}
+template <int EPAD, int W, int NH>
+static void occ_update_t(hipStream_t s, const FusedArgs& a, float raw_threshold, uint32_t* tmp, uint32_t* bits) {
+    using S = FusedShape<EPAD, W, NH>;
+    constexpr uint32_t n_words = kOccRes * kOccRes * kOccRes / 32;
+    hipLaunchKernelGGL((k_build_frag_image<EPAD, W, NH>), dim3((S::F_WOT * 512 + 255) / 256), dim3(256), 0, s, a.params, a.nd.L, const_cast<uint16_t*>(a.frag_image), (const DevState*)nullptr);
+    hipLaunchKernelGGL((k_occ_density<EPAD, W, NH>), dim3(n_words / S::WAVES), dim3(256), S::FRAG_BYTES + S::LT_BYTES, s, a, raw_threshold, tmp);
+    hipLaunchKernelGGL(k_occ_dilate, dim3((n_words + 255) / 256), dim3(256), 0, s, tmp, bits);
+}
 // ------------------------------------------------------------------ host side
 bool fused_supported(const NetDims& nd, uint32_t S, uint32_t R) {
     return S == 32 && R <= 16384u && nd.L >= 1 && nd.L <= kMaxLevels && (nd.Epad == 16 || nd.Epad == 32) && (nd.W == 32 || nd.W == 64) && (nd.NH == 1 || nd.NH == 2);
@@ -1079,9 +1144,9 @@ static void candidates_frags_t(hipStream_t s, const BatchPtrs& b, const DatasetP
     } while (0)
 
 void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
-                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched) {
+                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched, const uint32_t* occ_bits) {
     const uint32_t ablate = (uint32_t)options().fused_ablate;
-    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate, touched ? touched + (nd.n_mlp >> 3) : nullptr, big_switch };
+    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate, touched ? touched + (nd.n_mlp >> 3) : nullptr, big_switch, occ_bits };
     const uint32_t grid = fused_train_grid(nd, oc.R);
     MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);
 }
@@ -1099,5 +1164,11 @@ void launch_fused_render(hipStream_t s, const LevelFast& lt, const NetDims& nd, 
     FusedArgs a{ lt, nd, oc, b, params, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, frag_image, build_image ? 1u : 0u };   // `ablate` bit 0 doubles as "build the fragment image first" on the host side of the render path
     MON_FUSED_DISPATCH(fused_render_t, s, a, n_rays, idx_base, rgb, depth, mask);
 }
+
+void launch_occupancy_update(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const ObjectConst& oc, uint16_t* frag_image, float raw_threshold, uint32_t* tmp, uint32_t* bits) {
+    FusedArgs a{}; a.lt = lt; a.nd = nd; a.oc = oc; a.params = params; a.frag_image = frag_image;
+    MON_FUSED_DISPATCH(occ_update_t, s, a, raw_threshold, tmp, bits);
+}
+
 
 }  // namespace mon

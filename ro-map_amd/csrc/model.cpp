@@ -233,6 +233,15 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         const bool flags_on = options().touched_flags != 0;
         if (flags_on && m.lazy_ema && m.lds_mask && m.lds_mask != ((m.nd.L >= 32) ? 0xffffffffu : ((1u << m.nd.L) - 1u)) && (rc = dev_alloc(m, m.d_touched, (m.n_params >> 3) + 16))) return rc;
     }
+    if (cfg.occupancy_skip && fused_supported(m.nd, S, m.oc.R)) {
+        constexpr size_t words = (size_t)kOccRes * kOccRes * kOccRes / 32;
+        if ((rc = dev_alloc(m, m.d_occ, words, false)) || (rc = dev_alloc(m, m.d_occ_tmp, words, false)) || (rc = dev_alloc(m, m.d_frag_occ, 64 * 512))) return rc;
+        HIPCHECK(hipMemset(m.d_occ, 0xff, words * 4));                       // warm-up: every cell counts as occupied
+        // a cell is empty when one sample interval through it would be transparent: alpha = 1 - exp(-sigma * dt) < 1e-3 with dt = box diagonal / samples
+        float diag2 = 0.f; for (int a = 0; a < 3; ++a) diag2 += (amax[a] - amin[a]) * (amax[a] - amin[a]);
+        const float dt = std::sqrt(diag2) / (float)S;
+        m.occ_raw_threshold = std::log(1e-3f / std::max(dt, 1e-6f));
+    }
     m.boxes_cap = 1024;
     if ((rc = dev_alloc(m, m.d_boxes, m.boxes_cap))) return rc;
     B.boxes = m.d_boxes;
@@ -375,7 +384,7 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
         } else {
             if (m.scatter_pending) hipMemsetAsync(m.d_state->n_scatter, 0, sizeof(m.d_state->n_scatter), s);      // stage-wise debugging: a forward/backward without an optimizer step after it
-            launch_fused_train(s, m.lf, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask, m.d_frag_train, m.big_active ? m.big_switch : 0u, m.d_touched);
+            launch_fused_train(s, m.lf, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask, m.d_frag_train, m.big_active ? m.big_switch : 0u, m.d_touched, m.occ_refreshed_iter ? m.d_occ : nullptr);      // (no grid look-ups before the first refresh: every cell is live during the warm-up)
             m.scatter_pending = true;
         }
     }
@@ -408,6 +417,13 @@ static void enqueue_iteration(Model& m, int stages) {
     }
 }
 
+// Occupancy grid refresh (cfg.occupancy_skip): before iteration `iter` when it is due.  Stream-ordered between two iterations, from the training weights.
+static void maybe_refresh_occupancy(Model& m, uint32_t iter) {
+    if (!m.d_occ || m.backend != 1 || iter < (uint32_t)kOccWarmup || iter % (uint32_t)kOccInterval != 0u || iter == m.occ_refreshed_iter) return;
+    launch_occupancy_update(m.train_stream, m.lf, m.nd, m.P.half, m.oc, m.d_frag_occ, m.occ_raw_threshold, m.d_occ_tmp, m.d_occ);
+    m.occ_refreshed_iter = iter;
+}
+
 static int sync_state(Model& m) {
     // :1645 (once per call instead of once per iteration); the state rides the same sync in a pinned buffer -- the online manager trains
     // in slices of a few iterations, where a second blocking copy would be a visible share of the slice
@@ -426,9 +442,9 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     // once the host has seen that count well below the switch point it stops launching the (then empty) binning kernels at all.
     m.big_active = m.big_switch && (m.h_state.n_scatter_last == 0u || m.h_state.n_scatter_last > m.big_switch / 2u);
     const bool use_graph_env = options().use_graph != 0;
-    const bool use_graph = use_graph_env && !m.profiling && stages == 7 && iters >= 2;
+    const bool use_graph = use_graph_env && !m.profiling && stages == 7 && iters >= 2 && !(m.d_occ && !m.occ_refreshed_iter);      // (the first occupancy refresh changes a kernel argument)
     if (use_graph) {
-        const int graph_key = m.backend | (m.big_active ? 256 : 0);
+        const int graph_key = m.backend | (m.big_active ? 256 : 0) | (m.occ_refreshed_iter ? 512 : 0);
         if (!m.graph_exec || m.graph_backend != graph_key) {
             drop_graph(m);
             hipGraph_t g = nullptr;
@@ -439,9 +455,9 @@ int model_train(Model& m, int iters, float* loss, int stages) {
             HIPCHECK(hipGraphInstantiate(&m.graph_exec, g, nullptr, nullptr, 0));
             hipGraphDestroy(g); m.graph_backend = graph_key;
         }
-        for (int i = 0; i < iters; ++i) HIPCHECK(hipGraphLaunch(m.graph_exec, m.train_stream));
+        for (int i = 0; i < iters; ++i) { maybe_refresh_occupancy(m, m.h_state.iter + (uint32_t)i); HIPCHECK(hipGraphLaunch(m.graph_exec, m.train_stream)); }
     } else {
-        for (int i = 0; i < iters; ++i) enqueue_iteration(m, stages);
+        for (int i = 0; i < iters; ++i) { if (stages == 7) maybe_refresh_occupancy(m, m.h_state.iter + (uint32_t)i); enqueue_iteration(m, stages); }
     }
     HIPCHECK(hipGetLastError());
     int rc = sync_state(m); if (rc) return rc;

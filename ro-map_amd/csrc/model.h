@@ -133,7 +133,8 @@ void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_par
 bool fused_supported(const NetDims& nd, uint32_t S, uint32_t R);
 uint32_t fused_train_grid(const NetDims& nd, uint32_t R);
 void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
-                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched);
+                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched, const uint32_t* occ_bits);
+void launch_occupancy_update(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const ObjectConst& oc, uint16_t* frag_image, float raw_threshold, uint32_t* tmp, uint32_t* bits);
 uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl);
 uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd);
 bool grid_scatter_sums_partials(const LevelTable& lt, const NetDims& nd);
@@ -175,6 +176,7 @@ struct Model {
     uint16_t* d_frag_train = nullptr; uint16_t* d_frag_render = nullptr;           // MFMA A-fragment images (training weights / inference weights)
     uint32_t* d_ema_step = nullptr; uint8_t* d_touched = nullptr;                  // lazy EMA bookkeeping, chunk flags (ParamPtrs)
     uint8_t* d_big_ws = nullptr; uint32_t big_switch = 0; bool big_active = false; // kernels_bigscatter.hip: workspace, switch point, launched in this train call
+    uint32_t *d_occ = nullptr, *d_occ_tmp = nullptr; uint16_t* d_frag_occ = nullptr; float occ_raw_threshold = 0.f; uint32_t occ_refreshed_iter = 0;   // occupancy grid (cfg.occupancy_skip)
     float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr; size_t out_cap = 0;   // whole-crop render outputs (grow-only)
     std::vector<void*> allocs;
     DevState h_state{}; DevState* h_state_pinned = nullptr; int backend = 0; bool profiling = false; int fused_dump = 0;

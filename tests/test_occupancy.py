@@ -1,0 +1,46 @@
+"""Occupancy-grid skipping in the forward pass (BASELINE.json north star; mon_config::occupancy_skip).  The reference has no such grid -- it
+evaluates all 32 samples of every ray (nerf_model.cu:536-566) -- so the switch is off by default and every parity test runs without it.
+Here: it is opt-in, does nothing during its warm-up (bit-identical parameters), and afterwards trades a bounded loss of quality for fewer
+table gathers."""
+import time
+import zlib
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from parity import psnr
+
+pytestmark = pytest.mark.gpu
+
+
+def _score(obj, sc, ss):
+    ps, ious = [], []
+    for box in sc.objects[0]["boxes"][::4]:
+        v, x, y, h, w = (int(q) for q in box); rgb, depth, mask = obj.render(box, ss.colmajor(sc.Twc[v]))
+        gm = sc.instance[v, y:y + h, x:x + w] > 0; gt = np.where(gm[..., None], sc.rgb[v, y:y + h, x:x + w] / 255.0, 1.0)
+        ps.append(psnr(rgb, gt)); ious.append((mask.astype(bool) & gm).sum() / max(1, (mask.astype(bool) | gm).sum()))
+    return float(np.mean(ps)), float(np.mean(ious))
+
+
+def test_occupancy_skipping_is_opt_in_inert_during_warmup_and_close_afterwards(pkg, ss):
+    assert pkg.device_count() >= 1
+    assert pkg.default_config().occupancy_skip == 0                                  # off unless asked for
+    sc = ss.make_scene(n_views=16, H=240, W=320, f=260.0, seed=2)
+    ds, exact = ge.make_problem(pkg, sc, dict(sample_seed=77))
+    _, skip = ge.make_problem(pkg, sc, dict(sample_seed=77, occupancy_skip=1), dataset=ds)
+    exact.train(256); skip.train(256)                                                # warm-up: every cell counts as occupied
+    assert zlib.crc32(exact.get_params(0).tobytes()) == zlib.crc32(skip.get_params(0).tobytes())
+    exact.train(544); skip.train(544)
+    t = []
+    for o in (exact, skip):
+        pkg.lib().mon_device_synchronize(0); t0 = time.perf_counter(); o.train(200); pkg.lib().mon_device_synchronize(0); t.append((time.perf_counter() - t0) / 200)
+    (p_e, iou_e), (p_s, iou_s) = _score(exact, sc, ss), _score(skip, sc, ss)
+    print("exact %.2f dB IoU %.3f, %.1f us/step; occupancy skipping %.2f dB IoU %.3f, %.1f us/step" % (p_e, iou_e, 1e6 * t[0], p_s, iou_s, 1e6 * t[1]))
+    assert zlib.crc32(exact.get_params(0).tobytes()) != zlib.crc32(skip.get_params(0).tobytes())      # it really skipped something
+    assert p_s > p_e - 1.5 and iou_s > 0.9 and iou_s > iou_e - 0.03
+    assert t[1] < 1.05 * t[0]                                                        # never slower (the refresh costs ~60 us every 32 iterations)
+    for o in (exact, skip):
+        assert np.isfinite(o.get_params(0)).all()
+        o.close()
+    ds.close()
