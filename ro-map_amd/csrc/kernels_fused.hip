@@ -60,6 +60,9 @@ __device__ __forceinline__ int unit_of_slot(int s, int h, int j) { return 32 * (
 #ifndef MON_V_SCALAR
 #define MON_V_SCALAR 0          // measured: -2 us with the bookkeeping left on the vector unit (100 SGPRs were already in use; the scalar version spills them into VGPR lanes)
 #endif
+#ifndef MON_V_WPS
+#define MON_V_WPS 2            // waves per SIMD k_fused_train is compiled for (3: smaller epilogue scratch so that three workgroups fit a CU's LDS)
+#endif
 #ifndef MON_V_SBATCH
 #define MON_V_SBATCH 4          // samples per thread and software-pipeline round of k_grid_scatter
 #endif
@@ -96,7 +99,11 @@ template <int EPAD, int W, int NH> struct FusedShape {
     static constexpr int OFF_W1 = W * EPAD;
     static constexpr int OFF_WO = W * EPAD + (NH - 1) * W * W;
     static constexpr int WAVES = 4;
+#if MON_V_WPS >= 3
+    static constexpr int RED_BYTES = (N_MLP + 64) * 4 * 2;          // two private fp32 copies at a time: the epilogue reduces the waves in two rounds
+#else
     static constexpr int RED_BYTES = (N_MLP + 64) * 4 * WAVES;      // one private fp32 copy per wave
+#endif
     static constexpr int SMEM_BYTES = FRAG_BYTES + LT_BYTES + ((WAVES * SCR_BYTES > RED_BYTES) ? WAVES * SCR_BYTES : RED_BYTES);
 };
 
@@ -196,7 +203,7 @@ struct TileState {
     float out4[4];
 };
 
-template <int EPAD, int W, int NH>
+template <int EPAD, int W, int NH, bool MASKED = false>
 __device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const half_t* frags, const LevelFast& klt, const half2_t* __restrict__ table,
                                              int L, const float x[3], int lane, TimingCtx* tc = nullptr, bool live = true) {
     using S = FusedShape<EPAD, W, NH>;
@@ -218,7 +225,7 @@ __device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const h
         for (int d = 0; d < 3; ++d) pg[d] = (uint32_t)(int32_t)floorf(fmaf(scale, x[d], 0.5f));
         const uint32_t ax = pg[0] + (uint32_t)h, y0 = pg[1] * my, z0 = pg[2] * mz;
         const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
-        if (!live) return;                                                              // (r[] was zeroed by the caller; an exec-masked load costs no L2 request)
+        if (MASKED && !live) return;                                                    // (r[] was zeroed by the caller; an exec-masked load costs no L2 request)
 #if MON_V_GATHER == 0
         const bool hashed = klt.hashed[level] != 0u; const uint32_t off = klt.offset[level];
 #pragma unroll
@@ -362,8 +369,8 @@ __device__ __forceinline__ float lane_prev(float v, float fill) { return dpp_f<0
 __device__ __forceinline__ float lane_bcast(float v, int src_lane_uniform) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane_uniform)); }
 
 // ------------------------------------------------------------------ fused training kernel
-template <int EPAD, int W, int NH, bool DUMP, bool ATOMIC_LEVELS>
-__global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_train(FusedArgs a) {
+template <int EPAD, int W, int NH, bool DUMP, bool ATOMIC_LEVELS, bool OCC = false>
+__global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k_fused_train(FusedArgs a) {
     using S = FusedShape<EPAD, W, NH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half_t* frags = reinterpret_cast<half_t*>(smem);
@@ -444,12 +451,12 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         tstamp(tc, 1);
         // occupancy-grid skipping (default off): a sample whose cell the grid marks empty is not evaluated -- no gathers, alpha = 0, no gradient
         bool live = true;
-        if (a.occ_bits) {
+        if constexpr (OCC) {
             const uint32_t cx = (uint32_t)min(max((int)(x[0] * (float)kOccRes), 0), kOccRes - 1), cy = (uint32_t)min(max((int)(x[1] * (float)kOccRes), 0), kOccRes - 1), cz = (uint32_t)min(max((int)(x[2] * (float)kOccRes), 0), kOccRes - 1);
             live = ((a.occ_bits[((cz * kOccRes + cy) * kOccRes + cx) >> 5] >> (cx & 31u)) & 1u) != 0u;
         }
         TileState<EPAD, W, NH> ts;
-        if (__ballot(live) != 0ull) tile_forward<EPAD, W, NH>(ts, frags, a.lt, table, L, x, lane, tc, live);
+        if (!OCC || __ballot(live) != 0ull) tile_forward<EPAD, W, NH, OCC>(ts, frags, a.lt, table, L, x, lane, tc, live);
         else {                                                                           // the whole ray crosses empty cells only: nothing to evaluate
 #pragma unroll
             for (int i = 0; i < EPAD / 2; ++i) ts.ef[i] = (half_t)0.f;
@@ -466,7 +473,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         const float c0 = logistic_f(v0), c1 = logistic_f(v1), c2 = logistic_f(v2), sigma = __expf(v3);
         float tprev = lane_prev(t, 0.f); if (n == 0) tprev = 0.f;                         // :770 last_distance = 0
         const float dt = t - tprev;
-        const float alpha = live ? 1.f - __expf(-sigma * dt) : 0.f, om = 1.f - alpha;
+        const float alpha = (!OCC || live) ? 1.f - __expf(-sigma * dt) : 0.f, om = 1.f - alpha;
         const float tincl = scan_mul32(om);                                               // T after this sample
         float T = lane_prev(tincl, 1.f); if (n == 0) T = 1.f;                             // T before this sample
         const bool active = T >= kTransmittanceEps;                                        // :774 early-out (T is non-increasing)
@@ -488,7 +495,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         half8_t bdo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) bdo[j] = (half_t)0.f;
-        if (active && h == 0 && live) {
+        if (active && h == 0 && (!OCC || live)) {
             const float Tn = tincl;                                                       // T after the update (:912)
             const float s0 = rgb0 - p0, s1 = rgb1 - p1, s2 = rgb2 - p2;                   // suffix :915
             bdo[0] = (half_t)(ls * ((wgt * g0) * (c0 * (1.f - c0))));
@@ -691,30 +698,49 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     //      Each wave stores its accumulators to a private LDS copy (independent plain stores; read-modify-write
     //      rounds serialise on LDS latency), then all threads sum the four copies element-wise.
     __syncthreads();
-    float* red = reinterpret_cast<float*>(dyn) + (size_t)wave * (S::N_MLP + 64);
     const int col = n;
+    const auto store_copy = [&](float* red) {
 #pragma unroll
-    for (int mb = 0; mb < S::MB; ++mb)
+        for (int mb = 0; mb < S::MB; ++mb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int u = 32 * mb + rho(h, r);
-            if (col < EPAD) red[u * EPAD + col] = dW0[mb][r];
-            if (col < kOut) red[S::OFF_WO + col * W + u] = dWo[mb][r];
-            if constexpr (NH == 2) {
+            for (int r = 0; r < 16; ++r) {
+                const int u = 32 * mb + rho(h, r);
+                if (col < EPAD) red[u * EPAD + col] = dW0[mb][r];
+                if (col < kOut) red[S::OFF_WO + col * W + u] = dWo[mb][r];
+                if constexpr (NH == 2) {
 #pragma unroll
-                for (int nb = 0; nb < S::MB; ++nb) red[S::OFF_W1 + u * W + 32 * nb + col] = dW1[mb][nb][r];
+                    for (int nb = 0; nb < S::MB; ++nb) red[S::OFF_W1 + u * W + 32 * nb + col] = dW1[mb][nb][r];
+                }
             }
-        }
-    if (lane == 0) red[S::N_MLP] = loss_acc;
-    __syncthreads();
+        if (lane == 0) red[S::N_MLP] = loss_acc;
+    };
     const float* r0 = reinterpret_cast<const float*>(dyn);
     float* dst = a.partials + (size_t)blockIdx.x * (S::N_MLP + 64);
+#if MON_V_WPS >= 3
+    constexpr int PER = (S::N_MLP + 1 + 255) / 256;
+    float part[PER];
+    for (int round = 0; round < 2; ++round) {
+        if ((wave >> 1) == round) store_copy(reinterpret_cast<float*>(dyn) + (size_t)(wave & 1) * (S::N_MLP + 64));
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { const int i = threadIdx.x + q * 256; const float v = (i < S::N_MLP + 1) ? r0[i] + r0[(S::N_MLP + 64) + i] : 0.f; part[q] = round ? part[q] + v : v; }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int i = threadIdx.x + q * 256; const bool dead = i >= S::OFF_WO + kOut * W && i < S::N_MLP;
+        if (i < S::N_MLP + 1) dst[i] = dead ? 0.f : part[q];
+    }
+#else
+    store_copy(reinterpret_cast<float*>(dyn) + (size_t)wave * (S::N_MLP + 64));
+    __syncthreads();
     for (int i = threadIdx.x; i < S::N_MLP + 1; i += blockDim.x) {
         const bool dead = i >= S::OFF_WO + kOut * W && i < S::N_MLP;             // rows 4..15 of the padded output layer: no gradient
         float v = 0.f;
         if (!dead) v = (r0[i] + r0[(S::N_MLP + 64) + i]) + (r0[2 * (S::N_MLP + 64) + i] + r0[3 * (S::N_MLP + 64) + i]);
         dst[i] = v;
     }
+#endif
 #ifdef MON_FUSED_TIMING
     tstamp(tc, 9);
     if (lane == 0) for (int k = 0; k < 16; ++k) a.b.tdist[(blockIdx.x * S::WAVES + wave) * 16 + k] = tcx.acc[k];
@@ -1093,7 +1119,8 @@ bool fused_supported(const NetDims& nd, uint32_t S, uint32_t R) {
 
 uint32_t fused_train_grid(const NetDims&, uint32_t R) {
     const uint32_t want = (R + 3) / 4;            // one ray per wavefront when it fits
-    const uint32_t cap = options().fused_grid > 0 ? (uint32_t)options().fused_grid : 512u;
+    uint32_t cap = options().fused_grid > 0 ? (uint32_t)options().fused_grid : kMaxFusedGrid;
+    if (cap > kMaxFusedGrid) cap = kMaxFusedGrid;          // (the dW partial rows are allocated for kMaxFusedGrid workgroups)
     return want < cap ? want : cap;
 }
 
@@ -1105,9 +1132,13 @@ static void fused_train_t(hipStream_t s, const FusedArgs& a, uint32_t grid, int 
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
     }
     const bool all_lds = a.lds_level_mask != 0u && (a.lds_level_mask == ((a.nd.L >= 32) ? 0xffffffffu : ((1u << a.nd.L) - 1u)));
-    if (dump) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
+    if (dump) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);          // (the debug dump evaluates every sample)
+    else if (a.occ_bits) { if (all_lds) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
+                           else hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a); }
     else if (all_lds) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
     else hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
 }

@@ -213,7 +213,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         (rc = dev_alloc(m, B.Hid, (size_t)Btrain * m.nd.W * m.nd.NH)) || (rc = dev_alloc(m, B.dO, (size_t)Btrain * kOut)) ||
         (rc = dev_alloc(m, B.dHid, (size_t)Btrain * m.nd.W * m.nd.NH)) || (rc = dev_alloc(m, B.dE, (size_t)Btrain * m.nd.Epad)) ||
         (rc = dev_alloc(m, B.rgb_ray, 3 * (size_t)R)) || (rc = dev_alloc(m, B.depth_ray, R)) || (rc = dev_alloc(m, B.mask_ray, R)) || (rc = dev_alloc(m, B.loss_ray, R)) ||
-        (rc = dev_alloc(m, m.d_state, 1)) || (rc = dev_alloc(m, m.d_dw_partials, (size_t)(m.nd.n_mlp + 64) * 512)) ||
+        (rc = dev_alloc(m, m.d_state, 1)) || (rc = dev_alloc(m, m.d_dw_partials, (size_t)(m.nd.n_mlp + 64) * kMaxFusedGrid)) ||
         (rc = dev_alloc(m, m.d_out_rgb, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_depth, kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_mask, kRenderChunkRays))) return rc;
     m.out_cap = kRenderChunkRays;
     // lazy EMA: only where the optimizer is not the dense variant anyway and the table is large (> 8 M parameters); MON_LAZY_EMA=0/1 overrides

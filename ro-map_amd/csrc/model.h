@@ -130,6 +130,7 @@ void launch_ema_finalize(hipStream_t s, const ParamPtrs& p, const OptimConst& oc
 void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_partials, uint32_t stride, uint32_t n_mlp, float* gmlp, DevState* st);
 
 // fused MFMA path (kernels_fused.hip)
+constexpr uint32_t kMaxFusedGrid = 512;       // workgroups of k_fused_train (= dW partial rows per step): two per CU
 bool fused_supported(const NetDims& nd, uint32_t S, uint32_t R);
 uint32_t fused_train_grid(const NetDims& nd, uint32_t R);
 void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
