@@ -861,26 +861,32 @@ __device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restr
 struct PartialsArgs { const float* partials; uint32_t n_partials, stride, n_mlp; float* gmlp; DevState* st; };
 constexpr uint32_t kPartialsMaxPasses = 2;          // column-group passes a workgroup may hold in registers (n_mlp + 1 <= 2 * 8 * 4 * gridDim.x)
 
+// column groups (of 4 columns) a workgroup sums per pass: as few as cover all groups with the whole grid (1, 2, 4 or 8), so that every workgroup
+// carries the same small share instead of the first third of the grid carrying everything
+__device__ __forceinline__ uint32_t partials_groups(const PartialsArgs& pa) {
+    const uint32_t n4 = (pa.n_mlp + 1u + 3u) / 4u, need = (n4 + gridDim.x - 1u) / gridDim.x;
+    return need <= 1u ? 1u : (need <= 2u ? 2u : (need <= 4u ? 4u : 8u));
+}
 __device__ __forceinline__ void partials_prefetch(const PartialsArgs& pa, float4_t (&acc)[kPartialsMaxPasses]) {
-    // thread = (column group gs of 8, row subset sub of 128)
-    const uint32_t n4 = (pa.n_mlp + 1u + 3u) / 4u, gs = threadIdx.x >> 7, sub = threadIdx.x & 127u;
+    // thread = (column group gs of G, row subset sub of 1024 / G)
+    const uint32_t n4 = (pa.n_mlp + 1u + 3u) / 4u, G = partials_groups(pa), subs = blockDim.x / G, gs = threadIdx.x / subs, sub = threadIdx.x - gs * subs;
 #pragma unroll
     for (uint32_t ps = 0; ps < kPartialsMaxPasses; ++ps) {
-        const uint32_t g = (blockIdx.x + ps * gridDim.x) * 8u + gs; acc[ps] = float4_t{ 0.f, 0.f, 0.f, 0.f };
-        if (g < n4) for (uint32_t k0 = sub; k0 < pa.n_partials; k0 += 512u) {                // four independent 16-byte loads per round (rows are padded to n_mlp + 64 floats)
+        const uint32_t g = (blockIdx.x + ps * gridDim.x) * G + gs; acc[ps] = float4_t{ 0.f, 0.f, 0.f, 0.f };
+        if (g < n4) for (uint32_t k0 = sub; k0 < pa.n_partials; k0 += 4u * subs) {            // four independent 16-byte loads per round (rows are padded to n_mlp + 64 floats)
             float4_t v[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) { const uint32_t k = k0 + 128u * u; v[u] = (k < pa.n_partials) ? *reinterpret_cast<const float4_t*>(pa.partials + (size_t)k * pa.stride + 4u * g) : float4_t{ 0.f, 0.f, 0.f, 0.f }; }
+            for (uint32_t u = 0; u < 4u; ++u) { const uint32_t k = k0 + subs * u; v[u] = (k < pa.n_partials) ? *reinterpret_cast<const float4_t*>(pa.partials + (size_t)k * pa.stride + 4u * g) : float4_t{ 0.f, 0.f, 0.f, 0.f }; }
             acc[ps] += (v[0] + v[1]) + (v[2] + v[3]);
         }
     }
 }
 __device__ __forceinline__ void partials_finish(const PartialsArgs& pa, const float4_t (&acc)[kPartialsMaxPasses], float* red) {
-    // the 64 subsets of a wave are summed with DPP, the two waves of a column group through LDS
-    const uint32_t n4 = (pa.n_mlp + 1u + 3u) / 4u, wave = threadIdx.x >> 6;
+    // the 64 subsets of a wave are summed with DPP, the 16 / G waves of a column group through LDS
+    const uint32_t n4 = (pa.n_mlp + 1u + 3u) / 4u, G = partials_groups(pa), wave = threadIdx.x >> 6, wpg = (blockDim.x >> 6) / G;
 #pragma unroll
     for (uint32_t ps = 0; ps < kPartialsMaxPasses; ++ps) {
-        const uint32_t g0 = (blockIdx.x + ps * gridDim.x) * 8u;
+        const uint32_t g0 = (blockIdx.x + ps * gridDim.x) * G;
         if (g0 >= n4) break;                                                               // uniform
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -890,9 +896,9 @@ __device__ __forceinline__ void partials_finish(const PartialsArgs& pa, const fl
             if ((threadIdx.x & 63u) == 63u) red[wave * 4u + (uint32_t)c] = v;               // lane 63 holds the wave total
         }
         __syncthreads();
-        if (threadIdx.x < 32u) {
-            const uint32_t gg = g0 + (threadIdx.x >> 2), c = threadIdx.x & 3u, pi = 4u * gg + c;
-            const float v = red[(2u * (threadIdx.x >> 2)) * 4u + c] + red[(2u * (threadIdx.x >> 2) + 1u) * 4u + c];
+        if (threadIdx.x < 4u * G) {
+            const uint32_t gi = threadIdx.x >> 2, gg = g0 + gi, c = threadIdx.x & 3u, pi = 4u * gg + c;
+            float v = 0.f; for (uint32_t w = 0; w < wpg; ++w) v += red[(gi * wpg + w) * 4u + c];
             if (gg < n4) { if (pi < pa.n_mlp) pa.gmlp[pi] = v; else if (pi == pa.n_mlp) pa.st->loss_sum = v; }
         }
         __syncthreads();
