@@ -129,7 +129,8 @@ int mon_object_train(mon_object* obj, int iters, float* loss);
 int mon_object_render(mon_object* obj, mon_frame_bbox box, const float* pose16, int pose_is_Toc,
                       float* rgb, float* depth, float* mask, int dst_on_device);
 /* The same render on the object's INFERENCE stream (mpInferenceStream, nerf_model.cu:1269) from the inference weights the training side
- * published last (at the end of every mon_object_train call / online training slice): callable from any thread WHILE another thread trains
+ * published last (at the end of a mon_object_train call / online training slice -- of every call of 64 or more iterations, otherwise when a
+ * viewer has asked since the last publication or 10 ms have passed): callable from any thread WHILE another thread trains
  * the object -- no model lock, nothing queued behind training.  *snapshot_step (may be NULL) = optimizer steps the weights had.  Host
  * outputs.  MON_ERR_STATE before the first publication and for objects without an inference side (tables above 8 M parameters, unfused
  * backend): use mon_object_render under the caller's own serialisation there. */

@@ -317,6 +317,16 @@ void launch_ema_finalize(hipStream_t s, const ParamPtrs& p, const OptimConst& oc
 __global__ void __launch_bounds__(256) k_master_to_half(const float* __restrict__ master, uint16_t* __restrict__ half, uint32_t n) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const half_t h = (half_t)master[i]; half[i] = __builtin_bit_cast(uint16_t, h); }
 }
+// plain device copy of a parameter vector (the inference-side snapshots): a kernel of our own rather than hipMemcpyAsync, whose blit path brackets
+// the copy with cache maintenance that the following training kernels pay for
+__global__ void __launch_bounds__(256) k_copy_params(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16, const uint16_t* __restrict__ src_tail, uint16_t* __restrict__ dst_tail, uint32_t n_tail) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+void launch_copy_params(hipStream_t s, const uint16_t* src, uint16_t* dst, uint32_t n) {
+    const uint32_t n16 = n / 8u, tail = n - n16 * 8u;
+    hipLaunchKernelGGL(k_copy_params, dim3(512), dim3(256), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16, src + (size_t)n16 * 8u, dst + (size_t)n16 * 8u, tail);
+}
 void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, uint32_t n) {
     hipLaunchKernelGGL(k_master_to_half, dim3(1024), dim3(256), 0, s, master, half, n);
 }

@@ -354,6 +354,7 @@ static int train_sliced(OnlineObject* o) {
         int n = kOnlineSlice / (sharing > 0 ? sharing : 1); if (n < 2) n = 2; if (n > o->iterations - done) n = o->iterations - done;
         std::unique_lock<std::mutex> dl(*o->dataset_mutex); std::lock_guard<std::mutex> lm(o->mu_model);
         rc = model_train(*o->model, n, &o->last_loss, 7); done += n;
+        if (rc == MON_OK && done >= o->iterations) rc = model_publish_snapshot(*o->model);       // viewers see the end of every Train_Step_Online
     }
     return rc;
 }

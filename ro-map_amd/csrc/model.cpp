@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -51,7 +52,10 @@ int config_from_json(const char* path, mon_config& c);
 // maps n logical devices round-robin onto the physical ones, so the multi-device code paths (object k -> device k mod nGPU, one dataset replica and
 // one stream pool per device, CORE/src/nerf.cu:27-33, nerf_manager.cu:44-55) also run -- oversubscribed -- on a box with fewer GPUs.
 static std::atomic<int> g_logical_devices{ 0 };
-static int physical_count() { int c = 0; return (hipGetDeviceCount(&c) == hipSuccess) ? c : 0; }
+static int physical_count() {          // (asked once: use_device sits on every entry point, and the runtime call takes a process-wide lock)
+    static const int n = [] { int c = 0; return (hipGetDeviceCount(&c) == hipSuccess) ? c : 0; }();
+    return n;
+}
 hipError_t use_device(int logical) {
     const int phys = physical_count(); if (phys < 1) return hipErrorNoDevice;
     const int n = g_logical_devices.load(); if (logical < 0 || logical >= (n > 0 ? n : phys)) return hipErrorInvalidDevice;
@@ -152,6 +156,7 @@ struct InferState {
     hipStream_t stream = nullptr;
     uint16_t* snap[2] = { nullptr, nullptr }; hipEvent_t ready[2] = { nullptr, nullptr }; uint32_t step_of[2] = { 0, 0 };
     int latest = -1, readers[2] = { 0, 0 }; std::mutex mu;              // which snapshot is current, who is reading which
+    std::atomic<bool> wanted{ false }; std::chrono::steady_clock::time_point last_pub{};      // a viewer asked since the last publication; when that was
     std::mutex render_mu;                                               // one snapshot render per object at a time (they share the workspace below)
     BatchPtrs rb{}; float *out_rgb = nullptr, *out_depth = nullptr, *out_mask = nullptr; size_t out_cap = 0; uint16_t* frag = nullptr;
     std::vector<void*> grown;                                           // superseded output buffers, freed with the object
@@ -254,8 +259,8 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     m.mesh = mesh_state_create(m.device);
     if (m.backend == 1 && !m.lazy_ema) {          // (tables above 8 M parameters keep their EMA lazily and would cost 2 x 200 MB of snapshots: they render on the train stream)
         InferState* is = new InferState(); m.infer = is;
-        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        HIPCHECK(hipStreamCreateWithPriority(&is->stream, hipStreamNonBlocking, hi));
+        // (the stream itself is created by the first viewer render: every stream is another hardware-queue client, and a pool of idle high-priority
+        //  queues next to the training streams measurably slows sliced training -- 72 -> 76 us per object-step with four objects)
         for (int k = 0; k < 2; ++k) { if ((rc = dev_alloc(m, is->snap[k], n, false))) return rc; HIPCHECK(hipEventCreateWithFlags(&is->ready[k], hipEventDisableTiming)); }
         is->rb = m.B;
         if ((rc = dev_alloc(m, is->rb.ray_o, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, is->rb.ray_d, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, is->rb.ray_dn, kRenderChunkRays)) ||
@@ -270,12 +275,17 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
 
 // Owner thread, after a train call's state read-back: copy the inference weights (EMA once a step has been taken) into the snapshot buffer no reader
 // holds and make it the current one.  ~4 us of device-to-device copy at base.json size, ordered on the train stream.
-static int publish_snapshot(Model& m) {
+// A publication costs the owner thread ~15 us of host time (copy + event), which matters when the online manager trains in slices of a few
+// iterations: unless forced (long train calls, set_params), it happens when a viewer has asked since the last one or 10 ms have passed.
+static int publish_snapshot(Model& m, bool force = true) {
     InferState* is = m.infer; if (!is) return MON_OK;
+    const auto now = std::chrono::steady_clock::now();
+    if (!force && is->latest >= 0 && !is->wanted.load() && now - is->last_pub < std::chrono::milliseconds(10)) return MON_OK;
+    is->wanted.store(false); is->last_pub = now;
     int w;
     { std::lock_guard<std::mutex> l(is->mu); w = is->latest == 0 ? 1 : 0; if (is->readers[w] > 0) return MON_OK; }          // a render still reads the older buffer: keep the current snapshot this round
     const uint16_t* src = (m.h_state.step > 0) ? m.P.ema : m.P.half;
-    HIPCHECK(hipMemcpyAsync(is->snap[w], src, (size_t)m.n_params * 2, hipMemcpyDeviceToDevice, m.train_stream));
+    launch_copy_params(m.train_stream, src, is->snap[w], m.n_params);
     HIPCHECK(hipEventRecord(is->ready[w], m.train_stream));
     { std::lock_guard<std::mutex> l(is->mu); is->step_of[w] = m.h_state.step; is->latest = w; }
     return MON_OK;
@@ -462,9 +472,11 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     HIPCHECK(hipGetLastError());
     int rc = sync_state(m); if (rc) return rc;
     if (loss) *loss = m.h_state.loss_sum / (float)m.oc.R;       // :1650-1658
-    if (stages == 7 && iters > 0) rc = publish_snapshot(m);
+    if (stages == 7 && iters > 0) rc = publish_snapshot(m, iters >= 64);
     return rc;
 }
+
+int model_publish_snapshot(Model& m) { HIPCHECK(use_device(m.device)); return publish_snapshot(m, true); }      // owner thread: the end of a whole Train_Step_Online
 
 // Render of the latest PUBLISHED inference weights on the inference stream: callable from any thread while the owner trains (no model mutex,
 // no train-stream work).  MON_ERR_STATE when nothing has been published yet (or the model has no inference side): the caller falls back to
@@ -473,10 +485,12 @@ int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int
     if (!pose16 || !rgb || !depth || !mask || box.w == 0 || box.h == 0) { set_error("render: bad argument"); return MON_ERR_ARG; }
     InferState* is = m.infer; if (!is) { set_error("render_snapshot: this object renders on its train stream"); return MON_ERR_STATE; }
     std::lock_guard<std::mutex> one(is->render_mu);
+    is->wanted.store(true);                                             // the training side refreshes the snapshot at the end of its current slice
     int r;
     { std::lock_guard<std::mutex> l(is->mu); r = is->latest; if (r < 0) { set_error("render_snapshot: no weights published yet"); return MON_ERR_STATE; } ++is->readers[r]; }
     struct Release { InferState* is; int r; ~Release() { std::lock_guard<std::mutex> l(is->mu); --is->readers[r]; } } release{ is, r };
     HIPCHECK(use_device(m.device));
+    if (!is->stream) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIPCHECK(hipStreamCreateWithPriority(&is->stream, hipStreamNonBlocking, hi)); }
     hipStream_t s = is->stream;
     HIPCHECK(hipStreamWaitEvent(s, is->ready[r], 0));
     if (snapshot_step) *snapshot_step = is->step_of[r];

@@ -123,6 +123,7 @@ void launch_composite_grad(hipStream_t s, const BatchPtrs& b, const ObjectConst&
 void launch_composite_render(hipStream_t s, const BatchPtrs& b, uint32_t S, uint32_t n_rays, float* rgb, float* depth, float* mask);
 void launch_extract_density(hipStream_t s, const uint16_t* O, float* out, uint32_t n);
 void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, uint32_t n);
+void launch_copy_params(hipStream_t s, const uint16_t* src, uint16_t* dst, uint32_t n);
 
 // optimizer (kernels_optim.hip)
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx);
@@ -189,6 +190,7 @@ struct Model {
 };
 
 int ensure_ema_current(Model& m);
+int model_publish_snapshot(Model& m);
 int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, uint32_t* snapshot_step);
 int level_table_build(const mon_config& c, LevelTable& lt, NetDims& nd, uint32_t& n_grid);
 void level_fast_build(const LevelTable& lt, const NetDims& nd, LevelFast& lf);

@@ -66,7 +66,9 @@ def main():
                 busy = v[(k, "SQ_BUSY_CYCLES")] / 32.0            # summed over the 32 shader engines -> cycles the kernel kept the SQs busy
                 d[k + "_sq_busy_cycles"] = int(busy)
                 d[k + "_mfma_busy_frac"] = round(v.get((k, "SQ_VALU_MFMA_BUSY_CYCLES"), 0.0) / (busy * 1024.0), 5)          # of 1024 SIMD matrix pipes
-                d[k + "_valu_issue_frac"] = round(v.get((k, "SQ_INSTS_VALU"), 0.0) * 2.0 / (busy * 1024.0), 4)               # wave64 VALU = 2 cycles on a SIMD-32
+                d[k + "_valu_busy_frac"] = round(v.get((k, "SQ_ACTIVE_INST_VALU"), 0.0) * 4.0 / (busy * 1024.0), 4)           # SIMD-time with a VALU instruction in flight (quad-cycles -> cycles, 1024 SIMDs)
+                if v.get((k, "SQ_INSTS_VALU")):
+                    d[k + "_cycles_per_valu_instruction"] = round(v.get((k, "SQ_ACTIVE_INST_VALU"), 0.0) * 4.0 / v[(k, "SQ_INSTS_VALU")], 2)
                 d[k + "_lds_active_frac"] = round(v.get((k, "SQ_LDS_IDX_ACTIVE"), 0.0) / (busy * 256.0), 4)                  # of 256 LDS arrays
                 d[k + "_lds_bank_conflict_share"] = round(v.get((k, "SQ_LDS_BANK_CONFLICT"), 0.0) / max(1.0, v.get((k, "SQ_LDS_IDX_ACTIVE"), 0.0)), 4)
                 wc = v.get((k, "SQ_WAVE_CYCLES"), 0.0)
