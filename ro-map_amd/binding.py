@@ -377,7 +377,7 @@ class ObjectNeRF:
                       dE=(np.uint16, B * Ep), rgb_ray=(np.float32, R * 3), depth_ray=(np.float32, R), mask_ray=(np.float32, R), loss_ray=(np.float32, R),
                       ray_o=(np.float32, R * 3), ray_d=(np.float32, R * 3), ray_t0=(np.float32, R), ray_t1=(np.float32, R), target=(np.float32, R * 3),
                       target_depth=(np.float32, R), bgcol=(np.float32, R * 3), ray_flag=(np.uint8, R), ray_dn=(np.float32, R), mask=(np.uint64, R // 64),
-                      state=(np.uint32, 28), frag_train=(np.uint16, 64 * 512), frag_ref=(np.uint16, 64 * 512))
+                      state=(np.uint32, 28 + 2 * 128 * 16), frag_train=(np.uint16, 64 * 512), frag_ref=(np.uint16, 64 * 512))
         dt, cnt = shapes[name]; out = np.empty(cnt, dt)
         _check(diag_lib().mon_object_debug_read(self.h, BUF[name], _p(out), out.nbytes)); return out
 

@@ -26,11 +26,13 @@ constexpr uint32_t kBigTile = 8192, kBigTileShift = 13, kBigBins = 16, kBigMaxTi
 
 struct BigLevels { int n; int level[kMaxLevels]; uint32_t tiles[kMaxLevels]; uint32_t tile_base[kMaxLevels + 1]; };
 
-// samples of ray bin b: compacted run of st->n_scatter[b] samples at b * (B / 16)
+// samples of bin group g (of kBigBins): the ray bins g, g + kBigBins, ... < n_bins, each a compacted run of st->n_scatter[b] samples at b * (B / n_bins)
 template <class F>
-__device__ __forceinline__ void for_bin_samples(const LevelFast& lf, int level, const half2_t* __restrict__ de, const float* __restrict__ x_soa, uint32_t B, uint32_t b,
+__device__ __forceinline__ void for_bin_samples(const LevelFast& lf, int level, const half2_t* __restrict__ de, const float* __restrict__ x_soa, uint32_t B, uint32_t n_bins, uint32_t g,
                                                 const DevState* __restrict__ st, F&& f) {
-    const uint32_t cap = B >> 4, cnt = min(st->n_scatter[b], cap), s0 = b * cap;
+  const uint32_t cap = B / n_bins;
+  for (uint32_t b = g; b < n_bins; b += kBigBins) {
+    const uint32_t cnt = min(st->n_scatter[scatter_counter(st->iter, b)], cap), s0 = b * cap;
     for (uint32_t s = s0 + threadIdx.x; s < s0 + cnt; s += blockDim.x) {
         const half2_t g = de[s];
         float g0 = (float)g.x, g1 = (float)g.y;
@@ -43,16 +45,17 @@ __device__ __forceinline__ void for_bin_samples(const LevelFast& lf, int level, 
             if (bits & 0x7fff7fffu) f(idx, bits);
         });
     }
+  }
 }
 
-__global__ void __launch_bounds__(1024) k_big_hist(LevelFast lf, BigLevels big, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa, uint32_t B,
+__global__ void __launch_bounds__(1024) k_big_hist(LevelFast lf, BigLevels big, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa, uint32_t B, uint32_t n_bins,
                                                   const DevState* __restrict__ st, uint32_t big_switch, uint32_t* __restrict__ hist) {
     __shared__ uint32_t h[kBigMaxTiles];
     if (st->n_valid == 0u || !big_levels_binned(st->n_scatter_last, big_switch)) return;
     const uint32_t bl = blockIdx.x / kBigBins, b = blockIdx.x - bl * kBigBins; const int level = big.level[bl];
     for (uint32_t i = threadIdx.x; i < big.tiles[bl]; i += blockDim.x) h[i] = 0u;
     __syncthreads();
-    for_bin_samples(lf, level, de_soa + (size_t)level * B, x_soa, B, b, st, [&](uint32_t idx, uint32_t) { atomicAdd(&h[idx >> kBigTileShift], 1u); });
+    for_bin_samples(lf, level, de_soa + (size_t)level * B, x_soa, B, n_bins, b, st, [&](uint32_t idx, uint32_t) { atomicAdd(&h[idx >> kBigTileShift], 1u); });
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < big.tiles[bl]; i += blockDim.x) hist[(size_t)blockIdx.x * kBigMaxTiles + i] = h[i];
 }
@@ -75,7 +78,7 @@ __global__ void __launch_bounds__(1024) k_big_scan(BigLevels big, const DevState
     }
 }
 
-__global__ void __launch_bounds__(1024) k_big_emit(LevelFast lf, BigLevels big, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa, uint32_t B,
+__global__ void __launch_bounds__(1024) k_big_emit(LevelFast lf, BigLevels big, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa, uint32_t B, uint32_t n_bins,
                                                   const DevState* __restrict__ st, uint32_t big_switch, const uint32_t* __restrict__ woff, uint2* __restrict__ rec) {
     __shared__ uint32_t cur[kBigMaxTiles];
     if (st->n_valid == 0u || !big_levels_binned(st->n_scatter_last, big_switch)) return;
@@ -83,7 +86,7 @@ __global__ void __launch_bounds__(1024) k_big_emit(LevelFast lf, BigLevels big, 
     for (uint32_t i = threadIdx.x; i < big.tiles[bl]; i += blockDim.x) cur[i] = woff[(size_t)blockIdx.x * kBigMaxTiles + i];
     __syncthreads();
     uint2* out = rec + (size_t)bl * 8u * B;                                         // a level holds at most 8 contributions per sample
-    for_bin_samples(lf, level, de_soa + (size_t)level * B, x_soa, B, b, st, [&](uint32_t idx, uint32_t bits) {
+    for_bin_samples(lf, level, de_soa + (size_t)level * B, x_soa, B, n_bins, b, st, [&](uint32_t idx, uint32_t bits) {
         const uint32_t slot = atomicAdd(&cur[idx >> kBigTileShift], 1u);            // order inside a bin segment is arbitrary: the accumulation below is exact
         out[slot] = make_uint2(idx, bits);
     });
@@ -139,7 +142,7 @@ size_t big_scatter_workspace_bytes(const LevelTable& lt, const NetDims& nd, uint
     return (size_t)n_big * (2 * kBigBins + 2) * kBigMaxTiles * 4 + (size_t)n_big * 8u * B * 8u;
 }
 void launch_big_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, uint32_t lds_mask, const uint16_t* de_soa, const float* x_soa, uint32_t B,
-                        const DevState* st, uint32_t big_switch, void* workspace, uint16_t* ggrid, uint8_t* touched_grid) {
+                        uint32_t n_bins, const DevState* st, uint32_t big_switch, void* workspace, uint16_t* ggrid, uint8_t* touched_grid) {
     BigLevels big; if (big_levels_plan(lt, nd, lds_mask, big) <= 0) return;
     uint32_t* hist = reinterpret_cast<uint32_t*>(workspace); uint32_t* woff = hist + (size_t)big.n * kBigBins * kBigMaxTiles;
     uint32_t* tcnt = woff + (size_t)big.n * kBigBins * kBigMaxTiles; uint32_t* toff = tcnt + (size_t)big.n * kBigMaxTiles;
@@ -148,9 +151,9 @@ void launch_big_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf
     { int dev = 0; (void)hipGetDevice(&dev); const uint64_t bit = 1ull << (dev & 63);
       if (!(attr_devices.fetch_or(bit) & bit)) hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_accum), hipFuncAttributeMaxDynamicSharedMemorySize, kBigTile * 8); }
     const half2_t* de = reinterpret_cast<const half2_t*>(de_soa);
-    hipLaunchKernelGGL(k_big_hist, dim3(big.n * kBigBins), dim3(1024), 0, s, lf, big, de, x_soa, B, st, big_switch, hist);
+    hipLaunchKernelGGL(k_big_hist, dim3(big.n * kBigBins), dim3(1024), 0, s, lf, big, de, x_soa, B, n_bins, st, big_switch, hist);
     hipLaunchKernelGGL(k_big_scan, dim3(big.n), dim3(1024), 0, s, big, st, big_switch, hist, woff, tcnt, toff);
-    hipLaunchKernelGGL(k_big_emit, dim3(big.n * kBigBins), dim3(1024), 0, s, lf, big, de, x_soa, B, st, big_switch, woff, rec);
+    hipLaunchKernelGGL(k_big_emit, dim3(big.n * kBigBins), dim3(1024), 0, s, lf, big, de, x_soa, B, n_bins, st, big_switch, woff, rec);
     hipLaunchKernelGGL(k_big_accum, dim3(big.tile_base[big.n]), dim3(1024), kBigTile * 8, s, lf, big, st, big_switch, tcnt, toff, rec, B, reinterpret_cast<uint32_t*>(ggrid), touched_grid);
 }
 

@@ -120,6 +120,7 @@ struct FusedArgs {
     uint32_t ablate;            // timing experiments only (MON_FUSED_ABLATE): 2 no dW, 4 no dE/x stores, 8 no rays (prologue + epilogue only), 16 keep zero-gradient samples
     uint8_t* touched_grid;      // per 4 grid entries (= one 8-parameter optimizer chunk): set to 1 next to every global atomic, or nullptr (see ParamPtrs::touched)
     uint32_t big_switch;        // > 0: while big_levels_binned(st, big_switch) holds, EVERY level's dE rows are stored (kernels_bigscatter.hip bins the large levels)
+    uint32_t n_bins;            // ray bins of the compacted gradient rows (scatter_bins(R), host-chosen)
     const uint32_t* occ_bits;   // occupancy-grid skipping (mon_config::occupancy_skip, default off): kOccRes^3 bits, 1 = the cell may hold density; nullptr = evaluate every sample
 };
 
@@ -414,6 +415,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
     typedef __attribute__((address_space(1))) half2_t gh2;
     gh2* gtable = (gh2*)reinterpret_cast<half2_t*>(a.ggrid);
     const float ls = a.oc.loss_scale / (float)R;
+    const uint32_t n_bins = a.n_bins;                                                // ray bins of the compacted gradient rows
 
     float16_t dW0[S::MB], dWo[S::MB], dW1[NH == 2 ? S::MB : 1][NH == 2 ? S::MB : 1];
 #pragma unroll
@@ -518,7 +520,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
         // ---- which samples carry a gradient at all.  dL/dO is fp16 with a loss scale of 128/R: once empty space is learnt
         //      (sigma = exp(-15), alpha * T -> 0) it underflows to exact zeros, 94-98 % of the samples after ~200 steps
         //      (tools/zero_grad_fraction.py).  Zero rows contribute exact zeros to dW and dE, so a ray without any is done
-        //      here, and only the non-zero samples are handed to k_grid_scatter, compacted into 16 bins by ray index.  Inside a
+        //      here, and only the non-zero samples are handed to k_grid_scatter, compacted into ray bins (ray mod n_bins, up to 128: one returning atomic per ray on 16 counters cost 7 us of contention).  Inside a
         //      bin the order is whatever the atomics give -- irrelevant, the scatter's integer accumulation is exact -- while
         //      bin membership, and with it every fp16-rounded partial table, is a fixed function of the ray: the result stays
         //      deterministic.  The slot reservation is issued now and consumed after the MFMAs.
@@ -526,7 +528,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
         const uint32_t nz32 = (a.ablate & 16u) ? 0xffffffffu : (uint32_t)__ballot(h == 0 && ((bdo_bits.x | bdo_bits.y) & 0x7fff7fffu) != 0u);   // ablate 16: no skipping (A/B check)
         const uint32_t nz_cnt = __popc(nz32);
         uint32_t slot_base = 0u;
-        if (nz_cnt != 0u && lane == 0 && lds_level_mask) slot_base = atomicAdd(&a.st->n_scatter[ray & 15u], nz_cnt);
+        if (nz_cnt != 0u && lane == 0 && lds_level_mask) slot_base = atomicAdd(&a.st->n_scatter[scatter_counter(iter, ray & (n_bins - 1u))], nz_cnt);
         if (lane == 0) {
             loss_acc += loss;
             a.b.rgb_ray[3 * ray] = rgb0; a.b.rgb_ray[3 * ray + 1] = rgb1; a.b.rgb_ray[3 * ray + 2] = rgb2;
@@ -666,8 +668,8 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
         tstamp(tc, 7);
         const uint32_t Btot = R * 32u;
         const bool mine = ((nz32 >> n) & 1u) != 0u;                                        // this lane's sample is one of the non-zero ones
-        const uint32_t bin_cap = Btot >> 4, in_bin = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_base) + __popc(nz32 & ((1u << n) - 1u));
-        const uint32_t slot = (ray & 15u) * bin_cap + in_bin;                              // a bin holds the samples of R/16 rays at most
+        const uint32_t bin_cap = Btot / n_bins, in_bin = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_base) + __popc(nz32 & ((1u << n) - 1u));
+        const uint32_t slot = (ray & (n_bins - 1u)) * bin_cap + in_bin;                    // a bin holds the samples of R / n_bins rays at most
         const bool do_store = (a.ablate & 4u) == 0u && mine && in_bin < bin_cap;
         if (lds_level_mask && h == 0 && do_store) reinterpret_cast<float4_t*>(a.x_soa)[slot] = float4_t{ x[0], x[1], x[2], 0.f };          // one 16-byte store per sample
 #pragma unroll
@@ -813,30 +815,36 @@ __device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bo
 }
 
 template <bool HASHED, bool POW2>
-__device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restrict__ de, const float4_t* __restrict__ x4, uint32_t cnt_lanes /* lane b: run length of ray bin b */,
-                                                uint32_t bin0, uint32_t bin_step, uint32_t bin_cap, uint32_t feature,
+__device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restrict__ de, const float4_t* __restrict__ x4, uint32_t cnt_lo, uint32_t cnt_hi /* lane b: run length of ray bin b / b + 64 */,
+                                                uint32_t n_bins, uint32_t bin0, uint32_t bin_step, uint32_t bin_cap, uint32_t feature,
                                                 float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask, uint32_t base, uint32_t tile, float fs) {
-    // This workgroup's samples are the ray bins bin0, bin0 + bin_step, ... (< 16), each a compacted run of samples at b * bin_cap.  They are
-    // walked in STEPS: step s = (round r, k-th bin), thread t takes offset o = r * 1024 + t of that bin -- the bin is uniform per step, so its
-    // run length and base come from scalar registers (v_readlane with a scalar lane index) and a sample costs two vector instructions of
-    // bookkeeping.  NOTHING inside the loop may wait on an LDS or scalar-memory read: both share the counter (lgkmcnt) the LDS atomics are
-    // counted on, in order, so such a wait drains every atomic issued before it.
+    // This workgroup's samples are the ray bins bin0, bin0 + bin_step, ... (< n_bins), each a compacted run of samples at b * bin_cap.  They are
+    // walked in STEPS.  While the runs are long (every sample carries a gradient: 1024 per bin) a step is one bin and thread t takes offset
+    // r * 1024 + t; once they are short (late training: a few dozen per bin) the workgroup's waves split into G groups of W2 = 1024 / G threads
+    // and a step covers G bins at once.  Either way the bin is uniform per WAVE, so its run length and base come from scalar registers
+    // (v_readlane with a scalar lane index) and a sample costs two vector instructions of bookkeeping.  NOTHING inside the loop may wait on an
+    // LDS or scalar-memory read: both share the counter (lgkmcnt) the LDS atomics are counted on, in order, so such a wait drains every atomic
+    // issued before it.
     // Software pipeline: the kBatch steps of round r + 1 are requested before round r's index math and LDS atomics run, so the global-load
     // latency hides behind arithmetic (all 16 waves of the workgroup start in phase; without the prefetch they also wait in phase).
     constexpr int kBatch = MON_V_SBATCH;
+    const auto count_of = [&](uint32_t b) { return (uint32_t)((b < 64u) ? __builtin_amdgcn_readlane((int)cnt_lo, (int)b) : __builtin_amdgcn_readlane((int)cnt_hi, (int)(b - 64u))); };   // b uniform
     uint32_t nb = 0, width = 0;
-    for (uint32_t b = bin0; b < 16u; b += bin_step) { ++nb; width = max(width, (uint32_t)__builtin_amdgcn_readlane((int)cnt_lanes, (int)b)); }
+    for (uint32_t b = bin0; b < n_bins; b += bin_step) { ++nb; width = max(width, count_of(b)); }
     if (width == 0u) return;
-    const uint32_t rounds = (width + blockDim.x - 1u) / blockDim.x, n_steps = rounds * nb;
-    uint32_t fk = 0, fo = threadIdx.x, fb = bin0, fs_left = n_steps;          // running state of the step the next fetch serves: bin ordinal, offset, bin, steps left (all but fo uniform)
+    uint32_t w2s = 6u; while ((1u << w2s) < blockDim.x && (1u << w2s) < width) ++w2s;   // threads per bin and step: W2 = 2^w2s = the run length rounded up to a power of two, one wave at least
+    const uint32_t W2 = 1u << w2s, gs = 10u - w2s, G = 1u << gs;                         // (1024 threads: G = 1024 / W2 groups; powers of two throughout, no divisions)
+    const uint32_t wg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> w2s)), lane_o = threadIdx.x & (W2 - 1u);
+    const uint32_t ksteps = (nb + G - 1u) >> gs, rounds = (width + W2 - 1u) >> w2s, n_steps = rounds * ksteps;
+    uint32_t fks = 0, fo = lane_o, fs_left = n_steps;                                   // running state of the step the next fetch serves (all but fo uniform)
     const auto fetch = [&](ScatterItem& it, bool& valid) {
-        const uint32_t b = min(fb, 15u);
-        const uint32_t cnt = fs_left ? (uint32_t)__builtin_amdgcn_readlane((int)cnt_lanes, (int)b) : 0u;
+        const uint32_t k = (fks << gs) + wg, b = min(bin0 + k * bin_step, n_bins - 1u);
+        const uint32_t cnt = (fs_left && k < nb) ? count_of(b) : 0u;
         valid = fo < cnt; const uint32_t sc = b * bin_cap + (valid ? fo : 0u);
         it.g = de[sc]; it.x = x4[sc];
         fs_left -= fs_left ? 1u : 0u;
-        const bool wrap = fk + 1u == nb;                                         // (selects, not branches: the compiler turned conditional updates of the captured state into scratch memory)
-        fo += wrap ? blockDim.x : 0u; fb = wrap ? bin0 : fb + bin_step; fk = wrap ? 0u : fk + 1u;
+        const bool wrap = fks + 1u == ksteps;                                    // (selects, not branches: the compiler turned conditional updates of the captured state into scratch memory)
+        fo += wrap ? W2 : 0u; fks = wrap ? 0u : fks + 1u;
     };
     ScatterItem nxt[kBatch]; bool nv[kBatch];
 #pragma unroll
@@ -906,8 +914,17 @@ __device__ __forceinline__ void partials_finish(const PartialsArgs& pa, const fl
 }
 
 __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLevels sl, const half2_t* __restrict__ de_soa, const float4_t* __restrict__ x4,
-                                                       uint32_t B, half_t* __restrict__ gpart, uint32_t n_entries, const DevState* __restrict__ st, PartialsArgs pa, float* __restrict__ timing) {
+                                                       uint32_t B, uint32_t n_bins, half_t* __restrict__ gpart, uint32_t n_entries, const DevState* __restrict__ st, DevState* st_rw, PartialsArgs pa, float* __restrict__ timing) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t iter = st->iter;
+    if (blockIdx.x == 0 && threadIdx.x < 64u) {
+        // slot-counter housekeeping (also for a skipped batch): clear the OTHER set -- k_fused_train of the next iteration counts there -- and note how many
+        // samples carried a gradient in this one (the optimizer's last block publishes it; the large-table path of the next iteration decides on it)
+        uint32_t v = 0u;
+        for (uint32_t b = threadIdx.x; b < n_bins; b += 64u) { v += st->n_scatter[scatter_counter(iter, b)]; st_rw->n_scatter[scatter_counter(iter + 1u, b)] = 0u; }
+        v = scan_add64_u32(v);
+        if (threadIdx.x == 63u) st_rw->n_scatter_now = v;
+    }
     if (st->n_valid == 0u) return;
 #ifdef MON_SCATTER_TIMING
     long long tq[10]; int tn = 0;
@@ -920,8 +937,12 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
     if (pa.partials) partials_prefetch(pa, pacc);                                    // loads in flight while the tile is cleared and filled
     int* tab = reinterpret_cast<int*>(smem);
     float* red = reinterpret_cast<float*>(smem + (size_t)kScatterTile * 4u);           // 256 B behind the tile
-    // run lengths of the 16 compacted ray bins, lane b of every wave holds bin b's (read back with v_readlane: no memory access in the sample loop)
-    const uint32_t cnt_lanes = min(st->n_scatter[threadIdx.x & 15u], B >> 4);
+    // run lengths of the compacted ray bins, lane b of every wave holds bin b's and bin (b + 64)'s (read back with v_readlane: no memory access in the sample loop)
+    const uint32_t bin_cap = B / n_bins, lb = threadIdx.x & 63u;
+    // (both sets are requested and the iteration's one is picked afterwards: the address must not wait for the load of the iteration counter)
+    const uint32_t c_lo0 = (lb < n_bins) ? st->n_scatter[scatter_counter(0u, lb)] : 0u, c_lo1 = (lb < n_bins) ? st->n_scatter[scatter_counter(1u, lb)] : 0u;
+    const uint32_t c_hi0 = (lb + 64u < n_bins) ? st->n_scatter[scatter_counter(0u, lb + 64u)] : 0u, c_hi1 = (lb + 64u < n_bins) ? st->n_scatter[scatter_counter(1u, lb + 64u)] : 0u;
+    const uint32_t cnt_lo = min((iter & 1u) ? c_lo1 : c_lo0, bin_cap), cnt_hi = min((iter & 1u) ? c_hi1 : c_hi0, bin_cap);
     const uint32_t slot = blockIdx.x / kScatterWgPerLevel, j = blockIdx.x - slot * kScatterWgPerLevel;
     const int level = sl.level[slot]; const uint32_t P = sl.P[level];
     const uint32_t part = j / P, p = j - part * P, feature = part & 1u;
@@ -941,9 +962,8 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
         __syncthreads();
         MON_ST_STAMP();
         // sample partition p of this level = the ray bins b = p, p + P, ... (16 bins, compacted by k_fused_train: only samples with a non-zero gradient)
-        const uint32_t bin_cap = B >> 4;
         const half2_t* de = de_soa + (size_t)level * B;
-#define MON_SCATTER_CALL(H, PW) scatter_samples<H, PW>(tab, de, x4, cnt_lanes, p, P, bin_cap, feature, scale, size, my, mz, mask, base, tile, fs)
+#define MON_SCATTER_CALL(H, PW) scatter_samples<H, PW>(tab, de, x4, cnt_lo, cnt_hi, n_bins, p, P, bin_cap, feature, scale, size, my, mz, mask, base, tile, fs)
         if (hashed) { if (pow2) MON_SCATTER_CALL(true, true); else MON_SCATTER_CALL(true, false); }
         else { if (pow2) MON_SCATTER_CALL(false, true); else MON_SCATTER_CALL(false, false); }
 #undef MON_SCATTER_CALL
@@ -1003,7 +1023,7 @@ bool grid_scatter_sums_partials(const LevelTable& lt, const NetDims& nd) {
     ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return false;
     return nd.n_mlp + 1u <= kPartialsMaxPasses * 8u * 4u * sl.n_levels * kScatterWgPerLevel;
 }
-void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
+void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint32_t n_bins, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
                          const float* partials, uint32_t n_partials, float* gmlp) {
     ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return;
     const PartialsArgs pa{ partials, n_partials, nd.n_mlp + 64u, nd.n_mlp, gmlp, st };
@@ -1014,8 +1034,8 @@ void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& l
 #ifdef MON_SCATTER_TIMING
     static float* g_timing = nullptr; if (!g_timing) hipMalloc((void**)&g_timing, 256 * 16 * 8 * 4); timing = g_timing; g_scatter_timing_buf = g_timing;
 #endif
-    hipLaunchKernelGGL(k_grid_scatter, dim3(sl.n_levels * kScatterWgPerLevel), dim3(1024), smem, s, lf, sl, reinterpret_cast<const half2_t*>(de_soa), reinterpret_cast<const float4_t*>(x_soa), B,
-                       reinterpret_cast<half_t*>(gpart), part_stride_entries, st, pa, timing);
+    hipLaunchKernelGGL(k_grid_scatter, dim3(sl.n_levels * kScatterWgPerLevel), dim3(1024), smem, s, lf, sl, reinterpret_cast<const half2_t*>(de_soa), reinterpret_cast<const float4_t*>(x_soa), B, n_bins,
+                       reinterpret_cast<half_t*>(gpart), part_stride_entries, st, st, pa, timing);
 }
 #ifdef MON_SCATTER_TIMING
 extern "C" int mon_debug_scatter_timing(float* out) { hipDeviceSynchronize(); return g_scatter_timing_buf ? (int)hipMemcpy(out, g_scatter_timing_buf, 256 * 16 * 8 * 4, hipMemcpyDeviceToHost) : -1; }
@@ -1181,9 +1201,9 @@ static void candidates_frags_t(hipStream_t s, const BatchPtrs& b, const DatasetP
     } while (0)
 
 void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
-                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched, const uint32_t* occ_bits) {
+                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched, const uint32_t* occ_bits, uint32_t n_bins) {
     const uint32_t ablate = (uint32_t)options().fused_ablate;
-    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate, touched ? touched + (nd.n_mlp >> 3) : nullptr, big_switch, occ_bits };
+    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate, touched ? touched + (nd.n_mlp >> 3) : nullptr, big_switch, n_bins, occ_bits };
     const uint32_t grid = fused_train_grid(nd, oc.R);
     MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);
 }

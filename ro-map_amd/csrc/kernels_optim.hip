@@ -42,7 +42,7 @@ __device__ __forceinline__ void ema_catch_up(half8_t& e, const half8_t& w, uint3
 // gradient or when the inference weights are needed (k_ema_finalize).  The weights and Adam state are exactly those of the eager
 // schedule; the EMA differs from the step-by-step fp16 recurrence by rounding only.
 template <bool DENSE, bool LAZY>
-__global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, DevState* __restrict__ st, OptimNext nx) {
+__global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, DevState* __restrict__ st, OptimNext nx, uint32_t n_bins) {
     const uint32_t n_valid = st->n_valid, step = st->step;
     const bool cand_block = blockIdx.x < nx.cand_blocks;            // GenerateRays of iteration iter + 1 (every block reads the state before its ticket)
     if (cand_block) gen_candidate(nx.b, nx.ds, nx.oc, st->n_boxes, st->iter + 1u, blockIdx.x * blockDim.x + threadIdx.x);
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
         if (t == gridDim.x - 1u) {
             st->ticket = 0u;
             st->iter = st->iter + 1u;
-            { uint32_t tot = 0; for (int b = 0; b < 16; ++b) { tot += st->n_scatter[b]; st->n_scatter[b] = 0u; } st->n_scatter_last = tot; st->n_scatter_total += tot; }   // slot counters of k_fused_train's compacted gradient rows
+            { const uint32_t tot = st->n_scatter_now; st->n_scatter_now = 0u; st->n_scatter_last = tot; st->n_scatter_total += tot; (void)n_bins; }   // (the slot counters themselves are cleared and summed by k_grid_scatter)
             if (n_valid != 0u) {
                 st->step = cur;
                 st->ema_deb_old = 1.f - (float)pow((double)d, (double)cur);              // factors of step cur + 1
@@ -331,16 +331,16 @@ void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, u
     hipLaunchKernelGGL(k_master_to_half, dim3(1024), dim3(256), 0, s, master, half, n);
 }
 
-void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx) {
+void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx, uint32_t n_bins) {
     const uint32_t chunks = oc.n_params >> 3;
     const uint32_t env_cap = (uint32_t)options().opt_blocks;
     // measured: base.json (239 k chunks) 256 / 512 / 1024 blocks = 28.1 / 23.7 / 26.2 us; T = 2^22 (13.2 M chunks) 512 / 2048 / 8192 / 32768 blocks = 368 / 244 / 251 / 406 us
     uint32_t cap = chunks / (256u * 8u); if (cap < 512u) cap = 512u; if (cap > 2048u) cap = 2048u; if (env_cap) cap = env_cap;
     uint32_t blocks = (chunks + 255) / 256; if (blocks > cap) blocks = cap; if (blocks < 1u) blocks = 1u;     // ~2 chunks per thread at base.json size: measured best (256: 28.1, 512: 23.7, 1024: 26.2 us)
     // dense = every level goes through the LDS scatter, i.e. tables of at most 2^18 entries that a 131 072-sample batch covers
-    if (p.gpart && p.all_levels_dense) hipLaunchKernelGGL((k_optimizer<true, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx);
-    else if (p.ema_step) hipLaunchKernelGGL((k_optimizer<false, true>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx);
-    else hipLaunchKernelGGL((k_optimizer<false, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx);
+    if (p.gpart && p.all_levels_dense) hipLaunchKernelGGL((k_optimizer<true, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx, n_bins);
+    else if (p.ema_step) hipLaunchKernelGGL((k_optimizer<false, true>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx, n_bins);
+    else hipLaunchKernelGGL((k_optimizer<false, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx, n_bins);
 }
 
 }  // namespace mon

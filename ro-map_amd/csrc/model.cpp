@@ -38,7 +38,7 @@ static long* option_slot(const char* name) {
         { "backend", &Options::backend }, { "use_graph", &Options::use_graph }, { "lazy_ema", &Options::lazy_ema }, { "big_switch", &Options::big_switch },
         { "touched_flags", &Options::touched_flags }, { "lds_scatter", &Options::lds_scatter }, { "fold_reduce", &Options::fold_reduce }, { "fold_next", &Options::fold_next },
         { "fused_grid", &Options::fused_grid }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate },
-        { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner } };
+        { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner }, { "scatter_bins", &Options::scatter_bins } };
     for (const auto& e : tab) if (name && std::strcmp(name, e.n) == 0) return &(g_options.*(e.f));
     return nullptr;
 }
@@ -189,6 +189,8 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     m.oc.instance_id = (uint32_t)(uint8_t)class_id;                 // nerf.cu:75,158
     m.oc.R = (uint32_t)cfg.rays_per_batch; m.oc.S = (uint32_t)cfg.n_samples; m.oc.use_depth = cfg.use_depth && ds->use_depth;
     m.oc.sample_seed = cfg.sample_seed; m.oc.loss_scale = cfg.loss_scale;
+    m.n_bins = kDefaultScatterBins;
+    if (options().scatter_bins > 16) { const uint32_t cap = scatter_bins_max(m.oc.R); while (m.n_bins * 2u <= (uint32_t)options().scatter_bins && m.n_bins * 2u <= cap) m.n_bins *= 2u; }
     m.opt = OptimConst{ cfg.beta1, cfg.beta2, cfg.epsilon, cfg.l2_reg, cfg.ema_decay, cfg.loss_scale, cfg.decay_base, std::log2(cfg.beta1), std::log2(cfg.beta2), std::log2(cfg.ema_decay), cfg.decay_start, cfg.decay_interval, m.nd.n_mlp, m.n_params };
     { const int rcs = stream_acquire(m.device, &m.train_stream); if (rcs) return rcs; }
     // ---- parameters (ResetNetwork :1286-1342; Trainer init)
@@ -394,16 +396,16 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
         } else {
             if (m.scatter_pending) hipMemsetAsync(m.d_state->n_scatter, 0, sizeof(m.d_state->n_scatter), s);      // stage-wise debugging: a forward/backward without an optimizer step after it
-            launch_fused_train(s, m.lf, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask, m.d_frag_train, m.big_active ? m.big_switch : 0u, m.d_touched, m.occ_refreshed_iter ? m.d_occ : nullptr);      // (no grid look-ups before the first refresh: every cell is live during the warm-up)
+            launch_fused_train(s, m.lf, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask, m.d_frag_train, m.big_active ? m.big_switch : 0u, m.d_touched, m.occ_refreshed_iter ? m.d_occ : nullptr, m.n_bins);      // (no grid look-ups before the first refresh: every cell is live during the warm-up)
             m.scatter_pending = true;
         }
     }
     if ((stages & 2) && m.backend == 1) {
         const bool fold_reduce = options().fold_reduce != 0;
         const bool folded = m.lds_mask && fold_reduce && grid_scatter_sums_partials(m.lt, m.nd);   // the scatter workgroups also sum the dW partial rows
-        if (m.lds_mask) { ProfScope ps(m, MON_K_SCATTER); launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.d_gpart, m.n_grid / 2, m.d_state,
+        if (m.lds_mask) { ProfScope ps(m, MON_K_SCATTER); launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_gpart, m.n_grid / 2, m.d_state,
                                                                                 folded ? m.d_dw_partials : nullptr, fused_train_grid(m.nd, m.oc.R), m.P.gmlp); }
-        if (m.big_active) { ProfScope ps(m, MON_K_SCATTER); launch_big_scatter(s, m.lt, m.lf, m.nd, m.lds_mask, m.d_de_soa, m.d_x_soa, B, m.d_state, m.big_switch, m.d_big_ws, m.P.ggrid, m.d_touched ? m.d_touched + (m.nd.n_mlp >> 3) : nullptr); }
+        if (m.big_active) { ProfScope ps(m, MON_K_SCATTER); launch_big_scatter(s, m.lt, m.lf, m.nd, m.lds_mask, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_state, m.big_switch, m.d_big_ws, m.P.ggrid, m.d_touched ? m.d_touched + (m.nd.n_mlp >> 3) : nullptr); }
         if (!folded) { ProfScope ps(m, MON_K_REDUCE); launch_reduce_partials(s, m.d_dw_partials, fused_train_grid(m.nd, m.oc.R), m.nd.n_mlp + 64, m.nd.n_mlp, m.P.gmlp, m.d_state); }
     }
     if (stages & 4) {      // Trainer::optimizer_step :1644
@@ -422,7 +424,7 @@ static void enqueue_iteration(Model& m, int stages) {
             nx.cand_blocks = (m.oc.R + 255) / 256; nx.frag_image = m.d_frag_train; nx.fd = FragDims{ m.nd.Epad, m.nd.W, m.nd.NH, m.nd.L };
             nx.b = m.B; nx.ds = m.ds->ptrs(); nx.oc = m.oc;
         }
-        launch_optimizer(s, P, m.opt, m.d_state, nx); m.scatter_pending = false;
+        launch_optimizer(s, P, m.opt, m.d_state, nx, m.n_bins); m.scatter_pending = false;
         m.next_ready = (m.backend == 1 && fold);
     }
 }

@@ -21,10 +21,14 @@ struct DevState {
     float loss_sum;      // sum of per-ray losses of the current batch (SumLoss, nerf_model.cu:1231-1253)
     uint32_t ticket;     // last-block-done counter of the optimizer kernel
     uint32_t skipped;    // batches skipped because n_valid == 0
-    uint32_t n_scatter[16];   // fused backend: samples with a non-zero dL/dO handed to k_grid_scatter this iteration, per ray bin (ray & 15): slot counters, reset by the optimizer's last block
+    uint32_t n_scatter_now;   // gradient-carrying samples of the CURRENT iteration (written by k_grid_scatter; the optimizer's last block makes it n_scatter_last, so every kernel of an iteration sees the same previous count)
+    uint32_t reserved_bins[15];
     uint32_t n_scatter_last;  // their sum in the last completed iteration (reporting)
     uint32_t n_scatter_total; // running sum over all iterations, modulo 2^32 (reporting: differences over a measurement window)
     float ema_deb_old, ema_deb_new;   // EMA debias factors of the NEXT optimizer step (1 - d^(t-1), 1 / (1 - d^t)); the last block of a step leaves them for the following one
+    uint32_t n_scatter[2 * kMaxScatterBins * kScatterCounterStride];   // TWO sets (iteration parity: k_fused_train(i) counts in set i & 1, k_grid_scatter(i) reads it and clears the other one for
+                                           // iteration i + 1), counter of bin b at [set * kMaxScatterBins * stride + b * stride]: one 64-byte line each -- returning atomics on one line serialise in its L2 channel.  fused backend: samples with a non-zero dL/dO handed to k_grid_scatter this iteration, per ray bin (ray & (bins - 1)): slot counters, reset by the
+                                           // optimizer's last block.  Up to 128 bins: a wave reserves its slots with one returning atomic per ray, and 4096 rays on 16 counters cost 7 us of k_fused_train
 };
 
 // ---- dataset pointers (HBM layout: one slab per kind, frame-major)
@@ -95,7 +99,7 @@ enum {
 // Process-wide test and tuning switches (mon_set_option, include/mon_core.h); defaults are the product behaviour.
 struct Options {
     long backend = -1, use_graph = 0, lazy_ema = -1, big_switch = 16384, touched_flags = 1, lds_scatter = 1, fold_reduce = 1, fold_next = 1,
-         fused_grid = 0, opt_blocks = 0, fused_ablate = 0, offline_outer = 10, offline_inner = 500;
+         fused_grid = 0, opt_blocks = 0, fused_ablate = 0, offline_outer = 10, offline_inner = 500, scatter_bins = 0;
 };
 Options& options();
 int option_set(const char* name, long value);
@@ -126,7 +130,7 @@ void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, u
 void launch_copy_params(hipStream_t s, const uint16_t* src, uint16_t* dst, uint32_t n);
 
 // optimizer (kernels_optim.hip)
-void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx);
+void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx, uint32_t n_bins);
 void launch_ema_finalize(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, const DevState* st);
 void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_partials, uint32_t stride, uint32_t n_mlp, float* gmlp, DevState* st);
 
@@ -135,16 +139,16 @@ constexpr uint32_t kMaxFusedGrid = 512;       // workgroups of k_fused_train (= 
 bool fused_supported(const NetDims& nd, uint32_t S, uint32_t R);
 uint32_t fused_train_grid(const NetDims& nd, uint32_t R);
 void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
-                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched, const uint32_t* occ_bits);
+                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched, const uint32_t* occ_bits, uint32_t n_bins);
 void launch_occupancy_update(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const ObjectConst& oc, uint16_t* frag_image, float raw_threshold, uint32_t* tmp, uint32_t* bits);
 uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl);
 uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd);
 bool grid_scatter_sums_partials(const LevelTable& lt, const NetDims& nd);
-void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
+void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint32_t n_bins, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
                          const float* partials_or_null, uint32_t n_partials, float* gmlp);   // partials != null: also sums the dW partial rows (k_reduce_partials folded in)
 size_t big_scatter_workspace_bytes(const LevelTable& lt, const NetDims& nd, uint32_t lds_mask, uint32_t B);
 void launch_big_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, uint32_t lds_mask, const uint16_t* de_soa, const float* x_soa, uint32_t B,
-                        const DevState* st, uint32_t big_switch, void* workspace, uint16_t* ggrid, uint8_t* touched_grid);
+                        uint32_t n_bins, const DevState* st, uint32_t big_switch, void* workspace, uint16_t* ggrid, uint8_t* touched_grid);
 void launch_fused_render(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask, uint16_t* frag_image, int build_image);
 void launch_build_frag_image(hipStream_t s, const uint16_t* params, const NetDims& nd, uint16_t* image);
 void launch_candidates_and_frags(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st, const uint16_t* params, const NetDims& nd, uint16_t* frag_image);
@@ -176,6 +180,7 @@ struct Model {
     uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr;       // compacted dL/dE rows [L][B] and positions [B] float4 for the scatter kernels
     uint16_t* d_gpart = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0;   // k_grid_scatter: partial tables, plan, levels it covers
     uint16_t* d_frag_train = nullptr; uint16_t* d_frag_render = nullptr;           // MFMA A-fragment images (training weights / inference weights)
+    uint32_t n_bins = 16;                                         // ray bins of the compacted gradient rows (scatter_bins(R) unless the option caps it)
     uint32_t* d_ema_step = nullptr; uint8_t* d_touched = nullptr;                  // lazy EMA bookkeeping, chunk flags (ParamPtrs)
     uint8_t* d_big_ws = nullptr; uint32_t big_switch = 0; bool big_active = false; // kernels_bigscatter.hip: workspace, switch point, launched in this train call
     uint32_t *d_occ = nullptr, *d_occ_tmp = nullptr; uint16_t* d_frag_occ = nullptr; float occ_raw_threshold = 0.f; uint32_t occ_refreshed_iter = 0;   // occupancy grid (cfg.occupancy_skip)
