@@ -52,11 +52,7 @@ __device__ __forceinline__ int unit_of_slot(int s, int h, int j) { return 32 * (
 #ifndef MON_ENCODE_BATCH
 #define MON_ENCODE_BATCH 4
 #endif
-// experiment switches (tools/variant_build.sh -D...): MON_V_GATHER 0 = both index forms + select per corner, 1 = scalar branch on the level kind,
-// 2 = 1 + the level's table offset in the buffer load's SGPR offset; MON_V_SCALAR 1 = wave-uniform ray bookkeeping pinned to SGPRs
-#ifndef MON_V_GATHER
-#define MON_V_GATHER 1
-#endif
+// experiment switches (tools/variant_build.sh -D...): MON_V_SCALAR 1 = wave-uniform ray bookkeeping pinned to SGPRs
 #ifndef MON_V_SCALAR
 #define MON_V_SCALAR 0          // measured: -2 us with the bookkeeping left on the vector unit (100 SGPRs were already in use; the scalar version spills them into VGPR lanes)
 #endif
@@ -72,6 +68,10 @@ __device__ __forceinline__ int unit_of_slot(int s, int h, int j) { return 32 * (
 #define MON_UNIFORM(x) (x)
 #endif
 constexpr int kEncodeBatch = MON_ENCODE_BATCH;
+#ifndef MON_V_STAGGER
+#define MON_V_STAGGER 0
+#endif
+constexpr uint32_t kDefaultStagger = MON_V_STAGGER;
 
 template <int EPAD, int W, int NH> struct FusedShape {
     static constexpr int MB = W / 32;            // 32-row M blocks of a hidden layer
@@ -121,6 +121,7 @@ struct FusedArgs {
     uint8_t* touched_grid;      // per 4 grid entries (= one 8-parameter optimizer chunk): set to 1 next to every global atomic, or nullptr (see ParamPtrs::touched)
     uint32_t big_switch;        // > 0: while big_levels_binned(st, big_switch) holds, EVERY level's dE rows are stored (kernels_bigscatter.hip bins the large levels)
     uint32_t n_bins;            // ray bins of the compacted gradient rows (scatter_bins(R), host-chosen)
+    uint32_t stagger;           // bits 0-15: start delay of the second wave group in units of 1024 cycles, bits 16-17: how the groups are formed (see k_fused_train)
     const uint32_t* occ_bits;   // occupancy-grid skipping (mon_config::occupancy_skip, default off): kOccRes^3 bits, 1 = the cell may hold density; nullptr = evaluate every sample
 };
 
@@ -204,8 +205,28 @@ struct TileState {
     float out4[4];
 };
 
+// Per-level constants of the encode, one level per LANE: lane h * 32 + il holds level h * LPH + il, the level half-wave h owns in level pair il (a pair past the
+// last level holds a 1-entry dummy of level 0).  The gather code fetches them with v_readlane at compile-time lane numbers: no scalar loads (and no lgkmcnt waits) inside
+// the ray loop, and none of the 7 x 16 constants pinned in SGPRs (the kernel runs at the SGPR limit; as kernel arguments they were re-loaded from the argument segment
+// for every level of every ray).
+struct LevelRegs { float scale; uint32_t size, my, mz, mask, off4, hashed; };
+// the same registers filled from the kernel ARGUMENTS (scalar loads + one select per field and level): nothing to wait for but the argument segment, no LDS copy, no barrier
+__device__ __forceinline__ LevelRegs load_level_regs_uniform(const LevelFast& klt, int L, int lane) {
+    const int LPH = (L + 1) >> 1;
+    LevelRegs r; r.scale = klt.scale[0]; r.size = 1u; r.my = klt.my[0]; r.mz = klt.mz[0]; r.mask = 0u; r.off4 = 0u; r.hashed = 1u;      // the dummy level: always entry 0
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; ++l) {
+        const bool here = l < L && lane == ((l < LPH) ? l : 32 + l - LPH);
+        r.scale = here ? klt.scale[l] : r.scale; r.size = here ? klt.size[l] : r.size; r.my = here ? klt.my[l] : r.my; r.mz = here ? klt.mz[l] : r.mz;
+        r.mask = here ? klt.mask[l] : r.mask; r.off4 = here ? klt.offset[l] * 4u : r.off4; r.hashed = here ? klt.hashed[l] : r.hashed;
+    }
+    return r;
+}
+__device__ __forceinline__ uint32_t lane_u(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ float lane_f(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
+
 template <int EPAD, int W, int NH, bool MASKED = false>
-__device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const half_t* frags, const LevelFast& klt, const half2_t* __restrict__ table,
+__device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const half_t* frags, const LevelRegs& lr, const half2_t* __restrict__ table, uint32_t table_bytes,
                                              int L, const float x[3], int lane, TimingCtx* tc = nullptr, bool live = true) {
     using S = FusedShape<EPAD, W, NH>;
     const int h = lane >> 5, LPH = (L + 1) >> 1;      // `live` = false: this lane's sample sits in a cell the occupancy grid marks empty -- its gathers are not issued (features 0)
@@ -217,91 +238,66 @@ __device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const h
     //      (x ^ h keeps the upper bits).  So pairing them in one instruction halves the lines per level; a
     //      v_permlane32_swap per value then hands each half the 8 corners of the level it owns, and the interpolation runs
     //      the same chain in the same order as before (bit-identical results).
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half2_t*>(table), 0, (int)(klt.offset[L] * 4u), 0x00020000);
-    auto half_gather = [&](int level, uint32_t (&r)[4]) {                              // `level` is wave-uniform: constants come from SGPRs, the hashed / dense choice is a scalar branch
-        const float scale = klt.scale[level];
-        const uint32_t size = klt.size[level], my = klt.my[level], mz = klt.mz[level], mask = klt.mask[level], off4 = klt.offset[level] * 4u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half2_t*>(table), 0, (int)table_bytes, 0x00020000);
+    auto half_gather = [&](int slot, uint32_t (&r)[4]) {                               // `slot` = the lane of `lr` that holds this level: a compile-time number
+        const float scale = lane_f(lr.scale, slot);
+        const uint32_t size = lane_u(lr.size, slot), my = lane_u(lr.my, slot), mz = lane_u(lr.mz, slot), mask = lane_u(lr.mask, slot), off4 = lane_u(lr.off4, slot);
         uint32_t pg[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) pg[d] = (uint32_t)(int32_t)floorf(fmaf(scale, x[d], 0.5f));
         const uint32_t ax = pg[0] + (uint32_t)h, y0 = pg[1] * my, z0 = pg[2] * mz;
         const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
         if (MASKED && !live) return;                                                    // (r[] was zeroed by the caller; an exec-masked load costs no L2 request)
-#if MON_V_GATHER == 0
-        const bool hashed = klt.hashed[level] != 0u; const uint32_t off = klt.offset[level];
+        // the hashed / dense choice is a scalar branch around index arithmetic ONLY: the four loads sit after the join (a load inside either arm made the
+        // compiler drain vmcnt at the top of the other one -- every dense level waited for all gathers in flight)
+        uint32_t idx[4];
+        if (lane_u(lr.hashed, slot) != 0u) {                                            // hashed levels hold 2^T entries: the mask IS the modulo
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t ih = ax ^ ay[j & 1] ^ az[j >> 1], id = ax + ay[j & 1] + az[j >> 1];
-            uint32_t idx = (hashed ? ih : id) & mask;
-            idx -= (idx >= size) ? size : 0u;
-            idx = min(idx, size - 1u);
-            r[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (off + idx) * 4u, 0, 0);
-        }
-#else
-        if (klt.hashed[level] != 0u) {                                                  // hashed levels hold 2^T entries: the mask IS the modulo
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t idx = (ax ^ ay[j & 1] ^ az[j >> 1]) & mask;
-#if MON_V_GATHER == 2
-                r[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, idx << 2, off4, 0);
-#else
-                r[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (idx << 2) + off4, 0, 0);
-#endif
-            }
+            for (int j = 0; j < 4; ++j) idx[j] = (ax ^ ay[j & 1] ^ az[j >> 1]) & mask;
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                uint32_t idx = (ax + ay[j & 1] + az[j >> 1]) & mask;
-                idx -= (idx >= size) ? size : 0u;                                       // dense sizes are not powers of two: index < 2 * size, so % size is one subtract
-                idx = min(idx, size - 1u);                                              // memory safety for positions far outside [0,1]^3 (never produced by the sampler)
-#if MON_V_GATHER == 2
-                r[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, idx << 2, off4, 0);
-#else
-                r[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (idx << 2) + off4, 0, 0);
-#endif
+                uint32_t i = (ax + ay[j & 1] + az[j >> 1]) & mask;
+                i -= (i >= size) ? size : 0u;                                           // dense sizes are not powers of two: index < 2 * size, so % size is one subtract
+                idx[j] = min(i, size - 1u);                                             // memory safety for positions far outside [0,1]^3 (never produced by the sampler)
             }
         }
-#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (idx[j] << 2) + off4, 0, 0);
     };
+    // All control flow around the loads is compile-time (pairs past the last level gather the dummy level: one line per instruction), so the compiler's vmcnt
+    // bookkeeping stays exact: a pair's interpolation waits for ITS eight loads only, and the next pair's loads are issued into the registers it frees
+    // (runtime guards around the gather groups made every first use wait for the whole batch).
     constexpr int EB = (S::LLV < kEncodeBatch) ? S::LLV : kEncodeBatch;              // level pairs in flight
+    uint32_t ra[EB][4], rb[EB][4];
+    auto issue = [&](int il) {
 #pragma unroll
-    for (int b0 = 0; b0 < S::LLV; b0 += EB) {
-        uint32_t ra[EB][4], rb[EB][4];
+        for (int j = 0; j < 4; ++j) { ra[il % EB][j] = 0u; rb[il % EB][j] = 0u; }      // (dead unless MASKED)
+        half_gather(il, ra[il % EB]); half_gather(32 + il, rb[il % EB]);
+    };
 #pragma unroll
-        for (int ib = 0; ib < EB; ++ib) {
-            const int il = b0 + ib;
+    for (int il = 0; il < EB; ++il) issue(il);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { ra[ib][j] = 0u; rb[ib][j] = 0u; }
-            if (il < LPH) {                                                             // uniform
-                half_gather(il, ra[ib]);
-                if (LPH + il < L) half_gather(LPH + il, rb[ib]);
-            }
+    for (int il = 0; il < S::LLV; ++il) {
+        typedef unsigned u2v __attribute__((ext_vector_type(2)));
+        uint32_t c0[4], c1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const u2v sw = __builtin_amdgcn_permlane32_swap(ra[il % EB][j], rb[il % EB][j], false, false); c0[j] = sw.x; c1[j] = sw.y; }
+        if (il + EB < S::LLV) issue(il + EB);
+        const float scale = h ? lane_f(lr.scale, 32 + il) : lane_f(lr.scale, il);
+        float pos[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, x[d], 0.5f); pos[d] = q - floorf(q); }
+        const float wx[2] = { 1.f - pos[0], pos[0] }, wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const half2_t v = __builtin_bit_cast(half2_t, (k & 1) ? c1[k >> 1] : c0[k >> 1]);
+            const float wgt = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
+            a0 = fmaf(wgt, (float)v.x, a0); a1 = fmaf(wgt, (float)v.y, a1);
         }
-#pragma unroll
-        for (int ib = 0; ib < EB; ++ib) {
-            const int il = b0 + ib, level = h * LPH + il;
-            float a0 = 0.f, a1 = 0.f;
-            if (il < LPH) {
-                typedef unsigned u2v __attribute__((ext_vector_type(2)));
-                uint32_t c0[4], c1[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const u2v sw = __builtin_amdgcn_permlane32_swap(ra[ib][j], rb[ib][j], false, false); c0[j] = sw.x; c1[j] = sw.y; }
-                if (level < L) {
-                    const float scale = h ? klt.scale[(LPH + il < L) ? LPH + il : il] : klt.scale[il];
-                    float pos[3];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, x[d], 0.5f); pos[d] = q - floorf(q); }
-                    const float wx[2] = { 1.f - pos[0], pos[0] }, wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const half2_t v = __builtin_bit_cast(half2_t, (k & 1) ? c1[k >> 1] : c0[k >> 1]);
-                        const float wgt = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
-                        a0 = fmaf(wgt, (float)v.x, a0); a1 = fmaf(wgt, (float)v.y, a1);
-                    }
-                }
-            }
-            ts.ef[2 * il] = (half_t)a0; ts.ef[2 * il + 1] = (half_t)a1;
-        }
+        const bool real = il < LPH && h * LPH + il < L;                                 // (a select, not a branch)
+        ts.ef[2 * il] = real ? (half_t)a0 : (half_t)0.f; ts.ef[2 * il + 1] = real ? (half_t)a1 : (half_t)0.f;
     }
     tstamp(tc, 2);
     // ---- layer 0
@@ -384,16 +380,25 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
 #else
     TimingCtx* tc = nullptr;
 #endif
-    build_fragments<EPAD, W, NH>(frags, llt, a, true);
-    // the wave index is uniform by construction, but anything derived from threadIdx is divergent to the compiler: pin it to an SGPR so that the ray
-    // bookkeeping below (ray index, candidate search, the candidate record, the background colour's RNG) runs on the scalar unit and in scalar registers
+    // ---- prologue.  Everything a wave needs before its first gather is requested up front, and only the weight fragments (first read by the MLP) wait for
+    //      the workgroup barrier: the iteration counter, the candidates' ballot words, the fragment image.
     const int wave = MON_UNIFORM(threadIdx.x >> 6), lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+    const int L = a.nd.L, LPH = (L + 1) >> 1;
+    const uint32_t R = (a.ablate & 8u) ? 0u : a.oc.R, iter = a.st->iter;
+    // ---- ray compaction (fill_rollover_rays :280-294 without a kernel of its own): training ray j is valid candidate number (j mod n_valid) in candidate
+    //      order.  Up to 4096 candidates (64 ballot words) every WAVE keeps the words and their exclusive prefix in registers, one word per lane, and finds a
+    //      ray's candidate with a ballot and two v_readlanes; larger batches go through a table in LDS built by wave 0.
+    const uint32_t nwords = a.oc.R >> 6;                                           // <= 256 (fused_supported)
+    const bool small = nwords <= 64u;                                              // uniform
+    unsigned long long my_word = 0ull;
+    if (small && (uint32_t)lane < nwords) my_word = a.b.mask[lane];
+    const LevelRegs lregs = load_level_regs_uniform(a.lt, L, lane); const uint32_t table_bytes = a.lt.offset[L] * 4u;      // (from the argument segment: it ends up in the buffer descriptor, which must be scalar)
+    build_fragments<EPAD, W, NH>(frags, llt, a, true);
     half_t* scr = reinterpret_cast<half_t*>(dyn + wave * S::SCR_BYTES);
     for (int i = 2 * a.nd.L * 32 + lane; i < EPAD * 32; i += 64) scr[S::SCR_E + i] = (half_t)0.f;   // pad feature rows stay zero; every other row is rewritten per ray before it is read
-    // ---- ray compaction table (fill_rollover_rays :280-294 without a kernel of its own): every workgroup scans the
-    //      candidates' 64-bit ballot words; training ray j is valid candidate number (j mod n_valid) in candidate order.
-    const uint32_t nwords = a.oc.R >> 6;                                           // <= 256 (fused_supported)
-    if (wave == 0) {
+    uint32_t my_excl = 0u, nvalid = 0u;
+    if (small) { const uint32_t c = __popcll(my_word), inc = scan_add64_u32(c); my_excl = inc - c; nvalid = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63); }
+    else if (wave == 0) {
         uint32_t carry = 0;
         for (uint32_t base = 0; base < nwords; base += 64) {
             const unsigned long long wd = (base + lane < nwords) ? a.b.mask[base + lane] : 0ull;
@@ -403,13 +408,36 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
         }
         if (lane == 0) cprefix[nwords] = carry;
     }
+    // candidate number `kth` -> candidate index (wave-uniform)
+    const auto select = [&](uint32_t kth) -> uint32_t {
+        unsigned long long wd; uint32_t kk, lo;
+        if (small) {
+            lo = (uint32_t)__popcll(__ballot(my_excl <= kth)) - 1u;                  // the prefix is non-decreasing (lanes past the last word hold the total)
+            wd = ((unsigned long long)lane_u((uint32_t)(my_word >> 32), (int)lo) << 32) | lane_u((uint32_t)my_word, (int)lo); kk = kth - lane_u(my_excl, (int)lo);
+        } else {
+            lo = 0; uint32_t hi = nwords - 1u;
+            while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if ((uint32_t)MON_UNIFORM(cprefix[mid]) <= kth) lo = mid; else hi = mid - 1u; }
+            wd = cwords[lo]; kk = kth - cprefix[lo];
+        }
+        uint32_t pos = 0;
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t c = __popcll(wd & ((1ull << sh) - 1ull)); if (kk >= c) { kk -= c; wd >>= sh; pos += sh; } }
+        return (lo << 6) + pos;
+    };
+    // the candidate's record, one field per lane (rgba, t0, t1, d[3], o[3], depth): ONE load, requested a whole ray ahead of its use
+    const char* rec_base; uint32_t rec_mul = 1u;
+    {   const void* fb = lane == 0 ? (const void*)a.b.cand_rgba : lane == 1 ? (const void*)a.b.cand_t0 : lane == 2 ? (const void*)a.b.cand_t1
+                       : lane < 6 ? (const void*)(a.b.cand_d + (lane - 3)) : lane < 9 ? (const void*)(a.b.cand_o + (lane - 6)) : (const void*)a.b.cand_depth;
+        rec_base = reinterpret_cast<const char*>(fb); if (lane >= 3 && lane < 9) rec_mul = 3u; }
+    const auto load_record = [&](uint32_t cand) -> uint32_t { uint32_t v = 0u; if (lane < 10) v = *reinterpret_cast<const uint32_t*>(rec_base + 4u * (size_t)(cand * rec_mul)); return v; };
+    const uint32_t ray0 = blockIdx.x * S::WAVES + wave;
+    uint32_t cand = 0u, rec = 0u;
+    if (small && nvalid != 0u && ray0 < R) { cand = select(ray0 % nvalid); rec = load_record(cand); }
     __syncthreads();
-    const uint32_t nvalid = cprefix[nwords];
+    if (!small) { nvalid = cprefix[nwords]; if (nvalid != 0u && ray0 < R) { cand = select(ray0 % nvalid); rec = load_record(cand); } }
     if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->n_valid = nvalid; a.st->loss_sum = 0.f; }
     if (nvalid == 0u) return;                                                        // batch skipped (uniform over the grid)
 
-    const int L = a.nd.L, LPH = (L + 1) >> 1;
-    const uint32_t R = (a.ablate & 8u) ? 0u : a.oc.R, iter = a.st->iter;
     const uint32_t lds_level_mask = (ATOMIC_LEVELS && a.big_switch != 0u && big_levels_binned(a.st->n_scatter_last, a.big_switch)) ? 0xffffffffu : a.lds_level_mask;   // wave-uniform
     const half2_t* table = reinterpret_cast<const half2_t*>(a.params + a.nd.n_mlp);
     typedef __attribute__((address_space(1))) half2_t gh2;
@@ -427,28 +455,33 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
             for (int nb = 0; nb < S::MB; ++nb) dW1[mb][nb] = float16_t{ 0 };
     }
     float loss_acc = 0.f;
+    // ---- phase stagger.  All waves of a CU share one texture-address path, and a ray's 64 gather instructions keep it busy for ~1.5 us; the waves start together and
+    //      their phases have equal lengths, so they would ALL gather, then ALL run the MLP / composite / backward with the address path idle.  Half of the waves therefore
+    //      start late by about one gather phase: from then on one group computes while the other gathers.
+    if (a.stagger & 0xffffu) {
+        const uint32_t mode = (a.stagger >> 16) & 3u;
+        const uint32_t slot = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) ;      // HW_ID.wave_id: this wave's slot on its SIMD
+        const bool late = mode == 0u ? (slot & 1u) != 0u : mode == 1u ? blockIdx.x >= (gridDim.x >> 1) : mode == 2u ? (wave & 1) != 0 : ((blockIdx.x >> 3) & 1u) != 0u;
+        if (late) for (uint32_t i = 0; i < (a.stagger & 0xffffu); ++i) __builtin_amdgcn_s_sleep(16);
+    }
     tstamp(tc, 0);
 
-    for (uint32_t ray = blockIdx.x * S::WAVES + wave; ray < R; ray += gridDim.x * S::WAVES) {
-        // ---- which candidate is this ray (wave-uniform binary search over the prefix table + in-word select)
-        const uint32_t kth = ray % nvalid;
-        uint32_t lo = 0, hi = nwords - 1u;
-        while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if ((uint32_t)MON_UNIFORM(cprefix[mid]) <= kth) lo = mid; else hi = mid - 1u; }
-        uint32_t cand;
-        { unsigned long long wd = cwords[lo]; uint32_t kk = kth - cprefix[lo], pos = 0;
-#pragma unroll
-          for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t c = __popcll(wd & ((1ull << sh) - 1ull)); if (kk >= c) { kk -= c; wd >>= sh; pos += sh; } }
-          cand = (uint32_t)MON_UNIFORM((lo << 6) + pos); }          // (the table lives in LDS: the reads came back in VGPRs)
-        const uint32_t rgba = a.b.cand_rgba[cand];
+    for (uint32_t ray = ray0; ray < R; ray += gridDim.x * S::WAVES) {
+        // ---- this ray's candidate record arrived while the previous ray was processed; request the next one's
+        const uint32_t kth = ray % nvalid, cand_cur = cand;
+        const uint32_t rgba = lane_u(rec, 0);
+        const float t0 = __builtin_bit_cast(float, lane_u(rec, 1)), t1 = __builtin_bit_cast(float, lane_u(rec, 2)), tdp = __builtin_bit_cast(float, lane_u(rec, 9));
+        const float rd[3] = { __builtin_bit_cast(float, lane_u(rec, 3)), __builtin_bit_cast(float, lane_u(rec, 4)), __builtin_bit_cast(float, lane_u(rec, 5)) };
+        const float ro[3] = { __builtin_bit_cast(float, lane_u(rec, 6)), __builtin_bit_cast(float, lane_u(rec, 7)), __builtin_bit_cast(float, lane_u(rec, 8)) };
+        { const uint32_t nxt = ray + gridDim.x * S::WAVES; if (nxt < R) { cand = select(nxt % nvalid); rec = load_record(cand); } }
         const bool is_obj = (rgba >> 24) != 0u;
         // ---- sample position (GenerateInputPoints, nerf_model.cu:553-566)
-        const float t0 = a.b.cand_t0[cand], t1 = a.b.cand_t1[cand];
         const float dtr = (t1 - t0) / 32.0f;
         const uint32_t s_idx = ray * 32u + (uint32_t)n;
         const float t = fmaf(dtr, (float)n + rand01(a.oc.sample_seed, kStreamDt, iter, s_idx), t0);
         float x[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { const float p = fmaf(t, a.b.cand_d[3 * cand + d], a.b.cand_o[3 * cand + d]); x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
+        for (int d = 0; d < 3; ++d) { const float p = fmaf(t, rd[d], ro[d]); x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
 
         tstamp(tc, 1);
         // occupancy-grid skipping (default off): a sample whose cell the grid marks empty is not evaluated -- no gathers, alpha = 0, no gradient
@@ -458,7 +491,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
             live = ((a.occ_bits[((cz * kOccRes + cy) * kOccRes + cx) >> 5] >> (cx & 31u)) & 1u) != 0u;
         }
         TileState<EPAD, W, NH> ts;
-        if (!OCC || __ballot(live) != 0ull) tile_forward<EPAD, W, NH, OCC>(ts, frags, a.lt, table, L, x, lane, tc, live);
+        if (!OCC || __ballot(live) != 0ull) tile_forward<EPAD, W, NH, OCC>(ts, frags, lregs, table, table_bytes, L, x, lane, tc, live);
         else {                                                                           // the whole ray crosses empty cells only: nothing to evaluate
 #pragma unroll
             for (int i = 0; i < EPAD / 2; ++i) ts.ef[i] = (half_t)0.f;
@@ -490,7 +523,6 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
         const float tg0 = is_obj ? (float)(rgba & 0xffu) / 255.0f : bg0, tg1 = is_obj ? (float)((rgba >> 8) & 0xffu) / 255.0f : bg1, tg2 = is_obj ? (float)((rgba >> 16) & 0xffu) / 255.0f : bg2;
         const float e0 = rgb0 - tg0, e1 = rgb1 - tg1, e2 = rgb2 - tg2;
         const float g0 = 2.f * e0, g1 = 2.f * e1, g2 = 2.f * e2;
-        const float tdp = a.b.cand_depth[cand];
         float dl_dd = 0.f; if (tdp > 0.f) dl_dd = 0.5f * ((dep - tdp >= 0.f) ? 1.f : -1.f);
         const float mean_loss = (e0 * e0 + e1 * e1 + e2 * e2) / 3.f;
         const float loss = is_obj ? mean_loss + dl_dd * (dep - tdp) + (1.f - mask) : mean_loss + mask;
@@ -536,8 +568,8 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
         }
         if (DUMP) {
             if (lane == 0) {
-                for (int d = 0; d < 3; ++d) { a.b.ray_o[3 * ray + d] = a.b.cand_o[3 * cand + d]; a.b.ray_d[3 * ray + d] = a.b.cand_d[3 * cand + d]; }
-                a.b.ray_t0[ray] = t0; a.b.ray_t1[ray] = t1; a.b.ray_dn[ray] = a.b.cand_dn[cand]; a.b.ray_flag[ray] = is_obj ? 1 : 0; a.b.target_depth[ray] = tdp;
+                for (int d = 0; d < 3; ++d) { a.b.ray_o[3 * ray + d] = a.b.cand_o[3 * cand_cur + d]; a.b.ray_d[3 * ray + d] = a.b.cand_d[3 * cand_cur + d]; }
+                a.b.ray_t0[ray] = t0; a.b.ray_t1[ray] = t1; a.b.ray_dn[ray] = a.b.cand_dn[cand_cur]; a.b.ray_flag[ray] = is_obj ? 1 : 0; a.b.target_depth[ray] = tdp;
                 a.b.bgcol[3 * ray] = bg0; a.b.bgcol[3 * ray + 1] = bg1; a.b.bgcol[3 * ray + 2] = bg2; a.b.target[3 * ray] = tg0; a.b.target[3 * ray + 1] = tg1; a.b.target[3 * ray + 2] = tg2;
             }
             if (h == 0) {
@@ -700,6 +732,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
     //      Each wave stores its accumulators to a private LDS copy (independent plain stores; read-modify-write
     //      rounds serialise on LDS latency), then all threads sum the four copies element-wise.
     __syncthreads();
+    if (a.ablate & 32u) return;                                                      // timing experiments: no dW reduction (wrong results)
     const int col = n;
     const auto store_copy = [&](float* red) {
 #pragma unroll
@@ -1056,6 +1089,7 @@ __global__ void __launch_bounds__(256) k_fused_render(FusedArgs a, uint32_t n_ra
     const int wave = MON_UNIFORM(threadIdx.x >> 6), lane = threadIdx.x & 63, n = lane & 31;
     const int L = a.nd.L; const uint32_t S2 = 2u * a.oc.S;      // 64
     const half2_t* table = reinterpret_cast<const half2_t*>(a.params + a.nd.n_mlp);
+    const LevelRegs lregs = load_level_regs_uniform(a.lt, L, lane); const uint32_t table_bytes = a.lt.offset[L] * 4u;      // (from the argument segment: it ends up in the buffer descriptor, which must be scalar)
     for (uint32_t ray = blockIdx.x * S::WAVES + wave; ray < n_rays; ray += gridDim.x * S::WAVES) {
         float o0 = 1.f, o1 = 1.f, o2 = 1.f, od = 0.f, om_ = 0.f;
         if (a.b.ray_flag[ray]) {
@@ -1069,7 +1103,7 @@ __global__ void __launch_bounds__(256) k_fused_render(FusedArgs a, uint32_t n_ra
 #pragma unroll
                 for (int d = 0; d < 3; ++d) { const float p = fmaf(t, a.b.ray_d[3 * ray + d], a.b.ray_o[3 * ray + d]); x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
                 TileState<EPAD, W, NH> ts;
-                tile_forward<EPAD, W, NH>(ts, frags, a.lt, table, L, x, lane);
+                tile_forward<EPAD, W, NH>(ts, frags, lregs, table, table_bytes, L, x, lane);
                 const float c0 = logistic_f(ts.out4[0]), c1 = logistic_f(ts.out4[1]), c2 = logistic_f(ts.out4[2]), sigma = __expf(ts.out4[3]);
                 float tprev = lane_prev(t, tlast); if (n == 0) tprev = tlast;
                 const float alpha = 1.f - __expf(-sigma * (t - tprev)), omv = 1.f - alpha;
@@ -1106,11 +1140,12 @@ __global__ void __launch_bounds__(256) k_occ_density(FusedArgs a, float raw_thre
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31;
     const half2_t* table = reinterpret_cast<const half2_t*>(a.params + a.nd.n_mlp);
     constexpr uint32_t n_words = kOccRes * kOccRes * kOccRes / 32;
+    const LevelRegs lregs = load_level_regs_uniform(a.lt, a.nd.L, lane); const uint32_t table_bytes = a.lt.offset[a.nd.L] * 4u;
     for (uint32_t word = blockIdx.x * S::WAVES + wave; word < n_words; word += gridDim.x * S::WAVES) {
         const uint32_t cell = word * 32u + (uint32_t)n, cx = cell % kOccRes, cy = (cell / kOccRes) % kOccRes, cz = cell / (kOccRes * kOccRes);
         const float x[3] = { ((float)cx + 0.5f) / (float)kOccRes, ((float)cy + 0.5f) / (float)kOccRes, ((float)cz + 0.5f) / (float)kOccRes };
         TileState<EPAD, W, NH> ts;
-        tile_forward<EPAD, W, NH>(ts, frags, a.lt, table, a.nd.L, x, lane);
+        tile_forward<EPAD, W, NH>(ts, frags, lregs, table, table_bytes, a.nd.L, x, lane);
         const uint32_t occ = (uint32_t)__ballot(lane < 32 && ts.out4[3] > raw_threshold);      // raw channel 3 = log density (network_to_density = exp, nerf_model.cu:49)
         if (lane == 0) bits_out[word] = occ;
     }
@@ -1203,7 +1238,8 @@ static void candidates_frags_t(hipStream_t s, const BatchPtrs& b, const DatasetP
 void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
                         uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched, const uint32_t* occ_bits, uint32_t n_bins) {
     const uint32_t ablate = (uint32_t)options().fused_ablate;
-    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate, touched ? touched + (nd.n_mlp >> 3) : nullptr, big_switch, n_bins, occ_bits };
+    const uint32_t stagger = options().fused_stagger < 0 ? kDefaultStagger : (uint32_t)options().fused_stagger;
+    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate, touched ? touched + (nd.n_mlp >> 3) : nullptr, big_switch, n_bins, stagger, occ_bits };
     const uint32_t grid = fused_train_grid(nd, oc.R);
     MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);
 }

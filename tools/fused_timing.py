@@ -29,11 +29,13 @@ def main():
     import importlib; binding = importlib.import_module(pkg.__name__ + ".binding")
     binding.lib_path = lambda: lib; binding._lib = None
     sc = ss.make_scene(n_views=40, H=480, W=640, f=525.0, seed=0)
+    grid = int(os.environ.get("MON_TIMING_GRID", "512")); pkg.set_option("fused_grid", grid)
     ds, obj = ge.make_problem(pkg, sc, {}); obj.set_backend(1)
-    obj.train(50)
-    t = obj.buffer("tdist")[:2048 * 16].reshape(2048, 16)
+    obj.train(int(os.environ.get("MON_TIMING_STEPS", "50")))
+    t = obj.buffer("tdist")[:grid * 4 * 16].reshape(grid * 4, 16)
+    print("grid %d workgroups: %d rays per wave" % (grid, 4096 // (grid * 4)))
     tot = t[:, :10].sum(1).mean()
-    print("| phase | mean cycles / wave (2 rays) | share |\n|---|---|---|")
+    print("| phase | mean cycles / wave | share |\n|---|---|---|")
     for k, name in enumerate(PH):
         print("| %s | %.0f | %.1f%% |" % (name, t[:, k].mean(), 100 * t[:, k].mean() / tot))
     print("| total | %.0f | |" % tot)
