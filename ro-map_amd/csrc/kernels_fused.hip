@@ -69,7 +69,7 @@ __device__ __forceinline__ int unit_of_slot(int s, int h, int j) { return 32 * (
 #endif
 constexpr int kEncodeBatch = MON_ENCODE_BATCH;
 #ifndef MON_V_STAGGER
-#define MON_V_STAGGER 0
+#define MON_V_STAGGER 0x2000c      // odd waves of every workgroup start 12 x 1024 cycles late (measured: 51.0 -> 47.7 us dense, 45.8 -> 45.0 us late; modes 0, 1, 3 and delays of 4..24 units were slower)
 #endif
 constexpr uint32_t kDefaultStagger = MON_V_STAGGER;
 
@@ -99,11 +99,11 @@ template <int EPAD, int W, int NH> struct FusedShape {
     static constexpr int OFF_W1 = W * EPAD;
     static constexpr int OFF_WO = W * EPAD + (NH - 1) * W * W;
     static constexpr int WAVES = 4;
-#if MON_V_WPS >= 3
-    static constexpr int RED_BYTES = (N_MLP + 64) * 4 * 2;          // two private fp32 copies at a time: the epilogue reduces the waves in two rounds
-#else
-    static constexpr int RED_BYTES = (N_MLP + 64) * 4 * WAVES;      // one private fp32 copy per wave
-#endif
+    // dW partial row in accumulator layout (frag_layout.h acc_param): dW0 tiles, dW1 tiles, the 4 real columns of dWout, then the loss partial
+    static constexpr int ACC_W1 = MB * 1024;
+    static constexpr int ACC_WO = ACC_W1 + (NH == 2 ? MB * MB * 1024 : 0);
+    static constexpr int ACC_COLS = ACC_WO + MB * 128;
+    static constexpr int RED_BYTES = (ACC_COLS + 64) * 4 * WAVES;   // one private fp32 copy per wave
     static constexpr int SMEM_BYTES = FRAG_BYTES + LT_BYTES + ((WAVES * SCR_BYTES > RED_BYTES) ? WAVES * SCR_BYTES : RED_BYTES);
 };
 
@@ -111,7 +111,7 @@ struct FusedArgs {
     LevelFast lt; NetDims nd; ObjectConst oc; BatchPtrs b;
     const uint16_t* params;     // fp16 parameter vector (MLP matrices then grid)
     uint16_t* ggrid;            // fp16 grid gradient table
-    float* partials;            // [gridDim.x][N_MLP + 64] fp32: dW partial sums, slot N_MLP = loss partial
+    float* partials;            // [gridDim.x][ACC_COLS + 64] fp32: dW partial sums in accumulator layout, column ACC_COLS = loss partial
     DevState* st;
     half2_t* de_soa;            // [L][B] dL/dE of the levels scattered through LDS (k_grid_scatter), or nullptr
     float* x_soa;               // [B] float4 {x, y, z, 0}: warped sample positions for k_grid_scatter
@@ -728,54 +728,39 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
         tstamp(tc, 8);
     }
 
-    // ---- reduce the weight-gradient accumulators over the workgroup's waves, write one fp32 partial row.
-    //      Each wave stores its accumulators to a private LDS copy (independent plain stores; read-modify-write
-    //      rounds serialise on LDS latency), then all threads sum the four copies element-wise.
+    // ---- reduce the weight-gradient accumulators over the workgroup's waves, write one fp32 partial row -- in ACCUMULATOR layout (frag_layout.h acc_param):
+    //      each wave stores its registers to a private LDS copy as 16-byte pieces, consecutive lanes at consecutive addresses (no bank conflicts, no
+    //      transposition), then all threads sum the four copies with 16-byte reads and store the row coalesced.  The summing kernel maps columns to parameters.
     __syncthreads();
     if (a.ablate & 32u) return;                                                      // timing experiments: no dW reduction (wrong results)
-    const int col = n;
-    const auto store_copy = [&](float* red) {
+    {
+        float* cp = reinterpret_cast<float*>(dyn) + (size_t)wave * (S::ACC_COLS + 64);
 #pragma unroll
         for (int mb = 0; mb < S::MB; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int u = 32 * mb + rho(h, r);
-                if (col < EPAD) red[u * EPAD + col] = dW0[mb][r];
-                if (col < kOut) red[S::OFF_WO + col * W + u] = dWo[mb][r];
+            for (int rq = 0; rq < 4; ++rq) {
+                *reinterpret_cast<float4_t*>(cp + ((mb * 4 + rq) * 64 + lane) * 4) = float4_t{ dW0[mb][4 * rq], dW0[mb][4 * rq + 1], dW0[mb][4 * rq + 2], dW0[mb][4 * rq + 3] };
+                if (n < kOut) *reinterpret_cast<float4_t*>(cp + S::ACC_WO + ((mb * 4 + rq) * 8 + h * 4 + n) * 4) = float4_t{ dWo[mb][4 * rq], dWo[mb][4 * rq + 1], dWo[mb][4 * rq + 2], dWo[mb][4 * rq + 3] };
                 if constexpr (NH == 2) {
 #pragma unroll
-                    for (int nb = 0; nb < S::MB; ++nb) red[S::OFF_W1 + u * W + 32 * nb + col] = dW1[mb][nb][r];
+                    for (int nb = 0; nb < S::MB; ++nb)
+                        *reinterpret_cast<float4_t*>(cp + S::ACC_W1 + (((mb * S::MB + nb) * 4 + rq) * 64 + lane) * 4) = float4_t{ dW1[mb][nb][4 * rq], dW1[mb][nb][4 * rq + 1], dW1[mb][nb][4 * rq + 2], dW1[mb][nb][4 * rq + 3] };
                 }
             }
-        if (lane == 0) red[S::N_MLP] = loss_acc;
-    };
-    const float* r0 = reinterpret_cast<const float*>(dyn);
-    float* dst = a.partials + (size_t)blockIdx.x * (S::N_MLP + 64);
-#if MON_V_WPS >= 3
-    constexpr int PER = (S::N_MLP + 1 + 255) / 256;
-    float part[PER];
-    for (int round = 0; round < 2; ++round) {
-        if ((wave >> 1) == round) store_copy(reinterpret_cast<float*>(dyn) + (size_t)(wave & 1) * (S::N_MLP + 64));
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < PER; ++q) { const int i = threadIdx.x + q * 256; const float v = (i < S::N_MLP + 1) ? r0[i] + r0[(S::N_MLP + 64) + i] : 0.f; part[q] = round ? part[q] + v : v; }
-        __syncthreads();
+        if (lane == 0) cp[S::ACC_COLS] = loss_acc;
     }
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int i = threadIdx.x + q * 256; const bool dead = i >= S::OFF_WO + kOut * W && i < S::N_MLP;
-        if (i < S::N_MLP + 1) dst[i] = dead ? 0.f : part[q];
-    }
-#else
-    store_copy(reinterpret_cast<float*>(dyn) + (size_t)wave * (S::N_MLP + 64));
     __syncthreads();
-    for (int i = threadIdx.x; i < S::N_MLP + 1; i += blockDim.x) {
-        const bool dead = i >= S::OFF_WO + kOut * W && i < S::N_MLP;             // rows 4..15 of the padded output layer: no gradient
-        float v = 0.f;
-        if (!dead) v = (r0[i] + r0[(S::N_MLP + 64) + i]) + (r0[2 * (S::N_MLP + 64) + i] + r0[3 * (S::N_MLP + 64) + i]);
-        dst[i] = v;
+    {
+        const float* r0 = reinterpret_cast<const float*>(dyn);
+        float* dst = a.partials + (size_t)blockIdx.x * (S::ACC_COLS + 64);
+        constexpr int ST = S::ACC_COLS + 64;
+        for (int i = threadIdx.x * 4; i < S::ACC_COLS; i += blockDim.x * 4) {
+            const float4_t v0 = *reinterpret_cast<const float4_t*>(r0 + i), v1 = *reinterpret_cast<const float4_t*>(r0 + ST + i);
+            const float4_t v2 = *reinterpret_cast<const float4_t*>(r0 + 2 * ST + i), v3 = *reinterpret_cast<const float4_t*>(r0 + 3 * ST + i);
+            *reinterpret_cast<float4_t*>(dst + i) = (v0 + v1) + (v2 + v3);
+        }
+        if (threadIdx.x == 0) dst[S::ACC_COLS] = (r0[S::ACC_COLS] + r0[ST + S::ACC_COLS]) + (r0[2 * ST + S::ACC_COLS] + r0[3 * ST + S::ACC_COLS]);
     }
-#endif
 #ifdef MON_FUSED_TIMING
     tstamp(tc, 9);
     if (lane == 0) for (int k = 0; k < 16; ++k) a.b.tdist[(blockIdx.x * S::WAVES + wave) * 16 + k] = tcx.acc[k];
@@ -899,22 +884,22 @@ __device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restr
 // takes a few float4 column groups (128 row subsets x 8 groups per pass).  The loads are issued at kernel entry and the sums
 // are finished (DPP + a small LDS exchange) after the tile has been written, so their latency hides behind the scatter itself
 // (k_reduce_partials remains for networks whose levels all go through global atomics).
-struct PartialsArgs { const float* partials; uint32_t n_partials, stride, n_mlp; float* gmlp; DevState* st; };
+struct PartialsArgs { const float* partials; uint32_t n_partials, stride, n_cols; FragDims fd; float* gmlp; DevState* st; };      // rows in accumulator layout: n_cols = acc_cols(fd), loss partial behind them
 constexpr uint32_t kPartialsMaxPasses = 2;          // column-group passes a workgroup may hold in registers (n_mlp + 1 <= 2 * 8 * 4 * gridDim.x)
 
 // column groups (of 4 columns) a workgroup sums per pass: as few as cover all groups with the whole grid (1, 2, 4 or 8), so that every workgroup
 // carries the same small share instead of the first third of the grid carrying everything
 __device__ __forceinline__ uint32_t partials_groups(const PartialsArgs& pa) {
-    const uint32_t n4 = (pa.n_mlp + 1u + 3u) / 4u, need = (n4 + gridDim.x - 1u) / gridDim.x;
+    const uint32_t n4 = (pa.n_cols + 1u + 3u) / 4u, need = (n4 + gridDim.x - 1u) / gridDim.x;
     return need <= 1u ? 1u : (need <= 2u ? 2u : (need <= 4u ? 4u : 8u));
 }
 __device__ __forceinline__ void partials_prefetch(const PartialsArgs& pa, float4_t (&acc)[kPartialsMaxPasses]) {
     // thread = (column group gs of G, row subset sub of 1024 / G)
-    const uint32_t n4 = (pa.n_mlp + 1u + 3u) / 4u, G = partials_groups(pa), subs = blockDim.x / G, gs = threadIdx.x / subs, sub = threadIdx.x - gs * subs;
+    const uint32_t n4 = (pa.n_cols + 1u + 3u) / 4u, G = partials_groups(pa), subs = blockDim.x / G, gs = threadIdx.x / subs, sub = threadIdx.x - gs * subs;
 #pragma unroll
     for (uint32_t ps = 0; ps < kPartialsMaxPasses; ++ps) {
         const uint32_t g = (blockIdx.x + ps * gridDim.x) * G + gs; acc[ps] = float4_t{ 0.f, 0.f, 0.f, 0.f };
-        if (g < n4) for (uint32_t k0 = sub; k0 < pa.n_partials; k0 += 4u * subs) {            // four independent 16-byte loads per round (rows are padded to n_mlp + 64 floats)
+        if (g < n4) for (uint32_t k0 = sub; k0 < pa.n_partials; k0 += 4u * subs) {            // four independent 16-byte loads per round (rows are padded to n_cols + 64 floats)
             float4_t v[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4u; ++u) { const uint32_t k = k0 + subs * u; v[u] = (k < pa.n_partials) ? *reinterpret_cast<const float4_t*>(pa.partials + (size_t)k * pa.stride + 4u * g) : float4_t{ 0.f, 0.f, 0.f, 0.f }; }
@@ -924,7 +909,7 @@ __device__ __forceinline__ void partials_prefetch(const PartialsArgs& pa, float4
 }
 __device__ __forceinline__ void partials_finish(const PartialsArgs& pa, const float4_t (&acc)[kPartialsMaxPasses], float* red) {
     // the 64 subsets of a wave are summed with DPP, the 16 / G waves of a column group through LDS
-    const uint32_t n4 = (pa.n_mlp + 1u + 3u) / 4u, G = partials_groups(pa), wave = threadIdx.x >> 6, wpg = (blockDim.x >> 6) / G;
+    const uint32_t n4 = (pa.n_cols + 1u + 3u) / 4u, G = partials_groups(pa), wave = threadIdx.x >> 6, wpg = (blockDim.x >> 6) / G;
 #pragma unroll
     for (uint32_t ps = 0; ps < kPartialsMaxPasses; ++ps) {
         const uint32_t g0 = (blockIdx.x + ps * gridDim.x) * G;
@@ -940,7 +925,7 @@ __device__ __forceinline__ void partials_finish(const PartialsArgs& pa, const fl
         if (threadIdx.x < 4u * G) {
             const uint32_t gi = threadIdx.x >> 2, gg = g0 + gi, c = threadIdx.x & 3u, pi = 4u * gg + c;
             float v = 0.f; for (uint32_t w = 0; w < wpg; ++w) v += red[(gi * wpg + w) * 4u + c];
-            if (gg < n4) { if (pi < pa.n_mlp) pa.gmlp[pi] = v; else if (pi == pa.n_mlp) pa.st->loss_sum = v; }
+            if (gg < n4) { if (pi < pa.n_cols) { const int prm = acc_param(pa.fd, (int)pi); if (prm >= 0) pa.gmlp[prm] = v; } else if (pi == pa.n_cols) pa.st->loss_sum = v; }
         }
         __syncthreads();
     }
@@ -1051,15 +1036,16 @@ uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd) { ScatterLe
 #ifdef MON_SCATTER_TIMING
 static float* g_scatter_timing_buf = nullptr;
 #endif
+uint32_t fused_partial_cols(const NetDims& nd) { return (uint32_t)acc_cols(FragDims{ nd.Epad, nd.W, nd.NH, nd.L }); }
 bool grid_scatter_sums_partials(const LevelTable& lt, const NetDims& nd) {
     // the scatter workgroups hold their share of the dW column groups in registers (kPartialsMaxPasses passes of 8 groups of 4 columns)
     ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return false;
-    return nd.n_mlp + 1u <= kPartialsMaxPasses * 8u * 4u * sl.n_levels * kScatterWgPerLevel;
+    return fused_partial_cols(nd) + 1u <= kPartialsMaxPasses * 8u * 4u * sl.n_levels * kScatterWgPerLevel;
 }
 void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint32_t n_bins, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
                          const float* partials, uint32_t n_partials, float* gmlp) {
     ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return;
-    const PartialsArgs pa{ partials, n_partials, nd.n_mlp + 64u, nd.n_mlp, gmlp, st };
+    const PartialsArgs pa{ partials, n_partials, fused_partial_cols(nd) + 64u, fused_partial_cols(nd), FragDims{ nd.Epad, nd.W, nd.NH, nd.L }, gmlp, st };
     constexpr uint32_t smem = kScatterTile * 4 + 256;
     static std::atomic<uint64_t> attr_devices{ 0 };       // function attributes are per device: the managers run objects on every GPU of the node from one process
     if (first_use_on_this_device(attr_devices)) hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1238,7 +1224,8 @@ static void candidates_frags_t(hipStream_t s, const BatchPtrs& b, const DatasetP
 void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
                         uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched, const uint32_t* occ_bits, uint32_t n_bins) {
     const uint32_t ablate = (uint32_t)options().fused_ablate;
-    const uint32_t stagger = options().fused_stagger < 0 ? kDefaultStagger : (uint32_t)options().fused_stagger;
+    uint32_t stagger = options().fused_stagger < 0 ? kDefaultStagger : (uint32_t)options().fused_stagger;
+    if (oc.R < 2u * 4u * fused_train_grid(nd, oc.R)) stagger = 0u;      // a wave with one ray has no second phase to interleave: the delay would only be lost
     FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate, touched ? touched + (nd.n_mlp >> 3) : nullptr, big_switch, n_bins, stagger, occ_bits };
     const uint32_t grid = fused_train_grid(nd, oc.R);
     MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);

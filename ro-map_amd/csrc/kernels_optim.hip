@@ -52,7 +52,12 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
     // last block of the previous step, so no block waits for a software pow before it can issue its loads
     const uint32_t cur = step + 1u;
     const float d = oc.ema_decay;
-    const float deb_old = st->ema_deb_old, deb_new = st->ema_deb_new;
+    const bool odd = (cur & 1u) != 0u;
+    const float deb_old = odd ? st->ema_deb_old : st->ema_deb_even_old, deb_new = odd ? st->ema_deb_new : st->ema_deb_even_new;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                      // factors of step cur + 1, into the pair nobody reads during this step (a skipped batch rewrites the same values)
+        const float o = 1.f - (float)pow((double)d, (double)cur), nw = 1.f / (1.f - (float)pow((double)d, (double)(cur + 1u)));
+        if (odd) { st->ema_deb_even_old = o; st->ema_deb_even_new = nw; } else { st->ema_deb_old = o; st->ema_deb_new = nw; }
+    }
     // gradient / loss_scale: a power-of-two scale (the reference's 128) divides exactly as a multiplication by its reciprocal (same
     // correctly rounded result, ~10 instructions less per parameter than an IEEE division); anything else keeps the division
     const bool pow2_scale = (__float_as_uint(oc.loss_scale) & 0x007fffffu) == 0u && oc.loss_scale > 0.f;
@@ -135,7 +140,13 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                 for (int j = 0; j < 8; ++j) { any |= g[j] != 0.f; g[j] = unscale(g[j]); }
             }
             if (lazy_chunk && !any) return;                                            // untouched: nothing to do now (see k_ema_finalize)
-            half8_t wh = (pre && !LAZY) ? cur_w : *reinterpret_cast<const half8_t*>(p.half + i0);
+            // the fp16 working copy is h(master) by construction (creation, set_params, every update): where the master weights are loaded anyway it is not read back
+            half8_t wh;
+            if (DENSE) {
+                const float wm[8] = { w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3] };
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wh[j] = (half_t)wm[j];
+            } else wh = (pre && !LAZY) ? cur_w : *reinterpret_cast<const half8_t*>(p.half + i0);
             if (lazy_chunk) {                                                        // touched again: first the steps it sat out, with the weight it had
                 ema_in = *reinterpret_cast<const half8_t*>(p.ema + i0);
                 const uint32_t last = p.ema_step[c], k = (cur - 1u) - last;
@@ -260,8 +271,6 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
             { const uint32_t tot = st->n_scatter_now; st->n_scatter_now = 0u; st->n_scatter_last = tot; st->n_scatter_total += tot; (void)n_bins; }   // (the slot counters themselves are cleared and summed by k_grid_scatter)
             if (n_valid != 0u) {
                 st->step = cur;
-                st->ema_deb_old = 1.f - (float)pow((double)d, (double)cur);              // factors of step cur + 1
-                st->ema_deb_new = 1.f / (1.f - (float)pow((double)d, (double)(cur + 1u)));
                 if ((int)cur >= oc.decay_start && oc.decay_interval > 0 && ((int)cur - oc.decay_start) % oc.decay_interval == 0) st->lr = lr0 * oc.decay_base;
             } else {
                 st->skipped = st->skipped + 1u;
@@ -273,14 +282,14 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
 // Fused backend: sums the per-workgroup fp32 weight-gradient partials (and loss partials) written by
 // k_fused_train into gmlp / DevState::loss_sum.  One block = 16 parameters (4 float4 columns) x 64 row subsets,
 // so every thread has only n_partials/64 independent 16-byte loads in flight (the kernel is latency bound).
-__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ partials, uint32_t n_partials, uint32_t stride, uint32_t n_mlp,
+__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ partials, uint32_t n_partials, uint32_t stride, uint32_t n_cols, FragDims fd,
                                                          float* __restrict__ gmlp, DevState* __restrict__ st) {
     if (st->n_valid == 0u) return;
     __shared__ float4_t red[256];
     const uint32_t c4 = threadIdx.x & 3u, sub = threadIdx.x >> 2;              // column group, row subset (0..63)
     const uint32_t p0 = blockIdx.x * 16u + c4 * 4u;
     float4_t acc = { 0.f, 0.f, 0.f, 0.f };
-    if (p0 < n_mlp + 4u) {                                                      // rows are padded to n_mlp + 64 floats: in-bounds
+    if (p0 < n_cols + 4u) {                                                     // rows are padded to n_cols + 64 floats: in-bounds
         for (uint32_t k = sub; k < n_partials; k += 64u) acc += *reinterpret_cast<const float4_t*>(partials + (size_t)k * stride + p0);
     }
     red[threadIdx.x] = acc;
@@ -289,12 +298,13 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict
     if (threadIdx.x < 4u) {
         const float4_t v = red[threadIdx.x];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t pi = p0 + j; if (pi < n_mlp) gmlp[pi] = v[j]; else if (pi == n_mlp) st->loss_sum = v[j]; }
+        for (int j = 0; j < 4; ++j) { const uint32_t pi = p0 + j; if (pi < n_cols) { const int prm = acc_param(fd, (int)pi); if (prm >= 0) gmlp[prm] = v[j]; } else if (pi == n_cols) st->loss_sum = v[j]; }      // rows are in accumulator layout
     }
 }
 
-void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_partials, uint32_t stride, uint32_t n_mlp, float* gmlp, DevState* st) {
-    hipLaunchKernelGGL(k_reduce_partials, dim3((n_mlp + 1 + 15) / 16), dim3(256), 0, s, partials, n_partials, stride, n_mlp, gmlp, st);
+void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_partials, const NetDims& nd, float* gmlp, DevState* st) {
+    const uint32_t n_cols = fused_partial_cols(nd);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((n_cols + 1 + 15) / 16), dim3(256), 0, s, partials, n_partials, n_cols + 64u, n_cols, FragDims{ nd.Epad, nd.W, nd.NH, nd.L }, gmlp, st);
 }
 
 // Brings every lazily maintained EMA chunk up to the last completed optimizer step (before render / mesh / parameter read-back).

@@ -220,7 +220,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         (rc = dev_alloc(m, B.Hid, (size_t)Btrain * m.nd.W * m.nd.NH)) || (rc = dev_alloc(m, B.dO, (size_t)Btrain * kOut)) ||
         (rc = dev_alloc(m, B.dHid, (size_t)Btrain * m.nd.W * m.nd.NH)) || (rc = dev_alloc(m, B.dE, (size_t)Btrain * m.nd.Epad)) ||
         (rc = dev_alloc(m, B.rgb_ray, 3 * (size_t)R)) || (rc = dev_alloc(m, B.depth_ray, R)) || (rc = dev_alloc(m, B.mask_ray, R)) || (rc = dev_alloc(m, B.loss_ray, R)) ||
-        (rc = dev_alloc(m, m.d_state, 1)) || (rc = dev_alloc(m, m.d_dw_partials, (size_t)(m.nd.n_mlp + 64) * kMaxFusedGrid)) ||
+        (rc = dev_alloc(m, m.d_state, 1)) || (rc = dev_alloc(m, m.d_dw_partials, (size_t)(fused_partial_cols(m.nd) + 64) * kMaxFusedGrid)) ||
         (rc = dev_alloc(m, m.d_out_rgb, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_depth, kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_mask, kRenderChunkRays))) return rc;
     m.out_cap = kRenderChunkRays;
     // lazy EMA: only where the optimizer is not the dense variant anyway and the table is large (> 8 M parameters); MON_LAZY_EMA=0/1 overrides
@@ -406,7 +406,7 @@ static void enqueue_iteration(Model& m, int stages) {
         if (m.lds_mask) { ProfScope ps(m, MON_K_SCATTER); launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_gpart, m.n_grid / 2, m.d_state,
                                                                                 folded ? m.d_dw_partials : nullptr, fused_train_grid(m.nd, m.oc.R), m.P.gmlp); }
         if (m.big_active) { ProfScope ps(m, MON_K_SCATTER); launch_big_scatter(s, m.lt, m.lf, m.nd, m.lds_mask, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_state, m.big_switch, m.d_big_ws, m.P.ggrid, m.d_touched ? m.d_touched + (m.nd.n_mlp >> 3) : nullptr); }
-        if (!folded) { ProfScope ps(m, MON_K_REDUCE); launch_reduce_partials(s, m.d_dw_partials, fused_train_grid(m.nd, m.oc.R), m.nd.n_mlp + 64, m.nd.n_mlp, m.P.gmlp, m.d_state); }
+        if (!folded) { ProfScope ps(m, MON_K_REDUCE); launch_reduce_partials(s, m.d_dw_partials, fused_train_grid(m.nd, m.oc.R), m.nd, m.P.gmlp, m.d_state); }
     }
     if (stages & 4) {      // Trainer::optimizer_step :1644
         ProfScope ps(m, MON_K_OPTIM);

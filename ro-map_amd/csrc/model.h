@@ -22,10 +22,12 @@ struct DevState {
     uint32_t ticket;     // last-block-done counter of the optimizer kernel
     uint32_t skipped;    // batches skipped because n_valid == 0
     uint32_t n_scatter_now;   // gradient-carrying samples of the CURRENT iteration (written by k_grid_scatter; the optimizer's last block makes it n_scatter_last, so every kernel of an iteration sees the same previous count)
-    uint32_t reserved_bins[15];
+    float ema_deb_even_old, ema_deb_even_new;   // EMA debias factors of the next EVEN optimizer step (see ema_deb_old)
+    uint32_t reserved_bins[13];
     uint32_t n_scatter_last;  // their sum in the last completed iteration (reporting)
     uint32_t n_scatter_total; // running sum over all iterations, modulo 2^32 (reporting: differences over a measurement window)
-    float ema_deb_old, ema_deb_new;   // EMA debias factors of the NEXT optimizer step (1 - d^(t-1), 1 / (1 - d^t)); the last block of a step leaves them for the following one
+    float ema_deb_old, ema_deb_new;   // EMA debias factors (1 - d^(t-1), 1 / (1 - d^t)) of the next ODD optimizer step t; step t's kernel reads its pair and one of its threads writes the
+                                      // other pair for step t + 1 at kernel ENTRY (two double-precision pows: at the end of the last block they were ~1 us of serial tail per step)
     uint32_t n_scatter[2 * kMaxScatterBins * kScatterCounterStride];   // TWO sets (iteration parity: k_fused_train(i) counts in set i & 1, k_grid_scatter(i) reads it and clears the other one for
                                            // iteration i + 1), counter of bin b at [set * kMaxScatterBins * stride + b * stride]: one 64-byte line each -- returning atomics on one line serialise in its L2 channel.  fused backend: samples with a non-zero dL/dO handed to k_grid_scatter this iteration, per ray bin (ray & (bins - 1)): slot counters, reset by the
                                            // optimizer's last block.  Up to 128 bins: a wave reserves its slots with one returning atomic per ray, and 4096 rays on 16 counters cost 7 us of k_fused_train
@@ -132,7 +134,8 @@ void launch_copy_params(hipStream_t s, const uint16_t* src, uint16_t* dst, uint3
 // optimizer (kernels_optim.hip)
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx, uint32_t n_bins);
 void launch_ema_finalize(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, const DevState* st);
-void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_partials, uint32_t stride, uint32_t n_mlp, float* gmlp, DevState* st);
+void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_partials, const NetDims& nd, float* gmlp, DevState* st);
+uint32_t fused_partial_cols(const NetDims& nd);      // columns of a k_fused_train dW partial row (accumulator layout), the loss partial follows
 
 // fused MFMA path (kernels_fused.hip)
 constexpr uint32_t kMaxFusedGrid = 512;       // workgroups of k_fused_train (= dW partial rows per step): two per CU
@@ -176,7 +179,7 @@ struct Model {
     ParamPtrs P{}; BatchPtrs B{}; DevState* d_state = nullptr; mon_frame_bbox* d_boxes = nullptr;
     uint32_t boxes_cap = 0, n_boxes = 0; uint32_t ws_samples = 0, ws_rays = 0;
     // fused backend
-    float* d_dw_partials = nullptr;                               // [512][n_mlp + 64] fp32 dW partial rows of k_fused_train
+    float* d_dw_partials = nullptr;                               // [512][fused_partial_cols + 64] fp32 dW partial rows of k_fused_train, accumulator layout (frag_layout.h acc_param)
     uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr;       // compacted dL/dE rows [L][B] and positions [B] float4 for the scatter kernels
     uint16_t* d_gpart = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0;   // k_grid_scatter: partial tables, plan, levels it covers
     uint16_t* d_frag_train = nullptr; uint16_t* d_frag_render = nullptr;           // MFMA A-fragment images (training weights / inference weights)
