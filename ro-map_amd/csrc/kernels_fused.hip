@@ -225,81 +225,109 @@ __device__ __forceinline__ LevelRegs load_level_regs_uniform(const LevelFast& kl
 __device__ __forceinline__ uint32_t lane_u(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 __device__ __forceinline__ float lane_f(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
 
-template <int EPAD, int W, int NH, bool MASKED = false>
-__device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const half_t* frags, const LevelRegs& lr, const half2_t* __restrict__ table, uint32_t table_bytes,
-                                             int L, const float x[3], int lane, TimingCtx* tc = nullptr, bool live = true) {
-    using S = FusedShape<EPAD, W, NH>;
-    const int h = lane >> 5, LPH = (L + 1) >> 1;      // `live` = false: this lane's sample sits in a cell the occupancy grid marks empty -- its gathers are not issued (features 0)
-    // ---- hash-grid encode (tcnn kernel_grid; fp32 fmaf chain over the 8 corners, one rounding).  Half-wave h OWNS levels
-    //      h*LPH + il (their features are its K slots), but the GATHERS are issued level by level with all 64 lanes on one
-    //      level: lane (n, c) fetches the four (y, z) corners with x-corner c of sample n.  Measured on MI355X
-    //      (tools/run_gatherbench.py): a divergent gather costs ~2.4 clk per distinct 64-byte line per instruction and nothing
-    //      more for further lanes in the same line -- and corners x, x+1 share a line 15 times out of 16, on hashed levels too
-    //      (x ^ h keeps the upper bits).  So pairing them in one instruction halves the lines per level; a
-    //      v_permlane32_swap per value then hands each half the 8 corners of the level it owns, and the interpolation runs
-    //      the same chain in the same order as before (bit-identical results).
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half2_t*>(table), 0, (int)table_bytes, 0x00020000);
-    auto half_gather = [&](int slot, uint32_t (&r)[4]) {                               // `slot` = the lane of `lr` that holds this level: a compile-time number
-        const float scale = lane_f(lr.scale, slot);
-        const uint32_t size = lane_u(lr.size, slot), my = lane_u(lr.my, slot), mz = lane_u(lr.mz, slot), mask = lane_u(lr.mask, slot), off4 = lane_u(lr.off4, slot);
-        uint32_t pg[3];
+// ---- hash-grid encode (tcnn kernel_grid; fp32 fmaf chain over the 8 corners, one rounding).  Half-wave h OWNS levels
+//      h*LPH + il (their features are its K slots), but the GATHERS are issued level by level with all 64 lanes on one
+//      level: lane (n, c) fetches the four (y, z) corners with x-corner c of sample n.  Measured on MI355X
+//      (tools/run_gatherbench.py): a divergent gather costs ~2.4 clk per distinct 64-byte line per instruction and nothing
+//      more for further lanes in the same line -- and corners x, x+1 share a line 15 times out of 16, on hashed levels too
+//      (x ^ h keeps the upper bits).  So pairing them in one instruction halves the lines per level; a
+//      v_permlane32_swap per value then hands each half the 8 corners of the level it owns, and the interpolation runs
+//      the same chain in the same order as before (bit-identical results).
+// All control flow around the loads is compile-time (pairs past the last level gather the dummy level: one line per instruction), so the compiler's vmcnt
+// bookkeeping stays exact: a pair's interpolation waits for ITS eight loads only, and the next pair's loads are issued into the registers it frees
+// (runtime guards around the gather groups made every first use wait for the whole batch).
+template <int EPAD, int W, int NH> struct GatherWindow {
+    static constexpr int LLV = FusedShape<EPAD, W, NH>::LLV;
+    static constexpr int EB = (LLV < kEncodeBatch) ? LLV : kEncodeBatch;              // level pairs in flight
+    uint32_t ra[EB][4], rb[EB][4];                                                    // pair il lives in slot il % EB: lanes (n, c) hold x-corner c of the four (y, z) corners, ra = level il, rb = level LPH + il
+};
+
+// the four gathers of one level (`slot` = the lane of `lr` that holds it: a compile-time number); `live` = false: this lane's sample sits in a cell the
+// occupancy grid marks empty -- its gathers are not issued (an exec-masked load costs no L2 request; r[] was zeroed by the caller)
+template <bool MASKED>
+__device__ __forceinline__ void gather_level(uint32_t (&r)[4], const LevelRegs& lr, int slot, const __amdgpu_buffer_rsrc_t rsrc, const float x[3], int h, bool live) {
+    const float scale = lane_f(lr.scale, slot);
+    const uint32_t size = lane_u(lr.size, slot), my = lane_u(lr.my, slot), mz = lane_u(lr.mz, slot), mask = lane_u(lr.mask, slot), off4 = lane_u(lr.off4, slot);
+    uint32_t pg[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) pg[d] = (uint32_t)(int32_t)floorf(fmaf(scale, x[d], 0.5f));
-        const uint32_t ax = pg[0] + (uint32_t)h, y0 = pg[1] * my, z0 = pg[2] * mz;
-        const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
-        if (MASKED && !live) return;                                                    // (r[] was zeroed by the caller; an exec-masked load costs no L2 request)
-        // the hashed / dense choice is a scalar branch around index arithmetic ONLY: the four loads sit after the join (a load inside either arm made the
-        // compiler drain vmcnt at the top of the other one -- every dense level waited for all gathers in flight)
-        uint32_t idx[4];
-        if (lane_u(lr.hashed, slot) != 0u) {                                            // hashed levels hold 2^T entries: the mask IS the modulo
+    for (int d = 0; d < 3; ++d) pg[d] = (uint32_t)(int32_t)floorf(fmaf(scale, x[d], 0.5f));
+    const uint32_t ax = pg[0] + (uint32_t)h, y0 = pg[1] * my, z0 = pg[2] * mz;
+    const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
+    if (MASKED && !live) return;
+    // the hashed / dense choice is a scalar branch around index arithmetic ONLY: the four loads sit after the join (a load inside either arm made the
+    // compiler drain vmcnt at the top of the other one -- every dense level waited for all gathers in flight)
+    uint32_t idx[4];
+    if (lane_u(lr.hashed, slot) != 0u) {                                            // hashed levels hold 2^T entries: the mask IS the modulo
 #pragma unroll
-            for (int j = 0; j < 4; ++j) idx[j] = (ax ^ ay[j & 1] ^ az[j >> 1]) & mask;
-        } else {
+        for (int j = 0; j < 4; ++j) idx[j] = (ax ^ ay[j & 1] ^ az[j >> 1]) & mask;
+    } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint32_t i = (ax + ay[j & 1] + az[j >> 1]) & mask;
-                i -= (i >= size) ? size : 0u;                                           // dense sizes are not powers of two: index < 2 * size, so % size is one subtract
-                idx[j] = min(i, size - 1u);                                             // memory safety for positions far outside [0,1]^3 (never produced by the sampler)
-            }
+        for (int j = 0; j < 4; ++j) {
+            uint32_t i = (ax + ay[j & 1] + az[j >> 1]) & mask;
+            i -= (i >= size) ? size : 0u;                                           // dense sizes are not powers of two: index < 2 * size, so % size is one subtract
+            idx[j] = min(i, size - 1u);                                             // memory safety for positions far outside [0,1]^3 (never produced by the sampler)
         }
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (idx[j] << 2) + off4, 0, 0);
-    };
-    // All control flow around the loads is compile-time (pairs past the last level gather the dummy level: one line per instruction), so the compiler's vmcnt
-    // bookkeeping stays exact: a pair's interpolation waits for ITS eight loads only, and the next pair's loads are issued into the registers it frees
-    // (runtime guards around the gather groups made every first use wait for the whole batch).
-    constexpr int EB = (S::LLV < kEncodeBatch) ? S::LLV : kEncodeBatch;              // level pairs in flight
-    uint32_t ra[EB][4], rb[EB][4];
-    auto issue = [&](int il) {
+    for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (idx[j] << 2) + off4, 0, 0);
+}
+template <int EPAD, int W, int NH, bool MASKED>
+__device__ __forceinline__ void encode_issue(GatherWindow<EPAD, W, NH>& g, int il, const LevelRegs& lr, const __amdgpu_buffer_rsrc_t rsrc, const float x[3], int h, bool live) {
+    constexpr int EB = GatherWindow<EPAD, W, NH>::EB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ra[il % EB][j] = 0u; rb[il % EB][j] = 0u; }      // (dead unless MASKED)
-        half_gather(il, ra[il % EB]); half_gather(32 + il, rb[il % EB]);
-    };
+    for (int j = 0; j < 4; ++j) { g.ra[il % EB][j] = 0u; g.rb[il % EB][j] = 0u; }      // (dead unless MASKED)
+    gather_level<MASKED>(g.ra[il % EB], lr, il, rsrc, x, h, live); gather_level<MASKED>(g.rb[il % EB], lr, 32 + il, rsrc, x, h, live);
+}
+// interpolation of level pair il (its eight loads must have been issued); returns the two features of the level this half-wave owns
+template <int EPAD, int W, int NH>
+__device__ __forceinline__ void encode_swap(const GatherWindow<EPAD, W, NH>& g, int il, uint32_t (&c0)[4], uint32_t (&c1)[4]) {
+    constexpr int EB = GatherWindow<EPAD, W, NH>::EB;
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int il = 0; il < EB; ++il) issue(il);
+    for (int j = 0; j < 4; ++j) { const u2v sw = __builtin_amdgcn_permlane32_swap(g.ra[il % EB][j], g.rb[il % EB][j], false, false); c0[j] = sw.x; c1[j] = sw.y; }
+}
+template <int EPAD, int W, int NH>
+__device__ __forceinline__ void encode_interp(TileState<EPAD, W, NH>& ts, int il, const uint32_t (&c0)[4], const uint32_t (&c1)[4], const LevelRegs& lr, const float x[3], int h, int L) {
+    const int LPH = (L + 1) >> 1;
+    const float scale = h ? lane_f(lr.scale, 32 + il) : lane_f(lr.scale, il);
+    float pos[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, x[d], 0.5f); pos[d] = q - floorf(q); }
+    const float wx[2] = { 1.f - pos[0], pos[0] }, wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const half2_t v = __builtin_bit_cast(half2_t, (k & 1) ? c1[k >> 1] : c0[k >> 1]);
+        const float wgt = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
+        a0 = fmaf(wgt, (float)v.x, a0); a1 = fmaf(wgt, (float)v.y, a1);
+    }
+    const bool real = il < LPH && h * LPH + il < L;                                 // (a select, not a branch)
+    ts.ef[2 * il] = real ? (half_t)a0 : (half_t)0.f; ts.ef[2 * il + 1] = real ? (half_t)a1 : (half_t)0.f;
+}
+// the rest of a ray's encode once its first EB level pairs are in flight: a rolling window, pair il + EB is requested into the registers pair il frees
+template <int EPAD, int W, int NH, bool MASKED>
+__device__ __forceinline__ void encode_finish(TileState<EPAD, W, NH>& ts, GatherWindow<EPAD, W, NH>& g, const LevelRegs& lr, const __amdgpu_buffer_rsrc_t rsrc, const float x[3], int lane, int L, bool live) {
+    using S = FusedShape<EPAD, W, NH>; constexpr int EB = GatherWindow<EPAD, W, NH>::EB; const int h = lane >> 5;
 #pragma unroll
     for (int il = 0; il < S::LLV; ++il) {
-        typedef unsigned u2v __attribute__((ext_vector_type(2)));
         uint32_t c0[4], c1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const u2v sw = __builtin_amdgcn_permlane32_swap(ra[il % EB][j], rb[il % EB][j], false, false); c0[j] = sw.x; c1[j] = sw.y; }
-        if (il + EB < S::LLV) issue(il + EB);
-        const float scale = h ? lane_f(lr.scale, 32 + il) : lane_f(lr.scale, il);
-        float pos[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, x[d], 0.5f); pos[d] = q - floorf(q); }
-        const float wx[2] = { 1.f - pos[0], pos[0] }, wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const half2_t v = __builtin_bit_cast(half2_t, (k & 1) ? c1[k >> 1] : c0[k >> 1]);
-            const float wgt = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
-            a0 = fmaf(wgt, (float)v.x, a0); a1 = fmaf(wgt, (float)v.y, a1);
-        }
-        const bool real = il < LPH && h * LPH + il < L;                                 // (a select, not a branch)
-        ts.ef[2 * il] = real ? (half_t)a0 : (half_t)0.f; ts.ef[2 * il + 1] = real ? (half_t)a1 : (half_t)0.f;
+        encode_swap<EPAD, W, NH>(g, il, c0, c1);
+        if (il + EB < S::LLV) encode_issue<EPAD, W, NH, MASKED>(g, il + EB, lr, rsrc, x, h, live);
+        encode_interp<EPAD, W, NH>(ts, il, c0, c1, lr, x, h, L);
     }
-    tstamp(tc, 2);
+}
+template <int EPAD, int W, int NH, bool MASKED>
+__device__ __forceinline__ void encode_begin(GatherWindow<EPAD, W, NH>& g, const LevelRegs& lr, const __amdgpu_buffer_rsrc_t rsrc, const float x[3], int lane, bool live) {
+    constexpr int EB = GatherWindow<EPAD, W, NH>::EB;
+#pragma unroll
+    for (int il = 0; il < EB; ++il) encode_issue<EPAD, W, NH, MASKED>(g, il, lr, rsrc, x, lane >> 5, live);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const half2_t* table, uint32_t table_bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<half2_t*>(table), 0, (int)table_bytes, 0x00020000); }
+
+// MLP forward of one 32-sample tile from ts.ef: leaves the hidden activations as packed B fragments and out4 (raw network outputs of sample n, valid in half-wave 0)
+template <int EPAD, int W, int NH>
+__device__ __forceinline__ void mlp_forward(TileState<EPAD, W, NH>& ts, const half_t* frags, int lane) {
+    using S = FusedShape<EPAD, W, NH>;
     // ---- layer 0
     float16_t acc[S::MB];
 #pragma unroll
@@ -333,6 +361,16 @@ __device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const h
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) ts.out4[c] = (float)(half_t)ao[c];        // network output is fp16 (tcnn network_precision_t)
+}
+
+// Forward pass of one 32-sample tile in one go (render, occupancy grid): encode + MLP
+template <int EPAD, int W, int NH>
+__device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const half_t* frags, const LevelRegs& lr, const half2_t* __restrict__ table, uint32_t table_bytes, int L, const float x[3], int lane) {
+    const __amdgpu_buffer_rsrc_t rsrc = table_rsrc(table, table_bytes);
+    GatherWindow<EPAD, W, NH> g;
+    encode_begin<EPAD, W, NH, false>(g, lr, rsrc, x, lane, true);
+    encode_finish<EPAD, W, NH, false>(ts, g, lr, rsrc, x, lane, L, true);
+    mlp_forward<EPAD, W, NH>(ts, frags, lane);
 }
 
 // Cross-lane helpers on DPP (VALU data path, a few cycles each) instead of __shfl_* (ds_bpermute through the LDS crossbar,
@@ -377,6 +415,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
     unsigned char* dyn = smem + S::FRAG_BYTES + S::LT_BYTES;
 #ifdef MON_FUSED_TIMING
     TimingCtx tcx; for (float& v : tcx.acc) v = 0.f; tcx.last = clock64(); TimingCtx* tc = &tcx;
+    tcx.acc[13] = (float)(uint32_t)(wall_clock64() & 0xffffffull); tcx.acc[15] = (float)(uint32_t)__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);      // start time (100 MHz ticks, low 24 bits), HW_ID[15:0]
 #else
     TimingCtx* tc = nullptr;
 #endif
@@ -461,38 +500,49 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
     if (a.stagger & 0xffffu) {
         const uint32_t mode = (a.stagger >> 16) & 3u;
         const uint32_t slot = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) ;      // HW_ID.wave_id: this wave's slot on its SIMD
-        const bool late = mode == 0u ? (slot & 1u) != 0u : mode == 1u ? blockIdx.x >= (gridDim.x >> 1) : mode == 2u ? (wave & 1) != 0 : ((blockIdx.x >> 3) & 1u) != 0u;
-        if (late) for (uint32_t i = 0; i < (a.stagger & 0xffffu); ++i) __builtin_amdgcn_s_sleep(16);
+        const bool late = mode == 0u ? (slot & 1u) != 0u : mode == 1u ? blockIdx.x >= (gridDim.x >> 1) : mode == 2u ? (wave & 1) != 0 : wave != 0;
+        const uint32_t units = (a.stagger & 0xffffu) * (mode == 3u ? (uint32_t)wave : 1u);        // mode 3: graduated, wave w waits w units
+        if (late) for (uint32_t i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
     }
     tstamp(tc, 0);
 
-    for (uint32_t ray = ray0; ray < R; ray += gridDim.x * S::WAVES) {
-        // ---- this ray's candidate record arrived while the previous ray was processed; request the next one's
-        const uint32_t kth = ray % nvalid, cand_cur = cand;
-        const uint32_t rgba = lane_u(rec, 0);
-        const float t0 = __builtin_bit_cast(float, lane_u(rec, 1)), t1 = __builtin_bit_cast(float, lane_u(rec, 2)), tdp = __builtin_bit_cast(float, lane_u(rec, 9));
-        const float rd[3] = { __builtin_bit_cast(float, lane_u(rec, 3)), __builtin_bit_cast(float, lane_u(rec, 4)), __builtin_bit_cast(float, lane_u(rec, 5)) };
-        const float ro[3] = { __builtin_bit_cast(float, lane_u(rec, 6)), __builtin_bit_cast(float, lane_u(rec, 7)), __builtin_bit_cast(float, lane_u(rec, 8)) };
-        { const uint32_t nxt = ray + gridDim.x * S::WAVES; if (nxt < R) { cand = select(nxt % nvalid); rec = load_record(cand); } }
-        const bool is_obj = (rgba >> 24) != 0u;
-        // ---- sample position (GenerateInputPoints, nerf_model.cu:553-566)
-        const float dtr = (t1 - t0) / 32.0f;
-        const uint32_t s_idx = ray * 32u + (uint32_t)n;
-        const float t = fmaf(dtr, (float)n + rand01(a.oc.sample_seed, kStreamDt, iter, s_idx), t0);
-        float x[3];
+    // ---- ray loop.  The candidate record of ray k + 1 is requested while ray k is processed.  (Also tried: requesting the first EB level pairs of ray k + 1
+    //      before ray k's MLP / composite / backward -- no gain, 48.4 vs 48.6 us without the stagger and 9 spilled registers: the gather phase is bound by the
+    //      chip-wide L2 request rate, not by its start-up latency; an encode-only variant of this kernel, `fused_ablate` 96, takes 39.5 us.)
+    struct RaySample { float t, x[3]; uint32_t rgba; float tdp, t0, t1; bool live, any; };
+    const auto ray_sample = [&](uint32_t recv, uint32_t ray) {                           // sample n of the ray described by record `recv` (GenerateInputPoints, nerf_model.cu:553-566)
+        RaySample q; q.rgba = lane_u(recv, 0); q.tdp = __builtin_bit_cast(float, lane_u(recv, 9));
+        const float t0 = __builtin_bit_cast(float, lane_u(recv, 1)), t1 = __builtin_bit_cast(float, lane_u(recv, 2));
+        const float rd[3] = { __builtin_bit_cast(float, lane_u(recv, 3)), __builtin_bit_cast(float, lane_u(recv, 4)), __builtin_bit_cast(float, lane_u(recv, 5)) };
+        const float ro[3] = { __builtin_bit_cast(float, lane_u(recv, 6)), __builtin_bit_cast(float, lane_u(recv, 7)), __builtin_bit_cast(float, lane_u(recv, 8)) };
+        const float dtr = (t1 - t0) / 32.0f; q.t0 = t0; q.t1 = t1;
+        q.t = fmaf(dtr, (float)n + rand01(a.oc.sample_seed, kStreamDt, iter, ray * 32u + (uint32_t)n), t0);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { const float p = fmaf(t, rd[d], ro[d]); x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
-
-        tstamp(tc, 1);
+        for (int d = 0; d < 3; ++d) { const float p = fmaf(q.t, rd[d], ro[d]); q.x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
         // occupancy-grid skipping (default off): a sample whose cell the grid marks empty is not evaluated -- no gathers, alpha = 0, no gradient
-        bool live = true;
+        q.live = true;
         if constexpr (OCC) {
-            const uint32_t cx = (uint32_t)min(max((int)(x[0] * (float)kOccRes), 0), kOccRes - 1), cy = (uint32_t)min(max((int)(x[1] * (float)kOccRes), 0), kOccRes - 1), cz = (uint32_t)min(max((int)(x[2] * (float)kOccRes), 0), kOccRes - 1);
-            live = ((a.occ_bits[((cz * kOccRes + cy) * kOccRes + cx) >> 5] >> (cx & 31u)) & 1u) != 0u;
+            const uint32_t cx = (uint32_t)min(max((int)(q.x[0] * (float)kOccRes), 0), kOccRes - 1), cy = (uint32_t)min(max((int)(q.x[1] * (float)kOccRes), 0), kOccRes - 1), cz = (uint32_t)min(max((int)(q.x[2] * (float)kOccRes), 0), kOccRes - 1);
+            q.live = ((a.occ_bits[((cz * kOccRes + cy) * kOccRes + cx) >> 5] >> (cx & 31u)) & 1u) != 0u;
         }
+        q.any = !OCC || __ballot(q.live) != 0ull;                                         // false: the whole ray crosses empty cells only, nothing to evaluate
+        return q;
+    };
+    const __amdgpu_buffer_rsrc_t rsrc = table_rsrc(table, table_bytes);
+    const uint32_t ray_stride = gridDim.x * S::WAVES;
+    for (uint32_t ray = ray0; ray < R; ray += ray_stride) {
+        const RaySample cur = ray_sample(rec, ray); const uint32_t cand_this = cand;
+        if (ray + ray_stride < R) { cand = select((ray + ray_stride) % nvalid); rec = load_record(cand); }
+        const uint32_t kth = ray % nvalid, rgba = cur.rgba, s_idx = ray * 32u + (uint32_t)n;
+        const float t = cur.t, tdp = cur.tdp, t0 = cur.t0, t1 = cur.t1; const bool live = cur.live, is_obj = (rgba >> 24) != 0u;
+        const float x[3] = { cur.x[0], cur.x[1], cur.x[2] };
+        tstamp(tc, 1);
         TileState<EPAD, W, NH> ts;
-        if (!OCC || __ballot(live) != 0ull) tile_forward<EPAD, W, NH, OCC>(ts, frags, lregs, table, table_bytes, L, x, lane, tc, live);
-        else {                                                                           // the whole ray crosses empty cells only: nothing to evaluate
+        if (cur.any) { GatherWindow<EPAD, W, NH> gw; encode_begin<EPAD, W, NH, OCC>(gw, lregs, rsrc, x, lane, live); encode_finish<EPAD, W, NH, OCC>(ts, gw, lregs, rsrc, x, lane, L, live); }
+        tstamp(tc, 2);
+        if (a.ablate & 64u) { float sacc = 0.f; for (int i = 0; i < EPAD / 2; ++i) sacc += (float)ts.ef[i]; loss_acc += sacc; continue; }      // timing experiments: the encode alone
+        if (!OCC || __ballot(live) != 0ull) mlp_forward<EPAD, W, NH>(ts, frags, lane);
+        else {
 #pragma unroll
             for (int i = 0; i < EPAD / 2; ++i) ts.ef[i] = (half_t)0.f;
 #pragma unroll
@@ -568,8 +618,8 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
         }
         if (DUMP) {
             if (lane == 0) {
-                for (int d = 0; d < 3; ++d) { a.b.ray_o[3 * ray + d] = a.b.cand_o[3 * cand_cur + d]; a.b.ray_d[3 * ray + d] = a.b.cand_d[3 * cand_cur + d]; }
-                a.b.ray_t0[ray] = t0; a.b.ray_t1[ray] = t1; a.b.ray_dn[ray] = a.b.cand_dn[cand_cur]; a.b.ray_flag[ray] = is_obj ? 1 : 0; a.b.target_depth[ray] = tdp;
+                for (int d = 0; d < 3; ++d) { a.b.ray_o[3 * ray + d] = a.b.cand_o[3 * cand_this + d]; a.b.ray_d[3 * ray + d] = a.b.cand_d[3 * cand_this + d]; }
+                a.b.ray_t0[ray] = t0; a.b.ray_t1[ray] = t1; a.b.ray_dn[ray] = a.b.cand_dn[cand_this]; a.b.ray_flag[ray] = is_obj ? 1 : 0; a.b.target_depth[ray] = tdp;
                 a.b.bgcol[3 * ray] = bg0; a.b.bgcol[3 * ray + 1] = bg1; a.b.bgcol[3 * ray + 2] = bg2; a.b.target[3 * ray] = tg0; a.b.target[3 * ray + 1] = tg1; a.b.target[3 * ray + 2] = tg2;
             }
             if (h == 0) {
@@ -763,6 +813,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
     }
 #ifdef MON_FUSED_TIMING
     tstamp(tc, 9);
+    tcx.acc[14] = (float)(uint32_t)(wall_clock64() & 0xffffffull);
     if (lane == 0) for (int k = 0; k < 16; ++k) a.b.tdist[(blockIdx.x * S::WAVES + wave) * 16 + k] = tcx.acc[k];
 #endif
 }
