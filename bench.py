@@ -207,10 +207,15 @@ def main():
                         "note": "the path is gather-bound; MFMA is used only for the MLP's tiny GEMMs (busy_frac_pmc: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES of the committed pass)"}
     req, rate = pmc.get("k_fused_train_l2_read_requests_per_launch"), pmc.get("l2_rate")
     if fused and req and rate:
-        # one L2 request per distinct 64-byte line per gather instruction; the chip serves ~270 G of those per second (128 L2 channels x
-        # ~2.1 GHz, profiles/r01_microbench.md); requests from the committed PMC pass of this regime
-        roofline["l2_request_bound"] = {"requests_per_launch": req, "measured_peak_requests_per_s": rate, "min_ms": round(1e3 * req / rate, 4),
-                                        "frac": round(1e3 * req / rate / fb_ms, 4), "regime": regime}
+        # one L2 request per distinct 64-byte line per gather instruction.  Two rates from the gather micro-benchmark (profiles/r01_microbench.md): ~270 G/s is
+        # the most the chip serves for ANY lane arrangement (four lanes per line), ~210 G/s what it serves for this kernel's arrangement (lane pairs share a
+        # line); `frac` prices the requests of the committed PMC pass of this regime at the second.  encode_only_ms: the same kernel with everything but the
+        # gathers switched off (profiles/r02_fused_floor.md) -- the measured floor of the gather phase.
+        prate = pj.get("l2_line_request_rate_pair_pattern_per_s") or rate
+        roofline["l2_request_bound"] = {"requests_per_launch": req, "measured_peak_requests_per_s": prate, "min_ms": round(1e3 * req / prate, 4),
+                                        "frac": round(1e3 * req / prate / fb_ms, 4), "regime": regime, "any_pattern_peak_requests_per_s": rate,
+                                        "frac_of_any_pattern_peak": round(1e3 * req / rate / fb_ms, 4),
+                                        "encode_only_ms": (pj.get("k_fused_train_encode_only_us") or 0) / 1e3 or None, "source": pj.get("floor_source")}
 
     # ---- extra, not the headline: the same measurement late in training (the scatter handles only the samples that still carry a
     #      gradient; an OfflineNeRF job runs 5000 iterations)
