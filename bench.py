@@ -216,6 +216,12 @@ def main():
                                         "frac": round(1e3 * req / prate / fb_ms, 4), "regime": regime, "any_pattern_peak_requests_per_s": rate,
                                         "frac_of_any_pattern_peak": round(1e3 * req / rate / fb_ms, 4),
                                         "encode_only_ms": (pj.get("k_fused_train_encode_only_us") or 0) / 1e3 or None, "source": pj.get("floor_source")}
+        gr = pj.get("gather_rate_microbench_per_s") or {}
+        own = gr.get("lanes_l_l32_share_a_line (the kernel's arrangement)")
+        if own:      # the same bound in the unit the gather micro-benchmark reports: half2 gathers (lane-loads) per second
+            gathers = 8 * L * B
+            roofline["gather_rate"] = {"gathers_per_launch": gathers, "achieved_per_s": round(gathers / (fb_ms * 1e-3), 1), "microbench_same_lane_arrangement_per_s": own,
+                                       "frac": round(gathers / (fb_ms * 1e-3) / own, 4), "microbench_best_pair_arrangement_per_s": gr.get("adjacent_lanes_share_a_line"), "source": gr.get("source")}
 
     # ---- extra, not the headline: the same measurement late in training (the scatter handles only the samples that still carry a
     #      gradient; an OfflineNeRF job runs 5000 iterations)

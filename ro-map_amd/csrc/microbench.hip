@@ -22,21 +22,22 @@ __global__ void __launch_bounds__(256) k_ub(int mode, int pattern, uint32_t n_en
     // gather-sharing probes (all read-only half2 gathers, pattern as given):
     //   mode 7: consecutive loads of one lane hit the same 64-byte line (idx, idx^1)      mode 8: lanes l and l^32 of one load share a line
     //   mode 9: as mode 3 through buffer_load (SGPR descriptor + 32-bit offset)            mode 20: 4 lanes (l, l^16, l^32, l^48) share a line
+    //   mode 21: ADJACENT lanes l, l^1 share a line      mode 22: lanes l, l^16      mode 23: 4 adjacent lanes share a line
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(table, 0, (int)(n_entries * 32u), 0x00020000);
 #pragma unroll 8
     for (uint32_t i = 0; i < ops_per_thread; ++i) {
         uint32_t key = gid, it = i;
-        if (mode == 7) it = i >> 1; else if (mode == 8) key = gid & ~32u; else if (mode == 20) key = gid & ~48u;
+        if (mode == 7) it = i >> 1; else if (mode == 8) key = gid & ~32u; else if (mode == 20) key = gid & ~48u; else if (mode == 21) key = gid & ~1u; else if (mode == 22) key = gid & ~16u; else if (mode == 23) key = gid & ~3u;
         uint32_t r = mix32(key * 0x9E3779B9u + it * 0x85EBCA6Bu + 12345u), idx;
         if (pattern == 0) idx = r % n_entries;
         else { const uint32_t lvl = i & 15u; const uint32_t size = lvl == 0 ? 4096u : (lvl == 1 ? 32768u : 65536u); const uint32_t off = lvl == 0 ? 0u : (lvl == 1 ? 4096u : 36864u + (lvl - 2u) * 65536u); idx = off + (r % size); }
-        if (mode == 7) idx ^= (i & 1u); else if (mode == 8) idx ^= (gid >> 5) & 1u; else if (mode == 20) idx ^= (gid >> 4) & 3u;
+        if (mode == 7) idx ^= (i & 1u); else if (mode == 8) idx ^= (gid >> 5) & 1u; else if (mode == 20) idx ^= (gid >> 4) & 3u; else if (mode == 21) idx ^= gid & 1u; else if (mode == 22) idx ^= (gid >> 4) & 1u; else if (mode == 23) idx ^= gid & 3u;
         const half2_t v = { (half_t)1e-3f, (half_t)-1e-3f };
         if (mode == 0) __builtin_amdgcn_global_atomic_fadd_v2f16(t16 + idx, v);
         else if (mode == 1) __builtin_amdgcn_global_atomic_fadd_v2f16(t16 + (size_t)xcc * n_entries + idx, v);
         else if (mode == 2) atomicAdd(reinterpret_cast<float*>(table) + idx, 1e-3f);
         else if (mode == 9) { acc += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, idx * 4u, 0, 0)); }
-        else if (mode == 3 || mode == 7 || mode == 8 || mode == 20) { const half2_t g = reinterpret_cast<const half2_t*>(table)[idx]; acc += (float)g.x + (float)g.y; }
+        else if (mode == 3 || mode == 7 || mode == 8 || mode >= 20) { const half2_t g = reinterpret_cast<const half2_t*>(table)[idx]; acc += (float)g.x + (float)g.y; }
         else if (mode == 4) { const uint32_t b = (idx & ~7u) + ((idx + (i & 7u)) & 7u); __builtin_amdgcn_global_atomic_fadd_v2f16(t16 + b, v); }
         else if (mode == 5) { const uint4 g = reinterpret_cast<const uint4*>(table)[idx >> 2]; acc += __uint_as_float(g.x ^ g.y ^ g.z ^ g.w); }      // 16-byte aligned quad gather
         else { const uint2 g = reinterpret_cast<const uint2*>(table)[idx >> 1]; acc += __uint_as_float(g.x ^ g.y); }                          // mode 6: 8-byte pair gather
@@ -92,10 +93,11 @@ int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n
     const uint32_t ops_per_thread = 64, threads = n_ops / ops_per_thread, blocks = (threads + 255) / 256;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
-    if (mode >= 10) hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ub_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    const bool lds_mode = mode >= 10 && mode < 20;      // (modes 20+ are gather probes again)
+    if (lds_mode) hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ub_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0, 0);
-        if (mode >= 10) hipLaunchKernelGGL(k_ub_lds, dim3(256), dim3(1024), 131072, 0, mode, n_ops / (256u * 1024u), sink);
+        if (lds_mode) hipLaunchKernelGGL(k_ub_lds, dim3(256), dim3(1024), 131072, 0, mode, n_ops / (256u * 1024u), sink);
         else hipLaunchKernelGGL(k_ub, dim3(blocks), dim3(256), 0, 0, mode, pattern, n_entries, ops_per_thread, table, sink);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms = 0.f; hipEventElapsedTime(&ms, e0, e1); if (rep > 0 && ms < best) best = ms;
