@@ -148,17 +148,38 @@ int stream_pool_reserve(int device, int n) {
     return rc;
 }
 
+// One inference stream and one pinned result buffer per DEVICE, shared by the objects on it: created with the device's first object (CreateNeRF is a
+// milliseconds call anyway; created by the first render it was a 10 ms spike in front of the viewer), and only one more hardware-queue client however many objects
+// train (a high-priority queue per object measurably slowed sliced training).  Renders of one device take turns on it.
+struct InferShared { std::mutex mu; hipStream_t stream = nullptr; float* h_out = nullptr; size_t h_cap = 0; };
+static std::mutex g_infer_mu; static std::map<int, InferShared*> g_infer_shared;
+static int infer_shared_get(int device, size_t pixels_hint, InferShared** out) {
+    std::lock_guard<std::mutex> l(g_infer_mu);
+    InferShared*& sh = g_infer_shared[device];
+    if (!sh) {
+        sh = new InferShared();
+        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&sh->stream, hipStreamNonBlocking, hi) != hipSuccess) { delete sh; sh = nullptr; set_error("inference stream creation failed on device %d", device); return MON_ERR_HIP; }
+    }
+    if (5 * pixels_hint > sh->h_cap) {
+        std::lock_guard<std::mutex> l2(sh->mu);
+        float* q = nullptr; if (hipHostMalloc((void**)&q, 5 * pixels_hint * sizeof(float), hipHostMallocDefault) != hipSuccess) { set_error("pinned render buffer allocation failed"); return MON_ERR_HIP; }
+        if (sh->h_out) hipHostFree(sh->h_out);
+        sh->h_out = q; sh->h_cap = 5 * pixels_hint;
+    }
+    *out = sh; return MON_OK;
+}
+
 // ---- inference side of a model (the reference's second stream, nerf_model.cu:1268-1269).  The training thread PUBLISHES the inference weights
 // at the end of every train call / online slice: a device-to-device copy into one of two snapshot buffers, ordered on the train stream, with an
 // event.  A viewer thread renders from the latest published snapshot on the inference stream (created with the highest priority) and in a
 // workspace of its own: it takes no model mutex, never touches the train stream, and its kernels do not queue behind training slices.
 struct InferState {
-    hipStream_t stream = nullptr;
-    uint16_t* snap[2] = { nullptr, nullptr }; hipEvent_t ready[2] = { nullptr, nullptr }; uint32_t step_of[2] = { 0, 0 };
+    InferShared* shared = nullptr;                                      // the device's inference stream (highest priority) and pinned result buffer
+    uint16_t* snap[2] = { nullptr, nullptr }; hipEvent_t ready[2] = { nullptr, nullptr }; uint32_t step_of[2] = { 0, 0 }; bool written[2] = { false, false };
     int latest = -1, readers[2] = { 0, 0 }; std::mutex mu;              // which snapshot is current, who is reading which
     std::atomic<bool> wanted{ false }; std::chrono::steady_clock::time_point last_pub{};      // a viewer asked since the last publication; when that was
-    std::mutex render_mu;                                               // one snapshot render per object at a time (they share the workspace below)
-    BatchPtrs rb{}; float *out_rgb = nullptr, *out_depth = nullptr, *out_mask = nullptr; size_t out_cap = 0; uint16_t* frag = nullptr;
+    BatchPtrs rb{}; float *out_all = nullptr, *out_rgb = nullptr, *out_depth = nullptr, *out_mask = nullptr; size_t out_cap = 0; uint16_t* frag = nullptr;
     std::vector<void*> grown;                                           // superseded output buffers, freed with the object
 };
 
@@ -261,14 +282,12 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     m.mesh = mesh_state_create(m.device);
     if (m.backend == 1 && !m.lazy_ema) {          // (tables above 8 M parameters keep their EMA lazily and would cost 2 x 200 MB of snapshots: they render on the train stream)
         InferState* is = new InferState(); m.infer = is;
-        // (the stream itself is created by the first viewer render: every stream is another hardware-queue client, and a pool of idle high-priority
-        //  queues next to the training streams measurably slows sliced training -- 72 -> 76 us per object-step with four objects)
+        if ((rc = infer_shared_get(m.device, (size_t)ds->K.W * (size_t)ds->K.H, &is->shared))) return rc;      // (a whole frame fits: no growth in front of a viewer)
         for (int k = 0; k < 2; ++k) { if ((rc = dev_alloc(m, is->snap[k], n, false))) return rc; HIPCHECK(hipEventCreateWithFlags(&is->ready[k], hipEventDisableTiming)); }
         is->rb = m.B;
         if ((rc = dev_alloc(m, is->rb.ray_o, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, is->rb.ray_d, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, is->rb.ray_dn, kRenderChunkRays)) ||
             (rc = dev_alloc(m, is->rb.ray_t0, kRenderChunkRays)) || (rc = dev_alloc(m, is->rb.ray_t1, kRenderChunkRays)) || (rc = dev_alloc(m, is->rb.ray_flag, kRenderChunkRays)) ||
-            (rc = dev_alloc(m, is->out_rgb, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, is->out_depth, kRenderChunkRays)) || (rc = dev_alloc(m, is->out_mask, kRenderChunkRays)) ||
-            (rc = dev_alloc(m, is->frag, 64 * 512))) return rc;
+            (rc = dev_alloc(m, is->out_all, 5 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, is->frag, 64 * 512))) return rc;
         is->out_cap = kRenderChunkRays;
     }
     HIPCHECK(hipDeviceSynchronize());
@@ -289,7 +308,7 @@ static int publish_snapshot(Model& m, bool force = true) {
     const uint16_t* src = (m.h_state.step > 0) ? m.P.ema : m.P.half;
     launch_copy_params(m.train_stream, src, is->snap[w], m.n_params);
     HIPCHECK(hipEventRecord(is->ready[w], m.train_stream));
-    { std::lock_guard<std::mutex> l(is->mu); is->step_of[w] = m.h_state.step; is->latest = w; }
+    { std::lock_guard<std::mutex> l(is->mu); is->step_of[w] = m.h_state.step; is->written[w] = true; is->latest = w; }
     return MON_OK;
 }
 
@@ -313,7 +332,7 @@ int model_destroy(Model* mp) {
     model_mesh_free(m);
     if (m.train_stream) hipStreamSynchronize(m.train_stream);
     if (m.infer) {
-        InferState* is = m.infer; if (is->stream) { hipStreamSynchronize(is->stream); hipStreamDestroy(is->stream); }
+        InferState* is = m.infer; if (is->shared) { std::lock_guard<std::mutex> l(is->shared->mu); hipStreamSynchronize(is->shared->stream); }      // (the stream and the pinned buffer stay with the device)
         for (int k = 0; k < 2; ++k) if (is->ready[k]) hipEventDestroy(is->ready[k]);
         for (void* p : is->grown) hipFree(p);
         delete is; m.infer = nullptr;
@@ -486,34 +505,46 @@ int model_publish_snapshot(Model& m) { HIPCHECK(use_device(m.device)); return pu
 int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, uint32_t* snapshot_step) {
     if (!pose16 || !rgb || !depth || !mask || box.w == 0 || box.h == 0) { set_error("render: bad argument"); return MON_ERR_ARG; }
     InferState* is = m.infer; if (!is) { set_error("render_snapshot: this object renders on its train stream"); return MON_ERR_STATE; }
-    std::lock_guard<std::mutex> one(is->render_mu);
+    InferShared* sh = is->shared; std::lock_guard<std::mutex> one(sh->mu);      // one snapshot render per device at a time
     is->wanted.store(true);                                             // the training side refreshes the snapshot at the end of its current slice
     int r;
-    { std::lock_guard<std::mutex> l(is->mu); r = is->latest; if (r < 0) { set_error("render_snapshot: no weights published yet"); return MON_ERR_STATE; } ++is->readers[r]; }
+    {   std::lock_guard<std::mutex> l(is->mu); r = is->latest; if (r < 0) { set_error("render_snapshot: no weights published yet"); return MON_ERR_STATE; }
+        // the newest snapshot's copy may still be queued behind other objects' training kernels (it runs on the train stream, at normal priority: 1-2 ms on a
+        // busy device); the one before it is complete, and nobody writes it before the train stream has been synchronised again -- by which time the newest is
+        // complete and chosen here.  A viewer prefers a finished snapshot one slice older to waiting.
+        if (is->written[1 - r] && hipEventQuery(is->ready[r]) != hipSuccess && hipEventQuery(is->ready[1 - r]) == hipSuccess) r = 1 - r;
+        ++is->readers[r]; }
     struct Release { InferState* is; int r; ~Release() { std::lock_guard<std::mutex> l(is->mu); --is->readers[r]; } } release{ is, r };
     HIPCHECK(use_device(m.device));
-    if (!is->stream) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIPCHECK(hipStreamCreateWithPriority(&is->stream, hipStreamNonBlocking, hi)); }
-    hipStream_t s = is->stream;
+    hipStream_t s = sh->stream;
     HIPCHECK(hipStreamWaitEvent(s, is->ready[r], 0));
     if (snapshot_step) *snapshot_step = is->step_of[r];
     Mat4 pose; std::memcpy(pose.m, pose16, 64);
     const uint32_t n_pix = box.w * box.h, S2 = 2 * m.oc.S;
-    if (n_pix > is->out_cap) {
-        const size_t cap = std::max<size_t>(n_pix, 2 * is->out_cap); void* q[3] = { nullptr, nullptr, nullptr };
-        HIPCHECK(hipMalloc(&q[0], 12 * cap)); HIPCHECK(hipMalloc(&q[1], 4 * cap)); HIPCHECK(hipMalloc(&q[2], 4 * cap));
-        for (void* p : q) is->grown.push_back(p);                       // (freed with the object; the superseded ones are smaller than the live one)
-        is->out_rgb = (float*)q[0]; is->out_depth = (float*)q[1]; is->out_mask = (float*)q[2]; is->out_cap = cap;
+    if (n_pix > is->out_cap) {                                           // one buffer of 5 floats per pixel: rgb | depth | mask laid out back to back for THIS crop, so one copy brings them home
+        const size_t cap = std::max<size_t>(n_pix, 2 * is->out_cap); void* q = nullptr;
+        HIPCHECK(hipMalloc(&q, 20 * cap));
+        is->grown.push_back(q);                                         // (freed with the object; the superseded ones are smaller than the live one)
+        is->out_all = (float*)q; is->out_cap = cap;
     }
+    is->out_rgb = is->out_all; is->out_depth = is->out_all + 3 * (size_t)n_pix; is->out_mask = is->out_all + 4 * (size_t)n_pix;
     for (uint32_t p0 = 0; p0 < n_pix; p0 += kRenderChunkRays) {
         const uint32_t n = (n_pix - p0) < kRenderChunkRays ? (n_pix - p0) : kRenderChunkRays;
         launch_render_rays(s, is->rb, m.ds->K, m.oc, box, pose, pose_is_Toc, p0, n);
         launch_fused_render(s, m.lf, m.nd, is->snap[r], is->rb, m.oc, n, p0 * S2, is->out_rgb + 3 * (size_t)p0, is->out_depth + p0, is->out_mask + p0, is->frag, p0 == 0u);
     }
-    HIPCHECK(hipMemcpyAsync(rgb, is->out_rgb, 12 * (size_t)n_pix, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(depth, is->out_depth, 4 * (size_t)n_pix, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(mask, is->out_mask, 4 * (size_t)n_pix, hipMemcpyDeviceToHost, s));
+    // results: through a PINNED staging buffer of the inference side.  A device-to-host copy into the caller's pageable memory is done by the runtime's own
+    // blit path, which queues at normal priority behind every training kernel on the device (12 objects training: 5-6 ms for 1 MB, one render in five); into
+    // pinned memory it is ordered on this high-priority stream.
+    if (5 * (size_t)n_pix > sh->h_cap) {                                  // (a crop larger than a frame: not produced by the managers)
+        float* q = nullptr; HIPCHECK(hipHostMalloc((void**)&q, 5 * (size_t)n_pix * sizeof(float), hipHostMallocDefault));
+        if (sh->h_out) hipHostFree(sh->h_out);
+        sh->h_out = q; sh->h_cap = 5 * (size_t)n_pix;
+    }
+    HIPCHECK(hipMemcpyAsync(sh->h_out, is->out_all, 20 * (size_t)n_pix, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipGetLastError());
+    std::memcpy(rgb, sh->h_out, 12 * (size_t)n_pix); std::memcpy(depth, sh->h_out + 3 * (size_t)n_pix, 4 * (size_t)n_pix); std::memcpy(mask, sh->h_out + 4 * (size_t)n_pix, 4 * (size_t)n_pix);
     return MON_OK;
 }
 
@@ -604,7 +635,8 @@ int model_set_params(Model& m, const float* master, size_t n) {
     launch_master_to_half(m.train_stream, m.P.master, m.P.half, (uint32_t)n);
     HIPCHECK(hipStreamSynchronize(m.train_stream));
     m.next_ready = false;                                   // the fragment image no longer matches the weights
-    return publish_snapshot(m);                             // (viewers of an untrained object see the weights just set)
+    { const int rc = publish_snapshot(m); if (rc) return rc; }   // (viewers of an untrained object see the weights just set:
+    HIPCHECK(hipStreamSynchronize(m.train_stream)); return MON_OK;   //  the snapshot is complete before the call returns, so no render prefers the one before it)
 }
 
 }  // namespace mon
