@@ -21,6 +21,9 @@ int mon_debug_fast_index(const mon_config* cfg, int level, uint32_t x, uint32_t 
  * source[n_image] = MLP parameter index held by each image element (-1 = structural zero); slots[2 * n_mlp] = the (<= 2) image elements
  * each parameter feeds (-1 = none).  Either pointer may be NULL. */
 int mon_debug_frag_layout(int encoded_width_padded, int n_neurons, int n_hidden_layers, int n_levels, int* source, int* slots, int* n_image, int* n_mlp);
+/* Accumulator layout of k_fused_train's dW partial rows (frag_layout.h acc_param): param[n_cols] = MLP parameter index each column sums into
+ * (-1 = pad column of a narrow encoding); the loss partial follows at column n_cols.  param may be NULL. */
+int mon_debug_acc_layout(int encoded_width_padded, int n_neurons, int n_hidden_layers, int n_levels, int* param, int* n_cols);
 /* MFMA fragment-layout self-test: D[32x32] = A[32x16] * B[16x32], fp16 in / fp32 out, through the lane mapping the fused kernels rely on. */
 int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
 /* config.yaml key look-up of the sequence reader (cv::FileStorage semantics: exact key at line start); returns MON_ERR_IO when absent. */

@@ -120,6 +120,7 @@ _DIAG_SIGS = {
     "mon_object_debug_read": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "mon_microbench": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
     "mon_debug_frag_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mon_debug_acc_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "mon_debug_fast_index": (C.c_int, [C.POINTER(MonConfig), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mon_selftest_mfma": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mon_debug_yaml_number": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_double)]),
@@ -548,6 +549,14 @@ def marching_cubes(density, res3, thresh, aabb_min, aabb_max, device=0):
 
 def generate_toc(theta_deg, phi_deg, radius):
     T = np.empty(16, np.float32); _check(lib().mon_generate_toc(theta_deg, phi_deg, radius, _p(T))); return T
+
+
+def acc_layout(epad, W, NH, L):
+    """param[n_cols]: the MLP parameter each column of k_fused_train's dW partial rows sums into (frag_layout.h acc_param; -1 = pad column)."""
+    nc = C.c_int(0)
+    _check(diag_lib().mon_debug_acc_layout(epad, W, NH, L, None, C.byref(nc)))
+    prm = np.empty(nc.value, np.int32)
+    _check(diag_lib().mon_debug_acc_layout(epad, W, NH, L, _p(prm), C.byref(nc))); return prm
 
 
 def frag_layout(epad, W, NH, L):

@@ -92,6 +92,13 @@ int mon_debug_frag_layout(int epad, int W, int NH, int L, int* source, int* slot
     if (slots) for (int p = 0; p < d.N_MLP(); ++p) { int o[2] = { -1, -1 }; const int n = frag_slots(d, p, o); slots[2 * p] = n > 0 ? o[0] : -1; slots[2 * p + 1] = n > 1 ? o[1] : -1; }
     return MON_OK;
 }
+int mon_debug_acc_layout(int epad, int W, int NH, int L, int* param, int* n_cols) {
+    if (!(epad == 16 || epad == 32) || !(W == 32 || W == 64) || !(NH == 1 || NH == 2) || L < 1 || 2 * L > epad) { set_error("acc_layout: unsupported shape"); return MON_ERR_ARG; }
+    const FragDims d{ epad, W, NH, L };
+    if (n_cols) *n_cols = acc_cols(d);
+    if (param) for (int i = 0; i < acc_cols(d); ++i) param[i] = acc_param(d, i);
+    return MON_OK;
+}
 int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D) { REQUIRE(A, "A"); REQUIRE(B, "B"); REQUIRE(D, "D"); return selftest_mfma(device, A, B, D); }
 int mon_debug_yaml_number(const char* text, const char* key, double* value) {
     REQUIRE(text, "text"); REQUIRE(key, "key"); REQUIRE(value, "value");

@@ -156,6 +156,26 @@ def test_fragment_layout_maps_are_inverse(pkg, shape):
     assert ((slots[:, 0] >= 0) == real).all() and ((slots[:, 1] >= 0) == real).all()
 
 
+@pytest.mark.parametrize("shape", [(32, 64, 1, 16), (16, 32, 2, 4), (32, 64, 2, 13), (16, 64, 1, 7), (32, 32, 2, 16)])
+def test_accumulator_layout_of_the_dw_partial_rows(pkg, shape):
+    """frag_layout.h acc_param: k_fused_train writes its weight-gradient partial rows in MFMA accumulator order and the summing kernels map columns to
+    parameters.  The map must hit every parameter that can carry a gradient exactly once and nothing else."""
+    epad, W, NH, L = shape
+    prm = pkg.acc_layout(epad, W, NH, L)
+    n_mlp = W * epad + (NH - 1) * W * W + 16 * W
+    hit = prm[prm >= 0]
+    assert hit.max() < n_mlp and np.unique(hit).size == hit.size                  # no parameter is summed from two columns
+    expect = np.zeros(n_mlp, bool)
+    expect[: W * epad] = True                                                     # all of W0 (pad-feature columns receive exact zeros: their inputs are zero)
+    if NH == 2:
+        expect[W * epad: W * epad + W * W] = True
+    off_wo = W * epad + (NH - 1) * W * W; expect[off_wo: off_wo + 4 * W] = True    # the 4 real output rows; rows 4..15 of the padded layer never get a gradient
+    got = np.zeros(n_mlp, bool); got[hit] = True
+    assert (got == expect).all()
+    assert prm.size == (W // 32) * 1024 + (NH - 1) * (W // 32) ** 2 * 1024 + (W // 32) * 128
+    assert ((prm < 0).sum() == 0) if epad == 32 else ((prm < 0).sum() == (W // 32) * 512)   # a 16-wide encoding leaves half of the dW0 tile columns unused
+
+
 def test_diagnostics_live_in_their_own_library(pkg):
     """libmon_core.so is the product only: the micro-benchmarks, the MFMA self-test, the debug read-back and the layout hooks are exported by
     libmon_core_diag.so (include/mon_core_diag.h), which links against the product library -- never the other way round."""
