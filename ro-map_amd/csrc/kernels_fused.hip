@@ -52,20 +52,8 @@ __device__ __forceinline__ int unit_of_slot(int s, int h, int j) { return 32 * (
 #ifndef MON_ENCODE_BATCH
 #define MON_ENCODE_BATCH 4
 #endif
-// experiment switches (tools/variant_build.sh -D...): MON_V_SCALAR 1 = wave-uniform ray bookkeeping pinned to SGPRs
-#ifndef MON_V_SCALAR
-#define MON_V_SCALAR 0          // measured: -2 us with the bookkeeping left on the vector unit (100 SGPRs were already in use; the scalar version spills them into VGPR lanes)
-#endif
-#ifndef MON_V_WPS
-#define MON_V_WPS 2            // waves per SIMD k_fused_train is compiled for (3: smaller epilogue scratch so that three workgroups fit a CU's LDS)
-#endif
 #ifndef MON_V_SBATCH
 #define MON_V_SBATCH 4          // samples per thread and software-pipeline round of k_grid_scatter
-#endif
-#if MON_V_SCALAR
-#define MON_UNIFORM(x) __builtin_amdgcn_readfirstlane((int)(x))
-#else
-#define MON_UNIFORM(x) (x)
 #endif
 constexpr int kEncodeBatch = MON_ENCODE_BATCH;
 #ifndef MON_V_STAGGER
@@ -405,7 +393,7 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane_uniform) { ret
 
 // ------------------------------------------------------------------ fused training kernel
 template <int EPAD, int W, int NH, bool DUMP, bool ATOMIC_LEVELS, bool OCC = false>
-__global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k_fused_train(FusedArgs a) {
+__global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_train(FusedArgs a) {
     using S = FusedShape<EPAD, W, NH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half_t* frags = reinterpret_cast<half_t*>(smem);
@@ -421,7 +409,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
 #endif
     // ---- prologue.  Everything a wave needs before its first gather is requested up front, and only the weight fragments (first read by the MLP) wait for
     //      the workgroup barrier: the iteration counter, the candidates' ballot words, the fragment image.
-    const int wave = MON_UNIFORM(threadIdx.x >> 6), lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
     const int L = a.nd.L, LPH = (L + 1) >> 1;
     const uint32_t R = (a.ablate & 8u) ? 0u : a.oc.R, iter = a.st->iter;
     // ---- ray compaction (fill_rollover_rays :280-294 without a kernel of its own): training ray j is valid candidate number (j mod n_valid) in candidate
@@ -455,7 +443,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : MON_V_WPS)) k
             wd = ((unsigned long long)lane_u((uint32_t)(my_word >> 32), (int)lo) << 32) | lane_u((uint32_t)my_word, (int)lo); kk = kth - lane_u(my_excl, (int)lo);
         } else {
             lo = 0; uint32_t hi = nwords - 1u;
-            while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if ((uint32_t)MON_UNIFORM(cprefix[mid]) <= kth) lo = mid; else hi = mid - 1u; }
+            while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if (cprefix[mid] <= kth) lo = mid; else hi = mid - 1u; }
             wd = cwords[lo]; kk = kth - cprefix[lo];
         }
         uint32_t pos = 0;
@@ -1123,7 +1111,7 @@ __global__ void __launch_bounds__(256) k_fused_render(FusedArgs a, uint32_t n_ra
     LevelLds* llt = reinterpret_cast<LevelLds*>(smem + S::FRAG_BYTES);
     build_fragments<EPAD, W, NH>(frags, llt, a, false);
     __syncthreads();
-    const int wave = MON_UNIFORM(threadIdx.x >> 6), lane = threadIdx.x & 63, n = lane & 31;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31;
     const int L = a.nd.L; const uint32_t S2 = 2u * a.oc.S;      // 64
     const half2_t* table = reinterpret_cast<const half2_t*>(a.params + a.nd.n_mlp);
     const LevelRegs lregs = load_level_regs_uniform(a.lt, L, lane); const uint32_t table_bytes = a.lt.offset[L] * 4u;      // (from the argument segment: it ends up in the buffer descriptor, which must be scalar)
