@@ -54,12 +54,12 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
         std::vector<uint16_t> part(m.n_grid); std::vector<float> acc(m.n_grid);
         uint16_t* out = reinterpret_cast<uint16_t*>(dst);
         for (uint32_t i = 0; i < m.n_grid; ++i) { _Float16 h; std::memcpy(&h, &out[i], 2); acc[i] = (float)h; }
-        const uint32_t n_ent = m.n_grid / 2;                                  // partial tables are planar: [partition][feature][entry]
+        const uint32_t n_ent = m.n_grid / 2, n_half = n_ent / 2;              // partial tables are planar: [partition][feature][parity][entry / 2]
         for (uint32_t q = 0; q < m.scatter.max_P; ++q) {
             HIPCHECK(hipMemcpy(part.data(), m.d_gpart + (size_t)q * m.n_grid, (size_t)m.n_grid * 2, hipMemcpyDeviceToHost));
             for (int l = 0; l < m.nd.L; ++l) {
                 if (q >= m.scatter.P[l]) continue;                              // this level has fewer partial tables: the rest of the buffer is not its data
-                for (uint32_t e = m.lt.offset[l]; e < m.lt.offset[l + 1]; ++e) for (uint32_t f = 0; f < 2; ++f) { _Float16 h; std::memcpy(&h, &part[(size_t)f * n_ent + e], 2); acc[2 * e + f] += (float)h; }
+                for (uint32_t e = m.lt.offset[l]; e < m.lt.offset[l + 1]; ++e) for (uint32_t f = 0; f < 2; ++f) { _Float16 h; std::memcpy(&h, &part[((size_t)f * 2 + (e & 1u)) * n_half + (e >> 1)], 2); acc[2 * e + f] += (float)h; }
             }
         }
         for (uint32_t i = 0; i < m.n_grid; ++i) { const _Float16 h = (_Float16)acc[i]; std::memcpy(&out[i], &h, 2); }

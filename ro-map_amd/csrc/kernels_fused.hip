@@ -816,26 +816,46 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
 // a larger loss scale coarsens the unit by the same factor (LevelFast::fix_scale, set by the host), which keeps the range at
 // "un-scaled gradient below 1.0" -- tcnn's own fp16 atomics would be down to 3 significant digits there.
 //
-// One workgroup = (level, 32768-entry part of that level, FEATURE, sample partition): a 128 KB tile of int32 accumulators for
-// one of the two features.  The kernel is VALU-bound (profiles/r02_*: ~4 cycles per wave instruction, the LDS array 20-30 %
-// busy), and a workgroup pays the index arithmetic of every sample of its partition for the few corners that land in its tile;
-// splitting by feature instead of into four 16384-entry parts halves the corner work inside the divergent in-tile branch and
-// doubles the share of lanes that take it (a hashed corner pair is in a given 32768-entry half of a 2^16 table with
-// probability 1/2).  Every level gets 16 workgroups: parts_l = 2 * ceil(entries_l / 32768) parts x P_l = 16 / parts_l sample
-// partitions.  Tiles are written densely as fp16 to partial table p, feature plane f of that level ([P][2][entries]); the
-// optimizer sums the P_l partial tables.  No global atomics, no memset: every tile is fully rewritten each step.
-constexpr uint32_t kScatterTile = 32768;          // entries per LDS tile: one int32 accumulator per entry (one feature) = 128 KB
+// A level's accumulators (entries x 2 features x 4 B: 512 KB at 65 536 entries) need several workgroups, and each of them walks every sample of
+// its partition -- so what matters is how little a workgroup does per sample, and that every level's workgroups finish together (the kernel ends with
+// the slowest).  Two costs set the pace (profiles/r02_*): VALU issue (~4 cycles per wave instruction) and the LDS atomic unit (~4 lanes per clock, more
+// when lanes collide: the samples of a ray that share a coarse cell hit the same eight addresses).
+//   * hashed / large levels: one workgroup = (FEATURE, PARITY of the entry index, 32 768-entry range of that parity half, sample partition), a 128 KB tile
+//     of int32.  Both features share all index arithmetic, but the split halves the corner work per workgroup.  The two x-corners of a (y, z) pair always
+//     differ in the lowest index bit (scatter_item), so the owner of the even (odd) entries takes exactly ONE corner of each of the four pairs: no in-tile
+//     test, no divergent branch, all lanes busy (tiles by entry range: eight tests for four hits on average, inside a branch every wave took anyway).
+//   * small levels (the dense coarse ones: the LDS atomic unit is their limit): BOTH features in one 64-bit accumulator per entry -- lo = feature 0,
+//     hi = feature 1, added as one sign-extended 64-bit integer, so a corner costs one ds_add_u64 instead of two ds_add_u32 in two workgroups; the whole
+//     level in one tile while it fits the CU's 160 KB (20 448 entries), else one tile per parity (40 896 entries).
+// Every level gets 16 workgroups: parts_l x P_l sample partitions (parts = 1 / 2 for the 64-bit tiles, 4 x ceil(entries / 65 536) otherwise).  Tiles are
+// written densely as fp16 to partial table p, plane (feature, parity) of that level ([P][2][2][entries / 2]); the optimizer sums the P_l partial tables.
+// No global atomics, no memset: every tile is fully rewritten each step.
+constexpr uint32_t kScatterTile = 32768;          // entries per int32 tile of a parity half (one feature) = 128 KB
+constexpr uint32_t kScatterLdsBytes = 163840;     // the workgroup declares the CU's whole LDS
+constexpr uint32_t kScatterTile64 = (kScatterLdsBytes - 256u) / 8u;      // entries per 64-bit tile (both features): 20 448
 constexpr uint32_t kScatterWgPerLevel = 16;
+enum : int { kTileParity = 0, kTileParityRanged = 1, kTileWhole64 = 2, kTileParity64 = 3 };
+__host__ __device__ inline int scatter_tile_mode(uint32_t size) { return size <= kScatterTile64 ? kTileWhole64 : (size <= 2u * kScatterTile64 ? kTileParity64 : (size <= 2u * kScatterTile ? kTileParity : kTileParityRanged)); }
+__host__ __device__ inline uint32_t scatter_parts(uint32_t size) { const int m = scatter_tile_mode(size); return m == kTileWhole64 ? 1u : (m == kTileParity64 ? 2u : 4u * ((size + 2u * kScatterTile - 1u) / (2u * kScatterTile))); }
 
 struct ScatterItem { half2_t g; float4_t x; };
 
 // fixed-point contribution of one corner and feature: tcnn's (T)(weight * grad), exact in 1 / fs units
 __device__ __forceinline__ int contrib_fix(float w, float g, float fs) { return (int)((float)(half_t)(w * g) * fs); }
 
-template <bool HASHED, bool POW2>
-__device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bool valid, uint32_t feature, float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask, uint32_t base, uint32_t tile, float fs) {
-    const float g = (float)(feature ? it.g.y : it.g.x);          // (k_fused_train stores dL/dE already clamped to the fixed-point range)
-    if (!valid || g == 0.f) return;
+// sign-extended packing of two fixed-point contributions into one 64-bit addend: the 64-bit sum S of such addends decodes exactly as lo = (int32)S,
+// hi = (S - lo) >> 32 while both sums stay inside int32 (they do: the same clamp as for the 32-bit tiles)
+__device__ __forceinline__ unsigned long long pack_fix(int lo, int hi) { return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)(hi + (lo >> 31)) << 32); }
+
+// One sample, one level.  The two x-corners of a (y, z) pair always have entry indices of different parity -- hashed: idx1 = idx0 ^ ((x ^ (x + 1)) & mask)
+// and x ^ (x + 1) is odd; dense: idx1 = idx0 + 1 modulo an even size (the clamps below only act on positions far outside [0,1]^3, which the sampler never
+// produces: they keep such a sample inside the table, where it lands is then as meaningless as the sample).
+template <bool HASHED, bool POW2, int MODE, bool DEGEN /* the index ignores y and z: the four pairs of a sample are ONE entry */>
+__device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bool valid, uint32_t feature, float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask,
+                                             uint32_t parity, uint32_t base_half, uint32_t tile, float fs) {
+    constexpr bool BOTH = MODE == kTileWhole64 || MODE == kTileParity64;
+    const float g = (float)(feature ? it.g.y : it.g.x), g0 = (float)it.g.x, g1 = (float)it.g.y;          // (k_fused_train stores dL/dE already clamped to the fixed-point range)
+    if (!valid || (BOTH ? (g0 == 0.f && g1 == 0.f) : g == 0.f)) return;
     float pos[3]; uint32_t pg[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, it.x[d], 0.5f), fl = floorf(q); pg[d] = (uint32_t)(int32_t)fl; pos[d] = q - fl; }
@@ -843,38 +863,44 @@ __device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bo
     const uint32_t ax0 = pg[0], ax1 = pg[0] + 1u, y0 = (HASHED && POW2) ? __umul24(pg[1], my & 0xffffffu) : pg[1] * my, z0 = (HASHED && POW2) ? __umul24(pg[2], mz & 0xffffffu) : pg[2] * mz;
     const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
     const float wx[2] = { 1.f - pos[0], pos[0] }, wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
-    // Hashed power-of-two level: the two x corners of a (y, z) pair are idx0 and idx0 ^ dxm with dxm = (x ^ (x + 1)) & mask.  Unless x ends in 15 or
-    // more one-bits, dxm stays below the tile size, both corners fall into the same tile and ONE range test covers the pair (the rare other case --
-    // decided per wave -- takes the corner-by-corner walk below).
-    const uint32_t dxm = (ax0 ^ ax1) & mask;
-    if (HASHED && POW2 && __ballot(dxm >= kScatterTile) == 0ull) {                         // (tile bases are multiples of kScatterTile)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t l0 = ((ax0 ^ ay[j & 1] ^ az[j >> 1]) & mask) - base;
-            if (l0 < tile) {
-                const float wyz0 = wx[0] * wy[j & 1], wyz1 = wx[1] * wy[j & 1];           // ((wx * wy) * wz): the reference walk's product order
-                atomicAdd(tab + l0, contrib_fix(wyz0 * wz[j >> 1], g, fs));
-                atomicAdd(tab + (l0 ^ dxm), contrib_fix(wyz1 * wz[j >> 1], g, fs));
-            }
-        }
-    } else {
-        uint32_t ayz[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ayz[j] = HASHED ? (ay[j & 1] ^ az[j >> 1]) : (ay[j & 1] + az[j >> 1]);
+    unsigned long long* tab64 = reinterpret_cast<unsigned long long*>(tab);
+    if (MODE == kTileWhole64) {                                   // the whole level is this workgroup's: eight corners, nothing to test, one 64-bit atomic each
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            uint32_t idx = (HASHED ? ((k & 1 ? ax1 : ax0) ^ ayz[k >> 1]) : ((k & 1 ? ax1 : ax0) + ayz[k >> 1])) & mask;
+            const uint32_t t = HASHED ? (ay[(k >> 1) & 1] ^ az[k >> 2]) : (ay[(k >> 1) & 1] + az[k >> 2]);
+            uint32_t idx = (HASHED ? ((k & 1 ? ax1 : ax0) ^ t) : ((k & 1 ? ax1 : ax0) + t)) & mask;
             if (!POW2) { idx -= (idx >= size) ? size : 0u; idx = min(idx, size - 1u); }
-            const uint32_t local = idx - base;
-            if (local < tile) atomicAdd(tab + local, contrib_fix((wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2], g, fs));
+            const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];      // ((wx * wy) * wz): the reference walk's product order
+            atomicAdd(tab64 + idx, pack_fix(contrib_fix(w, g0, fs), contrib_fix(w, g1, fs)));
         }
+        return;
     }
+    const uint32_t dxm = (ax0 ^ ax1) & mask;                      // hashed power-of-two level: idx1 = idx0 ^ dxm (odd)
+    int dsum = 0; uint32_t dlocal = 0;                            // (degenerate level, see below)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t idx0, idx1;
+        if (HASHED && POW2) { idx0 = (ax0 ^ ay[j & 1] ^ az[j >> 1]) & mask; idx1 = idx0 ^ dxm; }
+        else {
+            const uint32_t t = HASHED ? (ay[j & 1] ^ az[j >> 1]) : (ay[j & 1] + az[j >> 1]);
+            idx0 = (HASHED ? (ax0 ^ t) : (ax0 + t)) & mask; idx1 = (HASHED ? (ax1 ^ t) : (ax1 + t)) & mask;
+            if (!POW2) { idx0 -= (idx0 >= size) ? size : 0u; idx0 = min(idx0, size - 1u); idx1 -= (idx1 >= size) ? size : 0u; idx1 = min(idx1, size - 1u); }
+        }
+        const bool second = ((idx0 ^ parity) & 1u) != 0u;        // which corner of the pair is this workgroup's
+        const uint32_t idx = second ? idx1 : idx0;
+        const float w = ((second ? wx[1] : wx[0]) * wy[j & 1]) * wz[j >> 1];
+        const uint32_t local = (idx >> 1) - base_half;
+        if (MODE == kTileParity64) atomicAdd(tab64 + local, pack_fix(contrib_fix(w, g0, fs), contrib_fix(w, g1, fs)));
+        else if (DEGEN) { dsum += contrib_fix(w, g, fs); dlocal = local; }      // all four pairs are the SAME entry: one atomic for the (exact) sum
+        else if (MODE == kTileParity || local < tile) atomicAdd(tab + local, contrib_fix(w, g, fs));
+    }
+    if (DEGEN) atomicAdd(tab + dlocal, dsum);
 }
 
-template <bool HASHED, bool POW2>
+template <bool HASHED, bool POW2, int MODE, bool DEGEN = false>
 __device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restrict__ de, const float4_t* __restrict__ x4, uint32_t cnt_lo, uint32_t cnt_hi /* lane b: run length of ray bin b / b + 64 */,
                                                 uint32_t n_bins, uint32_t bin0, uint32_t bin_step, uint32_t bin_cap, uint32_t feature,
-                                                float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask, uint32_t base, uint32_t tile, float fs) {
+                                                float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask, uint32_t parity, uint32_t base_half, uint32_t tile, float fs) {
     // This workgroup's samples are the ray bins bin0, bin0 + bin_step, ... (< n_bins), each a compacted run of samples at b * bin_cap.  They are
     // walked in STEPS.  While the runs are long (every sample carries a gradient: 1024 per bin) a step is one bin and thread t takes offset
     // r * 1024 + t; once they are short (late training: a few dozen per bin) the workgroup's waves split into G groups of W2 = 1024 / G threads
@@ -915,7 +941,7 @@ __device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restr
             for (int u = 0; u < kBatch; ++u) fetch(nxt[u], nv[u]);
         }
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) scatter_item<HASHED, POW2>(tab, cur[u], cv[u], feature, scale, size, my, mz, mask, base, tile, fs);
+        for (int u = 0; u < kBatch; ++u) scatter_item<HASHED, POW2, MODE, DEGEN>(tab, cur[u], cv[u], feature, scale, size, my, mz, mask, parity, base_half, tile, fs);
     }
 }
 
@@ -993,7 +1019,7 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
     float4_t pacc[kPartialsMaxPasses];
     if (pa.partials) partials_prefetch(pa, pacc);                                    // loads in flight while the tile is cleared and filled
     int* tab = reinterpret_cast<int*>(smem);
-    float* red = reinterpret_cast<float*>(smem + (size_t)kScatterTile * 4u);           // 256 B behind the tile
+    float* red = reinterpret_cast<float*>(smem + (size_t)kScatterLdsBytes - 256u);     // 256 B behind the largest tile
     // run lengths of the compacted ray bins, lane b of every wave holds bin b's and bin (b + 64)'s (read back with v_readlane: no memory access in the sample loop)
     const uint32_t bin_cap = B / n_bins, lb = threadIdx.x & 63u;
     // (both sets are requested and the iteration's one is picked afterwards: the address must not wait for the load of the iteration counter)
@@ -1002,42 +1028,72 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
     const uint32_t cnt_lo = min((iter & 1u) ? c_lo1 : c_lo0, bin_cap), cnt_hi = min((iter & 1u) ? c_hi1 : c_hi0, bin_cap);
     const uint32_t slot = blockIdx.x / kScatterWgPerLevel, j = blockIdx.x - slot * kScatterWgPerLevel;
     const int level = sl.level[slot]; const uint32_t P = sl.P[level];
-    const uint32_t part = j / P, p = j - part * P, feature = part & 1u;
+    const uint32_t part = j / P, p = j - part * P;
     const uint32_t off = lt.offset[level], size = lt.size[level], my = lt.my[level], mz = lt.mz[level], mask = lt.mask[level];
     const bool hashed = lt.hashed[level] != 0u, pow2 = mask != 0xffffffffu;
     const float scale = lt.scale[level], fs = lt.fix_scale;
-    const uint32_t base = (part >> 1) * kScatterTile;
+    const int mode = scatter_tile_mode(size);                                         // uniform: which kind of tile this level's workgroups hold (see above)
+    const bool both = mode == kTileWhole64 || mode == kTileParity64;
+    const uint32_t feature = both ? 0u : (part & 1u), parity = mode == kTileWhole64 ? 0u : (both ? (part & 1u) : ((part >> 1) & 1u));
+    const uint32_t half_size = size >> 1, base_half = mode == kTileParityRanged ? (part >> 2) * kScatterTile : 0u;      // (level sizes are multiples of 8) parity tiles: idx = 2 * (base_half + local) + parity
+    const bool degenerate = hashed && pow2 && (my & mask) == 0u && (mz & mask) == 0u;  // the index ignores y and z (tcnn's stride wrap-around at res = 65 536): the four pairs of a sample are one entry
     MON_ST_STAMP();
-    if (base < size) {                                                                // (levels whose part count does not divide 16 leave workgroups without a tile)
-        const uint32_t tile = min(kScatterTile, size - base);
-        {   // tile sizes are multiples of 8 entries (tcnn rounds level sizes up to 8): clear with 16-byte stores
-            typedef int int4v __attribute__((ext_vector_type(4)));
-            int4v* t4 = reinterpret_cast<int4v*>(tab);
-            for (uint32_t i = threadIdx.x; i < tile / 4u; i += blockDim.x) t4[i] = int4v{ 0, 0, 0, 0 };
+    if (mode != kTileParityRanged || base_half < half_size) {                         // (levels whose part count does not divide 16 leave workgroups without a tile)
+        const uint32_t tile = mode == kTileWhole64 ? size : min(mode == kTileParity64 ? kScatterTile64 : kScatterTile, half_size - base_half);      // entries
+        typedef int int4v __attribute__((ext_vector_type(4)));
+        {   // tiles are multiples of 4 entries (tcnn rounds level sizes up to 8): clear with 16-byte stores
+            int4v* t4 = reinterpret_cast<int4v*>(tab); const uint32_t n16 = both ? tile / 2u : tile / 4u;
+            for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) t4[i] = int4v{ 0, 0, 0, 0 };
         }
         MON_ST_STAMP();
         __syncthreads();
         MON_ST_STAMP();
         // sample partition p of this level = the ray bins b = p, p + P, ... (16 bins, compacted by k_fused_train: only samples with a non-zero gradient)
         const half2_t* de = de_soa + (size_t)level * B;
-#define MON_SCATTER_CALL(H, PW) scatter_samples<H, PW>(tab, de, x4, cnt_lo, cnt_hi, n_bins, p, P, bin_cap, feature, scale, size, my, mz, mask, base, tile, fs)
-        if (hashed) { if (pow2) MON_SCATTER_CALL(true, true); else MON_SCATTER_CALL(true, false); }
-        else { if (pow2) MON_SCATTER_CALL(false, true); else MON_SCATTER_CALL(false, false); }
+#define MON_SCATTER_CALL(H, PW, MD, ...) scatter_samples<H, PW, MD, ##__VA_ARGS__>(tab, de, x4, cnt_lo, cnt_hi, n_bins, p, P, bin_cap, feature, scale, size, my, mz, mask, parity, base_half, tile, fs)
+#define MON_SCATTER_MODE(MD) do { if (hashed) { if (pow2) MON_SCATTER_CALL(true, true, MD); else MON_SCATTER_CALL(true, false, MD); } else { if (pow2) MON_SCATTER_CALL(false, true, MD); else MON_SCATTER_CALL(false, false, MD); } } while (0)
+        if (mode == kTileWhole64) MON_SCATTER_MODE(kTileWhole64);
+        else if (mode == kTileParity64) MON_SCATTER_MODE(kTileParity64);
+        else if (mode == kTileParity) { if (degenerate) MON_SCATTER_CALL(true, true, kTileParity, true); else MON_SCATTER_MODE(kTileParity); }
+        else MON_SCATTER_MODE(kTileParityRanged);
+#undef MON_SCATTER_MODE
 #undef MON_SCATTER_CALL
         MON_ST_STAMP();
         __syncthreads();
         MON_ST_STAMP();
-        half_t* dst = gpart + ((size_t)p * 2u + feature) * n_entries + off + base;     // partial table p, plane `feature`
-        {   // 8 entries per thread and pass: 32 bytes of accumulators in, one 16-byte store of eight halves out
-            typedef int int4v __attribute__((ext_vector_type(4)));
-            const int4v* t4 = reinterpret_cast<const int4v*>(tab);
-            const float inv = 1.0f / fs;
+        const int4v* t4 = reinterpret_cast<const int4v*>(tab);
+        const float inv = 1.0f / fs;
+        const size_t plane = n_entries >> 1;                                           // partial table p, plane (feature, parity): entry idx at [idx >> 1]
+        half_t* pl = gpart + ((size_t)p * 4u) * plane + (off >> 1);
+        const auto lo_hi = [&](int lo_bits, int hi_bits, float& f0, float& f1) { f0 = (float)lo_bits * inv; f1 = (float)(hi_bits - (lo_bits >> 31)) * inv; };      // undo pack_fix
+        if (mode == kTileWhole64) {            // entries 2k, 2k + 1 interleaved, both features: 4 entries (32 B) per thread and pass -> 2 halves into each of the four planes
+            for (uint32_t i = threadIdx.x; i < tile / 4u; i += blockDim.x) {
+                const int4v a = t4[2u * i], c = t4[2u * i + 1u];                        // entries 4i, 4i+1 | 4i+2, 4i+3
+                float e0f0, e0f1, e1f0, e1f1, e2f0, e2f1, e3f0, e3f1; lo_hi(a[0], a[1], e0f0, e0f1); lo_hi(a[2], a[3], e1f0, e1f1); lo_hi(c[0], c[1], e2f0, e2f1); lo_hi(c[2], c[3], e3f0, e3f1);
+                *reinterpret_cast<half2_t*>(pl + 0u * plane + 2u * i) = half2_t{ (half_t)e0f0, (half_t)e2f0 };      // feature 0, even entries
+                *reinterpret_cast<half2_t*>(pl + 1u * plane + 2u * i) = half2_t{ (half_t)e1f0, (half_t)e3f0 };      // feature 0, odd
+                *reinterpret_cast<half2_t*>(pl + 2u * plane + 2u * i) = half2_t{ (half_t)e0f1, (half_t)e2f1 };      // feature 1, even
+                *reinterpret_cast<half2_t*>(pl + 3u * plane + 2u * i) = half2_t{ (half_t)e1f1, (half_t)e3f1 };      // feature 1, odd
+            }
+        } else if (mode == kTileParity64) {    // one parity, both features: 4 entries (32 B) per thread and pass -> 4 halves into each of the two feature planes
+            for (uint32_t i = threadIdx.x; i < tile / 4u; i += blockDim.x) {
+                const int4v a = t4[2u * i], c = t4[2u * i + 1u];
+                float f0[4], f1[4]; lo_hi(a[0], a[1], f0[0], f1[0]); lo_hi(a[2], a[3], f0[1], f1[1]); lo_hi(c[0], c[1], f0[2], f1[2]); lo_hi(c[2], c[3], f0[3], f1[3]);
+                *reinterpret_cast<half4_t*>(pl + (0u + parity) * plane + 4u * i) = half4_t{ (half_t)f0[0], (half_t)f0[1], (half_t)f0[2], (half_t)f0[3] };
+                *reinterpret_cast<half4_t*>(pl + (2u + parity) * plane + 4u * i) = half4_t{ (half_t)f1[0], (half_t)f1[1], (half_t)f1[2], (half_t)f1[3] };
+            }
+        } else {                               // int32 tile of one feature and parity: 8 entries per thread and pass, one 16-byte store of eight halves
+            half_t* dst = pl + (feature * 2u + parity) * plane + base_half;
             for (uint32_t i = threadIdx.x; i < tile / 8u; i += blockDim.x) {
                 const int4v a0 = t4[2u * i], a1 = t4[2u * i + 1u];
                 half8_t o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { o[e] = (half_t)((float)a0[e] * inv); o[4 + e] = (half_t)((float)a1[e] * inv); }
                 *reinterpret_cast<half8_t*>(dst + 8u * i) = o;
+            }
+            if ((tile & 4u) && threadIdx.x == 0u) {                                    // a parity half is a multiple of 4 entries, not always of 8
+                const int4v a0 = t4[tile / 4u - 1u];
+                *reinterpret_cast<half4_t*>(dst + (tile & ~7u)) = half4_t{ (half_t)((float)a0[0] * inv), (half_t)((float)a0[1] * inv), (half_t)((float)a0[2] * inv), (half_t)((float)a0[3] * inv) };
             }
         }
     }
@@ -1059,10 +1115,10 @@ uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl
     // for its one tile.  When the table has levels that need the large-table path anyway (kernels_bigscatter.hip), levels of 5..16
     // tiles go there too.
     uint32_t max_parts = kScatterWgPerLevel;
-    for (int l = 0; l < nd.L; ++l) if (2u * ((lt.offset[l + 1] - lt.offset[l] + kScatterTile - 1) / kScatterTile) > kScatterWgPerLevel) max_parts = 4;
+    for (int l = 0; l < nd.L; ++l) if (scatter_parts(lt.offset[l + 1] - lt.offset[l]) > kScatterWgPerLevel) max_parts = 4;
     for (int l = 0; l < nd.L; ++l) {
         const uint32_t size = lt.offset[l + 1] - lt.offset[l];
-        const uint32_t parts = 2u * ((size + kScatterTile - 1) / kScatterTile);              // entry ranges x the two features
+        const uint32_t parts = scatter_parts(size);
         if (parts <= max_parts) {
             mask |= 1u << l; sl.level[sl.n_levels++] = (uint8_t)l;
             sl.P[l] = (uint8_t)(kScatterWgPerLevel / parts); if (sl.P[l] > sl.max_P) sl.max_P = sl.P[l];
@@ -1085,7 +1141,7 @@ void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& l
                          const float* partials, uint32_t n_partials, float* gmlp) {
     ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return;
     const PartialsArgs pa{ partials, n_partials, fused_partial_cols(nd) + 64u, fused_partial_cols(nd), FragDims{ nd.Epad, nd.W, nd.NH, nd.L }, gmlp, st };
-    constexpr uint32_t smem = kScatterTile * 4 + 256;
+    constexpr uint32_t smem = kScatterLdsBytes;
     static std::atomic<uint64_t> attr_devices{ 0 };       // function attributes are per device: the managers run objects on every GPU of the node from one process
     if (first_use_on_this_device(attr_devices)) hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     float* timing = nullptr;

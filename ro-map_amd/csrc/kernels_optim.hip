@@ -121,20 +121,29 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                     for (int l = 1; l < kMaxLevels; ++l) lvl += (e0 >= p.sl.entry_offset[l]) ? 1 : 0;
                     n_part = p.sl.P[lvl];
                 }
-                // dense partial tables of k_grid_scatter (fused backend): [partition][feature plane][entry]; this chunk = entries e0 .. e0 + 3, both features
-                const uint16_t* pp = p.gpart + ((i0 - oc.n_mlp) >> 1);
-                const size_t plane = p.part_stride >> 1;                 // entries per plane
-                uint32_t q = 0;
-                for (; q + 2 <= n_part; q += 2) {                       // 4 independent 8-byte loads in flight
-                    const half4_t a0 = *reinterpret_cast<const half4_t*>(pp + (size_t)(2u * q) * plane), a1 = *reinterpret_cast<const half4_t*>(pp + (size_t)(2u * q + 1u) * plane);
-                    const half4_t b0 = *reinterpret_cast<const half4_t*>(pp + (size_t)(2u * q + 2u) * plane), b1 = *reinterpret_cast<const half4_t*>(pp + (size_t)(2u * q + 3u) * plane);
+                // dense partial tables of k_grid_scatter (fused backend): [partition][feature][parity][entry / 2]; this chunk = entries e0 .. e0 + 3 (e0 a multiple
+                // of 4), both features: per partition four 4-byte pieces -- plane (f, b) holds entries e0 + b and e0 + 2 + b next to each other
+                const uint16_t* pp = p.gpart + ((i0 - oc.n_mlp) >> 2);
+                const size_t plane = p.part_stride >> 2;                 // entries per (feature, parity) plane
+                auto quad = [&](uint32_t q, float (&v)[8]) {             // partition q's eight values in parameter order (entry-major, feature-minor)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { g[2 * e] += (float)a0[e] + (float)b0[e]; g[2 * e + 1] += (float)a1[e] + (float)b1[e]; }
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const half2_t h = *reinterpret_cast<const half2_t*>(pp + ((size_t)(q * 2u + (uint32_t)f) * 2u + (uint32_t)b) * plane);
+                            v[2 * b + f] = (float)h.x; v[2 * (2 + b) + f] = (float)h.y;
+                        }
+                };
+                uint32_t q = 0;
+                for (; q + 2 <= n_part; q += 2) {                       // 8 independent 4-byte loads in flight
+                    float va[8], vb[8]; quad(q, va); quad(q + 1u, vb);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] += va[j] + vb[j];
                 }
                 for (; q < n_part; ++q) {
-                    const half4_t a0 = *reinterpret_cast<const half4_t*>(pp + (size_t)(2u * q) * plane), a1 = *reinterpret_cast<const half4_t*>(pp + (size_t)(2u * q + 1u) * plane);
+                    float va[8]; quad(q, va);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { g[2 * e] += (float)a0[e]; g[2 * e + 1] += (float)a1[e]; }
+                    for (int j = 0; j < 8; ++j) g[j] += va[j];
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { any |= g[j] != 0.f; g[j] = unscale(g[j]); }

@@ -207,6 +207,34 @@ def test_nondefault_hyperparameters_match_oracle(pkg, orc, small_scene, backend)
     obj.close(); ds.close(); ref.close()
 
 
+@pytest.mark.parametrize("kw", [dict(log2_hashmap_size=17, n_levels=8, base_resolution=16),        # sizes 4920 / 35944 / 131072 x 6: 64-bit whole, 64-bit per parity, parity halves cut into two ranges
+                                dict(log2_hashmap_size=18, n_levels=6, base_resolution=16),        # 262144-entry levels: four ranges per parity half, one sample partition
+                                dict(log2_hashmap_size=14, n_levels=16, base_resolution=16)],      # every hashed level a 64-bit whole-level tile (16384 entries)
+                         ids=["T17", "T18", "T14"])
+def test_grid_scatter_tile_modes_match_oracle(pkg, orc, small_scene, kw):
+    """k_grid_scatter picks a tile shape per level from its size (whole level / one parity half / ranges of a parity half; 32- or 64-bit accumulators):
+    one forward/backward against the oracle's grid gradient on tables that exercise every shape, at base.json's batch size of the LDS path."""
+    kw = dict(kw, rays_per_batch=256, n_neurons=64, n_hidden_layers=1)
+    ds, obj, ref = _pair(pkg, orc, small_scene, kw, 1)
+    p = pattern_params(ref); obj.set_params(p); ref.set_params(p)
+    obj.train_stages(1 | 2); ref.generate_batch(); ref.forward_backward()
+    assert int(obj.buffer("state")[2]) == ref.n_valid > 0
+    assert np.array_equal(obj.buffer("E"), ref.buffer("E")), "hash-grid encode must be bit-exact"
+    gg = h2f(obj.buffer("ggrid_h")).astype(np.float64); rg = ref.buffer("ggrid").astype(np.float64); ra = ref.buffer("ggrid_abs").astype(np.float64)
+    bound = 2.0 ** -9 * ra + 2.0 ** -10 * np.abs(rg) + 1e-7              # exact integer accumulation, one fp16 rounding per sample partition
+    bad = np.abs(gg - rg) > bound
+    assert float(bad.mean()) < 1e-4 and (gg != 0).sum() > 1000, (float(bad.mean()), int((gg != 0).sum()))
+    assert ((gg != 0) == (rg != 0)).mean() > 0.999                       # the same entries receive a gradient
+    obj.close(); ds.close(); ref.close()
+    ds, obj, ref = _pair(pkg, orc, small_scene, kw, 1)                    # and three optimizer steps: the optimizer reads the planes the scatter wrote
+    obj.set_debug_dump(False); obj.set_params(p); ref.set_params(p)
+    for _ in range(3):
+        la = obj.train(1); ref.train(1)
+    nm = ref.n_mlp; a, b = obj.get_params(0), ref.buffer("master")
+    assert float((np.abs(a[nm:] - b[nm:]) > 3e-4).mean()) < 1e-2
+    obj.close(); ds.close(); ref.close()
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_learning_rate_decay_follows_the_oracle(pkg, orc, small_scene, backend):
     """ExponentialDecay (base.json:9-13: start 20000, interval 10000, base 0.33 -- never reached by the 5000 offline steps, reached
