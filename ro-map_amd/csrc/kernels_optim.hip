@@ -42,8 +42,12 @@ __device__ __forceinline__ void ema_catch_up(half8_t& e, const half8_t& w, uint3
 // gradient or when the inference weights are needed (k_ema_finalize).  The weights and Adam state are exactly those of the eager
 // schedule; the EMA differs from the step-by-step fp16 recurrence by rounding only.
 template <bool DENSE, bool LAZY>
-__global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, DevState* __restrict__ st, OptimNext nx, uint32_t n_bins) {
+__global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, DevState* __restrict__ st, OptimNext nx, uint32_t lazy_below) {
     const uint32_t n_valid = st->n_valid, step = st->step;
+    // DENSE tables: while most samples carry a gradient practically every chunk is updated and the optimizer state is requested together with the gradients
+    // (one memory round trip); once few do (late training: k_grid_scatter left the count in n_scatter_now) most chunks only need their EMA advanced, and
+    // the 112 B of Adam state per chunk are requested behind the gradient test instead
+    const bool eager = DENSE && !(lazy_below != 0u && st->n_scatter_now <= lazy_below);
     const bool cand_block = blockIdx.x < nx.cand_blocks;            // GenerateRays of iteration iter + 1 (every block reads the state before its ticket)
     if (cand_block) gen_candidate(nx.b, nx.ds, nx.oc, st->n_boxes, st->iter + 1u, blockIdx.x * blockDim.x + threadIdx.x);
     const uint32_t bid = blockIdx.x - nx.cand_blocks, nblk = gridDim.x - nx.cand_blocks;
@@ -83,7 +87,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
             // DENSE (small tables: practically every entry has a gradient each step): the optimizer state is requested together
             // with the gradients -- one memory round trip instead of two; sparse tables keep the state loads behind the test.
             float4_t w0, w1, a0, a1, b0, b1; uint4 s0, s1;
-            if (DENSE) {
+            if (eager) {
                 w0 = *reinterpret_cast<const float4_t*>(p.master + i0); w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
                 a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0); a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
                 b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
@@ -151,7 +155,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
             if (lazy_chunk && !any) return;                                            // untouched: nothing to do now (see k_ema_finalize)
             // the fp16 working copy is h(master) by construction (creation, set_params, every update): where the master weights are loaded anyway it is not read back
             half8_t wh;
-            if (DENSE) {
+            if (eager) {
                 const float wm[8] = { w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3] };
 #pragma unroll
                 for (int j = 0; j < 8; ++j) wh[j] = (half_t)wm[j];
@@ -163,7 +167,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                 p.ema_step[c] = cur;
             }
             if (any) {
-                if (!DENSE) {
+                if (!eager) {
                     w0 = *reinterpret_cast<const float4_t*>(p.master + i0); w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
                     a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0); a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
                     b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
@@ -277,7 +281,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
         if (t == gridDim.x - 1u) {
             st->ticket = 0u;
             st->iter = st->iter + 1u;
-            { const uint32_t tot = st->n_scatter_now; st->n_scatter_now = 0u; st->n_scatter_last = tot; st->n_scatter_total += tot; (void)n_bins; }   // (the slot counters themselves are cleared and summed by k_grid_scatter)
+            { const uint32_t tot = st->n_scatter_now; st->n_scatter_now = 0u; st->n_scatter_last = tot; st->n_scatter_total += tot; }   // (the slot counters themselves are cleared and summed by k_grid_scatter)
             if (n_valid != 0u) {
                 st->step = cur;
                 if ((int)cur >= oc.decay_start && oc.decay_interval > 0 && ((int)cur - oc.decay_start) % oc.decay_interval == 0) st->lr = lr0 * oc.decay_base;
@@ -350,16 +354,16 @@ void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, u
     hipLaunchKernelGGL(k_master_to_half, dim3(1024), dim3(256), 0, s, master, half, n);
 }
 
-void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx, uint32_t n_bins) {
+void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx, uint32_t lazy_below) {
     const uint32_t chunks = oc.n_params >> 3;
     const uint32_t env_cap = (uint32_t)options().opt_blocks;
     // measured: base.json (239 k chunks) 256 / 512 / 1024 blocks = 28.1 / 23.7 / 26.2 us; T = 2^22 (13.2 M chunks) 512 / 2048 / 8192 / 32768 blocks = 368 / 244 / 251 / 406 us
     uint32_t cap = chunks / (256u * 8u); if (cap < 512u) cap = 512u; if (cap > 2048u) cap = 2048u; if (env_cap) cap = env_cap;
     uint32_t blocks = (chunks + 255) / 256; if (blocks > cap) blocks = cap; if (blocks < 1u) blocks = 1u;     // ~2 chunks per thread at base.json size: measured best (256: 28.1, 512: 23.7, 1024: 26.2 us)
     // dense = every level goes through the LDS scatter, i.e. tables of at most 2^18 entries that a 131 072-sample batch covers
-    if (p.gpart && p.all_levels_dense) hipLaunchKernelGGL((k_optimizer<true, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx, n_bins);
-    else if (p.ema_step) hipLaunchKernelGGL((k_optimizer<false, true>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx, n_bins);
-    else hipLaunchKernelGGL((k_optimizer<false, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx, n_bins);
+    if (p.gpart && p.all_levels_dense) hipLaunchKernelGGL((k_optimizer<true, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx, lazy_below);
+    else if (p.ema_step) hipLaunchKernelGGL((k_optimizer<false, true>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx, lazy_below);
+    else hipLaunchKernelGGL((k_optimizer<false, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx, lazy_below);
 }
 
 }  // namespace mon

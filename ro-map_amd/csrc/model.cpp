@@ -38,7 +38,7 @@ static long* option_slot(const char* name) {
         { "backend", &Options::backend }, { "use_graph", &Options::use_graph }, { "lazy_ema", &Options::lazy_ema }, { "big_switch", &Options::big_switch },
         { "touched_flags", &Options::touched_flags }, { "lds_scatter", &Options::lds_scatter }, { "fold_reduce", &Options::fold_reduce }, { "fold_next", &Options::fold_next },
         { "fused_grid", &Options::fused_grid }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger },
-        { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner }, { "scatter_bins", &Options::scatter_bins } };
+        { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner }, { "scatter_bins", &Options::scatter_bins }, { "opt_lazy_below", &Options::opt_lazy_below } };
     for (const auto& e : tab) if (name && std::strcmp(name, e.n) == 0) return &(g_options.*(e.f));
     return nullptr;
 }
@@ -443,7 +443,7 @@ static void enqueue_iteration(Model& m, int stages) {
             nx.cand_blocks = (m.oc.R + 255) / 256; nx.frag_image = m.d_frag_train; nx.fd = FragDims{ m.nd.Epad, m.nd.W, m.nd.NH, m.nd.L };
             nx.b = m.B; nx.ds = m.ds->ptrs(); nx.oc = m.oc;
         }
-        launch_optimizer(s, P, m.opt, m.d_state, nx, m.n_bins); m.scatter_pending = false;
+        launch_optimizer(s, P, m.opt, m.d_state, nx, options().opt_lazy_below < 0 ? (m.oc.R * m.oc.S) / 8u : (uint32_t)options().opt_lazy_below); m.scatter_pending = false;
         m.next_ready = (m.backend == 1 && fold);
     }
 }

@@ -101,7 +101,7 @@ enum {
 // Process-wide test and tuning switches (mon_set_option, include/mon_core.h); defaults are the product behaviour.
 struct Options {
     long backend = -1, use_graph = 0, lazy_ema = -1, big_switch = 16384, touched_flags = 1, lds_scatter = 1, fold_reduce = 1, fold_next = 1,
-         fused_grid = 0, opt_blocks = 0, fused_ablate = 0, fused_stagger = -1, offline_outer = 10, offline_inner = 500, scatter_bins = 0;
+         fused_grid = 0, opt_blocks = 0, fused_ablate = 0, fused_stagger = -1, offline_outer = 10, offline_inner = 500, scatter_bins = 0, opt_lazy_below = -1;
 };
 Options& options();
 int option_set(const char* name, long value);
@@ -132,7 +132,7 @@ void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, u
 void launch_copy_params(hipStream_t s, const uint16_t* src, uint16_t* dst, uint32_t n);
 
 // optimizer (kernels_optim.hip)
-void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx, uint32_t n_bins);
+void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx, uint32_t lazy_below);   // lazy_below: gradient-carrying samples at or below which the dense-table optimizer requests Adam state per touched chunk only
 void launch_ema_finalize(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, const DevState* st);
 void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_partials, const NetDims& nd, float* gmlp, DevState* st);
 uint32_t fused_partial_cols(const NetDims& nd);      // columns of a k_fused_train dW partial row (accumulator layout), the loss partial follows
