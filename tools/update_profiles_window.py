@@ -43,11 +43,12 @@ def main():
     rnd = sys.argv[1]
     pj_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     old = json.load(open(pj_path)) if os.path.exists(pj_path) else {}
-    out = {"l2_line_request_rate_measured_per_s": old.get("l2_line_request_rate_measured_per_s", 270e9),
+    out = dict(old)                      # (keys written by other tools -- fused_floor, gatherbench -- stay)
+    out.update({"l2_line_request_rate_measured_per_s": old.get("l2_line_request_rate_measured_per_s", 270e9),
            "note": "rocprofv3 --kernel-trace --pmc, one counter set per pass (tools/gpu_profile_window.sh), means per dispatch over the 20 dispatches of the named window of "
                    "`python tools/profile_window.py` (base.json object, bench scene); hbm bytes = (2*FETCH_SIZE + WRITE_SIZE) KB per MI355X_MICROARCH.md (the FETCH_SIZE correction is "
                    "calibrated for wide streams only; 4-byte gathers are uncalibrated). l2_line_request_rate: distinct-line gather rate measured by tools/run_gatherbench.py "
-                   "(238-273 G lines/s chip-wide whatever the lane arrangement = 128 L2 channels x ~2.1 GHz). SQ_* cycle counters are in quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES."}
+                   "(266-272 G lines/s chip-wide with every lane on its own line = 128 L2 channels x ~2.1 GHz; profiles/r02_gatherbench.md). SQ_* cycle counters are in quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES."})
     for k in ("dense", "sparse"):
         if k in old and isinstance(old[k], dict):
             out[k] = old[k]
