@@ -541,7 +541,9 @@ int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int
         if (sh->h_out) hipHostFree(sh->h_out);
         sh->h_out = q; sh->h_cap = 5 * (size_t)n_pix;
     }
-    HIPCHECK(hipMemcpyAsync(sh->h_out, is->out_all, 20 * (size_t)n_pix, hipMemcpyDeviceToHost, s));
+    // (a copy KERNEL on this stream writing the pinned buffer over PCIe, not hipMemcpyAsync: the runtime's copy path has its own queueing, 1-2 ms on a device
+    //  busy with a dozen training objects, while a kernel inherits the stream's priority like the render kernels before it)
+    launch_copy_params(s, reinterpret_cast<const uint16_t*>(is->out_all), reinterpret_cast<uint16_t*>(sh->h_out), (uint32_t)(10 * (size_t)n_pix));
     HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipGetLastError());
     std::memcpy(rgb, sh->h_out, 12 * (size_t)n_pix); std::memcpy(depth, sh->h_out + 3 * (size_t)n_pix, 4 * (size_t)n_pix); std::memcpy(mask, sh->h_out + 4 * (size_t)n_pix, 4 * (size_t)n_pix);
