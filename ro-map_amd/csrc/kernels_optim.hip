@@ -348,7 +348,8 @@ __global__ void __launch_bounds__(256) k_copy_params(const uint4* __restrict__ s
 }
 void launch_copy_params(hipStream_t s, const uint16_t* src, uint16_t* dst, uint32_t n) {
     const uint32_t n16 = n / 8u, tail = n - n16 * 8u;
-    hipLaunchKernelGGL(k_copy_params, dim3(512), dim3(256), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16, src + (size_t)n16 * 8u, dst + (size_t)n16 * 8u, tail);
+    const uint32_t blocks = n16 >= 512u * 256u ? 512u : (n16 + 255u) / 256u + (n16 == 0u ? 1u : 0u);
+    hipLaunchKernelGGL(k_copy_params, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16, src + (size_t)n16 * 8u, dst + (size_t)n16 * 8u, tail);
 }
 void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, uint32_t n) {
     hipLaunchKernelGGL(k_master_to_half, dim3(1024), dim3(256), 0, s, master, half, n);

@@ -458,9 +458,11 @@ static void maybe_refresh_occupancy(Model& m, uint32_t iter) {
 static int sync_state(Model& m) {
     // :1645 (once per call instead of once per iteration); the state rides the same sync in a pinned buffer -- the online manager trains
     // in slices of a few iterations, where a second blocking copy would be a visible share of the slice
-    HIPCHECK(hipMemcpyAsync(m.h_state_pinned, m.d_state, sizeof(DevState), hipMemcpyDeviceToHost, m.train_stream));
+    // (only the head: the slot counters behind it are 16 KB the host never reads; written by a one-block kernel rather than hipMemcpyAsync, whose small-copy path
+    //  costs the slicing online thread ~10 us per call)
+    launch_copy_params(m.train_stream, reinterpret_cast<const uint16_t*>(m.d_state), reinterpret_cast<uint16_t*>(m.h_state_pinned), (uint32_t)(offsetof(DevState, n_scatter) / 2));
     HIPCHECK(hipStreamSynchronize(m.train_stream));
-    m.h_state = *m.h_state_pinned;
+    std::memcpy(&m.h_state, m.h_state_pinned, offsetof(DevState, n_scatter));
     collect_profile(m);
     return MON_OK;
 }
