@@ -163,4 +163,15 @@ void launch_grid_points(hipStream_t s, float* pts, int rx, int ry, int rz, uint3
     hipLaunchKernelGGL(k_grid_points, dim3((n + 255) / 256), dim3(256), 0, s, pts, rx, ry, rz, p0, n);
 }
 
+// One incoming frame: colour (3 or 4 bytes per pixel, in pinned host memory: the loads cross PCIe) + instance byte -> r | g << 8 | b << 16 | instance << 24.
+__global__ void __launch_bounds__(256) k_pack_frame(const uint8_t* __restrict__ rgb, int ch, int ri, int bi, const uint8_t* __restrict__ inst, uint32_t* __restrict__ dst, uint32_t px) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < px; i += gridDim.x * blockDim.x) {
+        const uint8_t* c = rgb + (size_t)i * (uint32_t)ch;
+        dst[i] = (uint32_t)c[ri] | ((uint32_t)c[1] << 8) | ((uint32_t)c[bi] << 16) | ((uint32_t)inst[i] << 24);
+    }
+}
+void launch_pack_frame(hipStream_t s, const uint8_t* rgb, int ch, int ri, int bi, const uint8_t* inst, uint32_t* dst, uint32_t px) {
+    hipLaunchKernelGGL(k_pack_frame, dim3((px + 255u) / 256u > 1024u ? 1024u : (px + 255u) / 256u), dim3(256), 0, s, rgb, ch, ri, bi, inst, dst, px);
+}
+
 }  // namespace mon

@@ -73,6 +73,28 @@ int device_count(int* n) {
 
 // ------------------------------------------------------------------ dataset
 int dataset_destroy(Dataset* d);
+// One high-priority stream and one pinned result buffer per DEVICE, shared by the objects on it (viewer renders) and by the device's dataset (frame uploads): created with the device's first object (CreateNeRF is a
+// milliseconds call anyway; created by the first render it was a 10 ms spike in front of the viewer), and only one more hardware-queue client however many objects
+// train (a high-priority queue per object measurably slowed sliced training).  Renders of one device take turns on it.
+struct InferShared { std::mutex mu; hipStream_t stream = nullptr; float* h_out = nullptr; size_t h_cap = 0; };
+static std::mutex g_infer_mu; static std::map<int, InferShared*> g_infer_shared;
+static int infer_shared_get(int device, size_t pixels_hint, InferShared** out) {
+    std::lock_guard<std::mutex> l(g_infer_mu);
+    InferShared*& sh = g_infer_shared[device];
+    if (!sh) {
+        sh = new InferShared();
+        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&sh->stream, hipStreamNonBlocking, hi) != hipSuccess) { delete sh; sh = nullptr; set_error("inference stream creation failed on device %d", device); return MON_ERR_HIP; }
+    }
+    if (5 * pixels_hint > sh->h_cap) {
+        std::lock_guard<std::mutex> l2(sh->mu);
+        float* q = nullptr; if (hipHostMalloc((void**)&q, 5 * pixels_hint * sizeof(float), hipHostMallocDefault) != hipSuccess) { set_error("pinned render buffer allocation failed"); return MON_ERR_HIP; }
+        if (sh->h_out) hipHostFree(sh->h_out);
+        sh->h_out = q; sh->h_cap = 5 * pixels_hint;
+    }
+    *out = sh; return MON_OK;
+}
+
 int dataset_create(int device, int H, int W, float fx, float fy, float cx, float cy, uint32_t max_frames, int use_depth, Dataset** out) {
     int n = 0; int rc = device_count(&n); if (rc) return rc;
     if (device < 0 || device >= n || H <= 0 || W <= 0 || max_frames == 0) { set_error("dataset_create: bad argument"); return MON_ERR_ARG; }
@@ -89,7 +111,13 @@ int dataset_create(int device, int H, int W, float fx, float fy, float cx, float
         return MON_OK;
     };
     if ((rc = alloc())) { dataset_destroy(d); return rc; }          // e.g. out of memory for max_frames images: free what was taken
-    d->staging.resize(px); d->present.assign(max_frames, 0);
+    d->present.assign(max_frames, 0);
+    // frames arrive through a pinned staging buffer and are packed by a kernel on the device's high-priority stream (see dataset_add_frame)
+    { InferShared* sh = nullptr; if ((rc = infer_shared_get(device, px, &sh))) { dataset_destroy(d); return rc; } d->upload = sh; }
+    // (COHERENT pinned memory: the packing kernel re-reads the same host addresses for every frame, and with the default (cacheable) mapping it saw lines of the
+    //  previous frame -- a few hundred stale pixels per image)
+    d->stage_bytes = px * 9 + 128;                                      // raw colour (<= 4 B/pixel), instance (1 B), depth (4 B), pose
+    if (hipHostMalloc((void**)&d->h_stage, d->stage_bytes, hipHostMallocCoherent) != hipSuccess) { set_error("dataset_create: pinned staging allocation failed"); dataset_destroy(d); return MON_ERR_HIP; }
     *out = d; return MON_OK;
 }
 int dataset_add_frame(Dataset* d, uint32_t id, const uint8_t* rgb, int ch, int is_bgr, const uint8_t* inst, const float* depth, const float* Twc) {
@@ -99,11 +127,16 @@ int dataset_add_frame(Dataset* d, uint32_t id, const uint8_t* rgb, int ch, int i
     HIPCHECK(use_device(d->device));
     const size_t px = (size_t)d->K.H * d->K.W;
     const int ri = is_bgr ? 2 : 0, bi = is_bgr ? 0 : 2;             // cv::COLOR_BGR2RGB, nerf_data.cu:167,286
-    for (size_t i = 0; i < px; ++i)
-        d->staging[i] = (uint32_t)rgb[i * ch + ri] | ((uint32_t)rgb[i * ch + 1] << 8) | ((uint32_t)rgb[i * ch + bi] << 16) | ((uint32_t)inst[i] << 24);
-    HIPCHECK(hipMemcpy(d->d_rgba + px * id, d->staging.data(), px * 4, hipMemcpyHostToDevice));
-    if (d->use_depth) HIPCHECK(hipMemcpy(d->d_depth + px * id, depth, px * 4, hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(d->d_poses + 16 * (size_t)id, Twc, 64, hipMemcpyHostToDevice));
+    // The caller's (pageable) images are copied into pinned memory and packed to 4 B/pixel by a kernel that reads them across PCIe, on the device's
+    // high-priority stream: a synchronous hipMemcpy from pageable memory goes through the runtime's blit path at normal priority and, with a dozen objects
+    // training, kept the SLAM thread 4 ms per frame (8 ms worst case); the host-side pack loop alone cost 0.4 ms.
+    InferShared* sh = static_cast<InferShared*>(d->upload); std::lock_guard<std::mutex> one(sh->mu);
+    uint8_t* st_rgb = d->h_stage, *st_inst = st_rgb + px * 4; float* st_depth = reinterpret_cast<float*>(st_inst + ((px + 15) & ~(size_t)15)); float* st_pose = st_depth + (d->use_depth ? px : 0);
+    std::memcpy(st_rgb, rgb, px * (size_t)ch); std::memcpy(st_inst, inst, px); std::memcpy(st_pose, Twc, 64);
+    launch_pack_frame(sh->stream, st_rgb, ch, ri, bi, st_inst, d->d_rgba + px * id, (uint32_t)px);
+    if (d->use_depth) { std::memcpy(st_depth, depth, px * 4); launch_copy_params(sh->stream, reinterpret_cast<const uint16_t*>(st_depth), reinterpret_cast<uint16_t*>(d->d_depth + px * id), (uint32_t)(px * 2)); }
+    launch_copy_params(sh->stream, reinterpret_cast<const uint16_t*>(st_pose), reinterpret_cast<uint16_t*>(d->d_poses + 16 * (size_t)id), 32u);
+    HIPCHECK(hipStreamSynchronize(sh->stream)); HIPCHECK(hipGetLastError());
     if (id + 1 > d->n_frames) d->n_frames = id + 1;                 // mFrameDataNum, nerf_data.cu:338
     d->present[id] = 1;
     return MON_OK;
@@ -121,6 +154,7 @@ int dataset_destroy(Dataset* d) {
     if (d->d_rgba) hipFree(d->d_rgba);
     if (d->d_depth) hipFree(d->d_depth);
     if (d->d_poses) hipFree(d->d_poses);
+    if (d->h_stage) hipHostFree(d->h_stage);
     delete d; return MON_OK;
 }
 
@@ -146,28 +180,6 @@ int stream_pool_reserve(int device, int n) {
     }
     std::lock_guard<std::mutex> l(g_stream_mu); for (hipStream_t s : fresh) g_stream_pool[device].push_back(s);      // what was created is kept either way
     return rc;
-}
-
-// One inference stream and one pinned result buffer per DEVICE, shared by the objects on it: created with the device's first object (CreateNeRF is a
-// milliseconds call anyway; created by the first render it was a 10 ms spike in front of the viewer), and only one more hardware-queue client however many objects
-// train (a high-priority queue per object measurably slowed sliced training).  Renders of one device take turns on it.
-struct InferShared { std::mutex mu; hipStream_t stream = nullptr; float* h_out = nullptr; size_t h_cap = 0; };
-static std::mutex g_infer_mu; static std::map<int, InferShared*> g_infer_shared;
-static int infer_shared_get(int device, size_t pixels_hint, InferShared** out) {
-    std::lock_guard<std::mutex> l(g_infer_mu);
-    InferShared*& sh = g_infer_shared[device];
-    if (!sh) {
-        sh = new InferShared();
-        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&sh->stream, hipStreamNonBlocking, hi) != hipSuccess) { delete sh; sh = nullptr; set_error("inference stream creation failed on device %d", device); return MON_ERR_HIP; }
-    }
-    if (5 * pixels_hint > sh->h_cap) {
-        std::lock_guard<std::mutex> l2(sh->mu);
-        float* q = nullptr; if (hipHostMalloc((void**)&q, 5 * pixels_hint * sizeof(float), hipHostMallocDefault) != hipSuccess) { set_error("pinned render buffer allocation failed"); return MON_ERR_HIP; }
-        if (sh->h_out) hipHostFree(sh->h_out);
-        sh->h_out = q; sh->h_cap = 5 * pixels_hint;
-    }
-    *out = sh; return MON_OK;
 }
 
 // ---- inference side of a model (the reference's second stream, nerf_model.cu:1268-1269).  The training thread PUBLISHES the inference weights

@@ -130,6 +130,7 @@ void launch_composite_render(hipStream_t s, const BatchPtrs& b, uint32_t S, uint
 void launch_extract_density(hipStream_t s, const uint16_t* O, float* out, uint32_t n);
 void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, uint32_t n);
 void launch_copy_params(hipStream_t s, const uint16_t* src, uint16_t* dst, uint32_t n);
+void launch_pack_frame(hipStream_t s, const uint8_t* rgb, int ch, int ri, int bi, const uint8_t* inst, uint32_t* dst, uint32_t px);      // host (pinned) images -> packed RGBA8 | instance << 24
 
 // optimizer (kernels_optim.hip)
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx, uint32_t lazy_below);   // lazy_below: gradient-carrying samples at or below which the dense-table optimizer requests Adam state per touched chunk only
@@ -161,7 +162,8 @@ int selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
 struct Dataset {
     int device = 0; Intrinsics K{}; uint32_t max_frames = 0, n_frames = 0; bool use_depth = false;
     uint32_t* d_rgba = nullptr; float* d_depth = nullptr; float* d_poses = nullptr;
-    std::vector<uint32_t> staging; std::vector<uint8_t> present;      // present[id]: frame id has been uploaded (a new id lands in memory no kernel reads yet)
+    std::vector<uint8_t> present;      // present[id]: frame id has been uploaded (a new id lands in memory no kernel reads yet)
+    uint8_t* h_stage = nullptr; size_t stage_bytes = 0; void* upload = nullptr;      // pinned staging of one incoming frame; the device's high-priority stream (model.cpp InferShared)
     DatasetPtrs ptrs() const { return DatasetPtrs{ d_rgba, d_depth, d_poses, K }; }
 };
 
