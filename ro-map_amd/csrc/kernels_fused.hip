@@ -105,7 +105,7 @@ struct FusedArgs {
     float* x_soa;               // [B] float4 {x, y, z, 0}: warped sample positions for k_grid_scatter
     uint32_t lds_level_mask;    // bit l set: level l goes through k_grid_scatter instead of global atomics
     const uint16_t* frag_image; // A fragments in LDS layout (k_build_frag_image), N_FRAGS x 512 halves
-    uint32_t ablate;            // timing experiments only (MON_FUSED_ABLATE): 2 no dW, 4 no dE/x stores, 8 no rays (prologue + epilogue only), 16 keep zero-gradient samples
+    uint32_t ablate;            // timing experiments only (option fused_ablate): 2 no dW, 4 no dE/x stores, 8 no rays (prologue + epilogue only), 16 keep zero-gradient samples, 32 no dW reduction, 64 encode only
     uint8_t* touched_grid;      // per 4 grid entries (= one 8-parameter optimizer chunk): set to 1 next to every global atomic, or nullptr (see ParamPtrs::touched)
     uint32_t big_switch;        // > 0: while big_levels_binned(st, big_switch) holds, EVERY level's dE rows are stored (kernels_bigscatter.hip bins the large levels)
     uint32_t n_bins;            // ray bins of the compacted gradient rows (scatter_bins(R), host-chosen)

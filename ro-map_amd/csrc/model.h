@@ -28,9 +28,11 @@ struct DevState {
     uint32_t n_scatter_total; // running sum over all iterations, modulo 2^32 (reporting: differences over a measurement window)
     float ema_deb_old, ema_deb_new;   // EMA debias factors (1 - d^(t-1), 1 / (1 - d^t)) of the next ODD optimizer step t; step t's kernel reads its pair and one of its threads writes the
                                       // other pair for step t + 1 at kernel ENTRY (two double-precision pows: at the end of the last block they were ~1 us of serial tail per step)
-    uint32_t n_scatter[2 * kMaxScatterBins * kScatterCounterStride];   // TWO sets (iteration parity: k_fused_train(i) counts in set i & 1, k_grid_scatter(i) reads it and clears the other one for
-                                           // iteration i + 1), counter of bin b at [set * kMaxScatterBins * stride + b * stride]: one 64-byte line each -- returning atomics on one line serialise in its L2 channel.  fused backend: samples with a non-zero dL/dO handed to k_grid_scatter this iteration, per ray bin (ray & (bins - 1)): slot counters, reset by the
-                                           // optimizer's last block.  Up to 128 bins: a wave reserves its slots with one returning atomic per ray, and 4096 rays on 16 counters cost 7 us of k_fused_train
+    // fused backend: slot counters of the gradient rows k_fused_train hands to k_grid_scatter -- samples with a non-zero dL/dO, per ray bin (ray & (bins - 1)); a
+    // wave reserves its slots with one returning atomic per ray.  Counter of bin b at [set * kMaxScatterBins * stride + b * stride]: a 64-byte line each
+    // (returning atomics on one line serialise in its L2 channel: 4096 of them on 16 adjacent counters cost 7 us of k_fused_train).  TWO sets, by iteration
+    // parity: k_fused_train(i) counts in set i & 1, k_grid_scatter(i) reads it and clears the other one for iteration i + 1.
+    uint32_t n_scatter[2 * kMaxScatterBins * kScatterCounterStride];
 };
 
 // ---- dataset pointers (HBM layout: one slab per kind, frame-major)
