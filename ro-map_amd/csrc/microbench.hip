@@ -83,11 +83,18 @@ __global__ void __launch_bounds__(1024) k_ub_lds(int mode, uint32_t ops_per_thre
     if (tab[threadIdx.x] == 0x12345678u) sink[0] = 1.f;
 }
 
+// mode 30: streaming copy of n_ops bytes (read + write: 2 * n_ops bytes of traffic) with `pattern` blocks of 256 threads -- what a short memory-bound kernel of
+// the optimizer's footprint can reach on this device
+typedef uint32_t ub_u4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_ub_copy(const ub_u4* __restrict__ src, ub_u4* __restrict__ dst, uint32_t n16) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) __builtin_nontemporal_store(src[i], dst + i);
+}
+
 int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms_out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || use_device(device) != hipSuccess) { set_error("microbench: no HIP device"); return MON_ERR_NO_DEVICE; }
     uint32_t* table = nullptr; float* sink = nullptr;
-    const size_t bytes = (size_t)n_entries * 4 * 8;
+    const size_t bytes = mode == 30 ? 2 * (size_t)n_ops : (size_t)n_entries * 4 * 8;
     if (hipMalloc((void**)&table, bytes) != hipSuccess || hipMalloc((void**)&sink, 64) != hipSuccess) { set_error("microbench: hipMalloc failed"); return MON_ERR_HIP; }
     hipMemset(table, 0, bytes);
     const uint32_t ops_per_thread = 64, threads = n_ops / ops_per_thread, blocks = (threads + 255) / 256;
@@ -97,7 +104,8 @@ int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n
     if (lds_mode) hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ub_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0, 0);
-        if (lds_mode) hipLaunchKernelGGL(k_ub_lds, dim3(256), dim3(1024), 131072, 0, mode, n_ops / (256u * 1024u), sink);
+        if (mode == 30) hipLaunchKernelGGL(k_ub_copy, dim3(pattern > 0 ? pattern : 512), dim3(256), 0, 0, reinterpret_cast<const ub_u4*>(table), reinterpret_cast<ub_u4*>(table) + n_ops / 16u, n_ops / 16u);
+        else if (lds_mode) hipLaunchKernelGGL(k_ub_lds, dim3(256), dim3(1024), 131072, 0, mode, n_ops / (256u * 1024u), sink);
         else hipLaunchKernelGGL(k_ub, dim3(blocks), dim3(256), 0, 0, mode, pattern, n_entries, ops_per_thread, table, sink);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms = 0.f; hipEventElapsedTime(&ms, e0, e1); if (rep > 0 && ms < best) best = ms;
