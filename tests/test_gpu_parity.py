@@ -61,6 +61,25 @@ def test_batch_generation_matches_oracle(pkg, orc, small_scene, kw, use_depth):
     obj.close(); ds.close(); ref.close()
 
 
+@pytest.mark.parametrize("hw", [(45, 67), (61, 83)], ids=["45x67", "61x83"])
+def test_ragged_image_sizes_upload_exactly(pkg, orc, ss, hw):
+    """Frames whose pixel count is not a multiple of 4 or 16 (the upload packs them with a kernel out of pinned staging, depth and pose behind the colour and
+    instance bytes at 16-byte steps): every frame re-uses the same staging addresses, so a stale or misaligned read shows up as a candidate mismatch in some
+    later frame -- the batch of 4096 candidates over all frames is compared with the oracle's, with and without depth."""
+    sc = ss.make_scene(n_views=12, H=hw[0], W=hw[1], f=55.0, seed=9)
+    for use_depth in (False, True):
+        kw = dict(rays_per_batch=4096, n_levels=4, n_neurons=32, n_hidden_layers=2)
+        ds, obj, ref = _pair(pkg, orc, sc, kw, 0, use_depth)
+        for it in range(2):
+            obj.train_stages(1); ref.generate_batch()
+            assert int(obj.buffer("state")[2]) == ref.n_valid and ref.n_valid > 0
+            assert np.array_equal(obj.buffer("ray_flag"), ref.buffer("ray_flag"))
+            for b in ("target", "target_depth", "ray_o", "ray_d"):
+                close_f32(obj.buffer(b), ref.buffer(b), b, 1e-6)
+            obj.train_stages(2 | 4); ref.train_step()
+        obj.close(); ds.close(); ref.close()
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("name", sorted(CFGS))
 def test_forward_backward_matches_oracle_and_golden(pkg, orc, ss, name, backend):
