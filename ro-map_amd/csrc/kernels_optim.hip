@@ -19,6 +19,14 @@
 
 namespace mon {
 
+template <class T> __device__ __forceinline__ void state_store(T v, T* p) {
+#ifdef MON_OPT_PLAIN_STORES
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+
 __device__ __forceinline__ float adam_update(float g, float w, float& m1, float& m2, uint32_t& steps, float lr0, const OptimConst& oc) {
     const float gsq = g * g;
     m1 = oc.beta1 * m1 + (1.f - oc.beta1) * g;
@@ -186,11 +194,11 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
                     wh[j] = (half_t)w[j];
                 }
                 // optimizer state is not touched again before the next step: stream it past the caches
-                __builtin_nontemporal_store(float4_t{ w[0], w[1], w[2], w[3] }, reinterpret_cast<float4_t*>(p.master + i0)); __builtin_nontemporal_store(float4_t{ w[4], w[5], w[6], w[7] }, reinterpret_cast<float4_t*>(p.master + i0 + 4));
-                __builtin_nontemporal_store(float4_t{ m1[0], m1[1], m1[2], m1[3] }, reinterpret_cast<float4_t*>(p.m1 + i0)); __builtin_nontemporal_store(float4_t{ m1[4], m1[5], m1[6], m1[7] }, reinterpret_cast<float4_t*>(p.m1 + i0 + 4));
-                __builtin_nontemporal_store(float4_t{ m2[0], m2[1], m2[2], m2[3] }, reinterpret_cast<float4_t*>(p.m2 + i0)); __builtin_nontemporal_store(float4_t{ m2[4], m2[5], m2[6], m2[7] }, reinterpret_cast<float4_t*>(p.m2 + i0 + 4));
+                state_store(float4_t{ w[0], w[1], w[2], w[3] }, reinterpret_cast<float4_t*>(p.master + i0)); state_store(float4_t{ w[4], w[5], w[6], w[7] }, reinterpret_cast<float4_t*>(p.master + i0 + 4));
+                state_store(float4_t{ m1[0], m1[1], m1[2], m1[3] }, reinterpret_cast<float4_t*>(p.m1 + i0)); state_store(float4_t{ m1[4], m1[5], m1[6], m1[7] }, reinterpret_cast<float4_t*>(p.m1 + i0 + 4));
+                state_store(float4_t{ m2[0], m2[1], m2[2], m2[3] }, reinterpret_cast<float4_t*>(p.m2 + i0)); state_store(float4_t{ m2[4], m2[5], m2[6], m2[7] }, reinterpret_cast<float4_t*>(p.m2 + i0 + 4));
                 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(u4v{ sc[0], sc[1], sc[2], sc[3] }, reinterpret_cast<u4v*>(p.steps + i0)); __builtin_nontemporal_store(u4v{ sc[4], sc[5], sc[6], sc[7] }, reinterpret_cast<u4v*>(p.steps + i0 + 4));
+                state_store(u4v{ sc[0], sc[1], sc[2], sc[3] }, reinterpret_cast<u4v*>(p.steps + i0)); state_store(u4v{ sc[4], sc[5], sc[6], sc[7] }, reinterpret_cast<u4v*>(p.steps + i0 + 4));
                 *reinterpret_cast<half8_t*>(p.half + i0) = wh;
                 if (is_matrix && nx.frag_image) {                                     // next iteration's A fragments
 #pragma unroll
