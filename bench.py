@@ -341,7 +341,7 @@ def main():
                "late_training": late, "late_training_with_occupancy_skipping": occ, "multi_object": multi,
                "pcie_inclusive": {"dataset_upload_ms": round(1e3 * upload_s, 2), "dataset_bytes": int(sc.n_views * sc.H * sc.W * 4),
                                   "value_for_a_5000_step_job": round(world * 5000 * B / (upload_s + 5000 * dt / args.steps), 1), "unit": "ray-samples/s",
-                                  "note": "host frames -> HBM once per sequence (pack + hipMemcpy), then 5000 steps at the measured step time; never the headline value"},
+                                  "note": "host frames -> HBM once per sequence (pinned staging + packing kernel), then 5000 steps at the measured step time; never the headline value"},
                "render": render_info, "psnr_db": [round(p, 2) for p in psnrs], "train_steps_before_render": (late["after_steps"] + args.steps) if late else args.warmup + args.steps,
                "final_loss": round(obj.info().last_loss, 5)}
         print(json.dumps(out), flush=True)
