@@ -997,7 +997,7 @@ __device__ __forceinline__ void partials_finish(const PartialsArgs& pa, const fl
 }
 
 __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLevels sl, const half2_t* __restrict__ de_soa, const float4_t* __restrict__ x4,
-                                                       uint32_t B, uint32_t n_bins, half_t* __restrict__ gpart, uint32_t n_entries, const DevState* __restrict__ st, DevState* st_rw, PartialsArgs pa, float* __restrict__ timing) {
+                                                       uint32_t B, uint32_t n_bins, half_t* __restrict__ gpart, uint32_t n_entries, const DevState* __restrict__ st, DevState* st_rw, PartialsArgs pa, float* __restrict__ timing, uint32_t ablate /* timing experiments: 1 no tile write-out, 2 no dW row sums, 4 no sample walk */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t iter = st->iter;
     if (blockIdx.x == 0 && threadIdx.x < 64u) {
@@ -1017,6 +1017,7 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
 #endif
     MON_ST_STAMP();
     float4_t pacc[kPartialsMaxPasses];
+    if (ablate & 2u) pa.partials = nullptr;
     if (pa.partials) partials_prefetch(pa, pacc);                                    // loads in flight while the tile is cleared and filled
     int* tab = reinterpret_cast<int*>(smem);
     float* red = reinterpret_cast<float*>(smem + (size_t)kScatterLdsBytes - 256u);     // 256 B behind the largest tile
@@ -1052,7 +1053,8 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
         const half2_t* de = de_soa + (size_t)level * B;
 #define MON_SCATTER_CALL(H, PW, MD, ...) scatter_samples<H, PW, MD, ##__VA_ARGS__>(tab, de, x4, cnt_lo, cnt_hi, n_bins, p, P, bin_cap, feature, scale, size, my, mz, mask, parity, base_half, tile, fs)
 #define MON_SCATTER_MODE(MD) do { if (hashed) { if (pow2) MON_SCATTER_CALL(true, true, MD); else MON_SCATTER_CALL(true, false, MD); } else { if (pow2) MON_SCATTER_CALL(false, true, MD); else MON_SCATTER_CALL(false, false, MD); } } while (0)
-        if (mode == kTileWhole64) MON_SCATTER_MODE(kTileWhole64);
+        if (ablate & 4u) { }
+        else if (mode == kTileWhole64) MON_SCATTER_MODE(kTileWhole64);
         else if (mode == kTileParity64) MON_SCATTER_MODE(kTileParity64);
         else if (mode == kTileParity) { if (degenerate) MON_SCATTER_CALL(true, true, kTileParity, true); else MON_SCATTER_MODE(kTileParity); }
         else MON_SCATTER_MODE(kTileParityRanged);
@@ -1063,6 +1065,7 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
         MON_ST_STAMP();
         const int4v* t4 = reinterpret_cast<const int4v*>(tab);
         const float inv = 1.0f / fs;
+        if (!(ablate & 1u)) {
         const size_t plane = n_entries >> 1;                                           // partial table p, plane (feature, parity): entry idx at [idx >> 1]
         half_t* pl = gpart + ((size_t)p * 4u) * plane + (off >> 1);
         const auto lo_hi = [&](int lo_bits, int hi_bits, float& f0, float& f1) { f0 = (float)lo_bits * inv; f1 = (float)(hi_bits - (lo_bits >> 31)) * inv; };      // undo pack_fix
@@ -1095,6 +1098,7 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
                 const int4v a0 = t4[tile / 4u - 1u];
                 *reinterpret_cast<half4_t*>(dst + (tile & ~7u)) = half4_t{ (half_t)((float)a0[0] * inv), (half_t)((float)a0[1] * inv), (half_t)((float)a0[2] * inv), (half_t)((float)a0[3] * inv) };
             }
+        }
         }
     }
     MON_ST_STAMP();
@@ -1149,7 +1153,7 @@ void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& l
     static float* g_timing = nullptr; if (!g_timing) hipMalloc((void**)&g_timing, 256 * 16 * 8 * 4); timing = g_timing; g_scatter_timing_buf = g_timing;
 #endif
     hipLaunchKernelGGL(k_grid_scatter, dim3(sl.n_levels * kScatterWgPerLevel), dim3(1024), smem, s, lf, sl, reinterpret_cast<const half2_t*>(de_soa), reinterpret_cast<const float4_t*>(x_soa), B, n_bins,
-                       reinterpret_cast<half_t*>(gpart), part_stride_entries, st, st, pa, timing);
+                       reinterpret_cast<half_t*>(gpart), part_stride_entries, st, st, pa, timing, (uint32_t)options().scatter_ablate);
 }
 #ifdef MON_SCATTER_TIMING
 extern "C" int mon_debug_scatter_timing(float* out) { hipDeviceSynchronize(); return g_scatter_timing_buf ? (int)hipMemcpy(out, g_scatter_timing_buf, 256 * 16 * 8 * 4, hipMemcpyDeviceToHost) : -1; }
