@@ -520,7 +520,6 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     const uint32_t ray_stride = gridDim.x * S::WAVES;
     for (uint32_t ray = ray0; ray < R; ray += ray_stride) {
         const RaySample cur = ray_sample(rec, ray); const uint32_t cand_this = cand;
-        if (ray + ray_stride < R) { cand = select((ray + ray_stride) % nvalid); rec = load_record(cand); }
         const uint32_t kth = ray % nvalid, rgba = cur.rgba, s_idx = ray * 32u + (uint32_t)n;
         const float t = cur.t, tdp = cur.tdp, t0 = cur.t0, t1 = cur.t1; const bool live = cur.live, is_obj = (rgba >> 24) != 0u;
         const float x[3] = { cur.x[0], cur.x[1], cur.x[2] };
@@ -528,6 +527,9 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         TileState<EPAD, W, NH> ts;
         if (cur.any) { GatherWindow<EPAD, W, NH> gw; encode_begin<EPAD, W, NH, OCC>(gw, lregs, rsrc, x, lane, live); encode_finish<EPAD, W, NH, OCC>(ts, gw, lregs, rsrc, x, lane, L, live); }
         tstamp(tc, 2);
+        // the next ray's candidate record is requested HERE, behind this ray's last gather: vmcnt retires in order, so a load issued before the gathers would
+        // have to land before the first level pair can be consumed; now its latency runs under the MLP, composite and backward pass
+        if (ray + ray_stride < R) { cand = select((ray + ray_stride) % nvalid); rec = load_record(cand); }
         if (a.ablate & 64u) { float sacc = 0.f; for (int i = 0; i < EPAD / 2; ++i) sacc += (float)ts.ef[i]; loss_acc += sacc; continue; }      // timing experiments: the encode alone
         if (!OCC || __ballot(live) != 0ull) mlp_forward<EPAD, W, NH>(ts, frags, lane);
         else {
@@ -1018,7 +1020,7 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
     MON_ST_STAMP();
     float4_t pacc[kPartialsMaxPasses];
     if (ablate & 2u) pa.partials = nullptr;
-    if (pa.partials) partials_prefetch(pa, pacc);                                    // loads in flight while the tile is cleared and filled
+    bool pacc_loaded = false;
     int* tab = reinterpret_cast<int*>(smem);
     float* red = reinterpret_cast<float*>(smem + (size_t)kScatterLdsBytes - 256u);     // 256 B behind the largest tile
     // run lengths of the compacted ray bins, lane b of every wave holds bin b's and bin (b + 64)'s (read back with v_readlane: no memory access in the sample loop)
@@ -1060,6 +1062,9 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
         else MON_SCATTER_MODE(kTileParityRanged);
 #undef MON_SCATTER_MODE
 #undef MON_SCATTER_CALL
+        // the dW partial rows are requested HERE, behind the walk's last load: vmcnt retires in order, so anything loaded after them -- the bin counters, every
+        // sample fetch -- would wait for these HBM round trips first (requested at kernel entry they cost 1.8 us); now they land while the tile is written out
+        if (pa.partials) { partials_prefetch(pa, pacc); pacc_loaded = true; }
         MON_ST_STAMP();
         __syncthreads();
         MON_ST_STAMP();
@@ -1102,6 +1107,7 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
         }
     }
     MON_ST_STAMP();
+    if (pa.partials && !pacc_loaded) partials_prefetch(pa, pacc);                     // (a workgroup without a tile)
     if (pa.partials) partials_finish(pa, pacc, red);
     MON_ST_STAMP();
 #ifdef MON_SCATTER_TIMING
