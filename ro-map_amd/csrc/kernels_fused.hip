@@ -999,14 +999,15 @@ __device__ __forceinline__ void partials_finish(const PartialsArgs& pa, const fl
 }
 
 __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLevels sl, const half2_t* __restrict__ de_soa, const float4_t* __restrict__ x4,
-                                                       uint32_t B, uint32_t n_bins, half_t* __restrict__ gpart, uint32_t n_entries, const DevState* __restrict__ st, DevState* st_rw, PartialsArgs pa, float* __restrict__ timing, uint32_t ablate /* timing experiments: 1 no tile write-out, 2 no dW row sums, 4 no sample walk */) {
+                                                       uint32_t B, uint32_t n_bins, half_t* __restrict__ gpart, uint32_t n_entries, const DevState* __restrict__ st, DevState* st_rw, DevState* st_next, PartialsArgs pa, float* __restrict__ timing, uint32_t ablate /* timing experiments: 1 no tile write-out, 2 no dW row sums, 4 no sample walk */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t iter = st->iter;
     if (blockIdx.x == 0 && threadIdx.x < 64u) {
-        // slot-counter housekeeping (also for a skipped batch): clear the OTHER set -- k_fused_train of the next iteration counts there -- and note how many
-        // samples carried a gradient in this one (the optimizer's last block publishes it; the large-table path of the next iteration decides on it)
+        // slot-counter housekeeping (also for a skipped batch): clear the counters k_fused_train of the NEXT iteration counts in -- they live in the other
+        // DevState, which nobody reads during this iteration -- and note how many samples carried a gradient in this one (k_optimizer hands it to the next
+        // iteration as n_scatter_last; the large-table path decides on it)
         uint32_t v = 0u;
-        for (uint32_t b = threadIdx.x; b < n_bins; b += 64u) { v += st->n_scatter[scatter_counter(iter, b)]; st_rw->n_scatter[scatter_counter(iter + 1u, b)] = 0u; }
+        for (uint32_t b = threadIdx.x; b < n_bins; b += 64u) { v += st->n_scatter[scatter_counter(iter, b)]; st_next->n_scatter[scatter_counter(iter + 1u, b)] = 0u; }
         v = scan_add64_u32(v);
         if (threadIdx.x == 63u) st_rw->n_scatter_now = v;
     }
@@ -1148,7 +1149,7 @@ bool grid_scatter_sums_partials(const LevelTable& lt, const NetDims& nd) {
     return fused_partial_cols(nd) + 1u <= kPartialsMaxPasses * 8u * 4u * sl.n_levels * kScatterWgPerLevel;
 }
 void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint32_t n_bins, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
-                         const float* partials, uint32_t n_partials, float* gmlp) {
+                         const float* partials, uint32_t n_partials, float* gmlp, DevState* st_next) {
     ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return;
     const PartialsArgs pa{ partials, n_partials, fused_partial_cols(nd) + 64u, fused_partial_cols(nd), FragDims{ nd.Epad, nd.W, nd.NH, nd.L }, gmlp, st };
     constexpr uint32_t smem = kScatterLdsBytes;
@@ -1159,7 +1160,7 @@ void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& l
     static float* g_timing = nullptr; if (!g_timing) hipMalloc((void**)&g_timing, 256 * 16 * 8 * 4); timing = g_timing; g_scatter_timing_buf = g_timing;
 #endif
     hipLaunchKernelGGL(k_grid_scatter, dim3(sl.n_levels * kScatterWgPerLevel), dim3(1024), smem, s, lf, sl, reinterpret_cast<const half2_t*>(de_soa), reinterpret_cast<const float4_t*>(x_soa), B, n_bins,
-                       reinterpret_cast<half_t*>(gpart), part_stride_entries, st, st, pa, timing, (uint32_t)options().scatter_ablate);
+                       reinterpret_cast<half_t*>(gpart), part_stride_entries, st, st, st_next, pa, timing, (uint32_t)options().scatter_ablate);
 }
 #ifdef MON_SCATTER_TIMING
 extern "C" int mon_debug_scatter_timing(float* out) { hipDeviceSynchronize(); return g_scatter_timing_buf ? (int)hipMemcpy(out, g_scatter_timing_buf, 256 * 16 * 8 * 4, hipMemcpyDeviceToHost) : -1; }

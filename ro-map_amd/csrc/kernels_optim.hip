@@ -50,25 +50,34 @@ __device__ __forceinline__ void ema_catch_up(half8_t& e, const half8_t& w, uint3
 // gradient or when the inference weights are needed (k_ema_finalize).  The weights and Adam state are exactly those of the eager
 // schedule; the EMA differs from the step-by-step fp16 recurrence by rounding only.
 template <bool DENSE, bool LAZY>
-__global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, DevState* __restrict__ st, OptimNext nx, uint32_t lazy_below) {
+__global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, const DevState* __restrict__ st, DevState* __restrict__ st_next, OptimNext nx, uint32_t lazy_below) {
     const uint32_t n_valid = st->n_valid, step = st->step;
     // DENSE tables: while most samples carry a gradient practically every chunk is updated and the optimizer state is requested together with the gradients
     // (one memory round trip); once few do (late training: k_grid_scatter left the count in n_scatter_now) most chunks only need their EMA advanced, and
     // the 112 B of Adam state per chunk are requested behind the gradient test instead
     const bool eager = DENSE && !(lazy_below != 0u && st->n_scatter_now <= lazy_below);
-    const bool cand_block = blockIdx.x < nx.cand_blocks;            // GenerateRays of iteration iter + 1 (every block reads the state before its ticket)
+    const bool cand_block = blockIdx.x < nx.cand_blocks;            // GenerateRays of iteration iter + 1
     if (cand_block) gen_candidate(nx.b, nx.ds, nx.oc, st->n_boxes, st->iter + 1u, blockIdx.x * blockDim.x + threadIdx.x);
     const uint32_t bid = blockIdx.x - nx.cand_blocks, nblk = gridDim.x - nx.cand_blocks;
     const float lr0 = st->lr;
-    // EMA debias factors of this step (ema_step_half_precision; double-precision pow like tcnn's host code): computed by the
-    // last block of the previous step, so no block waits for a software pow before it can issue its loads
+    // EMA debias factors of this step (ema_step_half_precision; double-precision pow like tcnn's host code): left in the state by the previous step
     const uint32_t cur = step + 1u;
     const float d = oc.ema_decay;
-    const bool odd = (cur & 1u) != 0u;
-    const float deb_old = odd ? st->ema_deb_old : st->ema_deb_even_old, deb_new = odd ? st->ema_deb_new : st->ema_deb_even_new;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {                      // factors of step cur + 1, into the pair nobody reads during this step (a skipped batch rewrites the same values)
-        const float o = 1.f - (float)pow((double)d, (double)cur), nw = 1.f / (1.f - (float)pow((double)d, (double)(cur + 1u)));
-        if (odd) { st->ema_deb_even_old = o; st->ema_deb_even_new = nw; } else { st->ema_deb_old = o; st->ema_deb_new = nw; }
+    const float deb_old = st->ema_deb_old, deb_new = st->ema_deb_new;
+    // ---- the state of the NEXT iteration.  Iteration i reads DevState i & 1, and everything that changes from one iteration to the next is known when this
+    //      kernel starts, so one thread writes the other DevState right away.  (Advancing one shared state in place needed a "last block": a returning atomic
+    //      on one address per block and the round trip behind the last of them -- 4.3 us of this kernel.)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        DevState& nxs = *st_next;
+        nxs.iter = st->iter + 1u; nxs.n_valid = n_valid; nxs.loss_sum = st->loss_sum;      // (n_valid / loss_sum: what the host reads after the call; k_fused_train overwrites them)
+        { const uint32_t tot = st->n_scatter_now; nxs.n_scatter_last = tot; nxs.n_scatter_total = st->n_scatter_total + tot; }   // (the slot counters themselves are cleared and summed by k_grid_scatter)
+        uint32_t nstep = step;
+        if (n_valid != 0u) {
+            nstep = cur; nxs.skipped = st->skipped;
+            nxs.lr = ((int)cur >= oc.decay_start && oc.decay_interval > 0 && ((int)cur - oc.decay_start) % oc.decay_interval == 0) ? lr0 * oc.decay_base : lr0;
+        } else { nxs.skipped = st->skipped + 1u; nxs.lr = lr0; }
+        nxs.step = nstep;
+        nxs.ema_deb_old = 1.f - (float)pow((double)d, (double)nstep); nxs.ema_deb_new = 1.f / (1.f - (float)pow((double)d, (double)(nstep + 1u)));      // factors of step nstep + 1
     }
     // gradient / loss_scale: a power-of-two scale (the reference's 128) divides exactly as a multiplication by its reciprocal (same
     // correctly rounded result, ~10 instructions less per parameter than an IEEE division); anything else keeps the division
@@ -281,23 +290,6 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, D
             }
         }
     }
-    // ---- last block advances the counters (one ticket per block).  No fence: the other blocks only READ the state
-    //      (at kernel entry, before their ticket), and a __threadfence() here costs an L2 write-back per block.
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t t = atomicAdd(&st->ticket, 1u);
-        if (t == gridDim.x - 1u) {
-            st->ticket = 0u;
-            st->iter = st->iter + 1u;
-            { const uint32_t tot = st->n_scatter_now; st->n_scatter_now = 0u; st->n_scatter_last = tot; st->n_scatter_total += tot; }   // (the slot counters themselves are cleared and summed by k_grid_scatter)
-            if (n_valid != 0u) {
-                st->step = cur;
-                if ((int)cur >= oc.decay_start && oc.decay_interval > 0 && ((int)cur - oc.decay_start) % oc.decay_interval == 0) st->lr = lr0 * oc.decay_base;
-            } else {
-                st->skipped = st->skipped + 1u;
-            }
-        }
-    }
 }
 
 // Fused backend: sums the per-workgroup fp32 weight-gradient partials (and loss partials) written by
@@ -363,16 +355,16 @@ void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, u
     hipLaunchKernelGGL(k_master_to_half, dim3(1024), dim3(256), 0, s, master, half, n);
 }
 
-void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx, uint32_t lazy_below) {
+void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, const DevState* st, DevState* st_next, const OptimNext& nx, uint32_t lazy_below) {
     const uint32_t chunks = oc.n_params >> 3;
     const uint32_t env_cap = (uint32_t)options().opt_blocks;
     // measured: base.json (239 k chunks) 256 / 512 / 1024 blocks = 28.1 / 23.7 / 26.2 us; T = 2^22 (13.2 M chunks) 512 / 2048 / 8192 / 32768 blocks = 368 / 244 / 251 / 406 us
     uint32_t cap = chunks / (256u * 8u); if (cap < 512u) cap = 512u; if (cap > 2048u) cap = 2048u; if (env_cap) cap = env_cap;
     uint32_t blocks = (chunks + 255) / 256; if (blocks > cap) blocks = cap; if (blocks < 1u) blocks = 1u;     // ~2 chunks per thread at base.json size: measured best (256: 28.1, 512: 23.7, 1024: 26.2 us)
     // dense = every level goes through the LDS scatter, i.e. tables of at most 2^18 entries that a 131 072-sample batch covers
-    if (p.gpart && p.all_levels_dense) hipLaunchKernelGGL((k_optimizer<true, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx, lazy_below);
-    else if (p.ema_step) hipLaunchKernelGGL((k_optimizer<false, true>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx, lazy_below);
-    else hipLaunchKernelGGL((k_optimizer<false, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, nx, lazy_below);
+    if (p.gpart && p.all_levels_dense) hipLaunchKernelGGL((k_optimizer<true, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
+    else if (p.ema_step) hipLaunchKernelGGL((k_optimizer<false, true>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
+    else hipLaunchKernelGGL((k_optimizer<false, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
 }
 
 }  // namespace mon

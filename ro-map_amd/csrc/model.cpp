@@ -253,7 +253,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         (rc = dev_alloc(m, B.Hid, (size_t)Btrain * m.nd.W * m.nd.NH)) || (rc = dev_alloc(m, B.dO, (size_t)Btrain * kOut)) ||
         (rc = dev_alloc(m, B.dHid, (size_t)Btrain * m.nd.W * m.nd.NH)) || (rc = dev_alloc(m, B.dE, (size_t)Btrain * m.nd.Epad)) ||
         (rc = dev_alloc(m, B.rgb_ray, 3 * (size_t)R)) || (rc = dev_alloc(m, B.depth_ray, R)) || (rc = dev_alloc(m, B.mask_ray, R)) || (rc = dev_alloc(m, B.loss_ray, R)) ||
-        (rc = dev_alloc(m, m.d_state, 1)) || (rc = dev_alloc(m, m.d_dw_partials, (size_t)(fused_partial_cols(m.nd) + 64) * kMaxFusedGrid)) ||
+        (rc = dev_alloc(m, m.d_state, 2)) || (rc = dev_alloc(m, m.d_dw_partials, (size_t)(fused_partial_cols(m.nd) + 64) * kMaxFusedGrid)) ||
         (rc = dev_alloc(m, m.d_out_rgb, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_depth, kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_mask, kRenderChunkRays))) return rc;
     m.out_cap = kRenderChunkRays;
     // lazy EMA: only where the optimizer is not the dense variant anyway and the table is large (> 8 M parameters); MON_LAZY_EMA=0/1 overrides
@@ -287,7 +287,8 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     B.boxes = m.d_boxes;
     m.h_state = DevState{}; m.h_state.lr = cfg.learning_rate;
     m.h_state.ema_deb_old = 0.0f; m.h_state.ema_deb_new = 1.0f / (1.0f - (float)std::pow((double)cfg.ema_decay, 1.0));   // step 1
-    HIPCHECK(hipMemcpy(m.d_state, &m.h_state, sizeof(DevState), hipMemcpyHostToDevice));
+    m.d_state_next = m.d_state + 1;                          // two states: iteration i runs on one, k_optimizer(i) writes the other for iteration i + 1
+    HIPCHECK(hipMemcpy(m.d_state, &m.h_state, sizeof(DevState), hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(m.d_state_next, &m.h_state, sizeof(DevState), hipMemcpyHostToDevice));
     HIPCHECK(hipHostMalloc((void**)&m.h_state_pinned, sizeof(DevState), hipHostMallocDefault));
     m.backend = fused_supported(m.nd, S, m.oc.R) ? 1 : 0;
     if (options().backend >= 0) m.backend = options().backend ? (fused_supported(m.nd, S, m.oc.R) ? 1 : 0) : 0;
@@ -380,7 +381,7 @@ int model_add_boxes(Model& m, const mon_frame_bbox* boxes, size_t n) {
     }
     HIPCHECK(hipMemcpy(m.d_boxes + m.n_boxes, boxes, sizeof(mon_frame_bbox) * n, hipMemcpyHostToDevice));   // nerf_model.cu:1625
     m.n_boxes += (uint32_t)n;
-    HIPCHECK(hipMemcpy(&m.d_state->n_boxes, &m.n_boxes, 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(&m.d_state->n_boxes, &m.n_boxes, 4, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(&m.d_state_next->n_boxes, &m.n_boxes, 4, hipMemcpyHostToDevice));
     m.next_ready = false;                                   // candidates pre-generated for the next iteration used the old box list
     return MON_OK;
 }
@@ -435,7 +436,7 @@ static void enqueue_iteration(Model& m, int stages) {
         const bool fold_reduce = options().fold_reduce != 0;
         const bool folded = m.lds_mask && fold_reduce && grid_scatter_sums_partials(m.lt, m.nd);   // the scatter workgroups also sum the dW partial rows
         if (m.lds_mask) { ProfScope ps(m, MON_K_SCATTER); launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_gpart, m.n_grid / 2, m.d_state,
-                                                                                folded ? m.d_dw_partials : nullptr, fused_train_grid(m.nd, m.oc.R), m.P.gmlp); }
+                                                                                folded ? m.d_dw_partials : nullptr, fused_train_grid(m.nd, m.oc.R), m.P.gmlp, m.d_state_next); }
         if (m.big_active) { ProfScope ps(m, MON_K_SCATTER); launch_big_scatter(s, m.lt, m.lf, m.nd, m.lds_mask, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_state, m.big_switch, m.d_big_ws, m.P.ggrid, m.d_touched ? m.d_touched + (m.nd.n_mlp >> 3) : nullptr); }
         if (!folded) { ProfScope ps(m, MON_K_REDUCE); launch_reduce_partials(s, m.d_dw_partials, fused_train_grid(m.nd, m.oc.R), m.nd, m.P.gmlp, m.d_state); }
     }
@@ -455,7 +456,8 @@ static void enqueue_iteration(Model& m, int stages) {
             nx.cand_blocks = (m.oc.R + 255) / 256; nx.frag_image = m.d_frag_train; nx.fd = FragDims{ m.nd.Epad, m.nd.W, m.nd.NH, m.nd.L };
             nx.b = m.B; nx.ds = m.ds->ptrs(); nx.oc = m.oc;
         }
-        launch_optimizer(s, P, m.opt, m.d_state, nx, options().opt_lazy_below < 0 ? (m.oc.R * m.oc.S) / 8u : (uint32_t)options().opt_lazy_below); m.scatter_pending = false;
+        launch_optimizer(s, P, m.opt, m.d_state, m.d_state_next, nx, options().opt_lazy_below < 0 ? (m.oc.R * m.oc.S) / 8u : (uint32_t)options().opt_lazy_below); m.scatter_pending = false;
+        std::swap(m.d_state, m.d_state_next);                // the next iteration (and the host's read-back) uses the state this launch prepares
         m.next_ready = (m.backend == 1 && fold);
     }
 }
@@ -490,17 +492,20 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     const bool use_graph = use_graph_env && !m.profiling && stages == 7 && iters >= 2 && !(m.d_occ && !m.occ_refreshed_iter);      // (the first occupancy refresh changes a kernel argument)
     if (use_graph) {
         const int graph_key = m.backend | (m.big_active ? 256 : 0) | (m.occ_refreshed_iter ? 512 : 0);
-        if (!m.graph_exec || m.graph_backend != graph_key) {
+        if (!m.graph_exec || m.graph_backend != graph_key || m.graph_state != m.d_state) {
             drop_graph(m);
             hipGraph_t g = nullptr;
             HIPCHECK(hipStreamBeginCapture(m.train_stream, hipStreamCaptureModeThreadLocal));
-            m.next_ready = false;                           // the captured iteration is self-contained
-            enqueue_iteration(m, 7);
+            m.next_ready = false;                           // the captured iterations are self-contained
+            m.graph_state = m.d_state;
+            enqueue_iteration(m, 7); enqueue_iteration(m, 7);      // a PAIR: the two DevStates swap roles every iteration, after two the captured pointers are current again
             HIPCHECK(hipStreamEndCapture(m.train_stream, &g));
             HIPCHECK(hipGraphInstantiate(&m.graph_exec, g, nullptr, nullptr, 0));
             hipGraphDestroy(g); m.graph_backend = graph_key;
         }
-        for (int i = 0; i < iters; ++i) { maybe_refresh_occupancy(m, m.h_state.iter + (uint32_t)i); HIPCHECK(hipGraphLaunch(m.graph_exec, m.train_stream)); }
+        int i = 0;
+        for (; i + 2 <= iters; i += 2) { maybe_refresh_occupancy(m, m.h_state.iter + (uint32_t)i); HIPCHECK(hipGraphLaunch(m.graph_exec, m.train_stream)); }
+        for (; i < iters; ++i) { maybe_refresh_occupancy(m, m.h_state.iter + (uint32_t)i); m.next_ready = false; enqueue_iteration(m, 7); }
     } else {
         for (int i = 0; i < iters; ++i) { if (stages == 7) maybe_refresh_occupancy(m, m.h_state.iter + (uint32_t)i); enqueue_iteration(m, stages); }
     }

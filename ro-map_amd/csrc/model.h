@@ -19,7 +19,7 @@ struct DevState {
     uint32_t n_boxes;    // mnBbox
     float lr;            // Adam learning rate after ExponentialDecay
     float loss_sum;      // sum of per-ray losses of the current batch (SumLoss, nerf_model.cu:1231-1253)
-    uint32_t ticket;     // last-block-done counter of the optimizer kernel
+    uint32_t ticket;     // (unused since the optimizer prepares the next iteration's state at its entry)
     uint32_t skipped;    // batches skipped because n_valid == 0
     uint32_t n_scatter_now;   // gradient-carrying samples of the CURRENT iteration (written by k_grid_scatter; the optimizer's last block makes it n_scatter_last, so every kernel of an iteration sees the same previous count)
     float ema_deb_even_old, ema_deb_even_new;   // EMA debias factors of the next EVEN optimizer step (see ema_deb_old)
@@ -135,7 +135,7 @@ void launch_copy_params(hipStream_t s, const uint16_t* src, uint16_t* dst, uint3
 void launch_pack_frame(hipStream_t s, const uint8_t* rgb, int ch, int ri, int bi, const uint8_t* inst, uint32_t* dst, uint32_t px);      // host (pinned) images -> packed RGBA8 | instance << 24
 
 // optimizer (kernels_optim.hip)
-void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, DevState* st, const OptimNext& nx, uint32_t lazy_below);   // lazy_below: gradient-carrying samples at or below which the dense-table optimizer requests Adam state per touched chunk only
+void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, const DevState* st, DevState* st_next, const OptimNext& nx, uint32_t lazy_below);   // lazy_below: gradient-carrying samples at or below which the dense-table optimizer requests Adam state per touched chunk only
 void launch_ema_finalize(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, const DevState* st);
 void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_partials, const NetDims& nd, float* gmlp, DevState* st);
 uint32_t fused_partial_cols(const NetDims& nd);      // columns of a k_fused_train dW partial row (accumulator layout), the loss partial follows
@@ -151,7 +151,7 @@ uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl
 uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd);
 bool grid_scatter_sums_partials(const LevelTable& lt, const NetDims& nd);
 void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint32_t n_bins, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
-                         const float* partials_or_null, uint32_t n_partials, float* gmlp);   // partials != null: also sums the dW partial rows (k_reduce_partials folded in)
+                         const float* partials_or_null, uint32_t n_partials, float* gmlp, DevState* st_next);   // partials != null: also sums the dW partial rows (k_reduce_partials folded in)
 size_t big_scatter_workspace_bytes(const LevelTable& lt, const NetDims& nd, uint32_t lds_mask, uint32_t B);
 void launch_big_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, uint32_t lds_mask, const uint16_t* de_soa, const float* x_soa, uint32_t B,
                         uint32_t n_bins, const DevState* st, uint32_t big_switch, void* workspace, uint16_t* ggrid, uint8_t* touched_grid);
@@ -180,7 +180,8 @@ struct Model {
     uint32_t n_grid = 0, n_params = 0;
     hipStream_t train_stream = nullptr;      // mpTrainStream :1268; inference (render, mesh) runs on the same stream: the reference's mpInferenceStream is only
                                              // ever used from the object's own thread between training calls
-    ParamPtrs P{}; BatchPtrs B{}; DevState* d_state = nullptr; mon_frame_bbox* d_boxes = nullptr;
+    ParamPtrs P{}; BatchPtrs B{}; DevState* d_state = nullptr; DevState* d_state_next = nullptr;      // iteration i runs on one DevState and prepares the other for i + 1 (k_optimizer); swapped when an optimizer step is enqueued
+    mon_frame_bbox* d_boxes = nullptr;
     uint32_t boxes_cap = 0, n_boxes = 0; uint32_t ws_samples = 0, ws_rays = 0;
     // fused backend
     float* d_dw_partials = nullptr;                               // [512][fused_partial_cols + 64] fp32 dW partial rows of k_fused_train, accumulator layout (frag_layout.h acc_param)
@@ -198,7 +199,7 @@ struct Model {
     bool scatter_pending = false;   // a fused forward/backward was enqueued whose slot counter has not been reset by an optimizer step yet
     bool next_ready = false;     // fused backend: candidates + fragment image of the coming iteration were already produced by the last k_optimizer
     mon_profile prof{}; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pending;
-    hipGraphExec_t graph_exec = nullptr; int graph_backend = -1;
+    hipGraphExec_t graph_exec = nullptr; int graph_backend = -1; const DevState* graph_state = nullptr;      // (the state the captured pair of iterations starts on)
 };
 
 int ensure_ema_current(Model& m);
