@@ -96,15 +96,29 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                 if (!LAZY) { nx_w = *reinterpret_cast<const half8_t*>(p.half + in0); nx_e = *reinterpret_cast<const half8_t*>(p.ema + in0); }
             }
         };
-        // one 8-parameter chunk; `pre`: its always-needed loads (cur_*) were issued an iteration ago
-        auto update_chunk = [&](uint32_t c, bool pre, const half8_t& cur_g, const half8_t& cur_w, const half8_t& cur_e) {
+        // DENSE tables, eager state: the 160 B of optimizer state of a thread's SECOND chunk are requested before its first chunk is worked on (`Pre`), so that
+        // their latency runs under that chunk's arithmetic (vmcnt retires in order: they have to be issued before the first chunk's stores, not after).
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        struct Pre { float4_t w0, w1, a0, a1, b0, b1; u32x4 s0, s1; half8_t e; float4_t gm0, gm1; };      // (plain vector types and no arrays: HIP's uint4 is a union, and either keeps the struct in scratch memory)
+        auto issue = [&](uint32_t c, Pre& L) __attribute__((always_inline)) {
+            const uint32_t i0 = c << 3;
+            L.w0 = *reinterpret_cast<const float4_t*>(p.master + i0); L.w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
+            L.a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0); L.a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
+            L.b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); L.b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
+            L.s0 = *reinterpret_cast<const u32x4*>(p.steps + i0); L.s1 = *reinterpret_cast<const u32x4*>(p.steps + i0 + 4);
+            L.e = *reinterpret_cast<const half8_t*>(p.ema + i0);
+            if (i0 < oc.n_mlp) { L.gm0 = *reinterpret_cast<const float4_t*>(p.gmlp + i0); L.gm1 = *reinterpret_cast<const float4_t*>(p.gmlp + i0 + 4); }
+        };
+        // one 8-parameter chunk; `pre`: its always-needed loads (cur_*) were issued an iteration ago; `L`: state, EMA and MLP gradient were (eager dense path)
+        auto update_chunk = [&](uint32_t c, bool pre, const half8_t& cur_g, const half8_t& cur_w, const half8_t& cur_e, const Pre* L = nullptr) __attribute__((always_inline)) {
             const uint32_t i0 = c << 3;
             const bool is_matrix = i0 < oc.n_mlp;                     // n_mlp is a multiple of 8: uniform per chunk
             float g[8]; bool any = false;
             // DENSE (small tables: practically every entry has a gradient each step): the optimizer state is requested together
             // with the gradients -- one memory round trip instead of two; sparse tables keep the state loads behind the test.
             float4_t w0, w1, a0, a1, b0, b1; uint4 s0, s1;
-            if (eager) {
+            if (L) { w0 = L->w0; w1 = L->w1; a0 = L->a0; a1 = L->a1; b0 = L->b0; b1 = L->b1; s0 = uint4{ L->s0[0], L->s0[1], L->s0[2], L->s0[3] }; s1 = uint4{ L->s1[0], L->s1[1], L->s1[2], L->s1[3] }; }
+            else if (eager) {
                 w0 = *reinterpret_cast<const float4_t*>(p.master + i0); w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
                 a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0); a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
                 b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
@@ -112,12 +126,13 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
             }
             const bool lazy_chunk = LAZY && !is_matrix;
             half8_t ema_in;
-            if (!lazy_chunk) ema_in = pre ? cur_e : *reinterpret_cast<const half8_t*>(p.ema + i0);
+            if (L) ema_in = L->e;
+            else if (!lazy_chunk) ema_in = pre ? cur_e : *reinterpret_cast<const half8_t*>(p.ema + i0);
             if (is_matrix) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const uint32_t i = i0 + j;
-                    const float gs = p.gmlp[i]; p.gmlp[i] = 0.f;
+                    const float gs = L ? (j < 4 ? L->gm0[j & 3] : L->gm1[j & 3]) : p.gmlp[i]; p.gmlp[i] = 0.f;
                     g[j] = unscale(gs);
                 }
                 any = true;
@@ -280,6 +295,18 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
             }
             if (qn > kQueueCap) qn = kQueueCap;
             for (uint32_t q0 = 0; q0 < qn; q0 += 64u) if (q0 + lane < qn) update_chunk(queue[wave][q0 + lane], false, none, none, none);
+        } else if (eager) {
+            // a thread has two chunks at these table sizes (the launch gives ~2 chunks per thread): the state of both is requested before the first is worked on;
+            // straight-line code, no loop-carried buffers (those ended up in scratch memory)
+            const half8_t none{};
+            const uint32_t c0 = c_first, c1 = c_first + c_stride;
+            if (c0 < n_chunks) {
+                Pre A, B2; const bool two = c1 < n_chunks;
+                issue(c0, A); if (two) issue(c1, B2);
+                update_chunk(c0, false, none, none, none, &A);
+                if (two) update_chunk(c1, false, none, none, none, &B2);
+                for (uint32_t c = c1 + c_stride; c < n_chunks; c += c_stride) update_chunk(c, false, none, none, none);
+            }
         } else {
             prefetch(c_first);
             for (uint32_t c = c_first; c < n_chunks; c += c_stride) {
