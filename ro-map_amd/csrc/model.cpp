@@ -37,7 +37,7 @@ static long* option_slot(const char* name) {
     static const struct { const char* n; long Options::*f; } tab[] = {
         { "backend", &Options::backend }, { "use_graph", &Options::use_graph }, { "lazy_ema", &Options::lazy_ema }, { "big_switch", &Options::big_switch },
         { "touched_flags", &Options::touched_flags }, { "lds_scatter", &Options::lds_scatter }, { "fold_reduce", &Options::fold_reduce }, { "fold_next", &Options::fold_next },
-        { "fused_grid", &Options::fused_grid }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger },
+        { "fused_grid", &Options::fused_grid }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk },
         { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner }, { "scatter_bins", &Options::scatter_bins }, { "opt_lazy_below", &Options::opt_lazy_below }, { "scatter_ablate", &Options::scatter_ablate } };
     for (const auto& e : tab) if (name && std::strcmp(name, e.n) == 0) return &(g_options.*(e.f));
     return nullptr;
@@ -94,6 +94,73 @@ static int infer_shared_get(int device, size_t pixels_hint, InferShared** out) {
     }
     *out = sh; return MON_OK;
 }
+
+// ---- training lanes: the per-device scheduler behind "one host thread per object" (nerf_manager.cu:89,256-259).
+// Measured (tools/multi_object.py, base.json objects): two objects training concurrently fall into anti-phase on their own -- one gathers (k_fused_train, bound by the
+// L2 request path) while the other scatters and updates (LDS atomics, HBM) -- 1.75 G ray-samples/s against 1.38 G for one; with three or more streams in flight the
+// dispatcher mixes workgroups of kernels that exclude each other on a CU (k_grid_scatter takes a CU's whole LDS; streams beyond the hardware queues share one and block
+// each other) and the aggregate drops to 1.5 G.  So the training work of ALL objects of a device goes through `train_lanes` (2) shared streams: a chunk of an object's
+// iterations is enqueued on the lane with the least work in flight (the lane of the object's previous chunk while that is still running: stream order then keeps the
+// object's iterations in sequence; a change of lane is ordered by an event).  The device sees two streams of whole training steps whatever the number of objects.
+// Lanes order work for speed only: no result depends on them.
+constexpr int kMaxLanes = 4; constexpr uint32_t kLaneRing = 256;
+// lane events order device work only: without the system-scope fence of a default event (an L2 write-back per chunk; the host reads nothing these events guard)
+constexpr unsigned kLaneEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
+struct TrainLanes {
+    std::mutex mu; std::atomic<int> objects{ 0 };      // live objects of the device
+    struct Lane { hipStream_t stream = nullptr; hipEvent_t ev[kLaneRing] = {}; uint32_t head = 0, tail = 0; } lane[kMaxLanes];
+};
+static std::mutex g_lanes_mu; static std::map<int, TrainLanes*> g_lanes;
+static TrainLanes* lanes_get(int device) { std::lock_guard<std::mutex> l(g_lanes_mu); TrainLanes*& t = g_lanes[device]; if (!t) t = new TrainLanes(); return t; }
+// marks the end of what the object has enqueued so far on its current stream (called where an entry point returns with work still in flight: the end of a train call)
+static void mark_tail(Model& m) {
+    if (!m.switch_event && hipEventCreateWithFlags(&m.switch_event, kLaneEventFlags) != hipSuccess) { m.switch_event = nullptr; m.tail_marked = false; return; }
+    m.tail_marked = hipEventRecord(m.switch_event, m.train_stream) == hipSuccess;
+}
+// moves the object's work to stream `to`: everything it has enqueued so far is ordered before whatever follows on the new stream.  The wait is for the object's OWN last
+// work (mark_tail) -- an event recorded now would also stand behind every chunk other objects have queued on the old lane since, and tie the two lanes together.
+static void switch_stream(Model& m, hipStream_t to) {
+    if (m.train_stream == to) return;
+    if (!m.tail_marked) mark_tail(m);
+    if (m.tail_marked) (void)hipStreamWaitEvent(to, m.switch_event, 0);
+    else (void)hipStreamSynchronize(m.train_stream);
+    m.train_stream = to; m.tail_marked = false;
+}
+// One chunk of an object's iterations on a lane.  The lock is held while the chunk is ENQUEUED (a few microseconds per launch): the chunks of different objects do not
+// interleave within a lane, and the lane loads are read and written by one thread at a time.
+struct LaneChunk {
+    Model& m; TrainLanes* tl = nullptr; std::unique_lock<std::mutex> lock; int l = -1;
+    explicit LaneChunk(Model& mm, bool enabled) : m(mm) {
+        const int n = options().train_lanes < kMaxLanes ? options().train_lanes : kMaxLanes;
+        if (!enabled || n <= 0 || !m.lanes || m.lanes->objects.load() <= n) { switch_stream(m, m.own_stream); return; }      // (up to `n` objects: their own streams ARE the lanes)
+        tl = m.lanes; lock = std::unique_lock<std::mutex>(tl->mu);
+        if (m.lane >= 0 && m.lane < n && m.lane_event && m.train_stream == tl->lane[m.lane].stream && hipEventQuery(m.lane_event) == hipErrorNotReady) l = m.lane;      // previous chunk still in flight: same lane
+        else {
+            uint32_t best = ~0u, mine = ~0u;
+            for (int i = 0; i < n; ++i) {
+                TrainLanes::Lane& L = tl->lane[i];
+                while (L.tail != L.head && hipEventQuery(L.ev[L.tail % kLaneRing]) == hipSuccess) ++L.tail;      // retire finished chunks
+                const uint32_t load = L.head - L.tail;
+                if (i == m.lane && m.train_stream == L.stream) mine = load;
+                if (load < best) { best = load; l = i; }
+            }
+            if (mine != ~0u && mine < best + 2u) l = m.lane;                                                   // stay unless the other lane is clearly shorter
+        }
+        (void)hipGetLastError();                                                                               // (a hipErrorNotReady would otherwise be reported by the next hipGetLastError)
+        TrainLanes::Lane& L = tl->lane[l];
+        if (!L.stream && hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) { L.stream = nullptr; tl = nullptr; lock.unlock(); switch_stream(m, m.own_stream); return; }
+        switch_stream(m, L.stream);
+    }
+    ~LaneChunk() {
+        if (!tl) return;
+        TrainLanes::Lane& L = tl->lane[l];
+        if (L.head - L.tail == kLaneRing) { (void)hipEventSynchronize(L.ev[L.tail % kLaneRing]); ++L.tail; }  // ring full: wait for the oldest chunk
+        hipEvent_t& e = L.ev[L.head % kLaneRing];
+        if (!e && hipEventCreateWithFlags(&e, kLaneEventFlags) != hipSuccess) { e = nullptr; return; }
+        if (hipEventRecord(e, m.train_stream) != hipSuccess) return;
+        ++L.head; m.lane = l; m.lane_event = e;
+    }
+};
 
 int dataset_create(int device, int H, int W, float fx, float fy, float cx, float cy, uint32_t max_frames, int use_depth, Dataset** out) {
     int n = 0; int rc = device_count(&n); if (rc) return rc;
@@ -225,7 +292,8 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     m.n_bins = kDefaultScatterBins;
     if (options().scatter_bins > 16) { const uint32_t cap = scatter_bins_max(m.oc.R); while (m.n_bins * 2u <= (uint32_t)options().scatter_bins && m.n_bins * 2u <= cap) m.n_bins *= 2u; }
     m.opt = OptimConst{ cfg.beta1, cfg.beta2, cfg.epsilon, cfg.l2_reg, cfg.ema_decay, cfg.loss_scale, cfg.decay_base, std::log2(cfg.beta1), std::log2(cfg.beta2), std::log2(cfg.ema_decay), cfg.decay_start, cfg.decay_interval, m.nd.n_mlp, m.n_params };
-    { const int rcs = stream_acquire(m.device, &m.train_stream); if (rcs) return rcs; }
+    { const int rcs = stream_acquire(m.device, &m.own_stream); if (rcs) return rcs; }
+    m.train_stream = m.own_stream; m.lanes = lanes_get(m.device); m.lanes->objects.fetch_add(1);
     // ---- parameters (ResetNetwork :1286-1342; Trainer init)
     const size_t n = m.n_params;
     if ((rc = dev_alloc(m, m.P.master, n, false)) || (rc = dev_alloc(m, m.P.half, n, false)) || (rc = dev_alloc(m, m.P.ema, n)) ||
@@ -354,7 +422,10 @@ int model_destroy(Model* mp) {
     for (auto& e : m.ev_pool) hipEventDestroy(e);
     for (void* p : m.allocs) hipFree(p);
     if (m.h_state_pinned) hipHostFree(m.h_state_pinned);
-    if (m.train_stream) stream_release(m.device, m.train_stream);        // idle (synchronised above): the next object of this device takes it
+    if (m.lanes) m.lanes->objects.fetch_sub(1);
+    if (m.switch_event) hipEventDestroy(m.switch_event);
+    if (m.sync_event) hipEventDestroy(m.sync_event);
+    if (m.own_stream) { hipStreamSynchronize(m.own_stream); stream_release(m.device, m.own_stream); }        // idle: the next object of this device takes it
     delete mp; return MON_OK;
 }
 
@@ -475,7 +546,9 @@ static int sync_state(Model& m) {
     // (only the head: the slot counters behind it are 16 KB the host never reads; written by a one-block kernel rather than hipMemcpyAsync, whose small-copy path
     //  costs the slicing online thread ~10 us per call)
     launch_copy_params(m.train_stream, reinterpret_cast<const uint16_t*>(m.d_state), reinterpret_cast<uint16_t*>(m.h_state_pinned), (uint32_t)(offsetof(DevState, n_scatter) / 2));
-    HIPCHECK(hipStreamSynchronize(m.train_stream));
+    // (an event, not hipStreamSynchronize: the stream may be a lane other objects keep feeding)
+    if (!m.sync_event) HIPCHECK(hipEventCreateWithFlags(&m.sync_event, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(m.sync_event, m.train_stream)); HIPCHECK(hipEventSynchronize(m.sync_event));
     std::memcpy(&m.h_state, m.h_state_pinned, offsetof(DevState, n_scatter));
     collect_profile(m);
     return MON_OK;
@@ -490,33 +563,43 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     m.big_active = m.big_switch && (m.h_state.n_scatter_last == 0u || m.h_state.n_scatter_last > m.big_switch / 2u);
     const bool use_graph_env = options().use_graph != 0;
     const bool use_graph = use_graph_env && !m.profiling && stages == 7 && iters >= 2 && !(m.d_occ && !m.occ_refreshed_iter);      // (the first occupancy refresh changes a kernel argument)
+    // chunks of iterations go through the device's training lanes (whole steps only; big-table objects are HBM-bound in their optimizer and gain from more overlap, not less)
+    const bool lanes_on = stages == 7 && m.big_switch == 0u; const int chunk = options().lane_chunk >= 2 ? (options().lane_chunk & ~1) : 2;
     if (use_graph) {
         const int graph_key = m.backend | (m.big_active ? 256 : 0) | (m.occ_refreshed_iter ? 512 : 0);
         if (!m.graph_exec || m.graph_backend != graph_key || m.graph_state != m.d_state) {
             drop_graph(m);
             hipGraph_t g = nullptr;
+            const hipStream_t cur = m.train_stream; m.train_stream = m.own_stream;      // captured on the object's own stream (a lane is shared with other host threads), replayed on the current one
             HIPCHECK(hipStreamBeginCapture(m.train_stream, hipStreamCaptureModeThreadLocal));
             m.next_ready = false;                           // the captured iterations are self-contained
             m.graph_state = m.d_state;
             enqueue_iteration(m, 7); enqueue_iteration(m, 7);      // a PAIR: the two DevStates swap roles every iteration, after two the captured pointers are current again
-            HIPCHECK(hipStreamEndCapture(m.train_stream, &g));
+            const hipError_t ce = hipStreamEndCapture(m.train_stream, &g); m.train_stream = cur; HIPCHECK(ce);
             HIPCHECK(hipGraphInstantiate(&m.graph_exec, g, nullptr, nullptr, 0));
             hipGraphDestroy(g); m.graph_backend = graph_key;
         }
         int i = 0;
-        for (; i + 2 <= iters; i += 2) { maybe_refresh_occupancy(m, m.h_state.iter + (uint32_t)i); HIPCHECK(hipGraphLaunch(m.graph_exec, m.train_stream)); }
-        for (; i < iters; ++i) { maybe_refresh_occupancy(m, m.h_state.iter + (uint32_t)i); m.next_ready = false; enqueue_iteration(m, 7); }
+        while (i + 2 <= iters) {
+            LaneChunk lc(m, lanes_on);
+            for (int k = 0; k < chunk && i + 2 <= iters; k += 2, i += 2) { maybe_refresh_occupancy(m, m.h_state.iter + (uint32_t)i); HIPCHECK(hipGraphLaunch(m.graph_exec, m.train_stream)); }
+        }
+        for (; i < iters; ++i) { LaneChunk lc(m, lanes_on); maybe_refresh_occupancy(m, m.h_state.iter + (uint32_t)i); m.next_ready = false; enqueue_iteration(m, 7); }
     } else {
-        for (int i = 0; i < iters; ++i) { if (stages == 7) maybe_refresh_occupancy(m, m.h_state.iter + (uint32_t)i); enqueue_iteration(m, stages); }
+        for (int i = 0; i < iters; ) {
+            LaneChunk lc(m, lanes_on);
+            for (int k = 0; k < chunk && i < iters; ++k, ++i) { if (stages == 7) maybe_refresh_occupancy(m, m.h_state.iter + (uint32_t)i); enqueue_iteration(m, stages); }
+        }
     }
     HIPCHECK(hipGetLastError());
     int rc = sync_state(m); if (rc) return rc;
     if (loss) *loss = m.h_state.loss_sum / (float)m.oc.R;       // :1650-1658
     if (stages == 7 && iters > 0) rc = publish_snapshot(m, iters >= 64);
+    mark_tail(m);
     return rc;
 }
 
-int model_publish_snapshot(Model& m) { HIPCHECK(use_device(m.device)); return publish_snapshot(m, true); }      // owner thread: the end of a whole Train_Step_Online
+int model_publish_snapshot(Model& m) { HIPCHECK(use_device(m.device)); const int rc = publish_snapshot(m, true); mark_tail(m); return rc; }      // owner thread: the end of a whole Train_Step_Online
 
 // Render of the latest PUBLISHED inference weights on the inference stream: callable from any thread while the owner trains (no model mutex,
 // no train-stream work).  MON_ERR_STATE when nothing has been published yet (or the model has no inference side): the caller falls back to

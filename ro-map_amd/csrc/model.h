@@ -103,7 +103,7 @@ enum {
 // Process-wide test and tuning switches (mon_set_option, include/mon_core.h); defaults are the product behaviour.
 struct Options {
     long backend = -1, use_graph = 0, lazy_ema = -1, big_switch = 16384, touched_flags = 1, lds_scatter = 1, fold_reduce = 1, fold_next = 1,
-         fused_grid = 0, opt_blocks = 0, fused_ablate = 0, fused_stagger = -1, offline_outer = 10, offline_inner = 500, scatter_bins = 0, opt_lazy_below = -1, scatter_ablate = 0;
+         fused_grid = 0, opt_blocks = 0, fused_ablate = 0, fused_stagger = -1, offline_outer = 10, offline_inner = 500, scatter_bins = 0, opt_lazy_below = -1, scatter_ablate = 0, train_lanes = 2, lane_chunk = 16;
 };
 Options& options();
 int option_set(const char* name, long value);
@@ -199,6 +199,8 @@ struct Model {
     bool scatter_pending = false;   // a fused forward/backward was enqueued whose slot counter has not been reset by an optimizer step yet
     bool next_ready = false;     // fused backend: candidates + fragment image of the coming iteration were already produced by the last k_optimizer
     mon_profile prof{}; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pending;
+    struct TrainLanes* lanes = nullptr; int lane = -1; hipEvent_t lane_event = nullptr, switch_event = nullptr, sync_event = nullptr;      // per-device training lanes (model.cpp): the lane and completion event of this object's last chunk
+    bool tail_marked = false; hipStream_t own_stream = nullptr;        // the object's private stream; train_stream is the one its work currently goes to (this one or a lane's)
     hipGraphExec_t graph_exec = nullptr; int graph_backend = -1; const DevState* graph_state = nullptr;      // (the state the captured pair of iterations starts on)
 };
 

@@ -93,14 +93,18 @@ def test_stress_shape_eight_t22_objects_concurrently_on_one_gpu(pkg, ss):
 
 
 def test_concurrent_objects_train_exactly_like_lone_ones(pkg, ss):
-    """Independent units: four base.json objects trained concurrently on one GPU (thread + stream each, as the managers do) end with
-    bit-identical parameters to the same objects trained one at a time -- no cross-object state, deterministic scatter."""
+    """Independent units: four base.json objects trained concurrently on one GPU (one host thread each, as the managers do; with more objects
+    than training lanes their chunks of iterations share the device's two lane streams and change lanes between calls) end with bit-identical
+    parameters to the same objects trained one at a time -- no cross-object state, deterministic scatter, lanes order work for speed only."""
     assert pkg.device_count() >= 1
     sc = ss.make_scene(n_views=16, H=240, W=320, f=260.0, seed=2)
     ds = None; objs = []
     for k in range(4):
         ds, o = ge.make_problem(pkg, sc, dict(sample_seed=700 + k), dataset=ds); objs.append(o)
-    th = [threading.Thread(target=o.train, args=(150,)) for o in objs]
+    def sliced(o, k):                                             # uneven slices: objects drop out of and re-enter the lanes at different times
+        for n in ((40, 1, 33, 60, 16), (150,), (7,) * 20 + (10,), (75, 75))[k]:
+            o.train(n)
+    th = [threading.Thread(target=sliced, args=(o, k)) for k, o in enumerate(objs)]
     [t.start() for t in th]; [t.join() for t in th]
     together = [zlib.crc32(o.get_params(0).tobytes()) for o in objs]
     for o in objs:
