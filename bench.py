@@ -302,9 +302,9 @@ def main():
         cpu = time_oracle({}, args.cpu_seconds, "R=4096 x S=32, base.json network")
         cpu_c1 = time_oracle(dict(rays_per_batch=1024, n_levels=4, n_neurons=32, n_hidden_layers=2), max(2.0, args.cpu_seconds / 3), "BASELINE configs[0]: R=1024 x S=32, hash L=4, MLP 2x32")
 
-    # ---- extra, not the headline: K object NeRFs trained concurrently on this GPU (thread + HIP stream per object, as the managers do,
-    #      CORE/src/nerf_manager.cu:89,259); the kernels of different objects overlap, so the aggregate rate says how much of the chip
-    #      one object's launch chain leaves idle.  Every object is at the timed window's training stage (steps W..W+K from init).
+    # ---- extra, not the headline: K object NeRFs trained concurrently on this GPU (a host thread per object, as the managers do,
+    #      CORE/src/nerf_manager.cu:89,259; the library threads their work through two shared streams); the kernels of different objects
+    #      overlap, so the aggregate rate says how much of the chip one object's launch chain leaves idle.  Every object is at the timed window's training stage (steps W..W+K from init).
     multi = None
     if rank == 0 and world == 1 and args.objects_per_gpu > 1:
         try:
@@ -318,7 +318,7 @@ def main():
             [t.start() for t in th]; [t.join() for t in th]
             sync(); tm = time.perf_counter() - tm0
             multi = {"objects": K, "value": round(K * args.steps * B / tm, 1), "unit": "ray-samples/s (all objects)", "ms_per_step_per_object": round(1e3 * tm / args.steps, 4),
-                     "note": "K independent objects, one host thread and one HIP stream each, same GPU, each over steps %d..%d from init" % (args.warmup, args.warmup + args.steps)}
+                     "note": "K independent objects, one host thread each, their training work on the device's two training lanes (DESIGN 7.2), same GPU, each over steps %d..%d from init" % (args.warmup, args.warmup + args.steps)}
             for o in objs:
                 o.close()
         except Exception as e:
