@@ -343,15 +343,17 @@ static bool online_check_finish(OnlineObject* o) { std::unique_lock<std::mutex> 
 // thread's NewFrameToDataset never waits longer than one batch generation.  Here an iteration is three stream-ordered launches without
 // host involvement, so the mutexes are held for slices of up to kOnlineSlice iterations (~1.5 ms at base.json size, one host sync per
 // slice) and anybody waiting for them is let in between two slices.  With several objects on a device the slices shrink (16 / n, at
-// least 2): the other objects' queued work keeps the GPU busy across this thread's syncs, and a frame upload or a viewer's render --
-// which share the device's few hardware queues with all those streams -- finds them shallow.
+// least option `online_slice_min` = 2): the other objects' queued work keeps the GPU busy across this thread's syncs (the device's training
+// lanes, model.cpp, hold a chunk of every object), and a frame upload -- which takes every object's dataset mutex -- waits for short
+// slices only.  Measured with 12 objects (tools/online_replay.py): a minimum of 4 / 8 / 16 iterations trains 5 % more in the same time but
+// NewFrameToDataset's p99 goes 1.7 -> 2.1 / 5.4 / 10 ms (and the viewer's crop 0.9 -> 4.4 ms at 16).
 static constexpr int kOnlineSlice = 16;
 static int train_sliced(OnlineObject* o) {
     int rc = MON_OK;
     for (int done = 0; done < o->iterations && rc == MON_OK; ) {
         while (o->waiters.load() > 0) std::this_thread::yield();
         const int sharing = o->device_objects ? o->device_objects->load() : 1;
-        int n = kOnlineSlice / (sharing > 0 ? sharing : 1); if (n < 2) n = 2; if (n > o->iterations - done) n = o->iterations - done;
+        int n = kOnlineSlice / (sharing > 0 ? sharing : 1); const int n_min = options().online_slice_min > 0 ? options().online_slice_min : 2; if (n < n_min) n = n_min; if (n > o->iterations - done) n = o->iterations - done;
         std::unique_lock<std::mutex> dl(*o->dataset_mutex); std::lock_guard<std::mutex> lm(o->mu_model);
         rc = model_train(*o->model, n, &o->last_loss, 7); done += n;
         if (rc == MON_OK && done >= o->iterations) rc = model_publish_snapshot(*o->model);       // viewers see the end of every Train_Step_Online

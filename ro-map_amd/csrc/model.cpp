@@ -37,7 +37,7 @@ static long* option_slot(const char* name) {
     static const struct { const char* n; long Options::*f; } tab[] = {
         { "backend", &Options::backend }, { "use_graph", &Options::use_graph }, { "lazy_ema", &Options::lazy_ema }, { "big_switch", &Options::big_switch },
         { "touched_flags", &Options::touched_flags }, { "lds_scatter", &Options::lds_scatter }, { "fold_reduce", &Options::fold_reduce }, { "fold_next", &Options::fold_next },
-        { "fused_grid", &Options::fused_grid }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk },
+        { "fused_grid", &Options::fused_grid }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
         { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner }, { "scatter_bins", &Options::scatter_bins }, { "opt_lazy_below", &Options::opt_lazy_below }, { "scatter_ablate", &Options::scatter_ablate } };
     for (const auto& e : tab) if (name && std::strcmp(name, e.n) == 0) return &(g_options.*(e.f));
     return nullptr;
