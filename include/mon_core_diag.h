@@ -12,6 +12,9 @@ extern "C" {
 
 /* Copy an internal device buffer to the host; ids in ro-map_amd/csrc/model.h (MON_BUF_*). */
 int mon_object_debug_read(mon_object* obj, int which, void* dst, size_t bytes);
+/* Copy one uploaded frame of a dataset back to the host: rgba[H*W] packed r | g << 8 | b << 16 | instance << 24, depth[H*W] (NULL or a dataset without depth:
+ * skipped), pose[16] (Twc, column-major).  The upload test compares what arrived with what was sent, frame by frame. */
+int mon_dataset_debug_read(mon_dataset* ds, uint32_t frame, uint32_t* rgba, float* depth, float* pose16);
 /* Diagnostic micro-benchmarks of scatter strategies (ro-map_amd/csrc/microbench.hip); *ms = best of 3 runs. */
 int mon_microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms);
 /* Host-side check hook: corner index of the fused kernels' closed form (device_common.h:fast_grid_index) for level `level`

@@ -118,6 +118,7 @@ _SIGS = {
 # every symbol include/mon_core_diag.h declares (libmon_core_diag.so: diagnostics and test scaffolding, not the product)
 _DIAG_SIGS = {
     "mon_object_debug_read": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "mon_dataset_debug_read": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mon_microbench": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
     "mon_debug_frag_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mon_debug_acc_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
@@ -262,6 +263,12 @@ class Dataset:
     @property
     def n_frames(self):
         n = C.c_uint32(0); _check(lib().mon_dataset_n_frames(self.h, C.byref(n))); return n.value
+
+    def debug_read(self, frame_id, with_depth=False):
+        """(diagnostics library) what the device holds for one frame: packed rgba | instance << 24, depth or None, pose (Twc, column-major)."""
+        rgba = np.empty((self.H, self.W), np.uint32); pose = np.empty(16, np.float32); dep = np.empty((self.H, self.W), np.float32) if with_depth else None
+        _check(diag_lib().mon_dataset_debug_read(self.h, frame_id, _p(rgba), _p(dep), _p(pose)))
+        return rgba, dep, pose
 
     def close(self):
         if self.h:

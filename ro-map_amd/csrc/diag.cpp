@@ -75,6 +75,16 @@ using namespace mon;
 
 extern "C" {
 int mon_object_debug_read(mon_object* o, int which, void* dst, size_t bytes) { REQUIRE(o, "object"); return model_debug_read(*o->m, which, dst, bytes); }
+int mon_dataset_debug_read(mon_dataset* ds, uint32_t frame, uint32_t* rgba, float* depth, float* pose16) {
+    REQUIRE(ds, "dataset"); Dataset& d = *ds->d;
+    if (frame >= d.max_frames) { set_error("dataset_debug_read: frame %u >= capacity %u", frame, d.max_frames); return MON_ERR_ARG; }
+    const size_t px = (size_t)d.K.H * d.K.W;
+    HIPCHECK(use_device(d.device)); HIPCHECK(hipDeviceSynchronize());
+    if (rgba) HIPCHECK(hipMemcpy(rgba, d.d_rgba + px * frame, px * 4, hipMemcpyDeviceToHost));
+    if (depth && d.d_depth) HIPCHECK(hipMemcpy(depth, d.d_depth + px * frame, px * 4, hipMemcpyDeviceToHost));
+    if (pose16) HIPCHECK(hipMemcpy(pose16, d.d_poses + 16 * (size_t)frame, 64, hipMemcpyDeviceToHost));
+    return MON_OK;
+}
 int mon_microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms) { REQUIRE(ms, "ms"); return microbench(device, mode, pattern, n_entries, n_ops, ms); }
 int mon_debug_fast_index(const mon_config* cfg, int level, uint32_t x, uint32_t y, uint32_t z, uint32_t* index, uint32_t* size) {
     REQUIRE(cfg, "cfg"); REQUIRE(index, "index"); REQUIRE(size, "size");

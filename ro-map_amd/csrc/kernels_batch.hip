@@ -164,11 +164,28 @@ void launch_grid_points(hipStream_t s, float* pts, int rx, int ry, int rz, uint3
 }
 
 // One incoming frame: colour (3 or 4 bytes per pixel, in pinned host memory: the loads cross PCIe) + instance byte -> r | g << 8 | b << 16 | instance << 24.
-__global__ void __launch_bounds__(256) k_pack_frame(const uint8_t* __restrict__ rgb, int ch, int ri, int bi, const uint8_t* __restrict__ inst, uint32_t* __restrict__ dst, uint32_t px) {
+// The host rewrites the same staging addresses for every frame, so they are read with SYSTEM-scope loads (sc0 sc1: past the GPU's caches): an ordinary load
+// may legally be served from a line a cache kept from the previous frame's kernel, whatever coherence flag the pinned allocation carries.
+template <class T> __device__ __forceinline__ T host_load(const T* p) {
+#ifdef MON_PLAIN_HOST_LOADS          // (variant build for the upload test: ordinary loads, to show what it catches)
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+__global__ void __launch_bounds__(256) k_pack_frame(const uint8_t* rgb, int ch, int ri, int bi, const uint8_t* inst, uint32_t* __restrict__ dst, uint32_t px) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < px; i += gridDim.x * blockDim.x) {
         const uint8_t* c = rgb + (size_t)i * (uint32_t)ch;
-        dst[i] = (uint32_t)c[ri] | ((uint32_t)c[1] << 8) | ((uint32_t)c[bi] << 16) | ((uint32_t)inst[i] << 24);
+        dst[i] = (uint32_t)host_load(c + ri) | ((uint32_t)host_load(c + 1) << 8) | ((uint32_t)host_load(c + bi) << 16) | ((uint32_t)host_load(inst + i) << 24);
     }
+}
+// n 4-byte words from rewritten pinned host memory to the device (a frame's depth image, its pose)
+__global__ void __launch_bounds__(256) k_copy_from_host(const uint32_t* src, uint32_t* __restrict__ dst, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = host_load(src + i);
+}
+void launch_copy_from_host(hipStream_t s, const void* src, void* dst, uint32_t n_words) {
+    const uint32_t blocks = (n_words + 255u) / 256u > 1024u ? 1024u : (n_words + 255u) / 256u;
+    hipLaunchKernelGGL(k_copy_from_host, dim3(blocks ? blocks : 1u), dim3(256), 0, s, static_cast<const uint32_t*>(src), static_cast<uint32_t*>(dst), n_words);
 }
 void launch_pack_frame(hipStream_t s, const uint8_t* rgb, int ch, int ri, int bi, const uint8_t* inst, uint32_t* dst, uint32_t px) {
     hipLaunchKernelGGL(k_pack_frame, dim3((px + 255u) / 256u > 1024u ? 1024u : (px + 255u) / 256u), dim3(256), 0, s, rgb, ch, ri, bi, inst, dst, px);

@@ -175,14 +175,16 @@ int dataset_create(int device, int H, int W, float fx, float fy, float cx, float
         if (d->use_depth) { HIPCHECK(hipMalloc((void**)&d->d_depth, px * 4 * max_frames)); HIPCHECK(hipMemset(d->d_depth, 0, px * 4 * max_frames)); }
         HIPCHECK(hipMalloc((void**)&d->d_poses, 64 * (size_t)max_frames));
         HIPCHECK(hipMemset(d->d_poses, 0, 64 * (size_t)max_frames));
+        // hipMemset returns before the fill has run (null stream), and the upload stream is non-blocking: without this wait the fill can land AFTER the first
+        // frames' packing kernels and wipe them (seen as frames that read as black / instance 0 now and then -- more valid candidate rays than the oracle has)
+        HIPCHECK(hipStreamSynchronize(nullptr));
         return MON_OK;
     };
     if ((rc = alloc())) { dataset_destroy(d); return rc; }          // e.g. out of memory for max_frames images: free what was taken
     d->present.assign(max_frames, 0);
     // frames arrive through a pinned staging buffer and are packed by a kernel on the device's high-priority stream (see dataset_add_frame)
     { InferShared* sh = nullptr; if ((rc = infer_shared_get(device, px, &sh))) { dataset_destroy(d); return rc; } d->upload = sh; }
-    // (COHERENT pinned memory: the packing kernel re-reads the same host addresses for every frame, and with the default (cacheable) mapping it saw lines of the
-    //  previous frame -- a few hundred stale pixels per image)
+    // (coherent pinned memory, and the packing kernels read it with system-scope loads: the same host addresses are rewritten for every frame)
     d->stage_bytes = px * 9 + 128;                                      // raw colour (<= 4 B/pixel), instance (1 B), depth (4 B), pose
     if (hipHostMalloc((void**)&d->h_stage, d->stage_bytes, hipHostMallocCoherent) != hipSuccess) { set_error("dataset_create: pinned staging allocation failed"); dataset_destroy(d); return MON_ERR_HIP; }
     *out = d; return MON_OK;
@@ -201,8 +203,8 @@ int dataset_add_frame(Dataset* d, uint32_t id, const uint8_t* rgb, int ch, int i
     uint8_t* st_rgb = d->h_stage, *st_inst = st_rgb + px * 4; float* st_depth = reinterpret_cast<float*>(st_inst + ((px + 15) & ~(size_t)15)); float* st_pose = st_depth + (d->use_depth ? px : 0);
     std::memcpy(st_rgb, rgb, px * (size_t)ch); std::memcpy(st_inst, inst, px); std::memcpy(st_pose, Twc, 64);
     launch_pack_frame(sh->stream, st_rgb, ch, ri, bi, st_inst, d->d_rgba + px * id, (uint32_t)px);
-    if (d->use_depth) { std::memcpy(st_depth, depth, px * 4); launch_copy_params(sh->stream, reinterpret_cast<const uint16_t*>(st_depth), reinterpret_cast<uint16_t*>(d->d_depth + px * id), (uint32_t)(px * 2)); }
-    launch_copy_params(sh->stream, reinterpret_cast<const uint16_t*>(st_pose), reinterpret_cast<uint16_t*>(d->d_poses + 16 * (size_t)id), 32u);
+    if (d->use_depth) { std::memcpy(st_depth, depth, px * 4); launch_copy_from_host(sh->stream, st_depth, d->d_depth + px * id, (uint32_t)px); }
+    launch_copy_from_host(sh->stream, st_pose, d->d_poses + 16 * (size_t)id, 16u);
     HIPCHECK(hipStreamSynchronize(sh->stream)); HIPCHECK(hipGetLastError());
     if (id + 1 > d->n_frames) d->n_frames = id + 1;                 // mFrameDataNum, nerf_data.cu:338
     d->present[id] = 1;

@@ -64,7 +64,7 @@ def test_batch_generation_matches_oracle(pkg, orc, small_scene, kw, use_depth):
 @pytest.mark.parametrize("hw", [(45, 67), (61, 83)], ids=["45x67", "61x83"])
 def test_ragged_image_sizes_upload_exactly(pkg, orc, ss, hw):
     """Frames whose pixel count is not a multiple of 4 or 16 (the upload packs them with a kernel out of pinned staging, depth and pose behind the colour and
-    instance bytes at 16-byte steps): every frame re-uses the same staging addresses, so a stale or misaligned read shows up as a candidate mismatch in some
+    instance bytes at 16-byte steps): every frame re-uses the same staging addresses, so a misaligned or out-of-date read shows up as a candidate mismatch in some
     later frame -- the batch of 4096 candidates over all frames is compared with the oracle's, with and without depth."""
     sc = ss.make_scene(n_views=12, H=hw[0], W=hw[1], f=55.0, seed=9)
     for use_depth in (False, True):
@@ -78,6 +78,40 @@ def test_ragged_image_sizes_upload_exactly(pkg, orc, ss, hw):
                 close_f32(obj.buffer(b), ref.buffer(b), b, 1e-6)
             obj.train_stages(2 | 4); ref.train_step()
         obj.close(); ds.close(); ref.close()
+
+
+def test_every_uploaded_frame_arrives_as_sent(pkg):
+    """Frame upload read back from the device, frame by frame: 96 frames go through the SAME pinned staging addresses back to back (colour, instance,
+    depth, pose), each with its own contents.  A read served from a cache line the previous frame's kernel left behind -- seen as frames arriving with
+    the previous frame's pose -- shows up here directly (the staging reads are system-scope loads for that reason)."""
+    H, W, n = 37, 53, 96
+    rng = np.random.default_rng(5)
+    ds = pkg.Dataset(0, H, W, 60.0, 60.0, W / 2, H / 2, n, use_depth=True)
+    sent = []
+    for k in range(n):
+        rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8); inst = rng.integers(0, 4, (H, W), dtype=np.uint8)
+        dep = rng.random((H, W), dtype=np.float32) * 3.0; pose = rng.standard_normal(16).astype(np.float32)
+        ds.add_frame(k, rgb, inst, pose, depth=dep); sent.append((rgb, inst, dep, pose))
+    for k, (rgb, inst, dep, pose) in enumerate(sent):
+        rgba, d, p = ds.debug_read(k, with_depth=True)
+        want = rgb[..., 0].astype(np.uint32) | (rgb[..., 1].astype(np.uint32) << 8) | (rgb[..., 2].astype(np.uint32) << 16) | (inst.astype(np.uint32) << 24)
+        assert np.array_equal(rgba, want), "frame %d: colour / instance" % k
+        assert np.array_equal(d, dep), "frame %d: depth" % k
+        assert np.array_equal(p, pose), "frame %d: pose" % k
+    ds.close()
+    # a dataset whose zero-fill at creation takes ~1 ms (2 GB), and the LAST frame slot uploaded right away: the fill must not land after the upload
+    free, _ = pkg.device_mem_info(0)
+    if free > (8 << 30):
+        cap = (2 << 30) // (H * W * 4)
+        ds = pkg.Dataset(0, H, W, 60.0, 60.0, W / 2, H / 2, cap)
+        rgb, inst, dep, pose = sent[0]
+        for k in (cap - 1, cap // 2, 0):
+            ds.add_frame(k, rgb, inst, pose)
+        want = rgb[..., 0].astype(np.uint32) | (rgb[..., 1].astype(np.uint32) << 8) | (rgb[..., 2].astype(np.uint32) << 16) | (inst.astype(np.uint32) << 24)
+        for k in (cap - 1, cap // 2, 0):
+            rgba, _, p = ds.debug_read(k)
+            assert np.array_equal(rgba, want) and np.array_equal(p, pose), "frame %d of a freshly created %d-frame dataset" % (k, cap)
+        ds.close()
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
