@@ -2,7 +2,7 @@
 # Late in training (default: the stress configuration; CFG='{}' = base.json): kernel split of iterations 800..860 (the kernel trace covers all 860; the table shows min/avg/max).
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/big_late; mkdir -p $OUT
-(cd /tmp && MON_CRC_CFG="${CFG:-{\"log2_hashmap_size\": 22\}}" timeout 300 rocprofv3 --kernel-trace -d $OUT/prof -o st -- python $GRAFT_REPO_ROOT/tools/param_crc.py 800 60 > $OUT/run.log 2>&1)
+(cd /tmp && MON_CRC_CFG="${CFG:-{\"log2_hashmap_size\": 22\}}" timeout 300 rocprofv3 --kernel-trace -d $OUT/prof -o st -- python $GRAFT_REPO_ROOT/tools/param_crc.py ${WARM:-800} 60 > $OUT/run.log 2>&1)
 DB=$(find "$OUT/prof" -name "*_results.db" | head -1)
 python - "$DB" <<'PY'
 import sqlite3, sys, re
