@@ -106,11 +106,19 @@ def test_concurrent_objects_train_exactly_like_lone_ones(pkg, ss):
             o.train(n)
     th = [threading.Thread(target=sliced, args=(o, k)) for k, o in enumerate(objs)]
     [t.start() for t in th]; [t.join() for t in th]
+    pkg.set_option("train_lanes", 0)                              # the scheduler switched off under running objects: their work moves back to their own streams
+    try:
+        th = [threading.Thread(target=o.train, args=(20,)) for o in objs]
+        [t.start() for t in th]; [t.join() for t in th]
+    finally:
+        pkg.set_option("train_lanes", 2)
+    th = [threading.Thread(target=o.train, args=(30,)) for o in objs]   # ... and on again
+    [t.start() for t in th]; [t.join() for t in th]
     together = [zlib.crc32(o.get_params(0).tobytes()) for o in objs]
     for o in objs:
         o.close()
     for k in range(4):
-        _, o = ge.make_problem(pkg, sc, dict(sample_seed=700 + k), dataset=ds); o.train(150)
+        _, o = ge.make_problem(pkg, sc, dict(sample_seed=700 + k), dataset=ds); o.train(200)
         assert zlib.crc32(o.get_params(0).tobytes()) == together[k], "object %d" % k
         o.close()
     assert len(set(together)) == 4
