@@ -139,7 +139,7 @@ def main():
         t0 = time.perf_counter()
         obj.train(args.steps)              # K iterations enqueued on the object's HIP stream, one sync at the end
         sync(); barrier()
-        dt_r = time.perf_counter() - t0
+        dt_r = own_last = time.perf_counter() - t0
         if dist is not None:
             dt_r = sharding.max_over_ranks(dist, torch, dt_r, coll_dev)
         reps.append(dt_r)
@@ -148,7 +148,7 @@ def main():
     value = world * args.steps * B / dt
     per_rank = None
     if dist is not None:                   # every rank's own last-repeat time (the headline uses the max over ranks)
-        t = torch.tensor([reps[-1]], dtype=torch.float64, device=coll_dev); outs = [torch.zeros_like(t) for _ in range(world)]
+        t = torch.tensor([own_last], dtype=torch.float64, device=coll_dev); outs = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(outs, t); per_rank = [round(args.steps * B / float(o.item()), 1) for o in outs]
 
     # ---- roofline of the dominant kernel: HIP events on the kernel's own stream (the object's train stream) around every launch of

@@ -19,6 +19,7 @@ bool read_yaml_number(const std::string& text, const char* key, double& v);
         set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return MON_ERR_HIP; } } while (0)
 
 int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
+    model_leave_lane(m);
     if (which == MON_BUF_EMA) { int rc = ensure_ema_current(m); if (rc) return rc; }
     const size_t R = m.oc.R, B = R * m.oc.S, n = m.n_params; const void* src = nullptr; size_t sz = 0;
     switch (which) {

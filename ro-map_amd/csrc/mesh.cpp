@@ -141,6 +141,7 @@ int model_generate_mesh(Model& m, int res, float thresh, uint32_t* n_verts, uint
     if (res < 2 || res > 512) { set_error("generate_mesh: res must be in [2, 512]"); return MON_ERR_ARG; }
     HIPCHECK(use_device(m.device));
     if (!m.mesh) { set_error("mesh: object has no mesh state"); return MON_ERR_STATE; }       // created with the object (no lazily published pointer for readers to race on)
+    model_leave_lane(m);
     MeshState& ms = *m.mesh; hipStream_t s = m.train_stream;
     const size_t res3 = (size_t)res * res * res;
     int rc = mesh_reserve_lattice(ms, res3); if (rc) return rc;

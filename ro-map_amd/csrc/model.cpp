@@ -119,6 +119,10 @@ static void mark_tail(Model& m) {
 }
 // moves the object's work to stream `to`: everything it has enqueued so far is ordered before whatever follows on the new stream.  The wait is for the object's OWN last
 // work (mark_tail) -- an event recorded now would also stand behind every chunk other objects have queued on the old lane since, and tie the two lanes together.
+static void switch_stream(Model& m, hipStream_t to);
+// Everything that is not a training chunk (renders on the train stream, density grids, meshes, parameter access, box uploads) runs on the object's OWN stream:
+// on a lane it would queue -- and its synchronisation would wait -- behind every chunk other objects have enqueued there.
+void model_leave_lane(Model& m) { switch_stream(m, m.own_stream); }
 static void switch_stream(Model& m, hipStream_t to) {
     if (m.train_stream == to) return;
     if (!m.tail_marked) mark_tail(m);
@@ -413,6 +417,7 @@ int model_destroy(Model* mp) {
     if (!mp) return MON_OK;
     Model& m = *mp; use_device(m.device);
     model_mesh_free(m);
+    if (m.own_stream) model_leave_lane(m);
     if (m.train_stream) hipStreamSynchronize(m.train_stream);
     if (m.infer) {
         InferState* is = m.infer; if (is->shared) { std::lock_guard<std::mutex> l(is->shared->mu); hipStreamSynchronize(is->shared->stream); }      // (the stream and the pinned buffer stay with the device)
@@ -445,7 +450,7 @@ int model_add_boxes(Model& m, const mon_frame_bbox* boxes, size_t n) {
             return MON_ERR_STATE;
         }
     }
-    HIPCHECK(hipStreamSynchronize(m.train_stream));
+    model_leave_lane(m); HIPCHECK(hipStreamSynchronize(m.train_stream));
     if (m.n_boxes + n > m.boxes_cap) {
         uint32_t cap = m.boxes_cap; while (cap < m.n_boxes + n) cap *= 2;
         mon_frame_bbox* nb = nullptr; int rc = dev_alloc(m, nb, cap); if (rc) return rc;
@@ -658,7 +663,7 @@ int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int
 // Lazy EMA: apply the steps untouched chunks sat out before the inference weights are read.
 int ensure_ema_current(Model& m) {
     if (!m.ema_pending) return MON_OK;
-    HIPCHECK(use_device(m.device));
+    HIPCHECK(use_device(m.device)); model_leave_lane(m);
     ParamPtrs P = m.P; P.ema_step = m.d_ema_step;
     launch_ema_finalize(m.train_stream, P, m.opt, m.d_state);
     HIPCHECK(hipGetLastError()); m.ema_pending = false; return MON_OK;
@@ -667,6 +672,7 @@ int ensure_ema_current(Model& m) {
 int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, int dst_on_device) {
     if (!pose16 || !rgb || !depth || !mask || box.w == 0 || box.h == 0) { set_error("render: bad argument"); return MON_ERR_ARG; }
     HIPCHECK(use_device(m.device));
+    model_leave_lane(m);
     { int rc = ensure_ema_current(m); if (rc) return rc; }
     hipStream_t s = m.train_stream;
     HIPCHECK(hipStreamSynchronize(s));
@@ -706,6 +712,7 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
 int model_density_grid(Model& m, int rx, int ry, int rz, float* out_host) {
     if (rx < 2 || ry < 2 || rz < 2 || !out_host || (uint64_t)rx * (uint64_t)ry * (uint64_t)rz > (1ull << 31)) { set_error("density_grid: bad argument"); return MON_ERR_ARG; }
     HIPCHECK(use_device(m.device));
+    model_leave_lane(m);
     { int rc = ensure_ema_current(m); if (rc) return rc; }
     hipStream_t s = m.train_stream;
     HIPCHECK(hipStreamSynchronize(s));
@@ -729,14 +736,14 @@ int model_get_params(Model& m, int which, void* dst, size_t bytes) {
     switch (which) { case 0: src = m.P.master; need = (size_t)m.n_params * 4; break; case 1: src = m.P.half; need = (size_t)m.n_params * 2; break;
                      case 2: src = m.P.ema; need = (size_t)m.n_params * 2; break; default: set_error("get_params: which must be 0..2"); return MON_ERR_ARG; }
     if (!dst || bytes < need) { set_error("get_params: buffer too small (%zu < %zu)", bytes, need); return MON_ERR_ARG; }
-    HIPCHECK(use_device(m.device));
+    HIPCHECK(use_device(m.device)); model_leave_lane(m);
     if (which == 2) { int rc = ensure_ema_current(m); if (rc) return rc; }
     HIPCHECK(hipStreamSynchronize(m.train_stream));
     HIPCHECK(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost)); return MON_OK;
 }
 int model_set_params(Model& m, const float* master, size_t n) {
     if (!master || n != m.n_params) { set_error("set_params: expected %u values", m.n_params); return MON_ERR_ARG; }
-    HIPCHECK(use_device(m.device)); HIPCHECK(hipStreamSynchronize(m.train_stream));
+    HIPCHECK(use_device(m.device)); model_leave_lane(m); HIPCHECK(hipStreamSynchronize(m.train_stream));
     HIPCHECK(hipMemcpy(m.P.master, master, n * 4, hipMemcpyHostToDevice));
     launch_master_to_half(m.train_stream, m.P.master, m.P.half, (uint32_t)n);
     HIPCHECK(hipStreamSynchronize(m.train_stream));

@@ -132,6 +132,7 @@ void launch_composite_render(hipStream_t s, const BatchPtrs& b, uint32_t S, uint
 void launch_extract_density(hipStream_t s, const uint16_t* O, float* out, uint32_t n);
 void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, uint32_t n);
 void launch_copy_params(hipStream_t s, const uint16_t* src, uint16_t* dst, uint32_t n);
+void model_leave_lane(struct Model& m);      // non-training work goes to the object's own stream (model.cpp, training lanes)
 void launch_pack_frame(hipStream_t s, const uint8_t* rgb, int ch, int ri, int bi, const uint8_t* inst, uint32_t* dst, uint32_t px);      // host (pinned) images -> packed RGBA8 | instance << 24
 void launch_copy_from_host(hipStream_t s, const void* src, void* dst, uint32_t n_words);      // source: pinned host memory the host rewrites (system-scope loads)
 

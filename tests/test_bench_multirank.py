@@ -38,8 +38,13 @@ def test_two_self_spawned_ranks_report_two_gpus_and_gather_both_crops(pkg):
     assert r1.returncode == 0, r1.stderr[-3000:]
     j1 = _json_line(r1.stdout)
     assert j1["n_gpus"] == 1 and len(j1["psnr_db"]) == 1 and j1["config"]["launcher"] == "single process"
-    # whole-job value: two ranks each time the same per-rank work (on one shared GPU they slow each other down, so no scaling claim here)
-    assert j2["value"] > 0.5 * j1["value"]
+    # whole-job value = the ray-samples of ALL ranks over the slowest rank's time (two processes sharing one GPU slow each other down by an amount that varies from
+    # run to run, so nothing is claimed against the one-rank value): n_gpus x R x S per step time, and every rank's own rate is at least the slowest rank's
+    B = 4096 * 32
+    for j, n in ((j1, 1), (j2, 2)):
+        assert abs(j["value"] - n * B / (1e-3 * j["ms_per_step"])) < 2e-3 * j["value"], (j["value"], j["ms_per_step"])
+    pr = j2["per_rank_ray_samples_per_s"]
+    assert min(pr) >= 0.999 * B / (1e-3 * j2["ms_per_step_repeats"][-1]), (pr, j2["ms_per_step_repeats"])
     for j in (j1, j2):
         rf = j["roofline"]
         assert rf["bound"] in ("l2-requests", "hbm") and 0 < rf["frac"] < 1 and rf["avg_launch_ms"] > 0
