@@ -111,7 +111,18 @@ struct TrainLanes {
     struct Lane { hipStream_t stream = nullptr; hipEvent_t ev[kLaneRing] = {}; uint32_t head = 0, tail = 0; } lane[kMaxLanes];
 };
 static std::mutex g_lanes_mu; static std::map<int, TrainLanes*> g_lanes;
-static TrainLanes* lanes_get(int device) { std::lock_guard<std::mutex> l(g_lanes_mu); TrainLanes*& t = g_lanes[device]; if (!t) t = new TrainLanes(); return t; }
+// (the device is current.)  The lane streams are created TOGETHER, with the device's dataset and before any object's own stream: the runtime places a new stream on the
+// hardware queue with the fewest users, so two streams created back to back get different queues -- created lazily, with object streams in between, both lanes could
+// land on one queue and run strictly one after the other.
+static TrainLanes* lanes_get(int device) {
+    std::lock_guard<std::mutex> l(g_lanes_mu); TrainLanes*& t = g_lanes[device];
+    if (!t) {
+        t = new TrainLanes();
+        const int n = options().train_lanes < kMaxLanes ? options().train_lanes : kMaxLanes;
+        for (int i = 0; i < n; ++i) if (hipStreamCreateWithFlags(&t->lane[i].stream, hipStreamNonBlocking) != hipSuccess) { t->lane[i].stream = nullptr; (void)hipGetLastError(); }
+    }
+    return t;
+}
 // marks the end of what the object has enqueued so far on its current stream (called where an entry point returns with work still in flight: the end of a train call)
 static void mark_tail(Model& m) {
     if (!m.switch_event && hipEventCreateWithFlags(&m.switch_event, kLaneEventFlags) != hipSuccess) { m.switch_event = nullptr; m.tail_marked = false; return; }
@@ -188,6 +199,7 @@ int dataset_create(int device, int H, int W, float fx, float fy, float cx, float
     d->present.assign(max_frames, 0);
     // frames arrive through a pinned staging buffer and are packed by a kernel on the device's high-priority stream (see dataset_add_frame)
     { InferShared* sh = nullptr; if ((rc = infer_shared_get(device, px, &sh))) { dataset_destroy(d); return rc; } d->upload = sh; }
+    (void)lanes_get(device);                                            // the device's training lanes exist before its first object
     // (coherent pinned memory, and the packing kernels read it with system-scope loads: the same host addresses are rewritten for every frame)
     d->stage_bytes = px * 9 + 128;                                      // raw colour (<= 4 B/pixel), instance (1 B), depth (4 B), pose
     if (hipHostMalloc((void**)&d->h_stage, d->stage_bytes, hipHostMallocCoherent) != hipSuccess) { set_error("dataset_create: pinned staging allocation failed"); dataset_destroy(d); return MON_ERR_HIP; }
