@@ -108,7 +108,9 @@ constexpr int kMaxLanes = 4; constexpr uint32_t kLaneRing = 256;
 constexpr unsigned kLaneEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
 struct TrainLanes {
     std::mutex mu; std::atomic<int> objects{ 0 };      // live objects of the device
-    struct Lane { hipStream_t stream = nullptr; hipEvent_t ev[kLaneRing] = {}; uint32_t head = 0, tail = 0; } lane[kMaxLanes];
+    // per lane: `mu` orders the enqueueing of whole chunks; ev[tail .. head) = completion events of the chunks in flight (head: written by the enqueuer, tail: by whoever
+    // picks a lane, under TrainLanes::mu); pending = chunks that have picked the lane and not finished enqueueing
+    struct Lane { std::mutex mu; hipStream_t stream = nullptr; hipEvent_t ev[kLaneRing] = {}; std::atomic<uint32_t> head{ 0 }, pending{ 0 }, tail{ 0 }; } lane[kMaxLanes];
 };
 static std::mutex g_lanes_mu; static std::map<int, TrainLanes*> g_lanes;
 // (the device is current.)  The lane streams are created TOGETHER, with the device's dataset and before any object's own stream: the runtime places a new stream on the
@@ -141,39 +143,47 @@ static void switch_stream(Model& m, hipStream_t to) {
     else (void)hipStreamSynchronize(m.train_stream);
     m.train_stream = to; m.tail_marked = false;
 }
-// One chunk of an object's iterations on a lane.  The lock is held while the chunk is ENQUEUED (a few microseconds per launch): the chunks of different objects do not
-// interleave within a lane, and the lane loads are read and written by one thread at a time.
+// One chunk of an object's iterations on a lane.  The lane is picked under the device-wide lock (short); the chunk is then ENQUEUED under the lane's own lock (a few
+// microseconds per launch), so the chunks of different objects do not interleave within a lane while the host threads of different lanes enqueue side by side.
 struct LaneChunk {
     Model& m; TrainLanes* tl = nullptr; std::unique_lock<std::mutex> lock; int l = -1;
     explicit LaneChunk(Model& mm, bool enabled) : m(mm) {
         const int n = options().train_lanes < kMaxLanes ? options().train_lanes : kMaxLanes;
         if (!enabled || n <= 0 || !m.lanes || m.lanes->objects.load() <= n) { switch_stream(m, m.own_stream); return; }      // (up to `n` objects: their own streams ARE the lanes)
-        tl = m.lanes; lock = std::unique_lock<std::mutex>(tl->mu);
-        if (m.lane >= 0 && m.lane < n && m.lane_event && m.train_stream == tl->lane[m.lane].stream && hipEventQuery(m.lane_event) == hipErrorNotReady) l = m.lane;      // previous chunk still in flight: same lane
-        else {
-            uint32_t best = ~0u, mine = ~0u;
-            for (int i = 0; i < n; ++i) {
-                TrainLanes::Lane& L = tl->lane[i];
-                while (L.tail != L.head && hipEventQuery(L.ev[L.tail % kLaneRing]) == hipSuccess) ++L.tail;      // retire finished chunks
-                const uint32_t load = L.head - L.tail;
-                if (i == m.lane && m.train_stream == L.stream) mine = load;
-                if (load < best) { best = load; l = i; }
+        tl = m.lanes;
+        {   std::lock_guard<std::mutex> pick(tl->mu);
+            if (m.lane >= 0 && m.lane < n && m.lane_event && m.train_stream == tl->lane[m.lane].stream && hipEventQuery(m.lane_event) == hipErrorNotReady) l = m.lane;      // previous chunk still in flight: same lane
+            else {
+                uint32_t best = ~0u, mine = ~0u;
+                for (int i = 0; i < n; ++i) {
+                    TrainLanes::Lane& L = tl->lane[i];
+                    const uint32_t head = L.head.load(std::memory_order_acquire);
+                    uint32_t tail = L.tail.load(std::memory_order_relaxed);
+                    while (tail != head && hipEventQuery(L.ev[tail % kLaneRing]) == hipSuccess) ++tail;          // retire finished chunks
+                    L.tail.store(tail, std::memory_order_relaxed);
+                    const uint32_t load = head - tail + L.pending.load();
+                    if (i == m.lane && m.train_stream == L.stream) mine = load;
+                    if (load < best) { best = load; l = i; }
+                }
+                if (mine != ~0u && mine < best + 2u) l = m.lane;                                               // stay unless the other lane is clearly shorter
             }
-            if (mine != ~0u && mine < best + 2u) l = m.lane;                                                   // stay unless the other lane is clearly shorter
+            (void)hipGetLastError();                                                                           // (a hipErrorNotReady would otherwise be reported by the next hipGetLastError)
+            tl->lane[l].pending.fetch_add(1);
         }
-        (void)hipGetLastError();                                                                               // (a hipErrorNotReady would otherwise be reported by the next hipGetLastError)
         TrainLanes::Lane& L = tl->lane[l];
-        if (!L.stream && hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) { L.stream = nullptr; tl = nullptr; lock.unlock(); switch_stream(m, m.own_stream); return; }
+        lock = std::unique_lock<std::mutex>(L.mu);
+        if (!L.stream && hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) { L.stream = nullptr; L.pending.fetch_sub(1); tl = nullptr; lock.unlock(); switch_stream(m, m.own_stream); return; }
         switch_stream(m, L.stream);
     }
     ~LaneChunk() {
         if (!tl) return;
         TrainLanes::Lane& L = tl->lane[l];
-        if (L.head - L.tail == kLaneRing) { (void)hipEventSynchronize(L.ev[L.tail % kLaneRing]); ++L.tail; }  // ring full: wait for the oldest chunk
-        hipEvent_t& e = L.ev[L.head % kLaneRing];
-        if (!e && hipEventCreateWithFlags(&e, kLaneEventFlags) != hipSuccess) { e = nullptr; return; }
-        if (hipEventRecord(e, m.train_stream) != hipSuccess) return;
-        ++L.head; m.lane = l; m.lane_event = e;
+        const uint32_t head = L.head.load(std::memory_order_relaxed);
+        if (head - L.tail.load(std::memory_order_relaxed) < kLaneRing) {                                                                       // (a full ring -- 256 chunks in flight on one lane -- goes uncounted)
+            hipEvent_t& e = L.ev[head % kLaneRing];
+            if ((e || hipEventCreateWithFlags(&e, kLaneEventFlags) == hipSuccess) && hipEventRecord(e, m.train_stream) == hipSuccess) { L.head.store(head + 1u, std::memory_order_release); m.lane_event = e; }
+        }
+        m.lane = l; L.pending.fetch_sub(1);
     }
 };
 
