@@ -190,3 +190,13 @@ def test_object_placement_over_logical_devices(pkg, ss, tmp_path):
     finally:
         pkg.set_logical_devices(0); pkg.set_option("offline_outer", 10); pkg.set_option("offline_inner", 500)
     assert pkg.device_count() >= 1
+
+
+def test_objects_come_and_go_while_others_train(pkg):
+    """Object churn (tools/churn_stress.py): four host threads create, train in slices of random length, render (train stream and snapshot), read parameters,
+    add boxes and destroy objects for a few seconds on one device -- the training lanes, the stream pool and the inference side see the object count change
+    under running work.  No error, no non-finite loss or image, no skipped batch."""
+    import subprocess, sys
+    assert pkg.device_count() >= 1
+    r = subprocess.run([sys.executable, os.path.join(ge.ROOT, "tools", "churn_stress.py"), "4", "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "errors: []" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
