@@ -960,12 +960,21 @@ __device__ __forceinline__ uint32_t partials_groups(const PartialsArgs& pa) {
     const uint32_t n4 = (pa.n_cols + 1u + 3u) / 4u, need = (n4 + gridDim.x - 1u) / gridDim.x;
     return need <= 1u ? 1u : (need <= 2u ? 2u : (need <= 4u ? 4u : 8u));
 }
+// the column groups go to the LAST workgroups of the grid: the first ones hold the coarse dense levels, whose sample walk is the longest of the kernel (their samples
+// collide in the LDS atomic unit), so the row sums ride on workgroups that have slack
+__device__ __forceinline__ uint32_t partials_block() {
+#ifdef MON_PARTIALS_FIRST            // (variant build for the A/B measurement)
+    return blockIdx.x;
+#else
+    return gridDim.x - 1u - blockIdx.x;
+#endif
+}
 __device__ __forceinline__ void partials_prefetch(const PartialsArgs& pa, float4_t (&acc)[kPartialsMaxPasses]) {
     // thread = (column group gs of G, row subset sub of 1024 / G)
     const uint32_t n4 = (pa.n_cols + 1u + 3u) / 4u, G = partials_groups(pa), subs = blockDim.x / G, gs = threadIdx.x / subs, sub = threadIdx.x - gs * subs;
 #pragma unroll
     for (uint32_t ps = 0; ps < kPartialsMaxPasses; ++ps) {
-        const uint32_t g = (blockIdx.x + ps * gridDim.x) * G + gs; acc[ps] = float4_t{ 0.f, 0.f, 0.f, 0.f };
+        const uint32_t g = (partials_block() + ps * gridDim.x) * G + gs; acc[ps] = float4_t{ 0.f, 0.f, 0.f, 0.f };
         if (g < n4) for (uint32_t k0 = sub; k0 < pa.n_partials; k0 += 4u * subs) {            // four independent 16-byte loads per round (rows are padded to n_cols + 64 floats)
             float4_t v[4];
 #pragma unroll
@@ -979,7 +988,7 @@ __device__ __forceinline__ void partials_finish(const PartialsArgs& pa, const fl
     const uint32_t n4 = (pa.n_cols + 1u + 3u) / 4u, G = partials_groups(pa), wave = threadIdx.x >> 6, wpg = (blockDim.x >> 6) / G;
 #pragma unroll
     for (uint32_t ps = 0; ps < kPartialsMaxPasses; ++ps) {
-        const uint32_t g0 = (blockIdx.x + ps * gridDim.x) * G;
+        const uint32_t g0 = (partials_block() + ps * gridDim.x) * G;
         if (g0 >= n4) break;                                                               // uniform
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
