@@ -1007,11 +1007,14 @@ __device__ __forceinline__ void partials_finish(const PartialsArgs& pa, const fl
     }
 }
 
+#ifndef MON_HOUSEKEEPING_BLOCK
+#define MON_HOUSEKEEPING_BLOCK (gridDim.x - 1u)
+#endif
 __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLevels sl, const half2_t* __restrict__ de_soa, const float4_t* __restrict__ x4,
                                                        uint32_t B, uint32_t n_bins, half_t* __restrict__ gpart, uint32_t n_entries, const DevState* __restrict__ st, DevState* st_rw, DevState* st_next, PartialsArgs pa, float* __restrict__ timing, uint32_t ablate /* timing experiments: 1 no tile write-out, 2 no dW row sums, 4 no sample walk */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t iter = st->iter;
-    if (blockIdx.x == 0 && threadIdx.x < 64u) {
+    if (blockIdx.x == MON_HOUSEKEEPING_BLOCK && threadIdx.x < 64u) {      // (the last workgroup: the first ones hold the coarse dense levels, the kernel's critical path)
         // slot-counter housekeeping (also for a skipped batch): clear the counters k_fused_train of the NEXT iteration counts in -- they live in the other
         // DevState, which nobody reads during this iteration -- and note how many samples carried a gradient in this one (k_optimizer hands it to the next
         // iteration as n_scatter_last; the large-table path decides on it)
