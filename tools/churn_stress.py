@@ -18,6 +18,7 @@ def main():
     pkg = ge.load_package(); ss = ge.load_tools()
     sc = ss.make_scene(n_views=16, H=240, W=320, f=260.0, seed=2)
     ds, first = ge.make_problem(pkg, sc, dict(sample_seed=1)); first.close()
+    free0, _ = pkg.device_mem_info(0)
     stop = time.perf_counter() + seconds; stats = [0] * T; steps = [0] * T; errs = []
 
     def worker(k):
@@ -45,7 +46,10 @@ def main():
             errs.append((k, repr(e)))
     th = [threading.Thread(target=worker, args=(k,)) for k in range(T)]
     t0 = time.perf_counter(); [t.start() for t in th]; [t.join() for t in th]; dt = time.perf_counter() - t0
-    print("churn: %d threads, %.1f s: %d objects created and destroyed, %d training steps (%.2f G ray-samples/s aggregate), errors: %s" % (T, dt, sum(stats), sum(steps), sum(steps) * 131072 / dt / 1e9, errs))
+    free1, _ = pkg.device_mem_info(0)
+    if free0 - free1 > (256 << 20):                              # every object gone: device memory is back (to within what the runtime's pools keep)
+        errs.append(("leak", "%d MB of device memory not returned" % ((free0 - free1) >> 20)))
+    print("churn: %d threads, %.1f s: %d objects created and destroyed, %d training steps (%.2f G ray-samples/s aggregate), device memory %+d MB, errors: %s" % (T, dt, sum(stats), sum(steps), sum(steps) * 131072 / dt / 1e9, (free1 - free0) >> 20, errs))
     ds.close()
     sys.exit(1 if errs else 0)
 
