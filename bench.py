@@ -95,6 +95,8 @@ def main():
         import torch.distributed as dist
         # "nccl" IS RCCL on ROCm (xGMI); gloo when ranks share a device (1-GPU box) or when asked for
         coll_backend = os.environ.get("MON_BENCH_DIST_BACKEND", "nccl")
+        if coll_backend == "nccl" and world > ndev and "MON_BENCH_DIST_BACKEND" not in os.environ:
+            coll_backend = "gloo"                      # more ranks than devices (a launcher on a small box): RCCL refuses two ranks on one device
         if coll_backend == "nccl":
             torch.cuda.set_device(device); coll_dev = torch.device("cuda", device)
             dist.init_process_group(backend="nccl", device_id=coll_dev)
