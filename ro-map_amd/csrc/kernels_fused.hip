@@ -57,7 +57,7 @@ __device__ __forceinline__ int unit_of_slot(int s, int h, int j) { return 32 * (
 #endif
 constexpr int kEncodeBatch = MON_ENCODE_BATCH;
 #ifndef MON_V_STAGGER
-#define MON_V_STAGGER 0x2000c      // odd waves of every workgroup start 12 x 1024 cycles late (measured: 51.0 -> 47.7 us dense, 45.8 -> 45.0 us late; modes 0, 1, 3 and delays of 4..24 units were slower)
+#define MON_V_STAGGER 0x20010      // odd waves of every workgroup start 16 x 1024 cycles late (measured: 51.0 -> 47.7 us dense, 45.8 -> 45.0 us late with 12; on the final kernels 12 / 14 / 16 / 18 / 20 units: 46.8 / 46.5 / 46.4 / 46.7 / 47.8 us dense, 43.5 / 43.6 / 43.2 / 43.3 / 44.9 late; modes 0, 1, 3 were slower)
 #endif
 constexpr uint32_t kDefaultStagger = MON_V_STAGGER;
 
