@@ -482,6 +482,7 @@ int model_add_boxes(Model& m, const mon_frame_bbox* boxes, size_t n) {
     HIPCHECK(hipMemcpy(m.d_boxes + m.n_boxes, boxes, sizeof(mon_frame_bbox) * n, hipMemcpyHostToDevice));   // nerf_model.cu:1625
     m.n_boxes += (uint32_t)n;
     HIPCHECK(hipMemcpy(&m.d_state->n_boxes, &m.n_boxes, 4, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(&m.d_state_next->n_boxes, &m.n_boxes, 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipStreamSynchronize(nullptr));                 // (the copies above ran on the null stream, which the object's non-blocking streams do not wait for: a grown box list's zero-fill and device-to-device copy are done before the next batch reads it)
     m.next_ready = false;                                   // candidates pre-generated for the next iteration used the old box list
     return MON_OK;
 }
