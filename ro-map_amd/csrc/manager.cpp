@@ -129,31 +129,45 @@ int offline_read_dataset(OfflineManager& m) {                           // nerf_
     }
     const size_t n = m.poses.size() / 16;
     if (n == 0 || n != m.names.size()) { set_error("Load dataset error...No images (%zu poses, %zu image names)", n, m.names.size()); return MON_ERR_IO; }
-    const size_t px = (size_t)m.H * m.W; std::string err;
-    std::vector<uint8_t> rgb(px * 3), inst(px); std::vector<float> depth(m.use_depth ? px : 0);
+    const size_t px = (size_t)m.H * m.W;
     for (int g = 0; g < m.n_dev; ++g) { Dataset* d = nullptr; int rc = dataset_create(g, m.H, m.W, m.fx, m.fy, m.cx, m.cy, (uint32_t)n, m.use_depth, &d); if (rc) return rc; m.ds.push_back(d); }
-    for (size_t i = 0; i < n; ++i) {
-        PngImage c, s, z;
-        if (!png_read(m.dataset + "/rgb/" + m.names[i], c, err) || !png_read(m.dataset + "/instance/" + m.names[i], s, err)) { set_error("%s", err.c_str()); return MON_ERR_IO; }
-        if (c.width != m.W || c.height != m.H || s.width != m.W || s.height != m.H || s.bit_depth != 8) { set_error("image %s does not match config.yaml", m.names[i].c_str()); return MON_ERR_IO; }
+    // The PNGs of a batch of frames are decoded by a few host threads at once (inflate + unfilter: ~10 ms per 640x480 frame, the whole read of a sequence otherwise),
+    // then handed to the device(s) in frame order.  The reference reads them one by one with cv::imread (nerf_data.cu:151-221).
+    struct Decoded { std::vector<uint8_t> rgb, inst; std::vector<float> depth; std::string err; };
+    const auto decode = [&](size_t i, Decoded& o) {
+        PngImage c, s, z; o.err.clear(); o.rgb.resize(px * 3); o.inst.resize(px); if (m.use_depth) o.depth.resize(px);
+        if (!png_read(m.dataset + "/rgb/" + m.names[i], c, o.err) || !png_read(m.dataset + "/instance/" + m.names[i], s, o.err)) return;
+        if (c.width != m.W || c.height != m.H || s.width != m.W || s.height != m.H || s.bit_depth != 8) { o.err = "image " + m.names[i] + " does not match config.yaml"; return; }
         {   // cv::imread(IMREAD_COLOR), nerf_data.cu:158: gray is replicated to three channels, alpha dropped, 16-bit samples reduced to their high byte
             const size_t sb = c.bit_depth == 16 ? 2 : 1, pb = (size_t)c.channels * sb; const bool gray = c.channels < 3;
             for (size_t p = 0; p < px; ++p) {
                 const uint8_t* q = &c.data[p * pb];
-                rgb[3 * p] = q[0]; rgb[3 * p + 1] = gray ? q[0] : q[sb]; rgb[3 * p + 2] = gray ? q[0] : q[2 * sb];
+                o.rgb[3 * p] = q[0]; o.rgb[3 * p + 1] = gray ? q[0] : q[sb]; o.rgb[3 * p + 2] = gray ? q[0] : q[2 * sb];
             }
             // instance: IMREAD_UNCHANGED, first byte of every pixel (nerf_data.cu:196-207 reads the buffer as one u8 per pixel); OpenCV orders colour
             // pixels B,G,R, so for a colour / palette mask that byte is the blue sample
             const int ic = s.channels >= 3 ? 2 : 0;
-            for (size_t p = 0; p < px; ++p) inst[p] = s.data[p * s.channels + ic];
+            for (size_t p = 0; p < px; ++p) o.inst[p] = s.data[p * s.channels + ic];
         }
         if (m.use_depth) {
-            if (!png_read(m.dataset + "/depth/" + m.names[i], z, err)) { set_error("%s", err.c_str()); return MON_ERR_IO; }
-            if (z.width != m.W || z.height != m.H || z.bit_depth != 16) { set_error("depth image %s must be 16-bit %dx%d", m.names[i].c_str(), m.W, m.H); return MON_ERR_IO; }
-            for (size_t p = 0; p < px; ++p) depth[p] = (float)((z.data[2 * p * z.channels] << 8) | z.data[2 * p * z.channels + 1]) * m.depth_scale;      // convertTo(CV_32FC1, mfDepthScale), nerf_data.cu:187
+            if (!png_read(m.dataset + "/depth/" + m.names[i], z, o.err)) return;
+            if (z.width != m.W || z.height != m.H || z.bit_depth != 16) { o.err = "depth image " + m.names[i] + " must be 16-bit " + std::to_string(m.W) + "x" + std::to_string(m.H); return; }
+            for (size_t p = 0; p < px; ++p) o.depth[p] = (float)((z.data[2 * p * z.channels] << 8) | z.data[2 * p * z.channels + 1]) * m.depth_scale;      // convertTo(CV_32FC1, mfDepthScale), nerf_data.cu:187
         }
-        for (int g = 0; g < m.n_dev; ++g) {                             // PNG stores RGB; is_bgr = 0 (cv::imread would hand BGR)
-            int rc = dataset_add_frame(m.ds[g], (uint32_t)i, rgb.data(), 3, 0, inst.data(), m.use_depth ? depth.data() : nullptr, &m.poses[16 * i]); if (rc) return rc;
+    };
+    unsigned nt = std::thread::hardware_concurrency(); nt = nt < 1u ? 1u : (nt > 8u ? 8u : nt);
+    std::vector<Decoded> batch(nt);
+    for (size_t base = 0; base < n; base += nt) {
+        const size_t cnt = std::min<size_t>(nt, n - base);
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < cnt; ++t) th.emplace_back([&, t] { decode(base + t, batch[t]); });
+        decode(base, batch[0]);
+        for (std::thread& t : th) t.join();
+        for (size_t t = 0; t < cnt; ++t) {
+            if (!batch[t].err.empty()) { set_error("%s", batch[t].err.c_str()); return MON_ERR_IO; }
+            for (int g = 0; g < m.n_dev; ++g) {                         // PNG stores RGB; is_bgr = 0 (cv::imread would hand BGR)
+                int rc = dataset_add_frame(m.ds[g], (uint32_t)(base + t), batch[t].rgb.data(), 3, 0, batch[t].inst.data(), m.use_depth ? batch[t].depth.data() : nullptr, &m.poses[16 * (base + t)]); if (rc) return rc;
+            }
         }
     }
     return MON_OK;

@@ -104,7 +104,7 @@ static int infer_shared_get(int device, size_t pixels_hint, InferShared** out) {
 // object's iterations in sequence; a change of lane is ordered by an event).  The device sees two streams of whole training steps whatever the number of objects.
 // Lanes order work for speed only: no result depends on them.
 constexpr int kMaxLanes = 4; constexpr uint32_t kLaneRing = 256;
-// lane events order device work only: without the system-scope fence of a default event (an L2 write-back per chunk; the host reads nothing these events guard)
+// a lane's chunk events are only QUERIED (how much work is in flight): without the system-scope fence of a default event (an L2 write-back per chunk)
 constexpr unsigned kLaneEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
 struct TrainLanes {
     std::mutex mu; std::atomic<int> objects{ 0 };      // live objects of the device
@@ -125,9 +125,15 @@ static TrainLanes* lanes_get(int device) {
     }
     return t;
 }
+#ifdef MON_VARIANT_STALE_MARK          // (variant build for the regression test: the bug it guards against)
+#define MON_INVALIDATE_MARK(m) ((void)0)
+#else
+#define MON_INVALIDATE_MARK(m) ((m).tail_marked = false)
+#endif
 // marks the end of what the object has enqueued so far on its current stream (called where an entry point returns with work still in flight: the end of a train call)
 static void mark_tail(Model& m) {
-    if (!m.switch_event && hipEventCreateWithFlags(&m.switch_event, kLaneEventFlags) != hipSuccess) { m.switch_event = nullptr; m.tail_marked = false; return; }
+    // (a DEFAULT event, with its release fence: this one orders the object's kernels across two hardware queues)
+    if (!m.switch_event && hipEventCreateWithFlags(&m.switch_event, hipEventDisableTiming) != hipSuccess) { m.switch_event = nullptr; m.tail_marked = false; return; }
     m.tail_marked = hipEventRecord(m.switch_event, m.train_stream) == hipSuccess;
 }
 // moves the object's work to stream `to`: everything it has enqueued so far is ordered before whatever follows on the new stream.  The wait is for the object's OWN last
@@ -135,7 +141,7 @@ static void mark_tail(Model& m) {
 static void switch_stream(Model& m, hipStream_t to);
 // Everything that is not a training chunk (renders on the train stream, density grids, meshes, parameter access, box uploads) runs on the object's OWN stream:
 // on a lane it would queue -- and its synchronisation would wait -- behind every chunk other objects have enqueued there.
-void model_leave_lane(Model& m) { switch_stream(m, m.own_stream); }
+void model_leave_lane(Model& m) { switch_stream(m, m.own_stream); MON_INVALIDATE_MARK(m); }      // (work follows: an earlier mark no longer stands for the object's last work)
 static void switch_stream(Model& m, hipStream_t to) {
     if (m.train_stream == to) return;
     if (!m.tail_marked) mark_tail(m);
@@ -149,7 +155,7 @@ struct LaneChunk {
     Model& m; TrainLanes* tl = nullptr; std::unique_lock<std::mutex> lock; int l = -1;
     explicit LaneChunk(Model& mm, bool enabled) : m(mm) {
         const int n = options().train_lanes < kMaxLanes ? options().train_lanes : kMaxLanes;
-        if (!enabled || n <= 0 || !m.lanes || m.lanes->objects.load() <= n) { switch_stream(m, m.own_stream); return; }      // (up to `n` objects: their own streams ARE the lanes)
+        if (!enabled || n <= 0 || !m.lanes || m.lanes->objects.load() <= n) { switch_stream(m, m.own_stream); MON_INVALIDATE_MARK(m); return; }      // (up to `n` objects: their own streams ARE the lanes)
         tl = m.lanes;
         {   std::lock_guard<std::mutex> pick(tl->mu);
             if (m.lane >= 0 && m.lane < n && m.lane_event && m.train_stream == tl->lane[m.lane].stream && hipEventQuery(m.lane_event) == hipErrorNotReady) l = m.lane;      // previous chunk still in flight: same lane
@@ -172,8 +178,9 @@ struct LaneChunk {
         }
         TrainLanes::Lane& L = tl->lane[l];
         lock = std::unique_lock<std::mutex>(L.mu);
-        if (!L.stream && hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) { L.stream = nullptr; L.pending.fetch_sub(1); tl = nullptr; lock.unlock(); switch_stream(m, m.own_stream); return; }
+        if (!L.stream && hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) { L.stream = nullptr; L.pending.fetch_sub(1); tl = nullptr; lock.unlock(); switch_stream(m, m.own_stream); MON_INVALIDATE_MARK(m); return; }
         switch_stream(m, L.stream);
+        MON_INVALIDATE_MARK(m);                                         // work follows on this stream: the mark of an earlier call no longer stands for the object's last work
     }
     ~LaneChunk() {
         if (!tl) return;

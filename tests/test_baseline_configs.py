@@ -114,11 +114,25 @@ def test_concurrent_objects_train_exactly_like_lone_ones(pkg, ss):
         pkg.set_option("train_lanes", 2)
     th = [threading.Thread(target=o.train, args=(30,)) for o in objs]   # ... and on again
     [t.start() for t in th]; [t.join() for t in th]
+    # ... and flipped every millisecond DURING long train calls: an object changes streams between two chunks of one call, after earlier calls ended on the
+    # same stream -- every chunk must still be ordered behind the object's previous one (a stale end-of-call mark once let two chunks run side by side)
+    flip = threading.Event()
+
+    def flipper():                                                # (the first chunks of the calls go where the previous calls ended -- no switch -- before the first flip)
+        v = 0; time.sleep(0.003)
+        while not flip.is_set():
+            pkg.set_option("train_lanes", v); v = 2 - v; time.sleep(0.001)
+    th = [threading.Thread(target=o.train, args=(300,)) for o in objs]
+    ft = threading.Thread(target=flipper)
+    try:
+        [t.start() for t in th]; ft.start(); [t.join() for t in th]
+    finally:
+        flip.set(); ft.join(); pkg.set_option("train_lanes", 2)
     together = [zlib.crc32(o.get_params(0).tobytes()) for o in objs]
     for o in objs:
         o.close()
     for k in range(4):
-        _, o = ge.make_problem(pkg, sc, dict(sample_seed=700 + k), dataset=ds); o.train(200)
+        _, o = ge.make_problem(pkg, sc, dict(sample_seed=700 + k), dataset=ds); o.train(500)
         assert zlib.crc32(o.get_params(0).tobytes()) == together[k], "object %d" % k
         o.close()
     assert len(set(together)) == 4
