@@ -45,7 +45,19 @@ def main():
         except Exception as e:                                   # pragma: no cover
             errs.append((k, repr(e)))
     th = [threading.Thread(target=worker, args=(k,)) for k in range(T)]
-    t0 = time.perf_counter(); [t.start() for t in th]; [t.join() for t in th]; dt = time.perf_counter() - t0
+    flip = threading.Event()
+
+    def flipper():                                              # MON_CHURN_FLIP=1: the lanes switched off / to 2 / to 3 every millisecond under everything else
+        i = 0
+        while not flip.is_set():
+            pkg.set_option("train_lanes", (0, 2, 3)[i % 3]); i += 1; time.sleep(0.001)
+    ft = threading.Thread(target=flipper) if os.environ.get("MON_CHURN_FLIP") else None
+    t0 = time.perf_counter(); [t.start() for t in th]
+    if ft:
+        ft.start()
+    [t.join() for t in th]; dt = time.perf_counter() - t0
+    if ft:
+        flip.set(); ft.join(); pkg.set_option("train_lanes", 2)
     free1, _ = pkg.device_mem_info(0)
     if free0 - free1 > (256 << 20):                              # every object gone: device memory is back (to within what the runtime's pools keep)
         errs.append(("leak", "%d MB of device memory not returned" % ((free0 - free1) >> 20)))
