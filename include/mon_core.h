@@ -78,7 +78,7 @@ typedef struct mon_object_info {
 } mon_object_info;
 
 /* Kernel classes timed with HIP events on the object's train stream when profiling is on. */
-enum { MON_K_BATCH = 0, MON_K_FWDBWD = 1, MON_K_OPTIM = 2, MON_K_RENDER = 3, MON_K_SCATTER = 4, MON_K_REDUCE = 5, MON_K_COUNT = 8 };
+enum { MON_K_BATCH = 0, MON_K_FWDBWD = 1, MON_K_OPTIM = 2, MON_K_RENDER = 3, MON_K_SCATTER = 4, MON_K_REDUCE = 5, MON_K_ENCODE = 6 /* k_encode_tiles */, MON_K_POINTS = 7 /* k_sample_points */, MON_K_COUNT = 8 };
 /* FWDBWD = k_fused_train alone (fused backend) or the unfused forward/backward kernel group; SCATTER = k_grid_scatter; REDUCE = k_reduce_partials. */
 typedef struct mon_profile { double ms[MON_K_COUNT]; uint64_t launches[MON_K_COUNT]; } mon_profile;
 

@@ -1,0 +1,273 @@
+// kernels_encode.hip -- hash-grid encode of a whole training batch from LDS-resident level tiles (gfx950).
+//
+// Why: inside k_fused_train the forward gathers are 16.8 M 4-byte reads of an L2-resident table per base.json step, and the chip serves
+// ~190-210 G distinct 64-byte lines/s on that path whatever the occupancy or lane arrangement: 39.8 us of the kernel's 44.6
+// (profiles/r02_fused_floor.md).  Random 4-byte LDS reads run at ~3.5 lanes/clk/CU = ~1.9 T reads/s chip-wide
+// (profiles/r02_gatherbench.md, mode 17) -- five times the L2 request rate.  So the encode is turned inside out, the way k_grid_scatter
+// already turns the backward: a workgroup owns one LEVEL (its table slice copied into the CU's 160 KB LDS with coalesced 16-byte loads) and walks
+// a sixteenth of the batch's samples; the encoded features go to HBM once (4 B per sample and level, 8 MB per step) and k_fused_train<PRE>
+// reads them back coalesced instead of gathering.
+//
+//   k_sample_points : ray compaction (fill_rollover_rays, nerf_model.cu:280-294) + GenerateInputPoints (:536-566) -> warped positions x[B] (float4)
+//   k_encode_tiles  : tcnn kernel_grid forward (call site nerf_model.cu:1557) per (level, sample partition) workgroup -> E[L][B] half2
+//
+// Numerics are those of encode_interp in kernels_fused.hip, bit for bit: the 8-corner fp32 fmaf chain in corner order k = x + 2y + 4z, one
+// rounding to fp16 per feature.  A level of up to 40 960 entries sits in LDS whole; a larger one (up to 65 536 entries) is walked in TWO passes
+// over its even and its odd entries: the two x-corners of a (y, z) pair always differ in the lowest index bit (kernels_fused.hip scatter_item),
+// so each pass reads exactly one corner of each of the four pairs -- no range test, no divergence -- and the thread keeps the four values of
+// the first pass in registers until the second one completes the chain in its original order.
+#include "device_common.h"
+#include "model.h"
+
+namespace mon {
+
+constexpr uint32_t kEncLdsBytes = 163840;                 // the CU's whole LDS
+static_assert(kEncWholeMax == kEncLdsBytes / 4u, "model.h: a whole-level tile is the CU's LDS");
+constexpr uint32_t kEncParityMax = 65536u;                // entries of a level walked as two parity tiles (cached indices are 16 bits)
+constexpr uint32_t kEncWgPerLevel = 16;                   // sample partitions per level and chunk
+constexpr uint32_t kEncSpt = 8;                           // samples per thread
+constexpr uint32_t kEncThreads = 1024;
+
+bool encode_tiles_supported(const LevelTable& lt, const NetDims& nd) {
+    if (nd.L < 1 || nd.L > kMaxLevels) return false;
+    for (int l = 0; l < nd.L; ++l) { const uint32_t size = lt.offset[l + 1] - lt.offset[l]; if (size > kEncParityMax || (size & 7u)) return false; }
+    return (nd.n_mlp & 7u) == 0u;         // the table starts 16-byte aligned behind the MLP matrices
+}
+
+// ------------------------------------------------------------------ sample positions
+// One thread per sample.  Training ray j is valid candidate number (j mod n_valid) in candidate order; every block finds its rays' candidates
+// from the candidates' ballot words (<= 256 words, prefix in LDS).  The position arithmetic is ray_sample's of k_fused_train, which recomputes
+// t (it needs the distances for the composite) and stores the same x for the gradient scatter.
+__global__ void __launch_bounds__(256) k_sample_points(BatchPtrs b, ObjectConst oc, DevState* __restrict__ st, float4_t* __restrict__ x_all) {
+    __shared__ unsigned long long words[256];
+    __shared__ uint32_t prefix[257];
+    const uint32_t R = oc.R, nwords = R >> 6, iter = st->iter;
+    if (threadIdx.x < 64u) {
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < nwords; base += 64u) {
+            const uint32_t w = base + threadIdx.x;
+            const unsigned long long wd = (w < nwords) ? b.mask[w] : 0ull;
+            uint32_t c = (uint32_t)__popcll(wd), inc = c;
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, sh, 64); if ((int)threadIdx.x >= sh) inc += o; }
+            if (w < nwords) { words[w] = wd; prefix[w] = carry + inc - c; }
+            carry += (uint32_t)__shfl((int)inc, 63, 64);
+        }
+        if (threadIdx.x == 0u) prefix[nwords] = carry;
+    }
+    __syncthreads();
+    const uint32_t nvalid = prefix[nwords];
+    if (blockIdx.x == 0u && threadIdx.x == 0u) st->n_valid = nvalid;
+    if (nvalid == 0u) return;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x, ray = s >> 5, n = s & 31u;
+    if (ray >= R) return;
+    const uint32_t kth = ray % nvalid;
+    uint32_t lo = 0, hi = nwords - 1u;
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if (prefix[mid] <= kth) lo = mid; else hi = mid - 1u; }
+    unsigned long long wd = words[lo]; uint32_t kk = kth - prefix[lo], pos = 0;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t c = (uint32_t)__popcll(wd & ((1ull << sh) - 1ull)); if (kk >= c) { kk -= c; wd >>= sh; pos += (uint32_t)sh; } }
+    const uint32_t cand = (lo << 6) + pos;
+    const float t0 = b.cand_t0[cand], t1 = b.cand_t1[cand];
+    const float dtr = (t1 - t0) / 32.0f;
+    const float t = fmaf(dtr, (float)n + rand01(oc.sample_seed, kStreamDt, iter, ray * 32u + n), t0);
+    float x[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { const float p = fmaf(t, b.cand_d[3u * cand + d], b.cand_o[3u * cand + d]); x[d] = (p - oc.aabb.mn[d]) / (oc.aabb.mx[d] - oc.aabb.mn[d]); }
+    x_all[s] = float4_t{ x[0], x[1], x[2], t };
+}
+
+// ------------------------------------------------------------------ level-tile encode
+struct EncodeArgs {
+    LevelFast lt; int L; uint32_t n_mlp;
+    const uint16_t* half_tiles;    // the fp16 grid in tile order (ParamPtrs::half_tiles)
+    const float4_t* x_all;         // [B] warped positions
+    half2_t* e_soa;                // [L][B] encoded features
+    uint32_t B, spw;               // samples of the batch, samples per workgroup (<= kEncThreads * kEncSpt)
+    uint32_t ablate;               // timing experiments (option encode_ablate): 1 no sample walk, 2 no tile loads
+    const DevState* st;
+};
+
+// x-corner-0 and x-corner-1 entry index of the four (y, z) pairs (j = y + 2z) and the position inside the cell; the arithmetic of gather_level / encode_interp.
+// Hashed levels hold 2^T <= 65 536 entries: only index bits below the table size matter, so the products come from the full-rate 24-bit multiplier
+// (v_mul_lo_u32 runs at a quarter of it), and the two x-corners differ by the xor with dxm = (x ^ (x + 1)) & mask.
+typedef float float2_t __attribute__((ext_vector_type(2)));
+template <bool HASHED, bool POW2>
+__device__ __forceinline__ void enc_indices(const float4_t& xv, float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask, uint32_t (&i0)[4], uint32_t (&i1)[4], float (&pos)[3]) {
+    uint32_t pg[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, xv[d], 0.5f), fl = floorf(q); pg[d] = (uint32_t)(int32_t)fl; pos[d] = q - fl; }
+    const uint32_t y0 = (HASHED && POW2) ? __umul24(pg[1], my & 0xffffffu) : pg[1] * my, z0 = (HASHED && POW2) ? __umul24(pg[2], mz & 0xffffffu) : pg[2] * mz;
+    const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
+    const uint32_t dxm = (pg[0] ^ (pg[0] + 1u)) & mask;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (HASHED) {
+            const uint32_t t = ay[j & 1] ^ az[j >> 1];
+            i0[j] = (pg[0] ^ t) & mask;
+            if (POW2) i1[j] = i0[j] ^ dxm;
+            else { i1[j] = ((pg[0] + 1u) ^ t) & mask; i0[j] -= (i0[j] >= size) ? size : 0u; i0[j] = min(i0[j], size - 1u); i1[j] -= (i1[j] >= size) ? size : 0u; i1[j] = min(i1[j], size - 1u); }
+        } else {
+            const uint32_t t = ay[j & 1] + az[j >> 1];
+            i0[j] = (pg[0] + t) & mask; i1[j] = (pg[0] + 1u + t) & mask;
+            i0[j] -= (i0[j] >= size) ? size : 0u; i0[j] = min(i0[j], size - 1u); i1[j] -= (i1[j] >= size) ? size : 0u; i1[j] = min(i1[j], size - 1u);
+        }
+    }
+}
+// the chain of encode_interp: corners in order k = x + 2y + 4z, c0[j] / c1[j] = x-corner 0 / 1 of pair j, weight ((wx * wy) * wz); the two x-corners of a pair and
+// the two features of a corner are worked on as pairs (v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operations, two per instruction)
+__device__ __forceinline__ half2_t enc_chain(const uint32_t (&c0)[4], const uint32_t (&c1)[4], const float (&pos)[3]) {
+    const float2_t wx = { 1.f - pos[0], pos[0] };
+    const float wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
+    const float2_t wxy[2] = { wx * wy[0], wx * wy[1] };
+    float2_t a = { 0.f, 0.f };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float2_t w = wxy[j & 1] * wz[j >> 1];
+        const half2_t v0 = __builtin_bit_cast(half2_t, c0[j]), v1 = __builtin_bit_cast(half2_t, c1[j]);
+        a = __builtin_elementwise_fma(float2_t{ w.x, w.x }, float2_t{ (float)v0.x, (float)v0.y }, a);
+        a = __builtin_elementwise_fma(float2_t{ w.y, w.y }, float2_t{ (float)v1.x, (float)v1.y }, a);
+    }
+    return half2_t{ (half_t)a.x, (half_t)a.y };
+}
+
+// a thread's kEncSpt positions, requested together (one load per loop trip put a global round trip in front of every sample)
+__device__ __forceinline__ void load_positions(float4_t (&xs)[kEncSpt], const float4_t* __restrict__ x_all, uint32_t s0, uint32_t s_end) {
+#pragma unroll
+    for (uint32_t k = 0; k < kEncSpt; ++k) { const uint32_t s = s0 + k * kEncThreads; xs[k] = x_all[min(s, s_end - 1u)]; }
+}
+
+template <bool HASHED, bool POW2>
+__device__ __forceinline__ void encode_whole(const uint32_t* tile, const EncodeArgs& a, uint32_t s0, uint32_t s_end, half2_t* __restrict__ out, float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask) {
+    if (s0 >= s_end) return;
+    float4_t xs[kEncSpt]; load_positions(xs, a.x_all, s0, s_end);
+#pragma unroll
+    for (uint32_t k = 0; k < kEncSpt; ++k) {
+        const uint32_t s = s0 + k * kEncThreads;
+        uint32_t i0[4], i1[4], c0[4], c1[4]; float pos[3];
+        enc_indices<HASHED, POW2>(xs[k], scale, size, my, mz, mask, i0, i1, pos);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c0[j] = tile[i0[j]]; c1[j] = tile[i1[j]]; }
+        const half2_t e = enc_chain(c0, c1, pos);
+        if (s < s_end) out[s] = e;
+    }
+}
+
+// Tile copy: global -> LDS without a register round trip (global_load_lds_dwordx4: every lane names its 16 source bytes, the wave's 1 KB lands at the
+// wave-uniform LDS base in M0 + 16 * lane).  The source is the TILE IMAGE of the grid (ParamPtrs::half_tiles, tile_slot in model.h), in which a tile is one
+// contiguous run; all of a thread's loads are in flight at once (a copy through registers with one load per loop trip left a workgroup with 16 KB
+// outstanding, and the copy of a 256 KB level took longer than the walk it feeds).
+__device__ __forceinline__ void tile_copy(uint32_t* tile, const uint4* __restrict__ src, uint32_t n16) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void gbl_void;
+    unsigned char* base = reinterpret_cast<unsigned char*>(tile);
+    const uint32_t wave0 = threadIdx.x & ~63u;
+    for (uint32_t i0 = 0; i0 < n16; i0 += kEncThreads) {
+        const uint32_t i = i0 + threadIdx.x;
+        if (i < n16)                                                   // (lanes past the tile's end stay out: a lane's LDS address is its position in the wave, active or not)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src + i), (lds_void*)(base + (size_t)(i0 + wave0) * 16u), 16, 0, 0);
+    }
+}
+
+template <bool HASHED, bool POW2>
+__device__ __forceinline__ void encode_parity(uint32_t* tile, const uint4* __restrict__ src /* the level in the tile image: evens, then odds */, const EncodeArgs& a, uint32_t s0, uint32_t s_end, half2_t* __restrict__ out, float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask) {
+    // pass 0: the even entries.  Per pair the even one of (i0, i1) is read now; the odd one is kept for pass 1 as 16 bits whose (always set) lowest bit is
+    // replaced by "the odd one is x-corner 0"
+    uint32_t veven[kEncSpt][4], cache[kEncSpt][2]; float pos[kEncSpt][3];      // (the position inside the cell is kept too: 24 registers against a second load + 9 instructions per sample)
+    const bool walk = !(a.ablate & 1u) && s0 < s_end;
+    float4_t xs[kEncSpt];
+    if (walk) load_positions(xs, a.x_all, s0, s_end);          // requested ahead of the tile: they land while it is copied
+    if (!(a.ablate & 2u)) tile_copy(tile, src, size / 8u);
+    __builtin_amdgcn_s_waitcnt(0x0f70);                                   // vmcnt(0): the LDS writes of the copy are counted there
+    __syncthreads();
+    if (walk) {
+#pragma unroll
+        for (uint32_t k = 0; k < kEncSpt; ++k) {
+            uint32_t i0[4], i1[4], c[4];
+            enc_indices<HASHED, POW2>(xs[k], scale, size, my, mz, mask, i0, i1, pos[k]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool odd0 = (i0[j] & 1u) != 0u;
+                const uint32_t ev = odd0 ? i1[j] : i0[j], od = odd0 ? i0[j] : i1[j];
+                veven[k][j] = tile[ev >> 1];
+                c[j] = (od & 0xfffeu) | (odd0 ? 1u : 0u);
+            }
+            cache[k][0] = c[0] | (c[1] << 16); cache[k][1] = c[2] | (c[3] << 16);
+        }
+    }
+    __syncthreads();
+    if (!(a.ablate & 2u)) tile_copy(tile, src + size / 8u, size / 8u);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    if (walk) {
+#pragma unroll
+        for (uint32_t k = 0; k < kEncSpt; ++k) {
+            const uint32_t s = s0 + k * kEncThreads;
+            uint32_t c0[4], c1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t c = (j & 1) ? (cache[k][j >> 1] >> 16) : (cache[k][j >> 1] & 0xffffu);
+                const uint32_t vodd = tile[c >> 1];
+                const bool odd0 = (c & 1u) != 0u;
+                c0[j] = odd0 ? vodd : veven[k][j]; c1[j] = odd0 ? veven[k][j] : vodd;
+            }
+            const half2_t e = enc_chain(c0, c1, pos[k]);
+            if (s < s_end) out[s] = e;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kEncThreads) k_encode_tiles(EncodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (a.st->n_valid == 0u) return;                                   // batch skipped (k_sample_points wrote the count)
+    uint32_t* tile = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t level = blockIdx.x / kEncWgPerLevel, part = blockIdx.x - level * kEncWgPerLevel;
+    const uint32_t w = blockIdx.y * kEncWgPerLevel + part;             // sample partition of the batch
+    const uint32_t s_base = w * a.spw, s_end = min(s_base + a.spw, a.B), s0 = s_base + threadIdx.x;
+    if (s_base >= a.B) return;
+    const uint32_t off = a.lt.offset[level], size = a.lt.size[level], my = a.lt.my[level], mz = a.lt.mz[level], mask = a.lt.mask[level];
+    const bool hashed = a.lt.hashed[level] != 0u, pow2 = mask != 0xffffffffu;
+    const float scale = a.lt.scale[level];
+    const uint4* src = reinterpret_cast<const uint4*>(a.half_tiles + 2u * (size_t)off);
+    half2_t* out = a.e_soa + (size_t)level * a.B;
+    if (size <= kEncWholeMax) {
+        tile_copy(tile, src, size / 4u);
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        if (hashed) { if (pow2) encode_whole<true, true>(tile, a, s0, s_end, out, scale, size, my, mz, mask); else encode_whole<true, false>(tile, a, s0, s_end, out, scale, size, my, mz, mask); }
+        else encode_whole<false, false>(tile, a, s0, s_end, out, scale, size, my, mz, mask);
+    } else {
+        if (hashed) { if (pow2) encode_parity<true, true>(tile, src, a, s0, s_end, out, scale, size, my, mz, mask); else encode_parity<true, false>(tile, src, a, s0, s_end, out, scale, size, my, mz, mask); }
+        else encode_parity<false, false>(tile, src, a, s0, s_end, out, scale, size, my, mz, mask);
+    }
+}
+
+// the tile image from the fp16 working copy (object creation, set_params, backend switch: whenever the weights changed outside k_optimizer, which keeps it current itself)
+__global__ void __launch_bounds__(256) k_build_tiles_image(LevelFast lt, int L, const uint32_t* __restrict__ grid /* half2 per entry */, uint32_t* __restrict__ image) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= lt.offset[L]) return;
+    int lvl = 0;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; ++l) lvl += (l < L && e >= lt.offset[l]) ? 1 : 0;
+    image[tile_slot(lt.offset[lvl], lt.size[lvl], e - lt.offset[lvl])] = grid[e];
+}
+void launch_build_tiles_image(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* params, uint16_t* half_tiles) {
+    const uint32_t n = lf.offset[nd.L];
+    hipLaunchKernelGGL(k_build_tiles_image, dim3((n + 255u) / 256u), dim3(256), 0, s, lf, nd.L, reinterpret_cast<const uint32_t*>(params + nd.n_mlp), reinterpret_cast<uint32_t*>(half_tiles));
+}
+
+void encode_tiles_setup_device() { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsBytes); }
+
+void launch_sample_points(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* x_all) {
+    const uint32_t B = oc.R * 32u;
+    hipLaunchKernelGGL(k_sample_points, dim3((B + 255u) / 256u), dim3(256), 0, s, b, oc, st, reinterpret_cast<float4_t*>(x_all));
+}
+
+void launch_encode_tiles(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* half_tiles, const float* x_all, uint16_t* e_soa, uint32_t B, const DevState* st) {
+    const uint32_t per_chunk = kEncWgPerLevel * kEncThreads * kEncSpt, chunks = (B + per_chunk - 1u) / per_chunk;
+    const uint32_t spw = (B + kEncWgPerLevel * chunks - 1u) / (kEncWgPerLevel * chunks);
+    EncodeArgs a{ lf, nd.L, nd.n_mlp, half_tiles, reinterpret_cast<const float4_t*>(x_all), reinterpret_cast<half2_t*>(e_soa), B, spw, (uint32_t)options().encode_ablate, st };
+    hipLaunchKernelGGL(k_encode_tiles, dim3((uint32_t)nd.L * kEncWgPerLevel, chunks), dim3(kEncThreads), kEncLdsBytes, s, a);
+}
+
+}  // namespace mon

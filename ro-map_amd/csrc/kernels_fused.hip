@@ -111,6 +111,7 @@ struct FusedArgs {
     uint32_t n_bins;            // ray bins of the compacted gradient rows (scatter_bins(R), host-chosen)
     uint32_t stagger;           // bits 0-15: start delay of the second wave group in units of 1024 cycles, bits 16-17: how the groups are formed (see k_fused_train)
     const uint32_t* occ_bits;   // occupancy-grid skipping (mon_config::occupancy_skip, default off): kOccRes^3 bits, 1 = the cell may hold density; nullptr = evaluate every sample
+    const half2_t* e_soa;       // PRE variant: [L][B] encoded features written by k_encode_tiles (kernels_encode.hip); the kernel then issues no gathers at all
 };
 
 // A fragments: the weight matrices pre-permuted to K-slot order (see the header).  They depend only on the weights,
@@ -392,7 +393,7 @@ __device__ __forceinline__ float lane_prev(float v, float fill) { return dpp_f<0
 __device__ __forceinline__ float lane_bcast(float v, int src_lane_uniform) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane_uniform)); }
 
 // ------------------------------------------------------------------ fused training kernel
-template <int EPAD, int W, int NH, bool DUMP, bool ATOMIC_LEVELS, bool OCC = false>
+template <int EPAD, int W, int NH, bool DUMP, bool ATOMIC_LEVELS, bool OCC = false, bool PRE = false /* the encode was done by k_encode_tiles: features are loaded, not gathered */>
 __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_train(FusedArgs a) {
     using S = FusedShape<EPAD, W, NH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -518,6 +519,17 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     };
     const __amdgpu_buffer_rsrc_t rsrc = table_rsrc(table, table_bytes);
     const uint32_t ray_stride = gridDim.x * S::WAVES;
+    // PRE: lane (n, h) reads the features of the levels half-wave h owns, one dword (half2) per level at [level][ray * 32 + n] -- 128 contiguous bytes per
+    // half-wave and level; a ray's eight loads are requested one ray ahead, like its candidate record
+    uint32_t epre[S::LLV];
+    const auto load_encoded = [&](uint32_t r) {
+#pragma unroll
+        for (int il = 0; il < S::LLV; ++il) {
+            const int level = h * LPH + il; epre[il] = 0u;
+            if (il < LPH && level < L) epre[il] = reinterpret_cast<const uint32_t*>(a.e_soa)[(size_t)level * (R * 32u) + r * 32u + (uint32_t)n];
+        }
+    };
+    if constexpr (PRE) { if (ray0 < R) load_encoded(ray0); }
     for (uint32_t ray = ray0; ray < R; ray += ray_stride) {
         const RaySample cur = ray_sample(rec, ray); const uint32_t cand_this = cand;
         const uint32_t kth = ray % nvalid, rgba = cur.rgba, s_idx = ray * 32u + (uint32_t)n;
@@ -525,11 +537,14 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         const float x[3] = { cur.x[0], cur.x[1], cur.x[2] };
         tstamp(tc, 1);
         TileState<EPAD, W, NH> ts;
-        if (cur.any) { GatherWindow<EPAD, W, NH> gw; encode_begin<EPAD, W, NH, OCC>(gw, lregs, rsrc, x, lane, live); encode_finish<EPAD, W, NH, OCC>(ts, gw, lregs, rsrc, x, lane, L, live); }
+        if constexpr (PRE) {
+#pragma unroll
+            for (int il = 0; il < S::LLV; ++il) { const half2_t v = __builtin_bit_cast(half2_t, epre[il]); ts.ef[2 * il] = v.x; ts.ef[2 * il + 1] = v.y; }
+        } else if (cur.any) { GatherWindow<EPAD, W, NH> gw; encode_begin<EPAD, W, NH, OCC>(gw, lregs, rsrc, x, lane, live); encode_finish<EPAD, W, NH, OCC>(ts, gw, lregs, rsrc, x, lane, L, live); }
         tstamp(tc, 2);
         // the next ray's candidate record is requested HERE, behind this ray's last gather: vmcnt retires in order, so a load issued before the gathers would
         // have to land before the first level pair can be consumed; now its latency runs under the MLP, composite and backward pass
-        if (ray + ray_stride < R) { cand = select((ray + ray_stride) % nvalid); rec = load_record(cand); }
+        if (ray + ray_stride < R) { cand = select((ray + ray_stride) % nvalid); rec = load_record(cand); if constexpr (PRE) load_encoded(ray + ray_stride); }
         if (a.ablate & 64u) { float sacc = 0.f; for (int i = 0; i < EPAD / 2; ++i) sacc += (float)ts.ef[i]; loss_acc += sacc; continue; }      // timing experiments: the encode alone
         if (!OCC || __ballot(live) != 0ull) mlp_forward<EPAD, W, NH>(ts, frags, lane);
         else {
@@ -1299,8 +1314,10 @@ static void fused_train_t(hipStream_t s, const FusedArgs& a, uint32_t grid, int 
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
     }
     const bool all_lds = a.lds_level_mask != 0u && (a.lds_level_mask == ((a.nd.L >= 32) ? 0xffffffffu : ((1u << a.nd.L) - 1u)));
+    if (a.e_soa && all_lds && !dump && !a.occ_bits) { hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false, false, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a); return; }
     if (dump) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);          // (the debug dump evaluates every sample)
     else if (a.occ_bits) { if (all_lds) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
                            else hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a); }
@@ -1340,11 +1357,12 @@ static void candidates_frags_t(hipStream_t s, const BatchPtrs& b, const DatasetP
     } while (0)
 
 void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
-                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched, const uint32_t* occ_bits, uint32_t n_bins) {
+                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched, const uint32_t* occ_bits, uint32_t n_bins, const uint16_t* e_soa) {
     const uint32_t ablate = (uint32_t)options().fused_ablate;
     uint32_t stagger = options().fused_stagger < 0 ? kDefaultStagger : (uint32_t)options().fused_stagger;
     if (oc.R < 2u * 4u * fused_train_grid(nd, oc.R)) stagger = 0u;      // a wave with one ray has no second phase to interleave: the delay would only be lost
-    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate, touched ? touched + (nd.n_mlp >> 3) : nullptr, big_switch, n_bins, stagger, occ_bits };
+    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate, touched ? touched + (nd.n_mlp >> 3) : nullptr, big_switch, n_bins, stagger, occ_bits, reinterpret_cast<const half2_t*>(e_soa) };
+    if (e_soa) a.stagger = 0u;          // (the stagger interleaves gather phases with compute phases; a pre-encoded batch has no gather phase)
     const uint32_t grid = fused_train_grid(nd, oc.R);
     MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);
 }

@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
             const uint32_t i0 = c << 3;
             const bool is_matrix = i0 < oc.n_mlp;                     // n_mlp is a multiple of 8: uniform per chunk
             float g[8]; bool any = false;
+            uint32_t lvl_off = 0u, lvl_end = p.sl.entry_offset[1];    // the chunk's level: [lvl_off, lvl_end) in entries
             // DENSE (small tables: practically every entry has a gradient each step): the optimizer state is requested together
             // with the gradients -- one memory round trip instead of two; sparse tables keep the state loads behind the test.
             float4_t w0, w1, a0, a1, b0, b1; uint4 s0, s1;
@@ -154,7 +155,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                 if (p.gpart) {                                       // which level is this chunk in -> how many partial tables it has
                     const uint32_t e0 = (i0 - oc.n_mlp) >> 1; int lvl = 0;
 #pragma unroll
-                    for (int l = 1; l < kMaxLevels; ++l) lvl += (e0 >= p.sl.entry_offset[l]) ? 1 : 0;
+                    for (int l = 1; l < kMaxLevels; ++l) { const bool in = e0 >= p.sl.entry_offset[l]; lvl += in ? 1 : 0; lvl_off = in ? p.sl.entry_offset[l] : lvl_off; lvl_end = in ? p.sl.entry_offset[l + 1] : lvl_end; }
                     n_part = p.sl.P[lvl];
                 }
                 // dense partial tables of k_grid_scatter (fused backend): [partition][feature][parity][entry / 2]; this chunk = entries e0 .. e0 + 3 (e0 a multiple
@@ -224,6 +225,15 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
                 state_store(u4v{ sc[0], sc[1], sc[2], sc[3] }, reinterpret_cast<u4v*>(p.steps + i0)); state_store(u4v{ sc[4], sc[5], sc[6], sc[7] }, reinterpret_cast<u4v*>(p.steps + i0 + 4));
                 *reinterpret_cast<half8_t*>(p.half + i0) = wh;
+                if (p.half_tiles && !is_matrix) {                                     // the same four entries in tile order for k_encode_tiles (tile_slot): whole level = as they are, else evens | odds
+                    const uint32_t e0 = (i0 - oc.n_mlp) >> 1, size = lvl_end - lvl_off, e_rel = e0 - lvl_off;
+                    if (size <= kEncWholeMax) *reinterpret_cast<half8_t*>(p.half_tiles + 2u * (size_t)e0) = wh;
+                    else {
+                        const size_t s0 = lvl_off + (e_rel >> 1);
+                        *reinterpret_cast<half4_t*>(p.half_tiles + 2u * s0) = half4_t{ wh[0], wh[1], wh[4], wh[5] };
+                        *reinterpret_cast<half4_t*>(p.half_tiles + 2u * (s0 + (size >> 1))) = half4_t{ wh[2], wh[3], wh[6], wh[7] };
+                    }
+                }
                 if (is_matrix && nx.frag_image) {                                     // next iteration's A fragments
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { int sl[2]; const int ns = frag_slots(nx.fd, (int)(i0 + j), sl); for (int q = 0; q < ns; ++q) reinterpret_cast<half_t*>(nx.frag_image)[sl[q]] = wh[j]; }

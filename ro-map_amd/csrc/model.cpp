@@ -37,7 +37,7 @@ static long* option_slot(const char* name) {
     static const struct { const char* n; long Options::*f; } tab[] = {
         { "backend", &Options::backend }, { "use_graph", &Options::use_graph }, { "lazy_ema", &Options::lazy_ema }, { "big_switch", &Options::big_switch },
         { "touched_flags", &Options::touched_flags }, { "lds_scatter", &Options::lds_scatter }, { "fold_reduce", &Options::fold_reduce }, { "fold_next", &Options::fold_next },
-        { "fused_grid", &Options::fused_grid }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
+        { "fused_grid", &Options::fused_grid }, { "lds_encode", &Options::lds_encode }, { "encode_ablate", &Options::encode_ablate }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
         { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner }, { "scatter_bins", &Options::scatter_bins }, { "opt_lazy_below", &Options::opt_lazy_below }, { "scatter_ablate", &Options::scatter_ablate } };
     for (const auto& e : tab) if (name && std::strcmp(name, e.n) == 0) return &(g_options.*(e.f));
     return nullptr;
@@ -372,6 +372,11 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         const size_t big_bytes = m.lds_mask ? big_scatter_workspace_bytes(m.lt, m.nd, m.lds_mask, Btrain) : 0;
         const uint32_t big_switch = (uint32_t)options().big_switch;
         if (big_bytes && big_switch) { if ((rc = dev_alloc(m, m.d_big_ws, big_bytes))) return rc; m.big_switch = big_switch; }
+        // level-tile encode (kernels_encode.hip): every level must fit two LDS tiles and go through the LDS scatter (option lds_encode = 0: gathers inside k_fused_train)
+        if (options().lds_encode && !cfg.occupancy_skip && m.lds_mask == ((1u << m.nd.L) - 1u) && encode_tiles_supported(m.lt, m.nd)) {
+            if ((rc = dev_alloc(m, m.d_x_all, 4 * (size_t)Btrain)) || (rc = dev_alloc(m, m.d_e_soa, (size_t)m.nd.L * Btrain * 2)) || (rc = dev_alloc(m, m.d_half_tiles, (size_t)m.n_grid + 64))) return rc;
+            encode_tiles_setup_device();
+        }
         // chunk flags for the lazy optimizer (tables above 8 M parameters with levels outside the LDS plan); MON_TOUCHED_FLAGS=0: scan the gradient table
         const bool flags_on = options().touched_flags != 0;
         if (flags_on && m.lazy_ema && m.lds_mask && m.lds_mask != ((m.nd.L >= 32) ? 0xffffffffu : ((1u << m.nd.L) - 1u)) && (rc = dev_alloc(m, m.d_touched, (m.n_params >> 3) + 16))) return rc;
@@ -518,7 +523,7 @@ static void enqueue_iteration(Model& m, int stages) {
     hipStream_t s = m.train_stream; const uint32_t B = m.oc.R * m.oc.S;
     if (stages & 1) {      // GenerateBatch :1429-1502
         ProfScope ps(m, MON_K_BATCH);
-        if (m.backend == 1) { if (!m.next_ready) launch_candidates_and_frags(s, m.B, m.ds->ptrs(), m.oc, m.d_state, m.P.half, m.nd, m.d_frag_train); }   // otherwise the last k_optimizer already did both
+        if (m.backend == 1) { if (!m.next_ready) { launch_candidates_and_frags(s, m.B, m.ds->ptrs(), m.oc, m.d_state, m.P.half, m.nd, m.d_frag_train); if (m.d_half_tiles) launch_build_tiles_image(s, m.lf, m.nd, m.P.half, m.d_half_tiles); } }   // otherwise the last k_optimizer already did all of it
         else launch_gen_candidates(s, m.B, m.ds->ptrs(), m.oc, m.d_state);
         if (m.backend == 0) {                       // the fused kernel compacts the rays itself
             launch_build_rays(s, m.B, m.oc, m.d_state);
@@ -526,8 +531,8 @@ static void enqueue_iteration(Model& m, int stages) {
         }
     }
     if (stages & 2) {      // Step_No_Compacted :1552-1607
-        ProfScope ps(m, MON_K_FWDBWD);
         if (m.backend == 0) {
+            ProfScope ps(m, MON_K_FWDBWD);
             launch_encode(s, m.lt, m.nd, m.P.half, m.B.pts, m.B.E, B, m.d_state);
             launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);
             launch_composite_grad(s, m.B, m.oc, m.d_state);
@@ -536,7 +541,13 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
         } else {
             if (m.scatter_pending) hipMemsetAsync(m.d_state->n_scatter, 0, sizeof(m.d_state->n_scatter), s);      // stage-wise debugging: a forward/backward without an optimizer step after it
-            launch_fused_train(s, m.lf, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask, m.d_frag_train, m.big_active ? m.big_switch : 0u, m.d_touched, m.occ_refreshed_iter ? m.d_occ : nullptr, m.n_bins);      // (no grid look-ups before the first refresh: every cell is live during the warm-up)
+            const bool pre = m.d_e_soa && !m.fused_dump && options().lds_encode;          // the encode as LDS reads of level tiles; the fused kernel then loads the features
+            if (pre) {
+                { ProfScope pp(m, MON_K_POINTS); launch_sample_points(s, m.B, m.oc, m.d_state, m.d_x_all); }
+                { ProfScope pe(m, MON_K_ENCODE); launch_encode_tiles(s, m.lf, m.nd, m.d_half_tiles, m.d_x_all, m.d_e_soa, B, m.d_state); }
+            }
+            ProfScope ps(m, MON_K_FWDBWD);
+            launch_fused_train(s, m.lf, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask, m.d_frag_train, m.big_active ? m.big_switch : 0u, m.d_touched, m.occ_refreshed_iter ? m.d_occ : nullptr, m.n_bins, pre ? m.d_e_soa : nullptr);      // (no grid look-ups before the first refresh: every cell is live during the warm-up)
             m.scatter_pending = true;
         }
     }
@@ -552,6 +563,7 @@ static void enqueue_iteration(Model& m, int stages) {
         ProfScope ps(m, MON_K_OPTIM);
         ParamPtrs P = m.P;
         if (m.backend == 1 && m.lds_mask) { P.gpart = m.d_gpart; P.part_stride = m.n_grid; P.sl = m.scatter; P.all_levels_dense = (m.lds_mask == ((1u << m.nd.L) - 1u)) ? 1 : 0; }
+        P.half_tiles = (m.backend == 1 && P.gpart && P.all_levels_dense) ? m.d_half_tiles : nullptr;
         const bool lazy = m.lazy_ema && !(P.gpart && P.all_levels_dense);
         P.ema_step = lazy ? m.d_ema_step : nullptr; if (lazy) m.ema_pending = true;
         if (lazy && m.backend == 1 && m.d_touched && (m.lds_mask & (m.lds_mask + 1u)) == 0u) {      // (the LDS-scattered levels are a prefix: sizes grow with the level)              // every writer of ggrid on the fused path sets the chunk flags; the unfused grid backward does not

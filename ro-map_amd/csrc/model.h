@@ -77,7 +77,13 @@ struct ParamPtrs {
     uint8_t* touched; uint32_t first_flag_chunk;                    // lazy EMA + fused backend: one byte per 8-parameter chunk, set by whoever adds into ggrid (k_fused_train's atomics, k_big_accum),
                                                                     // read and cleared by k_optimizer instead of scanning ggrid; chunks below first_flag_chunk (MLP, LDS-scattered levels) are always visited
     int all_levels_dense;                                           // every level is LDS-scattered (no global-atomic table in use)
+    uint16_t* half_tiles;                                           // level-tile encode: the fp16 grid a second time, in LDS-tile order (tile_slot below), kept current by k_optimizer; nullptr = unused
 };
+
+// Tile image of the level-tile encode (kernels_encode.hip): a level that fits the CU's LDS whole keeps its entry order; a larger one (two parity tiles)
+// stores its even entries first, then its odd ones, so that either tile is one contiguous copy.  Entry e of a level (offset off, size entries) sits at:
+constexpr uint32_t kEncWholeMax = 163840u / 4u;                     // entries (half2) of a level that fits in one 160 KB tile
+__host__ __device__ inline uint32_t tile_slot(uint32_t off, uint32_t size, uint32_t e_rel) { return size <= kEncWholeMax ? off + e_rel : off + (e_rel & 1u) * (size >> 1) + (e_rel >> 1); }
 
 struct OptimConst {
     float beta1, beta2, epsilon, l2_reg, ema_decay, loss_scale, decay_base, log2_beta1, log2_beta2, log2_decay;
@@ -103,7 +109,7 @@ enum {
 // Process-wide test and tuning switches (mon_set_option, include/mon_core.h); defaults are the product behaviour.
 struct Options {
     long backend = -1, use_graph = 0, lazy_ema = -1, big_switch = 16384, touched_flags = 1, lds_scatter = 1, fold_reduce = 1, fold_next = 1,
-         fused_grid = 0, opt_blocks = 0, fused_ablate = 0, fused_stagger = -1, offline_outer = 10, offline_inner = 500, scatter_bins = 0, opt_lazy_below = -1, scatter_ablate = 0, train_lanes = 2, lane_chunk = 16, online_slice_min = 2;
+         fused_grid = 0, lds_encode = 1, encode_ablate = 0, opt_blocks = 0, fused_ablate = 0, fused_stagger = -1, offline_outer = 10, offline_inner = 500, scatter_bins = 0, opt_lazy_below = -1, scatter_ablate = 0, train_lanes = 2, lane_chunk = 16, online_slice_min = 2;
 };
 Options& options();
 int option_set(const char* name, long value);
@@ -147,7 +153,13 @@ constexpr uint32_t kMaxFusedGrid = 512;       // workgroups of k_fused_train (= 
 bool fused_supported(const NetDims& nd, uint32_t S, uint32_t R);
 uint32_t fused_train_grid(const NetDims& nd, uint32_t R);
 void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
-                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched, const uint32_t* occ_bits, uint32_t n_bins);
+                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched, const uint32_t* occ_bits, uint32_t n_bins, const uint16_t* e_soa_or_null);
+// level-tile encode (kernels_encode.hip): the forward gathers as LDS reads of a level tile, one workgroup per (level, sample partition)
+bool encode_tiles_supported(const LevelTable& lt, const NetDims& nd);
+void encode_tiles_setup_device();
+void launch_sample_points(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* x_all);
+void launch_encode_tiles(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* half_tiles, const float* x_all, uint16_t* e_soa, uint32_t B, const DevState* st);
+void launch_build_tiles_image(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* params, uint16_t* half_tiles);
 void launch_occupancy_update(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const ObjectConst& oc, uint16_t* frag_image, float raw_threshold, uint32_t* tmp, uint32_t* bits);
 uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl);
 uint32_t scatter_level_mask(const LevelTable& lt, const NetDims& nd);
@@ -188,6 +200,7 @@ struct Model {
     // fused backend
     float* d_dw_partials = nullptr;                               // [512][fused_partial_cols + 64] fp32 dW partial rows of k_fused_train, accumulator layout (frag_layout.h acc_param)
     uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr;       // compacted dL/dE rows [L][B] and positions [B] float4 for the scatter kernels
+    float* d_x_all = nullptr; uint16_t* d_e_soa = nullptr; uint16_t* d_half_tiles = nullptr;        // level-tile encode: positions [B] float4 of every sample, encoded features [L][B] half2 (nullptr: the fused kernel gathers)
     uint16_t* d_gpart = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0;   // k_grid_scatter: partial tables, plan, levels it covers
     uint16_t* d_frag_train = nullptr; uint16_t* d_frag_render = nullptr;           // MFMA A-fragment images (training weights / inference weights)
     uint32_t n_bins = 16;                                         // ray bins of the compacted gradient rows (scatter_bins(R) unless the option caps it)

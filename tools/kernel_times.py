@@ -23,7 +23,7 @@ def window(pkg, sc, extra, kw):
     obj.train(extra + 5); obj.set_profiling(True); obj.profile(reset=True); obj.train(20); p = obj.profile(reset=True)
     obj.close(); ds.close()
     avg = lambda k: round(1e3 * p["ms"][k] / max(1, p["launches"][k]), 2)
-    return dict(step_us=round(1e6 * plain, 2), fused_us=avg(1), scatter_us=avg(4), optim_us=avg(2), crc="%08x" % crc)
+    return dict(step_us=round(1e6 * plain, 2), points_us=avg(7), encode_us=avg(6), fused_us=avg(1), scatter_us=avg(4), optim_us=avg(2), crc="%08x" % crc)
 
 
 def main():
