@@ -34,10 +34,6 @@ def train_bytes_per_sample(L):
     return 52 + 96 * L
 
 
-def train_bytes_per_sample_fused(L):          # k_fused_train's share: everything except the gradient scatter RMW (64*L)
-    return 52 + 32 * L
-
-
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,75 +162,56 @@ def main():
     pobj.close()
     avg = lambda k: prof["ms"][k] / max(1, prof["launches"][k])
     fused = obj_backend(pkg, obj) == 1
-    fb_ms, sc_ms, rd_ms = avg(1), avg(4), avg(5)
-    dom_bytes = (train_bytes_per_sample_fused(L) if fused else train_bytes_per_sample(L)) * B
-    achieved = dom_bytes / (fb_ms * 1e-3) / 1e9
+    n_params = int(obj.info().n_params)
     regime = "dense" if scattered > 0.5 * B else "sparse"          # which committed PMC pass matches this window
     pmc = {}
     base_cfg = not args.log2_hashmap_size            # the committed PMC numbers were collected on the base.json workload only
     try:
         if base_cfg:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            pmc = dict(pj.get(regime, {}), l2_rate=pj.get("l2_line_request_rate_measured_per_s"), source=pj.get(regime, {}).get("source"))
+            pmc = dict(pj.get(regime, {}), source=pj.get(regime, {}).get("source"))
     except Exception:
         pmc = {}
-    traffic = pmc.get("k_fused_train_hbm_bytes_per_launch" if fused else "unfused_hbm_bytes_per_launch")
-    # `bound`: the contract's two roofs are HBM bytes and MFMA flops.  What holds k_fused_train at base.json size is neither: the
-    # 3.8 MB table is L2-resident and the kernel is paced by L1->L2 line requests.  achieved / peak / frac therefore price the requests (VERDICT r01
-    # item 4), the HBM figures of the contract sit next to them in `hbm` / `hbm_frac`, and `l2_request_bound` / `gather_rate` give the same roof against
-    # the rates measured for the kernel's own lane arrangement.
-    hbm = {"achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "algorithmic_bytes_per_launch": dom_bytes}
-    req0 = pmc.get("k_fused_train_l2_read_requests_per_launch") if (fused and base_cfg) else None
-    if req0:
-        # the kernel's own roof: distinct 64-byte lines requested from L2 per second.  peak = 128 L2 channels x 2.1 GHz = the guide's 34.5 TB/s of L2 bandwidth in
-        # 128-byte channel slots (a 4-byte gather occupies a slot like a full line does); the gather micro-benchmark reaches 266-272 G/s with every lane on its
-        # own line (profiles/r02_gatherbench.md).  Requests per launch: the committed PMC pass of this regime (TCP_TCC_READ_REQ).
-        l2_peak = 128 * 2.1
-        roofline = {"bound": "l2-requests", "achieved": round(req0 / (fb_ms * 1e-3) / 1e9, 2), "peak": round(l2_peak, 1), "unit": "G requests/s",
-                    "frac": round(req0 / (fb_ms * 1e-3) / 1e9 / l2_peak, 4), "requests_per_launch": req0, "hbm": hbm, "hbm_frac": hbm["frac"]}
-    else:
-        roofline = dict(hbm, bound="hbm", hbm_frac=hbm["frac"])
-    roofline.update({"traffic": traffic, "traffic_regime": regime if traffic else None, "traffic_source": pmc.get("source"),
-                     "kernel": "k_fused_train" if fused else "unfused fwd+bwd kernel group",
-                     "avg_launch_ms": round(fb_ms, 4), "algorithmic_bytes_per_launch": dom_bytes,
-                     "measured_over": "HIP events around every launch on the object's train stream over steps %d..%d from init of a fresh object -- the same window as "
-                                      "the timed region, measured separately because the events add ~37 us per step between the launches" % (args.warmup, args.warmup + args.steps)})
+    # Algorithmic bytes per launch, SURVEY 8(d) split over the kernels of a step: per ray-sample position 12 + table gathers 32*L (encode),
+    # distance 4 + network output w+r 16 + dL/dO w+r 16 + distance re-read 4 (forward/backward), gradient scatter read-modify-write 64*L of the samples that
+    # carry a gradient (scatter); per step 40 B per parameter (optimizer: fp16 gradient, fp32 Adam moments + master r/w, step counter r/w, fp16 copy, EMA r/w).
+    step_ms = 1e3 * dt / args.steps
     if fused:
-        grp_ms = fb_ms + sc_ms
-        sc_bytes = 64 * L * scattered                # the scatter's read-modify-write bytes of the samples that carry a gradient
-        roofline["scatter_kernel"] = {"kernel": "k_grid_scatter", "avg_launch_ms": round(sc_ms, 4), "gradient_carrying_samples_per_launch": round(scattered, 1),
-                                      "algorithmic_bytes_per_launch": int(sc_bytes), "achieved": round(sc_bytes / (sc_ms * 1e-3) / 1e9, 2) if sc_ms else None,
-                                      "frac": round(sc_bytes / (sc_ms * 1e-3) / 1e9 / 8000.0, 4) if sc_ms else None}
-        pair_bytes = train_bytes_per_sample_fused(L) * B + sc_bytes
-        roofline["fwd_bwd_pair"] = {"avg_ms": round(grp_ms, 4), "algorithmic_bytes": int(pair_bytes),
-                                    "achieved": round(pair_bytes / (grp_ms * 1e-3) / 1e9, 2), "frac": round(pair_bytes / (grp_ms * 1e-3) / 1e9 / 8000.0, 4)}
-    roofline["other_kernels_ms"] = {"candidates+frags (folded into k_optimizer in steady state)": round(avg(0), 4),
-                                    "reduce_partials (folded into k_grid_scatter)": round(rd_ms, 4), "optimizer": round(avg(2), 4)}
-    # MFMA side of the same kernel (the tiny-GEMM of the MLP is the only matrix work): algorithmic flops = 2 * MACs of forward, input
-    # gradients and weight gradients (3 GEMMs per layer, no padding counted), against the dense fp16 peak
+        enc_ms = avg(6) + avg(7)
+        kern = [("k_encode_tiles", enc_ms, (12 + 32 * L) * B, "VALU issue + LDS reads (level tiles in LDS; HBM traffic is the tile copies)")] if enc_ms > 0 else []
+        kern += [("k_fused_train", avg(1), ((40 if enc_ms > 0 else 52 + 32 * L) * B), "latency of a ray's MLP / composite / backward chain" if enc_ms > 0 else "L1->L2 line requests of the hash-grid gathers"),
+                 ("k_grid_scatter", avg(4) + avg(5), 64 * L * scattered, "VALU issue + LDS integer atomics"),
+                 ("k_optimizer", avg(2), 40 * n_params, "HBM / Infinity Cache streaming")]
+    else:
+        kern = [("unfused fwd+bwd kernel group", avg(0) + avg(1), train_bytes_per_sample(L) * B, "global atomics"), ("k_optimizer", avg(2), 40 * n_params, "HBM streaming")]
+    table = []
+    for name, ms, nbytes, limiter in kern:
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        tr = pmc.get(name + "_hbm_bytes_per_launch")
+        table.append({"kernel": name, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(nbytes), "achieved": round(gbs, 2), "peak": 8000.0, "unit": "GB/s",
+                      "frac": round(gbs / 8000.0, 4), "traffic": tr, "limited_by": limiter})
+    dom = max(table, key=lambda r: r["avg_launch_ms"])
+    roofline = {"bound": "hbm", "achieved": dom["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
+                "traffic_regime": regime if dom["traffic"] else None, "traffic_source": pmc.get("source"),
+                "kernel": dom["kernel"], "avg_launch_ms": dom["avg_launch_ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "limited_by": dom["limited_by"],
+                "gradient_carrying_samples_per_launch": round(scattered, 1),
+                "measured_over": "HIP events around every launch on the object's train stream over steps %d..%d from init of a fresh object -- the same window as "
+                                 "the timed region, measured separately because the events add ~35 us per step between the launches" % (args.warmup, args.warmup + args.steps),
+                "kernels": table}
+    # the whole step against the contract's bytes: (52 + 96 L) B per nominal ray-sample + 40 B per parameter, over the TIMED step (no events)
+    contract_bytes = train_bytes_per_sample(L) * B + 40 * n_params
+    roofline["contract"] = {"bytes_per_step": int(contract_bytes), "bytes_per_ray_sample": train_bytes_per_sample(L), "optimizer_bytes_per_step": 40 * n_params,
+                            "ms_per_step": round(step_ms, 4), "achieved": round(contract_bytes / (step_ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                            "frac_of_hbm": round(contract_bytes / (step_ms * 1e-3) / 1e9 / 8000.0, 4),
+                            "note": "nominal bytes: every sample counts its scatter bytes whether or not its gradient underflowed to zero (DESIGN.md 3.2b)"}
+    # MFMA side (the tiny GEMMs of the MLP are the only matrix work): algorithmic flops = 2 * MACs of forward, input gradients and weight gradients
     W_, NH_, F_in = cfg.n_neurons, cfg.n_hidden_layers, 2 * L
     macs = F_in * W_ + (NH_ - 1) * W_ * W_ + W_ * 4
     mlp_flops = 3 * 2 * macs * B
-    roofline["mfma"] = {"algorithmic_flops_per_launch": mlp_flops, "achieved": round(mlp_flops / (fb_ms * 1e-3) / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                        "frac": round(mlp_flops / (fb_ms * 1e-3) / 1e12 / 2500.0, 4), "busy_frac_pmc": pmc.get("k_fused_train_mfma_busy_frac"),
-                        "note": "the path is gather-bound; MFMA is used only for the MLP's tiny GEMMs (busy_frac_pmc: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES of the committed pass)"}
-    req, rate = pmc.get("k_fused_train_l2_read_requests_per_launch"), pmc.get("l2_rate")
-    if fused and req and rate:
-        # one L2 request per distinct 64-byte line per gather instruction.  Two rates from the gather micro-benchmark (profiles/r01_microbench.md): ~270 G/s is
-        # the most the chip serves for ANY lane arrangement (four lanes per line), ~210 G/s what it serves for this kernel's arrangement (lane pairs share a
-        # line); `frac` prices the requests of the committed PMC pass of this regime at the second.  encode_only_ms: the same kernel with everything but the
-        # gathers switched off (profiles/r02_fused_floor.md) -- the measured floor of the gather phase.
-        prate = pj.get("l2_line_request_rate_pair_pattern_per_s") or rate
-        roofline["l2_request_bound"] = {"requests_per_launch": req, "measured_peak_requests_per_s": prate, "min_ms": round(1e3 * req / prate, 4),
-                                        "frac": round(1e3 * req / prate / fb_ms, 4), "regime": regime, "any_pattern_peak_requests_per_s": rate,
-                                        "frac_of_any_pattern_peak": round(1e3 * req / rate / fb_ms, 4),
-                                        "encode_only_ms": (pj.get("k_fused_train_encode_only_us") or 0) / 1e3 or None, "source": pj.get("floor_source")}
-        gr = pj.get("gather_rate_microbench_per_s") or {}
-        own = gr.get("lanes_l_l32_share_a_line (the kernel's arrangement)")
-        if own:      # the same bound in the unit the gather micro-benchmark reports: half2 gathers (lane-loads) per second
-            gathers = 8 * L * B
-            roofline["gather_rate"] = {"gathers_per_launch": gathers, "achieved_per_s": round(gathers / (fb_ms * 1e-3), 1), "microbench_same_lane_arrangement_per_s": own,
-                                       "frac": round(gathers / (fb_ms * 1e-3) / own, 4), "microbench_best_pair_arrangement_per_s": gr.get("adjacent_lanes_share_a_line"), "source": gr.get("source")}
+    fb_ms = avg(1)
+    roofline["mfma"] = {"kernel": "k_fused_train", "algorithmic_flops_per_launch": mlp_flops, "achieved": round(mlp_flops / (fb_ms * 1e-3) / 1e12, 2) if fb_ms else None, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": round(mlp_flops / (fb_ms * 1e-3) / 1e12 / 2500.0, 4) if fb_ms else None, "busy_frac_pmc": pmc.get("k_fused_train_mfma_busy_frac"),
+                        "note": "MFMA is used only for the MLP's tiny GEMMs (busy_frac_pmc: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES of the committed pass); the path is not priced against this roof"}
 
     # ---- extra, not the headline: the same measurement late in training (the scatter handles only the samples that still carry a
     #      gradient; an OfflineNeRF job runs 5000 iterations)

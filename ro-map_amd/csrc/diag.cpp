@@ -42,6 +42,9 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
         case MON_BUF_RAY_DN: src = m.B.ray_dn; sz = R * 4; break;       case MON_BUF_MASK: src = m.B.mask; sz = (R / 64) * 8; break;
         case MON_BUF_STATE: src = m.d_state; sz = sizeof(DevState); break;
         case MON_BUF_FRAG_TRAIN: src = m.d_frag_train; sz = 64 * 512 * 2; break;
+        case MON_BUF_X_ALL: if (!m.d_x_all) { set_error("debug_read: level-tile encode not in use"); return MON_ERR_STATE; } src = m.d_x_all; sz = B * 16; break;
+        case MON_BUF_E_SOA: if (!m.d_e_soa) { set_error("debug_read: level-tile encode not in use"); return MON_ERR_STATE; } src = m.d_e_soa; sz = B * (size_t)m.nd.L * 4; break;
+        case MON_BUF_HALF_TILES: if (!m.d_half_tiles) { set_error("debug_read: level-tile encode not in use"); return MON_ERR_STATE; } src = m.d_half_tiles; sz = (size_t)m.n_grid * 2; break;
         case MON_BUF_FRAG_REF:
             if (!m.d_frag_render) { set_error("debug_read: fused backend not available"); return MON_ERR_STATE; }
             HIPCHECK(use_device(m.device)); HIPCHECK(hipMemsetAsync(m.d_frag_render, 0, 64 * 512 * 2, m.train_stream));

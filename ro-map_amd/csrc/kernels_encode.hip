@@ -18,6 +18,8 @@
 // the first pass in registers until the second one completes the chain in its original order.
 #include "device_common.h"
 #include "model.h"
+#include "batch_device.h"
+#include "encode_device.h"
 
 namespace mon {
 
@@ -39,42 +41,13 @@ bool encode_tiles_supported(const LevelTable& lt, const NetDims& nd) {
 // from the candidates' ballot words (<= 256 words, prefix in LDS).  The position arithmetic is ray_sample's of k_fused_train, which recomputes
 // t (it needs the distances for the composite) and stores the same x for the gradient scatter.
 __global__ void __launch_bounds__(256) k_sample_points(BatchPtrs b, ObjectConst oc, DevState* __restrict__ st, float4_t* __restrict__ x_all) {
-    __shared__ unsigned long long words[256];
-    __shared__ uint32_t prefix[257];
+    __shared__ PointsLds lds;
     const uint32_t R = oc.R, nwords = R >> 6, iter = st->iter;
-    if (threadIdx.x < 64u) {
-        uint32_t carry = 0;
-        for (uint32_t base = 0; base < nwords; base += 64u) {
-            const uint32_t w = base + threadIdx.x;
-            const unsigned long long wd = (w < nwords) ? b.mask[w] : 0ull;
-            uint32_t c = (uint32_t)__popcll(wd), inc = c;
-#pragma unroll
-            for (int sh = 1; sh < 64; sh <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, sh, 64); if ((int)threadIdx.x >= sh) inc += o; }
-            if (w < nwords) { words[w] = wd; prefix[w] = carry + inc - c; }
-            carry += (uint32_t)__shfl((int)inc, 63, 64);
-        }
-        if (threadIdx.x == 0u) prefix[nwords] = carry;
-    }
-    __syncthreads();
-    const uint32_t nvalid = prefix[nwords];
-    if (blockIdx.x == 0u && threadIdx.x == 0u) st->n_valid = nvalid;
+    const uint32_t nvalid = points_prefix(lds, b.mask, nwords);
+    if (blockIdx.x == 0u && threadIdx.x == 0u) st->n_valid_pre = nvalid;
     if (nvalid == 0u) return;
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x, ray = s >> 5, n = s & 31u;
-    if (ray >= R) return;
-    const uint32_t kth = ray % nvalid;
-    uint32_t lo = 0, hi = nwords - 1u;
-    while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if (prefix[mid] <= kth) lo = mid; else hi = mid - 1u; }
-    unsigned long long wd = words[lo]; uint32_t kk = kth - prefix[lo], pos = 0;
-#pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t c = (uint32_t)__popcll(wd & ((1ull << sh) - 1ull)); if (kk >= c) { kk -= c; wd >>= sh; pos += (uint32_t)sh; } }
-    const uint32_t cand = (lo << 6) + pos;
-    const float t0 = b.cand_t0[cand], t1 = b.cand_t1[cand];
-    const float dtr = (t1 - t0) / 32.0f;
-    const float t = fmaf(dtr, (float)n + rand01(oc.sample_seed, kStreamDt, iter, ray * 32u + n), t0);
-    float x[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { const float p = fmaf(t, b.cand_d[3u * cand + d], b.cand_o[3u * cand + d]); x[d] = (p - oc.aabb.mn[d]) / (oc.aabb.mx[d] - oc.aabb.mn[d]); }
-    x_all[s] = float4_t{ x[0], x[1], x[2], t };
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < R * 32u) points_sample(lds, b, oc, iter, nvalid, nwords, s, x_all);
 }
 
 // ------------------------------------------------------------------ level-tile encode
@@ -86,6 +59,10 @@ struct EncodeArgs {
     uint32_t B, spw;               // samples of the batch, samples per workgroup (<= kEncThreads * kEncSpt)
     uint32_t ablate;               // timing experiments (option encode_ablate): 1 no sample walk, 2 no tile loads
     const DevState* st;
+    // GenerateRays (nerf_model.cu:369-446) of the NEXT iteration rides on the workgroups of level 0 (the coarsest level's tile is a few KB and its walk the
+    // shortest of the grid): workgroup p of level 0 generates candidates [256 p, 256 p + 256) into the OTHER candidate set; k_optimizer's position blocks
+    // then turn them into next iteration's positions (gen_next = 0: nothing to prepare)
+    uint32_t gen_next; BatchPtrs b_next; DatasetPtrs ds;  ObjectConst oc;
 };
 
 // x-corner-0 and x-corner-1 entry index of the four (y, z) pairs (j = y + 2z) and the position inside the cell; the arithmetic of gather_level / encode_interp.
@@ -219,9 +196,11 @@ __device__ __forceinline__ void encode_parity(uint32_t* tile, const uint4* __res
 
 __global__ void __launch_bounds__(kEncThreads) k_encode_tiles(EncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (a.st->n_valid == 0u) return;                                   // batch skipped (k_sample_points wrote the count)
     uint32_t* tile = reinterpret_cast<uint32_t*>(smem);
     const uint32_t level = blockIdx.x / kEncWgPerLevel, part = blockIdx.x - level * kEncWgPerLevel;
+    if (a.gen_next && level == 0u && blockIdx.y == 0u && threadIdx.x < 256u)
+        for (uint32_t c0 = part * 256u; c0 < a.oc.R; c0 += kEncWgPerLevel * 256u) gen_candidate(a.b_next, a.ds, a.oc, a.st->n_boxes, a.st->iter + 1u, c0 + threadIdx.x);
+    if (a.st->n_valid_pre == 0u) return;                               // batch skipped (the position pass wrote the count)
     const uint32_t w = blockIdx.y * kEncWgPerLevel + part;             // sample partition of the batch
     const uint32_t s_base = w * a.spw, s_end = min(s_base + a.spw, a.B), s0 = s_base + threadIdx.x;
     if (s_base >= a.B) return;
@@ -263,10 +242,11 @@ void launch_sample_points(hipStream_t s, const BatchPtrs& b, const ObjectConst& 
     hipLaunchKernelGGL(k_sample_points, dim3((B + 255u) / 256u), dim3(256), 0, s, b, oc, st, reinterpret_cast<float4_t*>(x_all));
 }
 
-void launch_encode_tiles(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* half_tiles, const float* x_all, uint16_t* e_soa, uint32_t B, const DevState* st) {
+void launch_encode_tiles(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* half_tiles, const float* x_all, uint16_t* e_soa, uint32_t B, const DevState* st,
+                         const BatchPtrs* b_next, const DatasetPtrs& ds, const ObjectConst& oc) {
     const uint32_t per_chunk = kEncWgPerLevel * kEncThreads * kEncSpt, chunks = (B + per_chunk - 1u) / per_chunk;
     const uint32_t spw = (B + kEncWgPerLevel * chunks - 1u) / (kEncWgPerLevel * chunks);
-    EncodeArgs a{ lf, nd.L, nd.n_mlp, half_tiles, reinterpret_cast<const float4_t*>(x_all), reinterpret_cast<half2_t*>(e_soa), B, spw, (uint32_t)options().encode_ablate, st };
+    EncodeArgs a{ lf, nd.L, nd.n_mlp, half_tiles, reinterpret_cast<const float4_t*>(x_all), reinterpret_cast<half2_t*>(e_soa), B, spw, (uint32_t)options().encode_ablate, st, b_next ? 1u : 0u, b_next ? *b_next : BatchPtrs{}, ds, oc };
     hipLaunchKernelGGL(k_encode_tiles, dim3((uint32_t)nd.L * kEncWgPerLevel, chunks), dim3(kEncThreads), kEncLdsBytes, s, a);
 }
 

@@ -16,6 +16,7 @@
 #include "model.h"
 #include "frag_layout.h"
 #include "batch_device.h"
+#include "encode_device.h"
 
 namespace mon {
 
@@ -56,9 +57,16 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
     // (one memory round trip); once few do (late training: k_grid_scatter left the count in n_scatter_now) most chunks only need their EMA advanced, and
     // the 112 B of Adam state per chunk are requested behind the gradient test instead
     const bool eager = DENSE && !(lazy_below != 0u && st->n_scatter_now <= lazy_below);
-    const bool cand_block = blockIdx.x < nx.cand_blocks;            // GenerateRays of iteration iter + 1
-    if (cand_block) gen_candidate(nx.b, nx.ds, nx.oc, st->n_boxes, st->iter + 1u, blockIdx.x * blockDim.x + threadIdx.x);
-    const uint32_t bid = blockIdx.x - nx.cand_blocks, nblk = gridDim.x - nx.cand_blocks;
+    const uint32_t extra = nx.cand_blocks + nx.pos_blocks;          // (one or the other)
+    const bool cand_block = blockIdx.x < extra;                     // GenerateRays of iteration iter + 1 / its sample positions
+    if (blockIdx.x < nx.cand_blocks) gen_candidate(nx.b, nx.ds, nx.oc, st->n_boxes, st->iter + 1u, blockIdx.x * blockDim.x + threadIdx.x);
+    else if (cand_block) {                                          // level-tile encode: the next iteration's candidates are complete (k_encode_tiles), sample their positions
+        __shared__ PointsLds plds;
+        const uint32_t nwords = nx.oc.R >> 6, nv = points_prefix(plds, nx.b.mask, nwords);
+        if (blockIdx.x == 0 && threadIdx.x == 0) st_next->n_valid_pre = nv;
+        if (nv != 0u) for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nx.oc.R * 32u; s += nx.pos_blocks * blockDim.x) points_sample(plds, nx.b, nx.oc, st->iter + 1u, nv, nwords, s, reinterpret_cast<float4_t*>(nx.x_all));
+    }
+    const uint32_t bid = blockIdx.x - extra, nblk = gridDim.x - extra;
     const float lr0 = st->lr;
     // EMA debias factors of this step (ema_step_half_precision; double-precision pow like tcnn's host code): left in the state by the previous step
     const uint32_t cur = step + 1u;
@@ -399,9 +407,9 @@ void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, c
     uint32_t cap = chunks / (256u * 8u); if (cap < 512u) cap = 512u; if (cap > 2048u) cap = 2048u; if (env_cap) cap = env_cap;
     uint32_t blocks = (chunks + 255) / 256; if (blocks > cap) blocks = cap; if (blocks < 1u) blocks = 1u;     // ~2 chunks per thread at base.json size: measured best (256: 28.1, 512: 23.7, 1024: 26.2 us)
     // dense = every level goes through the LDS scatter, i.e. tables of at most 2^18 entries that a 131 072-sample batch covers
-    if (p.gpart && p.all_levels_dense) hipLaunchKernelGGL((k_optimizer<true, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
-    else if (p.ema_step) hipLaunchKernelGGL((k_optimizer<false, true>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
-    else hipLaunchKernelGGL((k_optimizer<false, false>), dim3(blocks + nx.cand_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
+    if (p.gpart && p.all_levels_dense) hipLaunchKernelGGL((k_optimizer<true, false>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
+    else if (p.ema_step) hipLaunchKernelGGL((k_optimizer<false, true>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
+    else hipLaunchKernelGGL((k_optimizer<false, false>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
 }
 
 }  // namespace mon

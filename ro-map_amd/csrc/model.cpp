@@ -374,6 +374,10 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         if (big_bytes && big_switch) { if ((rc = dev_alloc(m, m.d_big_ws, big_bytes))) return rc; m.big_switch = big_switch; }
         // level-tile encode (kernels_encode.hip): every level must fit two LDS tiles and go through the LDS scatter (option lds_encode = 0: gathers inside k_fused_train)
         if (options().lds_encode && !cfg.occupancy_skip && m.lds_mask == ((1u << m.nd.L) - 1u) && encode_tiles_supported(m.lt, m.nd)) {
+            m.B_alt = B;                             // (cand_* / mask replaced below, after the workspace pointers are final)
+            if ((rc = dev_alloc(m, m.B_alt.cand_o, 3 * (size_t)R)) || (rc = dev_alloc(m, m.B_alt.cand_d, 3 * (size_t)R)) || (rc = dev_alloc(m, m.B_alt.cand_dn, R)) ||
+                (rc = dev_alloc(m, m.B_alt.cand_t0, R)) || (rc = dev_alloc(m, m.B_alt.cand_t1, R)) || (rc = dev_alloc(m, m.B_alt.cand_depth, R)) ||
+                (rc = dev_alloc(m, m.B_alt.cand_rgba, R)) || (rc = dev_alloc(m, m.B_alt.mask, (R + 63) / 64 + 64))) return rc;
             if ((rc = dev_alloc(m, m.d_x_all, 4 * (size_t)Btrain)) || (rc = dev_alloc(m, m.d_e_soa, (size_t)m.nd.L * Btrain * 2)) || (rc = dev_alloc(m, m.d_half_tiles, (size_t)m.n_grid + 64))) return rc;
             encode_tiles_setup_device();
         }
@@ -392,7 +396,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     }
     m.boxes_cap = 1024;
     if ((rc = dev_alloc(m, m.d_boxes, m.boxes_cap))) return rc;
-    B.boxes = m.d_boxes;
+    B.boxes = m.d_boxes; m.B_alt.boxes = m.d_boxes;
     m.h_state = DevState{}; m.h_state.lr = cfg.learning_rate;
     m.h_state.ema_deb_old = 0.0f; m.h_state.ema_deb_new = 1.0f / (1.0f - (float)std::pow((double)cfg.ema_decay, 1.0));   // step 1
     m.d_state_next = m.d_state + 1;                          // two states: iteration i runs on one, k_optimizer(i) writes the other for iteration i + 1
@@ -489,7 +493,7 @@ int model_add_boxes(Model& m, const mon_frame_bbox* boxes, size_t n) {
         uint32_t cap = m.boxes_cap; while (cap < m.n_boxes + n) cap *= 2;
         mon_frame_bbox* nb = nullptr; int rc = dev_alloc(m, nb, cap); if (rc) return rc;
         HIPCHECK(hipMemcpy(nb, m.d_boxes, sizeof(mon_frame_bbox) * m.n_boxes, hipMemcpyDeviceToDevice));
-        m.d_boxes = nb; m.B.boxes = nb; m.boxes_cap = cap; drop_graph(m);       // old buffer stays in allocs until destroy
+        m.d_boxes = nb; m.B.boxes = nb; m.B_alt.boxes = nb; m.boxes_cap = cap; drop_graph(m);       // old buffer stays in allocs until destroy
     }
     HIPCHECK(hipMemcpy(m.d_boxes + m.n_boxes, boxes, sizeof(mon_frame_bbox) * n, hipMemcpyHostToDevice));   // nerf_model.cu:1625
     m.n_boxes += (uint32_t)n;
@@ -542,9 +546,12 @@ static void enqueue_iteration(Model& m, int stages) {
         } else {
             if (m.scatter_pending) hipMemsetAsync(m.d_state->n_scatter, 0, sizeof(m.d_state->n_scatter), s);      // stage-wise debugging: a forward/backward without an optimizer step after it
             const bool pre = m.d_e_soa && !m.fused_dump && options().lds_encode;          // the encode as LDS reads of level tiles; the fused kernel then loads the features
+            m.pre_active = pre;
             if (pre) {
-                { ProfScope pp(m, MON_K_POINTS); launch_sample_points(s, m.B, m.oc, m.d_state, m.d_x_all); }
-                { ProfScope pe(m, MON_K_ENCODE); launch_encode_tiles(s, m.lf, m.nd, m.d_half_tiles, m.d_x_all, m.d_e_soa, B, m.d_state); }
+                // positions of this batch: normally the last k_optimizer's position blocks already wrote them (and k_encode_tiles of the last iteration the candidates)
+                if (!(m.next_ready && m.points_ready)) { ProfScope pp(m, MON_K_POINTS); launch_sample_points(s, m.B, m.oc, m.d_state, m.d_x_all); }
+                const bool gen_next = options().fold_next != 0;
+                { ProfScope pe(m, MON_K_ENCODE); launch_encode_tiles(s, m.lf, m.nd, m.d_half_tiles, m.d_x_all, m.d_e_soa, B, m.d_state, gen_next ? &m.B_alt : nullptr, m.ds->ptrs(), m.oc); }
             }
             ProfScope ps(m, MON_K_FWDBWD);
             launch_fused_train(s, m.lf, m.nd, m.P, m.B, m.oc, m.d_state, m.d_dw_partials, m.fused_dump, m.d_de_soa, m.d_x_soa, m.lds_mask, m.d_frag_train, m.big_active ? m.big_switch : 0u, m.d_touched, m.occ_refreshed_iter ? m.d_occ : nullptr, m.n_bins, pre ? m.d_e_soa : nullptr);      // (no grid look-ups before the first refresh: every cell is live during the warm-up)
@@ -572,13 +579,16 @@ static void enqueue_iteration(Model& m, int stages) {
         }
         OptimNext nx{};
         const bool fold = options().fold_next != 0;
+        const bool pos_mode = m.backend == 1 && fold && m.pre_active && m.d_e_soa;      // k_encode_tiles generated the next candidates into B_alt; sample their positions here
         if (m.backend == 1 && fold) {
-            nx.cand_blocks = (m.oc.R + 255) / 256; nx.frag_image = m.d_frag_train; nx.fd = FragDims{ m.nd.Epad, m.nd.W, m.nd.NH, m.nd.L };
-            nx.b = m.B; nx.ds = m.ds->ptrs(); nx.oc = m.oc;
+            nx.cand_blocks = pos_mode ? 0u : (m.oc.R + 255) / 256; nx.frag_image = m.d_frag_train; nx.fd = FragDims{ m.nd.Epad, m.nd.W, m.nd.NH, m.nd.L };
+            nx.b = pos_mode ? m.B_alt : m.B; nx.ds = m.ds->ptrs(); nx.oc = m.oc;
+            if (pos_mode) { nx.pos_blocks = 64u; nx.x_all = m.d_x_all; }
         }
         launch_optimizer(s, P, m.opt, m.d_state, m.d_state_next, nx, options().opt_lazy_below < 0 ? (m.oc.R * m.oc.S) / 8u : (uint32_t)options().opt_lazy_below); m.scatter_pending = false;
         std::swap(m.d_state, m.d_state_next);                // the next iteration (and the host's read-back) uses the state this launch prepares
-        m.next_ready = (m.backend == 1 && fold);
+        if (pos_mode) std::swap(m.B, m.B_alt);               // ... and the candidate set k_encode_tiles filled for it
+        m.next_ready = (m.backend == 1 && fold); m.points_ready = pos_mode;
     }
 }
 
@@ -616,13 +626,13 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     const bool lanes_on = stages == 7 && m.big_switch == 0u; const int chunk = options().lane_chunk >= 2 ? (options().lane_chunk & ~1) : 2;
     if (use_graph) {
         const int graph_key = m.backend | (m.big_active ? 256 : 0) | (m.occ_refreshed_iter ? 512 : 0);
-        if (!m.graph_exec || m.graph_backend != graph_key || m.graph_state != m.d_state) {
+        if (!m.graph_exec || m.graph_backend != graph_key || m.graph_state != m.d_state || m.graph_mask != m.B.mask) {      // (the captured pair starts on this DevState and this candidate set)
             drop_graph(m);
             hipGraph_t g = nullptr;
             const hipStream_t cur = m.train_stream; m.train_stream = m.own_stream;      // captured on the object's own stream (a lane is shared with other host threads), replayed on the current one
             HIPCHECK(hipStreamBeginCapture(m.train_stream, hipStreamCaptureModeThreadLocal));
             m.next_ready = false;                           // the captured iterations are self-contained
-            m.graph_state = m.d_state;
+            m.graph_state = m.d_state; m.graph_mask = m.B.mask;
             enqueue_iteration(m, 7); enqueue_iteration(m, 7);      // a PAIR: the two DevStates swap roles every iteration, after two the captured pointers are current again
             const hipError_t ce = hipStreamEndCapture(m.train_stream, &g); m.train_stream = cur; HIPCHECK(ce);
             HIPCHECK(hipGraphInstantiate(&m.graph_exec, g, nullptr, nullptr, 0));

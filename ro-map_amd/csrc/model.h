@@ -19,7 +19,7 @@ struct DevState {
     uint32_t n_boxes;    // mnBbox
     float lr;            // Adam learning rate after ExponentialDecay
     float loss_sum;      // sum of per-ray losses of the current batch (SumLoss, nerf_model.cu:1231-1253)
-    uint32_t ticket;     // (unused since the optimizer prepares the next iteration's state at its entry)
+    uint32_t n_valid_pre; // level-tile encode: n_valid of THIS iteration as counted by the position pass that ran ahead of it (k_sample_points / k_optimizer's position blocks)
     uint32_t skipped;    // batches skipped because n_valid == 0
     uint32_t n_scatter_now;   // gradient-carrying samples of the CURRENT iteration (written by k_grid_scatter; the optimizer's last block makes it n_scatter_last, so every kernel of an iteration sees the same previous count)
     float ema_deb_even_old, ema_deb_even_new;   // EMA debias factors of the next EVEN optimizer step (see ema_deb_old)
@@ -92,7 +92,8 @@ struct OptimConst {
 };
 
 // What k_optimizer prepares for the next iteration of the fused backend (all zero = nothing): candidate rays and the A-fragment image.
-struct OptimNext { uint32_t cand_blocks; uint16_t* frag_image; FragDims fd; BatchPtrs b; DatasetPtrs ds; ObjectConst oc; };
+struct OptimNext { uint32_t cand_blocks; uint16_t* frag_image; FragDims fd; BatchPtrs b; DatasetPtrs ds; ObjectConst oc;
+                   uint32_t pos_blocks; float* x_all; };      // pos_blocks > 0 (level-tile encode): `b` holds the NEXT iteration's candidates already (k_encode_tiles generated them), these blocks sample its positions
 
 // debug buffer ids for mon_object_debug_read (stable numbering, see binding.py BUF)
 enum {
@@ -103,7 +104,10 @@ enum {
     MON_BUF_RAY_T1 = 25, MON_BUF_TARGET = 26, MON_BUF_TARGET_DEPTH = 27, MON_BUF_BGCOL = 28, MON_BUF_RAY_FLAG = 29,
     MON_BUF_RAY_DN = 31, MON_BUF_MASK = 32, MON_BUF_STATE = 33,
     MON_BUF_FRAG_TRAIN = 34,    // the A-fragment image the next fused iteration will use (64 x 512 halves)
-    MON_BUF_FRAG_REF = 35       // the same image rebuilt from the current fp16 weights by k_build_frag_image (layout test)
+    MON_BUF_FRAG_REF = 35,      // the same image rebuilt from the current fp16 weights by k_build_frag_image (layout test)
+    MON_BUF_X_ALL = 36,         // level-tile encode: positions float4 [B] of the batch the next / last iteration uses
+    MON_BUF_E_SOA = 37,         // level-tile encode: encoded features half2 [L][B] of the last iteration
+    MON_BUF_HALF_TILES = 38     // level-tile encode: the fp16 grid in tile order (ParamPtrs::half_tiles)
 };
 
 // Process-wide test and tuning switches (mon_set_option, include/mon_core.h); defaults are the product behaviour.
@@ -158,7 +162,8 @@ void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, c
 bool encode_tiles_supported(const LevelTable& lt, const NetDims& nd);
 void encode_tiles_setup_device();
 void launch_sample_points(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* x_all);
-void launch_encode_tiles(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* half_tiles, const float* x_all, uint16_t* e_soa, uint32_t B, const DevState* st);
+void launch_encode_tiles(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* half_tiles, const float* x_all, uint16_t* e_soa, uint32_t B, const DevState* st,
+                         const BatchPtrs* b_next_or_null, const DatasetPtrs& ds, const ObjectConst& oc);      // b_next: the candidate set GenerateRays of the next iteration goes to
 void launch_build_tiles_image(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* params, uint16_t* half_tiles);
 void launch_occupancy_update(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const ObjectConst& oc, uint16_t* frag_image, float raw_threshold, uint32_t* tmp, uint32_t* bits);
 uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl);
@@ -194,6 +199,7 @@ struct Model {
     uint32_t n_grid = 0, n_params = 0;
     hipStream_t train_stream = nullptr;      // mpTrainStream :1268; inference (render, mesh) runs on the same stream: the reference's mpInferenceStream is only
                                              // ever used from the object's own thread between training calls
+    BatchPtrs B_alt{};                          // level-tile encode: the second candidate set (cand_*, mask differ from B; everything else is shared); B and B_alt swap with the DevStates
     ParamPtrs P{}; BatchPtrs B{}; DevState* d_state = nullptr; DevState* d_state_next = nullptr;      // iteration i runs on one DevState and prepares the other for i + 1 (k_optimizer); swapped when an optimizer step is enqueued
     mon_frame_bbox* d_boxes = nullptr;
     uint32_t boxes_cap = 0, n_boxes = 0; uint32_t ws_samples = 0, ws_rays = 0;
@@ -212,11 +218,12 @@ struct Model {
     DevState h_state{}; DevState* h_state_pinned = nullptr; int backend = 0; bool profiling = false; int fused_dump = 0;
     bool lazy_ema = false, ema_pending = false;   // large tables: EMA of untouched chunks is brought up to date on demand (k_ema_finalize)
     bool scatter_pending = false;   // a fused forward/backward was enqueued whose slot counter has not been reset by an optimizer step yet
+    bool pre_active = false, points_ready = false;   // level-tile encode: used by the iteration being enqueued / the next batch's positions were written by the last k_optimizer
     bool next_ready = false;     // fused backend: candidates + fragment image of the coming iteration were already produced by the last k_optimizer
     mon_profile prof{}; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pending;
     struct TrainLanes* lanes = nullptr; int lane = -1; hipEvent_t lane_event = nullptr, switch_event = nullptr, sync_event = nullptr;      // per-device training lanes (model.cpp): the lane and completion event of this object's last chunk
     bool tail_marked = false; hipStream_t own_stream = nullptr;        // the object's private stream; train_stream is the one its work currently goes to (this one or a lane's)
-    hipGraphExec_t graph_exec = nullptr; int graph_backend = -1; const DevState* graph_state = nullptr;      // (the state the captured pair of iterations starts on)
+    hipGraphExec_t graph_exec = nullptr; int graph_backend = -1; const DevState* graph_state = nullptr; const void* graph_mask = nullptr;      // (the state the captured pair of iterations starts on)
 };
 
 int ensure_ema_current(Model& m);

@@ -676,3 +676,72 @@ def test_lazy_ema_matches_eager_on_large_tables(pkg, small_scene):
     # reading the inference weights again changes nothing; training on and reading again stays consistent
     assert np.array_equal(h2f(obj.get_params(2)), got)
     obj.close(); ds.close()
+
+
+def _level_sizes(cfg):
+    """tcnn's level table (grid.h): entries per level = min(round_up(res^3, 8), 2^T), res = ceil(base * scale^l - 1) + 1."""
+    sizes = []
+    for l in range(cfg.n_levels):
+        scale = np.float32(2.0 ** (l * np.log2(cfg.per_level_scale)) * cfg.base_resolution - 1.0)
+        res = int(np.ceil(scale)) + 1
+        sizes.append(min(((res ** 3 + 7) // 8) * 8, 1 << cfg.log2_hashmap_size))
+    return sizes
+
+
+@pytest.mark.parametrize("kw", [C1, dict(rays_per_batch=256), dict(rays_per_batch=320, n_levels=6, base_resolution=20, per_level_scale=1.235, log2_hashmap_size=16),
+                                dict(rays_per_batch=8192, n_levels=3, log2_hashmap_size=14)], ids=["c1", "c2net", "dense_parity_levels", "two_chunks"])
+def test_level_tile_encode_matches_oracle_and_the_gather_path(pkg, orc, small_scene, kw):
+    """The default forward pass of the fused backend: positions by k_sample_points / k_optimizer's position blocks, hash-grid encode by k_encode_tiles from
+    LDS-resident level tiles (whole levels and even / odd parity tiles), features loaded by k_fused_train<PRE>.  Positions and encoded features must equal
+    the oracle's bit for bit, the tile image must be the tile_slot permutation of the fp16 grid, and training must give the same parameters as the gather path."""
+    ds, obj, ref = _pair(pkg, orc, small_scene, kw, 1)
+    obj.set_debug_dump(False)
+    p = pattern_params(ref); obj.set_params(p); ref.set_params(p)
+    L, B = obj.cfg.n_levels, obj.R * obj.S
+    Ep = obj.info().encoded_width
+    def check_batch():
+        x = obj.buffer("x_all").reshape(B, 4); close_f32(x[:, :3], ref.buffer("pts").reshape(B, 3), "positions", 1e-6); close_f32(x[:, 3], ref.buffer("tdist"), "distances", 1e-6)
+        e = obj.buffer("e_soa").reshape(L, B, 2); want = ref.buffer("E").reshape(B, Ep)[:, :2 * L].reshape(B, L, 2).transpose(1, 0, 2)
+        assert np.array_equal(e, want), "level-tile encode must be bit-exact (levels differing: %s)" % sorted(set(np.argwhere(e != want)[:, 0].tolist()))
+    obj.train_stages(1 | 2); ref.generate_batch(); ref.forward_backward()          # iteration 0: stand-alone position kernel
+    assert int(obj.buffer("state")[2]) == ref.n_valid
+    check_batch()
+    obj.train_stages(4); ref.train_step()
+    # the tile image after an optimizer step: a permutation of the fp16 grid, level by level
+    half = obj.buffer("half")[obj.info().n_mlp_params:].reshape(-1, 2); tiles = obj.buffer("half_tiles").reshape(-1, 2)
+    off = 0
+    for size in _level_sizes(obj.cfg):
+        lv = half[off:off + size]
+        want = lv if size <= 163840 // 4 else np.concatenate([lv[0::2], lv[1::2]])
+        assert np.array_equal(tiles[off:off + size], want), "tile image of the level at entry offset %d" % off
+        off += size
+    # iteration 1: candidates by k_encode_tiles' level-0 workgroups, positions by k_optimizer's blocks, the oracle restarted from the device's weights
+    ref.set_params(obj.get_params(0))                                              # (train_step advanced the oracle's iteration counter)
+    obj.train_stages(1 | 2); ref.generate_batch(); ref.forward_backward()
+    assert int(obj.buffer("state")[2]) == ref.n_valid
+    check_batch()
+    obj.train_stages(4)
+    crc_pre = obj.get_params(0).tobytes()
+    obj.close(); ds.close(); ref.close()
+    # the same two steps with the gathers inside k_fused_train
+    pkg.set_option("lds_encode", 0)
+    try:
+        ds, obj = ge.make_problem(pkg, small_scene, kw); obj.set_backend(1); obj.set_params(p)
+        obj.train(2)
+        assert obj.get_params(0).tobytes() == crc_pre
+        obj.close(); ds.close()
+    finally:
+        pkg.set_option("lds_encode", 1)
+
+
+def test_level_tile_encode_trains_bit_identically_to_the_gather_path():
+    """base.json on the bench scene, 400 steps: the level-tile encode (default), the same under hipGraph replay, and the gathers inside k_fused_train
+    (option lds_encode = 0) must leave bit-identical parameters, through the dense and the sparse-gradient regime."""
+    import subprocess, sys
+    from conftest import ROOT
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "param_crc.py"), "3", "150", "250"], capture_output=True, text=True, env=dict(os.environ, **extra), timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return [ln.split()[2] for ln in r.stdout.strip().split("\n") if ln.startswith("steps+")]
+    a = run({}); b = run({"MON_OPTIONS": "lds_encode=0"}); c = run({"MON_OPTIONS": "use_graph=1"})
+    assert a == b == c, (a, b, c)
