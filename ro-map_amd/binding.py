@@ -125,6 +125,7 @@ _DIAG_SIGS = {
     "mon_debug_fast_index": (C.c_int, [C.POINTER(MonConfig), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mon_selftest_mfma": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mon_debug_yaml_number": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_double)]),
+    "mon_debug_occupancy_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
 }
 
 
@@ -389,6 +390,9 @@ class ObjectNeRF:
                       x_all=(np.float32, B * 4), e_soa=(np.uint16, B * 2 * self.cfg.n_levels), half_tiles=(np.uint16, i.n_grid_params))
         dt, cnt = shapes[name]; out = np.empty(cnt, dt)
         _check(diag_lib().mon_object_debug_read(self.h, BUF[name], _p(out), out.nbytes)); return out
+
+    def occupancy_state(self):
+        out = (C.c_uint32 * 2)(); _check(diag_lib().mon_debug_occupancy_state(self.h, out)); return int(out[0]), int(out[1])
 
     def set_debug_dump(self, on):
         _check(lib().mon_object_set_debug_dump(self.h, int(on)))

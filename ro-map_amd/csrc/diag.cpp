@@ -114,6 +114,10 @@ int mon_debug_acc_layout(int epad, int W, int NH, int L, int* param, int* n_cols
     return MON_OK;
 }
 int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D) { REQUIRE(A, "A"); REQUIRE(B, "B"); REQUIRE(D, "D"); return selftest_mfma(device, A, B, D); }
+int mon_debug_occupancy_state(mon_object* o, uint32_t out[2]) {
+    if (!o || !o->m || !out) { mon::set_error("debug_occupancy_state: null argument"); return MON_ERR_ARG; }
+    out[0] = o->m->occ_refreshed_iter; out[1] = o->m->occ_next_refresh; return MON_OK;
+}
 int mon_debug_yaml_number(const char* text, const char* key, double* value) {
     REQUIRE(text, "text"); REQUIRE(key, "key"); REQUIRE(value, "value");
     if (!read_yaml_number(text, key, *value)) { set_error("config.yaml: %s missing or not a number", key); return MON_ERR_IO; }

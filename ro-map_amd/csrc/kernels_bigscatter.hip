@@ -17,6 +17,7 @@
 // host has seen the count well below the switch it stops launching these kernels (model.cpp).  k_big_accum also sets the lazy
 // optimizer's chunk flags (ParamPtrs::touched) next to every entry it writes.
 #include <atomic>
+#include <mutex>
 #include "model.h"
 #include "grid_walk.h"
 
@@ -147,9 +148,14 @@ void launch_big_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf
     uint32_t* hist = reinterpret_cast<uint32_t*>(workspace); uint32_t* woff = hist + (size_t)big.n * kBigBins * kBigMaxTiles;
     uint32_t* tcnt = woff + (size_t)big.n * kBigBins * kBigMaxTiles; uint32_t* toff = tcnt + (size_t)big.n * kBigMaxTiles;
     uint2* rec = reinterpret_cast<uint2*>(toff + (size_t)big.n * kBigMaxTiles);
-    static std::atomic<uint64_t> attr_devices{ 0 };
-    { int dev = 0; (void)hipGetDevice(&dev); const uint64_t bit = 1ull << (dev & 63);
-      if (!(attr_devices.fetch_or(bit) & bit)) hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_accum), hipFuncAttributeMaxDynamicSharedMemorySize, kBigTile * 8); }
+    {   // once per device, and no launch before it has run (the flag is set AFTER the attribute call, under the lock: objects of one device launch from several host threads)
+        static std::atomic<uint64_t> attr_devices{ 0 }; static std::mutex attr_mu;
+        int dev = 0; (void)hipGetDevice(&dev); const uint64_t bit = 1ull << (dev & 63);
+        if (!(attr_devices.load(std::memory_order_acquire) & bit)) {
+            std::lock_guard<std::mutex> l(attr_mu);
+            if (!(attr_devices.load(std::memory_order_relaxed) & bit)) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_accum), hipFuncAttributeMaxDynamicSharedMemorySize, kBigTile * 8); attr_devices.fetch_or(bit, std::memory_order_release); }
+        }
+    }
     const half2_t* de = reinterpret_cast<const half2_t*>(de_soa);
     hipLaunchKernelGGL(k_big_hist, dim3(big.n * kBigBins), dim3(1024), 0, s, lf, big, de, x_soa, B, n_bins, st, big_switch, hist);
     hipLaunchKernelGGL(k_big_scan, dim3(big.n), dim3(1024), 0, s, big, st, big_switch, hist, woff, tcnt, toff);

@@ -26,6 +26,7 @@
 //     across the workgroup in LDS and written as one fp32 partial per workgroup (summed by the optimizer).
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include "device_common.h"
 #include "model.h"
 #include "frag_layout.h"
@@ -34,13 +35,18 @@
 
 namespace mon {
 
-// true the first time the calling thread's current device is seen by this call site
-static bool first_use_on_this_device(std::atomic<uint64_t>& seen) {
+// Runs `setup` once per device and call site, and returns only after it has run: function attributes (the dynamic LDS size) are per device, objects of several
+// devices and several host threads per device launch from one process, and a launch must never precede its kernel's attribute call (a flag set BEFORE the
+// attribute call let a second thread's first launch slip past it and fail with the large LDS size).
+template <class F> static void once_per_device(std::atomic<uint64_t>& done, std::mutex& mu, F&& setup) {
     int dev = 0; (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
-    return (seen.fetch_or(bit) & bit) == 0ull;
+    if (done.load(std::memory_order_acquire) & bit) return;
+    std::lock_guard<std::mutex> l(mu);
+    if (done.load(std::memory_order_relaxed) & bit) return;
+    setup();
+    done.fetch_or(bit, std::memory_order_release);
 }
-
 
 void set_error(const char* fmt, ...);
 
@@ -1180,8 +1186,8 @@ void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& l
     ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return;
     const PartialsArgs pa{ partials, n_partials, fused_partial_cols(nd) + 64u, fused_partial_cols(nd), FragDims{ nd.Epad, nd.W, nd.NH, nd.L }, gmlp, st };
     constexpr uint32_t smem = kScatterLdsBytes;
-    static std::atomic<uint64_t> attr_devices{ 0 };       // function attributes are per device: the managers run objects on every GPU of the node from one process
-    if (first_use_on_this_device(attr_devices)) hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    static std::atomic<uint64_t> attr_devices{ 0 }; static std::mutex attr_mu;
+    once_per_device(attr_devices, attr_mu, [] { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
     float* timing = nullptr;
 #ifdef MON_SCATTER_TIMING
     static float* g_timing = nullptr; if (!g_timing) hipMalloc((void**)&g_timing, 256 * 16 * 8 * 4); timing = g_timing; g_scatter_timing_buf = g_timing;
@@ -1307,15 +1313,15 @@ uint32_t fused_train_grid(const NetDims&, uint32_t R) {
 template <int EPAD, int W, int NH>
 static void fused_train_t(hipStream_t s, const FusedArgs& a, uint32_t grid, int dump) {
     using S = FusedShape<EPAD, W, NH>;
-    static std::atomic<uint64_t> attr_devices{ 0 };
-    if (first_use_on_this_device(attr_devices)) {
+    static std::atomic<uint64_t> attr_devices{ 0 }; static std::mutex attr_mu;
+    once_per_device(attr_devices, attr_mu, [] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
-    }
+    });
     const bool all_lds = a.lds_level_mask != 0u && (a.lds_level_mask == ((a.nd.L >= 32) ? 0xffffffffu : ((1u << a.nd.L) - 1u)));
     if (a.e_soa && all_lds && !dump && !a.occ_bits) { hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false, false, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a); return; }
     if (dump) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);          // (the debug dump evaluates every sample)

@@ -533,7 +533,7 @@ int mon_online_create_nerf(mon_online* h, int cls, const float* Tow16, const flo
     return MON_OK;
 }
 int mon_online_update_nerf_bbox(mon_online* h, size_t idx, const mon_frame_bbox* boxes, size_t n, int train_step) {   // :298-303 + UpdateFrameBBox nerf.cu:406-421
-    REQ(h); if (n == 0) return MON_OK; REQ(boxes);
+    REQ(h); if (n != 0) REQ(boxes);            // an EMPTY update still stores train_step and wakes the object's thread, like UpdateFrameBBox (nerf.cu:416-420)
     if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
     OnlineObject* o = h->m->objs[idx];
     std::unique_lock<std::mutex> lock(o->mu_boxes);

@@ -147,7 +147,7 @@ int model_generate_mesh(Model& m, int res, float thresh, uint32_t* n_verts, uint
     int rc = mesh_reserve_lattice(ms, res3); if (rc) return rc;
     rc = ensure_ema_current(m); if (rc) return rc;
     HIPCHECK(hipStreamSynchronize(s));
-    HIPCHECK(hipMemcpy(&m.h_state, m.d_state, sizeof(DevState), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(&m.h_state, m.d_state, offsetof(DevState, n_scatter), hipMemcpyDeviceToHost));
     const uint16_t* prm = (m.h_state.step > 0) ? m.P.ema : m.P.half;
     const uint32_t chunk = m.ws_samples;
     for (size_t p0 = 0; p0 < res3; p0 += chunk) {                             // GetDensityOnGrid :2007-2048

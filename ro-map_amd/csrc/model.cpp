@@ -86,8 +86,8 @@ static int infer_shared_get(int device, size_t pixels_hint, InferShared** out) {
         int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&sh->stream, hipStreamNonBlocking, hi) != hipSuccess) { delete sh; sh = nullptr; set_error("inference stream creation failed on device %d", device); return MON_ERR_HIP; }
     }
+    std::lock_guard<std::mutex> l2(sh->mu);              // (h_out / h_cap belong to sh->mu: model_render_snapshot resizes them under it)
     if (5 * pixels_hint > sh->h_cap) {
-        std::lock_guard<std::mutex> l2(sh->mu);
         float* q = nullptr; if (hipHostMalloc((void**)&q, 5 * pixels_hint * sizeof(float), hipHostMallocDefault) != hipSuccess) { set_error("pinned render buffer allocation failed"); return MON_ERR_HIP; }
         if (sh->h_out) hipHostFree(sh->h_out);
         sh->h_out = q; sh->h_cap = 5 * pixels_hint;
@@ -427,13 +427,17 @@ static int publish_snapshot(Model& m, bool force = true) {
     InferState* is = m.infer; if (!is) return MON_OK;
     const auto now = std::chrono::steady_clock::now();
     if (!force && is->latest >= 0 && !is->wanted.load() && now - is->last_pub < std::chrono::milliseconds(10)) return MON_OK;
-    is->wanted.store(false); is->last_pub = now;
     int w;
-    { std::lock_guard<std::mutex> l(is->mu); w = is->latest == 0 ? 1 : 0; if (is->readers[w] > 0) return MON_OK; }          // a render still reads the older buffer: keep the current snapshot this round
+    {   std::lock_guard<std::mutex> l(is->mu); w = is->latest == 0 ? 1 : 0;
+        if (is->readers[w] > 0) return MON_OK;          // a render still reads the older buffer: keep the current snapshot this round (the viewer's request stays standing)
+        // from here until the new copy's event is recorded the buffer is not a valid fall-back for a render: its event still shows the PREVIOUS copy as complete
+        // (two publications back to back, the first copy still queued behind other objects' chunks: a render fell back to this buffer while it was rewritten)
+        is->written[w] = false; }
     const uint16_t* src = (m.h_state.step > 0) ? m.P.ema : m.P.half;
     launch_copy_params(m.train_stream, src, is->snap[w], m.n_params);
     HIPCHECK(hipEventRecord(is->ready[w], m.train_stream));
     { std::lock_guard<std::mutex> l(is->mu); is->step_of[w] = m.h_state.step; is->written[w] = true; is->latest = w; }
+    is->wanted.store(false); is->last_pub = now;          // (only now: a publication skipped above must not discard the viewer's request)
     return MON_OK;
 }
 
@@ -594,9 +598,11 @@ static void enqueue_iteration(Model& m, int stages) {
 
 // Occupancy grid refresh (cfg.occupancy_skip): before iteration `iter` when it is due.  Stream-ordered between two iterations, from the training weights.
 static void maybe_refresh_occupancy(Model& m, uint32_t iter) {
-    if (!m.d_occ || m.backend != 1 || iter < (uint32_t)kOccWarmup || iter % (uint32_t)kOccInterval != 0u || iter == m.occ_refreshed_iter) return;
+    // due at the first iteration it is asked for at or after the next multiple of kOccInterval (the hipGraph path only asks at the start of a captured PAIR: after an
+    // odd number of iterations an exact "iter % interval == 0" test was never true again and the grid was never refreshed)
+    if (!m.d_occ || m.backend != 1 || iter < (uint32_t)kOccWarmup || iter < m.occ_next_refresh) return;
     launch_occupancy_update(m.train_stream, m.lf, m.nd, m.P.half, m.oc, m.d_frag_occ, m.occ_raw_threshold, m.d_occ_tmp, m.d_occ);
-    m.occ_refreshed_iter = iter;
+    m.occ_refreshed_iter = iter; m.occ_next_refresh = (iter / (uint32_t)kOccInterval + 1u) * (uint32_t)kOccInterval;
 }
 
 static int sync_state(Model& m) {
@@ -674,12 +680,11 @@ int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int
         // busy device); the one before it is complete, and nobody writes it before the train stream has been synchronised again -- by which time the newest is
         // complete and chosen here.  A viewer prefers a finished snapshot one slice older to waiting.
         if (is->written[1 - r] && hipEventQuery(is->ready[r]) != hipSuccess && hipEventQuery(is->ready[1 - r]) == hipSuccess) r = 1 - r;
-        ++is->readers[r]; }
+        ++is->readers[r]; if (snapshot_step) *snapshot_step = is->step_of[r]; }
     struct Release { InferState* is; int r; ~Release() { std::lock_guard<std::mutex> l(is->mu); --is->readers[r]; } } release{ is, r };
     HIPCHECK(use_device(m.device));
     hipStream_t s = sh->stream;
     HIPCHECK(hipStreamWaitEvent(s, is->ready[r], 0));
-    if (snapshot_step) *snapshot_step = is->step_of[r];
     Mat4 pose; std::memcpy(pose.m, pose16, 64);
     const uint32_t n_pix = box.w * box.h, S2 = 2 * m.oc.S;
     if (n_pix > is->out_cap) {                                           // one buffer of 5 floats per pixel: rgb | depth | mask laid out back to back for THIS crop, so one copy brings them home
@@ -728,7 +733,7 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
     { int rc = ensure_ema_current(m); if (rc) return rc; }
     hipStream_t s = m.train_stream;
     HIPCHECK(hipStreamSynchronize(s));
-    HIPCHECK(hipMemcpy(&m.h_state, m.d_state, sizeof(DevState), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(&m.h_state, m.d_state, offsetof(DevState, n_scatter), hipMemcpyDeviceToHost));      // (the head: the slot counters behind it are 16 KB the host never reads)
     const uint16_t* prm = (m.h_state.step > 0) ? m.P.ema : m.P.half;
     Mat4 pose; std::memcpy(pose.m, pose16, 64);
     const uint32_t n_pix = box.w * box.h, S2 = 2 * m.oc.S;
@@ -768,7 +773,7 @@ int model_density_grid(Model& m, int rx, int ry, int rz, float* out_host) {
     { int rc = ensure_ema_current(m); if (rc) return rc; }
     hipStream_t s = m.train_stream;
     HIPCHECK(hipStreamSynchronize(s));
-    HIPCHECK(hipMemcpy(&m.h_state, m.d_state, sizeof(DevState), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(&m.h_state, m.d_state, offsetof(DevState, n_scatter), hipMemcpyDeviceToHost));      // (the head: the slot counters behind it are 16 KB the host never reads)
     const uint16_t* prm = (m.h_state.step > 0) ? m.P.ema : m.P.half;
     const uint32_t total = (uint32_t)rx * ry * rz, chunk = m.ws_samples;
     for (uint32_t p0 = 0; p0 < total; p0 += chunk) {

@@ -44,3 +44,23 @@ def test_occupancy_skipping_is_opt_in_inert_during_warmup_and_close_afterwards(p
         assert np.isfinite(o.get_params(0)).all()
         o.close()
     ds.close()
+
+
+def test_occupancy_grid_keeps_refreshing_under_hipgraph_replay_after_an_odd_iteration_count(pkg, ss):
+    """the hipGraph path asks for a refresh only at the start of a captured pair of iterations; after an odd number of iterations an exact
+    `iter % 32 == 0` test was never true again.  The refresh is due at the first asked-for iteration at or after the next multiple of the interval."""
+    assert pkg.device_count() >= 1
+    sc = ss.make_scene(n_views=12, H=120, W=160, f=130.0, seed=0)
+    pkg.set_option("use_graph", 1)
+    try:
+        ds, obj = ge.make_problem(pkg, sc, dict(rays_per_batch=256, occupancy_skip=1))
+        obj.train(257)                                                               # odd: pairs now start at odd iterations
+        last, due = obj.occupancy_state(); assert last == 256 and due == 288, (last, due)
+        obj.train(64)                                                                # pairs at 257, 259, ...: 289 is the first at or after 288
+        last, due = obj.occupancy_state(); assert last >= 288 and due == (last // 32 + 1) * 32 and due > 257 + 64 - 32, (last, due)
+        obj.train(63)
+        last2, _ = obj.occupancy_state(); assert last2 > last
+        assert np.isfinite(obj.get_params(0)).all()
+        obj.close(); ds.close()
+    finally:
+        pkg.set_option("use_graph", 0)
