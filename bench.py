@@ -9,7 +9,7 @@ A "step" is one iteration of NeRF_Model::Train_Step's loop (GenerateBatch -> for
 gradient -> backward -> Adam/EMA), nerf_model.cu:1637-1646.
 
 N > 1: objects shard one per rank (CORE/src/nerf.cu:27-33: object k -> device k mod N), no data-path collective while
-training; the final render is gathered over RCCL (torch.distributed backend "nccl") from device-resident crops.
+training; the final render is gathered to rank 0 over RCCL (torch.distributed backend "nccl") from device-resident crops.
 Launched by torch.distributed.run the ranks come from the environment; launched plainly as `python bench.py --gpus N`
 the script spawns its N ranks itself (rank r -> device r mod visible devices; ranks that share a device use gloo, RCCL
 refuses two ranks on one GPU).
@@ -238,15 +238,15 @@ def main():
             occ = {"value": None, "note": "failed: %s" % e}
 
     # ---- quality: PSNR of a rendered crop vs the synthetic ground truth; N > 1: every rank's crop is rendered into a tensor on the
-    #      collective's device (HBM for RCCL) and gathered with one padded all_gather -- the only collective on the path
+    #      collective's device (HBM for RCCL) and gathered to rank 0 (sizes, then one point-to-point message per peer) -- the only collective on the path
     box = sc.objects[0]["boxes"][0]; v, x, y, h, w = (int(q) for q in box)
     gm = sc.instance[v, y:y + h, x:x + w] > 0
     gt = np.where(gm[..., None], sc.rgb[v, y:y + h, x:x + w] / 255.0, 1.0)
     psnr_of = lambda img: float(-10 * np.log10(max(1e-12, ((img - gt) ** 2).mean())))
     if dist is not None:
         packed = sharding.render_packed(obj, box, ss.colmajor(sc.Twc[v]), torch, coll_dev)
-        crops = sharding.gather_crops(dist, torch, [packed], coll_dev)
-        psnrs = [psnr_of(items[0][0]) for items in crops if items]
+        crops = sharding.gather_crops(dist, torch, [packed], coll_dev, root=0)          # gather-to-root: only rank 0 holds (and scores) the crops
+        psnrs = [psnr_of(items[0][0]) for items in crops if items] if crops is not None else []
     else:
         rgb, depth, mask = obj.render(box, ss.colmajor(sc.Twc[v]))
         psnrs = [psnr_of(rgb)]
@@ -312,7 +312,7 @@ def main():
                "config": {"workload": "OfflineNeRF-style training, 1 synthetic 'room'-like object per GPU, base.json defaults (hash L=16 F=2 T=2^16, MLP 64x1), "
                                       "R=4096 rays x S=32 samples/step, %d views 640x480 resident in HBM%s" % (args.views, (", T overridden to 2^%d" % args.log2_hashmap_size) if args.log2_hashmap_size else ""),
                           "objects": world, "rays_per_step": cfg.rays_per_batch, "samples_per_ray": cfg.n_samples, "backend": obj_backend(pkg, obj),
-                          "parallelism": "object-per-GPU (no training collective; %s all_gather of the final render%s)" % (
+                          "parallelism": "object-per-GPU (no training collective; %s gather-to-root of the final render%s)" % (
                               {"nccl": "RCCL", None: "RCCL"}.get(coll_backend, coll_backend), ", device-resident crops" if coll_backend == "nccl" else ""),
                           "launcher": "self-spawned ranks" if os.environ.get("MON_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "single process")},
                "timed_region": "median of %d independent repeats; each repeat: fresh object, %d warm-up steps, %d timed steps from init, barrier + device sync on both sides, max over ranks" % (len(reps), args.warmup, args.steps),

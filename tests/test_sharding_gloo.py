@@ -34,14 +34,20 @@ def _worker(rank, world, port, q):
         rgb = np.full((h, w, 3), k + 0.25, np.float32); depth = np.full((h, w), k + 0.5, np.float32); mask = np.full((h, w), float(k % 2), np.float32)
         c = sh.pack_crop(rgb, depth, mask)
         crops.append(torch.from_numpy(c) if k % 2 else c)          # both input kinds: host arrays and tensors already on the collective's device
-    got = sh.gather_crops(dist, torch, crops, "cpu")
+    got = sh.gather_crops(dist, torch, crops, "cpu", root=0)                       # gather-to-root: the root holds every rank's crops, the others nothing
     tmax = sh.max_over_ranks(dist, torch, 1.0 + rank, "cpu")
-    ok = True
-    for r in range(world):
+    ok = (got is None) == (rank != 0)
+    for r in range(world if rank == 0 else 0):
         ks = sh.objects_of_rank(n_objects, world, r)
         ok &= len(got[r]) == len(ks)
         for (rgb, depth, mask), k in zip(got[r], ks):
             ok &= rgb.shape == (3 + k, 4 + 2 * k, 3) and float(rgb[0, 0, 0]) == k + 0.25 and float(depth[-1, -1]) == k + 0.5 and float(mask[0, 0]) == float(k % 2)
+    # a second gather with another root and an empty contribution from this rank's side when it has nothing to send
+    got2 = sh.gather_crops(dist, torch, crops if rank == 0 else [], "cpu", root=1)
+    ok &= (got2 is None) == (rank != 1)
+    if rank == 1:
+        ok &= len(got2[1]) == 0 and len(got2[0]) == len(sh.objects_of_rank(n_objects, world, 0))
+    # (sharding.loopback_crop -- a message to oneself -- is an RCCL-only check, tests/test_rccl_gpu.py: gloo has no pair to itself)
     q.put((rank, mine, bool(ok), tmax))
     dist.destroy_process_group()
 
