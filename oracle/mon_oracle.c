@@ -66,8 +66,11 @@ typedef struct {
     int32_t decay_start, decay_interval;     /* base.json:10-11            */
     float   decay_base;          /* base.json:12                           */
     uint32_t param_seed;         /* nerf_model.h:145 (1337)                */
-    uint32_t reserved0;
-    uint64_t sample_seed;        /* cuRAND XORWOW stream parity is not attempted; counter RNG below */
+    uint32_t rng_flags;          /* "same inputs" mode for a comparison with the CUDA build (0 = this repo's defaults):
+                                  *   bits 0-1  sample stream: 0 counter RNG (below) | 1 XORWOW, cuRAND flavour | 2 XORWOW, rocRAND flavour
+                                  *   bit  4    parameter init in tcnn's generate_random_uniform element order (pcg32 draws interleaved per thread)
+                                  *   bits 16-31 XORWOW lanes (independent subsequences of the host generator) in units of 1024; 0 = 4 (cuRAND: 4096) */
+    uint64_t sample_seed;        /* key of the counter RNG; the XORWOW stream uses the reference's seed (the generator's default, 0: nerf_model.cu never sets one) */
     int32_t use_depth;           /* NeRF_Model::mbUseDepth                 */
     int32_t numerics_flags;      /* oracle-only, bit field (0 = the contract of DESIGN.md section 1):
                                   *   ORC_NUM_GRID_HALF  accumulate grid gradients sequentially in fp16 (tcnn: atomicAdd(__half2))
@@ -80,6 +83,9 @@ typedef struct {
 } orc_config;
 #define ORC_NUM_GRID_HALF 1
 #define ORC_NUM_TCNN_HALF 2
+#define ORC_RNG_STREAM(c) ((c)->rng_flags & 3u)
+#define ORC_RNG_TCNN_INIT(c) (((c)->rng_flags >> 4) & 1u)
+#define ORC_RNG_LANES(c) ((((c)->rng_flags >> 16) ? ((c)->rng_flags >> 16) : 4u) * 1024u)
 
 typedef struct { uint32_t FrameId, x, y, h, w; } orc_bbox;   /* common.h:18-23 (h before w) */
 
@@ -128,6 +134,75 @@ static inline float rand01(uint64_t seed, uint32_t stream, uint32_t step, uint32
     return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
 }
 float orc_rand01(uint64_t seed, uint32_t stream, uint32_t step, uint32_t idx) { return rand01(seed, stream, step, idx); }
+
+/* XORWOW (Marsaglia 2003, "Xorshift RNGs", the generator behind CURAND_RNG_PSEUDO_DEFAULT and ROCRAND_RNG_PSEUDO_XORWOW): the reference draws its three
+ * per-iteration arrays from ONE host generator with the default seed (nerf_model.cu:1432,1434,1468; created :1392-1394, no seed call) and a fresh one per
+ * Render (:1725-1728,1781).  Restated here from the published algorithm:
+ *   state: five 32-bit xorshift words x[0..4] + a Weyl counter d;  next: t = x0 ^ (x0 >> 2); shift the words down; x4 = (x4 ^ (x4 << 4)) ^ (t ^ (t << 1));
+ *          d += 362437; output = x4 + d.
+ *   host-API ordering (cuRAND documentation, CURAND_ORDERING_PSEUDO_DEFAULT): the value at offset n of a generate call comes from position
+ *          (n mod LANES) * 2^67 + floor(n / LANES) of the sequence, LANES = 4096: lane k starts 2^67 * k steps ahead (the Weyl counter is unaffected: 2^67 = 0 mod 2^32)
+ *          and the lanes keep their states from one generate call to the next.
+ *   the jump by 2^67: the xorshift part is linear over GF(2); its 160 x 160 transition matrix is squared 67 times here (no table).
+ * What differs between the two libraries, and is therefore a named assumption for the CUDA side (cuRAND is not in this image): the seed scramble --
+ *   rocRAND (rocrand_xorwow.h:107-118, checked against that header in tests/test_xorwow.py): s0 = lo ^ 0x2c7f967f, s1 = hi ^ 0xa03697cb, t0 = 1228688033 s0, t1 = 2073658381 s1;
+ *   cuRAND  (CURAND-A1, curand_kernel.h _curand_init_scratch, from the published header): s0 = lo ^ 0xaad26b49, s1 = hi ^ 0xf7dcefdd, t0 = 1099087573 s0, t1 = 2591861531 s1;
+ *   both then set x = {123456789 + t0, 362436069 ^ t0, 521288629 + t1, 88675123 ^ t1, 5783321 + t0}, d = 6615241 + t1 + t0 --
+ * and the integer -> (0, 1] map: rocRAND 2^-32 + v 2^-32, cuRAND (CURAND-A2) v 2^-32 + 2^-33, in fp32.
+ * CURAND-A3: a generate call of n values advances lane k by the number of values it produced (ceil((n - k) / LANES)); base.json's sizes are multiples of 4096. */
+typedef struct { uint32_t x[5], d; } orc_xw;
+static inline uint32_t xw_next(orc_xw* s) {
+    const uint32_t t = s->x[0] ^ (s->x[0] >> 2);
+    s->x[0] = s->x[1]; s->x[1] = s->x[2]; s->x[2] = s->x[3]; s->x[3] = s->x[4];
+    s->x[4] = (s->x[4] ^ (s->x[4] << 4)) ^ (t ^ (t << 1));
+    s->d += 362437u; return s->d + s->x[4];
+}
+static void xw_seed(orc_xw* s, uint64_t seed, int rocrand_flavour) {
+    const uint32_t s0 = (uint32_t)seed ^ (rocrand_flavour ? 0x2c7f967fu : 0xaad26b49u), s1 = (uint32_t)(seed >> 32) ^ (rocrand_flavour ? 0xa03697cbu : 0xf7dcefddu);
+    const uint32_t t0 = (rocrand_flavour ? 1228688033u : 1099087573u) * s0, t1 = (rocrand_flavour ? 2073658381u : 2591861531u) * s1;
+    s->x[0] = 123456789u + t0; s->x[1] = 362436069u ^ t0; s->x[2] = 521288629u + t1; s->x[3] = 88675123u ^ t1; s->x[4] = 5783321u + t0; s->d = 6615241u + t1 + t0;
+}
+static inline float xw_uniform(uint32_t v, int rocrand_flavour) { return rocrand_flavour ? 2.3283064e-10f + ((float)v * 2.3283064e-10f) : (float)v * 2.3283064e-10f + (2.3283064e-10f / 2.0f); }
+/* 160 x 160 bit matrices as 160 columns of 5 words: (M v) = xor of the columns whose bit is set in v */
+typedef struct { uint32_t col[160][5]; } xw_mat;
+static void xw_matvec(const xw_mat* M, const uint32_t v[5], uint32_t out[5]) {
+    uint32_t r[5] = { 0, 0, 0, 0, 0 };
+    for (int b = 0; b < 160; ++b) if ((v[b >> 5] >> (b & 31)) & 1u) for (int k = 0; k < 5; ++k) r[k] ^= M->col[b][k];
+    memcpy(out, r, 20);
+}
+static void xw_jump_2pow(xw_mat* M, int log2_steps) {          /* M = (one step of the xorshift part) ^ (2 ^ log2_steps) */
+    for (int b = 0; b < 160; ++b) {
+        orc_xw e; memset(&e, 0, sizeof e); e.x[b >> 5] = 1u << (b & 31); xw_next(&e); memcpy(M->col[b], e.x, 20);
+    }
+    xw_mat* T = (xw_mat*)malloc(sizeof(xw_mat));
+    for (int q = 0; q < log2_steps; ++q) { for (int b = 0; b < 160; ++b) xw_matvec(M, M->col[b], T->col[b]); memcpy(M, T, sizeof(xw_mat)); }
+    free(T);
+}
+/* the host generator: `lanes` states, lane k = seed state jumped k * 2^67 steps */
+typedef struct { orc_xw* lane; uint32_t lanes; int flavour; } orc_xwgen;
+static void xwgen_init(orc_xwgen* g, uint64_t seed, int rocrand_flavour, uint32_t lanes) {
+    static xw_mat* J = NULL;
+    #pragma omp critical(orc_xw_jump)
+    { if (!J) { J = (xw_mat*)malloc(sizeof(xw_mat)); xw_jump_2pow(J, 67); } }
+    g->lanes = lanes; g->flavour = rocrand_flavour; g->lane = (orc_xw*)realloc(g->lane, sizeof(orc_xw) * lanes);
+    xw_seed(&g->lane[0], seed, rocrand_flavour);
+    for (uint32_t k = 1; k < lanes; ++k) { g->lane[k].d = g->lane[0].d; xw_matvec(J, g->lane[k - 1].x, g->lane[k].x); }
+}
+static void xwgen_uniform(orc_xwgen* g, float* out, size_t n) {              /* curandGenerateUniform(gen, out, n) */
+    for (uint32_t k = 0; k < g->lanes; ++k) for (size_t j = k; j < n; j += g->lanes) out[j] = xw_uniform(xw_next(&g->lane[k]), g->flavour);
+}
+/* test hooks (tests/test_xorwow.py): raw draws of one lane, and one generate call of a fresh generator */
+void orc_xorwow_lane_draws(uint64_t seed, int rocrand_flavour, uint32_t lane, uint32_t n, uint32_t* out) {
+    orc_xwgen g; memset(&g, 0, sizeof g); xwgen_init(&g, seed, rocrand_flavour, lane + 1u);
+    for (uint32_t i = 0; i < n; ++i) out[i] = xw_next(&g.lane[lane]);
+    free(g.lane);
+}
+void orc_xorwow_generate(uint64_t seed, int rocrand_flavour, uint32_t lanes, uint32_t n_first, uint32_t n_second, float* out_second) {
+    /* a fresh generator, one call of n_first values (discarded), then a call of n_second values -> out_second (states carry over) */
+    orc_xwgen g; memset(&g, 0, sizeof g); xwgen_init(&g, seed, rocrand_flavour, lanes);
+    if (n_first) { float* tmp = (float*)malloc(sizeof(float) * n_first); xwgen_uniform(&g, tmp, n_first); free(tmp); }
+    xwgen_uniform(&g, out_second, n_second); free(g.lane);
+}
 
 /* Parameter-init stream: pcg32 as used by tcnn::default_rng_t (public-domain PCG, Jakob's
  * pcg32.h): seed(initstate, initseq=1).  Element k of the parameter vector takes the k-th
@@ -200,6 +275,8 @@ typedef struct {
     float *ray_o, *ray_d, *ray_dn, *ray_tmin, *ray_tmax, *target, *target_depth, *bgcol; uint8_t* ray_flag;
     float *pts, *tdist; uint16_t *E, *Hid, *O, *dO, *dHid, *dE;
     float *rgb_ray, *depth_ray, *mask_ray, *loss_ray; float loss;
+    /* XORWOW sample stream (cfg.rng_flags): the training generator and this iteration's three arrays SampleXY[2R] | RandColors[3R] | RandDt[S R] */
+    orc_xwgen xw; float* xw_buf; uint32_t xw_iter;     /* xw_iter: the iteration xw_buf holds (UINT32_MAX: none) */
 } orc_model;
 
 static uint32_t mlp_params(int W, int NH, int Epad) { return (uint32_t)(W * Epad + (NH - 1) * W * W + ORC_OUT_PAD * W); }
@@ -218,12 +295,31 @@ orc_model* orc_create(const orc_config* c) {
     /* TCNN-A5: MLP Xavier-uniform per matrix, grid U(-1e-4,1e-4); network params first. */
     pcg32 rng; pcg_seed(&rng, c->param_seed, 1u);
     uint32_t k = 0;
+    if (!ORC_RNG_TCNN_INIT(c)) {
     for (int layer = 0; layer <= m->NH; ++layer) {
         int rows = (layer == m->NH) ? ORC_OUT_PAD : m->W, cols = (layer == 0) ? m->Epad : m->W;
         float sc = sqrtf(6.0f / (float)(rows + cols));
         for (int i = 0; i < rows * cols; ++i, ++k) m->master[k] = pcg_float(&rng) * (2.0f * sc) - sc;
     }
     for (; k < m->n_params; ++k) m->master[k] = pcg_float(&rng) * 2e-4f - 1e-4f;
+    } else {
+        /* TCNN-A5b (rng_flags bit 4): tiny-cuda-nn's generate_random_uniform (common_device / random.h as published): one launch per tensor -- every MLP matrix,
+         * then the grid -- of ceil(n / (128 * 4)) blocks of 128 threads; thread i advances the generator by 4 i and writes its draws j = 0..3 to element
+         * i + n_threads * j; the host generator then advances by n.  So element e of a tensor takes draw 4 (e mod n_threads) + floor(e / n_threads) of the
+         * tensor's stretch of the pcg32 sequence, value = draw * (hi - lo) + lo. */
+        uint64_t base = 0;
+        for (int layer = 0; layer <= m->NH + 1; ++layer) {
+            size_t n; float lo, hi;
+            if (layer <= m->NH) { int rows = (layer == m->NH) ? ORC_OUT_PAD : m->W, cols = (layer == 0) ? m->Epad : m->W; float sc = sqrtf(6.0f / (float)(rows + cols)); n = (size_t)rows * cols; lo = -sc; hi = sc; }
+            else { n = m->n_grid; lo = -1e-4f; hi = 1e-4f; }
+            const size_t n_threads = ((n + 511) / 512) * 128;
+            float* draws = (float*)malloc(sizeof(float) * n_threads * 4);
+            pcg32 r2; pcg_seed(&r2, c->param_seed, 1u); for (uint64_t a = 0; a < base; ++a) pcg_next(&r2);
+            for (size_t a = 0; a < n_threads * 4; ++a) draws[a] = pcg_float(&r2);
+            for (size_t e = 0; e < n; ++e) m->master[k + e] = draws[4 * (e % n_threads) + e / n_threads] * (hi - lo) + lo;
+            free(draws); k += (uint32_t)n; base += n;
+        }
+    }
     for (k = 0; k < m->n_params; ++k) m->half[k] = f2h(m->master[k]);
     size_t R = (size_t)m->R, B = R * (size_t)m->S;
     m->valid = (uint8_t*)calloc(R, 1); m->sel = (uint32_t*)calloc(R, 4);
@@ -234,6 +330,8 @@ orc_model* orc_create(const orc_config* c) {
     m->E = (uint16_t*)calloc(B * m->Epad, 2); m->Hid = (uint16_t*)calloc(B * m->W * m->NH, 2); m->O = (uint16_t*)calloc(B * ORC_OUT, 2);
     m->dO = (uint16_t*)calloc(B * ORC_OUT, 2); m->dHid = (uint16_t*)calloc(B * m->W * m->NH, 2); m->dE = (uint16_t*)calloc(B * m->Epad, 2);
     m->rgb_ray = (float*)calloc(R * 3, 4); m->depth_ray = (float*)calloc(R, 4); m->mask_ray = (float*)calloc(R, 4); m->loss_ray = (float*)calloc(R, 4);
+    m->xw_iter = 0xffffffffu;
+    if (ORC_RNG_STREAM(c)) { xwgen_init(&m->xw, 0ull /* the generator's default seed: nerf_model.cu never sets one */, ORC_RNG_STREAM(c) == 2u, ORC_RNG_LANES(c)); m->xw_buf = (float*)calloc((5 + (size_t)m->S) * R, 4); }
     return m;
 }
 void orc_destroy(orc_model* m) {
@@ -242,6 +340,7 @@ void orc_destroy(orc_model* m) {
         m->ray_o, m->ray_d, m->ray_dn, m->ray_tmin, m->ray_tmax, m->target, m->target_depth, m->bgcol, m->ray_flag, m->pts, m->tdist,
         m->E, m->Hid, m->O, m->dO, m->dHid, m->dE, m->rgb_ray, m->depth_ray, m->mask_ray, m->loss_ray };
     for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); ++i) free(p[i]);
+    free(m->xw.lane); free(m->xw_buf);
     free(m);
 }
 uint32_t orc_n_params(const orc_model* m) { return m->n_params; }
@@ -316,8 +415,22 @@ static void pixel_ray(const orc_model* m, float px, float py, const float* Twc, 
  * nerf_model.cu:1429-1502 = GenerateRays (:369-446) + fill_rollover_rays (:280-294) +
  * GenerateInputPoints (:536-566).  The atomicAdd compaction order of the reference is
  * unspecified; this restatement (and the HIP path) use the stable candidate order. */
+/* one uniform of iteration `step`: stream 0 SampleXY[2R], 1 RandColors[3R], 2 RandDt[S R].  XORWOW mode: the three arrays of an iteration are generated once, in the
+ * reference's order (nerf_model.cu:1432,1434,1468), by the model's one host generator; iterations that were skipped over (advance_iter) consume their draws too. */
+static void xw_ensure(orc_model* m) {
+    const size_t R = (size_t)m->R, S = (size_t)m->S;
+    while (m->xw_iter == 0xffffffffu || m->xw_iter < m->iter) {
+        xwgen_uniform(&m->xw, m->xw_buf, 2 * R); xwgen_uniform(&m->xw, m->xw_buf + 2 * R, 3 * R); xwgen_uniform(&m->xw, m->xw_buf + 5 * R, S * R);
+        m->xw_iter = (m->xw_iter == 0xffffffffu) ? 0u : m->xw_iter + 1u;
+    }
+}
+static inline float batch_rand(const orc_model* m, uint32_t stream, uint32_t step, uint32_t idx) {
+    if (!ORC_RNG_STREAM(&m->cfg)) return rand01(m->cfg.sample_seed, stream, step, idx);
+    return m->xw_buf[(stream == 0 ? 0u : stream == 1 ? 2u * (uint32_t)m->R : 5u * (uint32_t)m->R) + idx];
+}
 static void generate_batch(orc_model* m) {
     const orc_config* c = &m->cfg; const int R = m->R, S = m->S; const uint32_t step = m->iter;
+    if (ORC_RNG_STREAM(c)) xw_ensure(m);
     float *co = (float*)malloc((size_t)R * 3 * 4), *cd = (float*)malloc((size_t)R * 3 * 4), *cdn = (float*)malloc((size_t)R * 4),
           *ct0 = (float*)malloc((size_t)R * 4), *ct1 = (float*)malloc((size_t)R * 4), *ctg = (float*)malloc((size_t)R * 3 * 4), *ctd = (float*)malloc((size_t)R * 4);
     uint8_t* cfl = (uint8_t*)malloc((size_t)R);
@@ -325,8 +438,10 @@ static void generate_batch(orc_model* m) {
     for (int i = 0; i < R; ++i) {
         m->valid[i] = 0;
         const orc_bbox* b = &m->boxes[(size_t)i % m->n_boxes];
-        float u0 = rand01(c->sample_seed, 0, step, 2u * i), u1 = rand01(c->sample_seed, 0, step, 2u * i + 1u);
+        float u0 = batch_rand(m, 0, step, 2u * i), u1 = batch_rand(m, 0, step, 2u * i + 1u);
         uint32_t x = b->x + (uint32_t)(u0 * (float)(int)b->w), y = b->y + (uint32_t)(u1 * (float)(int)b->h);
+        if (x > (uint32_t)m->Wimg - 1u) x = (uint32_t)m->Wimg - 1u;           /* guard (XORWOW uniforms reach 1.0: a box that touches the image border would read past the row, as the reference does) */
+        if (y > (uint32_t)m->H - 1u) y = (uint32_t)m->H - 1u;
         size_t pix = ((size_t)b->FrameId * m->H + y) * m->Wimg + x;
         uint8_t inst = m->rgba[pix * 4 + 3];
         if (inst != 0 && inst != m->inst) continue;                            /* occlusion :398-401 */
@@ -344,13 +459,13 @@ static void generate_batch(orc_model* m) {
     if (nv == 0) goto done;     /* reference: i % 0 UB (:287,:760); here the step is skipped */
     for (int j = 0; j < R; ++j) {
         uint32_t k = (uint32_t)j % nv, i = m->sel[k];
-        for (int a = 0; a < 3; ++a) m->bgcol[3 * j + a] = rand01(c->sample_seed, 1, step, 3u * k + a);     /* :760 RandomColor[(i % n)*3] */
+        for (int a = 0; a < 3; ++a) m->bgcol[3 * j + a] = batch_rand(m, 1, step, 3u * k + a);     /* :760 RandomColor[(i % n)*3] */
         memcpy(m->ray_o + 3 * j, co + 3 * i, 12); memcpy(m->ray_d + 3 * j, cd + 3 * i, 12);
         m->ray_dn[j] = cdn[i]; m->ray_tmin[j] = ct0[i]; m->ray_tmax[j] = ct1[i]; m->ray_flag[j] = cfl[i]; m->target_depth[j] = ctd[i];
         for (int a = 0; a < 3; ++a) m->target[3 * j + a] = cfl[i] ? ctg[3 * i + a] : m->bgcol[3 * j + a];     /* :438-441 */
         float dt = (ct1[i] - ct0[i]) / (float)S;
         for (int n = 0; n < S; ++n) {                                           /* :553-566 */
-            float t = fmaf(dt, (float)n + rand01(c->sample_seed, 2, step, (uint32_t)(j * S + n)), ct0[i]);
+            float t = fmaf(dt, (float)n + batch_rand(m, 2, step, (uint32_t)(j * S + n)), ct0[i]);
             size_t s = (size_t)j * S + n;
             for (int a = 0; a < 3; ++a) { float p = fmaf(t, cd[3 * i + a], co[3 * i + a]); m->pts[3 * s + a] = (p - m->amin[a]) / (m->amax[a] - m->amin[a]); }
             m->tdist[s] = t;
@@ -649,6 +764,9 @@ void orc_forward_backward(orc_model* m) { forward_backward(m); }
 void orc_render(const orc_model* m, orc_bbox box, const float* pose16, int pose_is_Toc, int use_ema, float* rgb, float* depth, float* mask) {
     const int S = 2 * m->S; const long n = (long)box.w * box.h;
     const uint16_t* prm = (use_ema && m->has_ema) ? m->ema : m->half;
+    /* XORWOW mode: the reference creates a NEW generator for every Render (default seed) and draws the whole crop's RandDt in one call (:1725-1728,1781) */
+    float* xwr = NULL;
+    if (ORC_RNG_STREAM(&m->cfg)) { orc_xwgen g; memset(&g, 0, sizeof g); xwgen_init(&g, 0ull, ORC_RNG_STREAM(&m->cfg) == 2u, ORC_RNG_LANES(&m->cfg)); xwr = (float*)malloc(sizeof(float) * (size_t)n * S); xwgen_uniform(&g, xwr, (size_t)n * S); free(g.lane); }
     #pragma omp parallel for schedule(dynamic, 16)
     for (long i = 0; i < n; ++i) {
         int x = (int)box.x + (int)(i % box.w), y = (int)box.y + (int)(i / box.w);
@@ -660,7 +778,7 @@ void orc_render(const orc_model* m, orc_bbox box, const float* pose16, int pose_
         uint16_t E[2 * ORC_MAX_LEVELS + 16], hid[256], out[4];
         for (int k = 0; k < S; ++k) {
             if (T < 1e-4f) break;
-            float t = fmaf(dt, (float)k + rand01(m->cfg.sample_seed, 3, 0, (uint32_t)(i * S + k)), t0), p[3];
+            float t = fmaf(dt, (float)k + (xwr ? xwr[(size_t)i * S + k] : rand01(m->cfg.sample_seed, 3, 0, (uint32_t)(i * S + k))), t0), p[3];
             for (int a = 0; a < 3; ++a) { float q = fmaf(t, d[a], o[a]); p[a] = (q - m->amin[a]) / (m->amax[a] - m->amin[a]); }
             encode_one(m, prm + m->n_mlp, p, E); mlp_forward_one(m, prm, E, hid, out);
             float c0 = logistic(h2f(out[0])), c1 = logistic(h2f(out[1])), c2 = logistic(h2f(out[2]));
@@ -670,6 +788,7 @@ void orc_render(const orc_model* m, orc_bbox box, const float* pose16, int pose_
         if (1.0f - T > 0.5f) { rgb[3 * i] = r[0] + T; rgb[3 * i + 1] = r[1] + T; rgb[3 * i + 2] = r[2] + T; depth[i] = dep / dn; mask[i] = 1.0f; }
         else { rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = 1.0f; depth[i] = 0.0f; mask[i] = 0.0f; }
     }
+    free(xwr);
 }
 
 /* GetDensityOnGrid nerf_model.cu:2007-2048: raw (pre-activation) channel 3 on a res^3 lattice of the unit cube

@@ -13,7 +13,7 @@ class OrcConfig(C.Structure):
                 ("per_level_scale", C.c_float), ("n_neurons", C.c_int32), ("n_hidden_layers", C.c_int32), ("rays_per_batch", C.c_int32),
                 ("n_samples", C.c_int32), ("loss_scale", C.c_float), ("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("epsilon", C.c_float), ("l2_reg", C.c_float), ("ema_decay", C.c_float), ("decay_start", C.c_int32), ("decay_interval", C.c_int32),
-                ("decay_base", C.c_float), ("param_seed", C.c_uint32), ("reserved0", C.c_uint32), ("sample_seed", C.c_uint64),
+                ("decay_base", C.c_float), ("param_seed", C.c_uint32), ("rng_flags", C.c_uint32), ("sample_seed", C.c_uint64),
                 ("use_depth", C.c_int32), ("numerics_flags", C.c_int32)]
 
 
@@ -34,9 +34,11 @@ def default_config(**kw):
         flags |= NUM_GRID_HALF
     if kw.pop("tcnn_half_accum", 0):               # ORC_NUM_TCNN_HALF: model of tiny-cuda-nn's own fp16 accumulation (encode, MLP fwd/bwd, dW)
         flags |= NUM_TCNN_HALF
+    # "same inputs" mode (mon_oracle.c orc_config.rng_flags): xorwow = 0 counter RNG | 1 cuRAND flavour | 2 rocRAND flavour, xorwow_lanes (multiple of 1024, default 4096), tcnn_init_order
+    rng = int(kw.pop("xorwow", 0)) | (int(bool(kw.pop("tcnn_init_order", 0))) << 4) | ((int(kw.pop("xorwow_lanes", 0)) // 1024) << 16)
     for k, v in kw.items():
         setattr(c, k, v)
-    c.numerics_flags |= flags
+    c.numerics_flags |= flags; c.rng_flags |= rng
     return c
 
 
@@ -80,6 +82,8 @@ def lib():
         L.orc_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.orc_composite.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_xorwow_lane_draws.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_xorwow_generate.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_gradient.restype = C.c_float
         L.orc_gradient.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.orc_level_table.restype = C.c_int; L.orc_level_table.argtypes = [C.POINTER(OrcConfig), C.c_void_p, C.c_void_p, C.c_void_p]

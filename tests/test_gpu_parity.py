@@ -745,3 +745,55 @@ def test_level_tile_encode_trains_bit_identically_to_the_gather_path():
         return [ln.split()[2] for ln in r.stdout.strip().split("\n") if ln.startswith("steps+")]
     a = run({}); b = run({"MON_OPTIONS": "lds_encode=0"}); c = run({"MON_OPTIONS": "use_graph=1"})
     assert a == b == c, (a, b, c)
+
+
+def test_training_parity_c2_three_seeds_against_the_serial_oracle_fixture(pkg, ss):
+    """BASELINE configs[1] (base.json defaults, full batch), 200 steps, THREE sampling seeds, against the oracle run with its SERIAL grid scatter in the build
+    container (tests/golden/c2_trained.npz, generator next to it: 13 minutes of CPU): mutual PSNR of every rendered training crop above the chaos floor's bar,
+    mean-of-three absolute PSNR within the floor's own spread of the oracle's (tests/test_numerics_study.py::trained_model_bars)."""
+    from test_numerics_study import trained_model_bars
+    _need_gpu(pkg)
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_trained.npz")))
+    mutual_floor, abs_tol = trained_model_bars()
+    sc = ss.make_scene(n_views=12, H=120, W=160, f=130.0, seed=0)
+    steps, every = int(g["steps"]), int(g["every"]); mutual, a_hip, a_ref = [], [], []
+    for seed in (int(s) for s in g["seeds"]):
+        ds, obj = ge.make_problem(pkg, sc, dict(C2, sample_seed=seed)); obj.set_backend(1)
+        loss = obj.train(steps)
+        assert np.isfinite(loss) and abs(loss - float(g["loss_s%d" % seed])) < max(float(g["loss_s%d" % seed]), 0.02)
+        for i, box in enumerate(sc.objects[0]["boxes"][::every]):
+            v, x, y, h, w = (int(q) for q in box)
+            rgb, depth, mask = obj.render(box, ss.colmajor(sc.Twc[v]))
+            gm = sc.instance[v, y:y + h, x:x + w] > 0; gt = np.where(gm[..., None], sc.rgb[v, y:y + h, x:x + w] / 255.0, 1.0)
+            mutual.append(psnr(rgb, g["rgb_s%d_c%d" % (seed, i)])); a_hip.append(psnr(rgb, gt)); a_ref.append(float(g["psnr_s%d" % seed][i]))
+            assert (mask.astype(bool) != g["mask_s%d_c%d" % (seed, i)].astype(bool)).mean() < 0.02          # the hard 0.5 opacity mask agrees on all but silhouette pixels
+        obj.close(); ds.close()
+    print("C2 x 3 seeds vs serial oracle: mutual PSNR min %.2f mean %.2f dB (bar %.2f), abs HIP %.2f dB, abs oracle %.2f dB (tol %.2f)" % (min(mutual), np.mean(mutual), mutual_floor, np.mean(a_hip), np.mean(a_ref), abs_tol))
+    assert min(mutual) > mutual_floor
+    assert abs(np.mean(a_hip) - np.mean(a_ref)) < abs_tol and np.mean(a_hip) > 24.0
+
+
+def test_parameter_trajectory_against_both_numeric_models_of_the_oracle(pkg, orc, small_scene):
+    """Between the 1 / 3 / 8-step parameter checks and the trained-model PSNR: the parameters after 1, 2, 4, 8, 16, 32 steps (BASELINE configs[0], the default
+    fused path) against the oracle under the numeric contract AND under its model of tiny-cuda-nn's fp16 accumulation (tcnn_half_accum).  Measure: the fraction
+    of parameters further than 1e-4 (1 % of a learning rate) from the oracle's.  Adam's early steps have magnitude lr whatever the gradient, so a gradient that
+    rounds to the other side of zero moves a weight by 2 lr and the trajectories decorrelate from there: the bound is a GROWTH bound (it doubles per doubling
+    of the step count from what one step leaves), and the distance to the contract must not exceed the distance to the tcnn-half model -- the implementation
+    sits on the contract's side of the reference's own numerics."""
+    _need_gpu(pkg)
+    kw = dict(C1, sample_seed=31)
+    ds, obj = ge.make_problem(pkg, small_scene, kw); obj.set_backend(1)
+    ref = ge.make_oracle(orc, small_scene, kw); th = ge.make_oracle(orc, small_scene, dict(kw, tcnn_half_accum=1))
+    nm = ref.n_mlp; done = 0; rows = []
+    for k in (1, 2, 4, 8, 16, 32):
+        obj.train(k - done); ref.train(k - done); th.train(k - done); done = k
+        a, b, c = obj.get_params(0), ref.buffer("master"), th.buffer("master")
+        far = lambda u, v, s: float((np.abs(u[s] - v[s]) > 1e-4).mean())
+        rows.append((k, far(a, b, slice(0, nm)), far(a, b, slice(nm, None)), far(a, c, slice(0, nm)), far(a, c, slice(nm, None)), far(b, c, slice(0, nm)), far(b, c, slice(nm, None))))
+    for r in rows:
+        print("step %2d: HIP vs contract MLP %.4f grid %.4f | HIP vs tcnn-half MLP %.4f grid %.4f | contract vs tcnn-half MLP %.4f grid %.4f" % r)
+    for k, m_c, g_c, m_t, g_t, m_ct, g_ct in rows:
+        assert m_c <= min(1.0, 5e-3 * 2 * k) and g_c <= min(1.0, 5e-3 * 2 * k), (k, m_c, g_c)          # growth bound: one step leaves < 0.5 % (parity.py), doubling per doubling
+        assert m_c <= m_t + 0.02 and g_c <= g_t + 0.02, (k, m_c, m_t, g_c, g_t)                          # never further from the contract than from the tcnn-half model
+    assert np.isfinite(obj.get_params(0)).all()
+    obj.close(); ds.close(); ref.close(); th.close()
