@@ -50,8 +50,12 @@ typedef struct mon_config {
     int32_t  decay_start, decay_interval;
     float    decay_base;
     uint32_t param_seed;           /* m_seed (1337)                                          */
-    uint32_t reserved0;
-    uint64_t sample_seed;          /* counter-RNG key replacing the cuRAND XORWOW stream     */
+    uint32_t rng_flags;            /* "same inputs" mode for a comparison with the CUDA build; 0 (default) = this repo's own streams:
+                                    *   bits 0-1   sample stream: 0 counter RNG keyed by sample_seed | 1 XORWOW in the reference's order of draws, cuRAND
+                                    *              flavour (nerf_model.cu:1432,1434,1468 and :1781; default seed) | 2 the same with rocRAND's seeding / float map
+                                    *   bit  4     parameter init in tcnn's generate_random_uniform element order (pcg32 draws interleaved per thread)
+                                    *   bits 16-31 XORWOW lanes in units of 1024 (0 = 4: cuRAND's 4096 subsequences)   -- ro-map_amd/csrc/xorwow.h */
+    uint64_t sample_seed;          /* key of the counter RNG that replaces the cuRAND XORWOW stream by default */
     int32_t  use_depth;            /* NeRF_Model::mbUseDepth                                 */
     int32_t  occupancy_skip;       /* 0 (default, the reference's behaviour: every one of the 32 samples of a ray is evaluated) | 1: occupancy-grid skipping -- a 64^3
                                     * bit grid over the object's box, refreshed from the training weights every 32 iterations after 256 warm-up iterations and dilated

@@ -149,7 +149,8 @@ float orc_rand01(uint64_t seed, uint32_t stream, uint32_t step, uint32_t idx) { 
  *   cuRAND  (CURAND-A1, curand_kernel.h _curand_init_scratch, from the published header): s0 = lo ^ 0xaad26b49, s1 = hi ^ 0xf7dcefdd, t0 = 1099087573 s0, t1 = 2591861531 s1;
  *   both then set x = {123456789 + t0, 362436069 ^ t0, 521288629 + t1, 88675123 ^ t1, 5783321 + t0}, d = 6615241 + t1 + t0 --
  * and the integer -> (0, 1] map: rocRAND 2^-32 + v 2^-32, cuRAND (CURAND-A2) v 2^-32 + 2^-33, in fp32.
- * CURAND-A3: a generate call of n values advances lane k by the number of values it produced (ceil((n - k) / LANES)); base.json's sizes are multiples of 4096. */
+ * CURAND-A3: the offset n of the ordering rule counts the values generated since the generator was created, ACROSS calls (what librocrand does with its 131 072 lanes:
+ * tests/test_xorwow_gpu.py); base.json's call sizes are multiples of 4096, for which every reading of the rule gives the same values. */
 typedef struct { uint32_t x[5], d; } orc_xw;
 static inline uint32_t xw_next(orc_xw* s) {
     const uint32_t t = s->x[0] ^ (s->x[0] >> 2);
@@ -179,17 +180,19 @@ static void xw_jump_2pow(xw_mat* M, int log2_steps) {          /* M = (one step 
     free(T);
 }
 /* the host generator: `lanes` states, lane k = seed state jumped k * 2^67 steps */
-typedef struct { orc_xw* lane; uint32_t lanes; int flavour; } orc_xwgen;
+typedef struct { orc_xw* lane; uint32_t lanes; int flavour; uint64_t offset; } orc_xwgen;      /* offset: values generated since creation (the n of the ordering rule runs across calls) */
 static void xwgen_init(orc_xwgen* g, uint64_t seed, int rocrand_flavour, uint32_t lanes) {
     static xw_mat* J = NULL;
     #pragma omp critical(orc_xw_jump)
     { if (!J) { J = (xw_mat*)malloc(sizeof(xw_mat)); xw_jump_2pow(J, 67); } }
-    g->lanes = lanes; g->flavour = rocrand_flavour; g->lane = (orc_xw*)realloc(g->lane, sizeof(orc_xw) * lanes);
+    g->lanes = lanes; g->flavour = rocrand_flavour; g->offset = 0; g->lane = (orc_xw*)realloc(g->lane, sizeof(orc_xw) * lanes);
     xw_seed(&g->lane[0], seed, rocrand_flavour);
     for (uint32_t k = 1; k < lanes; ++k) { g->lane[k].d = g->lane[0].d; xw_matvec(J, g->lane[k - 1].x, g->lane[k].x); }
 }
-static void xwgen_uniform(orc_xwgen* g, float* out, size_t n) {              /* curandGenerateUniform(gen, out, n) */
-    for (uint32_t k = 0; k < g->lanes; ++k) for (size_t j = k; j < n; j += g->lanes) out[j] = xw_uniform(xw_next(&g->lane[k]), g->flavour);
+static void xwgen_uniform(orc_xwgen* g, float* out, size_t n) {              /* curandGenerateUniform(gen, out, n): value j of this call sits at offset g->offset + j of the generator's output */
+    const uint32_t start = (uint32_t)(g->offset % g->lanes);
+    for (uint32_t k = 0; k < g->lanes; ++k) for (size_t j = (k + g->lanes - start) % g->lanes; j < n; j += g->lanes) out[j] = xw_uniform(xw_next(&g->lane[k]), g->flavour);
+    g->offset += n;
 }
 /* test hooks (tests/test_xorwow.py): raw draws of one lane, and one generate call of a fresh generator */
 void orc_xorwow_lane_draws(uint64_t seed, int rocrand_flavour, uint32_t lane, uint32_t n, uint32_t* out) {
@@ -202,6 +205,12 @@ void orc_xorwow_generate(uint64_t seed, int rocrand_flavour, uint32_t lanes, uin
     orc_xwgen g; memset(&g, 0, sizeof g); xwgen_init(&g, seed, rocrand_flavour, lanes);
     if (n_first) { float* tmp = (float*)malloc(sizeof(float) * n_first); xwgen_uniform(&g, tmp, n_first); free(tmp); }
     xwgen_uniform(&g, out_second, n_second); free(g.lane);
+}
+void orc_xorwow_generate_calls(uint64_t seed, int rocrand_flavour, uint32_t lanes, uint32_t n_calls, const uint32_t* sizes, float* out) {
+    /* a fresh generator and n_calls generate calls in sequence; outputs back to back */
+    orc_xwgen g; memset(&g, 0, sizeof g); xwgen_init(&g, seed, rocrand_flavour, lanes);
+    for (uint32_t c = 0; c < n_calls; ++c) { xwgen_uniform(&g, out, sizes[c]); out += sizes[c]; }
+    free(g.lane);
 }
 
 /* Parameter-init stream: pcg32 as used by tcnn::default_rng_t (public-domain PCG, Jakob's

@@ -84,6 +84,7 @@ def lib():
         L.orc_composite.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_xorwow_lane_draws.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_xorwow_generate.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_xorwow_generate_calls.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_gradient.restype = C.c_float
         L.orc_gradient.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.orc_level_table.restype = C.c_int; L.orc_level_table.argtypes = [C.POINTER(OrcConfig), C.c_void_p, C.c_void_p, C.c_void_p]

@@ -19,7 +19,7 @@ class MonConfig(C.Structure):
                 ("per_level_scale", C.c_float), ("n_neurons", C.c_int32), ("n_hidden_layers", C.c_int32), ("rays_per_batch", C.c_int32),
                 ("n_samples", C.c_int32), ("loss_scale", C.c_float), ("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("epsilon", C.c_float), ("l2_reg", C.c_float), ("ema_decay", C.c_float), ("decay_start", C.c_int32), ("decay_interval", C.c_int32),
-                ("decay_base", C.c_float), ("param_seed", C.c_uint32), ("reserved0", C.c_uint32), ("sample_seed", C.c_uint64),
+                ("decay_base", C.c_float), ("param_seed", C.c_uint32), ("rng_flags", C.c_uint32), ("sample_seed", C.c_uint64),
                 ("use_depth", C.c_int32), ("occupancy_skip", C.c_int32)]
 
 
@@ -226,8 +226,12 @@ def device_mem_info(device=0):
 
 def default_config(**kw):
     c = MonConfig(); _check(lib().mon_config_default(C.byref(c)))
+    kw = dict(kw)
+    # "same inputs" mode (mon_config.rng_flags): xorwow = 0 counter RNG | 1 cuRAND flavour | 2 rocRAND flavour, xorwow_lanes (multiple of 1024, default 4096), tcnn_init_order
+    rng = int(kw.pop("xorwow", 0)) | (int(bool(kw.pop("tcnn_init_order", 0))) << 4) | ((int(kw.pop("xorwow_lanes", 0)) // 1024) << 16)
     for k, v in kw.items():
         setattr(c, k, v)
+    c.rng_flags |= rng
     return c
 
 

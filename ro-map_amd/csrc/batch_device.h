@@ -13,7 +13,7 @@ __device__ __forceinline__ void gen_candidate(const BatchPtrs& b, const DatasetP
     bool ok = false;
     if (i < R) {
         const mon_frame_bbox box = b.boxes[i % nb];
-        const float u0 = rand01(oc.sample_seed, kStreamXY, iter, 2u * i), u1 = rand01(oc.sample_seed, kStreamXY, iter, 2u * i + 1u);
+        const float u0 = batch_rand(oc, kStreamXY, iter, 2u * i), u1 = batch_rand(oc, kStreamXY, iter, 2u * i + 1u);
         uint32_t x = box.x + (uint32_t)(u0 * (float)(int)box.w);          // :395
         uint32_t y = box.y + (uint32_t)(u1 * (float)(int)box.h);          // :396
         x = min(x, (uint32_t)ds.K.W - 1u); y = min(y, (uint32_t)ds.K.H - 1u);   // guard (reference reads out of bounds for boxes past the image)

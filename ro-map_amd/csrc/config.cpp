@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 #include "model.h"
+#include "xorwow.h"
 
 namespace mon {
 
@@ -194,12 +195,55 @@ void init_params_host(const mon_config& c, const NetDims& nd, uint32_t n_params,
     master.resize(n_params);
     Pcg32 rng; rng.seed(c.param_seed, 1u);
     uint32_t k = 0;
+    if (rng_tcnn_init_order(c.rng_flags)) {
+        // TCNN-A5b: tiny-cuda-nn's generate_random_uniform as published -- one launch per tensor (every MLP matrix, then the grid) of ceil(n / 512) blocks of 128 threads;
+        // thread i advances the generator by 4 i and writes draw j = 0..3 to element i + n_threads j; the host generator then advances by n.  Element e of a tensor
+        // = draw 4 (e mod n_threads) + floor(e / n_threads) of the tensor's stretch of the pcg32 sequence, scaled as draw * (hi - lo) + lo.
+        uint64_t base = 0;
+        for (int layer = 0; layer <= nd.NH + 1; ++layer) {
+            size_t n; float lo, hi;
+            if (layer <= nd.NH) { const int rows = (layer == nd.NH) ? kOutPad : nd.W, cols = (layer == 0) ? nd.Epad : nd.W; const float sc = std::sqrt(6.0f / (float)(rows + cols)); n = (size_t)rows * cols; lo = -sc; hi = sc; }
+            else { n = n_params - nd.n_mlp; lo = -1e-4f; hi = 1e-4f; }
+            const size_t n_threads = ((n + 511) / 512) * 128;
+            std::vector<float> draws(n_threads * 4);
+            Pcg32 r2; r2.seed(c.param_seed, 1u); for (uint64_t a = 0; a < base; ++a) (void)r2.next();
+            for (auto& d : draws) d = r2.next_float();
+            for (size_t e = 0; e < n; ++e) master[k + e] = draws[4 * (e % n_threads) + e / n_threads] * (hi - lo) + lo;
+            k += (uint32_t)n; base += n;
+        }
+        return;
+    }
     for (int layer = 0; layer <= nd.NH; ++layer) {
         const int rows = (layer == nd.NH) ? kOutPad : nd.W, cols = (layer == 0) ? nd.Epad : nd.W;
         const float sc = std::sqrt(6.0f / (float)(rows + cols));
         for (int i = 0; i < rows * cols; ++i, ++k) master[k] = rng.next_float() * (2.0f * sc) - sc;
     }
     for (; k < n_params; ++k) master[k] = rng.next_float() * 2e-4f - 1e-4f;
+}
+
+// ---- XORWOW lane states (xorwow.h): lane k = the seed state advanced 2^67 k steps.  The xorshift part of the state is linear over GF(2): its one-step matrix
+//      (160 columns of 5 words) is squared 67 times, once per process.
+namespace {
+struct XwMat { uint32_t col[160][5]; };
+void xw_matvec(const XwMat& M, const uint32_t v[5], uint32_t out[5]) {
+    uint32_t r[5] = { 0, 0, 0, 0, 0 };
+    for (int b = 0; b < 160; ++b) if ((v[b >> 5] >> (b & 31)) & 1u) for (int k = 0; k < 5; ++k) r[k] ^= M.col[b][k];
+    for (int k = 0; k < 5; ++k) out[k] = r[k];
+}
+const XwMat& xw_jump_2pow67() {
+    static const XwMat J = [] {
+        XwMat M{}, T{};
+        for (int b = 0; b < 160; ++b) { XorwowState e{}; e.x[b >> 5] = 1u << (b & 31); (void)xorwow_next(e); for (int k = 0; k < 5; ++k) M.col[b][k] = e.x[k]; }
+        for (int q = 0; q < 67; ++q) { for (int b = 0; b < 160; ++b) xw_matvec(M, M.col[b], T.col[b]); M = T; }
+        return M;
+    }();
+    return J;
+}
+}  // namespace
+void xorwow_lane_states(uint64_t seed, int flavour, uint32_t lanes, std::vector<XorwowState>& out) {
+    out.resize(lanes); xorwow_seed(out[0], seed, flavour);
+    const XwMat& J = xw_jump_2pow67();
+    for (uint32_t k = 1; k < lanes; ++k) { out[k].d = out[0].d; xw_matvec(J, out[k - 1].x, out[k].x); }
 }
 
 }  // namespace mon

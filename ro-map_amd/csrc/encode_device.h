@@ -41,7 +41,7 @@ __device__ __forceinline__ void points_sample(const PointsLds& l, const BatchPtr
     const uint32_t cand = (lo << 6) + pos;
     const float t0 = b.cand_t0[cand], t1 = b.cand_t1[cand];
     const float dtr = (t1 - t0) / 32.0f;
-    const float t = fmaf(dtr, (float)n + rand01(oc.sample_seed, kStreamDt, iter, ray * 32u + n), t0);
+    const float t = fmaf(dtr, (float)n + batch_rand(oc, kStreamDt, iter, ray * 32u + n), t0);
     float x[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) { const float p = fmaf(t, b.cand_d[3u * cand + d], b.cand_o[3u * cand + d]); x[d] = (p - oc.aabb.mn[d]) / (oc.aabb.mx[d] - oc.aabb.mn[d]); }

@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) k_build_rays(BatchPtrs b, ObjectConst oc,
     const bool is_obj = (rgba >> 24) != 0u;
     float bg[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) bg[a] = rand01(oc.sample_seed, kStreamColor, iter, 3u * k + a);     // :760, :438-441
+    for (int a = 0; a < 3; ++a) bg[a] = batch_rand(oc, kStreamColor, iter, 3u * k + a);     // :760, :438-441
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         b.ray_o[3 * j + a] = b.cand_o[3 * cand + a];
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) k_gen_samples(BatchPtrs b, ObjectConst oc
     if (render && b.ray_flag[j] == 0) { b.pts[3 * s] = 0.f; b.pts[3 * s + 1] = 0.f; b.pts[3 * s + 2] = 0.f; b.tdist[s] = 0.f; return; }   // :599-602 (left uninitialised there)
     const float t0 = b.ray_t0[j], t1 = b.ray_t1[j];
     const float dt = (t1 - t0) / (float)S;
-    const float t = fmaf(dt, (float)n + rand01(oc.sample_seed, rng_stream, iter, idx_base + s), t0);
+    const float t = fmaf(dt, (float)n + (render ? render_rand(oc, idx_base + s) : batch_rand(oc, rng_stream, iter, idx_base + s)), t0);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float p = fmaf(t, b.ray_d[3 * j + a], b.ray_o[3 * j + a]);

@@ -20,6 +20,7 @@
 #include "model.h"
 #include "batch_device.h"
 #include "encode_device.h"
+#include "xorwow.h"
 
 namespace mon {
 
@@ -233,6 +234,27 @@ __global__ void __launch_bounds__(256) k_build_tiles_image(LevelFast lt, int L, 
 void launch_build_tiles_image(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* params, uint16_t* half_tiles) {
     const uint32_t n = lf.offset[nd.L];
     hipLaunchKernelGGL(k_build_tiles_image, dim3((n + 255u) / 256u), dim3(256), 0, s, lf, nd.L, reinterpret_cast<const uint32_t*>(params + nd.n_mlp), reinterpret_cast<uint32_t*>(half_tiles));
+}
+
+// ------------------------------------------------------------------ XORWOW sample stream (xorwow.h; mon_config::rng_flags, default off)
+// One thread per lane of the host generator: up to three generate calls in sequence (an iteration's SampleXY, RandColors, RandDt; or one Render's RandDt), value j of a
+// call from lane j mod LANES; the lane's state goes back to memory for the next iteration's calls.
+__global__ void __launch_bounds__(256) k_xorwow_fill(XorwowState* __restrict__ states, uint32_t lanes, int flavour, uint32_t start /* generator offset mod lanes before the first call */,
+                                                     float* __restrict__ out0, uint32_t n0, float* __restrict__ out1, uint32_t n1, float* __restrict__ out2, uint32_t n2) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= lanes) return;
+    XorwowState st = states[k];
+    // value j of a call sits at offset (values generated before it) + j of the generator's output and comes from lane offset mod LANES
+    uint32_t s = start;
+    for (uint32_t j = (k + lanes - s) % lanes; j < n0; j += lanes) out0[j] = xorwow_uniform(xorwow_next(st), flavour);
+    s = (uint32_t)(((uint64_t)s + n0) % lanes);
+    for (uint32_t j = (k + lanes - s) % lanes; j < n1; j += lanes) out1[j] = xorwow_uniform(xorwow_next(st), flavour);
+    s = (uint32_t)(((uint64_t)s + n1) % lanes);
+    for (uint32_t j = (k + lanes - s) % lanes; j < n2; j += lanes) out2[j] = xorwow_uniform(xorwow_next(st), flavour);
+    states[k] = st;
+}
+void launch_xorwow_fill(hipStream_t s, void* lane_states, uint32_t lanes, int flavour, uint32_t start, float* out0, uint32_t n0, float* out1, uint32_t n1, float* out2, uint32_t n2) {
+    hipLaunchKernelGGL(k_xorwow_fill, dim3((lanes + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<XorwowState*>(lane_states), lanes, flavour, start, out0, n0, out1, n1, out2, n2);
 }
 
 void encode_tiles_setup_device() { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsBytes); }

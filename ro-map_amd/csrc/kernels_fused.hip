@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         const float rd[3] = { __builtin_bit_cast(float, lane_u(recv, 3)), __builtin_bit_cast(float, lane_u(recv, 4)), __builtin_bit_cast(float, lane_u(recv, 5)) };
         const float ro[3] = { __builtin_bit_cast(float, lane_u(recv, 6)), __builtin_bit_cast(float, lane_u(recv, 7)), __builtin_bit_cast(float, lane_u(recv, 8)) };
         const float dtr = (t1 - t0) / 32.0f; q.t0 = t0; q.t1 = t1;
-        q.t = fmaf(dtr, (float)n + rand01(a.oc.sample_seed, kStreamDt, iter, ray * 32u + (uint32_t)n), t0);
+        q.t = fmaf(dtr, (float)n + batch_rand(a.oc, kStreamDt, iter, ray * 32u + (uint32_t)n), t0);
 #pragma unroll
         for (int d = 0; d < 3; ++d) { const float p = fmaf(q.t, rd[d], ro[d]); q.x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
         // occupancy-grid skipping (default off): a sample whose cell the grid marks empty is not evaluated -- no gathers, alpha = 0, no gradient
@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         const float Tfin = lane_bcast(tincl, nact - 1);                                    // broadcast from half-wave 0 (sample 0 is always active: nact >= 1)
         const float wgt = active ? alpha * T : 0.f;
         const float p0 = scan_add32(wgt * c0), p1 = scan_add32(wgt * c1), p2 = scan_add32(wgt * c2), pd = scan_add32(wgt * t);
-        const float bg0 = rand01(a.oc.sample_seed, kStreamColor, iter, 3u * kth), bg1 = rand01(a.oc.sample_seed, kStreamColor, iter, 3u * kth + 1u), bg2 = rand01(a.oc.sample_seed, kStreamColor, iter, 3u * kth + 2u);   // :760, :438-441
+        const float bg0 = batch_rand(a.oc, kStreamColor, iter, 3u * kth), bg1 = batch_rand(a.oc, kStreamColor, iter, 3u * kth + 1u), bg2 = batch_rand(a.oc, kStreamColor, iter, 3u * kth + 2u);   // :760, :438-441
         const float rgb0 = lane_bcast(p0, 31) + Tfin * bg0, rgb1 = lane_bcast(p1, 31) + Tfin * bg1, rgb2 = lane_bcast(p2, 31) + Tfin * bg2;
         const float dep = lane_bcast(pd, 31), mask = 1.f - Tfin;
         // ---- loss + dL/dO (VolumeRenderGradient_No_Compacted :853-953)
@@ -1223,7 +1223,7 @@ __global__ void __launch_bounds__(256) k_fused_render(FusedArgs a, uint32_t n_ra
             for (uint32_t tile = 0; tile < 2u; ++tile) {
                 if (Tc < kTransmittanceEps) break;
                 const uint32_t k = tile * 32u + (uint32_t)n;
-                const float t = fmaf(dtr, (float)k + rand01(a.oc.sample_seed, kStreamRender, 0u, idx_base + ray * S2 + k), t0);
+                const float t = fmaf(dtr, (float)k + render_rand(a.oc, idx_base + ray * S2 + k), t0);
                 float x[3];
 #pragma unroll
                 for (int d = 0; d < 3; ++d) { const float p = fmaf(t, a.b.ray_d[3 * ray + d], a.b.ray_o[3 * ray + d]); x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }

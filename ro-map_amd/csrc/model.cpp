@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 #include "model.h"
+#include "xorwow.h"
 
 namespace mon {
 
@@ -359,6 +360,16 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         (rc = dev_alloc(m, m.d_state, 2)) || (rc = dev_alloc(m, m.d_dw_partials, (size_t)(fused_partial_cols(m.nd) + 64) * kMaxFusedGrid)) ||
         (rc = dev_alloc(m, m.d_out_rgb, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_depth, kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_mask, kRenderChunkRays))) return rc;
     m.out_cap = kRenderChunkRays;
+    if (rng_stream_mode(cfg.rng_flags)) {          // "same inputs" mode: the reference's XORWOW stream (xorwow.h) instead of the counter RNG
+        m.xw_lanes = rng_xorwow_lanes(cfg.rng_flags); m.xw_flavour = rng_stream_mode(cfg.rng_flags) == 2 ? kXorwowRocrand : kXorwowCurand;
+        std::vector<XorwowState> st; xorwow_lane_states(0ull /* the generator's default seed: nerf_model.cu never sets one */, m.xw_flavour, m.xw_lanes, st);
+        XorwowState *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;
+        if ((rc = dev_alloc(m, d_a, m.xw_lanes, false)) || (rc = dev_alloc(m, d_b, m.xw_lanes, false)) || (rc = dev_alloc(m, d_c, m.xw_lanes, false)) ||
+            (rc = dev_alloc(m, m.d_xw, 2 * (size_t)(5 + S) * R))) return rc;
+        HIPCHECK(hipMemcpy(d_a, st.data(), sizeof(XorwowState) * m.xw_lanes, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(d_c, st.data(), sizeof(XorwowState) * m.xw_lanes, hipMemcpyHostToDevice));
+        m.d_xw_states = d_a; m.d_xw_render_states = d_b; m.d_xw_render_init = d_c;
+        m.oc.xw[0] = m.d_xw; m.oc.xw[1] = m.d_xw + (size_t)(5 + S) * R;
+    }
     // lazy EMA: only where the optimizer is not the dense variant anyway and the table is large (> 8 M parameters); MON_LAZY_EMA=0/1 overrides
     m.lazy_ema = m.n_grid > (8u << 20);
     if (options().lazy_ema >= 0) m.lazy_ema = options().lazy_ema != 0;
@@ -405,7 +416,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     m.backend = fused_supported(m.nd, S, m.oc.R) ? 1 : 0;
     if (options().backend >= 0) m.backend = options().backend ? (fused_supported(m.nd, S, m.oc.R) ? 1 : 0) : 0;
     m.mesh = mesh_state_create(m.device);
-    if (m.backend == 1 && !m.lazy_ema) {          // (tables above 8 M parameters keep their EMA lazily and would cost 2 x 200 MB of snapshots: they render on the train stream)
+    if (m.backend == 1 && !m.lazy_ema && !m.d_xw) {          // (the XORWOW mode renders on the train stream: one generator per Render, like the reference; tables above 8 M parameters keep their EMA lazily and would cost 2 x 200 MB of snapshots: they render on the train stream)
         InferState* is = new InferState(); m.infer = is;
         if ((rc = infer_shared_get(m.device, (size_t)ds->K.W * (size_t)ds->K.H, &is->shared))) return rc;      // (a whole frame fits: no growth in front of a viewer)
         for (int k = 0; k < 2; ++k) { if ((rc = dev_alloc(m, is->snap[k], n, false))) return rc; HIPCHECK(hipEventCreateWithFlags(&is->ready[k], hipEventDisableTiming)); }
@@ -529,6 +540,14 @@ static void collect_profile(Model& m) {
 // One iteration of Train_Step's loop body (nerf_model.cu:1637-1646), enqueued without host syncs.
 static void enqueue_iteration(Model& m, int stages) {
     hipStream_t s = m.train_stream; const uint32_t B = m.oc.R * m.oc.S;
+    if (m.d_xw) {          // XORWOW mode: the generate calls of this iteration and of the next one (whose candidates and positions are prepared during this one), in order, once each
+        const uint32_t R = m.oc.R, n_it = (5u + m.oc.S) * R;
+        while (m.xw_filled <= m.enq_iter + 1u) {
+            float* set = m.d_xw + (size_t)(m.xw_filled & 1u) * n_it;
+            launch_xorwow_fill(s, m.d_xw_states, m.xw_lanes, m.xw_flavour, (uint32_t)(m.xw_offset % m.xw_lanes), set, 2u * R, set + 2u * R, 3u * R, set + 5u * R, m.oc.S * R);      // :1432, :1434, :1468
+            ++m.xw_filled; m.xw_offset += n_it;
+        }
+    }
     if (stages & 1) {      // GenerateBatch :1429-1502
         ProfScope ps(m, MON_K_BATCH);
         if (m.backend == 1) { if (!m.next_ready) { launch_candidates_and_frags(s, m.B, m.ds->ptrs(), m.oc, m.d_state, m.P.half, m.nd, m.d_frag_train); if (m.d_half_tiles) launch_build_tiles_image(s, m.lf, m.nd, m.P.half, m.d_half_tiles); } }   // otherwise the last k_optimizer already did all of it
@@ -592,7 +611,7 @@ static void enqueue_iteration(Model& m, int stages) {
         launch_optimizer(s, P, m.opt, m.d_state, m.d_state_next, nx, options().opt_lazy_below < 0 ? (m.oc.R * m.oc.S) / 8u : (uint32_t)options().opt_lazy_below); m.scatter_pending = false;
         std::swap(m.d_state, m.d_state_next);                // the next iteration (and the host's read-back) uses the state this launch prepares
         if (pos_mode) std::swap(m.B, m.B_alt);               // ... and the candidate set k_encode_tiles filled for it
-        m.next_ready = (m.backend == 1 && fold); m.points_ready = pos_mode;
+        m.next_ready = (m.backend == 1 && fold); m.points_ready = pos_mode; ++m.enq_iter;
     }
 }
 
@@ -627,7 +646,8 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     // once the host has seen that count well below the switch point it stops launching the (then empty) binning kernels at all.
     m.big_active = m.big_switch && (m.h_state.n_scatter_last == 0u || m.h_state.n_scatter_last > m.big_switch / 2u);
     const bool use_graph_env = options().use_graph != 0;
-    const bool use_graph = use_graph_env && !m.profiling && stages == 7 && iters >= 2 && !(m.d_occ && !m.occ_refreshed_iter);      // (the first occupancy refresh changes a kernel argument)
+    m.enq_iter = m.h_state.iter;                             // (nothing of this object is in flight between calls: the read-back at the end of the last one is current)
+    const bool use_graph = use_graph_env && !m.profiling && stages == 7 && iters >= 2 && !(m.d_occ && !m.occ_refreshed_iter) && !m.d_xw;      // (the first occupancy refresh changes a kernel argument)
     // chunks of iterations go through the device's training lanes (whole steps only; big-table objects are HBM-bound in their optimizer and gain from more overlap, not less)
     const bool lanes_on = stages == 7 && m.big_switch == 0u; const int chunk = options().lane_chunk >= 2 ? (options().lane_chunk & ~1) : 2;
     if (use_graph) {
@@ -742,6 +762,13 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
         const size_t cap = std::max<size_t>(n_pix, 2 * m.out_cap);   // doubling: the superseded buffers (freed with the object) add up to less than the live one
         int rc; if ((rc = dev_alloc(m, m.d_out_rgb, 3 * cap, false)) || (rc = dev_alloc(m, m.d_out_depth, cap, false)) || (rc = dev_alloc(m, m.d_out_mask, cap, false))) return rc;
         m.out_cap = cap;
+    }
+    if (m.d_xw) {          // XORWOW mode: a NEW generator per Render (default seed) draws the whole crop's RandDt in one call (nerf_model.cu:1725-1728, :1781)
+        const size_t need = (size_t)n_pix * S2;
+        if (need > m.xw_render_cap) { int rc = dev_alloc(m, m.d_xw_render, need, false); if (rc) return rc; m.xw_render_cap = need; }
+        HIPCHECK(hipMemcpyAsync(m.d_xw_render_states, m.d_xw_render_init, sizeof(XorwowState) * m.xw_lanes, hipMemcpyDeviceToDevice, s));
+        launch_xorwow_fill(s, m.d_xw_render_states, m.xw_lanes, m.xw_flavour, 0u, m.d_xw_render, (uint32_t)need, nullptr, 0u, nullptr, 0u);
+        m.oc.xw_render = m.d_xw_render;
     }
     for (uint32_t p0 = 0; p0 < n_pix; p0 += kRenderChunkRays) {
         const uint32_t n = (n_pix - p0) < kRenderChunkRays ? (n_pix - p0) : kRenderChunkRays;

@@ -48,7 +48,16 @@ struct ObjectConst {
     uint32_t instance_id; uint32_t R; uint32_t S; int use_depth;
     uint64_t sample_seed;
     float loss_scale;
+    // "same inputs" mode (mon_config::rng_flags, xorwow.h): per iteration parity the three arrays SampleXY[2R] | RandColors[3R] | RandDt[S R] that k_xorwow_fill wrote
+    // for that iteration; nullptr = the counter RNG.  xw_render: RandDt of the crop being rendered (index = sample index within the crop).
+    const float* xw[2]; const float* xw_render;
 };
+// one uniform of training iteration `step`, stream kStreamXY / kStreamColor / kStreamDt (index semantics of the reference's arrays: nerf_model.cu:395-396, :760, :553)
+__device__ __forceinline__ float batch_rand(const ObjectConst& oc, uint32_t stream, uint32_t step, uint32_t idx) {
+    if (oc.xw[0]) return oc.xw[step & 1u][(stream == kStreamXY ? 0u : stream == kStreamColor ? 2u * oc.R : 5u * oc.R) + idx];
+    return rand01(oc.sample_seed, stream, step, idx);
+}
+__device__ __forceinline__ float render_rand(const ObjectConst& oc, uint32_t idx) { return oc.xw_render ? oc.xw_render[idx] : rand01(oc.sample_seed, kStreamRender, 0u, idx); }
 
 struct BatchPtrs {
     const mon_frame_bbox* boxes;
@@ -164,6 +173,8 @@ void encode_tiles_setup_device();
 void launch_sample_points(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* x_all);
 void launch_encode_tiles(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* half_tiles, const float* x_all, uint16_t* e_soa, uint32_t B, const DevState* st,
                          const BatchPtrs* b_next_or_null, const DatasetPtrs& ds, const ObjectConst& oc);      // b_next: the candidate set GenerateRays of the next iteration goes to
+// XORWOW sample stream (kernels_encode.hip k_xorwow_fill): one thread per lane, the generate calls of one iteration / one Render in the reference's order
+void launch_xorwow_fill(hipStream_t s, void* lane_states, uint32_t lanes, int flavour, uint32_t start_lane, float* out0, uint32_t n0, float* out1, uint32_t n1, float* out2, uint32_t n2);
 void launch_build_tiles_image(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* params, uint16_t* half_tiles);
 void launch_occupancy_update(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const ObjectConst& oc, uint16_t* frag_image, float raw_threshold, uint32_t* tmp, uint32_t* bits);
 uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl);
@@ -218,6 +229,9 @@ struct Model {
     DevState h_state{}; DevState* h_state_pinned = nullptr; int backend = 0; bool profiling = false; int fused_dump = 0;
     bool lazy_ema = false, ema_pending = false;   // large tables: EMA of untouched chunks is brought up to date on demand (k_ema_finalize)
     bool scatter_pending = false;   // a fused forward/backward was enqueued whose slot counter has not been reset by an optimizer step yet
+    // XORWOW sample stream: lane states of the training generator (device), the two per-parity array sets, the iteration the fills have reached, the per-Render generator
+    void* d_xw_states = nullptr; float* d_xw = nullptr; uint32_t xw_filled = 0, xw_lanes = 0; int xw_flavour = 0; uint32_t enq_iter = 0; uint64_t xw_offset = 0;      // xw_offset: values the training generator has produced
+    void* d_xw_render_states = nullptr; void* d_xw_render_init = nullptr; float* d_xw_render = nullptr; size_t xw_render_cap = 0;
     bool pre_active = false, points_ready = false;   // level-tile encode: used by the iteration being enqueued / the next batch's positions were written by the last k_optimizer
     bool next_ready = false;     // fused backend: candidates + fragment image of the coming iteration were already produced by the last k_optimizer
     mon_profile prof{}; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pending;

@@ -34,7 +34,9 @@ def test_host_ordering_and_state_carry_over(orc):
     first = np.zeros(n1, np.float32); orc.lib().orc_xorwow_generate(C.c_uint64(0), 1, lanes, 0, n1, _p(first))
     second = np.zeros(n2, np.float32); orc.lib().orc_xorwow_generate(C.c_uint64(0), 1, lanes, n1, n2, _p(second))
     both = np.zeros(n1 + n2, np.float32); orc.lib().orc_xorwow_generate(C.c_uint64(0), 1, lanes, 0, n1 + n2, _p(both))
-    assert np.array_equal(first, both[:n1]) and np.array_equal(second, both[n1:])          # sizes that are multiples of LANES: two calls = one call
+    assert np.array_equal(first, both[:n1]) and np.array_equal(second, both[n1:])          # two calls = one call of the total size ...
+    odd = np.zeros(100 + 5000, np.float32); sz = np.array([100, 5000], np.uint32); orc.lib().orc_xorwow_generate_calls(C.c_uint64(0), 1, lanes, 2, _p(sz), _p(odd))
+    assert np.array_equal(odd, both[:5100])                                                 # ... whatever the sizes: the offset of the ordering rule runs across calls
     for lane in (0, 1, 4095):
         d = np.zeros(5, np.uint32); orc.lib().orc_xorwow_lane_draws(C.c_uint64(0), 1, lane, 5, _p(d))
         u = np.float32(2.3283064e-10) + d.astype(np.float32) * np.float32(2.3283064e-10)
