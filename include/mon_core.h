@@ -240,8 +240,8 @@ int mon_png_write(const char* path, int width, int height, int channels, int bit
 /* Process-wide test and tuning switches (none is needed for normal operation; defaults are the product behaviour).  Read when an object is
  * created or a training call is enqueued -- set them before.  Names: "backend" (-1 auto, 0 layer-at-a-time kernels, 1 fused), "use_graph" (replay
  * an iteration as a hipGraph), "lazy_ema" (-1 auto: tables above 8 M parameters), "big_switch" (gradient-carrying samples below which the
- * large-table levels scatter with global atomics; 0 = always), "touched_flags", "lds_scatter", "fold_reduce", "fold_next" (1 = on: the
- * optimizer's chunk flags, the LDS scatter, the dW row sums inside k_grid_scatter, next-iteration preparation inside k_optimizer),
+ * large-table levels scatter with global atomics; 0 = always), "touched_flags" (1 = on: the lazy optimizer's chunk flags), "lds_encode" (1 = on: the forward
+ * hash-grid encode from LDS-resident level tiles, kernels_encode.hip; 0 = gathers inside k_fused_train -- both give bit-identical parameters),
  * "fused_grid", "opt_blocks" (workgroup caps, 0 = built-in), "scatter_bins" (ray bins of the compacted gradient rows, a power of two up to 128; 0 = built-in 16), "fused_ablate" (timing ablations of k_fused_train; bit 16 = keep zero-gradient
  * samples, used by the exactness test), "offline_outer" / "offline_inner" (NerfManagerOffline's 10 x 500 iterations, nerf_manager.cu:89).
  * Unknown names return MON_ERR_ARG. */

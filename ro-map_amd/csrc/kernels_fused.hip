@@ -1154,7 +1154,6 @@ uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl
     uint32_t mask = 0; sl.n_levels = 0; sl.max_P = 0;
     for (int l = 0; l < kMaxLevels; ++l) { sl.P[l] = 0; sl.level[l] = 0; sl.entry_offset[l] = lt.offset[l]; }
     sl.entry_offset[kMaxLevels] = lt.offset[kMaxLevels];
-    if (!options().lds_scatter) return 0u;
     // A level of up to 16 tiles fits the 16-workgroup plan, but with more than 4 tiles every workgroup walks all the samples of the batch
     // for its one tile.  When the table has levels that need the large-table path anyway (kernels_bigscatter.hip), levels of 5..16
     // tiles go there too.

@@ -341,6 +341,7 @@ struct OnlineManager {
     std::string cfg_path; bool use_depth = false; int iters = 500, n_dev = 0, next_dev = 0; mon_config cfg{};
     size_t n_images = 0; std::vector<Dataset*> ds; std::vector<std::vector<std::unique_ptr<std::mutex>>> ds_mutex; std::vector<std::unique_ptr<std::atomic<int>>> dev_objects;
     std::map<std::string, uint32_t> stamp_to_idx; std::vector<OnlineObject*> objs; std::vector<std::thread> threads;
+    std::mutex mu_objs;      // objs grows on the SLAM thread (CreateNeRF) while the viewer looks objects up (DrawMesh, renders): look-ups copy the pointer under this lock
     int H = 0, W = 0; std::map<uint32_t, std::vector<float>> poses;       // host copy of the poses for train.txt (nerf.cu:369-373 reads them back from the device)
 };
 
@@ -367,13 +368,16 @@ static int train_sliced(OnlineObject* o) {
     for (int done = 0; done < o->iterations && rc == MON_OK; ) {
         while (o->waiters.load() > 0) std::this_thread::yield();
         const int sharing = o->device_objects ? o->device_objects->load() : 1;
-        int n = kOnlineSlice / (sharing > 0 ? sharing : 1); const int n_min = options().online_slice_min > 0 ? options().online_slice_min : 2; if (n < n_min) n = n_min; if (n > o->iterations - done) n = o->iterations - done;
+        int n = kOnlineSlice / (sharing > 0 ? sharing : 1); const long slice_min = options().online_slice_min; const int n_min = slice_min > 0 ? (int)slice_min : 2; if (n < n_min) n = n_min; if (n > o->iterations - done) n = o->iterations - done;
         std::unique_lock<std::mutex> dl(*o->dataset_mutex); std::lock_guard<std::mutex> lm(o->mu_model);
         rc = model_train(*o->model, n, &o->last_loss, 7); done += n;
         if (rc == MON_OK && done >= o->iterations) rc = model_publish_snapshot(*o->model);       // viewers see the end of every Train_Step_Online
     }
     return rc;
 }
+
+static OnlineObject* online_object(OnlineManager& m, size_t idx) { std::lock_guard<std::mutex> l(m.mu_objs); return idx < m.objs.size() ? m.objs[idx] : nullptr; }
+static std::vector<OnlineObject*> online_objects(OnlineManager& m) { std::lock_guard<std::mutex> l(m.mu_objs); return m.objs; }
 
 static void train_online_thread(OnlineObject* o) {                       // NeRF::TrainOnline, nerf.cu:187-253
     int train_step_count = 0;
@@ -489,7 +493,7 @@ int mon_online_new_frame(mon_online* h, uint32_t img_id, const char* timestamp, 
         // (UpdateNeRFBbox) -- so training is only excluded when an id that is already in use is overwritten.
         const bool overwrite = img_id < m.ds[g]->max_frames && m.ds[g]->present[img_id];
         std::vector<std::unique_ptr<AnnouncedLock>> held;
-        if (overwrite) for (auto* o : m.objs) if (o->device == g) held.emplace_back(new AnnouncedLock(o, *o->dataset_mutex));
+        if (overwrite) for (auto* o : online_objects(m)) if (o->device == g) held.emplace_back(new AnnouncedLock(o, *o->dataset_mutex));
         const int rc = dataset_add_frame(m.ds[g], img_id, bgr, channels, 1, instance, m.use_depth ? depth : nullptr, Twc16);
         if (rc) return rc;
     }
@@ -504,9 +508,9 @@ int mon_online_update_dataset(mon_online* h, uint32_t cur_id, uint32_t frame_num
         // every object's dataset mutex on the device (nerf_data.cu:345-347), announced so a training slice lets the update in; the candidate rays
         // an object prepared for its next iteration used the old poses: they are regenerated
         std::vector<std::unique_ptr<AnnouncedLock>> held, models;
-        for (auto* o : m.objs) if (o->device == g) held.emplace_back(new AnnouncedLock(o, *o->dataset_mutex));
+        for (auto* o : online_objects(m)) if (o->device == g) held.emplace_back(new AnnouncedLock(o, *o->dataset_mutex));
         const int rc = dataset_update_poses(m.ds[g], head, frame_num, Twc16s); if (rc) return rc;
-        for (auto* o : m.objs) if (o->device == g && o->model) { AnnouncedLock lm(o, o->mu_model); o->model->next_ready = false; }
+        for (auto* o : online_objects(m)) if (o->device == g && o->model) { AnnouncedLock lm(o, o->mu_model); o->model->next_ready = false; }
     }
     for (uint32_t i = 0; i < frame_num; ++i) m.poses[head + i].assign(Twc16s + 16 * (size_t)i, Twc16s + 16 * (size_t)i + 16);
     return MON_OK;
@@ -528,14 +532,14 @@ int mon_online_create_nerf(mon_online* h, int cls, const float* Tow16, const flo
     int rc = model_create(m.ds[o->device], m.cfg, cls, o->Tow, o->amin, o->amax, &o->model);
     if (rc) { delete o; return rc; }
     o->handle.m = o->model; o->device_objects = m.dev_objects[o->device].get(); m.dev_objects[o->device]->fetch_add(1);
-    *idx_out = m.objs.size(); m.objs.push_back(o);
+    { std::lock_guard<std::mutex> l(m.mu_objs); *idx_out = m.objs.size(); m.objs.push_back(o); }
     m.threads.emplace_back(train_online_thread, o);                      // thread per object, nerf_manager.cu:259
     return MON_OK;
 }
 int mon_online_update_nerf_bbox(mon_online* h, size_t idx, const mon_frame_bbox* boxes, size_t n, int train_step) {   // :298-303 + UpdateFrameBBox nerf.cu:406-421
     REQ(h); if (n != 0) REQ(boxes);            // an EMPTY update still stores train_step and wakes the object's thread, like UpdateFrameBBox (nerf.cu:416-420)
-    if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
-    OnlineObject* o = h->m->objs[idx];
+    OnlineObject* o = online_object(*h->m, idx);
+    if (!o) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
     std::unique_lock<std::mutex> lock(o->mu_boxes);
     if (o->n_boxes + n > o->boxes.size()) o->boxes.resize(o->n_boxes + n);
     for (size_t i = 0; i < n; ++i) o->boxes[o->n_boxes + i] = boxes[i];
@@ -548,31 +552,31 @@ int mon_online_get_frame_idx(mon_online* h, const char* timestamp, int* idx) {  
 int mon_online_wait_threads_end(mon_online* h) {                           // :263-278
     REQ(h); OnlineManager& m = *h->m;
     if (m.threads.empty()) { set_error("WaitThreadsEnd: no threads"); return MON_ERR_STATE; }
-    for (auto* o : m.objs) request_finish(o);                               // RequestFinish nerf.cu:443-448
+    for (auto* o : online_objects(m)) request_finish(o);                     // RequestFinish nerf.cu:443-448
     for (auto& t : m.threads) if (t.joinable()) t.join();
     m.threads.clear(); std::puts("All NeRF threads completed ...");
-    for (auto* o : m.objs) if (o->rc != MON_OK) { set_error("object %d: %s", o->id, o->err.c_str()); return o->rc; }
+    for (auto* o : online_objects(m)) if (o->rc != MON_OK) { set_error("object %d: %s", o->id, o->err.c_str()); return o->rc; }
     return MON_OK;
 }
 int mon_online_object_info(mon_online* h, size_t idx, float* loss, int* train_calls, int* device, uint32_t* n_boxes) {
-    REQ(h); if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
-    OnlineObject* o = h->m->objs[idx]; AnnouncedLock lm(o, o->mu_model); if (loss) *loss = o->last_loss; if (train_calls) *train_calls = o->train_calls; if (device) *device = o->device; if (n_boxes) *n_boxes = (uint32_t)o->n_uploaded; return MON_OK;
+    REQ(h); OnlineObject* o = online_object(*h->m, idx); if (!o) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
+    AnnouncedLock lm(o, o->mu_model); if (loss) *loss = o->last_loss; if (train_calls) *train_calls = o->train_calls; if (device) *device = o->device; if (n_boxes) *n_boxes = (uint32_t)o->n_uploaded; return MON_OK;
 }
 int mon_online_render(mon_online* h, size_t idx, mon_frame_bbox box, const float* Twc16, float* rgb, float* depth, float* mask) {   // one view of RenderNeRFsTest :280-285
-    REQ(h); if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
+    REQ(h); OnlineObject* o = online_object(*h->m, idx); if (!o) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
     // a viewer's render: the latest published inference weights on the object's inference stream -- no model mutex, nothing queued behind training
-    if (model_render_snapshot(*h->m->objs[idx]->model, box, Twc16, 0, rgb, depth, mask, nullptr) == MON_OK) return MON_OK;
-    AnnouncedLock lm(h->m->objs[idx], h->m->objs[idx]->mu_model);         // nothing published yet / no inference side: let in between two slices of a running training step
-    return model_render(*h->m->objs[idx]->model, box, Twc16, 0, rgb, depth, mask, 0);
+    if (model_render_snapshot(*o->model, box, Twc16, 0, rgb, depth, mask, nullptr) == MON_OK) return MON_OK;
+    AnnouncedLock lm(o, o->mu_model);         // nothing published yet / no inference side: let in between two slices of a running training step
+    return model_render(*o->model, box, Twc16, 0, rgb, depth, mask, 0);
 }
 // NerfManagerOnline::RenderNeRFsTest -> NeRF::RenderTestImg, nerf.cu:255-404: <out>/<id>/{test_img,test_depth,test_mask}/<stamp>.png,
 // test.txt, train.txt (object-centric poses), 60-view video_img / video_depth, obj.ply
 int mon_online_render_nerfs_test(mon_online* h, const char* out_path, size_t idx, const char* const* timestamps, const mon_frame_bbox* boxes, const float* Twcs16, size_t n, float radius) {
     REQ(h); REQ(out_path); OnlineManager& m = *h->m;
-    if (m.objs.empty()) return MON_OK;                                    // nerf_manager.cu:282
-    if (idx >= m.objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
+    if (online_objects(m).empty()) return MON_OK;                          // nerf_manager.cu:282
+    if (!online_object(m, idx)) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
     if (n && (!timestamps || !boxes || !Twcs16)) { set_error("RenderNeRFsTest: null argument"); return MON_ERR_ARG; }
-    OnlineObject* o = m.objs[idx]; const std::string root = std::string(out_path) + "/" + std::to_string(o->id);
+    OnlineObject* o = online_object(m, idx); const std::string root = std::string(out_path) + "/" + std::to_string(o->id);
     std::vector<mon_frame_bbox> trained;                                  // snapshot of the uploaded boxes (lock order everywhere: mu_boxes, then mu_model)
     { std::lock_guard<std::mutex> lb(o->mu_boxes); trained.assign(o->boxes.begin(), o->boxes.begin() + (ptrdiff_t)o->n_uploaded); }
     AnnouncedLock lm(o, o->mu_model);
@@ -611,7 +615,7 @@ int mon_online_render_nerfs_test(mon_online* h, const char* out_path, size_t idx
     return MON_OK;
 }
 int mon_generate_toc(float theta_deg, float phi_deg, float radius, float* Toc16) { REQ(Toc16); generate_toc(theta_deg, phi_deg, radius, Toc16); return MON_OK; }
-int mon_online_object(mon_online* h, size_t idx, mon_object** borrowed) { REQ(h); REQ(borrowed); if (idx >= h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *borrowed = &h->m->objs[idx]->handle; return MON_OK; }
+int mon_online_object(mon_online* h, size_t idx, mon_object** borrowed) { REQ(h); REQ(borrowed); OnlineObject* o = online_object(*h->m, idx); if (!o) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *borrowed = &o->handle; return MON_OK; }
 int mon_online_destroy(mon_online* h) { if (!h) return MON_OK; online_destroy(h->m); delete h; return MON_OK; }
 
 int mon_png_read(const char* path, int* width, int* height, int* channels, int* bit_depth, uint8_t* pixels, size_t capacity) {

@@ -34,17 +34,17 @@ const char* last_error() { return g_err.c_str(); }
 
 static Options g_options;
 Options& options() { return g_options; }
-static long* option_slot(const char* name) {
-    static const struct { const char* n; long Options::*f; } tab[] = {
+static std::atomic<long>* option_slot(const char* name) {
+    static const struct { const char* n; std::atomic<long> Options::*f; } tab[] = {
         { "backend", &Options::backend }, { "use_graph", &Options::use_graph }, { "lazy_ema", &Options::lazy_ema }, { "big_switch", &Options::big_switch },
-        { "touched_flags", &Options::touched_flags }, { "lds_scatter", &Options::lds_scatter }, { "fold_reduce", &Options::fold_reduce }, { "fold_next", &Options::fold_next },
+        { "touched_flags", &Options::touched_flags },
         { "fused_grid", &Options::fused_grid }, { "lds_encode", &Options::lds_encode }, { "encode_ablate", &Options::encode_ablate }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
         { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner }, { "scatter_bins", &Options::scatter_bins }, { "opt_lazy_below", &Options::opt_lazy_below }, { "scatter_ablate", &Options::scatter_ablate } };
     for (const auto& e : tab) if (name && std::strcmp(name, e.n) == 0) return &(g_options.*(e.f));
     return nullptr;
 }
-int option_set(const char* name, long value) { long* p = option_slot(name); if (!p) { set_error("set_option: unknown option '%s'", name ? name : "(null)"); return MON_ERR_ARG; } *p = value; return MON_OK; }
-int option_get(const char* name, long* value) { long* p = option_slot(name); if (!p || !value) { set_error("get_option: unknown option '%s'", name ? name : "(null)"); return MON_ERR_ARG; } *value = *p; return MON_OK; }
+int option_set(const char* name, long value) { std::atomic<long>* p = option_slot(name); if (!p) { set_error("set_option: unknown option '%s'", name ? name : "(null)"); return MON_ERR_ARG; } *p = value; return MON_OK; }
+int option_get(const char* name, long* value) { std::atomic<long>* p = option_slot(name); if (!p || !value) { set_error("get_option: unknown option '%s'", name ? name : "(null)"); return MON_ERR_ARG; } *value = *p; return MON_OK; }
 
 void config_default(mon_config& c);
 int config_from_json(const char* path, mon_config& c);
@@ -121,7 +121,7 @@ static TrainLanes* lanes_get(int device) {
     std::lock_guard<std::mutex> l(g_lanes_mu); TrainLanes*& t = g_lanes[device];
     if (!t) {
         t = new TrainLanes();
-        const int n = options().train_lanes < kMaxLanes ? options().train_lanes : kMaxLanes;
+        const long want_lanes = options().train_lanes; const int n = want_lanes < kMaxLanes ? (int)want_lanes : kMaxLanes;
         for (int i = 0; i < n; ++i) if (hipStreamCreateWithFlags(&t->lane[i].stream, hipStreamNonBlocking) != hipSuccess) { t->lane[i].stream = nullptr; (void)hipGetLastError(); }
     }
     return t;
@@ -155,7 +155,7 @@ static void switch_stream(Model& m, hipStream_t to) {
 struct LaneChunk {
     Model& m; TrainLanes* tl = nullptr; std::unique_lock<std::mutex> lock; int l = -1;
     explicit LaneChunk(Model& mm, bool enabled) : m(mm) {
-        const int n = options().train_lanes < kMaxLanes ? options().train_lanes : kMaxLanes;
+        const long want_lanes = options().train_lanes; const int n = want_lanes < kMaxLanes ? (int)want_lanes : kMaxLanes;
         if (!enabled || n <= 0 || !m.lanes || m.lanes->objects.load() <= n) { switch_stream(m, m.own_stream); MON_INVALIDATE_MARK(m); return; }      // (up to `n` objects: their own streams ARE the lanes)
         tl = m.lanes;
         {   std::lock_guard<std::mutex> pick(tl->mu);
@@ -573,7 +573,7 @@ static void enqueue_iteration(Model& m, int stages) {
             if (pre) {
                 // positions of this batch: normally the last k_optimizer's position blocks already wrote them (and k_encode_tiles of the last iteration the candidates)
                 if (!(m.next_ready && m.points_ready)) { ProfScope pp(m, MON_K_POINTS); launch_sample_points(s, m.B, m.oc, m.d_state, m.d_x_all); }
-                const bool gen_next = options().fold_next != 0;
+                const bool gen_next = true;                      // (the next iteration is always prepared ahead: the stand-alone kernels run after an invalidation only)
                 { ProfScope pe(m, MON_K_ENCODE); launch_encode_tiles(s, m.lf, m.nd, m.d_half_tiles, m.d_x_all, m.d_e_soa, B, m.d_state, gen_next ? &m.B_alt : nullptr, m.ds->ptrs(), m.oc); }
             }
             ProfScope ps(m, MON_K_FWDBWD);
@@ -582,8 +582,7 @@ static void enqueue_iteration(Model& m, int stages) {
         }
     }
     if ((stages & 2) && m.backend == 1) {
-        const bool fold_reduce = options().fold_reduce != 0;
-        const bool folded = m.lds_mask && fold_reduce && grid_scatter_sums_partials(m.lt, m.nd);   // the scatter workgroups also sum the dW partial rows
+        const bool folded = m.lds_mask && grid_scatter_sums_partials(m.lt, m.nd);   // the scatter workgroups also sum the dW partial rows
         if (m.lds_mask) { ProfScope ps(m, MON_K_SCATTER); launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_gpart, m.n_grid / 2, m.d_state,
                                                                                 folded ? m.d_dw_partials : nullptr, fused_train_grid(m.nd, m.oc.R), m.P.gmlp, m.d_state_next); }
         if (m.big_active) { ProfScope ps(m, MON_K_SCATTER); launch_big_scatter(s, m.lt, m.lf, m.nd, m.lds_mask, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_state, m.big_switch, m.d_big_ws, m.P.ggrid, m.d_touched ? m.d_touched + (m.nd.n_mlp >> 3) : nullptr); }
@@ -601,7 +600,7 @@ static void enqueue_iteration(Model& m, int stages) {
             P.first_flag_chunk = (m.nd.n_mlp + 2u * m.lt.offset[first_big]) >> 3;
         }
         OptimNext nx{};
-        const bool fold = options().fold_next != 0;
+        const bool fold = true;                              // (see gen_next above: options fold_next / fold_reduce / lds_scatter were measurement switches of rounds 1-2 and are gone)
         const bool pos_mode = m.backend == 1 && fold && m.pre_active && m.d_e_soa;      // k_encode_tiles generated the next candidates into B_alt; sample their positions here
         if (m.backend == 1 && fold) {
             nx.cand_blocks = pos_mode ? 0u : (m.oc.R + 255) / 256; nx.frag_image = m.d_frag_train; nx.fd = FragDims{ m.nd.Epad, m.nd.W, m.nd.NH, m.nd.L };

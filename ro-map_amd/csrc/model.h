@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 #include "../../include/mon_core.h"
@@ -120,9 +121,10 @@ enum {
 };
 
 // Process-wide test and tuning switches (mon_set_option, include/mon_core.h); defaults are the product behaviour.
-struct Options {
-    long backend = -1, use_graph = 0, lazy_ema = -1, big_switch = 16384, touched_flags = 1, lds_scatter = 1, fold_reduce = 1, fold_next = 1,
-         fused_grid = 0, lds_encode = 1, encode_ablate = 0, opt_blocks = 0, fused_ablate = 0, fused_stagger = -1, offline_outer = 10, offline_inner = 500, scatter_bins = 0, opt_lazy_below = -1, scatter_ablate = 0, train_lanes = 2, lane_chunk = 16, online_slice_min = 2;
+struct Options {      // (atomics: tests and tools flip options while object threads read them)
+    std::atomic<long> backend{ -1 }, use_graph{ 0 }, lazy_ema{ -1 }, big_switch{ 16384 }, touched_flags{ 1 },
+         fused_grid{ 0 }, lds_encode{ 1 }, encode_ablate{ 0 }, opt_blocks{ 0 }, fused_ablate{ 0 }, fused_stagger{ -1 }, offline_outer{ 10 }, offline_inner{ 500 }, scatter_bins{ 0 }, opt_lazy_below{ -1 },
+         scatter_ablate{ 0 }, train_lanes{ 2 }, lane_chunk{ 16 }, online_slice_min{ 2 };
 };
 Options& options();
 int option_set(const char* name, long value);
