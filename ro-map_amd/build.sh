@@ -19,7 +19,7 @@ for s in "${SRCS[@]}" "${DIAG_SRCS[@]}"; do
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
 objs=(); for s in "${SRCS[@]}"; do objs+=("$OBJ/${s%.*}.o"); done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$HERE/libmon_core.so" "${objs[@]}" -lz -lpthread
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$HERE/libmon_core.so" "${objs[@]}" -lz -lpthread -ldl
 dobjs=(); for s in "${DIAG_SRCS[@]}"; do dobjs+=("$OBJ/${s%.*}.o"); done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$HERE/libmon_core_diag.so" "${dobjs[@]}" -L"$HERE" -lmon_core -Wl,-rpath,'$ORIGIN'
 g++ -O2 -std=c++17 "$HERE/../tools/offline_nerf.cpp" -o "$HERE/offline_nerf" -L"$HERE" -lmon_core -Wl,-rpath,'$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib

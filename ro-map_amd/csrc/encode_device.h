@@ -46,6 +46,12 @@ __device__ __forceinline__ void points_sample(const PointsLds& l, const BatchPtr
 #pragma unroll
     for (int d = 0; d < 3; ++d) { const float p = fmaf(t, b.cand_d[3u * cand + d], b.cand_o[3u * cand + d]); x[d] = (p - oc.aabb.mn[d]) / (oc.aabb.mx[d] - oc.aabb.mn[d]); }
     x_all[s] = float4_t{ x[0], x[1], x[2], t };
+    if (n == 0u && b.ray_rec) {          // the ray's record for k_fused_train<PRE> (the fields its load_record collects from the candidate arrays)
+        float* r = b.ray_rec + 12u * (size_t)ray;
+        reinterpret_cast<float4_t*>(r)[0] = float4_t{ __builtin_bit_cast(float, b.cand_rgba[cand]), t0, t1, b.cand_d[3u * cand] };
+        reinterpret_cast<float4_t*>(r)[1] = float4_t{ b.cand_d[3u * cand + 1u], b.cand_d[3u * cand + 2u], b.cand_o[3u * cand], b.cand_o[3u * cand + 1u] };
+        reinterpret_cast<float4_t*>(r)[2] = float4_t{ b.cand_o[3u * cand + 2u], b.cand_depth[cand], __builtin_bit_cast(float, cand), 0.f };
+    }
 }
 
 }  // namespace mon

@@ -425,13 +425,15 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     const uint32_t nwords = a.oc.R >> 6;                                           // <= 256 (fused_supported)
     const bool small = nwords <= 64u;                                              // uniform
     unsigned long long my_word = 0ull;
-    if (small && (uint32_t)lane < nwords) my_word = a.b.mask[lane];
+    const bool have_rec = PRE && a.b.ray_rec != nullptr;                           // (uniform) the position pass left the compacted rays' records: no ballot words, no scan, no select
+    if (!have_rec && small && (uint32_t)lane < nwords) my_word = a.b.mask[lane];
     const LevelRegs lregs = load_level_regs_uniform(a.lt, L, lane); const uint32_t table_bytes = a.lt.offset[L] * 4u;      // (from the argument segment: it ends up in the buffer descriptor, which must be scalar)
     build_fragments<EPAD, W, NH>(frags, llt, a, true);
     half_t* scr = reinterpret_cast<half_t*>(dyn + wave * S::SCR_BYTES);
     for (int i = 2 * a.nd.L * 32 + lane; i < EPAD * 32; i += 64) scr[S::SCR_E + i] = (half_t)0.f;   // pad feature rows stay zero; every other row is rewritten per ray before it is read
     uint32_t my_excl = 0u, nvalid = 0u;
-    if (small) { const uint32_t c = __popcll(my_word), inc = scan_add64_u32(c); my_excl = inc - c; nvalid = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63); }
+    if (have_rec) nvalid = a.st->n_valid_pre;
+    else if (small) { const uint32_t c = __popcll(my_word), inc = scan_add64_u32(c); my_excl = inc - c; nvalid = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63); }
     else if (wave == 0) {
         uint32_t carry = 0;
         for (uint32_t base = 0; base < nwords; base += 64) {
@@ -464,11 +466,14 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
                        : lane < 6 ? (const void*)(a.b.cand_d + (lane - 3)) : lane < 9 ? (const void*)(a.b.cand_o + (lane - 6)) : (const void*)a.b.cand_depth;
         rec_base = reinterpret_cast<const char*>(fb); if (lane >= 3 && lane < 9) rec_mul = 3u; }
     const auto load_record = [&](uint32_t cand) -> uint32_t { uint32_t v = 0u; if (lane < 10) v = *reinterpret_cast<const uint32_t*>(rec_base + 4u * (size_t)(cand * rec_mul)); return v; };
+    // (PRE with records: lane l < 10 takes field l of ray `r`'s 12-float record -- one coalesced 40-byte load, requested a ray ahead like the candidate record)
+    const auto load_ray_rec = [&](uint32_t r) -> uint32_t { uint32_t v = 0u; if (lane < 10) v = reinterpret_cast<const uint32_t*>(a.b.ray_rec)[12u * (size_t)r + (uint32_t)lane]; return v; };
     const uint32_t ray0 = blockIdx.x * S::WAVES + wave;
     uint32_t cand = 0u, rec = 0u;
-    if (small && nvalid != 0u && ray0 < R) { cand = select(ray0 % nvalid); rec = load_record(cand); }
+    if (have_rec) { if (nvalid != 0u && ray0 < R) rec = load_ray_rec(ray0); }
+    else if (small && nvalid != 0u && ray0 < R) { cand = select(ray0 % nvalid); rec = load_record(cand); }
     __syncthreads();
-    if (!small) { nvalid = cprefix[nwords]; if (nvalid != 0u && ray0 < R) { cand = select(ray0 % nvalid); rec = load_record(cand); } }
+    if (!have_rec && !small) { nvalid = cprefix[nwords]; if (nvalid != 0u && ray0 < R) { cand = select(ray0 % nvalid); rec = load_record(cand); } }
     if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->n_valid = nvalid; a.st->loss_sum = 0.f; }
     if (nvalid == 0u) return;                                                        // batch skipped (uniform over the grid)
 
@@ -550,7 +555,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         tstamp(tc, 2);
         // the next ray's candidate record is requested HERE, behind this ray's last gather: vmcnt retires in order, so a load issued before the gathers would
         // have to land before the first level pair can be consumed; now its latency runs under the MLP, composite and backward pass
-        if (ray + ray_stride < R) { cand = select((ray + ray_stride) % nvalid); rec = load_record(cand); if constexpr (PRE) load_encoded(ray + ray_stride); }
+        if (ray + ray_stride < R) { if (have_rec) rec = load_ray_rec(ray + ray_stride); else { cand = select((ray + ray_stride) % nvalid); rec = load_record(cand); } if constexpr (PRE) load_encoded(ray + ray_stride); }
         if (a.ablate & 64u) { float sacc = 0.f; for (int i = 0; i < EPAD / 2; ++i) sacc += (float)ts.ef[i]; loss_acc += sacc; continue; }      // timing experiments: the encode alone
         if (!OCC || __ballot(live) != 0ull) mlp_forward<EPAD, W, NH>(ts, frags, lane);
         else {

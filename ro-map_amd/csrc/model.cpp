@@ -17,6 +17,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <dlfcn.h>
 #include "model.h"
 #include "xorwow.h"
 
@@ -38,7 +39,7 @@ static std::atomic<long>* option_slot(const char* name) {
     static const struct { const char* n; std::atomic<long> Options::*f; } tab[] = {
         { "backend", &Options::backend }, { "use_graph", &Options::use_graph }, { "lazy_ema", &Options::lazy_ema }, { "big_switch", &Options::big_switch },
         { "touched_flags", &Options::touched_flags },
-        { "fused_grid", &Options::fused_grid }, { "lds_encode", &Options::lds_encode }, { "encode_ablate", &Options::encode_ablate }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
+        { "fused_grid", &Options::fused_grid }, { "lds_encode", &Options::lds_encode }, { "roctx", &Options::roctx }, { "ray_records", &Options::ray_records }, { "encode_ablate", &Options::encode_ablate }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
         { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner }, { "scatter_bins", &Options::scatter_bins }, { "opt_lazy_below", &Options::opt_lazy_below }, { "scatter_ablate", &Options::scatter_ablate } };
     for (const auto& e : tab) if (name && std::strcmp(name, e.n) == 0) return &(g_options.*(e.f));
     return nullptr;
@@ -385,6 +386,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         if (big_bytes && big_switch) { if ((rc = dev_alloc(m, m.d_big_ws, big_bytes))) return rc; m.big_switch = big_switch; }
         // level-tile encode (kernels_encode.hip): every level must fit two LDS tiles and go through the LDS scatter (option lds_encode = 0: gathers inside k_fused_train)
         if (options().lds_encode && !cfg.occupancy_skip && m.lds_mask == ((1u << m.nd.L) - 1u) && encode_tiles_supported(m.lt, m.nd)) {
+            if (options().ray_records && (rc = dev_alloc(m, B.ray_rec, 12 * (size_t)R))) return rc;
             m.B_alt = B;                             // (cand_* / mask replaced below, after the workspace pointers are final)
             if ((rc = dev_alloc(m, m.B_alt.cand_o, 3 * (size_t)R)) || (rc = dev_alloc(m, m.B_alt.cand_d, 3 * (size_t)R)) || (rc = dev_alloc(m, m.B_alt.cand_dn, R)) ||
                 (rc = dev_alloc(m, m.B_alt.cand_t0, R)) || (rc = dev_alloc(m, m.B_alt.cand_t1, R)) || (rc = dev_alloc(m, m.B_alt.cand_depth, R)) ||
@@ -523,10 +525,25 @@ static hipEvent_t get_event(Model& m) {
     if (!m.ev_pool.empty()) { hipEvent_t e = m.ev_pool.back(); m.ev_pool.pop_back(); return e; }
     hipEvent_t e; hipEventCreate(&e); return e;
 }
+// roctx ranges per phase (option "roctx" = 1): the phases of an iteration show up by name in a rocprofv3 --marker-trace of the host side.  The library is
+// looked up at run time (librocprofiler-sdk-roctx.so, then libroctx64.so) -- nothing links against it, and without the option nothing is loaded.
+struct Roctx {
+    int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+    Roctx() {
+        for (const char* lib : { "librocprofiler-sdk-roctx.so", "libroctx64.so" }) {
+            void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL); if (!h) continue;
+            push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA")); pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) break;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+static Roctx* roctx() { if (!options().roctx) return nullptr; static Roctx r; return r.push ? &r : nullptr; }
+static const char* const kPhaseName[MON_K_COUNT] = { "mon.batch (GenerateBatch)", "mon.fwd_bwd (k_fused_train)", "mon.optimizer (k_optimizer)", "mon.render", "mon.scatter (k_grid_scatter)", "mon.reduce_partials", "mon.encode (k_encode_tiles)", "mon.points (k_sample_points)" };
 struct ProfScope {
-    Model& m; int cls; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(Model& mm, int c) : m(mm), cls(c) { if (m.profiling) { a = get_event(m); b = get_event(m); hipEventRecord(a, m.train_stream); } }
-    ~ProfScope() { if (m.profiling) { hipEventRecord(b, m.train_stream); m.ev_pending.push_back({ cls, { a, b } }); } }
+    Model& m; int cls; hipEvent_t a = nullptr, b = nullptr; Roctx* rx;
+    ProfScope(Model& mm, int c) : m(mm), cls(c), rx(roctx()) { if (rx) rx->push(kPhaseName[c]); if (m.profiling) { a = get_event(m); b = get_event(m); hipEventRecord(a, m.train_stream); } }
+    ~ProfScope() { if (m.profiling) { hipEventRecord(b, m.train_stream); m.ev_pending.push_back({ cls, { a, b } }); } if (rx) rx->pop(); }
 };
 static void collect_profile(Model& m) {
     for (auto& p : m.ev_pending) {
@@ -605,7 +622,7 @@ static void enqueue_iteration(Model& m, int stages) {
         if (m.backend == 1 && fold) {
             nx.cand_blocks = pos_mode ? 0u : (m.oc.R + 255) / 256; nx.frag_image = m.d_frag_train; nx.fd = FragDims{ m.nd.Epad, m.nd.W, m.nd.NH, m.nd.L };
             nx.b = pos_mode ? m.B_alt : m.B; nx.ds = m.ds->ptrs(); nx.oc = m.oc;
-            if (pos_mode) { nx.pos_blocks = 64u; nx.x_all = m.d_x_all; }
+            if (pos_mode) { nx.pos_blocks = (B + 255u) / 256u; nx.x_all = m.d_x_all; }      // one sample per thread: a thread's chain is select -> candidate loads -> store, ~5 us of latency that several samples per thread would put in series (64 blocks of 8 samples per thread made these blocks the kernel's tail)
         }
         launch_optimizer(s, P, m.opt, m.d_state, m.d_state_next, nx, options().opt_lazy_below < 0 ? (m.oc.R * m.oc.S) / 8u : (uint32_t)options().opt_lazy_below); m.scatter_pending = false;
         std::swap(m.d_state, m.d_state_next);                // the next iteration (and the host's read-back) uses the state this launch prepares

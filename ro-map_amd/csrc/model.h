@@ -72,6 +72,9 @@ struct BatchPtrs {
     uint16_t *E, *Hid, *O, *dO, *dHid, *dE;
     // per-ray results
     float *rgb_ray, *depth_ray, *mask_ray, *loss_ray;
+    // level-tile encode: the compacted batch's ray records, 12 floats per training ray {rgba bits, t0, t1, d[3], o[3], target depth, candidate index bits, 0}, written by the
+    // position pass (k_sample_points / k_optimizer's position blocks) so that k_fused_train<PRE> needs neither the ballot scan nor the candidate select
+    float* ray_rec;
 };
 
 // LDS scatter plan: levels handled by k_grid_scatter and their sample-partition counts (partial tables per level)
@@ -124,7 +127,7 @@ enum {
 struct Options {      // (atomics: tests and tools flip options while object threads read them)
     std::atomic<long> backend{ -1 }, use_graph{ 0 }, lazy_ema{ -1 }, big_switch{ 16384 }, touched_flags{ 1 },
          fused_grid{ 0 }, lds_encode{ 1 }, encode_ablate{ 0 }, opt_blocks{ 0 }, fused_ablate{ 0 }, fused_stagger{ -1 }, offline_outer{ 10 }, offline_inner{ 500 }, scatter_bins{ 0 }, opt_lazy_below{ -1 },
-         scatter_ablate{ 0 }, train_lanes{ 2 }, lane_chunk{ 16 }, online_slice_min{ 2 };
+         scatter_ablate{ 0 }, train_lanes{ 2 }, lane_chunk{ 16 }, online_slice_min{ 2 }, roctx{ 0 }, ray_records{ 1 };
 };
 Options& options();
 int option_set(const char* name, long value);

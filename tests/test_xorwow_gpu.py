@@ -20,24 +20,23 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def test_rocrand_host_generator_matches_the_oracle_stream(orc):
-    torch = pytest.importorskip("torch")
-    assert torch.cuda.device_count() >= 1, "no HIP device visible: the GPU tests must run on the MI355X box"
-    rr = C.CDLL("librocrand.so")
+def test_rocrand_host_generator_matches_the_oracle_stream(pkg, orc):
+    assert pkg.device_count() >= 1, "no HIP device visible: the GPU tests must run on the MI355X box"
+    rr = C.CDLL("librocrand.so"); hip = C.CDLL("libamdhip64.so")          # (plain HIP allocations: torch cannot always initialise its own context once the product library holds the device)
     # two base.json iterations (2R, 3R, S R with R = 4096), then sizes that are no multiple of anything
     for sizes in ([8192, 12288, 131072, 8192, 12288, 131072], [2048, 3072, 32768, 5, 131073, 262144 + 7, 1]):
         g = C.c_void_p(); assert rr.rocrand_create_generator(C.byref(g), 401) == 0                     # ROCRAND_RNG_PSEUDO_XORWOW, seed 0 by default
         got = []
         for n in sizes:
-            t = torch.zeros(n, dtype=torch.float32, device="cuda")
-            assert rr.rocrand_generate_uniform(g, C.c_void_p(t.data_ptr()), C.c_size_t(n)) == 0
-            torch.cuda.synchronize(); got.append(t.cpu().numpy())
+            d = C.c_void_p(); assert hip.hipMalloc(C.byref(d), C.c_size_t(4 * n)) == 0
+            assert rr.rocrand_generate_uniform(g, d, C.c_size_t(n)) == 0 and hip.hipDeviceSynchronize() == 0
+            a = np.zeros(n, np.float32); assert hip.hipMemcpy(_p(a), d, C.c_size_t(4 * n), 2) == 0; hip.hipFree(d); got.append(a)
         rr.rocrand_destroy_generator(g)
         want = np.zeros(sum(sizes), np.float32); sz = np.array(sizes, np.uint32)
         orc.lib().orc_xorwow_generate_calls(C.c_uint64(0), 1, 131072, len(sizes), _p(sz), _p(want))
         off = 0
-        for n, a in zip(sizes, got):
-            assert np.array_equal(a, want[off:off + n]), "call of %d values (after %s)" % (n, sizes[:sizes.index(n)]); off += n
+        for i, (n, a) in enumerate(zip(sizes, got)):
+            assert np.array_equal(a, want[off:off + n]), "call %d of %d values (after %s)" % (i, n, sizes[:i]); off += n
 
 
 @pytest.mark.parametrize("backend", [0, 1])

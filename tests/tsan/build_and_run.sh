@@ -16,7 +16,7 @@ for p in "${pids[@]}"; do wait "$p"; done
 gcc -c "$OUT/fatbin_syms.c" -o "$OUT/fatbin_syms.o"
 objs=(); for s in "${SRCS[@]}"; do objs+=("$OUT/${s%.*}.o"); done
 clang=/opt/rocm/lib/llvm/bin/clang++
-"$clang" -fsanitize=thread -g -O1 -std=c++17 "$HERE/tsan_driver.cpp" "${objs[@]}" "$OUT/hip_stub.o" "$OUT/fatbin_syms.o" -o "$OUT/tsan_driver" -lz -lpthread
+"$clang" -fsanitize=thread -g -O1 -std=c++17 "$HERE/tsan_driver.cpp" "${objs[@]}" "$OUT/hip_stub.o" "$OUT/fatbin_syms.o" -o "$OUT/tsan_driver" -lz -lpthread -ldl
 cd "$REPO"
 set +e
 TSAN_OPTIONS="halt_on_error=0 exitcode=66 report_signal_unsafe=0" "$OUT/tsan_driver" ro-map_amd/configs/base.json 2> "$OUT/tsan.log" | tail -3
