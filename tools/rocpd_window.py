@@ -24,7 +24,7 @@ def short(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("root"); ap.add_argument("--skip", type=int, default=5); ap.add_argument("--take", type=int, default=20)
-    ap.add_argument("--only", default="k_fused_train,k_grid_scatter,k_optimizer,k_big,k_reduce,k_cand,k_step")
+    ap.add_argument("--only", default="k_encode_tiles,k_sample_points,k_fused_train,k_grid_scatter,k_optimizer,k_big,k_reduce,k_cand,k_step")
     a = ap.parse_args()
     only = [s for s in a.only.split(",") if s]
     keep = lambda n: (not only) or any(o in n for o in only)
