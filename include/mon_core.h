@@ -242,6 +242,8 @@ int mon_png_write(const char* path, int width, int height, int channels, int bit
  * an iteration as a hipGraph), "lazy_ema" (-1 auto: tables above 8 M parameters), "big_switch" (gradient-carrying samples below which the
  * large-table levels scatter with global atomics; 0 = always), "touched_flags" (1 = on: the lazy optimizer's chunk flags), "lds_encode" (1 = on: the forward
  * hash-grid encode from LDS-resident level tiles, kernels_encode.hip; 0 = gathers inside k_fused_train -- both give bit-identical parameters),
+ * "step_variant" (1: NeRF_Model::Step's sample-compaction schedule, nerf_model.cu:1504-1550, on the layer-at-a-time kernels -- the reference's own "unavailable, for
+ * reference only" path, kept checkable; 0 = Step_No_Compacted, what both drivers train with), "roctx" (1: roctx ranges per phase), "ray_records",
  * "fused_grid", "opt_blocks" (workgroup caps, 0 = built-in), "scatter_bins" (ray bins of the compacted gradient rows, a power of two up to 128; 0 = built-in 16), "fused_ablate" (timing ablations of k_fused_train; bit 16 = keep zero-gradient
  * samples, used by the exactness test), "offline_outer" / "offline_inner" (NerfManagerOffline's 10 x 500 iterations, nerf_manager.cu:89).
  * Unknown names return MON_ERR_ARG. */

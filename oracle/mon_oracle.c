@@ -285,6 +285,7 @@ typedef struct {
     float *pts, *tdist; uint16_t *E, *Hid, *O, *dO, *dHid, *dE;
     float *rgb_ray, *depth_ray, *mask_ray, *loss_ray; float loss;
     /* XORWOW sample stream (cfg.rng_flags): the training generator and this iteration's three arrays SampleXY[2R] | RandColors[3R] | RandDt[S R] */
+    int step_variant; uint32_t n_compacted;          /* NeRF_Model::Step schedule (forward_backward_compacted) instead of Step_No_Compacted; samples in the compacted batch */
     orc_xwgen xw; float* xw_buf; uint32_t xw_iter;     /* xw_iter: the iteration xw_buf holds (UINT32_MAX: none) */
 } orc_model;
 
@@ -603,15 +604,21 @@ static int g_parallel_scatter = 0;
 void orc_set_parallel_scatter(int on) { g_parallel_scatter = on; }
 
 /* ------------------------------------------------------------------ Step_No_Compacted nerf_model.cu:1552-1607 */
-static void forward_backward(orc_model* m) {
+static void network_forward(orc_model* m) {          /* encode + MLP of every sample of m->pts (tcnn forward / inference, call sites :1557, :1509) */
     const int R = m->R, S = m->S, W = m->W, NH = m->NH, Ep = m->Epad; const size_t B = (size_t)R * S;
     const uint16_t* wt = m->half; const uint16_t* table = m->half + m->n_mlp;
-    const int tcnn = m->cfg.numerics_flags & ORC_NUM_TCNN_HALF, grid_half = (m->cfg.numerics_flags & (ORC_NUM_GRID_HALF | ORC_NUM_TCNN_HALF)) != 0;
     #pragma omp parallel for schedule(static)
     for (long s = 0; s < (long)B; ++s) {
         encode_one(m, table, m->pts + 3 * s, m->E + (size_t)s * Ep);
         mlp_forward_one(m, wt, m->E + (size_t)s * Ep, m->Hid + (size_t)s * W * NH, m->O + (size_t)s * 4);
     }
+}
+static void network_backward(orc_model* m);
+static void forward_backward_compacted(orc_model* m);
+static void forward_backward(orc_model* m) {
+    if (m->step_variant) { forward_backward_compacted(m); return; }
+    const int R = m->R, S = m->S; const size_t B = (size_t)R * S;
+    network_forward(m);
     memset(m->dO, 0, B * 4 * 2);                                                 /* :1578 */
     #pragma omp parallel for schedule(static)
     for (long j = 0; j < R; ++j) {
@@ -622,6 +629,76 @@ static void forward_backward(orc_model* m) {
     }
     double ls = 0; for (int j = 0; j < R; ++j) ls += m->loss_ray[j];             /* SumLoss :1231-1253 + :1650-1658 */
     m->loss = (float)(ls / R);
+    network_backward(m);
+}
+
+/* NeRF_Model::Step (nerf_model.cu:1504-1550, "unavailable, for reference only": never called by either driver) -- the schedule with per-ray SAMPLE
+ * compaction: (1) inference of every sample with the training weights (:1509); (2) VolumeRenderGradient (:957-1132): per ray, composite until T < 1e-4 (numsteps
+ * samples), L2 loss on the colour only (no depth / mask terms), background = ONE colour for all rays (the kernel's by-value copy of the pcg32 generator: every
+ * thread draws the same three floats, :1038) -- here the iteration's first three RandColors; the numsteps positions and their dL/dO go to a compacted batch
+ * (reference: slot = atomicAdd in arrival order; here in ray order); (3) fill_rollover_and_rescale (:269-279) + fill_rollover (:258-266): the compacted batch of n
+ * samples is repeated cyclically up to the full batch size B and ONLY THE COPIES' gradients are scaled by n / B (the originals keep theirs: `i < n * stride` returns
+ * early); (4) forward + backward of the full-size compacted batch (:1545-1548), then the optimizer step as usual.  m->pts / m->dO hold the compacted batch afterwards. */
+static void forward_backward_compacted(orc_model* m) {
+    const int R = m->R, S = m->S; const size_t B = (size_t)R * S; const orc_config* c = &m->cfg;
+    network_forward(m);
+    uint32_t* steps = (uint32_t*)calloc((size_t)R + 1, 4);
+    float bg[3]; for (int a = 0; a < 3; ++a) bg[a] = batch_rand(m, 1, m->iter, (uint32_t)a);
+    const float ls = c->loss_scale / (float)R;
+    #pragma omp parallel for schedule(static)
+    for (long j = 0; j < R; ++j) {                                               /* first loop of the kernel: :996-1036 */
+        const uint16_t* o4 = m->O + (size_t)j * S * 4; const float* t = m->tdist + (size_t)j * S;
+        float T = 1.0f, r[3] = { 0, 0, 0 }, dep = 0.0f, last = 0.0f; int n = 0;
+        for (; n < S; ++n) {
+            if (T < 1e-4f) break;
+            float c0 = logistic(h2f(o4[4 * n])), c1 = logistic(h2f(o4[4 * n + 1])), c2 = logistic(h2f(o4[4 * n + 2]));
+            float dt = t[n] - last, sigma = expf(h2f(o4[4 * n + 3])), alpha = 1.0f - expf(-sigma * dt), w = alpha * T;
+            r[0] += w * c0; r[1] += w * c1; r[2] += w * c2; dep += w * t[n]; T *= (1.0f - alpha); last = t[n];      /* (depth: |point - o| = t for a unit direction) */
+        }
+        for (int a = 0; a < 3; ++a) m->rgb_ray[3 * j + a] = r[a] + T * bg[a];
+        m->depth_ray[j] = dep; m->mask_ray[j] = 1.0f - T; steps[j + 1] = (uint32_t)n;
+    }
+    for (int j = 0; j < R; ++j) steps[j + 1] += steps[j];                        /* exclusive prefix: ray order instead of atomicAdd's arrival order */
+    const uint32_t n_comp = steps[R];
+    float* pc = (float*)calloc(B * 3, 4); uint16_t* dc = (uint16_t*)calloc(B * 4, 2);
+    #pragma omp parallel for schedule(static)
+    for (long j = 0; j < R; ++j) {                                               /* second loop: :1048-1131 */
+        const uint16_t* o4 = m->O + (size_t)j * S * 4; const float* t = m->tdist + (size_t)j * S; const float* tg = m->target + 3 * j;
+        const float* rr = m->rgb_ray + 3 * j; const uint32_t base = steps[j], ns = steps[j + 1] - steps[j];
+        float g[3], e2 = 0.0f; for (int a = 0; a < 3; ++a) { float d = rr[a] - tg[a]; g[a] = 2.0f * d; e2 += d * d; }
+        m->loss_ray[j] = e2 / 3.0f;
+        float T = 1.0f, q[3] = { 0, 0, 0 }, last = 0.0f;
+        for (uint32_t n = 0; n < ns; ++n) {
+            if (T < 1e-4f) break;
+            size_t s = (size_t)j * S + n, d = (size_t)base + n;
+            for (int a = 0; a < 3; ++a) pc[3 * d + a] = m->pts[3 * s + a];
+            float v3 = h2f(o4[4 * n + 3]), cc[3] = { logistic(h2f(o4[4 * n])), logistic(h2f(o4[4 * n + 1])), logistic(h2f(o4[4 * n + 2])) };
+            float dt = t[n] - last, sigma = expf(v3), alpha = 1.0f - expf(-sigma * dt), w = alpha * T; last = t[n];
+            for (int a = 0; a < 3; ++a) q[a] += w * cc[a];
+            T *= (1.0f - alpha);
+            float dot = 0.0f;
+            for (int a = 0; a < 3; ++a) { dc[4 * d + a] = f2h(ls * ((w * g[a]) * (cc[a] * (1.0f - cc[a])))); dot += g[a] * (T * cc[a] - (rr[a] - q[a])); }
+            float dsig = expf(fminf(fmaxf(v3, -15.0f), 15.0f));
+            dc[4 * d + 3] = f2h(ls * (dsig * (dt * dot)));
+        }
+    }
+    double lsum = 0; for (int j = 0; j < R; ++j) lsum += m->loss_ray[j];
+    m->loss = (float)(lsum / R);
+    if (n_comp > 0) for (size_t i = n_comp; i < B; ++i) {                         /* fill_rollover + fill_rollover_and_rescale: copies only, i >= n */
+        size_t src = i % n_comp;
+        for (int a = 0; a < 3; ++a) pc[3 * i + a] = pc[3 * src + a];
+        for (int a = 0; a < 4; ++a) dc[4 * i + a] = f2h((h2f(dc[4 * src + a]) * (float)n_comp) / (float)B);
+    }
+    memcpy(m->pts, pc, B * 3 * 4); memcpy(m->dO, dc, B * 4 * 2); m->n_compacted = n_comp;
+    free(pc); free(dc); free(steps);
+    network_forward(m);                                                          /* :1545 forward of the compacted batch (keeps E / hidden activations) */
+    network_backward(m);                                                         /* :1547 */
+}
+
+static void network_backward(orc_model* m) {
+    const int R = m->R, S = m->S, W = m->W, NH = m->NH, Ep = m->Epad; const size_t B = (size_t)R * S;
+    const uint16_t* wt = m->half;
+    const int tcnn = m->cfg.numerics_flags & ORC_NUM_TCNN_HALF, grid_half = (m->cfg.numerics_flags & (ORC_NUM_GRID_HALF | ORC_NUM_TCNN_HALF)) != 0;
     /* tcnn backward (EGradientMode::Overwrite): dh, dE per sample */
     #pragma omp parallel for schedule(static)
     for (long s = 0; s < (long)B; ++s) {
@@ -761,6 +838,8 @@ uint32_t orc_train_step(orc_model* m) {
 }
 float orc_train(orc_model* m, int iters) { for (int i = 0; i < iters; ++i) orc_train_step(m); return m->loss; }
 /* forward+backward only on the current batch (tests compare gradients without touching params) */
+void orc_set_step_variant(orc_model* m, int on) { m->step_variant = on; }
+uint32_t orc_n_compacted(const orc_model* m) { return m->n_compacted; }
 void orc_generate_batch(orc_model* m) { generate_batch(m); }   /* does not advance iter */
 void orc_advance_iter(orc_model* m) { m->iter++; }
 void orc_forward_backward(orc_model* m) { forward_backward(m); }

@@ -82,6 +82,7 @@ def lib():
         L.orc_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.orc_composite.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_set_step_variant.argtypes = [C.c_void_p, C.c_int]; L.orc_n_compacted.restype = C.c_uint32; L.orc_n_compacted.argtypes = [C.c_void_p]
         L.orc_xorwow_lane_draws.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_xorwow_generate.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_xorwow_generate_calls.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -148,6 +149,13 @@ class OracleModel:
 
     def train(self, iters):
         return self.L.orc_train(self.h, iters)
+
+    def set_step_variant(self, on):
+        self.L.orc_set_step_variant(self.h, int(on))
+
+    @property
+    def n_compacted(self):
+        return self.L.orc_n_compacted(self.h)
 
     def advance_iter(self):
         self.L.orc_advance_iter(self.h)

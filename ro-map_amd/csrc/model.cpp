@@ -39,7 +39,7 @@ static std::atomic<long>* option_slot(const char* name) {
     static const struct { const char* n; std::atomic<long> Options::*f; } tab[] = {
         { "backend", &Options::backend }, { "use_graph", &Options::use_graph }, { "lazy_ema", &Options::lazy_ema }, { "big_switch", &Options::big_switch },
         { "touched_flags", &Options::touched_flags },
-        { "fused_grid", &Options::fused_grid }, { "lds_encode", &Options::lds_encode }, { "roctx", &Options::roctx }, { "ray_records", &Options::ray_records }, { "encode_ablate", &Options::encode_ablate }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
+        { "fused_grid", &Options::fused_grid }, { "lds_encode", &Options::lds_encode }, { "roctx", &Options::roctx }, { "ray_records", &Options::ray_records }, { "step_variant", &Options::step_variant }, { "encode_ablate", &Options::encode_ablate }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
         { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner }, { "scatter_bins", &Options::scatter_bins }, { "opt_lazy_below", &Options::opt_lazy_below }, { "scatter_ablate", &Options::scatter_ablate } };
     for (const auto& e : tab) if (name && std::strcmp(name, e.n) == 0) return &(g_options.*(e.f));
     return nullptr;
@@ -575,7 +575,21 @@ static void enqueue_iteration(Model& m, int stages) {
         }
     }
     if (stages & 2) {      // Step_No_Compacted :1552-1607
-        if (m.backend == 0) {
+        if (m.backend == 0 && options().step_variant) {
+            // NeRF_Model::Step (nerf_model.cu:1504-1550): inference of every sample, per-ray sample compaction + rollover (kernels_step.hip), then forward +
+            // backward of the compacted batch.  B.pts / B.dO hold the compacted batch afterwards.
+            ProfScope ps(m, MON_K_FWDBWD);
+            if (!m.d_step_counts) { if (dev_alloc(m, m.d_step_counts, (size_t)m.oc.R + 1) || dev_alloc(m, m.d_step_pts, 3 * (size_t)B)) return; }
+            launch_encode(s, m.lt, m.nd, m.P.half, m.B.pts, m.B.E, B, m.d_state);
+            launch_mlp_forward(s, m.nd, m.P.half, m.B.E, nullptr, m.B.O, B, m.d_state);                      // :1509 inference_mixed_precision_impl, training weights
+            launch_step_compaction(s, m.B, m.oc, m.d_state, m.d_step_counts, m.d_step_pts);
+            hipMemcpyAsync(m.B.pts, m.d_step_pts, 12 * (size_t)B, hipMemcpyDeviceToDevice, s);
+            launch_encode(s, m.lt, m.nd, m.P.half, m.B.pts, m.B.E, B, m.d_state);                             // :1545 forward of the compacted batch
+            launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);
+            launch_mlp_backward(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state);          // :1547
+            launch_weight_grads(s, m.nd, m.B.E, m.B.Hid, m.B.dHid, m.B.dO, m.P.gmlp, B, m.d_state);
+            launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
+        } else if (m.backend == 0) {
             ProfScope ps(m, MON_K_FWDBWD);
             launch_encode(s, m.lt, m.nd, m.P.half, m.B.pts, m.B.E, B, m.d_state);
             launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);

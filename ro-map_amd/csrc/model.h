@@ -127,7 +127,7 @@ enum {
 struct Options {      // (atomics: tests and tools flip options while object threads read them)
     std::atomic<long> backend{ -1 }, use_graph{ 0 }, lazy_ema{ -1 }, big_switch{ 16384 }, touched_flags{ 1 },
          fused_grid{ 0 }, lds_encode{ 1 }, encode_ablate{ 0 }, opt_blocks{ 0 }, fused_ablate{ 0 }, fused_stagger{ -1 }, offline_outer{ 10 }, offline_inner{ 500 }, scatter_bins{ 0 }, opt_lazy_below{ -1 },
-         scatter_ablate{ 0 }, train_lanes{ 2 }, lane_chunk{ 16 }, online_slice_min{ 2 }, roctx{ 0 }, ray_records{ 1 };
+         scatter_ablate{ 0 }, train_lanes{ 2 }, lane_chunk{ 16 }, online_slice_min{ 2 }, roctx{ 0 }, ray_records{ 1 }, step_variant{ 0 };
 };
 Options& options();
 int option_set(const char* name, long value);
@@ -159,6 +159,9 @@ void launch_copy_params(hipStream_t s, const uint16_t* src, uint16_t* dst, uint3
 void model_leave_lane(struct Model& m);      // non-training work goes to the object's own stream (model.cpp, training lanes)
 void launch_pack_frame(hipStream_t s, const uint8_t* rgb, int ch, int ri, int bi, const uint8_t* inst, uint32_t* dst, uint32_t px);      // host (pinned) images -> packed RGBA8 | instance << 24
 void launch_copy_from_host(hipStream_t s, const void* src, void* dst, uint32_t n_words);      // source: pinned host memory the host rewrites (system-scope loads)
+
+// NeRF_Model::Step's schedule (kernels_step.hip; option step_variant): sample compaction + rollover of the batch between the two network passes
+void launch_step_compaction(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st, uint32_t* steps, float* pts_compacted);
 
 // optimizer (kernels_optim.hip)
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, const DevState* st, DevState* st_next, const OptimNext& nx, uint32_t lazy_below);   // lazy_below: gradient-carrying samples at or below which the dense-table optimizer requests Adam state per touched chunk only
@@ -237,6 +240,7 @@ struct Model {
     // XORWOW sample stream: lane states of the training generator (device), the two per-parity array sets, the iteration the fills have reached, the per-Render generator
     void* d_xw_states = nullptr; float* d_xw = nullptr; uint32_t xw_filled = 0, xw_lanes = 0; int xw_flavour = 0; uint32_t enq_iter = 0; uint64_t xw_offset = 0;      // xw_offset: values the training generator has produced
     void* d_xw_render_states = nullptr; void* d_xw_render_init = nullptr; float* d_xw_render = nullptr; size_t xw_render_cap = 0;
+    uint32_t* d_step_counts = nullptr; float* d_step_pts = nullptr;      // NeRF_Model::Step schedule (option step_variant): per-ray sample counts / slots, the compacted positions
     bool pre_active = false, points_ready = false;   // level-tile encode: used by the iteration being enqueued / the next batch's positions were written by the last k_optimizer
     bool next_ready = false;     // fused backend: candidates + fragment image of the coming iteration were already produced by the last k_optimizer
     mon_profile prof{}; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pending;
