@@ -137,6 +137,7 @@ int config_from_json(const char* path, mon_config& c) {
         c.loss_scale = (float)t->number("loss_scale", c.loss_scale);
         c.sample_seed = (uint64_t)t->number("sample_seed", (double)c.sample_seed);
         c.param_seed = (uint32_t)t->number("param_seed", (double)c.param_seed);
+        c.rng_flags = (uint32_t)t->number("rng_flags", (double)c.rng_flags);      // "same inputs" mode (include/mon_core.h mon_config::rng_flags), e.g. 17 = XORWOW in cuRAND's flavour + tcnn's init order
     }
     return MON_OK;
 }
