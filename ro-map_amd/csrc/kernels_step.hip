@@ -1,6 +1,6 @@
 // kernels_step.hip -- NeRF_Model::Step (CORE/src/nerf_model.cu:1504-1550), the reference's schedule with per-ray SAMPLE compaction.
 // The reference marks it "unavailable, for reference only" and neither driver calls it; it is built here behind mon_set_option("step_variant", 1) on the
-// layer-at-a-time kernels (backend 0) so that the row exists and is checked against the oracle's restatement (oracle/mon_oracle.c forward_backward_compacted):
+// layer-at-a-time kernels (backend 0) so that the row exists and can be checked against a CPU restatement (tests/test_step_variant.py):
 //   1. inference of every sample with the training weights (:1509)                                   -> launch_encode + launch_mlp_forward (model.cpp)
 //   2. VolumeRenderGradient (:957-1132), one thread per ray: composite until T < 1e-4 (numsteps), colour-only L2 loss, ONE background colour for all rays
 //      (the kernel's by-value copy of the generator: every thread draws the same three floats, :1038 -- here the iteration's first three RandColors), the
