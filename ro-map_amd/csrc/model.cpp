@@ -458,6 +458,7 @@ int model_destroy(Model* mp);
 int model_create(Dataset* ds, const mon_config& cfg, int class_id, const float* Tow, const float* amin, const float* amax, Model** out) {
     if (!ds || !Tow || !amin || !amax) { set_error("object_create: bad argument"); return MON_ERR_ARG; }
     if (cfg.rays_per_batch < 64 || (cfg.rays_per_batch % 64) != 0 || cfg.n_samples < 1 || cfg.n_samples > 64) { set_error("rays_per_batch must be a multiple of 64, n_samples 1..64"); return MON_ERR_ARG; }
+    if ((cfg.rng_flags & 3u) == 3u || (cfg.rng_flags & ~0xffff0013u) != 0u || (cfg.rng_flags >> 16) > 1024u) { set_error("rng_flags: bits 0-1 = 0 (counter RNG) | 1 (XORWOW, cuRAND flavour) | 2 (XORWOW, rocRAND flavour), bit 4 = tcnn init order, bits 16-31 = XORWOW lanes / 1024 (at most 1024)"); return MON_ERR_ARG; }
     if (!(cfg.loss_scale > 0.f) || !(cfg.loss_scale <= 65536.f)) { set_error("loss_scale must be in (0, 65536] (fp16 gradients; the reference uses 128)"); return MON_ERR_ARG; }
     Model* mp = new Model();
     const int rc = model_init(*mp, ds, cfg, class_id, Tow, amin, amax);

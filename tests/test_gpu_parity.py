@@ -484,6 +484,12 @@ def test_edge_cases(pkg, ss, small_scene):
     # ragged ray count
     with pytest.raises(pkg.MonError):
         pkg.ObjectNeRF(ds, pkg.default_config(rays_per_batch=1000), 1, ss.colmajor(ob["Tow"]), -ob["half"], ob["half"])
+    # rng_flags outside its definition (stream mode 3, stray bits, a million lanes)
+    for bad_flags in (3, 1 << 8, (2048 << 16) | 1):
+        c_bad = pkg.default_config(**C1); c_bad.rng_flags = bad_flags
+        with pytest.raises(pkg.MonError) as e:
+            pkg.ObjectNeRF(ds, c_bad, 1, ss.colmajor(ob["Tow"]), -ob["half"], ob["half"])
+        assert e.value.code == 1
     # occluder: pixels of another instance id never become rays (nerf_model.cu:398-401)
     sc2 = ss.make_scene(n_views=8, H=120, W=160, f=130.0, n_objects=3, seed=4)
     ds2, o4 = ge.make_problem(pkg, sc2, C1, obj_index=1)
