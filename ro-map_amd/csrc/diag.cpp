@@ -25,7 +25,7 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
     switch (which) {
         case MON_BUF_MASTER: src = m.P.master; sz = n * 4; break;       case MON_BUF_HALF: src = m.P.half; sz = n * 2; break;
         case MON_BUF_EMA: src = m.P.ema; sz = n * 2; break;             case MON_BUF_M1: src = m.P.m1; sz = n * 4; break;
-        case MON_BUF_M2: src = m.P.m2; sz = n * 4; break;               case MON_BUF_STEPS: src = m.P.steps; sz = n * 4; break;
+        case MON_BUF_M2: src = m.P.m2; sz = n * 4; break;               case MON_BUF_STEPS: src = m.P.steps ? (const void*)m.P.steps : (const void*)m.P.steps16; sz = n * 4; break;      // (16-bit counters are widened below)
         case MON_BUF_GMLP: src = m.P.gmlp; sz = (size_t)m.nd.n_mlp * 4; break;
         case MON_BUF_GGRID_H: src = m.P.ggrid; sz = (size_t)m.n_grid * 2; break;
         case MON_BUF_PTS: src = m.B.pts; sz = B * 12; break;            case MON_BUF_TDIST: src = m.B.tdist; sz = B * 4; break;
@@ -53,6 +53,11 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
     }
     if (!dst || bytes < sz) { set_error("debug_read: buffer too small (%zu < %zu)", bytes, sz); return MON_ERR_ARG; }
     HIPCHECK(use_device(m.device)); HIPCHECK(hipStreamSynchronize(m.train_stream));
+    if (which == MON_BUF_STEPS && !m.P.steps) {                            // saturating 16-bit counters on the device (ParamPtrs::steps16): hand out uint32 like before
+        std::vector<uint16_t> h16(n); HIPCHECK(hipMemcpy(h16.data(), src, n * 2, hipMemcpyDeviceToHost));
+        uint32_t* out = reinterpret_cast<uint32_t*>(dst); for (size_t i = 0; i < n; ++i) out[i] = h16[i];
+        return MON_OK;
+    }
     HIPCHECK(hipMemcpy(dst, src, sz, hipMemcpyDeviceToHost));
     if (which == MON_BUF_GGRID_H && m.backend == 1 && m.lds_mask) {        // total gradient = atomic table + sum of the scatter partials
         std::vector<uint16_t> part(m.n_grid); std::vector<float> acc(m.n_grid);

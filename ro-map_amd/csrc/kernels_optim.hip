@@ -28,11 +28,11 @@ template <class T> __device__ __forceinline__ void state_store(T v, T* p) {
 #endif
 }
 
-__device__ __forceinline__ float adam_update(float g, float w, float& m1, float& m2, uint32_t& steps, float lr0, const OptimConst& oc) {
+__device__ __forceinline__ float adam_update(float g, float w, float& m1, float& m2, uint32_t& steps, float lr0, const OptimConst& oc, uint32_t step_cap) {
     const float gsq = g * g;
     m1 = oc.beta1 * m1 + (1.f - oc.beta1) * g;
     m2 = oc.beta2 * m2 + (1.f - oc.beta2) * gsq;
-    const uint32_t cs = ++steps;
+    const uint32_t cs = min(steps + 1u, step_cap); steps = cs;      // (16-bit counters saturate at 65535: both bias corrections are exactly 1.0f from far below that, ParamPtrs::steps16)
     // beta^cs as exp2(cs * log2 beta): v_exp_f32-based, within ~3e-6 relative of powf for cs < 1e5
     const float lr = lr0 * sqrtf(1.f - exp2f((float)cs * oc.log2_beta2)) / (1.f - exp2f((float)cs * oc.log2_beta1));
     const float eff = lr / (sqrtf(m2) + oc.epsilon);
@@ -107,13 +107,19 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
         // DENSE tables, eager state: the 160 B of optimizer state of a thread's SECOND chunk are requested before its first chunk is worked on (`Pre`), so that
         // their latency runs under that chunk's arithmetic (vmcnt retires in order: they have to be issued before the first chunk's stores, not after).
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const uint32_t step_cap = p.steps16 ? 65535u : 0xffffffffu;
+        // a chunk's eight step counters: two 16-byte loads of uint32, or ONE of eight uint16 (4 B per parameter less to read and to write back)
+        auto load_steps = [&](uint32_t i0, u32x4& s0, u32x4& s1) __attribute__((always_inline)) {
+            if (p.steps16) { const u32x4 v = *reinterpret_cast<const u32x4*>(p.steps16 + i0); s0 = u32x4{ v[0] & 0xffffu, v[0] >> 16, v[1] & 0xffffu, v[1] >> 16 }; s1 = u32x4{ v[2] & 0xffffu, v[2] >> 16, v[3] & 0xffffu, v[3] >> 16 }; }
+            else { s0 = *reinterpret_cast<const u32x4*>(p.steps + i0); s1 = *reinterpret_cast<const u32x4*>(p.steps + i0 + 4); }
+        };
         struct Pre { float4_t w0, w1, a0, a1, b0, b1; u32x4 s0, s1; half8_t e; float4_t gm0, gm1; };      // (plain vector types and no arrays: HIP's uint4 is a union, and either keeps the struct in scratch memory)
         auto issue = [&](uint32_t c, Pre& L) __attribute__((always_inline)) {
             const uint32_t i0 = c << 3;
             L.w0 = *reinterpret_cast<const float4_t*>(p.master + i0); L.w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
             L.a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0); L.a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
             L.b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); L.b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
-            L.s0 = *reinterpret_cast<const u32x4*>(p.steps + i0); L.s1 = *reinterpret_cast<const u32x4*>(p.steps + i0 + 4);
+            load_steps(i0, L.s0, L.s1);
             L.e = *reinterpret_cast<const half8_t*>(p.ema + i0);
             if (i0 < oc.n_mlp) { L.gm0 = *reinterpret_cast<const float4_t*>(p.gmlp + i0); L.gm1 = *reinterpret_cast<const float4_t*>(p.gmlp + i0 + 4); }
         };
@@ -131,7 +137,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                 w0 = *reinterpret_cast<const float4_t*>(p.master + i0); w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
                 a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0); a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
                 b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
-                s0 = *reinterpret_cast<const uint4*>(p.steps + i0); s1 = *reinterpret_cast<const uint4*>(p.steps + i0 + 4);
+                { u32x4 t0, t1; load_steps(i0, t0, t1); s0 = uint4{ t0[0], t0[1], t0[2], t0[3] }; s1 = uint4{ t1[0], t1[1], t1[2], t1[3] }; }
             }
             const bool lazy_chunk = LAZY && !is_matrix;
             half8_t ema_in;
@@ -212,7 +218,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                     w0 = *reinterpret_cast<const float4_t*>(p.master + i0); w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
                     a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0); a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
                     b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
-                    s0 = *reinterpret_cast<const uint4*>(p.steps + i0); s1 = *reinterpret_cast<const uint4*>(p.steps + i0 + 4);
+                    { u32x4 t0, t1; load_steps(i0, t0, t1); s0 = uint4{ t0[0], t0[1], t0[2], t0[3] }; s1 = uint4{ t1[0], t1[1], t1[2], t1[3] }; }
                 }
                 float w[8] = { w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3] };
                 float m1[8] = { a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3] };
@@ -223,7 +229,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                     float gj = g[j];
                     if (is_matrix) gj += oc.l2_reg * w[j];                            // L2 only on matrix weights
                     else if (gj == 0.f) continue;                                     // untouched grid entry: skipped entirely
-                    w[j] = adam_update(gj, w[j], m1[j], m2[j], sc[j], lr0, oc);
+                    w[j] = adam_update(gj, w[j], m1[j], m2[j], sc[j], lr0, oc, step_cap);
                     wh[j] = (half_t)w[j];
                 }
                 // optimizer state is not touched again before the next step: stream it past the caches
@@ -231,7 +237,8 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                 state_store(float4_t{ m1[0], m1[1], m1[2], m1[3] }, reinterpret_cast<float4_t*>(p.m1 + i0)); state_store(float4_t{ m1[4], m1[5], m1[6], m1[7] }, reinterpret_cast<float4_t*>(p.m1 + i0 + 4));
                 state_store(float4_t{ m2[0], m2[1], m2[2], m2[3] }, reinterpret_cast<float4_t*>(p.m2 + i0)); state_store(float4_t{ m2[4], m2[5], m2[6], m2[7] }, reinterpret_cast<float4_t*>(p.m2 + i0 + 4));
                 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-                state_store(u4v{ sc[0], sc[1], sc[2], sc[3] }, reinterpret_cast<u4v*>(p.steps + i0)); state_store(u4v{ sc[4], sc[5], sc[6], sc[7] }, reinterpret_cast<u4v*>(p.steps + i0 + 4));
+                if (p.steps16) state_store(u4v{ sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16), sc[4] | (sc[5] << 16), sc[6] | (sc[7] << 16) }, reinterpret_cast<u4v*>(p.steps16 + i0));
+                else { state_store(u4v{ sc[0], sc[1], sc[2], sc[3] }, reinterpret_cast<u4v*>(p.steps + i0)); state_store(u4v{ sc[4], sc[5], sc[6], sc[7] }, reinterpret_cast<u4v*>(p.steps + i0 + 4)); }
                 *reinterpret_cast<half8_t*>(p.half + i0) = wh;
                 if (p.half_tiles && !is_matrix) {                                     // the same four entries in tile order for k_encode_tiles (tile_slot): whole level = as they are, else evens | odds
                     const uint32_t e0 = (i0 - oc.n_mlp) >> 1, size = lvl_end - lvl_off, e_rel = e0 - lvl_off;

@@ -39,7 +39,7 @@ static std::atomic<long>* option_slot(const char* name) {
     static const struct { const char* n; std::atomic<long> Options::*f; } tab[] = {
         { "backend", &Options::backend }, { "use_graph", &Options::use_graph }, { "lazy_ema", &Options::lazy_ema }, { "big_switch", &Options::big_switch },
         { "touched_flags", &Options::touched_flags },
-        { "fused_grid", &Options::fused_grid }, { "lds_encode", &Options::lds_encode }, { "roctx", &Options::roctx }, { "ray_records", &Options::ray_records }, { "step_variant", &Options::step_variant }, { "encode_ablate", &Options::encode_ablate }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
+        { "fused_grid", &Options::fused_grid }, { "lds_encode", &Options::lds_encode }, { "roctx", &Options::roctx }, { "ray_records", &Options::ray_records }, { "step_variant", &Options::step_variant }, { "steps16", &Options::steps16 }, { "encode_ablate", &Options::encode_ablate }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
         { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner }, { "scatter_bins", &Options::scatter_bins }, { "opt_lazy_below", &Options::opt_lazy_below }, { "scatter_ablate", &Options::scatter_ablate } };
     for (const auto& e : tab) if (name && std::strcmp(name, e.n) == 0) return &(g_options.*(e.f));
     return nullptr;
@@ -333,8 +333,10 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     m.train_stream = m.own_stream; m.lanes = lanes_get(m.device); m.lanes->objects.fetch_add(1);
     // ---- parameters (ResetNetwork :1286-1342; Trainer init)
     const size_t n = m.n_params;
+    // per-parameter step counters in 16 bits, saturating, where that is EXACT: 1 - beta^t == 1.0f (beta^t < 2^-25) for every t >= 65535 and both betas (option steps16 = 0: always 32 bits)
+    const bool steps16 = options().steps16 != 0 && std::pow((double)cfg.beta1, 65535.0) < std::ldexp(1.0, -25) && std::pow((double)cfg.beta2, 65535.0) < std::ldexp(1.0, -25);
     if ((rc = dev_alloc(m, m.P.master, n, false)) || (rc = dev_alloc(m, m.P.half, n, false)) || (rc = dev_alloc(m, m.P.ema, n)) ||
-        (rc = dev_alloc(m, m.P.m1, n)) || (rc = dev_alloc(m, m.P.m2, n)) || (rc = dev_alloc(m, m.P.steps, n)) || (rc = dev_alloc(m, m.d_ema_step, n / 8 + 1)) ||
+        (rc = dev_alloc(m, m.P.m1, n)) || (rc = dev_alloc(m, m.P.m2, n)) || (rc = steps16 ? dev_alloc(m, m.P.steps16, n + 8) : dev_alloc(m, m.P.steps, n)) || (rc = dev_alloc(m, m.d_ema_step, n / 8 + 1)) ||
         (rc = dev_alloc(m, m.P.gmlp, m.nd.n_mlp)) || (rc = dev_alloc(m, m.P.ggrid, m.n_grid))) return rc;
     {
         std::vector<float> master; init_params_host(cfg, m.nd, m.n_params, master);
