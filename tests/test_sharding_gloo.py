@@ -52,6 +52,20 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_gather_to_root_with_four_ranks():
+    """BASELINE configs[2]'s shape in small: more ranks than two, objects spread unevenly (5 objects over 4 ranks), both gathers of _worker (root 0, root 1)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port(); world = 4
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60); assert p.exitcode == 0
+    assert [r[1] for r in res] == [[0, 4], [1], [2], [3]]
+    assert all(r[2] for r in res) and all(r[3] == 4.0 for r in res)
+
+
 def test_round_robin_map_and_gather():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port(); world = 2
