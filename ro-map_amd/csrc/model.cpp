@@ -387,7 +387,11 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         const uint32_t big_switch = (uint32_t)options().big_switch;
         if (big_bytes && big_switch) { if ((rc = dev_alloc(m, m.d_big_ws, big_bytes))) return rc; m.big_switch = big_switch; }
         // level-tile encode (kernels_encode.hip): every level must fit two LDS tiles and go through the LDS scatter (option lds_encode = 0: gathers inside k_fused_train)
-        if (options().lds_encode && !cfg.occupancy_skip && m.lds_mask == ((1u << m.nd.L) - 1u) && encode_tiles_supported(m.lt, m.nd)) {
+        // Batch size: a workgroup's two tile copies, four barriers and the launch cost the same whatever it walks -- measured (tools/kernel_times.py, both chains, same box):
+        // R = 1024 (C1) 48.9 vs 41.3 us per step for the gather chain, R = 2048 75.1 vs 75.4, R = 4096 99 vs 107, R = 8192 166 vs 172.  Option lds_encode = 1 (default) takes the
+        // tile chain from 3072 rays (98 304 samples) up, 2 always (tests), 0 never.
+        const bool tiles_pay = options().lds_encode >= 2 || Btrain >= 98304u;
+        if (options().lds_encode && tiles_pay && !cfg.occupancy_skip && m.lds_mask == ((1u << m.nd.L) - 1u) && encode_tiles_supported(m.lt, m.nd)) {
             if (options().ray_records && (rc = dev_alloc(m, B.ray_rec, 12 * (size_t)R))) return rc;
             m.B_alt = B;                             // (cand_* / mask replaced below, after the workspace pointers are final)
             if ((rc = dev_alloc(m, m.B_alt.cand_o, 3 * (size_t)R)) || (rc = dev_alloc(m, m.B_alt.cand_d, 3 * (size_t)R)) || (rc = dev_alloc(m, m.B_alt.cand_dn, R)) ||
@@ -639,7 +643,7 @@ static void enqueue_iteration(Model& m, int stages) {
         if (m.backend == 1 && fold) {
             nx.cand_blocks = pos_mode ? 0u : (m.oc.R + 255) / 256; nx.frag_image = m.d_frag_train; nx.fd = FragDims{ m.nd.Epad, m.nd.W, m.nd.NH, m.nd.L };
             nx.b = pos_mode ? m.B_alt : m.B; nx.ds = m.ds->ptrs(); nx.oc = m.oc;
-            if (pos_mode) { nx.pos_blocks = (B + 255u) / 256u; nx.x_all = m.d_x_all; }      // one sample per thread: a thread's chain is select -> candidate loads -> store, ~5 us of latency that several samples per thread would put in series (64 blocks of 8 samples per thread made these blocks the kernel's tail)
+            if (pos_mode) { nx.pos_blocks = std::min((B + 255u) / 256u, 512u); nx.x_all = m.d_x_all; }      // one sample per thread up to 131 072 samples (two beyond: as many position blocks as optimizer blocks made the kernel 10 us longer at R = 8192): a thread's chain is select -> candidate loads -> store, ~5 us of latency that several samples per thread put in series (64 blocks of 8 samples per thread made these blocks the kernel's tail)
         }
         launch_optimizer(s, P, m.opt, m.d_state, m.d_state_next, nx, options().opt_lazy_below < 0 ? (m.oc.R * m.oc.S) / 8u : (uint32_t)options().opt_lazy_below); m.scatter_pending = false;
         std::swap(m.d_state, m.d_state_next);                // the next iteration (and the host's read-back) uses the state this launch prepares

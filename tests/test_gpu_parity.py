@@ -700,7 +700,11 @@ def test_level_tile_encode_matches_oracle_and_the_gather_path(pkg, orc, small_sc
     """The default forward pass of the fused backend: positions by k_sample_points / k_optimizer's position blocks, hash-grid encode by k_encode_tiles from
     LDS-resident level tiles (whole levels and even / odd parity tiles), features loaded by k_fused_train<PRE>.  Positions and encoded features must equal
     the oracle's bit for bit, the tile image must be the tile_slot permutation of the fp16 grid, and training must give the same parameters as the gather path."""
-    ds, obj, ref = _pair(pkg, orc, small_scene, kw, 1)
+    pkg.set_option("lds_encode", 2)                       # (the default takes the tile chain from 3072 rays up: below that its fixed costs lose against the gathers)
+    try:
+        ds, obj, ref = _pair(pkg, orc, small_scene, kw, 1)
+    finally:
+        pkg.set_option("lds_encode", 1)
     obj.set_debug_dump(False)
     p = pattern_params(ref); obj.set_params(p); ref.set_params(p)
     L, B = obj.cfg.n_levels, obj.R * obj.S

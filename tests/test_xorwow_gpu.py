@@ -44,7 +44,11 @@ def test_rocrand_host_generator_matches_the_oracle_stream(pkg, orc):
 def test_hip_path_in_xorwow_mode_matches_the_oracle(pkg, orc, ss, small_scene, backend, mode):
     assert pkg.device_count() >= 1
     kw = dict(C1, **mode)
-    ds, obj = ge.make_problem(pkg, small_scene, kw); obj.set_backend(backend)
+    pkg.set_option("lds_encode", 2)                       # the tile chain also at this small batch (default: from 3072 rays up), so that its position / candidate pipeline runs on the XORWOW arrays
+    try:
+        ds, obj = ge.make_problem(pkg, small_scene, kw); obj.set_backend(backend)
+    finally:
+        pkg.set_option("lds_encode", 1)
     ref = ge.make_oracle(orc, small_scene, kw)
     assert np.array_equal(obj.get_params(0), ref.buffer("master"))                     # same initial weights, also in tcnn's element order
     if backend == 1:
