@@ -15,7 +15,10 @@
  *       hash-grid encoding, fully fused MLP, Adam / ExponentialDecay / EMA optimizers.
  * It is pinned by this repo's own known-answer tests (tests/test_oracle_*.py): closed-form
  * composite, finite-difference / torch-autograd checks of the hand-derived gradient,
- * closed-form Adam/EMA step, hash-index KATs.
+ * closed-form Adam/EMA step, hash-index KATs; since round 3 also the WHOLE backward chain against
+ * torch autograd, the grid backward per entry against an fp64 NumPy scatter, and -- the one piece
+ * with a second source in the image -- the XORWOW sample stream of the "same inputs" mode against
+ * rocRAND (engine: tests/test_xorwow.py; host generator on the GPU: tests/test_xorwow_gpu.py).
  *
  * Numeric model (rounding points; "h()" = round-to-nearest-even to IEEE fp16):
  *   table/weights  fp16 working copy of fp32 master           (tcnn: half params + fp32 master)
