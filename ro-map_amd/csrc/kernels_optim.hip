@@ -64,7 +64,12 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
         __shared__ PointsLds plds;
         const uint32_t nwords = nx.oc.R >> 6, nv = points_prefix(plds, nx.b.mask, nwords);
         if (blockIdx.x == 0 && threadIdx.x == 0) st_next->n_valid_pre = nv;
-        if (nv != 0u) for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nx.oc.R * 32u; s += nx.pos_blocks * blockDim.x) points_sample(plds, nx.b, nx.oc, st->iter + 1u, nv, nwords, s, reinterpret_cast<float4_t*>(nx.x_all));
+#if defined(MON_OPT_ABLATE) && (MON_OPT_ABLATE & 4)
+        if (false)
+#else
+        if (nv != 0u)
+#endif
+            for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nx.oc.R * 32u; s += nx.pos_blocks * blockDim.x) points_sample(plds, nx.b, nx.oc, st->iter + 1u, nv, nwords, s, reinterpret_cast<float4_t*>(nx.x_all));
     }
     const uint32_t bid = blockIdx.x - extra, nblk = gridDim.x - extra;
     const float lr0 = st->lr;
@@ -186,6 +191,10 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                         }
                 };
                 uint32_t q = 0;
+#if defined(MON_OPT_ABLATE) && (MON_OPT_ABLATE & 2)
+                for (int j = 0; j < 8; ++j) g[j] = 1e-3f;
+                n_part = 0;
+#endif
                 for (; q + 2 <= n_part; q += 2) {                       // 8 independent 4-byte loads in flight
                     float va[8], vb[8]; quad(q, va); quad(q + 1u, vb);
 #pragma unroll
@@ -229,7 +238,11 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                     float gj = g[j];
                     if (is_matrix) gj += oc.l2_reg * w[j];                            // L2 only on matrix weights
                     else if (gj == 0.f) continue;                                     // untouched grid entry: skipped entirely
+#if defined(MON_OPT_ABLATE) && (MON_OPT_ABLATE & 1)
+                    m1[j] += gj; m2[j] += gj; sc[j] += 1u; w[j] -= 1e-6f * gj;
+#else
                     w[j] = adam_update(gj, w[j], m1[j], m2[j], sc[j], lr0, oc, step_cap);
+#endif
                     wh[j] = (half_t)w[j];
                 }
                 // optimizer state is not touched again before the next step: stream it past the caches
@@ -240,7 +253,11 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                 if (p.steps16) state_store(u4v{ sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16), sc[4] | (sc[5] << 16), sc[6] | (sc[7] << 16) }, reinterpret_cast<u4v*>(p.steps16 + i0));
                 else { state_store(u4v{ sc[0], sc[1], sc[2], sc[3] }, reinterpret_cast<u4v*>(p.steps + i0)); state_store(u4v{ sc[4], sc[5], sc[6], sc[7] }, reinterpret_cast<u4v*>(p.steps + i0 + 4)); }
                 *reinterpret_cast<half8_t*>(p.half + i0) = wh;
-                if (p.half_tiles && !is_matrix) {                                     // the same four entries in tile order for k_encode_tiles (tile_slot): whole level = as they are, else evens | odds
+#if defined(MON_OPT_ABLATE) && (MON_OPT_ABLATE & 8)
+                if (false) {
+#else
+                if (p.half_tiles && !is_matrix) {
+#endif                                     // the same four entries in tile order for k_encode_tiles (tile_slot): whole level = as they are, else evens | odds
                     const uint32_t e0 = (i0 - oc.n_mlp) >> 1, size = lvl_end - lvl_off, e_rel = e0 - lvl_off;
                     if (size <= kEncWholeMax) *reinterpret_cast<half8_t*>(p.half_tiles + 2u * (size_t)e0) = wh;
                     else {

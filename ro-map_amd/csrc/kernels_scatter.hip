@@ -28,6 +28,9 @@ namespace mon {
 // Every level gets 16 workgroups: parts_l x P_l sample partitions (parts = 1 / 2 for the 64-bit tiles, 4 x ceil(entries / 65 536) otherwise).  Tiles are
 // written densely as fp16 to partial table p, plane (feature, parity) of that level ([P][2][2][entries / 2]); the optimizer sums the P_l partial tables.
 // No global atomics, no memset: every tile is fully rewritten each step.
+#ifndef MON_V_SGROUP
+#define MON_V_SGROUP 2
+#endif
 constexpr uint32_t kScatterTile = 32768;          // entries per int32 tile of a parity half (one feature) = 128 KB
 constexpr uint32_t kScatterLdsBytes = 163840;     // the workgroup declares the CU's whole LDS
 constexpr uint32_t kScatterTile64 = (kScatterLdsBytes - 256u) / 8u;      // entries per 64-bit tile (both features): 20 448
@@ -45,6 +48,10 @@ __device__ __forceinline__ int contrib_fix(float w, float g, float fs) { return 
 // hi = (S - lo) >> 32 while both sums stay inside int32 (they do: the same clamp as for the 32-bit tiles)
 __device__ __forceinline__ unsigned long long pack_fix(int lo, int hi) { return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)(hi + (lo >> 31)) << 32); }
 
+// (written as instructions: from the C forms the compiler rebuilt a compare + select pair for each of the two)
+__device__ __forceinline__ uint32_t sign_of_bit0(uint32_t h) { uint32_t m; asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m) : "v"(h)); return m; }                                       // bit 0 set ? ~0 : 0
+__device__ __forceinline__ uint32_t bit_select(uint32_t m, uint32_t a, uint32_t b) { uint32_t r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b)); return r; }   // (m & a) | (~m & b)
+
 // One sample, one level.  The two x-corners of a (y, z) pair always have entry indices of different parity -- hashed: idx1 = idx0 ^ ((x ^ (x + 1)) & mask)
 // and x ^ (x + 1) is odd; dense: idx1 = idx0 + 1 modulo an even size (the clamps below only act on positions far outside [0,1]^3, which the sampler never
 // produces: they keep such a sample inside the table, where it lands is then as meaningless as the sample).
@@ -54,45 +61,67 @@ __device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bo
     constexpr bool BOTH = MODE == kTileWhole64 || MODE == kTileParity64;
     const float g = (float)(feature ? it.g.y : it.g.x), g0 = (float)it.g.x, g1 = (float)it.g.y;          // (k_fused_train stores dL/dE already clamped to the fixed-point range)
     if (!valid || (BOTH ? (g0 == 0.f && g1 == 0.f) : g == 0.f)) return;
-    float pos[3]; uint32_t pg[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, it.x[d], 0.5f), fl = floorf(q); pg[d] = (uint32_t)(int32_t)fl; pos[d] = q - fl; }
+    // The floating-point side works on PAIRS (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations, two per instruction -- the walk is bound by
+    // VALU issue): x | y of the position, the weights of the pairs j = 0, 1 (they share wz[0]) and j = 2, 3 (wz[1]), and the products with the fixed-point unit.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 qxy = __builtin_elementwise_fma(f2{ scale, scale }, f2{ it.x[0], it.x[1] }, f2{ 0.5f, 0.5f }); const float qz = fmaf(scale, it.x[2], 0.5f);
+    const f2 fxy = { floorf(qxy.x), floorf(qxy.y) }; const float fz = floorf(qz);
+    const f2 pxy = qxy - fxy, nxy = f2{ 1.f, 1.f } - pxy; const float pz = qz - fz;
+    const uint32_t pg[3] = { (uint32_t)(int32_t)fxy.x, (uint32_t)(int32_t)fxy.y, (uint32_t)(int32_t)fz };
     // hashed levels: only the index bits below the (power-of-two) table size matter, so the 24-bit multiply (full rate) serves: positions are < 2^24
     const uint32_t ax0 = pg[0], ax1 = pg[0] + 1u, y0 = (HASHED && POW2) ? __umul24(pg[1], my & 0xffffffu) : pg[1] * my, z0 = (HASHED && POW2) ? __umul24(pg[2], mz & 0xffffffu) : pg[2] * mz;
     const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
-    const float wx[2] = { 1.f - pos[0], pos[0] }, wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
+    const float wx[2] = { nxy.x, pxy.x }, wz[2] = { 1.f - pz, pz }; const f2 wy2 = { nxy.y, pxy.y };
     unsigned long long* tab64 = reinterpret_cast<unsigned long long*>(tab);
+    const auto fix2 = [&](f2 w, float gg) -> f2 { return f2{ (float)(half_t)(w.x * gg), (float)(half_t)(w.y * gg) } * fs; };      // contrib_fix of two corners, before the conversion to int
     if (MODE == kTileWhole64) {                                   // the whole level is this workgroup's: eight corners, nothing to test, one 64-bit atomic each
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t t = HASHED ? (ay[(k >> 1) & 1] ^ az[k >> 2]) : (ay[(k >> 1) & 1] + az[k >> 2]);
-            uint32_t idx = (HASHED ? ((k & 1 ? ax1 : ax0) ^ t) : ((k & 1 ? ax1 : ax0) + t)) & mask;
-            if (!POW2) { idx -= (idx >= size) ? size : 0u; idx = min(idx, size - 1u); }
-            const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];      // ((wx * wy) * wz): the reference walk's product order
-            atomicAdd(tab64 + idx, pack_fix(contrib_fix(w, g0, fs), contrib_fix(w, g1, fs)));
+        for (int j = 0; j < 4; ++j) {                             // the two x-corners of pair j = y + 2 z
+            const uint32_t t = HASHED ? (ay[j & 1] ^ az[j >> 1]) : (ay[j & 1] + az[j >> 1]);
+            uint32_t idx[2] = { (HASHED ? (ax0 ^ t) : (ax0 + t)) & mask, (HASHED ? (ax1 ^ t) : (ax1 + t)) & mask };
+            if (!POW2) { idx[0] -= (idx[0] >= size) ? size : 0u; idx[0] = min(idx[0], size - 1u); idx[1] -= (idx[1] >= size) ? size : 0u; idx[1] = min(idx[1], size - 1u); }
+            const f2 w = (f2{ wx[0], wx[1] } * ((j & 1) ? wy2.y : wy2.x)) * wz[j >> 1];      // ((wx * wy) * wz): the reference walk's product order
+            const f2 c0 = fix2(w, g0), c1 = fix2(w, g1);
+            atomicAdd(tab64 + idx[0], pack_fix((int)c0.x, (int)c1.x)); atomicAdd(tab64 + idx[1], pack_fix((int)c0.y, (int)c1.y));
         }
         return;
     }
-    const uint32_t dxm = (ax0 ^ ax1) & mask;                      // hashed power-of-two level: idx1 = idx0 ^ dxm (odd)
-    int dsum = 0; uint32_t dlocal = 0;                            // (degenerate level, see below)
+    uint32_t local[4]; float ws[4];                               // per pair: this workgroup's corner -- its place in the tile and its x-weight
+    if (HASHED && POW2) {
+        // idx0 = (x ^ y' ^ z') & mask, idx1 = idx0 ^ dxm with dxm odd: with the tile's parity folded into x, bit 0 of h says which x-corner is this workgroup's
+        // (m = all ones: the second), and the place in the parity half is (idx >> 1) = bits 1.. of h, xor-ed with dxm >> 1 for the second corner
+        const uint32_t axp = ax0 ^ parity, dxh = ((ax0 ^ ax1) & mask) >> 1, nb = (uint32_t)__popc(mask) - 1u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t idx0, idx1;
-        if (HASHED && POW2) { idx0 = (ax0 ^ ay[j & 1] ^ az[j >> 1]) & mask; idx1 = idx0 ^ dxm; }
-        else {
-            const uint32_t t = HASHED ? (ay[j & 1] ^ az[j >> 1]) : (ay[j & 1] + az[j >> 1]);
-            idx0 = (HASHED ? (ax0 ^ t) : (ax0 + t)) & mask; idx1 = (HASHED ? (ax1 ^ t) : (ax1 + t)) & mask;
-            if (!POW2) { idx0 -= (idx0 >= size) ? size : 0u; idx0 = min(idx0, size - 1u); idx1 -= (idx1 >= size) ? size : 0u; idx1 = min(idx1, size - 1u); }
+        for (int j = 0; j < 4; ++j) {
+            if (DEGEN && j) { local[j] = local[0]; ws[j] = ws[0]; continue; }      // (the index ignores y and z: one entry, one x-corner for all four pairs)
+            const uint32_t h = axp ^ ay[j & 1] ^ az[j >> 1];
+            const uint32_t m = sign_of_bit0(h);
+            local[j] = (__builtin_amdgcn_ubfe(h, 1u, nb) ^ (dxh & m)) - (MODE == kTileParityRanged ? base_half : 0u);
+            ws[j] = __builtin_bit_cast(float, bit_select(m, __builtin_bit_cast(uint32_t, wx[1]), __builtin_bit_cast(uint32_t, wx[0])));
         }
-        const bool second = ((idx0 ^ parity) & 1u) != 0u;        // which corner of the pair is this workgroup's
-        const uint32_t idx = second ? idx1 : idx0;
-        const float w = ((second ? wx[1] : wx[0]) * wy[j & 1]) * wz[j >> 1];
-        const uint32_t local = (idx >> 1) - base_half;
-        if (MODE == kTileParity64) atomicAdd(tab64 + local, pack_fix(contrib_fix(w, g0, fs), contrib_fix(w, g1, fs)));
-        else if (DEGEN) { dsum += contrib_fix(w, g, fs); dlocal = local; }      // all four pairs are the SAME entry: one atomic for the (exact) sum
-        else if (MODE == kTileParity || local < tile) atomicAdd(tab + local, contrib_fix(w, g, fs));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t t = HASHED ? (ay[j & 1] ^ az[j >> 1]) : (ay[j & 1] + az[j >> 1]);
+            uint32_t idx0 = (HASHED ? (ax0 ^ t) : (ax0 + t)) & mask, idx1 = (HASHED ? (ax1 ^ t) : (ax1 + t)) & mask;
+            if (!POW2) { idx0 -= (idx0 >= size) ? size : 0u; idx0 = min(idx0, size - 1u); idx1 -= (idx1 >= size) ? size : 0u; idx1 = min(idx1, size - 1u); }
+            const bool second = ((idx0 ^ parity) & 1u) != 0u;    // which corner of the pair is this workgroup's
+            local[j] = ((second ? idx1 : idx0) >> 1) - (MODE == kTileParityRanged ? base_half : 0u);
+            ws[j] = second ? wx[1] : wx[0];
+        }
     }
-    if (DEGEN) atomicAdd(tab + dlocal, dsum);
+    const f2 w01 = (f2{ ws[0], ws[1] } * wy2) * wz[0], w23 = (f2{ ws[2], ws[3] } * wy2) * wz[1];      // ((wx * wy) * wz): the reference walk's product order
+    if (MODE == kTileParity64) {
+        const f2 a0 = fix2(w01, g0), a1 = fix2(w01, g1), b0 = fix2(w23, g0), b1 = fix2(w23, g1);
+        atomicAdd(tab64 + local[0], pack_fix((int)a0.x, (int)a1.x)); atomicAdd(tab64 + local[1], pack_fix((int)a0.y, (int)a1.y));
+        atomicAdd(tab64 + local[2], pack_fix((int)b0.x, (int)b1.x)); atomicAdd(tab64 + local[3], pack_fix((int)b0.y, (int)b1.y));
+        return;
+    }
+    const f2 a = fix2(w01, g), b = fix2(w23, g);
+    const int c[4] = { (int)a.x, (int)a.y, (int)b.x, (int)b.y };
+    if (DEGEN) { atomicAdd(tab + local[3], (c[0] + c[1]) + (c[2] + c[3])); return; }      // all four pairs are the SAME entry: one atomic for the (exact) sum
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (MODE == kTileParity || local[j] < tile) atomicAdd(tab + local[j], c[j]);
 }
 
 template <bool HASHED, bool POW2, int MODE, bool DEGEN = false>
@@ -115,7 +144,13 @@ __device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restr
     if (width == 0u) return;
     uint32_t w2s = 6u; while ((1u << w2s) < blockDim.x && (1u << w2s) < width) ++w2s;   // threads per bin and step: W2 = 2^w2s = the run length rounded up to a power of two, one wave at least
     const uint32_t W2 = 1u << w2s, gs = 10u - w2s, G = 1u << gs;                         // (1024 threads: G = 1024 / W2 groups; powers of two throughout, no divisions)
-    const uint32_t wg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> w2s)), lane_o = threadIdx.x & (W2 - 1u);
+    // Dense levels: the rows of a run are a ray's samples in order, and neighbours along a ray sit in the same coarse cell -- the lanes of a wave would add into
+    // the same few entries, and the LDS serialises same-address atomics (ds_add_u64: 19 cycles per wave instruction on random addresses, 46 when four lanes
+    // share one: tools/ldsatomicbench.py).  There a wave takes GROUPS of kGroup consecutive rows (still 16 * kGroup contiguous bytes per group) from runs W2 / 16
+    // rows apart; hashed levels scramble the addresses themselves and keep the contiguous rows.
+    constexpr uint32_t kGroupBits = MON_V_SGROUP;
+    const uint32_t wg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> w2s)), lane_c = threadIdx.x & (W2 - 1u);
+    const uint32_t lane_o = HASHED ? lane_c : ((((lane_c & 63u) >> kGroupBits) << (w2s - 6u + kGroupBits)) | ((lane_c >> 6) << kGroupBits) | (lane_c & ((1u << kGroupBits) - 1u)));
     const uint32_t ksteps = (nb + G - 1u) >> gs, rounds = (width + W2 - 1u) >> w2s, n_steps = rounds * ksteps;
     uint32_t fks = 0, fo = lane_o, fs_left = n_steps;                                   // running state of the step the next fetch serves (all but fo uniform)
     const auto fetch = [&](ScatterItem& it, bool& valid) {
@@ -248,7 +283,7 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
     const bool both = mode == kTileWhole64 || mode == kTileParity64;
     const uint32_t feature = both ? 0u : (part & 1u), parity = mode == kTileWhole64 ? 0u : (both ? (part & 1u) : ((part >> 1) & 1u));
     const uint32_t half_size = size >> 1, base_half = mode == kTileParityRanged ? (part >> 2) * kScatterTile : 0u;      // (level sizes are multiples of 8) parity tiles: idx = 2 * (base_half + local) + parity
-    const bool degenerate = hashed && pow2 && (my & mask) == 0u && (mz & mask) == 0u;  // the index ignores y and z (tcnn's stride wrap-around at res = 65 536): the four pairs of a sample are one entry
+    const bool degenerate = pow2 && (my & mask) == 0u && (mz & mask) == 0u && size > 1u;  // the index ignores y and z (tcnn's stride wrap-around at res = 65 536): the four pairs of a sample are one entry
     MON_ST_STAMP();
     if (mode != kTileParityRanged || base_half < half_size) {                         // (levels whose part count does not divide 16 leave workgroups without a tile)
         const uint32_t tile = mode == kTileWhole64 ? size : min(mode == kTileParity64 ? kScatterTile64 : kScatterTile, half_size - base_half);      // entries

@@ -55,6 +55,21 @@ __global__ void __launch_bounds__(1024) k_ub_lds(int mode, uint32_t ops_per_thre
     __syncthreads();
     typedef __attribute__((address_space(3))) half2_t lh2;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode >= 40 && mode <= 49) {            // minimal-ALU atomics with SHARED addresses: groups of 2^share adjacent lanes follow the same index sequence
+        // 40..43: ds_add_u64 over the 128 KB tile, share = mode - 40 (1, 2, 4, 8 lanes per address);  44..47: ds_add_u32 likewise;  48 / 49: ds_add_u64 / u32 over a 32 KB range, no sharing
+        const uint32_t share = (mode <= 47) ? (uint32_t)(mode - 40) & 3u : 0u, range = mode >= 48 ? 4095u : 16383u;
+        const bool wide = mode <= 43 || mode == 48;
+        uint32_t idx = mix32((gid >> share) * 0x9E3779B9u + 777u) & 32767u;
+#pragma unroll 16
+        for (uint32_t i = 0; i < ops_per_thread; ++i) {
+            idx = (idx * 5u + 12345u) & 32767u;
+            if (wide) atomicAdd(reinterpret_cast<unsigned long long*>(tab) + (idx & range), 0x0000000100000001ull);
+            else atomicAdd(tab + (idx & (2u * range + 1u)), 1u);
+        }
+        __syncthreads();
+        if (tab[threadIdx.x] == 0x12345678u) sink[0] = 1.f;
+        return;
+    }
     if (mode >= 17 && mode <= 19) {            // minimal-ALU probes: 17 ds_read_b32 random, 18 ds_add_u32 random, 19 ds_read_b64 random (LCG index, 2 VALU per op)
         uint32_t idx = mix32(gid * 0x9E3779B9u + 777u) & 32767u, accu = 0u;
 #pragma unroll 16
@@ -90,21 +105,100 @@ __global__ void __launch_bounds__(256) k_ub_copy(const ub_u4* __restrict__ src, 
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) __builtin_nontemporal_store(src[i], dst + i);
 }
 
+// modes 31 / 32: the optimizer's memory streams without its arithmetic -- n_ops parameters: fp32 master / m1 / m2 read + written, 16-bit step counters and EMA read + written,
+// fp16 copy and tile image written, `parts` fp16 partial-table planes read (flags bits 8..11).  flags bit 0: plain instead of non-temporal stores.
+//   31: the shipped kernel's shape -- a thread owns 8 consecutive parameters (two 16-byte pieces of every fp32 array, lane stride 32 B), `units` such chunks
+//       requested up front;   32: a thread owns 4 consecutive parameters per unit (one 16-byte piece: a wave instruction covers 1 KB without holes), units a wave apart
+struct StreamPtrs { float *master, *m1, *m2; uint16_t *steps, *ema, *half, *tiles; const uint16_t* parts; uint32_t n, n_parts, flags; };
+typedef float ub_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t ub_u2 __attribute__((ext_vector_type(2)));
+template <class T> __device__ __forceinline__ void ub_store(T v, T* p, bool plain) { if (plain) *p = v; else __builtin_nontemporal_store(v, p); }
+template <int UNITS>
+__global__ void __launch_bounds__(256) k_ub_stream8(StreamPtrs a) {
+    const bool plain = a.flags & 1u;
+    const uint32_t n_chunks = a.n >> 3, stride = gridDim.x * blockDim.x;
+    for (uint32_t c0 = blockIdx.x * blockDim.x + threadIdx.x; c0 < n_chunks; c0 += stride * UNITS) {
+        ub_f4 w[UNITS][2], m1[UNITS][2], m2[UNITS][2]; ub_u4 st[UNITS], e[UNITS]; float g[UNITS];
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const uint32_t c = min(c0 + u * stride, n_chunks - 1u), i0 = c << 3;
+            w[u][0] = *reinterpret_cast<const ub_f4*>(a.master + i0); w[u][1] = *reinterpret_cast<const ub_f4*>(a.master + i0 + 4);
+            m1[u][0] = *reinterpret_cast<const ub_f4*>(a.m1 + i0); m1[u][1] = *reinterpret_cast<const ub_f4*>(a.m1 + i0 + 4);
+            m2[u][0] = *reinterpret_cast<const ub_f4*>(a.m2 + i0); m2[u][1] = *reinterpret_cast<const ub_f4*>(a.m2 + i0 + 4);
+            st[u] = *reinterpret_cast<const ub_u4*>(a.steps + i0); e[u] = *reinterpret_cast<const ub_u4*>(a.ema + i0);
+            g[u] = 0.f;
+            for (uint32_t q = 0; q < a.n_parts; ++q)
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) g[u] += (float)*reinterpret_cast<const uint32_t*>(a.parts + ((size_t)(q * 4u + pl) * (a.n >> 2)) + (i0 >> 2));
+        }
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const uint32_t c = c0 + u * stride, i0 = c << 3;
+            if (c >= n_chunks) break;
+            const float d = g[u] * 1e-30f + 1.f;
+            ub_store(w[u][0] + d, reinterpret_cast<ub_f4*>(a.master + i0), plain); ub_store(w[u][1] + d, reinterpret_cast<ub_f4*>(a.master + i0 + 4), plain);
+            ub_store(m1[u][0] + d, reinterpret_cast<ub_f4*>(a.m1 + i0), plain); ub_store(m1[u][1] + d, reinterpret_cast<ub_f4*>(a.m1 + i0 + 4), plain);
+            ub_store(m2[u][0] + d, reinterpret_cast<ub_f4*>(a.m2 + i0), plain); ub_store(m2[u][1] + d, reinterpret_cast<ub_f4*>(a.m2 + i0 + 4), plain);
+            ub_store(st[u] + 1u, reinterpret_cast<ub_u4*>(a.steps + i0), plain);
+            *reinterpret_cast<ub_u4*>(a.ema + i0) = e[u] + 1u; *reinterpret_cast<ub_u4*>(a.half + i0) = e[u] + st[u]; *reinterpret_cast<ub_u4*>(a.tiles + i0) = e[u] ^ st[u];
+        }
+    }
+}
+template <int UNITS>
+__global__ void __launch_bounds__(256) k_ub_stream4(StreamPtrs a) {
+    const bool plain = a.flags & 1u;
+    const uint32_t n_quads = a.n >> 2, stride = gridDim.x * blockDim.x;
+    for (uint32_t c0 = blockIdx.x * blockDim.x + threadIdx.x; c0 < n_quads; c0 += stride * UNITS) {
+        ub_f4 w[UNITS], m1[UNITS], m2[UNITS]; ub_u2 st[UNITS], e[UNITS]; float g[UNITS];
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const uint32_t c = min(c0 + u * stride, n_quads - 1u), i0 = c << 2;
+            w[u] = *reinterpret_cast<const ub_f4*>(a.master + i0); m1[u] = *reinterpret_cast<const ub_f4*>(a.m1 + i0); m2[u] = *reinterpret_cast<const ub_f4*>(a.m2 + i0);
+            st[u] = *reinterpret_cast<const ub_u2*>(a.steps + i0); e[u] = *reinterpret_cast<const ub_u2*>(a.ema + i0);
+            g[u] = 0.f;
+            for (uint32_t q = 0; q < a.n_parts; ++q) { const ub_u2 v = *reinterpret_cast<const ub_u2*>(a.parts + (size_t)q * a.n + i0); g[u] += (float)(v[0] ^ v[1]); }       // (a parameter-order partial layout: 8 bytes per quad and partition)
+        }
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const uint32_t c = c0 + u * stride, i0 = c << 2;
+            if (c >= n_quads) break;
+            const float d = g[u] * 1e-30f + 1.f;
+            ub_store(w[u] + d, reinterpret_cast<ub_f4*>(a.master + i0), plain); ub_store(m1[u] + d, reinterpret_cast<ub_f4*>(a.m1 + i0), plain); ub_store(m2[u] + d, reinterpret_cast<ub_f4*>(a.m2 + i0), plain);
+            ub_store(st[u] + 1u, reinterpret_cast<ub_u2*>(a.steps + i0), plain);
+            *reinterpret_cast<ub_u2*>(a.ema + i0) = e[u] + 1u; *reinterpret_cast<ub_u2*>(a.half + i0) = e[u] + st[u]; *reinterpret_cast<ub_u2*>(a.tiles + i0) = e[u] ^ st[u];
+        }
+    }
+}
+static void launch_stream(int mode, int blocks, int units, const StreamPtrs& a) {
+#define MON_UB_STREAM(K) do { if (units == 1) hipLaunchKernelGGL(K<1>, dim3(blocks), dim3(256), 0, 0, a); else if (units == 2) hipLaunchKernelGGL(K<2>, dim3(blocks), dim3(256), 0, 0, a); \
+                              else if (units == 4) hipLaunchKernelGGL(K<4>, dim3(blocks), dim3(256), 0, 0, a); else hipLaunchKernelGGL(K<8>, dim3(blocks), dim3(256), 0, 0, a); } while (0)
+    if (mode == 31) MON_UB_STREAM(k_ub_stream8); else MON_UB_STREAM(k_ub_stream4);
+#undef MON_UB_STREAM
+}
+
 int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms_out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || use_device(device) != hipSuccess) { set_error("microbench: no HIP device"); return MON_ERR_NO_DEVICE; }
     uint32_t* table = nullptr; float* sink = nullptr;
-    const size_t bytes = mode == 30 ? 2 * (size_t)n_ops : (size_t)n_entries * 4 * 8;
+    const bool stream = mode == 31 || mode == 32;                 // n_ops parameters; n_entries = flags: bit 0 plain stores, bits 4..7 units per thread, bits 8..11 partial tables
+    const size_t np = ((size_t)n_ops + 1023) & ~(size_t)1023;
+    const size_t bytes = stream ? np * (12 + 8 + 2 * 8) + 4096 : mode == 30 ? 2 * (size_t)n_ops : (size_t)n_entries * 4 * 8;
     if (hipMalloc((void**)&table, bytes) != hipSuccess || hipMalloc((void**)&sink, 64) != hipSuccess) { set_error("microbench: hipMalloc failed"); return MON_ERR_HIP; }
     hipMemset(table, 0, bytes);
     const uint32_t ops_per_thread = 64, threads = n_ops / ops_per_thread, blocks = (threads + 255) / 256;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
-    const bool lds_mode = mode >= 10 && mode < 20;      // (modes 20+ are gather probes again)
+    const bool lds_mode = (mode >= 10 && mode < 20) || (mode >= 40 && mode < 50);      // (modes 20..29 are gather probes again)
     if (lds_mode) hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ub_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0, 0);
-        if (mode == 30) hipLaunchKernelGGL(k_ub_copy, dim3(pattern > 0 ? pattern : 512), dim3(256), 0, 0, reinterpret_cast<const ub_u4*>(table), reinterpret_cast<ub_u4*>(table) + n_ops / 16u, n_ops / 16u);
+        if (stream) {
+            unsigned char* b = reinterpret_cast<unsigned char*>(table);
+            StreamPtrs a{ reinterpret_cast<float*>(b), reinterpret_cast<float*>(b + 4 * np), reinterpret_cast<float*>(b + 8 * np), reinterpret_cast<uint16_t*>(b + 12 * np), reinterpret_cast<uint16_t*>(b + 14 * np),
+                          reinterpret_cast<uint16_t*>(b + 16 * np), reinterpret_cast<uint16_t*>(b + 18 * np), reinterpret_cast<const uint16_t*>(b + 20 * np), (uint32_t)np, (n_entries >> 8) & 15u, n_entries & 1u };
+            launch_stream(mode, pattern > 0 ? pattern : 512, (int)((n_entries >> 4) & 15u), a);
+        }
+        else if (mode == 30) hipLaunchKernelGGL(k_ub_copy, dim3(pattern > 0 ? pattern : 512), dim3(256), 0, 0, reinterpret_cast<const ub_u4*>(table), reinterpret_cast<ub_u4*>(table) + n_ops / 16u, n_ops / 16u);
         else if (lds_mode) hipLaunchKernelGGL(k_ub_lds, dim3(256), dim3(1024), 131072, 0, mode, n_ops / (256u * 1024u), sink);
         else hipLaunchKernelGGL(k_ub, dim3(blocks), dim3(256), 0, 0, mode, pattern, n_entries, ops_per_thread, table, sink);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
