@@ -52,26 +52,33 @@ __device__ __forceinline__ void ema_catch_up(half8_t& e, const half8_t& w, uint3
 // schedule; the EMA differs from the step-by-step fp16 recurrence by rounding only.
 template <bool DENSE, bool LAZY>
 __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, const DevState* __restrict__ st, DevState* __restrict__ st_next, OptimNext nx, uint32_t lazy_below) {
+    // block roles by VIRTUAL index: [0, extra) prepare the next iteration, the rest update parameters.  Physically the parameter blocks come first (they are
+    // the ones that stream 80 MB and should be in flight from the first cycle), the short preparation blocks fill in behind them.
+#ifdef MON_OPT_POS_FIRST
+    const uint32_t vblock = blockIdx.x;
+#else
+    const uint32_t n_extra = nx.cand_blocks + nx.pos_blocks, n_opt = gridDim.x - n_extra, vblock = blockIdx.x < n_opt ? blockIdx.x + n_extra : blockIdx.x - n_opt;
+#endif
     const uint32_t n_valid = st->n_valid, step = st->step;
     // DENSE tables: while most samples carry a gradient practically every chunk is updated and the optimizer state is requested together with the gradients
     // (one memory round trip); once few do (late training: k_grid_scatter left the count in n_scatter_now) most chunks only need their EMA advanced, and
     // the 112 B of Adam state per chunk are requested behind the gradient test instead
     const bool eager = DENSE && !(lazy_below != 0u && st->n_scatter_now <= lazy_below);
     const uint32_t extra = nx.cand_blocks + nx.pos_blocks;          // (one or the other)
-    const bool cand_block = blockIdx.x < extra;                     // GenerateRays of iteration iter + 1 / its sample positions
-    if (blockIdx.x < nx.cand_blocks) gen_candidate(nx.b, nx.ds, nx.oc, st->n_boxes, st->iter + 1u, blockIdx.x * blockDim.x + threadIdx.x);
+    const bool cand_block = vblock < extra;                     // GenerateRays of iteration iter + 1 / its sample positions
+    if (vblock < nx.cand_blocks) gen_candidate(nx.b, nx.ds, nx.oc, st->n_boxes, st->iter + 1u, vblock * blockDim.x + threadIdx.x);
     else if (cand_block) {                                          // level-tile encode: the next iteration's candidates are complete (k_encode_tiles), sample their positions
         __shared__ PointsLds plds;
         const uint32_t nwords = nx.oc.R >> 6, nv = points_prefix(plds, nx.b.mask, nwords);
-        if (blockIdx.x == 0 && threadIdx.x == 0) st_next->n_valid_pre = nv;
+        if (vblock == 0 && threadIdx.x == 0) st_next->n_valid_pre = nv;
 #if defined(MON_OPT_ABLATE) && (MON_OPT_ABLATE & 4)
         if (false)
 #else
         if (nv != 0u)
 #endif
-            for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nx.oc.R * 32u; s += nx.pos_blocks * blockDim.x) points_sample(plds, nx.b, nx.oc, st->iter + 1u, nv, nwords, s, reinterpret_cast<float4_t*>(nx.x_all));
+            for (uint32_t s = vblock * blockDim.x + threadIdx.x; s < nx.oc.R * 32u; s += nx.pos_blocks * blockDim.x) points_sample(plds, nx.b, nx.oc, st->iter + 1u, nv, nwords, s, reinterpret_cast<float4_t*>(nx.x_all));
     }
-    const uint32_t bid = blockIdx.x - extra, nblk = gridDim.x - extra;
+    const uint32_t bid = vblock - extra, nblk = gridDim.x - extra;
     const float lr0 = st->lr;
     // EMA debias factors of this step (ema_step_half_precision; double-precision pow like tcnn's host code): left in the state by the previous step
     const uint32_t cur = step + 1u;
@@ -80,7 +87,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
     // ---- the state of the NEXT iteration.  Iteration i reads DevState i & 1, and everything that changes from one iteration to the next is known when this
     //      kernel starts, so one thread writes the other DevState right away.  (Advancing one shared state in place needed a "last block": a returning atomic
     //      on one address per block and the round trip behind the last of them -- 4.3 us of this kernel.)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (vblock == 0 && threadIdx.x == 0) {
         DevState& nxs = *st_next;
         nxs.iter = st->iter + 1u; nxs.n_valid = n_valid; nxs.loss_sum = st->loss_sum;      // (n_valid / loss_sum: what the host reads after the call; k_fused_train overwrites them)
         { const uint32_t tot = st->n_scatter_now; nxs.n_scatter_last = tot; nxs.n_scatter_total = st->n_scatter_total + tot; }   // (the slot counters themselves are cleared and summed by k_grid_scatter)
@@ -427,9 +434,10 @@ void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, u
 void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, const DevState* st, DevState* st_next, const OptimNext& nx, uint32_t lazy_below) {
     const uint32_t chunks = oc.n_params >> 3;
     const uint32_t env_cap = (uint32_t)options().opt_blocks;
-    // measured: base.json (239 k chunks) 256 / 512 / 1024 blocks = 28.1 / 23.7 / 26.2 us; T = 2^22 (13.2 M chunks) 512 / 2048 / 8192 / 32768 blocks = 368 / 244 / 251 / 406 us
-    uint32_t cap = chunks / (256u * 8u); if (cap < 512u) cap = 512u; if (cap > 2048u) cap = 2048u; if (env_cap) cap = env_cap;
-    uint32_t blocks = (chunks + 255) / 256; if (blocks > cap) blocks = cap; if (blocks < 1u) blocks = 1u;     // ~2 chunks per thread at base.json size: measured best (256: 28.1, 512: 23.7, 1024: 26.2 us)
+    // measured: base.json (239 k chunks), parameter blocks ahead of the preparation blocks: 384 / 512 / 640 / 768 / 1024 blocks = 27.9 / 24.1 / 24.7 / 23.6 / 22.9 us (one chunk per thread;
+    // with the preparation blocks FIRST 512 was the best: 28.1 / 23.7 / 26.2 us for 256 / 512 / 1024); T = 2^22 (13.2 M chunks) 512 / 2048 / 8192 / 32768 blocks = 368 / 244 / 251 / 406 us
+    uint32_t cap = chunks / (256u * 8u); if (cap < 1024u) cap = 1024u; if (cap > 2048u) cap = 2048u; if (env_cap) cap = env_cap;
+    uint32_t blocks = (chunks + 255) / 256; if (blocks > cap) blocks = cap; if (blocks < 1u) blocks = 1u;
     // dense = every level goes through the LDS scatter, i.e. tables of at most 2^18 entries that a 131 072-sample batch covers
     if (p.gpart && p.all_levels_dense) hipLaunchKernelGGL((k_optimizer<true, false>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
     else if (p.ema_step) hipLaunchKernelGGL((k_optimizer<false, true>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
