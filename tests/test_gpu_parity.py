@@ -262,8 +262,9 @@ def test_nondefault_hyperparameters_match_oracle(pkg, orc, small_scene, backend)
 
 @pytest.mark.parametrize("kw", [dict(log2_hashmap_size=17, n_levels=8, base_resolution=16),        # sizes 4920 / 35944 / 131072 x 6: 64-bit whole, 64-bit per parity, parity halves cut into two ranges
                                 dict(log2_hashmap_size=18, n_levels=6, base_resolution=16),        # 262144-entry levels: four ranges per parity half, one sample partition
-                                dict(log2_hashmap_size=14, n_levels=16, base_resolution=16)],      # every hashed level a 64-bit whole-level tile (16384 entries)
-                         ids=["T17", "T18", "T14"])
+                                dict(log2_hashmap_size=14, n_levels=16, base_resolution=16),       # every hashed level a 64-bit whole-level tile (16384 entries)
+                                dict(log2_hashmap_size=16, n_levels=13, base_resolution=16)],      # base.json's first 13 levels: the last has res = 65536, whose index is x mod 65536 (tcnn's wrapped stride loop): the one-atomic path
+                         ids=["T17", "T18", "T14", "T16_res65536"])
 def test_grid_scatter_tile_modes_match_oracle(pkg, orc, small_scene, kw):
     """k_grid_scatter picks a tile shape per level from its size (whole level / one parity half / ranges of a parity half; 32- or 64-bit accumulators):
     one forward/backward against the oracle's grid gradient on tables that exercise every shape, at base.json's batch size of the LDS path."""
