@@ -11,6 +11,8 @@
 // fp16 weights straight into the MFMA A-fragment image (frag_layout.h), and `cand_blocks` extra blocks generate the next
 // iteration's candidate rays (they depend on the iteration counter and the dataset only), so the steady-state loop is
 // k_fused_train -> k_grid_scatter -> k_reduce_partials -> k_optimizer with no batch-generation launch.
+// Variant builds for measurements (tools/variant_build.sh <tag> -D...; profiles/r03_scatter_levels.md): MON_OPT_ABLATE bits 1 no Adam arithmetic, 2 no partial-table
+// reads, 4 no position blocks, 8 no tile-image stores; MON_OPT_POS_FIRST the preparation blocks ahead of the parameter blocks; MON_OPT_PLAIN_STORES.
 #include <cstdlib>
 #include "device_common.h"
 #include "model.h"
