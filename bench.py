@@ -23,6 +23,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -248,10 +249,28 @@ def main():
     gm = sc.instance[v, y:y + h, x:x + w] > 0
     gt = np.where(gm[..., None], sc.rgb[v, y:y + h, x:x + w] / 255.0, 1.0)
     psnr_of = lambda img: float(-10 * np.log10(max(1e-12, ((img - gt) ** 2).mean())))
+    gather_note = None
     if dist is not None:
-        packed = sharding.render_packed(obj, box, ss.colmajor(sc.Twc[v]), torch, coll_dev)
-        crops = sharding.gather_crops(dist, torch, [packed], coll_dev, root=0)          # gather-to-root: only rank 0 holds (and scores) the crops
-        psnrs = [psnr_of(items[0][0]) for items in crops if items] if crops is not None else []
+        # The throughput above is complete at this point; the gather must not be able to take the JSON line with it (a point-to-point transport problem on a node this
+        # script has never seen would otherwise leave the driver without a number): it runs in a worker thread with a deadline, and a rank whose gather did not
+        # finish reports so, scores its own crop and leaves the process group alone at exit.
+        box_res = {}
+        packed = sharding.render_packed(obj, box, ss.colmajor(sc.Twc[v]), torch, coll_dev)      # (the render itself is this rank's own work: only the collective sits behind the deadline)
+        def gather_job():
+            try:
+                if coll_backend == "nccl":
+                    torch.cuda.set_device(coll_dev)
+                box_res["crops"] = sharding.gather_crops(dist, torch, [packed], coll_dev, root=0)          # gather-to-root: only rank 0 holds (and scores) the crops
+                box_res["ok"] = True
+            except Exception as e:                      # noqa: BLE001 -- reported in the JSON line
+                box_res["error"] = "%s: %s" % (type(e).__name__, e)
+        gt_thread = threading.Thread(target=gather_job, daemon=True); gt_thread.start(); gt_thread.join(float(os.environ.get("MON_BENCH_GATHER_TIMEOUT", "180")))
+        if box_res.get("ok"):
+            crops = box_res["crops"]
+            psnrs = [psnr_of(items[0][0]) for items in crops if items] if crops is not None else []
+        else:
+            gather_note = box_res.get("error", "timed out after %s s" % os.environ.get("MON_BENCH_GATHER_TIMEOUT", "180"))
+            rgb, depth, mask = obj.render(box, ss.colmajor(sc.Twc[v])); psnrs = [psnr_of(rgb)] if rank == 0 else []
     else:
         rgb, depth, mask = obj.render(box, ss.colmajor(sc.Twc[v]))
         psnrs = [psnr_of(rgb)]
@@ -292,7 +311,6 @@ def main():
     multi = None
     if rank == 0 and world == 1 and args.objects_per_gpu > 1:
         try:
-            import threading
             K = args.objects_per_gpu
             msteps = 5 * args.steps                      # (a 20-step window of four threads is mostly thread start-up)
             tms = []
@@ -331,11 +349,13 @@ def main():
                "pcie_inclusive": {"dataset_upload_ms": round(1e3 * upload_s, 2), "dataset_bytes": int(sc.n_views * sc.H * sc.W * 4),
                                   "value_for_a_5000_step_job": round(world * 5000 * B / (upload_s + 5000 * dt / args.steps), 1), "unit": "ray-samples/s",
                                   "note": "host frames -> HBM once per sequence (pinned staging + packing kernel), then 5000 steps at the measured step time; never the headline value"},
-               "render": render_info, "psnr_db": [round(p, 2) for p in psnrs], "train_steps_before_render": (late["after_steps"] + 3 * args.steps) if late else args.warmup + args.steps,
+               "render": render_info, "psnr_db": [round(p, 2) for p in psnrs], "render_gather": ("ok" if gather_note is None else "FAILED (%s): psnr_db is rank 0's own crop" % gather_note) if dist is not None else None, "train_steps_before_render": (late["after_steps"] + 3 * args.steps) if late else args.warmup + args.steps,
                "final_loss": round(obj.info().last_loss, 5)}
         print(json.dumps(out), flush=True)
     obj.close(); ds.close()
     if dist is not None:
+        if gather_note is not None:
+            sys.stdout.flush(); os._exit(0)             # (a gather that hangs would also hang the teardown; the line is out)
         dist.destroy_process_group()
 
 
