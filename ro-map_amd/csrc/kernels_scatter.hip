@@ -49,6 +49,8 @@ __device__ __forceinline__ int contrib_fix(float w, float g, float fs) { return 
 __device__ __forceinline__ unsigned long long pack_fix(int lo, int hi) { return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)(hi + (lo >> 31)) << 32); }
 
 // (written as instructions: from the C forms the compiler rebuilt a compare + select pair for each of the two)
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }      // a ^ b ^ c
+__device__ __forceinline__ int floor_to_int(float q) { int r; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(q)); return r; }                                                                      // (int)floorf(q)
 __device__ __forceinline__ uint32_t sign_of_bit0(uint32_t h) { uint32_t m; asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m) : "v"(h)); return m; }                                       // bit 0 set ? ~0 : 0
 __device__ __forceinline__ uint32_t bit_select(uint32_t m, uint32_t a, uint32_t b) { uint32_t r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b)); return r; }   // (m & a) | (~m & b)
 
@@ -65,9 +67,9 @@ __device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bo
     // VALU issue): x | y of the position, the weights of the pairs j = 0, 1 (they share wz[0]) and j = 2, 3 (wz[1]), and the products with the fixed-point unit.
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 qxy = __builtin_elementwise_fma(f2{ scale, scale }, f2{ it.x[0], it.x[1] }, f2{ 0.5f, 0.5f }); const float qz = fmaf(scale, it.x[2], 0.5f);
-    const f2 fxy = { floorf(qxy.x), floorf(qxy.y) }; const float fz = floorf(qz);
-    const f2 pxy = qxy - fxy, nxy = f2{ 1.f, 1.f } - pxy; const float pz = qz - fz;
-    const uint32_t pg[3] = { (uint32_t)(int32_t)fxy.x, (uint32_t)(int32_t)fxy.y, (uint32_t)(int32_t)fz };
+    // (q - floor(q) and (int)floor(q) as ONE instruction each: v_fract_f32 is exactly that difference for the non-negative q of a sample inside the box)
+    const f2 pxy = { __builtin_amdgcn_fractf(qxy.x), __builtin_amdgcn_fractf(qxy.y) }, nxy = f2{ 1.f, 1.f } - pxy; const float pz = __builtin_amdgcn_fractf(qz);
+    const uint32_t pg[3] = { (uint32_t)floor_to_int(qxy.x), (uint32_t)floor_to_int(qxy.y), (uint32_t)floor_to_int(qz) };
     // hashed levels: only the index bits below the (power-of-two) table size matter, so the 24-bit multiply (full rate) serves: positions are < 2^24
     const uint32_t ax0 = pg[0], ax1 = pg[0] + 1u, y0 = (HASHED && POW2) ? __umul24(pg[1], my & 0xffffffu) : pg[1] * my, z0 = (HASHED && POW2) ? __umul24(pg[2], mz & 0xffffffu) : pg[2] * mz;
     const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
@@ -94,7 +96,7 @@ __device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bo
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (DEGEN && j) { local[j] = local[0]; ws[j] = ws[0]; continue; }      // (the index ignores y and z: one entry, one x-corner for all four pairs)
-            const uint32_t h = axp ^ ay[j & 1] ^ az[j >> 1];
+            const uint32_t h = xor3(axp, ay[j & 1], az[j >> 1]);
             const uint32_t m = sign_of_bit0(h);
             local[j] = (__builtin_amdgcn_ubfe(h, 1u, nb) ^ (dxh & m)) - (MODE == kTileParityRanged ? base_half : 0u);
             ws[j] = __builtin_bit_cast(float, bit_select(m, __builtin_bit_cast(uint32_t, wx[1]), __builtin_bit_cast(uint32_t, wx[0])));
