@@ -464,9 +464,14 @@ static void fused_train_t(hipStream_t s, const FusedArgs& a, uint32_t grid, int 
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
     });
     const bool all_lds = a.lds_level_mask != 0u && (a.lds_level_mask == ((a.nd.L >= 32) ? 0xffffffffu : ((1u << a.nd.L) - 1u)));
-    if (a.e_soa && all_lds && !dump && !a.occ_bits) { hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false, false, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a); return; }
+    if (a.e_soa && all_lds && !dump) {          // features from k_encode_tiles (with the occupancy grid: a dead sample's features are there too, its alpha and gradient are zero all the same)
+        if (a.occ_bits) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
+        else hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false, false, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
+        return;
+    }
     if (dump) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);          // (the debug dump evaluates every sample)
     else if (a.occ_bits) { if (all_lds) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
                            else hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a); }

@@ -391,7 +391,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         // R = 1024 (C1) 48.9 vs 41.3 us per step for the gather chain, R = 2048 75.1 vs 75.4, R = 4096 99 vs 107, R = 8192 166 vs 172.  Option lds_encode = 1 (default) takes the
         // tile chain from 3072 rays (98 304 samples) up, 2 always (tests), 0 never.
         const bool tiles_pay = options().lds_encode >= 2 || Btrain >= 98304u;
-        if (options().lds_encode && tiles_pay && !cfg.occupancy_skip && m.lds_mask == ((1u << m.nd.L) - 1u) && encode_tiles_supported(m.lt, m.nd)) {
+        if (options().lds_encode && tiles_pay && m.lds_mask == ((1u << m.nd.L) - 1u) && encode_tiles_supported(m.lt, m.nd)) {
             if (options().ray_records && (rc = dev_alloc(m, B.ray_rec, 12 * (size_t)R))) return rc;
             m.B_alt = B;                             // (cand_* / mask replaced below, after the workspace pointers are final)
             if ((rc = dev_alloc(m, m.B_alt.cand_o, 3 * (size_t)R)) || (rc = dev_alloc(m, m.B_alt.cand_d, 3 * (size_t)R)) || (rc = dev_alloc(m, m.B_alt.cand_dn, R)) ||
@@ -606,7 +606,7 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
         } else {
             if (m.scatter_pending) hipMemsetAsync(m.d_state->n_scatter, 0, sizeof(m.d_state->n_scatter), s);      // stage-wise debugging: a forward/backward without an optimizer step after it
-            const bool pre = m.d_e_soa && !m.fused_dump && options().lds_encode;          // the encode as LDS reads of level tiles; the fused kernel then loads the features
+            const bool pre = m.d_e_soa && !m.fused_dump && options().lds_encode && !m.gathers_preferred;          // the encode as LDS reads of level tiles; the fused kernel then loads the features
             m.pre_active = pre;
             if (pre) {
                 // positions of this batch: normally the last k_optimizer's position blocks already wrote them (and k_encode_tiles of the last iteration the candidates)
@@ -682,6 +682,10 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     // Large-table scatter: the device picks binned / atomic per iteration from the previous iteration's gradient-carrying sample count;
     // once the host has seen that count well below the switch point it stops launching the (then empty) binning kernels at all.
     m.big_active = m.big_switch && (m.h_state.n_scatter_last == 0u || m.h_state.n_scatter_last > m.big_switch / 2u);
+    // Occupancy-grid skipping (opt-in): once the grid is in use and few samples are left, the gather chain wins -- k_fused_train skips the gathers of the samples in
+    // empty cells, k_encode_tiles encodes every sample (kernel_times, late window: 63.3 against 65.4 us per step; early, 99.6 against 92.1).  Both chains leave
+    // bit-identical parameters, so the choice is free per call; the host knows the regime from the last call's read-back.
+    m.gathers_preferred = m.d_occ && m.occ_refreshed_iter && m.h_state.n_scatter_last != 0u && 8u * m.h_state.n_scatter_last < m.oc.R * m.oc.S;
     const bool use_graph_env = options().use_graph != 0;
     m.enq_iter = m.h_state.iter;                             // (nothing of this object is in flight between calls: the read-back at the end of the last one is current)
     const bool use_graph = use_graph_env && !m.profiling && stages == 7 && iters >= 2 && !(m.d_occ && !m.occ_refreshed_iter) && !m.d_xw;      // (the first occupancy refresh changes a kernel argument)

@@ -243,7 +243,7 @@ struct Model {
     void* d_xw_states = nullptr; float* d_xw = nullptr; uint32_t xw_filled = 0, xw_lanes = 0; int xw_flavour = 0; uint32_t enq_iter = 0; uint64_t xw_offset = 0;      // xw_offset: values the training generator has produced
     void* d_xw_render_states = nullptr; void* d_xw_render_init = nullptr; float* d_xw_render = nullptr; size_t xw_render_cap = 0;
     uint32_t* d_step_counts = nullptr; float* d_step_pts = nullptr;      // NeRF_Model::Step schedule (option step_variant): per-ray sample counts / slots, the compacted positions
-    bool pre_active = false, points_ready = false;   // level-tile encode: used by the iteration being enqueued / the next batch's positions were written by the last k_optimizer
+    bool pre_active = false, points_ready = false, gathers_preferred = false;   // level-tile encode: used by the iteration being enqueued / the next batch's positions were written by the last k_optimizer / this train call runs the gather chain (occupancy grid + few live samples)
     bool next_ready = false;     // fused backend: candidates + fragment image of the coming iteration were already produced by the last k_optimizer
     mon_profile prof{}; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pending;
     struct TrainLanes* lanes = nullptr; int lane = -1; hipEvent_t lane_event = nullptr, switch_event = nullptr, sync_event = nullptr;      // per-device training lanes (model.cpp): the lane and completion event of this object's last chunk

@@ -64,3 +64,24 @@ def test_occupancy_grid_keeps_refreshing_under_hipgraph_replay_after_an_odd_iter
         obj.close(); ds.close()
     finally:
         pkg.set_option("use_graph", 0)
+
+
+def test_occupancy_skipping_trains_identically_on_either_forward_chain_and_across_the_switch(pkg, ss):
+    """With the grid in use the library picks the forward chain per train call: level tiles (k_encode_tiles + k_fused_train<PRE, OCC>) while most samples carry a
+    gradient, the gathers inside k_fused_train<OCC> once few do (they are skipped for the samples in empty cells).  Both chains must leave the same parameters bit
+    for bit, also when a run changes from one to the other: five calls of 160 steps against a run that stays on the gather chain (option lds_encode = 0)."""
+    assert pkg.device_count() >= 1
+    sc = ss.make_scene(n_views=16, H=240, W=320, f=260.0, seed=2)
+    crcs = []
+    for lds in (1, 0):
+        pkg.set_option("lds_encode", lds)
+        try:
+            ds, obj = ge.make_problem(pkg, sc, dict(sample_seed=78, occupancy_skip=1))
+            c = []
+            for _ in range(5):
+                obj.train(160); c.append(zlib.crc32(obj.get_params(0).tobytes()))
+            last, due = obj.occupancy_state(); assert last > 0                      # the grid was refreshed and is in use
+            crcs.append(c); obj.close(); ds.close()
+        finally:
+            pkg.set_option("lds_encode", 1)
+    assert crcs[0] == crcs[1], crcs
