@@ -692,7 +692,7 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     // chunks of iterations go through the device's training lanes (whole steps only; big-table objects are HBM-bound in their optimizer and gain from more overlap, not less)
     const bool lanes_on = stages == 7 && m.big_switch == 0u; const int chunk = options().lane_chunk >= 2 ? (options().lane_chunk & ~1) : 2;
     if (use_graph) {
-        const int graph_key = m.backend | (m.big_active ? 256 : 0) | (m.occ_refreshed_iter ? 512 : 0);
+        const int graph_key = m.backend | (m.big_active ? 256 : 0) | (m.occ_refreshed_iter ? 512 : 0) | ((m.d_e_soa && options().lds_encode && !m.gathers_preferred) ? 1024 : 0);      // (the last bit: which forward chain the captured pair runs)
         if (!m.graph_exec || m.graph_backend != graph_key || m.graph_state != m.d_state || m.graph_mask != m.B.mask) {      // (the captured pair starts on this DevState and this candidate set)
             drop_graph(m);
             hipGraph_t g = nullptr;
