@@ -73,8 +73,8 @@ def test_occupancy_skipping_trains_identically_on_either_forward_chain_and_acros
     assert pkg.device_count() >= 1
     sc = ss.make_scene(n_views=16, H=240, W=320, f=260.0, seed=2)
     crcs = []
-    for lds in (1, 0):
-        pkg.set_option("lds_encode", lds)
+    for lds, graph in ((1, 0), (0, 0), (1, 1)):                  # (the third run: hipGraph replay, whose cached graph must follow the change of chain)
+        pkg.set_option("lds_encode", lds); pkg.set_option("use_graph", graph)
         try:
             ds, obj = ge.make_problem(pkg, sc, dict(sample_seed=78, occupancy_skip=1))
             c = []
@@ -83,5 +83,5 @@ def test_occupancy_skipping_trains_identically_on_either_forward_chain_and_acros
             last, due = obj.occupancy_state(); assert last > 0                      # the grid was refreshed and is in use
             crcs.append(c); obj.close(); ds.close()
         finally:
-            pkg.set_option("lds_encode", 1)
-    assert crcs[0] == crcs[1], crcs
+            pkg.set_option("lds_encode", 1); pkg.set_option("use_graph", 0)
+    assert crcs[0] == crcs[1] == crcs[2], crcs
