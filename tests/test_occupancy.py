@@ -81,6 +81,9 @@ def test_occupancy_skipping_trains_identically_on_either_forward_chain_and_acros
             for _ in range(5):
                 obj.train(160); c.append(zlib.crc32(obj.get_params(0).tobytes()))
             last, due = obj.occupancy_state(); assert last > 0                      # the grid was refreshed and is in use
+            if lds and not graph:                                                   # ... and the change of chain did happen: a further call launches no k_encode_tiles (kernel class 6)
+                obj.set_profiling(True); obj.profile(reset=True); obj.train(8); prof = obj.profile(reset=True); obj.set_profiling(False)
+                assert prof["launches"][6] == 0 and prof["launches"][1] == 8, prof["launches"]
             crcs.append(c); obj.close(); ds.close()
         finally:
             pkg.set_option("lds_encode", 1); pkg.set_option("use_graph", 0)
