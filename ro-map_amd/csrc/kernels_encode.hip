@@ -155,8 +155,7 @@ __device__ __forceinline__ void encode_parity(uint32_t* tile, const uint4* __res
     uint32_t veven[kEncSpt][4], cache[kEncSpt][2]; float pos[kEncSpt][3];      // (the position inside the cell is kept too: 24 registers against a second load + 9 instructions per sample)
     const bool walk = !(a.ablate & 1u) && s0 < s_end;
     float4_t xs[kEncSpt];
-    if (walk) load_positions(xs, a.x_all, s0, s_end);          // requested ahead of the tile: they land while it is copied
-    if (!(a.ablate & 2u)) tile_copy(tile, src, size / 8u);
+    if (walk) load_positions(xs, a.x_all, s0, s_end);          // (the copy of the even half is under way: k_encode_tiles requested it at its entry)
     __builtin_amdgcn_s_waitcnt(0x0f70);                                   // vmcnt(0): the LDS writes of the copy are counted there
     __syncthreads();
     if (walk) {
@@ -202,7 +201,6 @@ __global__ void __launch_bounds__(kEncThreads) k_encode_tiles(EncodeArgs a) {
     const uint32_t level = blockIdx.x / kEncWgPerLevel, part = blockIdx.x - level * kEncWgPerLevel;
     if (a.gen_next && level == 0u && blockIdx.y == 0u && threadIdx.x < 256u)
         for (uint32_t c0 = part * 256u; c0 < a.oc.R; c0 += kEncWgPerLevel * 256u) gen_candidate(a.b_next, a.ds, a.oc, a.st->n_boxes, a.st->iter + 1u, c0 + threadIdx.x);
-    if (a.st->n_valid_pre == 0u) return;                               // batch skipped (the position pass wrote the count)
     const uint32_t w = blockIdx.y * kEncWgPerLevel + part;             // sample partition of the batch
     const uint32_t s_base = w * a.spw, s_end = min(s_base + a.spw, a.B), s0 = s_base + threadIdx.x;
     if (s_base >= a.B) return;
@@ -211,8 +209,10 @@ __global__ void __launch_bounds__(kEncThreads) k_encode_tiles(EncodeArgs a) {
     const float scale = a.lt.scale[level];
     const uint4* src = reinterpret_cast<const uint4*>(a.half_tiles + 2u * (size_t)off);
     half2_t* out = a.e_soa + (size_t)level * a.B;
+    // the first tile is requested BEFORE the state is looked at (everything above comes from the argument segment): the round trip for n_valid_pre runs under the copy
+    if (!(a.ablate & 2u) || size <= kEncWholeMax) tile_copy(tile, src, size <= kEncWholeMax ? size / 4u : size / 8u);
+    if (a.st->n_valid_pre == 0u) return;                               // batch skipped (the position pass wrote the count)
     if (size <= kEncWholeMax) {
-        tile_copy(tile, src, size / 4u);
         __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
         if (hashed) { if (pow2) encode_whole<true, true>(tile, a, s0, s_end, out, scale, size, my, mz, mask); else encode_whole<true, false>(tile, a, s0, s_end, out, scale, size, my, mz, mask); }
