@@ -52,7 +52,7 @@ __device__ __forceinline__ void ema_catch_up(half8_t& e, const half8_t& w, uint3
 // remembers the optimizer step its EMA is current for, and the missing steps are applied in closed form when the chunk next receives a
 // gradient or when the inference weights are needed (k_ema_finalize).  The weights and Adam state are exactly those of the eager
 // schedule; the EMA differs from the step-by-step fp16 recurrence by rounding only.
-template <bool DENSE, bool LAZY>
+template <bool DENSE, bool LAZY, bool ONE = false /* the grid covers every chunk with one thread: no second chunk's state to hold (44 registers less) */>
 __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, const DevState* __restrict__ st, DevState* __restrict__ st_next, OptimNext nx, uint32_t lazy_below) {
     // block roles by VIRTUAL index: [0, extra) prepare the next iteration, the rest update parameters.  Physically the parameter blocks come first (they are
     // the ones that stream 80 MB and should be in flight from the first cycle), the short preparation blocks fill in behind them.
@@ -351,7 +351,9 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
             // straight-line code, no loop-carried buffers (those ended up in scratch memory)
             const half8_t none{};
             const uint32_t c0 = c_first, c1 = c_first + c_stride;
-            if (c0 < n_chunks) {
+            if constexpr (ONE) {
+                if (c0 < n_chunks) { Pre A; issue(c0, A); update_chunk(c0, false, none, none, none, &A); }
+            } else if (c0 < n_chunks) {
                 Pre A, B2; const bool two = c1 < n_chunks;
                 issue(c0, A); if (two) issue(c1, B2);
                 update_chunk(c0, false, none, none, none, &A);
@@ -441,7 +443,10 @@ void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, c
     uint32_t cap = chunks / (256u * 8u); if (cap < 1024u) cap = 1024u; if (cap > 2048u) cap = 2048u; if (env_cap) cap = env_cap;
     uint32_t blocks = (chunks + 255) / 256; if (blocks > cap) blocks = cap; if (blocks < 1u) blocks = 1u;
     // dense = every level goes through the LDS scatter, i.e. tables of at most 2^18 entries that a 131 072-sample batch covers
-    if (p.gpart && p.all_levels_dense) hipLaunchKernelGGL((k_optimizer<true, false>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
+    if (p.gpart && p.all_levels_dense) {
+        if ((size_t)blocks * 256u >= chunks) hipLaunchKernelGGL((k_optimizer<true, false, true>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
+        else hipLaunchKernelGGL((k_optimizer<true, false>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
+    }
     else if (p.ema_step) hipLaunchKernelGGL((k_optimizer<false, true>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
     else hipLaunchKernelGGL((k_optimizer<false, false>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
 }
