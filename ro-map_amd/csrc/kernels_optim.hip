@@ -61,11 +61,35 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
 #else
     const uint32_t n_extra = nx.cand_blocks + nx.pos_blocks, n_opt = gridDim.x - n_extra, vblock = blockIdx.x < n_opt ? blockIdx.x + n_extra : blockIdx.x - n_opt;
 #endif
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t step_cap = p.steps16 ? 65535u : 0xffffffffu;
+    // a chunk's eight step counters: two 16-byte loads of uint32, or ONE of eight uint16 (4 B per parameter less to read and to write back)
+    auto load_steps = [&](uint32_t i0, u32x4& s0, u32x4& s1) __attribute__((always_inline)) {
+        if (p.steps16) { const u32x4 v = *reinterpret_cast<const u32x4*>(p.steps16 + i0); s0 = u32x4{ v[0] & 0xffffu, v[0] >> 16, v[1] & 0xffffu, v[1] >> 16 }; s1 = u32x4{ v[2] & 0xffffu, v[2] >> 16, v[3] & 0xffffu, v[3] >> 16 }; }
+        else { s0 = *reinterpret_cast<const u32x4*>(p.steps + i0); s1 = *reinterpret_cast<const u32x4*>(p.steps + i0 + 4); }
+    };
+    struct Pre { float4_t w0, w1, a0, a1, b0, b1; u32x4 s0, s1; half8_t e; float4_t gm0, gm1; };      // (plain vector types and no arrays: HIP's uint4 is a union, and either keeps the struct in scratch memory)
+    auto issue = [&](uint32_t c, Pre& L) __attribute__((always_inline)) {
+        const uint32_t i0 = c << 3;
+        L.w0 = *reinterpret_cast<const float4_t*>(p.master + i0); L.w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
+        L.a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0); L.a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
+        L.b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); L.b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
+        load_steps(i0, L.s0, L.s1);
+        L.e = *reinterpret_cast<const half8_t*>(p.ema + i0);
+        if (i0 < oc.n_mlp) { L.gm0 = *reinterpret_cast<const float4_t*>(p.gmlp + i0); L.gm1 = *reinterpret_cast<const float4_t*>(p.gmlp + i0 + 4); }
+    };
+    // ONE chunk per thread: its state is requested HERE, before the kernel has seen its DevState -- the addresses come from the argument segment, and the round trip for
+    // n_valid / step / lr would otherwise stand in front of the streams (eager path below; a skipped batch drops the values)
+    Pre early; bool early_issued = false;
+    if constexpr (ONE) {
+        const uint32_t extra0 = nx.cand_blocks + nx.pos_blocks;
+        if (vblock >= extra0) { const uint32_t ce = (vblock - extra0) * blockDim.x + threadIdx.x; if (ce < (oc.n_params >> 3)) { issue(ce, early); early_issued = true; } }
+    }
     const uint32_t n_valid = st->n_valid, step = st->step;
     // DENSE tables: while most samples carry a gradient practically every chunk is updated and the optimizer state is requested together with the gradients
     // (one memory round trip); once few do (late training: k_grid_scatter left the count in n_scatter_now) most chunks only need their EMA advanced, and
     // the 112 B of Adam state per chunk are requested behind the gradient test instead
-    const bool eager = DENSE && !(lazy_below != 0u && st->n_scatter_now <= lazy_below);
+    const bool eager = DENSE && (ONE || !(lazy_below != 0u && st->n_scatter_now <= lazy_below));      // (ONE: the state is on its way already; the two orders measure the same late in training with one chunk per thread)
     const uint32_t extra = nx.cand_blocks + nx.pos_blocks;          // (one or the other)
     const bool cand_block = vblock < extra;                     // GenerateRays of iteration iter + 1 / its sample positions
     if (vblock < nx.cand_blocks) gen_candidate(nx.b, nx.ds, nx.oc, st->n_boxes, st->iter + 1u, vblock * blockDim.x + threadIdx.x);
@@ -120,23 +144,6 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
         };
         // DENSE tables, eager state: the 160 B of optimizer state of a thread's SECOND chunk are requested before its first chunk is worked on (`Pre`), so that
         // their latency runs under that chunk's arithmetic (vmcnt retires in order: they have to be issued before the first chunk's stores, not after).
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const uint32_t step_cap = p.steps16 ? 65535u : 0xffffffffu;
-        // a chunk's eight step counters: two 16-byte loads of uint32, or ONE of eight uint16 (4 B per parameter less to read and to write back)
-        auto load_steps = [&](uint32_t i0, u32x4& s0, u32x4& s1) __attribute__((always_inline)) {
-            if (p.steps16) { const u32x4 v = *reinterpret_cast<const u32x4*>(p.steps16 + i0); s0 = u32x4{ v[0] & 0xffffu, v[0] >> 16, v[1] & 0xffffu, v[1] >> 16 }; s1 = u32x4{ v[2] & 0xffffu, v[2] >> 16, v[3] & 0xffffu, v[3] >> 16 }; }
-            else { s0 = *reinterpret_cast<const u32x4*>(p.steps + i0); s1 = *reinterpret_cast<const u32x4*>(p.steps + i0 + 4); }
-        };
-        struct Pre { float4_t w0, w1, a0, a1, b0, b1; u32x4 s0, s1; half8_t e; float4_t gm0, gm1; };      // (plain vector types and no arrays: HIP's uint4 is a union, and either keeps the struct in scratch memory)
-        auto issue = [&](uint32_t c, Pre& L) __attribute__((always_inline)) {
-            const uint32_t i0 = c << 3;
-            L.w0 = *reinterpret_cast<const float4_t*>(p.master + i0); L.w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
-            L.a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0); L.a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
-            L.b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); L.b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
-            load_steps(i0, L.s0, L.s1);
-            L.e = *reinterpret_cast<const half8_t*>(p.ema + i0);
-            if (i0 < oc.n_mlp) { L.gm0 = *reinterpret_cast<const float4_t*>(p.gmlp + i0); L.gm1 = *reinterpret_cast<const float4_t*>(p.gmlp + i0 + 4); }
-        };
         // one 8-parameter chunk; `pre`: its always-needed loads (cur_*) were issued an iteration ago; `L`: state, EMA and MLP gradient were (eager dense path)
         auto update_chunk = [&](uint32_t c, bool pre, const half8_t& cur_g, const half8_t& cur_w, const half8_t& cur_e, const Pre* L = nullptr) __attribute__((always_inline)) {
             const uint32_t i0 = c << 3;
@@ -352,7 +359,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
             const half8_t none{};
             const uint32_t c0 = c_first, c1 = c_first + c_stride;
             if constexpr (ONE) {
-                if (c0 < n_chunks) { Pre A; issue(c0, A); update_chunk(c0, false, none, none, none, &A); }
+                if (c0 < n_chunks) { if (!early_issued) issue(c0, early); update_chunk(c0, false, none, none, none, &early); }
             } else if (c0 < n_chunks) {
                 Pre A, B2; const bool two = c1 < n_chunks;
                 issue(c0, A); if (two) issue(c1, B2);
