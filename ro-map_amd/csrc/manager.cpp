@@ -537,9 +537,13 @@ int mon_online_create_nerf(mon_online* h, int cls, const float* Tow16, const flo
     return MON_OK;
 }
 int mon_online_update_nerf_bbox(mon_online* h, size_t idx, const mon_frame_bbox* boxes, size_t n, int train_step) {   // :298-303 + UpdateFrameBBox nerf.cu:406-421
-    REQ(h); if (n != 0) REQ(boxes);            // an EMPTY update still stores train_step and wakes the object's thread, like UpdateFrameBBox (nerf.cu:416-420)
+    REQ(h);
     OnlineObject* o = online_object(*h->m, idx);
     if (!o) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
+    // the manager drops an EMPTY update before it reaches the NeRF (nerf_manager.cu:300-301): pending_train_step of an update
+    // the object's thread has not consumed yet must not be overwritten by it
+    if (n == 0) return MON_OK;
+    REQ(boxes);
     std::unique_lock<std::mutex> lock(o->mu_boxes);
     if (o->n_boxes + n > o->boxes.size()) o->boxes.resize(o->n_boxes + n);
     for (size_t i = 0; i < n; ++i) o->boxes[o->n_boxes + i] = boxes[i];

@@ -40,7 +40,8 @@ static std::atomic<long>* option_slot(const char* name) {
         { "backend", &Options::backend }, { "use_graph", &Options::use_graph }, { "lazy_ema", &Options::lazy_ema }, { "big_switch", &Options::big_switch },
         { "touched_flags", &Options::touched_flags },
         { "fused_grid", &Options::fused_grid }, { "lds_encode", &Options::lds_encode }, { "roctx", &Options::roctx }, { "ray_records", &Options::ray_records }, { "step_variant", &Options::step_variant }, { "steps16", &Options::steps16 }, { "encode_ablate", &Options::encode_ablate }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
-        { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner }, { "scatter_bins", &Options::scatter_bins }, { "opt_lazy_below", &Options::opt_lazy_below }, { "scatter_ablate", &Options::scatter_ablate } };
+        { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner }, { "scatter_bins", &Options::scatter_bins }, { "opt_lazy_below", &Options::opt_lazy_below }, { "scatter_ablate", &Options::scatter_ablate },
+        { "tile_render", &Options::tile_render } };
     for (const auto& e : tab) if (name && std::strcmp(name, e.n) == 0) return &(g_options.*(e.f));
     return nullptr;
 }
@@ -78,23 +79,90 @@ int dataset_destroy(Dataset* d);
 // One high-priority stream and one pinned result buffer per DEVICE, shared by the objects on it (viewer renders) and by the device's dataset (frame uploads): created with the device's first object (CreateNeRF is a
 // milliseconds call anyway; created by the first render it was a 10 ms spike in front of the viewer), and only one more hardware-queue client however many objects
 // train (a high-priority queue per object measurably slowed sliced training).  Renders of one device take turns on it.
-struct InferShared { std::mutex mu; hipStream_t stream = nullptr; float* h_out = nullptr; size_t h_cap = 0; };
+struct InferShared { std::mutex mu; hipStream_t stream = nullptr; float* h_out = nullptr; std::atomic<size_t> h_cap{ 0 }; };      // h_cap only grows; h_out / growth belong to mu
 static std::mutex g_infer_mu; static std::map<int, InferShared*> g_infer_shared;
 static int infer_shared_get(int device, size_t pixels_hint, InferShared** out) {
-    std::lock_guard<std::mutex> l(g_infer_mu);
-    InferShared*& sh = g_infer_shared[device];
-    if (!sh) {
-        sh = new InferShared();
-        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&sh->stream, hipStreamNonBlocking, hi) != hipSuccess) { delete sh; sh = nullptr; set_error("inference stream creation failed on device %d", device); return MON_ERR_HIP; }
+    InferShared* sh = nullptr;
+    {   std::lock_guard<std::mutex> l(g_infer_mu);       // the map lookup only: a viewer render holds sh->mu across stream syncs, and object creation
+        InferShared*& slot = g_infer_shared[device];     // (SLAM thread, any device) must not queue behind it with the global lock held
+        if (!slot) {
+            slot = new InferShared();
+            int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (hipStreamCreateWithPriority(&slot->stream, hipStreamNonBlocking, hi) != hipSuccess) {
+                delete slot; slot = nullptr; set_error("inference stream creation failed on device %d", device); return MON_ERR_HIP;
+            }
+        }
+        sh = slot;
     }
-    std::lock_guard<std::mutex> l2(sh->mu);              // (h_out / h_cap belong to sh->mu: model_render_snapshot resizes them under it)
-    if (5 * pixels_hint > sh->h_cap) {
+    if (5 * pixels_hint > sh->h_cap.load(std::memory_order_acquire)) {      // (grow-only: the common case takes no lock at all)
+        std::lock_guard<std::mutex> l2(sh->mu);          // h_out / growth belong to sh->mu: model_render_snapshot resizes them under it
+        if (5 * pixels_hint <= sh->h_cap.load(std::memory_order_relaxed)) { *out = sh; return MON_OK; }
         float* q = nullptr; if (hipHostMalloc((void**)&q, 5 * pixels_hint * sizeof(float), hipHostMallocDefault) != hipSuccess) { set_error("pinned render buffer allocation failed"); return MON_ERR_HIP; }
         if (sh->h_out) hipHostFree(sh->h_out);
         sh->h_out = q; sh->h_cap = 5 * pixels_hint;
     }
     *out = sh; return MON_OK;
+}
+
+// ---- tile render workspace (kernels_tilerender.hip): per device and side, grow-only, never freed (like the inference stream)
+static std::atomic<uint64_t> g_weights_epoch{ 1 };
+uint64_t next_weights_epoch() { return g_weights_epoch.fetch_add(1); }
+struct TileWsPair { TileWs side[2]; };
+static std::mutex g_tile_mu; static std::map<int, TileWsPair*> g_tile_ws;
+template <class T> static int ws_grow(T*& p, size_t n_elems) {      // (contents are scratch: nothing to carry over)
+    void* q = nullptr;
+    if (hipMalloc(&q, n_elems * sizeof(T)) != hipSuccess) { set_error("tile render workspace: allocation of %zu bytes failed", n_elems * sizeof(T)); return MON_ERR_HIP; }
+    if (p) hipFree(p);
+    p = (T*)q; return MON_OK;
+}
+// caller must hold ws->mu before it touches the buffers; the capacity checks below run under it too (two objects of one device may ask at once)
+int tile_ws_get(Model& m, int side, size_t n_pix, TileWs** out) {
+    TileWsPair* pr = nullptr;
+    {   std::lock_guard<std::mutex> l(g_tile_mu);
+        TileWsPair*& slot = g_tile_ws[m.device]; if (!slot) slot = new TileWsPair(); pr = slot; }
+    TileWs& ws = pr->side[side & 1];
+    std::lock_guard<std::mutex> l(ws.mu);
+    int rc;
+    const uint32_t cap = kTileChunkJobs * 64u;
+    if (!ws.counters) { if ((rc = ws_grow(ws.counters, 64))) return rc; HIPCHECK(hipMemset(ws.counters, 0, 256)); }
+    if (ws.cap < cap || ws.L_cap < m.nd.L) {
+        const int L = std::max(ws.L_cap, m.nd.L);
+        if ((rc = ws_grow(ws.x, 4 * (size_t)cap)) || (rc = ws_grow(ws.e, (size_t)L * 2 * cap)) || (rc = ws_grow(ws.O, 4 * (size_t)cap))) return rc;
+        ws.cap = cap; ws.L_cap = L;
+    }
+    if (!ws.frag && (rc = ws_grow(ws.frag, 64 * 512))) return rc;
+    if (ws.image_cap < 2 * (size_t)m.n_grid) { if ((rc = ws_grow(ws.image, 2 * (size_t)m.n_grid + 64))) return rc; ws.image_cap = 2 * (size_t)m.n_grid; ws.key_epoch = ~0ull; }
+    if (ws.rec_cap < n_pix) { const size_t c = std::max<size_t>(n_pix, 2 * ws.rec_cap); if ((rc = ws_grow(ws.rec, 12 * c))) return rc; ws.rec_cap = c; }
+    *out = &ws; return MON_OK;
+}
+void tile_ws_weights(Model& m, TileWs& ws, hipStream_t s, const uint16_t* prm, uint64_t epoch) {
+    if (ws.key_params == prm && ws.key_epoch == epoch) return;
+    launch_build_feat_image(s, m.lf, m.nd, prm, ws.image, nullptr);
+    launch_forward_frag_image(s, m.nd, prm, ws.frag);
+    ws.key_params = prm; ws.key_epoch = epoch;
+}
+void tile_points_forward(Model& m, TileWs& ws, hipStream_t s, uint32_t n) {
+    launch_encode_feat(s, m.lf, m.nd, ws.image, ws.x, ws.e, ws.cap, n, nullptr, 0u, 0u, 1u);
+    launch_tile_points_mlp(s, m.nd, ws.frag, ws.e, ws.cap, n, ws.O);
+}
+// NeRF_Model::Render's body (:1768-1828) for a whole crop on the tile path: rays + hit compaction, then per chunk of jobs points -> encode -> MLP + composite
+// into the device buffers rgb / depth / mask (pixel order); caller holds ws.mu and has called tile_ws_weights
+static void tile_render_crop(Model& m, TileWs& ws, hipStream_t s, const ObjectConst& oc, mon_frame_bbox box, const Mat4& pose, int pose_is_Toc,
+                             float* rgb, float* depth, float* mask) {
+    const uint32_t n_pix = box.w * box.h;
+    uint32_t* cnt = ws.counters + 16u * (ws.flip & 1u); uint32_t* next = ws.counters + 16u * ((ws.flip + 1u) & 1u); ++ws.flip;
+    launch_render_rays_jobs(s, m.ds->K, oc, box, pose, pose_is_Toc, n_pix, ws.rec, cnt, next, rgb, depth, mask);
+    for (uint32_t j0 = 0; j0 < n_pix; j0 += kTileChunkJobs) {          // (the job count lives on the device: chunks past it return at once)
+        const uint32_t jc = std::min(kTileChunkJobs, n_pix - j0);
+        launch_render_points(s, oc, ws.rec, cnt, j0, jc, ws.x);
+        launch_encode_feat(s, m.lf, m.nd, ws.image, ws.x, ws.e, ws.cap, 0u, cnt, j0, jc, 2u * oc.S);
+        launch_tile_render(s, m.nd, oc, ws.frag, ws.rec, cnt, j0, jc, ws.x, ws.e, ws.cap, rgb, depth, mask);
+    }
+}
+// whether a crop of n_pix rays goes to the tile path (option tile_render: 0 never, 1 from 4096 rays up -- below that the tile copies cost what the gathers cost --, 2 always)
+static bool tile_render_wanted(const Model& m, size_t n_pix) {
+    const long o = options().tile_render;
+    return m.backend == 1 && m.tile_ok && m.oc.S == 32u && o != 0 && (o >= 2 || n_pix >= 4096);
 }
 
 // ---- training lanes: the per-device scheduler behind "one host thread per object" (nerf_manager.cu:89,256-259).
@@ -294,6 +362,7 @@ struct InferState {
     InferShared* shared = nullptr;                                      // the device's inference stream (highest priority) and pinned result buffer
     uint16_t* snap[2] = { nullptr, nullptr }; hipEvent_t ready[2] = { nullptr, nullptr }; uint32_t step_of[2] = { 0, 0 }; bool written[2] = { false, false };
     int latest = -1, readers[2] = { 0, 0 }; std::mutex mu;              // which snapshot is current, who is reading which
+    uint64_t epoch_of[2] = { 0, 0 };                                    // weights stamp of each snapshot (next_weights_epoch at publication: the tile render's image key)
     std::atomic<bool> wanted{ false }; std::chrono::steady_clock::time_point last_pub{};      // a viewer asked since the last publication; when that was
     BatchPtrs rb{}; float *out_all = nullptr, *out_rgb = nullptr, *out_depth = nullptr, *out_mask = nullptr; size_t out_cap = 0; uint16_t* frag = nullptr;
     std::vector<void*> grown;                                           // superseded output buffers, freed with the object
@@ -333,8 +402,11 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     m.train_stream = m.own_stream; m.lanes = lanes_get(m.device); m.lanes->objects.fetch_add(1);
     // ---- parameters (ResetNetwork :1286-1342; Trainer init)
     const size_t n = m.n_params;
-    // per-parameter step counters in 16 bits, saturating, where that is EXACT: 1 - beta^t == 1.0f (beta^t < 2^-25) for every t >= 65535 and both betas (option steps16 = 0: always 32 bits)
-    const bool steps16 = options().steps16 != 0 && std::pow((double)cfg.beta1, 65535.0) < std::ldexp(1.0, -25) && std::pow((double)cfg.beta2, 65535.0) < std::ldexp(1.0, -25);
+    // per-parameter step counters in 16 bits, saturating, where that is EXACT: 1 - beta^t == 1.0f (beta^t < 2^-25) for every t >= 65535 and both betas
+    // (option steps16 = 0: always 32 bits).  The device evaluates 1 - exp2f(t * log2(beta)) in fp32; the host test runs in double, so it keeps a
+    // margin of four binades (beta^65535 < 2^-29, i.e. beta <= 0.99969) instead of sitting on the rounding boundary.
+    const double kSteps16Bound = std::ldexp(1.0, -29);
+    const bool steps16 = options().steps16 != 0 && std::pow((double)cfg.beta1, 65535.0) < kSteps16Bound && std::pow((double)cfg.beta2, 65535.0) < kSteps16Bound;
     if ((rc = dev_alloc(m, m.P.master, n, false)) || (rc = dev_alloc(m, m.P.half, n, false)) || (rc = dev_alloc(m, m.P.ema, n)) ||
         (rc = dev_alloc(m, m.P.m1, n)) || (rc = dev_alloc(m, m.P.m2, n)) || (rc = steps16 ? dev_alloc(m, m.P.steps16, n + 8) : dev_alloc(m, m.P.steps, n)) || (rc = dev_alloc(m, m.d_ema_step, n / 8 + 1)) ||
         (rc = dev_alloc(m, m.P.gmlp, m.nd.n_mlp)) || (rc = dev_alloc(m, m.P.ggrid, m.n_grid))) return rc;
@@ -424,6 +496,8 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     m.backend = fused_supported(m.nd, S, m.oc.R) ? 1 : 0;
     if (options().backend >= 0) m.backend = options().backend ? (fused_supported(m.nd, S, m.oc.R) ? 1 : 0) : 0;
     m.mesh = mesh_state_create(m.device);
+    m.tile_ok = fused_supported(m.nd, S, m.oc.R) && !m.lazy_ema && tile_render_supported(m.lt, m.nd);
+    m.weights_epoch = next_weights_epoch();
     if (m.backend == 1 && !m.lazy_ema && !m.d_xw) {          // (the XORWOW mode renders on the train stream: one generator per Render, like the reference; tables above 8 M parameters keep their EMA lazily and would cost 2 x 200 MB of snapshots: they render on the train stream)
         InferState* is = new InferState(); m.infer = is;
         if ((rc = infer_shared_get(m.device, (size_t)ds->K.W * (size_t)ds->K.H, &is->shared))) return rc;      // (a whole frame fits: no growth in front of a viewer)
@@ -455,7 +529,7 @@ static int publish_snapshot(Model& m, bool force = true) {
     const uint16_t* src = (m.h_state.step > 0) ? m.P.ema : m.P.half;
     launch_copy_params(m.train_stream, src, is->snap[w], m.n_params);
     HIPCHECK(hipEventRecord(is->ready[w], m.train_stream));
-    { std::lock_guard<std::mutex> l(is->mu); is->step_of[w] = m.h_state.step; is->written[w] = true; is->latest = w; }
+    { std::lock_guard<std::mutex> l(is->mu); is->step_of[w] = m.h_state.step; is->epoch_of[w] = next_weights_epoch(); is->written[w] = true; is->latest = w; }
     is->wanted.store(false); is->last_pub = now;          // (only now: a publication skipped above must not discard the viewer's request)
     return MON_OK;
 }
@@ -586,7 +660,6 @@ static void enqueue_iteration(Model& m, int stages) {
             // NeRF_Model::Step (nerf_model.cu:1504-1550): inference of every sample, per-ray sample compaction + rollover (kernels_step.hip), then forward +
             // backward of the compacted batch.  B.pts / B.dO hold the compacted batch afterwards.
             ProfScope ps(m, MON_K_FWDBWD);
-            if (!m.d_step_counts) { if (dev_alloc(m, m.d_step_counts, (size_t)m.oc.R + 1) || dev_alloc(m, m.d_step_pts, 3 * (size_t)B)) return; }
             launch_encode(s, m.lt, m.nd, m.P.half, m.B.pts, m.B.E, B, m.d_state);
             launch_mlp_forward(s, m.nd, m.P.half, m.B.E, nullptr, m.B.O, B, m.d_state);                      // :1509 inference_mixed_precision_impl, training weights
             launch_step_compaction(s, m.B, m.oc, m.d_state, m.d_step_counts, m.d_step_pts);
@@ -679,6 +752,10 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     if (iters < 0) { set_error("train: negative iteration count"); return MON_ERR_ARG; }
     if (m.n_boxes == 0) { set_error("train: no 2-D boxes (UpdateFrameIdAndBbox was never called)"); return MON_ERR_STATE; }
     HIPCHECK(use_device(m.device));
+    if (m.backend == 0 && options().step_variant && !m.d_step_counts) {      // workspace of the Step() schedule (enqueue_iteration cannot report a failed allocation)
+        int rc;
+        if ((rc = dev_alloc(m, m.d_step_counts, (size_t)m.oc.R + 1)) || (rc = dev_alloc(m, m.d_step_pts, 3 * (size_t)m.oc.R * m.oc.S))) return rc;
+    }
     // Large-table scatter: the device picks binned / atomic per iteration from the previous iteration's gradient-carrying sample count;
     // once the host has seen that count well below the switch point it stops launching the (then empty) binning kernels at all.
     m.big_active = m.big_switch && (m.h_state.n_scatter_last == 0u || m.h_state.n_scatter_last > m.big_switch / 2u);
@@ -687,6 +764,7 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     // bit-identical parameters, so the choice is free per call; the host knows the regime from the last call's read-back.
     m.gathers_preferred = m.d_occ && m.occ_refreshed_iter && m.h_state.n_scatter_last != 0u && 8u * m.h_state.n_scatter_last < m.oc.R * m.oc.S;
     const bool use_graph_env = options().use_graph != 0;
+    if (iters > 0) m.weights_epoch = next_weights_epoch();
     m.enq_iter = m.h_state.iter;                             // (nothing of this object is in flight between calls: the read-back at the end of the last one is current)
     const bool use_graph = use_graph_env && !m.profiling && stages == 7 && iters >= 2 && !(m.d_occ && !m.occ_refreshed_iter) && !m.d_xw;      // (the first occupancy refresh changes a kernel argument)
     // chunks of iterations go through the device's training lanes (whole steps only; big-table objects are HBM-bound in their optimizer and gain from more overlap, not less)
@@ -755,10 +833,19 @@ int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int
         is->out_all = (float*)q; is->out_cap = cap;
     }
     is->out_rgb = is->out_all; is->out_depth = is->out_all + 3 * (size_t)n_pix; is->out_mask = is->out_all + 4 * (size_t)n_pix;
-    for (uint32_t p0 = 0; p0 < n_pix; p0 += kRenderChunkRays) {
-        const uint32_t n = (n_pix - p0) < kRenderChunkRays ? (n_pix - p0) : kRenderChunkRays;
-        launch_render_rays(s, is->rb, m.ds->K, m.oc, box, pose, pose_is_Toc, p0, n);
-        launch_fused_render(s, m.lf, m.nd, is->snap[r], is->rb, m.oc, n, p0 * S2, is->out_rgb + 3 * (size_t)p0, is->out_depth + p0, is->out_mask + p0, is->frag, p0 == 0u);
+    TileWs* tws = nullptr; std::unique_lock<std::mutex> tile_lock;
+    if (tile_render_wanted(m, n_pix)) {                                  // level tiles in LDS (kernels_tilerender.hip); the inference side's own workspace
+        { const int rc = tile_ws_get(m, 1, n_pix, &tws); if (rc) return rc; }
+        tile_lock = std::unique_lock<std::mutex>(tws->mu);                // (held until the stream is synchronised below)
+        uint64_t ep; { std::lock_guard<std::mutex> l(is->mu); ep = is->epoch_of[r]; }
+        tile_ws_weights(m, *tws, s, is->snap[r], ep);
+        tile_render_crop(m, *tws, s, m.oc, box, pose, pose_is_Toc, is->out_rgb, is->out_depth, is->out_mask);
+    } else {
+        for (uint32_t p0 = 0; p0 < n_pix; p0 += kRenderChunkRays) {
+            const uint32_t n = (n_pix - p0) < kRenderChunkRays ? (n_pix - p0) : kRenderChunkRays;
+            launch_render_rays(s, is->rb, m.ds->K, m.oc, box, pose, pose_is_Toc, p0, n);
+            launch_fused_render(s, m.lf, m.nd, is->snap[r], is->rb, m.oc, n, p0 * S2, is->out_rgb + 3 * (size_t)p0, is->out_depth + p0, is->out_mask + p0, is->frag, p0 == 0u);
+        }
     }
     // results: through a PINNED staging buffer of the inference side.  A device-to-host copy into the caller's pageable memory is done by the runtime's own
     // blit path, which queues at normal priority behind every training kernel on the device (12 objects training: 5-6 ms for 1 MB, one render in five); into
@@ -784,7 +871,7 @@ int ensure_ema_current(Model& m) {
     HIPCHECK(use_device(m.device)); model_leave_lane(m);
     ParamPtrs P = m.P; P.ema_step = m.d_ema_step;
     launch_ema_finalize(m.train_stream, P, m.opt, m.d_state);
-    HIPCHECK(hipGetLastError()); m.ema_pending = false; return MON_OK;
+    HIPCHECK(hipGetLastError()); m.ema_pending = false; m.weights_epoch = next_weights_epoch(); return MON_OK;
 }
 
 int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, int dst_on_device) {
@@ -811,6 +898,14 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
         launch_xorwow_fill(s, m.d_xw_render_states, m.xw_lanes, m.xw_flavour, 0u, m.d_xw_render, (uint32_t)need, nullptr, 0u, nullptr, 0u);
         m.oc.xw_render = m.d_xw_render;
     }
+    TileWs* tws = nullptr; std::unique_lock<std::mutex> tile_lock;
+    if (tile_render_wanted(m, n_pix)) {          // level tiles in LDS (kernels_tilerender.hip), the device's train-side workspace: held until the stream is synchronised below
+        { const int rc = tile_ws_get(m, 0, n_pix, &tws); if (rc) return rc; }
+        tile_lock = std::unique_lock<std::mutex>(tws->mu);
+        ProfScope ps(m, MON_K_RENDER);
+        tile_ws_weights(m, *tws, s, prm, m.weights_epoch);
+        tile_render_crop(m, *tws, s, m.oc, box, pose, pose_is_Toc, m.d_out_rgb, m.d_out_depth, m.d_out_mask);
+    } else
     for (uint32_t p0 = 0; p0 < n_pix; p0 += kRenderChunkRays) {
         const uint32_t n = (n_pix - p0) < kRenderChunkRays ? (n_pix - p0) : kRenderChunkRays;
         ProfScope ps(m, MON_K_RENDER);
@@ -844,6 +939,21 @@ int model_density_grid(Model& m, int rx, int ry, int rz, float* out_host) {
     HIPCHECK(hipMemcpy(&m.h_state, m.d_state, offsetof(DevState, n_scatter), hipMemcpyDeviceToHost));      // (the head: the slot counters behind it are 16 KB the host never reads)
     const uint16_t* prm = (m.h_state.step > 0) ? m.P.ema : m.P.half;
     const uint32_t total = (uint32_t)rx * ry * rz, chunk = m.ws_samples;
+    if (m.backend == 1 && m.tile_ok && options().tile_render != 0) {      // level tiles in LDS: the device's train-side workspace
+        TileWs* ws = nullptr; { const int rc = tile_ws_get(m, 0, 0, &ws); if (rc) return rc; }
+        std::lock_guard<std::mutex> wl(ws->mu);
+        tile_ws_weights(m, *ws, s, prm, m.weights_epoch);
+        const uint32_t tchunk = std::min(ws->cap, m.ws_samples);
+        for (uint32_t p0 = 0; p0 < total; p0 += tchunk) {
+            const uint32_t n = std::min(total - p0, tchunk);
+            launch_grid_points4(s, ws->x, rx, ry, rz, p0, n);
+            tile_points_forward(m, *ws, s, n);
+            launch_extract_density(s, ws->O, m.B.tdist, n);
+            HIPCHECK(hipMemcpyAsync(out_host + p0, m.B.tdist, 4 * (size_t)n, hipMemcpyDeviceToHost, s));
+            HIPCHECK(hipStreamSynchronize(s));
+        }
+        return MON_OK;
+    }
     for (uint32_t p0 = 0; p0 < total; p0 += chunk) {
         const uint32_t n = (total - p0) < chunk ? (total - p0) : chunk;
         launch_grid_points(s, m.B.pts, rx, ry, rz, p0, n);
@@ -873,6 +983,7 @@ int model_set_params(Model& m, const float* master, size_t n) {
     launch_master_to_half(m.train_stream, m.P.master, m.P.half, (uint32_t)n);
     HIPCHECK(hipStreamSynchronize(m.train_stream));
     m.next_ready = false;                                   // the fragment image no longer matches the weights
+    m.weights_epoch = next_weights_epoch();
     { const int rc = publish_snapshot(m); if (rc) return rc; }   // (viewers of an untrained object see the weights just set:
     HIPCHECK(hipStreamSynchronize(m.train_stream)); return MON_OK;   //  the snapshot is complete before the call returns, so no render prefers the one before it)
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/mon_core.h"
@@ -129,7 +130,8 @@ enum {
 struct Options {      // (atomics: tests and tools flip options while object threads read them)
     std::atomic<long> backend{ -1 }, use_graph{ 0 }, lazy_ema{ -1 }, big_switch{ 16384 }, touched_flags{ 1 },
          fused_grid{ 0 }, lds_encode{ 1 }, encode_ablate{ 0 }, opt_blocks{ 0 }, fused_ablate{ 0 }, fused_stagger{ -1 }, offline_outer{ 10 }, offline_inner{ 500 }, scatter_bins{ 0 }, opt_lazy_below{ -1 },
-         scatter_ablate{ 0 }, train_lanes{ 2 }, lane_chunk{ 16 }, online_slice_min{ 2 }, roctx{ 0 }, ray_records{ 1 }, step_variant{ 0 }, steps16{ 1 };
+         scatter_ablate{ 0 }, train_lanes{ 2 }, lane_chunk{ 16 }, online_slice_min{ 2 }, roctx{ 0 }, ray_records{ 1 }, step_variant{ 0 }, steps16{ 1 },
+         tile_render{ 1 };      // inference on feature-planar level tiles: 0 never (gathers), 1 crops of 4096 rays and more + point queries, 2 always
 };
 Options& options();
 int option_set(const char* name, long value);
@@ -197,6 +199,21 @@ void launch_big_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf
                         uint32_t n_bins, const DevState* st, uint32_t big_switch, void* workspace, uint16_t* ggrid, uint8_t* touched_grid);
 void launch_fused_render(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask, uint16_t* frag_image, int build_image);
 void launch_build_frag_image(hipStream_t s, const uint16_t* params, const NetDims& nd, uint16_t* image);
+// inference on feature-planar level tiles (kernels_tilerender.hip): Render / RenderVideo, GetDensityOnGrid, mesh vertex colours
+constexpr uint32_t kTileChunkJobs = 16384;          // rays (jobs of 2S = 64 samples) per chunk of the tile render
+bool tile_render_supported(const LevelTable& lt, const NetDims& nd);
+void launch_build_feat_image(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* params, uint16_t* image, uint32_t* zero_counter);
+void launch_forward_frag_image(hipStream_t s, const NetDims& nd, const uint16_t* params, uint16_t* image);
+void launch_render_rays_jobs(hipStream_t s, const Intrinsics& K, const ObjectConst& oc, mon_frame_bbox box, const Mat4& pose, int pose_is_Toc, uint32_t n_pix,
+                             float* rec, uint32_t* count, uint32_t* next_count, float* rgb, float* depth, float* mask);
+void launch_render_points(hipStream_t s, const ObjectConst& oc, const float* rec, const uint32_t* count, uint32_t job_base, uint32_t jobs_cap, float* x);
+void launch_grid_points4(hipStream_t s, float* x, int rx, int ry, int rz, uint32_t p0, uint32_t n);
+void launch_mesh_warp4(hipStream_t s, const float* verts, float* x, uint32_t v0, uint32_t n, const Aabb& box);
+void launch_encode_feat(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* image, const float* x, uint16_t* e, uint32_t cap,
+                        uint32_t n_host, const uint32_t* count, uint32_t job_base, uint32_t jobs_cap, uint32_t spj);
+void launch_tile_render(hipStream_t s, const NetDims& nd, const ObjectConst& oc, const uint16_t* frag_image, const float* rec, const uint32_t* count,
+                        uint32_t job_base, uint32_t jobs_cap, const float* x, const uint16_t* e, uint32_t cap, float* rgb, float* depth, float* mask);
+void launch_tile_points_mlp(hipStream_t s, const NetDims& nd, const uint16_t* frag_image, const uint16_t* e, uint32_t cap, uint32_t n_points, uint16_t* O);
 void launch_candidates_and_frags(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st, const uint16_t* params, const NetDims& nd, uint16_t* frag_image);
 int selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
 
@@ -244,6 +261,9 @@ struct Model {
     void* d_xw_render_states = nullptr; void* d_xw_render_init = nullptr; float* d_xw_render = nullptr; size_t xw_render_cap = 0;
     uint32_t* d_step_counts = nullptr; float* d_step_pts = nullptr;      // NeRF_Model::Step schedule (option step_variant): per-ray sample counts / slots, the compacted positions
     bool pre_active = false, points_ready = false, gathers_preferred = false;   // level-tile encode: used by the iteration being enqueued / the next batch's positions were written by the last k_optimizer / this train call runs the gather chain (occupancy grid + few live samples)
+    bool tile_ok = false;        // the inference side may run on feature-planar level tiles (tile_render_supported)
+    uint64_t weights_epoch = 0;  // process-wide unique stamp of the weights' current content (a new one after every train call / set_params / EMA catch-up):
+                                 // the tile render's per-device workspace keeps its tile image while the stamp it was built for is current
     bool next_ready = false;     // fused backend: candidates + fragment image of the coming iteration were already produced by the last k_optimizer
     mon_profile prof{}; std::vector<hipEvent_t> ev_pool; std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_pending;
     struct TrainLanes* lanes = nullptr; int lane = -1; hipEvent_t lane_event = nullptr, switch_event = nullptr, sync_event = nullptr;      // per-device training lanes (model.cpp): the lane and completion event of this object's last chunk
@@ -252,6 +272,22 @@ struct Model {
 };
 
 int ensure_ema_current(Model& m);
+uint64_t next_weights_epoch();
+// Per-device workspace of the tile render, shared by the objects on the device; `side` 0: train-stream users (model_render, density lattice, mesh), 1: the
+// inference stream.  A user holds `mu` from its first launch until its stream is synchronised.
+struct TileWs {
+    std::mutex mu;
+    float* rec = nullptr; size_t rec_cap = 0;                   // job records of a crop: 12 floats per pixel
+    uint32_t* counters = nullptr; uint32_t flip = 0;            // two job counters, used by alternate render calls (a call's ray kernel clears the next call's)
+    float* x = nullptr; uint16_t* e = nullptr; uint16_t* O = nullptr; uint32_t cap = 0; int L_cap = 0;      // chunk buffers: positions, features, raw outputs
+    uint16_t* image = nullptr; size_t image_cap = 0; uint16_t* frag = nullptr;      // feature-planar tile image + forward A fragments of the weights in use
+    const void* key_params = nullptr; uint64_t key_epoch = ~0ull;
+};
+int tile_ws_get(Model& m, int side, size_t n_pix, TileWs** out);
+// the weights `prm` (stamp `epoch`) as tile image + fragments in `ws` (rebuilt only when the stamp changed); caller holds ws.mu
+void tile_ws_weights(Model& m, TileWs& ws, hipStream_t s, const uint16_t* prm, uint64_t epoch);
+// ws.x holds n points -> ws.O (raw fp16 outputs [n][4]); caller holds ws.mu and has called tile_ws_weights
+void tile_points_forward(Model& m, TileWs& ws, hipStream_t s, uint32_t n);
 int model_publish_snapshot(Model& m);
 int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_Toc, float* rgb, float* depth, float* mask, uint32_t* snapshot_step);
 int level_table_build(const mon_config& c, LevelTable& lt, NetDims& nd, uint32_t& n_grid);

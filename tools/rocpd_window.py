@@ -60,11 +60,11 @@ def main():
                     ctr[(n, cn)] = (len(v), sum(v) / len(v))
     print("window: dispatches [%d, %d) of every kernel\n" % (a.skip, a.skip + a.take))
     if dur:
-        print("| kernel | dispatches in window (of) | avg us | min us | max us | arch VGPR | acc VGPR | LDS B | workgroups x threads |")
-        print("|---|---|---|---|---|---|---|---|---|")
+        print("| kernel | dispatches in window (of) | avg us | min us | max us | total us | arch VGPR | acc VGPR | LDS B | workgroups x threads |")
+        print("|---|---|---|---|---|---|---|---|---|---|")
         for n, (c, avg, mn, mx, tot) in sorted(dur.items(), key=lambda kv: -kv[1][1]):
             vg, ag, lds, g, w = res[n]
-            print("| %s | %d (%d) | %.2f | %.2f | %.2f | %s | %s | %s | %d x %d |" % (n[:70], c, tot, avg, mn, mx, vg, ag, lds, g, w))
+            print("| %s | %d (%d) | %.2f | %.2f | %.2f | %.1f | %s | %s | %s | %d x %d |" % (n[:70], c, tot, avg, mn, mx, avg * c, vg, ag, lds, g, w))
         print()
     if ctr:
         print("| kernel | counter | dispatches | mean per dispatch |")
