@@ -61,9 +61,10 @@ __global__ void __launch_bounds__(256) k_build_feat_image(LevelFast lt, int L, c
 
 // ------------------------------------------------------------------ rays of a whole crop, hits compacted into jobs
 // Job record: three float4 {o, t0} {d, t1} {d_norm, pixel index bits, 0, 0}.
-__global__ void __launch_bounds__(256) k_render_rays_jobs(Intrinsics K, ObjectConst oc, mon_frame_bbox box, Mat4 pose, int pose_is_Toc, uint32_t n_pix,
-                                                          float4_t* __restrict__ rec, uint32_t* __restrict__ count, uint32_t* __restrict__ next_count,
-                                                          float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ mask) {
+__global__ void __launch_bounds__(1024) k_render_rays_jobs(Intrinsics K, ObjectConst oc, mon_frame_bbox box, Mat4 pose, int pose_is_Toc, uint32_t n_pix,
+                                                           float4_t* __restrict__ rec, uint32_t* __restrict__ count, uint32_t* __restrict__ next_count,
+                                                           float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ mask) {
+    __shared__ uint32_t wave_hits[16], wg_base;
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p == 0u && next_count) *next_count = 0u;              // the counter the NEXT render call on this workspace will use
     const bool in = p < n_pix;
@@ -75,14 +76,20 @@ __global__ void __launch_bounds__(256) k_render_rays_jobs(Intrinsics K, ObjectCo
         hit = ray_intersect(oc.aabb, o, d, t0, t1);
         if (!hit) { rgb[3 * (size_t)p] = 1.f; rgb[3 * (size_t)p + 1] = 1.f; rgb[3 * (size_t)p + 2] = 1.f; depth[p] = 0.f; mask[p] = 0.f; }      // :1221-1226
     }
+    // slots: ballot per wave, the waves' counts summed in LDS, ONE returning atomic per workgroup (same-address atomics serialise in their L2 channel: one
+    // per wave, 1120 of them for a 313 x 229 crop, cost 11 us of a 16 us kernel)
     const unsigned long long bal = __ballot(hit);
-    if (bal == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    uint32_t base = 0u;
-    if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(bal));
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_hits[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0u;
+        for (int w = 0; w < 16; ++w) { const uint32_t c = wave_hits[w]; wave_hits[w] = tot; tot += c; }      // -> exclusive prefix
+        wg_base = tot ? atomicAdd(count, tot) : 0u;
+    }
+    __syncthreads();
     if (hit) {
-        const uint32_t job = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        const uint32_t job = wg_base + wave_hits[wave] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         rec[3 * (size_t)job] = float4_t{ o[0], o[1], o[2], fmaxf(t0, 0.0f) };
         rec[3 * (size_t)job + 1] = float4_t{ d[0], d[1], d[2], t1 };
         rec[3 * (size_t)job + 2] = float4_t{ dn, __builtin_bit_cast(float, p), 0.f, 0.f };
@@ -141,52 +148,107 @@ __device__ __forceinline__ void feat_load(float4_t (&xs)[kFeatSpt], const float4
     for (uint32_t k = 0; k < kFeatSpt; ++k) xs[k] = x[min(r * kFeatRound + k * kTileThreads + threadIdx.x, n - 1u)];
 }
 
+// LDS BYTE offsets of a sample's eight corners in a feature plane (2 bytes per entry) and its position inside the cell: enc_indices (tile_device.h) with every
+// term carried doubled -- xor, and, add and the conditional subtract commute with the shift, and only product bits below the table size matter -- so the
+// eight address shifts disappear.  size2 / my2 / mz2 / mask2 = 2 x the level's constants.
 template <bool HASHED, bool POW2>
-__device__ __forceinline__ void feat_walk(const uint16_t* tile, const FeatArgs& a, uint32_t n, uint32_t part, uint16_t* __restrict__ out,
+__device__ __forceinline__ void feat_offsets(const float4_t& xv, float scale, uint32_t size2, uint32_t my2, uint32_t mz2, uint32_t mask2,
+                                             uint32_t (&o0)[4], uint32_t (&o1)[4], float (&pos)[3]) {
+    uint32_t pg[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, xv[d], 0.5f); pg[d] = (uint32_t)floor_to_int(q); pos[d] = __builtin_amdgcn_fractf(q); }
+    const uint32_t y0 = (HASHED && POW2) ? __umul24(pg[1], my2 & 0xffffffu) : pg[1] * my2, z0 = (HASHED && POW2) ? __umul24(pg[2], mz2 & 0xffffffu) : pg[2] * mz2;
+    const uint32_t ay[2] = { y0, y0 + my2 }, az[2] = { z0, z0 + mz2 };
+    const uint32_t x2 = pg[0] << 1, dxm = (x2 ^ (x2 + 2u)) & mask2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (HASHED) {
+            const uint32_t t = ay[j & 1] ^ az[j >> 1];
+            o0[j] = (x2 ^ t) & mask2;
+            if (POW2) o1[j] = o0[j] ^ dxm;
+            else {
+                o1[j] = ((x2 + 2u) ^ t) & mask2;
+                o0[j] -= (o0[j] >= size2) ? size2 : 0u; o0[j] = min(o0[j], size2 - 2u); o1[j] -= (o1[j] >= size2) ? size2 : 0u; o1[j] = min(o1[j], size2 - 2u);
+            }
+        } else {
+            const uint32_t t = ay[j & 1] + az[j >> 1];
+            o0[j] = (x2 + t) & mask2; o1[j] = (x2 + 2u + t) & mask2;
+            o0[j] -= (o0[j] >= size2) ? size2 : 0u; o0[j] = min(o0[j], size2 - 2u); o1[j] -= (o1[j] >= size2) ? size2 : 0u; o1[j] = min(o1[j], size2 - 2u);
+        }
+    }
+}
+
+// A sample in flight: its eight corner values (requested) and its position inside the cell.
+struct FeatPend { uint16_t c0[4], c1[4]; float pos[3]; };
+template <bool HASHED, bool POW2>
+__device__ __forceinline__ void feat_issue(FeatPend& p, const unsigned char* tile, const float4_t& xv, float scale, uint32_t size2, uint32_t my2, uint32_t mz2, uint32_t mask2) {
+    uint32_t o0[4], o1[4];
+    feat_offsets<HASHED, POW2>(xv, scale, size2, my2, mz2, mask2, o0, o1, p.pos);
+    // (the tile starts at LDS address 0 -- the kernel has no static LDS, checked at its entry -- so the byte offset IS the address: through `tile + offset`
+    //  the compiler emits a v_add_u32 with a literal 0 per read, an eighth of the walk's instructions)
+    typedef const __attribute__((address_space(3))) uint16_t* lds_u16;
+    (void)tile;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { p.c0[j] = *(lds_u16)(uintptr_t)o0[j]; p.c1[j] = *(lds_u16)(uintptr_t)o1[j]; }
+}
+// one feature's chain of encode_interp / enc_chain: corners in order k = x + 2y + 4z, weight ((wx * wy) * wz), one rounding
+__device__ __forceinline__ uint16_t feat_finish(const FeatPend& p) {
+    const float2_t wx = { 1.f - p.pos[0], p.pos[0] };
+    const float wy[2] = { 1.f - p.pos[1], p.pos[1] }, wz[2] = { 1.f - p.pos[2], p.pos[2] };
+    const float2_t wxy[2] = { wx * wy[0], wx * wy[1] };
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float2_t w = wxy[j & 1] * wz[j >> 1];
+        acc = fmaf(w.x, (float)__builtin_bit_cast(half_t, p.c0[j]), acc);
+        acc = fmaf(w.y, (float)__builtin_bit_cast(half_t, p.c1[j]), acc);
+    }
+    // (the value passes through an opaque register: left alone, the compiler folds the last fma and the conversion into v_fma_mixlo_f16, which rounds the
+    //  exact sum ONCE to fp16 -- one result in ~2^13 then differs from fmaf + conversion, the contract of encode_interp and the oracle)
+    asm volatile("" : "+v"(acc));
+    return __builtin_bit_cast(uint16_t, (half_t)acc);
+}
+
+// The walk of one workgroup: rounds part, part + P, ... of kFeatRound samples.  Inside a round a thread's samples form a two-deep software pipeline -- the
+// corner reads of sample k + 1 are requested before sample k's chain consumes its own (16 LDS reads in flight per wave: the counter's range) -- and the next
+// round's positions travel under the current round's arithmetic.
+template <bool HASHED, bool POW2>
+__device__ __forceinline__ void feat_walk(const unsigned char* tile, const FeatArgs& a, uint32_t n, uint32_t part, uint16_t* __restrict__ out,
                                           float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask) {
     const uint32_t rounds = (n + kFeatRound - 1u) / kFeatRound;
+    const uint32_t size2 = size << 1, my2 = my << 1, mz2 = mz << 1, mask2 = mask << 1;
     float4_t cur[kFeatSpt], nxt[kFeatSpt];
     uint32_t r = part;
     if (r < rounds) feat_load(cur, a.x, r, n);                   // (requested behind the tile copy: both run under one wait)
     __builtin_amdgcn_s_waitcnt(0x0f70);                           // vmcnt(0): the LDS writes of the copy are counted there
     __syncthreads();
-    for (; r < rounds; r += kFeatParts) {
-        const bool more = r + kFeatParts < rounds;
-        if (more) feat_load(nxt, a.x, r + kFeatParts, n);         // the next round's positions travel under this round's arithmetic
+    const auto round = [&](const float4_t (&xs)[kFeatSpt], uint32_t rr) {
+        const uint32_t s0 = rr * kFeatRound + threadIdx.x;
+        const bool full = (rr + 1u) * kFeatRound <= n;            // (uniform: only the last round of a chunk can be partial)
+        FeatPend pend[2];
+        feat_issue<HASHED, POW2>(pend[0], tile, xs[0], scale, size2, my2, mz2, mask2);
 #pragma unroll
-        for (uint32_t k = 0; k < kFeatSpt; ++k) {
-            const uint32_t s = r * kFeatRound + k * kTileThreads + threadIdx.x;
-            uint32_t i0[4], i1[4]; float pos[3];
-            enc_indices<HASHED, POW2>(cur[k], scale, size, my, mz, mask, i0, i1, pos);
-            uint16_t c0[4], c1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { c0[j] = tile[i0[j]]; c1[j] = tile[i1[j]]; }
-            // one feature's chain of encode_interp / enc_chain: corners in order k = x + 2y + 4z, weight ((wx * wy) * wz)
-            const float2_t wx = { 1.f - pos[0], pos[0] };
-            const float wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
-            const float2_t wxy[2] = { wx * wy[0], wx * wy[1] };
-            float acc = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float2_t w = wxy[j & 1] * wz[j >> 1];
-                acc = fmaf(w.x, (float)__builtin_bit_cast(half_t, c0[j]), acc);
-                acc = fmaf(w.y, (float)__builtin_bit_cast(half_t, c1[j]), acc);
-            }
-            // (the value passes through an opaque register: left alone, the compiler folds the last fma and the conversion into v_fma_mixlo_f16, which rounds the
-            //  exact sum ONCE to fp16 -- one result in ~2^13 then differs from fmaf + conversion, the contract of encode_interp and the oracle)
-            asm volatile("" : "+v"(acc));
-            if (s < n) out[s] = __builtin_bit_cast(uint16_t, (half_t)acc);
+        for (uint32_t k = 1; k <= kFeatSpt; ++k) {
+            if (k < kFeatSpt) feat_issue<HASHED, POW2>(pend[k & 1u], tile, xs[k], scale, size2, my2, mz2, mask2);
+            const uint16_t e = feat_finish(pend[(k - 1u) & 1u]);
+            const uint32_t s = s0 + (k - 1u) * kTileThreads;
+            if (full || s < n) out[s] = e;
         }
-        if (more) {
-#pragma unroll
-            for (uint32_t k = 0; k < kFeatSpt; ++k) cur[k] = nxt[k];
-        }
+    };
+    for (; r < rounds; r += 2u * kFeatParts) {                    // two rounds per trip: the position buffers swap roles, no register copies
+        const uint32_t r1 = r + kFeatParts, r2 = r + 2u * kFeatParts;
+        if (r1 < rounds) feat_load(nxt, a.x, r1, n);
+        round(cur, r);
+        if (r1 >= rounds) break;
+        if (r2 < rounds) feat_load(cur, a.x, r2, n);
+        round(nxt, r1);
     }
 }
 
 __global__ void __launch_bounds__(kTileThreads) k_encode_feat(FeatArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
+    unsigned char* tile = smem;
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();      // feat_issue addresses the tile from LDS offset 0
     const uint32_t tid = blockIdx.x / kFeatParts, part = blockIdx.x - tid * kFeatParts, level = tid >> 1, f = tid & 1u;
     const uint32_t n = a.count ? chunk_jobs(a.count, a.job_base, a.jobs_cap) * a.spj : a.n_host;
     if (n == 0u || part * kFeatRound >= n) return;               // (before the tile copy: an empty chunk, or a partition without a round)
@@ -232,6 +294,37 @@ __device__ __forceinline__ void load_features(TileState<EPAD, W, NH>& ts, const 
     }
 }
 
+// One 32-sample tile's operands as they come from memory: the sample distances and the encoded features of the levels this half-wave owns.
+template <int EPAD> struct TileLoad { float t; uint16_t f[EPAD / 2]; };
+// The features come through buffer loads: ONE vector offset per tile (the sample's place in the planes of the first level this half-wave owns) and a scalar
+// offset per (local level, feature) -- address arithmetic per load was a fifth of the kernel's instructions.  A level slot this half-wave does not own gets a
+// scalar offset past the buffer's end, and a level past the last one lies there by itself: out-of-range buffer loads return zero, the padding the MLP expects.
+struct FeatBuf { __amdgpu_buffer_rsrc_t rsrc; uint32_t lane_base; uint32_t plane_bytes; };
+__device__ __forceinline__ FeatBuf feat_buffer(const TileMlpArgs& a, int L, int h) {
+    const int LPH = (L + 1) >> 1;
+    FeatBuf fb; fb.plane_bytes = a.cap * 2u;
+    fb.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.e), 0, (int)((uint32_t)L * 2u * fb.plane_bytes), 0x00020000);
+    fb.lane_base = (uint32_t)(h * LPH) * 2u * fb.plane_bytes;
+    return fb;
+}
+template <int EPAD, int W, int NH>
+__device__ __forceinline__ void tile_request(TileLoad<EPAD>& q, const TileMlpArgs& a, const FeatBuf& fb, uint32_t j, uint32_t tile, int L, int n) {
+    using S = FusedShape<EPAD, W, NH>;
+    const int LPH = (L + 1) >> 1;
+    const uint32_t s = j * 64u + tile * 32u + (uint32_t)n;
+    q.t = reinterpret_cast<const float*>(a.x)[4 * (size_t)s + 3];
+    const uint32_t voff = fb.lane_base + s * 2u;
+#pragma unroll
+    for (int il = 0; il < S::LLV; ++il) {
+        const uint32_t soff = il < LPH ? (uint32_t)(2 * il) * fb.plane_bytes : 0xfffffff0u;      // (uniform)
+        q.f[2 * il] = __builtin_amdgcn_raw_buffer_load_b16(fb.rsrc, voff, soff, 0);
+        q.f[2 * il + 1] = __builtin_amdgcn_raw_buffer_load_b16(fb.rsrc, voff, il < LPH ? soff + fb.plane_bytes : 0xfffffff0u, 0);
+    }
+}
+
+// One wavefront per job, two 32-sample tiles with a carried transmittance.  A wave walks its tiles (job j tile 0, job j tile 1, job j + stride tile 0, ...)
+// as a two-deep pipeline: the next tile's operands are requested before the current tile is evaluated (a second tile behind an opaque first one is
+// requested in vain and skipped).
 template <int EPAD, int W, int NH>
 __global__ void __launch_bounds__(256) k_tile_render(TileMlpArgs a, float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ mask) {
     using S = FusedShape<EPAD, W, NH>;
@@ -239,38 +332,47 @@ __global__ void __launch_bounds__(256) k_tile_render(TileMlpArgs a, float* __res
     half_t* frags = reinterpret_cast<half_t*>(smem);
     const uint32_t njobs = chunk_jobs(a.count, a.job_base, a.jobs_cap);
     if (blockIdx.x * S::WAVES >= njobs) return;
-    copy_forward_frags<EPAD, W, NH>(frags, a.frag_image);
-    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
     const int L = a.nd.L;
-    const float* xt = reinterpret_cast<const float*>(a.x);
-    for (uint32_t j = blockIdx.x * S::WAVES + wave; j < njobs; j += gridDim.x * S::WAVES) {
+    const uint32_t stride = gridDim.x * S::WAVES;
+    uint32_t j = blockIdx.x * S::WAVES + wave;
+    TileLoad<EPAD> cur, nxt;
+    const FeatBuf fb = feat_buffer(a, L, h);
+    if (j < njobs) tile_request<EPAD, W, NH>(cur, a, fb, j, 0u, L, n);      // (ahead of the fragment copy: its round trip runs under it)
+    copy_forward_frags<EPAD, W, NH>(frags, a.frag_image);
+    __syncthreads();
+    for (; j < njobs; j += stride) {
         const float4_t rc = a.rec[3 * (size_t)(a.job_base + j) + 2];
-        const float dn = rc.x, rc_y = rc.y; const uint32_t pix = __builtin_bit_cast(uint32_t, rc_y);
         float Tc = 1.f, r0 = 0.f, r1 = 0.f, r2 = 0.f, dep = 0.f, tlast = 0.f;
+#pragma unroll
         for (uint32_t tile = 0; tile < 2u; ++tile) {
-            if (Tc < kTransmittanceEps) break;
-            const uint32_t s = j * 64u + tile * 32u + (uint32_t)n;
-            const float t = xt[4 * (size_t)s + 3];
-            TileState<EPAD, W, NH> ts;
-            load_features<EPAD, W, NH>(ts, a.e, a.cap, s, L, h);
-            mlp_forward<EPAD, W, NH>(ts, frags, lane);
-            // VolumeRender_Render :1134-1229 over lanes 0..31 (the arithmetic of k_fused_render)
-            const float c0 = logistic_f(ts.out4[0]), c1 = logistic_f(ts.out4[1]), c2 = logistic_f(ts.out4[2]), sigma = __expf(ts.out4[3]);
-            float tprev = lane_prev(t, tlast); if (n == 0) tprev = tlast;
-            const float alpha = 1.f - __expf(-sigma * (t - tprev)), omv = 1.f - alpha;
-            const float tincl = scan_mul32(omv) * Tc;
-            float T = lane_prev(tincl, Tc); if (n == 0) T = Tc;
-            const bool active = T >= kTransmittanceEps;
-            const int nact = __popc((uint32_t)__ballot(active));
-            const float wgt = active ? alpha * T : 0.f;
-            r0 += lane_bcast(scan_add32(wgt * c0), 31); r1 += lane_bcast(scan_add32(wgt * c1), 31); r2 += lane_bcast(scan_add32(wgt * c2), 31);
-            dep += lane_bcast(scan_add32(wgt * t), 31);
-            Tc = (nact > 0) ? lane_bcast(tincl, nact > 0 ? nact - 1 : 0) : Tc;      // all 64 lanes carry half-wave 0's state (uniform control flow)
-            tlast = lane_bcast(t, 31);
+            if (tile == 0u) tile_request<EPAD, W, NH>(nxt, a, fb, j, 1u, L, n);
+            else if (j + stride < njobs) tile_request<EPAD, W, NH>(nxt, a, fb, j + stride, 0u, L, n);
+            if (Tc >= kTransmittanceEps) {
+                const float t = cur.t;
+                TileState<EPAD, W, NH> ts;
+#pragma unroll
+                for (int i = 0; i < EPAD / 2; ++i) ts.ef[i] = __builtin_bit_cast(half_t, cur.f[i]);
+                mlp_forward<EPAD, W, NH>(ts, frags, lane);
+                // VolumeRender_Render :1134-1229 over lanes 0..31 (the arithmetic of k_fused_render)
+                const float c0 = logistic_f(ts.out4[0]), c1 = logistic_f(ts.out4[1]), c2 = logistic_f(ts.out4[2]), sigma = __expf(ts.out4[3]);
+                float tprev = lane_prev(t, tlast); if (n == 0) tprev = tlast;
+                const float alpha = 1.f - __expf(-sigma * (t - tprev)), omv = 1.f - alpha;
+                const float tincl = scan_mul32(omv) * Tc;
+                float T = lane_prev(tincl, Tc); if (n == 0) T = Tc;
+                const bool active = T >= kTransmittanceEps;
+                const int nact = __popc((uint32_t)__ballot(active));
+                const float wgt = active ? alpha * T : 0.f;
+                r0 += lane_bcast(scan_add32(wgt * c0), 31); r1 += lane_bcast(scan_add32(wgt * c1), 31); r2 += lane_bcast(scan_add32(wgt * c2), 31);
+                dep += lane_bcast(scan_add32(wgt * t), 31);
+                Tc = (nact > 0) ? lane_bcast(tincl, nact > 0 ? nact - 1 : 0) : Tc;      // all 64 lanes carry half-wave 0's state (uniform control flow)
+                tlast = lane_bcast(t, 31);
+            }
+            cur = nxt;
         }
         float o0 = 1.f, o1 = 1.f, o2 = 1.f, od = 0.f, om_ = 0.f;
-        if (1.f - Tc > 0.5f) { o0 = r0 + Tc; o1 = r1 + Tc; o2 = r2 + Tc; od = dep / dn; om_ = 1.f; }      // :1213-1220
+        if (1.f - Tc > 0.5f) { o0 = r0 + Tc; o1 = r1 + Tc; o2 = r2 + Tc; od = dep / rc.x; om_ = 1.f; }      // :1213-1220
+        const float rc_y = rc.y; const uint32_t pix = __builtin_bit_cast(uint32_t, rc_y);
         if (lane == 0) { rgb[3 * (size_t)pix] = o0; rgb[3 * (size_t)pix + 1] = o1; rgb[3 * (size_t)pix + 2] = o2; depth[pix] = od; mask[pix] = om_; }
     }
 }
@@ -309,7 +411,7 @@ void launch_build_feat_image(hipStream_t s, const LevelFast& lf, const NetDims& 
 }
 void launch_render_rays_jobs(hipStream_t s, const Intrinsics& K, const ObjectConst& oc, mon_frame_bbox box, const Mat4& pose, int pose_is_Toc, uint32_t n_pix,
                              float* rec, uint32_t* count, uint32_t* next_count, float* rgb, float* depth, float* mask) {
-    hipLaunchKernelGGL(k_render_rays_jobs, dim3((n_pix + 255u) / 256u), dim3(256), 0, s, K, oc, box, pose, pose_is_Toc, n_pix,
+    hipLaunchKernelGGL(k_render_rays_jobs, dim3((n_pix + 1023u) / 1024u), dim3(1024), 0, s, K, oc, box, pose, pose_is_Toc, n_pix,
                        reinterpret_cast<float4_t*>(rec), count, next_count, rgb, depth, mask);
 }
 void launch_render_points(hipStream_t s, const ObjectConst& oc, const float* rec, const uint32_t* count, uint32_t job_base, uint32_t jobs_cap, float* x) {
@@ -334,7 +436,7 @@ void launch_encode_feat(hipStream_t s, const LevelFast& lf, const NetDims& nd, c
 template <int EPAD, int W, int NH>
 static void tile_render_t(hipStream_t s, const TileMlpArgs& a, float* rgb, float* depth, float* mask) {
     using S = FusedShape<EPAD, W, NH>;
-    uint32_t grid = (a.jobs_cap + S::WAVES - 1u) / S::WAVES; if (grid > 2048u) grid = 2048u;
+    uint32_t grid = (a.jobs_cap + S::WAVES - 1u) / S::WAVES; if (grid > 1280u) grid = 1280u;      // five workgroups per CU: a wave takes several jobs and prefetches the next
     hipLaunchKernelGGL((k_tile_render<EPAD, W, NH>), dim3(grid), dim3(256), S::F_WOT * 1024, s, a, rgb, depth, mask);
 }
 template <int EPAD, int W, int NH>

@@ -46,6 +46,44 @@ __global__ void __launch_bounds__(256) k_ub(int mode, int pattern, uint32_t n_en
 }
 
 // LDS atomics on a 128 KB tile, 1024 threads per workgroup, one workgroup per CU.
+// modes 50-59: read-width / active-lane probes of random LDS reads (compile-time mode; full-rate index arithmetic: one add + one and per op)
+// 50 ds_read_u16, 51 ds_read_b32, 52 ds_read_b64 (8-byte aligned), 53 ds_read_b128 (16-byte aligned); 54 / 55 / 56: ds_read_b32 with 1/2, 1/4, 1/8 of the
+// lanes active (random lanes); 57: ds_read_b128 by every lane + ds_read_u16 by 1/8 of them; 58: ds_read_b64 + ds_read_u16 by 1/4; 59: ds_read_b32 + u16 by 1/2
+template <int MODE>
+__global__ void __launch_bounds__(1024) k_ub_lds_read(uint32_t ops_per_thread, float* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
+    for (uint32_t i = threadIdx.x; i < 32768u; i += blockDim.x) tab[i] = i * 0x9E3779B9u;
+    __syncthreads();
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t h = mix32(gid * 0x9E3779B9u + 777u);
+    uint32_t idx = h & 32767u, accu = 0u; const uint32_t stride = (mix32(h) | 1u) & 32767u;
+    const bool sel2 = (h >> 16) & 1u, sel4 = ((h >> 16) & 3u) == 0u, sel8 = ((h >> 16) & 7u) == 0u;
+    const unsigned char* tb = reinterpret_cast<const unsigned char*>(tab);
+#pragma unroll 16
+    for (uint32_t i = 0; i < ops_per_thread; ++i) {
+        idx = (idx + stride) & 32767u;
+        if constexpr (MODE == 50) accu += *reinterpret_cast<const uint16_t*>(tb + ((idx * 4u) & ~1u));
+        else if constexpr (MODE == 51) accu += tab[idx];
+        else if constexpr (MODE == 52) { const uint2 v = *reinterpret_cast<const uint2*>(tab + (idx & ~1u)); accu += v.x ^ v.y; }
+        else if constexpr (MODE == 53) { const uint4 v = *reinterpret_cast<const uint4*>(tab + (idx & ~3u)); accu += v.x ^ v.y ^ v.z ^ v.w; }
+        else if constexpr (MODE == 54) { if (sel2) accu += tab[idx]; }
+        else if constexpr (MODE == 55) { if (sel4) accu += tab[idx]; }
+        else if constexpr (MODE == 56) { if (sel8) accu += tab[idx]; }
+        else if constexpr (MODE == 57) { const uint4 v = *reinterpret_cast<const uint4*>(tab + (idx & ~3u)); accu += v.x ^ v.y ^ v.z ^ v.w;
+                                         if (sel8) accu += *reinterpret_cast<const uint16_t*>(tb + (((idx ^ 0x5555u) * 4u) & ~1u)); }
+        else if constexpr (MODE == 58) { const uint2 v = *reinterpret_cast<const uint2*>(tab + (idx & ~1u)); accu += v.x ^ v.y;
+                                         if (sel4) accu += *reinterpret_cast<const uint16_t*>(tb + (((idx ^ 0x5555u) * 4u) & ~1u)); }
+        else if constexpr (MODE == 59) { accu += tab[idx]; if (sel2) accu += *reinterpret_cast<const uint16_t*>(tb + (((idx ^ 0x5555u) * 4u) & ~1u)); }
+        else if constexpr (MODE == 60) accu += tab[(idx & ~63u) | (threadIdx.x & 63u)];                    // conflict-free: the wave reads 64 consecutive dwords
+        else if constexpr (MODE == 61) accu += tab[__builtin_amdgcn_readfirstlane(idx)];                   // broadcast: every lane the same address
+        else if constexpr (MODE == 62) accu += tab[(idx & ~63u) | ((idx >> 6) & 63u)];                     // random within a 256-byte window (conflicts, one row)
+        else if constexpr (MODE == 63) accu += tab[(idx & ~1u) | (threadIdx.x & 1u)];                      // random, lane pairs read adjacent dwords
+        else accu += tab[sel8 ? idx : ((idx & ~63u) | (threadIdx.x & 63u))];                               // 64: 1/8 random lanes, the rest conflict-free (no exec masking)
+    }
+    if (accu == 0x12345678u) sink[0] = 1.f;
+}
+
 // mode 10: ds_pk_add_f16 random   11: ds_add_f32 random   12: ds_add_u32 random
 // mode 13: ds_pk_add_f16, lane pairs share an address   14: ds_write_b32 random (no atomic)   15: ds_pk_add_f16, 4 lanes share   16: ds_add_u64 random
 __global__ void __launch_bounds__(1024) k_ub_lds(int mode, uint32_t ops_per_thread, float* __restrict__ sink) {
@@ -188,7 +226,7 @@ int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n
     const uint32_t ops_per_thread = 64, threads = n_ops / ops_per_thread, blocks = (threads + 255) / 256;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
-    const bool lds_mode = (mode >= 10 && mode < 20) || (mode >= 40 && mode < 50);      // (modes 20..29 are gather probes again)
+    const bool lds_mode = (mode >= 10 && mode < 20) || (mode >= 40 && mode < 70);      // (modes 20..29 are gather probes again)
     if (lds_mode) hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ub_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0, 0);
@@ -199,6 +237,12 @@ int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n
             launch_stream(mode, pattern > 0 ? pattern : 512, (int)((n_entries >> 4) & 15u), a);
         }
         else if (mode == 30) hipLaunchKernelGGL(k_ub_copy, dim3(pattern > 0 ? pattern : 512), dim3(256), 0, 0, reinterpret_cast<const ub_u4*>(table), reinterpret_cast<ub_u4*>(table) + n_ops / 16u, n_ops / 16u);
+        else if (mode >= 50 && mode < 70) {
+#define MON_UB_READ(M) case M: hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ub_lds_read<M>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+                               hipLaunchKernelGGL(k_ub_lds_read<M>, dim3(256), dim3(1024), 131072, 0, n_ops / (256u * 1024u), sink); break;
+            switch (mode) { MON_UB_READ(50) MON_UB_READ(51) MON_UB_READ(52) MON_UB_READ(53) MON_UB_READ(54) MON_UB_READ(55) MON_UB_READ(56) MON_UB_READ(57) MON_UB_READ(58) MON_UB_READ(59) MON_UB_READ(60) MON_UB_READ(61) MON_UB_READ(62) MON_UB_READ(63) MON_UB_READ(64) }
+#undef MON_UB_READ
+        }
         else if (lds_mode) hipLaunchKernelGGL(k_ub_lds, dim3(256), dim3(1024), 131072, 0, mode, n_ops / (256u * 1024u), sink);
         else hipLaunchKernelGGL(k_ub, dim3(blocks), dim3(256), 0, 0, mode, pattern, n_entries, ops_per_thread, table, sink);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);

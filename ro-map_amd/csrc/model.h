@@ -200,7 +200,7 @@ void launch_big_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf
 void launch_fused_render(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask, uint16_t* frag_image, int build_image);
 void launch_build_frag_image(hipStream_t s, const uint16_t* params, const NetDims& nd, uint16_t* image);
 // inference on feature-planar level tiles (kernels_tilerender.hip): Render / RenderVideo, GetDensityOnGrid, mesh vertex colours
-constexpr uint32_t kTileChunkJobs = 16384;          // rays (jobs of 2S = 64 samples) per chunk of the tile render
+constexpr uint32_t kTileChunkJobs = 32768;          // rays (jobs of 2S = 64 samples) per chunk of the tile render
 bool tile_render_supported(const LevelTable& lt, const NetDims& nd);
 void launch_build_feat_image(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* params, uint16_t* image, uint32_t* zero_counter);
 void launch_forward_frag_image(hipStream_t s, const NetDims& nd, const uint16_t* params, uint16_t* image);

@@ -8,7 +8,7 @@ TAG="${1:-rwin}"; shift || true
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$REPO/gpurun_out/$TAG"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-ONLY="k_render,k_fused_render,k_encode_tiles,k_build,k_occ,k_grid_points,k_encode,k_mlp,k_extract,k_mc,k_mesh,k_density,k_copy"
+ONLY="k_render,k_fused_render,k_tile,k_encode_feat,k_build,k_occ,k_grid_points,k_encode,k_mlp,k_extract,k_mc,k_mesh,k_density,k_copy"
 python "$REPO/tools/render_window.py" "$@" > "$OUT/plain.log" 2>&1; cat "$OUT/plain.log"
 CMD="python $REPO/tools/render_window.py --train 300 --crops 10 --orbit 60 --meshes 3 $*"
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $CMD > "$OUT/trace.log" 2>&1); echo "trace exit $?"; tail -5 "$OUT/trace.log"
