@@ -35,6 +35,10 @@ int mon_debug_yaml_number(const char* text, const char* key, double* value);
  * out[1] = first iteration at or after which the next one is due. */
 int mon_debug_occupancy_state(mon_object* obj, uint32_t out[2]);
 
+/* Tile render bookkeeping (ro-map_amd/csrc/kernels_tilerender.hip): jobs (rays that hit the object's box, 2S samples each) of the LAST crop rendered on the
+ * object's device through the per-device workspace of `side` (0: train-stream renders, 1: the inference stream); what bench.py's evaluated-sample count is. */
+int mon_debug_render_jobs(mon_object* obj, int side, uint32_t* jobs);
+
 #ifdef __cplusplus
 }
 #endif

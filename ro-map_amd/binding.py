@@ -125,6 +125,7 @@ _DIAG_SIGS = {
     "mon_debug_fast_index": (C.c_int, [C.POINTER(MonConfig), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mon_selftest_mfma": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mon_debug_yaml_number": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_double)]),
+    "mon_debug_render_jobs": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]),
     "mon_debug_occupancy_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
 }
 
@@ -397,6 +398,10 @@ class ObjectNeRF:
 
     def occupancy_state(self):
         out = (C.c_uint32 * 2)(); _check(diag_lib().mon_debug_occupancy_state(self.h, out)); return int(out[0]), int(out[1])
+
+    def render_jobs(self, side=0):
+        """Jobs (rays that hit the box) of the last crop the tile render evaluated on this object's device (side 0: train stream, 1: inference stream)."""
+        n = C.c_uint32(0); _check(diag_lib().mon_debug_render_jobs(self.h, int(side), C.byref(n))); return n.value
 
     def set_debug_dump(self, on):
         _check(lib().mon_object_set_debug_dump(self.h, int(on)))

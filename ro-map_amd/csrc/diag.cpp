@@ -123,6 +123,14 @@ int mon_debug_occupancy_state(mon_object* o, uint32_t out[2]) {
     if (!o || !o->m || !out) { mon::set_error("debug_occupancy_state: null argument"); return MON_ERR_ARG; }
     out[0] = o->m->occ_refreshed_iter; out[1] = o->m->occ_next_refresh; return MON_OK;
 }
+int mon_debug_render_jobs(mon_object* o, int side, uint32_t* jobs) {
+    if (!o || !o->m || !jobs) { mon::set_error("debug_render_jobs: null argument"); return MON_ERR_ARG; }
+    mon::TileWs* ws = nullptr; const int rc = mon::tile_ws_get(*o->m, side, 0, &ws); if (rc) return rc;
+    std::lock_guard<std::mutex> l(ws->mu);
+    if (mon::use_device(o->m->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { mon::set_error("debug_render_jobs: device error"); return MON_ERR_HIP; }
+    if (hipMemcpy(jobs, ws->counters + 16u * ((ws->flip + 1u) & 1u), 4, hipMemcpyDeviceToHost) != hipSuccess) { mon::set_error("debug_render_jobs: copy failed"); return MON_ERR_HIP; }
+    return MON_OK;
+}
 int mon_debug_yaml_number(const char* text, const char* key, double* value) {
     REQUIRE(text, "text"); REQUIRE(key, "key"); REQUIRE(value, "value");
     if (!read_yaml_number(text, key, *value)) { set_error("config.yaml: %s missing or not a number", key); return MON_ERR_IO; }

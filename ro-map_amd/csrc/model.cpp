@@ -107,7 +107,7 @@ static int infer_shared_get(int device, size_t pixels_hint, InferShared** out) {
 // ---- tile render workspace (kernels_tilerender.hip): per device and side, grow-only, never freed (like the inference stream)
 static std::atomic<uint64_t> g_weights_epoch{ 1 };
 uint64_t next_weights_epoch() { return g_weights_epoch.fetch_add(1); }
-struct TileWsPair { TileWs side[2]; };
+struct TileWsPair { TileWs side[2]; int objects = 0; };      // objects: tile-capable objects alive on the device (under g_tile_mu); the buffers go with the last one
 static std::mutex g_tile_mu; static std::map<int, TileWsPair*> g_tile_ws;
 template <class T> static int ws_grow(T*& p, size_t n_elems) {      // (contents are scratch: nothing to carry over)
     void* q = nullptr;
@@ -134,6 +134,17 @@ int tile_ws_get(Model& m, int side, size_t n_pix, TileWs** out) {
     if (ws.image_cap < 2 * (size_t)m.n_grid) { if ((rc = ws_grow(ws.image, 2 * (size_t)m.n_grid + 64))) return rc; ws.image_cap = 2 * (size_t)m.n_grid; ws.key_epoch = ~0ull; }
     if (ws.rec_cap < n_pix) { const size_t c = std::max<size_t>(n_pix, 2 * ws.rec_cap); if ((rc = ws_grow(ws.rec, 12 * c))) return rc; ws.rec_cap = c; }
     *out = &ws; return MON_OK;
+}
+static void tile_ws_object_born(int device) { std::lock_guard<std::mutex> l(g_tile_mu); TileWsPair*& slot = g_tile_ws[device]; if (!slot) slot = new TileWsPair(); ++slot->objects; }
+static void tile_ws_object_gone(int device) {
+    std::lock_guard<std::mutex> l(g_tile_mu);
+    auto it = g_tile_ws.find(device); if (it == g_tile_ws.end() || --it->second->objects > 0) return;
+    for (TileWs& ws : it->second->side) {          // the device's last object: a few hundred MB of scratch are returned (nobody can hold ws.mu: users are objects)
+        std::lock_guard<std::mutex> wl(ws.mu);
+        for (void* q : { (void*)ws.rec, (void*)ws.counters, (void*)ws.x, (void*)ws.e, (void*)ws.O, (void*)ws.image, (void*)ws.frag }) if (q) hipFree(q);
+        ws.rec = nullptr; ws.counters = nullptr; ws.x = nullptr; ws.e = nullptr; ws.O = nullptr; ws.image = nullptr; ws.frag = nullptr;
+        ws.rec_cap = 0; ws.cap = 0; ws.L_cap = 0; ws.image_cap = 0; ws.flip = 0; ws.key_params = nullptr; ws.key_epoch = ~0ull;
+    }
 }
 void tile_ws_weights(Model& m, TileWs& ws, hipStream_t s, const uint16_t* prm, uint64_t epoch) {
     if (ws.key_params == prm && ws.key_epoch == epoch) return;
@@ -498,6 +509,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     m.mesh = mesh_state_create(m.device);
     m.tile_ok = fused_supported(m.nd, S, m.oc.R) && !m.lazy_ema && tile_render_supported(m.lt, m.nd);
     m.weights_epoch = next_weights_epoch();
+    if (m.tile_ok) { tile_ws_object_born(m.device); m.tile_counted = true; }
     if (m.backend == 1 && !m.lazy_ema && !m.d_xw) {          // (the XORWOW mode renders on the train stream: one generator per Render, like the reference; tables above 8 M parameters keep their EMA lazily and would cost 2 x 200 MB of snapshots: they render on the train stream)
         InferState* is = new InferState(); m.infer = is;
         if ((rc = infer_shared_get(m.device, (size_t)ds->K.W * (size_t)ds->K.H, &is->shared))) return rc;      // (a whole frame fits: no growth in front of a viewer)
@@ -562,6 +574,7 @@ int model_destroy(Model* mp) {
         delete is; m.infer = nullptr;
     }
     drop_graph(m);
+    if (m.tile_counted) { tile_ws_object_gone(m.device); m.tile_counted = false; }
     for (auto& e : m.ev_pool) hipEventDestroy(e);
     for (void* p : m.allocs) hipFree(p);
     if (m.h_state_pinned) hipHostFree(m.h_state_pinned);

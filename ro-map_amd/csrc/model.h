@@ -261,6 +261,7 @@ struct Model {
     void* d_xw_render_states = nullptr; void* d_xw_render_init = nullptr; float* d_xw_render = nullptr; size_t xw_render_cap = 0;
     uint32_t* d_step_counts = nullptr; float* d_step_pts = nullptr;      // NeRF_Model::Step schedule (option step_variant): per-ray sample counts / slots, the compacted positions
     bool pre_active = false, points_ready = false, gathers_preferred = false;   // level-tile encode: used by the iteration being enqueued / the next batch's positions were written by the last k_optimizer / this train call runs the gather chain (occupancy grid + few live samples)
+    bool tile_counted = false;   // this object is counted in its device's tile workspace (freed with the device's last such object)
     bool tile_ok = false;        // the inference side may run on feature-planar level tiles (tile_render_supported)
     uint64_t weights_epoch = 0;  // process-wide unique stamp of the weights' current content (a new one after every train call / set_params / EMA catch-up):
                                  // the tile render's per-device workspace keeps its tile image while the stamp it was built for is current
