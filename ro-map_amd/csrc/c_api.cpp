@@ -104,7 +104,7 @@ int mon_object_set_backend(mon_object* o, int backend) {
     if (backend != 0 && backend != 1) { set_error("backend must be 0 or 1"); return MON_ERR_ARG; }
     o->m->backend = backend; o->m->next_ready = false; return MON_OK;
 }
-int mon_object_set_debug_dump(mon_object* o, int enable) { REQUIRE(o, "object"); o->m->fused_dump = enable != 0; o->m->graph_backend = -1; return MON_OK; }
+int mon_object_set_debug_dump(mon_object* o, int enable) { REQUIRE(o, "object"); o->m->fused_dump = enable < 0 ? 0 : (enable > 2 ? 2 : enable); o->m->graph_backend = -1; return MON_OK; }
 int mon_object_set_profiling(mon_object* o, int enable) { REQUIRE(o, "object"); o->m->profiling = enable != 0; return MON_OK; }
 int mon_object_get_profile(mon_object* o, mon_profile* out, int reset) {
     REQUIRE(o, "object"); REQUIRE(out, "out"); *out = o->m->prof; if (reset) std::memset(&o->m->prof, 0, sizeof(mon_profile)); return MON_OK;

@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         rec_base = reinterpret_cast<const char*>(fb); if (lane >= 3 && lane < 9) rec_mul = 3u; }
     const auto load_record = [&](uint32_t cand) -> uint32_t { uint32_t v = 0u; if (lane < 10) v = *reinterpret_cast<const uint32_t*>(rec_base + 4u * (size_t)(cand * rec_mul)); return v; };
     // (PRE with records: lane l < 10 takes field l of ray `r`'s 12-float record -- one coalesced 40-byte load, requested a ray ahead like the candidate record)
-    const auto load_ray_rec = [&](uint32_t r) -> uint32_t { uint32_t v = 0u; if (lane < 10) v = reinterpret_cast<const uint32_t*>(a.b.ray_rec)[12u * (size_t)r + (uint32_t)lane]; return v; };
+    const auto load_ray_rec = [&](uint32_t r) -> uint32_t { uint32_t v = 0u; if (lane < 11) v = reinterpret_cast<const uint32_t*>(a.b.ray_rec)[12u * (size_t)r + (uint32_t)lane]; return v; };
     const uint32_t ray0 = blockIdx.x * S::WAVES + wave;
     uint32_t cand = 0u, rec = 0u;
     if (have_rec) { if (nvalid != 0u && ray0 < R) rec = load_ray_rec(ray0); }
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     };
     if constexpr (PRE) { if (ray0 < R) load_encoded(ray0); }
     for (uint32_t ray = ray0; ray < R; ray += ray_stride) {
-        const RaySample cur = ray_sample(rec, ray); const uint32_t cand_this = cand;
+        const RaySample cur = ray_sample(rec, ray); const uint32_t cand_this = have_rec ? lane_u(rec, 10) : cand;      // (only the debug dump reads it)
         const uint32_t kth = ray % nvalid, rgba = cur.rgba, s_idx = ray * 32u + (uint32_t)n;
         const float t = cur.t, tdp = cur.tdp, t0 = cur.t0, t1 = cur.t1; const bool live = cur.live, is_obj = (rgba >> 24) != 0u;
         const float x[3] = { cur.x[0], cur.x[1], cur.x[2] };
@@ -465,8 +465,13 @@ static void fused_train_t(hipStream_t s, const FusedArgs& a, uint32_t grid, int 
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
     });
     const bool all_lds = a.lds_level_mask != 0u && (a.lds_level_mask == ((a.nd.L >= 32) ? 0xffffffffu : ((1u << a.nd.L) - 1u)));
+    if (a.e_soa && all_lds && dump) {           // the benched chain's kernel with the debug dump compiled in (mon_object_set_debug_dump(obj, 2)): E / h / O / dO / dh / dE of every sample
+        hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true, false, false, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
+        return;
+    }
     if (a.e_soa && all_lds && !dump) {          // features from k_encode_tiles (with the occupancy grid: a dead sample's features are there too, its alpha and gradient are zero all the same)
         if (a.occ_bits) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
         else hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false, false, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);

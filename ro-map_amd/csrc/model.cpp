@@ -692,7 +692,7 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
         } else {
             if (m.scatter_pending) hipMemsetAsync(m.d_state->n_scatter, 0, sizeof(m.d_state->n_scatter), s);      // stage-wise debugging: a forward/backward without an optimizer step after it
-            const bool pre = m.d_e_soa && !m.fused_dump && options().lds_encode && !m.gathers_preferred;          // the encode as LDS reads of level tiles; the fused kernel then loads the features
+            const bool pre = m.d_e_soa && m.fused_dump != 1 && options().lds_encode && !m.gathers_preferred;          // the encode as LDS reads of level tiles; the fused kernel then loads the features
             m.pre_active = pre;
             if (pre) {
                 // positions of this batch: normally the last k_optimizer's position blocks already wrote them (and k_encode_tiles of the last iteration the candidates)

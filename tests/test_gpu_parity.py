@@ -156,6 +156,43 @@ def test_forward_backward_matches_oracle_and_golden(pkg, orc, ss, name, backend)
     obj.close(); ds.close(); ref.close()
 
 
+@pytest.mark.parametrize("name,kw", [("c2s", dict(CFGS["c2s"])), ("c2", dict(C2))], ids=["c2s-R256", "c2-R4096"])
+def test_benched_chain_forward_backward_matches_oracle(pkg, orc, ss, name, kw):
+    """The instantiation bench.py times -- k_encode_tiles -> k_fused_train<PRE> -> k_grid_scatter -- against the oracle DIRECTLY (the other oracle comparisons of
+    backend 1 run the gather chain's dump variant): mon_object_set_debug_dump(obj, 2) keeps the level-tile chain and compiles the dump into its kernel.
+    base.json at the full batch (R = 4096) and the fixtures' small batch (level tiles forced)."""
+    sc = ss.make_scene(**SCENE)
+    old = pkg.get_option("lds_encode"); pkg.set_option("lds_encode", 2)
+    try:
+        _need_gpu(pkg)
+        ds, obj = ge.make_problem(pkg, sc, kw); obj.set_backend(1); obj.set_debug_dump(2)
+        ref = ge.make_oracle(orc, sc, kw)
+        p = pattern_params(ref); obj.set_params(p); ref.set_params(p)
+        obj.train_stages(1 | 2); ref.generate_batch(); ref.forward_backward()
+        assert int(obj.buffer("state")[2]) == ref.n_valid > 0
+        B, Ep, L = ref.R * ref.S, ref.Epad, ref.cfg.n_levels
+        e_soa = obj.buffer("e_soa").reshape(L, B, 2)                      # what k_encode_tiles wrote: the chain is the level-tile one
+        assert np.array_equal(e_soa.transpose(1, 0, 2).reshape(B, 2 * L), ref.buffer("E").reshape(B, Ep)[:, :2 * L]), "level-tile encode must be bit-exact"
+        assert np.array_equal(obj.buffer("E"), ref.buffer("E")), "the features k_fused_train<PRE> loaded"
+        ex = close_half(obj.buffer("Hid"), ref.buffer("Hid"), "hidden activations", frac_ok=0.999)
+        close_half(obj.buffer("O"), ref.buffer("O"), "network output", frac_ok=0.999)
+        close_half(obj.buffer("dO"), ref.buffer("dO"), "dL/dO", ulps=4, frac_ok=0.999)
+        close_half(obj.buffer("dHid"), ref.buffer("dHid"), "dL/dh", ulps=4, frac_ok=0.999)
+        close_half(obj.buffer("dE").reshape(B, Ep)[:, :2 * L], ref.buffer("dE").reshape(B, Ep)[:, :2 * L], "dL/dE", ulps=4, frac_ok=0.999)
+        assert ex > 0.9
+        for b, tol in (("rgb_ray", 2e-3), ("mask_ray", 2e-3), ("depth_ray", 3e-3), ("loss_ray", 5e-3)):
+            close_f32(obj.buffer(b), ref.buffer(b), b, tol)
+        gm, rm = obj.buffer("gmlp").astype(np.float64), ref.buffer("gmlp").astype(np.float64)
+        assert np.abs(gm - rm).max() < 5e-3 * np.abs(rm).max(), (np.abs(gm - rm).max(), np.abs(rm).max())
+        # grid gradient = the sum of k_grid_scatter's partial tables (exact int32 accumulation per tile, one fp16 rounding per partial table)
+        gg = h2f(obj.buffer("ggrid_h")).astype(np.float64); rg = ref.buffer("ggrid").astype(np.float64); ra = ref.buffer("ggrid_abs").astype(np.float64)
+        frac_bad = float((np.abs(gg - rg) > 2.0 ** -8 * ra + 2.0 ** -10 * np.abs(rg) + 1e-7).mean())
+        assert frac_bad < 2e-3 and (gg != 0).sum() > 0, frac_bad
+        obj.close(); ds.close(); ref.close()
+    finally:
+        pkg.set_option("lds_encode", old)
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("name", sorted(CFGS))
 def test_one_training_step_matches_oracle_and_golden(pkg, orc, ss, name, backend):
