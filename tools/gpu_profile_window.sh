@@ -8,7 +8,7 @@ TAG="${1:-win}"; EXTRA="${2:-0}"
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$REPO/gpurun_out/$TAG"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python $REPO/tools/profile_window.py --warmup 5 --steps 20 --extra $EXTRA"
+CMD="python $REPO/tools/profile_window.py --warmup 5 --steps 20 --extra $EXTRA ${WINDOW_ARGS:-}"      # WINDOW_ARGS: e.g. "--log2-hashmap-size 22 --objects 8"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $CMD > "$OUT/trace.log" 2>&1); echo "trace exit $?"; tail -1 "$OUT/trace.log"
 python "$REPO/tools/rocpd_window.py" "$OUT/trace" --skip $((5 + EXTRA)) --take 20 > "$OUT/kernel_window.md"; cat "$OUT/kernel_window.md"; rm -rf "$OUT/trace"
 i=0
