@@ -96,6 +96,7 @@ int mon_device_count(int* n_devices);
  * per device (nerf.cu:27-33, nerf_manager.cu:44-55) can be driven -- oversubscribed -- on a box with fewer GPUs; 0 restores the default.  Call before
  * creating datasets / managers. */
 int mon_set_logical_devices(int n);
+int mon_physical_device(int logical_device, int* physical_device);   /* the HIP device a logical device runs on (what a multi-device consumer groups objects by) */
 
 /* NeRF_Model::ReadNetworkConfig (nerf_model.cu:1272-1284): tcnn JSON with comments. */
 int mon_config_default(mon_config* cfg);                       /* CORE/configs/base.json values */
@@ -200,6 +201,7 @@ int mon_offline_render_test(mon_offline* mgr, int idx, const char* out_dir, int 
 int mon_offline_get_intrinsics(mon_offline* mgr, float* fx, float* fy, float* cx, float* cy, int* H, int* W);
 int mon_offline_get_poses(mon_offline* mgr, float* Twc16s, size_t capacity_frames, size_t* n_frames);
 int mon_offline_object_meta(mon_offline* mgr, int idx, int* class_id, float* Tow16, float* aabb_min3, float* aabb_max3, mon_frame_bbox* boxes, size_t capacity_boxes, size_t* n_boxes);
+int mon_offline_object_stamp(mon_offline* mgr, int idx, size_t box_index, char* buf, size_t capacity);   /* the timestamp string of the object's box_index-th observation (the test images' file names) */
 int mon_offline_set_output_dir(mon_offline* mgr, const char* dir);       /* where the training thread saves <id>.ply (default "./output", nerf.cu:148; "" = do not save) */
 int mon_offline_object(mon_offline* mgr, int idx, mon_object** borrowed); /* GetAllNeRF()[idx]: owned by the manager, do not destroy; only mon_object_copy_mesh(try_lock) is safe while its thread trains */
 int mon_offline_destroy(mon_offline* mgr);
@@ -236,6 +238,9 @@ int mon_online_destroy(mon_online* mgr);
  * pixels may be NULL to query the header only. */
 int mon_png_read(const char* path, int* width, int* height, int* channels, int* bit_depth, uint8_t* pixels, size_t capacity);
 int mon_png_write(const char* path, int width, int height, int channels, int bit_depth, const uint8_t* pixels_big_endian);
+/* A rendered crop as the reference stores it (nerf.cu:335-349: img.convertTo(CV_8UC3, 255), depth.convertTo(CV_16UC1, 20000), mask.convertTo(CV_8UC1, 255); saturating,
+ * round half to even); mask / mask_path may be NULL (RenderVideo writes none). */
+int mon_write_render_pngs(const char* img_path, const char* depth_path, const char* mask_path, uint32_t w, uint32_t h, const float* rgb, const float* depth, const float* mask);
 
 /* Process-wide test and tuning switches (none is needed for normal operation; defaults are the product behaviour).  Read when an object is
  * created or a training call is enqueued -- set them before.  Names: "backend" (-1 auto, 0 layer-at-a-time kernels, 1 fused), "use_graph" (replay

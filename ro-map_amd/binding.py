@@ -111,6 +111,9 @@ _SIGS = {
     "mon_online_destroy": (C.c_int, [C.c_void_p]),
     "mon_png_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
     "mon_png_write": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mon_write_render_pngs": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mon_physical_device": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "mon_offline_object_stamp": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_char_p, C.c_size_t]),
     "mon_device_synchronize": (C.c_int, [C.c_int]),
 }
 
@@ -132,6 +135,81 @@ _DIAG_SIGS = {
 
 def exported_symbols():
     return sorted(_SIGS)
+
+
+# libmon_core_rccl.so (include/mon_core_rccl.h): the in-process gather-to-root over RCCL
+_RCCL_SIGS = {
+    "mon_gather_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "mon_gather_destroy": (C.c_int, [C.c_void_p]),
+    "mon_gather_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mon_gather_renders": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mon_gather_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "mon_offline_render_test_gathered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]),
+}
+_rccl_lib = None
+
+
+def rccl_symbols():
+    return sorted(_RCCL_SIGS)
+
+
+def rccl_lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmon_core_rccl.so")
+
+
+def rccl_lib():
+    """libmon_core_rccl.so next to libmon_core.so (the core is loaded first: the gather library resolves its symbols against it)."""
+    global _rccl_lib
+    if _rccl_lib is None:
+        lib()
+        L = C.CDLL(rccl_lib_path(), mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _RCCL_SIGS.items():
+            f = getattr(L, name); f.restype = res; f.argtypes = args
+        _rccl_lib = L
+    return _rccl_lib
+
+
+def gather_plan(object_device, n_pix, n_devices):
+    d = np.ascontiguousarray(object_device, np.int32); p = np.ascontiguousarray(n_pix, np.uint32)
+    per = np.zeros(n_devices, np.uint64); off = np.zeros(len(d), np.uint64)
+    rc = rccl_lib().mon_gather_plan(_p(d), _p(p), len(d), int(n_devices), _p(per), _p(off))
+    if rc:
+        raise MonError(rc, "mon_gather_plan failed")
+    return per, off
+
+
+class Gather:
+    """mon_gather: single-process RCCL communicator over the visible devices + the gather-to-root of rendered crops."""
+
+    def __init__(self, root_device=0):
+        self.h = C.c_void_p()
+        rc = rccl_lib().mon_gather_create(int(root_device), C.byref(self.h))
+        if rc:
+            raise MonError(rc, "mon_gather_create failed (see stderr)")
+
+    def renders(self, objects, boxes, poses16, pose_is_Toc=False):
+        n = len(objects); b = np.ascontiguousarray(boxes, np.uint32).reshape(n, 5); T = np.ascontiguousarray(poses16, np.float32).reshape(n, 16)
+        oh = (C.c_void_p * n)(*[o.h for o in objects])
+        rgb = [np.empty((int(q[3]), int(q[4]), 3), np.float32) for q in b]; dep = [np.empty((int(q[3]), int(q[4])), np.float32) for q in b]; msk = [np.empty_like(d) for d in dep]
+        pr = (C.c_void_p * n)(*[a.ctypes.data for a in rgb]); pd = (C.c_void_p * n)(*[a.ctypes.data for a in dep]); pm = (C.c_void_p * n)(*[a.ctypes.data for a in msk])
+        rc = rccl_lib().mon_gather_renders(self.h, oh, _p(b), _p(T), int(pose_is_Toc), n, pr, pd, pm)
+        if rc:
+            raise MonError(rc, "mon_gather_renders failed (see stderr)")
+        return list(zip(rgb, dep, msk))
+
+    def stats(self):
+        a = C.c_uint64(0); b = C.c_uint64(0); s = C.c_int(0); ms = C.c_double(0)
+        rccl_lib().mon_gather_stats(self.h, C.byref(a), C.byref(b), C.byref(s), C.byref(ms))
+        return dict(bytes_over_links=a.value, bytes_on_root=b.value, sending_devices=s.value, transfer_ms=ms.value)
+
+    def offline_render_test(self, manager, out_dir, max_views=0):
+        rc = rccl_lib().mon_offline_render_test_gathered(self.h, manager.h, out_dir.encode(), int(max_views))
+        if rc:
+            raise MonError(rc, "mon_offline_render_test_gathered failed (see stderr)")
+
+    def close(self):
+        if self.h:
+            rccl_lib().mon_gather_destroy(self.h); self.h = C.c_void_p()
 
 
 def diag_symbols():

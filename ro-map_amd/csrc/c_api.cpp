@@ -7,6 +7,7 @@ namespace mon {
 void set_error(const char* fmt, ...);
 const char* last_error();
 int device_count(int* n);
+int physical_device(int logical, int* phys_out);
 void config_default(mon_config& c);
 int config_from_json(const char* path, mon_config& c);
 int dataset_create(int device, int H, int W, float fx, float fy, float cx, float cy, uint32_t max_frames, int use_depth, Dataset** out);
@@ -111,6 +112,7 @@ int mon_object_get_profile(mon_object* o, mon_profile* out, int reset) {
 }
 int mon_object_destroy(mon_object* o) { if (!o) return MON_OK; model_destroy(o->m); delete o; return MON_OK; }
 
+int mon_physical_device(int logical_device, int* physical_device) { return mon::physical_device(logical_device, physical_device); }
 int mon_device_synchronize(int device) {
     if (use_device(device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { set_error("device synchronize failed"); return MON_ERR_HIP; }
     return MON_OK;

@@ -457,6 +457,16 @@ int mon_offline_object_meta(mon_offline* h, int idx, int* class_id, float* Tow16
     if (boxes) { if (capacity_boxes < o->boxes.size()) { set_error("object_meta: buffer holds %zu of %zu boxes", capacity_boxes, o->boxes.size()); return MON_ERR_ARG; } std::memcpy(boxes, o->boxes.data(), o->boxes.size() * sizeof(mon_frame_bbox)); }
     return MON_OK;
 }
+int mon_offline_object_stamp(mon_offline* h, int idx, size_t box_index, char* buf, size_t capacity) {
+    REQ(h); REQ(buf); if (idx < 0 || idx >= (int)h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
+    OfflineObject* o = h->m->objs[idx];
+    if (box_index >= o->stamps.size() || capacity < o->stamps[box_index].size() + 1) { set_error("object_stamp: box index or buffer size"); return MON_ERR_ARG; }
+    std::memcpy(buf, o->stamps[box_index].c_str(), o->stamps[box_index].size() + 1); return MON_OK;
+}
+int mon_write_render_pngs(const char* img_path, const char* depth_path, const char* mask_path, uint32_t w, uint32_t h, const float* rgb, const float* depth, const float* mask) {
+    if (!img_path || !depth_path || !rgb || !depth || (mask && !mask_path) || !w || !h) { set_error("write_render_pngs: bad argument"); return MON_ERR_ARG; }
+    return write_render_pngs(img_path, depth_path, mask_path ? mask_path : "", w, h, rgb, depth, mask);
+}
 int mon_offline_set_output_dir(mon_offline* h, const char* dir) { REQ(h); h->m->mesh_dir = dir ? dir : ""; return MON_OK; }
 int mon_offline_object(mon_offline* h, int idx, mon_object** borrowed) { REQ(h); REQ(borrowed); if (idx < 0 || idx >= (int)h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *borrowed = &h->m->objs[idx]->handle; return MON_OK; }
 int mon_offline_destroy(mon_offline* h) { if (!h) return MON_OK; offline_destroy(h->m); delete h; return MON_OK; }

@@ -64,6 +64,11 @@ hipError_t use_device(int logical) {
     const int n = g_logical_devices.load(); if (logical < 0 || logical >= (n > 0 ? n : phys)) return hipErrorInvalidDevice;
     return hipSetDevice(logical % phys);
 }
+int physical_device(int logical, int* phys_out) {
+    const int phys = physical_count(); const int n = g_logical_devices.load();
+    if (phys < 1 || logical < 0 || logical >= (n > 0 ? n : phys) || !phys_out) { set_error("physical_device: no such logical device %d", logical); return MON_ERR_ARG; }
+    *phys_out = logical % phys; return MON_OK;
+}
 int set_logical_devices(int n) {
     if (n < 0 || n > 64) { set_error("set_logical_devices: 0 (= the physical devices) .. 64"); return MON_ERR_ARG; }
     g_logical_devices.store(n); return MON_OK;

@@ -1,0 +1,106 @@
+"""libmon_core_rccl.so (include/mon_core_rccl.h): the gather-to-root of final renders over RCCL inside ONE process whose objects sit on several devices
+(single-process communicator, grouped ncclSend / ncclRecv of the true sizes).  CPU: the exported surface and the message bookkeeping.
+GPU (one device on the box: the communicator has one rank, every message is already on the root): crops equal to mon_object_render's bit for bit, and
+OfflineNeRF's test images through the gather equal to the per-object writer's byte for byte.  Transfers between devices need an N > 1 node (the driver's)."""
+import ctypes
+import filecmp
+import os
+import re
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from conftest import ROOT
+
+
+def _header_symbols(name):
+    text = open(os.path.join(ROOT, "include", name)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mon_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_gather_library_exports_its_header_and_keeps_rccl_out_of_the_core(pkg):
+    import subprocess
+    syms = _header_symbols("mon_core_rccl.h")
+    assert sorted(pkg.rccl_symbols()) == syms and len(syms) >= 5
+    assert os.path.exists(pkg.rccl_lib_path()), "run __graft_entry__.build() first"
+    L = pkg.rccl_lib()
+    for s in syms:
+        assert hasattr(L, s), "libmon_core_rccl.so does not export " + s
+    core = ctypes.CDLL(pkg.lib_path())
+    assert not any(hasattr(core, s) for s in syms)
+    needed = subprocess.run(["readelf", "-d", pkg.lib_path()], capture_output=True, text=True).stdout
+    assert "rccl" not in needed                                                     # the product library does not depend on RCCL
+    needed = subprocess.run(["readelf", "-d", pkg.rccl_lib_path()], capture_output=True, text=True).stdout
+    assert "librccl" in needed and "libmon_core.so" in needed
+
+
+def test_gather_plan_packs_one_message_per_device(pkg):
+    """Eight objects placed k mod 4 (CORE/src/nerf.cu:27-33) with crops of different sizes: one message per device, crops back to back in object order."""
+    dev = [k % 4 for k in range(8)]; npx = [64 * 64, 100, 313 * 229, 1, 7, 640 * 480, 50, 33]
+    per, off = pkg.gather_plan(dev, npx, 4)
+    assert per.tolist() == [5 * (npx[0] + npx[4]), 5 * (npx[1] + npx[5]), 5 * (npx[2] + npx[6]), 5 * (npx[3] + npx[7])]
+    assert off.tolist() == [0, 0, 0, 0, 5 * npx[0], 5 * npx[1], 5 * npx[2], 5 * npx[3]]
+    per, off = pkg.gather_plan([], [], 3); assert per.tolist() == [0, 0, 0] and off.size == 0
+    with pytest.raises(pkg.MonError):
+        pkg.gather_plan([0, 5], [1, 1], 4)                                           # a device the communicator does not have
+
+
+@pytest.mark.gpu
+def test_gathered_crops_equal_the_objects_own_renders(pkg, ss):
+    assert pkg.device_count() >= 1
+    sc = ss.make_scene(n_views=12, H=120, W=160, f=130.0, n_objects=3, seed=4)
+    ds, o0 = ge.make_problem(pkg, sc, dict(rays_per_batch=1024)); objs = [o0]
+    for k in (1, 2):
+        objs.append(ge.make_problem(pkg, sc, dict(rays_per_batch=1024, sample_seed=50 + k), obj_index=k, dataset=ds)[1])
+    for o in objs:
+        o.train(120)
+    g = pkg.Gather(0)
+    boxes = [sc.objects[k]["boxes"][2] for k in range(3)]; boxes[1] = np.array([int(boxes[1][0]), 0, 0, sc.H, sc.W], np.uint32)      # one whole frame among the crops
+    poses = [ss.colmajor(sc.Twc[int(b[0])]) for b in boxes]
+    got = g.renders(objs, boxes, poses)
+    for o, b, T, (rgb, dep, msk) in zip(objs, boxes, poses, got):
+        r2, d2, m2 = o.render(b, T)
+        assert np.array_equal(rgb, r2) and np.array_equal(dep, d2) and np.array_equal(msk, m2) and m2.mean() > 0.01
+    st = g.stats()
+    n_dev = pkg.device_count()
+    assert st["bytes_over_links"] + st["bytes_on_root"] == 20 * sum(int(b[3]) * int(b[4]) for b in boxes)
+    if n_dev == 1:
+        assert st["bytes_over_links"] == 0 and st["sending_devices"] == 0
+    got2 = g.renders(objs[:1], boxes[:1], poses[:1])                                 # a smaller call after a larger one (buffers are grow-only)
+    assert np.array_equal(got2[0][0], got[0][0])
+    g.close()
+    for o in objs:
+        o.close()
+    ds.close()
+
+
+@pytest.mark.gpu
+def test_offline_test_images_through_the_gather_are_the_same_files(pkg, ss, tmp_path):
+    """mon_offline_render_test_gathered against mon_offline_render_test on a 3-object sequence: same directory tree, same PNG bytes."""
+    assert pkg.device_count() >= 1
+    sc = ss.make_scene(n_views=8, H=120, W=160, f=130.0, n_objects=3, seed=6)
+    seq = str(tmp_path / "seq"); ss.write_sequence(sc, seq)
+    pkg.set_option("offline_outer", 1); pkg.set_option("offline_inner", 100)
+    try:
+        m = pkg.OfflineManager(seq, os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json")); m.init(); m.read_dataset()
+    finally:
+        pkg.set_option("offline_outer", 10); pkg.set_option("offline_inner", 500)
+    m.set_output_dir("")
+    for k in range(3):
+        m.create_nerf(os.path.join(seq, "obj_offline", "%d.txt" % k))
+    m.wait_threads_end()
+    a, b = str(tmp_path / "per_object"), str(tmp_path / "gathered")
+    for k in range(3):
+        m.render_test(k, a, 3)
+    g = pkg.Gather(0); g.offline_render_test(m, b, 3); g.close()
+    n = 0
+    for k in range(3):
+        for sub in ("test_img", "test_depth", "test_mask"):
+            fa = sorted(os.listdir(os.path.join(a, str(k), sub))); fb = sorted(os.listdir(os.path.join(b, str(k), sub)))
+            assert fa == fb and len(fa) == 3
+            for f in fa:
+                assert filecmp.cmp(os.path.join(a, str(k), sub, f), os.path.join(b, str(k), sub, f), shallow=False), (k, sub, f); n += 1
+    assert n == 27
+    m.close()
