@@ -22,6 +22,13 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
     model_leave_lane(m);
     if (which == MON_BUF_EMA) { int rc = ensure_ema_current(m); if (rc) return rc; }
     const size_t R = m.oc.R, B = R * m.oc.S, n = m.n_params; const void* src = nullptr; size_t sz = 0;
+    if (m.P.rec && (which == MON_BUF_MASTER || which == MON_BUF_M1 || which == MON_BUF_M2 || which == MON_BUF_STEPS)) {      // optimizer state kept as chunk records
+        if (!dst || bytes < n * 4) { set_error("debug_read: buffer too small"); return MON_ERR_ARG; }
+        HIPCHECK(use_device(m.device)); void* tmp = nullptr; HIPCHECK(hipMalloc(&tmp, n * 4));
+        launch_state_unpack(m.train_stream, m.P.rec, which == MON_BUF_MASTER ? 0 : which == MON_BUF_M1 ? 1 : which == MON_BUF_M2 ? 2 : 3, tmp, (uint32_t)n);
+        hipError_t e = hipStreamSynchronize(m.train_stream); if (e == hipSuccess) e = hipMemcpy(dst, tmp, n * 4, hipMemcpyDeviceToHost);
+        (void)hipFree(tmp); HIPCHECK(e); return MON_OK;
+    }
     switch (which) {
         case MON_BUF_MASTER: src = m.P.master; sz = n * 4; break;       case MON_BUF_HALF: src = m.P.half; sz = n * 2; break;
         case MON_BUF_EMA: src = m.P.ema; sz = n * 2; break;             case MON_BUF_M1: src = m.P.m1; sz = n * 4; break;

@@ -22,11 +22,14 @@
 
 namespace mon {
 
-template <class T> __device__ __forceinline__ void state_store(T v, T* p) {
+// Optimizer state is not read again before the next step.  Small tables (everything streamed once per step, working set inside the Infinity Cache): non-temporal
+// stores, a wash against plain ones (round 2).  LARGE tables (T = 2^22: 2-3 GB of scattered 32-byte pieces per step, HBM-bound): plain stores -- the L2 merges a
+// chunk's pieces into whole lines before they leave; non-temporal ones cost 20 % of the kernel there (645-725 us against 535-550 us over steps 20..40, four runs each).
+template <bool NT, class T> __device__ __forceinline__ void state_store(T v, T* p) {
 #ifdef MON_OPT_PLAIN_STORES
     *p = v;
 #else
-    __builtin_nontemporal_store(v, p);
+    if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
 #endif
 }
 
@@ -62,18 +65,24 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
     const uint32_t n_extra = nx.cand_blocks + nx.pos_blocks, n_opt = gridDim.x - n_extra, vblock = blockIdx.x < n_opt ? blockIdx.x + n_extra : blockIdx.x - n_opt;
 #endif
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const uint32_t step_cap = p.steps16 ? 65535u : 0xffffffffu;
+    const uint32_t step_cap = (p.steps16 || p.rec) ? 65535u : 0xffffffffu;
+    // where a chunk's optimizer state lives: the four SoA arrays, or (large tables, ParamPtrs::rec) ONE 128-byte record per chunk -- master | m1 | m2 | step counters --
+    // so that a touched chunk among untouched ones costs one full line instead of four half-used 64-byte sectors
+    auto st_master = [&](uint32_t c) -> float* { return p.rec ? p.rec + 32u * (size_t)c : p.master + 8u * (size_t)c; };
+    auto st_m1 = [&](uint32_t c) -> float* { return p.rec ? p.rec + 32u * (size_t)c + 8u : p.m1 + 8u * (size_t)c; };
+    auto st_m2 = [&](uint32_t c) -> float* { return p.rec ? p.rec + 32u * (size_t)c + 16u : p.m2 + 8u * (size_t)c; };
+    auto st_steps16 = [&](uint32_t c) -> uint16_t* { return p.rec ? reinterpret_cast<uint16_t*>(p.rec + 32u * (size_t)c + 24u) : p.steps16 + 8u * (size_t)c; };
     // a chunk's eight step counters: two 16-byte loads of uint32, or ONE of eight uint16 (4 B per parameter less to read and to write back)
     auto load_steps = [&](uint32_t i0, u32x4& s0, u32x4& s1) __attribute__((always_inline)) {
-        if (p.steps16) { const u32x4 v = *reinterpret_cast<const u32x4*>(p.steps16 + i0); s0 = u32x4{ v[0] & 0xffffu, v[0] >> 16, v[1] & 0xffffu, v[1] >> 16 }; s1 = u32x4{ v[2] & 0xffffu, v[2] >> 16, v[3] & 0xffffu, v[3] >> 16 }; }
+        if (p.steps16 || p.rec) { const u32x4 v = *reinterpret_cast<const u32x4*>(st_steps16(i0 >> 3)); s0 = u32x4{ v[0] & 0xffffu, v[0] >> 16, v[1] & 0xffffu, v[1] >> 16 }; s1 = u32x4{ v[2] & 0xffffu, v[2] >> 16, v[3] & 0xffffu, v[3] >> 16 }; }
         else { s0 = *reinterpret_cast<const u32x4*>(p.steps + i0); s1 = *reinterpret_cast<const u32x4*>(p.steps + i0 + 4); }
     };
     struct Pre { float4_t w0, w1, a0, a1, b0, b1; u32x4 s0, s1; half8_t e; float4_t gm0, gm1; };      // (plain vector types and no arrays: HIP's uint4 is a union, and either keeps the struct in scratch memory)
     auto issue = [&](uint32_t c, Pre& L) __attribute__((always_inline)) {
         const uint32_t i0 = c << 3;
-        L.w0 = *reinterpret_cast<const float4_t*>(p.master + i0); L.w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
-        L.a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0); L.a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
-        L.b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); L.b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
+        L.w0 = *reinterpret_cast<const float4_t*>(st_master(c)); L.w1 = *reinterpret_cast<const float4_t*>(st_master(c) + 4);
+        L.a0 = *reinterpret_cast<const float4_t*>(st_m1(c)); L.a1 = *reinterpret_cast<const float4_t*>(st_m1(c) + 4);
+        L.b0 = *reinterpret_cast<const float4_t*>(st_m2(c)); L.b1 = *reinterpret_cast<const float4_t*>(st_m2(c) + 4);
         load_steps(i0, L.s0, L.s1);
         L.e = *reinterpret_cast<const half8_t*>(p.ema + i0);
         if (i0 < oc.n_mlp) { L.gm0 = *reinterpret_cast<const float4_t*>(p.gmlp + i0); L.gm1 = *reinterpret_cast<const float4_t*>(p.gmlp + i0 + 4); }
@@ -155,9 +164,9 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
             float4_t w0, w1, a0, a1, b0, b1; uint4 s0, s1;
             if (L) { w0 = L->w0; w1 = L->w1; a0 = L->a0; a1 = L->a1; b0 = L->b0; b1 = L->b1; s0 = uint4{ L->s0[0], L->s0[1], L->s0[2], L->s0[3] }; s1 = uint4{ L->s1[0], L->s1[1], L->s1[2], L->s1[3] }; }
             else if (eager) {
-                w0 = *reinterpret_cast<const float4_t*>(p.master + i0); w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
-                a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0); a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
-                b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
+                w0 = *reinterpret_cast<const float4_t*>(st_master(c)); w1 = *reinterpret_cast<const float4_t*>(st_master(c) + 4);
+                a0 = *reinterpret_cast<const float4_t*>(st_m1(c)); a1 = *reinterpret_cast<const float4_t*>(st_m1(c) + 4);
+                b0 = *reinterpret_cast<const float4_t*>(st_m2(c)); b1 = *reinterpret_cast<const float4_t*>(st_m2(c) + 4);
                 { u32x4 t0, t1; load_steps(i0, t0, t1); s0 = uint4{ t0[0], t0[1], t0[2], t0[3] }; s1 = uint4{ t1[0], t1[1], t1[2], t1[3] }; }
             }
             const bool lazy_chunk = LAZY && !is_matrix;
@@ -240,9 +249,9 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
             }
             if (any) {
                 if (!eager) {
-                    w0 = *reinterpret_cast<const float4_t*>(p.master + i0); w1 = *reinterpret_cast<const float4_t*>(p.master + i0 + 4);
-                    a0 = *reinterpret_cast<const float4_t*>(p.m1 + i0); a1 = *reinterpret_cast<const float4_t*>(p.m1 + i0 + 4);
-                    b0 = *reinterpret_cast<const float4_t*>(p.m2 + i0); b1 = *reinterpret_cast<const float4_t*>(p.m2 + i0 + 4);
+                    w0 = *reinterpret_cast<const float4_t*>(st_master(c)); w1 = *reinterpret_cast<const float4_t*>(st_master(c) + 4);
+                    a0 = *reinterpret_cast<const float4_t*>(st_m1(c)); a1 = *reinterpret_cast<const float4_t*>(st_m1(c) + 4);
+                    b0 = *reinterpret_cast<const float4_t*>(st_m2(c)); b1 = *reinterpret_cast<const float4_t*>(st_m2(c) + 4);
                     { u32x4 t0, t1; load_steps(i0, t0, t1); s0 = uint4{ t0[0], t0[1], t0[2], t0[3] }; s1 = uint4{ t1[0], t1[1], t1[2], t1[3] }; }
                 }
                 float w[8] = { w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3] };
@@ -262,12 +271,12 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                     wh[j] = (half_t)w[j];
                 }
                 // optimizer state is not touched again before the next step: stream it past the caches
-                state_store(float4_t{ w[0], w[1], w[2], w[3] }, reinterpret_cast<float4_t*>(p.master + i0)); state_store(float4_t{ w[4], w[5], w[6], w[7] }, reinterpret_cast<float4_t*>(p.master + i0 + 4));
-                state_store(float4_t{ m1[0], m1[1], m1[2], m1[3] }, reinterpret_cast<float4_t*>(p.m1 + i0)); state_store(float4_t{ m1[4], m1[5], m1[6], m1[7] }, reinterpret_cast<float4_t*>(p.m1 + i0 + 4));
-                state_store(float4_t{ m2[0], m2[1], m2[2], m2[3] }, reinterpret_cast<float4_t*>(p.m2 + i0)); state_store(float4_t{ m2[4], m2[5], m2[6], m2[7] }, reinterpret_cast<float4_t*>(p.m2 + i0 + 4));
+                state_store<!LAZY>(float4_t{ w[0], w[1], w[2], w[3] }, reinterpret_cast<float4_t*>(st_master(c))); state_store<!LAZY>(float4_t{ w[4], w[5], w[6], w[7] }, reinterpret_cast<float4_t*>(st_master(c) + 4));
+                state_store<!LAZY>(float4_t{ m1[0], m1[1], m1[2], m1[3] }, reinterpret_cast<float4_t*>(st_m1(c))); state_store<!LAZY>(float4_t{ m1[4], m1[5], m1[6], m1[7] }, reinterpret_cast<float4_t*>(st_m1(c) + 4));
+                state_store<!LAZY>(float4_t{ m2[0], m2[1], m2[2], m2[3] }, reinterpret_cast<float4_t*>(st_m2(c))); state_store<!LAZY>(float4_t{ m2[4], m2[5], m2[6], m2[7] }, reinterpret_cast<float4_t*>(st_m2(c) + 4));
                 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-                if (p.steps16) state_store(u4v{ sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16), sc[4] | (sc[5] << 16), sc[6] | (sc[7] << 16) }, reinterpret_cast<u4v*>(p.steps16 + i0));
-                else { state_store(u4v{ sc[0], sc[1], sc[2], sc[3] }, reinterpret_cast<u4v*>(p.steps + i0)); state_store(u4v{ sc[4], sc[5], sc[6], sc[7] }, reinterpret_cast<u4v*>(p.steps + i0 + 4)); }
+                if (p.steps16 || p.rec) state_store<!LAZY>(u4v{ sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16), sc[4] | (sc[5] << 16), sc[6] | (sc[7] << 16) }, reinterpret_cast<u4v*>(st_steps16(c)));
+                else { state_store<!LAZY>(u4v{ sc[0], sc[1], sc[2], sc[3] }, reinterpret_cast<u4v*>(p.steps + i0)); state_store<!LAZY>(u4v{ sc[4], sc[5], sc[6], sc[7] }, reinterpret_cast<u4v*>(p.steps + i0 + 4)); }
                 *reinterpret_cast<half8_t*>(p.half + i0) = wh;
 #if defined(MON_OPT_ABLATE) && (MON_OPT_ABLATE & 8)
                 if (false) {
@@ -437,6 +446,23 @@ void launch_copy_params(hipStream_t s, const uint16_t* src, uint16_t* dst, uint3
     const uint32_t n16 = n / 8u, tail = n - n16 * 8u;
     const uint32_t blocks = n16 >= 512u * 256u ? 512u : (n16 + 255u) / 256u + (n16 == 0u ? 1u : 0u);
     hipLaunchKernelGGL(k_copy_params, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16, src + (size_t)n16 * 8u, dst + (size_t)n16 * 8u, tail);
+}
+// Record layout of the optimizer state (ParamPtrs::rec) <-> the flat arrays the boundary speaks (get / set_params, debug read-back): which = 0 master, 1 m1, 2 m2
+// (floats), 3 the step counters (uint16 widened to uint32 on the way out).
+__global__ void __launch_bounds__(256) k_state_unpack(const float* __restrict__ rec, int which, uint32_t* __restrict__ dst, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float* r = rec + 32u * (size_t)(i >> 3);
+        dst[i] = which < 3 ? __builtin_bit_cast(uint32_t, r[8 * which + (i & 7u)]) : (uint32_t)reinterpret_cast<const uint16_t*>(r + 24)[i & 7u];
+    }
+}
+__global__ void __launch_bounds__(256) k_state_pack_master(const float* __restrict__ master, float* __restrict__ rec, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) rec[32u * (size_t)(i >> 3) + (i & 7u)] = master[i];
+}
+void launch_state_unpack(hipStream_t s, const float* rec, int which, void* dst, uint32_t n) {
+    hipLaunchKernelGGL(k_state_unpack, dim3(2048), dim3(256), 0, s, rec, which, static_cast<uint32_t*>(dst), n);
+}
+void launch_state_pack_master(hipStream_t s, const float* master, float* rec, uint32_t n) {
+    hipLaunchKernelGGL(k_state_pack_master, dim3(2048), dim3(256), 0, s, master, rec, n);
 }
 void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, uint32_t n) {
     hipLaunchKernelGGL(k_master_to_half, dim3(1024), dim3(256), 0, s, master, half, n);

@@ -41,7 +41,7 @@ static std::atomic<long>* option_slot(const char* name) {
         { "touched_flags", &Options::touched_flags },
         { "fused_grid", &Options::fused_grid }, { "lds_encode", &Options::lds_encode }, { "roctx", &Options::roctx }, { "ray_records", &Options::ray_records }, { "step_variant", &Options::step_variant }, { "steps16", &Options::steps16 }, { "encode_ablate", &Options::encode_ablate }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
         { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner }, { "scatter_bins", &Options::scatter_bins }, { "opt_lazy_below", &Options::opt_lazy_below }, { "scatter_ablate", &Options::scatter_ablate },
-        { "tile_render", &Options::tile_render } };
+        { "tile_render", &Options::tile_render }, { "state_records", &Options::state_records } };
     for (const auto& e : tab) if (name && std::strcmp(name, e.n) == 0) return &(g_options.*(e.f));
     return nullptr;
 }
@@ -393,6 +393,19 @@ template <class T> static int dev_alloc(Model& m, T*& p, size_t n, bool zero = t
 
 static constexpr uint32_t kRenderChunkRays = 16384;   // rays per render pass (x 2S samples)
 
+// fp32 master weights from the host into the model (the arrays, or the chunk records through a staging buffer) + the fp16 working copy h(master)
+static int upload_master(Model& m, const float* master) {
+    const size_t n = m.n_params;
+    if (!m.P.rec) {
+        HIPCHECK(hipMemcpy(m.P.master, master, n * 4, hipMemcpyHostToDevice));
+        launch_master_to_half(m.train_stream, m.P.master, m.P.half, (uint32_t)n);        // h(master), same rounding as every later update
+        return MON_OK;
+    }
+    float* tmp = nullptr; HIPCHECK(hipMalloc((void**)&tmp, n * 4));
+    hipError_t e = hipMemcpy(tmp, master, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) { launch_state_pack_master(m.train_stream, tmp, m.P.rec, (uint32_t)n); launch_master_to_half(m.train_stream, tmp, m.P.half, (uint32_t)n); e = hipStreamSynchronize(m.train_stream); }
+    (void)hipFree(tmp); HIPCHECK(e); return MON_OK;
+}
 MeshState* mesh_state_create(int device);
 static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id, const float* Tow, const float* amin, const float* amax) {
     m.ds = ds; m.cfg = cfg; m.device = ds->device;
@@ -423,13 +436,19 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     // margin of four binades (beta^65535 < 2^-29, i.e. beta <= 0.99969) instead of sitting on the rounding boundary.
     const double kSteps16Bound = std::ldexp(1.0, -29);
     const bool steps16 = options().steps16 != 0 && std::pow((double)cfg.beta1, 65535.0) < kSteps16Bound && std::pow((double)cfg.beta2, 65535.0) < kSteps16Bound;
-    if ((rc = dev_alloc(m, m.P.master, n, false)) || (rc = dev_alloc(m, m.P.half, n, false)) || (rc = dev_alloc(m, m.P.ema, n)) ||
-        (rc = dev_alloc(m, m.P.m1, n)) || (rc = dev_alloc(m, m.P.m2, n)) || (rc = steps16 ? dev_alloc(m, m.P.steps16, n + 8) : dev_alloc(m, m.P.steps, n)) || (rc = dev_alloc(m, m.d_ema_step, n / 8 + 1)) ||
+    // lazy EMA: only where the optimizer is not the dense variant anyway and the table is large (> 8 M parameters); option lazy_ema = 0 / 1 overrides
+    m.lazy_ema = m.n_grid > (8u << 20);
+    if (options().lazy_ema >= 0) m.lazy_ema = options().lazy_ema != 0;
+    // large tables (lazy EMA, 16-bit step counters): the optimizer state as one 128-byte record per chunk (ParamPtrs::rec) instead of four arrays
+    const bool records = m.lazy_ema && steps16 && options().state_records != 0 && (n & 7u) == 0u;
+    if (records) { if ((rc = dev_alloc(m, m.P.rec, 4 * n))) return rc; }
+    else if ((rc = dev_alloc(m, m.P.master, n, false)) || (rc = dev_alloc(m, m.P.m1, n)) || (rc = dev_alloc(m, m.P.m2, n)) ||
+             (rc = steps16 ? dev_alloc(m, m.P.steps16, n + 8) : dev_alloc(m, m.P.steps, n))) return rc;
+    if ((rc = dev_alloc(m, m.P.half, n, false)) || (rc = dev_alloc(m, m.P.ema, n)) || (rc = dev_alloc(m, m.d_ema_step, n / 8 + 1)) ||
         (rc = dev_alloc(m, m.P.gmlp, m.nd.n_mlp)) || (rc = dev_alloc(m, m.P.ggrid, m.n_grid))) return rc;
     {
         std::vector<float> master; init_params_host(cfg, m.nd, m.n_params, master);
-        HIPCHECK(hipMemcpy(m.P.master, master.data(), n * 4, hipMemcpyHostToDevice));
-        launch_master_to_half(m.train_stream, m.P.master, m.P.half, (uint32_t)n);        // h(master), same rounding as every later update
+        const int urc = upload_master(m, master.data()); if (urc) return urc;
     }
     // ---- workspace (AllocateBatchWorkspace :1344-1427), sized for max(train batch, render chunk)
     const uint32_t R = m.oc.R, S = m.oc.S;
@@ -461,9 +480,6 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         m.d_xw_states = d_a; m.d_xw_render_states = d_b; m.d_xw_render_init = d_c;
         m.oc.xw[0] = m.d_xw; m.oc.xw[1] = m.d_xw + (size_t)(5 + S) * R;
     }
-    // lazy EMA: only where the optimizer is not the dense variant anyway and the table is large (> 8 M parameters); MON_LAZY_EMA=0/1 overrides
-    m.lazy_ema = m.n_grid > (8u << 20);
-    if (options().lazy_ema >= 0) m.lazy_ema = options().lazy_ema != 0;
     if (fused_supported(m.nd, S, m.oc.R)) {
         if ((rc = dev_alloc(m, m.d_frag_train, 64 * 512)) || (rc = dev_alloc(m, m.d_frag_render, 64 * 512))) return rc;       // <= 30 fragments of 512 halves
         m.lds_mask = scatter_plan(m.lt, m.nd, m.scatter);
@@ -989,6 +1005,14 @@ int model_density_grid(Model& m, int rx, int ry, int rz, float* out_host) {
 
 int model_get_params(Model& m, int which, void* dst, size_t bytes) {
     const void* src = nullptr; size_t need = 0;
+    if (which == 0 && m.P.rec) {                             // chunk records: the master weights through a staging buffer
+        if (!dst || bytes < (size_t)m.n_params * 4) { set_error("get_params: buffer too small"); return MON_ERR_ARG; }
+        HIPCHECK(use_device(m.device)); model_leave_lane(m);
+        float* tmp = nullptr; HIPCHECK(hipMalloc((void**)&tmp, (size_t)m.n_params * 4));
+        launch_state_unpack(m.train_stream, m.P.rec, 0, tmp, m.n_params);
+        hipError_t e = hipStreamSynchronize(m.train_stream); if (e == hipSuccess) e = hipMemcpy(dst, tmp, (size_t)m.n_params * 4, hipMemcpyDeviceToHost);
+        (void)hipFree(tmp); HIPCHECK(e); return MON_OK;
+    }
     switch (which) { case 0: src = m.P.master; need = (size_t)m.n_params * 4; break; case 1: src = m.P.half; need = (size_t)m.n_params * 2; break;
                      case 2: src = m.P.ema; need = (size_t)m.n_params * 2; break; default: set_error("get_params: which must be 0..2"); return MON_ERR_ARG; }
     if (!dst || bytes < need) { set_error("get_params: buffer too small (%zu < %zu)", bytes, need); return MON_ERR_ARG; }
@@ -1000,8 +1024,7 @@ int model_get_params(Model& m, int which, void* dst, size_t bytes) {
 int model_set_params(Model& m, const float* master, size_t n) {
     if (!master || n != m.n_params) { set_error("set_params: expected %u values", m.n_params); return MON_ERR_ARG; }
     HIPCHECK(use_device(m.device)); model_leave_lane(m); HIPCHECK(hipStreamSynchronize(m.train_stream));
-    HIPCHECK(hipMemcpy(m.P.master, master, n * 4, hipMemcpyHostToDevice));
-    launch_master_to_half(m.train_stream, m.P.master, m.P.half, (uint32_t)n);
+    { const int urc = upload_master(m, master); if (urc) return urc; }
     HIPCHECK(hipStreamSynchronize(m.train_stream));
     m.next_ready = false;                                   // the fragment image no longer matches the weights
     m.weights_epoch = next_weights_epoch();

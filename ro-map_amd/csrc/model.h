@@ -85,6 +85,9 @@ struct ParamPtrs {
     float* master; uint16_t* half; uint16_t* ema; float* m1; float* m2; uint32_t* steps;
     uint16_t* steps16;      // the per-parameter step counters as SATURATING 16-bit values (steps == nullptr then): exact whenever beta^65535 < 2^-25 for both betas -- the bias
                             // correction 1 - beta^t is then exactly 1.0f for every t the counter can no longer tell apart (beta <= 0.99973; base.json: 0.9 / 0.99)
+    float* rec;         // large tables (lazy EMA): the optimizer state as ONE 128-byte record per 8-parameter chunk -- master[8] | m1[8] | m2[8] | 8 x uint16 step counters | pad --
+                        // instead of the four arrays above (which are null then): late in training a few per cent of the chunks are touched, and a touched chunk among
+                        // untouched ones is then one full line, not four half-used 64-byte sectors.  nullptr = the arrays (small tables: every chunk is streamed anyway)
     float* gmlp;        // fp32 dW [n_mlp]
     uint16_t* ggrid;    // fp16 grid gradient [n_grid], accumulated with global_atomic_pk_add_f16
     const uint16_t* gpart; uint32_t part_stride;                    // fused backend: dense fp16 partial gradient tables from k_grid_scatter (stride in halves); nullptr = unused
@@ -131,6 +134,7 @@ struct Options {      // (atomics: tests and tools flip options while object thr
     std::atomic<long> backend{ -1 }, use_graph{ 0 }, lazy_ema{ -1 }, big_switch{ 16384 }, touched_flags{ 1 },
          fused_grid{ 0 }, lds_encode{ 1 }, encode_ablate{ 0 }, opt_blocks{ 0 }, fused_ablate{ 0 }, fused_stagger{ -1 }, offline_outer{ 10 }, offline_inner{ 500 }, scatter_bins{ 0 }, opt_lazy_below{ -1 },
          scatter_ablate{ 0 }, train_lanes{ 2 }, lane_chunk{ 16 }, online_slice_min{ 2 }, roctx{ 0 }, ray_records{ 1 }, step_variant{ 0 }, steps16{ 1 },
+         state_records{ 1 },    // tables above 8 M parameters keep their optimizer state as 128-byte chunk records (ParamPtrs::rec); 0: the four arrays
          tile_render{ 1 };      // inference on feature-planar level tiles: 0 never (gathers), 1 crops of 4096 rays and more + point queries, 2 always
 };
 Options& options();
@@ -159,6 +163,8 @@ void launch_composite_grad(hipStream_t s, const BatchPtrs& b, const ObjectConst&
 void launch_composite_render(hipStream_t s, const BatchPtrs& b, uint32_t S, uint32_t n_rays, float* rgb, float* depth, float* mask);
 void launch_extract_density(hipStream_t s, const uint16_t* O, float* out, uint32_t n);
 void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, uint32_t n);
+void launch_state_unpack(hipStream_t s, const float* rec, int which, void* dst, uint32_t n);      // ParamPtrs::rec -> a flat array (0 master, 1 m1, 2 m2, 3 step counters as uint32)
+void launch_state_pack_master(hipStream_t s, const float* master, float* rec, uint32_t n);
 void launch_copy_params(hipStream_t s, const uint16_t* src, uint16_t* dst, uint32_t n);
 void model_leave_lane(struct Model& m);      // non-training work goes to the object's own stream (model.cpp, training lanes)
 void launch_pack_frame(hipStream_t s, const uint8_t* rgb, int ch, int ri, int bi, const uint8_t* inst, uint32_t* dst, uint32_t px);      // host (pinned) images -> packed RGBA8 | instance << 24

@@ -722,6 +722,31 @@ def test_lazy_ema_matches_eager_on_large_tables(pkg, small_scene):
     obj.close(); ds.close()
 
 
+def test_optimizer_state_records_train_exactly_like_the_arrays(pkg, small_scene):
+    """Tables above 8 M parameters keep master / m1 / m2 / step counters as one 128-byte record per 8-parameter chunk (ParamPtrs::rec) instead of four arrays
+    (option state_records = 0): a layout change only.  With the binned large-level scatter (deterministic) both must leave bit-identical weights, Adam
+    moments, step counters and EMA, also through set_params / get_params, which translate between the records and the flat arrays of the boundary."""
+    _need_gpu(pkg)
+    import zlib
+    kw = dict(rays_per_batch=1024, log2_hashmap_size=20, n_levels=8, per_level_scale=2.0, n_neurons=32, n_hidden_layers=2)
+    res = []
+    old_bs = pkg.get_option("big_switch"); pkg.set_option("big_switch", 1)        # always binned: no global-atomic arrival order in the comparison
+    try:
+        for rec in (1, 0):
+            pkg.set_option("state_records", rec)
+            ds, obj = ge.make_problem(pkg, small_scene, kw); obj.set_backend(1)
+            assert obj.info().n_grid_params > (8 << 20)
+            p0 = obj.get_params(0); p0[obj.info().n_mlp_params::7] *= 1.5; obj.set_params(p0)      # through the boundary once
+            assert np.array_equal(obj.get_params(0), p0)
+            obj.train(12)
+            res.append([zlib.crc32(obj.get_params(w).tobytes()) for w in (0, 1, 2)] + [zlib.crc32(obj.buffer(b).tobytes()) for b in ("m1", "m2", "steps")])
+            assert np.array_equal(obj.buffer("master"), obj.get_params(0)) and int(obj.buffer("steps").max()) >= 1
+            obj.close(); ds.close()
+    finally:
+        pkg.set_option("state_records", 1); pkg.set_option("big_switch", old_bs)
+    assert res[0] == res[1], res
+
+
 def _level_sizes(cfg):
     """tcnn's level table (grid.h): entries per level = min(round_up(res^3, 8), 2^T), res = ceil(base * scale^l - 1) + 1."""
     sizes = []
