@@ -10,7 +10,7 @@ OUT="$REPO/gpurun_out/$TAG"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 CMD="python $REPO/tools/profile_window.py --warmup 5 --steps 20 --extra $EXTRA ${WINDOW_ARGS:-}"      # WINDOW_ARGS: e.g. "--log2-hashmap-size 22 --objects 8"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $CMD > "$OUT/trace.log" 2>&1); echo "trace exit $?"; tail -1 "$OUT/trace.log"
-python "$REPO/tools/rocpd_window.py" "$OUT/trace" --skip $((5 + EXTRA)) --take 20 > "$OUT/kernel_window.md"; cat "$OUT/kernel_window.md"; rm -rf "$OUT/trace"
+python "$REPO/tools/rocpd_window.py" "$OUT/trace" --skip $(( (5 + EXTRA) * ${WINDOW_OBJECTS:-1} )) --take $(( 20 * ${WINDOW_OBJECTS:-1} )) > "$OUT/kernel_window.md"; cat "$OUT/kernel_window.md"; rm -rf "$OUT/trace"
 i=0
 while IFS= read -r C; do
   [ -z "$C" ] && continue
@@ -26,6 +26,6 @@ SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INS
 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM
 GRBM_GUI_ACTIVE
 LIST
-python "$REPO/tools/rocpd_window.py" "$OUT" --skip $((5 + EXTRA)) --take 20 > "$OUT/pmc_window.md"; cat "$OUT/pmc_window.md"
+python "$REPO/tools/rocpd_window.py" "$OUT" --skip $(( (5 + EXTRA) * ${WINDOW_OBJECTS:-1} )) --take $(( 20 * ${WINDOW_OBJECTS:-1} )) > "$OUT/pmc_window.md"; cat "$OUT/pmc_window.md"
 for d in "$OUT"/pmc*/; do rm -rf "$d"; done
 grep -il "error\|invalid\|not found" "$OUT"/pmc*.log 2>/dev/null | head
