@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--views", type=int, default=40)
     ap.add_argument("--log2-hashmap-size", type=int, default=0, help="override base.json's T (BASELINE configs[4] stress: 22); 0 = base.json")
+    ap.add_argument("--no-stress", action="store_true", help="skip the T = 2^22 side figure")
     ap.add_argument("--objects-per-gpu", type=int, default=4, help="extra (not the headline): aggregate rate of K objects trained concurrently on one GPU; 0 = skip")
     return ap.parse_args()
 
@@ -200,7 +201,8 @@ def main():
                 "kernel": dom["kernel"], "avg_launch_ms": dom["avg_launch_ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "limited_by": dom["limited_by"],
                 "gradient_carrying_samples_per_launch": round(scattered, 1),
                 "measured_over": "HIP events around every launch on the object's train stream over steps %d..%d from init of a fresh object -- the same window as "
-                                 "the timed region, measured separately because the events add ~35 us per step between the launches" % (args.warmup, args.warmup + args.steps),
+                                 "the timed region, measured separately because the events add ~35 us per step between the launches; an event pair also inflates the launch it brackets by ~2 us -- the kernels' "
+                                 "rocprofv3 durations of the same window are in profiles/r04_window_dense.md (their sum fits the timed step, the event times do not)" % (args.warmup, args.warmup + args.steps),
                 "kernels": table}
     # the whole step against the contract's bytes: (52 + 96 L) B per nominal ray-sample + 40 B per parameter, over the TIMED step (no events)
     contract_bytes = train_bytes_per_sample(L) * B + 40 * n_params
@@ -368,7 +370,7 @@ def main():
     if rank == 0 and world == 1 and args.objects_per_gpu > 1:
         try:
             K = args.objects_per_gpu
-            msteps = 5 * args.steps                      # (a 20-step window of four threads is mostly thread start-up)
+            msteps = max(320, 5 * args.steps)            # (a short window of four threads is mostly thread start-up; 320 steps = the window README / DESIGN quote)
             tms = []
             for rep in range(3):                         # three fresh sets of K objects, the median is reported
                 objs = [new_object(dict(sample_seed=3000 + 10 * rep + k)) for k in range(K)]
@@ -387,6 +389,33 @@ def main():
         except Exception as e:
             multi = {"objects": args.objects_per_gpu, "value": None, "note": "failed: %s" % e}
 
+    # ---- extra, not the headline: the stress configuration's table (BASELINE configs[4]: hash T = 2^22, 105 M parameters per object) on this GPU: the one
+    #      case whose kernels are HBM-bound (profiles/r04_window_T22.md).  One object, steps 20..60 from init and 800..840.
+    stress = None
+    if rank == 0 and world == 1 and not args.log2_hashmap_size and not args.no_stress:
+        try:
+            so = new_object(dict(log2_hashmap_size=22)); so.train(20); sync()
+            ts0 = time.perf_counter(); so.train(40); sync(); ts_init = (time.perf_counter() - ts0) / 40
+            so.train(740); sync()
+            ts0 = time.perf_counter(); so.train(40); sync(); ts_late = (time.perf_counter() - ts0) / 40
+            sp = {}
+            try:
+                sp = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("stress_T22", {})
+            except Exception:
+                sp = {}
+            def hbm_frac(key, ms):
+                b = sp.get(key); return round(b / (ms * 1e-3) / 8e12, 4) if b else None
+            stress = {"log2_hashmap_size": 22, "n_params": int(so.info().n_params),
+                      "from_init": {"steps": "20..60", "ms_per_step": round(1e3 * ts_init, 4), "value": round(B / ts_init, 1),
+                                    "frac_of_hbm_from_counters": hbm_frac("step_bytes_beyond_l2_steps_20_40", 1e3 * ts_init)},
+                      "late": {"steps": "800..840", "ms_per_step": round(1e3 * ts_late, 4), "value": round(B / ts_late, 1),
+                               "frac_of_hbm_from_counters": hbm_frac("step_bytes_beyond_l2_steps_800_820", 1e3 * ts_late)},
+                      "unit": "ray-samples/s", "traffic_source": sp.get("source"),
+                      "note": "frac_of_hbm = committed counter traffic of the step's kernels ((2 FETCH_SIZE + WRITE_SIZE) KB summed over the kernels of a step, profiles/r04_window_T22.md) / measured step time / 8 TB/s"}
+            so.close()
+        except Exception as e:
+            stress = {"value": None, "note": "failed: %s" % e}
+
     if rank == 0:
         out = {"metric": "ray-samples/sec (train: hash-encode->MLP->composite fwd+bwd+optimizer) per object-NeRF", "value": round(value, 1),
                "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -401,7 +430,7 @@ def main():
                "timed_region": "median of %d independent repeats; each repeat: fresh object, %d warm-up steps, %d timed steps from init, barrier + device sync on both sides, max over ranks" % (len(reps), args.warmup, args.steps),
                "ms_per_step_repeats": [round(1e3 * r / args.steps, 4) for r in reps], "per_rank_ray_samples_per_s": per_rank,
                "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": cpu_c1, "cpu_baseline_render": cpu_render,
-               "late_training": late, "late_training_with_occupancy_skipping": occ, "multi_object": multi,
+               "late_training": late, "late_training_with_occupancy_skipping": occ, "multi_object": multi, "stress_T22": stress,
                "pcie_inclusive": {"dataset_upload_ms": round(1e3 * upload_s, 2), "dataset_bytes": int(sc.n_views * sc.H * sc.W * 4),
                                   "value_for_a_5000_step_job": round(world * 5000 * B / (upload_s + 5000 * dt / args.steps), 1), "unit": "ray-samples/s",
                                   "note": "host frames -> HBM once per sequence (pinned staging + packing kernel), then 5000 steps at the measured step time; never the headline value"},
