@@ -214,13 +214,41 @@ static void launch_stream(int mode, int blocks, int units, const StreamPtrs& a) 
 #undef MON_UB_STREAM
 }
 
+// modes 70 / 71: what a persistent single-object step would trade: mode 70 = ONE resident grid of 256 workgroups x 1024 threads holding the CU's
+// whole LDS (the shape of k_encode_tiles / k_grid_scatter) that crosses n_ops grid barriers (one returning atomic per workgroup on a counter + a spin on its generation,
+// every workgroup touching 4 KB of memory between two barriers so that the barrier also carries the release / acquire a real phase change needs); mode 71 = n_ops
+// back-to-back launches of the same grid doing the same 4 KB per workgroup.  `pattern` > 0: that many workgroups instead of 256.
+__global__ void __launch_bounds__(1024) k_ub_grid_barrier(uint32_t n_barriers, uint32_t* __restrict__ ctr, uint32_t* __restrict__ scratch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    reinterpret_cast<uint32_t*>(smem)[threadIdx.x] = threadIdx.x;
+    uint32_t acc = 0u;
+    for (uint32_t b = 0; b < n_barriers; ++b) {
+        scratch[(size_t)blockIdx.x * 1024u + threadIdx.x] = acc + b;                     // this phase's output
+        __syncthreads();
+        if (threadIdx.x == 0) {                                                          // (counter and generation flag on lines of their own: 256 B apart)
+            const uint32_t arrived = __hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            if (arrived == (b + 1u) * gridDim.x) __hip_atomic_store(&ctr[64], b + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            else while (__hip_atomic_load(&ctr[64], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < b + 1u) __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+        acc += scratch[(size_t)((blockIdx.x + 1u) % gridDim.x) * 1024u + threadIdx.x];    // the next phase reads a neighbour's output
+    }
+    if (acc == 0x12345678u) scratch[0] = acc;
+}
+__global__ void __launch_bounds__(1024) k_ub_phase(uint32_t b, uint32_t* __restrict__ scratch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    reinterpret_cast<uint32_t*>(smem)[threadIdx.x] = threadIdx.x;
+    const uint32_t v = scratch[(size_t)((blockIdx.x + 1u) % gridDim.x) * 1024u + threadIdx.x];
+    scratch[(size_t)blockIdx.x * 1024u + threadIdx.x + (size_t)(b & 1u) * 1024u * 1024u] = v + b;
+}
+
 int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms_out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || use_device(device) != hipSuccess) { set_error("microbench: no HIP device"); return MON_ERR_NO_DEVICE; }
     uint32_t* table = nullptr; float* sink = nullptr;
     const bool stream = mode == 31 || mode == 32;                 // n_ops parameters; n_entries = flags: bit 0 plain stores, bits 4..7 units per thread, bits 8..11 partial tables
     const size_t np = ((size_t)n_ops + 1023) & ~(size_t)1023;
-    const size_t bytes = stream ? np * (12 + 8 + 2 * 8) + 4096 : mode == 30 ? 2 * (size_t)n_ops : (size_t)n_entries * 4 * 8;
+    const size_t bytes = stream ? np * (12 + 8 + 2 * 8) + 4096 : mode == 30 ? 2 * (size_t)n_ops : (mode == 70 || mode == 71) ? (size_t)16 << 20 : (size_t)n_entries * 4 * 8;
     if (hipMalloc((void**)&table, bytes) != hipSuccess || hipMalloc((void**)&sink, 64) != hipSuccess) { set_error("microbench: hipMalloc failed"); return MON_ERR_HIP; }
     hipMemset(table, 0, bytes);
     const uint32_t ops_per_thread = 64, threads = n_ops / ops_per_thread, blocks = (threads + 255) / 256;
@@ -235,6 +263,14 @@ int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n
             StreamPtrs a{ reinterpret_cast<float*>(b), reinterpret_cast<float*>(b + 4 * np), reinterpret_cast<float*>(b + 8 * np), reinterpret_cast<uint16_t*>(b + 12 * np), reinterpret_cast<uint16_t*>(b + 14 * np),
                           reinterpret_cast<uint16_t*>(b + 16 * np), reinterpret_cast<uint16_t*>(b + 18 * np), reinterpret_cast<const uint16_t*>(b + 20 * np), (uint32_t)np, (n_entries >> 8) & 15u, n_entries & 1u };
             launch_stream(mode, pattern > 0 ? pattern : 512, (int)((n_entries >> 4) & 15u), a);
+        }
+        else if (mode == 70 || mode == 71) {
+            const uint32_t wgs = pattern > 0 ? (uint32_t)pattern : 256u;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ub_grid_barrier), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ub_phase), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            hipMemsetAsync(table, 0, 1024, 0);
+            if (mode == 70) hipLaunchKernelGGL(k_ub_grid_barrier, dim3(wgs), dim3(1024), 163840, 0, n_ops, table, table + 256);
+            else for (uint32_t b = 0; b < n_ops; ++b) hipLaunchKernelGGL(k_ub_phase, dim3(wgs), dim3(1024), 163840, 0, b, table + 256);
         }
         else if (mode == 30) hipLaunchKernelGGL(k_ub_copy, dim3(pattern > 0 ? pattern : 512), dim3(256), 0, 0, reinterpret_cast<const ub_u4*>(table), reinterpret_cast<ub_u4*>(table) + n_ops / 16u, n_ops / 16u);
         else if (mode >= 50 && mode < 70) {

@@ -1,0 +1,10 @@
+"""What a persistent single-object step would trade: grid barriers inside one resident grid of 256 x 1024 threads with the CU's whole LDS
+against back-to-back launches of the same grid (microbench modes 70 / 71)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+pkg = ge.load_package()
+for wgs in (256, 128):
+    for n in (100, 1000):
+        a = min(pkg.microbench(70, wgs, 1024, n) for _ in range(3)); b = min(pkg.microbench(71, wgs, 1024, n) for _ in range(3))
+        print("%3d workgroups x 1024 threads, 160 KB LDS each: %4d phases -- resident grid + grid barriers %.2f us per phase, separate launches %.2f us per phase" % (wgs, n, 1e3 * a / n, 1e3 * b / n), flush=True)
