@@ -448,9 +448,7 @@ bool fused_supported(const NetDims& nd, uint32_t S, uint32_t R) {
 
 uint32_t fused_train_grid(const NetDims&, uint32_t R) {
     const uint32_t want = (R + 3) / 4;            // one ray per wavefront when it fits
-    uint32_t cap = options().fused_grid > 0 ? (uint32_t)options().fused_grid : kMaxFusedGrid;
-    if (cap > kMaxFusedGrid) cap = kMaxFusedGrid;          // (the dW partial rows are allocated for kMaxFusedGrid workgroups)
-    return want < cap ? want : cap;
+    return want < kMaxFusedGrid ? want : kMaxFusedGrid;  // (two workgroups per CU; the dW partial rows are allocated for kMaxFusedGrid of them.  One ray per wave -- 768 / 1024 workgroups -- measured slower)
 }
 
 template <int EPAD, int W, int NH>

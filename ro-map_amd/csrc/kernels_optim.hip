@@ -12,7 +12,7 @@
 // iteration's candidate rays (they depend on the iteration counter and the dataset only), so the steady-state loop is
 // k_fused_train -> k_grid_scatter -> k_reduce_partials -> k_optimizer with no batch-generation launch.
 // Variant builds for measurements (tools/variant_build.sh <tag> -D...; profiles/r03_scatter_levels.md): MON_OPT_ABLATE bits 1 no Adam arithmetic, 2 no partial-table
-// reads, 4 no position blocks, 8 no tile-image stores; MON_OPT_POS_FIRST the preparation blocks ahead of the parameter blocks; MON_OPT_PLAIN_STORES.
+// reads, 4 no position blocks, 8 no tile-image stores.
 #include <cstdlib>
 #include "device_common.h"
 #include "model.h"
@@ -26,11 +26,7 @@ namespace mon {
 // stores, a wash against plain ones (round 2).  LARGE tables (T = 2^22: 2-3 GB of scattered 32-byte pieces per step, HBM-bound): plain stores -- the L2 merges a
 // chunk's pieces into whole lines before they leave; non-temporal ones cost 20 % of the kernel there (645-725 us against 535-550 us over steps 20..40, four runs each).
 template <bool NT, class T> __device__ __forceinline__ void state_store(T v, T* p) {
-#ifdef MON_OPT_PLAIN_STORES
-    *p = v;
-#else
     if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
-#endif
 }
 
 __device__ __forceinline__ float adam_update(float g, float w, float& m1, float& m2, uint32_t& steps, float lr0, const OptimConst& oc, uint32_t step_cap) {
@@ -59,11 +55,7 @@ template <bool DENSE, bool LAZY, bool ONE = false /* the grid covers every chunk
 __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, const DevState* __restrict__ st, DevState* __restrict__ st_next, OptimNext nx, uint32_t lazy_below) {
     // block roles by VIRTUAL index: [0, extra) prepare the next iteration, the rest update parameters.  Physically the parameter blocks come first (they are
     // the ones that stream 80 MB and should be in flight from the first cycle), the short preparation blocks fill in behind them.
-#ifdef MON_OPT_POS_FIRST
-    const uint32_t vblock = blockIdx.x;
-#else
     const uint32_t n_extra = nx.cand_blocks + nx.pos_blocks, n_opt = gridDim.x - n_extra, vblock = blockIdx.x < n_opt ? blockIdx.x + n_extra : blockIdx.x - n_opt;
-#endif
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const uint32_t step_cap = (p.steps16 || p.rec) ? 65535u : 0xffffffffu;
     // where a chunk's optimizer state lives: the four SoA arrays, or (large tables, ParamPtrs::rec) ONE 128-byte record per chunk -- master | m1 | m2 | step counters --

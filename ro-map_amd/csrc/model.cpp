@@ -39,8 +39,8 @@ static std::atomic<long>* option_slot(const char* name) {
     static const struct { const char* n; std::atomic<long> Options::*f; } tab[] = {
         { "backend", &Options::backend }, { "use_graph", &Options::use_graph }, { "lazy_ema", &Options::lazy_ema }, { "big_switch", &Options::big_switch },
         { "touched_flags", &Options::touched_flags },
-        { "fused_grid", &Options::fused_grid }, { "lds_encode", &Options::lds_encode }, { "roctx", &Options::roctx }, { "ray_records", &Options::ray_records }, { "step_variant", &Options::step_variant }, { "steps16", &Options::steps16 }, { "encode_ablate", &Options::encode_ablate }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
-        { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner }, { "scatter_bins", &Options::scatter_bins }, { "opt_lazy_below", &Options::opt_lazy_below }, { "scatter_ablate", &Options::scatter_ablate },
+        { "lds_encode", &Options::lds_encode }, { "roctx", &Options::roctx }, { "step_variant", &Options::step_variant }, { "steps16", &Options::steps16 }, { "encode_ablate", &Options::encode_ablate }, { "opt_blocks", &Options::opt_blocks }, { "fused_ablate", &Options::fused_ablate }, { "fused_stagger", &Options::fused_stagger }, { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
+        { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner }, { "opt_lazy_below", &Options::opt_lazy_below }, { "scatter_ablate", &Options::scatter_ablate },
         { "tile_render", &Options::tile_render }, { "state_records", &Options::state_records } };
     for (const auto& e : tab) if (name && std::strcmp(name, e.n) == 0) return &(g_options.*(e.f));
     return nullptr;
@@ -425,7 +425,6 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     m.oc.R = (uint32_t)cfg.rays_per_batch; m.oc.S = (uint32_t)cfg.n_samples; m.oc.use_depth = cfg.use_depth && ds->use_depth;
     m.oc.sample_seed = cfg.sample_seed; m.oc.loss_scale = cfg.loss_scale;
     m.n_bins = kDefaultScatterBins;
-    if (options().scatter_bins > 16) { const uint32_t cap = scatter_bins_max(m.oc.R); while (m.n_bins * 2u <= (uint32_t)options().scatter_bins && m.n_bins * 2u <= cap) m.n_bins *= 2u; }
     m.opt = OptimConst{ cfg.beta1, cfg.beta2, cfg.epsilon, cfg.l2_reg, cfg.ema_decay, cfg.loss_scale, cfg.decay_base, std::log2(cfg.beta1), std::log2(cfg.beta2), std::log2(cfg.ema_decay), cfg.decay_start, cfg.decay_interval, m.nd.n_mlp, m.n_params };
     { const int rcs = stream_acquire(m.device, &m.own_stream); if (rcs) return rcs; }
     m.train_stream = m.own_stream; m.lanes = lanes_get(m.device); m.lanes->objects.fetch_add(1);
@@ -496,7 +495,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         // tile chain from 3072 rays (98 304 samples) up, 2 always (tests), 0 never.
         const bool tiles_pay = options().lds_encode >= 2 || Btrain >= 98304u;
         if (options().lds_encode && tiles_pay && m.lds_mask == ((1u << m.nd.L) - 1u) && encode_tiles_supported(m.lt, m.nd)) {
-            if (options().ray_records && (rc = dev_alloc(m, B.ray_rec, 12 * (size_t)R))) return rc;
+            if ((rc = dev_alloc(m, B.ray_rec, 12 * (size_t)R))) return rc;
             m.B_alt = B;                             // (cand_* / mask replaced below, after the workspace pointers are final)
             if ((rc = dev_alloc(m, m.B_alt.cand_o, 3 * (size_t)R)) || (rc = dev_alloc(m, m.B_alt.cand_d, 3 * (size_t)R)) || (rc = dev_alloc(m, m.B_alt.cand_dn, R)) ||
                 (rc = dev_alloc(m, m.B_alt.cand_t0, R)) || (rc = dev_alloc(m, m.B_alt.cand_t1, R)) || (rc = dev_alloc(m, m.B_alt.cand_depth, R)) ||

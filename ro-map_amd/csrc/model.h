@@ -132,8 +132,8 @@ enum {
 // Process-wide test and tuning switches (mon_set_option, include/mon_core.h); defaults are the product behaviour.
 struct Options {      // (atomics: tests and tools flip options while object threads read them)
     std::atomic<long> backend{ -1 }, use_graph{ 0 }, lazy_ema{ -1 }, big_switch{ 16384 }, touched_flags{ 1 },
-         fused_grid{ 0 }, lds_encode{ 1 }, encode_ablate{ 0 }, opt_blocks{ 0 }, fused_ablate{ 0 }, fused_stagger{ -1 }, offline_outer{ 10 }, offline_inner{ 500 }, scatter_bins{ 0 }, opt_lazy_below{ -1 },
-         scatter_ablate{ 0 }, train_lanes{ 2 }, lane_chunk{ 16 }, online_slice_min{ 2 }, roctx{ 0 }, ray_records{ 1 }, step_variant{ 0 }, steps16{ 1 },
+         lds_encode{ 1 }, encode_ablate{ 0 }, opt_blocks{ 0 }, fused_ablate{ 0 }, fused_stagger{ -1 }, offline_outer{ 10 }, offline_inner{ 500 }, opt_lazy_below{ -1 },
+         scatter_ablate{ 0 }, train_lanes{ 2 }, lane_chunk{ 16 }, online_slice_min{ 2 }, roctx{ 0 }, step_variant{ 0 }, steps16{ 1 },
          state_records{ 1 },    // tables above 8 M parameters keep their optimizer state as 128-byte chunk records (ParamPtrs::rec); 0: the four arrays
          tile_render{ 1 };      // inference on feature-planar level tiles: 0 never (gathers), 1 crops of 4096 rays and more + point queries, 2 always
 };

@@ -17,6 +17,7 @@ int main(int argc, char** argv) {
     const char* cfg_json = argc > 1 ? argv[1] : "ro-map_amd/configs/base.json";
     const int H = 48, W = 64, n_frames = 24;
     int n_dev = 0; OK(mon_device_count(&n_dev));
+    OK(mon_set_option("tile_render", 2));         // every render / density query through the per-device tile workspace (its mutexes, the image key, the refcount at object destruction)
     OK(mon_set_option("lds_encode", 2));          // the level-tile chain's host side (second candidate set, position mode of the optimizer launch) also for the small objects below
     mon_config cfg; OK(mon_config_default(&cfg)); cfg.rays_per_batch = 256;
     std::vector<unsigned char> rgb((size_t)H * W * 3, 128), inst((size_t)H * W, 7);

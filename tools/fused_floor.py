@@ -4,8 +4,8 @@ durations over the bench window (steps 5..25 from init, base.json object, bench 
 
   full                 the product kernel
   encode only          fused_ablate = 96: prologue + the hash-grid gathers and interpolation of every ray, nothing else (no MLP, composite, backward, stores, dW reduction)
-  encode only, 1 WG/CU fused_grid = 256: half the waves per CU
-  encode only, 64 CUs  fused_grid = 64: a quarter of the chip, 4x the rays per workgroup -- per-CU limit of the gather path without chip-wide contention
+  (round 2 also ran the encode-only variant on 256 and on 64 workgroups through an option `fused_grid`, retired in round 4 with the experiment closed:
+   profiles/r02_fused_floor.md keeps those rows)
   no rays              fused_ablate = 40: prologue only (launch, fragment image, ray select)
 
 Prints one markdown table (committed as profiles/r02_fused_floor.md)."""
@@ -23,10 +23,8 @@ def main():
     pkg = ge.load_package(); ss = ge.load_tools()
     sc = ss.make_scene(n_views=40, H=480, W=640, f=525.0, seed=0); kw = {"sample_seed": 2024}
     rows = [("full (stagger on)", {}), ("full, stagger off", {"fused_stagger": 0}), ("encode only (fused_ablate 96)", {"fused_ablate": 96, "fused_stagger": 0}),
-            ("encode only, 256 workgroups = 4 waves / CU", {"fused_ablate": 96, "fused_stagger": 0, "fused_grid": 256}),
-            ("encode only, 64 workgroups = 64 CUs busy, 64 rays each", {"fused_ablate": 96, "fused_stagger": 0, "fused_grid": 64}),
             ("no rays (fused_ablate 40): prologue only", {"fused_ablate": 40, "fused_stagger": 0})]
-    defaults = {"fused_ablate": 0, "fused_stagger": -1, "fused_grid": 0}
+    defaults = {"fused_ablate": 0, "fused_stagger": -1}
     out = {}
     print("| k_fused_train variant | mean launch, us (HIP events, steps 5..25) |\n|---|---|")
     for name, opts in rows:

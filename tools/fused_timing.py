@@ -29,7 +29,7 @@ def main():
     import importlib; binding = importlib.import_module(pkg.__name__ + ".binding")
     binding.lib_path = lambda: lib; binding._lib = None
     sc = ss.make_scene(n_views=40, H=480, W=640, f=525.0, seed=0)
-    grid = int(os.environ.get("MON_TIMING_GRID", "512")); pkg.set_option("fused_grid", grid)
+    grid = 512          # (k_fused_train's grid: two workgroups per CU)
     ds, obj = ge.make_problem(pkg, sc, {}); obj.set_backend(1)
     obj.train(int(os.environ.get("MON_TIMING_STEPS", "50")))
     t = obj.buffer("tdist")[:grid * 4 * 16].reshape(grid * 4, 16)

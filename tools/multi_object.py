@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Aggregate training rate of K base.json objects on one GPU (thread + stream per object), per option setting:
-   python tools/multi_object.py [K ...]            MON_OPTIONS=fused_grid=256 python tools/multi_object.py 1 4 8
+   python tools/multi_object.py [K ...]            MON_OPTIONS=train_lanes=0 python tools/multi_object.py 1 4 8
    Every object trains `warm` steps alone first, then all K train `steps` steps concurrently; prints aggregate G ray-samples/s."""
 import json
 import os
