@@ -130,6 +130,11 @@ __host__ __device__ inline void pixel_ray(const Intrinsics& K, float px, float p
     dnorm = n;
 }
 
+// h(a * b) as the contract and the oracle define it: the fp32 product ROUNDED, then rounded to fp16 (tcnn's `(T)(weight * grad)`, the reference's
+// `(network_precision_t)(loss_scale * ...)`).  Written plainly, the compiler folds the multiply and the conversion into v_fma_mixlo_f16, which rounds the exact
+// product once -- one result in ~2^13 then differs by an fp16 ulp.  The product passes through an opaque register.
+__device__ __forceinline__ float opaque_f32(float v) { asm volatile("" : "+v"(v)); return v; }
+
 // ---------------------------------------------------------------- activations, nerf_model.cu:22-64
 __device__ inline float logistic_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ inline float clamp_f(float x, float a, float b) { return fminf(fmaxf(x, a), b); }

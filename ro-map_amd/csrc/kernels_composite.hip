@@ -54,9 +54,9 @@ __global__ void __launch_bounds__(64) k_composite_grad(BatchPtrs b, ObjectConst 
             q0 += w * c0; q1 += w * c1; q2 += w * c2; d2 += w * cur; T *= (1.f - alpha);
             const float s0 = rgb0 - q0, s1 = rgb1 - q1, s2 = rgb2 - q2;
             half4_t dv;
-            dv[0] = (half_t)(ls * ((w * g0) * (c0 * (1.f - c0))));
-            dv[1] = (half_t)(ls * ((w * g1) * (c1 * (1.f - c1))));
-            dv[2] = (half_t)(ls * ((w * g2) * (c2 * (1.f - c2))));
+            dv[0] = (half_t)opaque_f32(ls * ((w * g0) * (c0 * (1.f - c0))));
+            dv[1] = (half_t)opaque_f32(ls * ((w * g1) * (c1 * (1.f - c1))));
+            dv[2] = (half_t)opaque_f32(ls * ((w * g2) * (c2 * (1.f - c2))));
             const float dsig = __expf(clamp_f((float)v[3], -15.f, 15.f));
             const float depth_sup = dl_dd * (T * cur - (dep - d2));
             const float dmask = 1.f - mask;
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(64) k_composite_grad(BatchPtrs b, ObjectConst 
                 const float dlm = 0.5f * (mask >= 0.f ? 1.f : -1.f);
                 dl = dsig * dt * dlm * dmask + dsig * 0.01f;
             }
-            dv[3] = (half_t)(ls * dl);
+            dv[3] = (half_t)opaque_f32(ls * dl);
             dout[n] = dv; last = cur;
         }
         const half4_t z = { (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f };

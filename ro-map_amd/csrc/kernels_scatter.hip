@@ -42,7 +42,7 @@ __host__ __device__ inline uint32_t scatter_parts(uint32_t size) { const int m =
 struct ScatterItem { half2_t g; float4_t x; };
 
 // fixed-point contribution of one corner and feature: tcnn's (T)(weight * grad), exact in 1 / fs units
-__device__ __forceinline__ int contrib_fix(float w, float g, float fs) { return (int)((float)(half_t)(w * g) * fs); }
+__device__ __forceinline__ int contrib_fix(float w, float g, float fs) { return (int)((float)(half_t)opaque_f32(w * g) * fs); }
 
 // sign-extended packing of two fixed-point contributions into one 64-bit addend: the 64-bit sum S of such addends decodes exactly as lo = (int32)S,
 // hi = (S - lo) >> 32 while both sums stay inside int32 (they do: the same clamp as for the 32-bit tiles)
@@ -75,7 +75,9 @@ __device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bo
     const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
     const float wx[2] = { nxy.x, pxy.x }, wz[2] = { 1.f - pz, pz }; const f2 wy2 = { nxy.y, pxy.y };
     unsigned long long* tab64 = reinterpret_cast<unsigned long long*>(tab);
-    const auto fix2 = [&](f2 w, float gg) -> f2 { return f2{ (float)(half_t)(w.x * gg), (float)(half_t)(w.y * gg) } * fs; };      // contrib_fix of two corners, before the conversion to int
+    // (the fp32 products pass through an opaque register pair: h(w * g) is the ROUNDED product rounded again, like tcnn's `(T)(weight * grad)` and the oracle -- the
+    //  compiler's own choice, v_fma_mixlo_f16, rounds the exact product once and differs in ~2^-13 of the contributions)
+    const auto fix2 = [&](f2 w, float gg) -> f2 { f2 pr = w * gg; asm volatile("" : "+v"(pr)); return f2{ (float)(half_t)pr.x, (float)(half_t)pr.y } * fs; };      // contrib_fix of two corners, before the conversion to int
     if (MODE == kTileWhole64) {                                   // the whole level is this workgroup's: eight corners, nothing to test, one 64-bit atomic each
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                             // the two x-corners of pair j = y + 2 z
