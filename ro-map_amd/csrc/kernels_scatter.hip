@@ -51,7 +51,8 @@ __device__ __forceinline__ unsigned long long pack_fix(int lo, int hi) { return 
 // (written as instructions: from the C forms the compiler rebuilt a compare + select pair for each of the two)
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }      // a ^ b ^ c
 __device__ __forceinline__ int floor_to_int(float q) { int r; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(q)); return r; }                                                                      // (int)floorf(q)
-__device__ __forceinline__ uint32_t sign_of_bit0(uint32_t h) { uint32_t m; asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m) : "v"(h)); return m; }                                       // bit 0 set ? ~0 : 0
+__device__ __forceinline__ uint32_t sign_of_bit0(uint32_t h) { uint32_t m; asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m) : "v"(h)); return m; }
+__device__ __forceinline__ uint32_t sign_of_bit1(uint32_t h) { uint32_t m; asm("v_bfe_i32 %0, %1, 1, 1" : "=v"(m) : "v"(h)); return m; }                                       // bit 1 set ? ~0 : 0                                       // bit 0 set ? ~0 : 0
 __device__ __forceinline__ uint32_t bit_select(uint32_t m, uint32_t a, uint32_t b) { uint32_t r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b)); return r; }   // (m & a) | (~m & b)
 
 // One sample, one level.  The two x-corners of a (y, z) pair always have entry indices of different parity -- hashed: idx1 = idx0 ^ ((x ^ (x + 1)) & mask)
@@ -91,7 +92,24 @@ __device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bo
         return;
     }
     uint32_t local[4]; float ws[4];                               // per pair: this workgroup's corner -- its place in the tile and its x-weight
-    if (HASHED && POW2) {
+    constexpr bool BYTES = HASHED && POW2 && !BOTH;               // the 32-bit tiles of the hashed levels (13 of base.json's 16): `local` holds LDS BYTE addresses
+    if constexpr (BYTES) {
+        // the walk of the branch below with every index term carried DOUBLED (h2 = h << 1: xor / and commute with the shift, and only product bits below the table
+        // size matter), so that a corner's place in the int32 tile comes out as its byte address -- (h >> 1) << 2 = h2 & mask4 -- and the four address shifts in
+        // front of the atomics disappear (the tile starts at LDS address 0: the kernel has no static LDS, checked at its entry)
+        const uint32_t my2 = my << 1, mz2 = mz << 1, mask4 = (mask << 1) & ~3u;
+        const uint32_t y2 = __umul24(pg[1], my2 & 0xffffffu), z2 = __umul24(pg[2], mz2 & 0xffffffu);
+        const uint32_t ay2[2] = { y2, y2 + my2 }, az2[2] = { z2, z2 + mz2 };
+        const uint32_t axp2 = (ax0 ^ parity) << 1, dx4 = (((ax0 ^ ax1) & mask) << 1) & ~3u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (DEGEN && j) { local[j] = local[0]; ws[j] = ws[0]; continue; }
+            const uint32_t h2 = xor3(axp2, ay2[j & 1], az2[j >> 1]);
+            const uint32_t m = sign_of_bit1(h2);                   // bit 0 of the hash: which x-corner is this workgroup's (all ones: the second)
+            local[j] = ((h2 & mask4) ^ (dx4 & m)) - (MODE == kTileParityRanged ? base_half * 4u : 0u);
+            ws[j] = __builtin_bit_cast(float, bit_select(m, __builtin_bit_cast(uint32_t, wx[1]), __builtin_bit_cast(uint32_t, wx[0])));
+        }
+    } else if (HASHED && POW2) {
         // idx0 = (x ^ y' ^ z') & mask, idx1 = idx0 ^ dxm with dxm odd: with the tile's parity folded into x, bit 0 of h says which x-corner is this workgroup's
         // (m = all ones: the second), and the place in the parity half is (idx >> 1) = bits 1.. of h, xor-ed with dxm >> 1 for the second corner
         const uint32_t axp = ax0 ^ parity, dxh = ((ax0 ^ ax1) & mask) >> 1, nb = (uint32_t)__popc(mask) - 1u;
@@ -123,9 +141,14 @@ __device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bo
     }
     const f2 a = fix2(w01, g), b = fix2(w23, g);
     const int c[4] = { (int)a.x, (int)a.y, (int)b.x, (int)b.y };
-    if (DEGEN) { atomicAdd(tab + local[3], (c[0] + c[1]) + (c[2] + c[3])); return; }      // all four pairs are the SAME entry: one atomic for the (exact) sum
+    typedef __attribute__((address_space(3))) int* lds_int;
+    const auto add = [&](uint32_t where, int v) {
+        if constexpr (BYTES) (void)__hip_atomic_fetch_add((lds_int)(uintptr_t)where, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else atomicAdd(tab + where, v);
+    };
+    if (DEGEN) { add(local[3], (c[0] + c[1]) + (c[2] + c[3])); return; }      // all four pairs are the SAME entry: one atomic for the (exact) sum
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (MODE == kTileParity || local[j] < tile) atomicAdd(tab + local[j], c[j]);
+    for (int j = 0; j < 4; ++j) if (MODE == kTileParity || local[j] < tile * (BYTES ? 4u : 1u)) add(local[j], c[j]);
 }
 
 template <bool HASHED, bool POW2, int MODE, bool DEGEN = false>
@@ -264,6 +287,7 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
     if (ablate & 2u) pa.partials = nullptr;
     bool pacc_loaded = false;
     int* tab = reinterpret_cast<int*>(smem);
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();      // scatter_item addresses the hashed levels' tiles from LDS offset 0
     float* red = reinterpret_cast<float*>(smem + (size_t)kScatterLdsBytes - 256u);     // 256 B behind the largest tile
     // run lengths of the compacted ray bins, lane b of every wave holds bin b's and bin (b + 64)'s (read back with v_readlane: no memory access in the sample loop)
     const uint32_t bin_cap = B / n_bins, lb = threadIdx.x & 63u;

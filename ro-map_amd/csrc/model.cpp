@@ -467,7 +467,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         (rc = dev_alloc(m, B.dHid, (size_t)Btrain * m.nd.W * m.nd.NH)) || (rc = dev_alloc(m, B.dE, (size_t)Btrain * m.nd.Epad)) ||
         (rc = dev_alloc(m, B.rgb_ray, 3 * (size_t)R)) || (rc = dev_alloc(m, B.depth_ray, R)) || (rc = dev_alloc(m, B.mask_ray, R)) || (rc = dev_alloc(m, B.loss_ray, R)) ||
         (rc = dev_alloc(m, m.d_state, 2)) || (rc = dev_alloc(m, m.d_dw_partials, (size_t)(fused_partial_cols(m.nd) + 64) * kMaxFusedGrid)) ||
-        (rc = dev_alloc(m, m.d_out_rgb, 3 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_depth, kRenderChunkRays)) || (rc = dev_alloc(m, m.d_out_mask, kRenderChunkRays))) return rc;
+        (rc = dev_alloc(m, m.d_out_all, 5 * (size_t)kRenderChunkRays))) return rc;
     m.out_cap = kRenderChunkRays;
     if (rng_stream_mode(cfg.rng_flags)) {          // "same inputs" mode: the reference's XORWOW stream (xorwow.h) instead of the counter RNG
         m.xw_lanes = rng_xorwow_lanes(cfg.rng_flags); m.xw_flavour = rng_stream_mode(cfg.rng_flags) == 2 ? kXorwowRocrand : kXorwowCurand;
@@ -598,6 +598,7 @@ int model_destroy(Model* mp) {
     for (auto& e : m.ev_pool) hipEventDestroy(e);
     for (void* p : m.allocs) hipFree(p);
     if (m.h_state_pinned) hipHostFree(m.h_state_pinned);
+    if (m.h_out) (void)hipHostFree(m.h_out);
     if (m.lanes) m.lanes->objects.fetch_sub(1);
     if (m.switch_event) hipEventDestroy(m.switch_event);
     if (m.sync_event) hipEventDestroy(m.sync_event);
@@ -916,16 +917,22 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
     model_leave_lane(m);
     { int rc = ensure_ema_current(m); if (rc) return rc; }
     hipStream_t s = m.train_stream;
-    HIPCHECK(hipStreamSynchronize(s));
-    HIPCHECK(hipMemcpy(&m.h_state, m.d_state, offsetof(DevState, n_scatter), hipMemcpyDeviceToHost));      // (the head: the slot counters behind it are 16 KB the host never reads)
+    // (no state read-back: every call that advances the optimizer ends with sync_state, so the host's copy of the step counter is current whenever this thread gets here --
+    //  the read-back and the synchronisation in front of it were two host round trips per render)
     const uint16_t* prm = (m.h_state.step > 0) ? m.P.ema : m.P.half;
     Mat4 pose; std::memcpy(pose.m, pose16, 64);
     const uint32_t n_pix = box.w * box.h, S2 = 2 * m.oc.S;
-    const hipMemcpyKind kind = dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    if (n_pix > m.out_cap) {                                         // whole-crop output buffers (grow-only): all chunks are enqueued back to back, one copy-out and one sync per call
+    if (n_pix > m.out_cap) {                                         // whole-crop output buffer (grow-only): all chunks are enqueued back to back, one copy-out and one sync per call
         const size_t cap = std::max<size_t>(n_pix, 2 * m.out_cap);   // doubling: the superseded buffers (freed with the object) add up to less than the live one
-        int rc; if ((rc = dev_alloc(m, m.d_out_rgb, 3 * cap, false)) || (rc = dev_alloc(m, m.d_out_depth, cap, false)) || (rc = dev_alloc(m, m.d_out_mask, cap, false))) return rc;
+        int rc; if ((rc = dev_alloc(m, m.d_out_all, 5 * cap, false))) return rc;
         m.out_cap = cap;
+    }
+    m.d_out_rgb = m.d_out_all; m.d_out_depth = m.d_out_all + 3 * (size_t)n_pix; m.d_out_mask = m.d_out_all + 4 * (size_t)n_pix;      // rgb | depth | mask of THIS crop, back to back
+    if (!dst_on_device && 5 * (size_t)n_pix > m.h_out_cap) {          // pinned staging: one device-to-host copy instead of three into pageable memory
+        const size_t cap = std::max<size_t>(5 * (size_t)n_pix, 2 * m.h_out_cap); float* q = nullptr;
+        HIPCHECK(hipHostMalloc((void**)&q, cap * sizeof(float), hipHostMallocDefault));
+        if (m.h_out) (void)hipHostFree(m.h_out);
+        m.h_out = q; m.h_out_cap = cap;
     }
     if (m.d_xw) {          // XORWOW mode: a NEW generator per Render (default seed) draws the whole crop's RandDt in one call (nerf_model.cu:1725-1728, :1781)
         const size_t need = (size_t)n_pix * S2;
@@ -955,10 +962,16 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
             launch_fused_render(s, m.lf, m.nd, prm, m.B, m.oc, n, p0 * S2, m.d_out_rgb + 3 * (size_t)p0, m.d_out_depth + p0, m.d_out_mask + p0, m.d_frag_render, p0 == 0u);
         }
     }
-    HIPCHECK(hipMemcpyAsync(rgb, m.d_out_rgb, 12 * (size_t)n_pix, kind, s));
-    HIPCHECK(hipMemcpyAsync(depth, m.d_out_depth, 4 * (size_t)n_pix, kind, s));
-    HIPCHECK(hipMemcpyAsync(mask, m.d_out_mask, 4 * (size_t)n_pix, kind, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    if (dst_on_device) {
+        HIPCHECK(hipMemcpyAsync(rgb, m.d_out_rgb, 12 * (size_t)n_pix, hipMemcpyDeviceToDevice, s));
+        HIPCHECK(hipMemcpyAsync(depth, m.d_out_depth, 4 * (size_t)n_pix, hipMemcpyDeviceToDevice, s));
+        HIPCHECK(hipMemcpyAsync(mask, m.d_out_mask, 4 * (size_t)n_pix, hipMemcpyDeviceToDevice, s));
+        HIPCHECK(hipStreamSynchronize(s));
+    } else {
+        HIPCHECK(hipMemcpyAsync(m.h_out, m.d_out_all, 20 * (size_t)n_pix, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        std::memcpy(rgb, m.h_out, 12 * (size_t)n_pix); std::memcpy(depth, m.h_out + 3 * (size_t)n_pix, 4 * (size_t)n_pix); std::memcpy(mask, m.h_out + 4 * (size_t)n_pix, 4 * (size_t)n_pix);
+    }
     HIPCHECK(hipGetLastError());
     collect_profile(m);
     return MON_OK;

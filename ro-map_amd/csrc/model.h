@@ -257,7 +257,8 @@ struct Model {
     uint32_t* d_ema_step = nullptr; uint8_t* d_touched = nullptr;                  // lazy EMA bookkeeping, chunk flags (ParamPtrs)
     uint8_t* d_big_ws = nullptr; uint32_t big_switch = 0; bool big_active = false; // kernels_bigscatter.hip: workspace, switch point, launched in this train call
     uint32_t *d_occ = nullptr, *d_occ_tmp = nullptr; uint16_t* d_frag_occ = nullptr; float occ_raw_threshold = 0.f; uint32_t occ_refreshed_iter = 0, occ_next_refresh = 0;   // occupancy grid (cfg.occupancy_skip)
-    float *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr; size_t out_cap = 0;   // whole-crop render outputs (grow-only)
+    float *d_out_all = nullptr, *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr; size_t out_cap = 0;   // whole-crop render outputs: ONE grow-only buffer, rgb | depth | mask of the current crop back to back
+    float* h_out = nullptr; size_t h_out_cap = 0;                                                            // pinned staging of a crop on its way to the caller's (pageable) buffers
     std::vector<void*> allocs;
     DevState h_state{}; DevState* h_state_pinned = nullptr; int backend = 0; bool profiling = false; int fused_dump = 0;
     bool lazy_ema = false, ema_pending = false;   // large tables: EMA of untouched chunks is brought up to date on demand (k_ema_finalize)
