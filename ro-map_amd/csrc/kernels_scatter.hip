@@ -78,7 +78,16 @@ __device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bo
     unsigned long long* tab64 = reinterpret_cast<unsigned long long*>(tab);
     // (the fp32 products pass through an opaque register pair: h(w * g) is the ROUNDED product rounded again, like tcnn's `(T)(weight * grad)` and the oracle -- the
     //  compiler's own choice, v_fma_mixlo_f16, rounds the exact product once and differs in ~2^-13 of the contributions)
-    const auto fix2 = [&](f2 w, float gg) -> f2 { f2 pr = w * gg; asm volatile("" : "+v"(pr)); return f2{ (float)(half_t)pr.x, (float)(half_t)pr.y } * fs; };      // contrib_fix of two corners, before the conversion to int
+    //  Per pair of corners: v_pk_mul_f32 (x g), v_cvt_pk_f16_f32 (both h()), then the widening back to fp32 and the multiplication by the fixed-point unit as ONE
+    //  v_fma_mix_f32 per value (fp16 source operand: exact) -- six instructions where conversions + a packed multiply took eight.
+    const auto fix2 = [&](f2 w, float gg) -> f2 {
+        f2 pr = w * gg; asm volatile("" : "+v"(pr));
+        const half2_t hv = { (half_t)pr.x, (half_t)pr.y }; const uint32_t hb = __builtin_bit_cast(uint32_t, hv);
+        f2 r;
+        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r.x) : "v"(hb), "s"(fs));
+        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.y) : "v"(hb), "s"(fs));
+        return r;
+    };      // contrib_fix of two corners, before the conversion to int
     if (MODE == kTileWhole64) {                                   // the whole level is this workgroup's: eight corners, nothing to test, one 64-bit atomic each
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                             // the two x-corners of pair j = y + 2 z
@@ -98,9 +107,10 @@ __device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bo
         // size matter), so that a corner's place in the int32 tile comes out as its byte address -- (h >> 1) << 2 = h2 & mask4 -- and the four address shifts in
         // front of the atomics disappear (the tile starts at LDS address 0: the kernel has no static LDS, checked at its entry)
         const uint32_t my2 = my << 1, mz2 = mz << 1, mask4 = (mask << 1) & ~3u;
-        const uint32_t y2 = __umul24(pg[1], my2 & 0xffffffu), z2 = __umul24(pg[2], mz2 & 0xffffffu);
+        uint32_t y2 = __umul24(pg[1], my2 & 0xffffffu), z2 = __umul24(pg[2], mz2 & 0xffffffu);
+        asm volatile("" : "+v"(y2), "+v"(z2));      // (kept as products: y2 + my2 is then one add with a scalar operand; the compiler's v_mad_u32_u24 needs the addend moved into a vector register first)
         const uint32_t ay2[2] = { y2, y2 + my2 }, az2[2] = { z2, z2 + mz2 };
-        const uint32_t axp2 = (ax0 ^ parity) << 1, dx4 = (((ax0 ^ ax1) & mask) << 1) & ~3u;
+        const uint32_t a2 = ax0 << 1, axp2 = a2 ^ (parity << 1), dx4 = (a2 ^ (a2 + 2u)) & mask4;      // ((x ^ (x + 1)) << 1 = 2x ^ (2x + 2); its bit 1 falls to mask4)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (DEGEN && j) { local[j] = local[0]; ws[j] = ws[0]; continue; }
