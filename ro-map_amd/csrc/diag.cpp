@@ -67,14 +67,14 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
     }
     HIPCHECK(hipMemcpy(dst, src, sz, hipMemcpyDeviceToHost));
     if (which == MON_BUF_GGRID_H && m.backend == 1 && m.lds_mask) {        // total gradient = atomic table + sum of the scatter partials
-        std::vector<uint16_t> part(m.n_grid); std::vector<float> acc(m.n_grid);
+        std::vector<uint16_t> part(m.part_halves); std::vector<float> acc(m.n_grid);
         uint16_t* out = reinterpret_cast<uint16_t*>(dst);
         for (uint32_t i = 0; i < m.n_grid; ++i) { _Float16 h; std::memcpy(&h, &out[i], 2); acc[i] = (float)h; }
-        const uint32_t n_ent = m.n_grid / 2, n_half = n_ent / 2;              // partial tables are planar: [partition][feature][parity][entry / 2]
+        const uint32_t n_ent = m.part_halves / 2, n_half = n_ent / 2;         // partial tables are planar: [partition][feature][parity][entry / 2], over the LDS-scattered levels' entries
         for (uint32_t q = 0; q < m.scatter.max_P; ++q) {
-            HIPCHECK(hipMemcpy(part.data(), m.d_gpart + (size_t)q * m.n_grid, (size_t)m.n_grid * 2, hipMemcpyDeviceToHost));
+            HIPCHECK(hipMemcpy(part.data(), m.d_gpart + (size_t)q * m.part_halves, (size_t)m.part_halves * 2, hipMemcpyDeviceToHost));
             for (int l = 0; l < m.nd.L; ++l) {
-                if (q >= m.scatter.P[l]) continue;                              // this level has fewer partial tables: the rest of the buffer is not its data
+                if (q >= m.scatter.P[l] || !((m.lds_mask >> l) & 1u)) continue;                              // this level has fewer partial tables: the rest of the buffer is not its data
                 for (uint32_t e = m.lt.offset[l]; e < m.lt.offset[l + 1]; ++e) for (uint32_t f = 0; f < 2; ++f) { _Float16 h; std::memcpy(&h, &part[((size_t)f * 2 + (e & 1u)) * n_half + (e >> 1)], 2); acc[2 * e + f] += (float)h; }
             }
         }

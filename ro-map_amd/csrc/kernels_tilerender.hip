@@ -271,7 +271,7 @@ struct TileMlpArgs {
     const float4_t* rec; const uint32_t* count; uint32_t job_base, jobs_cap;
     const float4_t* x;            // [cap] {x, y, z, t}
     const uint16_t* e; uint32_t cap;
-    uint32_t n_points;            // k_tile_points_mlp: points of the chunk
+    uint32_t n_points;            // k_tile_points_mlp: points of the chunk; k_tile_render: pixels of the crop
 };
 
 template <int EPAD, int W, int NH>
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) k_tile_render(TileMlpArgs a, float* __res
         float o0 = 1.f, o1 = 1.f, o2 = 1.f, od = 0.f, om_ = 0.f;
         if (1.f - Tc > 0.5f) { o0 = r0 + Tc; o1 = r1 + Tc; o2 = r2 + Tc; od = dep / rc.x; om_ = 1.f; }      // :1213-1220
         const float rc_y = rc.y; const uint32_t pix = __builtin_bit_cast(uint32_t, rc_y);
-        if (lane == 0) { rgb[3 * (size_t)pix] = o0; rgb[3 * (size_t)pix + 1] = o1; rgb[3 * (size_t)pix + 2] = o2; depth[pix] = od; mask[pix] = om_; }
+        if (lane == 0 && pix < a.n_points) { rgb[3 * (size_t)pix] = o0; rgb[3 * (size_t)pix + 1] = o1; rgb[3 * (size_t)pix + 2] = o2; depth[pix] = od; mask[pix] = om_; }      // (n_points = the crop's pixels: a record is never trusted with an address)
     }
 }
 
@@ -452,8 +452,8 @@ static void frag_image_t(hipStream_t s, const uint16_t* params, int L, uint16_t*
 }
 
 void launch_tile_render(hipStream_t s, const NetDims& nd, const ObjectConst& oc, const uint16_t* frag_image, const float* rec, const uint32_t* count,
-                        uint32_t job_base, uint32_t jobs_cap, const float* x, const uint16_t* e, uint32_t cap, float* rgb, float* depth, float* mask) {
-    TileMlpArgs a{ nd, oc, frag_image, reinterpret_cast<const float4_t*>(rec), count, job_base, jobs_cap, reinterpret_cast<const float4_t*>(x), e, cap, 0u };
+                        uint32_t job_base, uint32_t jobs_cap, const float* x, const uint16_t* e, uint32_t cap, uint32_t n_pix, float* rgb, float* depth, float* mask) {
+    TileMlpArgs a{ nd, oc, frag_image, reinterpret_cast<const float4_t*>(rec), count, job_base, jobs_cap, reinterpret_cast<const float4_t*>(x), e, cap, n_pix };
     MON_FUSED_DISPATCH(tile_render_t, s, a, rgb, depth, mask);
 }
 void launch_tile_points_mlp(hipStream_t s, const NetDims& nd, const uint16_t* frag_image, const uint16_t* e, uint32_t cap, uint32_t n_points, uint16_t* O) {

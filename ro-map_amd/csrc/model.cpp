@@ -129,7 +129,13 @@ int tile_ws_get(Model& m, int side, size_t n_pix, TileWs** out) {
     std::lock_guard<std::mutex> l(ws.mu);
     int rc;
     const uint32_t cap = kTileChunkJobs * 64u;
-    if (!ws.counters) { if ((rc = ws_grow(ws.counters, 64))) return rc; HIPCHECK(hipMemset(ws.counters, 0, 256)); }
+    if (!ws.counters) {
+        if ((rc = ws_grow(ws.counters, 64))) return rc;
+        // (hipMemset of device memory may return before the fill has run, and the renders' streams are non-blocking: without the synchronisation the fill can land
+        //  in the middle of the first render's ray kernel -- the job count restarts, k_tile_render reads job records nobody wrote and writes to the pixel index it
+        //  finds there: the memory fault of the object-churn test, seen whenever a device's last object had returned the workspace)
+        HIPCHECK(hipMemset(ws.counters, 0, 256)); HIPCHECK(hipDeviceSynchronize());
+    }
     if (ws.cap < cap || ws.L_cap < m.nd.L) {
         const int L = std::max(ws.L_cap, m.nd.L);
         if ((rc = ws_grow(ws.x, 4 * (size_t)cap)) || (rc = ws_grow(ws.e, (size_t)L * 2 * cap)) || (rc = ws_grow(ws.O, 4 * (size_t)cap))) return rc;
@@ -172,7 +178,7 @@ static void tile_render_crop(Model& m, TileWs& ws, hipStream_t s, const ObjectCo
         const uint32_t jc = std::min(kTileChunkJobs, n_pix - j0);
         launch_render_points(s, oc, ws.rec, cnt, j0, jc, ws.x);
         launch_encode_feat(s, m.lf, m.nd, ws.image, ws.x, ws.e, ws.cap, 0u, cnt, j0, jc, 2u * oc.S);
-        launch_tile_render(s, m.nd, oc, ws.frag, ws.rec, cnt, j0, jc, ws.x, ws.e, ws.cap, rgb, depth, mask);
+        launch_tile_render(s, m.nd, oc, ws.frag, ws.rec, cnt, j0, jc, ws.x, ws.e, ws.cap, n_pix, rgb, depth, mask);
     }
 }
 // whether a crop of n_pix rays goes to the tile path (option tile_render: 0 never, 1 from 4096 rays up -- below that the tile copies cost what the gathers cost --, 2 always)
@@ -452,7 +458,10 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     // ---- workspace (AllocateBatchWorkspace :1344-1427), sized for max(train batch, render chunk)
     const uint32_t R = m.oc.R, S = m.oc.S;
     m.ws_rays = R > kRenderChunkRays ? R : kRenderChunkRays;
-    const uint32_t Btrain = R * S, Brender = kRenderChunkRays * 2 * S;
+    // the layer-at-a-time buffers (pts, tdist, E, O) serve a render pass of the unfused backend; an object whose inference runs on the fused kernels / level tiles
+    // only needs them at the training batch's size (64 + 12 + 8 + 4 MB less per base.json object: a render of the unfused backend then takes passes of ws_samples / 2S rays)
+    const bool fused_inference = fused_supported(m.nd, S, R) && options().backend != 0;
+    const uint32_t Btrain = R * S, Brender = fused_inference ? Btrain : kRenderChunkRays * 2 * S;
     m.ws_samples = Btrain > Brender ? Btrain : Brender;
     BatchPtrs& B = m.B;
     if ((rc = dev_alloc(m, B.cand_o, 3 * (size_t)R)) || (rc = dev_alloc(m, B.cand_d, 3 * (size_t)R)) || (rc = dev_alloc(m, B.cand_dn, R)) ||
@@ -482,8 +491,13 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     if (fused_supported(m.nd, S, m.oc.R)) {
         if ((rc = dev_alloc(m, m.d_frag_train, 64 * 512)) || (rc = dev_alloc(m, m.d_frag_render, 64 * 512))) return rc;       // <= 30 fragments of 512 halves
         m.lds_mask = scatter_plan(m.lt, m.nd, m.scatter);
+        {   // a partial table spans the entries up to the end of the LAST LDS-scattered level (the plan covers a prefix of the levels: sizes grow with the level); sized by the
+            // whole table it was 16 x 211 MB = 3.4 GB of a T = 2^22 object for the 37 k entries of its two small levels
+            int last = -1; for (int l = 0; l < m.nd.L; ++l) if ((m.lds_mask >> l) & 1u) last = l;
+            m.part_halves = last < 0 ? 0u : ((2u * m.lt.offset[last + 1] + 15u) & ~15u);
+        }
         if (m.lds_mask && ((rc = dev_alloc(m, m.d_de_soa, (size_t)m.nd.L * Btrain * 2)) || (rc = dev_alloc(m, m.d_x_soa, 4 * (size_t)Btrain)) ||
-                           (rc = dev_alloc(m, m.d_gpart, (size_t)m.scatter.max_P * m.n_grid)))) return rc;
+                           (rc = dev_alloc(m, m.d_gpart, (size_t)m.scatter.max_P * m.part_halves)))) return rc;
         // Levels beyond the LDS plan (more than 2^18 entries): binned exact scatter while many samples carry a gradient (kernels_bigscatter.hip).
         // MON_BIG_SWITCH = gradient-carrying samples below which the global-atomic path takes over (0: atomics always).
         const size_t big_bytes = m.lds_mask ? big_scatter_workspace_bytes(m.lt, m.nd, m.lds_mask, Btrain) : 0;
@@ -728,7 +742,7 @@ static void enqueue_iteration(Model& m, int stages) {
     }
     if ((stages & 2) && m.backend == 1) {
         const bool folded = m.lds_mask && grid_scatter_sums_partials(m.lt, m.nd);   // the scatter workgroups also sum the dW partial rows
-        if (m.lds_mask) { ProfScope ps(m, MON_K_SCATTER); launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_gpart, m.n_grid / 2, m.d_state,
+        if (m.lds_mask) { ProfScope ps(m, MON_K_SCATTER); launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_gpart, m.part_halves / 2, m.d_state,
                                                                                 folded ? m.d_dw_partials : nullptr, fused_train_grid(m.nd, m.oc.R), m.P.gmlp, m.d_state_next); }
         if (m.big_active) { ProfScope ps(m, MON_K_SCATTER); launch_big_scatter(s, m.lt, m.lf, m.nd, m.lds_mask, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_state, m.big_switch, m.d_big_ws, m.P.ggrid, m.d_touched ? m.d_touched + (m.nd.n_mlp >> 3) : nullptr); }
         if (!folded) { ProfScope ps(m, MON_K_REDUCE); launch_reduce_partials(s, m.d_dw_partials, fused_train_grid(m.nd, m.oc.R), m.nd, m.P.gmlp, m.d_state); }
@@ -736,7 +750,7 @@ static void enqueue_iteration(Model& m, int stages) {
     if (stages & 4) {      // Trainer::optimizer_step :1644
         ProfScope ps(m, MON_K_OPTIM);
         ParamPtrs P = m.P;
-        if (m.backend == 1 && m.lds_mask) { P.gpart = m.d_gpart; P.part_stride = m.n_grid; P.sl = m.scatter; P.all_levels_dense = (m.lds_mask == ((1u << m.nd.L) - 1u)) ? 1 : 0; }
+        if (m.backend == 1 && m.lds_mask) { P.gpart = m.d_gpart; P.part_stride = m.part_halves; P.sl = m.scatter; P.all_levels_dense = (m.lds_mask == ((1u << m.nd.L) - 1u)) ? 1 : 0; }
         P.half_tiles = (m.backend == 1 && P.gpart && P.all_levels_dense) ? m.d_half_tiles : nullptr;
         const bool lazy = m.lazy_ema && !(P.gpart && P.all_levels_dense);
         P.ema_step = lazy ? m.d_ema_step : nullptr; if (lazy) m.ema_pending = true;
@@ -949,8 +963,11 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
         tile_ws_weights(m, *tws, s, prm, m.weights_epoch);
         tile_render_crop(m, *tws, s, m.oc, box, pose, pose_is_Toc, m.d_out_rgb, m.d_out_depth, m.d_out_mask);
     } else
-    for (uint32_t p0 = 0; p0 < n_pix; p0 += kRenderChunkRays) {
-        const uint32_t n = (n_pix - p0) < kRenderChunkRays ? (n_pix - p0) : kRenderChunkRays;
+    {
+      // rays per pass: the fused kernel takes kRenderChunkRays; the layer-at-a-time kernels what their sample buffers hold
+      const uint32_t pass = m.backend == 0 ? std::max(1u, std::min(kRenderChunkRays, m.ws_samples / S2)) : kRenderChunkRays;
+      for (uint32_t p0 = 0; p0 < n_pix; p0 += pass) {
+        const uint32_t n = (n_pix - p0) < pass ? (n_pix - p0) : pass;
         ProfScope ps(m, MON_K_RENDER);
         launch_render_rays(s, m.B, m.ds->K, m.oc, box, pose, pose_is_Toc, p0, n);
         if (m.backend == 0) {
@@ -961,6 +978,7 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
         } else {
             launch_fused_render(s, m.lf, m.nd, prm, m.B, m.oc, n, p0 * S2, m.d_out_rgb + 3 * (size_t)p0, m.d_out_depth + p0, m.d_out_mask + p0, m.d_frag_render, p0 == 0u);
         }
+      }
     }
     if (dst_on_device) {
         HIPCHECK(hipMemcpyAsync(rgb, m.d_out_rgb, 12 * (size_t)n_pix, hipMemcpyDeviceToDevice, s));

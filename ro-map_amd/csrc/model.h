@@ -218,7 +218,7 @@ void launch_mesh_warp4(hipStream_t s, const float* verts, float* x, uint32_t v0,
 void launch_encode_feat(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* image, const float* x, uint16_t* e, uint32_t cap,
                         uint32_t n_host, const uint32_t* count, uint32_t job_base, uint32_t jobs_cap, uint32_t spj);
 void launch_tile_render(hipStream_t s, const NetDims& nd, const ObjectConst& oc, const uint16_t* frag_image, const float* rec, const uint32_t* count,
-                        uint32_t job_base, uint32_t jobs_cap, const float* x, const uint16_t* e, uint32_t cap, float* rgb, float* depth, float* mask);
+                        uint32_t job_base, uint32_t jobs_cap, const float* x, const uint16_t* e, uint32_t cap, uint32_t n_pix, float* rgb, float* depth, float* mask);
 void launch_tile_points_mlp(hipStream_t s, const NetDims& nd, const uint16_t* frag_image, const uint16_t* e, uint32_t cap, uint32_t n_points, uint16_t* O);
 void launch_candidates_and_frags(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st, const uint16_t* params, const NetDims& nd, uint16_t* frag_image);
 int selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
@@ -252,6 +252,7 @@ struct Model {
     uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr;       // compacted dL/dE rows [L][B] and positions [B] float4 for the scatter kernels
     float* d_x_all = nullptr; uint16_t* d_e_soa = nullptr; uint16_t* d_half_tiles = nullptr;        // level-tile encode: positions [B] float4 of every sample, encoded features [L][B] half2 (nullptr: the fused kernel gathers)
     uint16_t* d_gpart = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0;   // k_grid_scatter: partial tables, plan, levels it covers
+    uint32_t part_halves = 0;                                     // halves of ONE partial table: the grid parameters of the LDS-scattered levels (a prefix of the levels), not of the whole table
     uint16_t* d_frag_train = nullptr; uint16_t* d_frag_render = nullptr;           // MFMA A-fragment images (training weights / inference weights)
     uint32_t n_bins = 16;                                         // ray bins of the compacted gradient rows (scatter_bins(R) unless the option caps it)
     uint32_t* d_ema_step = nullptr; uint8_t* d_touched = nullptr;                  // lazy EMA bookkeeping, chunk flags (ParamPtrs)
