@@ -257,7 +257,7 @@ int mon_get_option(const char* name, long* value);
 
 /* Whole-device helpers used by bench.py. */
 int mon_device_synchronize(int device);
-int mon_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes);   /* hipMemGetInfo: sizing how many object NeRFs a device takes (base.json: 38 MB each, T = 2^22: 2.2 GB) */
+int mon_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes);   /* hipMemGetInfo: sizing how many object NeRFs a device takes (measured: base.json 198 MB each incl. workspaces, T = 2^22 2.5 GB; + ~190 MB once per device for the render workspace) */
 /* Staged-execution companion (tests): the fused backend also writes its intermediate activations into the debug buffers (slower);
  * they are read back through libmon_core_diag.so (include/mon_core_diag.h).  enable = 1: on the gather chain (every level's grid gradient through
  * global atomics, readable as one table); 2: on the chain the object would run anyway (level tiles -> k_fused_train<PRE> -> k_grid_scatter). */
