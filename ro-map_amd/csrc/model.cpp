@@ -157,6 +157,7 @@ static void tile_ws_object_gone(int device) {
         ws.rec_cap = 0; ws.cap = 0; ws.L_cap = 0; ws.image_cap = 0; ws.flip = 0; ws.key_params = nullptr; ws.key_epoch = ~0ull;
     }
 }
+static int tile_ws_objects(int device) { std::lock_guard<std::mutex> l(g_tile_mu); auto it = g_tile_ws.find(device); return it == g_tile_ws.end() ? 0 : it->second->objects; }
 void tile_ws_weights(Model& m, TileWs& ws, hipStream_t s, const uint16_t* prm, uint64_t epoch) {
     if (ws.key_params == prm && ws.key_epoch == epoch) return;
     launch_build_feat_image(s, m.lf, m.nd, prm, ws.image, nullptr);
@@ -884,8 +885,12 @@ int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int
         is->out_all = (float*)q; is->out_cap = cap;
     }
     is->out_rgb = is->out_all; is->out_depth = is->out_all + 3 * (size_t)n_pix; is->out_mask = is->out_all + 4 * (size_t)n_pix;
+    // A viewer's render competes with the training kernels of every object on the device.  k_encode_feat's workgroups need a whole CU each (160 KB of LDS) and wait until
+    // training workgroups have drained from one; the gather render's small workgroups slip in anywhere.  Measured (tools/online_replay.py, 60 keyframes every 50 ms,
+    // mean / p99 of the viewer's crop): 1 object 0.85 / 1.13 ms on tiles against 1.20 / 1.93 ms through the gathers, 4 objects 0.51 / 2.0 against 0.68 / 1.7,
+    // 12 objects 0.58 / 3.1 against 0.67 / 1.7 -- so the tiles serve the viewer while few objects train on the device, the gathers once many do.
     TileWs* tws = nullptr; std::unique_lock<std::mutex> tile_lock;
-    if (tile_render_wanted(m, n_pix)) {                                  // level tiles in LDS (kernels_tilerender.hip); the inference side's own workspace
+    if (tile_render_wanted(m, n_pix) && (options().tile_render >= 2 || tile_ws_objects(m.device) <= 4)) {      // level tiles in LDS (kernels_tilerender.hip); the inference side's own workspace
         { const int rc = tile_ws_get(m, 1, n_pix, &tws); if (rc) return rc; }
         tile_lock = std::unique_lock<std::mutex>(tws->mu);                // (held until the stream is synchronised below)
         uint64_t ep; { std::lock_guard<std::mutex> l(is->mu); ep = is->epoch_of[r]; }
