@@ -50,17 +50,19 @@ typedef struct mon_config {
     int32_t  decay_start, decay_interval;
     float    decay_base;
     uint32_t param_seed;           /* m_seed (1337)                                          */
-    uint32_t rng_flags;            /* "same inputs" mode for a comparison with the CUDA build; 0 (default) = this repo's own streams:
-                                    *   bits 0-1   sample stream: 0 counter RNG keyed by sample_seed | 1 XORWOW in the reference's order of draws, cuRAND
-                                    *              flavour (nerf_model.cu:1432,1434,1468 and :1781; default seed) | 2 the same with rocRAND's seeding / float map
-                                    *   bit  4     parameter init in tcnn's generate_random_uniform element order (pcg32 draws interleaved per thread)
-                                    *   bits 16-31 XORWOW lanes in units of 1024 (0 = 4: cuRAND's 4096 subsequences)   -- ro-map_amd/csrc/xorwow.h */
+    /* rng_flags: "same inputs" mode for a comparison with the CUDA build; 0 (default) = this repo's own streams:
+     *   bits 0-1   sample stream: 0 counter RNG keyed by sample_seed | 1 XORWOW in the reference's order of draws, cuRAND flavour
+     *              (nerf_model.cu:1432,1434,1468 and :1781; default seed) | 2 the same with rocRAND's seeding / float map
+     *   bit  4     parameter init in tcnn's generate_random_uniform element order (pcg32 draws interleaved per thread)
+     *   bits 16-31 XORWOW lanes in units of 1024 (0 = 4: cuRAND's 4096 subsequences)   -- ro-map_amd/csrc/xorwow.h */
+    uint32_t rng_flags;
     uint64_t sample_seed;          /* key of the counter RNG that replaces the cuRAND XORWOW stream by default */
     int32_t  use_depth;            /* NeRF_Model::mbUseDepth                                 */
-    int32_t  occupancy_skip;       /* 0 (default, the reference's behaviour: every one of the 32 samples of a ray is evaluated) | 1: occupancy-grid skipping -- a 64^3
-                                    * bit grid over the object's box, refreshed from the training weights every 32 iterations after 256 warm-up iterations and dilated
-                                    * by one cell; samples in empty cells are not evaluated (no table gathers, no contribution, no gradient).  An approximation the
-                                    * reference does not have: parity runs leave it off. */
+    /* occupancy_skip: 0 (default, the reference's behaviour: every one of the 32 samples of a ray is evaluated) | 1: occupancy-grid skipping -- a 64^3 bit
+     * grid over the object's box, refreshed from the training weights (every 32 iterations at first, every 512 later) after 256 warm-up iterations and
+     * dilated by one cell; samples in empty cells are not evaluated (no table reads, no contribution, no gradient).  An approximation the reference does
+     * not have: parity runs leave it off. */
+    int32_t  occupancy_skip;
 } mon_config;
 
 /* CORE/include/common.h:18-23 (note: h before w). */
@@ -82,7 +84,8 @@ typedef struct mon_object_info {
 } mon_object_info;
 
 /* Kernel classes timed with HIP events on the object's train stream when profiling is on. */
-enum { MON_K_BATCH = 0, MON_K_FWDBWD = 1, MON_K_OPTIM = 2, MON_K_RENDER = 3, MON_K_SCATTER = 4, MON_K_REDUCE = 5, MON_K_ENCODE = 6 /* k_encode_tiles */, MON_K_POINTS = 7 /* k_sample_points */, MON_K_COUNT = 8 };
+enum { MON_K_BATCH = 0, MON_K_FWDBWD = 1, MON_K_OPTIM = 2, MON_K_RENDER = 3, MON_K_SCATTER = 4, MON_K_REDUCE = 5, MON_K_ENCODE = 6 /* k_encode_tiles */,
+       MON_K_POINTS = 7 /* k_sample_points */, MON_K_COUNT = 8 };
 /* FWDBWD = k_fused_train alone (fused backend) or the unfused forward/backward kernel group; SCATTER = k_grid_scatter; REDUCE = k_reduce_partials. */
 typedef struct mon_profile { double ms[MON_K_COUNT]; uint64_t launches[MON_K_COUNT]; } mon_profile;
 
@@ -96,7 +99,8 @@ int mon_device_count(int* n_devices);
  * per device (nerf.cu:27-33, nerf_manager.cu:44-55) can be driven -- oversubscribed -- on a box with fewer GPUs; 0 restores the default.  Call before
  * creating datasets / managers. */
 int mon_set_logical_devices(int n);
-int mon_physical_device(int logical_device, int* physical_device);   /* the HIP device a logical device runs on (what a multi-device consumer groups objects by) */
+/* the HIP device a logical device runs on (what a multi-device consumer groups objects by) */
+int mon_physical_device(int logical_device, int* physical_device);
 
 /* NeRF_Model::ReadNetworkConfig (nerf_model.cu:1272-1284): tcnn JSON with comments. */
 int mon_config_default(mon_config* cfg);                       /* CORE/configs/base.json values */
@@ -159,7 +163,8 @@ int mon_object_get_mesh(mon_object* obj, float* verts, float* normals, uint8_t* 
  * the needed counts in n_* when a buffer is too small; MON_ERR_STATE when try_lock_only and the trainer holds the mesh, or no mesh yet. */
 int mon_object_copy_mesh(mon_object* obj, uint32_t cap_verts, uint32_t cap_indices, float* verts, float* normals, uint8_t* colors, uint32_t* indices,
                          uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices, int try_lock_only);
-int mon_object_mesh_generation(mon_object* obj, uint64_t* generation);                  /* lock-free: number of meshes published so far (0 = none); a viewer copies again only when it changed */
+/* lock-free: number of meshes published so far (0 = none); a viewer copies again only when it changed */
+int mon_object_mesh_generation(mon_object* obj, uint64_t* generation);
 int mon_object_get_mesh_raw(mon_object* obj, float* normals_raw, float* colors_f32);      /* un-normalised normals, float colours (parity tests) */
 int mon_object_save_mesh(mon_object* obj, const char* path);                              /* ".ply" -> ASCII ply, anything else -> obj */
 /* Marching cubes + normals on a caller-supplied lattice (x fastest); buffers may be NULL to query the counts. */
@@ -167,7 +172,8 @@ int mon_marching_cubes(int device, const float* density, int rx, int ry, int rz,
                        float* verts, float* normals_raw, uint32_t* indices, uint32_t cap_verts, uint32_t cap_indices,
                        uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices);
 
-int mon_object_get_config(mon_object* obj, mon_config* cfg);                               /* the configuration the object was created with (borrowed objects of the managers: base.json as read) */
+/* the configuration the object was created with (borrowed objects of the managers: base.json as read) */
+int mon_object_get_config(mon_object* obj, mon_config* cfg);
 int mon_object_info_get(mon_object* obj, mon_object_info* info);
 /* Parameter I/O (the reference has none; needed for fixtures/checkpoints).
  * which: 0 fp32 master, 1 fp16 working copy, 2 fp16 EMA (inference) copy. */
@@ -200,10 +206,14 @@ int mon_offline_render_test(mon_offline* mgr, int idx, const char* out_dir, int 
  * Buffers may be NULL to query the counts. */
 int mon_offline_get_intrinsics(mon_offline* mgr, float* fx, float* fy, float* cx, float* cy, int* H, int* W);
 int mon_offline_get_poses(mon_offline* mgr, float* Twc16s, size_t capacity_frames, size_t* n_frames);
-int mon_offline_object_meta(mon_offline* mgr, int idx, int* class_id, float* Tow16, float* aabb_min3, float* aabb_max3, mon_frame_bbox* boxes, size_t capacity_boxes, size_t* n_boxes);
-int mon_offline_object_stamp(mon_offline* mgr, int idx, size_t box_index, char* buf, size_t capacity);   /* the timestamp string of the object's box_index-th observation (the test images' file names) */
-int mon_offline_set_output_dir(mon_offline* mgr, const char* dir);       /* where the training thread saves <id>.ply (default "./output", nerf.cu:148; "" = do not save) */
-int mon_offline_object(mon_offline* mgr, int idx, mon_object** borrowed); /* GetAllNeRF()[idx]: owned by the manager, do not destroy; only mon_object_copy_mesh(try_lock) is safe while its thread trains */
+int mon_offline_object_meta(mon_offline* mgr, int idx, int* class_id, float* Tow16, float* aabb_min3, float* aabb_max3, mon_frame_bbox* boxes,
+        size_t capacity_boxes, size_t* n_boxes);
+/* the timestamp string of the object's box_index-th observation (the test images' file names) */
+int mon_offline_object_stamp(mon_offline* mgr, int idx, size_t box_index, char* buf, size_t capacity);
+/* where the training thread saves <id>.ply (default "./output", nerf.cu:148; "" = do not save) */
+int mon_offline_set_output_dir(mon_offline* mgr, const char* dir);
+/* GetAllNeRF()[idx]: owned by the manager, do not destroy; only mon_object_copy_mesh(try_lock) is safe while its thread trains */
+int mon_offline_object(mon_offline* mgr, int idx, mon_object** borrowed);
 int mon_offline_destroy(mon_offline* mgr);
 /* ---- nerf::NerfManagerOnline (CORE/include/nerf_manager.h:54-90, CORE/src/nerf_manager.cu:133-312) + the online half of nerf::NeRF
  * (nerf.cu:155-253, 406-448): per-object training thread sleeping on a condition variable, training gated on > 10 boxes,
@@ -214,7 +224,8 @@ int mon_online_init(mon_online* mgr);
 int mon_online_dataset_init(mon_online* mgr, float fx, float fy, float cx, float cy, int H, int W, size_t imgs);
 int mon_online_new_frame(mon_online* mgr, uint32_t img_id, const char* timestamp, const uint8_t* bgr, int channels, const uint8_t* instance,
                          const float* depth, const float* Twc16);                                   /* NewFrameToDataset */
-int mon_online_create_nerf(mon_online* mgr, int cls, const float* Tow16, const float* aabb_min3, const float* aabb_max3, size_t* idx_out);   /* CreateNeRF: 1.1x / 1.2x box inflation applied */
+/* CreateNeRF: 1.1x / 1.2x box inflation applied */
+int mon_online_create_nerf(mon_online* mgr, int cls, const float* Tow16, const float* aabb_min3, const float* aabb_max3, size_t* idx_out);
 int mon_online_update_nerf_bbox(mon_online* mgr, size_t idx, const mon_frame_bbox* boxes, size_t n, int train_step);                        /* UpdateNeRFBbox */
 int mon_online_get_frame_idx(mon_online* mgr, const char* timestamp, int* idx);                     /* GetFrameIdx (-1 if unknown) */
 /* NerfManagerOnline::UpdateDataset -> NeRF_Dataset::UpdateDataGPU (nerf_manager.cu:220-235, nerf_data.cu:341-353): the poses of frames
@@ -225,39 +236,48 @@ int mon_online_update_dataset(mon_online* mgr, uint32_t cur_id, uint32_t frame_n
 int mon_online_get_pose(mon_online* mgr, uint32_t frame_id, float* Twc16);
 int mon_online_wait_threads_end(mon_online* mgr);                                                  /* WaitThreadsEnd: request finish + join */
 int mon_online_object_info(mon_online* mgr, size_t idx, float* loss, int* train_calls, int* device, uint32_t* n_boxes);
-int mon_online_render(mon_online* mgr, size_t idx, mon_frame_bbox box, const float* Twc16, float* rgb, float* depth, float* mask);   /* one view of RenderNeRFsTest */
+/* one view of RenderNeRFsTest */
+int mon_online_render(mon_online* mgr, size_t idx, mon_frame_bbox box, const float* Twc16, float* rgb, float* depth, float* mask);
 /* RenderNeRFsTest(out_path, idx, stamps, boxes, Twcs, radius) -> NeRF::RenderTestImg (nerf.cu:255-404): test images + test.txt +
  * train.txt + the 60-view 360-degree video (RenderVideo, nerf_model.cu:1832-1990) + obj.ply under <out_path>/<id>/ */
 int mon_online_render_nerfs_test(mon_online* mgr, const char* out_path, size_t idx, const char* const* timestamps, const mon_frame_bbox* boxes,
                                  const float* Twcs16, size_t n, float radius);
 int mon_generate_toc(float theta_deg, float phi_deg, float radius, float* Toc16);   /* NeRF_Model::GenerateToc, nerf_model.cu:2186-2205 */
-int mon_online_object(mon_online* mgr, size_t idx, mon_object** borrowed);  /* DrawMesh(idx) reads this object's CPUMeshData through mon_object_copy_mesh(try_lock) */
+/* DrawMesh(idx) reads this object's CPUMeshData through mon_object_copy_mesh(try_lock) */
+int mon_online_object(mon_online* mgr, size_t idx, mon_object** borrowed);
 int mon_online_destroy(mon_online* mgr);
 
 /* PNG codec used for the sequence layout (8/16-bit, gray/RGB/RGBA in; gray/RGB out; 16-bit samples big-endian as in the file).
  * pixels may be NULL to query the header only. */
 int mon_png_read(const char* path, int* width, int* height, int* channels, int* bit_depth, uint8_t* pixels, size_t capacity);
 int mon_png_write(const char* path, int width, int height, int channels, int bit_depth, const uint8_t* pixels_big_endian);
-/* A rendered crop as the reference stores it (nerf.cu:335-349: img.convertTo(CV_8UC3, 255), depth.convertTo(CV_16UC1, 20000), mask.convertTo(CV_8UC1, 255); saturating,
- * round half to even); mask / mask_path may be NULL (RenderVideo writes none). */
-int mon_write_render_pngs(const char* img_path, const char* depth_path, const char* mask_path, uint32_t w, uint32_t h, const float* rgb, const float* depth, const float* mask);
+/* A rendered crop as the reference stores it (nerf.cu:335-349: img.convertTo(CV_8UC3, 255), depth.convertTo(CV_16UC1, 20000), mask.convertTo(CV_8UC1, 255);
+ * saturating, round half to even); mask / mask_path may be NULL (RenderVideo writes none). */
+int mon_write_render_pngs(const char* img_path, const char* depth_path, const char* mask_path, uint32_t w, uint32_t h, const float* rgb, const float* depth,
+        const float* mask);
 
 /* Process-wide test and tuning switches (none is needed for normal operation; defaults are the product behaviour).  Read when an object is
  * created or a training call is enqueued -- set them before.  Names: "backend" (-1 auto, 0 layer-at-a-time kernels, 1 fused), "use_graph" (replay
  * an iteration as a hipGraph), "lazy_ema" (-1 auto: tables above 8 M parameters), "big_switch" (gradient-carrying samples below which the
  * large-table levels scatter with global atomics; 0 = always), "touched_flags" (1 = on: the lazy optimizer's chunk flags), "lds_encode" (1 = on: the forward
  * hash-grid encode from LDS-resident level tiles, kernels_encode.hip; 0 = gathers inside k_fused_train -- both give bit-identical parameters),
- * "step_variant" (1: NeRF_Model::Step's sample-compaction schedule, nerf_model.cu:1504-1550, on the layer-at-a-time kernels -- the reference's own "unavailable, for
- * reference only" path, kept checkable; 0 = Step_No_Compacted, what both drivers train with), "roctx" (1: roctx ranges per phase), "ray_records",
- * "fused_grid", "opt_blocks" (workgroup caps, 0 = built-in), "scatter_bins" (ray bins of the compacted gradient rows, a power of two up to 128; 0 = built-in 16), "fused_ablate" (timing ablations of k_fused_train; bit 16 = keep zero-gradient
- * samples, used by the exactness test), "offline_outer" / "offline_inner" (NerfManagerOffline's 10 x 500 iterations, nerf_manager.cu:89).
+ * "step_variant" (1: NeRF_Model::Step's sample-compaction schedule, nerf_model.cu:1504-1550, on the layer-at-a-time kernels -- the reference's own
+ * "unavailable, for
+ * reference only" path, kept checkable; 0 = Step_No_Compacted, what both drivers train with), "roctx" (1: roctx ranges per phase), "tile_render"
+ * (inference on feature-planar level tiles: 0 never, 1 crops of 4096 rays and more + point queries, 2 always), "state_records" (1 = on: tables above
+ * 8 M parameters keep their optimizer state as 128-byte chunk records), "steps16" (1 = on: 16-bit per-chunk step counters of the lazy optimizer),
+ * "keep_zero_samples" (1: zero-gradient samples are scattered too -- the exactness test's A/B), "train_lanes" / "lane_chunk" (per-device training lanes),
+ * "online_slice_min" (shortest training slice of the online manager), "offline_outer" / "offline_inner" (NerfManagerOffline's 10 x 500 iterations,
+ * nerf_manager.cu:89).
  * Unknown names return MON_ERR_ARG. */
 int mon_set_option(const char* name, long value);
 int mon_get_option(const char* name, long* value);
 
 /* Whole-device helpers used by bench.py. */
 int mon_device_synchronize(int device);
-int mon_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes);   /* hipMemGetInfo: sizing how many object NeRFs a device takes (measured: base.json 198 MB each incl. workspaces, T = 2^22 2.5 GB; + ~190 MB once per device for the render workspace) */
+/* hipMemGetInfo: sizing how many object NeRFs a device takes (measured: base.json 198 MB each incl. workspaces, T = 2^22 2.5 GB; + ~190 MB once per device
+ * for the render workspace) */
+int mon_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
 /* Staged-execution companion (tests): the fused backend also writes its intermediate activations into the debug buffers (slower);
  * they are read back through libmon_core_diag.so (include/mon_core_diag.h).  enable = 1: on the gather chain (every level's grid gradient through
  * global atomics, readable as one table); 2: on the chain the object would run anyway (level tiles -> k_fused_train<PRE> -> k_grid_scatter). */

@@ -31,8 +31,8 @@ int mon_debug_acc_layout(int encoded_width_padded, int n_neurons, int n_hidden_l
 int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D);
 /* config.yaml key look-up of the sequence reader (cv::FileStorage semantics: exact key at line start); returns MON_ERR_IO when absent. */
 int mon_debug_yaml_number(const char* text, const char* key, double* value);
-/* Occupancy-grid bookkeeping of an object created with occupancy_skip (model.cpp maybe_refresh_occupancy): out[0] = iteration of the last refresh (0 = none yet),
- * out[1] = first iteration at or after which the next one is due. */
+/* Occupancy-grid bookkeeping of an object created with occupancy_skip (model.cpp maybe_refresh_occupancy): out[0] = iteration of the last refresh
+ * (0 = none yet), out[1] = first iteration at or after which the next one is due. */
 int mon_debug_occupancy_state(mon_object* obj, uint32_t out[2]);
 
 /* Tile render bookkeeping (ro-map_amd/csrc/kernels_tilerender.hip): jobs (rays that hit the object's box, 2S samples each) of the LAST crop rendered on the

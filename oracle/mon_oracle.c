@@ -73,7 +73,8 @@ typedef struct {
                                   *   bits 0-1  sample stream: 0 counter RNG (below) | 1 XORWOW, cuRAND flavour | 2 XORWOW, rocRAND flavour
                                   *   bit  4    parameter init in tcnn's generate_random_uniform element order (pcg32 draws interleaved per thread)
                                   *   bits 16-31 XORWOW lanes (independent subsequences of the host generator) in units of 1024; 0 = 4 (cuRAND: 4096) */
-    uint64_t sample_seed;        /* key of the counter RNG; the XORWOW stream uses the reference's seed (the generator's default, 0: nerf_model.cu never sets one) */
+    /* key of the counter RNG; the XORWOW stream uses the reference's seed (the generator's default, 0: nerf_model.cu never sets one) */
+    uint64_t sample_seed;
     int32_t use_depth;           /* NeRF_Model::mbUseDepth                 */
     int32_t numerics_flags;      /* oracle-only, bit field (0 = the contract of DESIGN.md section 1):
                                   *   ORC_NUM_GRID_HALF  accumulate grid gradients sequentially in fp16 (tcnn: atomicAdd(__half2))
@@ -115,7 +116,8 @@ static inline float h2f(uint16_t h) {
     return _cvtsh_ss(h);
 #else
     uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ffu, x;
-    if (e == 0) { if (!m) x = sign; else { int s = 0; while (!(m & 0x400u)) { m <<= 1; s++; } m &= 0x3ffu; x = sign | ((uint32_t)(113 - s) << 23) | (m << 13); } }
+    if (e == 0) { if (!m) x = sign; else { int s = 0; while (!(m & 0x400u)) { m <<= 1; s++; } m &= 0x3ffu; x = sign | ((uint32_t)(113 - s) << 23) | (m << 13);
+            } }
     else if (e == 31) x = sign | 0x7f800000u | (m << 13);
     else x = sign | ((e + 112) << 23) | (m << 13);
     float f; memcpy(&f, &x, 4); return f;
@@ -144,15 +146,19 @@ float orc_rand01(uint64_t seed, uint32_t stream, uint32_t step, uint32_t idx) { 
  *   state: five 32-bit xorshift words x[0..4] + a Weyl counter d;  next: t = x0 ^ (x0 >> 2); shift the words down; x4 = (x4 ^ (x4 << 4)) ^ (t ^ (t << 1));
  *          d += 362437; output = x4 + d.
  *   host-API ordering (cuRAND documentation, CURAND_ORDERING_PSEUDO_DEFAULT): the value at offset n of a generate call comes from position
- *          (n mod LANES) * 2^67 + floor(n / LANES) of the sequence, LANES = 4096: lane k starts 2^67 * k steps ahead (the Weyl counter is unaffected: 2^67 = 0 mod 2^32)
+ * (n mod LANES) * 2^67 + floor(n / LANES) of the sequence, LANES = 4096: lane k starts 2^67 * k steps ahead (the Weyl counter is unaffected: 2^67 = 0 mod
+ * 2^32)
  *          and the lanes keep their states from one generate call to the next.
  *   the jump by 2^67: the xorshift part is linear over GF(2); its 160 x 160 transition matrix is squared 67 times here (no table).
  * What differs between the two libraries, and is therefore a named assumption for the CUDA side (cuRAND is not in this image): the seed scramble --
- *   rocRAND (rocrand_xorwow.h:107-118, checked against that header in tests/test_xorwow.py): s0 = lo ^ 0x2c7f967f, s1 = hi ^ 0xa03697cb, t0 = 1228688033 s0, t1 = 2073658381 s1;
- *   cuRAND  (CURAND-A1, curand_kernel.h _curand_init_scratch, from the published header): s0 = lo ^ 0xaad26b49, s1 = hi ^ 0xf7dcefdd, t0 = 1099087573 s0, t1 = 2591861531 s1;
+ * rocRAND (rocrand_xorwow.h:107-118, checked against that header in tests/test_xorwow.py): s0 = lo ^ 0x2c7f967f, s1 = hi ^ 0xa03697cb, t0 = 1228688033 s0,
+ * t1 = 2073658381 s1;
+ * cuRAND  (CURAND-A1, curand_kernel.h _curand_init_scratch, from the published header): s0 = lo ^ 0xaad26b49, s1 = hi ^ 0xf7dcefdd, t0 = 1099087573 s0, t1 =
+ * 2591861531 s1;
  *   both then set x = {123456789 + t0, 362436069 ^ t0, 521288629 + t1, 88675123 ^ t1, 5783321 + t0}, d = 6615241 + t1 + t0 --
  * and the integer -> (0, 1] map: rocRAND 2^-32 + v 2^-32, cuRAND (CURAND-A2) v 2^-32 + 2^-33, in fp32.
- * CURAND-A3: the offset n of the ordering rule counts the values generated since the generator was created, ACROSS calls (what librocrand does with its 131 072 lanes:
+ * CURAND-A3: the offset n of the ordering rule counts the values generated since the generator was created, ACROSS calls (what librocrand does with its 131
+ * 072 lanes:
  * tests/test_xorwow_gpu.py); base.json's call sizes are multiples of 4096, for which every reading of the rule gives the same values. */
 typedef struct { uint32_t x[5], d; } orc_xw;
 static inline uint32_t xw_next(orc_xw* s) {
@@ -162,11 +168,14 @@ static inline uint32_t xw_next(orc_xw* s) {
     s->d += 362437u; return s->d + s->x[4];
 }
 static void xw_seed(orc_xw* s, uint64_t seed, int rocrand_flavour) {
-    const uint32_t s0 = (uint32_t)seed ^ (rocrand_flavour ? 0x2c7f967fu : 0xaad26b49u), s1 = (uint32_t)(seed >> 32) ^ (rocrand_flavour ? 0xa03697cbu : 0xf7dcefddu);
+    const uint32_t s0 = (uint32_t)seed ^ (rocrand_flavour ? 0x2c7f967fu : 0xaad26b49u),
+            s1 = (uint32_t)(seed >> 32) ^ (rocrand_flavour ? 0xa03697cbu : 0xf7dcefddu);
     const uint32_t t0 = (rocrand_flavour ? 1228688033u : 1099087573u) * s0, t1 = (rocrand_flavour ? 2073658381u : 2591861531u) * s1;
-    s->x[0] = 123456789u + t0; s->x[1] = 362436069u ^ t0; s->x[2] = 521288629u + t1; s->x[3] = 88675123u ^ t1; s->x[4] = 5783321u + t0; s->d = 6615241u + t1 + t0;
+    s->x[0] = 123456789u + t0; s->x[1] = 362436069u ^ t0; s->x[2] = 521288629u + t1; s->x[3] = 88675123u ^ t1; s->x[4] = 5783321u + t0;
+    s->d = 6615241u + t1 + t0;
 }
-static inline float xw_uniform(uint32_t v, int rocrand_flavour) { return rocrand_flavour ? 2.3283064e-10f + ((float)v * 2.3283064e-10f) : (float)v * 2.3283064e-10f + (2.3283064e-10f / 2.0f); }
+static inline float xw_uniform(uint32_t v, int rocrand_flavour) {
+    return rocrand_flavour ? 2.3283064e-10f + ((float)v * 2.3283064e-10f) : (float)v * 2.3283064e-10f + (2.3283064e-10f / 2.0f); }
 /* 160 x 160 bit matrices as 160 columns of 5 words: (M v) = xor of the columns whose bit is set in v */
 typedef struct { uint32_t col[160][5]; } xw_mat;
 static void xw_matvec(const xw_mat* M, const uint32_t v[5], uint32_t out[5]) {
@@ -183,7 +192,8 @@ static void xw_jump_2pow(xw_mat* M, int log2_steps) {          /* M = (one step 
     free(T);
 }
 /* the host generator: `lanes` states, lane k = seed state jumped k * 2^67 steps */
-typedef struct { orc_xw* lane; uint32_t lanes; int flavour; uint64_t offset; } orc_xwgen;      /* offset: values generated since creation (the n of the ordering rule runs across calls) */
+/* offset: values generated since creation (the n of the ordering rule runs across calls) */
+typedef struct { orc_xw* lane; uint32_t lanes; int flavour; uint64_t offset; } orc_xwgen;
 static void xwgen_init(orc_xwgen* g, uint64_t seed, int rocrand_flavour, uint32_t lanes) {
     static xw_mat* J = NULL;
     #pragma omp critical(orc_xw_jump)
@@ -192,9 +202,11 @@ static void xwgen_init(orc_xwgen* g, uint64_t seed, int rocrand_flavour, uint32_
     xw_seed(&g->lane[0], seed, rocrand_flavour);
     for (uint32_t k = 1; k < lanes; ++k) { g->lane[k].d = g->lane[0].d; xw_matvec(J, g->lane[k - 1].x, g->lane[k].x); }
 }
-static void xwgen_uniform(orc_xwgen* g, float* out, size_t n) {              /* curandGenerateUniform(gen, out, n): value j of this call sits at offset g->offset + j of the generator's output */
+/* curandGenerateUniform(gen, out, n): value j of this call sits at offset g->offset + j of the generator's output */
+static void xwgen_uniform(orc_xwgen* g, float* out, size_t n) {
     const uint32_t start = (uint32_t)(g->offset % g->lanes);
-    for (uint32_t k = 0; k < g->lanes; ++k) for (size_t j = (k + g->lanes - start) % g->lanes; j < n; j += g->lanes) out[j] = xw_uniform(xw_next(&g->lane[k]), g->flavour);
+    for (uint32_t k = 0; k < g->lanes; ++k) for (size_t j = (k + g->lanes - start) % g->lanes; j < n; j += g->lanes) out[j] = xw_uniform(xw_next(&g->lane[k]),
+            g->flavour);
     g->offset += n;
 }
 /* test hooks (tests/test_xorwow.py): raw draws of one lane, and one generate call of a fresh generator */
@@ -288,7 +300,8 @@ typedef struct {
     float *pts, *tdist; uint16_t *E, *Hid, *O, *dO, *dHid, *dE;
     float *rgb_ray, *depth_ray, *mask_ray, *loss_ray; float loss;
     /* XORWOW sample stream (cfg.rng_flags): the training generator and this iteration's three arrays SampleXY[2R] | RandColors[3R] | RandDt[S R] */
-    int step_variant; uint32_t n_compacted;          /* NeRF_Model::Step schedule (forward_backward_compacted) instead of Step_No_Compacted; samples in the compacted batch */
+    /* NeRF_Model::Step schedule (forward_backward_compacted) instead of Step_No_Compacted; samples in the compacted batch */
+    int step_variant; uint32_t n_compacted;
     orc_xwgen xw; float* xw_buf; uint32_t xw_iter;     /* xw_iter: the iteration xw_buf holds (UINT32_MAX: none) */
 } orc_model;
 
@@ -316,14 +329,15 @@ orc_model* orc_create(const orc_config* c) {
     }
     for (; k < m->n_params; ++k) m->master[k] = pcg_float(&rng) * 2e-4f - 1e-4f;
     } else {
-        /* TCNN-A5b (rng_flags bit 4): tiny-cuda-nn's generate_random_uniform (common_device / random.h as published): one launch per tensor -- every MLP matrix,
-         * then the grid -- of ceil(n / (128 * 4)) blocks of 128 threads; thread i advances the generator by 4 i and writes its draws j = 0..3 to element
-         * i + n_threads * j; the host generator then advances by n.  So element e of a tensor takes draw 4 (e mod n_threads) + floor(e / n_threads) of the
+        /* TCNN-A5b (rng_flags bit 4): tiny-cuda-nn's generate_random_uniform (common_device / random.h as published): one launch per tensor -- every MLP
+         * matrix, then the grid -- of ceil(n / (128 * 4)) blocks of 128 threads; thread i advances the generator by 4 i and writes its draws j = 0..3 to
+         * element i + n_threads * j; the host generator then advances by n.  So element e of a tensor takes draw 4 (e mod n_threads) + floor(e / n_threads) of the
          * tensor's stretch of the pcg32 sequence, value = draw * (hi - lo) + lo. */
         uint64_t base = 0;
         for (int layer = 0; layer <= m->NH + 1; ++layer) {
             size_t n; float lo, hi;
-            if (layer <= m->NH) { int rows = (layer == m->NH) ? ORC_OUT_PAD : m->W, cols = (layer == 0) ? m->Epad : m->W; float sc = sqrtf(6.0f / (float)(rows + cols)); n = (size_t)rows * cols; lo = -sc; hi = sc; }
+            if (layer <= m->NH) { int rows = (layer == m->NH) ? ORC_OUT_PAD : m->W, cols = (layer == 0) ? m->Epad : m->W;
+                float sc = sqrtf(6.0f / (float)(rows + cols)); n = (size_t)rows * cols; lo = -sc; hi = sc; }
             else { n = m->n_grid; lo = -1e-4f; hi = 1e-4f; }
             const size_t n_threads = ((n + 511) / 512) * 128;
             float* draws = (float*)malloc(sizeof(float) * n_threads * 4);
@@ -344,7 +358,10 @@ orc_model* orc_create(const orc_config* c) {
     m->dO = (uint16_t*)calloc(B * ORC_OUT, 2); m->dHid = (uint16_t*)calloc(B * m->W * m->NH, 2); m->dE = (uint16_t*)calloc(B * m->Epad, 2);
     m->rgb_ray = (float*)calloc(R * 3, 4); m->depth_ray = (float*)calloc(R, 4); m->mask_ray = (float*)calloc(R, 4); m->loss_ray = (float*)calloc(R, 4);
     m->xw_iter = 0xffffffffu;
-    if (ORC_RNG_STREAM(c)) { xwgen_init(&m->xw, 0ull /* the generator's default seed: nerf_model.cu never sets one */, ORC_RNG_STREAM(c) == 2u, ORC_RNG_LANES(c)); m->xw_buf = (float*)calloc((5 + (size_t)m->S) * R, 4); }
+    if (ORC_RNG_STREAM(c)) {
+        xwgen_init(&m->xw, 0ull /* the generator's default seed: nerf_model.cu never sets one */, ORC_RNG_STREAM(c) == 2u, ORC_RNG_LANES(c));
+        m->xw_buf = (float*)calloc((5 + (size_t)m->S) * R, 4);
+    }
     return m;
 }
 void orc_destroy(orc_model* m) {
@@ -428,8 +445,9 @@ static void pixel_ray(const orc_model* m, float px, float py, const float* Twc, 
  * nerf_model.cu:1429-1502 = GenerateRays (:369-446) + fill_rollover_rays (:280-294) +
  * GenerateInputPoints (:536-566).  The atomicAdd compaction order of the reference is
  * unspecified; this restatement (and the HIP path) use the stable candidate order. */
-/* one uniform of iteration `step`: stream 0 SampleXY[2R], 1 RandColors[3R], 2 RandDt[S R].  XORWOW mode: the three arrays of an iteration are generated once, in the
- * reference's order (nerf_model.cu:1432,1434,1468), by the model's one host generator; iterations that were skipped over (advance_iter) consume their draws too. */
+/* one uniform of iteration `step`: stream 0 SampleXY[2R], 1 RandColors[3R], 2 RandDt[S R].  XORWOW mode: the three arrays of an iteration are generated
+ * once, in the reference's order (nerf_model.cu:1432,1434,1468), by the model's one host generator; iterations that were skipped over (advance_iter) consume their draws
+ * too. */
 static void xw_ensure(orc_model* m) {
     const size_t R = (size_t)m->R, S = (size_t)m->S;
     while (m->xw_iter == 0xffffffffu || m->xw_iter < m->iter) {
@@ -445,7 +463,8 @@ static void generate_batch(orc_model* m) {
     const orc_config* c = &m->cfg; const int R = m->R, S = m->S; const uint32_t step = m->iter;
     if (ORC_RNG_STREAM(c)) xw_ensure(m);
     float *co = (float*)malloc((size_t)R * 3 * 4), *cd = (float*)malloc((size_t)R * 3 * 4), *cdn = (float*)malloc((size_t)R * 4),
-          *ct0 = (float*)malloc((size_t)R * 4), *ct1 = (float*)malloc((size_t)R * 4), *ctg = (float*)malloc((size_t)R * 3 * 4), *ctd = (float*)malloc((size_t)R * 4);
+          *ct0 = (float*)malloc((size_t)R * 4), *ct1 = (float*)malloc((size_t)R * 4), *ctg = (float*)malloc((size_t)R * 3 * 4),
+                  *ctd = (float*)malloc((size_t)R * 4);
     uint8_t* cfl = (uint8_t*)malloc((size_t)R);
     uint32_t nv = 0;
     for (int i = 0; i < R; ++i) {
@@ -453,7 +472,8 @@ static void generate_batch(orc_model* m) {
         const orc_bbox* b = &m->boxes[(size_t)i % m->n_boxes];
         float u0 = batch_rand(m, 0, step, 2u * i), u1 = batch_rand(m, 0, step, 2u * i + 1u);
         uint32_t x = b->x + (uint32_t)(u0 * (float)(int)b->w), y = b->y + (uint32_t)(u1 * (float)(int)b->h);
-        if (x > (uint32_t)m->Wimg - 1u) x = (uint32_t)m->Wimg - 1u;           /* guard (XORWOW uniforms reach 1.0: a box that touches the image border would read past the row, as the reference does) */
+        /* guard (XORWOW uniforms reach 1.0: a box that touches the image border would read past the row, as the reference does) */
+        if (x > (uint32_t)m->Wimg - 1u) x = (uint32_t)m->Wimg - 1u;
         if (y > (uint32_t)m->H - 1u) y = (uint32_t)m->H - 1u;
         size_t pix = ((size_t)b->FrameId * m->H + y) * m->Wimg + x;
         uint8_t inst = m->rgba[pix * 4 + 3];
@@ -506,7 +526,8 @@ static void encode_one(const orc_model* m, const uint16_t* table /* grid part, [
         corners c; level_corners(m, l, x, &c); float a0 = 0.0f, a1 = 0.0f;
         if (tcnn) {          /* tcnn kernel_grid: ((T*)&result)[f] += (T)(weight * (float)val[f]) with T = __half */
             uint16_t r0 = 0, r1 = 0;
-            for (int k = 0; k < 8; ++k) { r0 = f2h(h2f(r0) + h2f(f2h(c.w[k] * h2f(table[2 * c.idx[k]])))); r1 = f2h(h2f(r1) + h2f(f2h(c.w[k] * h2f(table[2 * c.idx[k] + 1])))); }
+            for (int k = 0; k < 8; ++k) { r0 = f2h(h2f(r0) + h2f(f2h(c.w[k] * h2f(table[2 * c.idx[k]]))));
+                r1 = f2h(h2f(r1) + h2f(f2h(c.w[k] * h2f(table[2 * c.idx[k] + 1])))); }
             E[2 * l] = r0; E[2 * l + 1] = r1; continue;
         }
         for (int k = 0; k < 8; ++k) { a0 = fmaf(c.w[k], h2f(table[2 * c.idx[k]]), a0); a1 = fmaf(c.w[k], h2f(table[2 * c.idx[k] + 1]), a1); }
@@ -596,7 +617,8 @@ static float gradient_ray(const uint16_t* out4, const float* t, int S, int nRays
     return loss;
 }
 /* stage entry points for KATs */
-void orc_composite(const uint16_t* out4, const float* t, int S, const float* bg, float* rgb, float* depth, float* mask) { composite_ray(out4, t, S, bg, rgb, depth, mask); }
+void orc_composite(const uint16_t* out4, const float* t, int S, const float* bg, float* rgb, float* depth, float* mask) {
+    composite_ray(out4, t, S, bg, rgb, depth, mask); }
 float orc_gradient(const uint16_t* out4, const float* t, int S, int nRays, float loss_scale, int is_obj, const float* target, float target_depth,
                    const float* rgb_ray, float depth_ray, float mask_ray, uint16_t* dO) {
     memset(dO, 0, (size_t)S * 4 * 2);
@@ -636,12 +658,16 @@ static void forward_backward(orc_model* m) {
 }
 
 /* NeRF_Model::Step (nerf_model.cu:1504-1550, "unavailable, for reference only": never called by either driver) -- the schedule with per-ray SAMPLE
- * compaction: (1) inference of every sample with the training weights (:1509); (2) VolumeRenderGradient (:957-1132): per ray, composite until T < 1e-4 (numsteps
+ * compaction: (1) inference of every sample with the training weights (:1509); (2) VolumeRenderGradient (:957-1132): per ray, composite until T < 1e-4
+ * (numsteps
  * samples), L2 loss on the colour only (no depth / mask terms), background = ONE colour for all rays (the kernel's by-value copy of the pcg32 generator: every
  * thread draws the same three floats, :1038) -- here the iteration's first three RandColors; the numsteps positions and their dL/dO go to a compacted batch
- * (reference: slot = atomicAdd in arrival order; here in ray order); (3) fill_rollover_and_rescale (:269-279) + fill_rollover (:258-266): the compacted batch of n
- * samples is repeated cyclically up to the full batch size B and ONLY THE COPIES' gradients are scaled by n / B (the originals keep theirs: `i < n * stride` returns
- * early); (4) forward + backward of the full-size compacted batch (:1545-1548), then the optimizer step as usual.  m->pts / m->dO hold the compacted batch afterwards. */
+ * (reference: slot = atomicAdd in arrival order; here in ray order); (3) fill_rollover_and_rescale (:269-279) + fill_rollover (:258-266): the compacted
+ * batch of n
+ * samples is repeated cyclically up to the full batch size B and ONLY THE COPIES' gradients are scaled by n / B (the originals keep theirs: `i < n * stride`
+ * returns
+ * early); (4) forward + backward of the full-size compacted batch (:1545-1548), then the optimizer step as usual.  m->pts / m->dO hold the compacted batch
+ * afterwards. */
 static void forward_backward_compacted(orc_model* m) {
     const int R = m->R, S = m->S; const size_t B = (size_t)R * S; const orc_config* c = &m->cfg;
     network_forward(m);
@@ -656,7 +682,8 @@ static void forward_backward_compacted(orc_model* m) {
             if (T < 1e-4f) break;
             float c0 = logistic(h2f(o4[4 * n])), c1 = logistic(h2f(o4[4 * n + 1])), c2 = logistic(h2f(o4[4 * n + 2]));
             float dt = t[n] - last, sigma = expf(h2f(o4[4 * n + 3])), alpha = 1.0f - expf(-sigma * dt), w = alpha * T;
-            r[0] += w * c0; r[1] += w * c1; r[2] += w * c2; dep += w * t[n]; T *= (1.0f - alpha); last = t[n];      /* (depth: |point - o| = t for a unit direction) */
+            /* (depth: |point - o| = t for a unit direction) */
+            r[0] += w * c0; r[1] += w * c1; r[2] += w * c2; dep += w * t[n]; T *= (1.0f - alpha); last = t[n];
         }
         for (int a = 0; a < 3; ++a) m->rgb_ray[3 * j + a] = r[a] + T * bg[a];
         m->depth_ray[j] = dep; m->mask_ray[j] = 1.0f - T; steps[j + 1] = (uint32_t)n;
@@ -744,15 +771,18 @@ static void network_backward(orc_model* m) {
                 for (int u = 0; u < W; ++u) { float d = h2f(dh[u]); if (d != 0.0f) for (int k = 0; k < Ep; ++k) g0[u * Ep + k] += d * h2f(E[k]); }
                 for (int layer = 1; layer < NH; ++layer) {
                     float* gl = g + (size_t)W * Ep + (size_t)(layer - 1) * W * W;
-                    for (int u = 0; u < W; ++u) { float d = h2f(dh[layer * W + u]); if (d != 0.0f) for (int k = 0; k < W; ++k) gl[u * W + k] += d * h2f(hid[(layer - 1) * W + k]); }
+                    for (int u = 0; u < W; ++u) { float d = h2f(dh[layer * W + u]);
+                        if (d != 0.0f) for (int k = 0; k < W; ++k) gl[u * W + k] += d * h2f(hid[(layer - 1) * W + k]); }
                 }
                 float* go = g + (size_t)W * Ep + (size_t)(NH - 1) * W * W;
-                for (int c = 0; c < ORC_OUT; ++c) { float d = h2f(dO[c]); if (d != 0.0f) for (int k = 0; k < W; ++k) go[c * W + k] += d * h2f(hid[(NH - 1) * W + k]); }
+                for (int c = 0; c < ORC_OUT; ++c) { float d = h2f(dO[c]);
+                    if (d != 0.0f) for (int k = 0; k < W; ++k) go[c * W + k] += d * h2f(hid[(NH - 1) * W + k]); }
             }
         }
         for (int t = 0; t < nthreads; ++t) for (uint32_t k = 0; k < m->n_mlp; ++k) m->gmlp[k] += part[(size_t)t * m->n_mlp + k];
         free(part);
-        if (tcnn) for (uint32_t k = 0; k < m->n_mlp; ++k) m->gmlp[k] = h2f(f2h(m->gmlp[k]));      /* tcnn: the weight-gradient GEMMs write network_precision_t (fp16) */
+        /* tcnn: the weight-gradient GEMMs write network_precision_t (fp16) */
+        if (tcnn) for (uint32_t k = 0; k < m->n_mlp; ++k) m->gmlp[k] = h2f(f2h(m->gmlp[k]));
     }
     /* grid backward (tcnn kernel_grid_backward): contribution = h(w * dE) per corner; serial for determinism */
     memset(m->ggrid, 0, (size_t)m->n_grid * 4); memset(m->ggrid_abs, 0, (size_t)m->n_grid * 4);
@@ -857,13 +887,15 @@ void orc_render(const orc_model* m, orc_bbox box, const float* pose16, int pose_
     const uint16_t* prm = (use_ema && m->has_ema) ? m->ema : m->half;
     /* XORWOW mode: the reference creates a NEW generator for every Render (default seed) and draws the whole crop's RandDt in one call (:1725-1728,1781) */
     float* xwr = NULL;
-    if (ORC_RNG_STREAM(&m->cfg)) { orc_xwgen g; memset(&g, 0, sizeof g); xwgen_init(&g, 0ull, ORC_RNG_STREAM(&m->cfg) == 2u, ORC_RNG_LANES(&m->cfg)); xwr = (float*)malloc(sizeof(float) * (size_t)n * S); xwgen_uniform(&g, xwr, (size_t)n * S); free(g.lane); }
+    if (ORC_RNG_STREAM(&m->cfg)) { orc_xwgen g; memset(&g, 0, sizeof g); xwgen_init(&g, 0ull, ORC_RNG_STREAM(&m->cfg) == 2u, ORC_RNG_LANES(&m->cfg));
+        xwr = (float*)malloc(sizeof(float) * (size_t)n * S); xwgen_uniform(&g, xwr, (size_t)n * S); free(g.lane); }
     #pragma omp parallel for schedule(dynamic, 16)
     for (long i = 0; i < n; ++i) {
         int x = (int)box.x + (int)(i % box.w), y = (int)box.y + (int)(i / box.w);
         float o[3], d[3], dn, t0, t1;
         pixel_ray(m, (float)x, (float)y, pose16, pose_is_Toc ? NULL : m->Tow, o, d, &dn);
-        if (!ray_intersect(m->amin, m->amax, o, d, &t0, &t1)) { rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = 1.0f; depth[i] = 0.0f; mask[i] = 0.0f; continue; }
+        if (!ray_intersect(m->amin, m->amax, o, d, &t0, &t1)) { rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = 1.0f; depth[i] = 0.0f; mask[i] = 0.0f;
+            continue; }
         t0 = fmaxf(t0, 0.0f);
         float dt = (t1 - t0) / (float)S, T = 1.0f, r[3] = { 0, 0, 0 }, dep = 0.0f, last = 0.0f;
         uint16_t E[2 * ORC_MAX_LEVELS + 16], hid[256], out[4];

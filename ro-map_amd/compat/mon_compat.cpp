@@ -26,7 +26,8 @@ void NeRF::DrawCPUMesh() {                                                    //
         int rc = mon_object_copy_mesh(mpObject, nv, ni, cm.verts.data(), cm.normals.data(), cm.colors.data(), cm.indices.data(), &need_v, &need_r, &need_i, 1);
         if (rc == MON_ERR_ARG && (need_v > nv || need_i > ni)) {                   // the mesh grew: make room and try once more
             cm.verts.resize(3 * (size_t)need_v); cm.normals.resize(3 * (size_t)need_v); cm.colors.resize(3 * (size_t)need_v); cm.indices.resize(need_i);
-            rc = mon_object_copy_mesh(mpObject, need_v, need_i, cm.verts.data(), cm.normals.data(), cm.colors.data(), cm.indices.data(), &need_v, &need_r, &need_i, 1);
+            rc = mon_object_copy_mesh(mpObject, need_v, need_i, cm.verts.data(), cm.normals.data(), cm.colors.data(), cm.indices.data(), &need_v, &need_r,
+                    &need_i, 1);
         }
         if (rc == MON_OK) {
             cm.verts.resize(3 * (size_t)need_v); cm.normals.resize(3 * (size_t)need_v); cm.colors.resize(3 * (size_t)need_v); cm.indices.resize(need_i);
@@ -46,9 +47,17 @@ vector<Eigen::Matrix4f> NeRF::GetTwc() {                                      //
     if (mpOffline) {
         size_t n = 0; mon_offline_get_poses(mpOffline, nullptr, 0, &n); std::vector<float> flat(16 * n);
         if (n && mon_offline_get_poses(mpOffline, flat.data(), n, &n)) die("GetTwc");
-        for (const FrameIdAndBbox& b : mFrameIdBbox) { Eigen::Matrix4f T = Eigen::Matrix4f::Identity(); if (b.FrameId < n) std::memcpy(T.data(), &flat[16 * (size_t)b.FrameId], 64); out.push_back(T); }
+        for (const FrameIdAndBbox& b : mFrameIdBbox) {
+            Eigen::Matrix4f T = Eigen::Matrix4f::Identity();
+            if (b.FrameId < n) std::memcpy(T.data(), &flat[16 * (size_t)b.FrameId], 64);
+            out.push_back(T);
+        }
     } else if (mpOnline) {
-        for (const FrameIdAndBbox& b : mFrameIdBbox) { Eigen::Matrix4f T = Eigen::Matrix4f::Identity(); if (mon_online_get_pose(mpOnline, b.FrameId, T.data())) die("GetTwc"); out.push_back(T); }
+        for (const FrameIdAndBbox& b : mFrameIdBbox) {
+            Eigen::Matrix4f T = Eigen::Matrix4f::Identity();
+            if (mon_online_get_pose(mpOnline, b.FrameId, T.data())) die("GetTwc");
+            out.push_back(T);
+        }
     }
     return out;
 }
@@ -59,7 +68,8 @@ NerfManagerOffline::NerfManagerOffline(const string datasetPath, const string cf
     if (mon_offline_create(datasetPath.c_str(), cfg.c_str(), useDenseDepth ? 1 : 0, &mpManager)) die("NerfManagerOffline");
 }
 NerfManagerOffline::~NerfManagerOffline() { mon_offline_destroy(mpManager); }
-bool NerfManagerOffline::Init() { if (mon_offline_init(mpManager)) die("Init"); return true; }                       // "Can not Detect GPU" / config errors are fatal (:21-25)
+// "Can not Detect GPU" / config errors are fatal (:21-25)
+bool NerfManagerOffline::Init() { if (mon_offline_init(mpManager)) die("Init"); return true; }
 bool NerfManagerOffline::ReadDataset() {                                                                              // nerf_data.cu:27-235
     if (mon_offline_read_dataset(mpManager)) { std::cerr << "Load dataset error: " << mon_last_error() << std::endl; return false; }
     return true;
@@ -68,7 +78,8 @@ bool NerfManagerOffline::CreateNeRF(const string objectFile) {                  
     if (mon_offline_create_nerf(mpManager, objectFile.c_str())) { std::cerr << "Create NeRF error: " << mon_last_error() << std::endl; return false; }
     auto n = std::make_shared<NeRF>(); const int idx = (int)mvpNeRFs.size(); n->mId = idx; n->mpOffline = mpManager;
     size_t nb = 0;
-    if (mon_offline_object_meta(mpManager, idx, &n->mClass, n->mObjTow.data(), n->mBoundingBox.min.data(), n->mBoundingBox.max.data(), nullptr, 0, &nb)) die("CreateNeRF");
+    if (mon_offline_object_meta(mpManager, idx, &n->mClass, n->mObjTow.data(), n->mBoundingBox.min.data(), n->mBoundingBox.max.data(), nullptr, 0,
+            &nb)) die("CreateNeRF");
     n->mFrameIdBbox.resize(nb);
     if (mon_offline_object_meta(mpManager, idx, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<mon_frame_bbox*>(n->mFrameIdBbox.data()), nb, &nb) ||
         mon_offline_object(mpManager, idx, &n->mpObject)) die("CreateNeRF");
@@ -88,7 +99,8 @@ vector<Eigen::Matrix4f> NerfManagerOffline::GetAllTwc() {
     for (size_t i = 0; i < n; ++i) std::memcpy(out[i].data(), &flat[16 * i], 64);                                      // both sides column-major
     return out;
 }
-void NerfManagerOffline::GetIntrinsics(float& fx, float& fy, float& cx, float& cy) { mon_offline_get_intrinsics(mpManager, &fx, &fy, &cx, &cy, nullptr, nullptr); }
+void NerfManagerOffline::GetIntrinsics(float& fx, float& fy, float& cx, float& cy) {
+    mon_offline_get_intrinsics(mpManager, &fx, &fy, &cx, &cy, nullptr, nullptr); }
 
 // ------------------------------------------------------------------ online manager (nerf_manager.cu:133-312)
 NerfManagerOnline::NerfManagerOnline(const string cfg, bool UseSparseDepth, int iters)
@@ -100,14 +112,18 @@ bool NerfManagerOnline::Init() { if (mon_online_init(mpManager)) die("Init"); re
 void NerfManagerOnline::DatasetInit(float fx, float fy, float cx, float cy, int H, int W, size_t imgs) {
     if (mon_online_dataset_init(mpManager, fx, fy, cx, cy, H, W, imgs)) die("InitDataToGPU");
 }
-void NerfManagerOnline::NewFrameToDataset(unsigned int imgId, const string stamp, cv::Mat& img, cv::Mat& instance, const cv::Mat& depth, const Eigen::Matrix4f& pose) {
-    // 8-bit BGR(A) colour, 8-bit instance ids, CV_32FC1 z-depth in metres with 0 = no sample (nerf_data.cu:279-339; callers pass clones, LocalMapping.cc:1112-1113)
+void NerfManagerOnline::NewFrameToDataset(unsigned int imgId, const string stamp, cv::Mat& img, cv::Mat& instance, const cv::Mat& depth,
+        const Eigen::Matrix4f& pose) {
+    // 8-bit BGR(A) colour, 8-bit instance ids, CV_32FC1 z-depth in metres with 0 = no sample (nerf_data.cu:279-339; callers pass clones,
+    // LocalMapping.cc:1112-1113)
     const cv::Mat c = img.isContinuous() ? img : img.clone(), s = instance.isContinuous() ? instance : instance.clone();
     const cv::Mat z = (mbUseSparseDepth && !depth.isContinuous()) ? depth.clone() : depth;
-    if (mon_online_new_frame(mpManager, imgId, stamp.c_str(), c.data, c.channels(), s.data, mbUseSparseDepth ? z.ptr<float>() : nullptr, pose.data())) die("FrameDataToGPU");
+    if (mon_online_new_frame(mpManager, imgId, stamp.c_str(), c.data, c.channels(), s.data, mbUseSparseDepth ? z.ptr<float>() : nullptr,
+            pose.data())) die("FrameDataToGPU");
 }
 size_t NerfManagerOnline::CreateNeRF(const int Class, const Eigen::Matrix4f& ObjTow, const nerf::BoundingBox& box) {
-    size_t idx = 0;                                                           // the 1.1x / 1.2x inflation of SetAttributes (nerf.cu:163-172) is applied behind the C ABI
+    // the 1.1x / 1.2x inflation of SetAttributes (nerf.cu:163-172) is applied behind the C ABI
+    size_t idx = 0;
     if (mon_online_create_nerf(mpManager, Class, ObjTow.data(), box.min.data(), box.max.data(), &idx)) die("Create NeRF error");
     auto n = std::make_shared<NeRF>(); n->mId = (int)idx; n->mClass = Class; n->mInstanceId = (uint8_t)Class; n->mObjTow = ObjTow; n->mpOnline = mpManager;
     const float k = (Class == 41 || Class == 73) ? 1.2f : 1.1f;
@@ -121,7 +137,8 @@ int NerfManagerOnline::GetFrameIdx(double t) {                                //
 }
 void NerfManagerOnline::UpdateNeRFBbox(const size_t idx, const vector<nerf::FrameIdAndBbox>& v, const int train_step) {
     if (v.empty()) return;
-    if (idx < mvpNeRFs.size()) { mvpNeRFs[idx]->mFrameIdBbox.insert(mvpNeRFs[idx]->mFrameIdBbox.end(), v.begin(), v.end()); mvpNeRFs[idx]->mnBbox = mvpNeRFs[idx]->mFrameIdBbox.size(); }
+    if (idx < mvpNeRFs.size()) { mvpNeRFs[idx]->mFrameIdBbox.insert(mvpNeRFs[idx]->mFrameIdBbox.end(), v.begin(), v.end());
+        mvpNeRFs[idx]->mnBbox = mvpNeRFs[idx]->mFrameIdBbox.size(); }
     if (mon_online_update_nerf_bbox(mpManager, idx, reinterpret_cast<const mon_frame_bbox*>(v.data()), v.size(), train_step)) die("UpdateNeRFBbox");
 }
 void NerfManagerOnline::UpdateDataset(unsigned int CurId, unsigned int FrameNum, const vector<Eigen::Matrix4f>& Poses) {      // nerf_manager.cu:220-235
@@ -142,7 +159,8 @@ void NerfManagerOnline::RenderNeRFsTest(const string out_path, const size_t Idx,
     std::vector<const char*> stamps(ts.size()); std::vector<float> poses(16 * vT.size());
     for (size_t i = 0; i < ts.size(); ++i) stamps[i] = ts[i].c_str();
     for (size_t i = 0; i < vT.size(); ++i) std::memcpy(&poses[16 * i], vT[i].data(), 64);
-    if (mon_online_render_nerfs_test(mpManager, out_path.c_str(), Idx, stamps.data(), reinterpret_cast<const mon_frame_bbox*>(vb.data()), poses.data(), ts.size(), radius)) die("RenderNeRFsTest");
+    if (mon_online_render_nerfs_test(mpManager, out_path.c_str(), Idx, stamps.data(), reinterpret_cast<const mon_frame_bbox*>(vb.data()), poses.data(),
+            ts.size(), radius)) die("RenderNeRFsTest");
 }
 
 }  // namespace nerf

@@ -14,7 +14,8 @@ public:
     BoundingBox GetBoundingBox() { return mBoundingBox; }
     CPUMeshData& GetCPUMeshData() { return mCPUMeshData; }
     void DrawCPUMesh();                           // nerf.cu:484-507: try_lock, draw the last mesh the training thread published
-    void DrawMesh() { DrawCPUMesh(); }            // nerf.cu:509-551 draws CUDA-GL interop buffers; here the same mesh from host arrays (no interop on this side)
+    // nerf.cu:509-551 draws CUDA-GL interop buffers; here the same mesh from host arrays (no interop on this side)
+    void DrawMesh() { DrawCPUMesh(); }
     vector<Eigen::Matrix4f> GetTwc();             // nerf.cu:450-462: the dataset's pose of every frame the object has a 2-D box in
 
     int mId = -1, mClass = 0;

@@ -29,13 +29,15 @@ struct JVal {
 };
 
 struct JParser {
-    const std::string& s; size_t i = 0; bool ok = true; int depth = 0;          // nesting is bounded (tcnn configs are 3 deep): no stack exhaustion on hostile input
+    // nesting is bounded (tcnn configs are 3 deep): no stack exhaustion on hostile input
+    const std::string& s; size_t i = 0; bool ok = true; int depth = 0;
     explicit JParser(const std::string& src) : s(src) {}
     void ws() {
         for (;;) {
             while (i < s.size() && std::isspace((unsigned char)s[i])) ++i;
             if (i + 1 < s.size() && s[i] == '/' && s[i + 1] == '/') { while (i < s.size() && s[i] != '\n') ++i; continue; }
-            if (i + 1 < s.size() && s[i] == '/' && s[i + 1] == '*') { i += 2; while (i + 1 < s.size() && !(s[i] == '*' && s[i + 1] == '/')) ++i; i += 2; continue; }
+            if (i + 1 < s.size() && s[i] == '/' && s[i + 1] == '*') { i += 2; while (i + 1 < s.size() && !(s[i] == '*' && s[i + 1] == '/')) ++i; i += 2;
+                continue; }
             break;
         }
     }
@@ -137,7 +139,8 @@ int config_from_json(const char* path, mon_config& c) {
         c.loss_scale = (float)t->number("loss_scale", c.loss_scale);
         c.sample_seed = (uint64_t)t->number("sample_seed", (double)c.sample_seed);
         c.param_seed = (uint32_t)t->number("param_seed", (double)c.param_seed);
-        c.rng_flags = (uint32_t)t->number("rng_flags", (double)c.rng_flags);      // "same inputs" mode (include/mon_core.h mon_config::rng_flags), e.g. 17 = XORWOW in cuRAND's flavour + tcnn's init order
+        // "same inputs" mode (include/mon_core.h mon_config::rng_flags), e.g. 17 = XORWOW in cuRAND's flavour + tcnn's init order
+        c.rng_flags = (uint32_t)t->number("rng_flags", (double)c.rng_flags);
     }
     return MON_OK;
 }
@@ -146,8 +149,10 @@ int config_from_json(const char* path, mon_config& c) {
 static uint32_t next_multiple(uint32_t v, uint32_t d) { return ((v + d - 1) / d) * d; }
 
 int level_table_build(const mon_config& c, LevelTable& lt, NetDims& nd, uint32_t& n_grid) {
-    if (c.n_levels < 1 || c.n_levels > kMaxLevels || c.n_features != 2) { set_error("n_levels must be 1..%d and n_features 2", kMaxLevels); return MON_ERR_ARG; }
-    if (!(c.n_neurons == 32 || c.n_neurons == 64) || !(c.n_hidden_layers == 1 || c.n_hidden_layers == 2)) { set_error("n_neurons must be 32|64, n_hidden_layers 1|2"); return MON_ERR_ARG; }
+    if (c.n_levels < 1 || c.n_levels > kMaxLevels || c.n_features != 2) { set_error("n_levels must be 1..%d and n_features 2", kMaxLevels);
+        return MON_ERR_ARG; }
+    if (!(c.n_neurons == 32 || c.n_neurons == 64) || !(c.n_hidden_layers == 1 || c.n_hidden_layers == 2)) {
+        set_error("n_neurons must be 32|64, n_hidden_layers 1|2"); return MON_ERR_ARG; }
     if (c.log2_hashmap_size < 4 || c.log2_hashmap_size > 26) { set_error("log2_hashmap_size out of range"); return MON_ERR_ARG; }
     uint32_t off = 0; const float l2 = std::log2(c.per_level_scale);
     for (int l = 0; l < c.n_levels; ++l) {
@@ -168,7 +173,8 @@ int level_table_build(const mon_config& c, LevelTable& lt, NetDims& nd, uint32_t
 
 // Closed-form per-level index constants (device_common.h:LevelFast) = tcnn's stride loop replayed in uint32.
 void level_fast_build(const LevelTable& lt, const NetDims& nd, LevelFast& lf) {
-    for (int l = 0; l < kMaxLevels; ++l) { lf.scale[l] = 0.f; lf.size[l] = 1; lf.my[l] = lf.mz[l] = 0; lf.mask[l] = 0; lf.hashed[l] = 0; lf.offset[l] = lt.offset[l]; }
+    for (int l = 0; l < kMaxLevels; ++l) { lf.scale[l] = 0.f; lf.size[l] = 1; lf.my[l] = lf.mz[l] = 0; lf.mask[l] = 0; lf.hashed[l] = 0;
+        lf.offset[l] = lt.offset[l]; }
     lf.offset[kMaxLevels] = lt.offset[kMaxLevels];
     for (int l = 0; l < nd.L; ++l) {
         const uint32_t size = lt.offset[l + 1] - lt.offset[l], res = lt.res[l];
@@ -186,7 +192,8 @@ void level_fast_build(const LevelTable& lt, const NetDims& nd, LevelFast& lf) {
 namespace {
 struct Pcg32 {
     uint64_t state = 0, inc = 0;
-    uint32_t next() { const uint64_t old = state; state = old * 0x5851f42d4c957f2dull + inc; const uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u); return (xs >> rot) | (xs << ((~rot + 1u) & 31)); }
+    uint32_t next() { const uint64_t old = state; state = old * 0x5851f42d4c957f2dull + inc;
+        const uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u); return (xs >> rot) | (xs << ((~rot + 1u) & 31)); }
     void seed(uint64_t initstate, uint64_t initseq) { state = 0; inc = (initseq << 1u) | 1u; next(); state += initstate; next(); }
     float next_float() { const uint32_t u = (next() >> 9) | 0x3f800000u; float f; std::memcpy(&f, &u, 4); return f - 1.0f; }
 };
@@ -197,13 +204,16 @@ void init_params_host(const mon_config& c, const NetDims& nd, uint32_t n_params,
     Pcg32 rng; rng.seed(c.param_seed, 1u);
     uint32_t k = 0;
     if (rng_tcnn_init_order(c.rng_flags)) {
-        // TCNN-A5b: tiny-cuda-nn's generate_random_uniform as published -- one launch per tensor (every MLP matrix, then the grid) of ceil(n / 512) blocks of 128 threads;
-        // thread i advances the generator by 4 i and writes draw j = 0..3 to element i + n_threads j; the host generator then advances by n.  Element e of a tensor
+        // TCNN-A5b: tiny-cuda-nn's generate_random_uniform as published -- one launch per tensor (every MLP matrix, then the grid) of ceil(n / 512) blocks of
+        // 128 threads;
+        // thread i advances the generator by 4 i and writes draw j = 0..3 to element i + n_threads j; the host generator then advances by n.  Element e of a
+        // tensor
         // = draw 4 (e mod n_threads) + floor(e / n_threads) of the tensor's stretch of the pcg32 sequence, scaled as draw * (hi - lo) + lo.
         uint64_t base = 0;
         for (int layer = 0; layer <= nd.NH + 1; ++layer) {
             size_t n; float lo, hi;
-            if (layer <= nd.NH) { const int rows = (layer == nd.NH) ? kOutPad : nd.W, cols = (layer == 0) ? nd.Epad : nd.W; const float sc = std::sqrt(6.0f / (float)(rows + cols)); n = (size_t)rows * cols; lo = -sc; hi = sc; }
+            if (layer <= nd.NH) { const int rows = (layer == nd.NH) ? kOutPad : nd.W, cols = (layer == 0) ? nd.Epad : nd.W;
+                const float sc = std::sqrt(6.0f / (float)(rows + cols)); n = (size_t)rows * cols; lo = -sc; hi = sc; }
             else { n = n_params - nd.n_mlp; lo = -1e-4f; hi = 1e-4f; }
             const size_t n_threads = ((n + 511) / 512) * 128;
             std::vector<float> draws(n_threads * 4);

@@ -19,9 +19,13 @@ constexpr int kOutPad = 16;    // tcnn pads the output layer to 16 rows
 constexpr float kTransmittanceEps = 1e-4f;   // nerf_model.cu:763
 // Ray bins of the compacted gradient rows (k_fused_train -> k_grid_scatter): a power of two between 16 and 128, one bin per 32 rays where the batch allows
 constexpr uint32_t kMaxScatterBins = 128, kScatterCounterStride = 16;      // (dwords between two bins' slot counters: one 64-byte line each)
-__host__ __device__ inline uint32_t scatter_counter(uint32_t iter, uint32_t bin) { return ((iter & 1u) * kMaxScatterBins + bin) * kScatterCounterStride; }   // index into DevState::n_scatter
-constexpr uint32_t kDefaultScatterBins = 16;   // measured (profiles/r02): with the counters on separate lines 16 bins cost k_fused_train nothing, and every further bin is another short run k_grid_scatter walks late in training
-__host__ __device__ inline uint32_t scatter_bins_max(uint32_t R) {      // most bins a batch of R rays supports (one per 32 rays; the count always divides R, a multiple of 64)
+// index into DevState::n_scatter
+__host__ __device__ inline uint32_t scatter_counter(uint32_t iter, uint32_t bin) { return ((iter & 1u) * kMaxScatterBins + bin) * kScatterCounterStride; }
+// measured (profiles/r02): with the counters on separate lines 16 bins cost k_fused_train nothing, and every further bin is another short run k_grid_scatter
+// walks late in training
+constexpr uint32_t kDefaultScatterBins = 16;
+// most bins a batch of R rays supports (one per 32 rays; the count always divides R, a multiple of 64)
+__host__ __device__ inline uint32_t scatter_bins_max(uint32_t R) {
     uint32_t nb = 16; while (nb < kMaxScatterBins && nb * 64u <= R && R % (nb * 2u) == 0u) nb *= 2u; return nb;
 }
 constexpr int kOccRes = 64;                  // occupancy grid (opt-in forward-pass skipping): cells per axis over the object's box, one bit each

@@ -22,7 +22,8 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
     model_leave_lane(m);
     if (which == MON_BUF_EMA) { int rc = ensure_ema_current(m); if (rc) return rc; }
     const size_t R = m.oc.R, B = R * m.oc.S, n = m.n_params; const void* src = nullptr; size_t sz = 0;
-    if (m.P.rec && (which == MON_BUF_MASTER || which == MON_BUF_M1 || which == MON_BUF_M2 || which == MON_BUF_STEPS)) {      // optimizer state kept as chunk records
+    // optimizer state kept as chunk records
+    if (m.P.rec && (which == MON_BUF_MASTER || which == MON_BUF_M1 || which == MON_BUF_M2 || which == MON_BUF_STEPS)) {
         if (!dst || bytes < n * 4) { set_error("debug_read: buffer too small"); return MON_ERR_ARG; }
         HIPCHECK(use_device(m.device)); void* tmp = nullptr; HIPCHECK(hipMalloc(&tmp, n * 4));
         launch_state_unpack(m.train_stream, m.P.rec, which == MON_BUF_MASTER ? 0 : which == MON_BUF_M1 ? 1 : which == MON_BUF_M2 ? 2 : 3, tmp, (uint32_t)n);
@@ -32,7 +33,9 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
     switch (which) {
         case MON_BUF_MASTER: src = m.P.master; sz = n * 4; break;       case MON_BUF_HALF: src = m.P.half; sz = n * 2; break;
         case MON_BUF_EMA: src = m.P.ema; sz = n * 2; break;             case MON_BUF_M1: src = m.P.m1; sz = n * 4; break;
-        case MON_BUF_M2: src = m.P.m2; sz = n * 4; break;               case MON_BUF_STEPS: src = m.P.steps ? (const void*)m.P.steps : (const void*)m.P.steps16; sz = n * 4; break;      // (16-bit counters are widened below)
+        // (16-bit counters are widened below)
+        case MON_BUF_M2: src = m.P.m2; sz = n * 4; break;
+        case MON_BUF_STEPS: src = m.P.steps ? (const void*)m.P.steps : (const void*)m.P.steps16; sz = n * 4; break;
         case MON_BUF_GMLP: src = m.P.gmlp; sz = (size_t)m.nd.n_mlp * 4; break;
         case MON_BUF_GGRID_H: src = m.P.ggrid; sz = (size_t)m.n_grid * 2; break;
         case MON_BUF_PTS: src = m.B.pts; sz = B * 12; break;            case MON_BUF_TDIST: src = m.B.tdist; sz = B * 4; break;
@@ -49,9 +52,12 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
         case MON_BUF_RAY_DN: src = m.B.ray_dn; sz = R * 4; break;       case MON_BUF_MASK: src = m.B.mask; sz = (R / 64) * 8; break;
         case MON_BUF_STATE: src = m.d_state; sz = sizeof(DevState); break;
         case MON_BUF_FRAG_TRAIN: src = m.d_frag_train; sz = 64 * 512 * 2; break;
-        case MON_BUF_X_ALL: if (!m.d_x_all) { set_error("debug_read: level-tile encode not in use"); return MON_ERR_STATE; } src = m.d_x_all; sz = B * 16; break;
-        case MON_BUF_E_SOA: if (!m.d_e_soa) { set_error("debug_read: level-tile encode not in use"); return MON_ERR_STATE; } src = m.d_e_soa; sz = B * (size_t)m.nd.L * 4; break;
-        case MON_BUF_HALF_TILES: if (!m.d_half_tiles) { set_error("debug_read: level-tile encode not in use"); return MON_ERR_STATE; } src = m.d_half_tiles; sz = (size_t)m.n_grid * 2; break;
+        case MON_BUF_X_ALL: if (!m.d_x_all) { set_error("debug_read: level-tile encode not in use"); return MON_ERR_STATE; } src = m.d_x_all; sz = B * 16;
+        break;
+        case MON_BUF_E_SOA: if (!m.d_e_soa) { set_error("debug_read: level-tile encode not in use"); return MON_ERR_STATE; } src = m.d_e_soa;
+        sz = B * (size_t)m.nd.L * 4; break;
+        case MON_BUF_HALF_TILES: if (!m.d_half_tiles) { set_error("debug_read: level-tile encode not in use"); return MON_ERR_STATE; } src = m.d_half_tiles;
+        sz = (size_t)m.n_grid * 2; break;
         case MON_BUF_FRAG_REF:
             if (!m.d_frag_render) { set_error("debug_read: fused backend not available"); return MON_ERR_STATE; }
             HIPCHECK(use_device(m.device)); HIPCHECK(hipMemsetAsync(m.d_frag_render, 0, 64 * 512 * 2, m.train_stream));
@@ -60,7 +66,8 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
     }
     if (!dst || bytes < sz) { set_error("debug_read: buffer too small (%zu < %zu)", bytes, sz); return MON_ERR_ARG; }
     HIPCHECK(use_device(m.device)); HIPCHECK(hipStreamSynchronize(m.train_stream));
-    if (which == MON_BUF_STEPS && !m.P.steps) {                            // saturating 16-bit counters on the device (ParamPtrs::steps16): hand out uint32 like before
+    // saturating 16-bit counters on the device (ParamPtrs::steps16): hand out uint32 like before
+    if (which == MON_BUF_STEPS && !m.P.steps) {
         std::vector<uint16_t> h16(n); HIPCHECK(hipMemcpy(h16.data(), src, n * 2, hipMemcpyDeviceToHost));
         uint32_t* out = reinterpret_cast<uint32_t*>(dst); for (size_t i = 0; i < n; ++i) out[i] = h16[i];
         return MON_OK;
@@ -70,12 +77,15 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
         std::vector<uint16_t> part(m.part_halves); std::vector<float> acc(m.n_grid);
         uint16_t* out = reinterpret_cast<uint16_t*>(dst);
         for (uint32_t i = 0; i < m.n_grid; ++i) { _Float16 h; std::memcpy(&h, &out[i], 2); acc[i] = (float)h; }
-        const uint32_t n_ent = m.part_halves / 2, n_half = n_ent / 2;         // partial tables are planar: [partition][feature][parity][entry / 2], over the LDS-scattered levels' entries
+        // partial tables are planar: [partition][feature][parity][entry / 2], over the LDS-scattered levels' entries
+        const uint32_t n_ent = m.part_halves / 2, n_half = n_ent / 2;
         for (uint32_t q = 0; q < m.scatter.max_P; ++q) {
             HIPCHECK(hipMemcpy(part.data(), m.d_gpart + (size_t)q * m.part_halves, (size_t)m.part_halves * 2, hipMemcpyDeviceToHost));
             for (int l = 0; l < m.nd.L; ++l) {
-                if (q >= m.scatter.P[l] || !((m.lds_mask >> l) & 1u)) continue;                              // this level has fewer partial tables: the rest of the buffer is not its data
-                for (uint32_t e = m.lt.offset[l]; e < m.lt.offset[l + 1]; ++e) for (uint32_t f = 0; f < 2; ++f) { _Float16 h; std::memcpy(&h, &part[((size_t)f * 2 + (e & 1u)) * n_half + (e >> 1)], 2); acc[2 * e + f] += (float)h; }
+                // this level has fewer partial tables: the rest of the buffer is not its data
+                if (q >= m.scatter.P[l] || !((m.lds_mask >> l) & 1u)) continue;
+                for (uint32_t e = m.lt.offset[l]; e < m.lt.offset[l + 1]; ++e) for (uint32_t f = 0; f < 2; ++f) { _Float16 h;
+                    std::memcpy(&h, &part[((size_t)f * 2 + (e & 1u)) * n_half + (e >> 1)], 2); acc[2 * e + f] += (float)h; }
             }
         }
         for (uint32_t i = 0; i < m.n_grid; ++i) { const _Float16 h = (_Float16)acc[i]; std::memcpy(&out[i], &h, 2); }
@@ -101,7 +111,8 @@ int mon_dataset_debug_read(mon_dataset* ds, uint32_t frame, uint32_t* rgba, floa
     if (pose16) HIPCHECK(hipMemcpy(pose16, d.d_poses + 16 * (size_t)frame, 64, hipMemcpyDeviceToHost));
     return MON_OK;
 }
-int mon_microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms) { REQUIRE(ms, "ms"); return microbench(device, mode, pattern, n_entries, n_ops, ms); }
+int mon_microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms) { REQUIRE(ms, "ms");
+    return microbench(device, mode, pattern, n_entries, n_ops, ms); }
 int mon_debug_fast_index(const mon_config* cfg, int level, uint32_t x, uint32_t y, uint32_t z, uint32_t* index, uint32_t* size) {
     REQUIRE(cfg, "cfg"); REQUIRE(index, "index"); REQUIRE(size, "size");
     LevelTable lt{}; NetDims nd{}; uint32_t n_grid = 0; int rc = level_table_build(*cfg, lt, nd, n_grid); if (rc) return rc;
@@ -110,22 +121,26 @@ int mon_debug_fast_index(const mon_config* cfg, int level, uint32_t x, uint32_t 
     *index = fast_grid_index(lf, level, x, y, z); *size = lf.size[level]; return MON_OK;
 }
 int mon_debug_frag_layout(int epad, int W, int NH, int L, int* source, int* slots, int* n_image, int* n_mlp) {
-    if (!(epad == 16 || epad == 32) || !(W == 32 || W == 64) || !(NH == 1 || NH == 2) || L < 1 || 2 * L > epad) { set_error("frag_layout: unsupported shape"); return MON_ERR_ARG; }
+    if (!(epad == 16 || epad == 32) || !(W == 32 || W == 64) || !(NH == 1 || NH == 2) || L < 1 || 2 * L > epad) { set_error("frag_layout: unsupported shape");
+        return MON_ERR_ARG; }
     const FragDims d{ epad, W, NH, L };
     if (n_image) *n_image = d.N_FRAGS() * 512;
     if (n_mlp) *n_mlp = d.N_MLP();
     if (source) for (int i = 0; i < d.N_FRAGS() * 512; ++i) source[i] = frag_source(d, i);
-    if (slots) for (int p = 0; p < d.N_MLP(); ++p) { int o[2] = { -1, -1 }; const int n = frag_slots(d, p, o); slots[2 * p] = n > 0 ? o[0] : -1; slots[2 * p + 1] = n > 1 ? o[1] : -1; }
+    if (slots) for (int p = 0; p < d.N_MLP(); ++p) { int o[2] = { -1, -1 }; const int n = frag_slots(d, p, o); slots[2 * p] = n > 0 ? o[0] : -1;
+        slots[2 * p + 1] = n > 1 ? o[1] : -1; }
     return MON_OK;
 }
 int mon_debug_acc_layout(int epad, int W, int NH, int L, int* param, int* n_cols) {
-    if (!(epad == 16 || epad == 32) || !(W == 32 || W == 64) || !(NH == 1 || NH == 2) || L < 1 || 2 * L > epad) { set_error("acc_layout: unsupported shape"); return MON_ERR_ARG; }
+    if (!(epad == 16 || epad == 32) || !(W == 32 || W == 64) || !(NH == 1 || NH == 2) || L < 1 || 2 * L > epad) { set_error("acc_layout: unsupported shape");
+        return MON_ERR_ARG; }
     const FragDims d{ epad, W, NH, L };
     if (n_cols) *n_cols = acc_cols(d);
     if (param) for (int i = 0; i < acc_cols(d); ++i) param[i] = acc_param(d, i);
     return MON_OK;
 }
-int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D) { REQUIRE(A, "A"); REQUIRE(B, "B"); REQUIRE(D, "D"); return selftest_mfma(device, A, B, D); }
+int mon_selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D) { REQUIRE(A, "A"); REQUIRE(B, "B"); REQUIRE(D, "D");
+    return selftest_mfma(device, A, B, D); }
 int mon_debug_occupancy_state(mon_object* o, uint32_t out[2]) {
     if (!o || !o->m || !out) { mon::set_error("debug_occupancy_state: null argument"); return MON_ERR_ARG; }
     out[0] = o->m->occ_refreshed_iter; out[1] = o->m->occ_next_refresh; return MON_OK;
@@ -134,8 +149,10 @@ int mon_debug_render_jobs(mon_object* o, int side, uint32_t* jobs) {
     if (!o || !o->m || !jobs) { mon::set_error("debug_render_jobs: null argument"); return MON_ERR_ARG; }
     mon::TileWs* ws = nullptr; const int rc = mon::tile_ws_get(*o->m, side, 0, &ws); if (rc) return rc;
     std::lock_guard<std::mutex> l(ws->mu);
-    if (mon::use_device(o->m->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { mon::set_error("debug_render_jobs: device error"); return MON_ERR_HIP; }
-    if (hipMemcpy(jobs, ws->counters + 16u * ((ws->flip + 1u) & 1u), 4, hipMemcpyDeviceToHost) != hipSuccess) { mon::set_error("debug_render_jobs: copy failed"); return MON_ERR_HIP; }
+    if (mon::use_device(o->m->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { mon::set_error("debug_render_jobs: device error");
+        return MON_ERR_HIP; }
+    if (hipMemcpy(jobs, ws->counters + 16u * ((ws->flip + 1u) & 1u), 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        mon::set_error("debug_render_jobs: copy failed"); return MON_ERR_HIP; }
     return MON_OK;
 }
 int mon_debug_yaml_number(const char* text, const char* key, double* value) {

@@ -24,9 +24,11 @@ __global__ void __launch_bounds__(64) k_selftest_mfma(const uint16_t* __restrict
 
 int selftest_mfma(int device, const uint16_t* A, const uint16_t* B, float* D) {
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || use_device(device) != hipSuccess) { set_error("selftest: no HIP device"); return MON_ERR_NO_DEVICE; }
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || use_device(device) != hipSuccess) { set_error("selftest: no HIP device");
+        return MON_ERR_NO_DEVICE; }
     uint16_t *dA = nullptr, *dB = nullptr; float* dD = nullptr;
-    if (hipMalloc((void**)&dA, 32 * 16 * 2) != hipSuccess || hipMalloc((void**)&dB, 16 * 32 * 2) != hipSuccess || hipMalloc((void**)&dD, 32 * 32 * 4) != hipSuccess) { set_error("selftest: hipMalloc failed"); return MON_ERR_HIP; }
+    if (hipMalloc((void**)&dA, 32 * 16 * 2) != hipSuccess || hipMalloc((void**)&dB, 16 * 32 * 2) != hipSuccess
+            || hipMalloc((void**)&dD, 32 * 32 * 4) != hipSuccess) { set_error("selftest: hipMalloc failed"); return MON_ERR_HIP; }
     hipMemcpy(dA, A, 32 * 16 * 2, hipMemcpyHostToDevice); hipMemcpy(dB, B, 16 * 32 * 2, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, 0, dA, dB, dD);
     const hipError_t e = hipMemcpy(D, dD, 32 * 32 * 4, hipMemcpyDeviceToHost);

@@ -30,21 +30,24 @@ __device__ __forceinline__ uint32_t points_prefix(PointsLds& l, const unsigned l
 // sample s = ray * 32 + n of iteration `iter`: training ray j is valid candidate number (j mod n_valid) in candidate order (fill_rollover_rays,
 // nerf_model.cu:280-294); position = GenerateInputPoints (:553-566) + WarpPoint (:140-150) -- the arithmetic of ray_sample in k_fused_train, which
 // recomputes t for the composite and stores the same x for the gradient scatter
-__device__ __forceinline__ void points_sample(const PointsLds& l, const BatchPtrs& b, const ObjectConst& oc, uint32_t iter, uint32_t nvalid, uint32_t nwords, uint32_t s, float4_t* __restrict__ x_all) {
+__device__ __forceinline__ void points_sample(const PointsLds& l, const BatchPtrs& b, const ObjectConst& oc, uint32_t iter, uint32_t nvalid, uint32_t nwords,
+        uint32_t s, float4_t* __restrict__ x_all) {
     const uint32_t ray = s >> 5, n = s & 31u;
     const uint32_t kth = ray % nvalid;
     uint32_t lo = 0, hi = nwords - 1u;
     while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if (l.prefix[mid] <= kth) lo = mid; else hi = mid - 1u; }
     unsigned long long wd = l.words[lo]; uint32_t kk = kth - l.prefix[lo], pos = 0;
 #pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t c = (uint32_t)__popcll(wd & ((1ull << sh) - 1ull)); if (kk >= c) { kk -= c; wd >>= sh; pos += (uint32_t)sh; } }
+    for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t c = (uint32_t)__popcll(wd & ((1ull << sh) - 1ull)); if (kk >= c) { kk -= c; wd >>= sh;
+            pos += (uint32_t)sh; } }
     const uint32_t cand = (lo << 6) + pos;
     const float t0 = b.cand_t0[cand], t1 = b.cand_t1[cand];
     const float dtr = (t1 - t0) / 32.0f;
     const float t = fmaf(dtr, (float)n + batch_rand(oc, kStreamDt, iter, ray * 32u + n), t0);
     float x[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { const float p = fmaf(t, b.cand_d[3u * cand + d], b.cand_o[3u * cand + d]); x[d] = (p - oc.aabb.mn[d]) / (oc.aabb.mx[d] - oc.aabb.mn[d]); }
+    for (int d = 0; d < 3; ++d) { const float p = fmaf(t, b.cand_d[3u * cand + d], b.cand_o[3u * cand + d]);
+        x[d] = (p - oc.aabb.mn[d]) / (oc.aabb.mx[d] - oc.aabb.mn[d]); }
     x_all[s] = float4_t{ x[0], x[1], x[2], t };
     if (n == 0u && b.ray_rec) {          // the ray's record for k_fused_train<PRE> (the fields its load_record collects from the candidate arrays)
         float* r = b.ray_rec + 12u * (size_t)ray;

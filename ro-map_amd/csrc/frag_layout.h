@@ -99,14 +99,16 @@ __host__ __device__ inline int frag_slots(const FragDims& d, int p, int out[2]) 
 // ---- dW partial rows of k_fused_train.  A workgroup writes its weight-gradient sums in ACCUMULATOR layout -- the order the MFMA C/D registers hold them --
 // so that its epilogue is plain conflict-free 16-byte LDS stores and coalesced global stores; whoever sums the rows (k_grid_scatter, k_reduce_partials) maps a
 // column to its parameter once, when it writes the total.  Column = ((tile * 4 + r / 4) * 64 + lane) * 4 + r % 4 for the 32x32 tiles of dW0 (tile = mb), then
-// dW1 (tile = mb * MB + nb, NH == 2); dWout keeps its four real output columns only: ((mb * 4 + r / 4) * 8 + h * 4 + c) * 4 + r % 4.  Column acc_cols() = loss partial.
+// dW1 (tile = mb * MB + nb, NH == 2); dWout keeps its four real output columns only: ((mb * 4 + r / 4) * 8 + h * 4 + c) * 4 + r % 4.  Column acc_cols() = loss
+// partial.
 __host__ __device__ inline int acc_cols(const FragDims& d) { return d.MB() * 1024 + (d.NH == 2 ? d.MB() * d.MB() * 1024 : 0) + d.MB() * 128; }
 __host__ __device__ inline int acc_off_w1(const FragDims& d) { return d.MB() * 1024; }
 __host__ __device__ inline int acc_off_wo(const FragDims& d) { return d.MB() * 1024 + (d.NH == 2 ? d.MB() * d.MB() * 1024 : 0); }
 // column -> index into the MLP parameter vector, or -1 (pad column of a narrow encoding)
 __host__ __device__ inline int acc_param(const FragDims& d, int col) {
     if (col < acc_off_wo(d)) {
-        const bool w1 = col >= acc_off_w1(d); const int q = (w1 ? col - acc_off_w1(d) : col) >> 2, r = 4 * ((q >> 6) & 3) + (col & 3), lane = q & 63, tile = q >> 8;
+        const bool w1 = col >= acc_off_w1(d);
+        const int q = (w1 ? col - acc_off_w1(d) : col) >> 2, r = 4 * ((q >> 6) & 3) + (col & 3), lane = q & 63, tile = q >> 8;
         const int n = lane & 31, h = lane >> 5;
         if (!w1) return n < d.EPAD ? (32 * tile + frag_rho(h, r)) * d.EPAD + n : -1;
         return d.OFF_W1() + (32 * (tile / d.MB()) + frag_rho(h, r)) * d.W + 32 * (tile % d.MB()) + n;

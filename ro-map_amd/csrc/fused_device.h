@@ -67,7 +67,9 @@ __device__ __forceinline__ int unit_of_slot(int s, int h, int j) { return 32 * (
 #endif
 constexpr int kEncodeBatch = MON_ENCODE_BATCH;
 #ifndef MON_V_STAGGER
-#define MON_V_STAGGER 0x20010      // odd waves of every workgroup start 16 x 1024 cycles late (measured: 51.0 -> 47.7 us dense, 45.8 -> 45.0 us late with 12; on the final kernels 12 / 14 / 16 / 18 / 20 units: 46.8 / 46.5 / 46.4 / 46.7 / 47.8 us dense, 43.5 / 43.6 / 43.2 / 43.3 / 44.9 late; modes 0, 1, 3 were slower)
+// odd waves of every workgroup start 16 x 1024 cycles late (measured on the gather chain: 51.0 -> 47.7 us dense, 45.8 -> 45.0 us late with 12; on round 2's
+// final kernels 12 / 14 / 16 / 18 / 20 units: 46.8 / 46.5 / 46.4 / 46.7 / 47.8 us dense, 43.5 / 43.6 / 43.2 / 43.3 / 44.9 late; modes 0, 1, 3 were slower)
+#define MON_V_STAGGER 0x20010
 #endif
 constexpr uint32_t kDefaultStagger = MON_V_STAGGER;
 
@@ -115,12 +117,17 @@ struct FusedArgs {
     float* x_soa;               // [B] float4 {x, y, z, 0}: warped sample positions for k_grid_scatter
     uint32_t lds_level_mask;    // bit l set: level l goes through k_grid_scatter instead of global atomics
     const uint16_t* frag_image; // A fragments in LDS layout (k_build_frag_image), N_FRAGS x 512 halves
-    uint32_t ablate;            // timing experiments only (option fused_ablate): 2 no dW, 4 no dE/x stores, 8 no rays (prologue + epilogue only), 16 keep zero-gradient samples, 32 no dW reduction, 64 encode only
-    uint8_t* touched_grid;      // per 4 grid entries (= one 8-parameter optimizer chunk): set to 1 next to every global atomic, or nullptr (see ParamPtrs::touched)
-    uint32_t big_switch;        // > 0: while big_levels_binned(st, big_switch) holds, EVERY level's dE rows are stored (kernels_bigscatter.hip bins the large levels)
+    // training: 1 = keep zero-gradient samples (option keep_zero_samples, the exactness test's A/B).  Render launcher: 1 = build the fragment image first
+    uint32_t keep_zero;
+    // per 4 grid entries (= one 8-parameter optimizer chunk): set to 1 next to every global atomic, or nullptr (see ParamPtrs::touched)
+    uint8_t* touched_grid;
+    // > 0: while big_levels_binned(st, big_switch) holds, EVERY level's dE rows are stored (kernels_bigscatter.hip bins the large levels)
+    uint32_t big_switch;
     uint32_t n_bins;            // ray bins of the compacted gradient rows (scatter_bins(R), host-chosen)
-    uint32_t stagger;           // bits 0-15: start delay of the second wave group in units of 1024 cycles, bits 16-17: how the groups are formed (see k_fused_train)
-    const uint32_t* occ_bits;   // occupancy-grid skipping (mon_config::occupancy_skip, default off): kOccRes^3 bits, 1 = the cell may hold density; nullptr = evaluate every sample
+    // bits 0-15: start delay of the second wave group in units of 1024 cycles, bits 16-17: how the groups are formed (see k_fused_train)
+    uint32_t stagger;
+    // occupancy-grid skipping (mon_config::occupancy_skip, default off): kOccRes^3 bits, 1 = the cell may hold density; nullptr = evaluate every sample
+    const uint32_t* occ_bits;
     const half2_t* e_soa;       // PRE variant: [L][B] encoded features written by k_encode_tiles (kernels_encode.hip); the kernel then issues no gathers at all
 };
 
@@ -134,7 +141,8 @@ __device__ __forceinline__ half_t frag_element(const half_t* __restrict__ w, int
 }
 
 template <int EPAD, int W, int NH>
-__global__ void __launch_bounds__(256) k_build_frag_image(const uint16_t* __restrict__ params, int L, uint16_t* __restrict__ image, const DevState* __restrict__ st) {
+__global__ void __launch_bounds__(256) k_build_frag_image(const uint16_t* __restrict__ params, int L, uint16_t* __restrict__ image,
+        const DevState* __restrict__ st) {
     using S = FusedShape<EPAD, W, NH>;
     if (st && st->n_valid == 0u) return;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -144,7 +152,8 @@ __global__ void __launch_bounds__(256) k_build_frag_image(const uint16_t* __rest
 // First kernel of a fused-backend iteration: the candidate rays (GenerateRays) and the weight-fragment image are
 // independent, so they share one launch (blocks [0, cand_blocks) generate candidates, the rest build fragments).
 template <int EPAD, int W, int NH>
-__global__ void __launch_bounds__(256) k_candidates_and_frags(BatchPtrs b, DatasetPtrs ds, ObjectConst oc, const DevState* __restrict__ st, uint32_t cand_blocks,
+__global__ void __launch_bounds__(256) k_candidates_and_frags(BatchPtrs b, DatasetPtrs ds, ObjectConst oc, const DevState* __restrict__ st,
+        uint32_t cand_blocks,
                                                               const uint16_t* __restrict__ params, int L, uint16_t* __restrict__ image) {
     using S = FusedShape<EPAD, W, NH>;
     if (blockIdx.x < cand_blocks) { gen_candidate(b, ds, oc, st->n_boxes, st->iter, blockIdx.x * blockDim.x + threadIdx.x); return; }
@@ -158,14 +167,16 @@ __device__ __forceinline__ void build_fragments(half_t* frags, LevelLds* llt, co
     using S = FusedShape<EPAD, W, NH>;
     for (int i = threadIdx.x; i <= kMaxLevels; i += blockDim.x) {
         llt->offset[i] = a.lt.offset[i];
-        if (i < kMaxLevels) { llt->scale[i] = a.lt.scale[i]; llt->size[i] = a.lt.size[i]; llt->my[i] = a.lt.my[i]; llt->mz[i] = a.lt.mz[i]; llt->mask[i] = a.lt.mask[i]; llt->hashed[i] = a.lt.hashed[i]; }
+        if (i < kMaxLevels) { llt->scale[i] = a.lt.scale[i]; llt->size[i] = a.lt.size[i]; llt->my[i] = a.lt.my[i]; llt->mz[i] = a.lt.mz[i];
+            llt->mask[i] = a.lt.mask[i]; llt->hashed[i] = a.lt.hashed[i]; }
     }
     const int total16 = (backward ? S::N_FRAGS : S::F_WOT) * 64;            // 16-byte pieces
     const uint4* src = reinterpret_cast<const uint4*>(a.frag_image); uint4* dst = reinterpret_cast<uint4*>(frags);
     for (int i = threadIdx.x; i < total16; i += blockDim.x) dst[i] = src[i];
 }
 
-__device__ __forceinline__ half8_t lds_frag(const half_t* frags, int frag, int lane) { return *reinterpret_cast<const half8_t*>(frags + frag * 512 + lane * 8); }
+__device__ __forceinline__ half8_t lds_frag(const half_t* frags, int frag, int lane) {
+    return *reinterpret_cast<const half8_t*>(frags + frag * 512 + lane * 8); }
 
 // relu + round to fp16 of one 32x32 C/D fragment -> two B fragments (registers 0..7, 8..15)
 __device__ __forceinline__ void relu_pack(const float16_t& acc, half8_t& lo, half8_t& hi) {
@@ -208,15 +219,20 @@ struct TileState {
     float out4[4];
 };
 
-// Per-level constants of the encode, one level per LANE: lane h * 32 + il holds level h * LPH + il, the level half-wave h owns in level pair il (a pair past the
-// last level holds a 1-entry dummy of level 0).  The gather code fetches them with v_readlane at compile-time lane numbers: no scalar loads (and no lgkmcnt waits) inside
-// the ray loop, and none of the 7 x 16 constants pinned in SGPRs (the kernel runs at the SGPR limit; as kernel arguments they were re-loaded from the argument segment
+// Per-level constants of the encode, one level per LANE: lane h * 32 + il holds level h * LPH + il, the level half-wave h owns in level pair il (a pair past
+// the
+// last level holds a 1-entry dummy of level 0).  The gather code fetches them with v_readlane at compile-time lane numbers: no scalar loads (and no lgkmcnt
+// waits) inside
+// the ray loop, and none of the 7 x 16 constants pinned in SGPRs (the kernel runs at the SGPR limit; as kernel arguments they were re-loaded from the argument
+// segment
 // for every level of every ray).
 struct LevelRegs { float scale; uint32_t size, my, mz, mask, off4, hashed; };
-// the same registers filled from the kernel ARGUMENTS (scalar loads + one select per field and level): nothing to wait for but the argument segment, no LDS copy, no barrier
+// the same registers filled from the kernel ARGUMENTS (scalar loads + one select per field and level): nothing to wait for but the argument segment, no LDS
+// copy, no barrier
 __device__ __forceinline__ LevelRegs load_level_regs_uniform(const LevelFast& klt, int L, int lane) {
     const int LPH = (L + 1) >> 1;
-    LevelRegs r; r.scale = klt.scale[0]; r.size = 1u; r.my = klt.my[0]; r.mz = klt.mz[0]; r.mask = 0u; r.off4 = 0u; r.hashed = 1u;      // the dummy level: always entry 0
+    // the dummy level: always entry 0
+    LevelRegs r; r.scale = klt.scale[0]; r.size = 1u; r.my = klt.my[0]; r.mz = klt.mz[0]; r.mask = 0u; r.off4 = 0u; r.hashed = 1u;
 #pragma unroll
     for (int l = 0; l < kMaxLevels; ++l) {
         const bool here = l < L && lane == ((l < LPH) ? l : 32 + l - LPH);
@@ -242,13 +258,15 @@ __device__ __forceinline__ float lane_f(float v, int src) { return __builtin_bit
 template <int EPAD, int W, int NH> struct GatherWindow {
     static constexpr int LLV = FusedShape<EPAD, W, NH>::LLV;
     static constexpr int EB = (LLV < kEncodeBatch) ? LLV : kEncodeBatch;              // level pairs in flight
-    uint32_t ra[EB][4], rb[EB][4];                                                    // pair il lives in slot il % EB: lanes (n, c) hold x-corner c of the four (y, z) corners, ra = level il, rb = level LPH + il
+    // pair il lives in slot il % EB: lanes (n, c) hold x-corner c of the four (y, z) corners, ra = level il, rb = level LPH + il
+    uint32_t ra[EB][4], rb[EB][4];
 };
 
 // the four gathers of one level (`slot` = the lane of `lr` that holds it: a compile-time number); `live` = false: this lane's sample sits in a cell the
 // occupancy grid marks empty -- its gathers are not issued (an exec-masked load costs no L2 request; r[] was zeroed by the caller)
 template <bool MASKED>
-__device__ __forceinline__ void gather_level(uint32_t (&r)[4], const LevelRegs& lr, int slot, const __amdgpu_buffer_rsrc_t rsrc, const float x[3], int h, bool live) {
+__device__ __forceinline__ void gather_level(uint32_t (&r)[4], const LevelRegs& lr, int slot, const __amdgpu_buffer_rsrc_t rsrc, const float x[3], int h,
+        bool live) {
     const float scale = lane_f(lr.scale, slot);
     const uint32_t size = lane_u(lr.size, slot), my = lane_u(lr.my, slot), mz = lane_u(lr.mz, slot), mask = lane_u(lr.mask, slot), off4 = lane_u(lr.off4, slot);
     uint32_t pg[3];
@@ -267,15 +285,18 @@ __device__ __forceinline__ void gather_level(uint32_t (&r)[4], const LevelRegs& 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             uint32_t i = (ax + ay[j & 1] + az[j >> 1]) & mask;
-            i -= (i >= size) ? size : 0u;                                           // dense sizes are not powers of two: index < 2 * size, so % size is one subtract
-            idx[j] = min(i, size - 1u);                                             // memory safety for positions far outside [0,1]^3 (never produced by the sampler)
+            // dense sizes are not powers of two: index < 2 * size, so % size is one subtract
+            i -= (i >= size) ? size : 0u;
+            // memory safety for positions far outside [0,1]^3 (never produced by the sampler)
+            idx[j] = min(i, size - 1u);
         }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (idx[j] << 2) + off4, 0, 0);
 }
 template <int EPAD, int W, int NH, bool MASKED>
-__device__ __forceinline__ void encode_issue(GatherWindow<EPAD, W, NH>& g, int il, const LevelRegs& lr, const __amdgpu_buffer_rsrc_t rsrc, const float x[3], int h, bool live) {
+__device__ __forceinline__ void encode_issue(GatherWindow<EPAD, W, NH>& g, int il, const LevelRegs& lr, const __amdgpu_buffer_rsrc_t rsrc, const float x[3],
+        int h, bool live) {
     constexpr int EB = GatherWindow<EPAD, W, NH>::EB;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { g.ra[il % EB][j] = 0u; g.rb[il % EB][j] = 0u; }      // (dead unless MASKED)
@@ -287,10 +308,12 @@ __device__ __forceinline__ void encode_swap(const GatherWindow<EPAD, W, NH>& g, 
     constexpr int EB = GatherWindow<EPAD, W, NH>::EB;
     typedef unsigned u2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const u2v sw = __builtin_amdgcn_permlane32_swap(g.ra[il % EB][j], g.rb[il % EB][j], false, false); c0[j] = sw.x; c1[j] = sw.y; }
+    for (int j = 0; j < 4; ++j) { const u2v sw = __builtin_amdgcn_permlane32_swap(g.ra[il % EB][j], g.rb[il % EB][j], false, false); c0[j] = sw.x;
+        c1[j] = sw.y; }
 }
 template <int EPAD, int W, int NH>
-__device__ __forceinline__ void encode_interp(TileState<EPAD, W, NH>& ts, int il, const uint32_t (&c0)[4], const uint32_t (&c1)[4], const LevelRegs& lr, const float x[3], int h, int L) {
+__device__ __forceinline__ void encode_interp(TileState<EPAD, W, NH>& ts, int il, const uint32_t (&c0)[4], const uint32_t (&c1)[4], const LevelRegs& lr,
+        const float x[3], int h, int L) {
     const int LPH = (L + 1) >> 1;
     const float scale = h ? lane_f(lr.scale, 32 + il) : lane_f(lr.scale, il);
     float pos[3];
@@ -309,7 +332,8 @@ __device__ __forceinline__ void encode_interp(TileState<EPAD, W, NH>& ts, int il
 }
 // the rest of a ray's encode once its first EB level pairs are in flight: a rolling window, pair il + EB is requested into the registers pair il frees
 template <int EPAD, int W, int NH, bool MASKED>
-__device__ __forceinline__ void encode_finish(TileState<EPAD, W, NH>& ts, GatherWindow<EPAD, W, NH>& g, const LevelRegs& lr, const __amdgpu_buffer_rsrc_t rsrc, const float x[3], int lane, int L, bool live) {
+__device__ __forceinline__ void encode_finish(TileState<EPAD, W, NH>& ts, GatherWindow<EPAD, W, NH>& g, const LevelRegs& lr, const __amdgpu_buffer_rsrc_t rsrc,
+        const float x[3], int lane, int L, bool live) {
     using S = FusedShape<EPAD, W, NH>; constexpr int EB = GatherWindow<EPAD, W, NH>::EB; const int h = lane >> 5;
 #pragma unroll
     for (int il = 0; il < S::LLV; ++il) {
@@ -320,14 +344,17 @@ __device__ __forceinline__ void encode_finish(TileState<EPAD, W, NH>& ts, Gather
     }
 }
 template <int EPAD, int W, int NH, bool MASKED>
-__device__ __forceinline__ void encode_begin(GatherWindow<EPAD, W, NH>& g, const LevelRegs& lr, const __amdgpu_buffer_rsrc_t rsrc, const float x[3], int lane, bool live) {
+__device__ __forceinline__ void encode_begin(GatherWindow<EPAD, W, NH>& g, const LevelRegs& lr, const __amdgpu_buffer_rsrc_t rsrc, const float x[3], int lane,
+        bool live) {
     constexpr int EB = GatherWindow<EPAD, W, NH>::EB;
 #pragma unroll
     for (int il = 0; il < EB; ++il) encode_issue<EPAD, W, NH, MASKED>(g, il, lr, rsrc, x, lane >> 5, live);
 }
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const half2_t* table, uint32_t table_bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<half2_t*>(table), 0, (int)table_bytes, 0x00020000); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const half2_t* table, uint32_t table_bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<half2_t*>(table), 0, (int)table_bytes, 0x00020000); }
 
-// MLP forward of one 32-sample tile from ts.ef: leaves the hidden activations as packed B fragments and out4 (raw network outputs of sample n, valid in half-wave 0)
+// MLP forward of one 32-sample tile from ts.ef: leaves the hidden activations as packed B fragments and out4 (raw network outputs of sample n, valid in
+// half-wave 0)
 template <int EPAD, int W, int NH>
 __device__ __forceinline__ void mlp_forward(TileState<EPAD, W, NH>& ts, const half_t* frags, int lane) {
     using S = FusedShape<EPAD, W, NH>;
@@ -350,7 +377,8 @@ __device__ __forceinline__ void mlp_forward(TileState<EPAD, W, NH>& ts, const ha
         for (int mb = 0; mb < S::MB; ++mb) {
             float16_t a1 = float16_t{ 0 };
 #pragma unroll
-            for (int s = 0; s < S::KSW; ++s) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(frags, S::F_W1 + mb * S::KSW + s, lane), ts.h0[s >> 1][s & 1], a1, 0, 0, 0);
+            for (int s = 0; s < S::KSW; ++s) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(frags, S::F_W1 + mb * S::KSW + s, lane),
+                    ts.h0[s >> 1][s & 1], a1, 0, 0, 0);
             relu_pack(a1, ts.h1[mb][0], ts.h1[mb][1]);
         }
     }
@@ -368,7 +396,8 @@ __device__ __forceinline__ void mlp_forward(TileState<EPAD, W, NH>& ts, const ha
 
 // Forward pass of one 32-sample tile in one go (render, occupancy grid): encode + MLP
 template <int EPAD, int W, int NH>
-__device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const half_t* frags, const LevelRegs& lr, const half2_t* __restrict__ table, uint32_t table_bytes, int L, const float x[3], int lane) {
+__device__ __forceinline__ void tile_forward(TileState<EPAD, W, NH>& ts, const half_t* frags, const LevelRegs& lr, const half2_t* __restrict__ table,
+        uint32_t table_bytes, int L, const float x[3], int lane) {
     const __amdgpu_buffer_rsrc_t rsrc = table_rsrc(table, table_bytes);
     GatherWindow<EPAD, W, NH> g;
     encode_begin<EPAD, W, NH, false>(g, lr, rsrc, x, lane, true);
@@ -385,7 +414,8 @@ __device__ __forceinline__ float dpp_f(float old, float src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, false));
 }
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t src) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xF, false); }
 // 32-lane inclusive scans (each half-wave scans independently: rows 0-1 and rows 2-3)
 __device__ __forceinline__ float scan_mul32(float v) {
     v *= dpp_f<0x111, 0xF>(1.f, v); v *= dpp_f<0x112, 0xF>(1.f, v); v *= dpp_f<0x114, 0xF>(1.f, v); v *= dpp_f<0x118, 0xF>(1.f, v);
@@ -404,7 +434,8 @@ __device__ __forceinline__ uint32_t scan_add64_u32(uint32_t v) {                
 }
 // value of the previous lane (lane 0 keeps `fill`; callers overwrite lane 32 themselves where the halves are independent)
 __device__ __forceinline__ float lane_prev(float v, float fill) { return dpp_f<0x138, 0xF>(fill, v); }
-__device__ __forceinline__ float lane_bcast(float v, int src_lane_uniform) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane_uniform)); }
+__device__ __forceinline__ float lane_bcast(float v, int src_lane_uniform) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane_uniform)); }
 
 #define MON_FUSED_DISPATCH(FN, ...)                                                            \
     do {                                                                                       \

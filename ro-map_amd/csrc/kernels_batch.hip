@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(256) k_gen_samples(BatchPtrs b, ObjectConst oc
     if (!render && st->n_valid == 0u) return;
     const uint32_t j = s / S, n = s - j * S;
     const uint32_t iter = render ? 0u : st->iter;
-    if (render && b.ray_flag[j] == 0) { b.pts[3 * s] = 0.f; b.pts[3 * s + 1] = 0.f; b.pts[3 * s + 2] = 0.f; b.tdist[s] = 0.f; return; }   // :599-602 (left uninitialised there)
+    // :599-602 (left uninitialised there)
+    if (render && b.ray_flag[j] == 0) { b.pts[3 * s] = 0.f; b.pts[3 * s + 1] = 0.f; b.pts[3 * s + 2] = 0.f; b.tdist[s] = 0.f; return; }
     const float t0 = b.ray_t0[j], t1 = b.ray_t1[j];
     const float dt = (t1 - t0) / (float)S;
     const float t = fmaf(dt, (float)n + (render ? render_rand(oc, idx_base + s) : batch_rand(oc, rng_stream, iter, idx_base + s)), t0);
@@ -153,10 +154,12 @@ void launch_gen_candidates(hipStream_t s, const BatchPtrs& b, const DatasetPtrs&
 void launch_build_rays(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st) {
     hipLaunchKernelGGL(k_build_rays, dim3((oc.R + 255) / 256), dim3(256), 0, s, b, oc, st);
 }
-void launch_gen_samples(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, const DevState* st, uint32_t S, uint32_t n_samples, uint32_t stream_id, uint32_t idx_base, int render) {
+void launch_gen_samples(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, const DevState* st, uint32_t S, uint32_t n_samples, uint32_t stream_id,
+        uint32_t idx_base, int render) {
     hipLaunchKernelGGL(k_gen_samples, dim3((n_samples + 255) / 256), dim3(256), 0, s, b, oc, st, S, n_samples, stream_id, idx_base, render);
 }
-void launch_render_rays(hipStream_t s, const BatchPtrs& b, const Intrinsics& K, const ObjectConst& oc, mon_frame_bbox box, const Mat4& pose, int pose_is_Toc, uint32_t pix0, uint32_t n) {
+void launch_render_rays(hipStream_t s, const BatchPtrs& b, const Intrinsics& K, const ObjectConst& oc, mon_frame_bbox box, const Mat4& pose, int pose_is_Toc,
+        uint32_t pix0, uint32_t n) {
     hipLaunchKernelGGL(k_render_rays, dim3((n + 255) / 256), dim3(256), 0, s, b, K, oc, box, pose, pose_is_Toc, pix0, n);
 }
 void launch_grid_points(hipStream_t s, float* pts, int rx, int ry, int rz, uint32_t p0, uint32_t n) {

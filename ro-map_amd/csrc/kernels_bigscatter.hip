@@ -23,13 +23,15 @@
 
 namespace mon {
 
-constexpr uint32_t kBigTile = 8192, kBigTileShift = 13, kBigBins = 16, kBigMaxTiles = 2048;   // 64 KB of LDS per tile (two workgroups per CU); up to 2^24 entries per level
+// 64 KB of LDS per tile (two workgroups per CU); up to 2^24 entries per level
+constexpr uint32_t kBigTile = 8192, kBigTileShift = 13, kBigBins = 16, kBigMaxTiles = 2048;
 
 struct BigLevels { int n; int level[kMaxLevels]; uint32_t tiles[kMaxLevels]; uint32_t tile_base[kMaxLevels + 1]; };
 
 // samples of bin group g (of kBigBins): the ray bins g, g + kBigBins, ... < n_bins, each a compacted run of st->n_scatter[b] samples at b * (B / n_bins)
 template <class F>
-__device__ __forceinline__ void for_bin_samples(const LevelFast& lf, int level, const half2_t* __restrict__ de, const float* __restrict__ x_soa, uint32_t B, uint32_t n_bins, uint32_t g,
+__device__ __forceinline__ void for_bin_samples(const LevelFast& lf, int level, const half2_t* __restrict__ de, const float* __restrict__ x_soa, uint32_t B,
+        uint32_t n_bins, uint32_t g,
                                                 const DevState* __restrict__ st, F&& f) {
   const uint32_t cap = B / n_bins;
   for (uint32_t b = g; b < n_bins; b += kBigBins) {
@@ -49,7 +51,8 @@ __device__ __forceinline__ void for_bin_samples(const LevelFast& lf, int level, 
   }
 }
 
-__global__ void __launch_bounds__(1024) k_big_hist(LevelFast lf, BigLevels big, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa, uint32_t B, uint32_t n_bins,
+__global__ void __launch_bounds__(1024) k_big_hist(LevelFast lf, BigLevels big, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa,
+        uint32_t B, uint32_t n_bins,
                                                   const DevState* __restrict__ st, uint32_t big_switch, uint32_t* __restrict__ hist) {
     __shared__ uint32_t h[kBigMaxTiles];
     if (st->n_valid == 0u || !big_levels_binned(st->n_scatter_last, big_switch)) return;
@@ -62,25 +65,31 @@ __global__ void __launch_bounds__(1024) k_big_hist(LevelFast lf, BigLevels big, 
 }
 
 // one workgroup per level: tile totals, exclusive scan over tiles, then per-bin write offsets
-__global__ void __launch_bounds__(1024) k_big_scan(BigLevels big, const DevState* __restrict__ st, uint32_t big_switch, const uint32_t* __restrict__ hist, uint32_t* __restrict__ woff,
+__global__ void __launch_bounds__(1024) k_big_scan(BigLevels big, const DevState* __restrict__ st, uint32_t big_switch, const uint32_t* __restrict__ hist,
+        uint32_t* __restrict__ woff,
                                                    uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ tile_off) {
     __shared__ uint32_t part[1024];
     if (st->n_valid == 0u || !big_levels_binned(st->n_scatter_last, big_switch)) return;
     const uint32_t bl = blockIdx.x, t = threadIdx.x, nt = big.tiles[bl];
     uint32_t tot[2] = { 0u, 0u };                                                   // two consecutive tiles per thread
-    for (uint32_t j = 0; j < 2u; ++j) if (2u * t + j < nt) for (uint32_t b = 0; b < kBigBins; ++b) tot[j] += hist[((size_t)bl * kBigBins + b) * kBigMaxTiles + 2u * t + j];
+    for (uint32_t j = 0; j < 2u; ++j) if (2u * t + j < nt) for (uint32_t b = 0; b < kBigBins; ++b) tot[j] += hist[((size_t)bl * kBigBins + b) * kBigMaxTiles
+            + 2u * t + j];
     part[t] = tot[0] + tot[1]; __syncthreads();
-    for (uint32_t d = 1; d < 1024u; d <<= 1) { const uint32_t v = (t >= d) ? part[t - d] : 0u; __syncthreads(); part[t] += v; __syncthreads(); }   // inclusive scan
+    // inclusive scan
+    for (uint32_t d = 1; d < 1024u; d <<= 1) { const uint32_t v = (t >= d) ? part[t - d] : 0u; __syncthreads(); part[t] += v; __syncthreads(); }
     uint32_t off = part[t] - tot[0] - tot[1];
     for (uint32_t j = 0; j < 2u; ++j) {
         const uint32_t tile = 2u * t + j; if (tile >= nt) break;
         tile_cnt[(size_t)bl * kBigMaxTiles + tile] = tot[j]; tile_off[(size_t)bl * kBigMaxTiles + tile] = off;
-        for (uint32_t b = 0; b < kBigBins; ++b) { woff[((size_t)bl * kBigBins + b) * kBigMaxTiles + tile] = off; off += hist[((size_t)bl * kBigBins + b) * kBigMaxTiles + tile]; }
+        for (uint32_t b = 0; b < kBigBins; ++b) { woff[((size_t)bl * kBigBins + b) * kBigMaxTiles + tile] = off;
+            off += hist[((size_t)bl * kBigBins + b) * kBigMaxTiles + tile]; }
     }
 }
 
-__global__ void __launch_bounds__(1024) k_big_emit(LevelFast lf, BigLevels big, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa, uint32_t B, uint32_t n_bins,
-                                                  const DevState* __restrict__ st, uint32_t big_switch, const uint32_t* __restrict__ woff, uint2* __restrict__ rec) {
+__global__ void __launch_bounds__(1024) k_big_emit(LevelFast lf, BigLevels big, const half2_t* __restrict__ de_soa, const float* __restrict__ x_soa,
+        uint32_t B, uint32_t n_bins,
+                                                  const DevState* __restrict__ st, uint32_t big_switch, const uint32_t* __restrict__ woff,
+                                                          uint2* __restrict__ rec) {
     __shared__ uint32_t cur[kBigMaxTiles];
     if (st->n_valid == 0u || !big_levels_binned(st->n_scatter_last, big_switch)) return;
     const uint32_t bl = blockIdx.x / kBigBins, b = blockIdx.x - bl * kBigBins; const int level = big.level[bl];
@@ -93,8 +102,10 @@ __global__ void __launch_bounds__(1024) k_big_emit(LevelFast lf, BigLevels big, 
     });
 }
 
-__global__ void __launch_bounds__(1024) k_big_accum(LevelFast lf, BigLevels big, const DevState* __restrict__ st, uint32_t big_switch, const uint32_t* __restrict__ tile_cnt,
-                                                    const uint32_t* __restrict__ tile_off, const uint2* __restrict__ rec, uint32_t B, uint32_t* __restrict__ ggrid_h2, uint8_t* __restrict__ touched_grid) {
+__global__ void __launch_bounds__(1024) k_big_accum(LevelFast lf, BigLevels big, const DevState* __restrict__ st, uint32_t big_switch,
+        const uint32_t* __restrict__ tile_cnt,
+                                                    const uint32_t* __restrict__ tile_off, const uint2* __restrict__ rec, uint32_t B,
+                                                            uint32_t* __restrict__ ggrid_h2, uint8_t* __restrict__ touched_grid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (st->n_valid == 0u || !big_levels_binned(st->n_scatter_last, big_switch)) return;
     int bl = 0;
@@ -110,7 +121,8 @@ __global__ void __launch_bounds__(1024) k_big_accum(LevelFast lf, BigLevels big,
     const uint2* in = rec + (size_t)bl * 8u * B + tile_off[(size_t)bl * kBigMaxTiles + t];
     for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
         const uint2 r = in[i]; const uint32_t local = r.x - base; const half2_t c = __builtin_bit_cast(half2_t, r.y);
-        const int f0 = (int)((float)c.x * lf.fix_scale), f1 = (int)((float)c.y * lf.fix_scale);   // exact for loss_scale <= 128: every fp16 value is a multiple of 2^-24
+        // exact for loss_scale <= 128: every fp16 value is a multiple of 2^-24
+        const int f0 = (int)((float)c.x * lf.fix_scale), f1 = (int)((float)c.y * lf.fix_scale);
         if (f0) atomicAdd(tab + 2u * local, f0);
         if (f1) atomicAdd(tab + 2u * local + 1u, f1);
     }
@@ -138,29 +150,36 @@ static int big_levels_plan(const LevelTable& lt, const NetDims& nd, uint32_t lds
     return big.n;
 }
 // Bytes of workspace launch_big_scatter needs; 0 = no level qualifies (or one is larger than 2^24 entries: atomics stay).
-size_t big_scatter_workspace_bytes(const LevelTable& lt, const NetDims& nd, uint32_t lds_mask, uint32_t B) {      // hist + woff + tile_cnt + tile_off, then the records
+// hist + woff + tile_cnt + tile_off, then the records
+size_t big_scatter_workspace_bytes(const LevelTable& lt, const NetDims& nd, uint32_t lds_mask, uint32_t B) {
     BigLevels big; const int n_big = big_levels_plan(lt, nd, lds_mask, big); if (n_big <= 0) return 0;
     return (size_t)n_big * (2 * kBigBins + 2) * kBigMaxTiles * 4 + (size_t)n_big * 8u * B * 8u;
 }
-void launch_big_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, uint32_t lds_mask, const uint16_t* de_soa, const float* x_soa, uint32_t B,
+void launch_big_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, uint32_t lds_mask, const uint16_t* de_soa,
+        const float* x_soa, uint32_t B,
                         uint32_t n_bins, const DevState* st, uint32_t big_switch, void* workspace, uint16_t* ggrid, uint8_t* touched_grid) {
     BigLevels big; if (big_levels_plan(lt, nd, lds_mask, big) <= 0) return;
     uint32_t* hist = reinterpret_cast<uint32_t*>(workspace); uint32_t* woff = hist + (size_t)big.n * kBigBins * kBigMaxTiles;
     uint32_t* tcnt = woff + (size_t)big.n * kBigBins * kBigMaxTiles; uint32_t* toff = tcnt + (size_t)big.n * kBigMaxTiles;
     uint2* rec = reinterpret_cast<uint2*>(toff + (size_t)big.n * kBigMaxTiles);
-    {   // once per device, and no launch before it has run (the flag is set AFTER the attribute call, under the lock: objects of one device launch from several host threads)
+    // once per device, and no launch before it has run (the flag is set AFTER the attribute call, under the lock: objects of one device launch from several
+    // host threads)
+    {
         static std::atomic<uint64_t> attr_devices{ 0 }; static std::mutex attr_mu;
         int dev = 0; (void)hipGetDevice(&dev); const uint64_t bit = 1ull << (dev & 63);
         if (!(attr_devices.load(std::memory_order_acquire) & bit)) {
             std::lock_guard<std::mutex> l(attr_mu);
-            if (!(attr_devices.load(std::memory_order_relaxed) & bit)) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_accum), hipFuncAttributeMaxDynamicSharedMemorySize, kBigTile * 8); attr_devices.fetch_or(bit, std::memory_order_release); }
+            if (!(attr_devices.load(std::memory_order_relaxed) & bit)) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_accum), hipFuncAttributeMaxDynamicSharedMemorySize, kBigTile * 8);
+                attr_devices.fetch_or(bit, std::memory_order_release); }
         }
     }
     const half2_t* de = reinterpret_cast<const half2_t*>(de_soa);
     hipLaunchKernelGGL(k_big_hist, dim3(big.n * kBigBins), dim3(1024), 0, s, lf, big, de, x_soa, B, n_bins, st, big_switch, hist);
     hipLaunchKernelGGL(k_big_scan, dim3(big.n), dim3(1024), 0, s, big, st, big_switch, hist, woff, tcnt, toff);
     hipLaunchKernelGGL(k_big_emit, dim3(big.n * kBigBins), dim3(1024), 0, s, lf, big, de, x_soa, B, n_bins, st, big_switch, woff, rec);
-    hipLaunchKernelGGL(k_big_accum, dim3(big.tile_base[big.n]), dim3(1024), kBigTile * 8, s, lf, big, st, big_switch, tcnt, toff, rec, B, reinterpret_cast<uint32_t*>(ggrid), touched_grid);
+    hipLaunchKernelGGL(k_big_accum, dim3(big.tile_base[big.n]), dim3(1024), kBigTile * 8, s, lf, big, st, big_switch, tcnt, toff, rec, B,
+            reinterpret_cast<uint32_t*>(ggrid), touched_grid);
 }
 
 }  // namespace mon

@@ -82,7 +82,8 @@ __global__ void __launch_bounds__(64) k_composite_grad(BatchPtrs b, ObjectConst 
 }
 
 // One thread per pixel: rays that missed the box, or ended with opacity <= 0.5, become white / 0 / 0.
-__global__ void __launch_bounds__(64) k_composite_render(BatchPtrs b, uint32_t S, uint32_t n_rays, float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ mask) {
+__global__ void __launch_bounds__(64) k_composite_render(BatchPtrs b, uint32_t S, uint32_t n_rays, float* __restrict__ rgb, float* __restrict__ depth,
+        float* __restrict__ mask) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rays) return;
     float o0 = 1.f, o1 = 1.f, o2 = 1.f, od = 0.f, om = 0.f;

@@ -59,7 +59,6 @@ struct EncodeArgs {
     const float4_t* x_all;         // [B] warped positions
     half2_t* e_soa;                // [L][B] encoded features
     uint32_t B, spw;               // samples of the batch, samples per workgroup (<= kEncThreads * kEncSpt)
-    uint32_t ablate;               // timing experiments (option encode_ablate): 1 no sample walk, 2 no tile loads
     const DevState* st;
     // GenerateRays (nerf_model.cu:369-446) of the NEXT iteration rides on the workgroups of level 0 (the coarsest level's tile is a few KB and its walk the
     // shortest of the grid): workgroup p of level 0 generates candidates [256 p, 256 p + 256) into the OTHER candidate set; k_optimizer's position blocks
@@ -67,7 +66,8 @@ struct EncodeArgs {
     uint32_t gen_next; BatchPtrs b_next; DatasetPtrs ds;  ObjectConst oc;
 };
 
-// the chain of encode_interp: corners in order k = x + 2y + 4z, c0[j] / c1[j] = x-corner 0 / 1 of pair j, weight ((wx * wy) * wz); the two x-corners of a pair and
+// the chain of encode_interp: corners in order k = x + 2y + 4z, c0[j] / c1[j] = x-corner 0 / 1 of pair j, weight ((wx * wy) * wz); the two x-corners of a pair
+// and
 // the two features of a corner are worked on as pairs (v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operations, two per instruction)
 __device__ __forceinline__ half2_t enc_chain(const uint32_t (&c0)[4], const uint32_t (&c1)[4], const float (&pos)[3]) {
     const float2_t wx = { 1.f - pos[0], pos[0] };
@@ -91,7 +91,8 @@ __device__ __forceinline__ void load_positions(float4_t (&xs)[kEncSpt], const fl
 }
 
 template <bool HASHED, bool POW2>
-__device__ __forceinline__ void encode_whole(const uint32_t* tile, const EncodeArgs& a, uint32_t s0, uint32_t s_end, half2_t* __restrict__ out, float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask) {
+__device__ __forceinline__ void encode_whole(const uint32_t* tile, const EncodeArgs& a, uint32_t s0, uint32_t s_end, half2_t* __restrict__ out, float scale,
+        uint32_t size, uint32_t my, uint32_t mz, uint32_t mask) {
     if (s0 >= s_end) return;
     float4_t xs[kEncSpt]; load_positions(xs, a.x_all, s0, s_end);
 #pragma unroll
@@ -107,11 +108,14 @@ __device__ __forceinline__ void encode_whole(const uint32_t* tile, const EncodeA
 }
 
 template <bool HASHED, bool POW2>
-__device__ __forceinline__ void encode_parity(uint32_t* tile, const uint4* __restrict__ src /* the level in the tile image: evens, then odds */, const EncodeArgs& a, uint32_t s0, uint32_t s_end, half2_t* __restrict__ out, float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask) {
+// (src: the level in the tile image, evens then odds)
+__device__ __forceinline__ void encode_parity(uint32_t* tile, const uint4* __restrict__ src, const EncodeArgs& a, uint32_t s0, uint32_t s_end,
+                                              half2_t* __restrict__ out, float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask) {
     // pass 0: the even entries.  Per pair the even one of (i0, i1) is read now; the odd one is kept for pass 1 as 16 bits whose (always set) lowest bit is
     // replaced by "the odd one is x-corner 0"
-    uint32_t veven[kEncSpt][4], cache[kEncSpt][2]; float pos[kEncSpt][3];      // (the position inside the cell is kept too: 24 registers against a second load + 9 instructions per sample)
-    const bool walk = !(a.ablate & 1u) && s0 < s_end;
+    // (the position inside the cell is kept too: 24 registers against a second load + 9 instructions per sample)
+    uint32_t veven[kEncSpt][4], cache[kEncSpt][2]; float pos[kEncSpt][3];
+    const bool walk = s0 < s_end;
     float4_t xs[kEncSpt];
     if (walk) load_positions(xs, a.x_all, s0, s_end);          // (the copy of the even half is under way: k_encode_tiles requested it at its entry)
     __builtin_amdgcn_s_waitcnt(0x0f70);                                   // vmcnt(0): the LDS writes of the copy are counted there
@@ -132,7 +136,7 @@ __device__ __forceinline__ void encode_parity(uint32_t* tile, const uint4* __res
         }
     }
     __syncthreads();
-    if (!(a.ablate & 2u)) tile_copy(tile, src + size / 8u, size / 8u);
+    tile_copy(tile, src + size / 8u, size / 8u);
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
     if (walk) {
@@ -158,7 +162,8 @@ __global__ void __launch_bounds__(kEncThreads) k_encode_tiles(EncodeArgs a) {
     uint32_t* tile = reinterpret_cast<uint32_t*>(smem);
     const uint32_t level = blockIdx.x / kEncWgPerLevel, part = blockIdx.x - level * kEncWgPerLevel;
     if (a.gen_next && level == 0u && blockIdx.y == 0u && threadIdx.x < 256u)
-        for (uint32_t c0 = part * 256u; c0 < a.oc.R; c0 += kEncWgPerLevel * 256u) gen_candidate(a.b_next, a.ds, a.oc, a.st->n_boxes, a.st->iter + 1u, c0 + threadIdx.x);
+        for (uint32_t c0 = part * 256u; c0 < a.oc.R; c0 += kEncWgPerLevel * 256u) gen_candidate(a.b_next, a.ds, a.oc, a.st->n_boxes, a.st->iter + 1u,
+                c0 + threadIdx.x);
     const uint32_t w = blockIdx.y * kEncWgPerLevel + part;             // sample partition of the batch
     const uint32_t s_base = w * a.spw, s_end = min(s_base + a.spw, a.B), s0 = s_base + threadIdx.x;
     if (s_base >= a.B) return;
@@ -167,22 +172,27 @@ __global__ void __launch_bounds__(kEncThreads) k_encode_tiles(EncodeArgs a) {
     const float scale = a.lt.scale[level];
     const uint4* src = reinterpret_cast<const uint4*>(a.half_tiles + 2u * (size_t)off);
     half2_t* out = a.e_soa + (size_t)level * a.B;
-    // the first tile is requested BEFORE the state is looked at (everything above comes from the argument segment): the round trip for n_valid_pre runs under the copy
-    if (!(a.ablate & 2u) || size <= kEncWholeMax) tile_copy(tile, src, size <= kEncWholeMax ? size / 4u : size / 8u);
+    // the first tile is requested BEFORE the state is looked at (everything above comes from the argument segment): the round trip for n_valid_pre runs under
+    // the copy
+    tile_copy(tile, src, size <= kEncWholeMax ? size / 4u : size / 8u);
     if (a.st->n_valid_pre == 0u) return;                               // batch skipped (the position pass wrote the count)
     if (size <= kEncWholeMax) {
         __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
-        if (hashed) { if (pow2) encode_whole<true, true>(tile, a, s0, s_end, out, scale, size, my, mz, mask); else encode_whole<true, false>(tile, a, s0, s_end, out, scale, size, my, mz, mask); }
+        if (hashed) { if (pow2) encode_whole<true, true>(tile, a, s0, s_end, out, scale, size, my, mz, mask);
+            else encode_whole<true, false>(tile, a, s0, s_end, out, scale, size, my, mz, mask); }
         else encode_whole<false, false>(tile, a, s0, s_end, out, scale, size, my, mz, mask);
     } else {
-        if (hashed) { if (pow2) encode_parity<true, true>(tile, src, a, s0, s_end, out, scale, size, my, mz, mask); else encode_parity<true, false>(tile, src, a, s0, s_end, out, scale, size, my, mz, mask); }
+        if (hashed) { if (pow2) encode_parity<true, true>(tile, src, a, s0, s_end, out, scale, size, my, mz, mask);
+            else encode_parity<true, false>(tile, src, a, s0, s_end, out, scale, size, my, mz, mask); }
         else encode_parity<false, false>(tile, src, a, s0, s_end, out, scale, size, my, mz, mask);
     }
 }
 
-// the tile image from the fp16 working copy (object creation, set_params, backend switch: whenever the weights changed outside k_optimizer, which keeps it current itself)
-__global__ void __launch_bounds__(256) k_build_tiles_image(LevelFast lt, int L, const uint32_t* __restrict__ grid /* half2 per entry */, uint32_t* __restrict__ image) {
+// the tile image from the fp16 working copy (object creation, set_params, backend switch: whenever the weights changed outside k_optimizer, which keeps it
+// current itself)
+__global__ void __launch_bounds__(256) k_build_tiles_image(LevelFast lt, int L, const uint32_t* __restrict__ grid /* half2 per entry */,
+                                                           uint32_t* __restrict__ image) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= lt.offset[L]) return;
     int lvl = 0;
@@ -192,14 +202,18 @@ __global__ void __launch_bounds__(256) k_build_tiles_image(LevelFast lt, int L, 
 }
 void launch_build_tiles_image(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* params, uint16_t* half_tiles) {
     const uint32_t n = lf.offset[nd.L];
-    hipLaunchKernelGGL(k_build_tiles_image, dim3((n + 255u) / 256u), dim3(256), 0, s, lf, nd.L, reinterpret_cast<const uint32_t*>(params + nd.n_mlp), reinterpret_cast<uint32_t*>(half_tiles));
+    hipLaunchKernelGGL(k_build_tiles_image, dim3((n + 255u) / 256u), dim3(256), 0, s, lf, nd.L, reinterpret_cast<const uint32_t*>(params + nd.n_mlp),
+            reinterpret_cast<uint32_t*>(half_tiles));
 }
 
 // ------------------------------------------------------------------ XORWOW sample stream (xorwow.h; mon_config::rng_flags, default off)
-// One thread per lane of the host generator: up to three generate calls in sequence (an iteration's SampleXY, RandColors, RandDt; or one Render's RandDt), value j of a
+// One thread per lane of the host generator: up to three generate calls in sequence (an iteration's SampleXY, RandColors, RandDt; or one Render's RandDt),
+// value j of a
 // call from lane j mod LANES; the lane's state goes back to memory for the next iteration's calls.
-__global__ void __launch_bounds__(256) k_xorwow_fill(XorwowState* __restrict__ states, uint32_t lanes, int flavour, uint32_t start /* generator offset mod lanes before the first call */,
-                                                     float* __restrict__ out0, uint32_t n0, float* __restrict__ out1, uint32_t n1, float* __restrict__ out2, uint32_t n2) {
+// (start: generator offset mod lanes before the first call)
+__global__ void __launch_bounds__(256) k_xorwow_fill(XorwowState* __restrict__ states, uint32_t lanes, int flavour, uint32_t start,
+                                                     float* __restrict__ out0, uint32_t n0, float* __restrict__ out1, uint32_t n1, float* __restrict__ out2,
+                                                             uint32_t n2) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= lanes) return;
     XorwowState st = states[k];
@@ -212,22 +226,27 @@ __global__ void __launch_bounds__(256) k_xorwow_fill(XorwowState* __restrict__ s
     for (uint32_t j = (k + lanes - s) % lanes; j < n2; j += lanes) out2[j] = xorwow_uniform(xorwow_next(st), flavour);
     states[k] = st;
 }
-void launch_xorwow_fill(hipStream_t s, void* lane_states, uint32_t lanes, int flavour, uint32_t start, float* out0, uint32_t n0, float* out1, uint32_t n1, float* out2, uint32_t n2) {
-    hipLaunchKernelGGL(k_xorwow_fill, dim3((lanes + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<XorwowState*>(lane_states), lanes, flavour, start, out0, n0, out1, n1, out2, n2);
+void launch_xorwow_fill(hipStream_t s, void* lane_states, uint32_t lanes, int flavour, uint32_t start, float* out0, uint32_t n0, float* out1, uint32_t n1,
+        float* out2, uint32_t n2) {
+    hipLaunchKernelGGL(k_xorwow_fill, dim3((lanes + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<XorwowState*>(lane_states), lanes, flavour, start, out0,
+            n0, out1, n1, out2, n2);
 }
 
-void encode_tiles_setup_device() { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsBytes); }
+void encode_tiles_setup_device() {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsBytes); }
 
 void launch_sample_points(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* x_all) {
     const uint32_t B = oc.R * 32u;
     hipLaunchKernelGGL(k_sample_points, dim3((B + 255u) / 256u), dim3(256), 0, s, b, oc, st, reinterpret_cast<float4_t*>(x_all));
 }
 
-void launch_encode_tiles(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* half_tiles, const float* x_all, uint16_t* e_soa, uint32_t B, const DevState* st,
+void launch_encode_tiles(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* half_tiles, const float* x_all, uint16_t* e_soa, uint32_t B,
+        const DevState* st,
                          const BatchPtrs* b_next, const DatasetPtrs& ds, const ObjectConst& oc) {
     const uint32_t per_chunk = kEncWgPerLevel * kEncThreads * kEncSpt, chunks = (B + per_chunk - 1u) / per_chunk;
     const uint32_t spw = (B + kEncWgPerLevel * chunks - 1u) / (kEncWgPerLevel * chunks);
-    EncodeArgs a{ lf, nd.L, nd.n_mlp, half_tiles, reinterpret_cast<const float4_t*>(x_all), reinterpret_cast<half2_t*>(e_soa), B, spw, (uint32_t)options().encode_ablate, st, b_next ? 1u : 0u, b_next ? *b_next : BatchPtrs{}, ds, oc };
+    EncodeArgs a{ lf, nd.L, nd.n_mlp, half_tiles, reinterpret_cast<const float4_t*>(x_all), reinterpret_cast<half2_t*>(e_soa), B, spw, st,
+            b_next ? 1u : 0u, b_next ? *b_next : BatchPtrs{}, ds, oc };
     hipLaunchKernelGGL(k_encode_tiles, dim3((uint32_t)nd.L * kEncWgPerLevel, chunks), dim3(kEncThreads), kEncLdsBytes, s, a);
 }
 

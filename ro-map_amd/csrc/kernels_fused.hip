@@ -6,7 +6,8 @@
 namespace mon {
 
 // ------------------------------------------------------------------ fused training kernel
-template <int EPAD, int W, int NH, bool DUMP, bool ATOMIC_LEVELS, bool OCC = false, bool PRE = false /* the encode was done by k_encode_tiles: features are loaded, not gathered */>
+// (PRE: the encode was done by k_encode_tiles -- features are loaded, not gathered)
+template <int EPAD, int W, int NH, bool DUMP, bool ATOMIC_LEVELS, bool OCC = false, bool PRE = false>
 __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_train(FusedArgs a) {
     using S = FusedShape<EPAD, W, NH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -17,7 +18,8 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     unsigned char* dyn = smem + S::FRAG_BYTES + S::LT_BYTES;
 #ifdef MON_FUSED_TIMING
     TimingCtx tcx; for (float& v : tcx.acc) v = 0.f; tcx.last = clock64(); TimingCtx* tc = &tcx;
-    tcx.acc[13] = (float)(uint32_t)(wall_clock64() & 0xffffffull); tcx.acc[15] = (float)(uint32_t)__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);      // start time (100 MHz ticks, low 24 bits), HW_ID[15:0]
+    // start time (100 MHz ticks, low 24 bits), HW_ID[15:0]
+    tcx.acc[13] = (float)(uint32_t)(wall_clock64() & 0xffffffull); tcx.acc[15] = (float)(uint32_t)__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
 #else
     TimingCtx* tc = nullptr;
 #endif
@@ -25,22 +27,26 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     //      the workgroup barrier: the iteration counter, the candidates' ballot words, the fragment image.
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
     const int L = a.nd.L, LPH = (L + 1) >> 1;
-    const uint32_t R = (a.ablate & 8u) ? 0u : a.oc.R, iter = a.st->iter;
+    const uint32_t R = a.oc.R, iter = a.st->iter;
     // ---- ray compaction (fill_rollover_rays :280-294 without a kernel of its own): training ray j is valid candidate number (j mod n_valid) in candidate
     //      order.  Up to 4096 candidates (64 ballot words) every WAVE keeps the words and their exclusive prefix in registers, one word per lane, and finds a
     //      ray's candidate with a ballot and two v_readlanes; larger batches go through a table in LDS built by wave 0.
     const uint32_t nwords = a.oc.R >> 6;                                           // <= 256 (fused_supported)
     const bool small = nwords <= 64u;                                              // uniform
     unsigned long long my_word = 0ull;
-    const bool have_rec = PRE && a.b.ray_rec != nullptr;                           // (uniform) the position pass left the compacted rays' records: no ballot words, no scan, no select
+    // (uniform) the position pass left the compacted rays' records: no ballot words, no scan, no select
+    const bool have_rec = PRE && a.b.ray_rec != nullptr;
     if (!have_rec && small && (uint32_t)lane < nwords) my_word = a.b.mask[lane];
-    const LevelRegs lregs = load_level_regs_uniform(a.lt, L, lane); const uint32_t table_bytes = a.lt.offset[L] * 4u;      // (from the argument segment: it ends up in the buffer descriptor, which must be scalar)
+    // (from the argument segment: it ends up in the buffer descriptor, which must be scalar)
+    const LevelRegs lregs = load_level_regs_uniform(a.lt, L, lane); const uint32_t table_bytes = a.lt.offset[L] * 4u;
     build_fragments<EPAD, W, NH>(frags, llt, a, true);
     half_t* scr = reinterpret_cast<half_t*>(dyn + wave * S::SCR_BYTES);
-    for (int i = 2 * a.nd.L * 32 + lane; i < EPAD * 32; i += 64) scr[S::SCR_E + i] = (half_t)0.f;   // pad feature rows stay zero; every other row is rewritten per ray before it is read
+    // pad feature rows stay zero; every other row is rewritten per ray before it is read
+    for (int i = 2 * a.nd.L * 32 + lane; i < EPAD * 32; i += 64) scr[S::SCR_E + i] = (half_t)0.f;
     uint32_t my_excl = 0u, nvalid = 0u;
     if (have_rec) nvalid = a.st->n_valid_pre;
-    else if (small) { const uint32_t c = __popcll(my_word), inc = scan_add64_u32(c); my_excl = inc - c; nvalid = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63); }
+    else if (small) { const uint32_t c = __popcll(my_word), inc = scan_add64_u32(c); my_excl = inc - c;
+        nvalid = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63); }
     else if (wave == 0) {
         uint32_t carry = 0;
         for (uint32_t base = 0; base < nwords; base += 64) {
@@ -56,7 +62,8 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         unsigned long long wd; uint32_t kk, lo;
         if (small) {
             lo = (uint32_t)__popcll(__ballot(my_excl <= kth)) - 1u;                  // the prefix is non-decreasing (lanes past the last word hold the total)
-            wd = ((unsigned long long)lane_u((uint32_t)(my_word >> 32), (int)lo) << 32) | lane_u((uint32_t)my_word, (int)lo); kk = kth - lane_u(my_excl, (int)lo);
+            wd = ((unsigned long long)lane_u((uint32_t)(my_word >> 32), (int)lo) << 32) | lane_u((uint32_t)my_word, (int)lo);
+            kk = kth - lane_u(my_excl, (int)lo);
         } else {
             lo = 0; uint32_t hi = nwords - 1u;
             while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if (cprefix[mid] <= kth) lo = mid; else hi = mid - 1u; }
@@ -72,9 +79,11 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     {   const void* fb = lane == 0 ? (const void*)a.b.cand_rgba : lane == 1 ? (const void*)a.b.cand_t0 : lane == 2 ? (const void*)a.b.cand_t1
                        : lane < 6 ? (const void*)(a.b.cand_d + (lane - 3)) : lane < 9 ? (const void*)(a.b.cand_o + (lane - 6)) : (const void*)a.b.cand_depth;
         rec_base = reinterpret_cast<const char*>(fb); if (lane >= 3 && lane < 9) rec_mul = 3u; }
-    const auto load_record = [&](uint32_t cand) -> uint32_t { uint32_t v = 0u; if (lane < 10) v = *reinterpret_cast<const uint32_t*>(rec_base + 4u * (size_t)(cand * rec_mul)); return v; };
+    const auto load_record = [&](uint32_t cand) -> uint32_t { uint32_t v = 0u;
+        if (lane < 10) v = *reinterpret_cast<const uint32_t*>(rec_base + 4u * (size_t)(cand * rec_mul)); return v; };
     // (PRE with records: lane l < 10 takes field l of ray `r`'s 12-float record -- one coalesced 40-byte load, requested a ray ahead like the candidate record)
-    const auto load_ray_rec = [&](uint32_t r) -> uint32_t { uint32_t v = 0u; if (lane < 11) v = reinterpret_cast<const uint32_t*>(a.b.ray_rec)[12u * (size_t)r + (uint32_t)lane]; return v; };
+    const auto load_ray_rec = [&](uint32_t r) -> uint32_t { uint32_t v = 0u;
+        if (lane < 11) v = reinterpret_cast<const uint32_t*>(a.b.ray_rec)[12u * (size_t)r + (uint32_t)lane]; return v; };
     const uint32_t ray0 = blockIdx.x * S::WAVES + wave;
     uint32_t cand = 0u, rec = 0u;
     if (have_rec) { if (nvalid != 0u && ray0 < R) rec = load_ray_rec(ray0); }
@@ -84,7 +93,9 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->n_valid = nvalid; a.st->loss_sum = 0.f; }
     if (nvalid == 0u) return;                                                        // batch skipped (uniform over the grid)
 
-    const uint32_t lds_level_mask = (ATOMIC_LEVELS && a.big_switch != 0u && big_levels_binned(a.st->n_scatter_last, a.big_switch)) ? 0xffffffffu : a.lds_level_mask;   // wave-uniform
+    // wave-uniform
+    const uint32_t lds_level_mask = (ATOMIC_LEVELS && a.big_switch != 0u && big_levels_binned(a.st->n_scatter_last, a.big_switch)) ? 0xffffffffu
+            : a.lds_level_mask;
     const half2_t* table = reinterpret_cast<const half2_t*>(a.params + a.nd.n_mlp);
     typedef __attribute__((address_space(1))) half2_t gh2;
     gh2* gtable = (gh2*)reinterpret_cast<half2_t*>(a.ggrid);
@@ -101,8 +112,10 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
             for (int nb = 0; nb < S::MB; ++nb) dW1[mb][nb] = float16_t{ 0 };
     }
     float loss_acc = 0.f;
-    // ---- phase stagger.  All waves of a CU share one texture-address path, and a ray's 64 gather instructions keep it busy for ~1.5 us; the waves start together and
-    //      their phases have equal lengths, so they would ALL gather, then ALL run the MLP / composite / backward with the address path idle.  Half of the waves therefore
+    // ---- phase stagger.  All waves of a CU share one texture-address path, and a ray's 64 gather instructions keep it busy for ~1.5 us; the waves start
+    // together and
+    // their phases have equal lengths, so they would ALL gather, then ALL run the MLP / composite / backward with the address path idle.  Half of the waves
+    // therefore
     //      start late by about one gather phase: from then on one group computes while the other gathers.
     if (a.stagger & 0xffffu) {
         const uint32_t mode = (a.stagger >> 16) & 3u;
@@ -115,13 +128,16 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
 
     // ---- ray loop.  The candidate record of ray k + 1 is requested while ray k is processed.  (Also tried: requesting the first EB level pairs of ray k + 1
     //      before ray k's MLP / composite / backward -- no gain, 48.4 vs 48.6 us without the stagger and 9 spilled registers: the gather phase is bound by the
-    //      chip-wide L2 request rate, not by its start-up latency; an encode-only variant of this kernel, `fused_ablate` 96, takes 39.5 us.)
+    //      chip-wide L2 request rate, not by its start-up latency; an encode-only variant of this kernel took 39.5 us, profiles/r03_*.)
     struct RaySample { float t, x[3]; uint32_t rgba; float tdp, t0, t1; bool live, any; };
-    const auto ray_sample = [&](uint32_t recv, uint32_t ray) {                           // sample n of the ray described by record `recv` (GenerateInputPoints, nerf_model.cu:553-566)
+    // sample n of the ray described by record `recv` (GenerateInputPoints, nerf_model.cu:553-566)
+    const auto ray_sample = [&](uint32_t recv, uint32_t ray) {
         RaySample q; q.rgba = lane_u(recv, 0); q.tdp = __builtin_bit_cast(float, lane_u(recv, 9));
         const float t0 = __builtin_bit_cast(float, lane_u(recv, 1)), t1 = __builtin_bit_cast(float, lane_u(recv, 2));
-        const float rd[3] = { __builtin_bit_cast(float, lane_u(recv, 3)), __builtin_bit_cast(float, lane_u(recv, 4)), __builtin_bit_cast(float, lane_u(recv, 5)) };
-        const float ro[3] = { __builtin_bit_cast(float, lane_u(recv, 6)), __builtin_bit_cast(float, lane_u(recv, 7)), __builtin_bit_cast(float, lane_u(recv, 8)) };
+        const float rd[3] = { __builtin_bit_cast(float, lane_u(recv, 3)), __builtin_bit_cast(float, lane_u(recv, 4)),
+                __builtin_bit_cast(float, lane_u(recv, 5)) };
+        const float ro[3] = { __builtin_bit_cast(float, lane_u(recv, 6)), __builtin_bit_cast(float, lane_u(recv, 7)),
+                __builtin_bit_cast(float, lane_u(recv, 8)) };
         const float dtr = (t1 - t0) / 32.0f; q.t0 = t0; q.t1 = t1;
         q.t = fmaf(dtr, (float)n + batch_rand(a.oc, kStreamDt, iter, ray * 32u + (uint32_t)n), t0);
 #pragma unroll
@@ -129,7 +145,9 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         // occupancy-grid skipping (default off): a sample whose cell the grid marks empty is not evaluated -- no gathers, alpha = 0, no gradient
         q.live = true;
         if constexpr (OCC) {
-            const uint32_t cx = (uint32_t)min(max((int)(q.x[0] * (float)kOccRes), 0), kOccRes - 1), cy = (uint32_t)min(max((int)(q.x[1] * (float)kOccRes), 0), kOccRes - 1), cz = (uint32_t)min(max((int)(q.x[2] * (float)kOccRes), 0), kOccRes - 1);
+            const uint32_t cx = (uint32_t)min(max((int)(q.x[0] * (float)kOccRes), 0), kOccRes - 1),
+                    cy = (uint32_t)min(max((int)(q.x[1] * (float)kOccRes), 0), kOccRes - 1),
+                    cz = (uint32_t)min(max((int)(q.x[2] * (float)kOccRes), 0), kOccRes - 1);
             q.live = ((a.occ_bits[((cz * kOccRes + cy) * kOccRes + cx) >> 5] >> (cx & 31u)) & 1u) != 0u;
         }
         q.any = !OCC || __ballot(q.live) != 0ull;                                         // false: the whole ray crosses empty cells only, nothing to evaluate
@@ -158,22 +176,23 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         if constexpr (PRE) {
 #pragma unroll
             for (int il = 0; il < S::LLV; ++il) { const half2_t v = __builtin_bit_cast(half2_t, epre[il]); ts.ef[2 * il] = v.x; ts.ef[2 * il + 1] = v.y; }
-        } else if (cur.any) { GatherWindow<EPAD, W, NH> gw; encode_begin<EPAD, W, NH, OCC>(gw, lregs, rsrc, x, lane, live); encode_finish<EPAD, W, NH, OCC>(ts, gw, lregs, rsrc, x, lane, L, live); }
+        } else if (cur.any) { GatherWindow<EPAD, W, NH> gw; encode_begin<EPAD, W, NH, OCC>(gw, lregs, rsrc, x, lane, live);
+            encode_finish<EPAD, W, NH, OCC>(ts, gw, lregs, rsrc, x, lane, L, live); }
         tstamp(tc, 2);
         // the next ray's candidate record is requested HERE, behind this ray's last gather: vmcnt retires in order, so a load issued before the gathers would
         // have to land before the first level pair can be consumed; now its latency runs under the MLP, composite and backward pass
-        if (ray + ray_stride < R) { if (have_rec) rec = load_ray_rec(ray + ray_stride); else { cand = select((ray + ray_stride) % nvalid); rec = load_record(cand); } if constexpr (PRE) load_encoded(ray + ray_stride); }
-        if (a.ablate & 64u) { float sacc = 0.f; for (int i = 0; i < EPAD / 2; ++i) sacc += (float)ts.ef[i]; loss_acc += sacc; continue; }      // timing experiments: the encode alone
+        if (ray + ray_stride < R) { if (have_rec) rec = load_ray_rec(ray + ray_stride); else { cand = select((ray + ray_stride) % nvalid);
+                rec = load_record(cand); } if constexpr (PRE) load_encoded(ray + ray_stride); }
         if (!OCC || __ballot(live) != 0ull) mlp_forward<EPAD, W, NH>(ts, frags, lane);
         else {
 #pragma unroll
             for (int i = 0; i < EPAD / 2; ++i) ts.ef[i] = (half_t)0.f;
 #pragma unroll
-            for (int mb = 0; mb < S::MB; ++mb) { ts.h0[mb][0] = half8_t{}; ts.h0[mb][1] = half8_t{}; if constexpr (NH == 2) { ts.h1[mb][0] = half8_t{}; ts.h1[mb][1] = half8_t{}; } }
+            for (int mb = 0; mb < S::MB; ++mb) { ts.h0[mb][0] = half8_t{}; ts.h0[mb][1] = half8_t{}; if constexpr (NH == 2) { ts.h1[mb][0] = half8_t{};
+                    ts.h1[mb][1] = half8_t{}; } }
 #pragma unroll
             for (int c = 0; c < 4; ++c) ts.out4[c] = 0.f;
         }
-        const bool do_dw = (a.ablate & 2u) == 0u;
 
         tstamp(tc, 4);
         // ---- composite (VolumeRender :762-813) as wave scans over lanes 0..31
@@ -189,11 +208,14 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         const float Tfin = lane_bcast(tincl, nact - 1);                                    // broadcast from half-wave 0 (sample 0 is always active: nact >= 1)
         const float wgt = active ? alpha * T : 0.f;
         const float p0 = scan_add32(wgt * c0), p1 = scan_add32(wgt * c1), p2 = scan_add32(wgt * c2), pd = scan_add32(wgt * t);
-        const float bg0 = batch_rand(a.oc, kStreamColor, iter, 3u * kth), bg1 = batch_rand(a.oc, kStreamColor, iter, 3u * kth + 1u), bg2 = batch_rand(a.oc, kStreamColor, iter, 3u * kth + 2u);   // :760, :438-441
+        // :760, :438-441
+        const float bg0 = batch_rand(a.oc, kStreamColor, iter, 3u * kth), bg1 = batch_rand(a.oc, kStreamColor, iter, 3u * kth + 1u),
+                bg2 = batch_rand(a.oc, kStreamColor, iter, 3u * kth + 2u);
         const float rgb0 = lane_bcast(p0, 31) + Tfin * bg0, rgb1 = lane_bcast(p1, 31) + Tfin * bg1, rgb2 = lane_bcast(p2, 31) + Tfin * bg2;
         const float dep = lane_bcast(pd, 31), mask = 1.f - Tfin;
         // ---- loss + dL/dO (VolumeRenderGradient_No_Compacted :853-953)
-        const float tg0 = is_obj ? (float)(rgba & 0xffu) / 255.0f : bg0, tg1 = is_obj ? (float)((rgba >> 8) & 0xffu) / 255.0f : bg1, tg2 = is_obj ? (float)((rgba >> 16) & 0xffu) / 255.0f : bg2;
+        const float tg0 = is_obj ? (float)(rgba & 0xffu) / 255.0f : bg0, tg1 = is_obj ? (float)((rgba >> 8) & 0xffu) / 255.0f : bg1, tg2 = is_obj
+                ? (float)((rgba >> 16) & 0xffu) / 255.0f : bg2;
         const float e0 = rgb0 - tg0, e1 = rgb1 - tg1, e2 = rgb2 - tg2;
         const float g0 = 2.f * e0, g1 = 2.f * e1, g2 = 2.f * e2;
         float dl_dd = 0.f; if (tdp > 0.f) dl_dd = 0.5f * ((dep - tdp >= 0.f) ? 1.f : -1.f);
@@ -225,12 +247,14 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         // ---- which samples carry a gradient at all.  dL/dO is fp16 with a loss scale of 128/R: once empty space is learnt
         //      (sigma = exp(-15), alpha * T -> 0) it underflows to exact zeros, 94-98 % of the samples after ~200 steps
         //      (tools/zero_grad_fraction.py).  Zero rows contribute exact zeros to dW and dE, so a ray without any is done
-        //      here, and only the non-zero samples are handed to k_grid_scatter, compacted into ray bins (ray mod n_bins, up to 128: one returning atomic per ray on 16 counters cost 7 us of contention).  Inside a
+        // here, and only the non-zero samples are handed to k_grid_scatter, compacted into ray bins (ray mod n_bins, up to 128: one returning atomic per ray on
+        // 16 counters cost 7 us of contention).  Inside a
         //      bin the order is whatever the atomics give -- irrelevant, the scatter's integer accumulation is exact -- while
         //      bin membership, and with it every fp16-rounded partial table, is a fixed function of the ray: the result stays
         //      deterministic.  The slot reservation is issued now and consumed after the MFMAs.
         const uint2 bdo_bits = __builtin_bit_cast(uint2, half4_t{ bdo[0], bdo[1], bdo[2], bdo[3] });
-        const uint32_t nz32 = (a.ablate & 16u) ? 0xffffffffu : (uint32_t)__ballot(h == 0 && ((bdo_bits.x | bdo_bits.y) & 0x7fff7fffu) != 0u);   // ablate 16: no skipping (A/B check)
+        // option keep_zero_samples: no skipping (the exactness test's A/B)
+        const uint32_t nz32 = a.keep_zero ? 0xffffffffu : (uint32_t)__ballot(h == 0 && ((bdo_bits.x | bdo_bits.y) & 0x7fff7fffu) != 0u);
         const uint32_t nz_cnt = __popc(nz32);
         uint32_t slot_base = 0u;
         if (nz_cnt != 0u && lane == 0 && lds_level_mask) slot_base = atomicAdd(&a.st->n_scatter[scatter_counter(iter, ray & (n_bins - 1u))], nz_cnt);
@@ -242,8 +266,10 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         if (DUMP) {
             if (lane == 0) {
                 for (int d = 0; d < 3; ++d) { a.b.ray_o[3 * ray + d] = a.b.cand_o[3 * cand_this + d]; a.b.ray_d[3 * ray + d] = a.b.cand_d[3 * cand_this + d]; }
-                a.b.ray_t0[ray] = t0; a.b.ray_t1[ray] = t1; a.b.ray_dn[ray] = a.b.cand_dn[cand_this]; a.b.ray_flag[ray] = is_obj ? 1 : 0; a.b.target_depth[ray] = tdp;
-                a.b.bgcol[3 * ray] = bg0; a.b.bgcol[3 * ray + 1] = bg1; a.b.bgcol[3 * ray + 2] = bg2; a.b.target[3 * ray] = tg0; a.b.target[3 * ray + 1] = tg1; a.b.target[3 * ray + 2] = tg2;
+                a.b.ray_t0[ray] = t0; a.b.ray_t1[ray] = t1; a.b.ray_dn[ray] = a.b.cand_dn[cand_this]; a.b.ray_flag[ray] = is_obj ? 1 : 0;
+                a.b.target_depth[ray] = tdp;
+                a.b.bgcol[3 * ray] = bg0; a.b.bgcol[3 * ray + 1] = bg1; a.b.bgcol[3 * ray + 2] = bg2; a.b.target[3 * ray] = tg0; a.b.target[3 * ray + 1] = tg1;
+                a.b.target[3 * ray + 2] = tg2;
             }
             if (h == 0) {
                 a.b.pts[3 * s_idx] = x[0]; a.b.pts[3 * s_idx + 1] = x[1]; a.b.pts[3 * s_idx + 2] = x[2]; a.b.tdist[s_idx] = t;
@@ -252,7 +278,8 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
             }
             half_t* Eo = reinterpret_cast<half_t*>(a.b.E) + (size_t)s_idx * EPAD;
 #pragma unroll
-            for (int il = 0; il < S::LLV; ++il) { const int level = h * LPH + il; if (il < LPH && level < L) { Eo[2 * level] = ts.ef[2 * il]; Eo[2 * level + 1] = ts.ef[2 * il + 1]; } }
+            for (int il = 0; il < S::LLV; ++il) { const int level = h * LPH + il; if (il < LPH && level < L) { Eo[2 * level] = ts.ef[2 * il];
+                    Eo[2 * level + 1] = ts.ef[2 * il + 1]; } }
             half_t* Ho = reinterpret_cast<half_t*>(a.b.Hid) + (size_t)s_idx * W * NH;
 #pragma unroll
             for (int mb = 0; mb < S::MB; ++mb)
@@ -265,7 +292,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
 
         if (nz_cnt != 0u || DUMP) {
         // ---- transposes needed by the weight gradients
-        if (do_dw) {
+        {
 #pragma unroll
         for (int il = 0; il < S::LLV; ++il) {
             const int level = h * LPH + il;
@@ -273,19 +300,20 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         }
 #pragma unroll
         for (int mb = 0; mb < S::MB; ++mb) {
-            if constexpr (NH == 2) { scratch_store_units(scr + S::SCR_HB, mb, n, h, ts.h0[mb][0], ts.h0[mb][1]); scratch_store_units(scr + S::SCR_HA, mb, n, h, ts.h1[mb][0], ts.h1[mb][1]); }
+            if constexpr (NH == 2) { scratch_store_units(scr + S::SCR_HB, mb, n, h, ts.h0[mb][0], ts.h0[mb][1]);
+                scratch_store_units(scr + S::SCR_HA, mb, n, h, ts.h1[mb][0], ts.h1[mb][1]); }
             else scratch_store_units(scr + S::SCR_HA, mb, n, h, ts.h0[mb][0], ts.h0[mb][1]);
         }
         }
 
-        if (h == 0 && do_dw) {
+        if (h == 0) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) scr[S::SCR_DO + c * 32 + n] = bdo[c];
         }
         tstamp(tc, 5);
         // ---- backward: dWout += H_last^T-side outer products (K = samples, via the LDS transposes)
         const int m = n;     // A-fragment row / B-fragment column of this lane
-        if (do_dw) {
+        {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             half8_t bcol;
@@ -307,7 +335,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(frags, S::F_WOT + mb, lane), bdo, acc, 0, 0, 0);
             if constexpr (NH == 2) mask_pack(acc, ts.h1[mb][0], ts.h1[mb][1], dhl[mb][0], dhl[mb][1]);
             else mask_pack(acc, ts.h0[mb][0], ts.h0[mb][1], dhl[mb][0], dhl[mb][1]);
-            if (do_dw) scratch_store_units(scr + S::SCR_HA, mb, n, h, dhl[mb][0], dhl[mb][1]);       // H_last no longer needed: reuse as dH_last
+            scratch_store_units(scr + S::SCR_HA, mb, n, h, dhl[mb][0], dhl[mb][1]);       // H_last no longer needed: reuse as dH_last
         }
         half8_t dh0[S::MB][2];
         if constexpr (NH == 2) {
@@ -328,7 +356,8 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
             for (int mb = 0; mb < S::MB; ++mb) {
                 float16_t acc = float16_t{ 0 };
 #pragma unroll
-                for (int s = 0; s < S::KSW; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(frags, S::F_W1T + mb * S::KSW + s, lane), dhl[s >> 1][s & 1], acc, 0, 0, 0);
+                for (int s = 0; s < S::KSW; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(frags, S::F_W1T + mb * S::KSW + s, lane),
+                        dhl[s >> 1][s & 1], acc, 0, 0, 0);
                 mask_pack(acc, ts.h0[mb][0], ts.h0[mb][1], dh0[mb][0], dh0[mb][1]);
                 scratch_store_units(scr + S::SCR_HB, mb, n, h, dh0[mb][0], dh0[mb][1]);   // H0 no longer needed: reuse as dH0
             }
@@ -338,7 +367,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         }
         tstamp(tc, 6);
         // ---- dW0[u][f] += dH0[u][n] * E[n][f]
-        if (do_dw) {
+        {
             const half_t* dh0_scr = scr + (NH == 2 ? S::SCR_HB : S::SCR_HA);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -358,7 +387,8 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
             half_t* dEo = reinterpret_cast<half_t*>(a.b.dE) + (size_t)s_idx * EPAD;
             half_t* dHo = reinterpret_cast<half_t*>(a.b.dHid) + (size_t)s_idx * W * NH;
 #pragma unroll
-            for (int il = 0; il < S::LLV; ++il) { const int level = h * LPH + il; if (il < LPH && level < L) { dEo[2 * level] = (half_t)de[2 * il]; dEo[2 * level + 1] = (half_t)de[2 * il + 1]; } }
+            for (int il = 0; il < S::LLV; ++il) { const int level = h * LPH + il; if (il < LPH && level < L) { dEo[2 * level] = (half_t)de[2 * il];
+                    dEo[2 * level + 1] = (half_t)de[2 * il + 1]; } }
 #pragma unroll
             for (int mb = 0; mb < S::MB; ++mb)
 #pragma unroll
@@ -375,8 +405,9 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
         const bool mine = ((nz32 >> n) & 1u) != 0u;                                        // this lane's sample is one of the non-zero ones
         const uint32_t bin_cap = Btot / n_bins, in_bin = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_base) + __popc(nz32 & ((1u << n) - 1u));
         const uint32_t slot = (ray & (n_bins - 1u)) * bin_cap + in_bin;                    // a bin holds the samples of R / n_bins rays at most
-        const bool do_store = (a.ablate & 4u) == 0u && mine && in_bin < bin_cap;
-        if (lds_level_mask && h == 0 && do_store) reinterpret_cast<float4_t*>(a.x_soa)[slot] = float4_t{ x[0], x[1], x[2], 0.f };          // one 16-byte store per sample
+        const bool do_store = mine && in_bin < bin_cap;
+        // one 16-byte store per sample
+        if (lds_level_mask && h == 0 && do_store) reinterpret_cast<float4_t*>(a.x_soa)[slot] = float4_t{ x[0], x[1], x[2], 0.f };
 #pragma unroll
         for (int il = 0; il < S::LLV; ++il) {
             const int level = h * LPH + il;
@@ -384,7 +415,8 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
                 const half_t q0 = (half_t)de[2 * il], q1 = (half_t)de[2 * il + 1];
                 if (!ATOMIC_LEVELS || ((lds_level_mask >> level) & 1u)) {
                     // (clamped to the fixed-point range of the exact LDS accumulation, LevelFast::fix_clamp: |dL/dE| * fix_scale stays inside int32)
-                    if (do_store) a.de_soa[(size_t)level * Btot + slot] = half2_t{ (half_t)clamp_f((float)q0, -a.lt.fix_clamp, a.lt.fix_clamp), (half_t)clamp_f((float)q1, -a.lt.fix_clamp, a.lt.fix_clamp) };
+                    if (do_store) a.de_soa[(size_t)level * Btot + slot] = half2_t{ (half_t)clamp_f((float)q0, -a.lt.fix_clamp, a.lt.fix_clamp),
+                            (half_t)clamp_f((float)q1, -a.lt.fix_clamp, a.lt.fix_clamp) };
                 } else if constexpr (ATOMIC_LEVELS) {
                     const float gq0 = (float)q0, gq1 = (float)q1;
                     if (gq0 != 0.f || gq1 != 0.f) {
@@ -405,19 +437,21 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     //      each wave stores its registers to a private LDS copy as 16-byte pieces, consecutive lanes at consecutive addresses (no bank conflicts, no
     //      transposition), then all threads sum the four copies with 16-byte reads and store the row coalesced.  The summing kernel maps columns to parameters.
     __syncthreads();
-    if (a.ablate & 32u) return;                                                      // timing experiments: no dW reduction (wrong results)
     {
         float* cp = reinterpret_cast<float*>(dyn) + (size_t)wave * (S::ACC_COLS + 64);
 #pragma unroll
         for (int mb = 0; mb < S::MB; ++mb)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                *reinterpret_cast<float4_t*>(cp + ((mb * 4 + rq) * 64 + lane) * 4) = float4_t{ dW0[mb][4 * rq], dW0[mb][4 * rq + 1], dW0[mb][4 * rq + 2], dW0[mb][4 * rq + 3] };
-                if (n < kOut) *reinterpret_cast<float4_t*>(cp + S::ACC_WO + ((mb * 4 + rq) * 8 + h * 4 + n) * 4) = float4_t{ dWo[mb][4 * rq], dWo[mb][4 * rq + 1], dWo[mb][4 * rq + 2], dWo[mb][4 * rq + 3] };
+                *reinterpret_cast<float4_t*>(cp + ((mb * 4 + rq) * 64 + lane) * 4) = float4_t{ dW0[mb][4 * rq], dW0[mb][4 * rq + 1], dW0[mb][4 * rq + 2],
+                        dW0[mb][4 * rq + 3] };
+                if (n < kOut) *reinterpret_cast<float4_t*>(cp + S::ACC_WO + ((mb * 4 + rq) * 8 + h * 4 + n) * 4) = float4_t{ dWo[mb][4 * rq],
+                        dWo[mb][4 * rq + 1], dWo[mb][4 * rq + 2], dWo[mb][4 * rq + 3] };
                 if constexpr (NH == 2) {
 #pragma unroll
                     for (int nb = 0; nb < S::MB; ++nb)
-                        *reinterpret_cast<float4_t*>(cp + S::ACC_W1 + (((mb * S::MB + nb) * 4 + rq) * 64 + lane) * 4) = float4_t{ dW1[mb][nb][4 * rq], dW1[mb][nb][4 * rq + 1], dW1[mb][nb][4 * rq + 2], dW1[mb][nb][4 * rq + 3] };
+                        *reinterpret_cast<float4_t*>(cp + S::ACC_W1 + (((mb * S::MB + nb) * 4 + rq) * 64 + lane) * 4) = float4_t{ dW1[mb][nb][4 * rq],
+                                dW1[mb][nb][4 * rq + 1], dW1[mb][nb][4 * rq + 2], dW1[mb][nb][4 * rq + 3] };
                 }
             }
         if (lane == 0) cp[S::ACC_COLS] = loss_acc;
@@ -443,12 +477,15 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
 
 // ------------------------------------------------------------------ host side
 bool fused_supported(const NetDims& nd, uint32_t S, uint32_t R) {
-    return S == 32 && R <= 16384u && nd.L >= 1 && nd.L <= kMaxLevels && (nd.Epad == 16 || nd.Epad == 32) && (nd.W == 32 || nd.W == 64) && (nd.NH == 1 || nd.NH == 2);
+    return S == 32 && R <= 16384u && nd.L >= 1 && nd.L <= kMaxLevels && (nd.Epad == 16 || nd.Epad == 32) && (nd.W == 32 || nd.W == 64)
+            && (nd.NH == 1 || nd.NH == 2);
 }
 
 uint32_t fused_train_grid(const NetDims&, uint32_t R) {
     const uint32_t want = (R + 3) / 4;            // one ray per wavefront when it fits
-    return want < kMaxFusedGrid ? want : kMaxFusedGrid;  // (two workgroups per CU; the dW partial rows are allocated for kMaxFusedGrid of them.  One ray per wave -- 768 / 1024 workgroups -- measured slower)
+    // (two workgroups per CU; the dW partial rows are allocated for kMaxFusedGrid of them.  One ray per wave -- 768 / 1024 workgroups -- measured slower,
+    // DESIGN 7.6)
+    return want < kMaxFusedGrid ? want : kMaxFusedGrid;
 }
 
 template <int EPAD, int W, int NH>
@@ -456,44 +493,58 @@ static void fused_train_t(hipStream_t s, const FusedArgs& a, uint32_t grid, int 
     using S = FusedShape<EPAD, W, NH>;
     static std::atomic<uint64_t> attr_devices{ 0 }; static std::mutex attr_mu;
     once_per_device(attr_devices, attr_mu, [] {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S::SMEM_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                S::SMEM_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                S::SMEM_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                S::SMEM_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, false, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                S::SMEM_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_train<EPAD, W, NH, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                S::SMEM_BYTES);
     });
     const bool all_lds = a.lds_level_mask != 0u && (a.lds_level_mask == ((a.nd.L >= 32) ? 0xffffffffu : ((1u << a.nd.L) - 1u)));
-    if (a.e_soa && all_lds && dump) {           // the benched chain's kernel with the debug dump compiled in (mon_object_set_debug_dump(obj, 2)): E / h / O / dO / dh / dE of every sample
+    // the benched chain's kernel with the debug dump compiled in (mon_object_set_debug_dump(obj, 2)): E / h / O / dO / dh / dE of every sample
+    if (a.e_soa && all_lds && dump) {
         hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true, false, false, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
         return;
     }
-    if (a.e_soa && all_lds && !dump) {          // features from k_encode_tiles (with the occupancy grid: a dead sample's features are there too, its alpha and gradient are zero all the same)
+    // features from k_encode_tiles (with the occupancy grid: a dead sample's features are there too, its alpha and gradient are zero all the same)
+    if (a.e_soa && all_lds && !dump) {
         if (a.occ_bits) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
         else hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false, false, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
         return;
     }
-    if (dump) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);          // (the debug dump evaluates every sample)
+    // (the debug dump evaluates every sample)
+    if (dump) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
     else if (a.occ_bits) { if (all_lds) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
                            else hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, true, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a); }
     else if (all_lds) hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, false>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
     else hipLaunchKernelGGL((k_fused_train<EPAD, W, NH, false, true>), dim3(grid), dim3(256), S::SMEM_BYTES, s, a);
 }
 template <int EPAD, int W, int NH>
-static void candidates_frags_t(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st, const uint16_t* params, const NetDims& nd, uint16_t* image) {
+static void candidates_frags_t(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st, const uint16_t* params,
+        const NetDims& nd, uint16_t* image) {
     using S = FusedShape<EPAD, W, NH>;
     const uint32_t cand_blocks = (oc.R + 255) / 256, frag_blocks = (S::N_FRAGS * 512 + 255) / 256;
-    hipLaunchKernelGGL((k_candidates_and_frags<EPAD, W, NH>), dim3(cand_blocks + frag_blocks), dim3(256), 0, s, b, ds, oc, st, cand_blocks, params, nd.L, image);
+    hipLaunchKernelGGL((k_candidates_and_frags<EPAD, W, NH>), dim3(cand_blocks + frag_blocks), dim3(256), 0, s, b, ds, oc, st, cand_blocks, params, nd.L,
+            image);
 }
 
-void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* dw_partials, int debug_dump,
-                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched, const uint32_t* occ_bits, uint32_t n_bins, const uint16_t* e_soa) {
-    const uint32_t ablate = (uint32_t)options().fused_ablate;
-    uint32_t stagger = options().fused_stagger < 0 ? kDefaultStagger : (uint32_t)options().fused_stagger;
+void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, const ParamPtrs& p, const BatchPtrs& b, const ObjectConst& oc, DevState* st,
+        float* dw_partials, int debug_dump,
+                        uint16_t* de_soa, float* x_soa, uint32_t lds_level_mask, uint16_t* frag_image, uint32_t big_switch, uint8_t* touched,
+                                const uint32_t* occ_bits, uint32_t n_bins, const uint16_t* e_soa) {
+    const uint32_t keep_zero = options().keep_zero_samples != 0 ? 1u : 0u;
+    uint32_t stagger = kDefaultStagger;
     if (oc.R < 2u * 4u * fused_train_grid(nd, oc.R)) stagger = 0u;      // a wave with one ray has no second phase to interleave: the delay would only be lost
-    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, ablate, touched ? touched + (nd.n_mlp >> 3) : nullptr, big_switch, n_bins, stagger, occ_bits, reinterpret_cast<const half2_t*>(e_soa) };
+    FusedArgs a{ lt, nd, oc, b, p.half, p.ggrid, dw_partials, st, reinterpret_cast<half2_t*>(de_soa), x_soa, lds_level_mask, frag_image, keep_zero, touched
+            ? touched + (nd.n_mlp >> 3) : nullptr, big_switch, n_bins, stagger, occ_bits, reinterpret_cast<const half2_t*>(e_soa) };
     if (e_soa) a.stagger = 0u;          // (the stagger interleaves gather phases with compute phases; a pre-encoded batch has no gather phase)
     const uint32_t grid = fused_train_grid(nd, oc.R);
     MON_FUSED_DISPATCH(fused_train_t, s, a, grid, debug_dump);
@@ -503,9 +554,11 @@ static void build_frag_image_t(hipStream_t s, const uint16_t* params, const NetD
     using S = FusedShape<EPAD, W, NH>;
     hipLaunchKernelGGL((k_build_frag_image<EPAD, W, NH>), dim3((S::N_FRAGS * 512 + 255) / 256), dim3(256), 0, s, params, nd.L, image, (const DevState*)nullptr);
 }
-void launch_build_frag_image(hipStream_t s, const uint16_t* params, const NetDims& nd, uint16_t* image) { MON_FUSED_DISPATCH(build_frag_image_t, s, params, nd, image); }
+void launch_build_frag_image(hipStream_t s, const uint16_t* params, const NetDims& nd, uint16_t* image) {
+    MON_FUSED_DISPATCH(build_frag_image_t, s, params, nd, image); }
 
-void launch_candidates_and_frags(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st, const uint16_t* params, const NetDims& nd, uint16_t* frag_image) {
+void launch_candidates_and_frags(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st, const uint16_t* params,
+        const NetDims& nd, uint16_t* frag_image) {
     MON_FUSED_DISPATCH(candidates_frags_t, s, b, ds, oc, st, params, nd, frag_image);
 }
 

@@ -161,7 +161,8 @@ __global__ void __launch_bounds__(256) k_mc_vertices(const float* __restrict__ d
         if (cross & (1u << a)) {
             const float f1 = d[idx + step[a]]; const float dt = (g.thresh - f0) / (f1 - f0);
             float p[3] = { (float)x, (float)y, (float)z }; p[a] += dt;
-            verts[3 * id + 0] = fmaf(p[0], g.sc[0], g.off[0]); verts[3 * id + 1] = fmaf(p[1], g.sc[1], g.off[1]); verts[3 * id + 2] = fmaf(p[2], g.sc[2], g.off[2]);
+            verts[3 * id + 0] = fmaf(p[0], g.sc[0], g.off[0]); verts[3 * id + 1] = fmaf(p[1], g.sc[1], g.off[1]);
+            verts[3 * id + 2] = fmaf(p[2], g.sc[2], g.off[2]);
             vi = (int32_t)(++id);
         }
         vertidx[idx + g.res3 * (uint32_t)a] = vi;
@@ -238,7 +239,8 @@ __global__ void __launch_bounds__(256) k_mesh_warp(const float* __restrict__ ver
 }
 
 // extract_rgb_with_activation :328-339 + the colour half of trans_mesh_data :355-357
-__global__ void __launch_bounds__(256) k_mesh_colors(const uint16_t* __restrict__ O, float* __restrict__ colf, uint8_t* __restrict__ col8, uint32_t v0, uint32_t n) {
+__global__ void __launch_bounds__(256) k_mesh_colors(const uint16_t* __restrict__ O, float* __restrict__ colf, uint8_t* __restrict__ col8, uint32_t v0,
+        uint32_t n) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const half_t* o = reinterpret_cast<const half_t*>(O) + (size_t)i * kOut;

@@ -166,8 +166,10 @@ __global__ void __launch_bounds__(256) k_weight_grad(const uint16_t* __restrict_
     if (st->n_valid == 0u) return;
     const uint32_t s0 = blockIdx.x * kChunk;
     const uint32_t cnt = min((uint32_t)kChunk, n - s0);
-    for (uint32_t i = threadIdx.x; i < cnt * (uint32_t)rows; i += blockDim.x) { const uint32_t s = i / rows, r = i - s * rows; sa[i] = reinterpret_cast<const half_t*>(A)[(size_t)(s0 + s) * lda + r]; }
-    for (uint32_t i = threadIdx.x; i < cnt * (uint32_t)cols; i += blockDim.x) { const uint32_t s = i / cols, c = i - s * cols; sb[i] = reinterpret_cast<const half_t*>(Bm)[(size_t)(s0 + s) * ldb + c]; }
+    for (uint32_t i = threadIdx.x; i < cnt * (uint32_t)rows; i += blockDim.x) { const uint32_t s = i / rows, r = i - s * rows;
+        sa[i] = reinterpret_cast<const half_t*>(A)[(size_t)(s0 + s) * lda + r]; }
+    for (uint32_t i = threadIdx.x; i < cnt * (uint32_t)cols; i += blockDim.x) { const uint32_t s = i / cols, c = i - s * cols;
+        sb[i] = reinterpret_cast<const half_t*>(Bm)[(size_t)(s0 + s) * ldb + c]; }
     __syncthreads();
     for (uint32_t o = threadIdx.x; o < (uint32_t)(rows * cols); o += blockDim.x) {
         const uint32_t r = o / cols, c = o - r * cols;
@@ -205,7 +207,8 @@ __global__ void __launch_bounds__(256) k_grid_backward(LevelTable lt, NetDims nd
 }
 
 // ------------------------------------------------------------------ launchers
-void launch_encode(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* params, const float* pts, uint16_t* E, uint32_t n, const DevState* st) {
+void launch_encode(hipStream_t s, const LevelTable& lt, const NetDims& nd, const uint16_t* params, const float* pts, uint16_t* E, uint32_t n,
+        const DevState* st) {
     const uint64_t threads = (uint64_t)n * (nd.Epad / 2);
     hipLaunchKernelGGL(k_encode, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, lt, nd, params, pts, E, n, st);
 }
@@ -215,7 +218,8 @@ static void mlp_fwd_t(hipStream_t s, const NetDims& nd, const uint16_t* params, 
     hipLaunchKernelGGL((k_mlp_forward<EPAD, W, NH>), dim3((n + 255) / 256), dim3(256), nd.n_mlp * 2, s, params, nd.n_mlp, E, Hid, O, n, st);
 }
 template <int EPAD, int W, int NH>
-static void mlp_bwd_t(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE, uint32_t n, const DevState* st) {
+static void mlp_bwd_t(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE,
+        uint32_t n, const DevState* st) {
     hipLaunchKernelGGL((k_mlp_backward<EPAD, W, NH>), dim3((n + 255) / 256), dim3(256), nd.n_mlp * 2, s, params, nd.n_mlp, Hid, dO, dHid, dE, n, st);
 }
 #define MON_DISPATCH(FN, ...)                                                                  \
@@ -234,23 +238,28 @@ static void mlp_bwd_t(hipStream_t s, const NetDims& nd, const uint16_t* params, 
         }                                                                                      \
     } while (0)
 
-void launch_mlp_forward(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n, const DevState* st) {
+void launch_mlp_forward(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n,
+        const DevState* st) {
     MON_DISPATCH(mlp_fwd_t, s, nd, params, E, Hid, O, n, st);
 }
-void launch_mlp_backward(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE, uint32_t n, const DevState* st) {
+void launch_mlp_backward(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE,
+        uint32_t n, const DevState* st) {
     MON_DISPATCH(mlp_bwd_t, s, nd, params, Hid, dO, dHid, dE, n, st);
 }
-void launch_weight_grads(hipStream_t s, const NetDims& nd, const uint16_t* E, const uint16_t* Hid, const uint16_t* dHid, const uint16_t* dO, float* gmlp, uint32_t n, const DevState* st) {
+void launch_weight_grads(hipStream_t s, const NetDims& nd, const uint16_t* E, const uint16_t* Hid, const uint16_t* dHid, const uint16_t* dO, float* gmlp,
+        uint32_t n, const DevState* st) {
     const dim3 grid((n + kChunk - 1) / kChunk), block(256);
     const int W = nd.W, NH = nd.NH, ld = NH * W;
     // layer 0: dW0[u][k] = sum dh0[u] * E[k]
     hipLaunchKernelGGL(k_weight_grad, grid, block, 0, s, dHid, ld, W, E, nd.Epad, nd.Epad, gmlp, n, st);
     for (int layer = 1; layer < NH; ++layer)
-        hipLaunchKernelGGL(k_weight_grad, grid, block, 0, s, dHid + layer * W, ld, W, Hid + (layer - 1) * W, ld, W, gmlp + W * nd.Epad + (layer - 1) * W * W, n, st);
+        hipLaunchKernelGGL(k_weight_grad, grid, block, 0, s, dHid + layer * W, ld, W, Hid + (layer - 1) * W, ld, W, gmlp + W * nd.Epad + (layer - 1) * W * W,
+                n, st);
     // output layer: rows 0..3 only (dO rows 4..15 are identically zero)
     hipLaunchKernelGGL(k_weight_grad, grid, block, 0, s, dO, kOut, kOut, Hid + (NH - 1) * W, ld, W, gmlp + W * nd.Epad + (NH - 1) * W * W, n, st);
 }
-void launch_grid_backward(hipStream_t s, const LevelTable& lt, const NetDims& nd, const float* pts, const uint16_t* dE, uint16_t* ggrid, uint32_t n, const DevState* st) {
+void launch_grid_backward(hipStream_t s, const LevelTable& lt, const NetDims& nd, const float* pts, const uint16_t* dE, uint16_t* ggrid, uint32_t n,
+        const DevState* st) {
     const uint64_t threads = (uint64_t)n * nd.L;
     hipLaunchKernelGGL(k_grid_backward, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, lt, nd, pts, dE, ggrid, n, st);
 }

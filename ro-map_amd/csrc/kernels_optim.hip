@@ -11,7 +11,8 @@
 // fp16 weights straight into the MFMA A-fragment image (frag_layout.h), and `cand_blocks` extra blocks generate the next
 // iteration's candidate rays (they depend on the iteration counter and the dataset only), so the steady-state loop is
 // k_fused_train -> k_grid_scatter -> k_reduce_partials -> k_optimizer with no batch-generation launch.
-// Variant builds for measurements (tools/variant_build.sh <tag> -D...; profiles/r03_scatter_levels.md): MON_OPT_ABLATE bits 1 no Adam arithmetic, 2 no partial-table
+// Variant builds for measurements (tools/variant_build.sh <tag> -D...; profiles/r03_scatter_levels.md): MON_OPT_ABLATE bits 1 no Adam arithmetic, 2 no
+// partial-table
 // reads, 4 no position blocks, 8 no tile-image stores.
 #include <cstdlib>
 #include "device_common.h"
@@ -22,9 +23,12 @@
 
 namespace mon {
 
-// Optimizer state is not read again before the next step.  Small tables (everything streamed once per step, working set inside the Infinity Cache): non-temporal
-// stores, a wash against plain ones (round 2).  LARGE tables (T = 2^22: 2-3 GB of scattered 32-byte pieces per step, HBM-bound): plain stores -- the L2 merges a
-// chunk's pieces into whole lines before they leave; non-temporal ones cost 20 % of the kernel there (645-725 us against 535-550 us over steps 20..40, four runs each).
+// Optimizer state is not read again before the next step.  Small tables (everything streamed once per step, working set inside the Infinity Cache):
+// non-temporal
+// stores, a wash against plain ones (round 2).  LARGE tables (T = 2^22: 2-3 GB of scattered 32-byte pieces per step, HBM-bound): plain stores -- the L2 merges
+// a
+// chunk's pieces into whole lines before they leave; non-temporal ones cost 20 % of the kernel there (645-725 us against 535-550 us over steps 20..40, four
+// runs each).
 template <bool NT, class T> __device__ __forceinline__ void state_store(T v, T* p) {
     if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
 }
@@ -33,7 +37,8 @@ __device__ __forceinline__ float adam_update(float g, float w, float& m1, float&
     const float gsq = g * g;
     m1 = oc.beta1 * m1 + (1.f - oc.beta1) * g;
     m2 = oc.beta2 * m2 + (1.f - oc.beta2) * gsq;
-    const uint32_t cs = min(steps + 1u, step_cap); steps = cs;      // (16-bit counters saturate at 65535: both bias corrections are exactly 1.0f from far below that, ParamPtrs::steps16)
+    // (16-bit counters saturate at 65535: both bias corrections are exactly 1.0f from far below that, ParamPtrs::steps16)
+    const uint32_t cs = min(steps + 1u, step_cap); steps = cs;
     // beta^cs as exp2(cs * log2 beta): v_exp_f32-based, within ~3e-6 relative of powf for cs < 1e5
     const float lr = lr0 * sqrtf(1.f - exp2f((float)cs * oc.log2_beta2)) / (1.f - exp2f((float)cs * oc.log2_beta1));
     const float eff = lr / (sqrtf(m2) + oc.epsilon);
@@ -52,13 +57,16 @@ __device__ __forceinline__ void ema_catch_up(half8_t& e, const half8_t& w, uint3
 // gradient or when the inference weights are needed (k_ema_finalize).  The weights and Adam state are exactly those of the eager
 // schedule; the EMA differs from the step-by-step fp16 recurrence by rounding only.
 template <bool DENSE, bool LAZY, bool ONE = false /* the grid covers every chunk with one thread: no second chunk's state to hold (44 registers less) */>
-__global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, const DevState* __restrict__ st, DevState* __restrict__ st_next, OptimNext nx, uint32_t lazy_below) {
+__global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, const DevState* __restrict__ st, DevState* __restrict__ st_next, OptimNext nx,
+        uint32_t lazy_below) {
     // block roles by VIRTUAL index: [0, extra) prepare the next iteration, the rest update parameters.  Physically the parameter blocks come first (they are
     // the ones that stream 80 MB and should be in flight from the first cycle), the short preparation blocks fill in behind them.
-    const uint32_t n_extra = nx.cand_blocks + nx.pos_blocks, n_opt = gridDim.x - n_extra, vblock = blockIdx.x < n_opt ? blockIdx.x + n_extra : blockIdx.x - n_opt;
+    const uint32_t n_extra = nx.cand_blocks + nx.pos_blocks, n_opt = gridDim.x - n_extra, vblock = blockIdx.x < n_opt ? blockIdx.x + n_extra
+            : blockIdx.x - n_opt;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const uint32_t step_cap = (p.steps16 || p.rec) ? 65535u : 0xffffffffu;
-    // where a chunk's optimizer state lives: the four SoA arrays, or (large tables, ParamPtrs::rec) ONE 128-byte record per chunk -- master | m1 | m2 | step counters --
+    // where a chunk's optimizer state lives: the four SoA arrays, or (large tables, ParamPtrs::rec) ONE 128-byte record per chunk -- master | m1 | m2 | step
+    // counters --
     // so that a touched chunk among untouched ones costs one full line instead of four half-used 64-byte sectors
     auto st_master = [&](uint32_t c) -> float* { return p.rec ? p.rec + 32u * (size_t)c : p.master + 8u * (size_t)c; };
     auto st_m1 = [&](uint32_t c) -> float* { return p.rec ? p.rec + 32u * (size_t)c + 8u : p.m1 + 8u * (size_t)c; };
@@ -66,10 +74,12 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
     auto st_steps16 = [&](uint32_t c) -> uint16_t* { return p.rec ? reinterpret_cast<uint16_t*>(p.rec + 32u * (size_t)c + 24u) : p.steps16 + 8u * (size_t)c; };
     // a chunk's eight step counters: two 16-byte loads of uint32, or ONE of eight uint16 (4 B per parameter less to read and to write back)
     auto load_steps = [&](uint32_t i0, u32x4& s0, u32x4& s1) __attribute__((always_inline)) {
-        if (p.steps16 || p.rec) { const u32x4 v = *reinterpret_cast<const u32x4*>(st_steps16(i0 >> 3)); s0 = u32x4{ v[0] & 0xffffu, v[0] >> 16, v[1] & 0xffffu, v[1] >> 16 }; s1 = u32x4{ v[2] & 0xffffu, v[2] >> 16, v[3] & 0xffffu, v[3] >> 16 }; }
+        if (p.steps16 || p.rec) { const u32x4 v = *reinterpret_cast<const u32x4*>(st_steps16(i0 >> 3));
+            s0 = u32x4{ v[0] & 0xffffu, v[0] >> 16, v[1] & 0xffffu, v[1] >> 16 }; s1 = u32x4{ v[2] & 0xffffu, v[2] >> 16, v[3] & 0xffffu, v[3] >> 16 }; }
         else { s0 = *reinterpret_cast<const u32x4*>(p.steps + i0); s1 = *reinterpret_cast<const u32x4*>(p.steps + i0 + 4); }
     };
-    struct Pre { float4_t w0, w1, a0, a1, b0, b1; u32x4 s0, s1; half8_t e; float4_t gm0, gm1; };      // (plain vector types and no arrays: HIP's uint4 is a union, and either keeps the struct in scratch memory)
+    // (plain vector types and no arrays: HIP's uint4 is a union, and either keeps the struct in scratch memory)
+    struct Pre { float4_t w0, w1, a0, a1, b0, b1; u32x4 s0, s1; half8_t e; float4_t gm0, gm1; };
     auto issue = [&](uint32_t c, Pre& L) __attribute__((always_inline)) {
         const uint32_t i0 = c << 3;
         L.w0 = *reinterpret_cast<const float4_t*>(st_master(c)); L.w1 = *reinterpret_cast<const float4_t*>(st_master(c) + 4);
@@ -79,22 +89,26 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
         L.e = *reinterpret_cast<const half8_t*>(p.ema + i0);
         if (i0 < oc.n_mlp) { L.gm0 = *reinterpret_cast<const float4_t*>(p.gmlp + i0); L.gm1 = *reinterpret_cast<const float4_t*>(p.gmlp + i0 + 4); }
     };
-    // ONE chunk per thread: its state is requested HERE, before the kernel has seen its DevState -- the addresses come from the argument segment, and the round trip for
+    // ONE chunk per thread: its state is requested HERE, before the kernel has seen its DevState -- the addresses come from the argument segment, and the round
+    // trip for
     // n_valid / step / lr would otherwise stand in front of the streams (eager path below; a skipped batch drops the values)
     Pre early; bool early_issued = false;
     if constexpr (ONE) {
         const uint32_t extra0 = nx.cand_blocks + nx.pos_blocks;
-        if (vblock >= extra0) { const uint32_t ce = (vblock - extra0) * blockDim.x + threadIdx.x; if (ce < (oc.n_params >> 3)) { issue(ce, early); early_issued = true; } }
+        if (vblock >= extra0) { const uint32_t ce = (vblock - extra0) * blockDim.x + threadIdx.x; if (ce < (oc.n_params >> 3)) { issue(ce, early);
+                early_issued = true; } }
     }
     const uint32_t n_valid = st->n_valid, step = st->step;
     // DENSE tables: while most samples carry a gradient practically every chunk is updated and the optimizer state is requested together with the gradients
     // (one memory round trip); once few do (late training: k_grid_scatter left the count in n_scatter_now) most chunks only need their EMA advanced, and
     // the 112 B of Adam state per chunk are requested behind the gradient test instead
-    const bool eager = DENSE && (ONE || !(lazy_below != 0u && st->n_scatter_now <= lazy_below));      // (ONE: the state is on its way already; the two orders measure the same late in training with one chunk per thread)
+    // (ONE: the state is on its way already; the two orders measure the same late in training with one chunk per thread)
+    const bool eager = DENSE && (ONE || !(lazy_below != 0u && st->n_scatter_now <= lazy_below));
     const uint32_t extra = nx.cand_blocks + nx.pos_blocks;          // (one or the other)
     const bool cand_block = vblock < extra;                     // GenerateRays of iteration iter + 1 / its sample positions
     if (vblock < nx.cand_blocks) gen_candidate(nx.b, nx.ds, nx.oc, st->n_boxes, st->iter + 1u, vblock * blockDim.x + threadIdx.x);
-    else if (cand_block) {                                          // level-tile encode: the next iteration's candidates are complete (k_encode_tiles), sample their positions
+    // level-tile encode: the next iteration's candidates are complete (k_encode_tiles), sample their positions
+    else if (cand_block) {
         __shared__ PointsLds plds;
         const uint32_t nwords = nx.oc.R >> 6, nv = points_prefix(plds, nx.b.mask, nwords);
         if (vblock == 0 && threadIdx.x == 0) st_next->n_valid_pre = nv;
@@ -103,7 +117,8 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
 #else
         if (nv != 0u)
 #endif
-            for (uint32_t s = vblock * blockDim.x + threadIdx.x; s < nx.oc.R * 32u; s += nx.pos_blocks * blockDim.x) points_sample(plds, nx.b, nx.oc, st->iter + 1u, nv, nwords, s, reinterpret_cast<float4_t*>(nx.x_all));
+            for (uint32_t s = vblock * blockDim.x + threadIdx.x; s < nx.oc.R * 32u; s += nx.pos_blocks * blockDim.x) points_sample(plds, nx.b, nx.oc,
+                    st->iter + 1u, nv, nwords, s, reinterpret_cast<float4_t*>(nx.x_all));
     }
     const uint32_t bid = vblock - extra, nblk = gridDim.x - extra;
     const float lr0 = st->lr;
@@ -116,15 +131,18 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
     //      on one address per block and the round trip behind the last of them -- 4.3 us of this kernel.)
     if (vblock == 0 && threadIdx.x == 0) {
         DevState& nxs = *st_next;
-        nxs.iter = st->iter + 1u; nxs.n_valid = n_valid; nxs.loss_sum = st->loss_sum;      // (n_valid / loss_sum: what the host reads after the call; k_fused_train overwrites them)
-        { const uint32_t tot = st->n_scatter_now; nxs.n_scatter_last = tot; nxs.n_scatter_total = st->n_scatter_total + tot; }   // (the slot counters themselves are cleared and summed by k_grid_scatter)
+        // (n_valid / loss_sum: what the host reads after the call; k_fused_train overwrites them)
+        nxs.iter = st->iter + 1u; nxs.n_valid = n_valid; nxs.loss_sum = st->loss_sum;
+        // (the slot counters themselves are cleared and summed by k_grid_scatter)
+        { const uint32_t tot = st->n_scatter_now; nxs.n_scatter_last = tot; nxs.n_scatter_total = st->n_scatter_total + tot; }
         uint32_t nstep = step;
         if (n_valid != 0u) {
             nstep = cur; nxs.skipped = st->skipped;
             nxs.lr = ((int)cur >= oc.decay_start && oc.decay_interval > 0 && ((int)cur - oc.decay_start) % oc.decay_interval == 0) ? lr0 * oc.decay_base : lr0;
         } else { nxs.skipped = st->skipped + 1u; nxs.lr = lr0; }
         nxs.step = nstep;
-        nxs.ema_deb_old = 1.f - (float)pow((double)d, (double)nstep); nxs.ema_deb_new = 1.f / (1.f - (float)pow((double)d, (double)(nstep + 1u)));      // factors of step nstep + 1
+        // factors of step nstep + 1
+        nxs.ema_deb_old = 1.f - (float)pow((double)d, (double)nstep); nxs.ema_deb_new = 1.f / (1.f - (float)pow((double)d, (double)(nstep + 1u)));
     }
     // gradient / loss_scale: a power-of-two scale (the reference's 128) divides exactly as a multiplication by its reciprocal (same
     // correctly rounded result, ~10 instructions less per parameter than an IEEE division); anything else keeps the division
@@ -146,7 +164,8 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
         // DENSE tables, eager state: the 160 B of optimizer state of a thread's SECOND chunk are requested before its first chunk is worked on (`Pre`), so that
         // their latency runs under that chunk's arithmetic (vmcnt retires in order: they have to be issued before the first chunk's stores, not after).
         // one 8-parameter chunk; `pre`: its always-needed loads (cur_*) were issued an iteration ago; `L`: state, EMA and MLP gradient were (eager dense path)
-        auto update_chunk = [&](uint32_t c, bool pre, const half8_t& cur_g, const half8_t& cur_w, const half8_t& cur_e, const Pre* L = nullptr) __attribute__((always_inline)) {
+        auto update_chunk = [&](uint32_t c, bool pre, const half8_t& cur_g, const half8_t& cur_w, const half8_t& cur_e,
+                const Pre* L = nullptr) __attribute__((always_inline)) {
             const uint32_t i0 = c << 3;
             const bool is_matrix = i0 < oc.n_mlp;                     // n_mlp is a multiple of 8: uniform per chunk
             float g[8]; bool any = false;
@@ -154,7 +173,8 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
             // DENSE (small tables: practically every entry has a gradient each step): the optimizer state is requested together
             // with the gradients -- one memory round trip instead of two; sparse tables keep the state loads behind the test.
             float4_t w0, w1, a0, a1, b0, b1; uint4 s0, s1;
-            if (L) { w0 = L->w0; w1 = L->w1; a0 = L->a0; a1 = L->a1; b0 = L->b0; b1 = L->b1; s0 = uint4{ L->s0[0], L->s0[1], L->s0[2], L->s0[3] }; s1 = uint4{ L->s1[0], L->s1[1], L->s1[2], L->s1[3] }; }
+            if (L) { w0 = L->w0; w1 = L->w1; a0 = L->a0; a1 = L->a1; b0 = L->b0; b1 = L->b1; s0 = uint4{ L->s0[0], L->s0[1], L->s0[2], L->s0[3] };
+                s1 = uint4{ L->s1[0], L->s1[1], L->s1[2], L->s1[3] }; }
             else if (eager) {
                 w0 = *reinterpret_cast<const float4_t*>(st_master(c)); w1 = *reinterpret_cast<const float4_t*>(st_master(c) + 4);
                 a0 = *reinterpret_cast<const float4_t*>(st_m1(c)); a1 = *reinterpret_cast<const float4_t*>(st_m1(c) + 4);
@@ -191,10 +211,12 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                 if (p.gpart) {                                       // which level is this chunk in -> how many partial tables it has
                     const uint32_t e0 = (i0 - oc.n_mlp) >> 1; int lvl = 0;
 #pragma unroll
-                    for (int l = 1; l < kMaxLevels; ++l) { const bool in = e0 >= p.sl.entry_offset[l]; lvl += in ? 1 : 0; lvl_off = in ? p.sl.entry_offset[l] : lvl_off; lvl_end = in ? p.sl.entry_offset[l + 1] : lvl_end; }
+                    for (int l = 1; l < kMaxLevels; ++l) { const bool in = e0 >= p.sl.entry_offset[l]; lvl += in ? 1 : 0;
+                        lvl_off = in ? p.sl.entry_offset[l] : lvl_off; lvl_end = in ? p.sl.entry_offset[l + 1] : lvl_end; }
                     n_part = p.sl.P[lvl];
                 }
-                // dense partial tables of k_grid_scatter (fused backend): [partition][feature][parity][entry / 2]; this chunk = entries e0 .. e0 + 3 (e0 a multiple
+                // dense partial tables of k_grid_scatter (fused backend): [partition][feature][parity][entry / 2]; this chunk = entries e0 .. e0 + 3 (e0 a
+                // multiple
                 // of 4), both features: per partition four 4-byte pieces -- plane (f, b) holds entries e0 + b and e0 + 2 + b next to each other
                 const uint16_t* pp = p.gpart + ((i0 - oc.n_mlp) >> 2);
                 const size_t plane = p.part_stride >> 2;                 // entries per (feature, parity) plane
@@ -226,7 +248,8 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                 for (int j = 0; j < 8; ++j) { any |= g[j] != 0.f; g[j] = unscale(g[j]); }
             }
             if (lazy_chunk && !any) return;                                            // untouched: nothing to do now (see k_ema_finalize)
-            // the fp16 working copy is h(master) by construction (creation, set_params, every update): where the master weights are loaded anyway it is not read back
+            // the fp16 working copy is h(master) by construction (creation, set_params, every update): where the master weights are loaded anyway it is not
+            // read back
             half8_t wh;
             if (eager) {
                 const float wm[8] = { w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3] };
@@ -263,12 +286,17 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                     wh[j] = (half_t)w[j];
                 }
                 // optimizer state is not touched again before the next step: stream it past the caches
-                state_store<!LAZY>(float4_t{ w[0], w[1], w[2], w[3] }, reinterpret_cast<float4_t*>(st_master(c))); state_store<!LAZY>(float4_t{ w[4], w[5], w[6], w[7] }, reinterpret_cast<float4_t*>(st_master(c) + 4));
-                state_store<!LAZY>(float4_t{ m1[0], m1[1], m1[2], m1[3] }, reinterpret_cast<float4_t*>(st_m1(c))); state_store<!LAZY>(float4_t{ m1[4], m1[5], m1[6], m1[7] }, reinterpret_cast<float4_t*>(st_m1(c) + 4));
-                state_store<!LAZY>(float4_t{ m2[0], m2[1], m2[2], m2[3] }, reinterpret_cast<float4_t*>(st_m2(c))); state_store<!LAZY>(float4_t{ m2[4], m2[5], m2[6], m2[7] }, reinterpret_cast<float4_t*>(st_m2(c) + 4));
+                state_store<!LAZY>(float4_t{ w[0], w[1], w[2], w[3] }, reinterpret_cast<float4_t*>(st_master(c)));
+                state_store<!LAZY>(float4_t{ w[4], w[5], w[6], w[7] }, reinterpret_cast<float4_t*>(st_master(c) + 4));
+                state_store<!LAZY>(float4_t{ m1[0], m1[1], m1[2], m1[3] }, reinterpret_cast<float4_t*>(st_m1(c)));
+                state_store<!LAZY>(float4_t{ m1[4], m1[5], m1[6], m1[7] }, reinterpret_cast<float4_t*>(st_m1(c) + 4));
+                state_store<!LAZY>(float4_t{ m2[0], m2[1], m2[2], m2[3] }, reinterpret_cast<float4_t*>(st_m2(c)));
+                state_store<!LAZY>(float4_t{ m2[4], m2[5], m2[6], m2[7] }, reinterpret_cast<float4_t*>(st_m2(c) + 4));
                 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-                if (p.steps16 || p.rec) state_store<!LAZY>(u4v{ sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16), sc[4] | (sc[5] << 16), sc[6] | (sc[7] << 16) }, reinterpret_cast<u4v*>(st_steps16(c)));
-                else { state_store<!LAZY>(u4v{ sc[0], sc[1], sc[2], sc[3] }, reinterpret_cast<u4v*>(p.steps + i0)); state_store<!LAZY>(u4v{ sc[4], sc[5], sc[6], sc[7] }, reinterpret_cast<u4v*>(p.steps + i0 + 4)); }
+                if (p.steps16 || p.rec) state_store<!LAZY>(u4v{ sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16), sc[4] | (sc[5] << 16), sc[6] | (sc[7] << 16) },
+                        reinterpret_cast<u4v*>(st_steps16(c)));
+                else { state_store<!LAZY>(u4v{ sc[0], sc[1], sc[2], sc[3] }, reinterpret_cast<u4v*>(p.steps + i0));
+                    state_store<!LAZY>(u4v{ sc[4], sc[5], sc[6], sc[7] }, reinterpret_cast<u4v*>(p.steps + i0 + 4)); }
                 *reinterpret_cast<half8_t*>(p.half + i0) = wh;
 #if defined(MON_OPT_ABLATE) && (MON_OPT_ABLATE & 8)
                 if (false) {
@@ -285,7 +313,8 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                 }
                 if (is_matrix && nx.frag_image) {                                     // next iteration's A fragments
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { int sl[2]; const int ns = frag_slots(nx.fd, (int)(i0 + j), sl); for (int q = 0; q < ns; ++q) reinterpret_cast<half_t*>(nx.frag_image)[sl[q]] = wh[j]; }
+                    for (int j = 0; j < 8; ++j) { int sl[2]; const int ns = frag_slots(nx.fd, (int)(i0 + j), sl);
+                        for (int q = 0; q < ns; ++q) reinterpret_cast<half_t*>(nx.frag_image)[sl[q]] = wh[j]; }
                 }
             }
             half8_t* ep = reinterpret_cast<half8_t*>(p.ema + i0);
@@ -355,7 +384,8 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
             if (qn > kQueueCap) qn = kQueueCap;
             for (uint32_t q0 = 0; q0 < qn; q0 += 64u) if (q0 + lane < qn) update_chunk(queue[wave][q0 + lane], false, none, none, none);
         } else if (eager) {
-            // a thread has two chunks at these table sizes (the launch gives ~2 chunks per thread): the state of both is requested before the first is worked on;
+            // a thread has two chunks at these table sizes (the launch gives ~2 chunks per thread): the state of both is requested before the first is worked
+            // on;
             // straight-line code, no loop-carried buffers (those ended up in scratch memory)
             const half8_t none{};
             const uint32_t c0 = c_first, c1 = c_first + c_stride;
@@ -399,13 +429,16 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict
     if (threadIdx.x < 4u) {
         const float4_t v = red[threadIdx.x];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t pi = p0 + j; if (pi < n_cols) { const int prm = acc_param(fd, (int)pi); if (prm >= 0) gmlp[prm] = v[j]; } else if (pi == n_cols) st->loss_sum = v[j]; }      // rows are in accumulator layout
+        // rows are in accumulator layout
+        for (int j = 0; j < 4; ++j) { const uint32_t pi = p0 + j; if (pi < n_cols) { const int prm = acc_param(fd, (int)pi); if (prm >= 0) gmlp[prm] = v[j];
+                } else if (pi == n_cols) st->loss_sum = v[j]; }
     }
 }
 
 void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_partials, const NetDims& nd, float* gmlp, DevState* st) {
     const uint32_t n_cols = fused_partial_cols(nd);
-    hipLaunchKernelGGL(k_reduce_partials, dim3((n_cols + 1 + 15) / 16), dim3(256), 0, s, partials, n_partials, n_cols + 64u, n_cols, FragDims{ nd.Epad, nd.W, nd.NH, nd.L }, gmlp, st);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((n_cols + 1 + 15) / 16), dim3(256), 0, s, partials, n_partials, n_cols + 64u, n_cols, FragDims{ nd.Epad, nd.W,
+            nd.NH, nd.L }, gmlp, st);
 }
 
 // Brings every lazily maintained EMA chunk up to the last completed optimizer step (before render / mesh / parameter read-back).
@@ -426,20 +459,24 @@ void launch_ema_finalize(hipStream_t s, const ParamPtrs& p, const OptimConst& oc
 // fp16 working copy of the fp32 master weights, h(master): object creation and set_params (a scalar host loop without F16C costs ~13 ms for
 // base.json's 1.9 M parameters -- time the SLAM thread spends inside CreateNeRF)
 __global__ void __launch_bounds__(256) k_master_to_half(const float* __restrict__ master, uint16_t* __restrict__ half, uint32_t n) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const half_t h = (half_t)master[i]; half[i] = __builtin_bit_cast(uint16_t, h); }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const half_t h = (half_t)master[i];
+        half[i] = __builtin_bit_cast(uint16_t, h); }
 }
 // plain device copy of a parameter vector (the inference-side snapshots): a kernel of our own rather than hipMemcpyAsync, whose blit path brackets
 // the copy with cache maintenance that the following training kernels pay for
-__global__ void __launch_bounds__(256) k_copy_params(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16, const uint16_t* __restrict__ src_tail, uint16_t* __restrict__ dst_tail, uint32_t n_tail) {
+__global__ void __launch_bounds__(256) k_copy_params(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16,
+        const uint16_t* __restrict__ src_tail, uint16_t* __restrict__ dst_tail, uint32_t n_tail) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
     if (blockIdx.x == 0 && threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
 void launch_copy_params(hipStream_t s, const uint16_t* src, uint16_t* dst, uint32_t n) {
     const uint32_t n16 = n / 8u, tail = n - n16 * 8u;
     const uint32_t blocks = n16 >= 512u * 256u ? 512u : (n16 + 255u) / 256u + (n16 == 0u ? 1u : 0u);
-    hipLaunchKernelGGL(k_copy_params, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16, src + (size_t)n16 * 8u, dst + (size_t)n16 * 8u, tail);
+    hipLaunchKernelGGL(k_copy_params, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16,
+            src + (size_t)n16 * 8u, dst + (size_t)n16 * 8u, tail);
 }
-// Record layout of the optimizer state (ParamPtrs::rec) <-> the flat arrays the boundary speaks (get / set_params, debug read-back): which = 0 master, 1 m1, 2 m2
+// Record layout of the optimizer state (ParamPtrs::rec) <-> the flat arrays the boundary speaks (get / set_params, debug read-back): which = 0 master, 1 m1, 2
+// m2
 // (floats), 3 the step counters (uint16 widened to uint32 on the way out).
 __global__ void __launch_bounds__(256) k_state_unpack(const float* __restrict__ rec, int which, uint32_t* __restrict__ dst, uint32_t n) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -460,19 +497,23 @@ void launch_master_to_half(hipStream_t s, const float* master, uint16_t* half, u
     hipLaunchKernelGGL(k_master_to_half, dim3(1024), dim3(256), 0, s, master, half, n);
 }
 
-void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, const DevState* st, DevState* st_next, const OptimNext& nx, uint32_t lazy_below) {
+void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, const DevState* st, DevState* st_next, const OptimNext& nx,
+        uint32_t lazy_below) {
     const uint32_t chunks = oc.n_params >> 3;
-    const uint32_t env_cap = (uint32_t)options().opt_blocks;
-    // measured: base.json (239 k chunks), parameter blocks ahead of the preparation blocks: 384 / 512 / 640 / 768 / 1024 blocks = 27.9 / 24.1 / 24.7 / 23.6 / 22.9 us (one chunk per thread;
-    // with the preparation blocks FIRST 512 was the best: 28.1 / 23.7 / 26.2 us for 256 / 512 / 1024); T = 2^22 (13.2 M chunks) 512 / 2048 / 8192 / 32768 blocks = 368 / 244 / 251 / 406 us
-    uint32_t cap = chunks / (256u * 8u); if (cap < 1024u) cap = 1024u; if (cap > 2048u) cap = 2048u; if (env_cap) cap = env_cap;
+    // measured: base.json (239 k chunks), parameter blocks ahead of the preparation blocks: 384 / 512 / 640 / 768 / 1024 blocks = 27.9 / 24.1 / 24.7 / 23.6 /
+    // 22.9 us (one chunk per thread;
+    // with the preparation blocks FIRST 512 was the best: 28.1 / 23.7 / 26.2 us for 256 / 512 / 1024); T = 2^22 (13.2 M chunks) 512 / 2048 / 8192 / 32768
+    // blocks = 368 / 244 / 251 / 406 us
+    uint32_t cap = chunks / (256u * 8u); if (cap < 1024u) cap = 1024u; if (cap > 2048u) cap = 2048u;
     uint32_t blocks = (chunks + 255) / 256; if (blocks > cap) blocks = cap; if (blocks < 1u) blocks = 1u;
     // dense = every level goes through the LDS scatter, i.e. tables of at most 2^18 entries that a 131 072-sample batch covers
     if (p.gpart && p.all_levels_dense) {
-        if ((size_t)blocks * 256u >= chunks) hipLaunchKernelGGL((k_optimizer<true, false, true>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
+        if ((size_t)blocks * 256u >= chunks) hipLaunchKernelGGL((k_optimizer<true, false, true>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0,
+                s, p, oc, st, st_next, nx, lazy_below);
         else hipLaunchKernelGGL((k_optimizer<true, false>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
     }
-    else if (p.ema_step) hipLaunchKernelGGL((k_optimizer<false, true>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
+    else if (p.ema_step) hipLaunchKernelGGL((k_optimizer<false, true>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx,
+            lazy_below);
     else hipLaunchKernelGGL((k_optimizer<false, false>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
 }
 

@@ -9,7 +9,8 @@ namespace mon {
 // rays that miss the box and tiles behind an opaque prefix are skipped (wave-uniform).
 // GenerateRenderInputPoints :593-626 + inference + VolumeRender_Render :1134-1229.
 template <int EPAD, int W, int NH>
-__global__ void __launch_bounds__(256) k_fused_render(FusedArgs a, uint32_t n_rays, uint32_t idx_base, float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ mask) {
+__global__ void __launch_bounds__(256) k_fused_render(FusedArgs a, uint32_t n_rays, uint32_t idx_base, float* __restrict__ rgb, float* __restrict__ depth,
+        float* __restrict__ mask) {
     using S = FusedShape<EPAD, W, NH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half_t* frags = reinterpret_cast<half_t*>(smem);
@@ -19,7 +20,8 @@ __global__ void __launch_bounds__(256) k_fused_render(FusedArgs a, uint32_t n_ra
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31;
     const int L = a.nd.L; const uint32_t S2 = 2u * a.oc.S;      // 64
     const half2_t* table = reinterpret_cast<const half2_t*>(a.params + a.nd.n_mlp);
-    const LevelRegs lregs = load_level_regs_uniform(a.lt, L, lane); const uint32_t table_bytes = a.lt.offset[L] * 4u;      // (from the argument segment: it ends up in the buffer descriptor, which must be scalar)
+    // (from the argument segment: it ends up in the buffer descriptor, which must be scalar)
+    const LevelRegs lregs = load_level_regs_uniform(a.lt, L, lane); const uint32_t table_bytes = a.lt.offset[L] * 4u;
     for (uint32_t ray = blockIdx.x * S::WAVES + wave; ray < n_rays; ray += gridDim.x * S::WAVES) {
         float o0 = 1.f, o1 = 1.f, o2 = 1.f, od = 0.f, om_ = 0.f;
         if (a.b.ray_flag[ray]) {
@@ -31,7 +33,8 @@ __global__ void __launch_bounds__(256) k_fused_render(FusedArgs a, uint32_t n_ra
                 const float t = fmaf(dtr, (float)k + render_rand(a.oc, idx_base + ray * S2 + k), t0);
                 float x[3];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) { const float p = fmaf(t, a.b.ray_d[3 * ray + d], a.b.ray_o[3 * ray + d]); x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
+                for (int d = 0; d < 3; ++d) { const float p = fmaf(t, a.b.ray_d[3 * ray + d], a.b.ray_o[3 * ray + d]);
+                    x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
                 TileState<EPAD, W, NH> ts;
                 tile_forward<EPAD, W, NH>(ts, frags, lregs, table, table_bytes, L, x, lane);
                 const float c0 = logistic_f(ts.out4[0]), c1 = logistic_f(ts.out4[1]), c2 = logistic_f(ts.out4[2]), sigma = __expf(ts.out4[3]);
@@ -76,7 +79,8 @@ __global__ void __launch_bounds__(256) k_occ_density(FusedArgs a, float raw_thre
         const float x[3] = { ((float)cx + 0.5f) / (float)kOccRes, ((float)cy + 0.5f) / (float)kOccRes, ((float)cz + 0.5f) / (float)kOccRes };
         TileState<EPAD, W, NH> ts;
         tile_forward<EPAD, W, NH>(ts, frags, lregs, table, table_bytes, a.nd.L, x, lane);
-        const uint32_t occ = (uint32_t)__ballot(lane < 32 && ts.out4[3] > raw_threshold);      // raw channel 3 = log density (network_to_density = exp, nerf_model.cu:49)
+        // raw channel 3 = log density (network_to_density = exp, nerf_model.cu:49)
+        const uint32_t occ = (uint32_t)__ballot(lane < 32 && ts.out4[3] > raw_threshold);
         if (lane == 0) bits_out[word] = occ;
     }
 }
@@ -99,7 +103,8 @@ template <int EPAD, int W, int NH>
 static void occ_update_t(hipStream_t s, const FusedArgs& a, float raw_threshold, uint32_t* tmp, uint32_t* bits) {
     using S = FusedShape<EPAD, W, NH>;
     constexpr uint32_t n_words = kOccRes * kOccRes * kOccRes / 32;
-    hipLaunchKernelGGL((k_build_frag_image<EPAD, W, NH>), dim3((S::F_WOT * 512 + 255) / 256), dim3(256), 0, s, a.params, a.nd.L, const_cast<uint16_t*>(a.frag_image), (const DevState*)nullptr);
+    hipLaunchKernelGGL((k_build_frag_image<EPAD, W, NH>), dim3((S::F_WOT * 512 + 255) / 256), dim3(256), 0, s, a.params, a.nd.L,
+            const_cast<uint16_t*>(a.frag_image), (const DevState*)nullptr);
     hipLaunchKernelGGL((k_occ_density<EPAD, W, NH>), dim3(n_words / S::WAVES), dim3(256), S::FRAG_BYTES + S::LT_BYTES, s, a, raw_threshold, tmp);
     hipLaunchKernelGGL(k_occ_dilate, dim3((n_words + 255) / 256), dim3(256), 0, s, tmp, bits);
 }
@@ -108,18 +113,23 @@ static void fused_render_t(hipStream_t s, const FusedArgs& a, uint32_t n_rays, u
     using S = FusedShape<EPAD, W, NH>;
     const uint32_t smem = S::FRAG_BYTES + S::LT_BYTES;
     uint32_t grid = (n_rays + 3) / 4; if (grid > 2048u) grid = 2048u;
-    if (a.ablate & 1u) hipLaunchKernelGGL((k_build_frag_image<EPAD, W, NH>), dim3((S::F_WOT * 512 + 255) / 256), dim3(256), 0, s, a.params, a.nd.L, const_cast<uint16_t*>(a.frag_image), (const DevState*)nullptr);   // first chunk of a render call
+    // first chunk of a render call
+    if (a.keep_zero & 1u) hipLaunchKernelGGL((k_build_frag_image<EPAD, W, NH>), dim3((S::F_WOT * 512 + 255) / 256), dim3(256), 0, s, a.params, a.nd.L,
+            const_cast<uint16_t*>(a.frag_image), (const DevState*)nullptr);
     hipLaunchKernelGGL((k_fused_render<EPAD, W, NH>), dim3(grid), dim3(256), smem, s, a, n_rays, idx_base, rgb, depth, mask);
 }
 
 
-void launch_fused_render(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc, uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask, uint16_t* frag_image, int build_image) {
-    FusedArgs a{ lt, nd, oc, b, params, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, frag_image, build_image ? 1u : 0u };   // `ablate` bit 0 doubles as "build the fragment image first" on the host side of the render path
+void launch_fused_render(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const BatchPtrs& b, const ObjectConst& oc,
+        uint32_t n_rays, uint32_t idx_base, float* rgb, float* depth, float* mask, uint16_t* frag_image, int build_image) {
+    // `keep_zero` doubles as "build the fragment image first" on the host side of the render path
+    FusedArgs a{ lt, nd, oc, b, params, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, frag_image, build_image ? 1u : 0u };
     MON_FUSED_DISPATCH(fused_render_t, s, a, n_rays, idx_base, rgb, depth, mask);
 }
 
 
-void launch_occupancy_update(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const ObjectConst& oc, uint16_t* frag_image, float raw_threshold, uint32_t* tmp, uint32_t* bits) {
+void launch_occupancy_update(hipStream_t s, const LevelFast& lt, const NetDims& nd, const uint16_t* params, const ObjectConst& oc, uint16_t* frag_image,
+        float raw_threshold, uint32_t* tmp, uint32_t* bits) {
     FusedArgs a{}; a.lt = lt; a.nd = nd; a.oc = oc; a.params = params; a.frag_image = frag_image;
     MON_FUSED_DISPATCH(occ_update_t, s, a, raw_threshold, tmp, bits);
 }

@@ -36,8 +36,11 @@ constexpr uint32_t kScatterLdsBytes = 163840;     // the workgroup declares the 
 constexpr uint32_t kScatterTile64 = (kScatterLdsBytes - 256u) / 8u;      // entries per 64-bit tile (both features): 20 448
 constexpr uint32_t kScatterWgPerLevel = 16;
 enum : int { kTileParity = 0, kTileParityRanged = 1, kTileWhole64 = 2, kTileParity64 = 3 };
-__host__ __device__ inline int scatter_tile_mode(uint32_t size) { return size <= kScatterTile64 ? kTileWhole64 : (size <= 2u * kScatterTile64 ? kTileParity64 : (size <= 2u * kScatterTile ? kTileParity : kTileParityRanged)); }
-__host__ __device__ inline uint32_t scatter_parts(uint32_t size) { const int m = scatter_tile_mode(size); return m == kTileWhole64 ? 1u : (m == kTileParity64 ? 2u : 4u * ((size + 2u * kScatterTile - 1u) / (2u * kScatterTile))); }
+__host__ __device__ inline int scatter_tile_mode(uint32_t size) {
+    return size <= kScatterTile64 ? kTileWhole64
+        : (size <= 2u * kScatterTile64 ? kTileParity64 : (size <= 2u * kScatterTile ? kTileParity : kTileParityRanged)); }
+__host__ __device__ inline uint32_t scatter_parts(uint32_t size) { const int m = scatter_tile_mode(size);
+    return m == kTileWhole64 ? 1u : (m == kTileParity64 ? 2u : 4u * ((size + 2u * kScatterTile - 1u) / (2u * kScatterTile))); }
 
 struct ScatterItem { half2_t g; float4_t x; };
 
@@ -46,39 +49,50 @@ __device__ __forceinline__ int contrib_fix(float w, float g, float fs) { return 
 
 // sign-extended packing of two fixed-point contributions into one 64-bit addend: the 64-bit sum S of such addends decodes exactly as lo = (int32)S,
 // hi = (S - lo) >> 32 while both sums stay inside int32 (they do: the same clamp as for the 32-bit tiles)
-__device__ __forceinline__ unsigned long long pack_fix(int lo, int hi) { return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)(hi + (lo >> 31)) << 32); }
+__device__ __forceinline__ unsigned long long pack_fix(int lo, int hi) {
+    return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)(hi + (lo >> 31)) << 32); }
 
 // (written as instructions: from the C forms the compiler rebuilt a compare + select pair for each of the two)
-__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }      // a ^ b ^ c
-__device__ __forceinline__ int floor_to_int(float q) { int r; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(q)); return r; }                                                                      // (int)floorf(q)
+// a ^ b ^ c
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r; asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int floor_to_int(float q) { int r; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(q)); return r; }      // (int)floorf(q)
 __device__ __forceinline__ uint32_t sign_of_bit0(uint32_t h) { uint32_t m; asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m) : "v"(h)); return m; }
-__device__ __forceinline__ uint32_t sign_of_bit1(uint32_t h) { uint32_t m; asm("v_bfe_i32 %0, %1, 1, 1" : "=v"(m) : "v"(h)); return m; }                                       // bit 1 set ? ~0 : 0                                       // bit 0 set ? ~0 : 0
-__device__ __forceinline__ uint32_t bit_select(uint32_t m, uint32_t a, uint32_t b) { uint32_t r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b)); return r; }   // (m & a) | (~m & b)
+__device__ __forceinline__ uint32_t sign_of_bit1(uint32_t h) { uint32_t m; asm("v_bfe_i32 %0, %1, 1, 1" : "=v"(m) : "v"(h)); return m; }   // bit 1 set ? ~0 : 0
+// (m & a) | (~m & b)
+__device__ __forceinline__ uint32_t bit_select(uint32_t m, uint32_t a, uint32_t b) {
+    uint32_t r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b)); return r; }
 
 // One sample, one level.  The two x-corners of a (y, z) pair always have entry indices of different parity -- hashed: idx1 = idx0 ^ ((x ^ (x + 1)) & mask)
 // and x ^ (x + 1) is odd; dense: idx1 = idx0 + 1 modulo an even size (the clamps below only act on positions far outside [0,1]^3, which the sampler never
 // produces: they keep such a sample inside the table, where it lands is then as meaningless as the sample).
 template <bool HASHED, bool POW2, int MODE, bool DEGEN /* the index ignores y and z: the four pairs of a sample are ONE entry */>
-__device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bool valid, uint32_t feature, float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask,
+__device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bool valid, uint32_t feature, float scale, uint32_t size, uint32_t my,
+        uint32_t mz, uint32_t mask,
                                              uint32_t parity, uint32_t base_half, uint32_t tile, float fs) {
     constexpr bool BOTH = MODE == kTileWhole64 || MODE == kTileParity64;
-    const float g = (float)(feature ? it.g.y : it.g.x), g0 = (float)it.g.x, g1 = (float)it.g.y;          // (k_fused_train stores dL/dE already clamped to the fixed-point range)
+    // (k_fused_train stores dL/dE already clamped to the fixed-point range)
+    const float g = (float)(feature ? it.g.y : it.g.x), g0 = (float)it.g.x, g1 = (float)it.g.y;
     if (!valid || (BOTH ? (g0 == 0.f && g1 == 0.f) : g == 0.f)) return;
     // The floating-point side works on PAIRS (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations, two per instruction -- the walk is bound by
-    // VALU issue): x | y of the position, the weights of the pairs j = 0, 1 (they share wz[0]) and j = 2, 3 (wz[1]), and the products with the fixed-point unit.
+    // VALU issue): x | y of the position, the weights of the pairs j = 0, 1 (they share wz[0]) and j = 2, 3 (wz[1]), and the products with the fixed-point
+    // unit.
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 qxy = __builtin_elementwise_fma(f2{ scale, scale }, f2{ it.x[0], it.x[1] }, f2{ 0.5f, 0.5f }); const float qz = fmaf(scale, it.x[2], 0.5f);
     // (q - floor(q) and (int)floor(q) as ONE instruction each: v_fract_f32 is exactly that difference for the non-negative q of a sample inside the box)
     const f2 pxy = { __builtin_amdgcn_fractf(qxy.x), __builtin_amdgcn_fractf(qxy.y) }, nxy = f2{ 1.f, 1.f } - pxy; const float pz = __builtin_amdgcn_fractf(qz);
     const uint32_t pg[3] = { (uint32_t)floor_to_int(qxy.x), (uint32_t)floor_to_int(qxy.y), (uint32_t)floor_to_int(qz) };
     // hashed levels: only the index bits below the (power-of-two) table size matter, so the 24-bit multiply (full rate) serves: positions are < 2^24
-    const uint32_t ax0 = pg[0], ax1 = pg[0] + 1u, y0 = (HASHED && POW2) ? __umul24(pg[1], my & 0xffffffu) : pg[1] * my, z0 = (HASHED && POW2) ? __umul24(pg[2], mz & 0xffffffu) : pg[2] * mz;
+    const uint32_t ax0 = pg[0], ax1 = pg[0] + 1u, y0 = (HASHED && POW2) ? __umul24(pg[1], my & 0xffffffu) : pg[1] * my, z0 = (HASHED && POW2)
+            ? __umul24(pg[2], mz & 0xffffffu) : pg[2] * mz;
     const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
     const float wx[2] = { nxy.x, pxy.x }, wz[2] = { 1.f - pz, pz }; const f2 wy2 = { nxy.y, pxy.y };
     unsigned long long* tab64 = reinterpret_cast<unsigned long long*>(tab);
-    // (the fp32 products pass through an opaque register pair: h(w * g) is the ROUNDED product rounded again, like tcnn's `(T)(weight * grad)` and the oracle -- the
+    // (the fp32 products pass through an opaque register pair: h(w * g) is the ROUNDED product rounded again, like tcnn's `(T)(weight * grad)` and the oracle
+    // -- the
     //  compiler's own choice, v_fma_mixlo_f16, rounds the exact product once and differs in ~2^-13 of the contributions)
-    //  Per pair of corners: v_pk_mul_f32 (x g), v_cvt_pk_f16_f32 (both h()), then the widening back to fp32 and the multiplication by the fixed-point unit as ONE
+    // Per pair of corners: v_pk_mul_f32 (x g), v_cvt_pk_f16_f32 (both h()), then the widening back to fp32 and the multiplication by the fixed-point unit as
+    // ONE
     //  v_fma_mix_f32 per value (fp16 source operand: exact) -- six instructions where conversions + a packed multiply took eight.
     const auto fix2 = [&](f2 w, float gg) -> f2 {
         f2 pr = w * gg; asm volatile("" : "+v"(pr));
@@ -93,7 +107,8 @@ __device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bo
         for (int j = 0; j < 4; ++j) {                             // the two x-corners of pair j = y + 2 z
             const uint32_t t = HASHED ? (ay[j & 1] ^ az[j >> 1]) : (ay[j & 1] + az[j >> 1]);
             uint32_t idx[2] = { (HASHED ? (ax0 ^ t) : (ax0 + t)) & mask, (HASHED ? (ax1 ^ t) : (ax1 + t)) & mask };
-            if (!POW2) { idx[0] -= (idx[0] >= size) ? size : 0u; idx[0] = min(idx[0], size - 1u); idx[1] -= (idx[1] >= size) ? size : 0u; idx[1] = min(idx[1], size - 1u); }
+            if (!POW2) { idx[0] -= (idx[0] >= size) ? size : 0u; idx[0] = min(idx[0], size - 1u); idx[1] -= (idx[1] >= size) ? size : 0u;
+                idx[1] = min(idx[1], size - 1u); }
             const f2 w = (f2{ wx[0], wx[1] } * ((j & 1) ? wy2.y : wy2.x)) * wz[j >> 1];      // ((wx * wy) * wz): the reference walk's product order
             const f2 c0 = fix2(w, g0), c1 = fix2(w, g1);
             atomicAdd(tab64 + idx[0], pack_fix((int)c0.x, (int)c1.x)); atomicAdd(tab64 + idx[1], pack_fix((int)c0.y, (int)c1.y));
@@ -101,16 +116,21 @@ __device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bo
         return;
     }
     uint32_t local[4]; float ws[4];                               // per pair: this workgroup's corner -- its place in the tile and its x-weight
-    constexpr bool BYTES = HASHED && POW2 && !BOTH;               // the 32-bit tiles of the hashed levels (13 of base.json's 16): `local` holds LDS BYTE addresses
+    // the 32-bit tiles of the hashed levels (13 of base.json's 16): `local` holds LDS BYTE addresses
+    constexpr bool BYTES = HASHED && POW2 && !BOTH;
     if constexpr (BYTES) {
-        // the walk of the branch below with every index term carried DOUBLED (h2 = h << 1: xor / and commute with the shift, and only product bits below the table
-        // size matter), so that a corner's place in the int32 tile comes out as its byte address -- (h >> 1) << 2 = h2 & mask4 -- and the four address shifts in
+        // the walk of the branch below with every index term carried DOUBLED (h2 = h << 1: xor / and commute with the shift, and only product bits below the
+        // table
+        // size matter), so that a corner's place in the int32 tile comes out as its byte address -- (h >> 1) << 2 = h2 & mask4 -- and the four address shifts
+        // in
         // front of the atomics disappear (the tile starts at LDS address 0: the kernel has no static LDS, checked at its entry)
         const uint32_t my2 = my << 1, mz2 = mz << 1, mask4 = (mask << 1) & ~3u;
         uint32_t y2 = __umul24(pg[1], my2 & 0xffffffu), z2 = __umul24(pg[2], mz2 & 0xffffffu);
-        asm volatile("" : "+v"(y2), "+v"(z2));      // (kept as products: y2 + my2 is then one add with a scalar operand; the compiler's v_mad_u32_u24 needs the addend moved into a vector register first)
+        // (kept as products: y2 + my2 is then one add with a scalar operand; the compiler's v_mad_u32_u24 needs the addend moved into a vector register first)
+        asm volatile("" : "+v"(y2), "+v"(z2));
         const uint32_t ay2[2] = { y2, y2 + my2 }, az2[2] = { z2, z2 + mz2 };
-        const uint32_t a2 = ax0 << 1, axp2 = a2 ^ (parity << 1), dx4 = (a2 ^ (a2 + 2u)) & mask4;      // ((x ^ (x + 1)) << 1 = 2x ^ (2x + 2); its bit 1 falls to mask4)
+        // ((x ^ (x + 1)) << 1 = 2x ^ (2x + 2); its bit 1 falls to mask4)
+        const uint32_t a2 = ax0 << 1, axp2 = a2 ^ (parity << 1), dx4 = (a2 ^ (a2 + 2u)) & mask4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (DEGEN && j) { local[j] = local[0]; ws[j] = ws[0]; continue; }
@@ -162,9 +182,11 @@ __device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bo
 }
 
 template <bool HASHED, bool POW2, int MODE, bool DEGEN = false>
-__device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restrict__ de, const float4_t* __restrict__ x4, uint32_t cnt_lo, uint32_t cnt_hi /* lane b: run length of ray bin b / b + 64 */,
+__device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restrict__ de, const float4_t* __restrict__ x4,
+                                                uint32_t cnt_lo, uint32_t cnt_hi /* lane b: run length of ray bin b / b + 64 */,
                                                 uint32_t n_bins, uint32_t bin0, uint32_t bin_step, uint32_t bin_cap, uint32_t feature,
-                                                float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask, uint32_t parity, uint32_t base_half, uint32_t tile, float fs) {
+                                                float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask, uint32_t parity, uint32_t base_half,
+                                                        uint32_t tile, float fs) {
     // This workgroup's samples are the ray bins bin0, bin0 + bin_step, ... (< n_bins), each a compacted run of samples at b * bin_cap.  They are
     // walked in STEPS.  While the runs are long (every sample carries a gradient: 1024 per bin) a step is one bin and thread t takes offset
     // r * 1024 + t; once they are short (late training: a few dozen per bin) the workgroup's waves split into G groups of W2 = 1024 / G threads
@@ -175,19 +197,26 @@ __device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restr
     // Software pipeline: the kBatch steps of round r + 1 are requested before round r's index math and LDS atomics run, so the global-load
     // latency hides behind arithmetic (all 16 waves of the workgroup start in phase; without the prefetch they also wait in phase).
     constexpr int kBatch = MON_V_SBATCH;
-    const auto count_of = [&](uint32_t b) { return (uint32_t)((b < 64u) ? __builtin_amdgcn_readlane((int)cnt_lo, (int)b) : __builtin_amdgcn_readlane((int)cnt_hi, (int)(b - 64u))); };   // b uniform
+    // b uniform
+    const auto count_of = [&](uint32_t b) {
+        return (uint32_t)((b < 64u) ? __builtin_amdgcn_readlane((int)cnt_lo, (int)b) : __builtin_amdgcn_readlane((int)cnt_hi, (int)(b - 64u))); };
     uint32_t nb = 0, width = 0;
     for (uint32_t b = bin0; b < n_bins; b += bin_step) { ++nb; width = max(width, count_of(b)); }
     if (width == 0u) return;
-    uint32_t w2s = 6u; while ((1u << w2s) < blockDim.x && (1u << w2s) < width) ++w2s;   // threads per bin and step: W2 = 2^w2s = the run length rounded up to a power of two, one wave at least
-    const uint32_t W2 = 1u << w2s, gs = 10u - w2s, G = 1u << gs;                         // (1024 threads: G = 1024 / W2 groups; powers of two throughout, no divisions)
-    // Dense levels: the rows of a run are a ray's samples in order, and neighbours along a ray sit in the same coarse cell -- the lanes of a wave would add into
+    // threads per bin and step: W2 = 2^w2s = the run length rounded up to a power of two, one wave at least
+    uint32_t w2s = 6u; while ((1u << w2s) < blockDim.x && (1u << w2s) < width) ++w2s;
+    // (1024 threads: G = 1024 / W2 groups; powers of two throughout, no divisions)
+    const uint32_t W2 = 1u << w2s, gs = 10u - w2s, G = 1u << gs;
+    // Dense levels: the rows of a run are a ray's samples in order, and neighbours along a ray sit in the same coarse cell -- the lanes of a wave would add
+    // into
     // the same few entries, and the LDS serialises same-address atomics (ds_add_u64: 19 cycles per wave instruction on random addresses, 46 when four lanes
-    // share one: tools/ldsatomicbench.py).  There a wave takes GROUPS of kGroup consecutive rows (still 16 * kGroup contiguous bytes per group) from runs W2 / 16
+    // share one: tools/ldsatomicbench.py).  There a wave takes GROUPS of kGroup consecutive rows (still 16 * kGroup contiguous bytes per group) from runs W2 /
+    // 16
     // rows apart; hashed levels scramble the addresses themselves and keep the contiguous rows.
     constexpr uint32_t kGroupBits = MON_V_SGROUP;
     const uint32_t wg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> w2s)), lane_c = threadIdx.x & (W2 - 1u);
-    const uint32_t lane_o = HASHED ? lane_c : ((((lane_c & 63u) >> kGroupBits) << (w2s - 6u + kGroupBits)) | ((lane_c >> 6) << kGroupBits) | (lane_c & ((1u << kGroupBits) - 1u)));
+    const uint32_t lane_o = HASHED ? lane_c
+            : ((((lane_c & 63u) >> kGroupBits) << (w2s - 6u + kGroupBits)) | ((lane_c >> 6) << kGroupBits) | (lane_c & ((1u << kGroupBits) - 1u)));
     const uint32_t ksteps = (nb + G - 1u) >> gs, rounds = (width + W2 - 1u) >> w2s, n_steps = rounds * ksteps;
     uint32_t fks = 0, fo = lane_o, fs_left = n_steps;                                   // running state of the step the next fetch serves (all but fo uniform)
     const auto fetch = [&](ScatterItem& it, bool& valid) {
@@ -196,7 +225,8 @@ __device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restr
         valid = fo < cnt; const uint32_t sc = b * bin_cap + (valid ? fo : 0u);
         it.g = de[sc]; it.x = x4[sc];
         fs_left -= fs_left ? 1u : 0u;
-        const bool wrap = fks + 1u == ksteps;                                    // (selects, not branches: the compiler turned conditional updates of the captured state into scratch memory)
+        // (selects, not branches: the compiler turned conditional updates of the captured state into scratch memory)
+        const bool wrap = fks + 1u == ksteps;
         fo += wrap ? W2 : 0u; fks = wrap ? 0u : fks + 1u;
     };
     ScatterItem nxt[kBatch]; bool nv[kBatch];
@@ -211,7 +241,8 @@ __device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restr
             for (int u = 0; u < kBatch; ++u) fetch(nxt[u], nv[u]);
         }
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) scatter_item<HASHED, POW2, MODE, DEGEN>(tab, cur[u], cv[u], feature, scale, size, my, mz, mask, parity, base_half, tile, fs);
+        for (int u = 0; u < kBatch; ++u) scatter_item<HASHED, POW2, MODE,
+                DEGEN>(tab, cur[u], cv[u], feature, scale, size, my, mz, mask, parity, base_half, tile, fs);
     }
 }
 
@@ -219,7 +250,8 @@ __device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restr
 // takes a few float4 column groups (128 row subsets x 8 groups per pass).  The loads are issued at kernel entry and the sums
 // are finished (DPP + a small LDS exchange) after the tile has been written, so their latency hides behind the scatter itself
 // (k_reduce_partials remains for networks whose levels all go through global atomics).
-struct PartialsArgs { const float* partials; uint32_t n_partials, stride, n_cols; FragDims fd; float* gmlp; DevState* st; };      // rows in accumulator layout: n_cols = acc_cols(fd), loss partial behind them
+// rows in accumulator layout: n_cols = acc_cols(fd), loss partial behind them
+struct PartialsArgs { const float* partials; uint32_t n_partials, stride, n_cols; FragDims fd; float* gmlp; DevState* st; };
 constexpr uint32_t kPartialsMaxPasses = 2;          // column-group passes a workgroup may hold in registers (n_mlp + 1 <= 2 * 8 * 4 * gridDim.x)
 
 // column groups (of 4 columns) a workgroup sums per pass: as few as cover all groups with the whole grid (1, 2, 4 or 8), so that every workgroup
@@ -228,19 +260,24 @@ __device__ __forceinline__ uint32_t partials_groups(const PartialsArgs& pa) {
     const uint32_t n4 = (pa.n_cols + 1u + 3u) / 4u, need = (n4 + gridDim.x - 1u) / gridDim.x;
     return need <= 1u ? 1u : (need <= 2u ? 2u : (need <= 4u ? 4u : 8u));
 }
-// the column groups go to the LAST workgroups of the grid: the first ones hold the coarse dense levels, whose sample walk is the longest of the kernel (their samples
+// the column groups go to the LAST workgroups of the grid: the first ones hold the coarse dense levels, whose sample walk is the longest of the kernel (their
+// samples
 // collide in the LDS atomic unit), so the row sums ride on workgroups that have slack
-__device__ __forceinline__ uint32_t partials_block() { return gridDim.x - 1u - blockIdx.x; }      // (on the FIRST workgroups instead: 42.6 against 41.5 us, round 2)
+// (on the FIRST workgroups instead: 42.6 against 41.5 us, round 2)
+__device__ __forceinline__ uint32_t partials_block() { return gridDim.x - 1u - blockIdx.x; }
 __device__ __forceinline__ void partials_prefetch(const PartialsArgs& pa, float4_t (&acc)[kPartialsMaxPasses]) {
     // thread = (column group gs of G, row subset sub of 1024 / G)
     const uint32_t n4 = (pa.n_cols + 1u + 3u) / 4u, G = partials_groups(pa), subs = blockDim.x / G, gs = threadIdx.x / subs, sub = threadIdx.x - gs * subs;
 #pragma unroll
     for (uint32_t ps = 0; ps < kPartialsMaxPasses; ++ps) {
         const uint32_t g = (partials_block() + ps * gridDim.x) * G + gs; acc[ps] = float4_t{ 0.f, 0.f, 0.f, 0.f };
-        if (g < n4) for (uint32_t k0 = sub; k0 < pa.n_partials; k0 += 4u * subs) {            // four independent 16-byte loads per round (rows are padded to n_cols + 64 floats)
+        // four independent 16-byte loads per round (rows are padded to n_cols + 64 floats)
+        if (g < n4) for (uint32_t k0 = sub; k0 < pa.n_partials; k0 += 4u * subs) {
             float4_t v[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) { const uint32_t k = k0 + subs * u; v[u] = (k < pa.n_partials) ? *reinterpret_cast<const float4_t*>(pa.partials + (size_t)k * pa.stride + 4u * g) : float4_t{ 0.f, 0.f, 0.f, 0.f }; }
+            for (uint32_t u = 0; u < 4u; ++u) { const uint32_t k = k0 + subs * u;
+                v[u] = (k < pa.n_partials) ? *reinterpret_cast<const float4_t*>(pa.partials + (size_t)k * pa.stride + 4u * g) : float4_t{ 0.f, 0.f, 0.f,
+                    0.f }; }
             acc[ps] += (v[0] + v[1]) + (v[2] + v[3]);
         }
     }
@@ -263,7 +300,8 @@ __device__ __forceinline__ void partials_finish(const PartialsArgs& pa, const fl
         if (threadIdx.x < 4u * G) {
             const uint32_t gi = threadIdx.x >> 2, gg = g0 + gi, c = threadIdx.x & 3u, pi = 4u * gg + c;
             float v = 0.f; for (uint32_t w = 0; w < wpg; ++w) v += red[(gi * wpg + w) * 4u + c];
-            if (gg < n4) { if (pi < pa.n_cols) { const int prm = acc_param(pa.fd, (int)pi); if (prm >= 0) pa.gmlp[prm] = v; } else if (pi == pa.n_cols) pa.st->loss_sum = v; }
+            if (gg < n4) { if (pi < pa.n_cols) { const int prm = acc_param(pa.fd, (int)pi); if (prm >= 0) pa.gmlp[prm] = v;
+                    } else if (pi == pa.n_cols) pa.st->loss_sum = v; }
         }
         __syncthreads();
     }
@@ -273,15 +311,19 @@ __device__ __forceinline__ void partials_finish(const PartialsArgs& pa, const fl
 #define MON_HOUSEKEEPING_BLOCK (gridDim.x - 1u)
 #endif
 __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLevels sl, const half2_t* __restrict__ de_soa, const float4_t* __restrict__ x4,
-                                                       uint32_t B, uint32_t n_bins, half_t* __restrict__ gpart, uint32_t n_entries, const DevState* __restrict__ st, DevState* st_rw, DevState* st_next, PartialsArgs pa, float* __restrict__ timing, uint32_t ablate /* timing experiments: 1 no tile write-out, 2 no dW row sums, 4 no sample walk */) {
+                                                       uint32_t B, uint32_t n_bins, half_t* __restrict__ gpart, uint32_t n_entries,
+                                                       const DevState* __restrict__ st, DevState* st_rw, DevState* st_next, PartialsArgs pa,
+                                                       float* __restrict__ timing) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t iter = st->iter;
-    if (blockIdx.x == MON_HOUSEKEEPING_BLOCK && threadIdx.x < 64u) {      // (the last workgroup: the first ones hold the coarse dense levels, the kernel's critical path)
+    // (the last workgroup: the first ones hold the coarse dense levels, the kernel's critical path)
+    if (blockIdx.x == MON_HOUSEKEEPING_BLOCK && threadIdx.x < 64u) {
         // slot-counter housekeeping (also for a skipped batch): clear the counters k_fused_train of the NEXT iteration counts in -- they live in the other
         // DevState, which nobody reads during this iteration -- and note how many samples carried a gradient in this one (k_optimizer hands it to the next
         // iteration as n_scatter_last; the large-table path decides on it)
         uint32_t v = 0u;
-        for (uint32_t b = threadIdx.x; b < n_bins; b += 64u) { v += st->n_scatter[scatter_counter(iter, b)]; st_next->n_scatter[scatter_counter(iter + 1u, b)] = 0u; }
+        for (uint32_t b = threadIdx.x; b < n_bins; b += 64u) { v += st->n_scatter[scatter_counter(iter, b)];
+            st_next->n_scatter[scatter_counter(iter + 1u, b)] = 0u; }
         v = scan_add64_u32(v);
         if (threadIdx.x == 63u) st_rw->n_scatter_now = v;
     }
@@ -294,16 +336,18 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
 #endif
     MON_ST_STAMP();
     float4_t pacc[kPartialsMaxPasses];
-    if (ablate & 2u) pa.partials = nullptr;
     bool pacc_loaded = false;
     int* tab = reinterpret_cast<int*>(smem);
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();      // scatter_item addresses the hashed levels' tiles from LDS offset 0
+    // scatter_item addresses the hashed levels' tiles from LDS offset 0
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
     float* red = reinterpret_cast<float*>(smem + (size_t)kScatterLdsBytes - 256u);     // 256 B behind the largest tile
-    // run lengths of the compacted ray bins, lane b of every wave holds bin b's and bin (b + 64)'s (read back with v_readlane: no memory access in the sample loop)
+    // run lengths of the compacted ray bins, lane b of every wave holds bin b's and bin (b + 64)'s (read back with v_readlane: no memory access in the sample
+    // loop)
     const uint32_t bin_cap = B / n_bins, lb = threadIdx.x & 63u;
     // (both sets are requested and the iteration's one is picked afterwards: the address must not wait for the load of the iteration counter)
     const uint32_t c_lo0 = (lb < n_bins) ? st->n_scatter[scatter_counter(0u, lb)] : 0u, c_lo1 = (lb < n_bins) ? st->n_scatter[scatter_counter(1u, lb)] : 0u;
-    const uint32_t c_hi0 = (lb + 64u < n_bins) ? st->n_scatter[scatter_counter(0u, lb + 64u)] : 0u, c_hi1 = (lb + 64u < n_bins) ? st->n_scatter[scatter_counter(1u, lb + 64u)] : 0u;
+    const uint32_t c_hi0 = (lb + 64u < n_bins) ? st->n_scatter[scatter_counter(0u, lb + 64u)] : 0u, c_hi1 = (lb + 64u < n_bins)
+            ? st->n_scatter[scatter_counter(1u, lb + 64u)] : 0u;
     const uint32_t cnt_lo = min((iter & 1u) ? c_lo1 : c_lo0, bin_cap), cnt_hi = min((iter & 1u) ? c_hi1 : c_hi0, bin_cap);
     const uint32_t slot = blockIdx.x / kScatterWgPerLevel, j = blockIdx.x - slot * kScatterWgPerLevel;
     const int level = sl.level[slot]; const uint32_t P = sl.P[level];
@@ -314,10 +358,13 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
     const int mode = scatter_tile_mode(size);                                         // uniform: which kind of tile this level's workgroups hold (see above)
     const bool both = mode == kTileWhole64 || mode == kTileParity64;
     const uint32_t feature = both ? 0u : (part & 1u), parity = mode == kTileWhole64 ? 0u : (both ? (part & 1u) : ((part >> 1) & 1u));
-    const uint32_t half_size = size >> 1, base_half = mode == kTileParityRanged ? (part >> 2) * kScatterTile : 0u;      // (level sizes are multiples of 8) parity tiles: idx = 2 * (base_half + local) + parity
-    const bool degenerate = pow2 && (my & mask) == 0u && (mz & mask) == 0u && size > 1u;  // the index ignores y and z (tcnn's stride wrap-around at res = 65 536): the four pairs of a sample are one entry
+    // (level sizes are multiples of 8) parity tiles: idx = 2 * (base_half + local) + parity
+    const uint32_t half_size = size >> 1, base_half = mode == kTileParityRanged ? (part >> 2) * kScatterTile : 0u;
+    // the index ignores y and z (tcnn's stride wrap-around at res = 65 536): the four pairs of a sample are one entry
+    const bool degenerate = pow2 && (my & mask) == 0u && (mz & mask) == 0u && size > 1u;
     MON_ST_STAMP();
-    if (mode != kTileParityRanged || base_half < half_size) {                         // (levels whose part count does not divide 16 leave workgroups without a tile)
+    // (levels whose part count does not divide 16 leave workgroups without a tile)
+    if (mode != kTileParityRanged || base_half < half_size) {
         const uint32_t tile = mode == kTileWhole64 ? size : min(mode == kTileParity64 ? kScatterTile64 : kScatterTile, half_size - base_half);      // entries
         typedef int int4v __attribute__((ext_vector_type(4)));
         {   // tiles are multiples of 4 entries (tcnn rounds level sizes up to 8): clear with 16-byte stores
@@ -329,10 +376,13 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
         MON_ST_STAMP();
         // sample partition p of this level = the ray bins b = p, p + P, ... (16 bins, compacted by k_fused_train: only samples with a non-zero gradient)
         const half2_t* de = de_soa + (size_t)level * B;
-#define MON_SCATTER_CALL(H, PW, MD, ...) scatter_samples<H, PW, MD, ##__VA_ARGS__>(tab, de, x4, cnt_lo, cnt_hi, n_bins, p, P, bin_cap, feature, scale, size, my, mz, mask, parity, base_half, tile, fs)
-#define MON_SCATTER_MODE(MD) do { if (hashed) { if (pow2) MON_SCATTER_CALL(true, true, MD); else MON_SCATTER_CALL(true, false, MD); } else { if (pow2) MON_SCATTER_CALL(false, true, MD); else MON_SCATTER_CALL(false, false, MD); } } while (0)
-        if (ablate & 4u) { }
-        else if (mode == kTileWhole64) MON_SCATTER_MODE(kTileWhole64);
+#define MON_SCATTER_CALL(H, PW, MD, ...) \
+    scatter_samples<H, PW, MD, ##__VA_ARGS__>(tab, de, x4, cnt_lo, cnt_hi, n_bins, p, P, bin_cap, feature, scale, size, my, mz, mask, parity, base_half, tile, \
+                                              fs)
+#define MON_SCATTER_MODE(MD) do { \
+        if (hashed) { if (pow2) MON_SCATTER_CALL(true, true, MD); else MON_SCATTER_CALL(true, false, MD); } \
+        else { if (pow2) MON_SCATTER_CALL(false, true, MD); else MON_SCATTER_CALL(false, false, MD); } } while (0)
+        if (mode == kTileWhole64) MON_SCATTER_MODE(kTileWhole64);
         else if (mode == kTileParity64) MON_SCATTER_MODE(kTileParity64);
         else if (mode == kTileParity) { if (degenerate) MON_SCATTER_CALL(true, true, kTileParity, true); else MON_SCATTER_MODE(kTileParity); }
         else MON_SCATTER_MODE(kTileParityRanged);
@@ -346,23 +396,27 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
         MON_ST_STAMP();
         const int4v* t4 = reinterpret_cast<const int4v*>(tab);
         const float inv = 1.0f / fs;
-        if (!(ablate & 1u)) {
         const size_t plane = n_entries >> 1;                                           // partial table p, plane (feature, parity): entry idx at [idx >> 1]
         half_t* pl = gpart + ((size_t)p * 4u) * plane + (off >> 1);
-        const auto lo_hi = [&](int lo_bits, int hi_bits, float& f0, float& f1) { f0 = (float)lo_bits * inv; f1 = (float)(hi_bits - (lo_bits >> 31)) * inv; };      // undo pack_fix
-        if (mode == kTileWhole64) {            // entries 2k, 2k + 1 interleaved, both features: 4 entries (32 B) per thread and pass -> 2 halves into each of the four planes
+        // undo pack_fix
+        const auto lo_hi = [&](int lo_bits, int hi_bits, float& f0, float& f1) { f0 = (float)lo_bits * inv; f1 = (float)(hi_bits - (lo_bits >> 31)) * inv; };
+        // entries 2k, 2k + 1 interleaved, both features: 4 entries (32 B) per thread and pass -> 2 halves into each of the four planes
+        if (mode == kTileWhole64) {
             for (uint32_t i = threadIdx.x; i < tile / 4u; i += blockDim.x) {
                 const int4v a = t4[2u * i], c = t4[2u * i + 1u];                        // entries 4i, 4i+1 | 4i+2, 4i+3
-                float e0f0, e0f1, e1f0, e1f1, e2f0, e2f1, e3f0, e3f1; lo_hi(a[0], a[1], e0f0, e0f1); lo_hi(a[2], a[3], e1f0, e1f1); lo_hi(c[0], c[1], e2f0, e2f1); lo_hi(c[2], c[3], e3f0, e3f1);
+                float e0f0, e0f1, e1f0, e1f1, e2f0, e2f1, e3f0, e3f1; lo_hi(a[0], a[1], e0f0, e0f1); lo_hi(a[2], a[3], e1f0, e1f1);
+                lo_hi(c[0], c[1], e2f0, e2f1); lo_hi(c[2], c[3], e3f0, e3f1);
                 *reinterpret_cast<half2_t*>(pl + 0u * plane + 2u * i) = half2_t{ (half_t)e0f0, (half_t)e2f0 };      // feature 0, even entries
                 *reinterpret_cast<half2_t*>(pl + 1u * plane + 2u * i) = half2_t{ (half_t)e1f0, (half_t)e3f0 };      // feature 0, odd
                 *reinterpret_cast<half2_t*>(pl + 2u * plane + 2u * i) = half2_t{ (half_t)e0f1, (half_t)e2f1 };      // feature 1, even
                 *reinterpret_cast<half2_t*>(pl + 3u * plane + 2u * i) = half2_t{ (half_t)e1f1, (half_t)e3f1 };      // feature 1, odd
             }
-        } else if (mode == kTileParity64) {    // one parity, both features: 4 entries (32 B) per thread and pass -> 4 halves into each of the two feature planes
+        // one parity, both features: 4 entries (32 B) per thread and pass -> 4 halves into each of the two feature planes
+        } else if (mode == kTileParity64) {
             for (uint32_t i = threadIdx.x; i < tile / 4u; i += blockDim.x) {
                 const int4v a = t4[2u * i], c = t4[2u * i + 1u];
-                float f0[4], f1[4]; lo_hi(a[0], a[1], f0[0], f1[0]); lo_hi(a[2], a[3], f0[1], f1[1]); lo_hi(c[0], c[1], f0[2], f1[2]); lo_hi(c[2], c[3], f0[3], f1[3]);
+                float f0[4], f1[4]; lo_hi(a[0], a[1], f0[0], f1[0]); lo_hi(a[2], a[3], f0[1], f1[1]); lo_hi(c[0], c[1], f0[2], f1[2]);
+                lo_hi(c[2], c[3], f0[3], f1[3]);
                 *reinterpret_cast<half4_t*>(pl + (0u + parity) * plane + 4u * i) = half4_t{ (half_t)f0[0], (half_t)f0[1], (half_t)f0[2], (half_t)f0[3] };
                 *reinterpret_cast<half4_t*>(pl + (2u + parity) * plane + 4u * i) = half4_t{ (half_t)f1[0], (half_t)f1[1], (half_t)f1[2], (half_t)f1[3] };
             }
@@ -377,9 +431,9 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
             }
             if ((tile & 4u) && threadIdx.x == 0u) {                                    // a parity half is a multiple of 4 entries, not always of 8
                 const int4v a0 = t4[tile / 4u - 1u];
-                *reinterpret_cast<half4_t*>(dst + (tile & ~7u)) = half4_t{ (half_t)((float)a0[0] * inv), (half_t)((float)a0[1] * inv), (half_t)((float)a0[2] * inv), (half_t)((float)a0[3] * inv) };
+                *reinterpret_cast<half4_t*>(dst + (tile & ~7u)) = half4_t{ (half_t)((float)a0[0] * inv), (half_t)((float)a0[1] * inv),
+                        (half_t)((float)a0[2] * inv), (half_t)((float)a0[3] * inv) };
             }
-        }
         }
     }
     MON_ST_STAMP();
@@ -387,7 +441,8 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
     if (pa.partials) partials_finish(pa, pacc, red);
     MON_ST_STAMP();
 #ifdef MON_SCATTER_TIMING
-    if (timing && (threadIdx.x & 63u) == 0u) { float* o = timing + ((size_t)blockIdx.x * 16u + (threadIdx.x >> 6)) * 8u; for (int k = 0; k + 1 < tn && k < 6; ++k) o[k] = (float)(tq[k + 1] - tq[k]); o[6] = (float)(tq[0] & 0xffffff); o[7] = (float)level; }
+    if (timing && (threadIdx.x & 63u) == 0u) { float* o = timing + ((size_t)blockIdx.x * 16u + (threadIdx.x >> 6)) * 8u;
+        for (int k = 0; k + 1 < tn && k < 6; ++k) o[k] = (float)(tq[k + 1] - tq[k]); o[6] = (float)(tq[0] & 0xffffff); o[7] = (float)level; }
 #endif
 }
 
@@ -422,22 +477,26 @@ bool grid_scatter_sums_partials(const LevelTable& lt, const NetDims& nd) {
     ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return false;
     return fused_partial_cols(nd) + 1u <= kPartialsMaxPasses * 8u * 4u * sl.n_levels * kScatterWgPerLevel;
 }
-void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B, uint32_t n_bins, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
+void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B,
+        uint32_t n_bins, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
                          const float* partials, uint32_t n_partials, float* gmlp, DevState* st_next) {
     ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return;
     const PartialsArgs pa{ partials, n_partials, fused_partial_cols(nd) + 64u, fused_partial_cols(nd), FragDims{ nd.Epad, nd.W, nd.NH, nd.L }, gmlp, st };
     constexpr uint32_t smem = kScatterLdsBytes;
     static std::atomic<uint64_t> attr_devices{ 0 }; static std::mutex attr_mu;
-    once_per_device(attr_devices, attr_mu, [] { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
+    once_per_device(attr_devices, attr_mu,
+            [] { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, smem); });
     float* timing = nullptr;
 #ifdef MON_SCATTER_TIMING
     static float* g_timing = nullptr; if (!g_timing) hipMalloc((void**)&g_timing, 256 * 16 * 8 * 4); timing = g_timing; g_scatter_timing_buf = g_timing;
 #endif
-    hipLaunchKernelGGL(k_grid_scatter, dim3(sl.n_levels * kScatterWgPerLevel), dim3(1024), smem, s, lf, sl, reinterpret_cast<const half2_t*>(de_soa), reinterpret_cast<const float4_t*>(x_soa), B, n_bins,
-                       reinterpret_cast<half_t*>(gpart), part_stride_entries, st, st, st_next, pa, timing, (uint32_t)options().scatter_ablate);
+    hipLaunchKernelGGL(k_grid_scatter, dim3(sl.n_levels * kScatterWgPerLevel), dim3(1024), smem, s, lf, sl, reinterpret_cast<const half2_t*>(de_soa),
+            reinterpret_cast<const float4_t*>(x_soa), B, n_bins,
+                       reinterpret_cast<half_t*>(gpart), part_stride_entries, st, st, st_next, pa, timing);
 }
 #ifdef MON_SCATTER_TIMING
-extern "C" int mon_debug_scatter_timing(float* out) { hipDeviceSynchronize(); return g_scatter_timing_buf ? (int)hipMemcpy(out, g_scatter_timing_buf, 256 * 16 * 8 * 4, hipMemcpyDeviceToHost) : -1; }
+extern "C" int mon_debug_scatter_timing(float* out) { hipDeviceSynchronize();
+    return g_scatter_timing_buf ? (int)hipMemcpy(out, g_scatter_timing_buf, 256 * 16 * 8 * 4, hipMemcpyDeviceToHost) : -1; }
 #endif
 
 }  // namespace mon

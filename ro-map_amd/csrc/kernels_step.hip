@@ -15,7 +15,8 @@
 namespace mon {
 
 // first loop of the kernel (:996-1036): samples in front of the transmittance cut, the composited colour with the shared background
-__global__ void __launch_bounds__(64) k_step_count(BatchPtrs b, ObjectConst oc, const DevState* __restrict__ st, uint32_t* __restrict__ steps /* [R + 1], [0] = 0 */) {
+__global__ void __launch_bounds__(64) k_step_count(BatchPtrs b, ObjectConst oc, const DevState* __restrict__ st,
+                                                   uint32_t* __restrict__ steps /* [R + 1], [0] = 0 */) {
     if (st->n_valid == 0u) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, R = oc.R, S = oc.S;
     if (i >= R) return;
@@ -29,7 +30,8 @@ __global__ void __launch_bounds__(64) k_step_count(BatchPtrs b, ObjectConst oc, 
         const float alpha = 1.f - __expf(-sigma * dt), w = alpha * T;
         r0 += w * c0; r1 += w * c1; r2 += w * c2; dep += w * cur; T *= (1.f - alpha); last = cur;      // (depth: |point - o| = t for a unit direction)
     }
-    const float bg0 = batch_rand(oc, kStreamColor, st->iter, 0u), bg1 = batch_rand(oc, kStreamColor, st->iter, 1u), bg2 = batch_rand(oc, kStreamColor, st->iter, 2u);
+    const float bg0 = batch_rand(oc, kStreamColor, st->iter, 0u), bg1 = batch_rand(oc, kStreamColor, st->iter, 1u),
+            bg2 = batch_rand(oc, kStreamColor, st->iter, 2u);
     b.rgb_ray[3 * i] = r0 + T * bg0; b.rgb_ray[3 * i + 1] = r1 + T * bg1; b.rgb_ray[3 * i + 2] = r2 + T * bg2; b.depth_ray[i] = dep; b.mask_ray[i] = 1.f - T;
     steps[i + 1] = n; if (i == 0u) steps[0] = 0u;
 }
@@ -53,7 +55,8 @@ __global__ void __launch_bounds__(1024) k_step_scan(uint32_t* __restrict__ steps
     }
 }
 // second loop (:1048-1131): positions and dL/dO of the ray's numsteps samples at its slots of the compacted batch; colour-only L2 loss
-__global__ void __launch_bounds__(64) k_step_gradient(BatchPtrs b, ObjectConst oc, DevState* __restrict__ st, const uint32_t* __restrict__ steps, float* __restrict__ pts_c, uint16_t* __restrict__ dO_c) {
+__global__ void __launch_bounds__(64) k_step_gradient(BatchPtrs b, ObjectConst oc, DevState* __restrict__ st, const uint32_t* __restrict__ steps,
+        float* __restrict__ pts_c, uint16_t* __restrict__ dO_c) {
     if (st->n_valid == 0u) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, R = oc.R, S = oc.S;
     float loss = 0.f;
@@ -91,7 +94,8 @@ __global__ void __launch_bounds__(64) k_step_gradient(BatchPtrs b, ObjectConst o
     if ((threadIdx.x & 63) == 0) atomicAdd(&st->loss_sum, loss);
 }
 // fill_rollover (positions) + fill_rollover_and_rescale (gradients): slots n .. B - 1 repeat the compacted batch cyclically, the copies' gradients times n / B
-__global__ void __launch_bounds__(256) k_step_rollover(const uint32_t* __restrict__ steps, uint32_t R, uint32_t B, float* __restrict__ pts_c, uint16_t* __restrict__ dO_c, DevState* __restrict__ st) {
+__global__ void __launch_bounds__(256) k_step_rollover(const uint32_t* __restrict__ steps, uint32_t R, uint32_t B, float* __restrict__ pts_c,
+        uint16_t* __restrict__ dO_c, DevState* __restrict__ st) {
     if (st->n_valid == 0u) return;
     const uint32_t n = steps[R], i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0u) st->n_scatter_now = n;                                  // (reported as the step's sample count: mon_object_info / tests)

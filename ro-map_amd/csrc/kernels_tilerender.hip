@@ -157,7 +157,8 @@ __device__ __forceinline__ void feat_offsets(const float4_t& xv, float scale, ui
     uint32_t pg[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, xv[d], 0.5f); pg[d] = (uint32_t)floor_to_int(q); pos[d] = __builtin_amdgcn_fractf(q); }
-    const uint32_t y0 = (HASHED && POW2) ? __umul24(pg[1], my2 & 0xffffffu) : pg[1] * my2, z0 = (HASHED && POW2) ? __umul24(pg[2], mz2 & 0xffffffu) : pg[2] * mz2;
+    const uint32_t y0 = (HASHED && POW2) ? __umul24(pg[1], my2 & 0xffffffu) : pg[1] * my2, z0 = (HASHED && POW2) ? __umul24(pg[2], mz2 & 0xffffffu)
+            : pg[2] * mz2;
     const uint32_t ay[2] = { y0, y0 + my2 }, az[2] = { z0, z0 + mz2 };
     const uint32_t x2 = pg[0] << 1, dxm = (x2 ^ (x2 + 2u)) & mask2;
 #pragma unroll
@@ -181,7 +182,8 @@ __device__ __forceinline__ void feat_offsets(const float4_t& xv, float scale, ui
 // A sample in flight: its eight corner values (requested) and its position inside the cell.
 struct FeatPend { uint16_t c0[4], c1[4]; float pos[3]; };
 template <bool HASHED, bool POW2>
-__device__ __forceinline__ void feat_issue(FeatPend& p, const unsigned char* tile, const float4_t& xv, float scale, uint32_t size2, uint32_t my2, uint32_t mz2, uint32_t mask2) {
+__device__ __forceinline__ void feat_issue(FeatPend& p, const unsigned char* tile, const float4_t& xv, float scale, uint32_t size2, uint32_t my2, uint32_t mz2,
+        uint32_t mask2) {
     uint32_t o0[4], o1[4];
     feat_offsets<HASHED, POW2>(xv, scale, size2, my2, mz2, mask2, o0, o1, p.pos);
     // (the tile starts at LDS address 0 -- the kernel has no static LDS, checked at its entry -- so the byte offset IS the address: through `tile + offset`
@@ -248,7 +250,8 @@ __device__ __forceinline__ void feat_walk(const unsigned char* tile, const FeatA
 __global__ void __launch_bounds__(kTileThreads) k_encode_feat(FeatArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* tile = smem;
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();      // feat_issue addresses the tile from LDS offset 0
+    // feat_issue addresses the tile from LDS offset 0
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
     const uint32_t tid = blockIdx.x / kFeatParts, part = blockIdx.x - tid * kFeatParts, level = tid >> 1, f = tid & 1u;
     const uint32_t n = a.count ? chunk_jobs(a.count, a.job_base, a.jobs_cap) * a.spj : a.n_host;
     if (n == 0u || part * kFeatRound >= n) return;               // (before the tile copy: an empty chunk, or a partition without a round)
@@ -373,7 +376,9 @@ __global__ void __launch_bounds__(256) k_tile_render(TileMlpArgs a, float* __res
         float o0 = 1.f, o1 = 1.f, o2 = 1.f, od = 0.f, om_ = 0.f;
         if (1.f - Tc > 0.5f) { o0 = r0 + Tc; o1 = r1 + Tc; o2 = r2 + Tc; od = dep / rc.x; om_ = 1.f; }      // :1213-1220
         const float rc_y = rc.y; const uint32_t pix = __builtin_bit_cast(uint32_t, rc_y);
-        if (lane == 0 && pix < a.n_points) { rgb[3 * (size_t)pix] = o0; rgb[3 * (size_t)pix + 1] = o1; rgb[3 * (size_t)pix + 2] = o2; depth[pix] = od; mask[pix] = om_; }      // (n_points = the crop's pixels: a record is never trusted with an address)
+        // (n_points = the crop's pixels: a record is never trusted with an address)
+        if (lane == 0 && pix < a.n_points) { rgb[3 * (size_t)pix] = o0; rgb[3 * (size_t)pix + 1] = o1; rgb[3 * (size_t)pix + 2] = o2; depth[pix] = od;
+            mask[pix] = om_; }
     }
 }
 
@@ -407,7 +412,8 @@ static void feat_setup_device() {
 
 void launch_build_feat_image(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* params, uint16_t* image, uint32_t* zero_counter) {
     const uint32_t n = lf.offset[nd.L];
-    hipLaunchKernelGGL(k_build_feat_image, dim3((n + 255u) / 256u), dim3(256), 0, s, lf, nd.L, reinterpret_cast<const uint32_t*>(params + nd.n_mlp), image, zero_counter);
+    hipLaunchKernelGGL(k_build_feat_image, dim3((n + 255u) / 256u), dim3(256), 0, s, lf, nd.L, reinterpret_cast<const uint32_t*>(params + nd.n_mlp), image,
+            zero_counter);
 }
 void launch_render_rays_jobs(hipStream_t s, const Intrinsics& K, const ObjectConst& oc, mon_frame_bbox box, const Mat4& pose, int pose_is_Toc, uint32_t n_pix,
                              float* rec, uint32_t* count, uint32_t* next_count, float* rgb, float* depth, float* mask) {
@@ -436,7 +442,8 @@ void launch_encode_feat(hipStream_t s, const LevelFast& lf, const NetDims& nd, c
 template <int EPAD, int W, int NH>
 static void tile_render_t(hipStream_t s, const TileMlpArgs& a, float* rgb, float* depth, float* mask) {
     using S = FusedShape<EPAD, W, NH>;
-    uint32_t grid = (a.jobs_cap + S::WAVES - 1u) / S::WAVES; if (grid > 1280u) grid = 1280u;      // five workgroups per CU: a wave takes several jobs and prefetches the next
+    // five workgroups per CU: a wave takes several jobs and prefetches the next
+    uint32_t grid = (a.jobs_cap + S::WAVES - 1u) / S::WAVES; if (grid > 1280u) grid = 1280u;
     hipLaunchKernelGGL((k_tile_render<EPAD, W, NH>), dim3(grid), dim3(256), S::F_WOT * 1024, s, a, rgb, depth, mask);
 }
 template <int EPAD, int W, int NH>
@@ -452,7 +459,8 @@ static void frag_image_t(hipStream_t s, const uint16_t* params, int L, uint16_t*
 }
 
 void launch_tile_render(hipStream_t s, const NetDims& nd, const ObjectConst& oc, const uint16_t* frag_image, const float* rec, const uint32_t* count,
-                        uint32_t job_base, uint32_t jobs_cap, const float* x, const uint16_t* e, uint32_t cap, uint32_t n_pix, float* rgb, float* depth, float* mask) {
+                        uint32_t job_base, uint32_t jobs_cap, const float* x, const uint16_t* e, uint32_t cap, uint32_t n_pix, float* rgb, float* depth,
+                                float* mask) {
     TileMlpArgs a{ nd, oc, frag_image, reinterpret_cast<const float4_t*>(rec), count, job_base, jobs_cap, reinterpret_cast<const float4_t*>(x), e, cap, n_pix };
     MON_FUSED_DISPATCH(tile_render_t, s, a, rgb, depth, mask);
 }

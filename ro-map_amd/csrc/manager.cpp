@@ -99,7 +99,8 @@ int offline_init(OfflineManager& m) {                                   // nerf_
     int rc = device_count(&m.n_dev); if (rc) return rc;
     rc = config_from_json(m.cfg_path.c_str(), m.cfg); if (rc) return rc;
     m.cfg.use_depth = m.use_depth ? 1 : 0;
-    m.outer_iters = (int)options().offline_outer; m.inner_iters = (int)options().offline_inner;       // (10 x 500 unless a test shortened the job: mon_set_option)
+    // (10 x 500 unless a test shortened the job: mon_set_option)
+    m.outer_iters = (int)options().offline_outer; m.inner_iters = (int)options().offline_inner;
     return MON_OK;
 }
 
@@ -107,13 +108,15 @@ int offline_read_dataset(OfflineManager& m) {                           // nerf_
     std::ifstream fc(m.dataset + "/config.yaml");
     if (!fc) { set_error("Failed to open settings file at: %s/config.yaml", m.dataset.c_str()); return MON_ERR_IO; }
     std::stringstream ss; ss << fc.rdbuf(); const std::string y = ss.str(); double v;
-    const struct { const char* key; float* f; int* i; } fields[] = { { "Camera.fx", &m.fx, nullptr }, { "Camera.fy", &m.fy, nullptr }, { "Camera.cx", &m.cx, nullptr }, { "Camera.cy", &m.cy, nullptr },
+    const struct { const char* key; float* f; int* i; } fields[] = { { "Camera.fx", &m.fx, nullptr }, { "Camera.fy", &m.fy, nullptr }, { "Camera.cx", &m.cx,
+            nullptr }, { "Camera.cy", &m.cy, nullptr },
                                                                      { "Camera.H", nullptr, &m.H }, { "Camera.W", nullptr, &m.W } };
     for (const auto& fd : fields) {
         if (!read_yaml_number(y, fd.key, v)) { set_error("config.yaml: %s missing or not a number", fd.key); return MON_ERR_IO; }
         if (fd.f) *fd.f = (float)v; else *fd.i = (int)v;
     }
-    if (m.H <= 0 || m.W <= 0 || !(m.fx > 0.f) || !(m.fy > 0.f)) { set_error("config.yaml: bad intrinsics (fx %g fy %g H %d W %d)", (double)m.fx, (double)m.fy, m.H, m.W); return MON_ERR_IO; }
+    if (m.H <= 0 || m.W <= 0 || !(m.fx > 0.f) || !(m.fy > 0.f)) {
+        set_error("config.yaml: bad intrinsics (fx %g fy %g H %d W %d)", (double)m.fx, (double)m.fy, m.H, m.W); return MON_ERR_IO; }
     if (m.use_depth) {
         if (!read_yaml_number(y, "DepthMapFactor", v)) { set_error("config.yaml: DepthMapFactor missing or not a number"); return MON_ERR_IO; }
         m.depth_scale = (float)v;
@@ -121,23 +124,28 @@ int offline_read_dataset(OfflineManager& m) {                           // nerf_
     std::ifstream fi(m.dataset + "/img.txt"), fg(m.dataset + "/groundtruth.txt"); std::string line;
     if (!fi || !fg) { set_error("Load dataset error: img.txt / groundtruth.txt missing in %s", m.dataset.c_str()); return MON_ERR_IO; }
     std::getline(fi, line);                                             // skip comments
-    while (std::getline(fi, line)) { if (line.empty()) continue; std::stringstream s2(line); std::string st, nm; s2 >> st >> nm; m.stamp_to_idx[st] = (uint32_t)m.names.size(); m.names.push_back(nm); m.stamps.push_back(st); }
+    while (std::getline(fi, line)) { if (line.empty()) continue; std::stringstream s2(line); std::string st, nm; s2 >> st >> nm;
+        m.stamp_to_idx[st] = (uint32_t)m.names.size(); m.names.push_back(nm); m.stamps.push_back(st); }
     std::getline(fg, line);
     while (std::getline(fg, line)) {
-        if (line.empty()) continue; std::stringstream s2(line); std::string st; float t[3], qx, qy, qz, qw; s2 >> st >> t[0] >> t[1] >> t[2] >> qx >> qy >> qz >> qw;
+        if (line.empty()) continue; std::stringstream s2(line); std::string st; float t[3], qx, qy, qz, qw;
+        s2 >> st >> t[0] >> t[1] >> t[2] >> qx >> qy >> qz >> qw;
         float M[16]; pose_from_tq(t, qx, qy, qz, qw, M); m.poses.insert(m.poses.end(), M, M + 16);
     }
     const size_t n = m.poses.size() / 16;
     if (n == 0 || n != m.names.size()) { set_error("Load dataset error...No images (%zu poses, %zu image names)", n, m.names.size()); return MON_ERR_IO; }
     const size_t px = (size_t)m.H * m.W;
-    for (int g = 0; g < m.n_dev; ++g) { Dataset* d = nullptr; int rc = dataset_create(g, m.H, m.W, m.fx, m.fy, m.cx, m.cy, (uint32_t)n, m.use_depth, &d); if (rc) return rc; m.ds.push_back(d); }
-    // The PNGs of a batch of frames are decoded by a few host threads at once (inflate + unfilter: ~10 ms per 640x480 frame, the whole read of a sequence otherwise),
+    for (int g = 0; g < m.n_dev; ++g) { Dataset* d = nullptr; int rc = dataset_create(g, m.H, m.W, m.fx, m.fy, m.cx, m.cy, (uint32_t)n, m.use_depth, &d);
+        if (rc) return rc; m.ds.push_back(d); }
+    // The PNGs of a batch of frames are decoded by a few host threads at once (inflate + unfilter: ~10 ms per 640x480 frame, the whole read of a sequence
+    // otherwise),
     // then handed to the device(s) in frame order.  The reference reads them one by one with cv::imread (nerf_data.cu:151-221).
     struct Decoded { std::vector<uint8_t> rgb, inst; std::vector<float> depth; std::string err; };
     const auto decode = [&](size_t i, Decoded& o) {
         PngImage c, s, z; o.err.clear(); o.rgb.resize(px * 3); o.inst.resize(px); if (m.use_depth) o.depth.resize(px);
         if (!png_read(m.dataset + "/rgb/" + m.names[i], c, o.err) || !png_read(m.dataset + "/instance/" + m.names[i], s, o.err)) return;
-        if (c.width != m.W || c.height != m.H || s.width != m.W || s.height != m.H || s.bit_depth != 8) { o.err = "image " + m.names[i] + " does not match config.yaml"; return; }
+        if (c.width != m.W || c.height != m.H || s.width != m.W || s.height != m.H || s.bit_depth != 8) {
+            o.err = "image " + m.names[i] + " does not match config.yaml"; return; }
         {   // cv::imread(IMREAD_COLOR), nerf_data.cu:158: gray is replicated to three channels, alpha dropped, 16-bit samples reduced to their high byte
             const size_t sb = c.bit_depth == 16 ? 2 : 1, pb = (size_t)c.channels * sb; const bool gray = c.channels < 3;
             for (size_t p = 0; p < px; ++p) {
@@ -151,8 +159,10 @@ int offline_read_dataset(OfflineManager& m) {                           // nerf_
         }
         if (m.use_depth) {
             if (!png_read(m.dataset + "/depth/" + m.names[i], z, o.err)) return;
-            if (z.width != m.W || z.height != m.H || z.bit_depth != 16) { o.err = "depth image " + m.names[i] + " must be 16-bit " + std::to_string(m.W) + "x" + std::to_string(m.H); return; }
-            for (size_t p = 0; p < px; ++p) o.depth[p] = (float)((z.data[2 * p * z.channels] << 8) | z.data[2 * p * z.channels + 1]) * m.depth_scale;      // convertTo(CV_32FC1, mfDepthScale), nerf_data.cu:187
+            if (z.width != m.W || z.height != m.H || z.bit_depth != 16) {
+                o.err = "depth image " + m.names[i] + " must be 16-bit " + std::to_string(m.W) + "x" + std::to_string(m.H); return; }
+            // convertTo(CV_32FC1, mfDepthScale), nerf_data.cu:187
+            for (size_t p = 0; p < px; ++p) o.depth[p] = (float)((z.data[2 * p * z.channels] << 8) | z.data[2 * p * z.channels + 1]) * m.depth_scale;
         }
     };
     unsigned nt = std::thread::hardware_concurrency(); nt = nt < 1u ? 1u : (nt > 8u ? 8u : nt);
@@ -166,7 +176,8 @@ int offline_read_dataset(OfflineManager& m) {                           // nerf_
         for (size_t t = 0; t < cnt; ++t) {
             if (!batch[t].err.empty()) { set_error("%s", batch[t].err.c_str()); return MON_ERR_IO; }
             for (int g = 0; g < m.n_dev; ++g) {                         // PNG stores RGB; is_bgr = 0 (cv::imread would hand BGR)
-                int rc = dataset_add_frame(m.ds[g], (uint32_t)(base + t), batch[t].rgb.data(), 3, 0, batch[t].inst.data(), m.use_depth ? batch[t].depth.data() : nullptr, &m.poses[16 * (base + t)]); if (rc) return rc;
+                int rc = dataset_add_frame(m.ds[g], (uint32_t)(base + t), batch[t].rgb.data(), 3, 0, batch[t].inst.data(), m.use_depth ? batch[t].depth.data()
+                        : nullptr, &m.poses[16 * (base + t)]); if (rc) return rc;
             }
         }
     }
@@ -179,13 +190,15 @@ static void train_offline_thread(OfflineManager* m, OfflineObject* o) {  // NeRF
         std::lock_guard<std::mutex> l(o->mu_model);
         o->rc = model_train(*o->model, m->inner_iters, &o->last_loss, 7);
         if (o->rc == MON_OK) std::printf("Id: %d Step: %d loss: %f\n", o->id, i * m->inner_iters, o->last_loss);
-        if (o->rc == MON_OK && i % 2 == 0) o->rc = model_generate_mesh(*o->model, m->mesh_res, m->mesh_thresh, nullptr, nullptr);   // GenerateMesh + TransCPUMesh, nerf.cu:138-145
+        // GenerateMesh + TransCPUMesh, nerf.cu:138-145
+        if (o->rc == MON_OK && i % 2 == 0) o->rc = model_generate_mesh(*o->model, m->mesh_res, m->mesh_thresh, nullptr, nullptr);
     }
     std::lock_guard<std::mutex> l(o->mu_model);
     if (o->rc == MON_OK && !m->mesh_dir.empty()) {                        // SaveMesh("./output/<id>.ply"), nerf.cu:148-149
         uint32_t nv = 0; model_mesh_counts(*o->model, &nv, nullptr, nullptr);
         ::mkdir(m->mesh_dir.c_str(), 0755);
-        if (nv && model_save_mesh(*o->model, (m->mesh_dir + "/" + std::to_string(o->id) + ".ply").c_str()) != MON_OK) std::fprintf(stderr, "Id: %d mesh not saved: %s\n", o->id, last_error());
+        if (nv && model_save_mesh(*o->model, (m->mesh_dir + "/" + std::to_string(o->id) + ".ply").c_str()) != MON_OK) std::fprintf(stderr,
+                "Id: %d mesh not saved: %s\n", o->id, last_error());
     }
     if (o->rc != MON_OK) o->err = last_error();            // the message is thread-local: hand it to whoever joins this thread
 }
@@ -228,7 +241,8 @@ static int write_render_pngs(const std::string& img_path, const std::string& dep
     for (size_t p = 0; p < 3 * n; ++p) { const float q = rgb[p] * 255.f; c8[p] = (uint8_t)(q < 0.f ? 0.f : (q > 255.f ? 255.f : std::nearbyint(q))); }
     for (size_t p = 0; p < n; ++p) {
         if (mask) { const float q = mask[p] * 255.f; m8[p] = (uint8_t)(q > 0.f ? (q > 255.f ? 255.f : std::nearbyint(q)) : 0.f); }
-        const float q = depth[p] * 20000.f; const uint32_t u = (uint32_t)(q < 0.f ? 0.f : (q > 65535.f ? 65535.f : std::nearbyint(q))); d16[2 * p] = (uint8_t)(u >> 8); d16[2 * p + 1] = (uint8_t)u;
+        const float q = depth[p] * 20000.f; const uint32_t u = (uint32_t)(q < 0.f ? 0.f : (q > 65535.f ? 65535.f : std::nearbyint(q)));
+        d16[2 * p] = (uint8_t)(u >> 8); d16[2 * p + 1] = (uint8_t)u;
     }
     if (!png_write(img_path, (int)w, (int)h, 3, 8, c8.data(), err) || !png_write(depth_path, (int)w, (int)h, 1, 16, d16.data(), err) ||
         (mask && !png_write(mask_path, (int)w, (int)h, 1, 8, m8.data(), err))) { set_error("%s", err.c_str()); return MON_ERR_IO; }
@@ -238,7 +252,8 @@ static int write_render_pngs(const std::string& img_path, const std::string& dep
 // NeRF_Model::GenerateToc nerf_model.cu:2186-2205: camera on a sphere of radius r around the object, looking at its centre
 void generate_toc(float theta, float phi, float r, float* Toc16) {
     const double d2r = M_PI / 180.0;
-    const float t[3] = { (float)(r * std::cos(phi * d2r) * std::cos(theta * d2r)), (float)(r * std::cos(phi * d2r) * std::sin(theta * d2r)), (float)(r * std::sin(phi * d2r)) };
+    const float t[3] = { (float)(r * std::cos(phi * d2r) * std::cos(theta * d2r)), (float)(r * std::cos(phi * d2r) * std::sin(theta * d2r)),
+            (float)(r * std::sin(phi * d2r)) };
     float z[3] = { -t[0], -t[1], -t[2] }; const float zn = std::sqrt(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]); if (zn > 0.f) for (float& v : z) v /= zn;
     const float rv = (float)((theta + 90.0f) * d2r); float x[3] = { std::cos(rv), std::sin(rv), 0.f };
     const float xn = std::sqrt(x[0] * x[0] + x[1] * x[1]); if (xn > 0.f) for (float& v : x) v /= xn;
@@ -256,7 +271,8 @@ static int render_video(Model& m, int H, int W, float radius, const std::string&
     for (int i = 0; i < theta_num; ++i) {
         cur += theta; float Toc[16]; generate_toc(cur, 30.f, radius, Toc);
         int rc = model_render(m, box, Toc, 1, rgb.data(), depth.data(), mask.data(), 0); if (rc) return rc;
-        rc = write_render_pngs(img_dir + "/" + std::to_string(i) + ".png", depth_dir + "/" + std::to_string(i) + ".png", "", box.w, box.h, rgb.data(), depth.data(), nullptr); if (rc) return rc;
+        rc = write_render_pngs(img_dir + "/" + std::to_string(i) + ".png", depth_dir + "/" + std::to_string(i) + ".png", "", box.w, box.h, rgb.data(),
+                depth.data(), nullptr); if (rc) return rc;
     }
     return MON_OK;
 }
@@ -264,7 +280,8 @@ static int render_video(Model& m, int H, int W, float radius, const std::string&
 // Eigen::Quaternionf(Matrix3f) for a column-major 4x4 (x y z w); trace / largest-diagonal branches
 static void quat_from_pose(const float* M, float* q) {
     const float m00 = M[0], m11 = M[5], m22 = M[10], tr = m00 + m11 + m22;
-    if (tr > 0.f) { float t = std::sqrt(tr + 1.f); q[3] = 0.5f * t; t = 0.5f / t; q[0] = (M[6] - M[9]) * t; q[1] = (M[8] - M[2]) * t; q[2] = (M[1] - M[4]) * t; }
+    if (tr > 0.f) { float t = std::sqrt(tr + 1.f); q[3] = 0.5f * t; t = 0.5f / t; q[0] = (M[6] - M[9]) * t; q[1] = (M[8] - M[2]) * t;
+        q[2] = (M[1] - M[4]) * t; }
     else {
         int i = 0; if (m11 > m00) i = 1; if (m22 > (i ? m11 : m00)) i = 2; const int j = (i + 1) % 3, k = (j + 1) % 3;
         auto R = [&](int r, int c) { return M[c * 4 + r]; };
@@ -277,7 +294,8 @@ static void mat4_mul(const float* A, const float* B, float* C) {       // column
 }
 static void write_pose_line(std::ofstream& f, const std::string& stamp, const mon_frame_bbox& b, const float* Tow, const float* Twc) {
     float Toc[16], q[4]; mat4_mul(Tow, Twc, Toc); quat_from_pose(Toc, q);
-    f << stamp << " " << b.x << " " << b.y << " " << b.h << " " << b.w << " " << Toc[12] << " " << Toc[13] << " " << Toc[14] << " " << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << std::endl;
+    f << stamp << " " << b.x << " " << b.y << " " << b.h << " " << b.w << " " << Toc[12] << " " << Toc[13] << " " << Toc[14] << " " << q[0] << " " << q[1]
+            << " " << q[2] << " " << q[3] << std::endl;
 }
 
 // Test images of one object for each of its training boxes: <out>/<id>/test_img|test_depth|test_mask/<stamp>.png,
@@ -293,7 +311,8 @@ int offline_render_test(OfflineManager& m, int idx, const char* out_dir, int max
         const mon_frame_bbox b = o->boxes[i]; const size_t n = (size_t)b.w * b.h;
         std::vector<float> rgb(3 * n), depth(n), mask(n);
         int rc = model_render(*o->model, b, &m.poses[16 * (size_t)b.FrameId], 0, rgb.data(), depth.data(), mask.data(), 0); if (rc) return rc;
-        rc = write_render_pngs(root + "/test_img/" + o->stamps[i] + ".png", root + "/test_depth/" + o->stamps[i] + ".png", root + "/test_mask/" + o->stamps[i] + ".png", b.w, b.h, rgb.data(), depth.data(), mask.data());
+        rc = write_render_pngs(root + "/test_img/" + o->stamps[i] + ".png", root + "/test_depth/" + o->stamps[i] + ".png",
+                root + "/test_mask/" + o->stamps[i] + ".png", b.w, b.h, rgb.data(), depth.data(), mask.data());
         if (rc) return rc;
     }
     uint32_t n_mesh = 0; model_mesh_counts(*o->model, &n_mesh, nullptr, nullptr);
@@ -339,10 +358,13 @@ struct AnnouncedLock {
 
 struct OnlineManager {
     std::string cfg_path; bool use_depth = false; int iters = 500, n_dev = 0, next_dev = 0; mon_config cfg{};
-    size_t n_images = 0; std::vector<Dataset*> ds; std::vector<std::vector<std::unique_ptr<std::mutex>>> ds_mutex; std::vector<std::unique_ptr<std::atomic<int>>> dev_objects;
+    size_t n_images = 0; std::vector<Dataset*> ds; std::vector<std::vector<std::unique_ptr<std::mutex>>> ds_mutex;
+    std::vector<std::unique_ptr<std::atomic<int>>> dev_objects;
     std::map<std::string, uint32_t> stamp_to_idx; std::vector<OnlineObject*> objs; std::vector<std::thread> threads;
-    std::mutex mu_objs;      // objs grows on the SLAM thread (CreateNeRF) while the viewer looks objects up (DrawMesh, renders): look-ups copy the pointer under this lock
-    int H = 0, W = 0; std::map<uint32_t, std::vector<float>> poses;       // host copy of the poses for train.txt (nerf.cu:369-373 reads them back from the device)
+    // objs grows on the SLAM thread (CreateNeRF) while the viewer looks objects up (DrawMesh, renders): look-ups copy the pointer under this lock
+    std::mutex mu_objs;
+    // host copy of the poses for train.txt (nerf.cu:369-373 reads them back from the device)
+    int H = 0, W = 0; std::map<uint32_t, std::vector<float>> poses;
 };
 
 // The training thread tests `finish` and then waits on `cond` under mu_boxes; passing through mu_boxes between setting the flag and
@@ -368,7 +390,8 @@ static int train_sliced(OnlineObject* o) {
     for (int done = 0; done < o->iterations && rc == MON_OK; ) {
         while (o->waiters.load() > 0) std::this_thread::yield();
         const int sharing = o->device_objects ? o->device_objects->load() : 1;
-        int n = kOnlineSlice / (sharing > 0 ? sharing : 1); const long slice_min = options().online_slice_min; const int n_min = slice_min > 0 ? (int)slice_min : 2; if (n < n_min) n = n_min; if (n > o->iterations - done) n = o->iterations - done;
+        int n = kOnlineSlice / (sharing > 0 ? sharing : 1); const long slice_min = options().online_slice_min;
+        const int n_min = slice_min > 0 ? (int)slice_min : 2; if (n < n_min) n = n_min; if (n > o->iterations - done) n = o->iterations - done;
         std::unique_lock<std::mutex> dl(*o->dataset_mutex); std::lock_guard<std::mutex> lm(o->mu_model);
         rc = model_train(*o->model, n, &o->last_loss, 7); done += n;
         if (rc == MON_OK && done >= o->iterations) rc = model_publish_snapshot(*o->model);       // viewers see the end of every Train_Step_Online
@@ -376,7 +399,8 @@ static int train_sliced(OnlineObject* o) {
     return rc;
 }
 
-static OnlineObject* online_object(OnlineManager& m, size_t idx) { std::lock_guard<std::mutex> l(m.mu_objs); return idx < m.objs.size() ? m.objs[idx] : nullptr; }
+static OnlineObject* online_object(OnlineManager& m, size_t idx) { std::lock_guard<std::mutex> l(m.mu_objs);
+    return idx < m.objs.size() ? m.objs[idx] : nullptr; }
 static std::vector<OnlineObject*> online_objects(OnlineManager& m) { std::lock_guard<std::mutex> l(m.mu_objs); return m.objs; }
 
 static void train_online_thread(OnlineObject* o) {                       // NeRF::TrainOnline, nerf.cu:187-253
@@ -396,7 +420,8 @@ static void train_online_thread(OnlineObject* o) {                       // NeRF
             for (int i = 0; i < train_step && o->rc == MON_OK; ++i) {
                 o->rc = train_sliced(o); ++train_step_count;
                 std::lock_guard<std::mutex> lm(o->mu_model); ++o->train_calls;
-                if (o->rc == MON_OK && train_step_count % 2 == 0) o->rc = model_generate_mesh(*o->model, o->mesh_res, o->mesh_thresh, nullptr, nullptr);   // :228-236
+                // :228-236
+                if (o->rc == MON_OK && train_step_count % 2 == 0) o->rc = model_generate_mesh(*o->model, o->mesh_res, o->mesh_thresh, nullptr, nullptr);
             }
         }
         if (online_check_finish(o) || o->rc != MON_OK) break;
@@ -438,37 +463,48 @@ int mon_offline_read_dataset(mon_offline* h) { REQ(h); return offline_read_datas
 int mon_offline_create_nerf(mon_offline* h, const char* object_file) { REQ(h); REQ(object_file); return offline_create_nerf(*h->m, object_file); }
 int mon_offline_wait_threads_end(mon_offline* h) { REQ(h); return offline_wait(*h->m); }
 int mon_offline_n_objects(mon_offline* h, int* n) { REQ(h); REQ(n); *n = (int)h->m->objs.size(); return MON_OK; }
-int mon_offline_object_loss(mon_offline* h, int idx, float* loss, int* device) { REQ(h); REQ(loss); if (idx < 0 || idx >= (int)h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *loss = h->m->objs[idx]->last_loss; if (device) *device = h->m->objs[idx]->device; return MON_OK; }
-int mon_offline_render_test(mon_offline* h, int idx, const char* out_dir, int max_views) { REQ(h); REQ(out_dir); return offline_render_test(*h->m, idx, out_dir, max_views); }
+int mon_offline_object_loss(mon_offline* h, int idx, float* loss, int* device) { REQ(h); REQ(loss); if (idx < 0 || idx >= (int)h->m->objs.size()) {
+        set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *loss = h->m->objs[idx]->last_loss; if (device) *device = h->m->objs[idx]->device;
+        return MON_OK; }
+int mon_offline_render_test(mon_offline* h, int idx, const char* out_dir, int max_views) { REQ(h); REQ(out_dir);
+    return offline_render_test(*h->m, idx, out_dir, max_views); }
 // GetIntrinsics / GetAllTwc / NeRF::GetObjTow, GetBoundingBox, GetFrameIdAndBBox -- what MON/main.cpp:55,149-151,334-336 reads for its viewer
 int mon_offline_get_intrinsics(mon_offline* h, float* fx, float* fy, float* cx, float* cy, int* H, int* W) {
-    REQ(h); OfflineManager& m = *h->m; if (fx) *fx = m.fx; if (fy) *fy = m.fy; if (cx) *cx = m.cx; if (cy) *cy = m.cy; if (H) *H = m.H; if (W) *W = m.W; return MON_OK;
+    REQ(h); OfflineManager& m = *h->m; if (fx) *fx = m.fx; if (fy) *fy = m.fy; if (cx) *cx = m.cx; if (cy) *cy = m.cy; if (H) *H = m.H; if (W) *W = m.W;
+    return MON_OK;
 }
 int mon_offline_get_poses(mon_offline* h, float* Twc16s, size_t capacity_frames, size_t* n_frames) {
     REQ(h); OfflineManager& m = *h->m; const size_t n = m.poses.size() / 16; if (n_frames) *n_frames = n;
-    if (Twc16s) { if (capacity_frames < n) { set_error("get_poses: buffer holds %zu of %zu frames", capacity_frames, n); return MON_ERR_ARG; } std::memcpy(Twc16s, m.poses.data(), n * 64); }
+    if (Twc16s) { if (capacity_frames < n) { set_error("get_poses: buffer holds %zu of %zu frames", capacity_frames, n); return MON_ERR_ARG;
+            } std::memcpy(Twc16s, m.poses.data(), n * 64); }
     return MON_OK;
 }
-int mon_offline_object_meta(mon_offline* h, int idx, int* class_id, float* Tow16, float* aabb_min3, float* aabb_max3, mon_frame_bbox* boxes, size_t capacity_boxes, size_t* n_boxes) {
+int mon_offline_object_meta(mon_offline* h, int idx, int* class_id, float* Tow16, float* aabb_min3, float* aabb_max3, mon_frame_bbox* boxes,
+        size_t capacity_boxes, size_t* n_boxes) {
     REQ(h); if (idx < 0 || idx >= (int)h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
     OfflineObject* o = h->m->objs[idx];
-    if (class_id) *class_id = o->cls; if (Tow16) std::memcpy(Tow16, o->Tow, 64); if (aabb_min3) std::memcpy(aabb_min3, o->amin, 12); if (aabb_max3) std::memcpy(aabb_max3, o->amax, 12);
+    if (class_id) *class_id = o->cls; if (Tow16) std::memcpy(Tow16, o->Tow, 64); if (aabb_min3) std::memcpy(aabb_min3, o->amin, 12);
+    if (aabb_max3) std::memcpy(aabb_max3, o->amax, 12);
     if (n_boxes) *n_boxes = o->boxes.size();
-    if (boxes) { if (capacity_boxes < o->boxes.size()) { set_error("object_meta: buffer holds %zu of %zu boxes", capacity_boxes, o->boxes.size()); return MON_ERR_ARG; } std::memcpy(boxes, o->boxes.data(), o->boxes.size() * sizeof(mon_frame_bbox)); }
+    if (boxes) { if (capacity_boxes < o->boxes.size()) { set_error("object_meta: buffer holds %zu of %zu boxes", capacity_boxes, o->boxes.size());
+            return MON_ERR_ARG; } std::memcpy(boxes, o->boxes.data(), o->boxes.size() * sizeof(mon_frame_bbox)); }
     return MON_OK;
 }
 int mon_offline_object_stamp(mon_offline* h, int idx, size_t box_index, char* buf, size_t capacity) {
     REQ(h); REQ(buf); if (idx < 0 || idx >= (int)h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
     OfflineObject* o = h->m->objs[idx];
-    if (box_index >= o->stamps.size() || capacity < o->stamps[box_index].size() + 1) { set_error("object_stamp: box index or buffer size"); return MON_ERR_ARG; }
+    if (box_index >= o->stamps.size() || capacity < o->stamps[box_index].size() + 1) { set_error("object_stamp: box index or buffer size");
+        return MON_ERR_ARG; }
     std::memcpy(buf, o->stamps[box_index].c_str(), o->stamps[box_index].size() + 1); return MON_OK;
 }
-int mon_write_render_pngs(const char* img_path, const char* depth_path, const char* mask_path, uint32_t w, uint32_t h, const float* rgb, const float* depth, const float* mask) {
+int mon_write_render_pngs(const char* img_path, const char* depth_path, const char* mask_path, uint32_t w, uint32_t h, const float* rgb, const float* depth,
+        const float* mask) {
     if (!img_path || !depth_path || !rgb || !depth || (mask && !mask_path) || !w || !h) { set_error("write_render_pngs: bad argument"); return MON_ERR_ARG; }
     return write_render_pngs(img_path, depth_path, mask_path ? mask_path : "", w, h, rgb, depth, mask);
 }
 int mon_offline_set_output_dir(mon_offline* h, const char* dir) { REQ(h); h->m->mesh_dir = dir ? dir : ""; return MON_OK; }
-int mon_offline_object(mon_offline* h, int idx, mon_object** borrowed) { REQ(h); REQ(borrowed); if (idx < 0 || idx >= (int)h->m->objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *borrowed = &h->m->objs[idx]->handle; return MON_OK; }
+int mon_offline_object(mon_offline* h, int idx, mon_object** borrowed) { REQ(h); REQ(borrowed); if (idx < 0 || idx >= (int)h->m->objs.size()) {
+        set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *borrowed = &h->m->objs[idx]->handle; return MON_OK; }
 int mon_offline_destroy(mon_offline* h) { if (!h) return MON_OK; offline_destroy(h->m); delete h; return MON_OK; }
 
 // ---- NerfManagerOnline
@@ -489,11 +525,15 @@ int mon_online_dataset_init(mon_online* h, float fx, float fy, float cx, float c
     if (!m.ds.empty()) { set_error("DatasetInit called twice"); return MON_ERR_STATE; }
     m.n_images = imgs; m.ds_mutex.resize(m.n_dev); m.H = H; m.W = W;
     for (int g = 0; g < m.n_dev; ++g) m.dev_objects.emplace_back(new std::atomic<int>(0));
-    for (int g = 0; g < m.n_dev; ++g) { const int rcs = stream_pool_reserve(g, 8); if (rcs) return rcs; }          // CreateNeRF runs on the SLAM thread later: take the ~8 ms per stream now
-    for (int g = 0; g < m.n_dev; ++g) { Dataset* d = nullptr; int rc = dataset_create(g, H, W, fx, fy, cx, cy, (uint32_t)imgs, m.use_depth, &d); if (rc) return rc; m.ds.push_back(d); }
+    // CreateNeRF runs on the SLAM thread later: take the ~8 ms per stream now
+    for (int g = 0; g < m.n_dev; ++g) { const int rcs = stream_pool_reserve(g, 8); if (rcs) return rcs; }
+    for (int g = 0; g < m.n_dev; ++g) { Dataset* d = nullptr; int rc = dataset_create(g, H, W, fx, fy, cx, cy, (uint32_t)imgs, m.use_depth, &d);
+        if (rc) return rc; m.ds.push_back(d); }
     return MON_OK;
 }
-int mon_online_new_frame(mon_online* h, uint32_t img_id, const char* timestamp, const uint8_t* bgr, int channels, const uint8_t* instance, const float* depth, const float* Twc16) {   // :189-218
+// :189-218
+int mon_online_new_frame(mon_online* h, uint32_t img_id, const char* timestamp, const uint8_t* bgr, int channels, const uint8_t* instance, const float* depth,
+        const float* Twc16) {
     REQ(h); REQ(timestamp); OnlineManager& m = *h->m;
     m.stamp_to_idx[timestamp] = img_id;                                   // nerf_data.cu:284
     if (Twc16) m.poses[img_id].assign(Twc16, Twc16 + 16);
@@ -530,10 +570,12 @@ int mon_online_get_pose(mon_online* h, uint32_t frame_id, float* Twc16) {
     if (it == h->m->poses.end()) { set_error("get_pose: frame %u has not been added", frame_id); return MON_ERR_ARG; }
     std::memcpy(Twc16, it->second.data(), 64); return MON_OK;
 }
-int mon_online_create_nerf(mon_online* h, int cls, const float* Tow16, const float* aabb_min3, const float* aabb_max3, size_t* idx_out) {   // :237-261 + SetAttributes nerf.cu:155-185
+// :237-261 + SetAttributes nerf.cu:155-185
+int mon_online_create_nerf(mon_online* h, int cls, const float* Tow16, const float* aabb_min3, const float* aabb_max3, size_t* idx_out) {
     REQ(h); REQ(Tow16); REQ(aabb_min3); REQ(aabb_max3); REQ(idx_out); OnlineManager& m = *h->m;
     if (m.ds.empty()) { set_error("CreateNeRF before DatasetInit"); return MON_ERR_STATE; }
-    OnlineObject* o = new OnlineObject(); o->id = (int)m.objs.size(); o->device = m.next_dev; m.next_dev = (m.next_dev + 1) % m.n_dev; o->cls = cls; o->iterations = m.iters;
+    OnlineObject* o = new OnlineObject(); o->id = (int)m.objs.size(); o->device = m.next_dev; m.next_dev = (m.next_dev + 1) % m.n_dev; o->cls = cls;
+    o->iterations = m.iters;
     std::memcpy(o->Tow, Tow16, 64);
     const float k = (cls == 41 || cls == 73) ? 1.2f : 1.1f;              // appropriately expand the 3-D box (nerf.cu:163-172)
     for (int a = 0; a < 3; ++a) { o->amin[a] = k * aabb_min3[a]; o->amax[a] = k * aabb_max3[a]; }
@@ -546,7 +588,8 @@ int mon_online_create_nerf(mon_online* h, int cls, const float* Tow16, const flo
     m.threads.emplace_back(train_online_thread, o);                      // thread per object, nerf_manager.cu:259
     return MON_OK;
 }
-int mon_online_update_nerf_bbox(mon_online* h, size_t idx, const mon_frame_bbox* boxes, size_t n, int train_step) {   // :298-303 + UpdateFrameBBox nerf.cu:406-421
+// :298-303 + UpdateFrameBBox nerf.cu:406-421
+int mon_online_update_nerf_bbox(mon_online* h, size_t idx, const mon_frame_bbox* boxes, size_t n, int train_step) {
     REQ(h);
     OnlineObject* o = online_object(*h->m, idx);
     if (!o) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
@@ -574,9 +617,11 @@ int mon_online_wait_threads_end(mon_online* h) {                           // :2
 }
 int mon_online_object_info(mon_online* h, size_t idx, float* loss, int* train_calls, int* device, uint32_t* n_boxes) {
     REQ(h); OnlineObject* o = online_object(*h->m, idx); if (!o) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
-    AnnouncedLock lm(o, o->mu_model); if (loss) *loss = o->last_loss; if (train_calls) *train_calls = o->train_calls; if (device) *device = o->device; if (n_boxes) *n_boxes = (uint32_t)o->n_uploaded; return MON_OK;
+    AnnouncedLock lm(o, o->mu_model); if (loss) *loss = o->last_loss; if (train_calls) *train_calls = o->train_calls; if (device) *device = o->device;
+    if (n_boxes) *n_boxes = (uint32_t)o->n_uploaded; return MON_OK;
 }
-int mon_online_render(mon_online* h, size_t idx, mon_frame_bbox box, const float* Twc16, float* rgb, float* depth, float* mask) {   // one view of RenderNeRFsTest :280-285
+// one view of RenderNeRFsTest :280-285
+int mon_online_render(mon_online* h, size_t idx, mon_frame_bbox box, const float* Twc16, float* rgb, float* depth, float* mask) {
     REQ(h); OnlineObject* o = online_object(*h->m, idx); if (!o) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
     // a viewer's render: the latest published inference weights on the object's inference stream -- no model mutex, nothing queued behind training
     if (model_render_snapshot(*o->model, box, Twc16, 0, rgb, depth, mask, nullptr) == MON_OK) return MON_OK;
@@ -585,7 +630,8 @@ int mon_online_render(mon_online* h, size_t idx, mon_frame_bbox box, const float
 }
 // NerfManagerOnline::RenderNeRFsTest -> NeRF::RenderTestImg, nerf.cu:255-404: <out>/<id>/{test_img,test_depth,test_mask}/<stamp>.png,
 // test.txt, train.txt (object-centric poses), 60-view video_img / video_depth, obj.ply
-int mon_online_render_nerfs_test(mon_online* h, const char* out_path, size_t idx, const char* const* timestamps, const mon_frame_bbox* boxes, const float* Twcs16, size_t n, float radius) {
+int mon_online_render_nerfs_test(mon_online* h, const char* out_path, size_t idx, const char* const* timestamps, const mon_frame_bbox* boxes,
+        const float* Twcs16, size_t n, float radius) {
     REQ(h); REQ(out_path); OnlineManager& m = *h->m;
     if (online_objects(m).empty()) return MON_OK;                          // nerf_manager.cu:282
     if (!online_object(m, idx)) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
@@ -605,7 +651,8 @@ int mon_online_render_nerfs_test(mon_online* h, const char* out_path, size_t idx
         write_pose_line(f, st, b, o->Tow, Twc);
         std::vector<float> rgb(3 * px), depth(px), mask(px);
         int rc = model_render(*o->model, b, Twc, 0, rgb.data(), depth.data(), mask.data(), 0); if (rc) return rc;
-        rc = write_render_pngs(root + "/test_img/" + st + ".png", root + "/test_depth/" + st + ".png", root + "/test_mask/" + st + ".png", b.w, b.h, rgb.data(), depth.data(), mask.data()); if (rc) return rc;
+        rc = write_render_pngs(root + "/test_img/" + st + ".png", root + "/test_depth/" + st + ".png", root + "/test_mask/" + st + ".png", b.w, b.h,
+                rgb.data(), depth.data(), mask.data()); if (rc) return rc;
     }
     f.close();
     f.open(root + "/train.txt");                                          // training data, nerf.cu:356-390
@@ -629,7 +676,8 @@ int mon_online_render_nerfs_test(mon_online* h, const char* out_path, size_t idx
     return MON_OK;
 }
 int mon_generate_toc(float theta_deg, float phi_deg, float radius, float* Toc16) { REQ(Toc16); generate_toc(theta_deg, phi_deg, radius, Toc16); return MON_OK; }
-int mon_online_object(mon_online* h, size_t idx, mon_object** borrowed) { REQ(h); REQ(borrowed); OnlineObject* o = online_object(*h->m, idx); if (!o) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *borrowed = &o->handle; return MON_OK; }
+int mon_online_object(mon_online* h, size_t idx, mon_object** borrowed) { REQ(h); REQ(borrowed); OnlineObject* o = online_object(*h->m, idx); if (!o) {
+        set_error("NeRF Idx error ..."); return MON_ERR_ARG; } *borrowed = &o->handle; return MON_OK; }
 int mon_online_destroy(mon_online* h) { if (!h) return MON_OK; online_destroy(h->m); delete h; return MON_OK; }
 
 int mon_png_read(const char* path, int* width, int* height, int* channels, int* bit_depth, uint8_t* pixels, size_t capacity) {
@@ -637,7 +685,8 @@ int mon_png_read(const char* path, int* width, int* height, int* channels, int* 
     PngImage img; std::string err;
     if (!png_read(path, img, err)) { set_error("%s", err.c_str()); return MON_ERR_IO; }
     *width = img.width; *height = img.height; *channels = img.channels; *bit_depth = img.bit_depth;
-    if (pixels) { if (capacity < img.data.size()) { set_error("png_read: buffer too small"); return MON_ERR_ARG; } std::memcpy(pixels, img.data.data(), img.data.size()); }
+    if (pixels) { if (capacity < img.data.size()) { set_error("png_read: buffer too small"); return MON_ERR_ARG;
+            } std::memcpy(pixels, img.data.data(), img.data.size()); }
     return MON_OK;
 }
 int mon_png_write(const char* path, int width, int height, int channels, int bit_depth, const uint8_t* pixels_big_endian) {

@@ -39,7 +39,8 @@ template <class T> static int grow(T*& p, size_t& cap, size_t need, size_t elems
     if (need <= cap && p) return MON_OK;
     if (p) hipFree(p);
     p = nullptr; const size_t n = need + need / 4 + 128;
-    if (hipMalloc((void**)&p, n * elems_per_unit * sizeof(T)) != hipSuccess) { cap = 0; set_error("mesh: hipMalloc of %zu bytes failed", n * elems_per_unit * sizeof(T)); return MON_ERR_HIP; }
+    if (hipMalloc((void**)&p, n * elems_per_unit * sizeof(T)) != hipSuccess) { cap = 0;
+        set_error("mesh: hipMalloc of %zu bytes failed", n * elems_per_unit * sizeof(T)); return MON_ERR_HIP; }
     cap = n; return MON_OK;
 }
 
@@ -47,7 +48,8 @@ MeshState* mesh_state_create(int device) { MeshState* ms = new MeshState(); ms->
 void mesh_state_destroy(MeshState* ms) {
     if (!ms) return;
     use_device(ms->device);
-    for (void* p : { (void*)ms->d_density, (void*)ms->d_vertidx, (void*)ms->d_blocks, (void*)ms->d_verts, (void*)ms->d_nraw, (void*)ms->d_normals, (void*)ms->d_colf, (void*)ms->d_col8, (void*)ms->d_indices })
+    for (void* p : { (void*)ms->d_density, (void*)ms->d_vertidx, (void*)ms->d_blocks, (void*)ms->d_verts, (void*)ms->d_nraw, (void*)ms->d_normals,
+            (void*)ms->d_colf, (void*)ms->d_col8, (void*)ms->d_indices })
         if (p) hipFree(p);
     delete ms;
 }
@@ -66,7 +68,8 @@ int mesh_extract(MeshState& ms, hipStream_t s, int rx, int ry, int rz, float thr
     const size_t res3 = (size_t)rx * ry * rz; const uint32_t nb = (uint32_t)((res3 + 255) / 256);
     launch_mc_count(s, ms.d_density, rx, ry, rz, thresh, ms.d_blocks);
     uint64_t totals = 0;
-    HIPCHECK(hipMemcpyAsync(&totals, ms.d_blocks + nb, 8, hipMemcpyDeviceToHost, s)); HIPCHECK(hipStreamSynchronize(s));   // the reference's count-pass read-back :492-494
+    // the reference's count-pass read-back :492-494
+    HIPCHECK(hipMemcpyAsync(&totals, ms.d_blocks + nb, 8, hipMemcpyDeviceToHost, s)); HIPCHECK(hipStreamSynchronize(s));
     ms.n_verts_real = (uint32_t)(totals & 0xffffffffu); ms.n_indices = (uint32_t)(totals >> 32);
     ms.n_verts = (ms.n_verts_real + 127u) & ~127u;                                                                         // "round for later nn stuff" :496
     if (ms.n_verts > ms.cap_verts || !ms.d_verts) {
@@ -80,7 +83,8 @@ int mesh_extract(MeshState& ms, hipStream_t s, int rx, int ry, int rz, float thr
         HIPCHECK(hipMemsetAsync(ms.d_verts, 0, (size_t)ms.n_verts * 12, s)); HIPCHECK(hipMemsetAsync(ms.d_nraw, 0, (size_t)ms.n_verts * 12, s));
         HIPCHECK(hipMemsetAsync(ms.d_normals, 0, (size_t)ms.n_verts * 12, s));
     }
-    launch_mc_emit(s, ms.d_density, rx, ry, rz, thresh, amin, amax, ms.d_blocks, ms.d_vertidx, ms.d_verts, ms.d_indices, ms.d_nraw, ms.d_normals, ms.n_verts_real, ms.n_indices);
+    launch_mc_emit(s, ms.d_density, rx, ry, rz, thresh, amin, amax, ms.d_blocks, ms.d_vertidx, ms.d_verts, ms.d_indices, ms.d_nraw, ms.d_normals,
+            ms.n_verts_real, ms.n_indices);
     HIPCHECK(hipGetLastError());
     return MON_OK;
 }
@@ -89,11 +93,14 @@ int mesh_extract(MeshState& ms, hipStream_t s, int rx, int ry, int rz, float thr
 int mesh_to_cpu(MeshState& ms, hipStream_t s, bool with_colors) {
     std::unique_lock<std::mutex> lock(ms.mu);
     const size_t n = ms.n_verts;
-    ms.verts.resize(3 * n); ms.normals.resize(3 * n); ms.normals_raw.resize(3 * n); ms.colors.assign(3 * n, 0); ms.colors_f32.assign(3 * n, 0.f); ms.indices.resize(ms.n_indices);
+    ms.verts.resize(3 * n); ms.normals.resize(3 * n); ms.normals_raw.resize(3 * n); ms.colors.assign(3 * n, 0); ms.colors_f32.assign(3 * n, 0.f);
+    ms.indices.resize(ms.n_indices);
     if (n) {
-        HIPCHECK(hipMemcpyAsync(ms.verts.data(), ms.d_verts, n * 12, hipMemcpyDeviceToHost, s)); HIPCHECK(hipMemcpyAsync(ms.normals.data(), ms.d_normals, n * 12, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipMemcpyAsync(ms.verts.data(), ms.d_verts, n * 12, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipMemcpyAsync(ms.normals.data(), ms.d_normals, n * 12, hipMemcpyDeviceToHost, s));
         HIPCHECK(hipMemcpyAsync(ms.normals_raw.data(), ms.d_nraw, n * 12, hipMemcpyDeviceToHost, s));
-        if (with_colors) { HIPCHECK(hipMemcpyAsync(ms.colors.data(), ms.d_col8, n * 3, hipMemcpyDeviceToHost, s)); HIPCHECK(hipMemcpyAsync(ms.colors_f32.data(), ms.d_colf, n * 12, hipMemcpyDeviceToHost, s)); }
+        if (with_colors) { HIPCHECK(hipMemcpyAsync(ms.colors.data(), ms.d_col8, n * 3, hipMemcpyDeviceToHost, s));
+            HIPCHECK(hipMemcpyAsync(ms.colors_f32.data(), ms.d_colf, n * 12, hipMemcpyDeviceToHost, s)); }
     }
     if (ms.n_indices) HIPCHECK(hipMemcpyAsync(ms.indices.data(), ms.d_indices, (size_t)ms.n_indices * 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
@@ -118,17 +125,21 @@ int mesh_save(MeshState& ms, const char* path) {
         for (size_t i = 0; i < nv; ++i) {
             const float* p = &ms.verts[3 * i]; const float* n = &ms.normals[3 * i]; const float* c = &ms.colors_f32[3 * i];
             std::fprintf(f, "%0.5f %0.5f %0.5f %0.3f %0.3f %0.3f %d %d %d\n", p[0], p[1], p[2], n[0], n[1], n[2],
-                         (int)(unsigned char)clampf(c[0] * 255.f, 0.f, 255.f), (int)(unsigned char)clampf(c[1] * 255.f, 0.f, 255.f), (int)(unsigned char)clampf(c[2] * 255.f, 0.f, 255.f));
+                         (int)(unsigned char)clampf(c[0] * 255.f, 0.f, 255.f), (int)(unsigned char)clampf(c[1] * 255.f, 0.f, 255.f),
+                                 (int)(unsigned char)clampf(c[2] * 255.f, 0.f, 255.f));
         }
-        for (size_t i = 0; i < 3 * nf; i += 3) std::fprintf(f, "3 %d %d %d\n", (int)ms.indices[i + 2], (int)ms.indices[i + 1], (int)ms.indices[i]);   // reversed winding :609
+        // reversed winding :609
+        for (size_t i = 0; i < 3 * nf; i += 3) std::fprintf(f, "3 %d %d %d\n", (int)ms.indices[i + 2], (int)ms.indices[i + 1], (int)ms.indices[i]);
     } else {                                                                                                                                          // obj
         for (size_t i = 0; i < nv; ++i) {
             const float* p = &ms.verts[3 * i]; const float* c = &ms.colors_f32[3 * i];
-            std::fprintf(f, "v %0.5f %0.5f %0.5f %0.3f %0.3f %0.3f\n", p[0], p[1], p[2], clampf(c[0], 0.f, 1.f), clampf(c[1], 0.f, 1.f), clampf(c[2], 0.f, 1.f));
+            std::fprintf(f, "v %0.5f %0.5f %0.5f %0.3f %0.3f %0.3f\n", p[0], p[1], p[2], clampf(c[0], 0.f, 1.f), clampf(c[1], 0.f, 1.f),
+                    clampf(c[2], 0.f, 1.f));
         }
         for (size_t i = 0; i < nv; ++i) { const float* n = &ms.normals[3 * i]; std::fprintf(f, "vn %0.5f %0.5f %0.5f\n", n[0], n[1], n[2]); }
         for (size_t i = 0; i < 3 * nf; i += 3)
-            std::fprintf(f, "f %u//%u %u//%u %u//%u\n", ms.indices[i + 2] + 1, ms.indices[i + 2] + 1, ms.indices[i + 1] + 1, ms.indices[i + 1] + 1, ms.indices[i] + 1, ms.indices[i] + 1);
+            std::fprintf(f, "f %u//%u %u//%u %u//%u\n", ms.indices[i + 2] + 1, ms.indices[i + 2] + 1, ms.indices[i + 1] + 1, ms.indices[i + 1] + 1,
+                    ms.indices[i] + 1, ms.indices[i] + 1);
     }
     std::fclose(f);
     return MON_OK;
@@ -140,7 +151,8 @@ int model_generate_mesh(Model& m, int res, float thresh, uint32_t* n_verts, uint
     if (res <= 0) res = 64;                                                   // marching_cubes.h:30
     if (res < 2 || res > 512) { set_error("generate_mesh: res must be in [2, 512]"); return MON_ERR_ARG; }
     HIPCHECK(use_device(m.device));
-    if (!m.mesh) { set_error("mesh: object has no mesh state"); return MON_ERR_STATE; }       // created with the object (no lazily published pointer for readers to race on)
+    // created with the object (no lazily published pointer for readers to race on)
+    if (!m.mesh) { set_error("mesh: object has no mesh state"); return MON_ERR_STATE; }
     model_leave_lane(m);
     MeshState& ms = *m.mesh; hipStream_t s = m.train_stream;
     const size_t res3 = (size_t)res * res * res;
@@ -227,7 +239,8 @@ int model_copy_mesh(Model& m, uint32_t cap_verts, uint32_t cap_indices, float* v
     if (!ms.have_result) { set_error("copy_mesh: no mesh has been generated"); return MON_ERR_STATE; }
     const uint32_t nv = (uint32_t)(ms.verts.size() / 3), ni = (uint32_t)ms.indices.size();
     if (n_verts) *n_verts = nv; if (n_verts_real) *n_verts_real = ms.cpu_n_real; if (n_indices) *n_indices = ni;
-    if (nv > cap_verts || ni > cap_indices) { set_error("copy_mesh: buffers hold %u vertices / %u indices, the mesh has %u / %u", cap_verts, cap_indices, nv, ni); return MON_ERR_ARG; }
+    if (nv > cap_verts || ni > cap_indices) {
+        set_error("copy_mesh: buffers hold %u vertices / %u indices, the mesh has %u / %u", cap_verts, cap_indices, nv, ni); return MON_ERR_ARG; }
     if (verts) std::memcpy(verts, ms.verts.data(), ms.verts.size() * 4);
     if (normals) std::memcpy(normals, ms.normals.data(), ms.normals.size() * 4);
     if (colors) std::memcpy(colors, ms.colors.data(), ms.colors.size());
@@ -243,13 +256,15 @@ void model_mesh_free(Model& m) { mesh_state_destroy(m.mesh); m.mesh = nullptr; }
 
 // Marching cubes on a caller-supplied lattice (test / tooling entry: analytic fields, non-cubic lattices).
 int marching_cubes_host(int device, const float* density, int rx, int ry, int rz, float thresh, const float* amin, const float* amax,
-                        float* verts, float* normals_raw, uint32_t* indices, uint32_t cap_verts, uint32_t cap_indices, uint32_t* n_verts, uint32_t* n_verts_real, uint32_t* n_indices) {
+                        float* verts, float* normals_raw, uint32_t* indices, uint32_t cap_verts, uint32_t cap_indices, uint32_t* n_verts,
+                                uint32_t* n_verts_real, uint32_t* n_indices) {
     if (!density || !amin || !amax || rx < 2 || ry < 2 || rz < 2) { set_error("marching_cubes: bad argument"); return MON_ERR_ARG; }
     int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available"); return MON_ERR_NO_DEVICE; }
     HIPCHECK(use_device(device));
     MeshState* ms = mesh_state_create(device); const size_t res3 = (size_t)rx * ry * rz;
     int rc = mesh_reserve_lattice(*ms, res3);
-    if (!rc) { if (hipMemcpy(ms->d_density, density, res3 * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("marching_cubes: upload failed"); rc = MON_ERR_HIP; } }
+    if (!rc) { if (hipMemcpy(ms->d_density, density, res3 * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("marching_cubes: upload failed");
+            rc = MON_ERR_HIP; } }
     if (!rc) rc = mesh_extract(*ms, nullptr, rx, ry, rz, thresh, amin, amax);
     if (!rc) rc = mesh_to_cpu(*ms, nullptr, false);
     if (!rc) {
@@ -257,8 +272,10 @@ int marching_cubes_host(int device, const float* density, int rx, int ry, int rz
         if (verts && cap_verts >= ms->n_verts) std::memcpy(verts, ms->verts.data(), ms->verts.size() * 4);
         if (normals_raw && cap_verts >= ms->n_verts) std::memcpy(normals_raw, ms->normals_raw.data(), ms->normals_raw.size() * 4);
         if (indices && cap_indices >= ms->n_indices) std::memcpy(indices, ms->indices.data(), ms->indices.size() * 4);
-        if ((verts || normals_raw) && cap_verts < ms->n_verts) { set_error("marching_cubes: vertex buffer too small (%u < %u)", cap_verts, ms->n_verts); rc = MON_ERR_ARG; }
-        if (indices && cap_indices < ms->n_indices) { set_error("marching_cubes: index buffer too small (%u < %u)", cap_indices, ms->n_indices); rc = MON_ERR_ARG; }
+        if ((verts || normals_raw) && cap_verts < ms->n_verts) { set_error("marching_cubes: vertex buffer too small (%u < %u)", cap_verts, ms->n_verts);
+            rc = MON_ERR_ARG; }
+        if (indices && cap_indices < ms->n_indices) { set_error("marching_cubes: index buffer too small (%u < %u)", cap_indices, ms->n_indices);
+            rc = MON_ERR_ARG; }
     }
     mesh_state_destroy(ms);
     return rc;

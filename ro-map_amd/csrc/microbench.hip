@@ -13,7 +13,8 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7fe
 // mode 2: fp32 atomic add, shared table                    mode 3: half2 gather (read only)
 // mode 4: packed-f16 atomic add, shared table, 8 consecutive entries per lane (line-local bursts)
 // pattern 0: uniform over n_entries; pattern 1: hash-grid like (16 equal-traffic levels: 4096, 32768, 14 x 65536 entries)
-__global__ void __launch_bounds__(256) k_ub(int mode, int pattern, uint32_t n_entries, uint32_t ops_per_thread, uint32_t* __restrict__ table, float* __restrict__ sink) {
+__global__ void __launch_bounds__(256) k_ub(int mode, int pattern, uint32_t n_entries, uint32_t ops_per_thread, uint32_t* __restrict__ table,
+        float* __restrict__ sink) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
     typedef __attribute__((address_space(1))) half2_t gh2;
@@ -27,20 +28,26 @@ __global__ void __launch_bounds__(256) k_ub(int mode, int pattern, uint32_t n_en
 #pragma unroll 8
     for (uint32_t i = 0; i < ops_per_thread; ++i) {
         uint32_t key = gid, it = i;
-        if (mode == 7) it = i >> 1; else if (mode == 8) key = gid & ~32u; else if (mode == 20) key = gid & ~48u; else if (mode == 21) key = gid & ~1u; else if (mode == 22) key = gid & ~16u; else if (mode == 23) key = gid & ~3u;
+        if (mode == 7) it = i >> 1; else if (mode == 8) key = gid & ~32u; else if (mode == 20) key = gid & ~48u; else if (mode == 21) key = gid & ~1u;
+        else if (mode == 22) key = gid & ~16u; else if (mode == 23) key = gid & ~3u;
         uint32_t r = mix32(key * 0x9E3779B9u + it * 0x85EBCA6Bu + 12345u), idx;
         if (pattern == 0) idx = r % n_entries;
-        else { const uint32_t lvl = i & 15u; const uint32_t size = lvl == 0 ? 4096u : (lvl == 1 ? 32768u : 65536u); const uint32_t off = lvl == 0 ? 0u : (lvl == 1 ? 4096u : 36864u + (lvl - 2u) * 65536u); idx = off + (r % size); }
-        if (mode == 7) idx ^= (i & 1u); else if (mode == 8) idx ^= (gid >> 5) & 1u; else if (mode == 20) idx ^= (gid >> 4) & 3u; else if (mode == 21) idx ^= gid & 1u; else if (mode == 22) idx ^= (gid >> 4) & 1u; else if (mode == 23) idx ^= gid & 3u;
+        else { const uint32_t lvl = i & 15u; const uint32_t size = lvl == 0 ? 4096u : (lvl == 1 ? 32768u : 65536u);
+            const uint32_t off = lvl == 0 ? 0u : (lvl == 1 ? 4096u : 36864u + (lvl - 2u) * 65536u); idx = off + (r % size); }
+        if (mode == 7) idx ^= (i & 1u); else if (mode == 8) idx ^= (gid >> 5) & 1u; else if (mode == 20) idx ^= (gid >> 4) & 3u;
+        else if (mode == 21) idx ^= gid & 1u; else if (mode == 22) idx ^= (gid >> 4) & 1u; else if (mode == 23) idx ^= gid & 3u;
         const half2_t v = { (half_t)1e-3f, (half_t)-1e-3f };
         if (mode == 0) __builtin_amdgcn_global_atomic_fadd_v2f16(t16 + idx, v);
         else if (mode == 1) __builtin_amdgcn_global_atomic_fadd_v2f16(t16 + (size_t)xcc * n_entries + idx, v);
         else if (mode == 2) atomicAdd(reinterpret_cast<float*>(table) + idx, 1e-3f);
         else if (mode == 9) { acc += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, idx * 4u, 0, 0)); }
-        else if (mode == 3 || mode == 7 || mode == 8 || mode >= 20) { const half2_t g = reinterpret_cast<const half2_t*>(table)[idx]; acc += (float)g.x + (float)g.y; }
+        else if (mode == 3 || mode == 7 || mode == 8 || mode >= 20) { const half2_t g = reinterpret_cast<const half2_t*>(table)[idx];
+            acc += (float)g.x + (float)g.y; }
         else if (mode == 4) { const uint32_t b = (idx & ~7u) + ((idx + (i & 7u)) & 7u); __builtin_amdgcn_global_atomic_fadd_v2f16(t16 + b, v); }
-        else if (mode == 5) { const uint4 g = reinterpret_cast<const uint4*>(table)[idx >> 2]; acc += __uint_as_float(g.x ^ g.y ^ g.z ^ g.w); }      // 16-byte aligned quad gather
-        else { const uint2 g = reinterpret_cast<const uint2*>(table)[idx >> 1]; acc += __uint_as_float(g.x ^ g.y); }                          // mode 6: 8-byte pair gather
+        // 16-byte aligned quad gather
+        else if (mode == 5) { const uint4 g = reinterpret_cast<const uint4*>(table)[idx >> 2]; acc += __uint_as_float(g.x ^ g.y ^ g.z ^ g.w); }
+        // mode 6: 8-byte pair gather
+        else { const uint2 g = reinterpret_cast<const uint2*>(table)[idx >> 1]; acc += __uint_as_float(g.x ^ g.y); }
     }
     if (acc == 123.456f) sink[0] = acc;
 }
@@ -75,11 +82,14 @@ __global__ void __launch_bounds__(1024) k_ub_lds_read(uint32_t ops_per_thread, f
         else if constexpr (MODE == 58) { const uint2 v = *reinterpret_cast<const uint2*>(tab + (idx & ~1u)); accu += v.x ^ v.y;
                                          if (sel4) accu += *reinterpret_cast<const uint16_t*>(tb + (((idx ^ 0x5555u) * 4u) & ~1u)); }
         else if constexpr (MODE == 59) { accu += tab[idx]; if (sel2) accu += *reinterpret_cast<const uint16_t*>(tb + (((idx ^ 0x5555u) * 4u) & ~1u)); }
-        else if constexpr (MODE == 60) accu += tab[(idx & ~63u) | (threadIdx.x & 63u)];                    // conflict-free: the wave reads 64 consecutive dwords
+        // conflict-free: the wave reads 64 consecutive dwords
+        else if constexpr (MODE == 60) accu += tab[(idx & ~63u) | (threadIdx.x & 63u)];
         else if constexpr (MODE == 61) accu += tab[__builtin_amdgcn_readfirstlane(idx)];                   // broadcast: every lane the same address
-        else if constexpr (MODE == 62) accu += tab[(idx & ~63u) | ((idx >> 6) & 63u)];                     // random within a 256-byte window (conflicts, one row)
+        // random within a 256-byte window (conflicts, one row)
+        else if constexpr (MODE == 62) accu += tab[(idx & ~63u) | ((idx >> 6) & 63u)];
         else if constexpr (MODE == 63) accu += tab[(idx & ~1u) | (threadIdx.x & 1u)];                      // random, lane pairs read adjacent dwords
-        else accu += tab[sel8 ? idx : ((idx & ~63u) | (threadIdx.x & 63u))];                               // 64: 1/8 random lanes, the rest conflict-free (no exec masking)
+        // 64: 1/8 random lanes, the rest conflict-free (no exec masking)
+        else accu += tab[sel8 ? idx : ((idx & ~63u) | (threadIdx.x & 63u))];
     }
     if (accu == 0x12345678u) sink[0] = 1.f;
 }
@@ -94,7 +104,8 @@ __global__ void __launch_bounds__(1024) k_ub_lds(int mode, uint32_t ops_per_thre
     typedef __attribute__((address_space(3))) half2_t lh2;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (mode >= 40 && mode <= 49) {            // minimal-ALU atomics with SHARED addresses: groups of 2^share adjacent lanes follow the same index sequence
-        // 40..43: ds_add_u64 over the 128 KB tile, share = mode - 40 (1, 2, 4, 8 lanes per address);  44..47: ds_add_u32 likewise;  48 / 49: ds_add_u64 / u32 over a 32 KB range, no sharing
+        // 40..43: ds_add_u64 over the 128 KB tile, share = mode - 40 (1, 2, 4, 8 lanes per address);  44..47: ds_add_u32 likewise;  48 / 49: ds_add_u64 / u32
+        // over a 32 KB range, no sharing
         const uint32_t share = (mode <= 47) ? (uint32_t)(mode - 40) & 3u : 0u, range = mode >= 48 ? 4095u : 16383u;
         const bool wide = mode <= 43 || mode == 48;
         uint32_t idx = mix32((gid >> share) * 0x9E3779B9u + 777u) & 32767u;
@@ -108,7 +119,8 @@ __global__ void __launch_bounds__(1024) k_ub_lds(int mode, uint32_t ops_per_thre
         if (tab[threadIdx.x] == 0x12345678u) sink[0] = 1.f;
         return;
     }
-    if (mode >= 17 && mode <= 19) {            // minimal-ALU probes: 17 ds_read_b32 random, 18 ds_add_u32 random, 19 ds_read_b64 random (LCG index, 2 VALU per op)
+    // minimal-ALU probes: 17 ds_read_b32 random, 18 ds_add_u32 random, 19 ds_read_b64 random (LCG index, 2 VALU per op)
+    if (mode >= 17 && mode <= 19) {
         uint32_t idx = mix32(gid * 0x9E3779B9u + 777u) & 32767u, accu = 0u;
 #pragma unroll 16
         for (uint32_t i = 0; i < ops_per_thread; ++i) {
@@ -143,10 +155,12 @@ __global__ void __launch_bounds__(256) k_ub_copy(const ub_u4* __restrict__ src, 
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) __builtin_nontemporal_store(src[i], dst + i);
 }
 
-// modes 31 / 32: the optimizer's memory streams without its arithmetic -- n_ops parameters: fp32 master / m1 / m2 read + written, 16-bit step counters and EMA read + written,
+// modes 31 / 32: the optimizer's memory streams without its arithmetic -- n_ops parameters: fp32 master / m1 / m2 read + written, 16-bit step counters and EMA
+// read + written,
 // fp16 copy and tile image written, `parts` fp16 partial-table planes read (flags bits 8..11).  flags bit 0: plain instead of non-temporal stores.
 //   31: the shipped kernel's shape -- a thread owns 8 consecutive parameters (two 16-byte pieces of every fp32 array, lane stride 32 B), `units` such chunks
-//       requested up front;   32: a thread owns 4 consecutive parameters per unit (one 16-byte piece: a wave instruction covers 1 KB without holes), units a wave apart
+// requested up front;   32: a thread owns 4 consecutive parameters per unit (one 16-byte piece: a wave instruction covers 1 KB without holes), units a wave
+// apart
 struct StreamPtrs { float *master, *m1, *m2; uint16_t *steps, *ema, *half, *tiles; const uint16_t* parts; uint32_t n, n_parts, flags; };
 typedef float ub_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t ub_u2 __attribute__((ext_vector_type(2)));
@@ -178,7 +192,8 @@ __global__ void __launch_bounds__(256) k_ub_stream8(StreamPtrs a) {
             ub_store(m1[u][0] + d, reinterpret_cast<ub_f4*>(a.m1 + i0), plain); ub_store(m1[u][1] + d, reinterpret_cast<ub_f4*>(a.m1 + i0 + 4), plain);
             ub_store(m2[u][0] + d, reinterpret_cast<ub_f4*>(a.m2 + i0), plain); ub_store(m2[u][1] + d, reinterpret_cast<ub_f4*>(a.m2 + i0 + 4), plain);
             ub_store(st[u] + 1u, reinterpret_cast<ub_u4*>(a.steps + i0), plain);
-            *reinterpret_cast<ub_u4*>(a.ema + i0) = e[u] + 1u; *reinterpret_cast<ub_u4*>(a.half + i0) = e[u] + st[u]; *reinterpret_cast<ub_u4*>(a.tiles + i0) = e[u] ^ st[u];
+            *reinterpret_cast<ub_u4*>(a.ema + i0) = e[u] + 1u; *reinterpret_cast<ub_u4*>(a.half + i0) = e[u] + st[u];
+            *reinterpret_cast<ub_u4*>(a.tiles + i0) = e[u] ^ st[u];
         }
     }
 }
@@ -191,32 +206,43 @@ __global__ void __launch_bounds__(256) k_ub_stream4(StreamPtrs a) {
 #pragma unroll
         for (int u = 0; u < UNITS; ++u) {
             const uint32_t c = min(c0 + u * stride, n_quads - 1u), i0 = c << 2;
-            w[u] = *reinterpret_cast<const ub_f4*>(a.master + i0); m1[u] = *reinterpret_cast<const ub_f4*>(a.m1 + i0); m2[u] = *reinterpret_cast<const ub_f4*>(a.m2 + i0);
+            w[u] = *reinterpret_cast<const ub_f4*>(a.master + i0); m1[u] = *reinterpret_cast<const ub_f4*>(a.m1 + i0);
+            m2[u] = *reinterpret_cast<const ub_f4*>(a.m2 + i0);
             st[u] = *reinterpret_cast<const ub_u2*>(a.steps + i0); e[u] = *reinterpret_cast<const ub_u2*>(a.ema + i0);
             g[u] = 0.f;
-            for (uint32_t q = 0; q < a.n_parts; ++q) { const ub_u2 v = *reinterpret_cast<const ub_u2*>(a.parts + (size_t)q * a.n + i0); g[u] += (float)(v[0] ^ v[1]); }       // (a parameter-order partial layout: 8 bytes per quad and partition)
+            // (a parameter-order partial layout: 8 bytes per quad and partition)
+            for (uint32_t q = 0; q < a.n_parts; ++q) { const ub_u2 v = *reinterpret_cast<const ub_u2*>(a.parts + (size_t)q * a.n + i0);
+                g[u] += (float)(v[0] ^ v[1]); }
         }
 #pragma unroll
         for (int u = 0; u < UNITS; ++u) {
             const uint32_t c = c0 + u * stride, i0 = c << 2;
             if (c >= n_quads) break;
             const float d = g[u] * 1e-30f + 1.f;
-            ub_store(w[u] + d, reinterpret_cast<ub_f4*>(a.master + i0), plain); ub_store(m1[u] + d, reinterpret_cast<ub_f4*>(a.m1 + i0), plain); ub_store(m2[u] + d, reinterpret_cast<ub_f4*>(a.m2 + i0), plain);
+            ub_store(w[u] + d, reinterpret_cast<ub_f4*>(a.master + i0), plain); ub_store(m1[u] + d, reinterpret_cast<ub_f4*>(a.m1 + i0), plain);
+            ub_store(m2[u] + d, reinterpret_cast<ub_f4*>(a.m2 + i0), plain);
             ub_store(st[u] + 1u, reinterpret_cast<ub_u2*>(a.steps + i0), plain);
-            *reinterpret_cast<ub_u2*>(a.ema + i0) = e[u] + 1u; *reinterpret_cast<ub_u2*>(a.half + i0) = e[u] + st[u]; *reinterpret_cast<ub_u2*>(a.tiles + i0) = e[u] ^ st[u];
+            *reinterpret_cast<ub_u2*>(a.ema + i0) = e[u] + 1u; *reinterpret_cast<ub_u2*>(a.half + i0) = e[u] + st[u];
+            *reinterpret_cast<ub_u2*>(a.tiles + i0) = e[u] ^ st[u];
         }
     }
 }
 static void launch_stream(int mode, int blocks, int units, const StreamPtrs& a) {
-#define MON_UB_STREAM(K) do { if (units == 1) hipLaunchKernelGGL(K<1>, dim3(blocks), dim3(256), 0, 0, a); else if (units == 2) hipLaunchKernelGGL(K<2>, dim3(blocks), dim3(256), 0, 0, a); \
-                              else if (units == 4) hipLaunchKernelGGL(K<4>, dim3(blocks), dim3(256), 0, 0, a); else hipLaunchKernelGGL(K<8>, dim3(blocks), dim3(256), 0, 0, a); } while (0)
+#define MON_UB_STREAM(K) do { \
+        if (units == 1) hipLaunchKernelGGL(K<1>, dim3(blocks), dim3(256), 0, 0, a); \
+        else if (units == 2) hipLaunchKernelGGL(K<2>, dim3(blocks), dim3(256), 0, 0, a); \
+        else if (units == 4) hipLaunchKernelGGL(K<4>, dim3(blocks), dim3(256), 0, 0, a); \
+        else hipLaunchKernelGGL(K<8>, dim3(blocks), dim3(256), 0, 0, a); } while (0)
     if (mode == 31) MON_UB_STREAM(k_ub_stream8); else MON_UB_STREAM(k_ub_stream4);
 #undef MON_UB_STREAM
 }
 
-// modes 70 / 71: what a persistent single-object step would trade: mode 70 = ONE resident grid of 256 workgroups x 1024 threads holding the CU's
-// whole LDS (the shape of k_encode_tiles / k_grid_scatter) that crosses n_ops grid barriers (one returning atomic per workgroup on a counter + a spin on its generation,
-// every workgroup touching 4 KB of memory between two barriers so that the barrier also carries the release / acquire a real phase change needs); mode 71 = n_ops
+// modes 70 / 71: what a persistent single-object step would trade: mode 70 = ONE resident grid of 256 workgroups x 1024 threads holding
+// the CU's
+// whole LDS (the shape of k_encode_tiles / k_grid_scatter) that crosses n_ops grid barriers (one returning atomic per workgroup on a counter + a spin on its
+// generation,
+// every workgroup touching 4 KB of memory between two barriers so that the barrier also carries the release / acquire a real phase change needs); mode 71 =
+// n_ops
 // back-to-back launches of the same grid doing the same 4 KB per workgroup.  `pattern` > 0: that many workgroups instead of 256.
 __global__ void __launch_bounds__(1024) k_ub_grid_barrier(uint32_t n_barriers, uint32_t* __restrict__ ctr, uint32_t* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -244,12 +270,16 @@ __global__ void __launch_bounds__(1024) k_ub_phase(uint32_t b, uint32_t* __restr
 
 int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms_out) {
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || use_device(device) != hipSuccess) { set_error("microbench: no HIP device"); return MON_ERR_NO_DEVICE; }
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || use_device(device) != hipSuccess) { set_error("microbench: no HIP device");
+        return MON_ERR_NO_DEVICE; }
     uint32_t* table = nullptr; float* sink = nullptr;
-    const bool stream = mode == 31 || mode == 32;                 // n_ops parameters; n_entries = flags: bit 0 plain stores, bits 4..7 units per thread, bits 8..11 partial tables
+    // n_ops parameters; n_entries = flags: bit 0 plain stores, bits 4..7 units per thread, bits 8..11 partial tables
+    const bool stream = mode == 31 || mode == 32;
     const size_t np = ((size_t)n_ops + 1023) & ~(size_t)1023;
-    const size_t bytes = stream ? np * (12 + 8 + 2 * 8) + 4096 : mode == 30 ? 2 * (size_t)n_ops : (mode == 70 || mode == 71) ? (size_t)16 << 20 : (size_t)n_entries * 4 * 8;
-    if (hipMalloc((void**)&table, bytes) != hipSuccess || hipMalloc((void**)&sink, 64) != hipSuccess) { set_error("microbench: hipMalloc failed"); return MON_ERR_HIP; }
+    const size_t bytes = stream ? np * (12 + 8 + 2 * 8) + 4096 : mode == 30 ? 2 * (size_t)n_ops : (mode == 70 || mode == 71) ? (size_t)16 << 20
+            : (size_t)n_entries * 4 * 8;
+    if (hipMalloc((void**)&table, bytes) != hipSuccess || hipMalloc((void**)&sink, 64) != hipSuccess) { set_error("microbench: hipMalloc failed");
+        return MON_ERR_HIP; }
     hipMemset(table, 0, bytes);
     const uint32_t ops_per_thread = 64, threads = n_ops / ops_per_thread, blocks = (threads + 255) / 256;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -260,8 +290,10 @@ int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n
         hipEventRecord(e0, 0);
         if (stream) {
             unsigned char* b = reinterpret_cast<unsigned char*>(table);
-            StreamPtrs a{ reinterpret_cast<float*>(b), reinterpret_cast<float*>(b + 4 * np), reinterpret_cast<float*>(b + 8 * np), reinterpret_cast<uint16_t*>(b + 12 * np), reinterpret_cast<uint16_t*>(b + 14 * np),
-                          reinterpret_cast<uint16_t*>(b + 16 * np), reinterpret_cast<uint16_t*>(b + 18 * np), reinterpret_cast<const uint16_t*>(b + 20 * np), (uint32_t)np, (n_entries >> 8) & 15u, n_entries & 1u };
+            StreamPtrs a{ reinterpret_cast<float*>(b), reinterpret_cast<float*>(b + 4 * np), reinterpret_cast<float*>(b + 8 * np),
+                    reinterpret_cast<uint16_t*>(b + 12 * np), reinterpret_cast<uint16_t*>(b + 14 * np),
+                          reinterpret_cast<uint16_t*>(b + 16 * np), reinterpret_cast<uint16_t*>(b + 18 * np), reinterpret_cast<const uint16_t*>(b + 20 * np),
+                                  (uint32_t)np, (n_entries >> 8) & 15u, n_entries & 1u };
             launch_stream(mode, pattern > 0 ? pattern : 512, (int)((n_entries >> 4) & 15u), a);
         }
         else if (mode == 70 || mode == 71) {
@@ -272,11 +304,15 @@ int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n
             if (mode == 70) hipLaunchKernelGGL(k_ub_grid_barrier, dim3(wgs), dim3(1024), 163840, 0, n_ops, table, table + 256);
             else for (uint32_t b = 0; b < n_ops; ++b) hipLaunchKernelGGL(k_ub_phase, dim3(wgs), dim3(1024), 163840, 0, b, table + 256);
         }
-        else if (mode == 30) hipLaunchKernelGGL(k_ub_copy, dim3(pattern > 0 ? pattern : 512), dim3(256), 0, 0, reinterpret_cast<const ub_u4*>(table), reinterpret_cast<ub_u4*>(table) + n_ops / 16u, n_ops / 16u);
+        else if (mode == 30) hipLaunchKernelGGL(k_ub_copy, dim3(pattern > 0 ? pattern : 512), dim3(256), 0, 0, reinterpret_cast<const ub_u4*>(table),
+                reinterpret_cast<ub_u4*>(table) + n_ops / 16u, n_ops / 16u);
         else if (mode >= 50 && mode < 70) {
 #define MON_UB_READ(M) case M: hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ub_lds_read<M>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
                                hipLaunchKernelGGL(k_ub_lds_read<M>, dim3(256), dim3(1024), 131072, 0, n_ops / (256u * 1024u), sink); break;
-            switch (mode) { MON_UB_READ(50) MON_UB_READ(51) MON_UB_READ(52) MON_UB_READ(53) MON_UB_READ(54) MON_UB_READ(55) MON_UB_READ(56) MON_UB_READ(57) MON_UB_READ(58) MON_UB_READ(59) MON_UB_READ(60) MON_UB_READ(61) MON_UB_READ(62) MON_UB_READ(63) MON_UB_READ(64) }
+            switch (mode) {
+                MON_UB_READ(50) MON_UB_READ(51) MON_UB_READ(52) MON_UB_READ(53) MON_UB_READ(54) MON_UB_READ(55) MON_UB_READ(56) MON_UB_READ(57)
+                MON_UB_READ(58) MON_UB_READ(59) MON_UB_READ(60) MON_UB_READ(61) MON_UB_READ(62) MON_UB_READ(63) MON_UB_READ(64)
+            }
 #undef MON_UB_READ
         }
         else if (lds_mode) hipLaunchKernelGGL(k_ub_lds, dim3(256), dim3(1024), 131072, 0, mode, n_ops / (256u * 1024u), sink);

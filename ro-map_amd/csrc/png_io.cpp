@@ -14,7 +14,8 @@ namespace mon {
 
 static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 static void put32(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
-static int paeth(int a, int b, int c) { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+static int paeth(int a, int b, int c) { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
 
 // Un-filters `rows` scanlines of `stride` bytes each (filter byte in front of every line) from `in` into `out`.
 static bool unfilter(const uint8_t* in, uint8_t* out, size_t stride, size_t rows, size_t bpp) {
@@ -60,9 +61,11 @@ bool png_read(const std::string& path, PngImage& img, std::string& err) {
         else if (!std::memcmp(type, "IEND", 4)) break;
         pos += 12 + len;
     }
-    const bool depth_ok = (color == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) || (color == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
+    const bool depth_ok = (color == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16))
+            || (color == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
                           ((color == 2 || color == 4 || color == 6) && (depth == 8 || depth == 16));
-    if (!have_ihdr || img.width <= 0 || img.height <= 0 || img.width > 32768 || img.height > 32768 || (uint64_t)img.width * (uint64_t)img.height > (1ull << 26) || idat.empty() || interlace > 1 || !depth_ok ||
+    if (!have_ihdr || img.width <= 0 || img.height <= 0 || img.width > 32768 || img.height > 32768 || (uint64_t)img.width * (uint64_t)img.height > (1ull << 26)
+            || idat.empty() || interlace > 1 || !depth_ok ||
         (color == 3 && (plte.empty() || plte.size() % 3 != 0))) {
         err = "unsupported PNG format: " + path; return false;
     }
@@ -74,13 +77,15 @@ bool png_read(const std::string& path, PngImage& img, std::string& err) {
     const int n_pass = interlace ? 7 : 1;
     size_t pw[7], ph[7], total = 0;
     for (int p = 0; p < n_pass; ++p) {
-        pw[p] = interlace ? ((size_t)img.width + adx[p] - 1 - ax0[p]) / adx[p] : (size_t)img.width; ph[p] = interlace ? ((size_t)img.height + ady[p] - 1 - ay0[p]) / ady[p] : (size_t)img.height;
+        pw[p] = interlace ? ((size_t)img.width + adx[p] - 1 - ax0[p]) / adx[p] : (size_t)img.width;
+        ph[p] = interlace ? ((size_t)img.height + ady[p] - 1 - ay0[p]) / ady[p] : (size_t)img.height;
         if (interlace && (img.width <= ax0[p] || img.height <= ay0[p])) pw[p] = ph[p] = 0;
         if (pw[p] && ph[p]) total += (line_bytes(pw[p]) + 1) * ph[p];
     }
     std::vector<uint8_t> raw(total);
     uLongf out_len = (uLongf)raw.size();
-    if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) { err = "PNG inflate failed: " + path; return false; }
+    if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) { err = "PNG inflate failed: " + path;
+        return false; }
     // samples of the file, un-interlaced, one sample per output slot: 8-bit (sub-byte depths unpacked, not yet scaled) or 16-bit big-endian
     const size_t sample_bytes = depth == 16 ? 2 : 1, px_bytes = (size_t)file_ch * sample_bytes;
     std::vector<uint8_t> samples((size_t)img.width * img.height * px_bytes);
@@ -133,7 +138,8 @@ bool png_write(const std::string& path, int width, int height, int channels, int
     if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) { err = "png_write: deflate failed"; return false; }
     comp.resize(clen);
     std::vector<uint8_t> out = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a }, ihdr;
-    put32(ihdr, (uint32_t)width); put32(ihdr, (uint32_t)height); ihdr.push_back((uint8_t)bit_depth); ihdr.push_back(channels == 1 ? 0 : 2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    put32(ihdr, (uint32_t)width); put32(ihdr, (uint32_t)height); ihdr.push_back((uint8_t)bit_depth); ihdr.push_back(channels == 1 ? 0 : 2); ihdr.push_back(0);
+    ihdr.push_back(0); ihdr.push_back(0);
     chunk(out, "IHDR", ihdr); chunk(out, "IDAT", comp); chunk(out, "IEND", {});
     FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) { err = "png_write: cannot open " + path; return false; }

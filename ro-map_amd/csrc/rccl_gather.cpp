@@ -92,7 +92,8 @@ int mon_gather_renders(mon_gather* g, mon_object* const* objects, const mon_fram
     // ---- where every object lives, and the messages that follow from it
     std::vector<int> dev_of(n); std::vector<uint32_t> npix(n);
     for (int i = 0; i < n; ++i) {
-        mon_object_info info; if (mon_object_info_get(objects[i], &info) != MON_OK) return fail(MON_ERR_ARG, "gather_renders: object %d: %s", i, mon_last_error());
+        mon_object_info info;
+        if (mon_object_info_get(objects[i], &info) != MON_OK) return fail(MON_ERR_ARG, "gather_renders: object %d: %s", i, mon_last_error());
         if (mon_physical_device(info.device, &dev_of[i]) != MON_OK) return fail(MON_ERR_ARG, "gather_renders: object %d: %s", i, mon_last_error());
         npix[i] = boxes[i].w * boxes[i].h;
         if (!npix[i] || !rgb[i] || !depth[i] || !mask[i]) return fail(MON_ERR_ARG, "gather_renders: object %d: empty box or null output", i);
@@ -105,9 +106,11 @@ int mon_gather_renders(mon_gather* g, mon_object* const* objects, const mon_fram
     }
     std::vector<uint64_t> recv_off(g->n_dev, 0); uint64_t recv_len = 0; g->senders = 0;
     for (int d = 0; d < g->n_dev; ++d) if (d != g->root && len[d]) { recv_off[d] = recv_len; recv_len += len[d]; ++g->senders; }
-    if (recv_len > g->recv_cap) { HIP_OK(hipSetDevice(g->root)); if (g->recv) HIP_OK(hipFree(g->recv)); g->recv = nullptr; g->recv_cap = 0; HIP_OK(hipMalloc((void**)&g->recv, recv_len * 4)); g->recv_cap = recv_len; }
+    if (recv_len > g->recv_cap) { HIP_OK(hipSetDevice(g->root)); if (g->recv) HIP_OK(hipFree(g->recv)); g->recv = nullptr; g->recv_cap = 0;
+        HIP_OK(hipMalloc((void**)&g->recv, recv_len * 4)); g->recv_cap = recv_len; }
     uint64_t total = 0; for (int d = 0; d < g->n_dev; ++d) total += len[d];
-    if (total > g->h_cap) { HIP_OK(hipSetDevice(g->root)); if (g->h_stage) HIP_OK(hipHostFree(g->h_stage)); g->h_stage = nullptr; g->h_cap = 0; HIP_OK(hipHostMalloc((void**)&g->h_stage, total * 4, hipHostMallocDefault)); g->h_cap = total; }
+    if (total > g->h_cap) { HIP_OK(hipSetDevice(g->root)); if (g->h_stage) HIP_OK(hipHostFree(g->h_stage)); g->h_stage = nullptr; g->h_cap = 0;
+        HIP_OK(hipHostMalloc((void**)&g->h_stage, total * 4, hipHostMallocDefault)); g->h_cap = total; }
     // ---- render: every device's objects one after the other into the device's message (device-resident: dst_on_device = 1), the devices side by side
     std::vector<int> rcs(g->n_dev, MON_OK); std::vector<std::string> errs(g->n_dev); std::vector<std::thread> th;
     for (int d = 0; d < g->n_dev; ++d) {
@@ -116,7 +119,8 @@ int mon_gather_renders(mon_gather* g, mon_object* const* objects, const mon_fram
             for (int i = 0; i < n; ++i) {
                 if (dev_of[i] != d) continue;
                 float* base = g->dev[d].msg + off[i];
-                const int rc = mon_object_render(objects[i], boxes[i], poses16 + 16 * (size_t)i, pose_is_Toc, base, base + 3 * (size_t)npix[i], base + 4 * (size_t)npix[i], 1);
+                const int rc = mon_object_render(objects[i], boxes[i], poses16 + 16 * (size_t)i, pose_is_Toc, base, base + 3 * (size_t)npix[i],
+                        base + 4 * (size_t)npix[i], 1);
                 if (rc != MON_OK) { rcs[d] = rc; errs[d] = mon_last_error(); return; }
             }
         });
@@ -159,13 +163,16 @@ int mon_offline_render_test_gathered(mon_gather* g, mon_offline* mgr, const char
     if (!g || !mgr || !out_dir) return fail(MON_ERR_ARG, "render_test_gathered: null argument");
     int n_obj = 0; if (mon_offline_n_objects(mgr, &n_obj) != MON_OK) return fail(MON_ERR_ARG, "%s", mon_last_error());
     size_t n_frames = 0; mon_offline_get_poses(mgr, nullptr, 0, &n_frames);
-    std::vector<float> poses(16 * n_frames); if (n_frames && mon_offline_get_poses(mgr, poses.data(), n_frames, &n_frames) != MON_OK) return fail(MON_ERR_STATE, "%s", mon_last_error());
+    std::vector<float> poses(16 * n_frames);
+    if (n_frames && mon_offline_get_poses(mgr, poses.data(), n_frames, &n_frames) != MON_OK) return fail(MON_ERR_STATE, "%s", mon_last_error());
     std::vector<mon_object*> objs(n_obj); std::vector<std::vector<mon_frame_bbox>> boxes(n_obj); std::vector<int> ids(n_obj); size_t views = 0;
     ::mkdir(out_dir, 0755);
     for (int k = 0; k < n_obj; ++k) {
         if (mon_offline_object(mgr, k, &objs[k]) != MON_OK) return fail(MON_ERR_ARG, "%s", mon_last_error());
         size_t nb = 0; mon_offline_object_meta(mgr, k, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &nb);
-        boxes[k].resize(nb); if (nb && mon_offline_object_meta(mgr, k, nullptr, nullptr, nullptr, nullptr, boxes[k].data(), nb, &nb) != MON_OK) return fail(MON_ERR_STATE, "%s", mon_last_error());
+        boxes[k].resize(nb);
+        if (nb && mon_offline_object_meta(mgr, k, nullptr, nullptr, nullptr, nullptr, boxes[k].data(), nb, &nb) != MON_OK) return fail(MON_ERR_STATE, "%s",
+                mon_last_error());
         if (max_views > 0 && boxes[k].size() > (size_t)max_views) boxes[k].resize((size_t)max_views);
         views = std::max(views, boxes[k].size());
         ids[k] = k;                                                           // (object ids of OfflineNeRF are the creation order, nerf.cu:22-25)
@@ -175,16 +182,20 @@ int mon_offline_render_test_gathered(mon_gather* g, mon_offline* mgr, const char
     for (size_t v = 0; v < views; ++v) {                                      // view v of every object that has one: one gather
         std::vector<mon_object*> o; std::vector<mon_frame_bbox> b; std::vector<float> p; std::vector<int> who;
         for (int k = 0; k < n_obj; ++k) if (v < boxes[k].size()) {
-            const mon_frame_bbox bb = boxes[k][v]; if (bb.FrameId >= n_frames) return fail(MON_ERR_STATE, "render_test_gathered: frame %u of %zu", bb.FrameId, n_frames);
-            o.push_back(objs[k]); b.push_back(bb); who.push_back(k); p.insert(p.end(), poses.begin() + 16 * (size_t)bb.FrameId, poses.begin() + 16 * (size_t)bb.FrameId + 16);
+            const mon_frame_bbox bb = boxes[k][v];
+            if (bb.FrameId >= n_frames) return fail(MON_ERR_STATE, "render_test_gathered: frame %u of %zu", bb.FrameId, n_frames);
+            o.push_back(objs[k]); b.push_back(bb); who.push_back(k);
+            p.insert(p.end(), poses.begin() + 16 * (size_t)bb.FrameId, poses.begin() + 16 * (size_t)bb.FrameId + 16);
         }
         std::vector<std::vector<float>> rgb(o.size()), depth(o.size()), mask(o.size()); std::vector<float*> pr, pd, pm;
-        for (size_t i = 0; i < o.size(); ++i) { const size_t px = (size_t)b[i].w * b[i].h; rgb[i].resize(3 * px); depth[i].resize(px); mask[i].resize(px); pr.push_back(rgb[i].data()); pd.push_back(depth[i].data()); pm.push_back(mask[i].data()); }
+        for (size_t i = 0; i < o.size(); ++i) { const size_t px = (size_t)b[i].w * b[i].h; rgb[i].resize(3 * px); depth[i].resize(px); mask[i].resize(px);
+            pr.push_back(rgb[i].data()); pd.push_back(depth[i].data()); pm.push_back(mask[i].data()); }
         const int rc = mon_gather_renders(g, o.data(), b.data(), p.data(), 0, (int)o.size(), pr.data(), pd.data(), pm.data()); if (rc) return rc;
         for (size_t i = 0; i < o.size(); ++i) {
             char stamp[128]; if (mon_offline_object_stamp(mgr, who[i], v, stamp, sizeof stamp) != MON_OK) return fail(MON_ERR_STATE, "%s", mon_last_error());
             const std::string root = std::string(out_dir) + "/" + std::to_string(ids[who[i]]);
-            const int wrc = mon_write_render_pngs((root + "/test_img/" + stamp + ".png").c_str(), (root + "/test_depth/" + stamp + ".png").c_str(), (root + "/test_mask/" + stamp + ".png").c_str(),
+            const int wrc = mon_write_render_pngs((root + "/test_img/" + stamp + ".png").c_str(), (root + "/test_depth/" + stamp + ".png").c_str(),
+                    (root + "/test_mask/" + stamp + ".png").c_str(),
                                                   b[i].w, b[i].h, rgb[i].data(), depth[i].data(), mask[i].data());
             if (wrc != MON_OK) return fail(wrc, "%s", mon_last_error());
         }

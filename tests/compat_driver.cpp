@@ -47,13 +47,15 @@ static int run_offline(const std::string& seq, const std::string& cfg, const std
     std::vector<Eigen::Matrix4f> twc = mgr.GetAllTwc(); float fx, fy, cx, cy; mgr.GetIntrinsics(fx, fy, cx, cy);     // :334-335
     std::vector<std::shared_ptr<nerf::NeRF>> objs = mgr.GetAllNeRF();   // :336
     std::printf("n_twc=%zu fx=%.3f twc0_tx=%.6f n_objects=%zu\n", twc.size(), fx, twc[0](0, 3), objs.size());
-    for (int spin = 0; spin < 50; ++spin) { for (auto& o : objs) o->DrawCPUMesh(); ::usleep(20000); }                 // viewer loop while the threads train (:217)
+    // viewer loop while the threads train (:217)
+    for (int spin = 0; spin < 50; ++spin) { for (auto& o : objs) o->DrawCPUMesh(); ::usleep(20000); }
     const int draws_during = g_draws;
     if (!mgr.WaitThreadsEnd()) return 4;                                // :340
     for (auto& o : objs) {
         g_last_count = 0; o->DrawCPUMesh();
         const Eigen::Matrix4f Tow = o->GetObjTow(); const nerf::BoundingBox bb = o->GetBoundingBox();
-        std::printf("object=%d class=%d n_boxes=%zu tow_tx=%.6f bbox_max_x=%.6f mesh_indices=%d verts=%zu\n", o->mId, o->mClass, o->GetFrameIdAndBBox().size(), Tow(0, 3), bb.max(0),
+        std::printf("object=%d class=%d n_boxes=%zu tow_tx=%.6f bbox_max_x=%.6f mesh_indices=%d verts=%zu\n", o->mId, o->mClass, o->GetFrameIdAndBBox().size(),
+                Tow(0, 3), bb.max(0),
                     g_last_count, o->GetCPUMeshData().verts.size() / 3);
     }
     std::printf("draws_during_training=%d gl_state_balance=%d\n", draws_during, g_states);
@@ -65,36 +67,51 @@ static cv::Mat read_png(const std::string& path, int want_type) {
     if (mon_png_read(path.c_str(), &w, &h, &ch, &bits, nullptr, 0)) { std::cerr << mon_last_error() << std::endl; exit(5); }
     std::vector<uint8_t> px((size_t)w * h * ch * (bits / 8)); mon_png_read(path.c_str(), &w, &h, &ch, &bits, px.data(), px.size());
     cv::Mat m(h, w, want_type);
-    if (want_type == CV_8UC3) for (size_t p = 0; p < (size_t)w * h; ++p) { m.data[3 * p] = px[p * ch + 2]; m.data[3 * p + 1] = px[p * ch + 1]; m.data[3 * p + 2] = px[p * ch]; }   // cv::imread hands BGR
+    // cv::imread hands BGR
+    if (want_type == CV_8UC3) for (size_t p = 0; p < (size_t)w * h; ++p) { m.data[3 * p] = px[p * ch + 2]; m.data[3 * p + 1] = px[p * ch + 1];
+        m.data[3 * p + 2] = px[p * ch]; }
     else if (want_type == CV_8UC1) for (size_t p = 0; p < (size_t)w * h; ++p) m.data[p] = px[p * ch];
-    else for (size_t p = 0; p < (size_t)w * h; ++p) m.ptr<float>()[p] = (float)((px[2 * p * ch] << 8) | px[2 * p * ch + 1]) / 5000.0f;                                  // depth PNG -> metres
+    // depth PNG -> metres
+    else for (size_t p = 0; p < (size_t)w * h; ++p) m.ptr<float>()[p] = (float)((px[2 * p * ch] << 8) | px[2 * p * ch + 1]) / 5000.0f;
     return m;
 }
 
 static int run_online(const std::string& seq, const std::string& cfg, const std::string& out) {
     std::ifstream fc(seq + "/config.yaml"); std::stringstream ss; ss << fc.rdbuf(); const std::string y = ss.str();
-    auto num = [&](const char* key) { const std::string k = std::string("\n") + key + ":"; const size_t p = y.find(k); return p == std::string::npos ? 0.0 : std::strtod(y.c_str() + p + k.size(), nullptr); };   // exact key at line start
+    // exact key at line start
+    auto num = [&](const char* key) { const std::string k = std::string("\n") + key + ":"; const size_t p = y.find(k);
+        return p == std::string::npos ? 0.0 : std::strtod(y.c_str() + p + k.size(), nullptr); };
     std::vector<std::string> stamps, names; std::vector<Eigen::Matrix4f> twc; std::string line;
-    { std::ifstream fi(seq + "/img.txt"); std::getline(fi, line); while (std::getline(fi, line)) { std::stringstream s(line); std::string a, b; s >> a >> b; if (!a.empty()) { stamps.push_back(a); names.push_back(b); } } }
-    { std::ifstream fg(seq + "/groundtruth.txt"); std::getline(fg, line); while (std::getline(fg, line)) { std::stringstream s(line); std::string a; float t[3], q[4]; s >> a >> t[0] >> t[1] >> t[2] >> q[0] >> q[1] >> q[2] >> q[3]; if (!a.empty()) twc.push_back(pose_from_tq(t, q[0], q[1], q[2], q[3])); } }
+    { std::ifstream fi(seq + "/img.txt"); std::getline(fi, line); while (std::getline(fi, line)) {
+        std::stringstream s(line); std::string a, b; s >> a >> b; if (!a.empty()) { stamps.push_back(a); names.push_back(b); } } }
+    { std::ifstream fg(seq + "/groundtruth.txt"); std::getline(fg, line); while (std::getline(fg, line)) {
+        std::stringstream s(line); std::string a; float t[3], q[4]; s >> a >> t[0] >> t[1] >> t[2] >> q[0] >> q[1] >> q[2] >> q[3];
+        if (!a.empty()) twc.push_back(pose_from_tq(t, q[0], q[1], q[2], q[3])); } }
     // the object the "SLAM frontend" has detected: class, Two, half extents, one 2-D box per frame (obj_offline/0.txt)
     int cls = 0; float v[10]; std::vector<nerf::FrameIdAndBbox> boxes; std::vector<std::string> box_stamps;
-    { std::ifstream fo(seq + "/obj_offline/0.txt"); std::getline(fo, line); std::getline(fo, line); std::stringstream s(line); s >> cls; for (float& x : v) s >> x;
-      while (std::getline(fo, line)) { std::stringstream s2(line); std::string st; nerf::FrameIdAndBbox b{}; s2 >> st >> b.x >> b.y >> b.h >> b.w; if (!st.empty()) { boxes.push_back(b); box_stamps.push_back(st); } } }
+    { std::ifstream fo(seq + "/obj_offline/0.txt"); std::getline(fo, line); std::getline(fo, line); std::stringstream s(line); s >> cls; for (float& x
+            : v) s >> x;
+      while (std::getline(fo, line)) { std::stringstream s2(line); std::string st; nerf::FrameIdAndBbox b{}; s2 >> st >> b.x >> b.y >> b.h >> b.w;
+          if (!st.empty()) { boxes.push_back(b); box_stamps.push_back(st); } } }
     const Eigen::Matrix4f Tow = rigid_inverse(pose_from_tq(v, v[3], v[4], v[5], v[6]));
-    nerf::BoundingBox bb; bb.min = Eigen::Vector3f(-v[7] / 1.1f, -v[8] / 1.1f, -v[9] / 1.1f); bb.max = Eigen::Vector3f(v[7] / 1.1f, v[8] / 1.1f, v[9] / 1.1f);   // the manager inflates by 1.1
+    // the manager inflates by 1.1
+    nerf::BoundingBox bb; bb.min = Eigen::Vector3f(-v[7] / 1.1f, -v[8] / 1.1f, -v[9] / 1.1f); bb.max = Eigen::Vector3f(v[7] / 1.1f, v[8] / 1.1f, v[9] / 1.1f);
 
     nerf::NerfManagerOnline* mgr = new nerf::NerfManagerOnline(cfg, true, 60);                       // System.cc:122 (never deleted there)
-    mgr->Init(); mgr->DatasetInit((float)num("Camera.fx"), (float)num("Camera.fy"), (float)num("Camera.cx"), (float)num("Camera.cy"), (int)num("Camera.H"), (int)num("Camera.W"), stamps.size());
+    mgr->Init();
+    mgr->DatasetInit((float)num("Camera.fx"), (float)num("Camera.fy"), (float)num("Camera.cx"), (float)num("Camera.cy"), (int)num("Camera.H"),
+            (int)num("Camera.W"), stamps.size());
     size_t idx = 0; bool created = false; int unknown = mgr->GetFrameIdx(123.0);
     for (size_t f = 0; f < stamps.size(); ++f) {                                                       // LocalMapping.cc:1172-1280
         const double t = std::strtod(stamps[f].c_str(), nullptr);
-        cv::Mat img = read_png(seq + "/rgb/" + names[f], CV_8UC3), inst = read_png(seq + "/instance/" + names[f], CV_8UC1), depth = read_png(seq + "/depth/" + names[f], CV_32FC1);
+        cv::Mat img = read_png(seq + "/rgb/" + names[f], CV_8UC3), inst = read_png(seq + "/instance/" + names[f], CV_8UC1),
+                depth = read_png(seq + "/depth/" + names[f], CV_32FC1);
         cv::Mat ic = img.clone(), sc = inst.clone();
         mgr->NewFrameToDataset((unsigned)f, std::to_string(t), ic, sc, mgr->mbUseSparseDepth ? depth : cv::Mat(), twc[f]);
         if (!created) { idx = mgr->CreateNeRF(cls, Tow, bb); created = true; }
         std::vector<nerf::FrameIdAndBbox> nb;
-        for (size_t k = 0; k < boxes.size(); ++k) if (box_stamps[k] == stamps[f]) { nerf::FrameIdAndBbox b = boxes[k]; b.FrameId = (uint32_t)mgr->GetFrameIdx(t); nb.push_back(b); }
+        for (size_t k = 0; k < boxes.size(); ++k) if (box_stamps[k] == stamps[f]) { nerf::FrameIdAndBbox b = boxes[k];
+            b.FrameId = (uint32_t)mgr->GetFrameIdx(t); nb.push_back(b); }
         mgr->UpdateNeRFBbox(idx, nb, 1);
         mgr->DrawMesh(idx);                                                                            // MapDrawer.cc:396, every viewer frame
         ::usleep(15000);
@@ -103,15 +120,18 @@ static int run_online(const std::string& seq, const std::string& cfg, const std:
     // members no consumer calls today but the interface has (nerf_manager.h:66, nerf.h:41,47,59,64): pose refresh of the last three frames, per-object views
     { std::vector<Eigen::Matrix4f> last3(twc.end() - 3, twc.end()); mgr->UpdateDataset((unsigned)twc.size(), 3, last3); }
     const std::vector<Eigen::Matrix4f> obj_twc = mgr->mvpNeRFs[idx]->GetTwc();
-    std::printf("online_members n_obj_twc=%zu mnBbox=%zu instance=%d twc_last_tx=%.6f\n", obj_twc.size(), mgr->mvpNeRFs[idx]->mnBbox, (int)mgr->mvpNeRFs[idx]->mInstanceId, obj_twc.empty() ? 0.f : obj_twc.back()(0, 3));
+    std::printf("online_members n_obj_twc=%zu mnBbox=%zu instance=%d twc_last_tx=%.6f\n", obj_twc.size(), mgr->mvpNeRFs[idx]->mnBbox,
+            (int)mgr->mvpNeRFs[idx]->mInstanceId, obj_twc.empty() ? 0.f : obj_twc.back()(0, 3));
     mgr->mvpNeRFs[idx]->DrawMesh();
     mgr->WaitThreadsEnd();                                                                             // System.cc:567
     g_last_count = 0; mgr->DrawMesh(idx);
     std::vector<std::string> ts = { std::to_string(std::strtod(box_stamps[2].c_str(), nullptr)), std::to_string(std::strtod(box_stamps[5].c_str(), nullptr)) };
-    std::vector<nerf::FrameIdAndBbox> tb = { boxes[2], boxes[5] }; tb[0].FrameId = (uint32_t)mgr->GetFrameIdx(std::strtod(box_stamps[2].c_str(), nullptr)); tb[1].FrameId = (uint32_t)mgr->GetFrameIdx(std::strtod(box_stamps[5].c_str(), nullptr));
+    std::vector<nerf::FrameIdAndBbox> tb = { boxes[2], boxes[5] }; tb[0].FrameId = (uint32_t)mgr->GetFrameIdx(std::strtod(box_stamps[2].c_str(), nullptr));
+    tb[1].FrameId = (uint32_t)mgr->GetFrameIdx(std::strtod(box_stamps[5].c_str(), nullptr));
     std::vector<Eigen::Matrix4f> tT = { twc[tb[0].FrameId], twc[tb[1].FrameId] };
     mgr->RenderNeRFsTest(out, idx, ts, tb, tT, 0.8f);                                                  // System.cc:610
-    std::printf("online idx=%zu unknown_frame=%d frame5=%d n_boxes=%zu mesh_indices=%d draws_during_training=%d gl_state_balance=%d stamp0=%s\n", idx, unknown, mgr->GetFrameIdx(0.5),
+    std::printf("online idx=%zu unknown_frame=%d frame5=%d n_boxes=%zu mesh_indices=%d draws_during_training=%d gl_state_balance=%d stamp0=%s\n", idx, unknown,
+            mgr->GetFrameIdx(0.5),
                 mgr->mvpNeRFs[idx]->GetFrameIdAndBBox().size(), g_last_count, draws_during, g_states, ts[0].c_str());
     delete mgr;
     return 0;
@@ -121,7 +141,9 @@ static int run_online(const std::string& seq, const std::string& cfg, const std:
 static void apply_options_from_env() {
     const char* e = std::getenv("MON_OPTIONS"); if (!e) return;
     std::stringstream ss(e); std::string kv;
-    while (std::getline(ss, kv, ',')) { const size_t q = kv.find('='); if (q != std::string::npos && mon_set_option(kv.substr(0, q).c_str(), std::atol(kv.c_str() + q + 1))) { std::cerr << mon_last_error() << std::endl; exit(6); } }
+    while (std::getline(ss, kv, ',')) { const size_t q = kv.find('=');
+        if (q != std::string::npos && mon_set_option(kv.substr(0, q).c_str(), std::atol(kv.c_str() + q + 1))) { std::cerr << mon_last_error() << std::endl;
+            exit(6); } }
 }
 
 int main(int argc, char** argv) {

@@ -200,6 +200,6 @@ def test_options_are_an_explicit_interface(pkg):
     """Test and tuning switches go through mon_set_option / mon_get_option; the product library reads no environment variables."""
     assert pkg.get_option("big_switch") == 16384 and pkg.get_option("backend") == -1 and pkg.get_option("offline_inner") == 500
     assert pkg.get_option("train_lanes") == 2 and pkg.get_option("lane_chunk") == 16 and pkg.get_option("online_slice_min") == 2      # the per-device scheduler's defaults
-    pkg.set_option("fused_ablate", 16); assert pkg.get_option("fused_ablate") == 16; pkg.set_option("fused_ablate", 0)
+    pkg.set_option("keep_zero_samples", 1); assert pkg.get_option("keep_zero_samples") == 1; pkg.set_option("keep_zero_samples", 0)
     with pytest.raises(pkg.MonError):
         pkg.set_option("no_such_switch", 1)

@@ -564,7 +564,7 @@ def test_optimizer_prepares_the_next_iteration(pkg, orc, small_scene, kw):
 
 def test_zero_gradient_skipping_is_exact_and_deterministic():
     """k_fused_train drops rays / samples whose fp16 dL/dO is all zeros before the backward MFMAs and the grid scatter.  The trained
-    parameters must be bit-identical to a run that keeps every sample (option fused_ablate = 16) and identical from run to run."""
+    parameters must be bit-identical to a run that keeps every sample (option keep_zero_samples) and identical from run to run."""
     import subprocess, sys
     from conftest import ROOT
     def run(extra):
@@ -573,7 +573,7 @@ def test_zero_gradient_skipping_is_exact_and_deterministic():
         assert r.returncode == 0, r.stdout + r.stderr
         rows = [ln.split() for ln in r.stdout.strip().split("\n") if ln.startswith("steps+")]
         return [w[2] for w in rows], [int(w[4]) for w in rows]
-    crc_a, n_a = run({}); crc_b, n_b = run({}); crc_c, n_c = run({"MON_OPTIONS": "fused_ablate=16"})
+    crc_a, n_a = run({}); crc_b, n_b = run({}); crc_c, n_c = run({"MON_OPTIONS": "keep_zero_samples=1"})
     assert crc_a == crc_b == crc_c, (crc_a, crc_b, crc_c)
     crc_g, _ = run({"MON_OPTIONS": "use_graph=1"})                              # hipGraph replay of the same launches
     assert crc_g == crc_a, (crc_g, crc_a)

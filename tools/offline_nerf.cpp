@@ -15,12 +15,15 @@ int main(int argc, char** argv) {
     const int n_objects = argc > 4 ? std::atoi(argv[4]) : 4;                 // main.cpp:315-319 hard-codes 4
     const std::string out = argc > 5 ? argv[5] : "./output";
     if (use_depth != 0 && use_depth != 1) { std::fprintf(stderr, "UseGTdepth param error...\n0 or 1\n"); return 0; }
-    // harness convenience shared with the Python binding and tests/compat_driver.cpp (the library itself reads no environment variable): MON_OPTIONS="name=value,..."
+    // harness convenience shared with the Python binding and tests/compat_driver.cpp (the library itself reads no environment variable):
+    // MON_OPTIONS="name=value,..."
     if (const char* e = std::getenv("MON_OPTIONS")) {
         std::string kv, all = e; size_t p0 = 0;
         while (p0 <= all.size()) {
-            const size_t p1 = all.find(',', p0); kv = all.substr(p0, p1 == std::string::npos ? std::string::npos : p1 - p0); p0 = p1 == std::string::npos ? all.size() + 1 : p1 + 1;
-            const size_t q = kv.find('='); if (q != std::string::npos && mon_set_option(kv.substr(0, q).c_str(), std::atol(kv.c_str() + q + 1))) return fail("MON_OPTIONS");
+            const size_t p1 = all.find(',', p0); kv = all.substr(p0, p1 == std::string::npos ? std::string::npos : p1 - p0);
+            p0 = p1 == std::string::npos ? all.size() + 1 : p1 + 1;
+            const size_t q = kv.find('=');
+            if (q != std::string::npos && mon_set_option(kv.substr(0, q).c_str(), std::atol(kv.c_str() + q + 1))) return fail("MON_OPTIONS");
         }
     }
     mon_offline* mgr = nullptr;

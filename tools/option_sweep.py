@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Sweeps one library option over a list of values and prints tools/kernel_times.py's per-kernel durations for each:
-   python tools/option_sweep.py fused_stagger 0 4 8 12 [--sparse]"""
+   python tools/option_sweep.py big_switch 0 4096 16384 65536 [--sparse]"""
 import json
 import os
 import sys

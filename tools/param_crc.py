@@ -1,5 +1,5 @@
 """CRC of the trained fp32 parameters after a fixed schedule on the bench scene (determinism / A-B checks of kernel variants):
-   python tools/param_crc.py [steps ...]      e.g.  MON_OPTIONS=fused_ablate=16 python tools/param_crc.py 5 60 200
+   python tools/param_crc.py [steps ...]      e.g.  MON_OPTIONS=keep_zero_samples=1 python tools/param_crc.py 5 60 200
    MON_CRC_CFG='{"log2_hashmap_size": 20}' overrides network-configuration fields."""
 import json
 import os
