@@ -47,7 +47,8 @@ def parse_args():
     ap.add_argument("--views", type=int, default=40)
     ap.add_argument("--log2-hashmap-size", type=int, default=0, help="override base.json's T (BASELINE configs[4] stress: 22); 0 = base.json")
     ap.add_argument("--no-stress", action="store_true", help="skip the T = 2^22 side figure")
-    ap.add_argument("--objects-per-gpu", type=int, default=4, help="extra (not the headline): aggregate rate of K objects trained concurrently on one GPU; 0 = skip")
+    ap.add_argument("--objects-per-gpu", type=int, default=4,
+            help="extra (not the headline): aggregate rate of K objects trained concurrently on one GPU; 0 = skip")
     return ap.parse_args()
 
 
@@ -160,7 +161,8 @@ def main():
     pobj.set_profiling(True); pobj.profile(reset=True)
     sc0 = int(pobj.buffer("state")[25])
     pobj.train(args.steps); prof = pobj.profile(reset=True); pobj.set_profiling(False)
-    scattered = ((int(pobj.buffer("state")[25]) - sc0) % (1 << 32)) / float(args.steps)      # samples with a non-zero gradient per step in this window
+    # samples with a non-zero gradient per step in this window
+    scattered = ((int(pobj.buffer("state")[25]) - sc0) % (1 << 32)) / float(args.steps)
     pobj.close()
     avg = lambda k: prof["ms"][k] / max(1, prof["launches"][k])
     fused = obj_backend(pkg, obj) == 1
@@ -181,30 +183,41 @@ def main():
     opt_bpp = 38 if pkg.get_option("steps16") else 40      # 16-bit saturating step counters (exact for base.json's betas) read + write 2 B instead of 4 B each
     if fused:
         enc_ms = avg(6) + avg(7)
-        kern = [("k_encode_tiles", enc_ms, (12 + 32 * L) * B, "VALU issue + LDS reads (level tiles in LDS; HBM traffic is the tile copies)")] if enc_ms > 0 else []
-        kern += [("k_fused_train", avg(1), ((40 if enc_ms > 0 else 52 + 32 * L) * B), "latency of a ray's MLP / composite / backward chain" if enc_ms > 0 else "L1->L2 line requests of the hash-grid gathers"),
+        kern = [("k_encode_tiles", enc_ms, (12 + 32 * L) * B,
+                "VALU issue + LDS reads (level tiles in LDS; HBM traffic is the tile copies)")] if enc_ms > 0 else []
+        kern += [("k_fused_train", avg(1), ((40 if enc_ms > 0 else 52 + 32 * L) * B),
+                "latency of a ray's MLP / composite / backward chain" if enc_ms > 0 else "L1->L2 line requests of the hash-grid gathers"),
                  ("k_grid_scatter", avg(4) + avg(5), 64 * L * scattered, "VALU issue + LDS integer atomics"),
                  ("k_optimizer", avg(2), opt_bpp * n_params, "HBM / Infinity Cache streaming")]
     else:
-        kern = [("unfused fwd+bwd kernel group", avg(0) + avg(1), train_bytes_per_sample(L) * B, "global atomics"), ("k_optimizer", avg(2), opt_bpp * n_params, "HBM streaming")]
+        kern = [("unfused fwd+bwd kernel group", avg(0) + avg(1), train_bytes_per_sample(L) * B, "global atomics"), ("k_optimizer", avg(2), opt_bpp * n_params,
+                "HBM streaming")]
     table = []
     for name, ms, nbytes, limiter in kern:
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         tr = pmc.get(name + "_hbm_bytes_per_launch")
-        table.append({"kernel": name, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(nbytes), "achieved": round(gbs, 2), "peak": 8000.0, "unit": "GB/s",
+        table.append({"kernel": name, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(nbytes), "achieved": round(gbs, 2), "peak": 8000.0,
+                "unit": "GB/s",
                       "frac": round(gbs / 8000.0, 4), "traffic": tr, "limited_by": limiter})
     dom = max(table, key=lambda r: r["avg_launch_ms"])
-    # "bound" names the roof the contract prices the path against (SURVEY 8(d) accounts it in bytes); what the counters name as the kernel's limiter is `limited_by`
-    roofline = {"bound": "hbm", "bound_note": "priced against HBM bytes as SURVEY 8(d) prescribes; the dominant kernel's measured limiter is in limited_by (it is not HBM-bound at base.json size: tables live in L2 / LDS)",
+    # "bound" names the roof the contract prices the path against (SURVEY 8(d) accounts it in bytes); what the counters name as the kernel's limiter is
+    # `limited_by`
+    roofline = {"bound": "hbm", "bound_note": "priced against HBM bytes as SURVEY 8(d) prescribes; the dominant kernel's measured limiter is in limited_by "
+                                                "(it is not HBM-bound at base.json size: tables live in L2 / LDS)",
                 "achieved": dom["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
                 "traffic_regime": regime if dom["traffic"] else None, "traffic_source": pmc.get("source"),
-                "kernel": dom["kernel"], "avg_launch_ms": dom["avg_launch_ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "limited_by": dom["limited_by"],
+                "kernel": dom["kernel"], "avg_launch_ms": dom["avg_launch_ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                        "limited_by": dom["limited_by"],
                 "gradient_carrying_samples_per_launch": round(scattered, 1),
-                "measured_over": "HIP events around every launch on the object's train stream over steps %d..%d from init of a fresh object -- the same window as "
-                                 "the timed region, measured separately because the events add ~35 us per step between the launches; an event pair also inflates the launch it brackets by ~2 us -- the kernels' "
-                                 "rocprofv3 durations of the same window are in profiles/r04_window_dense.md (their sum fits the timed step, the event times do not)" % (args.warmup, args.warmup + args.steps),
+                "measured_over": "HIP events around every launch on the object's train stream over steps %d..%d from init of a fresh object -- the same "
+                                 "window as "
+                                 "the timed region, measured separately because the events add ~35 us per step between the launches; an event pair also "
+                                 "inflates the launch it brackets by ~2 us -- the kernels' rocprofv3 durations of the same window are in "
+                                 "profiles/r04_window_dense.md (their sum fits the timed step, the event times do not)"
+                                 % (args.warmup, args.warmup + args.steps),
                 "kernels": table}
-    # the whole step against the contract's bytes: (52 + 96 L) B per nominal ray-sample + 40 B per parameter, over the TIMED step (no events)
+    # the whole step against the contract's bytes: (52 + 96 L) B per nominal ray-sample + 40 B per parameter, over the TIMED step (no
+    # events)
     contract_bytes = train_bytes_per_sample(L) * B + 40 * n_params
     roofline["contract"] = {"bytes_per_step": int(contract_bytes), "bytes_per_ray_sample": train_bytes_per_sample(L), "optimizer_bytes_per_step": 40 * n_params,
                             "ms_per_step": round(step_ms, 4), "achieved": round(contract_bytes / (step_ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
@@ -215,9 +228,12 @@ def main():
     macs = F_in * W_ + (NH_ - 1) * W_ * W_ + W_ * 4
     mlp_flops = 3 * 2 * macs * B
     fb_ms = avg(1)
-    roofline["mfma"] = {"kernel": "k_fused_train", "algorithmic_flops_per_launch": mlp_flops, "achieved": round(mlp_flops / (fb_ms * 1e-3) / 1e12, 2) if fb_ms else None, "peak": 2500.0, "unit": "TFLOP/s",
-                        "frac": round(mlp_flops / (fb_ms * 1e-3) / 1e12 / 2500.0, 4) if fb_ms else None, "busy_frac_pmc": pmc.get("k_fused_train_mfma_busy_frac"),
-                        "note": "MFMA is used only for the MLP's tiny GEMMs (busy_frac_pmc: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES of the committed pass); the path is not priced against this roof"}
+    roofline["mfma"] = {"kernel": "k_fused_train", "algorithmic_flops_per_launch": mlp_flops, "achieved": round(mlp_flops / (fb_ms * 1e-3) / 1e12,
+            2) if fb_ms else None, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": round(mlp_flops / (fb_ms * 1e-3) / 1e12 / 2500.0, 4) if fb_ms else None,
+                                "busy_frac_pmc": pmc.get("k_fused_train_mfma_busy_frac"),
+                        "note": "MFMA is used only for the MLP's tiny GEMMs (busy_frac_pmc: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES of the committed pass); "
+                                "the path is not priced against this roof"}
 
     # ---- extra, not the headline: the same measurement late in training (the scatter handles only the samples that still carry a
     #      gradient; an OfflineNeRF job runs 5000 iterations)
@@ -232,7 +248,8 @@ def main():
                 tl_r = sharding.max_over_ranks(dist, torch, tl_r, coll_dev)
             tls.append(tl_r)
         tl = median(tls)
-        late = {"after_steps": done + extra, "ms_per_step": round(1e3 * tl / args.steps, 4), "value": round(world * args.steps * B / tl, 1), "unit": "ray-samples/s",
+        late = {"after_steps": done + extra, "ms_per_step": round(1e3 * tl / args.steps, 4), "value": round(world * args.steps * B / tl, 1),
+                "unit": "ray-samples/s",
                 "ms_per_step_windows": [round(1e3 * t / args.steps, 4) for t in tls]}
 
     # ---- extra, not the headline: the late-training window with occupancy-grid skipping switched on (mon_config::occupancy_skip -- named by
@@ -245,7 +262,8 @@ def main():
             for _ in range(3):                          # three consecutive windows of K steps, the median is reported (like late_training)
                 to0 = time.perf_counter(); oo.train(args.steps); sync(); tos.append(time.perf_counter() - to0)
             to = median(tos)
-            occ = {"after_steps": 800, "ms_per_step": round(1e3 * to / args.steps, 4), "value": round(args.steps * B / to, 1), "unit": "ray-samples/s (nominal: skipped samples count)",
+            occ = {"after_steps": 800, "ms_per_step": round(1e3 * to / args.steps, 4), "value": round(args.steps * B / to, 1),
+                    "unit": "ray-samples/s (nominal: skipped samples count)",
                    "ms_per_step_windows": [round(1e3 * t / args.steps, 4) for t in tos],
                    "note": "opt-in approximation (default off; parity and the headline run without it)"}
             oo.close()
@@ -260,20 +278,23 @@ def main():
     psnr_of = lambda img: float(-10 * np.log10(max(1e-12, ((img - gt) ** 2).mean())))
     gather_note = None
     if dist is not None:
-        # The throughput above is complete at this point; the gather must not be able to take the JSON line with it (a point-to-point transport problem on a node this
-        # script has never seen would otherwise leave the driver without a number): it runs in a worker thread with a deadline, and a rank whose gather did not
-        # finish reports so, scores its own crop and leaves the process group alone at exit.
+        # The throughput above is complete at this point; the gather must not be able to take the JSON line with it (a point-to-point transport problem on a
+        # node this script has never seen would otherwise leave the driver without a number): it runs in a worker thread with a deadline, and a rank whose
+        # gather did not finish reports so, scores its own crop and leaves the process group alone at exit.
         box_res = {}
-        packed = sharding.render_packed(obj, box, ss.colmajor(sc.Twc[v]), torch, coll_dev)      # (the render itself is this rank's own work: only the collective sits behind the deadline)
+        # (the render itself is this rank's own work: only the collective sits behind the deadline)
+        packed = sharding.render_packed(obj, box, ss.colmajor(sc.Twc[v]), torch, coll_dev)
         def gather_job():
             try:
                 if coll_backend == "nccl":
                     torch.cuda.set_device(coll_dev)
-                box_res["crops"] = sharding.gather_crops(dist, torch, [packed], coll_dev, root=0)          # gather-to-root: only rank 0 holds (and scores) the crops
+                # gather-to-root: only rank 0 holds (and scores) the crops
+                box_res["crops"] = sharding.gather_crops(dist, torch, [packed], coll_dev, root=0)
                 box_res["ok"] = True
             except Exception as e:                      # noqa: BLE001 -- reported in the JSON line
                 box_res["error"] = "%s: %s" % (type(e).__name__, e)
-        gt_thread = threading.Thread(target=gather_job, daemon=True); gt_thread.start(); gt_thread.join(float(os.environ.get("MON_BENCH_GATHER_TIMEOUT", "180")))
+        gt_thread = threading.Thread(target=gather_job, daemon=True); gt_thread.start()
+        gt_thread.join(float(os.environ.get("MON_BENCH_GATHER_TIMEOUT", "180")))
         if box_res.get("ok"):
             crops = box_res["crops"]
             psnrs = [psnr_of(items[0][0]) for items in crops if items] if crops is not None else []
@@ -306,15 +327,21 @@ def main():
         except Exception:
             evaluated = None
         bps = 16 + 32 * L
-        roofline_render = {"bound": "hbm", "limited_by": "LDS read-instruction rate + VALU issue of k_encode_feat (level tiles in LDS); priced against HBM bytes as SURVEY 8(d) prescribes",
+        roofline_render = {"bound": "hbm",
+                           "limited_by": "LDS read-instruction rate + VALU issue of k_encode_feat (level tiles in LDS); priced against HBM bytes as "
+                                         "SURVEY 8(d) prescribes",
                            "kernel_ms_per_crop": round(k_ms, 4),
                            "bytes_per_ray_sample": bps, "nominal_samples": nominal, "evaluated_samples": evaluated,
-                           "achieved_nominal": round(bps * nominal / (k_ms * 1e-3) / 1e9, 2), "achieved_evaluated": round(bps * evaluated / (k_ms * 1e-3) / 1e9, 2) if evaluated else None,
+                           "achieved_nominal": round(bps * nominal / (k_ms * 1e-3) / 1e9, 2),
+                                   "achieved_evaluated": round(bps * evaluated / (k_ms * 1e-3) / 1e9, 2) if evaluated else None,
                            "peak": 8000.0, "unit": "GB/s", "frac_nominal": round(bps * nominal / (k_ms * 1e-3) / 1e9 / 8000.0, 4),
                            "frac_evaluated": round(bps * evaluated / (k_ms * 1e-3) / 1e9 / 8000.0, 4) if evaluated else None,
                            "nominal_ray_samples_per_s_kernels_only": round(nominal / (k_ms * 1e-3), 1),
-                           "traffic": pmc.get("render_hbm_bytes_per_crop"), "measured_over": "HIP events around the kernels of %d renders of the %dx%d crop after %s training steps" % (n_rep, h, w, "the bench's"),
-                           "path": "level tiles (k_encode_feat + k_tile_render)" if pkg.get_option("tile_render") and h * w >= 4096 else "gathers (k_fused_render)"}
+                           "traffic": pmc.get("render_hbm_bytes_per_crop"),
+                                   "measured_over": "HIP events around the kernels of %d renders of the %dx%d crop after %s training steps" % (n_rep, h, w,
+                                   "the bench's"),
+                           "path": "level tiles (k_encode_feat + k_tile_render)" if pkg.get_option("tile_render") and h * w >= 4096
+                                   else "gathers (k_fused_render)"}
         render_info["kernel_ms_per_crop"] = round(k_ms, 4)
     except Exception as e:
         roofline_render = {"value": None, "note": "failed: %s" % e}
@@ -356,25 +383,31 @@ def main():
                 cdt = (time.perf_counter() - t1) / n
                 grgb, gd, gm = obj.render(box, pose)
                 same = gm == rm
-                out = {"value": round(h * w * 2 * cfg.n_samples / cdt, 1), "unit": "nominal ray-samples/s", "cores": orc.lib().orc_max_threads(), "kind": "port",
+                out = {"value": round(h * w * 2 * cfg.n_samples / cdt, 1), "unit": "nominal ray-samples/s", "cores": orc.lib().orc_max_threads(),
+                        "kind": "port",
                        "ms_per_crop": round(1e3 * cdt, 2),
-                       "sample": "%d renders of the %dx%d crop (2S = %d samples per pixel ray) by oracle/mon_oracle.c orc_render with OpenMP, the GPU object's EMA weights" % (n, h, w, 2 * cfg.n_samples),
-                       "gpu_vs_oracle": {"mask_agreement": round(float(same.mean()), 5), "max_abs_rgb_diff_where_masks_agree": round(float(np.abs(grgb - rr)[same].max()), 5) if same.any() else None}}
+                       "sample": "%d renders of the %dx%d crop (2S = %d samples per pixel ray) by oracle/mon_oracle.c orc_render with OpenMP, "
+                                 "the GPU object's EMA weights" % (n, h, w, 2 * cfg.n_samples),
+                       "gpu_vs_oracle": {"mask_agreement": round(float(same.mean()), 5),
+                               "max_abs_rgb_diff_where_masks_agree": round(float(np.abs(grgb - rr)[same].max()), 5) if same.any() else None}}
                 ref.close(); return out
             except Exception as e:
                 return {"value": None, "unit": "nominal ray-samples/s", "cores": 0, "kind": "port", "sample": "failed: %s" % e}
         cpu_render = time_oracle_render(max(2.0, args.cpu_seconds / 4))
         cpu = time_oracle({}, args.cpu_seconds, "R=4096 x S=32, base.json network")
-        cpu_c1 = time_oracle(dict(rays_per_batch=1024, n_levels=4, n_neurons=32, n_hidden_layers=2), max(2.0, args.cpu_seconds / 3), "BASELINE configs[0]: R=1024 x S=32, hash L=4, MLP 2x32")
+        cpu_c1 = time_oracle(dict(rays_per_batch=1024, n_levels=4, n_neurons=32, n_hidden_layers=2), max(2.0, args.cpu_seconds / 3),
+                "BASELINE configs[0]: R=1024 x S=32, hash L=4, MLP 2x32")
 
     # ---- extra, not the headline: K object NeRFs trained concurrently on this GPU (a host thread per object, as the managers do,
     #      CORE/src/nerf_manager.cu:89,259; the library threads their work through two shared streams); the kernels of different objects
-    #      overlap, so the aggregate rate says how much of the chip one object's launch chain leaves idle.  Every object is at the timed window's training stage (steps W..W+K from init).
+    # overlap, so the aggregate rate says how much of the chip one object's launch chain leaves idle.  Every object is at the timed window's training stage
+    # (steps W..W+K from init).
     multi = None
     if rank == 0 and world == 1 and args.objects_per_gpu > 1:
         try:
             K = args.objects_per_gpu
-            msteps = max(320, 5 * args.steps)            # (a short window of four threads is mostly thread start-up; 320 steps = the window README / DESIGN quote)
+            # (a short window of four threads is mostly thread start-up; 320 steps = the window README / DESIGN quote)
+            msteps = max(320, 5 * args.steps)
             tms = []
             for rep in range(3):                         # three fresh sets of K objects, the median is reported
                 objs = [new_object(dict(sample_seed=3000 + 10 * rep + k)) for k in range(K)]
@@ -387,9 +420,11 @@ def main():
                 for o in objs:
                     o.close()
             tm = median(tms)
-            multi = {"objects": K, "value": round(K * msteps * B / tm, 1), "unit": "ray-samples/s (all objects)", "ms_per_step_per_object": round(1e3 * tm / msteps / K, 4),
+            multi = {"objects": K, "value": round(K * msteps * B / tm, 1), "unit": "ray-samples/s (all objects)",
+                    "ms_per_step_per_object": round(1e3 * tm / msteps / K, 4),
                      "values_of_the_repeats": [round(K * msteps * B / t, 1) for t in tms],
-                     "note": "K independent objects, one host thread each, their training work on the device's two training lanes (DESIGN 7.2), same GPU, each over steps %d..%d from init; median of 3 fresh sets" % (args.warmup, args.warmup + msteps)}
+                     "note": "K independent objects, one host thread each, their training work on the device's two training lanes (DESIGN 7.2), same GPU, "
+                             "each over steps %d..%d from init; median of 3 fresh sets" % (args.warmup, args.warmup + msteps)}
         except Exception as e:
             multi = {"objects": args.objects_per_gpu, "value": None, "note": "failed: %s" % e}
 
@@ -415,7 +450,8 @@ def main():
                       "late": {"steps": "800..840", "ms_per_step": round(1e3 * ts_late, 4), "value": round(B / ts_late, 1),
                                "frac_of_hbm_from_counters": hbm_frac("step_bytes_beyond_l2_steps_800_820", 1e3 * ts_late)},
                       "unit": "ray-samples/s", "traffic_source": sp.get("source"),
-                      "note": "frac_of_hbm = committed counter traffic of the step's kernels ((2 FETCH_SIZE + WRITE_SIZE) KB summed over the kernels of a step, profiles/r04_window_T22.md) / measured step time / 8 TB/s"}
+                      "note": "frac_of_hbm = committed counter traffic of the step's kernels ((2 FETCH_SIZE + WRITE_SIZE) KB summed over the kernels of a "
+                              "step, profiles/r04_window_T22.md) / measured step time / 8 TB/s"}
             so.close()
         except Exception as e:
             stress = {"value": None, "note": "failed: %s" % e}
@@ -425,20 +461,27 @@ def main():
                "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16 params/activations, fp32 accumulate + fp32 master",
                "data": "synthetic",
-               "config": {"workload": "OfflineNeRF-style training, 1 synthetic 'room'-like object per GPU, base.json defaults (hash L=16 F=2 T=2^16, MLP 64x1), "
-                                      "R=4096 rays x S=32 samples/step, %d views 640x480 resident in HBM%s" % (args.views, (", T overridden to 2^%d" % args.log2_hashmap_size) if args.log2_hashmap_size else ""),
+               "config": {"workload": "OfflineNeRF-style training, 1 synthetic 'room'-like object per GPU, base.json defaults (hash L=16 F=2 T=2^16, "
+                                      "MLP 64x1), "
+                                      "R=4096 rays x S=32 samples/step, %d views 640x480 resident in HBM%s" % (args.views,
+                                              (", T overridden to 2^%d" % args.log2_hashmap_size) if args.log2_hashmap_size else ""),
                           "objects": world, "rays_per_step": cfg.rays_per_batch, "samples_per_ray": cfg.n_samples, "backend": obj_backend(pkg, obj),
                           "parallelism": "object-per-GPU (no training collective; %s gather-to-root of the final render%s)" % (
                               {"nccl": "RCCL", None: "RCCL"}.get(coll_backend, coll_backend), ", device-resident crops" if coll_backend == "nccl" else ""),
-                          "launcher": "self-spawned ranks" if os.environ.get("MON_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "single process")},
-               "timed_region": "median of %d independent repeats; each repeat: fresh object, %d warm-up steps, %d timed steps from init, barrier + device sync on both sides, max over ranks" % (len(reps), args.warmup, args.steps),
+                          "launcher": "self-spawned ranks" if os.environ.get("MON_BENCH_SPAWNED")
+                                       else ("torch.distributed.run" if world > 1 else "single process")},
+               "timed_region": "median of %d independent repeats; each repeat: fresh object, %d warm-up steps, %d timed steps from init, barrier + device sync "
+                               "on both sides, max over ranks" % (len(reps), args.warmup, args.steps),
                "ms_per_step_repeats": [round(1e3 * r / args.steps, 4) for r in reps], "per_rank_ray_samples_per_s": per_rank,
                "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_c1": cpu_c1, "cpu_baseline_render": cpu_render,
                "late_training": late, "late_training_with_occupancy_skipping": occ, "multi_object": multi, "stress_T22": stress,
                "pcie_inclusive": {"dataset_upload_ms": round(1e3 * upload_s, 2), "dataset_bytes": int(sc.n_views * sc.H * sc.W * 4),
                                   "value_for_a_5000_step_job": round(world * 5000 * B / (upload_s + 5000 * dt / args.steps), 1), "unit": "ray-samples/s",
-                                  "note": "host frames -> HBM once per sequence (pinned staging + packing kernel), then 5000 steps at the measured step time; never the headline value"},
-               "render": render_info, "psnr_db": [round(p, 2) for p in psnrs], "render_gather": ("ok" if gather_note is None else "FAILED (%s): psnr_db is rank 0's own crop" % gather_note) if dist is not None else None, "train_steps_before_render": (late["after_steps"] + 3 * args.steps) if late else args.warmup + args.steps,
+                                  "note": "host frames -> HBM once per sequence (pinned staging + packing kernel), then 5000 steps at the measured step time; "
+                                          "never the headline value"},
+               "render": render_info, "psnr_db": [round(p, 2) for p in psnrs],
+               "render_gather": ("ok" if gather_note is None else "FAILED (%s): psnr_db is rank 0's own crop" % gather_note) if dist is not None else None,
+               "train_steps_before_render": (late["after_steps"] + 3 * args.steps) if late else args.warmup + args.steps,
                "final_loss": round(obj.info().last_loss, 5)}
         print(json.dumps(out), flush=True)
     obj.close(); ds.close()

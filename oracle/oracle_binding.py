@@ -34,7 +34,8 @@ def default_config(**kw):
         flags |= NUM_GRID_HALF
     if kw.pop("tcnn_half_accum", 0):               # ORC_NUM_TCNN_HALF: model of tiny-cuda-nn's own fp16 accumulation (encode, MLP fwd/bwd, dW)
         flags |= NUM_TCNN_HALF
-    # "same inputs" mode (mon_oracle.c orc_config.rng_flags): xorwow = 0 counter RNG | 1 cuRAND flavour | 2 rocRAND flavour, xorwow_lanes (multiple of 1024, default 4096), tcnn_init_order
+    # "same inputs" mode (mon_oracle.c orc_config.rng_flags): xorwow = 0 counter RNG | 1 cuRAND flavour | 2 rocRAND flavour, xorwow_lanes (multiple of 1024,
+    # default 4096), tcnn_init_order
     rng = int(kw.pop("xorwow", 0)) | (int(bool(kw.pop("tcnn_init_order", 0))) << 4) | ((int(kw.pop("xorwow_lanes", 0)) // 1024) << 16)
     for k, v in kw.items():
         setattr(c, k, v)
@@ -87,7 +88,8 @@ def lib():
         L.orc_xorwow_generate.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_xorwow_generate_calls.argtypes = [C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_gradient.restype = C.c_float
-        L.orc_gradient.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.orc_gradient.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_float,
+                C.c_void_p]
         L.orc_level_table.restype = C.c_int; L.orc_level_table.argtypes = [C.POINTER(OrcConfig), C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_grid_index.restype = C.c_uint32; L.orc_grid_index.argtypes = [C.c_uint32] * 5
         L.orc_rand01.restype = C.c_float; L.orc_rand01.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -97,7 +99,8 @@ def lib():
         L.orc_set_ema.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_mc_case.restype = C.c_uint64; L.orc_mc_case.argtypes = [C.c_int]
         L.orc_mc_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
-        L.orc_mc_extract.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_mc_extract.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                C.c_uint32]
         L.orc_mesh_to_cpu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_mesh_colors.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_set_parallel_scatter.argtypes = [C.c_int]; L.orc_advance_iter.argtypes = [C.c_void_p]

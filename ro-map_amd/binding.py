@@ -83,14 +83,17 @@ _SIGS = {
     "mon_device_mem_info": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "mon_object_mesh_generation": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mon_object_get_config": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "mon_object_copy_mesh": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "mon_object_copy_mesh": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_int]),
     "mon_object_get_mesh_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mon_object_save_mesh": (C.c_int, [C.c_void_p, C.c_char_p]),
-    "mon_marching_cubes": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+    "mon_marching_cubes": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_uint32, C.c_uint32,
                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mon_offline_get_intrinsics": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_float)] * 4 + [C.POINTER(C.c_int)] * 2),
     "mon_offline_get_poses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
-    "mon_offline_object_meta": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mon_offline_object_meta": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+            C.POINTER(C.c_size_t)]),
     "mon_offline_set_output_dir": (C.c_int, [C.c_void_p, C.c_char_p]),
     "mon_offline_object": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "mon_online_object": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -190,8 +193,10 @@ class Gather:
     def renders(self, objects, boxes, poses16, pose_is_Toc=False):
         n = len(objects); b = np.ascontiguousarray(boxes, np.uint32).reshape(n, 5); T = np.ascontiguousarray(poses16, np.float32).reshape(n, 16)
         oh = (C.c_void_p * n)(*[o.h for o in objects])
-        rgb = [np.empty((int(q[3]), int(q[4]), 3), np.float32) for q in b]; dep = [np.empty((int(q[3]), int(q[4])), np.float32) for q in b]; msk = [np.empty_like(d) for d in dep]
-        pr = (C.c_void_p * n)(*[a.ctypes.data for a in rgb]); pd = (C.c_void_p * n)(*[a.ctypes.data for a in dep]); pm = (C.c_void_p * n)(*[a.ctypes.data for a in msk])
+        rgb = [np.empty((int(q[3]), int(q[4]), 3), np.float32) for q in b]; dep = [np.empty((int(q[3]), int(q[4])), np.float32) for q in b]
+        msk = [np.empty_like(d) for d in dep]
+        pr = (C.c_void_p * n)(*[a.ctypes.data for a in rgb]); pd = (C.c_void_p * n)(*[a.ctypes.data for a in dep])
+        pm = (C.c_void_p * n)(*[a.ctypes.data for a in msk])
         rc = rccl_lib().mon_gather_renders(self.h, oh, _p(b), _p(T), int(pose_is_Toc), n, pr, pd, pm)
         if rc:
             raise MonError(rc, "mon_gather_renders failed (see stderr)")
@@ -306,7 +311,8 @@ def device_mem_info(device=0):
 def default_config(**kw):
     c = MonConfig(); _check(lib().mon_config_default(C.byref(c)))
     kw = dict(kw)
-    # "same inputs" mode (mon_config.rng_flags): xorwow = 0 counter RNG | 1 cuRAND flavour | 2 rocRAND flavour, xorwow_lanes (multiple of 1024, default 4096), tcnn_init_order
+    # "same inputs" mode (mon_config.rng_flags): xorwow = 0 counter RNG | 1 cuRAND flavour | 2 rocRAND flavour, xorwow_lanes (multiple of 1024, default 4096),
+    # tcnn_init_order
     rng = int(kw.pop("xorwow", 0)) | (int(bool(kw.pop("tcnn_init_order", 0))) << 4) | ((int(kw.pop("xorwow_lanes", 0)) // 1024) << 16)
     for k, v in kw.items():
         setattr(c, k, v)
@@ -415,7 +421,8 @@ class ObjectNeRF:
         HBM addresses of this object's device (e.g. a torch tensor's data_ptr() -- the final-render gather sends them over RCCL as they are)."""
         FrameId, x, y, h, w = (int(v) for v in box)
         pose = np.ascontiguousarray(pose16, np.float32)
-        _check(lib().mon_object_render(self.h, MonBBox(FrameId, x, y, h, w), _p(pose), int(pose_is_Toc), C.c_void_p(int(rgb_ptr)), C.c_void_p(int(depth_ptr)), C.c_void_p(int(mask_ptr)), int(bool(on_device))))
+        _check(lib().mon_object_render(self.h, MonBBox(FrameId, x, y, h, w), _p(pose), int(pose_is_Toc), C.c_void_p(int(rgb_ptr)), C.c_void_p(int(depth_ptr)),
+                C.c_void_p(int(mask_ptr)), int(bool(on_device))))
 
     def generate_mesh(self, res=64, thresh=2.0):
         """GenerateMesh + TransCPUMesh (nerf_model.cu:1993-2095); returns (n_verts incl. padding, n_indices)."""
@@ -429,7 +436,8 @@ class ObjectNeRF:
         _check(lib().mon_object_mesh_counts(self.h, C.byref(nv), C.byref(nr), C.byref(ni)))
         for _ in range(8):
             cv, ci = nv.value, ni.value
-            out = dict(verts=np.empty((cv, 3), np.float32), normals=np.empty((cv, 3), np.float32), colors=np.empty((cv, 3), np.uint8), indices=np.empty(ci, np.uint32))
+            out = dict(verts=np.empty((cv, 3), np.float32), normals=np.empty((cv, 3), np.float32), colors=np.empty((cv, 3), np.uint8), indices=np.empty(ci,
+                    np.uint32))
             rc = lib().mon_object_copy_mesh(self.h, cv, ci, _p(out["verts"]), _p(out["normals"]), _p(out["colors"]), _p(out["indices"]),
                                             C.byref(nv), C.byref(nr), C.byref(ni), int(try_lock))
             if rc == 1 and (nv.value > cv or ni.value > ci):
@@ -614,7 +622,8 @@ class OnlineManager:
 
     def object_info(self, idx):
         l = C.c_float(0); t = C.c_int(0); d = C.c_int(0); n = C.c_uint32(0)
-        _check(lib().mon_online_object_info(self.h, idx, C.byref(l), C.byref(t), C.byref(d), C.byref(n))); return dict(loss=l.value, train_calls=t.value, device=d.value, n_boxes=n.value)
+        _check(lib().mon_online_object_info(self.h, idx, C.byref(l), C.byref(t), C.byref(d), C.byref(n)))
+        return dict(loss=l.value, train_calls=t.value, device=d.value, n_boxes=n.value)
 
     def render(self, idx, box, Twc16):
         FrameId, x, y, h, w = (int(v) for v in box)
@@ -642,7 +651,8 @@ def marching_cubes(density, res3, thresh, aabb_min, aabb_max, device=0):
     nv = C.c_uint32(0); nr = C.c_uint32(0); ni = C.c_uint32(0)
     _check(lib().mon_marching_cubes(device, _p(d), rx, ry, rz, float(thresh), _p(a0), _p(a1), None, None, None, 0, 0, C.byref(nv), C.byref(nr), C.byref(ni)))
     verts = np.empty((nv.value, 3), np.float32); nraw = np.empty((nv.value, 3), np.float32); idx = np.empty(ni.value, np.uint32)
-    _check(lib().mon_marching_cubes(device, _p(d), rx, ry, rz, float(thresh), _p(a0), _p(a1), _p(verts), _p(nraw), _p(idx), nv.value, ni.value, C.byref(nv), C.byref(nr), C.byref(ni)))
+    _check(lib().mon_marching_cubes(device, _p(d), rx, ry, rz, float(thresh), _p(a0), _p(a1), _p(verts), _p(nraw), _p(idx), nv.value, ni.value, C.byref(nv),
+            C.byref(nr), C.byref(ni)))
     return dict(verts=verts, normals_raw=nraw, indices=idx, n_verts_real=nr.value)
 
 

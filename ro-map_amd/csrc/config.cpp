@@ -205,9 +205,8 @@ void init_params_host(const mon_config& c, const NetDims& nd, uint32_t n_params,
     uint32_t k = 0;
     if (rng_tcnn_init_order(c.rng_flags)) {
         // TCNN-A5b: tiny-cuda-nn's generate_random_uniform as published -- one launch per tensor (every MLP matrix, then the grid) of ceil(n / 512) blocks of
-        // 128 threads;
-        // thread i advances the generator by 4 i and writes draw j = 0..3 to element i + n_threads j; the host generator then advances by n.  Element e of a
-        // tensor
+        // 128 threads; thread i advances the generator by 4 i and writes draw j = 0..3 to element i + n_threads j; the host generator then advances by n. 
+        // Element e of a tensor
         // = draw 4 (e mod n_threads) + floor(e / n_threads) of the tensor's stretch of the pcg32 sequence, scaled as draw * (hi - lo) + lo.
         uint64_t base = 0;
         for (int layer = 0; layer <= nd.NH + 1; ++layer) {

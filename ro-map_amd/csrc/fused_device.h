@@ -220,12 +220,9 @@ struct TileState {
 };
 
 // Per-level constants of the encode, one level per LANE: lane h * 32 + il holds level h * LPH + il, the level half-wave h owns in level pair il (a pair past
-// the
-// last level holds a 1-entry dummy of level 0).  The gather code fetches them with v_readlane at compile-time lane numbers: no scalar loads (and no lgkmcnt
-// waits) inside
-// the ray loop, and none of the 7 x 16 constants pinned in SGPRs (the kernel runs at the SGPR limit; as kernel arguments they were re-loaded from the argument
-// segment
-// for every level of every ray).
+// the last level holds a 1-entry dummy of level 0).  The gather code fetches them with v_readlane at compile-time lane numbers: no scalar loads (and no lgkmcnt
+// waits) inside the ray loop, and none of the 7 x 16 constants pinned in SGPRs (the kernel runs at the SGPR limit; as kernel arguments they were re-loaded from
+// the argument segment for every level of every ray).
 struct LevelRegs { float scale; uint32_t size, my, mz, mask, off4, hashed; };
 // the same registers filled from the kernel ARGUMENTS (scalar loads + one select per field and level): nothing to wait for but the argument segment, no LDS
 // copy, no barrier

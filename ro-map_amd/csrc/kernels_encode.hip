@@ -67,8 +67,7 @@ struct EncodeArgs {
 };
 
 // the chain of encode_interp: corners in order k = x + 2y + 4z, c0[j] / c1[j] = x-corner 0 / 1 of pair j, weight ((wx * wy) * wz); the two x-corners of a pair
-// and
-// the two features of a corner are worked on as pairs (v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operations, two per instruction)
+// and the two features of a corner are worked on as pairs (v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operations, two per instruction)
 __device__ __forceinline__ half2_t enc_chain(const uint32_t (&c0)[4], const uint32_t (&c1)[4], const float (&pos)[3]) {
     const float2_t wx = { 1.f - pos[0], pos[0] };
     const float wy[2] = { 1.f - pos[1], pos[1] }, wz[2] = { 1.f - pos[2], pos[2] };
@@ -208,8 +207,7 @@ void launch_build_tiles_image(hipStream_t s, const LevelFast& lf, const NetDims&
 
 // ------------------------------------------------------------------ XORWOW sample stream (xorwow.h; mon_config::rng_flags, default off)
 // One thread per lane of the host generator: up to three generate calls in sequence (an iteration's SampleXY, RandColors, RandDt; or one Render's RandDt),
-// value j of a
-// call from lane j mod LANES; the lane's state goes back to memory for the next iteration's calls.
+// value j of a call from lane j mod LANES; the lane's state goes back to memory for the next iteration's calls.
 // (start: generator offset mod lanes before the first call)
 __global__ void __launch_bounds__(256) k_xorwow_fill(XorwowState* __restrict__ states, uint32_t lanes, int flavour, uint32_t start,
                                                      float* __restrict__ out0, uint32_t n0, float* __restrict__ out1, uint32_t n1, float* __restrict__ out2,

@@ -12,8 +12,7 @@
 // iteration's candidate rays (they depend on the iteration counter and the dataset only), so the steady-state loop is
 // k_fused_train -> k_grid_scatter -> k_reduce_partials -> k_optimizer with no batch-generation launch.
 // Variant builds for measurements (tools/variant_build.sh <tag> -D...; profiles/r03_scatter_levels.md): MON_OPT_ABLATE bits 1 no Adam arithmetic, 2 no
-// partial-table
-// reads, 4 no position blocks, 8 no tile-image stores.
+// partial-table reads, 4 no position blocks, 8 no tile-image stores.
 #include <cstdlib>
 #include "device_common.h"
 #include "model.h"
@@ -24,11 +23,9 @@
 namespace mon {
 
 // Optimizer state is not read again before the next step.  Small tables (everything streamed once per step, working set inside the Infinity Cache):
-// non-temporal
-// stores, a wash against plain ones (round 2).  LARGE tables (T = 2^22: 2-3 GB of scattered 32-byte pieces per step, HBM-bound): plain stores -- the L2 merges
-// a
-// chunk's pieces into whole lines before they leave; non-temporal ones cost 20 % of the kernel there (645-725 us against 535-550 us over steps 20..40, four
-// runs each).
+// non-temporal stores, a wash against plain ones (round 2).  LARGE tables (T = 2^22: 2-3 GB of scattered 32-byte pieces per step, HBM-bound): plain stores --
+// the L2 merges a chunk's pieces into whole lines before they leave; non-temporal ones cost 20 % of the kernel there (645-725 us against 535-550 us over steps
+// 20..40, four runs each).
 template <bool NT, class T> __device__ __forceinline__ void state_store(T v, T* p) {
     if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
 }
@@ -66,8 +63,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const uint32_t step_cap = (p.steps16 || p.rec) ? 65535u : 0xffffffffu;
     // where a chunk's optimizer state lives: the four SoA arrays, or (large tables, ParamPtrs::rec) ONE 128-byte record per chunk -- master | m1 | m2 | step
-    // counters --
-    // so that a touched chunk among untouched ones costs one full line instead of four half-used 64-byte sectors
+    // counters -- so that a touched chunk among untouched ones costs one full line instead of four half-used 64-byte sectors
     auto st_master = [&](uint32_t c) -> float* { return p.rec ? p.rec + 32u * (size_t)c : p.master + 8u * (size_t)c; };
     auto st_m1 = [&](uint32_t c) -> float* { return p.rec ? p.rec + 32u * (size_t)c + 8u : p.m1 + 8u * (size_t)c; };
     auto st_m2 = [&](uint32_t c) -> float* { return p.rec ? p.rec + 32u * (size_t)c + 16u : p.m2 + 8u * (size_t)c; };
@@ -90,8 +86,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
         if (i0 < oc.n_mlp) { L.gm0 = *reinterpret_cast<const float4_t*>(p.gmlp + i0); L.gm1 = *reinterpret_cast<const float4_t*>(p.gmlp + i0 + 4); }
     };
     // ONE chunk per thread: its state is requested HERE, before the kernel has seen its DevState -- the addresses come from the argument segment, and the round
-    // trip for
-    // n_valid / step / lr would otherwise stand in front of the streams (eager path below; a skipped batch drops the values)
+    // trip for n_valid / step / lr would otherwise stand in front of the streams (eager path below; a skipped batch drops the values)
     Pre early; bool early_issued = false;
     if constexpr (ONE) {
         const uint32_t extra0 = nx.cand_blocks + nx.pos_blocks;
@@ -216,8 +211,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                     n_part = p.sl.P[lvl];
                 }
                 // dense partial tables of k_grid_scatter (fused backend): [partition][feature][parity][entry / 2]; this chunk = entries e0 .. e0 + 3 (e0 a
-                // multiple
-                // of 4), both features: per partition four 4-byte pieces -- plane (f, b) holds entries e0 + b and e0 + 2 + b next to each other
+                // multiple of 4), both features: per partition four 4-byte pieces -- plane (f, b) holds entries e0 + b and e0 + 2 + b next to each other
                 const uint16_t* pp = p.gpart + ((i0 - oc.n_mlp) >> 2);
                 const size_t plane = p.part_stride >> 2;                 // entries per (feature, parity) plane
                 auto quad = [&](uint32_t q, float (&v)[8]) {             // partition q's eight values in parameter order (entry-major, feature-minor)
@@ -385,8 +379,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
             for (uint32_t q0 = 0; q0 < qn; q0 += 64u) if (q0 + lane < qn) update_chunk(queue[wave][q0 + lane], false, none, none, none);
         } else if (eager) {
             // a thread has two chunks at these table sizes (the launch gives ~2 chunks per thread): the state of both is requested before the first is worked
-            // on;
-            // straight-line code, no loop-carried buffers (those ended up in scratch memory)
+            // on; straight-line code, no loop-carried buffers (those ended up in scratch memory)
             const half8_t none{};
             const uint32_t c0 = c_first, c1 = c_first + c_stride;
             if constexpr (ONE) {
@@ -501,9 +494,8 @@ void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, c
         uint32_t lazy_below) {
     const uint32_t chunks = oc.n_params >> 3;
     // measured: base.json (239 k chunks), parameter blocks ahead of the preparation blocks: 384 / 512 / 640 / 768 / 1024 blocks = 27.9 / 24.1 / 24.7 / 23.6 /
-    // 22.9 us (one chunk per thread;
-    // with the preparation blocks FIRST 512 was the best: 28.1 / 23.7 / 26.2 us for 256 / 512 / 1024); T = 2^22 (13.2 M chunks) 512 / 2048 / 8192 / 32768
-    // blocks = 368 / 244 / 251 / 406 us
+    // 22.9 us (one chunk per thread; with the preparation blocks FIRST 512 was the best: 28.1 / 23.7 / 26.2 us for 256 / 512 / 1024); T = 2^22 (13.2 M chunks)
+    // 512 / 2048 / 8192 / 32768 blocks = 368 / 244 / 251 / 406 us
     uint32_t cap = chunks / (256u * 8u); if (cap < 1024u) cap = 1024u; if (cap > 2048u) cap = 2048u;
     uint32_t blocks = (chunks + 255) / 256; if (blocks > cap) blocks = cap; if (blocks < 1u) blocks = 1u;
     // dense = every level goes through the LDS scatter, i.e. tables of at most 2^18 entries that a 131 072-sample batch covers

@@ -120,10 +120,8 @@ __device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bo
     constexpr bool BYTES = HASHED && POW2 && !BOTH;
     if constexpr (BYTES) {
         // the walk of the branch below with every index term carried DOUBLED (h2 = h << 1: xor / and commute with the shift, and only product bits below the
-        // table
-        // size matter), so that a corner's place in the int32 tile comes out as its byte address -- (h >> 1) << 2 = h2 & mask4 -- and the four address shifts
-        // in
-        // front of the atomics disappear (the tile starts at LDS address 0: the kernel has no static LDS, checked at its entry)
+        // table size matter), so that a corner's place in the int32 tile comes out as its byte address -- (h >> 1) << 2 = h2 & mask4 -- and the four address
+        // shifts in front of the atomics disappear (the tile starts at LDS address 0: the kernel has no static LDS, checked at its entry)
         const uint32_t my2 = my << 1, mz2 = mz << 1, mask4 = (mask << 1) & ~3u;
         uint32_t y2 = __umul24(pg[1], my2 & 0xffffffu), z2 = __umul24(pg[2], mz2 & 0xffffffu);
         // (kept as products: y2 + my2 is then one add with a scalar operand; the compiler's v_mad_u32_u24 needs the addend moved into a vector register first)
@@ -208,9 +206,9 @@ __device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restr
     // (1024 threads: G = 1024 / W2 groups; powers of two throughout, no divisions)
     const uint32_t W2 = 1u << w2s, gs = 10u - w2s, G = 1u << gs;
     // Dense levels: the rows of a run are a ray's samples in order, and neighbours along a ray sit in the same coarse cell -- the lanes of a wave would add
-    // into
-    // the same few entries, and the LDS serialises same-address atomics (ds_add_u64: 19 cycles per wave instruction on random addresses, 46 when four lanes
-    // share one: tools/ldsatomicbench.py).  There a wave takes GROUPS of kGroup consecutive rows (still 16 * kGroup contiguous bytes per group) from runs W2 /
+    // into the same few entries, and the LDS serialises same-address atomics (ds_add_u64: 19 cycles per wave instruction on random addresses, 46 when four
+    // lanes share one: tools/ldsatomicbench.py).  There a wave takes GROUPS of kGroup consecutive rows (still 16 * kGroup contiguous bytes per group) from runs
+    // W2 /
     // 16
     // rows apart; hashed levels scramble the addresses themselves and keep the contiguous rows.
     constexpr uint32_t kGroupBits = MON_V_SGROUP;
@@ -261,8 +259,7 @@ __device__ __forceinline__ uint32_t partials_groups(const PartialsArgs& pa) {
     return need <= 1u ? 1u : (need <= 2u ? 2u : (need <= 4u ? 4u : 8u));
 }
 // the column groups go to the LAST workgroups of the grid: the first ones hold the coarse dense levels, whose sample walk is the longest of the kernel (their
-// samples
-// collide in the LDS atomic unit), so the row sums ride on workgroups that have slack
+// samples collide in the LDS atomic unit), so the row sums ride on workgroups that have slack
 // (on the FIRST workgroups instead: 42.6 against 41.5 us, round 2)
 __device__ __forceinline__ uint32_t partials_block() { return gridDim.x - 1u - blockIdx.x; }
 __device__ __forceinline__ void partials_prefetch(const PartialsArgs& pa, float4_t (&acc)[kPartialsMaxPasses]) {

@@ -138,8 +138,7 @@ int offline_read_dataset(OfflineManager& m) {                           // nerf_
     for (int g = 0; g < m.n_dev; ++g) { Dataset* d = nullptr; int rc = dataset_create(g, m.H, m.W, m.fx, m.fy, m.cx, m.cy, (uint32_t)n, m.use_depth, &d);
         if (rc) return rc; m.ds.push_back(d); }
     // The PNGs of a batch of frames are decoded by a few host threads at once (inflate + unfilter: ~10 ms per 640x480 frame, the whole read of a sequence
-    // otherwise),
-    // then handed to the device(s) in frame order.  The reference reads them one by one with cv::imread (nerf_data.cu:151-221).
+    // otherwise), then handed to the device(s) in frame order.  The reference reads them one by one with cv::imread (nerf_data.cu:151-221).
     struct Decoded { std::vector<uint8_t> rgb, inst; std::vector<float> depth; std::string err; };
     const auto decode = [&](size_t i, Decoded& o) {
         PngImage c, s, z; o.err.clear(); o.rgb.resize(px * 3); o.inst.resize(px); if (m.use_depth) o.depth.resize(px);

@@ -156,8 +156,8 @@ __global__ void __launch_bounds__(256) k_ub_copy(const ub_u4* __restrict__ src, 
 }
 
 // modes 31 / 32: the optimizer's memory streams without its arithmetic -- n_ops parameters: fp32 master / m1 / m2 read + written, 16-bit step counters and EMA
-// read + written,
-// fp16 copy and tile image written, `parts` fp16 partial-table planes read (flags bits 8..11).  flags bit 0: plain instead of non-temporal stores.
+// read + written, fp16 copy and tile image written, `parts` fp16 partial-table planes read (flags bits 8..11).  flags bit 0: plain instead of non-temporal
+// stores.
 //   31: the shipped kernel's shape -- a thread owns 8 consecutive parameters (two 16-byte pieces of every fp32 array, lane stride 32 B), `units` such chunks
 // requested up front;   32: a thread owns 4 consecutive parameters per unit (one 16-byte piece: a wave instruction covers 1 KB without holes), units a wave
 // apart
@@ -238,12 +238,9 @@ static void launch_stream(int mode, int blocks, int units, const StreamPtrs& a) 
 }
 
 // modes 70 / 71: what a persistent single-object step would trade: mode 70 = ONE resident grid of 256 workgroups x 1024 threads holding
-// the CU's
-// whole LDS (the shape of k_encode_tiles / k_grid_scatter) that crosses n_ops grid barriers (one returning atomic per workgroup on a counter + a spin on its
-// generation,
-// every workgroup touching 4 KB of memory between two barriers so that the barrier also carries the release / acquire a real phase change needs); mode 71 =
-// n_ops
-// back-to-back launches of the same grid doing the same 4 KB per workgroup.  `pattern` > 0: that many workgroups instead of 256.
+// the CU's whole LDS (the shape of k_encode_tiles / k_grid_scatter) that crosses n_ops grid barriers (one returning atomic per workgroup on a counter + a spin
+// on its generation, every workgroup touching 4 KB of memory between two barriers so that the barrier also carries the release / acquire a real phase change
+// needs); mode 71 = n_ops back-to-back launches of the same grid doing the same 4 KB per workgroup.  `pattern` > 0: that many workgroups instead of 256.
 __global__ void __launch_bounds__(1024) k_ub_grid_barrier(uint32_t n_barriers, uint32_t* __restrict__ ctr, uint32_t* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     reinterpret_cast<uint32_t*>(smem)[threadIdx.x] = threadIdx.x;

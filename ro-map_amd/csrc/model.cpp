@@ -88,8 +88,7 @@ int dataset_destroy(Dataset* d);
 // One high-priority stream and one pinned result buffer per DEVICE, shared by the objects on it (viewer renders) and by the device's dataset (frame uploads):
 // created with the device's first object (CreateNeRF is a
 // milliseconds call anyway; created by the first render it was a 10 ms spike in front of the viewer), and only one more hardware-queue client however many
-// objects
-// train (a high-priority queue per object measurably slowed sliced training).  Renders of one device take turns on it.
+// objects train (a high-priority queue per object measurably slowed sliced training).  Renders of one device take turns on it.
 // h_cap only grows; h_out / growth belong to mu
 struct InferShared { std::mutex mu; hipStream_t stream = nullptr; float* h_out = nullptr; std::atomic<size_t> h_cap{ 0 }; };
 static std::mutex g_infer_mu; static std::map<int, InferShared*> g_infer_shared;
@@ -142,9 +141,8 @@ int tile_ws_get(Model& m, int side, size_t n_pix, TileWs** out) {
     if (!ws.counters) {
         if ((rc = ws_grow(ws.counters, 64))) return rc;
         // (hipMemset of device memory may return before the fill has run, and the renders' streams are non-blocking: without the synchronisation the fill can
-        // land
-        // in the middle of the first render's ray kernel -- the job count restarts, k_tile_render reads job records nobody wrote and writes to the pixel index
-        // it
+        // land in the middle of the first render's ray kernel -- the job count restarts, k_tile_render reads job records nobody wrote and writes to the pixel
+        // index it
         //  finds there: the memory fault of the object-churn test, seen whenever a device's last object had returned the workspace)
         HIPCHECK(hipMemset(ws.counters, 0, 256)); HIPCHECK(hipDeviceSynchronize());
     }
@@ -209,15 +207,11 @@ static bool tile_render_wanted(const Model& m, size_t n_pix) {
 // Measured (tools/multi_object.py, base.json objects): two objects training concurrently fall into anti-phase on their own -- one gathers (k_fused_train, bound
 // by the
 // L2 request path) while the other scatters and updates (LDS atomics, HBM) -- 1.75 G ray-samples/s against 1.38 G for one; with three or more streams in flight
-// the
-// dispatcher mixes workgroups of kernels that exclude each other on a CU (k_grid_scatter takes a CU's whole LDS; streams beyond the hardware queues share one
-// and block
-// each other) and the aggregate drops to 1.5 G.  So the training work of ALL objects of a device goes through `train_lanes` (2) shared streams: a chunk of an
-// object's
-// iterations is enqueued on the lane with the least work in flight (the lane of the object's previous chunk while that is still running: stream order then
-// keeps the
-// object's iterations in sequence; a change of lane is ordered by an event).  The device sees two streams of whole training steps whatever the number of
-// objects.
+// the dispatcher mixes workgroups of kernels that exclude each other on a CU (k_grid_scatter takes a CU's whole LDS; streams beyond the hardware queues share
+// one and block each other) and the aggregate drops to 1.5 G.  So the training work of ALL objects of a device goes through `train_lanes` (2) shared streams: a
+// chunk of an object's iterations is enqueued on the lane with the least work in flight (the lane of the object's previous chunk while that is still running:
+// stream order then keeps the object's iterations in sequence; a change of lane is ordered by an event).  The device sees two streams of whole training steps
+// whatever the number of objects.
 // Lanes order work for speed only: no result depends on them.
 constexpr int kMaxLanes = 4; constexpr uint32_t kLaneRing = 256;
 // a lane's chunk events are only QUERIED (how much work is in flight): without the system-scope fence of a default event (an L2 write-back per chunk)
@@ -225,17 +219,14 @@ constexpr unsigned kLaneEventFlags = hipEventDisableTiming | hipEventDisableSyst
 struct TrainLanes {
     std::mutex mu; std::atomic<int> objects{ 0 };      // live objects of the device
     // per lane: `mu` orders the enqueueing of whole chunks; ev[tail .. head) = completion events of the chunks in flight (head: written by the enqueuer, tail:
-    // by whoever
-    // picks a lane, under TrainLanes::mu); pending = chunks that have picked the lane and not finished enqueueing
+    // by whoever picks a lane, under TrainLanes::mu); pending = chunks that have picked the lane and not finished enqueueing
     struct Lane { std::mutex mu; hipStream_t stream = nullptr; hipEvent_t ev[kLaneRing] = {}; std::atomic<uint32_t> head{ 0 }, pending{ 0 },
             tail{ 0 }; } lane[kMaxLanes];
 };
 static std::mutex g_lanes_mu; static std::map<int, TrainLanes*> g_lanes;
 // (the device is current.)  The lane streams are created TOGETHER, with the device's dataset and before any object's own stream: the runtime places a new
-// stream on the
-// hardware queue with the fewest users, so two streams created back to back get different queues -- created lazily, with object streams in between, both lanes
-// could
-// land on one queue and run strictly one after the other.
+// stream on the hardware queue with the fewest users, so two streams created back to back get different queues -- created lazily, with object streams in
+// between, both lanes could land on one queue and run strictly one after the other.
 static TrainLanes* lanes_get(int device) {
     std::lock_guard<std::mutex> l(g_lanes_mu); TrainLanes*& t = g_lanes[device];
     if (!t) {
@@ -260,8 +251,7 @@ static void mark_tail(Model& m) {
     m.tail_marked = hipEventRecord(m.switch_event, m.train_stream) == hipSuccess;
 }
 // moves the object's work to stream `to`: everything it has enqueued so far is ordered before whatever follows on the new stream.  The wait is for the object's
-// OWN last
-// work (mark_tail) -- an event recorded now would also stand behind every chunk other objects have queued on the old lane since, and tie the two lanes
+// OWN last work (mark_tail) -- an event recorded now would also stand behind every chunk other objects have queued on the old lane since, and tie the two lanes
 // together.
 static void switch_stream(Model& m, hipStream_t to);
 // Everything that is not a training chunk (renders on the train stream, density grids, meshes, parameter access, box uploads) runs on the object's OWN stream:
@@ -276,8 +266,8 @@ static void switch_stream(Model& m, hipStream_t to) {
     m.train_stream = to; m.tail_marked = false;
 }
 // One chunk of an object's iterations on a lane.  The lane is picked under the device-wide lock (short); the chunk is then ENQUEUED under the lane's own lock
-// (a few
-// microseconds per launch), so the chunks of different objects do not interleave within a lane while the host threads of different lanes enqueue side by side.
+// (a few microseconds per launch), so the chunks of different objects do not interleave within a lane while the host threads of different lanes enqueue side by
+// side.
 struct LaneChunk {
     Model& m; TrainLanes* tl = nullptr; std::unique_lock<std::mutex> lock; int l = -1;
     explicit LaneChunk(Model& mm, bool enabled) : m(mm) {
@@ -509,8 +499,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     const uint32_t R = m.oc.R, S = m.oc.S;
     m.ws_rays = R > kRenderChunkRays ? R : kRenderChunkRays;
     // the layer-at-a-time buffers (pts, tdist, E, O) serve a render pass of the unfused backend; an object whose inference runs on the fused kernels / level
-    // tiles
-    // only needs them at the training batch's size (64 + 12 + 8 + 4 MB less per base.json object: a render of the unfused backend then takes passes of
+    // tiles only needs them at the training batch's size (64 + 12 + 8 + 4 MB less per base.json object: a render of the unfused backend then takes passes of
     // ws_samples / 2S rays)
     const bool fused_inference = fused_supported(m.nd, S, R) && options().backend != 0;
     const uint32_t Btrain = R * S, Brender = fused_inference ? Btrain : kRenderChunkRays * 2 * S;
@@ -565,8 +554,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         // Batch size: a workgroup's two tile copies, four barriers and the launch cost the same whatever it walks -- measured (tools/kernel_times.py, both
         // chains, same box):
         // R = 1024 (C1) 48.9 vs 41.3 us per step for the gather chain, R = 2048 75.1 vs 75.4, R = 4096 99 vs 107, R = 8192 166 vs 172.  Option lds_encode = 1
-        // (default) takes the
-        // tile chain from 3072 rays (98 304 samples) up, 2 always (tests), 0 never.
+        // (default) takes the tile chain from 3072 rays (98 304 samples) up, 2 always (tests), 0 never.
         const bool tiles_pay = options().lds_encode >= 2 || Btrain >= 98304u;
         if (options().lds_encode && tiles_pay && m.lds_mask == ((1u << m.nd.L) - 1u) && encode_tiles_supported(m.lt, m.nd)) {
             if ((rc = dev_alloc(m, B.ray_rec, 12 * (size_t)R))) return rc;
@@ -740,8 +728,7 @@ static hipEvent_t get_event(Model& m) {
     hipEvent_t e; hipEventCreate(&e); return e;
 }
 // roctx ranges per phase (option "roctx" = 1): the phases of an iteration show up by name in a rocprofv3 --marker-trace of the host side.  The
-// library is
-// looked up at run time (librocprofiler-sdk-roctx.so, then libroctx64.so) -- nothing links against it, and without the option nothing is loaded.
+// library is looked up at run time (librocprofiler-sdk-roctx.so, then libroctx64.so) -- nothing links against it, and without the option nothing is loaded.
 struct Roctx {
     int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
     Roctx() {
@@ -799,8 +786,7 @@ static void enqueue_iteration(Model& m, int stages) {
     if (stages & 2) {      // Step_No_Compacted :1552-1607
         if (m.backend == 0 && options().step_variant) {
             // NeRF_Model::Step (nerf_model.cu:1504-1550): inference of every sample, per-ray sample compaction + rollover (kernels_step.hip), then
-            // forward +
-            // backward of the compacted batch.  B.pts / B.dO hold the compacted batch afterwards.
+            // forward + backward of the compacted batch.  B.pts / B.dO hold the compacted batch afterwards.
             ProfScope ps(m, MON_K_FWDBWD);
             launch_encode(s, m.lt, m.nd, m.P.half, m.B.pts, m.B.E, B, m.d_state);
             // :1509 inference_mixed_precision_impl, training weights
@@ -890,8 +876,7 @@ static void enqueue_iteration(Model& m, int stages) {
 // Occupancy grid refresh (cfg.occupancy_skip): before iteration `iter` when it is due.  Stream-ordered between two iterations, from the training weights.
 static void maybe_refresh_occupancy(Model& m, uint32_t iter) {
     // due at the first iteration it is asked for at or after the next multiple of kOccInterval (the hipGraph path only asks at the start of a captured PAIR:
-    // after an
-    // odd number of iterations an exact "iter % interval == 0" test was never true again and the grid was never refreshed)
+    // after an odd number of iterations an exact "iter % interval == 0" test was never true again and the grid was never refreshed)
     if (!m.d_occ || m.backend != 1 || iter < (uint32_t)kOccWarmup || iter < m.occ_next_refresh) return;
     launch_occupancy_update(m.train_stream, m.lf, m.nd, m.P.half, m.oc, m.d_frag_occ, m.occ_raw_threshold, m.d_occ_tmp, m.d_occ);
     // the density field settles: every kOccInterval iterations at first, every 4th / 16th of that rate later (a refresh costs ~60 us, 1.9 us per step at the
@@ -929,9 +914,8 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     // once the host has seen that count well below the switch point it stops launching the (then empty) binning kernels at all.
     m.big_active = m.big_switch && (m.h_state.n_scatter_last == 0u || m.h_state.n_scatter_last > m.big_switch / 2u);
     // Occupancy-grid skipping (opt-in): once the grid is in use and few samples are left, the gather chain wins -- k_fused_train skips the gathers of the
-    // samples in
-    // empty cells, k_encode_tiles encodes every sample (kernel_times, late window: 63.3 against 65.4 us per step; early, 99.6 against 92.1).  Both chains leave
-    // bit-identical parameters, so the choice is free per call; the host knows the regime from the last call's read-back.
+    // samples in empty cells, k_encode_tiles encodes every sample (kernel_times, late window: 63.3 against 65.4 us per step; early, 99.6 against 92.1).  Both
+    // chains leave bit-identical parameters, so the choice is free per call; the host knows the regime from the last call's read-back.
     m.gathers_preferred = m.d_occ && m.occ_refreshed_iter && m.h_state.n_scatter_last != 0u && 8u * m.h_state.n_scatter_last < m.oc.R * m.oc.S;
     const bool use_graph_env = options().use_graph != 0;
     if (iters > 0) m.weights_epoch = next_weights_epoch();
@@ -1017,8 +1001,8 @@ int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int
     }
     is->out_rgb = is->out_all; is->out_depth = is->out_all + 3 * (size_t)n_pix; is->out_mask = is->out_all + 4 * (size_t)n_pix;
     // A viewer's render competes with the training kernels of every object on the device.  k_encode_feat's workgroups need a whole CU each (160 KB of LDS) and
-    // wait until
-    // training workgroups have drained from one; the gather render's small workgroups slip in anywhere.  Measured (tools/online_replay.py, 60 keyframes every
+    // wait until training workgroups have drained from one; the gather render's small workgroups slip in anywhere.  Measured (tools/online_replay.py, 60
+    // keyframes every
     // 50 ms,
     // mean / p99 of the viewer's crop): 1 object 0.85 / 1.13 ms on tiles against 1.20 / 1.93 ms through the gathers, 4 objects 0.51 / 2.0 against 0.68 / 1.7,
     // 12 objects 0.58 / 3.1 against 0.67 / 1.7 -- so the tiles serve the viewer while few objects train on the device, the gathers once many do.

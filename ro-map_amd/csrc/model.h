@@ -36,8 +36,7 @@ struct DevState {
                                       // other pair for step t + 1 at kernel ENTRY (two double-precision pows: at the end of the last block they were ~1 us of
                                       // serial tail per step)
     // fused backend: slot counters of the gradient rows k_fused_train hands to k_grid_scatter -- samples with a non-zero dL/dO, per ray bin (ray & (bins - 1));
-    // a
-    // wave reserves its slots with one returning atomic per ray.  Counter of bin b at [set * kMaxScatterBins * stride + b * stride]: a 64-byte line each
+    // a wave reserves its slots with one returning atomic per ray.  Counter of bin b at [set * kMaxScatterBins * stride + b * stride]: a 64-byte line each
     // (returning atomics on one line serialise in its L2 channel: 4096 of them on 16 adjacent counters cost 7 us of k_fused_train).  TWO sets, by iteration
     // parity: k_fused_train(i) counts in set i & 1, k_grid_scatter(i) reads it and clears the other one for iteration i + 1.
     uint32_t n_scatter[2 * kMaxScatterBins * kScatterCounterStride];
@@ -57,8 +56,7 @@ struct ObjectConst {
     uint64_t sample_seed;
     float loss_scale;
     // "same inputs" mode (mon_config::rng_flags, xorwow.h): per iteration parity the three arrays SampleXY[2R] | RandColors[3R] | RandDt[S R] that
-    // k_xorwow_fill wrote
-    // for that iteration; nullptr = the counter RNG.  xw_render: RandDt of the crop being rendered (index = sample index within the crop).
+    // k_xorwow_fill wrote for that iteration; nullptr = the counter RNG.  xw_render: RandDt of the crop being rendered (index = sample index within the crop).
     const float* xw[2]; const float* xw_render;
 };
 // one uniform of training iteration `step`, stream kStreamXY / kStreamColor / kStreamDt (index semantics of the reference's arrays: nerf_model.cu:395-396,
@@ -83,8 +81,8 @@ struct BatchPtrs {
     // per-ray results
     float *rgb_ray, *depth_ray, *mask_ray, *loss_ray;
     // level-tile encode: the compacted batch's ray records, 12 floats per training ray {rgba bits, t0, t1, d[3], o[3], target depth, candidate index bits, 0},
-    // written by the
-    // position pass (k_sample_points / k_optimizer's position blocks) so that k_fused_train<PRE> needs neither the ballot scan nor the candidate select
+    // written by the position pass (k_sample_points / k_optimizer's position blocks) so that k_fused_train<PRE> needs neither the ballot scan nor the candidate
+    // select
     float* ray_rec;
 };
 
@@ -101,9 +99,8 @@ struct ParamPtrs {
     // --
     float* rec;
                         // instead of the four arrays above (which are null then): late in training a few per cent of the chunks are touched, and a touched
-                        // chunk among
-                        // untouched ones is then one full line, not four half-used 64-byte sectors.  nullptr = the arrays (small tables: every chunk is
-                        // streamed anyway)
+                        // chunk among untouched ones is then one full line, not four half-used 64-byte sectors.  nullptr = the arrays (small tables: every
+                        // chunk is streamed anyway)
     float* gmlp;        // fp32 dW [n_mlp]
     uint16_t* ggrid;    // fp16 grid gradient [n_grid], accumulated with global_atomic_pk_add_f16
     // fused backend: dense fp16 partial gradient tables from k_grid_scatter (stride in halves); nullptr = unused
@@ -323,8 +320,7 @@ struct Model {
     bool lazy_ema = false, ema_pending = false;   // large tables: EMA of untouched chunks is brought up to date on demand (k_ema_finalize)
     bool scatter_pending = false;   // a fused forward/backward was enqueued whose slot counter has not been reset by an optimizer step yet
     // XORWOW sample stream: lane states of the training generator (device), the two per-parity array sets, the iteration the fills have reached, the per-Render
-    // generator
-    // xw_offset: values the training generator has produced
+    // generator xw_offset: values the training generator has produced
     void* d_xw_states = nullptr; float* d_xw = nullptr; uint32_t xw_filled = 0, xw_lanes = 0; int xw_flavour = 0; uint32_t enq_iter = 0; uint64_t xw_offset = 0;
     void* d_xw_render_states = nullptr; void* d_xw_render_init = nullptr; float* d_xw_render = nullptr; size_t xw_render_cap = 0;
     // NeRF_Model::Step schedule (option step_variant): per-ray sample counts / slots, the compacted positions

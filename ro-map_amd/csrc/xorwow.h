@@ -1,8 +1,8 @@
 // xorwow.h -- the reference's sample stream for the "same inputs" mode (mon_config::rng_flags bits 0-1; default off: the counter RNG of device_common.h).
 //
 // NeRF_Model draws its three per-iteration arrays -- SampleXY[2R], RandColors[3R], RandDt[S R] -- with curandGenerateUniform from ONE host generator of the
-// default
-// kind (XORWOW) and the default seed (CORE/src/nerf_model.cu:1432,1434,1468; no seed call anywhere), and the render jitter from a NEW generator per Render
+// default kind (XORWOW) and the default seed (CORE/src/nerf_model.cu:1432,1434,1468; no seed call anywhere), and the render jitter from a NEW generator per
+// Render
 // (:1725-1728,1781).  For a comparison with the CUDA build on identical inputs the same numbers are produced here:
 //   * Marsaglia's xorwow: x[0..4] + Weyl counter d;  t = x0 ^ (x0 >> 2); x0..x3 = x1..x4; x4 = (x4 ^ (x4 << 4)) ^ (t ^ (t << 1)); d += 362437; out = x4 + d;
 // * host-API ordering (cuRAND documentation, CURAND_ORDERING_PSEUDO_DEFAULT): value n of a generate call = position (n mod LANES) 2^67 + floor(n / LANES) of

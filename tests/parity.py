@@ -35,7 +35,8 @@ def close_half(got_u16, want_u16, what, ulps=2.0, scale=None, frac_ok=1.0):
 def close_f32(got, want, what, atol, rtol=0.0):
     g, w = np.asarray(got, np.float64), np.asarray(want, np.float64)
     err = np.abs(g - w); tol = atol + rtol * np.abs(w)
-    assert (err <= tol).all(), "%s: max err %.3e at %d (tol %.3e)" % (what, err.max(), int(err.argmax()), float(np.ravel(tol)[err.argmax()] if np.ndim(tol) else tol))
+    assert (err <= tol).all(), "%s: max err %.3e at %d (tol %.3e)" % (what, err.max(), int(err.argmax()),
+            float(np.ravel(tol)[err.argmax()] if np.ndim(tol) else tol))
     return float((g == w).mean())
 
 

@@ -78,7 +78,8 @@ def test_config_reader_survives_damaged_files(pkg, tmp_path):
     f.write_text("[" * 100000)
     with pytest.raises(pkg.MonError):
         pkg.config_from_json(str(f))
-    f.write_text('{"encoding": {"otype": "HashGrid", "n_levels": 99, "n_features_per_level": 2, "log2_hashmap_size": 40}, "network": {"n_neurons": 64, "n_hidden_layers": 1}}')
+    f.write_text('{"encoding": {"otype": "HashGrid", "n_levels": 99, "n_features_per_level": 2, "log2_hashmap_size": 40}, '
+                 '"network": {"n_neurons": 64, "n_hidden_layers": 1}}')
     try:
         c = pkg.config_from_json(str(f))
     except pkg.MonError:
@@ -199,7 +200,8 @@ def test_diagnostics_live_in_their_own_library(pkg):
 def test_options_are_an_explicit_interface(pkg):
     """Test and tuning switches go through mon_set_option / mon_get_option; the product library reads no environment variables."""
     assert pkg.get_option("big_switch") == 16384 and pkg.get_option("backend") == -1 and pkg.get_option("offline_inner") == 500
-    assert pkg.get_option("train_lanes") == 2 and pkg.get_option("lane_chunk") == 16 and pkg.get_option("online_slice_min") == 2      # the per-device scheduler's defaults
+    # the per-device scheduler's defaults
+    assert pkg.get_option("train_lanes") == 2 and pkg.get_option("lane_chunk") == 16 and pkg.get_option("online_slice_min") == 2
     pkg.set_option("keep_zero_samples", 1); assert pkg.get_option("keep_zero_samples") == 1; pkg.set_option("keep_zero_samples", 0)
     with pytest.raises(pkg.MonError):
         pkg.set_option("no_such_switch", 1)

@@ -29,7 +29,8 @@ def test_online_replay_at_500_iterations_on_base_json(pkg, ss):
     t_start = time.perf_counter()
     for v in range(sc.n_views):
         t_next = t_start + (v + 1) * period
-        t0 = time.perf_counter(); m.new_frame(v, "%.6f" % (v * 0.1), sc.rgb[v][..., ::-1], sc.instance[v], ss.colmajor(sc.Twc[v])); t_frame.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); m.new_frame(v, "%.6f" % (v * 0.1), sc.rgb[v][..., ::-1], sc.instance[v], ss.colmajor(sc.Twc[v]))
+        t_frame.append(time.perf_counter() - t0)
         for k, ob in enumerate(sc.objects):
             if k not in ids:
                 ids[k] = m.create_nerf(ob["cls"], ss.colmajor(ob["Tow"]), -ob["half"] / 1.1, ob["half"] / 1.1)
@@ -41,7 +42,8 @@ def test_online_replay_at_500_iterations_on_base_json(pkg, ss):
         time.sleep(max(0.0, t_next - time.perf_counter()))
     m.wait_threads_end()
     ms = lambda a: (1e3 * float(np.mean(a)), 1e3 * float(np.max(a)))
-    print("NewFrameToDataset mean %.2f max %.2f ms; UpdateNeRFBbox mean %.3f max %.2f ms; viewer crop mean %.2f max %.2f ms" % (ms(t_frame) + ms(t_box) + ms(t_render)))
+    print("NewFrameToDataset mean %.2f max %.2f ms; UpdateNeRFBbox mean %.3f max %.2f ms; viewer crop mean %.2f max %.2f ms"
+          % (ms(t_frame) + ms(t_box) + ms(t_render)))
     # the reference holds every object's dataset mutex for a whole 500-iteration Train_Step_Online around these calls (tens of ms on its own hardware)
     assert ms(t_frame)[0] < 6.0 and ms(t_frame)[1] < 60.0
     assert ms(t_box)[0] < 1.0 and ms(t_box)[1] < 20.0
@@ -70,7 +72,8 @@ def test_stress_shape_eight_t22_objects_concurrently_on_one_gpu(pkg, ss):
         assert o.info().n_params == 3072 + 2 * 52727808 and int(o.info().backend) == 1
         objs.append(o)
     l0 = [o.train(1) for o in objs]
-    warm = 200                                                    # the first ~100 steps are optimizer-bound (most of the 13 M chunks still receive gradients: ~1 ms per object-step)
+    # the first ~100 steps are optimizer-bound (most of the 13 M chunks still receive gradients: ~1 ms per object-step)
+    warm = 200
     th = [threading.Thread(target=o.train, args=(warm,)) for o in objs]
     [t.start() for t in th]; [t.join() for t in th]
     pkg.lib().mon_device_synchronize(0); t0 = time.perf_counter()
@@ -118,7 +121,8 @@ def test_concurrent_objects_train_exactly_like_lone_ones(pkg, ss):
     # same stream -- every chunk must still be ordered behind the object's previous one (a stale end-of-call mark once let two chunks run side by side)
     flip = threading.Event()
 
-    def flipper():                                                # (the first chunks of the calls go where the previous calls ended -- no switch -- before the first flip)
+    # (the first chunks of the calls go where the previous calls ended -- no switch -- before the first flip)
+    def flipper():
         v = 0; time.sleep(0.003)
         while not flip.is_set():
             pkg.set_option("train_lanes", v); v = 2 - v; time.sleep(0.001)
@@ -171,7 +175,8 @@ def test_viewer_renders_from_published_snapshots_while_the_object_trains(pkg, ss
         assert np.isfinite(rgb).all() and st % 16 == 0 and st > 0
     stop.set(); th.join(); assert not err, err
     assert len(steps) > 20 and steps == sorted(steps) and steps[-1] > steps[0]
-    print("snapshot renders while training: %d, mean %.2f ms, max %.2f ms; steps %d .. %d" % (len(lat), 1e3 * np.mean(lat), 1e3 * np.max(lat), steps[0], steps[-1]))
+    print("snapshot renders while training: %d, mean %.2f ms, max %.2f ms; steps %d .. %d" % (len(lat), 1e3 * np.mean(lat), 1e3 * np.max(lat), steps[0],
+            steps[-1]))
     assert np.mean(lat) < 0.02
     obj.train(64)                                                    # a call of 64 or more iterations always publishes
     a = obj.render_snapshot(box, pose); b = obj.render(box, pose)

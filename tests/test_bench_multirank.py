@@ -13,7 +13,8 @@ from conftest import ROOT
 
 
 def _run(args, timeout=900, env=None):
-    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MON_BENCH_DIST_BACKEND")}, **(env or {}))
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MON_BENCH_DIST_BACKEND")},
+            **(env or {}))
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
 
 
@@ -39,8 +40,8 @@ def test_two_self_spawned_ranks_report_two_gpus_and_gather_both_crops(pkg):
     assert r1.returncode == 0, r1.stderr[-3000:]
     j1 = _json_line(r1.stdout)
     assert j1["n_gpus"] == 1 and len(j1["psnr_db"]) == 1 and j1["config"]["launcher"] == "single process" and j1["render_gather"] is None
-    # whole-job value = the ray-samples of ALL ranks over the slowest rank's time (two processes sharing one GPU slow each other down by an amount that varies from
-    # run to run, so nothing is claimed against the one-rank value): n_gpus x R x S per step time, and every rank's own rate is at least the slowest rank's
+    # whole-job value = the ray-samples of ALL ranks over the slowest rank's time (two processes sharing one GPU slow each other down by an amount that varies
+    # from run to run, so nothing is claimed against the one-rank value): n_gpus x R x S per step time, and every rank's own rate is at least the slowest rank's
     B = 4096 * 32
     for j, n in ((j1, 1), (j2, 2)):
         assert abs(j["value"] - n * B / (1e-3 * j["ms_per_step"])) < 2e-3 * j["value"], (j["value"], j["ms_per_step"])
@@ -66,7 +67,8 @@ def test_a_gather_that_cannot_finish_does_not_take_the_bench_line_with_it(pkg):
     """The throughput is complete before the final render is gathered; a gather that hangs or fails (here: a deadline of zero seconds) must leave the JSON line,
     with the failure named in it and rank 0's own crop scored."""
     assert pkg.device_count() >= 1
-    r = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--objects-per-gpu", "0", "--views", "12"], env={"MON_BENCH_GATHER_TIMEOUT": "0"})
+    r = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--objects-per-gpu", "0", "--views", "12"],
+            env={"MON_BENCH_GATHER_TIMEOUT": "0"})
     assert r.returncode == 0, r.stderr[-3000:]
     j = _json_line(r.stdout)
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["render_gather"].startswith("FAILED") and len(j["psnr_db"]) == 1

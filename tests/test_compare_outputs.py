@@ -1,5 +1,5 @@
-"""tools/compare_with_reference_outputs.py (the diff of a CUDA-reference run's output directory against ours) on synthetic directories in the
-reference's layout (nerf.cu:255-349): identical runs pass, a slightly noisy run passes, a visibly different one and a missing image do not."""
+"""tools/compare_with_reference_outputs.py (the diff of a CUDA-reference run's output directory against ours) on synthetic directories in
+the reference's layout (nerf.cu:255-349): identical runs pass, a slightly noisy run passes, a visibly different one and a missing image do not."""
 import os
 import subprocess
 import sys
@@ -32,7 +32,8 @@ def _write(root, oid, rng, noise, shift=0.0, drop=None):
 
 def _ply(path, v):
     with open(path, "w") as f:
-        f.write("ply\nformat ascii 1.0\ncomment test\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nelement face 0\nproperty list uchar int vertex_indices\nend_header\n" % (len(v) + 2))
+        f.write("ply\nformat ascii 1.0\ncomment test\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nelement face 0\n"
+                "property list uchar int vertex_indices\nend_header\n" % (len(v) + 2))
         for p in v:
             f.write("%0.5f %0.5f %0.5f\n" % tuple(p))
         f.write("0.00000 0.00000 0.00000\n0.00000 0.00000 0.00000\n")              # the reference's zero padding

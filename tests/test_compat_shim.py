@@ -13,7 +13,8 @@ from conftest import ROOT
 
 def _build(tmp_path):
     exe = str(tmp_path / "compat_driver")
-    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "tests", "compat_stubs"), "-I" + os.path.join(ROOT, "ro-map_amd", "compat"),
+    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "tests", "compat_stubs"), "-I" + os.path.join(ROOT,
+            "ro-map_amd", "compat"),
            "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "ro-map_amd", "compat", "mon_compat.cpp"), os.path.join(ROOT, "tests", "compat_driver.cpp"),
            "-o", exe, "-L" + os.path.join(ROOT, "ro-map_amd"), "-lmon_core", "-Wl,-rpath," + os.path.join(ROOT, "ro-map_amd"), "-lpthread"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
@@ -64,9 +65,11 @@ def test_shim_runs_the_offline_and_online_call_sequences(pkg, ss, tmp_path):
     o = _kv(r.stdout, "online idx=")
     assert int(o["idx"]) == 0 and int(o["unknown_frame"]) == -1 and int(o["frame5"]) == 5 and int(o["n_boxes"]) == len(sc.objects[0]["boxes"])
     assert int(o["mesh_indices"]) > 300 and int(o["gl_state_balance"]) == 0
-    mem = _kv(r.stdout, "online_members ")          # UpdateDataset / NeRF::GetTwc / mnBbox / mInstanceId / DrawMesh (interface members without a consumer today)
+    # UpdateDataset / NeRF::GetTwc / mnBbox / mInstanceId / DrawMesh (interface members without a consumer today)
+    mem = _kv(r.stdout, "online_members ")
     nb = len(sc.objects[0]["boxes"]); last = int(sc.objects[0]["boxes"][-1][0])
-    assert int(mem["n_obj_twc"]) == nb and int(mem["mnBbox"]) == nb and int(mem["instance"]) == sc.objects[0]["cls"] and abs(float(mem["twc_last_tx"]) - sc.Twc[last][0, 3]) < 1e-4
+    assert int(mem["n_obj_twc"]) == nb and int(mem["mnBbox"]) == nb and int(mem["instance"]) == sc.objects[0]["cls"]
+    assert abs(float(mem["twc_last_tx"]) - sc.Twc[last][0, 3]) < 1e-4
     root = os.path.join(out2, "0")
     assert len(open(os.path.join(root, "test.txt")).read().strip().split("\n")) == 3
     assert os.path.exists(os.path.join(root, "test_img", o["stamp0"] + ".png")) and os.path.exists(os.path.join(root, "video_img", "59.png"))

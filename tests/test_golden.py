@@ -12,7 +12,8 @@ def test_oracle_reproduces_golden(orc, ss, name):
     m = ge.make_oracle(orc, sc, CFGS[name]); m.set_params(pattern_params(m))
     m.generate_batch(); m.forward_backward()
     assert m.n_valid == int(g["n_valid"])
-    for b in ("ray_o", "ray_d", "ray_t0", "ray_t1", "target", "bgcol", "ray_flag", "pts", "tdist", "E", "O", "dO", "dE", "rgb_ray", "depth_ray", "mask_ray", "loss_ray"):
+    for b in ("ray_o", "ray_d", "ray_t0", "ray_t1", "target", "bgcol", "ray_flag", "pts", "tdist", "E", "O", "dO", "dE", "rgb_ray", "depth_ray", "mask_ray",
+            "loss_ray"):
         assert np.array_equal(m.buffer(b)[:g[b].size], g[b]), b
     close_f32(m.buffer("gmlp"), g["gmlp"], "gmlp", 1e-6, 1e-5)            # OpenMP partial sums: order may differ
     gi = grid_probe_indices(m.n_params - m.n_mlp)

@@ -97,9 +97,11 @@ def test_mesh_matches_golden_fixture(pkg, ss):
     g = load_golden("mesh")
     m = pkg.marching_cubes(mc_field(MC_RES), MC_RES, 0.0, *MC_BOX)
     assert m["n_verts_real"] == int(g["mc_n_real"]) and np.array_equal(m["indices"], g["mc_indices"])
-    assert np.array_equal(m["verts"].view(np.uint32), g["mc_verts"].view(np.uint32)) and np.array_equal(m["normals_raw"].view(np.uint32), g["mc_normals_raw"].view(np.uint32))
+    assert np.array_equal(m["verts"].view(np.uint32), g["mc_verts"].view(np.uint32)) and np.array_equal(m["normals_raw"].view(np.uint32),
+            g["mc_normals_raw"].view(np.uint32))
     sc = ss.make_scene(**SCENE); ds, obj = ge.make_problem(pkg, sc, CFGS["c1"])
-    k = np.arange(obj.info().n_grid_params, dtype=np.float64); p = obj.get_params(0); p[obj.info().n_mlp_params:] = (0.5 * np.sin(0.37 * k)).astype(np.float32)   # parity.pattern_params
+    # parity.pattern_params
+    k = np.arange(obj.info().n_grid_params, dtype=np.float64); p = obj.get_params(0); p[obj.info().n_mlp_params:] = (0.5 * np.sin(0.37 * k)).astype(np.float32)
     obj.set_params(p)
     # (a) the layer-at-a-time network (fp32 sums in the oracle's order): the lattice equals the oracle's bit for bit, and so does the geometry
     old = pkg.get_option("tile_render"); pkg.set_option("tile_render", 0)
@@ -108,7 +110,8 @@ def test_mesh_matches_golden_fixture(pkg, ss):
     finally:
         pkg.set_option("tile_render", old)
     assert o["n_verts_real"] == int(g["obj_n_real"]) and np.array_equal(o["indices"], g["obj_indices"])
-    assert np.array_equal(o["verts"].view(np.uint32), g["obj_verts"].view(np.uint32)) and np.array_equal(o["normals"].view(np.uint32), g["obj_normals"].view(np.uint32))
+    assert np.array_equal(o["verts"].view(np.uint32), g["obj_verts"].view(np.uint32)) and np.array_equal(o["normals"].view(np.uint32),
+            g["obj_normals"].view(np.uint32))
     assert np.abs(o["colors"].astype(int) - g["obj_colors"].astype(int)).max() <= 1
     # (b) the default since round 4: level tiles + the MFMA network (kernels_tilerender.hip).  Its fp16 outputs are those of the renderer -- within one fp16
     # ulp of the oracle's on a fraction of a percent of the points (MFMA summation order) --, so the surface has the same topology and its vertices move by

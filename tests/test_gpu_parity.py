@@ -64,8 +64,8 @@ def test_batch_generation_matches_oracle(pkg, orc, small_scene, kw, use_depth):
 @pytest.mark.parametrize("hw", [(45, 67), (61, 83)], ids=["45x67", "61x83"])
 def test_ragged_image_sizes_upload_exactly(pkg, orc, ss, hw):
     """Frames whose pixel count is not a multiple of 4 or 16 (the upload packs them with a kernel out of pinned staging, depth and pose behind the colour and
-    instance bytes at 16-byte steps): every frame re-uses the same staging addresses, so a misaligned or out-of-date read shows up as a candidate mismatch in some
-    later frame -- the batch of 4096 candidates over all frames is compared with the oracle's, with and without depth."""
+    instance bytes at 16-byte steps): every frame re-uses the same staging addresses, so a misaligned or out-of-date read shows up as a candidate mismatch in
+    some later frame -- the batch of 4096 candidates over all frames is compared with the oracle's, with and without depth."""
     sc = ss.make_scene(n_views=12, H=hw[0], W=hw[1], f=55.0, seed=9)
     for use_depth in (False, True):
         kw = dict(rays_per_batch=4096, n_levels=4, n_neurons=32, n_hidden_layers=2)
@@ -158,8 +158,8 @@ def test_forward_backward_matches_oracle_and_golden(pkg, orc, ss, name, backend)
 
 @pytest.mark.parametrize("name,kw", [("c2s", dict(CFGS["c2s"])), ("c2", dict(C2))], ids=["c2s-R256", "c2-R4096"])
 def test_benched_chain_forward_backward_matches_oracle(pkg, orc, ss, name, kw):
-    """The instantiation bench.py times -- k_encode_tiles -> k_fused_train<PRE> -> k_grid_scatter -- against the oracle DIRECTLY (the other oracle comparisons of
-    backend 1 run the gather chain's dump variant): mon_object_set_debug_dump(obj, 2) keeps the level-tile chain and compiles the dump into its kernel.
+    """The instantiation bench.py times -- k_encode_tiles -> k_fused_train<PRE> -> k_grid_scatter -- against the oracle DIRECTLY (the other oracle comparisons
+    of backend 1 run the gather chain's dump variant): mon_object_set_debug_dump(obj, 2) keeps the level-tile chain and compiles the dump into its kernel.
     base.json at the full batch (R = 4096) and the fixtures' small batch (level tiles forced)."""
     sc = ss.make_scene(**SCENE)
     old = pkg.get_option("lds_encode"); pkg.set_option("lds_encode", 2)
@@ -297,10 +297,15 @@ def test_nondefault_hyperparameters_match_oracle(pkg, orc, small_scene, backend)
     obj.close(); ds.close(); ref.close()
 
 
-@pytest.mark.parametrize("kw", [dict(log2_hashmap_size=17, n_levels=8, base_resolution=16),        # sizes 4920 / 35944 / 131072 x 6: 64-bit whole, 64-bit per parity, parity halves cut into two ranges
-                                dict(log2_hashmap_size=18, n_levels=6, base_resolution=16),        # 262144-entry levels: four ranges per parity half, one sample partition
-                                dict(log2_hashmap_size=14, n_levels=16, base_resolution=16),       # every hashed level a 64-bit whole-level tile (16384 entries)
-                                dict(log2_hashmap_size=16, n_levels=13, base_resolution=16)],      # base.json's first 13 levels: the last has res = 65536, whose index is x mod 65536 (tcnn's wrapped stride loop): the one-atomic path
+# sizes 4920 / 35944 / 131072 x 6: 64-bit whole, 64-bit per parity, parity halves cut into two ranges
+@pytest.mark.parametrize("kw", [dict(log2_hashmap_size=17, n_levels=8, base_resolution=16),
+                                # 262144-entry levels: four ranges per parity half, one sample partition
+                                dict(log2_hashmap_size=18, n_levels=6, base_resolution=16),
+                                # every hashed level a 64-bit whole-level tile (16384 entries)
+                                dict(log2_hashmap_size=14, n_levels=16, base_resolution=16),
+                                # base.json's first 13 levels: the last has res = 65536, whose index is x mod 65536 (tcnn's wrapped stride loop): the one-atomic
+                                # path
+                                dict(log2_hashmap_size=16, n_levels=13, base_resolution=16)],
                          ids=["T17", "T18", "T14", "T16_res65536"])
 def test_grid_scatter_tile_modes_match_oracle(pkg, orc, small_scene, kw):
     """k_grid_scatter picks a tile shape per level from its size (whole level / one parity half / ranges of a parity half; 32- or 64-bit accumulators):
@@ -376,7 +381,8 @@ def test_training_parity_psnr_c1(pkg, orc, ss, small_scene, backend):
         mu, ah, ar, (l_hip, l_ref) = _trained_pair_scores(pkg, orc, ss, sc, dict(C1, sample_seed=seed), backend, steps)
         assert l_hip < 0.05 and abs(l_hip - l_ref) < max(l_ref, 0.02)          # last-iteration losses of two chaotic runs on the same batch
         mutual += mu; abs_hip += ah; abs_ref += ar
-    print("backend %d: mutual PSNR min %.2f dB (bar %.2f), abs HIP %.2f dB, abs oracle %.2f dB (tol %.2f)" % (backend, min(mutual), mutual_floor, np.mean(abs_hip), np.mean(abs_ref), abs_tol))
+    print("backend %d: mutual PSNR min %.2f dB (bar %.2f), abs HIP %.2f dB, abs oracle %.2f dB (tol %.2f)" % (backend, min(mutual), mutual_floor,
+            np.mean(abs_hip), np.mean(abs_ref), abs_tol))
     # backend 1 is deterministic (integer scatter); backend 0 sums the grid gradient with fp16 global atomics in arrival order, so
     # its trained weights differ from run to run on top of the floor: observed mean-of-3 absolute PSNR 30.4 .. 31.3 dB against the oracle's 31.33 dB
     assert min(mutual) > (mutual_floor if backend == 1 else mutual_floor - 2.0)
@@ -398,7 +404,8 @@ def test_training_parity_psnr_c2_base_json_200_steps(pkg, orc, ss, backend):
         mu, ah, ar, (l_hip, l_ref) = _trained_pair_scores(pkg, orc, ss, sc, dict(C2, sample_seed=21), backend, 200, every=3)
     finally:
         orc.lib().orc_set_parallel_scatter(0); orc.lib().orc_set_threads(int(os.environ.get("MON_ORACLE_THREADS", min(16, os.cpu_count() or 1))))
-    print("C2 backend %d: mutual PSNR min %.2f mean %.2f dB, abs HIP %.2f dB, abs oracle %.2f dB, loss %.5f / %.5f" % (backend, min(mu), np.mean(mu), np.mean(ah), np.mean(ar), l_hip, l_ref))
+    print("C2 backend %d: mutual PSNR min %.2f mean %.2f dB, abs HIP %.2f dB, abs oracle %.2f dB, loss %.5f / %.5f" % (backend, min(mu), np.mean(mu),
+            np.mean(ah), np.mean(ar), l_hip, l_ref))
     assert np.isfinite(l_hip) and abs(l_hip - l_ref) < max(l_ref, 0.02)
     assert min(mu) > (mutual_floor if backend == 1 else mutual_floor - 2.0)
     assert abs(np.mean(ah) - np.mean(ar)) < 2.0 * abs_tol and np.mean(ah) > 24.0          # single seed: twice the mean-of-three tolerance
@@ -436,7 +443,8 @@ def test_full_size_properties_c2(pkg, ss, backend):
     obj.close(); ds.close()
 
 
-@pytest.mark.parametrize("kw", [dict(rays_per_batch=64), dict(rays_per_batch=16384), dict(rays_per_batch=256, n_samples=16), dict(rays_per_batch=128, n_samples=64)],
+@pytest.mark.parametrize("kw", [dict(rays_per_batch=64), dict(rays_per_batch=16384), dict(rays_per_batch=256, n_samples=16),
+        dict(rays_per_batch=128, n_samples=64)],
                          ids=["R64_min", "R16384_fused_max", "S16_unfused", "S64_unfused"])
 def test_size_limits_match_oracle(pkg, orc, small_scene, kw):
     """Smallest / largest batch of the fused kernels (R = 64 .. 16 384 rays, S = 32) and sample counts only the layer-at-a-time kernels
@@ -569,7 +577,8 @@ def test_zero_gradient_skipping_is_exact_and_deterministic():
     from conftest import ROOT
     def run(extra):
         env = dict(os.environ, **extra)
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "param_crc.py"), "3", "150", "250"], capture_output=True, text=True, env=env, timeout=300)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "param_crc.py"), "3", "150", "250"], capture_output=True, text=True, env=env,
+                timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         rows = [ln.split() for ln in r.stdout.strip().split("\n") if ln.startswith("steps+")]
         return [w[2] for w in rows], [int(w[4]) for w in rows]
@@ -581,7 +590,8 @@ def test_zero_gradient_skipping_is_exact_and_deterministic():
 
 
 @pytest.mark.parametrize("kw", [dict(rays_per_batch=256, log2_hashmap_size=19, n_neurons=64, n_hidden_layers=1),
-                                dict(rays_per_batch=256, log2_hashmap_size=20, n_levels=8, per_level_scale=2.0, n_neurons=32, n_hidden_layers=2)], ids=["T19", "T20L8"])
+                                dict(rays_per_batch=256, log2_hashmap_size=20, n_levels=8, per_level_scale=2.0, n_neurons=32, n_hidden_layers=2)], ids=["T19",
+                                        "T20L8"])
 def test_large_tables_mix_lds_and_atomic_levels(pkg, orc, small_scene, kw):
     """Tables beyond 2^18 entries per level: the fine levels scatter with global packed-f16 atomics inside k_fused_train, the coarse ones
     through k_grid_scatter (compacted rows) -- one step against the oracle, then a short run that has to learn."""
@@ -757,13 +767,16 @@ def _level_sizes(cfg):
     return sizes
 
 
-@pytest.mark.parametrize("kw", [C1, dict(rays_per_batch=256), dict(rays_per_batch=320, n_levels=6, base_resolution=20, per_level_scale=1.235, log2_hashmap_size=16),
+@pytest.mark.parametrize("kw", [C1, dict(rays_per_batch=256), dict(rays_per_batch=320, n_levels=6, base_resolution=20, per_level_scale=1.235,
+        log2_hashmap_size=16),
                                 dict(rays_per_batch=8192, n_levels=3, log2_hashmap_size=14)], ids=["c1", "c2net", "dense_parity_levels", "two_chunks"])
 def test_level_tile_encode_matches_oracle_and_the_gather_path(pkg, orc, small_scene, kw):
     """The default forward pass of the fused backend: positions by k_sample_points / k_optimizer's position blocks, hash-grid encode by k_encode_tiles from
     LDS-resident level tiles (whole levels and even / odd parity tiles), features loaded by k_fused_train<PRE>.  Positions and encoded features must equal
-    the oracle's bit for bit, the tile image must be the tile_slot permutation of the fp16 grid, and training must give the same parameters as the gather path."""
-    pkg.set_option("lds_encode", 2)                       # (the default takes the tile chain from 3072 rays up: below that its fixed costs lose against the gathers)
+    the oracle's bit for bit, the tile image must be the tile_slot permutation of the fp16 grid, and training must give the same parameters as the gather
+    path."""
+    # (the default takes the tile chain from 3072 rays up: below that its fixed costs lose against the gathers)
+    pkg.set_option("lds_encode", 2)
     try:
         ds, obj, ref = _pair(pkg, orc, small_scene, kw, 1)
     finally:
@@ -773,7 +786,8 @@ def test_level_tile_encode_matches_oracle_and_the_gather_path(pkg, orc, small_sc
     L, B = obj.cfg.n_levels, obj.R * obj.S
     Ep = obj.info().encoded_width
     def check_batch():
-        x = obj.buffer("x_all").reshape(B, 4); close_f32(x[:, :3], ref.buffer("pts").reshape(B, 3), "positions", 1e-6); close_f32(x[:, 3], ref.buffer("tdist"), "distances", 1e-6)
+        x = obj.buffer("x_all").reshape(B, 4); close_f32(x[:, :3], ref.buffer("pts").reshape(B, 3), "positions", 1e-6)
+        close_f32(x[:, 3], ref.buffer("tdist"), "distances", 1e-6)
         e = obj.buffer("e_soa").reshape(L, B, 2); want = ref.buffer("E").reshape(B, Ep)[:, :2 * L].reshape(B, L, 2).transpose(1, 0, 2)
         assert np.array_equal(e, want), "level-tile encode must be bit-exact (levels differing: %s)" % sorted(set(np.argwhere(e != want)[:, 0].tolist()))
     obj.train_stages(1 | 2); ref.generate_batch(); ref.forward_backward()          # iteration 0: stand-alone position kernel
@@ -813,7 +827,8 @@ def test_level_tile_encode_trains_bit_identically_to_the_gather_path():
     import subprocess, sys
     from conftest import ROOT
     def run(extra):
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "param_crc.py"), "3", "150", "250"], capture_output=True, text=True, env=dict(os.environ, **extra), timeout=300)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "param_crc.py"), "3", "150", "250"], capture_output=True, text=True,
+                env=dict(os.environ, **extra), timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         return [ln.split()[2] for ln in r.stdout.strip().split("\n") if ln.startswith("steps+")]
     a = run({}); b = run({"MON_OPTIONS": "lds_encode=0"}); c = run({"MON_OPTIONS": "use_graph=1"})
@@ -839,9 +854,11 @@ def test_training_parity_c2_three_seeds_against_the_serial_oracle_fixture(pkg, s
             rgb, depth, mask = obj.render(box, ss.colmajor(sc.Twc[v]))
             gm = sc.instance[v, y:y + h, x:x + w] > 0; gt = np.where(gm[..., None], sc.rgb[v, y:y + h, x:x + w] / 255.0, 1.0)
             mutual.append(psnr(rgb, g["rgb_s%d_c%d" % (seed, i)])); a_hip.append(psnr(rgb, gt)); a_ref.append(float(g["psnr_s%d" % seed][i]))
-            assert (mask.astype(bool) != g["mask_s%d_c%d" % (seed, i)].astype(bool)).mean() < 0.02          # the hard 0.5 opacity mask agrees on all but silhouette pixels
+            # the hard 0.5 opacity mask agrees on all but silhouette pixels
+            assert (mask.astype(bool) != g["mask_s%d_c%d" % (seed, i)].astype(bool)).mean() < 0.02
         obj.close(); ds.close()
-    print("C2 x 3 seeds vs serial oracle: mutual PSNR min %.2f mean %.2f dB (bar %.2f), abs HIP %.2f dB, abs oracle %.2f dB (tol %.2f)" % (min(mutual), np.mean(mutual), mutual_floor, np.mean(a_hip), np.mean(a_ref), abs_tol))
+    print("C2 x 3 seeds vs serial oracle: mutual PSNR min %.2f mean %.2f dB (bar %.2f), abs HIP %.2f dB, abs oracle %.2f dB (tol %.2f)" % (min(mutual),
+            np.mean(mutual), mutual_floor, np.mean(a_hip), np.mean(a_ref), abs_tol))
     assert min(mutual) > mutual_floor
     assert abs(np.mean(a_hip) - np.mean(a_ref)) < abs_tol and np.mean(a_hip) > 24.0
 
@@ -862,11 +879,14 @@ def test_parameter_trajectory_against_both_numeric_models_of_the_oracle(pkg, orc
         obj.train(k - done); ref.train(k - done); th.train(k - done); done = k
         a, b, c = obj.get_params(0), ref.buffer("master"), th.buffer("master")
         far = lambda u, v, s: float((np.abs(u[s] - v[s]) > 1e-4).mean())
-        rows.append((k, far(a, b, slice(0, nm)), far(a, b, slice(nm, None)), far(a, c, slice(0, nm)), far(a, c, slice(nm, None)), far(b, c, slice(0, nm)), far(b, c, slice(nm, None))))
+        rows.append((k, far(a, b, slice(0, nm)), far(a, b, slice(nm, None)), far(a, c, slice(0, nm)), far(a, c, slice(nm, None)), far(b, c, slice(0, nm)),
+                far(b, c, slice(nm, None))))
     for r in rows:
         print("step %2d: HIP vs contract MLP %.4f grid %.4f | HIP vs tcnn-half MLP %.4f grid %.4f | contract vs tcnn-half MLP %.4f grid %.4f" % r)
     for k, m_c, g_c, m_t, g_t, m_ct, g_ct in rows:
-        assert m_c <= min(1.0, 5e-3 * 2 * k) and g_c <= min(1.0, 5e-3 * 2 * k), (k, m_c, g_c)          # growth bound: one step leaves < 0.5 % (parity.py), doubling per doubling
-        assert m_c <= m_t + 0.02 and g_c <= g_t + 0.02, (k, m_c, m_t, g_c, g_t)                          # never further from the contract than from the tcnn-half model
+        # growth bound: one step leaves < 0.5 % (parity.py), doubling per doubling
+        assert m_c <= min(1.0, 5e-3 * 2 * k) and g_c <= min(1.0, 5e-3 * 2 * k), (k, m_c, g_c)
+        # never further from the contract than from the tcnn-half model
+        assert m_c <= m_t + 0.02 and g_c <= g_t + 0.02, (k, m_c, m_t, g_c, g_t)
     assert np.isfinite(obj.get_params(0)).all()
     obj.close(); ds.close(); ref.close(); th.close()

@@ -34,7 +34,8 @@ def test_occupancy_skipping_is_opt_in_inert_during_warmup_and_close_afterwards(p
     exact.train(544); skip.train(544)
     t = []
     for o in (exact, skip):
-        pkg.lib().mon_device_synchronize(0); t0 = time.perf_counter(); o.train(200); pkg.lib().mon_device_synchronize(0); t.append((time.perf_counter() - t0) / 200)
+        pkg.lib().mon_device_synchronize(0); t0 = time.perf_counter(); o.train(200); pkg.lib().mon_device_synchronize(0)
+        t.append((time.perf_counter() - t0) / 200)
     (p_e, iou_e), (p_s, iou_s) = _score(exact, sc, ss), _score(skip, sc, ss)
     print("exact %.2f dB IoU %.3f, %.1f us/step; occupancy skipping %.2f dB IoU %.3f, %.1f us/step" % (p_e, iou_e, 1e6 * t[0], p_s, iou_s, 1e6 * t[1]))
     assert zlib.crc32(exact.get_params(0).tobytes()) != zlib.crc32(skip.get_params(0).tobytes())      # it really skipped something
@@ -67,9 +68,9 @@ def test_occupancy_grid_keeps_refreshing_under_hipgraph_replay_after_an_odd_iter
 
 
 def test_occupancy_skipping_trains_identically_on_either_forward_chain_and_across_the_switch(pkg, ss):
-    """With the grid in use the library picks the forward chain per train call: level tiles (k_encode_tiles + k_fused_train<PRE, OCC>) while most samples carry a
-    gradient, the gathers inside k_fused_train<OCC> once few do (they are skipped for the samples in empty cells).  Both chains must leave the same parameters bit
-    for bit, also when a run changes from one to the other: five calls of 160 steps against a run that stays on the gather chain (option lds_encode = 0)."""
+    """With the grid in use the library picks the forward chain per train call: level tiles (k_encode_tiles + k_fused_train<PRE, OCC>) while most samples carry
+    a gradient, the gathers inside k_fused_train<OCC> once few do (they are skipped for the samples in empty cells).  Both chains must leave the same parameters
+    bit for bit, also when a run changes from one to the other: five calls of 160 steps against a run that stays on the gather chain (option lds_encode = 0)."""
     assert pkg.device_count() >= 1
     sc = ss.make_scene(n_views=16, H=240, W=320, f=260.0, seed=2)
     crcs = []
@@ -81,7 +82,8 @@ def test_occupancy_skipping_trains_identically_on_either_forward_chain_and_acros
             for _ in range(5):
                 obj.train(160); c.append(zlib.crc32(obj.get_params(0).tobytes()))
             last, due = obj.occupancy_state(); assert last > 0                      # the grid was refreshed and is in use
-            if lds and not graph:                                                   # ... and the change of chain did happen: a further call launches no k_encode_tiles (kernel class 6)
+            # ... and the change of chain did happen: a further call launches no k_encode_tiles (kernel class 6)
+            if lds and not graph:
                 obj.set_profiling(True); obj.profile(reset=True); obj.train(8); prof = obj.profile(reset=True); obj.set_profiling(False)
                 assert prof["launches"][6] == 0 and prof["launches"][1] == 8, prof["launches"]
             crcs.append(c); obj.close(); ds.close()

@@ -265,7 +265,8 @@ def test_mlp_forward_backward_vs_fp64(orc, small_scene, kw):
     want = np.zeros_like(gg); cnt = np.zeros(gg.shape[0])
     for l, _, idx, w in _numpy_corners(cfg, pts):
         np.add.at(want[:, 0], idx, w * got_dE[:, 2 * l]); np.add.at(want[:, 1], idx, w * got_dE[:, 2 * l + 1]); np.add.at(cnt, idx, 1)
-    tol_e = 2.0 ** -10 * ga + cnt[:, None] * 2.0 ** -25 + 1e-9       # per contribution: half an fp16 ulp, or half the smallest subnormal (2^-24) where it underflows
+    # per contribution: half an fp16 ulp, or half the smallest subnormal (2^-24) where it underflows
+    tol_e = 2.0 ** -10 * ga + cnt[:, None] * 2.0 ** -25 + 1e-9
     bad = np.abs(gg - want) > tol_e
     assert not bad.any(), "grid gradient: %d entries off, worst %.3e at entry %d" % (bad.sum(), np.abs(gg - want).max(), int(np.abs(gg - want).max(1).argmax()))
     assert (want != 0).any(1).sum() > 1000 and ((gg != 0).any(1) == (np.abs(want) > 0).any(1)).mean() > 0.999      # the same entries are touched
@@ -277,7 +278,8 @@ def test_mlp_forward_backward_vs_fp64(orc, small_scene, kw):
 @pytest.mark.parametrize("use_depth", [False, True])
 def test_end_to_end_gradients_match_torch_autograd(orc, small_scene, kw, use_depth):
     """encode -> MLP -> composite -> loss on a 64-ray batch as ONE fp64 torch graph (the table and the matrices are leaves; corner indices and weights from the
-    NumPy re-derivation of tcnn's walk), its autograd gradients against the oracle's hand-written backward chain: gmlp (dW of every layer) and the grid gradient.
+    NumPy re-derivation of tcnn's walk), its autograd gradients against the oracle's hand-written backward chain: gmlp (dW of every layer) and the grid
+    gradient.
     The oracle also rounds dL/dO, dh, dE and every scatter contribution to fp16 (tcnn's network precision): agreement is to a few 1e-3 of the gradient scale."""
     torch = pytest.importorskip("torch")
     import __graft_entry__ as ge

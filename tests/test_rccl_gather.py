@@ -57,7 +57,8 @@ def test_gathered_crops_equal_the_objects_own_renders(pkg, ss):
     for o in objs:
         o.train(120)
     g = pkg.Gather(0)
-    boxes = [sc.objects[k]["boxes"][2] for k in range(3)]; boxes[1] = np.array([int(boxes[1][0]), 0, 0, sc.H, sc.W], np.uint32)      # one whole frame among the crops
+    # one whole frame among the crops
+    boxes = [sc.objects[k]["boxes"][2] for k in range(3)]; boxes[1] = np.array([int(boxes[1][0]), 0, 0, sc.H, sc.W], np.uint32)
     poses = [ss.colmajor(sc.Twc[int(b[0])]) for b in boxes]
     got = g.renders(objs, boxes, poses)
     for o, b, T, (rgb, dep, msk) in zip(objs, boxes, poses, got):

@@ -44,7 +44,8 @@ obj.close(); ds.close(); dist.destroy_process_group()
 def test_rccl_communicator_moves_a_device_resident_crop():
     import __graft_entry__ as ge
     assert ge.load_package().device_count() >= 1, "no HIP device visible: the GPU tests must run on the MI355X box"
-    env = dict(os.environ, MON_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env = dict(os.environ, MON_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY",
+            "0"))
     r = subprocess.run([sys.executable, "-c", WORKER], capture_output=True, text=True, env=env, timeout=420)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     import json

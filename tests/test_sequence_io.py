@@ -61,7 +61,8 @@ def test_png_reader_takes_what_cv_imread_takes(pkg, tmp_path):
     got = pkg.png_read(str(tmp_path / "p8.png")); want = palette.reshape(-1, 3)[idx]
     assert got.shape == (H, W, 3) and np.array_equal(got, want) and np.array_equal(pkg.png_read(str(tmp_path / "p4.png")), want)
     pal.save(tmp_path / "pt.png", transparency=2)                             # tRNS: palette entry 2 fully transparent -> RGBA like libpng's expand
-    got = pkg.png_read(str(tmp_path / "pt.png")); assert got.shape == (H, W, 4) and np.array_equal(got, np.asarray(Image.open(tmp_path / "pt.png").convert("RGBA")))
+    got = pkg.png_read(str(tmp_path / "pt.png"))
+    assert got.shape == (H, W, 4) and np.array_equal(got, np.asarray(Image.open(tmp_path / "pt.png").convert("RGBA")))
     bw = (rs.rand(H, W) > 0.5); Image.fromarray(bw).save(tmp_path / "g1.png")           # 1-bit gray
     assert np.array_equal(pkg.png_read(str(tmp_path / "g1.png"))[..., 0], bw.astype(np.uint8) * 255)
     # 2- and 4-bit gray, written by hand (Pillow only writes them for palettes): packed samples, filter 0
@@ -88,10 +89,12 @@ def test_png_reader_takes_what_cv_imread_takes(pkg, tmp_path):
         if sub.size:
             raw += b"".join(b"\x00" + sub[r].tobytes() for r in range(sub.shape[0]))
     def chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
-    (tmp_path / "i.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    (tmp_path / "i.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 1)) + chunk(b"IDAT",
+            zlib.compress(raw)) + chunk(b"IEND", b""))
     assert np.array_equal(np.asarray(Image.open(tmp_path / "i.png")), rgb) and np.array_equal(pkg.png_read(str(tmp_path / "i.png")), rgb)
     # a 12-byte IHDR (crafted) must be refused, not read past
-    (tmp_path / "short.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBB", W, H, 8, 2, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\x00" * 64)) + chunk(b"IEND", b""))
+    (tmp_path / "short.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBB", W, H, 8, 2, 0, 0)) + chunk(b"IDAT",
+            zlib.compress(b"\x00" * 64)) + chunk(b"IEND", b""))
     with pytest.raises(pkg.MonError):
         pkg.png_read(str(tmp_path / "short.png"))
 
@@ -160,7 +163,8 @@ def test_offline_nerf_flow_on_disk_sequence(pkg, ss, tmp_path):
     m.close()
     # the headless executable, same sequence, 1 object
     exe = os.path.join(ROOT, "ro-map_amd", "offline_nerf")
-    r = subprocess.run([exe, os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json"), seq, "0", "1", str(tmp_path / "out2")], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json"), seq, "0", "1", str(tmp_path / "out2")], capture_output=True,
+            text=True, timeout=300)
     assert r.returncode == 0 and "Training completed" in r.stdout, r.stdout + r.stderr
     assert os.path.exists(os.path.join(str(tmp_path / "out2"), "0", "test_img"))
 
@@ -214,7 +218,8 @@ def test_online_manager_incremental_flow(pkg, ss, tmp_path):
         if v == 8:
             time.sleep(0.3)
             assert all(m.object_info(i)["train_calls"] == 0 for i in ids.values())      # <= 10 boxes: no training yet (nerf.cu:223)
-        if v == 20:                                                  # an id that is already in use is overwritten: the one case that excludes the training threads
+        # an id that is already in use is overwritten: the one case that excludes the training threads
+        if v == 20:
             m.new_frame(3, "%.6f" % 0.3, sc.rgb[3][..., ::-1], sc.instance[3], ss.colmajor(sc.Twc[3]), sc.depth[3])
         if v in (14, 18, 22):                                        # a viewer reads while the training threads run (let in between two slices)
             for i in ids.values():
@@ -231,7 +236,8 @@ def test_online_manager_incremental_flow(pkg, ss, tmp_path):
         iou = ((mask > 0.5) & gm).sum() / max(1, ((mask > 0.5) | gm).sum())
         assert iou > 0.8, (k, iou)
         mesh = m.object(i).get_mesh(try_lock=True)                    # DrawMesh(idx)'s data
-        bo = m.object(i); assert bo.cfg.rays_per_batch == 1024 and int(bo.buffer("state")[0]) == bo.info().train_step > 0 and bo.mesh_generation() >= 1   # the borrowed handle is a full object
+        # the borrowed handle is a full object
+        bo = m.object(i); assert bo.cfg.rays_per_batch == 1024 and int(bo.buffer("state")[0]) == bo.info().train_step > 0 and bo.mesh_generation() >= 1
         assert mesh["n_verts_real"] > 50 and mesh["indices"].max() < mesh["n_verts_real"]
     # RenderNeRFsTest (System.cc:610): test images, test.txt / train.txt, 360-degree video, obj.ply
     from PIL import Image

@@ -41,7 +41,8 @@ def _worker(rank, world, port, q):
         ks = sh.objects_of_rank(n_objects, world, r)
         ok &= len(got[r]) == len(ks)
         for (rgb, depth, mask), k in zip(got[r], ks):
-            ok &= rgb.shape == (3 + k, 4 + 2 * k, 3) and float(rgb[0, 0, 0]) == k + 0.25 and float(depth[-1, -1]) == k + 0.5 and float(mask[0, 0]) == float(k % 2)
+            ok &= rgb.shape == (3 + k, 4 + 2 * k, 3) and float(rgb[0, 0, 0]) == k + 0.25 and float(depth[-1, -1]) == k + 0.5 and float(mask[0,
+                    0]) == float(k % 2)
     # a second gather with another root and an empty contribution from this rank's side when it has nothing to send
     got2 = sh.gather_crops(dist, torch, crops if rank == 0 else [], "cpu", root=1)
     ok &= (got2 is None) == (rank != 1)

@@ -39,7 +39,8 @@ def test_tile_render_is_bit_identical_to_the_gather_render(pkg, orc, ss, name, t
         box = np.array(bx, np.uint32); pose = ss.colmajor(sc.Twc[int(box[0])])
         (rgb0, d0, m0), (rgb1, d1, m1) = _render_both(pkg, obj, box, pose, tile_option)
         assert rgb1.shape == (int(box[3]), int(box[4]), 3)
-        assert np.array_equal(m0, m1) and np.array_equal(rgb0.view(np.uint32), rgb1.view(np.uint32)) and np.array_equal(d0.view(np.uint32), d1.view(np.uint32)), bx
+        assert np.array_equal(m0, m1) and np.array_equal(rgb0.view(np.uint32), rgb1.view(np.uint32)) and np.array_equal(d0.view(np.uint32),
+                d1.view(np.uint32)), bx
     box = np.array(g["render_box"], np.uint32); Toc = ss.colmajor(sc.objects[0]["Tow"] @ sc.Twc[int(box[0])])
     (rgb0, d0, m0), (rgb1, d1, m1) = _render_both(pkg, obj, box, Toc, tile_option, pose_is_Toc=True)
     assert np.array_equal(m0, m1) and np.array_equal(rgb0, rgb1) and np.array_equal(d0, d1) and m1.mean() > 0.02

@@ -3,7 +3,8 @@
      against the real thing: librocrand's HOST generator (ROCRAND_RNG_PSEUDO_XORWOW, default seed) running on the device -- rocRAND uses LANES = 131072
      (tools/xorwow_probe.py; cuRAND documents 4096), the reference's per-iteration call sizes and awkward ones.
   2. The HIP path in XORWOW mode (k_xorwow_fill + the consumers) against the oracle in the same mode: batch generation bit for bit, training, render.
-cuRAND itself is not in the image: its flavour differs from the pinned one in four seeding constants and the 2^-33 of _curand_uniform (CURAND-A1/A2)."""
+cuRAND itself is not in the image: its flavour differs from the pinned one in four seeding constants and the 2^-33 of _curand_uniform (CURAND-A1/A2, DESIGN.md
+1)."""
 import ctypes as C
 
 import numpy as np
@@ -22,7 +23,8 @@ def _p(a):
 
 def test_rocrand_host_generator_matches_the_oracle_stream(pkg, orc):
     assert pkg.device_count() >= 1, "no HIP device visible: the GPU tests must run on the MI355X box"
-    rr = C.CDLL("librocrand.so"); hip = C.CDLL("libamdhip64.so")          # (plain HIP allocations: torch cannot always initialise its own context once the product library holds the device)
+    # (plain HIP allocations: torch cannot always initialise its own context once the product library holds the device)
+    rr = C.CDLL("librocrand.so"); hip = C.CDLL("libamdhip64.so")
     # two base.json iterations (2R, 3R, S R with R = 4096), then sizes that are no multiple of anything
     for sizes in ([8192, 12288, 131072, 8192, 12288, 131072], [2048, 3072, 32768, 5, 131073, 262144 + 7, 1]):
         g = C.c_void_p(); assert rr.rocrand_create_generator(C.byref(g), 401) == 0                     # ROCRAND_RNG_PSEUDO_XORWOW, seed 0 by default
@@ -40,11 +42,13 @@ def test_rocrand_host_generator_matches_the_oracle_stream(pkg, orc):
 
 
 @pytest.mark.parametrize("backend", [0, 1])
-@pytest.mark.parametrize("mode", [dict(xorwow=2, xorwow_lanes=131072), dict(xorwow=1), dict(xorwow=1, tcnn_init_order=1)], ids=["rocrand131072", "curand4096", "curand4096_tcnn_init"])
+@pytest.mark.parametrize("mode", [dict(xorwow=2, xorwow_lanes=131072), dict(xorwow=1), dict(xorwow=1, tcnn_init_order=1)], ids=["rocrand131072", "curand4096",
+        "curand4096_tcnn_init"])
 def test_hip_path_in_xorwow_mode_matches_the_oracle(pkg, orc, ss, small_scene, backend, mode):
     assert pkg.device_count() >= 1
     kw = dict(C1, **mode)
-    pkg.set_option("lds_encode", 2)                       # the tile chain also at this small batch (default: from 3072 rays up), so that its position / candidate pipeline runs on the XORWOW arrays
+    # the tile chain also at this small batch (default: from 3072 rays up), so that its position / candidate pipeline runs on the XORWOW arrays
+    pkg.set_option("lds_encode", 2)
     try:
         ds, obj = ge.make_problem(pkg, small_scene, kw); obj.set_backend(backend)
     finally:
@@ -53,16 +57,19 @@ def test_hip_path_in_xorwow_mode_matches_the_oracle(pkg, orc, ss, small_scene, b
     assert np.array_equal(obj.get_params(0), ref.buffer("master"))                     # same initial weights, also in tcnn's element order
     if backend == 1:
         obj.set_debug_dump(True)
-    for it in range(3):                                                                 # stage-wise: batch generation bit for bit, three iterations of the stream
+    # stage-wise: batch generation bit for bit, three iterations of the stream
+    for it in range(3):
         obj.train_stages(1 | 2); ref.generate_batch(); ref.forward_backward()
         assert int(obj.buffer("state")[2]) == ref.n_valid and ref.n_valid > 0
         for b in ("ray_o", "ray_d", "ray_t0", "ray_t1", "target", "bgcol", "pts", "tdist"):
             close_f32(obj.buffer(b), ref.buffer(b), "%s (iteration %d)" % (b, it), 1e-6)
         assert np.array_equal(obj.buffer("E"), ref.buffer("E")), "hash-grid encode must be bit-exact (iteration %d)" % it
         obj.train_stages(4); ref.train_step()
-        ref.set_params(obj.get_params(0))                                               # (one Adam step leaves ~0.3 % of the weights a learning rate apart: the stream is what is compared here)
+        # (one Adam step leaves ~0.3 % of the weights a learning rate apart: the stream is what is compared here)
+        ref.set_params(obj.get_params(0))
     if backend == 1:
-        obj.set_debug_dump(False)                                                       # the default fused path: level-tile encode, positions prepared one iteration ahead
+        # the default fused path: level-tile encode, positions prepared one iteration ahead
+        obj.set_debug_dump(False)
     l_hip = obj.train(60); l_ref = ref.train(60)
     assert np.isfinite(l_hip) and abs(l_hip - l_ref) < max(0.5 * l_ref, 0.02), (l_hip, l_ref)
     box = small_scene.objects[0]["boxes"][2]; pose = ss.colmajor(small_scene.Twc[int(box[0])])

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Object churn on one GPU: T host threads each create an object, train it in slices of random length (sometimes rendering, reading parameters or adding boxes in
-between), destroy it and start over, for `seconds` -- the per-device training lanes, stream pool and snapshot side see objects come and go while others train.
+"""Object churn on one GPU: T host threads each create an object, train it in slices of random length (sometimes rendering, reading parameters or adding boxes
+in between), destroy it and start over, for `seconds` -- the per-device training lanes, stream pool and snapshot side see objects come and go while others
+train.
    python tools/churn_stress.py [threads] [seconds]"""
 import os
 import sys

@@ -6,10 +6,10 @@ mon_offline_*):   <dir>/<id>/test_img/<stamp>.png    8-bit colour (x 255)
                   <dir>/<id>/test_mask/<stamp>.png   8-bit mask (x 255)
                   <dir>/<id>/obj.ply                 ASCII mesh (marching_cubes.cu:573-605)
    python tools/compare_with_reference_outputs.py REFERENCE_DIR OUR_DIR [--json]
-Stated tolerance (the two numeric models -- this repo's fp32 accumulation and tiny-cuda-nn's fp16 accumulation -- end a training run as far apart as
-one run is from itself started one fp16 ulp away; tests/golden/numerics_study.json): per image mutual PSNR >= 30 dB, mask IoU >= 0.97, mean |depth difference|
-over pixels both masks cover <= 1 % of the mean depth; per object mean mutual PSNR >= 34 dB; mesh vertex-set distance (symmetric mean nearest neighbour) <= 1.5 %
-of the mesh's bounding-box diagonal.  Exit status 0 when every object is inside, 1 otherwise, 2 when the directories do not match up."""
+Stated tolerance (the two numeric models -- this repo's fp32 accumulation and tiny-cuda-nn's fp16 accumulation -- end a training run as far apart
+as one run is from itself started one fp16 ulp away; tests/golden/numerics_study.json): per image mutual PSNR >= 30 dB, mask IoU >= 0.97, mean |depth
+difference| over pixels both masks cover <= 1 % of the mean depth; per object mean mutual PSNR >= 34 dB; mesh vertex-set distance (symmetric mean nearest
+neighbour) <= 1.5 % of the mesh's bounding-box diagonal.  Exit status 0 when every object is inside, 1 otherwise, 2 when the directories do not match up."""
 import argparse
 import json
 import os
@@ -99,8 +99,10 @@ def main():
     else:
         for d, r in out.items():
             print("object %s: %d images, PSNR min %.2f mean %.2f dB, mask IoU min %.3f, depth rel max %.4f%s -> %s" % (
-                d, len(r["images"]), r.get("psnr_min_db", float("nan")), r.get("psnr_mean_db", float("nan")), r.get("mask_iou_min", float("nan")), r.get("depth_rel_max", float("nan")),
-                (", mesh %d / %d vertices, rel distance %.4f" % (r["mesh"]["ref_vertices"], r["mesh"]["our_vertices"], r["mesh"]["rel_distance"])) if "mesh" in r else "",
+                d, len(r["images"]), r.get("psnr_min_db", float("nan")), r.get("psnr_mean_db", float("nan")), r.get("mask_iou_min", float("nan")),
+                        r.get("depth_rel_max", float("nan")),
+                (", mesh %d / %d vertices, rel distance %.4f" % (r["mesh"]["ref_vertices"], r["mesh"]["our_vertices"],
+                        r["mesh"]["rel_distance"])) if "mesh" in r else "",
                 "inside tolerance" if r["inside_tolerance"] else "OUTSIDE tolerance" + (" (missing: %s)" % r["missing"] if r["missing"] else "")))
     return 0 if all(r["inside_tolerance"] for r in out.values()) else 1
 

@@ -40,16 +40,19 @@ def main():
         print("| %s | %.0f | %.1f%% |" % (name, t[:, k].mean(), 100 * t[:, k].mean() / tot))
     print("| total | %.0f | |" % tot)
     tw = t[:, :10].sum(1); enc = t[:, 2]
-    print("per-wave total: p10 %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f;   encode: p10 %.0f p50 %.0f p90 %.0f max %.0f" % (*np.percentile(tw, [10, 50, 90, 99, 100]), *np.percentile(enc, [10, 50, 90, 100])))
+    print("per-wave total: p10 %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f;   encode: p10 %.0f p50 %.0f p90 %.0f max %.0f" % (*np.percentile(tw, [10, 50, 90,
+            99, 100]), *np.percentile(enc, [10, 50, 90, 100])))
     hw = t[:, 15].astype(np.int64); start = t[:, 13]; end = t[:, 14]
     t0 = start.min(); dur = (np.where(end < start, end + 2 ** 24, end) - t0) / 100.0; st_us = (start - t0) / 100.0
-    print("wall clock: wave start p50 %.2f p99 %.2f max %.2f us after the first, wave end p10 %.2f p50 %.2f p90 %.2f max %.2f us" % (*np.percentile(st_us, [50, 99, 100]), *np.percentile(dur, [10, 50, 90, 100])))
+    print("wall clock: wave start p50 %.2f p99 %.2f max %.2f us after the first, wave end p10 %.2f p50 %.2f p90 %.2f max %.2f us" % (*np.percentile(st_us, [50,
+            99, 100]), *np.percentile(dur, [10, 50, 90, 100])))
     cu = (hw >> 8) & 0xff; se = (hw >> 13) & 7; key = cu  # HW_ID: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13
     ids = np.unique(hw >> 8)
     per = np.array([dur[(hw >> 8) == i].max() for i in ids]); cnt = np.array([((hw >> 8) == i).sum() for i in ids])
     print("distinct (se, sh, cu) ids per XCD slice seen: %d; waves per id: min %d max %d; slowest-wave end per id: p10 %.2f p50 %.2f p90 %.2f max %.2f us" % (len(ids), cnt.min(), cnt.max(), *np.percentile(per, [10, 50, 90, 100])))
     wgt = tw.reshape(-1, 4).max(1)
-    print("per-workgroup (slowest wave, without the epilogue wait): p50 %.0f p90 %.0f max %.0f;  by XCD (blockIdx %% 8) mean: %s" % (*np.percentile((tw - t[:, 9]).reshape(-1, 4).max(1), [50, 90, 100]), " ".join("%.0f" % wgt[x::8].mean() for x in range(8))))
+    print("per-workgroup (slowest wave, without the epilogue wait): p50 %.0f p90 %.0f max %.0f;  by XCD (blockIdx %% 8) mean: %s" % (*np.percentile((tw - t[:,
+            9]).reshape(-1, 4).max(1), [50, 90, 100]), " ".join("%.0f" % wgt[x::8].mean() for x in range(8))))
 
 
 if __name__ == "__main__":

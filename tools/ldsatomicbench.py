@@ -8,4 +8,5 @@ names = {40: "ds_add_u64 random", 41: "ds_add_u64, 2 lanes share", 42: "ds_add_u
 ops = 256 * 1024 * 512
 for m in sorted(names):
     ms = pkg.microbench(m, 0, 0, ops)
-    print("mode %d  %-30s %.3f ms  %.2f lanes/clk/CU @2.4GHz  (%.1f cycles per wave instruction)" % (m, names[m], ms, ops / (ms * 1e-3) / 256 / 2.4e9, 64 / (ops / (ms * 1e-3) / 256 / 2.4e9)), flush=True)
+    print("mode %d  %-30s %.3f ms  %.2f lanes/clk/CU @2.4GHz  (%.1f cycles per wave instruction)" % (m, names[m], ms, ops / (ms * 1e-3) / 256 / 2.4e9,
+            64 / (ops / (ms * 1e-3) / 256 / 2.4e9)), flush=True)

@@ -7,7 +7,8 @@ pkg = ge.load_package()
 OPS = 128 * 1024 * 1024
 names = {50: "ds_read_u16, every lane", 51: "ds_read_b32, every lane", 52: "ds_read_b64, every lane", 53: "ds_read_b128, every lane",
          54: "ds_read_b32, 1/2 of the lanes", 55: "ds_read_b32, 1/4 of the lanes", 56: "ds_read_b32, 1/8 of the lanes",
-         57: "ds_read_b128 all + ds_read_u16 by 1/8", 58: "ds_read_b64 all + ds_read_u16 by 1/4", 59: "ds_read_b32 all + ds_read_u16 by 1/2", 17: "ds_read_b32 (LCG index, r01 probe)",
+         57: "ds_read_b128 all + ds_read_u16 by 1/8", 58: "ds_read_b64 all + ds_read_u16 by 1/4", 59: "ds_read_b32 all + ds_read_u16 by 1/2",
+                 17: "ds_read_b32 (LCG index, r01 probe)",
          60: "ds_read_b32 conflict-free (64 consecutive dwords)", 61: "ds_read_b32 broadcast (one address)", 62: "ds_read_b32 random within 256 B",
          63: "ds_read_b32 random, lane pairs adjacent", 64: "ds_read_b32 1/8 random + 7/8 conflict-free lanes"}
 for mode in (17, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64):

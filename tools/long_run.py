@@ -22,8 +22,10 @@ def main():
         loss = obj.train(5000)
         rgb, depth, mask = obj.render(bx, ss.colmajor(sc.Twc[v]))
         info = obj.info()
-        print("step %6d  wall %.2f s  loss %.5f  PSNR %.2f dB  lr %.3e  skipped %d" % (info.train_step, time.perf_counter() - t0, loss, -10 * np.log10(np.mean((rgb - gt) ** 2)), info.learning_rate, info.skipped_batches), flush=True)
-    p = obj.get_params(0); print("parameters finite:", bool(np.isfinite(p).all()), " %.1f us per step over the whole run" % (1e6 * (time.perf_counter() - t0) / 50000))
+        print("step %6d  wall %.2f s  loss %.5f  PSNR %.2f dB  lr %.3e  skipped %d" % (info.train_step, time.perf_counter() - t0, loss,
+                -10 * np.log10(np.mean((rgb - gt) ** 2)), info.learning_rate, info.skipped_batches), flush=True)
+    p = obj.get_params(0)
+    print("parameters finite:", bool(np.isfinite(p).all()), " %.1f us per step over the whole run" % (1e6 * (time.perf_counter() - t0) / 50000))
     obj.close(); ds.close()
 
 

@@ -36,7 +36,8 @@ def main():
         th = [threading.Thread(target=run, args=(o,)) for o in objs]
         [t.start() for t in th]; [t.join() for t in th]
         pkg.lib().mon_device_synchronize(0); dt = time.perf_counter() - t0
-        print(json.dumps({"objects": K, "steps": [warm, warm + steps], "aggregate_G": round(K * steps * 4096 * 32 / dt / 1e9, 3), "us_per_object_step": round(1e6 * dt / steps / K, 2)}), flush=True)
+        print(json.dumps({"objects": K, "steps": [warm, warm + steps], "aggregate_G": round(K * steps * 4096 * 32 / dt / 1e9, 3),
+                "us_per_object_step": round(1e6 * dt / steps / K, 2)}), flush=True)
         for o in objs:
             o.close()
         ds.close()

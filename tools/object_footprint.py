@@ -14,6 +14,7 @@ for name, kw in (("base.json", {}), ("T = 2^22", dict(log2_hashmap_size=22))):
     f1, _ = pkg.device_mem_info(0)
     box = np.array([0, 0, 0, sc.H, sc.W], np.uint32); objs[0].render(box, ss.colmajor(sc.Twc[0]))
     f2, _ = pkg.device_mem_info(0)
-    print("%-10s %6.1f MB per object (mean of 4), + %d MB once per device for a full-frame render (workspace / output buffers)" % (name, (f0 - f1) / 4 / 2 ** 20, (f1 - f2) >> 20), flush=True)
+    print("%-10s %6.1f MB per object (mean of 4), + %d MB once per device for a full-frame render (workspace / output buffers)" % (name,
+            (f0 - f1) / 4 / 2 ** 20, (f1 - f2) >> 20), flush=True)
     for o in objs:
         o.close()

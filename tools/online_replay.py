@@ -21,7 +21,8 @@ ids = {}; t_frame, t_box, t_render = [], [], []
 t_start = time.perf_counter()
 for v in range(sc.n_views):
     t_next = t_start + (v + 1) * period
-    t0 = time.perf_counter(); m.new_frame(v, "%.6f" % (v * 0.1), sc.rgb[v][..., ::-1], sc.instance[v], ss.colmajor(sc.Twc[v])); t_frame.append(time.perf_counter() - t0)
+    t0 = time.perf_counter(); m.new_frame(v, "%.6f" % (v * 0.1), sc.rgb[v][..., ::-1], sc.instance[v], ss.colmajor(sc.Twc[v]))
+    t_frame.append(time.perf_counter() - t0)
     for k, ob in enumerate(sc.objects):
         if k not in ids:
             ids[k] = m.create_nerf(ob["cls"], ss.colmajor(ob["Tow"]), -ob["half"] / 1.1, ob["half"] / 1.1)

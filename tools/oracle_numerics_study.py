@@ -45,7 +45,8 @@ def main():
         a = ge.make_oracle(orc, sc, kw); b = ge.make_oracle(orc, sc, kw); t = ge.make_oracle(orc, sc, dict(kw, tcnn_half_accum=1))
         p0 = a.buffer("master")
         rs = np.random.RandomState(seed); pert = p0.copy(); sel = rs.rand(p0.size) < 0.01
-        h = pert[sel].astype(np.float16); pert[sel] = np.nextafter(h, np.float16(np.inf)).astype(np.float32); b.set_params(pert)   # the fp16 working copy moves by ONE fp16 ulp on 1 % of the parameters
+        # the fp16 working copy moves by ONE fp16 ulp on 1 % of the parameters
+        h = pert[sel].astype(np.float16); pert[sel] = np.nextafter(h, np.float16(np.inf)).astype(np.float32); b.set_params(pert)
         # one step: contract vs tcnn model
         a1 = ge.make_oracle(orc, sc, kw); t1 = ge.make_oracle(orc, sc, dict(kw, tcnn_half_accum=1)); a1.train(1); t1.train(1)
         pa, pt = a1.buffer("master"), t1.buffer("master"); nm = a1.n_mlp
@@ -55,20 +56,27 @@ def main():
         a.train(steps); b.train(steps); t.train(steps)
         ra, rb, rt = renders(a, sc, ss), renders(b, sc, ss), renders(t, sc, ss)
         row = dict(seed=seed, steps=steps,
-                   abs_contract=float(np.mean([psnr(r, g) for r, g in ra])), abs_perturbed=float(np.mean([psnr(r, g) for r, g in rb])), abs_tcnn_half=float(np.mean([psnr(r, g) for r, g in rt])),
-                   mutual_contract_vs_perturbed_min=float(min(psnr(x[0], y[0]) for x, y in zip(ra, rb))), mutual_contract_vs_perturbed_mean=float(np.mean([psnr(x[0], y[0]) for x, y in zip(ra, rb)])),
-                   mutual_contract_vs_tcnn_half_min=float(min(psnr(x[0], y[0]) for x, y in zip(ra, rt))), mutual_contract_vs_tcnn_half_mean=float(np.mean([psnr(x[0], y[0]) for x, y in zip(ra, rt)])),
+                   abs_contract=float(np.mean([psnr(r, g) for r, g in ra])), abs_perturbed=float(np.mean([psnr(r, g) for r, g in rb])),
+                           abs_tcnn_half=float(np.mean([psnr(r, g) for r, g in rt])),
+                   mutual_contract_vs_perturbed_min=float(min(psnr(x[0], y[0]) for x, y in zip(ra, rb))),
+                           mutual_contract_vs_perturbed_mean=float(np.mean([psnr(x[0], y[0]) for x, y in zip(ra, rb)])),
+                   mutual_contract_vs_tcnn_half_min=float(min(psnr(x[0], y[0]) for x, y in zip(ra, rt))),
+                           mutual_contract_vs_tcnn_half_mean=float(np.mean([psnr(x[0], y[0]) for x, y in zip(ra, rt)])),
                    one_step_contract_vs_tcnn_half=one)
         rows.append(row); print(json.dumps(row), flush=True)
         a.close(); b.close(); t.close()
     f = lambda k: [r[k] for r in rows]
     summary = dict(
         config="BASELINE configs[0] (R=1024, S=32, hash L=4, MLP 2x32), tests/conftest.py small_scene, %d steps, crops = every 4th training box" % steps,
-        chaos_floor=dict(what="oracle vs the same oracle run started one fp16 ulp away on 1 % of the parameters", mutual_psnr_min_db=min(f("mutual_contract_vs_perturbed_min")),
-                         mutual_psnr_mean_db=float(np.mean(f("mutual_contract_vs_perturbed_mean"))), abs_psnr_diff_max_db=float(max(abs(r["abs_contract"] - r["abs_perturbed"]) for r in rows)),
-                         abs_psnr_diff_mean3_max_db=float(max(abs(np.mean(f("abs_contract")[i:i + 3]) - np.mean(f("abs_perturbed")[i:i + 3])) for i in range(0, len(rows) - 2)))),
+        chaos_floor=dict(what="oracle vs the same oracle run started one fp16 ulp away on 1 % of the parameters",
+                mutual_psnr_min_db=min(f("mutual_contract_vs_perturbed_min")),
+                         mutual_psnr_mean_db=float(np.mean(f("mutual_contract_vs_perturbed_mean"))),
+                                 abs_psnr_diff_max_db=float(max(abs(r["abs_contract"] - r["abs_perturbed"]) for r in rows)),
+                         abs_psnr_diff_mean3_max_db=float(max(abs(np.mean(f("abs_contract")[i:i + 3]) - np.mean(f("abs_perturbed")[i:i + 3])) for i in range(0,
+                                 len(rows) - 2)))),
         tcnn_half_model=dict(what="contract numerics (fp32 accumulation) vs the model of tiny-cuda-nn's fp16 accumulation, same seeds",
-                             mutual_psnr_min_db=min(f("mutual_contract_vs_tcnn_half_min")), mutual_psnr_mean_db=float(np.mean(f("mutual_contract_vs_tcnn_half_mean"))),
+                             mutual_psnr_min_db=min(f("mutual_contract_vs_tcnn_half_min")),
+                                     mutual_psnr_mean_db=float(np.mean(f("mutual_contract_vs_tcnn_half_mean"))),
                              abs_psnr_contract_mean_db=float(np.mean(f("abs_contract"))), abs_psnr_tcnn_half_mean_db=float(np.mean(f("abs_tcnn_half"))),
                              abs_psnr_diff_max_db=float(max(abs(r["abs_contract"] - r["abs_tcnn_half"]) for r in rows)),
                              one_step_frac_mlp_gt_1e4_max=max(r["one_step_contract_vs_tcnn_half"]["frac_mlp_gt_1e4"] for r in rows),

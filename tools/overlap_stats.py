@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Overlap of kernels in a rocprofv3 --kernel-trace database (rocpd): per kernel the mean duration, and for the whole trace window the busy time
-(union of kernel intervals), the sum of kernel durations and their ratio (1.0 = nothing ever overlapped).   python tools/overlap_stats.py <results.db> [skip_first_ms]"""
+(union of kernel intervals), the sum of kernel durations and their ratio (1.0 = nothing ever overlapped).   python tools/overlap_stats.py <results.db>
+[skip_first_ms]"""
 import re
 import sqlite3
 import sys
@@ -23,4 +24,5 @@ busy += ce - cs
 tot = sum(e - s for _, s, e in rows)
 for n, v in sorted(per.items()):
     print("%-46s calls %6d   mean %7.2f us" % (n, len(v), sum(v) / len(v)))
-print("window %.2f ms   busy (union) %.2f ms   sum of kernel durations %.2f ms   overlap factor %.2f   idle %.1f %%" % ((rows[-1][2] - rows[0][1]) / 1e6, busy / 1e6, tot / 1e6, tot / busy, 100.0 * (1.0 - busy / (rows[-1][2] - rows[0][1]))))
+print("window %.2f ms   busy (union) %.2f ms   sum of kernel durations %.2f ms   overlap factor %.2f   idle %.1f %%" % ((rows[-1][2] - rows[0][1]) / 1e6,
+        busy / 1e6, tot / 1e6, tot / busy, 100.0 * (1.0 - busy / (rows[-1][2] - rows[0][1]))))

@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--extra", type=int, default=0)
     ap.add_argument("--log2-hashmap-size", type=int, default=0)
     ap.add_argument("--views", type=int, default=40)
-    ap.add_argument("--objects", type=int, default=1, help="K objects trained concurrently, one host thread each (dispatch numbers [K W, K (W + K_steps)) of a kernel are then the window)")
+    ap.add_argument("--objects", type=int, default=1,
+            help="K objects trained concurrently, one host thread each (dispatch numbers [K W, K (W + K_steps)) of a kernel are then the window)")
     a = ap.parse_args()
     pkg = ge.load_package(); ss = ge.load_tools()
     sc = ss.make_scene(n_views=a.views, H=480, W=640, f=525.0, seed=0)
@@ -44,7 +45,8 @@ def main():
     t0 = time.perf_counter(); all_train(a.steps); pkg.lib().mon_device_synchronize(0); dt = time.perf_counter() - t0
     B = obj.cfg.rays_per_batch * obj.cfg.n_samples
     print("window: %d object(s), steps %d..%d, %.4f ms/step per object-step, %.1f M ray-samples/s aggregate, scattered samples in the last step %d" %
-          (len(objs), a.extra + a.warmup, a.extra + a.warmup + a.steps, 1e3 * dt / a.steps / len(objs), len(objs) * a.steps * B / dt / 1e6, int(obj.buffer("state")[24])))
+          (len(objs), a.extra + a.warmup, a.extra + a.warmup + a.steps, 1e3 * dt / a.steps / len(objs), len(objs) * a.steps * B / dt / 1e6,
+                  int(obj.buffer("state")[24])))
     for o in objs[1:]:
         o.close()
     obj.close(); ds.close()

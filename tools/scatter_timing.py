@@ -11,7 +11,8 @@ sys.path.insert(0, ROOT)
 os.environ["MON_CORE_LIB"] = os.path.join(ROOT, "ro-map_amd", "build_sctime", "libmon_core.so")
 import __graft_entry__ as ge  # noqa: E402
 
-PH = ["setup (counters, level constants)", "tile clear", "barrier after clear", "walk (+ the dW row loads behind it)", "barrier (wait for the slowest wave)", "tile write-out", "wave start (low 24 bits of the clock)"]
+PH = ["setup (counters, level constants)", "tile clear", "barrier after clear", "walk (+ the dW row loads behind it)", "barrier (wait for the slowest wave)",
+        "tile write-out", "wave start (low 24 bits of the clock)"]
 
 
 def main():
@@ -28,8 +29,10 @@ def main():
         for l in sorted(set(lv)):
             m = buf[lv == l][:, :, :7].mean((0, 1)); print("| %d | " % l + " | ".join("%.0f" % v for v in m) + " | %.0f |" % m.sum())
         w = buf[:, :, 3]; print("walk cycles per wave: min %.0f mean %.0f max %.0f" % (w.min(), w.mean(), w.max()))
-        wg = int(np.where(lv == 7)[0][0]); print("workgroup %d (level 7), per wave:" % wg); print(np.array2string(buf[wg, :, :7], precision=0, suppress_small=True, max_line_width=200))
-        st = buf[:, :, 6]; print("wave start clock (low bits): spread inside a workgroup max %.0f; over the grid %.0f" % ((st.max(1) - st.min(1)).max(), st.max() - st.min()))
+        wg = int(np.where(lv == 7)[0][0]); print("workgroup %d (level 7), per wave:" % wg)
+        print(np.array2string(buf[wg, :, :7], precision=0, suppress_small=True, max_line_width=200))
+        st = buf[:, :, 6]
+        print("wave start clock (low bits): spread inside a workgroup max %.0f; over the grid %.0f" % ((st.max(1) - st.min(1)).max(), st.max() - st.min()))
     obj.close(); ds.close()
 
 

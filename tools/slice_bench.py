@@ -15,5 +15,6 @@ for sl in (4, 16, 200):
     n = 800 // sl
     pkg.lib().mon_device_synchronize(0); t0 = time.perf_counter(); run(objs[0], n, sl); pkg.lib().mon_device_synchronize(0); t1 = time.perf_counter() - t0
     th = [threading.Thread(target=run, args=(o, n, sl)) for o in objs]
-    pkg.lib().mon_device_synchronize(0); t0 = time.perf_counter(); [t.start() for t in th]; [t.join() for t in th]; pkg.lib().mon_device_synchronize(0); t4 = time.perf_counter() - t0
+    pkg.lib().mon_device_synchronize(0); t0 = time.perf_counter(); [t.start() for t in th]; [t.join() for t in th]; pkg.lib().mon_device_synchronize(0)
+    t4 = time.perf_counter() - t0
     print("%s slice %3d: 1 object %.1f us/step; 4 objects concurrently %.1f us per object-step" % (root[-5:], sl, 1e6 * t1 / (n * sl), 1e6 * t4 / (4 * n * sl)))

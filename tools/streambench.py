@@ -13,4 +13,5 @@ for parts in (0, 4):
                     ms = pkg.microbench(mode, blocks, plain | (units << 4) | (parts << 8), n)
                     if best is None or ms < best[0]: best = (ms, blocks)
                 mb = n * (24 + 8 + 4 + 2 * parts) / 1e6
-                print("mode %d  units %d  %s stores  partial tables %d: %.1f us (%d blocks)  %.0f MB  %.2f TB/s" % (mode, units, "plain" if plain else "nt   ", parts, 1e3 * best[0], best[1], mb, mb / best[0] / 1e6), flush=True)
+                print("mode %d  units %d  %s stores  partial tables %d: %.1f us (%d blocks)  %.0f MB  %.2f TB/s" % (mode, units, "plain" if plain else "nt   ",
+                        parts, 1e3 * best[0], best[1], mb, mb / best[0] / 1e6), flush=True)

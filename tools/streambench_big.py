@@ -9,4 +9,5 @@ for units in (1, 2, 4, 8):
         for blocks in (1024, 2048, 4096, 8192):
             ms = pkg.microbench(31, blocks, plain | (units << 4), n)
             mb = n * (24 + 8 + 4) / 1e6
-            print("units %d  %s stores  %5d blocks: %.1f us  %.0f MB  %.2f TB/s" % (units, "plain" if plain else "nt   ", blocks, 1e3 * ms, mb, mb / ms / 1e6), flush=True)
+            print("units %d  %s stores  %5d blocks: %.1f us  %.0f MB  %.2f TB/s" % (units, "plain" if plain else "nt   ", blocks, 1e3 * ms, mb, mb / ms / 1e6),
+                    flush=True)

@@ -135,7 +135,8 @@ def write_sequence(sc, out_dir):
     for sub in ("rgb", "depth", "instance", "obj_offline"):
         os.makedirs(os.path.join(out_dir, sub), exist_ok=True)
     with open(os.path.join(out_dir, "config.yaml"), "w") as f:
-        # decoys a substring / first-match reader would trip over (cv::FileStorage matches keys exactly): a comment naming a key, longer keys with the same prefix
+        # decoys a substring / first-match reader would trip over (cv::FileStorage matches keys exactly): a comment naming a key, longer keys with the same
+        # prefix
         f.write("%%YAML:1.0\n# Camera.fx: 1.0 (an old calibration, commented out)\nCamera.Height_mm: 9999\nCamera.Width_mm: 9999\nCamera.fx: %.6f\nCamera.fy: %.6f\nCamera.cx: %.6f\nCamera.cy: %.6f\nCamera.H: %d\nCamera.W: %d\nDepthMapFactor: %.8f\n"
                 % (sc.fx, sc.fy, sc.cx, sc.cy, sc.H, sc.W, 1.0 / 5000.0))
     with open(os.path.join(out_dir, "img.txt"), "w") as fi, open(os.path.join(out_dir, "groundtruth.txt"), "w") as fg:

@@ -11,5 +11,6 @@ for steps in (5, 200, 800, 3000):
     nz = g != 0
     ent = nz.reshape(-1, 2).any(1); ch = nz.reshape(-1, 8).any(1)
     st = obj.buffer("state")
-    print("step %5d: samples with gradient %6d | params nonzero %.3f, entries %.3f, 8-param chunks %.3f" % (steps, int(st[8]), nz.mean(), ent.mean(), ch.mean()), flush=True)
+    print("step %5d: samples with gradient %6d | params nonzero %.3f, entries %.3f, 8-param chunks %.3f" % (steps, int(st[8]), nz.mean(), ent.mean(),
+            ch.mean()), flush=True)
     obj.train_stages(4)

@@ -8,7 +8,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]; tag = os.path.basename(src.rstrip("/"))
-ks = open(os.path.join(src, "kernel_stats.md")).read(); bench = open(os.path.join(src, "bench.json")).read().strip(); pmc = open(os.path.join(src, "pmc_summary.md")).read()
+ks = open(os.path.join(src, "kernel_stats.md")).read(); bench = open(os.path.join(src, "bench.json")).read().strip()
+pmc = open(os.path.join(src, "pmc_summary.md")).read()
 val = {}
 for line in pmc.splitlines():
     m = re.match(r"\| (\S+).*?\| (\w+) \| (\d+) \| ([\d.]+) \|", line)
@@ -19,7 +20,8 @@ for line in pmc.splitlines():
 d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
 for k in ("k_fused_train", "k_grid_scatter", "k_optimizer"):
     f, w, h, mi = val[(k, "FETCH_SIZE")], val[(k, "WRITE_SIZE")], val[(k, "TCC_HIT_sum")], val[(k, "TCC_MISS_sum")]
-    d[k + "_FETCH_SIZE_KB"] = f; d[k + "_WRITE_SIZE_KB"] = w; d[k + "_hbm_bytes_per_launch"] = int((2 * f + w) * 1024); d[k + "_l2_hit_rate"] = round(h / (h + mi), 4)
+    d[k + "_FETCH_SIZE_KB"] = f; d[k + "_WRITE_SIZE_KB"] = w; d[k + "_hbm_bytes_per_launch"] = int((2 * f + w) * 1024)
+    d[k + "_l2_hit_rate"] = round(h / (h + mi), 4)
     d[k + "_l2_requests_per_launch"] = int(val[(k, "TCC_REQ_sum")])
 d["k_fused_train_l2_read_requests_per_launch"] = int(val[("k_fused_train", "TCP_TCC_READ_REQ_sum")])
 d["note"] = re.sub(r"gpurun \w+", "gpurun " + tag, d["note"])

@@ -22,7 +22,8 @@ def section(tag, title, L):
         cc = c.get(k, {}); g = lambda n: cc.get(n, (0, 0.0))[1]
         mb = (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) / 1e3
         hit = g("TCC_HIT_sum") / max(1.0, g("TCC_HIT_sum") + g("TCC_MISS_sum"))
-        L.append("| %s | %d | %.1f | %.1f | %.1f | %s | %s | %s | %s |" % (k, r["n"], r["avg"], r["mn"], r["mx"], ("%.0f" % mb) if cc else "-", ("%.2f" % (mb / r["avg"])) if cc and r["avg"] else "-",
+        L.append("| %s | %d | %.1f | %.1f | %.1f | %s | %s | %s | %s |" % (k, r["n"], r["avg"], r["mn"], r["mx"], ("%.0f" % mb) if cc else "-",
+                ("%.2f" % (mb / r["avg"])) if cc and r["avg"] else "-",
                                                                  ("%.2f M" % (g("TCC_REQ_sum") / 1e6)) if cc else "-", ("%.2f" % hit) if cc else "-"))
         tot += r["total"] / max(1, r["n"])
     L.append("\nsum of the kernels' average durations per step: %.0f us\n" % tot)

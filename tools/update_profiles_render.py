@@ -59,11 +59,13 @@ def main():
         for k, r in sorted(t.items(), key=lambda kv: -kv[1]["total"]):
             if k.startswith("k_encode_tiles") or k.startswith("k_copy_from_host"):
                 continue                          # the 300 training steps before the renders / the dataset upload
-            L.append("| %s | %d | %.2f | %.2f | %.2f | %.1f | %s | %s | %s |" % (k, r["n"], r["avg"], r["mn"], r["mx"], r["total"], r["rest"][0], r["rest"][2], r["rest"][3]))
+            L.append("| %s | %d | %.2f | %.2f | %.2f | %.1f | %s | %s | %s |" % (k, r["n"], r["avg"], r["mn"], r["mx"], r["total"], r["rest"][0], r["rest"][2],
+                    r["rest"][3]))
         L.append("")
     L.append("## counters (means per dispatch; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB on gfx950)\n")
     L.append("| kernel | HBM MB / dispatch | L2 requests | L2 hit share | VALU wave-insts | LDS wave-insts | MFMA wave-insts | LDS conflict share | wave time waiting |\n|---|---|---|---|---|---|---|---|---|")
-    for src, names in ((cb, [k for k in cb if k.startswith("k_fused_render")]), (ca, ["k_encode_feat"] + [k for k in ca if k.startswith("k_tile_render")] + ["k_render_points", "k_render_rays_jobs"])):
+    for src, names in ((cb, [k for k in cb if k.startswith("k_fused_render")]), (ca,
+            ["k_encode_feat"] + [k for k in ca if k.startswith("k_tile_render")] + ["k_render_points", "k_render_rays_jobs"])):
         for k in names:
             c = src.get(k, {})
             g = lambda n: c.get(n, (0, 0.0))[1]
@@ -71,9 +73,11 @@ def main():
             hit = g("TCC_HIT_sum") / max(1.0, g("TCC_HIT_sum") + g("TCC_MISS_sum"))
             conf = g("SQ_LDS_BANK_CONFLICT") / max(1.0, g("SQ_LDS_IDX_ACTIVE"))
             wait = g("SQ_WAIT_INST_ANY") / max(1.0, g("SQ_WAVE_CYCLES"))
-            L.append("| %s | %.1f | %.2f M | %.2f | %.2f M | %.2f M | %.3f M | %.2f | %.2f |" % (k, hbm, g("TCC_REQ_sum") / 1e6, hit, g("SQ_INSTS_VALU") / 1e6, g("SQ_INSTS_LDS") / 1e6, g("SQ_INSTS_MFMA") / 1e6, conf, wait))
+            L.append("| %s | %.1f | %.2f M | %.2f | %.2f M | %.2f M | %.3f M | %.2f | %.2f |" % (k, hbm, g("TCC_REQ_sum") / 1e6, hit, g("SQ_INSTS_VALU") / 1e6,
+                    g("SQ_INSTS_LDS") / 1e6, g("SQ_INSTS_MFMA") / 1e6, conf, wait))
     L.append("")
-    L.append(open(os.path.join(ROOT, "profiles", "r04_window_render_notes.md")).read() if os.path.exists(os.path.join(ROOT, "profiles", "r04_window_render_notes.md")) else "")
+    L.append(open(os.path.join(ROOT, "profiles", "r04_window_render_notes.md")).read() if os.path.exists(os.path.join(ROOT, "profiles",
+            "r04_window_render_notes.md")) else "")
     open(os.path.join(ROOT, "profiles", "r04_window_render.md"), "w").write("\n".join(L) + "\n")
     print("\n".join(L[:40]))
 

@@ -61,20 +61,23 @@ def main():
                 continue
             f, w, h, mi = v[(k, "FETCH_SIZE")], v[(k, "WRITE_SIZE")], v[(k, "TCC_HIT_sum")], v[(k, "TCC_MISS_sum")]
             d[k + "_avg_us"] = du.get(k)
-            d[k + "_FETCH_SIZE_KB"] = f; d[k + "_WRITE_SIZE_KB"] = w; d[k + "_hbm_bytes_per_launch"] = int((2 * f + w) * 1024); d[k + "_l2_hit_rate"] = round(h / (h + mi), 4)
+            d[k + "_FETCH_SIZE_KB"] = f; d[k + "_WRITE_SIZE_KB"] = w; d[k + "_hbm_bytes_per_launch"] = int((2 * f + w) * 1024)
+            d[k + "_l2_hit_rate"] = round(h / (h + mi), 4)
             d[k + "_l2_requests_per_launch"] = int(v[(k, "TCC_REQ_sum")]); d[k + "_l2_read_requests_per_launch"] = int(v[(k, "TCP_TCC_READ_REQ_sum")])
             if (k, "SQ_BUSY_CYCLES") in v and v[(k, "SQ_BUSY_CYCLES")] > 0:
                 busy = v[(k, "SQ_BUSY_CYCLES")] / 32.0            # summed over the 32 shader engines -> cycles the kernel kept the SQs busy
                 d[k + "_sq_busy_cycles"] = int(busy)
                 d[k + "_mfma_busy_frac"] = round(v.get((k, "SQ_VALU_MFMA_BUSY_CYCLES"), 0.0) / (busy * 1024.0), 5)          # of 1024 SIMD matrix pipes
-                d[k + "_valu_busy_frac"] = round(v.get((k, "SQ_ACTIVE_INST_VALU"), 0.0) * 4.0 / (busy * 1024.0), 4)           # SIMD-time with a VALU instruction in flight (quad-cycles -> cycles, 1024 SIMDs)
+                # SIMD-time with a VALU instruction in flight (quad-cycles -> cycles, 1024 SIMDs)
+                d[k + "_valu_busy_frac"] = round(v.get((k, "SQ_ACTIVE_INST_VALU"), 0.0) * 4.0 / (busy * 1024.0), 4)
                 if v.get((k, "SQ_INSTS_VALU")):
                     d[k + "_cycles_per_valu_instruction"] = round(v.get((k, "SQ_ACTIVE_INST_VALU"), 0.0) * 4.0 / v[(k, "SQ_INSTS_VALU")], 2)
                 d[k + "_lds_active_frac"] = round(v.get((k, "SQ_LDS_IDX_ACTIVE"), 0.0) / (busy * 256.0), 4)                  # of 256 LDS arrays
                 d[k + "_lds_bank_conflict_share"] = round(v.get((k, "SQ_LDS_BANK_CONFLICT"), 0.0) / max(1.0, v.get((k, "SQ_LDS_IDX_ACTIVE"), 0.0)), 4)
                 wc = v.get((k, "SQ_WAVE_CYCLES"), 0.0)
                 if wc:
-                    d[k + "_wave_time_split"] = {"active": round(v.get((k, "SQ_ACTIVE_INST_ANY"), 0) / wc, 3), "issue_stall": round(v.get((k, "SQ_WAIT_INST_ANY"), 0) / wc, 3),
+                    d[k + "_wave_time_split"] = {"active": round(v.get((k, "SQ_ACTIVE_INST_ANY"), 0) / wc, 3),
+                            "issue_stall": round(v.get((k, "SQ_WAIT_INST_ANY"), 0) / wc, 3),
                                                  "waitcnt_or_barrier": round(v.get((k, "SQ_WAIT_ANY"), 0) / wc, 3)}
         out[regime] = d
         with open(os.path.join(ROOT, "profiles", "%s_window_%s.md" % (rnd, regime)), "w") as fh:
@@ -82,8 +85,10 @@ def main():
                      "`rocprofv3 --kernel-trace --pmc <one counter set>` (tools/gpu_profile_window.sh, gpurun %s, MI355X). Per kernel, dispatches are put in order and the window's 20 are averaged "
                      "(tools/rocpd_window.py). The trace's VGPR column counts register pairs (x2 = the compiler's .vgpr_count).\n\n## Durations\n\n%s\n## Counters\n\nFETCH_SIZE / WRITE_SIZE in KB; TCC_* / TCP_* in requests; "
                      "SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* in quad-cycles summed over waves; SQ_BUSY_CYCLES summed over the 32 shader engines; SQ_LDS_* in LDS-array cycles summed over CUs; GRBM_GUI_ACTIVE summed over the 8 XCDs.\n\n%s\n"
-                     "## Derived (also in profiles/pmc_traffic.json)\n\n```\n%s\n```\n" % (rnd, regime, WHAT.get(regime, regime), " --extra 800" if regime == "sparse" else "", tag,
-                                                                                           kw.split("\n\n", 1)[-1], pw.split("\n\n", 1)[-1], json.dumps(d, indent=1)))
+                     "## Derived (also in profiles/pmc_traffic.json)\n\n```\n%s\n```\n" % (rnd, regime, WHAT.get(regime, regime),
+                             " --extra 800" if regime == "sparse" else "", tag,
+                                                                                           kw.split("\n\n", 1)[-1], pw.split("\n\n", 1)[-1], json.dumps(d,
+                                                                                                   indent=1)))
     json.dump(out, open(pj_path, "w"), indent=1)
     print("profiles updated:", [a.split("=")[0] for a in sys.argv[2:]])
 

@@ -76,6 +76,22 @@ def wrap_statement(text, toks, indent, depth0):
     return out
 
 
+def merge_orphans(lines, mark):
+    """A re-flowed comment leaves its overflow on a short line of its own; when the next line continues the same comment paragraph, move the words there."""
+    pat = re.compile(r"^([ \t]*)" + re.escape(mark) + r" ?(.*)$")
+    i = 0
+    while i + 2 < len(lines):
+        a, b, c = pat.match(lines[i]), pat.match(lines[i + 1]), pat.match(lines[i + 2])
+        if a and b and c and a.group(1) == b.group(1) == c.group(1) and len(lines[i]) >= LIMIT - 30 and 0 < len(b.group(2)) <= 48 \
+                and not b.group(2).startswith(" ") and c.group(2)[:1].isalnum() and c.group(2)[:1].islower() and not b.group(2).rstrip().endswith((".", ":",
+                        ")")):
+            merged = reflow_comment(b.group(1), b.group(2) + " " + c.group(2))
+            lines[i + 1:i + 3] = merged
+            continue
+        i += 1
+    return lines
+
+
 def process(path):
     src = open(path).read()
     try:
@@ -155,6 +171,7 @@ def process(path):
                     out.append(full)
                 else:
                     out += wrapped
+    out = merge_orphans(out, "#")
     new = "\n".join(out)
     try:
         same = ast.dump(ast.parse(new)) == tree0
