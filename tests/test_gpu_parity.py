@@ -757,6 +757,44 @@ def test_optimizer_state_records_train_exactly_like_the_arrays(pkg, small_scene)
     assert res[0] == res[1], res
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("group", ["base", "large"])
+def test_every_combination_of_the_equivalence_switches_trains_the_same_parameters(pkg, small_scene, group):
+    """The A/B switches of mon_set_option that claim "same parameters either way" are flipped in EVERY combination, not one at a time: level-tile encode or
+    gathers, hipGraph replay, zero-gradient samples kept, training lanes (base.json-sized tables); chunk records or arrays, touched flags, 16-bit step
+    counters, level-tile encode, zero-gradient samples kept (tables above 8 M parameters, binned scatter).  Master weights, fp16 weights and EMA must have
+    one CRC over all combinations of a group."""
+    _need_gpu(pkg)
+    import itertools, zlib
+    if group == "base":
+        kw, steps = dict(rays_per_batch=1024), 40
+        switches = {"lds_encode": (1, 0), "use_graph": (0, 1), "keep_zero_samples": (0, 1), "train_lanes": (2, 0)}
+        fixed = {}
+    else:
+        kw, steps = dict(rays_per_batch=1024, log2_hashmap_size=20, n_levels=8, per_level_scale=2.0, n_neurons=32, n_hidden_layers=2), 10
+        switches = {"state_records": (1, 0), "touched_flags": (1, 0), "steps16": (1, 0), "lds_encode": (1, 0), "keep_zero_samples": (0, 1)}
+        fixed = {"big_switch": 1}                                                   # always binned: no global-atomic arrival order in the comparison
+    names = list(switches) + list(fixed)
+    old = {n: pkg.get_option(n) for n in names}
+    seen = {}
+    try:
+        for n, v in fixed.items():
+            pkg.set_option(n, v)
+        for combo in itertools.product(*switches.values()):
+            for n, v in zip(switches, combo):
+                pkg.set_option(n, v)
+            ds, obj = ge.make_problem(pkg, small_scene, kw); obj.set_backend(1)
+            if group == "large":
+                assert obj.info().n_grid_params > (8 << 20)
+            obj.train(steps)
+            seen[combo] = tuple(zlib.crc32(obj.get_params(w).tobytes()) for w in (0, 1, 2))
+            obj.close(); ds.close()
+    finally:
+        for n, v in old.items():
+            pkg.set_option(n, v)
+    assert len(seen) == 2 ** len(switches) and len(set(seen.values())) == 1, {k: v for k, v in seen.items() if v != seen[next(iter(seen))]}
+
+
 def _level_sizes(cfg):
     """tcnn's level table (grid.h): entries per level = min(round_up(res^3, 8), 2^T), res = ceil(base * scale^l - 1) + 1."""
     sizes = []
