@@ -60,6 +60,7 @@ def main():
                     ctr[(n, cn)] = (len(v), sum(v) / len(v))
     print("window: dispatches [%d, %d) of every kernel\n" % (a.skip, a.skip + a.take))
     if dur:
+        # (rocprofv3's VGPR columns count in units of two registers on gfx950: 104 here = 207 in the code object's .vgpr_count)
         print("| kernel | dispatches in window (of) | avg us | min us | max us | total us | arch VGPR | acc VGPR | LDS B | workgroups x threads |")
         print("|---|---|---|---|---|---|---|---|---|---|")
         for n, (c, avg, mn, mx, tot) in sorted(dur.items(), key=lambda kv: -kv[1][1]):
