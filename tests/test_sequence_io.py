@@ -167,6 +167,15 @@ def test_offline_nerf_flow_on_disk_sequence(pkg, ss, tmp_path):
             text=True, timeout=300)
     assert r.returncode == 0 and "Training completed" in r.stdout, r.stdout + r.stderr
     assert os.path.exists(os.path.join(str(tmp_path / "out2"), "0", "test_img"))
+    # ... and with its test images through the in-process RCCL gather (libmon_core_rccl.so, loaded on demand): the same PNG bytes
+    r = subprocess.run([exe, os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json"), seq, "0", "1", str(tmp_path / "out3"), "gather"],
+            capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Training completed" in r.stdout and "gathered to device 0" in r.stdout, r.stdout + r.stderr
+    for sub in ("test_img", "test_depth", "test_mask"):
+        a_dir, b_dir = os.path.join(str(tmp_path / "out2"), "0", sub), os.path.join(str(tmp_path / "out3"), "0", sub)
+        names = sorted(os.listdir(a_dir)); assert names and names == sorted(os.listdir(b_dir))
+        for nm in names:
+            assert open(os.path.join(a_dir, nm), "rb").read() == open(os.path.join(b_dir, nm), "rb").read(), (sub, nm)
 
 
 def test_generate_toc_orbit_pose(pkg):

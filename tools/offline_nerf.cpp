@@ -1,19 +1,25 @@
 // offline_nerf.cpp -- headless equivalent of the reference's OfflineNeRF executable (MON/main.cpp:287-343) without the
-// Pangolin viewer: OfflineNeRF <config.json> <dataset_path> <UseGTdepth 0|1> [n_objects=4] [out_dir=./output]
-// Links only against the C ABI (include/mon_core.h).
+// Pangolin viewer: OfflineNeRF <config.json> <dataset_path> <UseGTdepth 0|1> [n_objects=4] [out_dir=./output] [gather]
+// Links only against the C ABI (include/mon_core.h).  With "gather" the test images of all objects go through the in-process RCCL gather-to-root of
+// libmon_core_rccl.so (include/mon_core_rccl.h; loaded on demand, so the plain job needs no RCCL): every object renders on its own device (k mod nGPU,
+// nerf_manager.cu:96), the crops travel to device 0 over xGMI and one writer stores the same PNG bytes mon_offline_render_test writes.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
+#include <dlfcn.h>
 #include "../include/mon_core.h"
+#include "../include/mon_core_rccl.h"
 
 static int fail(const char* what) { std::fprintf(stderr, "%s: %s\n", what, mon_last_error()); return 1; }
 
 int main(int argc, char** argv) {
     std::puts("......Multi-Object NeRF Offline (MI355X core)......");
-    if (argc < 4) { std::fprintf(stderr, "param error...\n./offline_nerf ./configs/base.json dataset_path UseGTdepth [n_objects] [out_dir]\n"); return 0; }
+    if (argc < 4) { std::fprintf(stderr, "param error...\n./offline_nerf ./configs/base.json dataset_path UseGTdepth [n_objects] [out_dir] [gather]\n"); return 0; }
     const std::string cfg = argv[1], dataset = argv[2]; const int use_depth = std::atoi(argv[3]);
     const int n_objects = argc > 4 ? std::atoi(argv[4]) : 4;                 // main.cpp:315-319 hard-codes 4
     const std::string out = argc > 5 ? argv[5] : "./output";
+    const bool gather = argc > 6 && std::strcmp(argv[6], "gather") == 0;
     if (use_depth != 0 && use_depth != 1) { std::fprintf(stderr, "UseGTdepth param error...\n0 or 1\n"); return 0; }
     // harness convenience shared with the Python binding and tests/compat_driver.cpp (the library itself reads no environment variable):
     // MON_OPTIONS="name=value,..."
@@ -39,7 +45,24 @@ int main(int argc, char** argv) {
     for (int i = 0; i < n_objects; ++i) {
         float loss = 0.f; int dev = 0; mon_offline_object_loss(mgr, i, &loss, &dev);
         std::printf("object %d on device %d: final loss %f\n", i, dev, loss);
-        if (mon_offline_render_test(mgr, i, out.c_str(), 4)) return fail("render");
+        if (!gather && mon_offline_render_test(mgr, i, out.c_str(), 4)) return fail("render");
+    }
+    if (gather) {
+        void* lib = dlopen("libmon_core_rccl.so", RTLD_NOW);
+        if (!lib) { std::fprintf(stderr, "gather: %s\n", dlerror()); return 1; }
+        const auto create = reinterpret_cast<decltype(&mon_gather_create)>(dlsym(lib, "mon_gather_create"));
+        const auto destroy = reinterpret_cast<decltype(&mon_gather_destroy)>(dlsym(lib, "mon_gather_destroy"));
+        const auto stats = reinterpret_cast<decltype(&mon_gather_stats)>(dlsym(lib, "mon_gather_stats"));
+        const auto render = reinterpret_cast<decltype(&mon_offline_render_test_gathered)>(dlsym(lib, "mon_offline_render_test_gathered"));
+        if (!create || !destroy || !stats || !render) { std::fprintf(stderr, "gather: libmon_core_rccl.so lacks an entry point\n"); return 1; }
+        mon_gather* g = nullptr;
+        if (create(0, &g)) return fail("mon_gather_create");
+        if (render(g, mgr, out.c_str(), 4)) return fail("mon_offline_render_test_gathered");
+        uint64_t over_links = 0, on_root = 0; int senders = 0; double ms = 0.0;
+        stats(g, &over_links, &on_root, &senders, &ms);
+        std::printf("gathered to device 0: last view %llu B over device links from %d device(s), %llu B already on the root, %.3f ms\n",
+                    (unsigned long long)over_links, senders, (unsigned long long)on_root, ms);
+        destroy(g);
     }
     mon_offline_destroy(mgr);
     std::puts("Training completed");
