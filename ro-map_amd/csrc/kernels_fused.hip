@@ -114,8 +114,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
     float loss_acc = 0.f;
     // ---- phase stagger.  All waves of a CU share one texture-address path, and a ray's 64 gather instructions keep it busy for ~1.5 us; the waves start
     // together and their phases have equal lengths, so they would ALL gather, then ALL run the MLP / composite / backward with the address path idle.  Half of
-    // the waves therefore
-    //      start late by about one gather phase: from then on one group computes while the other gathers.
+    // the waves therefore start late by about one gather phase: from then on one group computes while the other gathers.
     if (a.stagger & 0xffffu) {
         const uint32_t mode = (a.stagger >> 16) & 3u;
         const uint32_t slot = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) ;      // HW_ID.wave_id: this wave's slot on its SIMD

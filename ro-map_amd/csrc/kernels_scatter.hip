@@ -89,11 +89,9 @@ __device__ __forceinline__ void scatter_item(int* tab, const ScatterItem& it, bo
     const float wx[2] = { nxy.x, pxy.x }, wz[2] = { 1.f - pz, pz }; const f2 wy2 = { nxy.y, pxy.y };
     unsigned long long* tab64 = reinterpret_cast<unsigned long long*>(tab);
     // (the fp32 products pass through an opaque register pair: h(w * g) is the ROUNDED product rounded again, like tcnn's `(T)(weight * grad)` and the oracle
-    // -- the
-    //  compiler's own choice, v_fma_mixlo_f16, rounds the exact product once and differs in ~2^-13 of the contributions)
+    // -- the compiler's own choice, v_fma_mixlo_f16, rounds the exact product once and differs in ~2^-13 of the contributions)
     // Per pair of corners: v_pk_mul_f32 (x g), v_cvt_pk_f16_f32 (both h()), then the widening back to fp32 and the multiplication by the fixed-point unit as
-    // ONE
-    //  v_fma_mix_f32 per value (fp16 source operand: exact) -- six instructions where conversions + a packed multiply took eight.
+    // ONE v_fma_mix_f32 per value (fp16 source operand: exact) -- six instructions where conversions + a packed multiply took eight.
     const auto fix2 = [&](f2 w, float gg) -> f2 {
         f2 pr = w * gg; asm volatile("" : "+v"(pr));
         const half2_t hv = { (half_t)pr.x, (half_t)pr.y }; const uint32_t hb = __builtin_bit_cast(uint32_t, hv);

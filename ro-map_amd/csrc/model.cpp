@@ -142,8 +142,7 @@ int tile_ws_get(Model& m, int side, size_t n_pix, TileWs** out) {
         if ((rc = ws_grow(ws.counters, 64))) return rc;
         // (hipMemset of device memory may return before the fill has run, and the renders' streams are non-blocking: without the synchronisation the fill can
         // land in the middle of the first render's ray kernel -- the job count restarts, k_tile_render reads job records nobody wrote and writes to the pixel
-        // index it
-        //  finds there: the memory fault of the object-churn test, seen whenever a device's last object had returned the workspace)
+        // index it finds there: the memory fault of the object-churn test, seen whenever a device's last object had returned the workspace)
         HIPCHECK(hipMemset(ws.counters, 0, 256)); HIPCHECK(hipDeviceSynchronize());
     }
     if (ws.cap < cap || ws.L_cap < m.nd.L) {
@@ -889,8 +888,7 @@ static int sync_state(Model& m) {
     // :1645 (once per call instead of once per iteration); the state rides the same sync in a pinned buffer -- the online manager trains
     // in slices of a few iterations, where a second blocking copy would be a visible share of the slice
     // (only the head: the slot counters behind it are 16 KB the host never reads; written by a one-block kernel rather than hipMemcpyAsync, whose small-copy
-    // path
-    //  costs the slicing online thread ~10 us per call)
+    // path costs the slicing online thread ~10 us per call)
     launch_copy_params(m.train_stream, reinterpret_cast<const uint16_t*>(m.d_state), reinterpret_cast<uint16_t*>(m.h_state_pinned),
             (uint32_t)(offsetof(DevState, n_scatter) / 2));
     // (an event, not hipStreamSynchronize: the stream may be a lane other objects keep feeding)
@@ -1057,8 +1055,7 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
     { int rc = ensure_ema_current(m); if (rc) return rc; }
     hipStream_t s = m.train_stream;
     // (no state read-back: every call that advances the optimizer ends with sync_state, so the host's copy of the step counter is current whenever this thread
-    // gets here --
-    //  the read-back and the synchronisation in front of it were two host round trips per render)
+    // gets here -- the read-back and the synchronisation in front of it were two host round trips per render)
     const uint16_t* prm = (m.h_state.step > 0) ? m.P.ema : m.P.half;
     Mat4 pose; std::memcpy(pose.m, pose16, 64);
     const uint32_t n_pix = box.w * box.h, S2 = 2 * m.oc.S;

@@ -6,15 +6,13 @@
 // (:1725-1728,1781).  For a comparison with the CUDA build on identical inputs the same numbers are produced here:
 //   * Marsaglia's xorwow: x[0..4] + Weyl counter d;  t = x0 ^ (x0 >> 2); x0..x3 = x1..x4; x4 = (x4 ^ (x4 << 4)) ^ (t ^ (t << 1)); d += 362437; out = x4 + d;
 // * host-API ordering (cuRAND documentation, CURAND_ORDERING_PSEUDO_DEFAULT): value n of a generate call = position (n mod LANES) 2^67 + floor(n / LANES) of
-// the
-//     sequence, LANES = 4096; the lanes keep their states between calls.  Lane states are computed on the host (2^67 jump = the xorshift part's 160 x 160 GF(2)
+// the sequence, LANES = 4096; the lanes keep their states between calls. Lane states are computed on the host (2^67 jump = the xorshift part's 160 x 160 GF(2)
 //     transition matrix squared 67 times) and advanced on the device by k_xorwow_fill, one thread per lane, in the reference's order of calls;
 // * flavours: the seed scramble and the integer -> (0, 1] map differ between the two libraries.  rocRAND's (rocrand_xorwow.h:107-118, rocrand_uniform.h:67) is
 //     what the tests pin bit for bit (engine: tests/test_xorwow.py against the header; host generator: tests/test_xorwow_gpu.py against librocrand on the GPU);
 //     cuRAND's (curand_kernel.h _curand_init_scratch / _curand_uniform as published; the library is not in this image) differs in four constants and the
 // addend 2^-33 -- named assumptions CURAND-A1 / A2, CURAND-A3: the n of the ordering rule counts values since the generator's creation, across
-// calls (librocrand's
-//     behaviour, pinned on the GPU; base.json's call sizes are multiples of 4096, for which every reading of the rule agrees).
+// calls (librocrand's behaviour, pinned on the GPU; base.json's call sizes are multiples of 4096, for which every reading of the rule agrees).
 #pragma once
 #include <stdint.h>
 #include <vector>
