@@ -156,7 +156,8 @@ __global__ void __launch_bounds__(256) k_ub_copy(const ub_u4* __restrict__ src, 
 }
 
 // modes 31 / 32: the optimizer's memory streams without its arithmetic -- n_ops parameters: fp32 master / m1 / m2 read + written, 16-bit step counters and EMA
-// read + written, fp16 copy and tile image written, `parts` fp16 partial-table planes read (flags bits 8..11).  flags bit 0: plain instead of non-temporal stores.
+// read + written, fp16 copy and tile image written, `parts` fp16 partial-table planes read (flags bits 8..11).  flags bit 0: plain instead of non-temporal
+// stores.
 //   31: the shipped kernel's shape -- a thread owns 8 consecutive parameters (two 16-byte pieces of every fp32 array, lane stride 32 B), `units` such chunks
 //       requested up front;
 //   32: a thread owns 4 consecutive parameters per unit (one 16-byte piece: a wave instruction covers 1 KB without holes), units a wave apart
