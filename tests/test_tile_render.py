@@ -51,6 +51,30 @@ def test_tile_render_is_bit_identical_to_the_gather_render(pkg, orc, ss, name, t
     obj.close(); ds.close()
 
 
+@pytest.mark.parametrize("kw", [dict(log2_hashmap_size=14, n_levels=8, base_resolution=8, per_level_scale=1.5, n_neurons=64, n_hidden_layers=1),
+                                dict(log2_hashmap_size=15, n_levels=12, base_resolution=12, per_level_scale=1.7, n_neurons=32, n_hidden_layers=2),
+                                dict(log2_hashmap_size=16, n_levels=16, base_resolution=16, per_level_scale=2.0, n_neurons=64, n_hidden_layers=2)],
+                         ids=["T14-L8", "T15-L12-2x32", "T16-scale2-2x64"])
+def test_tile_render_matches_the_gather_render_on_other_level_tables(pkg, ss, tile_option, kw):
+    """Level tables the fixtures do not have -- small hashed levels (T = 2^14, 2^15), a per-level scale of 2 (the finest levels' resolutions pass the table
+    size, the res = 65 536 level indexes by x alone), other base resolutions -- on a briefly trained object: bit-identical images on both paths, the
+    density lattice likewise."""
+    sc = ss.make_scene(**SCENE)
+    ds, obj = ge.make_problem(pkg, sc, dict(rays_per_batch=1024, **kw)); obj.set_backend(1)
+    obj.train(60)
+    ob = sc.objects[0]["boxes"][1]; v = int(ob[0])
+    for bx in [(v, 0, 0, sc.H, sc.W), (v, int(ob[1]), int(ob[2]), int(ob[3]), int(ob[4]))]:
+        box = np.array(bx, np.uint32)
+        (rgb0, d0, m0), (rgb1, d1, m1) = _render_both(pkg, obj, box, ss.colmajor(sc.Twc[v]), tile_option)
+        assert np.array_equal(m0, m1) and np.array_equal(rgb0.view(np.uint32), rgb1.view(np.uint32)) and np.array_equal(d0.view(np.uint32),
+                d1.view(np.uint32)), (kw, bx)
+        assert m1.mean() > 0.01
+    tile_option(0); g0 = obj.density_grid(24, 20, 28)
+    tile_option(2); g1 = obj.density_grid(24, 20, 28)
+    assert np.allclose(g0, g1, rtol=2e-3, atol=1e-4) and np.isfinite(g1).all()
+    obj.close(); ds.close()
+
+
 def test_tile_render_of_a_trained_object_all_entry_points(pkg, ss, tile_option):
     """base.json network trained 300 steps (EMA weights, opaque surfaces: the opaque-prefix skip is exercised): the owner's render,
     the snapshot render on the inference stream, a second object's render in between (the per-device workspace changes hands and
