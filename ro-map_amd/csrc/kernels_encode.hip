@@ -22,6 +22,9 @@
 #include "encode_device.h"
 #include "tile_device.h"
 #include "xorwow.h"
+#ifdef MON_OVERLAP_PROBE
+#include <hip/hip_ext.h>
+#endif
 
 namespace mon {
 
@@ -240,12 +243,17 @@ void launch_sample_points(hipStream_t s, const BatchPtrs& b, const ObjectConst& 
 
 void launch_encode_tiles(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* half_tiles, const float* x_all, uint16_t* e_soa, uint32_t B,
         const DevState* st,
-                         const BatchPtrs* b_next, const DatasetPtrs& ds, const ObjectConst& oc) {
+                         const BatchPtrs* b_next, const DatasetPtrs& ds, const ObjectConst& oc, uint32_t lds_bytes) {
     const uint32_t per_chunk = kEncWgPerLevel * kEncThreads * kEncSpt, chunks = (B + per_chunk - 1u) / per_chunk;
     const uint32_t spw = (B + kEncWgPerLevel * chunks - 1u) / (kEncWgPerLevel * chunks);
     EncodeArgs a{ lf, nd.L, nd.n_mlp, half_tiles, reinterpret_cast<const float4_t*>(x_all), reinterpret_cast<half2_t*>(e_soa), B, spw, st,
             b_next ? 1u : 0u, b_next ? *b_next : BatchPtrs{}, ds, oc };
-    hipLaunchKernelGGL(k_encode_tiles, dim3((uint32_t)nd.L * kEncWgPerLevel, chunks), dim3(kEncThreads), kEncLdsBytes, s, a);
+#ifdef MON_OVERLAP_PROBE
+    // (lds_bytes bit 0 = launch without the AQL barrier bit, hipExtAnyOrderLaunch: ignored on gfx950)
+    if (lds_bytes & 1u) { hipExtLaunchKernelGGL(k_encode_tiles, dim3((uint32_t)nd.L * kEncWgPerLevel, chunks), dim3(kEncThreads), (lds_bytes & ~1u) ? (lds_bytes & ~1u)
+            : kEncLdsBytes, s, nullptr, nullptr, hipExtAnyOrderLaunch, a); return; }
+#endif
+    hipLaunchKernelGGL(k_encode_tiles, dim3((uint32_t)nd.L * kEncWgPerLevel, chunks), dim3(kEncThreads), lds_bytes ? lds_bytes : kEncLdsBytes, s, a);
 }
 
 }  // namespace mon

@@ -258,11 +258,111 @@ __global__ void __launch_bounds__(1024) k_ub_grid_barrier(uint32_t n_barriers, u
     }
     if (acc == 0x12345678u) scratch[0] = acc;
 }
+// mode 72: the same resident grid crossing XCD-HIERARCHICAL barriers (MI355X_MICROARCH.md, row barrier-xcd): a workgroup arrives at ITS XCD's counter with a relaxed
+// atomic; the last arriver of an XCD does the ONE agent-scope release of that XCD's L2 (buffer_wbl2 sc1), arrives at the top counter, and the last of the eight
+// publishes the generation to one word per XCD; every workgroup polls its XCD's word relaxed and does one agent acquire (buffer_inv sc1) behind it.  ctr layout
+// (64-dword = 256-byte spacing): [0] census barrier, [64 (1 + x)] census / arrivals of XCD x, [64 * 9] top counter, [64 (10 + x)] generation of XCD x.
+__global__ void __launch_bounds__(1024) k_ub_grid_barrier_xcd(uint32_t n_barriers, uint32_t* __restrict__ ctr, uint32_t* __restrict__ scratch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    reinterpret_cast<uint32_t*>(smem)[threadIdx.x] = threadIdx.x;
+    __shared__ uint32_t group_size;
+    uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc)); xcc &= 7u;
+    uint32_t* const arrive = ctr + 64u * (1u + xcc); uint32_t* const top = ctr + 64u * 9u; uint32_t* const gen = ctr + 64u * (10u + xcc);
+    uint32_t* const census = ctr + 64u * (18u + xcc);
+    if (threadIdx.x == 0) {       // census: how many workgroups share this XCD (the dispatcher decides; one flat barrier, outside the timed phases' pattern)
+        __hip_atomic_fetch_add(census, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t a = __hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (a < gridDim.x) while (__hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(2);
+        group_size = __hip_atomic_load(census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const uint32_t gs = group_size;
+    uint32_t acc = 0u;
+    for (uint32_t b = 0; b < n_barriers; ++b) {
+        scratch[(size_t)blockIdx.x * 1024u + threadIdx.x] = acc + b;                     // this phase's output (plain stores: they sit in this XCD's L2)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t a = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            if (a == (b + 1u) * gs) {                                                     // this XCD's last arriver: one release for the whole XCD
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const uint32_t t = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+                if (t == (b + 1u) * 8u) for (uint32_t x = 0; x < 8u; ++x) __hip_atomic_store(ctr + 64u * (10u + x), b + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < b + 1u) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        acc += scratch[(size_t)((blockIdx.x + 1u) % gridDim.x) * 1024u + threadIdx.x];    // the next phase reads a neighbour's output (another XCD's)
+    }
+    if (acc == 0x12345678u) scratch[0] = acc;
+}
 __global__ void __launch_bounds__(1024) k_ub_phase(uint32_t b, uint32_t* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     reinterpret_cast<uint32_t*>(smem)[threadIdx.x] = threadIdx.x;
     const uint32_t v = scratch[(size_t)((blockIdx.x + 1u) % gridDim.x) * 1024u + threadIdx.x];
     scratch[(size_t)blockIdx.x * 1024u + threadIdx.x + (size_t)(b & 1u) * 1024u * 1024u] = v + b;
+}
+
+// modes 80 / 81 / 82: fetch granularity of random 4-byte reads.  The T = 2^22 forward pass misses the L2 on 89 % of its corner reads and the
+// counters show a 128-byte line per miss; is there a cache policy under which a miss costs less?  Every lane reads words at pseudo-random offsets of a table of
+// n_entries words (well beyond the L2s; 2^28 = 1 GiB is beyond the Infinity Cache too), 64 reads per thread, 8 in flight.
+//   mode 80: buffer_load_dword, `pattern` = the aux cache-policy bits of the instruction (gfx942+: 1 = sc0, 2 = nt, 16 = sc1, and their sums)
+//   mode 81: buffer_load_dword ... lds (LDS-DMA gather, 4 bytes per lane), aux = pattern
+//   mode 82: plain global_load_dword (pattern 0) / __builtin_nontemporal_load (pattern 2)
+// One instantiation per policy so that a rocprofv3 --pmc pass lists them as separate kernels (TCC_EA0_RDREQ_sum / _32B_sum per dispatch).
+typedef int ub_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t ub_hash(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+template <int AUX> __global__ void __launch_bounds__(256) k_ub_fetch_buf(const uint32_t* __restrict__ table, uint32_t mask, uint32_t* __restrict__ sink) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(table), 0, (int)0xffffffffu, 0x00020000);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; uint32_t acc = 0u;
+    for (uint32_t r = 0; r < 8u; ++r) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) v[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)((ub_hash(t * 64u + r * 8u + k) & mask) << 2), 0, AUX);
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) acc += v[k];
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+template <int AUX> __global__ void __launch_bounds__(256) k_ub_fetch_lds(const uint32_t* __restrict__ table, uint32_t mask, uint32_t* __restrict__ sink) {
+    __shared__ uint32_t stage[8][256];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(table), 0, (int)0xffffffffu, 0x00020000);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; uint32_t acc = 0u;
+    for (uint32_t r = 0; r < 8u; ++r) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k)          // (the LDS address of an LDS-DMA load is wave-uniform base + lane * 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(&stage[k][threadIdx.x & ~63u]), 4,
+                    (int)((ub_hash(t * 64u + r * 8u + k) & mask) << 2), 0, 0, AUX);
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) acc += stage[k][threadIdx.x];
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+template <bool NT> __global__ void __launch_bounds__(256) k_ub_fetch_global(const uint32_t* __restrict__ table, uint32_t mask, uint32_t* __restrict__ sink) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; uint32_t acc = 0u;
+    for (uint32_t r = 0; r < 8u; ++r) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) { const uint32_t* q = table + (ub_hash(t * 64u + r * 8u + k) & mask); v[k] = NT ? __builtin_nontemporal_load(q) : *q; }
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) acc += v[k];
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+static bool launch_fetch_probe(int mode, int pattern, const uint32_t* table, uint32_t n_entries, uint32_t n_ops, uint32_t* sink) {
+    uint32_t mask = 1u; while ((mask << 1) <= n_entries && (mask << 1) != 0u) mask <<= 1; mask -= 1u;
+    const dim3 grid(n_ops / (64u * 256u)), block(256);
+#define MON_UB_F(K, A) case A: hipLaunchKernelGGL(K<A>, grid, block, 0, 0, table, mask, sink); return true;
+    if (mode == 80) switch (pattern) { MON_UB_F(k_ub_fetch_buf, 0) MON_UB_F(k_ub_fetch_buf, 1) MON_UB_F(k_ub_fetch_buf, 2) MON_UB_F(k_ub_fetch_buf, 3)
+        MON_UB_F(k_ub_fetch_buf, 16) MON_UB_F(k_ub_fetch_buf, 17) MON_UB_F(k_ub_fetch_buf, 18) MON_UB_F(k_ub_fetch_buf, 19) default: return false; }
+    if (mode == 81) switch (pattern) { MON_UB_F(k_ub_fetch_lds, 0) MON_UB_F(k_ub_fetch_lds, 2) MON_UB_F(k_ub_fetch_lds, 16) MON_UB_F(k_ub_fetch_lds, 17) default: return false; }
+#undef MON_UB_F
+    if (mode == 82) { if (pattern == 2) hipLaunchKernelGGL(k_ub_fetch_global<true>, grid, block, 0, 0, table, mask, sink);
+        else hipLaunchKernelGGL(k_ub_fetch_global<false>, grid, block, 0, 0, table, mask, sink); return true; }
+    return false;
 }
 
 int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n_ops, float* ms_out) {
@@ -273,11 +373,11 @@ int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n
     // n_ops parameters; n_entries = flags: bit 0 plain stores, bits 4..7 units per thread, bits 8..11 partial tables
     const bool stream = mode == 31 || mode == 32;
     const size_t np = ((size_t)n_ops + 1023) & ~(size_t)1023;
-    const size_t bytes = stream ? np * (12 + 8 + 2 * 8) + 4096 : mode == 30 ? 2 * (size_t)n_ops : (mode == 70 || mode == 71) ? (size_t)16 << 20
+    const size_t bytes = stream ? np * (12 + 8 + 2 * 8) + 4096 : mode == 30 ? 2 * (size_t)n_ops : (mode >= 70 && mode <= 72) ? (size_t)16 << 20 : (mode >= 80 && mode <= 82) ? (size_t)n_entries * 4
             : (size_t)n_entries * 4 * 8;
     if (hipMalloc((void**)&table, bytes) != hipSuccess || hipMalloc((void**)&sink, 64) != hipSuccess) { set_error("microbench: hipMalloc failed");
         return MON_ERR_HIP; }
-    hipMemset(table, 0, bytes);
+    hipMemset(table, mode >= 80 ? 1 : 0, bytes);
     const uint32_t ops_per_thread = 64, threads = n_ops / ops_per_thread, blocks = (threads + 255) / 256;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
@@ -293,14 +393,18 @@ int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n
                                   (uint32_t)np, (n_entries >> 8) & 15u, n_entries & 1u };
             launch_stream(mode, pattern > 0 ? pattern : 512, (int)((n_entries >> 4) & 15u), a);
         }
-        else if (mode == 70 || mode == 71) {
+        else if (mode >= 70 && mode <= 72) {
             const uint32_t wgs = pattern > 0 ? (uint32_t)pattern : 256u;
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ub_grid_barrier), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ub_phase), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-            hipMemsetAsync(table, 0, 1024, 0);
-            if (mode == 70) hipLaunchKernelGGL(k_ub_grid_barrier, dim3(wgs), dim3(1024), 163840, 0, n_ops, table, table + 256);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ub_grid_barrier_xcd), hipFuncAttributeMaxDynamicSharedMemorySize, 163840 - 64);
+            hipMemsetAsync(table, 0, 8192, 0);
+            if (mode == 72) hipLaunchKernelGGL(k_ub_grid_barrier_xcd, dim3(wgs), dim3(1024), 163840 - 64, 0, n_ops, table, table + 4096);
+            else if (mode == 70) hipLaunchKernelGGL(k_ub_grid_barrier, dim3(wgs), dim3(1024), 163840, 0, n_ops, table, table + 256);
             else for (uint32_t b = 0; b < n_ops; ++b) hipLaunchKernelGGL(k_ub_phase, dim3(wgs), dim3(1024), 163840, 0, b, table + 256);
         }
+        else if (mode >= 80 && mode <= 82) { if (!launch_fetch_probe(mode, pattern, table, n_entries, n_ops, reinterpret_cast<uint32_t*>(sink))) {
+                set_error("microbench: no such cache policy %d for mode %d", pattern, mode); hipFree(table); hipFree(sink); return MON_ERR_ARG; } }
         else if (mode == 30) hipLaunchKernelGGL(k_ub_copy, dim3(pattern > 0 ? pattern : 512), dim3(256), 0, 0, reinterpret_cast<const ub_u4*>(table),
                 reinterpret_cast<ub_u4*>(table) + n_ops / 16u, n_ops / 16u);
         else if (mode >= 50 && mode < 70) {

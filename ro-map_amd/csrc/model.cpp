@@ -42,7 +42,11 @@ static std::atomic<long>* option_slot(const char* name) {
         { "step_variant", &Options::step_variant }, { "steps16", &Options::steps16 }, { "keep_zero_samples", &Options::keep_zero_samples },
         { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
         { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner },
-        { "tile_render", &Options::tile_render }, { "state_records", &Options::state_records } };
+        { "tile_render", &Options::tile_render }, { "state_records", &Options::state_records },
+#ifdef MON_OVERLAP_PROBE
+        { "overlap", &Options::overlap }, { "enc_lds_kb", &Options::enc_lds_kb },
+#endif
+    };
     for (const auto& e : tab) if (name && std::strcmp(name, e.n) == 0) return &(g_options.*(e.f));
     return nullptr;
 }
@@ -818,7 +822,11 @@ static void enqueue_iteration(Model& m, int stages) {
                 // (the next iteration is always prepared ahead: the stand-alone kernels run after an invalidation only)
                 const bool gen_next = true;
                 { ProfScope pe(m, MON_K_ENCODE); launch_encode_tiles(s, m.lf, m.nd, m.d_half_tiles, m.d_x_all, m.d_e_soa, B, m.d_state, gen_next ? &m.B_alt
-                        : nullptr, m.ds->ptrs(), m.oc); }
+                        : nullptr, m.ds->ptrs(), m.oc
+#ifdef MON_OVERLAP_PROBE
+                        , (uint32_t)options().enc_lds_kb * 1024u
+#endif
+                        ); }
             }
             ProfScope ps(m, MON_K_FWDBWD);
             // (no grid look-ups before the first refresh: every cell is live during the warm-up)
@@ -865,7 +873,27 @@ static void enqueue_iteration(Model& m, int stages) {
             // thread made these blocks the kernel's tail)
             if (pos_mode) { nx.pos_blocks = std::min((B + 255u) / 256u, 512u); nx.x_all = m.d_x_all; }
         }
+#ifdef MON_OVERLAP_PROBE
+        // PROBE (option overlap): a second, throw-away k_encode_tiles of the CURRENT batch next to k_optimizer -- what would the pair cost side by side?
+        //   1 behind the optimizer on the same stream; 2 / 3 on a side stream, enqueued before / after the optimizer; 4 / 5 the same with a high-priority side
+        //   stream (its own hardware queue); 6 behind the optimizer on the same stream WITHOUT the barrier bit (hipExtAnyOrderLaunch)
+        const long ovl = pos_mode ? (long)options().overlap : 0; const uint32_t enc_lds = (uint32_t)options().enc_lds_kb * 1024u;
+        auto dummy_encode = [&](hipStream_t q, uint32_t any) { launch_encode_tiles(q, m.lf, m.nd, m.d_half_tiles, m.d_x_all, m.d_e_soa, B, m.d_state, nullptr,
+                m.ds->ptrs(), m.oc, enc_lds | any); };
+        const bool side = ovl >= 2 && ovl <= 5, enc_first = ovl == 2 || ovl == 4;
+        if (side && !m.side_stream) {
+            if (ovl >= 4) hipStreamCreateWithPriority(&m.side_stream, hipStreamNonBlocking, -1); else hipStreamCreateWithFlags(&m.side_stream, hipStreamNonBlocking);
+            hipEventCreateWithFlags(&m.ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&m.ev_join, hipEventDisableTiming); }
+        if (side) { hipEventRecord(m.ev_fork, s); hipStreamWaitEvent(m.side_stream, m.ev_fork, 0); }
+        if (side && enc_first) { dummy_encode(m.side_stream, 0u); hipEventRecord(m.ev_join, m.side_stream); }
+#endif
         launch_optimizer(s, P, m.opt, m.d_state, m.d_state_next, nx, (m.oc.R * m.oc.S) / 8u); m.scatter_pending = false;
+#ifdef MON_OVERLAP_PROBE
+        if (side && !enc_first) { dummy_encode(m.side_stream, 0u); hipEventRecord(m.ev_join, m.side_stream); }
+        if (side) hipStreamWaitEvent(s, m.ev_join, 0);
+        if (ovl == 1) dummy_encode(s, 0u);
+        if (ovl == 6) dummy_encode(s, 1u);
+#endif
         std::swap(m.d_state, m.d_state_next);                // the next iteration (and the host's read-back) uses the state this launch prepares
         if (pos_mode) std::swap(m.B, m.B_alt);               // ... and the candidate set k_encode_tiles filled for it
         m.next_ready = (m.backend == 1 && fold); m.points_ready = pos_mode; ++m.enq_iter;

@@ -157,6 +157,9 @@ struct Options {      // (atomics: tests and tools flip options while object thr
          keep_zero_samples{ 0 },   // 1: k_fused_train hands zero-gradient samples to the scatter too (the exactness test's A/B; same parameters, slower)
          state_records{ 1 },    // tables above 8 M parameters keep their optimizer state as 128-byte chunk records (ParamPtrs::rec); 0: the four arrays
          tile_render{ 1 };      // inference on feature-planar level tiles: 0 never (gathers), 1 crops of 4096 rays and more + point queries, 2 always
+#ifdef MON_OVERLAP_PROBE        // variant build only (tools/variant_build.sh ovl -DMON_OVERLAP_PROBE): k_optimizer(i) next to a throw-away k_encode_tiles
+    std::atomic<long> overlap{ 0 }, enc_lds_kb{ 0 };
+#endif
 };
 Options& options();
 int option_set(const char* name, long value);
@@ -226,7 +229,7 @@ void launch_sample_points(hipStream_t s, const BatchPtrs& b, const ObjectConst& 
 void launch_encode_tiles(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* half_tiles, const float* x_all, uint16_t* e_soa, uint32_t B,
         const DevState* st,
                          // b_next: the candidate set GenerateRays of the next iteration goes to
-                         const BatchPtrs* b_next_or_null, const DatasetPtrs& ds, const ObjectConst& oc);
+                         const BatchPtrs* b_next_or_null, const DatasetPtrs& ds, const ObjectConst& oc, uint32_t lds_bytes = 0);
 // XORWOW sample stream (kernels_encode.hip k_xorwow_fill): one thread per lane, the generate calls of one iteration / one Render in the reference's order
 void launch_xorwow_fill(hipStream_t s, void* lane_states, uint32_t lanes, int flavour, uint32_t start_lane, float* out0, uint32_t n0, float* out1, uint32_t n1,
         float* out2, uint32_t n2);
@@ -338,6 +341,9 @@ struct Model {
     struct TrainLanes* lanes = nullptr; int lane = -1; hipEvent_t lane_event = nullptr, switch_event = nullptr, sync_event = nullptr;
     // the object's private stream; train_stream is the one its work currently goes to (this one or a lane's)
     bool tail_marked = false; hipStream_t own_stream = nullptr;
+#ifdef MON_OVERLAP_PROBE
+    hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+#endif
     // (the state the captured pair of iterations starts on)
     hipGraphExec_t graph_exec = nullptr; int graph_backend = -1; const DevState* graph_state = nullptr; const void* graph_mask = nullptr;
 };

@@ -7,4 +7,5 @@ pkg = ge.load_package()
 for wgs in (256, 128):
     for n in (100, 1000):
         a = min(pkg.microbench(70, wgs, 1024, n) for _ in range(3)); b = min(pkg.microbench(71, wgs, 1024, n) for _ in range(3))
-        print("%3d workgroups x 1024 threads, 160 KB LDS each: %4d phases -- resident grid + grid barriers %.2f us per phase, separate launches %.2f us per phase" % (wgs, n, 1e3 * a / n, 1e3 * b / n), flush=True)
+        c = min(pkg.microbench(72, wgs, 1024, n) for _ in range(3))
+        print("%3d workgroups x 1024 threads, 160 KB LDS each: %4d phases -- resident grid + flat grid barriers %.2f us per phase, XCD-hierarchical barriers %.2f us per phase, separate launches %.2f us per phase" % (wgs, n, 1e3 * a / n, 1e3 * c / n, 1e3 * b / n), flush=True)

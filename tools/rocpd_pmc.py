@@ -10,7 +10,7 @@ import sys
 def main():
     root = sys.argv[1]
     rows = {}
-    for db_path in sorted(glob.glob(os.path.join(root, "*", "*_results.db"))):
+    for db_path in sorted(glob.glob(os.path.join(root, "**", "*_results.db"), recursive=True)):
         db = sqlite3.connect(db_path); cur = db.cursor()
         tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
         if "counters_collection" not in tabs:
