@@ -202,6 +202,8 @@ int mon_offline_n_objects(mon_offline* mgr, int* n);
 int mon_offline_object_loss(mon_offline* mgr, int idx, float* loss, int* device);
 /* test images for the first max_views (0 = all) training boxes of object idx: <out_dir>/<id>/test_{img,depth,mask}/<stamp>.png (nerf.cu:335-349) */
 int mon_offline_render_test(mon_offline* mgr, int idx, const char* out_dir, int max_views);
+/* the "Save Object Mesh" step of RenderTestImg alone (nerf.cu:397-403): <out_dir>/<id>/obj.ply if the object has a mesh; mon_offline_render_test includes it */
+int mon_offline_save_mesh(mon_offline* mgr, int idx, const char* out_dir);
 /* GetIntrinsics(), GetAllTwc() and, per object, GetObjTow() / GetBoundingBox() / GetFrameIdAndBBox() (MON/main.cpp:55,149-151,334-336: the viewer's inputs).
  * Buffers may be NULL to query the counts. */
 int mon_offline_get_intrinsics(mon_offline* mgr, float* fx, float* fy, float* cx, float* cy, int* H, int* W);

@@ -76,6 +76,7 @@ _SIGS = {
     "mon_offline_n_objects": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "mon_offline_object_loss": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "mon_offline_render_test": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
+    "mon_offline_save_mesh": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p]),
     "mon_offline_destroy": (C.c_int, [C.c_void_p]),
     "mon_object_generate_mesh": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mon_object_mesh_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -147,6 +148,9 @@ _RCCL_SIGS = {
     "mon_gather_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mon_gather_renders": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mon_gather_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "mon_gather_transport_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "mon_gather_set_transport": (C.c_int, [C.c_void_p, C.c_int]),
+    "mon_gather_last_error": (C.c_char_p, []),
     "mon_offline_render_test_gathered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]),
 }
 _rccl_lib = None
@@ -181,6 +185,10 @@ def gather_plan(object_device, n_pix, n_devices):
     return per, off
 
 
+def _gather_error():
+    return (rccl_lib().mon_gather_last_error() or b"").decode("utf-8", "replace")
+
+
 class Gather:
     """mon_gather: single-process RCCL communicator over the visible devices + the gather-to-root of rendered crops."""
 
@@ -188,7 +196,14 @@ class Gather:
         self.h = C.c_void_p()
         rc = rccl_lib().mon_gather_create(int(root_device), C.byref(self.h))
         if rc:
-            raise MonError(rc, "mon_gather_create failed (see stderr)")
+            raise MonError(rc, "mon_gather_create: " + _gather_error())
+
+    AUTO, RCCL, PEER_COPY = 0, 1, 2
+
+    def set_transport(self, transport):
+        rc = rccl_lib().mon_gather_set_transport(self.h, int(transport))
+        if rc:
+            raise MonError(rc, "mon_gather_set_transport: " + _gather_error())
 
     def renders(self, objects, boxes, poses16, pose_is_Toc=False):
         n = len(objects); b = np.ascontiguousarray(boxes, np.uint32).reshape(n, 5); T = np.ascontiguousarray(poses16, np.float32).reshape(n, 16)
@@ -199,18 +214,21 @@ class Gather:
         pm = (C.c_void_p * n)(*[a.ctypes.data for a in msk])
         rc = rccl_lib().mon_gather_renders(self.h, oh, _p(b), _p(T), int(pose_is_Toc), n, pr, pd, pm)
         if rc:
-            raise MonError(rc, "mon_gather_renders failed (see stderr)")
+            raise MonError(rc, "mon_gather_renders: " + _gather_error())
         return list(zip(rgb, dep, msk))
 
     def stats(self):
         a = C.c_uint64(0); b = C.c_uint64(0); s = C.c_int(0); ms = C.c_double(0)
         rccl_lib().mon_gather_stats(self.h, C.byref(a), C.byref(b), C.byref(s), C.byref(ms))
-        return dict(bytes_over_links=a.value, bytes_on_root=b.value, sending_devices=s.value, transfer_ms=ms.value)
+        nr = C.c_int(0); br = C.c_uint64(0); mr = C.c_int(0); bc = C.c_uint64(0); mc = C.c_int(0)
+        rccl_lib().mon_gather_transport_stats(self.h, C.byref(nr), C.byref(br), C.byref(mr), C.byref(bc), C.byref(mc))
+        return dict(bytes_over_links=a.value, bytes_on_root=b.value, sending_devices=s.value, transfer_ms=ms.value, n_ranks=nr.value, bytes_rccl=br.value,
+                messages_rccl=mr.value, bytes_peer_copy=bc.value, messages_peer_copy=mc.value)
 
     def offline_render_test(self, manager, out_dir, max_views=0):
         rc = rccl_lib().mon_offline_render_test_gathered(self.h, manager.h, out_dir.encode(), int(max_views))
         if rc:
-            raise MonError(rc, "mon_offline_render_test_gathered failed (see stderr)")
+            raise MonError(rc, "mon_offline_render_test_gathered: " + _gather_error())
 
     def close(self):
         if self.h:

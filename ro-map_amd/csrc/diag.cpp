@@ -147,8 +147,10 @@ int mon_debug_occupancy_state(mon_object* o, uint32_t out[2]) {
 }
 int mon_debug_render_jobs(mon_object* o, int side, uint32_t* jobs) {
     if (!o || !o->m || !jobs) { mon::set_error("debug_render_jobs: null argument"); return MON_ERR_ARG; }
+    if (!o->m->tile_ok) { mon::set_error("debug_render_jobs: this object does not render on level tiles"); return MON_ERR_STATE; }
     mon::TileWs* ws = nullptr; const int rc = mon::tile_ws_get(*o->m, side, 0, &ws); if (rc) return rc;
     std::lock_guard<std::mutex> l(ws->mu);
+    if (!ws->counters) { mon::set_error("debug_render_jobs: no tile workspace on the object's device"); return MON_ERR_STATE; }
     if (mon::use_device(o->m->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { mon::set_error("debug_render_jobs: device error");
         return MON_ERR_HIP; }
     if (hipMemcpy(jobs, ws->counters + 16u * ((ws->flip + 1u) & 1u), 4, hipMemcpyDeviceToHost) != hipSuccess) {

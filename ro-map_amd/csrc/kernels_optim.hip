@@ -421,8 +421,8 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict
     for (int off = 128; off >= 4; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
     if (threadIdx.x < 4u) {
         const float4_t v = red[threadIdx.x];
-#pragma unroll
         // rows are in accumulator layout
+#pragma unroll
         for (int j = 0; j < 4; ++j) { const uint32_t pi = p0 + j; if (pi < n_cols) { const int prm = acc_param(fd, (int)pi); if (prm >= 0) gmlp[prm] = v[j];
                 } else if (pi == n_cols) st->loss_sum = v[j]; }
     }
@@ -468,9 +468,8 @@ void launch_copy_params(hipStream_t s, const uint16_t* src, uint16_t* dst, uint3
     hipLaunchKernelGGL(k_copy_params, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16,
             src + (size_t)n16 * 8u, dst + (size_t)n16 * 8u, tail);
 }
-// Record layout of the optimizer state (ParamPtrs::rec) <-> the flat arrays the boundary speaks (get / set_params, debug read-back): which = 0 master, 1 m1, 2
-// m2
-// (floats), 3 the step counters (uint16 widened to uint32 on the way out).
+// Record layout of the optimizer state (ParamPtrs::rec) <-> the flat arrays the boundary speaks (get / set_params, debug read-back): which = 0 master, 1 m1,
+// 2 m2 (floats), 3 the step counters (uint16 widened to uint32 on the way out).
 __global__ void __launch_bounds__(256) k_state_unpack(const float* __restrict__ rec, int which, uint32_t* __restrict__ dst, uint32_t n) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float* r = rec + 32u * (size_t)(i >> 3);

@@ -205,10 +205,8 @@ __device__ __forceinline__ void scatter_samples(int* tab, const half2_t* __restr
     const uint32_t W2 = 1u << w2s, gs = 10u - w2s, G = 1u << gs;
     // Dense levels: the rows of a run are a ray's samples in order, and neighbours along a ray sit in the same coarse cell -- the lanes of a wave would add
     // into the same few entries, and the LDS serialises same-address atomics (ds_add_u64: 19 cycles per wave instruction on random addresses, 46 when four
-    // lanes share one: tools/ldsatomicbench.py).  There a wave takes GROUPS of kGroup consecutive rows (still 16 * kGroup contiguous bytes per group) from runs
-    // W2 /
-    // 16
-    // rows apart; hashed levels scramble the addresses themselves and keep the contiguous rows.
+    // lanes share one: tools/ldsatomicbench.py).  There a wave takes GROUPS of kGroup consecutive rows (still 16 * kGroup contiguous bytes per group) from
+    // runs W2 / 16 rows apart; hashed levels scramble the addresses themselves and keep the contiguous rows.
     constexpr uint32_t kGroupBits = MON_V_SGROUP;
     const uint32_t wg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> w2s)), lane_c = threadIdx.x & (W2 - 1u);
     const uint32_t lane_o = HASHED ? lane_c

@@ -69,7 +69,7 @@ struct OfflineManager {
     std::string dataset, cfg_path; bool use_depth = false; int n_dev = 0; mon_config cfg{};
     float fx = 0, fy = 0, cx = 0, cy = 0, depth_scale = 1.f; int H = 0, W = 0;
     std::vector<std::string> names, stamps; std::map<std::string, uint32_t> stamp_to_idx; std::vector<float> poses;   // [n][16]
-    std::vector<Dataset*> ds; std::vector<OfflineObject*> objs; std::vector<std::thread> threads;
+    std::vector<Dataset*> ds; std::vector<OfflineObject*> objs; std::vector<std::thread> threads; bool joined = false;
     int outer_iters = 10, inner_iters = 500;       // nerf_manager.cu:89, nerf_model.cu:1635
     std::string mesh_dir = "./output";              // nerf.cu:148
     int mesh_res = 64; float mesh_thresh = 2.0f;   // marching_cubes.h:30-31
@@ -226,9 +226,10 @@ int offline_create_nerf(OfflineManager& m, const char* object_file) {    // nerf
 }
 
 int offline_wait(OfflineManager& m) {                                    // nerf_manager.cu:94-102
-    if (m.threads.empty()) { set_error("WaitThreadsEnd: no threads"); return MON_ERR_STATE; }
+    // (a second call after the threads were joined reports the objects' results again: the gathered test images wait on their own, whether or not the caller did)
+    if (m.threads.empty() && !m.joined) { set_error("WaitThreadsEnd: no threads"); return MON_ERR_STATE; }
     for (auto& t : m.threads) if (t.joinable()) t.join();
-    m.threads.clear();
+    m.threads.clear(); m.joined = true;
     for (auto* o : m.objs) if (o->rc != MON_OK) { set_error("object %d: %s", o->id, o->err.c_str()); return o->rc; }
     return MON_OK;
 }
@@ -297,6 +298,16 @@ static void write_pose_line(std::ofstream& f, const std::string& stamp, const mo
             << " " << q[2] << " " << q[3] << std::endl;
 }
 
+// (caller holds o.mu_model)
+static int offline_save_mesh_locked(OfflineManager& m, OfflineObject& o, const std::string& root) {
+    uint32_t n_mesh = 0; model_mesh_counts(*o.model, &n_mesh, nullptr, nullptr);
+    if (n_mesh) {                                                        // "Save Object Mesh", nerf.cu:397-403
+        int rc = model_generate_mesh(*o.model, m.mesh_res, m.mesh_thresh, nullptr, nullptr); if (rc) return rc;
+        rc = model_save_mesh(*o.model, (root + "/obj.ply").c_str()); if (rc) return rc;
+    }
+    return MON_OK;
+}
+
 // Test images of one object for each of its training boxes: <out>/<id>/test_img|test_depth|test_mask/<stamp>.png,
 // 8-bit colour, 16-bit depth x 20000, 8-bit mask (nerf.cu:335-349).
 int offline_render_test(OfflineManager& m, int idx, const char* out_dir, int max_views) {
@@ -314,12 +325,17 @@ int offline_render_test(OfflineManager& m, int idx, const char* out_dir, int max
                 root + "/test_mask/" + o->stamps[i] + ".png", b.w, b.h, rgb.data(), depth.data(), mask.data());
         if (rc) return rc;
     }
-    uint32_t n_mesh = 0; model_mesh_counts(*o->model, &n_mesh, nullptr, nullptr);
-    if (n_mesh) {                                                        // "Save Object Mesh", nerf.cu:397-403
-        int rc = model_generate_mesh(*o->model, m.mesh_res, m.mesh_thresh, nullptr, nullptr); if (rc) return rc;
-        rc = model_save_mesh(*o->model, (root + "/obj.ply").c_str()); if (rc) return rc;
-    }
-    return MON_OK;
+    return offline_save_mesh_locked(m, *o, root);
+}
+
+// "Save Object Mesh" of RenderTestImg (nerf.cu:397-403) on its own: <out>/<id>/obj.ply when the object has a mesh (the gathered test images write the PNGs from
+// one place and still need every object's mesh from its own device)
+int offline_save_mesh(OfflineManager& m, int idx, const char* out_dir) {
+    if (idx < 0 || idx >= (int)m.objs.size()) { set_error("NeRF Idx error ..."); return MON_ERR_ARG; }
+    OfflineObject* o = m.objs[idx]; const std::string root = std::string(out_dir) + "/" + std::to_string(o->id);
+    ::mkdir(out_dir, 0755); ::mkdir(root.c_str(), 0755);
+    std::lock_guard<std::mutex> lm(o->mu_model);
+    return offline_save_mesh_locked(m, *o, root);
 }
 
 int offline_destroy(OfflineManager* m) {
@@ -467,6 +483,7 @@ int mon_offline_object_loss(mon_offline* h, int idx, float* loss, int* device) {
         return MON_OK; }
 int mon_offline_render_test(mon_offline* h, int idx, const char* out_dir, int max_views) { REQ(h); REQ(out_dir);
     return offline_render_test(*h->m, idx, out_dir, max_views); }
+int mon_offline_save_mesh(mon_offline* h, int idx, const char* out_dir) { REQ(h); REQ(out_dir); return offline_save_mesh(*h->m, idx, out_dir); }
 // GetIntrinsics / GetAllTwc / NeRF::GetObjTow, GetBoundingBox, GetFrameIdAndBBox -- what MON/main.cpp:55,149-151,334-336 reads for its viewer
 int mon_offline_get_intrinsics(mon_offline* h, float* fx, float* fy, float* cx, float* cy, int* H, int* W) {
     REQ(h); OfflineManager& m = *h->m; if (fx) *fx = m.fx; if (fy) *fy = m.fy; if (cx) *cx = m.cx; if (cy) *cy = m.cy; if (H) *H = m.H; if (W) *W = m.W;

@@ -161,41 +161,50 @@ int model_generate_mesh(Model& m, int res, float thresh, uint32_t* n_verts, uint
     HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipMemcpy(&m.h_state, m.d_state, offsetof(DevState, n_scatter), hipMemcpyDeviceToHost));
     const uint16_t* prm = (m.h_state.step > 0) ? m.P.ema : m.P.half;
-    // the two network passes: on feature-planar level tiles in LDS (kernels_tilerender.hip, the device's train-side workspace, held until mesh_to_cpu has
-    // synchronised the stream) or, for tables beyond the tiles, layer by layer
-    TileWs* ws = nullptr; std::unique_lock<std::mutex> tile_lock;
-    if (m.backend == 1 && m.tile_ok && options().tile_render != 0) {
-        rc = tile_ws_get(m, 0, 0, &ws); if (rc) return rc;
-        tile_lock = std::unique_lock<std::mutex>(ws->mu);
-        tile_ws_weights(m, *ws, s, prm, m.weights_epoch);
-    }
+    // the two network passes: on feature-planar level tiles in LDS (kernels_tilerender.hip, the device's train-side workspace) or, for tables beyond the
+    // tiles, layer by layer.  The workspace is shared by the device's objects: it is held for each PASS only -- the reference meshes objects concurrently, one
+    // thread each (nerf.cu:138-145), and marching cubes with its host round trips needs none of it -- and never released while kernels that read it may still
+    // be queued (TileWs::mu: "a user holds mu until its stream is synchronised"), on the error paths either.
+    struct TileHold {
+        TileWs* ws; hipStream_t s; std::unique_lock<std::mutex> lock;
+        TileHold(TileWs* w, hipStream_t st) : ws(w), s(st) { if (ws) lock = std::unique_lock<std::mutex>(ws->mu); }
+        ~TileHold() { if (lock.owns_lock()) { (void)hipStreamSynchronize(s); lock.unlock(); } }
+    };
+    TileWs* ws = nullptr;
+    if (m.backend == 1 && m.tile_ok && options().tile_render != 0) { rc = tile_ws_get(m, 0, 0, &ws); if (rc) return rc; }
     const uint32_t chunk = ws ? ws->cap : m.ws_samples;
-    for (size_t p0 = 0; p0 < res3; p0 += chunk) {                             // GetDensityOnGrid :2007-2048
-        const uint32_t n = (uint32_t)((res3 - p0) < chunk ? (res3 - p0) : chunk);
-        if (ws) {
-            launch_grid_points4(s, ws->x, res, res, res, (uint32_t)p0, n);
-            tile_points_forward(m, *ws, s, n);
-            launch_extract_density(s, ws->O, ms.d_density + p0, n);
-            continue;
+    {   TileHold hold(ws, s);
+        if (ws) tile_ws_weights(m, *ws, s, prm, m.weights_epoch);
+        for (size_t p0 = 0; p0 < res3; p0 += chunk) {                         // GetDensityOnGrid :2007-2048
+            const uint32_t n = (uint32_t)((res3 - p0) < chunk ? (res3 - p0) : chunk);
+            if (ws) {
+                launch_grid_points4(s, ws->x, res, res, res, (uint32_t)p0, n);
+                tile_points_forward(m, *ws, s, n);
+                launch_extract_density(s, ws->O, ms.d_density + p0, n);
+                continue;
+            }
+            launch_grid_points(s, m.B.pts, res, res, res, (uint32_t)p0, n);
+            launch_encode(s, m.lt, m.nd, prm, m.B.pts, m.B.E, n, nullptr);
+            launch_mlp_forward(s, m.nd, prm, m.B.E, nullptr, m.B.O, n, nullptr);
+            launch_extract_density(s, m.B.O, ms.d_density + p0, n);
         }
-        launch_grid_points(s, m.B.pts, res, res, res, (uint32_t)p0, n);
-        launch_encode(s, m.lt, m.nd, prm, m.B.pts, m.B.E, n, nullptr);
-        launch_mlp_forward(s, m.nd, prm, m.B.E, nullptr, m.B.O, n, nullptr);
-        launch_extract_density(s, m.B.O, ms.d_density + p0, n);
     }
     rc = mesh_extract(ms, s, res, res, res, thresh, m.oc.aabb.mn, m.oc.aabb.mx); if (rc) return rc;
-    for (uint32_t v0 = 0; v0 < ms.n_verts; v0 += chunk) {                     // compute_mesh_vertex_colors :2050-2069 (padding vertices included)
-        const uint32_t n = (ms.n_verts - v0) < chunk ? (ms.n_verts - v0) : chunk;
-        if (ws) {
-            launch_mesh_warp4(s, ms.d_verts, ws->x, v0, n, m.oc.aabb);
-            tile_points_forward(m, *ws, s, n);
-            launch_mesh_colors(s, ws->O, ms.d_colf, ms.d_col8, v0, n);
-            continue;
+    {   TileHold hold(ws, s);
+        if (ws) tile_ws_weights(m, *ws, s, prm, m.weights_epoch);             // (another object may have used the workspace meanwhile: rebuilt only then)
+        for (uint32_t v0 = 0; v0 < ms.n_verts; v0 += chunk) {                 // compute_mesh_vertex_colors :2050-2069 (padding vertices included)
+            const uint32_t n = (ms.n_verts - v0) < chunk ? (ms.n_verts - v0) : chunk;
+            if (ws) {
+                launch_mesh_warp4(s, ms.d_verts, ws->x, v0, n, m.oc.aabb);
+                tile_points_forward(m, *ws, s, n);
+                launch_mesh_colors(s, ws->O, ms.d_colf, ms.d_col8, v0, n);
+                continue;
+            }
+            launch_mesh_warp(s, ms.d_verts, m.B.pts, v0, n, m.oc.aabb);
+            launch_encode(s, m.lt, m.nd, prm, m.B.pts, m.B.E, n, nullptr);
+            launch_mlp_forward(s, m.nd, prm, m.B.E, nullptr, m.B.O, n, nullptr);
+            launch_mesh_colors(s, m.B.O, ms.d_colf, ms.d_col8, v0, n);
         }
-        launch_mesh_warp(s, ms.d_verts, m.B.pts, v0, n, m.oc.aabb);
-        launch_encode(s, m.lt, m.nd, prm, m.B.pts, m.B.E, n, nullptr);
-        launch_mlp_forward(s, m.nd, prm, m.B.E, nullptr, m.B.O, n, nullptr);
-        launch_mesh_colors(s, m.B.O, ms.d_colf, ms.d_col8, v0, n);
     }
     HIPCHECK(hipGetLastError());
     rc = mesh_to_cpu(ms, s, true); if (rc) return rc;

@@ -135,6 +135,8 @@ template <class T> static int ws_grow(T*& p, size_t n_elems) {      // (contents
 }
 // caller must hold ws->mu before it touches the buffers; the capacity checks below run under it too (two objects of one device may ask at once)
 int tile_ws_get(Model& m, int side, size_t n_pix, TileWs** out) {
+    // (the workspace is filed under m.device: allocate it there whatever device the calling thread happens to have current)
+    HIPCHECK(use_device(m.device));
     TileWsPair* pr = nullptr;
     {   std::lock_guard<std::mutex> l(g_tile_mu);
         TileWsPair*& slot = g_tile_ws[m.device]; if (!slot) slot = new TileWsPair(); pr = slot; }
@@ -207,9 +209,8 @@ static bool tile_render_wanted(const Model& m, size_t n_pix) {
 }
 
 // ---- training lanes: the per-device scheduler behind "one host thread per object" (nerf_manager.cu:89,256-259).
-// Measured (tools/multi_object.py, base.json objects): two objects training concurrently fall into anti-phase on their own -- one gathers (k_fused_train, bound
-// by the
-// L2 request path) while the other scatters and updates (LDS atomics, HBM) -- 1.75 G ray-samples/s against 1.38 G for one; with three or more streams in flight
+// Measured (tools/multi_object.py, base.json objects): two objects training concurrently fall into anti-phase on their own -- one gathers (k_fused_train,
+// bound by the L2 request path) while the other scatters and updates (LDS atomics, HBM) -- 1.75 G ray-samples/s against 1.38 G for one; with three or more streams in flight
 // the dispatcher mixes workgroups of kernels that exclude each other on a CU (k_grid_scatter takes a CU's whole LDS; streams beyond the hardware queues share
 // one and block each other) and the aggregate drops to 1.5 G.  So the training work of ALL objects of a device goes through `train_lanes` (2) shared streams: a
 // chunk of an object's iterations is enqueued on the lane with the least work in flight (the lane of the object's previous chunk while that is still running:
@@ -539,9 +540,8 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         if ((rc = dev_alloc(m, m.d_frag_train, 64 * 512)) || (rc = dev_alloc(m, m.d_frag_render, 64 * 512))) return rc;       // <= 30 fragments of 512 halves
         m.lds_mask = scatter_plan(m.lt, m.nd, m.scatter);
         // a partial table spans the entries up to the end of the LAST LDS-scattered level (the plan covers a prefix of the levels: sizes grow with the level);
-        // sized by the
+        // sized by the whole table it was 16 x 211 MB = 3.4 GB of a T = 2^22 object for the 37 k entries of its two small levels
         {
-            // whole table it was 16 x 211 MB = 3.4 GB of a T = 2^22 object for the 37 k entries of its two small levels
             int last = -1; for (int l = 0; l < m.nd.L; ++l) if ((m.lds_mask >> l) & 1u) last = l;
             m.part_halves = last < 0 ? 0u : ((2u * m.lt.offset[last + 1] + 15u) & ~15u);
         }
@@ -1027,11 +1027,10 @@ int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int
     }
     is->out_rgb = is->out_all; is->out_depth = is->out_all + 3 * (size_t)n_pix; is->out_mask = is->out_all + 4 * (size_t)n_pix;
     // A viewer's render competes with the training kernels of every object on the device.  k_encode_feat's workgroups need a whole CU each (160 KB of LDS) and
-    // wait until training workgroups have drained from one; the gather render's small workgroups slip in anywhere.  Measured (tools/online_replay.py, 60
-    // keyframes every
-    // 50 ms,
-    // mean / p99 of the viewer's crop): 1 object 0.85 / 1.13 ms on tiles against 1.20 / 1.93 ms through the gathers, 4 objects 0.51 / 2.0 against 0.68 / 1.7,
-    // 12 objects 0.58 / 3.1 against 0.67 / 1.7 -- so the tiles serve the viewer while few objects train on the device, the gathers once many do.
+    // wait until training workgroups have drained from one; the gather render's small workgroups slip in anywhere.  Measured (tools/online_replay.py,
+    // 60 keyframes every 50 ms, mean / p99 of the viewer's crop): 1 object 0.85 / 1.13 ms on tiles against 1.20 / 1.93 ms through the gathers, 4 objects 0.51 / 2.0 against 0.68 / 1.7,
+    // 12 objects 0.58 / 3.1 against 0.67 / 1.7 -- so the tiles serve the viewer while few objects live on the device, the gathers once many do
+    // (tile_ws_objects counts the tile-capable objects ALIVE on the device: in the online manager every live object has a training thread).
     TileWs* tws = nullptr; std::unique_lock<std::mutex> tile_lock;
     // level tiles in LDS (kernels_tilerender.hip); the inference side's own workspace
     if (tile_render_wanted(m, n_pix) && (options().tile_render >= 2 || tile_ws_objects(m.device) <= 4)) {

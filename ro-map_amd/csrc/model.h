@@ -92,15 +92,12 @@ struct ScatterLevels { uint32_t entry_offset[kMaxLevels + 1]; uint8_t P[kMaxLeve
 struct ParamPtrs {
     float* master; uint16_t* half; uint16_t* ema; float* m1; float* m2; uint32_t* steps;
     // the per-parameter step counters as SATURATING 16-bit values (steps == nullptr then): exact whenever beta^65535 < 2^-25 for both betas -- the bias
+    // correction 1 - beta^t is then exactly 1.0f for every t the counter can no longer tell apart (beta <= 0.99973; base.json: 0.9 / 0.99)
     uint16_t* steps16;
-                            // correction 1 - beta^t is then exactly 1.0f for every t the counter can no longer tell apart (beta <= 0.99973; base.json: 0.9 /
-                            // 0.99)
-    // large tables (lazy EMA): the optimizer state as ONE 128-byte record per 8-parameter chunk -- master[8] | m1[8] | m2[8] | 8 x uint16 step counters | pad
-    // --
+    // large tables (lazy EMA): the optimizer state as ONE 128-byte record per 8-parameter chunk -- master[8] | m1[8] | m2[8] | 8 x uint16 step counters | pad --
+    // instead of the four arrays above (which are null then): late in training a few per cent of the chunks are touched, and a touched chunk among untouched
+    // ones is then one full line, not four half-used 64-byte sectors.  nullptr = the arrays (small tables: every chunk is streamed anyway)
     float* rec;
-                        // instead of the four arrays above (which are null then): late in training a few per cent of the chunks are touched, and a touched
-                        // chunk among untouched ones is then one full line, not four half-used 64-byte sectors.  nullptr = the arrays (small tables: every
-                        // chunk is streamed anyway)
     float* gmlp;        // fp32 dW [n_mlp]
     uint16_t* ggrid;    // fp16 grid gradient [n_grid], accumulated with global_atomic_pk_add_f16
     // fused backend: dense fp16 partial gradient tables from k_grid_scatter (stride in halves); nullptr = unused

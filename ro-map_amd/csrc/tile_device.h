@@ -17,8 +17,8 @@ template <bool HASHED, bool POW2>
 __device__ __forceinline__ void enc_indices(const float4_t& xv, float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask, uint32_t (&i0)[4],
         uint32_t (&i1)[4], float (&pos)[3]) {
     uint32_t pg[3];
-#pragma unroll
     // (v_fract_f32 = q - floor(q) exactly for q >= 0; one instruction each instead of floor + subtract + convert)
+#pragma unroll
     for (int d = 0; d < 3; ++d) { const float q = fmaf(scale, xv[d], 0.5f); pg[d] = (uint32_t)floor_to_int(q); pos[d] = __builtin_amdgcn_fractf(q); }
     const uint32_t y0 = (HASHED && POW2) ? __umul24(pg[1], my & 0xffffffu) : pg[1] * my, z0 = (HASHED && POW2) ? __umul24(pg[2], mz & 0xffffffu) : pg[2] * mz;
     const uint32_t ay[2] = { y0, y0 + my }, az[2] = { z0, z0 + mz };
