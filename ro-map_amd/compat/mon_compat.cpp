@@ -4,14 +4,28 @@
 // libmon_core.so; fatal errors keep the reference's convention: message on cerr, exit(0) (nerf_manager.cu:21-25).
 // tests/test_compat_shim.py compiles this file against minimal stand-ins of the three third-party headers and runs the consumers'
 // call sequences (MON/main.cpp:322-340, REF/src/System.cc:120-138,567,610, LocalMapping.cc:1172-1280) on the device.
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <type_traits>
 #include "nerf_manager.h"
 
 namespace nerf {
 
-static_assert(sizeof(FrameIdAndBbox) == sizeof(mon_frame_bbox), "FrameIdAndBbox must stay layout-compatible with mon_frame_bbox");
+// What the C ABI relies on when this layer hands the reference's types across it.  With the stand-in headers of tests/compat_stubs/ these hold by construction;
+// tests/compat_real_deps.sh compiles this file against the machine's own Eigen3 / OpenCV / GLEW so that they are checked against the real types.
+// FrameIdAndBbox (CORE/include/common.h:18-23) IS mon_frame_bbox: vectors of it are passed as mon_frame_bbox arrays (h BEFORE w)
+static_assert(sizeof(FrameIdAndBbox) == 20 && sizeof(FrameIdAndBbox) == sizeof(mon_frame_bbox), "FrameIdAndBbox must stay layout-compatible with mon_frame_bbox");
+static_assert(offsetof(FrameIdAndBbox, FrameId) == 0 && offsetof(FrameIdAndBbox, x) == 4 && offsetof(FrameIdAndBbox, y) == 8 && offsetof(FrameIdAndBbox, h) == 12
+        && offsetof(FrameIdAndBbox, w) == 16, "FrameIdAndBbox: {FrameId, x, y, h, w}, four bytes each");
+static_assert(offsetof(mon_frame_bbox, h) == 12 && offsetof(mon_frame_bbox, w) == 16, "mon_frame_bbox: h before w like the reference");
+static_assert(std::is_standard_layout<FrameIdAndBbox>::value && std::is_trivially_copyable<FrameIdAndBbox>::value, "FrameIdAndBbox is a POD");
+// BoundingBox (common.h:25-30): two Vector3f, read through .data() as 3 + 3 floats; EIGEN_MAKE_ALIGNED_OPERATOR_NEW adds operators, no members
+static_assert(sizeof(Eigen::Vector3f) == 12, "Eigen::Vector3f = three packed floats");
+static_assert(sizeof(BoundingBox) == 24, "BoundingBox = {Vector3f min, max} without padding");
+// poses cross the boundary as 16 floats, COLUMN-major (Twc16 / Tow16 of include/mon_core.h): Eigen's default storage order, read through .data()
+static_assert(sizeof(Eigen::Matrix4f) == 64 && !Eigen::Matrix4f::IsRowMajor, "Eigen::Matrix4f = 16 floats, column-major");
 
 static void die(const char* what) { std::cerr << what << ": " << mon_last_error() << std::endl; exit(0); }
 

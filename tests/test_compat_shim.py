@@ -35,6 +35,16 @@ def test_shim_compiles_and_links_as_cxx14(pkg, tmp_path):
     assert r.returncode == 1 and "usage" in r.stderr
 
 
+def test_shim_against_the_machines_own_eigen_opencv_glew(pkg):
+    """tests/compat_real_deps.sh: the shim + its driver compiled against real Eigen3 / OpenCV / GLEW where the machine has them (the static_asserts of
+    mon_compat.cpp -- POD sizes and offsets, column-major 16-float Matrix4f -- then hold for the real types); the build image has none: skipped there."""
+    pkg.lib()
+    r = subprocess.run(["bash", os.path.join(ROOT, "tests", "compat_real_deps.sh")], capture_output=True, text=True, timeout=600)
+    if r.returncode == 77:
+        pytest.skip(r.stdout.strip())
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_shim_runs_the_offline_and_online_call_sequences(pkg, ss, tmp_path):
     if pkg.device_count() == 0:
