@@ -1,5 +1,6 @@
 // microbench.hip -- small device micro-benchmarks used to choose the gradient-scatter strategy
 // (diagnostic entry point mon_microbench; not on the product path).
+#include <vector>
 #include "device_common.h"
 #include "model.h"
 
@@ -305,6 +306,32 @@ __global__ void __launch_bounds__(1024) k_ub_phase(uint32_t b, uint32_t* __restr
     scratch[(size_t)blockIdx.x * 1024u + threadIdx.x + (size_t)(b & 1u) * 1024u * 1024u] = v + b;
 }
 
+// mode 33: the large-table optimizer's RECORD traffic without its arithmetic (T = 2^22: 13.2 M chunk records of 128 B, 60 % of them touched per step early in
+// training, k_optimizer<false, true> moves them at 4.07 TB/s).  A compact ascending list of the touched chunks (pattern = per cent touched, pseudo-random) is
+// walked with a full read + write of every listed record:
+//   n_entries 0: a LANE per record -- eight 16-byte loads and eight stores per lane, a wave instruction touches 64 different 128-byte lines (the shipped shape)
+//   n_entries 1: EIGHT lanes per record, one 16-byte piece each -- a wave instruction covers 8 whole lines
+//   n_entries 2: FOUR lanes per record, two pieces 64 B apart each
+__global__ void __launch_bounds__(256) k_ub_records(float* __restrict__ rec, const uint32_t* __restrict__ list, uint32_t n_list, int variant) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (variant == 0) {
+        if (t >= n_list) return;
+        ub_f4* r = reinterpret_cast<ub_f4*>(rec + 32u * (size_t)list[t]); ub_f4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = r[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = v[k] + 1.f;
+    } else if (variant == 1) {
+        if ((t >> 3) >= n_list) return;
+        ub_f4* r = reinterpret_cast<ub_f4*>(rec + 32u * (size_t)list[t >> 3]) + (t & 7u);
+        *r = *r + 1.f;
+    } else {
+        if ((t >> 2) >= n_list) return;
+        ub_f4* r = reinterpret_cast<ub_f4*>(rec + 32u * (size_t)list[t >> 2]) + (t & 3u);
+        const ub_f4 a = r[0], b = r[4]; r[0] = a + 1.f; r[4] = b + 1.f;
+    }
+}
+
 // modes 80 / 81 / 82: fetch granularity of random 4-byte reads.  The T = 2^22 forward pass misses the L2 on 89 % of its corner reads and the
 // counters show a 128-byte line per miss; is there a cache policy under which a miss costs less?  Every lane reads words at pseudo-random offsets of a table of
 // n_entries words (well beyond the L2s; 2^28 = 1 GiB is beyond the Infinity Cache too), 64 reads per thread, 8 in flight.
@@ -373,6 +400,23 @@ int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n
     // n_ops parameters; n_entries = flags: bit 0 plain stores, bits 4..7 units per thread, bits 8..11 partial tables
     const bool stream = mode == 31 || mode == 32;
     const size_t np = ((size_t)n_ops + 1023) & ~(size_t)1023;
+    if (mode == 33) {
+        const uint32_t n_chunks = n_ops; std::vector<uint32_t> list; list.reserve(n_chunks);
+        for (uint32_t c = 0; c < n_chunks; ++c) { uint32_t x = c * 0x9e3779b9u; x ^= x >> 15; x *= 0x85ebca6bu; x ^= x >> 13; if (x % 100u < (uint32_t)pattern) list.push_back(c); }
+        float* rec = nullptr; uint32_t* dl = nullptr;
+        if (hipMalloc((void**)&rec, 128 * (size_t)n_chunks) != hipSuccess || hipMalloc((void**)&dl, 4 * list.size() + 4) != hipSuccess) {
+            set_error("microbench: hipMalloc failed"); return MON_ERR_HIP; }
+        hipMemset(rec, 0, 128 * (size_t)n_chunks); hipMemcpy(dl, list.data(), 4 * list.size(), hipMemcpyHostToDevice);
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); float best = 1e30f;
+        const uint32_t lanes = n_entries == 0 ? 1u : (n_entries == 1 ? 8u : 4u), threads = (uint32_t)list.size() * lanes;
+        for (int rep = 0; rep < 4; ++rep) {
+            hipEventRecord(a, 0); hipLaunchKernelGGL(k_ub_records, dim3((threads + 255u) / 256u), dim3(256), 0, 0, rec, dl, (uint32_t)list.size(), (int)n_entries);
+            hipEventRecord(b, 0); hipEventSynchronize(b); float ms = 0.f; hipEventElapsedTime(&ms, a, b); if (rep > 0 && ms < best) best = ms;
+        }
+        hipEventDestroy(a); hipEventDestroy(b); hipFree(rec); hipFree(dl);
+        *ms_out = best * 1e6f / (float)(list.size() ? list.size() : 1);      // NANOSECONDS per 1000 touched records (the caller knows the percentage, not the count)
+        return hipGetLastError() == hipSuccess ? MON_OK : MON_ERR_HIP;
+    }
     const size_t bytes = stream ? np * (12 + 8 + 2 * 8) + 4096 : mode == 30 ? 2 * (size_t)n_ops : (mode >= 70 && mode <= 72) ? (size_t)16 << 20 : (mode >= 80 && mode <= 82) ? (size_t)n_entries * 4
             : (size_t)n_entries * 4 * 8;
     if (hipMalloc((void**)&table, bytes) != hipSuccess || hipMalloc((void**)&sink, 64) != hipSuccess) { set_error("microbench: hipMalloc failed");
