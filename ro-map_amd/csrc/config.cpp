@@ -151,8 +151,10 @@ static uint32_t next_multiple(uint32_t v, uint32_t d) { return ((v + d - 1) / d)
 int level_table_build(const mon_config& c, LevelTable& lt, NetDims& nd, uint32_t& n_grid) {
     if (c.n_levels < 1 || c.n_levels > kMaxLevels || c.n_features != 2) { set_error("n_levels must be 1..%d and n_features 2", kMaxLevels);
         return MON_ERR_ARG; }
-    if (!(c.n_neurons == 32 || c.n_neurons == 64) || !(c.n_hidden_layers == 1 || c.n_hidden_layers == 2)) {
-        set_error("n_neurons must be 32|64, n_hidden_layers 1|2"); return MON_ERR_ARG; }
+    // tcnn FullyFusedMLP's widths (base.json:30-36 is user-editable): 32 and 64 run on the fused MFMA kernels with one or two hidden layers, 128 with one;
+    // 16 neurons (half an MFMA tile) and 128 x 2 go through the layer-at-a-time kernels (fused_supported, kernels_fused.hip)
+    if (!(c.n_neurons == 16 || c.n_neurons == 32 || c.n_neurons == 64 || c.n_neurons == 128) || !(c.n_hidden_layers == 1 || c.n_hidden_layers == 2)) {
+        set_error("n_neurons must be 16|32|64|128, n_hidden_layers 1|2"); return MON_ERR_ARG; }
     if (c.log2_hashmap_size < 4 || c.log2_hashmap_size > 26) { set_error("log2_hashmap_size out of range"); return MON_ERR_ARG; }
     uint32_t off = 0; const float l2 = std::log2(c.per_level_scale);
     for (int l = 0; l < c.n_levels; ++l) {

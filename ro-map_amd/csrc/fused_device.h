@@ -446,6 +446,8 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane_uniform) {
             case 32 * 1000 + 32 * 10 + 2: FN<32, 32, 2>(__VA_ARGS__); break;                   \
             case 32 * 1000 + 64 * 10 + 1: FN<32, 64, 1>(__VA_ARGS__); break;                   \
             case 32 * 1000 + 64 * 10 + 2: FN<32, 64, 2>(__VA_ARGS__); break;                   \
+            case 16 * 1000 + 128 * 10 + 1: FN<16, 128, 1>(__VA_ARGS__); break;                 \
+            case 32 * 1000 + 128 * 10 + 1: FN<32, 128, 1>(__VA_ARGS__); break;                 \
             default: break;                                                                    \
         }                                                                                      \
     } while (0)

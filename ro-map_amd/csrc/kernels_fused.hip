@@ -8,7 +8,9 @@ namespace mon {
 // ------------------------------------------------------------------ fused training kernel
 // (PRE: the encode was done by k_encode_tiles -- features are loaded, not gathered)
 template <int EPAD, int W, int NH, bool DUMP, bool ATOMIC_LEVELS, bool OCC = false, bool PRE = false>
-__global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_train(FusedArgs a) {
+// (two waves per SIMD; the widest networks -- two hidden layers of 64, one of 128: tcnn FullyFusedMLP's largest width -- hold their dW accumulators and
+// activations in up to 512 registers at one wave per SIMD)
+__global__ void __launch_bounds__(256, (((NH == 2 && W == 64) || W == 128) ? 1 : 2)) k_fused_train(FusedArgs a) {
     using S = FusedShape<EPAD, W, NH>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half_t* frags = reinterpret_cast<half_t*>(smem);
@@ -475,8 +477,7 @@ __global__ void __launch_bounds__(256, ((NH == 2 && W == 64) ? 1 : 2)) k_fused_t
 
 // ------------------------------------------------------------------ host side
 bool fused_supported(const NetDims& nd, uint32_t S, uint32_t R) {
-    return S == 32 && R <= 16384u && nd.L >= 1 && nd.L <= kMaxLevels && (nd.Epad == 16 || nd.Epad == 32) && (nd.W == 32 || nd.W == 64)
-            && (nd.NH == 1 || nd.NH == 2);
+    return S == 32 && R <= 16384u && nd.L >= 1 && nd.L <= kMaxLevels && (nd.Epad == 16 || nd.Epad == 32) && (((nd.W == 32 || nd.W == 64) && (nd.NH == 1 || nd.NH == 2)) || (nd.W == 128 && nd.NH == 1));
 }
 
 uint32_t fused_train_grid(const NetDims&, uint32_t R) {

@@ -158,11 +158,11 @@ __global__ void __launch_bounds__(256) k_mlp_backward(const uint16_t* __restrict
 // ------------------------------------------------------------------ weight gradients
 // G[row][col] += sum_s A[s][row] * Bm[s][col]   (A: lda halves per sample, Bm: ldb), fp32.
 // One block per chunk of kChunk samples; chunk staged in LDS; one fp32 atomic per output per block.
-constexpr int kChunk = 128;
+constexpr int kChunk = 128, kMaxWidth = 128;
 __global__ void __launch_bounds__(256) k_weight_grad(const uint16_t* __restrict__ A, int lda, int rows, const uint16_t* __restrict__ Bm, int ldb, int cols,
                                                      float* __restrict__ G, uint32_t n, const DevState* __restrict__ st) {
-    __shared__ half_t sa[kChunk * 64];
-    __shared__ half_t sb[kChunk * 64];
+    __shared__ half_t sa[kChunk * kMaxWidth];      // rows, cols <= the widest layer (128 neurons)
+    __shared__ half_t sb[kChunk * kMaxWidth];
     if (st->n_valid == 0u) return;
     const uint32_t s0 = blockIdx.x * kChunk;
     const uint32_t cnt = min((uint32_t)kChunk, n - s0);
@@ -234,6 +234,15 @@ static void mlp_bwd_t(hipStream_t s, const NetDims& nd, const uint16_t* params, 
             case 32 * 1000 + 32 * 10 + 2: FN<32, 32, 2>(__VA_ARGS__); break;                   \
             case 32 * 1000 + 64 * 10 + 1: FN<32, 64, 1>(__VA_ARGS__); break;                   \
             case 32 * 1000 + 64 * 10 + 2: FN<32, 64, 2>(__VA_ARGS__); break;                   \
+            /* tcnn FullyFusedMLP's other widths (base.json:30-36 is user-editable): 16 and 128 neurons */ \
+            case 16 * 1000 + 16 * 10 + 1: FN<16, 16, 1>(__VA_ARGS__); break;                   \
+            case 16 * 1000 + 16 * 10 + 2: FN<16, 16, 2>(__VA_ARGS__); break;                   \
+            case 32 * 1000 + 16 * 10 + 1: FN<32, 16, 1>(__VA_ARGS__); break;                   \
+            case 32 * 1000 + 16 * 10 + 2: FN<32, 16, 2>(__VA_ARGS__); break;                   \
+            case 16 * 1000 + 128 * 10 + 1: FN<16, 128, 1>(__VA_ARGS__); break;                 \
+            case 16 * 1000 + 128 * 10 + 2: FN<16, 128, 2>(__VA_ARGS__); break;                 \
+            case 32 * 1000 + 128 * 10 + 1: FN<32, 128, 1>(__VA_ARGS__); break;                 \
+            case 32 * 1000 + 128 * 10 + 2: FN<32, 128, 2>(__VA_ARGS__); break;                 \
             default: break;                                                                    \
         }                                                                                      \
     } while (0)

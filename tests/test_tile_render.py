@@ -53,8 +53,11 @@ def test_tile_render_is_bit_identical_to_the_gather_render(pkg, orc, ss, name, t
 
 @pytest.mark.parametrize("kw", [dict(log2_hashmap_size=14, n_levels=8, base_resolution=8, per_level_scale=1.5, n_neurons=64, n_hidden_layers=1),
                                 dict(log2_hashmap_size=15, n_levels=12, base_resolution=12, per_level_scale=1.7, n_neurons=32, n_hidden_layers=2),
-                                dict(log2_hashmap_size=16, n_levels=16, base_resolution=16, per_level_scale=2.0, n_neurons=64, n_hidden_layers=2)],
-                         ids=["T14-L8", "T15-L12-2x32", "T16-scale2-2x64"])
+                                dict(log2_hashmap_size=16, n_levels=16, base_resolution=16, per_level_scale=2.0, n_neurons=64, n_hidden_layers=2),
+                                # tcnn FullyFusedMLP's widest network on the fused kernels (round 5), both encoder paddings
+                                dict(log2_hashmap_size=15, n_levels=16, n_neurons=128, n_hidden_layers=1),
+                                dict(log2_hashmap_size=15, n_levels=6, n_neurons=128, n_hidden_layers=1)],
+                         ids=["T14-L8", "T15-L12-2x32", "T16-scale2-2x64", "T15-1x128", "T15-L6-1x128"])
 def test_tile_render_matches_the_gather_render_on_other_level_tables(pkg, ss, tile_option, kw):
     """Level tables the fixtures do not have -- small hashed levels (T = 2^14, 2^15), a per-level scale of 2 (the finest levels' resolutions pass the table
     size, the res = 65 536 level indexes by x alone), other base resolutions -- on a briefly trained object: bit-identical images on both paths, the
