@@ -39,7 +39,7 @@ typedef struct mon_config {
     int32_t  log2_hashmap_size;    /* encoding.log2_hashmap_size (16)                        */
     int32_t  base_resolution;      /* encoding.base_resolution (16)                          */
     float    per_level_scale;      /* encoding.per_level_scale; tcnn default 2.0             */
-    int32_t  n_neurons;            /* network.n_neurons: 32 or 64                            */
+    int32_t  n_neurons;            /* network.n_neurons: 16, 32, 64 or 128 (tcnn FullyFusedMLP) */
     int32_t  n_hidden_layers;      /* network.n_hidden_layers: 1 or 2                        */
     int32_t  rays_per_batch;       /* mnRaysPerBatch (4096); multiple of 64                  */
     int32_t  n_samples;            /* mnSampleNum (32); render uses 2x (mnRenderSampleNum)   */
