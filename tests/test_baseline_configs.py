@@ -4,7 +4,9 @@
 configs[3]: online RO-MAP at TrainStepIterations = 500 on base.json -- the SLAM side's call sequence (LocalMapping.cc:1122-1270) replayed
 through the online manager while the object threads train: what the CALLERS wait is asserted, not only that training happens.
 configs[4]: the stress shape per GPU -- 8 object NeRFs with hash T = 2^22 (105 M parameters each) trained concurrently on one device.
-The two remaining configs need eight GPUs (configs[2] and the 64-object form of configs[4]); their per-GPU code path is what runs here."""
+The two remaining configs need eight GPUs (configs[2] and the 64-object form of configs[4]); their per-GPU code path is what runs here, and configs[2]'s
+whole shape -- 8 objects on 8 devices, base.json, the final render gathered to the root -- runs on 8 LOGICAL devices (one GPU underneath, peer copies where the
+node has RCCL between its GPUs)."""
 import os
 import threading
 import time
@@ -209,6 +211,40 @@ def test_object_placement_over_logical_devices(pkg, ss, tmp_path):
     finally:
         pkg.set_logical_devices(0); pkg.set_option("offline_outer", 10); pkg.set_option("offline_inner", 500)
     assert pkg.device_count() >= 1
+
+
+def test_configs2_shape_eight_objects_on_eight_logical_devices_with_the_gathered_render(pkg, ss, tmp_path):
+    """BASELINE configs[2]: OfflineNeRF, 8 objects sharded object-per-device over 8 devices, base.json, RCCL gather render -- on 8 logical devices: object k on
+    device k (nerf.cu:27-33), one dataset replica per device (nerf_manager.cu:44-55), every object trained, the test images of all of them gathered to device 0
+    (7 ranks send) and equal to the per-object writer's files."""
+    assert pkg.device_count() >= 1
+    sc = ss.make_scene(n_views=16, H=240, W=320, f=260.0, n_objects=8, seed=21)
+    seq = str(tmp_path / "seq"); ss.write_sequence(sc, seq)
+    pkg.set_option("offline_outer", 2); pkg.set_option("offline_inner", 100); pkg.set_logical_devices(8)
+    try:
+        assert pkg.device_count() == 8
+        m = pkg.OfflineManager(seq, os.path.join(ROOT, "ro-map_amd", "configs", "base.json")); m.set_output_dir(str(tmp_path / "out")); m.init(); m.read_dataset()
+        for k in range(8):
+            m.create_nerf(os.path.join(seq, "obj_offline", "%d.txt" % k))
+        m.wait_threads_end()
+        assert [int(m.object_loss(k)[1]) for k in range(8)] == list(range(8))
+        for k in range(8):
+            i = m.object(k).info()
+            assert int(i.train_step) == 200 and int(i.backend) == 1 and np.isfinite(m.object_loss(k)[0]) and m.object_loss(k)[0] < 0.1
+        a, b = str(tmp_path / "per_object"), str(tmp_path / "gathered")
+        g = pkg.Gather(0); g.offline_render_test(m, b, 2); st = g.stats(); g.close()
+        assert st["n_ranks"] == 8 and st["sending_devices"] == 7 and st["messages_rccl"] + st["messages_peer_copy"] == 7 and st["bytes_over_links"] > 0
+        for k in range(8):
+            m.render_test(k, a, 2)
+        n = 0
+        for d, _, files in os.walk(a):
+            for f in files:
+                pa = os.path.join(d, f); pb = os.path.join(b, os.path.relpath(pa, a))
+                assert os.path.exists(pb) and open(pa, "rb").read() == open(pb, "rb").read(), pb; n += 1
+        assert n == 8 * (3 * 2 + 1)                                                  # two views x (img, depth, mask) + obj.ply per object
+        m.close()
+    finally:
+        pkg.set_logical_devices(0); pkg.set_option("offline_outer", 10); pkg.set_option("offline_inner", 500)
 
 
 def test_objects_come_and_go_while_others_train(pkg):
