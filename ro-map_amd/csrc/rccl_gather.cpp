@@ -182,11 +182,15 @@ int mon_gather_renders(mon_gather* g, mon_object* const* objects, const mon_fram
         std::vector<char> via_rccl(g->n_ranks, 0);
         for (int d = 0; d < g->n_ranks; ++d) if (d != g->root && len[d])
             via_rccl[d] = g->transport != MON_GATHER_PEER_COPY && g->rk[d].phys != g->root_phys && g->comms[g->rk[d].phys] && g->comms[g->root_phys];
+        // (one stream per communicator inside a group: the ranks of one GPU send on the stream of that GPU's first rank; their messages were rendered
+        // synchronously, nothing is pending on the others)
+        std::vector<int> first_rank_of(g->n_phys, -1);
+        for (int d = g->n_ranks - 1; d >= 0; --d) first_rank_of[g->rk[d].phys] = d;
         {   NcclGroup grp; ncclResult_t r = ncclSuccess; bool any = false;
             for (int d = 0; d < g->n_ranks && r == ncclSuccess; ++d) {
                 if (!via_rccl[d]) continue;
                 if (!any) { r = grp.start(); any = true; if (r != ncclSuccess) break; }
-                r = ncclSend(g->rk[d].msg, len[d], ncclFloat, g->root_phys, g->comms[g->rk[d].phys], g->rk[d].stream);
+                r = ncclSend(g->rk[d].msg, len[d], ncclFloat, g->root_phys, g->comms[g->rk[d].phys], g->rk[first_rank_of[g->rk[d].phys]].stream);
                 if (r == ncclSuccess) r = ncclRecv(g->recv + recv_off[d], len[d], ncclFloat, g->rk[d].phys, g->comms[g->root_phys], g->rk[g->root].stream);
                 g->bytes_rccl += len[d] * 4; ++g->msgs_rccl;
             }
@@ -199,7 +203,8 @@ int mon_gather_renders(mon_gather* g, mon_object* const* objects, const mon_fram
             HIP_OK(hipMemcpyPeerAsync(g->recv + recv_off[d], g->root_phys, g->rk[d].msg, g->rk[d].phys, len[d] * 4, g->rk[d].stream));
             g->bytes_copy += len[d] * 4; ++g->msgs_copy;
         }
-        for (int d = 0; d < g->n_ranks; ++d) if (d != g->root && len[d]) { HIP_OK(hipSetDevice(g->rk[d].phys)); HIP_OK(hipStreamSynchronize(g->rk[d].stream)); }
+        for (int d = 0; d < g->n_ranks; ++d) if (d != g->root && len[d]) { HIP_OK(hipSetDevice(g->rk[d].phys));
+            HIP_OK(hipStreamSynchronize(via_rccl[d] ? g->rk[first_rank_of[g->rk[d].phys]].stream : g->rk[d].stream)); }
         HIP_OK(hipSetDevice(g->root_phys)); HIP_OK(hipStreamSynchronize(g->rk[g->root].stream));      // (the receives)
         g->bytes_links = g->bytes_rccl + g->bytes_copy;
     }
