@@ -616,7 +616,11 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
             (rc = dev_alloc(m, is->out_all, 5 * (size_t)kRenderChunkRays)) || (rc = dev_alloc(m, is->frag, 64 * 512))) return rc;
         is->out_cap = kRenderChunkRays;
     }
-    HIPCHECK(hipDeviceSynchronize());
+    // what this object's creation enqueued: the fills of its allocations (null stream) and its own stream's kernels.  NOT the device: with other objects'
+    // training threads running, a device-wide wait stands behind everything they have queued -- a whole Train_Step of 500 iterations each in the offline
+    // manager (CreateNeRF of the 8th object of a job took 125-140 ms, 9-23 ms with an idle device; eight objects 0.71-0.80 s -> 0.28-0.32 s of the caller's
+    // time, same PSNRs, same job wall: tools/offline_job.py, A/B/A/B on one box)
+    HIPCHECK(hipStreamSynchronize(nullptr)); HIPCHECK(hipStreamSynchronize(m.train_stream));
     return MON_OK;
 }
 

@@ -14,7 +14,7 @@ exe = os.path.join(ROOT, "ro-map_amd", "offline_nerf"); cfg = os.path.join(ROOT,
 t0 = time.perf_counter()
 r = subprocess.run([exe, cfg, seq, "0", str(n_obj), out], capture_output=True, text=True, timeout=1200)
 dt = time.perf_counter() - t0
-print(r.stdout[-600:]); assert r.returncode == 0, r.stderr
+print("\n".join(l for l in r.stdout.splitlines() if not l.startswith("Id:"))); assert r.returncode == 0, r.stderr
 for k, ob in enumerate(sc.objects):
     v, x, y, h, w = (int(q) for q in ob["boxes"][0]); stamp = "%.6f" % (v * 0.1)
     img = np.asarray(Image.open(os.path.join(out, str(k), "test_img", stamp + ".png"))).astype(np.float64) / 255.0

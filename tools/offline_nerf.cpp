@@ -3,6 +3,7 @@
 // Links only against the C ABI (include/mon_core.h).  With "gather" the test images of all objects go through the in-process RCCL gather-to-root of
 // libmon_core_rccl.so (include/mon_core_rccl.h; loaded on demand, so the plain job needs no RCCL): every object renders on its own device (k mod nGPU,
 // nerf_manager.cu:96), the crops travel to device 0 over xGMI and one writer stores the same PNG bytes mon_offline_render_test writes.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -32,16 +33,26 @@ int main(int argc, char** argv) {
             if (q != std::string::npos && mon_set_option(kv.substr(0, q).c_str(), std::atol(kv.c_str() + q + 1))) return fail("MON_OPTIONS");
         }
     }
+    // wall clock per phase (like the reference's steady_clock around Train_Step, nerf_model.cu:1632,1659)
+    auto t_last = std::chrono::steady_clock::now();
+    auto phase = [&](const char* what) { const auto now = std::chrono::steady_clock::now();
+        std::printf("phase %-28s %8.3f s\n", what, std::chrono::duration<double>(now - t_last).count()); t_last = now; };
     mon_offline* mgr = nullptr;
     if (mon_offline_create(dataset.c_str(), cfg.c_str(), use_depth, &mgr)) return fail("create");
     if (mon_offline_init(mgr)) return fail("Init");
+    phase("create + Init (device)");
     if (mon_offline_read_dataset(mgr)) return fail("ReadDataset");
+    phase("ReadDataset (PNGs -> HBM)");
     mon_offline_set_output_dir(mgr, out.c_str());                          // <out>/<id>.ply, the reference writes ./output/<id>.ply
     for (int i = 0; i < n_objects; ++i) {
         const std::string obj = dataset + "/obj_offline/" + std::to_string(i) + ".txt";
+        const auto tc = std::chrono::steady_clock::now();
         if (mon_offline_create_nerf(mgr, obj.c_str())) return fail("CreateNeRF");
+        std::printf("CreateNeRF %d: %.1f ms\n", i, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count());
     }
+    phase("CreateNeRF (threads started)");
     if (mon_offline_wait_threads_end(mgr)) return fail("WaitThreadsEnd");
+    phase("training + meshes (threads)");
     for (int i = 0; i < n_objects; ++i) {
         float loss = 0.f; int dev = 0; mon_offline_object_loss(mgr, i, &loss, &dev);
         std::printf("object %d on device %d: final loss %f\n", i, dev, loss);
@@ -64,7 +75,9 @@ int main(int argc, char** argv) {
                     (unsigned long long)over_links, senders, (unsigned long long)on_root, ms);
         destroy(g);
     }
+    phase("test images + obj.ply");
     mon_offline_destroy(mgr);
+    phase("destroy");
     std::puts("Training completed");
     return 0;
 }
