@@ -25,5 +25,5 @@ dobjs=(); for s in "${DIAG_SRCS[@]}"; do dobjs+=("$OBJ/${s%.*}.o"); done
 # libmon_core_rccl.so: the in-process gather-to-root over RCCL (include/mon_core_rccl.h), written against the public boundary; the core does not depend on RCCL
 "$HIPCC" --offload-arch=gfx950 -O2 -std=c++17 -fPIC -Wall -x hip -c "$HERE/csrc/rccl_gather.cpp" -o "$OBJ/rccl_gather.o"
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$HERE/libmon_core_rccl.so" "$OBJ/rccl_gather.o" -L"$HERE" -lmon_core -L/opt/rocm/lib -lrccl -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib
-g++ -O2 -std=c++17 "$HERE/../tools/offline_nerf.cpp" -o "$HERE/offline_nerf" -L"$HERE" -lmon_core -ldl -Wl,-rpath,'$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
+g++ -O2 -std=c++17 "$HERE/../tools/offline_nerf.cpp" -o "$HERE/offline_nerf" -L"$HERE" -lmon_core -ldl -lpthread -Wl,-rpath,'$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
 echo "built $HERE/libmon_core.so, $HERE/libmon_core_diag.so, $HERE/libmon_core_rccl.so and $HERE/offline_nerf"

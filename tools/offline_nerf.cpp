@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <vector>
 #include <dlfcn.h>
 #include "../include/mon_core.h"
 #include "../include/mon_core_rccl.h"
@@ -56,7 +58,12 @@ int main(int argc, char** argv) {
     for (int i = 0; i < n_objects; ++i) {
         float loss = 0.f; int dev = 0; mon_offline_object_loss(mgr, i, &loss, &dev);
         std::printf("object %d on device %d: final loss %f\n", i, dev, loss);
-        if (!gather && mon_offline_render_test(mgr, i, out.c_str(), 4)) return fail("render");
+    }
+    if (!gather) {          // every object's test images + obj.ply from a thread of its own: the renders take turns on the device, PNG / ply encoding runs side by side
+        std::vector<std::thread> th; std::vector<int> rcs(n_objects, 0); std::vector<std::string> errs(n_objects);
+        for (int i = 0; i < n_objects; ++i) th.emplace_back([&, i] { rcs[i] = mon_offline_render_test(mgr, i, out.c_str(), 4); if (rcs[i]) errs[i] = mon_last_error(); });
+        for (auto& t : th) t.join();
+        for (int i = 0; i < n_objects; ++i) if (rcs[i]) { std::fprintf(stderr, "OfflineNeRF: render of object %d failed: %s\n", i, errs[i].c_str()); return 1; }
     }
     if (gather) {
         void* lib = dlopen("libmon_core_rccl.so", RTLD_NOW);
