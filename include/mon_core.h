@@ -40,7 +40,7 @@ typedef struct mon_config {
     int32_t  base_resolution;      /* encoding.base_resolution (16)                          */
     float    per_level_scale;      /* encoding.per_level_scale; tcnn default 2.0             */
     int32_t  n_neurons;            /* network.n_neurons: 16, 32, 64 or 128 (tcnn FullyFusedMLP) */
-    int32_t  n_hidden_layers;      /* network.n_hidden_layers: 1 or 2                        */
+    int32_t  n_hidden_layers;      /* network.n_hidden_layers: 1 or 2; 3 or 4 up to 64 neurons */
     int32_t  rays_per_batch;       /* mnRaysPerBatch (4096); multiple of 64                  */
     int32_t  n_samples;            /* mnSampleNum (32); render uses 2x (mnRenderSampleNum)   */
     float    loss_scale;           /* mLoss_Scale (128)                                      */

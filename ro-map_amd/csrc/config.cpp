@@ -153,8 +153,10 @@ int level_table_build(const mon_config& c, LevelTable& lt, NetDims& nd, uint32_t
         return MON_ERR_ARG; }
     // tcnn FullyFusedMLP's widths (base.json:30-36 is user-editable): 32 and 64 run on the fused MFMA kernels with one or two hidden layers, 128 with one;
     // 16 neurons (half an MFMA tile) and 128 x 2 go through the layer-at-a-time kernels (fused_supported, kernels_fused.hip)
-    if (!(c.n_neurons == 16 || c.n_neurons == 32 || c.n_neurons == 64 || c.n_neurons == 128) || !(c.n_hidden_layers == 1 || c.n_hidden_layers == 2)) {
-        set_error("n_neurons must be 16|32|64|128, n_hidden_layers 1|2"); return MON_ERR_ARG; }
+    // Three and four hidden layers (tcnn takes any count) exist on the layer-at-a-time kernels for the widths up to 64.
+    const bool width_ok = c.n_neurons == 16 || c.n_neurons == 32 || c.n_neurons == 64 || c.n_neurons == 128;
+    const bool depth_ok = c.n_hidden_layers == 1 || c.n_hidden_layers == 2 || ((c.n_hidden_layers == 3 || c.n_hidden_layers == 4) && c.n_neurons <= 64);
+    if (!width_ok || !depth_ok) { set_error("n_neurons must be 16|32|64|128, n_hidden_layers 1|2 (3|4 up to 64 neurons)"); return MON_ERR_ARG; }
     if (c.log2_hashmap_size < 4 || c.log2_hashmap_size > 26) { set_error("log2_hashmap_size out of range"); return MON_ERR_ARG; }
     uint32_t off = 0; const float l2 = std::log2(c.per_level_scale);
     for (int l = 0; l < c.n_levels; ++l) {

@@ -121,7 +121,7 @@ int mon_debug_fast_index(const mon_config* cfg, int level, uint32_t x, uint32_t 
     *index = fast_grid_index(lf, level, x, y, z); *size = lf.size[level]; return MON_OK;
 }
 int mon_debug_frag_layout(int epad, int W, int NH, int L, int* source, int* slots, int* n_image, int* n_mlp) {
-    if (!(epad == 16 || epad == 32) || !(W == 32 || W == 64) || !(NH == 1 || NH == 2) || L < 1 || 2 * L > epad) { set_error("frag_layout: unsupported shape");
+    if (!(epad == 16 || epad == 32) || !((((W == 32 || W == 64) && (NH == 1 || NH == 2)) || (W == 128 && NH == 1))) || L < 1 || 2 * L > epad) { set_error("frag_layout: unsupported shape");
         return MON_ERR_ARG; }
     const FragDims d{ epad, W, NH, L };
     if (n_image) *n_image = d.N_FRAGS() * 512;
@@ -132,7 +132,7 @@ int mon_debug_frag_layout(int epad, int W, int NH, int L, int* source, int* slot
     return MON_OK;
 }
 int mon_debug_acc_layout(int epad, int W, int NH, int L, int* param, int* n_cols) {
-    if (!(epad == 16 || epad == 32) || !(W == 32 || W == 64) || !(NH == 1 || NH == 2) || L < 1 || 2 * L > epad) { set_error("acc_layout: unsupported shape");
+    if (!(epad == 16 || epad == 32) || !((((W == 32 || W == 64) && (NH == 1 || NH == 2)) || (W == 128 && NH == 1))) || L < 1 || 2 * L > epad) { set_error("acc_layout: unsupported shape");
         return MON_ERR_ARG; }
     const FragDims d{ epad, W, NH, L };
     if (n_cols) *n_cols = acc_cols(d);

@@ -3,11 +3,18 @@
 // general fallback for shapes the fused kernel does not cover.  It restates tiny-cuda-nn's
 // kernel_grid / kernel_mlp_fused / kernel_grid_backward (absent submodule; call sites
 // CORE/src/nerf_model.cu:1557,1604) with the rounding points fixed in DESIGN.md (numeric model).
+// The MLP kernels are instantiated per (encoder padding, width, hidden layers); the instantiations are spread over three translation units so that the
+// build compiles them side by side (this file: 32 / 64 neurons with one or two hidden layers, the shapes of BASELINE; kernels_net_wide.hip: 16 and 128
+// neurons; kernels_net_deep.hip: three and four hidden layers) -- MON_NET_PART selects which dispatch table a unit carries.
 #include "device_common.h"
 #include "model.h"
+#ifndef MON_NET_PART
+#define MON_NET_PART 0
+#endif
 
 namespace mon {
 
+#if MON_NET_PART == 0
 // ------------------------------------------------------------------ hash-grid encode
 // One thread per (sample, level).  Gathers 8 corners x half2, fp32 fmaf chain, one rounding to fp16.
 __global__ void __launch_bounds__(256) k_encode(LevelTable lt, NetDims nd, const uint16_t* __restrict__ params, const float* __restrict__ pts,
@@ -35,6 +42,8 @@ __global__ void __launch_bounds__(256) k_encode(LevelTable lt, NetDims nd, const
     }
     *out = half2_t{ (half_t)a0, (half_t)a1 };
 }
+
+#endif  // MON_NET_PART == 0
 
 // ------------------------------------------------------------------ MLP forward, one thread per sample
 template <int EPAD, int W, int NH>
@@ -155,6 +164,7 @@ __global__ void __launch_bounds__(256) k_mlp_backward(const uint16_t* __restrict
         dst[k] = v; }
 }
 
+#if MON_NET_PART == 0
 // ------------------------------------------------------------------ weight gradients
 // G[row][col] += sum_s A[s][row] * Bm[s][col]   (A: lda halves per sample, Bm: ldb), fp32.
 // One block per chunk of kChunk samples; chunk staged in LDS; one fp32 atomic per output per block.
@@ -213,6 +223,8 @@ void launch_encode(hipStream_t s, const LevelTable& lt, const NetDims& nd, const
     hipLaunchKernelGGL(k_encode, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, lt, nd, params, pts, E, n, st);
 }
 
+#endif  // MON_NET_PART == 0
+
 template <int EPAD, int W, int NH>
 static void mlp_fwd_t(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n, const DevState* st) {
     hipLaunchKernelGGL((k_mlp_forward<EPAD, W, NH>), dim3((n + 255) / 256), dim3(256), nd.n_mlp * 2, s, params, nd.n_mlp, E, Hid, O, n, st);
@@ -222,38 +234,45 @@ static void mlp_bwd_t(hipStream_t s, const NetDims& nd, const uint16_t* params, 
         uint32_t n, const DevState* st) {
     hipLaunchKernelGGL((k_mlp_backward<EPAD, W, NH>), dim3((n + 255) / 256), dim3(256), nd.n_mlp * 2, s, params, nd.n_mlp, Hid, dO, dHid, dE, n, st);
 }
-#define MON_DISPATCH(FN, ...)                                                                  \
-    do {                                                                                       \
-        const int key = nd.Epad * 1000 + nd.W * 10 + nd.NH;                                    \
-        switch (key) {                                                                         \
-            case 16 * 1000 + 32 * 10 + 1: FN<16, 32, 1>(__VA_ARGS__); break;                   \
-            case 16 * 1000 + 32 * 10 + 2: FN<16, 32, 2>(__VA_ARGS__); break;                   \
-            case 16 * 1000 + 64 * 10 + 1: FN<16, 64, 1>(__VA_ARGS__); break;                   \
-            case 16 * 1000 + 64 * 10 + 2: FN<16, 64, 2>(__VA_ARGS__); break;                   \
-            case 32 * 1000 + 32 * 10 + 1: FN<32, 32, 1>(__VA_ARGS__); break;                   \
-            case 32 * 1000 + 32 * 10 + 2: FN<32, 32, 2>(__VA_ARGS__); break;                   \
-            case 32 * 1000 + 64 * 10 + 1: FN<32, 64, 1>(__VA_ARGS__); break;                   \
-            case 32 * 1000 + 64 * 10 + 2: FN<32, 64, 2>(__VA_ARGS__); break;                   \
-            /* tcnn FullyFusedMLP's other widths (base.json:30-36 is user-editable): 16 and 128 neurons */ \
-            case 16 * 1000 + 16 * 10 + 1: FN<16, 16, 1>(__VA_ARGS__); break;                   \
-            case 16 * 1000 + 16 * 10 + 2: FN<16, 16, 2>(__VA_ARGS__); break;                   \
-            case 32 * 1000 + 16 * 10 + 1: FN<32, 16, 1>(__VA_ARGS__); break;                   \
-            case 32 * 1000 + 16 * 10 + 2: FN<32, 16, 2>(__VA_ARGS__); break;                   \
-            case 16 * 1000 + 128 * 10 + 1: FN<16, 128, 1>(__VA_ARGS__); break;                 \
-            case 16 * 1000 + 128 * 10 + 2: FN<16, 128, 2>(__VA_ARGS__); break;                 \
-            case 32 * 1000 + 128 * 10 + 1: FN<32, 128, 1>(__VA_ARGS__); break;                 \
-            case 32 * 1000 + 128 * 10 + 2: FN<32, 128, 2>(__VA_ARGS__); break;                 \
-            default: break;                                                                    \
-        }                                                                                      \
-    } while (0)
+#define MON_CASE(FN, E, W_, N, ...) case E * 1000 + W_ * 10 + N: FN<E, W_, N>(__VA_ARGS__); return true;
+// (one table per translation unit; returns false when the shape is not in it)
+#if MON_NET_PART == 0
+#define MON_DISPATCH(FN, ...) do { switch (nd.Epad * 1000 + nd.W * 10 + nd.NH) { \
+        MON_CASE(FN, 16, 32, 1, __VA_ARGS__) MON_CASE(FN, 16, 32, 2, __VA_ARGS__) MON_CASE(FN, 16, 64, 1, __VA_ARGS__) MON_CASE(FN, 16, 64, 2, __VA_ARGS__) MON_CASE(FN, 32, 32, 1, __VA_ARGS__) MON_CASE(FN, 32, 32, 2, __VA_ARGS__) MON_CASE(FN, 32, 64, 1, __VA_ARGS__) MON_CASE(FN, 32, 64, 2, __VA_ARGS__) \
+        default: return false; } } while (0)
+#elif MON_NET_PART == 1
+/* tcnn FullyFusedMLP's other widths (base.json:30-36 is user-editable): 16 and 128 neurons */
+#define MON_DISPATCH(FN, ...) do { switch (nd.Epad * 1000 + nd.W * 10 + nd.NH) { \
+        MON_CASE(FN, 16, 16, 1, __VA_ARGS__) MON_CASE(FN, 16, 16, 2, __VA_ARGS__) MON_CASE(FN, 32, 16, 1, __VA_ARGS__) MON_CASE(FN, 32, 16, 2, __VA_ARGS__) MON_CASE(FN, 16, 128, 1, __VA_ARGS__) MON_CASE(FN, 16, 128, 2, __VA_ARGS__) MON_CASE(FN, 32, 128, 1, __VA_ARGS__) MON_CASE(FN, 32, 128, 2, __VA_ARGS__) \
+        default: return false; } } while (0)
+#else
+/* three and four hidden layers (tcnn takes any count; base.json:35 has one) for the widths up to 64 */
+#define MON_DISPATCH(FN, ...) do { switch (nd.Epad * 1000 + nd.W * 10 + nd.NH) { \
+        MON_CASE(FN, 16, 16, 3, __VA_ARGS__) MON_CASE(FN, 16, 16, 4, __VA_ARGS__) MON_CASE(FN, 32, 16, 3, __VA_ARGS__) MON_CASE(FN, 32, 16, 4, __VA_ARGS__) MON_CASE(FN, 16, 32, 3, __VA_ARGS__) MON_CASE(FN, 16, 32, 4, __VA_ARGS__) MON_CASE(FN, 32, 32, 3, __VA_ARGS__) MON_CASE(FN, 32, 32, 4, __VA_ARGS__) \
+        MON_CASE(FN, 16, 64, 3, __VA_ARGS__) MON_CASE(FN, 16, 64, 4, __VA_ARGS__) MON_CASE(FN, 32, 64, 3, __VA_ARGS__) MON_CASE(FN, 32, 64, 4, __VA_ARGS__) \
+        default: return false; } } while (0)
+#endif
 
+#if MON_NET_PART == 0
+bool mlp_forward_part1(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n, const DevState* st);
+bool mlp_forward_part2(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n, const DevState* st);
+bool mlp_backward_part1(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE, uint32_t n,
+        const DevState* st);
+bool mlp_backward_part2(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE, uint32_t n,
+        const DevState* st);
+static bool mlp_forward_part0(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n,
+        const DevState* st) { MON_DISPATCH(mlp_fwd_t, s, nd, params, E, Hid, O, n, st); }
+static bool mlp_backward_part0(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE,
+        uint32_t n, const DevState* st) { MON_DISPATCH(mlp_bwd_t, s, nd, params, Hid, dO, dHid, dE, n, st); }
 void launch_mlp_forward(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n,
         const DevState* st) {
-    MON_DISPATCH(mlp_fwd_t, s, nd, params, E, Hid, O, n, st);
+    (void)(mlp_forward_part0(s, nd, params, E, Hid, O, n, st) || mlp_forward_part1(s, nd, params, E, Hid, O, n, st)
+            || mlp_forward_part2(s, nd, params, E, Hid, O, n, st));          // (config.cpp admits exactly the shapes of the three tables)
 }
 void launch_mlp_backward(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE,
         uint32_t n, const DevState* st) {
-    MON_DISPATCH(mlp_bwd_t, s, nd, params, Hid, dO, dHid, dE, n, st);
+    (void)(mlp_backward_part0(s, nd, params, Hid, dO, dHid, dE, n, st) || mlp_backward_part1(s, nd, params, Hid, dO, dHid, dE, n, st)
+            || mlp_backward_part2(s, nd, params, Hid, dO, dHid, dE, n, st));
 }
 void launch_weight_grads(hipStream_t s, const NetDims& nd, const uint16_t* E, const uint16_t* Hid, const uint16_t* dHid, const uint16_t* dO, float* gmlp,
         uint32_t n, const DevState* st) {
@@ -272,5 +291,17 @@ void launch_grid_backward(hipStream_t s, const LevelTable& lt, const NetDims& nd
     const uint64_t threads = (uint64_t)n * nd.L;
     hipLaunchKernelGGL(k_grid_backward, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, lt, nd, pts, dE, ggrid, n, st);
 }
+
+#elif MON_NET_PART == 1
+bool mlp_forward_part1(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n, const DevState* st) {
+    MON_DISPATCH(mlp_fwd_t, s, nd, params, E, Hid, O, n, st); }
+bool mlp_backward_part1(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE, uint32_t n,
+        const DevState* st) { MON_DISPATCH(mlp_bwd_t, s, nd, params, Hid, dO, dHid, dE, n, st); }
+#else
+bool mlp_forward_part2(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n, const DevState* st) {
+    MON_DISPATCH(mlp_fwd_t, s, nd, params, E, Hid, O, n, st); }
+bool mlp_backward_part2(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE, uint32_t n,
+        const DevState* st) { MON_DISPATCH(mlp_bwd_t, s, nd, params, Hid, dO, dHid, dE, n, st); }
+#endif
 
 }  // namespace mon

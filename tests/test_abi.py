@@ -135,7 +135,7 @@ def test_closed_form_corner_index_matches_tcnn_loop(pkg, orc):
                 assert n == size and got == orc.lib().orc_grid_index(size, r, x, y, z), (kw, l, r, size, x, y, z)
 
 
-@pytest.mark.parametrize("shape", [(32, 64, 1, 16), (16, 32, 2, 4), (32, 64, 2, 13), (16, 64, 1, 7), (32, 32, 2, 16)])
+@pytest.mark.parametrize("shape", [(32, 64, 1, 16), (16, 32, 2, 4), (32, 64, 2, 13), (16, 64, 1, 7), (32, 32, 2, 16), (32, 128, 1, 16), (16, 128, 1, 6)])
 def test_fragment_layout_maps_are_inverse(pkg, shape):
     """frag_layout.h: every image element names the parameter whose slot list contains it, and the other way round
     (the optimizer writes the image through frag_slots, k_build_frag_image reads through frag_source)."""
@@ -157,7 +157,7 @@ def test_fragment_layout_maps_are_inverse(pkg, shape):
     assert ((slots[:, 0] >= 0) == real).all() and ((slots[:, 1] >= 0) == real).all()
 
 
-@pytest.mark.parametrize("shape", [(32, 64, 1, 16), (16, 32, 2, 4), (32, 64, 2, 13), (16, 64, 1, 7), (32, 32, 2, 16)])
+@pytest.mark.parametrize("shape", [(32, 64, 1, 16), (16, 32, 2, 4), (32, 64, 2, 13), (16, 64, 1, 7), (32, 32, 2, 16), (32, 128, 1, 16), (16, 128, 1, 6)])
 def test_accumulator_layout_of_the_dw_partial_rows(pkg, shape):
     """frag_layout.h acc_param: k_fused_train writes its weight-gradient partial rows in MFMA accumulator order and the summing kernels map columns to
     parameters.  The map must hit every parameter that can carry a gradient exactly once and nothing else."""

@@ -297,11 +297,12 @@ def test_nondefault_hyperparameters_match_oracle(pkg, orc, small_scene, backend)
     obj.close(); ds.close(); ref.close()
 
 
-@pytest.mark.parametrize("W,NH,L,backends", [(128, 1, 16, (0, 1)), (128, 1, 6, (1,)), (128, 2, 8, (0,)), (16, 1, 16, (0,)), (16, 2, 4, (0,))],
-                         ids=["1x128", "1x128-L6", "2x128", "1x16", "2x16"])
+@pytest.mark.parametrize("W,NH,L,backends", [(128, 1, 16, (0, 1)), (128, 1, 6, (1,)), (128, 2, 8, (0,)), (16, 1, 16, (0,)), (16, 2, 4, (0,)), (64, 3, 16, (0,)),
+                                             (32, 4, 8, (0,)), (16, 4, 12, (0,))],
+                         ids=["1x128", "1x128-L6", "2x128", "1x16", "2x16", "3x64", "4x32", "4x16"])
 def test_the_other_fully_fused_mlp_widths_match_oracle(pkg, orc, small_scene, W, NH, L, backends):
     """tcnn's FullyFusedMLP takes 16 / 32 / 64 / 128 neurons and base.json:30-36 is the user's to edit: one hidden layer of 128 runs on the fused MFMA kernels
-    (the default backend for it), 2 x 128 and 16 neurons (half an MFMA tile) on the layer-at-a-time kernels.  Forward / backward and three optimizer steps
+    (the default backend for it), 2 x 128, 16 neurons (half an MFMA tile) and three / four hidden layers on the layer-at-a-time kernels.  Forward / backward and three optimizer steps
     against the oracle, a render against the oracle's, both encoder paddings."""
     _need_gpu(pkg)
     kw = dict(rays_per_batch=256, n_levels=L, log2_hashmap_size=15, n_neurons=W, n_hidden_layers=NH)
