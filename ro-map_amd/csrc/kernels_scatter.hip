@@ -439,6 +439,28 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
 #endif
 }
 
+// Layer-at-a-time backend (network shapes the fused kernel does not take: 16 neurons, 2 x 128, three / four hidden layers): its dL/dE rows [B][Epad] and positions
+// [B][3] in the hand-over layout k_grid_scatter walks -- EVERY sample at its natural slot (bin = ray & (bins - 1), slot (ray / bins) * S + n, like
+// k_fused_train with keep_zero_samples), every bin counter = its capacity -- so that the grid backward of those shapes is the same exact LDS accumulation
+// instead of tcnn's 16.8 M global packed-f16 atomics (k_grid_backward: 902 of the 1100 us such a step took).
+__global__ void __launch_bounds__(256) k_rows_to_bins(const half_t* __restrict__ dE, const float* __restrict__ pts, uint32_t Epad, int L, uint32_t R, uint32_t S,
+                                                      uint32_t n_bins, float clampv, half2_t* __restrict__ de_soa, float4_t* __restrict__ x4, DevState* st) {
+    if (st->n_valid == 0u) return;
+    const uint32_t B = R * S, s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0u && threadIdx.x < n_bins) st->n_scatter[scatter_counter(st->iter, threadIdx.x)] = B / n_bins;
+    if (s >= B) return;
+    const uint32_t ray = s / S, n = s - ray * S, bin = ray & (n_bins - 1u), slot = bin * (B / n_bins) + (ray / n_bins) * S + n;
+    x4[slot] = float4_t{ pts[3 * (size_t)s], pts[3 * (size_t)s + 1], pts[3 * (size_t)s + 2], 0.f };
+    const half2_t* row = reinterpret_cast<const half2_t*>(dE + (size_t)s * Epad);
+    for (int l = 0; l < L; ++l) { const half2_t g = row[l];
+        de_soa[(size_t)l * B + slot] = half2_t{ (half_t)clamp_f((float)g.x, -clampv, clampv), (half_t)clamp_f((float)g.y, -clampv, clampv) }; }
+}
+void launch_rows_to_bins(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* dE, const float* pts, uint32_t R, uint32_t S, uint32_t n_bins,
+        uint16_t* de_soa, float* x_soa, DevState* st) {
+    hipLaunchKernelGGL(k_rows_to_bins, dim3((R * S + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<const half_t*>(dE), pts, (uint32_t)nd.Epad, nd.L, R, S, n_bins,
+            lf.fix_clamp, reinterpret_cast<half2_t*>(de_soa), reinterpret_cast<float4_t*>(x_soa), st);
+}
+
 // Host: which levels go through the LDS scatter, with how many sample partitions each.
 uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl) {
     uint32_t mask = 0; sl.n_levels = 0; sl.max_P = 0;

@@ -575,6 +575,17 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         if (flags_on && m.lazy_ema && m.lds_mask && m.lds_mask != ((m.nd.L >= 32) ? 0xffffffffu : ((1u << m.nd.L) - 1u))
                 && (rc = dev_alloc(m, m.d_touched, (m.n_params >> 3) + 16))) return rc;
     }
+    else if (S == 32u && !m.lazy_ema) {
+        // Shapes the fused kernels do not take (16 neurons, 2 x 128, three / four hidden layers): the layer-at-a-time kernels, but their grid backward through
+        // k_grid_scatter when the plan covers every level (tables up to 2^18 entries per level) -- see k_rows_to_bins
+        ScatterLevels plan{}; const uint32_t mask = scatter_plan(m.lt, m.nd, plan);
+        if (mask == ((1u << m.nd.L) - 1u) && (R % kDefaultScatterBins) == 0u) {
+            m.scatter = plan; m.part_halves = (2u * m.lt.offset[m.nd.L] + 15u) & ~15u;
+            if ((rc = dev_alloc(m, m.d_de_soa, (size_t)m.nd.L * Btrain * 2)) || (rc = dev_alloc(m, m.d_x_soa, 4 * (size_t)Btrain)) ||
+                (rc = dev_alloc(m, m.d_gpart, (size_t)m.scatter.max_P * m.part_halves))) return rc;
+            m.hybrid_scatter = true;
+        }
+    }
     if (cfg.occupancy_skip && fused_supported(m.nd, S, m.oc.R)) {
         constexpr size_t words = (size_t)kOccRes * kOccRes * kOccRes / 32;
         if ((rc = dev_alloc(m, m.d_occ, words, false)) || (rc = dev_alloc(m, m.d_occ_tmp, words, false))
@@ -812,7 +823,16 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_composite_grad(s, m.B, m.oc, m.d_state);
             launch_mlp_backward(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state);
             launch_weight_grads(s, m.nd, m.B.E, m.B.Hid, m.B.dHid, m.B.dO, m.P.gmlp, B, m.d_state);
-            launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
+            // whole steps of a shape outside the fused kernels: the exact LDS scatter (partial tables, summed by the optimizer).  Stage-wise calls (the debugging
+            // entry that stops before the optimizer) keep tcnn's global atomics into ggrid, which only the non-dense optimizer clears: start from zeros there
+            if (m.hybrid_scatter && stages == 7) {
+                launch_rows_to_bins(s, m.lf, m.nd, m.B.dE, m.B.pts, m.oc.R, m.oc.S, m.n_bins, m.d_de_soa, m.d_x_soa, m.d_state);
+                launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_gpart, m.part_halves / 2, m.d_state, nullptr, 0u, m.P.gmlp,
+                        m.d_state_next);
+            } else {
+                if (m.hybrid_scatter) hipMemsetAsync(m.P.ggrid, 0, (size_t)m.n_grid * 2, s);
+                launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
+            }
         } else {
             // stage-wise debugging: a forward/backward without an optimizer step after it
             if (m.scatter_pending) hipMemsetAsync(m.d_state->n_scatter, 0, sizeof(m.d_state->n_scatter), s);
@@ -855,6 +875,7 @@ static void enqueue_iteration(Model& m, int stages) {
         ParamPtrs P = m.P;
         if (m.backend == 1 && m.lds_mask) { P.gpart = m.d_gpart; P.part_stride = m.part_halves; P.sl = m.scatter;
             P.all_levels_dense = (m.lds_mask == ((1u << m.nd.L) - 1u)) ? 1 : 0; }
+        if (m.backend == 0 && m.hybrid_scatter && stages == 7) { P.gpart = m.d_gpart; P.part_stride = m.part_halves; P.sl = m.scatter; P.all_levels_dense = 1; }
         P.half_tiles = (m.backend == 1 && P.gpart && P.all_levels_dense) ? m.d_half_tiles : nullptr;
         const bool lazy = m.lazy_ema && !(P.gpart && P.all_levels_dense);
         P.ema_step = lazy ? m.d_ema_step : nullptr; if (lazy) m.ema_pending = true;

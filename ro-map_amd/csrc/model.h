@@ -240,6 +240,9 @@ void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& l
         uint32_t n_bins, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
                          // partials != null: also sums the dW partial rows (k_reduce_partials folded in)
                          const float* partials_or_null, uint32_t n_partials, float* gmlp, DevState* st_next);
+// layer-at-a-time backend: dL/dE rows + positions of every sample into k_grid_scatter's hand-over layout (kernels_scatter.hip)
+void launch_rows_to_bins(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* dE, const float* pts, uint32_t R, uint32_t S, uint32_t n_bins,
+        uint16_t* de_soa, float* x_soa, DevState* st);
 size_t big_scatter_workspace_bytes(const LevelTable& lt, const NetDims& nd, uint32_t lds_mask, uint32_t B);
 void launch_big_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, uint32_t lds_mask, const uint16_t* de_soa,
         const float* x_soa, uint32_t B,
@@ -300,6 +303,8 @@ struct Model {
     uint16_t* d_de_soa = nullptr; float* d_x_soa = nullptr;       // compacted dL/dE rows [L][B] and positions [B] float4 for the scatter kernels
     // level-tile encode: positions [B] float4 of every sample, encoded features [L][B] half2 (nullptr: the fused kernel gathers)
     float* d_x_all = nullptr; uint16_t* d_e_soa = nullptr; uint16_t* d_half_tiles = nullptr;
+    // network shapes outside the fused kernels (backend 0 by necessity) whose levels all fit the LDS scatter plan: whole training steps scatter through k_grid_scatter
+    bool hybrid_scatter = false;
     uint16_t* d_gpart = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0;   // k_grid_scatter: partial tables, plan, levels it covers
     // halves of ONE partial table: the grid parameters of the LDS-scattered levels (a prefix of the levels), not of the whole table
     uint32_t part_halves = 0;
