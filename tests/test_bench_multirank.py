@@ -27,7 +27,7 @@ def _json_line(out):
 @pytest.mark.gpu
 def test_two_self_spawned_ranks_report_two_gpus_and_gather_both_crops(pkg):
     assert pkg.device_count() >= 1
-    small = ["--steps", "6", "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--objects-per-gpu", "0", "--views", "12"]
+    small = ["--steps", "6", "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--objects-per-gpu", "0", "--views", "12", "--no-sustained"]
     r2 = _run(["--gpus", "2"] + small)
     assert r2.returncode == 0, r2.stderr[-3000:]
     j2 = _json_line(r2.stdout)
