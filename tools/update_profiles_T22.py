@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/r04_window_T22.md from gpurun_out/r04_T22_{init,late,init8,late8} (tools/gpu_profile_window.sh with WINDOW_ARGS="--log2-hashmap-size 22 [--objects 8]")."""
+"""profiles/<round>_window_T22.md (round = argv[1], default r04) from gpurun_out/<round>_T22_{init,late,init8,late8} -- sections whose directory is missing are left out -- (tools/gpu_profile_window.sh with WINDOW_ARGS="--log2-hashmap-size 22 [--objects 8]")."""
 import os
 import re
 import sys
@@ -11,6 +11,8 @@ from update_profiles_render import counters, table  # noqa: E402
 
 def section(tag, title, L):
     d = os.path.join(ROOT, "gpurun_out", tag)
+    if not os.path.exists(os.path.join(d, "kernel_window.md")):
+        return
     t = table(os.path.join(d, "kernel_window.md")); c = counters(os.path.join(d, "pmc_window.md")) if os.path.exists(os.path.join(d, "pmc_window.md")) else {}
     head = [l for l in open(os.path.join(d, "trace.log")) if l.startswith("window:")]
     L.append("## %s\n" % title)
@@ -30,19 +32,20 @@ def section(tag, title, L):
 
 
 def main():
-    L = ["# r04: the stress configuration (BASELINE configs[4]: hash T = 2^22, 105 M parameters = 211 MB fp16 per object) -- rocprofv3 windows on one MI355X\n",
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    L = ["# %s: the stress" % rnd + " configuration (BASELINE configs[4]: hash T = 2^22, 105 M parameters = 211 MB fp16 per object) -- rocprofv3 windows on one MI355X\n",
          "`tools/gpu_profile_window.sh <tag> <extra>` with `WINDOW_ARGS=\"--log2-hashmap-size 22 [--objects 8]\"`: kernel trace of steps extra+5 .. extra+25 of",
          "`tools/profile_window.py`, then one `--pmc` pass per counter set.  \"traffic beyond L2\" = (2 x FETCH_SIZE + WRITE_SIZE) KB of the committed pass: what the L2s",
          "fetched from / wrote to the fabric -- Infinity Cache (256 MB, memory side) or HBM; the counters do not tell the two apart, the RATE does: a kernel whose traffic",
          "moves faster than HBM streams (6-7.3 TB/s for a two-stream copy, `profiles/r02_copybench.md`; 8 TB/s peak) is served partly by the Infinity Cache.\n"]
-    section("r04_T22_init", "one object, steps 20..40 from init (60 % of the 13.2 M parameter chunks carry a gradient)", L)
-    section("r04_T22_late", "one object, steps 800..820 (a few thousand gradient-carrying samples per step)", L)
-    section("r04_T22_init8", "eight objects on one GPU (a thread and a stream each), steps 20..40 of every object", L)
-    section("r04_T22_late8", "eight objects on one GPU, steps 800..820 (kernel trace only)", L)
-    notes = os.path.join(ROOT, "profiles", "r04_window_T22_notes.md")
+    section(rnd + "_T22_init", "one object, steps 20..40 from init (60 % of the 13.2 M parameter chunks carry a gradient)", L)
+    section(rnd + "_T22_late", "one object, steps 800..820 (a few thousand gradient-carrying samples per step)", L)
+    section(rnd + "_T22_init8", "eight objects on one GPU (a thread and a stream each), steps 20..40 of every object", L)
+    section(rnd + "_T22_late8", "eight objects on one GPU, steps 800..820 (kernel trace only)", L)
+    notes = os.path.join(ROOT, "profiles", rnd + "_window_T22_notes.md")
     if os.path.exists(notes):
         L.append(open(notes).read())
-    open(os.path.join(ROOT, "profiles", "r04_window_T22.md"), "w").write("\n".join(L) + "\n")
+    open(os.path.join(ROOT, "profiles", rnd + "_window_T22.md"), "w").write("\n".join(L) + "\n")
     print("\n".join(L))
 
 
