@@ -328,11 +328,23 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
             if (p.touched) {
                 // Chunk flags (one byte per chunk, set next to every addition into ggrid): the scan reads 1/16 of what the gradient table
                 // itself would cost.  Chunks below first_flag_chunk (MLP matrices, LDS-scattered levels) are few and always visited.
-                for (uint32_t c = c_first; c < p.first_flag_chunk; c += c_stride) update_chunk(c, false, none, none, none);
                 const uint32_t w_end = (n_chunks + 3u) >> 2; uint32_t* flags = reinterpret_cast<uint32_t*>(p.touched);
-                for (uint32_t w0 = (p.first_flag_chunk >> 2) + c_first - lane; w0 < w_end; w0 += c_stride) {     // wave-uniform trip count
+                // a wave's flag words (6-7 trips at T = 2^22) are requested TOGETHER and ahead of everything else: one load per loop trip put a memory round
+                // trip in front of every trip (late in training the kernel is a chain of such round trips, not bandwidth: 141 MB in 57 us)
+                constexpr uint32_t kFlagPre = 8;
+                const uint32_t wf0 = (p.first_flag_chunk >> 2) + c_first - lane; uint32_t fpre[kFlagPre];
+#pragma unroll
+                for (uint32_t k = 0; k < kFlagPre; ++k) { const uint32_t w = wf0 + k * c_stride + lane; fpre[k] = (w < w_end) ? flags[w] : 0u; }
+                for (uint32_t c = c_first; c < p.first_flag_chunk; c += c_stride) update_chunk(c, false, none, none, none);
+                uint32_t trip = 0;
+                for (uint32_t w0 = wf0; w0 < w_end; w0 += c_stride, ++trip) {     // wave-uniform trip count
                     const uint32_t w = w0 + lane; uint32_t f = 0u;
-                    if (w < w_end) { f = flags[w]; if (f) flags[w] = 0u; }
+                    if (trip < kFlagPre) {
+                        // (static register indices: a select chain over the preloaded words)
+#pragma unroll
+                        for (uint32_t k = 0; k < kFlagPre; ++k) f = (trip == k) ? fpre[k] : f;
+                    } else if (w < w_end) f = flags[w];
+                    if (f) flags[w] = 0u;
                     // queue in ascending chunk order (lane-major: a lane's four chunks are neighbours, the next lane's follow), so that the
                     // lanes working the queue touch adjacent 32-byte pieces of the state arrays where adjacent chunks are both touched
                     uint32_t before = 0u, total = 0u;
@@ -376,7 +388,59 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
             }
             }
             if (qn > kQueueCap) qn = kQueueCap;
-            for (uint32_t q0 = 0; q0 < qn; q0 += 64u) if (q0 + lane < qn) update_chunk(queue[wave][q0 + lane], false, none, none, none);
+            // A QUEUED chunk is a grid chunk outside the LDS-scattered levels whose flag (or gradient) says it was touched: its gradient, fp16 weights, EMA,
+            // EMA step and optimizer state are requested in ONE go -- update_chunk asks for them in three dependent rounds (gradient -> weights + EMA -> state),
+            // right for the in-place walk where most chunks stop after the first -- and the arithmetic below is update_chunk's lazy-chunk path, operation by
+            // operation (the record / array CRC tests and the lazy-EMA test run through both).
+            const auto update_queued = [&](uint32_t c) __attribute__((always_inline)) {
+                const uint32_t i0 = c << 3;
+                half8_t* gp = reinterpret_cast<half8_t*>(p.ggrid + (i0 - oc.n_mlp));
+                const half8_t gh = *gp; half8_t wh = *reinterpret_cast<const half8_t*>(p.half + i0); half8_t e = *reinterpret_cast<const half8_t*>(p.ema + i0);
+                const uint32_t last = p.ema_step[c];
+                const float4_t w0 = *reinterpret_cast<const float4_t*>(st_master(c)), w1 = *reinterpret_cast<const float4_t*>(st_master(c) + 4);
+                const float4_t a0 = *reinterpret_cast<const float4_t*>(st_m1(c)), a1 = *reinterpret_cast<const float4_t*>(st_m1(c) + 4);
+                const float4_t b0 = *reinterpret_cast<const float4_t*>(st_m2(c)), b1 = *reinterpret_cast<const float4_t*>(st_m2(c) + 4);
+                u32x4 t0, t1; load_steps(i0, t0, t1);
+                float g[8]; bool any = false;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { g[j] = (float)gh[j]; any |= g[j] != 0.f; }
+                if (!any) return;                                                     // (flagged, but every contribution cancelled: untouched after all)
+                { half8_t z;
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) z[j] = (half_t)0.f;
+                  *gp = z; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = unscale(g[j]);
+                const uint32_t k = (cur - 1u) - last;
+                if (k) ema_catch_up(e, wh, last, k, oc.log2_decay);
+                p.ema_step[c] = cur;
+                float w[8] = { w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3] };
+                float m1[8] = { a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3] };
+                float m2[8] = { b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3] };
+                uint32_t sc[8] = { t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3] };
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (g[j] == 0.f) continue;                                        // untouched grid entry: skipped entirely
+                    w[j] = adam_update(g[j], w[j], m1[j], m2[j], sc[j], lr0, oc, step_cap);
+                    wh[j] = (half_t)w[j];
+                }
+                state_store<false>(float4_t{ w[0], w[1], w[2], w[3] }, reinterpret_cast<float4_t*>(st_master(c)));
+                state_store<false>(float4_t{ w[4], w[5], w[6], w[7] }, reinterpret_cast<float4_t*>(st_master(c) + 4));
+                state_store<false>(float4_t{ m1[0], m1[1], m1[2], m1[3] }, reinterpret_cast<float4_t*>(st_m1(c)));
+                state_store<false>(float4_t{ m1[4], m1[5], m1[6], m1[7] }, reinterpret_cast<float4_t*>(st_m1(c) + 4));
+                state_store<false>(float4_t{ m2[0], m2[1], m2[2], m2[3] }, reinterpret_cast<float4_t*>(st_m2(c)));
+                state_store<false>(float4_t{ m2[4], m2[5], m2[6], m2[7] }, reinterpret_cast<float4_t*>(st_m2(c) + 4));
+                typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+                if (p.steps16 || p.rec) state_store<false>(u4v{ sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16), sc[4] | (sc[5] << 16), sc[6] | (sc[7] << 16) },
+                        reinterpret_cast<u4v*>(st_steps16(c)));
+                else { state_store<false>(u4v{ sc[0], sc[1], sc[2], sc[3] }, reinterpret_cast<u4v*>(p.steps + i0));
+                    state_store<false>(u4v{ sc[4], sc[5], sc[6], sc[7] }, reinterpret_cast<u4v*>(p.steps + i0 + 4)); }
+                *reinterpret_cast<half8_t*>(p.half + i0) = wh;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = (half_t)((((float)e[j] * d) * deb_old + (float)wh[j] * (1.f - d)) * deb_new);
+                *reinterpret_cast<half8_t*>(p.ema + i0) = e;
+            };
+            for (uint32_t q0 = 0; q0 < qn; q0 += 64u) if (q0 + lane < qn) update_queued(queue[wave][q0 + lane]);
         } else if (eager) {
             // a thread has two chunks at these table sizes (the launch gives ~2 chunks per thread): the state of both is requested before the first is worked
             // on; straight-line code, no loop-carried buffers (those ended up in scratch memory)
