@@ -68,6 +68,9 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
     auto st_m1 = [&](uint32_t c) -> float* { return p.rec ? p.rec + 32u * (size_t)c + 8u : p.m1 + 8u * (size_t)c; };
     auto st_m2 = [&](uint32_t c) -> float* { return p.rec ? p.rec + 32u * (size_t)c + 16u : p.m2 + 8u * (size_t)c; };
     auto st_steps16 = [&](uint32_t c) -> uint16_t* { return p.rec ? reinterpret_cast<uint16_t*>(p.rec + 32u * (size_t)c + 24u) : p.steps16 + 8u * (size_t)c; };
+    // lazy EMA: the optimizer step a chunk's EMA is current for -- in the chunk record's pad word (the same 128-byte line as the state: late in training a touched
+    // chunk's own 64-byte line of a separate array was a seventh of what the kernel moved), or in the array
+    auto ema_step_of = [&](uint32_t c) -> uint32_t* { return p.rec ? reinterpret_cast<uint32_t*>(p.rec + 32u * (size_t)c + 28u) : p.ema_step + c; };
     // a chunk's eight step counters: two 16-byte loads of uint32, or ONE of eight uint16 (4 B per parameter less to read and to write back)
     auto load_steps = [&](uint32_t i0, u32x4& s0, u32x4& s1) __attribute__((always_inline)) {
         if (p.steps16 || p.rec) { const u32x4 v = *reinterpret_cast<const u32x4*>(st_steps16(i0 >> 3));
@@ -252,9 +255,9 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
             } else wh = (pre && !LAZY) ? cur_w : *reinterpret_cast<const half8_t*>(p.half + i0);
             if (lazy_chunk) {                                                        // touched again: first the steps it sat out, with the weight it had
                 ema_in = *reinterpret_cast<const half8_t*>(p.ema + i0);
-                const uint32_t last = p.ema_step[c], k = (cur - 1u) - last;
+                const uint32_t last = *ema_step_of(c), k = (cur - 1u) - last;
                 if (k) ema_catch_up(ema_in, wh, last, k, oc.log2_decay);
-                p.ema_step[c] = cur;
+                *ema_step_of(c) = cur;
             }
             if (any) {
                 if (!eager) {
@@ -395,8 +398,10 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
             const auto update_queued = [&](uint32_t c) __attribute__((always_inline)) {
                 const uint32_t i0 = c << 3;
                 half8_t* gp = reinterpret_cast<half8_t*>(p.ggrid + (i0 - oc.n_mlp));
-                const half8_t gh = *gp; half8_t wh = *reinterpret_cast<const half8_t*>(p.half + i0); half8_t e = *reinterpret_cast<const half8_t*>(p.ema + i0);
-                const uint32_t last = p.ema_step[c];
+                // (the fp16 working copy is h(master) by construction -- creation, set_params, every update --: with the master weights on their way it is not
+                // read back, one 64-byte line less per touched chunk)
+                const half8_t gh = *gp; half8_t e = *reinterpret_cast<const half8_t*>(p.ema + i0);
+                const uint32_t last = *ema_step_of(c);
                 const float4_t w0 = *reinterpret_cast<const float4_t*>(st_master(c)), w1 = *reinterpret_cast<const float4_t*>(st_master(c) + 4);
                 const float4_t a0 = *reinterpret_cast<const float4_t*>(st_m1(c)), a1 = *reinterpret_cast<const float4_t*>(st_m1(c) + 4);
                 const float4_t b0 = *reinterpret_cast<const float4_t*>(st_m2(c)), b1 = *reinterpret_cast<const float4_t*>(st_m2(c) + 4);
@@ -411,10 +416,13 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                   *gp = z; }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) g[j] = unscale(g[j]);
+                float w[8] = { w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3] };
+                half8_t wh;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wh[j] = (half_t)w[j];
                 const uint32_t k = (cur - 1u) - last;
                 if (k) ema_catch_up(e, wh, last, k, oc.log2_decay);
-                p.ema_step[c] = cur;
-                float w[8] = { w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3] };
+                *ema_step_of(c) = cur;
                 float m1[8] = { a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3] };
                 float m2[8] = { b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3] };
                 uint32_t sc[8] = { t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3] };
@@ -502,11 +510,12 @@ void launch_reduce_partials(hipStream_t s, const float* partials, uint32_t n_par
 __global__ void __launch_bounds__(256) k_ema_finalize(ParamPtrs p, OptimConst oc, const DevState* __restrict__ st) {
     const uint32_t done = st->step, n_chunks = oc.n_params >> 3;
     for (uint32_t c = (oc.n_mlp >> 3) + blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += gridDim.x * blockDim.x) {
-        const uint32_t last = p.ema_step[c];
+        uint32_t* lp = p.rec ? reinterpret_cast<uint32_t*>(p.rec + 32u * (size_t)c + 28u) : p.ema_step + c;      // (records: in the pad word, k_optimizer)
+        const uint32_t last = *lp;
         if (last >= done) continue;
         half8_t e = *reinterpret_cast<const half8_t*>(p.ema + (c << 3)); const half8_t w = *reinterpret_cast<const half8_t*>(p.half + (c << 3));
         ema_catch_up(e, w, last, done - last, oc.log2_decay);
-        *reinterpret_cast<half8_t*>(p.ema + (c << 3)) = e; p.ema_step[c] = done;
+        *reinterpret_cast<half8_t*>(p.ema + (c << 3)) = e; *lp = done;
     }
 }
 void launch_ema_finalize(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, const DevState* st) {

@@ -493,7 +493,8 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     if (records) { if ((rc = dev_alloc(m, m.P.rec, 4 * n))) return rc; }
     else if ((rc = dev_alloc(m, m.P.master, n, false)) || (rc = dev_alloc(m, m.P.m1, n)) || (rc = dev_alloc(m, m.P.m2, n)) ||
              (rc = steps16 ? dev_alloc(m, m.P.steps16, n + 8) : dev_alloc(m, m.P.steps, n))) return rc;
-    if ((rc = dev_alloc(m, m.P.half, n, false)) || (rc = dev_alloc(m, m.P.ema, n)) || (rc = dev_alloc(m, m.d_ema_step, n / 8 + 1)) ||
+    if ((rc = dev_alloc(m, m.P.half, n, false)) || (rc = dev_alloc(m, m.P.ema, n)) || (rc = dev_alloc(m, m.d_ema_step, records ? 16 : n / 8 + 1)) ||      // (chunk records keep the EMA step in their pad word; the pointer still says "lazy")
+        
         (rc = dev_alloc(m, m.P.gmlp, m.nd.n_mlp)) || (rc = dev_alloc(m, m.P.ggrid, m.n_grid))) return rc;
     {
         std::vector<float> master; init_params_host(cfg, m.nd, m.n_params, master);

@@ -94,7 +94,7 @@ struct ParamPtrs {
     // the per-parameter step counters as SATURATING 16-bit values (steps == nullptr then): exact whenever beta^65535 < 2^-25 for both betas -- the bias
     // correction 1 - beta^t is then exactly 1.0f for every t the counter can no longer tell apart (beta <= 0.99973; base.json: 0.9 / 0.99)
     uint16_t* steps16;
-    // large tables (lazy EMA): the optimizer state as ONE 128-byte record per 8-parameter chunk -- master[8] | m1[8] | m2[8] | 8 x uint16 step counters | pad --
+    // large tables (lazy EMA): the optimizer state as ONE 128-byte record per 8-parameter chunk -- master[8] | m1[8] | m2[8] | 8 x uint16 step counters | pad (word 28: the lazy EMA's step, round 5) --
     // instead of the four arrays above (which are null then): late in training a few per cent of the chunks are touched, and a touched chunk among untouched
     // ones is then one full line, not four half-used 64-byte sectors.  nullptr = the arrays (small tables: every chunk is streamed anyway)
     float* rec;
