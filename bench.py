@@ -478,7 +478,7 @@ def main():
             multi = {"objects": args.objects_per_gpu, "value": None, "note": "failed: %s" % e}
 
     # ---- extra, not the headline: the stress configuration's table (BASELINE configs[4]: hash T = 2^22, 105 M parameters per object) on this GPU: the one
-    #      case whose kernels are HBM-bound (profiles/r04_window_T22.md).  One object, steps 20..60 from init and 800..840.
+    #      case whose kernels are HBM-bound (profiles/r05_window_T22.md).  One object, steps 20..60 from init and 800..840.
     stress = None
     if rank == 0 and world == 1 and not args.log2_hashmap_size and not args.no_stress:
         try:
@@ -500,7 +500,7 @@ def main():
                                "frac_of_hbm_from_counters": hbm_frac("step_bytes_beyond_l2_steps_800_820", 1e3 * ts_late)},
                       "unit": "ray-samples/s", "traffic_source": sp.get("source"),
                       "note": "frac_of_hbm = committed counter traffic of the step's kernels ((2 FETCH_SIZE + WRITE_SIZE) KB summed over the kernels of a "
-                              "step, profiles/r04_window_T22.md) / measured step time / 8 TB/s"}
+                              "step, profiles/r05_window_T22.md) / measured step time / 8 TB/s"}
             so.close()
         except Exception as e:
             stress = {"value": None, "note": "failed: %s" % e}
