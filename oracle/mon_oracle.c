@@ -838,12 +838,13 @@ static void adam_one(orc_model* m, uint32_t i, float gradient, int is_matrix) {
     float nw = w - eff * fm;
     m->master[i] = nw; m->half[i] = f2h(nw);
 }
-static void optimizer_step(orc_model* m) {
+/* grid_f32: the grid gradient as fp32 values (a hook for gradients that are fp32 sums of several fp16 tables); NULL = the fp16 table, as tcnn */
+static void optimizer_step_from(orc_model* m, const float* grid_f32) {
     const orc_config* c = &m->cfg; const float inv_ls = c->loss_scale;
     #pragma omp parallel for schedule(static)
     for (long i = 0; i < (long)m->n_mlp; ++i) adam_one(m, (uint32_t)i, m->gmlp[i] / inv_ls, 1);
     #pragma omp parallel for schedule(static)
-    for (long i = 0; i < (long)m->n_grid; ++i) adam_one(m, m->n_mlp + (uint32_t)i, h2f(m->ggrid_h[i]) / inv_ls, 0);
+    for (long i = 0; i < (long)m->n_grid; ++i) adam_one(m, m->n_mlp + (uint32_t)i, (grid_f32 ? grid_f32[i] : h2f(m->ggrid_h[i])) / inv_ls, 0);
     uint32_t cur = m->step + 1;                                          /* nested optimizer's step() after increment */
     if ((int32_t)cur >= c->decay_start && c->decay_interval > 0 && ((int32_t)cur - c->decay_start) % c->decay_interval == 0) m->lr *= c->decay_base;
     float d = c->ema_decay;
@@ -853,10 +854,17 @@ static void optimizer_step(orc_model* m) {
         m->ema[i] = f2h(((h2f(m->ema[i]) * d) * deb_old + h2f(m->half[i]) * (1.0f - d)) * deb_new);
     m->has_ema = 1;
 }
+static void optimizer_step(orc_model* m) { optimizer_step_from(m, NULL); }
 /* closed-form KAT hooks: run the optimizer on externally supplied gradients */
 void orc_optimizer_step_with(orc_model* m, const float* gmlp, const uint16_t* ggrid_h) {
     memcpy(m->gmlp, gmlp, (size_t)m->n_mlp * 4); memcpy(m->ggrid_h, ggrid_h, (size_t)m->n_grid * 2);
     optimizer_step(m); m->step++;
+}
+/* the same with the grid gradient in fp32 (tests/test_gpu_parity.py: the optimizer of the product driven step by step with the product's own gradients,
+ * which on the LDS-scattered levels are fp32 sums of fp16 partial tables) */
+void orc_optimizer_step_with_f32(orc_model* m, const float* gmlp, const float* ggrid_f32) {
+    memcpy(m->gmlp, gmlp, (size_t)m->n_mlp * 4);
+    optimizer_step_from(m, ggrid_f32); m->step++;
 }
 
 /* NeRF_Model::Train_Step body, nerf_model.cu:1635-1648 (one iteration). Returns n_valid. */

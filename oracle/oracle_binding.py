@@ -78,6 +78,7 @@ def lib():
         L.orc_train.restype = C.c_float; L.orc_train.argtypes = [C.c_void_p, C.c_int]
         L.orc_generate_batch.argtypes = [C.c_void_p]; L.orc_forward_backward.argtypes = [C.c_void_p]
         L.orc_optimizer_step_with.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_optimizer_step_with_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_render.argtypes = [C.c_void_p, OrcBBox, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_density_grid.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -152,6 +153,12 @@ class OracleModel:
 
     def train(self, iters):
         return self.L.orc_train(self.h, iters)
+
+    def optimizer_step_with(self, gmlp, ggrid_f32):
+        """Trainer::optimizer_step on externally supplied gradients (fp32 MLP gradient, fp32 grid gradient), still loss-scaled."""
+        a = np.ascontiguousarray(gmlp, np.float32); b = np.ascontiguousarray(ggrid_f32, np.float32)
+        assert a.size == self.n_mlp and b.size == self.n_params - self.n_mlp
+        self.L.orc_optimizer_step_with_f32(self.h, _p(a), _p(b))
 
     def set_step_variant(self, on):
         self.L.orc_set_step_variant(self.h, int(on))

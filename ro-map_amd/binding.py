@@ -386,7 +386,7 @@ class Dataset:
 # debug buffer ids (ro-map_amd/csrc/model.h MON_BUF_*): name -> (id, dtype, elements as f(R, B, info))
 BUF = dict(master=0, half=1, ema=2, m1=3, m2=4, steps=5, gmlp=6, ggrid_h=9, pts=10, tdist=11, E=12, Hid=13, O=14, dO=15, dHid=16, dE=17,
            rgb_ray=18, depth_ray=19, mask_ray=20, loss_ray=21, ray_o=22, ray_d=23, ray_t0=24, ray_t1=25, target=26, target_depth=27, bgcol=28,
-           ray_flag=29, ray_dn=31, mask=32, state=33, frag_train=34, frag_ref=35, x_all=36, e_soa=37, half_tiles=38)
+           ray_flag=29, ray_dn=31, mask=32, state=33, frag_train=34, frag_ref=35, x_all=36, e_soa=37, half_tiles=38, ggrid_f32=39)
 
 
 class ObjectNeRF:
@@ -490,7 +490,7 @@ class ObjectNeRF:
         i = self.info(); R, B, n = self.R, self.R * self.S, i.n_params
         W, NH, Ep = self.cfg.n_neurons, self.cfg.n_hidden_layers, i.encoded_width
         shapes = dict(master=(np.float32, n), half=(np.uint16, n), ema=(np.uint16, n), m1=(np.float32, n), m2=(np.float32, n), steps=(np.uint32, n),
-                      gmlp=(np.float32, i.n_mlp_params), ggrid_h=(np.uint16, i.n_grid_params), pts=(np.float32, B * 3), tdist=(np.float32, B),
+                      gmlp=(np.float32, i.n_mlp_params), ggrid_h=(np.uint16, i.n_grid_params), ggrid_f32=(np.float32, i.n_grid_params), pts=(np.float32, B * 3), tdist=(np.float32, B),
                       E=(np.uint16, B * Ep), Hid=(np.uint16, B * W * NH), O=(np.uint16, B * 4), dO=(np.uint16, B * 4), dHid=(np.uint16, B * W * NH),
                       dE=(np.uint16, B * Ep), rgb_ray=(np.float32, R * 3), depth_ray=(np.float32, R), mask_ray=(np.float32, R), loss_ray=(np.float32, R),
                       ray_o=(np.float32, R * 3), ray_d=(np.float32, R * 3), ray_t0=(np.float32, R), ray_t1=(np.float32, R), target=(np.float32, R * 3),

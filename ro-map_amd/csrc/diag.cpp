@@ -38,6 +38,7 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
         case MON_BUF_STEPS: src = m.P.steps ? (const void*)m.P.steps : (const void*)m.P.steps16; sz = n * 4; break;
         case MON_BUF_GMLP: src = m.P.gmlp; sz = (size_t)m.nd.n_mlp * 4; break;
         case MON_BUF_GGRID_H: src = m.P.ggrid; sz = (size_t)m.n_grid * 2; break;
+        case MON_BUF_GGRID_F32: src = m.P.ggrid; sz = (size_t)m.n_grid * 4; break;
         case MON_BUF_PTS: src = m.B.pts; sz = B * 12; break;            case MON_BUF_TDIST: src = m.B.tdist; sz = B * 4; break;
         case MON_BUF_E: src = m.B.E; sz = B * m.nd.Epad * 2; break;     case MON_BUF_HID: src = m.B.Hid; sz = B * m.nd.W * m.nd.NH * 2; break;
         case MON_BUF_O: src = m.B.O; sz = B * 8; break;                 case MON_BUF_DO: src = m.B.dO; sz = B * 8; break;
@@ -72,24 +73,43 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
         uint32_t* out = reinterpret_cast<uint32_t*>(dst); for (size_t i = 0; i < n; ++i) out[i] = h16[i];
         return MON_OK;
     }
-    HIPCHECK(hipMemcpy(dst, src, sz, hipMemcpyDeviceToHost));
-    if (which == MON_BUF_GGRID_H && m.backend == 1 && m.lds_mask) {        // total gradient = atomic table + sum of the scatter partials
-        std::vector<uint16_t> part(m.part_halves); std::vector<float> acc(m.n_grid);
-        uint16_t* out = reinterpret_cast<uint16_t*>(dst);
-        for (uint32_t i = 0; i < m.n_grid; ++i) { _Float16 h; std::memcpy(&h, &out[i], 2); acc[i] = (float)h; }
-        // partial tables are planar: [partition][feature][parity][entry / 2], over the LDS-scattered levels' entries
-        const uint32_t n_ent = m.part_halves / 2, n_half = n_ent / 2;
-        for (uint32_t q = 0; q < m.scatter.max_P; ++q) {
-            HIPCHECK(hipMemcpy(part.data(), m.d_gpart + (size_t)q * m.part_halves, (size_t)m.part_halves * 2, hipMemcpyDeviceToHost));
-            for (int l = 0; l < m.nd.L; ++l) {
-                // this level has fewer partial tables: the rest of the buffer is not its data
-                if (q >= m.scatter.P[l] || !((m.lds_mask >> l) & 1u)) continue;
-                for (uint32_t e = m.lt.offset[l]; e < m.lt.offset[l + 1]; ++e) for (uint32_t f = 0; f < 2; ++f) { _Float16 h;
-                    std::memcpy(&h, &part[((size_t)f * 2 + (e & 1u)) * n_half + (e >> 1)], 2); acc[2 * e + f] += (float)h; }
+    // the grid gradient as k_optimizer forms it: the fp16 gradient table (large levels: binned sums or tcnn's atomics) plus the fp16 partial tables of the
+    // LDS-scattered levels, summed in fp32 in the kernel's order -- pairs of partitions, (a + b) added to the running sum (update_chunk, kernels_optim.hip)
+    if (which == MON_BUF_GGRID_H || which == MON_BUF_GGRID_F32) {
+        std::vector<uint16_t> tab(m.n_grid); HIPCHECK(hipMemcpy(tab.data(), m.P.ggrid, (size_t)m.n_grid * 2, hipMemcpyDeviceToHost));
+        std::vector<float> acc(m.n_grid);
+        for (uint32_t i = 0; i < m.n_grid; ++i) { _Float16 h; std::memcpy(&h, &tab[i], 2); acc[i] = (float)h; }
+        // whole steps of the shapes outside the fused kernels keep their partial tables too (hybrid_scatter); the dense optimizer then never reads the table
+        const bool parts = (m.backend == 1 && m.lds_mask) || (m.backend == 0 && m.hybrid_scatter && which == MON_BUF_GGRID_F32);
+        if (parts) {
+            // partial tables are planar: [partition][feature][parity][entry / 2], over the LDS-scattered levels' entries
+            const uint32_t n_ent = m.part_halves / 2, n_half = n_ent / 2;
+            std::vector<uint16_t> pa(m.part_halves), pb(m.part_halves);
+            auto val = [&](const std::vector<uint16_t>& part, uint32_t e, uint32_t f) { _Float16 h;
+                std::memcpy(&h, &part[((size_t)f * 2 + (e & 1u)) * n_half + (e >> 1)], 2); return (float)h; };
+            for (uint32_t q = 0; q < m.scatter.max_P; q += 2) {
+                HIPCHECK(hipMemcpy(pa.data(), m.d_gpart + (size_t)q * m.part_halves, (size_t)m.part_halves * 2, hipMemcpyDeviceToHost));
+                if (q + 1 < m.scatter.max_P) HIPCHECK(hipMemcpy(pb.data(), m.d_gpart + (size_t)(q + 1) * m.part_halves, (size_t)m.part_halves * 2,
+                        hipMemcpyDeviceToHost));
+                for (int l = 0; l < m.nd.L; ++l) {
+                    // (a level with fewer partial tables: the rest of the buffer is not its data)
+                    const bool lds_level = m.backend == 1 ? ((m.lds_mask >> l) & 1u) != 0u : true;
+                    if (q >= m.scatter.P[l] || !lds_level) continue;
+                    const bool two = q + 1 < m.scatter.P[l];
+                    for (uint32_t e = m.lt.offset[l]; e < m.lt.offset[l + 1]; ++e) for (uint32_t f = 0; f < 2; ++f)
+                        acc[2 * e + f] += two ? val(pa, e, f) + val(pb, e, f) : val(pa, e, f);
+                }
             }
         }
+        if (which == MON_BUF_GGRID_F32) {
+            if (!dst || bytes < (size_t)m.n_grid * 4) { set_error("debug_read: buffer too small"); return MON_ERR_ARG; }
+            std::memcpy(dst, acc.data(), (size_t)m.n_grid * 4); return MON_OK;
+        }
+        uint16_t* out = reinterpret_cast<uint16_t*>(dst);
         for (uint32_t i = 0; i < m.n_grid; ++i) { const _Float16 h = (_Float16)acc[i]; std::memcpy(&out[i], &h, 2); }
+        return MON_OK;
     }
+    HIPCHECK(hipMemcpy(dst, src, sz, hipMemcpyDeviceToHost));
     return MON_OK;
 }
 

@@ -802,6 +802,10 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_gen_samples(s, m.B, m.oc, m.d_state, m.oc.S, B, kStreamDt, 0u, 0);
         }
     }
+    // whole steps of a shape outside the fused kernels scatter through k_rows_to_bins -> k_grid_scatter into partial tables that the DENSE optimizer sums; the
+    // Step() schedule and the stage-wise debugging entry keep tcnn's global atomics into ggrid, which only the non-dense optimizer reads and clears.  ONE flag for
+    // both sites (the scatter site and the optimizer site disagreed under step_variant, and the grid stopped training)
+    const bool hybrid = m.backend == 0 && m.hybrid_scatter && stages == 7 && !options().step_variant;
     if (stages & 2) {      // Step_No_Compacted :1552-1607
         if (m.backend == 0 && options().step_variant) {
             // NeRF_Model::Step (nerf_model.cu:1504-1550): inference of every sample, per-ray sample compaction + rollover (kernels_step.hip), then
@@ -816,6 +820,7 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);
             launch_mlp_backward(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state);          // :1547
             launch_weight_grads(s, m.nd, m.B.E, m.B.Hid, m.B.dHid, m.B.dO, m.P.gmlp, B, m.d_state);
+            if (m.hybrid_scatter) hipMemsetAsync(m.P.ggrid, 0, (size_t)m.n_grid * 2, s);           // (a whole step of the other schedule may have left partial sums)
             launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
         } else if (m.backend == 0) {
             ProfScope ps(m, MON_K_FWDBWD);
@@ -826,7 +831,7 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_weight_grads(s, m.nd, m.B.E, m.B.Hid, m.B.dHid, m.B.dO, m.P.gmlp, B, m.d_state);
             // whole steps of a shape outside the fused kernels: the exact LDS scatter (partial tables, summed by the optimizer).  Stage-wise calls (the debugging
             // entry that stops before the optimizer) keep tcnn's global atomics into ggrid, which only the non-dense optimizer clears: start from zeros there
-            if (m.hybrid_scatter && stages == 7) {
+            if (hybrid) {
                 launch_rows_to_bins(s, m.lf, m.nd, m.B.dE, m.B.pts, m.oc.R, m.oc.S, m.n_bins, m.d_de_soa, m.d_x_soa, m.d_state);
                 launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_gpart, m.part_halves / 2, m.d_state, nullptr, 0u, m.P.gmlp,
                         m.d_state_next);
@@ -876,7 +881,7 @@ static void enqueue_iteration(Model& m, int stages) {
         ParamPtrs P = m.P;
         if (m.backend == 1 && m.lds_mask) { P.gpart = m.d_gpart; P.part_stride = m.part_halves; P.sl = m.scatter;
             P.all_levels_dense = (m.lds_mask == ((1u << m.nd.L) - 1u)) ? 1 : 0; }
-        if (m.backend == 0 && m.hybrid_scatter && stages == 7) { P.gpart = m.d_gpart; P.part_stride = m.part_halves; P.sl = m.scatter; P.all_levels_dense = 1; }
+        if (hybrid) { P.gpart = m.d_gpart; P.part_stride = m.part_halves; P.sl = m.scatter; P.all_levels_dense = 1; }
         P.half_tiles = (m.backend == 1 && P.gpart && P.all_levels_dense) ? m.d_half_tiles : nullptr;
         const bool lazy = m.lazy_ema && !(P.gpart && P.all_levels_dense);
         P.ema_step = lazy ? m.d_ema_step : nullptr; if (lazy) m.ema_pending = true;

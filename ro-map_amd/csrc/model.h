@@ -144,7 +144,8 @@ enum {
     MON_BUF_FRAG_REF = 35,      // the same image rebuilt from the current fp16 weights by k_build_frag_image (layout test)
     MON_BUF_X_ALL = 36,         // level-tile encode: positions float4 [B] of the batch the next / last iteration uses
     MON_BUF_E_SOA = 37,         // level-tile encode: encoded features half2 [L][B] of the last iteration
-    MON_BUF_HALF_TILES = 38     // level-tile encode: the fp16 grid in tile order (ParamPtrs::half_tiles)
+    MON_BUF_HALF_TILES = 38,    // level-tile encode: the fp16 grid in tile order (ParamPtrs::half_tiles)
+    MON_BUF_GGRID_F32 = 39      // the grid gradient the next k_optimizer will form, fp32: gradient table + the partial tables summed in the kernel's order
 };
 
 // Process-wide test and tuning switches (mon_set_option, include/mon_core.h); defaults are the product behaviour.

@@ -801,6 +801,161 @@ def test_optimizer_state_records_train_exactly_like_the_arrays(pkg, small_scene)
     assert res[0] == res[1], res
 
 
+LARGE = {"T19": dict(rays_per_batch=256, log2_hashmap_size=19, n_neurons=64, n_hidden_layers=1),
+         "T20L8": dict(rays_per_batch=256, log2_hashmap_size=20, n_levels=8, per_level_scale=2.0, n_neurons=32, n_hidden_layers=2)}
+
+
+def _ulp16(x):
+    """fp16 ulp at |x| (normal range; the subnormal ulp 2^-24 below 2^-14)."""
+    return np.maximum(2.0 ** (np.floor(np.log2(np.maximum(np.abs(x), 2.0 ** -14))) - 10), 2.0 ** -24)
+
+
+@pytest.mark.parametrize("name", sorted(LARGE))
+def test_large_table_optimizer_matches_oracle(pkg, orc, small_scene, name):
+    """Tables above 8 M parameters (BASELINE configs[4]'s regime) run k_optimizer<false, true>: untouched chunks are skipped altogether (lazy EMA, closed-form
+    catch-up), the state sits in 128-byte chunk records, touched chunks are found through byte flags, step counters are 16-bit.  Three WHOLE steps on both
+    sides from the pattern parameters, binned scatter (deterministic), in every records / flags / 16-bit-counter combination -- against the ORACLE's
+    Trainer::optimizer_step (tcnn's rule, nerf_model.cu:1644: zero-gradient grid entries untouched, per-parameter bias correction, debiased EMA of every
+    parameter every step), with the bars of the base-size step tests.  Entries that never saw a gradient must still hold the pattern bit for bit, with empty
+    Adam state, and their lazily caught-up EMA must equal the oracle's eager step-by-step one."""
+    import itertools
+    _need_gpu(pkg)
+    kw = LARGE[name]
+    ref = ge.make_oracle(orc, small_scene, kw); p = pattern_params(ref); ref.set_params(p)
+    for _ in range(3):
+        ref.train(1)
+    nm = ref.n_mlp; want = {b: ref.buffer(b) for b in ("master", "half", "ema", "m1", "m2", "steps")}; loss_ref = ref.loss; ref.close()
+    names = ("state_records", "touched_flags", "steps16", "big_switch"); old = {n: pkg.get_option(n) for n in names}
+    try:
+        pkg.set_option("big_switch", 1)
+        for combo in itertools.product((1, 0), (1, 0), (1, 0)):
+            for n, v in zip(names, combo):
+                pkg.set_option(n, v)
+            ds, obj = ge.make_problem(pkg, small_scene, kw); obj.set_backend(1)
+            assert obj.info().n_grid_params > (8 << 20)
+            obj.set_params(p)
+            for _ in range(3):
+                la = obj.train(1)
+            assert abs(la - loss_ref) < 5e-3 * max(1.0, abs(loss_ref)), combo
+            a = obj.buffer("master"); st = obj.buffer("steps"); m1 = obj.buffer("m1"); m2 = obj.buffer("m2")
+            assert np.array_equal(a, obj.get_params(0))
+            close_f32(a[:nm], want["master"][:nm], "MLP master weights after three steps %s" % (combo,), 1e-3)
+            assert (st[:nm] == 3).all()
+            touched = (st > 0) | (want["steps"] > 0); touched[:nm] = False
+            assert 1000 < touched.sum() < 0.5 * touched.size, combo                  # most of such a table never sees a gradient in three small batches
+            d = np.abs(a[touched] - want["master"][touched])
+            assert float((d > 3e-4).mean()) < 1e-2, (combo, float((d > 3e-4).mean()))
+            assert float((st[touched] != want["steps"][touched]).mean()) < 2e-2, (combo, float((st[touched] != want["steps"][touched]).mean()))
+            same = touched & (st == want["steps"])
+            for got, w, what, rel in ((m1, want["m1"], "m1", 2.0 ** -6), (m2, want["m2"], "m2", 2.0 ** -5)):
+                bad = np.abs(got[same] - w[same]) > rel * np.abs(w[same]) + 1e-12
+                assert float(bad.mean()) < 2e-2, (combo, what, float(bad.mean()))
+            # never touched: the pattern itself, no Adam state (tcnn skips zero-gradient grid entries entirely)
+            un = ~touched; un[:nm] = False
+            assert np.array_equal(a[un], p[un]) and not m1[un].any() and not m2[un].any()
+            hw = obj.get_params(1); assert np.array_equal(h2f(hw), a.astype(np.float16).astype(np.float32))          # fp16 copy == h(master) everywhere
+            # EMA (inference weights, k_ema_finalize first): touched entries with the step bars, untouched ones -- closed-form catch-up over all three
+            # steps against the eager recurrence -- within an fp16 ulp
+            ea, eb = h2f(obj.get_params(2)), h2f(want["ema"])
+            assert (np.abs(ea - eb)[touched] > 4e-3 * np.maximum(np.abs(eb[touched]), 1e-2)).mean() < 1e-2, combo
+            err = np.abs(ea[un] - eb[un]); assert float((err > _ulp16(eb[un])).mean()) < 1e-4 and err.max() <= 2 * _ulp16(eb[un]).max(), (combo, err.max())
+            assert (np.abs(ea[:nm] - eb[:nm]) > 4e-3 * np.maximum(np.abs(eb[:nm]), 1e-2)).mean() < 1e-2
+            obj.close(); ds.close()
+    finally:
+        for n, v in old.items():
+            pkg.set_option(n, v)
+
+
+@pytest.mark.parametrize("variant", ["default", "binned-arrays"])
+def test_large_table_optimizer_follows_the_oracle_over_30_steps_on_its_own_gradients(pkg, orc, small_scene, variant):
+    """The large-table optimizer over a 30-step run, judged by the ORACLE's optimizer instead of a NumPy recurrence: every step the device's own gradients
+    (fp32 MLP gradient; grid gradient = gradient table + partial tables as k_optimizer sums them) are handed to the oracle's Trainer::optimizer_step, so both
+    sides integrate the SAME gradient sequence and the comparison is free of the training trajectory's chaos and of the arrival order of the fine levels'
+    atomics: master weights, both Adam moments and the per-parameter step counters must agree to fp32 rounding after 1, 2, 5 and 30 steps, the fp16 copy up to
+    rounding-boundary flips, and the LAZILY maintained EMA (chunks catch up in closed form when they are touched again or the inference weights are read)
+    must equal the oracle's eager every-parameter-every-step EMA.  `default`: the shipping options (records, flags, 16-bit counters, binned -> atomic switch);
+    `binned-arrays`: every switch the other way, with the inference weights also read in the middle of the run (finalize, then train on)."""
+    _need_gpu(pkg)
+    kw = dict(rays_per_batch=512, log2_hashmap_size=19)
+    opts = {} if variant == "default" else dict(state_records=0, touched_flags=0, steps16=0, big_switch=1)
+    old = {n: pkg.get_option(n) for n in opts}
+    try:
+        for n, v in opts.items():
+            pkg.set_option(n, v)
+        ds, obj = ge.make_problem(pkg, small_scene, kw); obj.set_backend(1)
+    finally:
+        for n, v in old.items():
+            pkg.set_option(n, v)                                       # (read when the object is created)
+    assert obj.info().n_grid_params > (8 << 20)
+    ref = ge.make_oracle(orc, small_scene, kw); nm = ref.n_mlp
+    p = obj.get_params(0); ref.set_params(p)                         # the same initial weights (pcg32 init on both sides; taken from the device to be sure)
+    ever = np.zeros(p.size, bool)
+    for t in range(1, 31):
+        obj.train_stages(1 | 2)
+        gm = obj.buffer("gmlp"); gg = obj.buffer("ggrid_f32")
+        obj.train_stages(4); ref.optimizer_step_with(gm, gg)
+        ever[nm:] |= gg != 0
+        if variant != "default" and t == 12:
+            ea, eb = h2f(obj.get_params(2)), h2f(ref.buffer("ema"))
+            err = np.abs(ea - eb); tol = 2.0 ** -9 * (np.abs(eb) + np.abs(h2f(ref.buffer("half")))) + 3 * 2.0 ** -24
+            assert (err > tol).mean() < 1e-3 and err.max() < 1e-3, (t, float((err > tol).mean()), float(err.max()))
+        if t in (1, 2, 5, 30):
+            a, b = obj.buffer("master"), ref.buffer("master")
+            assert np.array_equal(obj.buffer("steps"), ref.buffer("steps")), "per-parameter step counters after %d steps" % t
+            d = np.abs(a - b); assert d.max() <= 5e-6 and float((d > 1e-6).mean()) < 1e-4, (t, float(d.max()))
+            for name, rel in (("m1", 1e-5), ("m2", 1e-5)):
+                x, y = obj.buffer(name), ref.buffer(name)
+                assert (np.abs(x - y) <= rel * np.abs(y) + 1e-30).all(), (t, name, float(np.abs(x - y).max()))
+            assert float((obj.get_params(1) != ref.buffer("half")).mean()) < 1e-4
+    st = ref.buffer("steps")
+    assert (st[:nm] == 30).all() and 0.001 < (st[nm:] > 0).mean() < 0.9 and (st[nm:].max() > 3)       # a sparse table, some entries stepped again and again
+    assert np.array_equal(st > 0, ever | (np.arange(st.size) < nm))                                     # exactly the entries that ever had a gradient
+    ea, eb = h2f(obj.get_params(2)), h2f(ref.buffer("ema")); w = h2f(ref.buffer("half"))
+    # a few fp16 ulps of the quantities being averaged: the closed form rounds once where the recurrence rounds every step
+    err = np.abs(ea - eb); tol = 2.0 ** -9 * (np.abs(eb) + np.abs(w)) + 3 * 2.0 ** -24
+    assert (err > tol).mean() < 1e-3 and err.max() < 1e-3, (float((err > tol).mean()), float(err.max()))
+    assert np.array_equal(h2f(obj.get_params(2)), ea)                 # reading the inference weights again changes nothing
+    obj.close(); ds.close(); ref.close()
+
+
+def test_stress_configuration_t22_matches_oracle(pkg, orc, small_scene):
+    """BASELINE configs[4]'s table itself -- T = 2^22: 105 M parameters, levels whose res^3 overflows 32 bits -- against the oracle at a batch the oracle
+    finishes in seconds (R = 256, base.json otherwise): encode bit-exact on every level, network output and dL/dO within the fp16 bars, the grid gradient
+    inside the fp16 accumulation bound, and one whole optimizer step (chunk records, touched flags, lazy EMA) with the one-step bars on the entries that
+    received a gradient; everything else untouched.  (~3.5 GB of host memory for the oracle's state.)"""
+    kw = dict(rays_per_batch=256, log2_hashmap_size=22)
+    ds, obj, ref = _pair(pkg, orc, small_scene, kw, 1)
+    assert obj.info().n_grid_params > (100 << 20)
+    p = pattern_params(ref); obj.set_params(p); ref.set_params(p)
+    obj.train_stages(1 | 2); ref.generate_batch(); ref.forward_backward()
+    assert int(obj.buffer("state")[2]) == ref.n_valid > 0
+    assert np.array_equal(obj.buffer("E"), ref.buffer("E")), "hash-grid encode must be bit-exact at T = 2^22"
+    close_half(obj.buffer("O"), ref.buffer("O"), "network output", frac_ok=0.999)
+    close_half(obj.buffer("dO"), ref.buffer("dO"), "dL/dO", ulps=4, frac_ok=0.999)
+    gm, rm = obj.buffer("gmlp").astype(np.float64), ref.buffer("gmlp").astype(np.float64)
+    assert np.abs(gm - rm).max() < 5e-3 * np.abs(rm).max()
+    gg = h2f(obj.buffer("ggrid_h")); rg = ref.buffer("ggrid"); ra = ref.buffer("ggrid_abs")
+    nz = (gg != 0) | (rg != 0)
+    assert 10000 < nz.sum() < 0.1 * nz.size
+    bound = 2.0 ** -8 * ra[nz].astype(np.float64) + 2.0 ** -10 * np.abs(rg[nz]).astype(np.float64) + 1e-7
+    assert float((np.abs(gg[nz].astype(np.float64) - rg[nz]) > bound).mean()) < 2e-3
+    del gg, rg, ra
+    obj.train_stages(4); ref.train_step()                                # the oracle redoes the same batch, then steps
+    nm = ref.n_mlp; a, b = obj.buffer("master"), ref.buffer("master")
+    close_f32(a[:nm], b[:nm], "MLP master weights after one step", 2e-4)
+    st_a, st_b = obj.buffer("steps"), ref.buffer("steps")
+    touched = (st_a > 0) | (st_b > 0); touched[:nm] = False
+    assert (st_a[:nm] == 1).all() and int(st_a.max()) == 1 and float((st_a[touched] != st_b[touched]).mean()) < 5e-3
+    assert float((np.abs(a[touched] - b[touched]) > 1e-4).mean()) < 5e-3
+    un = ~touched; un[:nm] = False
+    assert np.array_equal(a[un], p[un])
+    ea, eb = h2f(obj.get_params(2)), h2f(ref.buffer("ema"))
+    assert (np.abs(ea[touched] - eb[touched]) > 2e-3 * np.maximum(np.abs(eb[touched]), 1e-2)).mean() < 5e-3
+    assert float((np.abs(ea[un] - eb[un]) > _ulp16(eb[un])).mean()) < 1e-4
+    i = obj.info(); assert i.train_step == 1 and i.last_n_valid == ref.n_valid
+    obj.close(); ds.close(); ref.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("group", ["base", "large"])
 def test_every_combination_of_the_equivalence_switches_trains_the_same_parameters(pkg, small_scene, group):
