@@ -1,6 +1,5 @@
 // diag.cpp -- libmon_core_diag.so: diagnostics and test scaffolding (include/mon_core_diag.h).  Links against libmon_core.so and reads its objects
 // through the internal headers; nothing here is on the product path.
-#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -86,9 +85,6 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
             // partial tables are planar: [partition][feature][parity][entry / 2], over the LDS-scattered levels' entries
             const uint32_t n_ent = m.part_halves / 2, n_half = n_ent / 2;
             std::vector<uint16_t> pa(m.part_halves), pb(m.part_halves);
-            // few gradient-carrying samples: k_grid_scatter wrote ONE partial table per level, k_optimizer will read one (ScatterLevels::single_below)
-            uint32_t n_now = 0; HIPCHECK(hipMemcpy(&n_now, &m.d_state->n_scatter_now, 4, hipMemcpyDeviceToHost));
-            const bool single = m.scatter.single_below != 0u && n_now <= m.scatter.single_below;
             auto val = [&](const std::vector<uint16_t>& part, uint32_t e, uint32_t f) { _Float16 h;
                 std::memcpy(&h, &part[((size_t)f * 2 + (e & 1u)) * n_half + (e >> 1)], 2); return (float)h; };
             for (uint32_t q = 0; q < m.scatter.max_P; q += 2) {
@@ -98,9 +94,8 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
                 for (int l = 0; l < m.nd.L; ++l) {
                     // (a level with fewer partial tables: the rest of the buffer is not its data)
                     const bool lds_level = m.backend == 1 ? ((m.lds_mask >> l) & 1u) != 0u : true;
-                    const uint32_t Pl = single ? std::min<uint32_t>(m.scatter.P[l], 1u) : m.scatter.P[l];
-                    if (q >= Pl || !lds_level) continue;
-                    const bool two = q + 1 < Pl;
+                    if (q >= m.scatter.P[l] || !lds_level) continue;
+                    const bool two = q + 1 < m.scatter.P[l];
                     for (uint32_t e = m.lt.offset[l]; e < m.lt.offset[l + 1]; ++e) for (uint32_t f = 0; f < 2; ++f)
                         acc[2 * e + f] += two ? val(pa, e, f) + val(pb, e, f) : val(pa, e, f);
                 }

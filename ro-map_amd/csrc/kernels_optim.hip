@@ -102,7 +102,6 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
     // the 112 B of Adam state per chunk are requested behind the gradient test instead
     // (ONE: the state is on its way already; the two orders measure the same late in training with one chunk per thread)
     const bool eager = DENSE && (ONE || !(lazy_below != 0u && st->n_scatter_now <= lazy_below));
-    const bool single_part = p.gpart && p.sl.single_below != 0u && st->n_scatter_now <= p.sl.single_below;
     const uint32_t extra = nx.cand_blocks + nx.pos_blocks;          // (one or the other)
     const bool cand_block = vblock < extra;                     // GenerateRays of iteration iter + 1 / its sample positions
     if (vblock < nx.cand_blocks) gen_candidate(nx.b, nx.ds, nx.oc, st->n_boxes, st->iter + 1u, vblock * blockDim.x + threadIdx.x);
@@ -213,8 +212,6 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                     for (int l = 1; l < kMaxLevels; ++l) { const bool in = e0 >= p.sl.entry_offset[l]; lvl += in ? 1 : 0;
                         lvl_off = in ? p.sl.entry_offset[l] : lvl_off; lvl_end = in ? p.sl.entry_offset[l + 1] : lvl_end; }
                     n_part = p.sl.P[lvl];
-                    // few gradient-carrying samples: k_grid_scatter ran ONE sample partition per level (same count, same threshold: kernels_scatter.hip)
-                    if (single_part) n_part = min(n_part, 1u);
                 }
                 // dense partial tables of k_grid_scatter (fused backend): [partition][feature][parity][entry / 2]; this chunk = entries e0 .. e0 + 3 (e0 a
                 // multiple of 4), both features: per partition four 4-byte pieces -- plane (f, b) holds entries e0 + b and e0 + 2 + b next to each other

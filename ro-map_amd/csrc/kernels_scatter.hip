@@ -341,18 +341,10 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
     const uint32_t c_lo0 = (lb < n_bins) ? st->n_scatter[scatter_counter(0u, lb)] : 0u, c_lo1 = (lb < n_bins) ? st->n_scatter[scatter_counter(1u, lb)] : 0u;
     const uint32_t c_hi0 = (lb + 64u < n_bins) ? st->n_scatter[scatter_counter(0u, lb + 64u)] : 0u, c_hi1 = (lb + 64u < n_bins)
             ? st->n_scatter[scatter_counter(1u, lb + 64u)] : 0u;
-    const uint32_t raw_lo = (iter & 1u) ? c_lo1 : c_lo0, raw_hi = (iter & 1u) ? c_hi1 : c_hi0;
-    const uint32_t cnt_lo = min(raw_lo, bin_cap), cnt_hi = min(raw_hi, bin_cap);
+    const uint32_t cnt_lo = min((iter & 1u) ? c_lo1 : c_lo0, bin_cap), cnt_hi = min((iter & 1u) ? c_hi1 : c_hi0, bin_cap);
     const uint32_t slot = blockIdx.x / kScatterWgPerLevel, j = blockIdx.x - slot * kScatterWgPerLevel;
     const int level = sl.level[slot]; const uint32_t P = sl.P[level];
     const uint32_t part = j / P, p = j - part * P;
-    // Few gradient-carrying samples (late in training: 2-6 % of the batch): ONE sample partition per level.  What a workgroup costs then is its fixed part --
-    // the tile's clear and its dense write-out, P partial tables for the optimizer to read back -- not its walk, so partition 0 takes every bin and the other
-    // partitions' workgroups leave (they still carry their share of the dW row sums).  The count is the sum of the raw bin counters -- what the housekeeping
-    // block leaves in n_scatter_now, from which k_optimizer takes the same decision; a function of the batch alone, so a run stays bit-reproducible.  The
-    // gradient of an entry is then the exact sum rounded ONCE instead of the fp32 sum of P rounded partial sums.
-    const bool single = sl.single_below != 0u && P > 1u &&
-            (uint32_t)__builtin_amdgcn_readlane((int)scan_add64_u32(raw_lo + raw_hi), 63) <= sl.single_below;
     const uint32_t off = lt.offset[level], size = lt.size[level], my = lt.my[level], mz = lt.mz[level], mask = lt.mask[level];
     const bool hashed = lt.hashed[level] != 0u, pow2 = mask != 0xffffffffu;
     const float scale = lt.scale[level], fs = lt.fix_scale;
@@ -365,7 +357,7 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
     const bool degenerate = pow2 && (my & mask) == 0u && (mz & mask) == 0u && size > 1u;
     MON_ST_STAMP();
     // (levels whose part count does not divide 16 leave workgroups without a tile)
-    if ((mode != kTileParityRanged || base_half < half_size) && !(single && p != 0u)) {
+    if (mode != kTileParityRanged || base_half < half_size) {
         const uint32_t tile = mode == kTileWhole64 ? size : min(mode == kTileParity64 ? kScatterTile64 : kScatterTile, half_size - base_half);      // entries
         typedef int int4v __attribute__((ext_vector_type(4)));
         {   // tiles are multiples of 4 entries (tcnn rounds level sizes up to 8): clear with 16-byte stores
@@ -378,8 +370,8 @@ __global__ void __launch_bounds__(1024) k_grid_scatter(LevelFast lt, ScatterLeve
         // sample partition p of this level = the ray bins b = p, p + P, ... (16 bins, compacted by k_fused_train: only samples with a non-zero gradient)
         const half2_t* de = de_soa + (size_t)level * B;
 #define MON_SCATTER_CALL(H, PW, MD, ...) \
-    scatter_samples<H, PW, MD, ##__VA_ARGS__>(tab, de, x4, cnt_lo, cnt_hi, n_bins, p, single ? 1u : P, bin_cap, feature, scale, size, my, mz, mask, parity, \
-                                              base_half, tile, fs)
+    scatter_samples<H, PW, MD, ##__VA_ARGS__>(tab, de, x4, cnt_lo, cnt_hi, n_bins, p, P, bin_cap, feature, scale, size, my, mz, mask, parity, base_half, tile, \
+                                              fs)
 #define MON_SCATTER_MODE(MD) do { \
         if (hashed) { if (pow2) MON_SCATTER_CALL(true, true, MD); else MON_SCATTER_CALL(true, false, MD); } \
         else { if (pow2) MON_SCATTER_CALL(false, true, MD); else MON_SCATTER_CALL(false, false, MD); } } while (0)
@@ -471,7 +463,7 @@ void launch_rows_to_bins(hipStream_t s, const LevelFast& lf, const NetDims& nd, 
 
 // Host: which levels go through the LDS scatter, with how many sample partitions each.
 uint32_t scatter_plan(const LevelTable& lt, const NetDims& nd, ScatterLevels& sl) {
-    uint32_t mask = 0; sl.n_levels = 0; sl.max_P = 0; sl.single_below = 0;
+    uint32_t mask = 0; sl.n_levels = 0; sl.max_P = 0;
     for (int l = 0; l < kMaxLevels; ++l) { sl.P[l] = 0; sl.level[l] = 0; sl.entry_offset[l] = lt.offset[l]; }
     sl.entry_offset[kMaxLevels] = lt.offset[kMaxLevels];
     // A level of up to 16 tiles fits the 16-workgroup plan, but with more than 4 tiles every workgroup walks all the samples of the batch
@@ -502,9 +494,8 @@ bool grid_scatter_sums_partials(const LevelTable& lt, const NetDims& nd) {
 }
 void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B,
         uint32_t n_bins, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
-                         const float* partials, uint32_t n_partials, float* gmlp, DevState* st_next, uint32_t single_below) {
+                         const float* partials, uint32_t n_partials, float* gmlp, DevState* st_next) {
     ScatterLevels sl; if (!scatter_plan(lt, nd, sl)) return;
-    sl.single_below = single_below;
     const PartialsArgs pa{ partials, n_partials, fused_partial_cols(nd) + 64u, fused_partial_cols(nd), FragDims{ nd.Epad, nd.W, nd.NH, nd.L }, gmlp, st };
     constexpr uint32_t smem = kScatterLdsBytes;
     static std::atomic<uint64_t> attr_devices{ 0 }; static std::mutex attr_mu;

@@ -42,7 +42,7 @@ static std::atomic<long>* option_slot(const char* name) {
         { "step_variant", &Options::step_variant }, { "steps16", &Options::steps16 }, { "keep_zero_samples", &Options::keep_zero_samples },
         { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
         { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner },
-        { "tile_render", &Options::tile_render }, { "state_records", &Options::state_records }, { "scatter_single_below", &Options::scatter_single_below },
+        { "tile_render", &Options::tile_render }, { "state_records", &Options::state_records },
 #ifdef MON_OVERLAP_PROBE
         { "overlap", &Options::overlap }, { "enc_lds_kb", &Options::enc_lds_kb },
 #endif
@@ -540,7 +540,6 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     if (fused_supported(m.nd, S, m.oc.R)) {
         if ((rc = dev_alloc(m, m.d_frag_train, 64 * 512)) || (rc = dev_alloc(m, m.d_frag_render, 64 * 512))) return rc;       // <= 30 fragments of 512 halves
         m.lds_mask = scatter_plan(m.lt, m.nd, m.scatter);
-        m.scatter.single_below = (uint32_t)std::max(0l, options().scatter_single_below.load());
         // a partial table spans the entries up to the end of the LAST LDS-scattered level (the plan covers a prefix of the levels: sizes grow with the level);
         // sized by the whole table it was 16 x 211 MB = 3.4 GB of a T = 2^22 object for the 37 k entries of its two small levels
         {
@@ -835,7 +834,7 @@ static void enqueue_iteration(Model& m, int stages) {
             if (hybrid) {
                 launch_rows_to_bins(s, m.lf, m.nd, m.B.dE, m.B.pts, m.oc.R, m.oc.S, m.n_bins, m.d_de_soa, m.d_x_soa, m.d_state);
                 launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_gpart, m.part_halves / 2, m.d_state, nullptr, 0u, m.P.gmlp,
-                        m.d_state_next, m.scatter.single_below);
+                        m.d_state_next);
             } else {
                 if (m.hybrid_scatter) hipMemsetAsync(m.P.ggrid, 0, (size_t)m.n_grid * 2, s);
                 launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
@@ -871,7 +870,7 @@ static void enqueue_iteration(Model& m, int stages) {
         if (m.lds_mask) { ProfScope ps(m, MON_K_SCATTER);
             launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_gpart, m.part_halves / 2, m.d_state,
                                                                                 folded ? m.d_dw_partials : nullptr, fused_train_grid(m.nd, m.oc.R), m.P.gmlp,
-                                                                                        m.d_state_next, m.scatter.single_below); }
+                                                                                        m.d_state_next); }
         if (m.big_active) { ProfScope ps(m, MON_K_SCATTER);
             launch_big_scatter(s, m.lt, m.lf, m.nd, m.lds_mask, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_state, m.big_switch, m.d_big_ws, m.P.ggrid, m.d_touched
                 ? m.d_touched + (m.nd.n_mlp >> 3) : nullptr); }

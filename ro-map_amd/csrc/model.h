@@ -87,11 +87,7 @@ struct BatchPtrs {
 };
 
 // LDS scatter plan: levels handled by k_grid_scatter and their sample-partition counts (partial tables per level)
-struct ScatterLevels { uint32_t entry_offset[kMaxLevels + 1]; uint8_t P[kMaxLevels]; uint8_t level[kMaxLevels]; uint32_t n_levels; uint32_t max_P;
-    // an iteration with at most this many gradient-carrying samples is scattered by ONE sample partition per level (option scatter_single_below, read when
-    // the object is created): k_grid_scatter's workgroups of the other partitions leave at once, k_optimizer reads one partial table instead of P.  Both
-    // kernels decide from the same device-side count (the bin counters / DevState::n_scatter_now); 0 = never
-    uint32_t single_below; };
+struct ScatterLevels { uint32_t entry_offset[kMaxLevels + 1]; uint8_t P[kMaxLevels]; uint8_t level[kMaxLevels]; uint32_t n_levels; uint32_t max_P; };
 
 struct ParamPtrs {
     float* master; uint16_t* half; uint16_t* ema; float* m1; float* m2; uint32_t* steps;
@@ -157,7 +153,6 @@ struct Options {      // (atomics: tests and tools flip options while object thr
     std::atomic<long> backend{ -1 }, use_graph{ 0 }, lazy_ema{ -1 }, big_switch{ 16384 }, touched_flags{ 1 }, lds_encode{ 1 }, offline_outer{ 10 },
          offline_inner{ 500 }, train_lanes{ 2 }, lane_chunk{ 16 }, online_slice_min{ 2 }, roctx{ 0 }, step_variant{ 0 }, steps16{ 1 },
          keep_zero_samples{ 0 },   // 1: k_fused_train hands zero-gradient samples to the scatter too (the exactness test's A/B; same parameters, slower)
-         scatter_single_below{ 12288 },    // gradient-carrying samples at or below which k_grid_scatter runs one sample partition per level (0 = never)
          state_records{ 1 },    // tables above 8 M parameters keep their optimizer state as 128-byte chunk records (ParamPtrs::rec); 0: the four arrays
          tile_render{ 1 };      // inference on feature-planar level tiles: 0 never (gathers), 1 crops of 4096 rays and more + point queries, 2 always
 #ifdef MON_OVERLAP_PROBE        // variant build only (tools/variant_build.sh ovl -DMON_OVERLAP_PROBE): k_optimizer(i) next to a throw-away k_encode_tiles
@@ -245,7 +240,7 @@ bool grid_scatter_sums_partials(const LevelTable& lt, const NetDims& nd);
 void launch_grid_scatter(hipStream_t s, const LevelTable& lt, const LevelFast& lf, const NetDims& nd, const uint16_t* de_soa, const float* x_soa, uint32_t B,
         uint32_t n_bins, uint16_t* gpart, uint32_t part_stride_entries, DevState* st,
                          // partials != null: also sums the dW partial rows (k_reduce_partials folded in)
-                         const float* partials_or_null, uint32_t n_partials, float* gmlp, DevState* st_next, uint32_t single_below);
+                         const float* partials_or_null, uint32_t n_partials, float* gmlp, DevState* st_next);
 // layer-at-a-time backend: dL/dE rows + positions of every sample into k_grid_scatter's hand-over layout (kernels_scatter.hip)
 void launch_rows_to_bins(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* dE, const float* pts, uint32_t R, uint32_t S, uint32_t n_bins,
         uint16_t* de_soa, float* x_soa, DevState* st);

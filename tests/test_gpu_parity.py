@@ -905,12 +905,8 @@ def test_large_table_optimizer_follows_the_oracle_over_30_steps_on_its_own_gradi
             d = np.abs(a - b); assert d.max() <= 5e-6 and float((d > 1e-6).mean()) < 1e-4, (t, float(d.max()))
             for name, rel in (("m1", 1e-5), ("m2", 1e-5)):
                 x, y = obj.buffer(name), ref.buffer(name)
-                # (a moment that has cancelled to far below its terms carries their rounding: bounded against the largest moment instead)
-                e = np.abs(x - y); assert float((e > rel * np.abs(y)).mean()) < 1e-5 and e.max() <= 1e-6 * np.abs(y).max(), (t, name, float(e.max()))
-            # fp16 copy = h(master): masters that agree to 1e-6 sit on either side of a rounding boundary now and then (grid values start at 1e-4,
-            # where the fp16 spacing is 6e-8) -- never further apart than one fp16 step
-            ha, hb = h2f(obj.get_params(1)), h2f(ref.buffer("half"))
-            assert float((ha != hb).mean()) < 1e-3 and (np.abs(ha - hb) <= _ulp16(hb)).all()
+                assert (np.abs(x - y) <= rel * np.abs(y) + 1e-30).all(), (t, name, float(np.abs(x - y).max()))
+            assert float((obj.get_params(1) != ref.buffer("half")).mean()) < 1e-4
     st = ref.buffer("steps")
     assert (st[:nm] == 30).all() and 0.001 < (st[nm:] > 0).mean() < 0.9 and (st[nm:].max() > 3)       # a sparse table, some entries stepped again and again
     assert np.array_equal(st > 0, ever | (np.arange(st.size) < nm))                                     # exactly the entries that ever had a gradient
