@@ -889,12 +889,12 @@ def test_large_table_optimizer_follows_the_oracle_over_30_steps_on_its_own_gradi
     assert obj.info().n_grid_params > (8 << 20)
     ref = ge.make_oracle(orc, small_scene, kw); nm = ref.n_mlp
     p = obj.get_params(0); ref.set_params(p)                         # the same initial weights (pcg32 init on both sides; taken from the device to be sure)
-    ever = np.zeros(p.size, bool)
+    ever = np.zeros(p.size, bool); per_step = []
     for t in range(1, 31):
         obj.train_stages(1 | 2)
         gm = obj.buffer("gmlp"); gg = obj.buffer("ggrid_f32")
         obj.train_stages(4); ref.optimizer_step_with(gm, gg)
-        ever[nm:] |= gg != 0
+        ever[nm:] |= gg != 0; per_step.append(float((gg != 0).mean()))
         if variant != "default" and t == 12:
             ea, eb = h2f(obj.get_params(2)), h2f(ref.buffer("ema"))
             err = np.abs(ea - eb); tol = 2.0 ** -9 * (np.abs(eb) + np.abs(h2f(ref.buffer("half")))) + 3 * 2.0 ** -24
@@ -905,10 +905,15 @@ def test_large_table_optimizer_follows_the_oracle_over_30_steps_on_its_own_gradi
             d = np.abs(a - b); assert d.max() <= 5e-6 and float((d > 1e-6).mean()) < 1e-4, (t, float(d.max()))
             for name, rel in (("m1", 1e-5), ("m2", 1e-5)):
                 x, y = obj.buffer(name), ref.buffer(name)
-                assert (np.abs(x - y) <= rel * np.abs(y) + 1e-30).all(), (t, name, float(np.abs(x - y).max()))
-            assert float((obj.get_params(1) != ref.buffer("half")).mean()) < 1e-4
+                # (a moment that has cancelled to far below its terms carries their rounding: bounded against the largest moment instead)
+                e = np.abs(x - y); assert float((e > rel * np.abs(y)).mean()) < 1e-5 and e.max() <= 1e-6 * np.abs(y).max(), (t, name, float(e.max()))
+            # fp16 copy = h(master): masters that agree to 1e-6 sit on either side of a rounding boundary now and then (grid values start at 1e-4,
+            # where the fp16 spacing is 6e-8) -- never further apart than one fp16 step
+            ha, hb = h2f(obj.get_params(1)), h2f(ref.buffer("half"))
+            assert float((ha != hb).mean()) < 1e-3 and (np.abs(ha - hb) <= _ulp16(hb)).all()
     st = ref.buffer("steps")
-    assert (st[:nm] == 30).all() and 0.001 < (st[nm:] > 0).mean() < 0.9 and (st[nm:].max() > 3)       # a sparse table, some entries stepped again and again
+    # every step leaves most of the table alone (the lazy path is what ran), over the run nearly every entry is stepped, some again and again
+    assert (st[:nm] == 30).all() and 0.001 < min(per_step) and max(per_step) < 0.5 and (st[nm:] > 0).mean() > 0.5 and st[nm:].max() > 3, (min(per_step), max(per_step))
     assert np.array_equal(st > 0, ever | (np.arange(st.size) < nm))                                     # exactly the entries that ever had a gradient
     ea, eb = h2f(obj.get_params(2)), h2f(ref.buffer("ema")); w = h2f(ref.buffer("half"))
     # a few fp16 ulps of the quantities being averaged: the closed form rounds once where the recurrence rounds every step
