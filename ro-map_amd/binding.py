@@ -386,7 +386,7 @@ class Dataset:
 # debug buffer ids (ro-map_amd/csrc/model.h MON_BUF_*): name -> (id, dtype, elements as f(R, B, info))
 BUF = dict(master=0, half=1, ema=2, m1=3, m2=4, steps=5, gmlp=6, ggrid_h=9, pts=10, tdist=11, E=12, Hid=13, O=14, dO=15, dHid=16, dE=17,
            rgb_ray=18, depth_ray=19, mask_ray=20, loss_ray=21, ray_o=22, ray_d=23, ray_t0=24, ray_t1=25, target=26, target_depth=27, bgcol=28,
-           ray_flag=29, ray_dn=31, mask=32, state=33, frag_train=34, frag_ref=35, x_all=36, e_soa=37, half_tiles=38, ggrid_f32=39)
+           ray_flag=29, ray_dn=31, mask=32, state=33, frag_train=34, frag_ref=35, x_all=36, e_soa=37, half_tiles=38, ggrid_f32=39, live_cnt=40)
 
 
 class ObjectNeRF:
@@ -496,7 +496,7 @@ class ObjectNeRF:
                       ray_o=(np.float32, R * 3), ray_d=(np.float32, R * 3), ray_t0=(np.float32, R), ray_t1=(np.float32, R), target=(np.float32, R * 3),
                       target_depth=(np.float32, R), bgcol=(np.float32, R * 3), ray_flag=(np.uint8, R), ray_dn=(np.float32, R), mask=(np.uint64, R // 64),
                       state=(np.uint32, 28 + 2 * 128 * 16), frag_train=(np.uint16, 64 * 512), frag_ref=(np.uint16, 64 * 512),
-                      x_all=(np.float32, B * 4), e_soa=(np.uint16, B * 2 * self.cfg.n_levels), half_tiles=(np.uint16, i.n_grid_params))
+                      live_cnt=(np.uint32, 2 * 64 * 16), x_all=(np.float32, B * 4), e_soa=(np.uint16, B * 2 * self.cfg.n_levels), half_tiles=(np.uint16, i.n_grid_params))
         dt, cnt = shapes[name]; out = np.empty(cnt, dt)
         _check(diag_lib().mon_object_debug_read(self.h, BUF[name], _p(out), out.nbytes)); return out
 

@@ -59,6 +59,8 @@ int model_debug_read(Model& m, int which, void* dst, size_t bytes) {
         sz = B * (size_t)m.nd.L * 4; break;
         case MON_BUF_HALF_TILES: if (!m.d_half_tiles) { set_error("debug_read: level-tile encode not in use"); return MON_ERR_STATE; } src = m.d_half_tiles;
         sz = (size_t)m.n_grid * 2; break;
+        case MON_BUF_LIVE_CNT: if (!m.d_live_cnt) { set_error("debug_read: no live-sample lists (occupancy_skip off, or not on the level tiles)"); return MON_ERR_STATE; }
+            src = m.d_live_cnt; sz = 2u * kLiveMaxParts * kLiveCntStride * 4u; break;
         case MON_BUF_FRAG_REF:
             if (!m.d_frag_render) { set_error("debug_read: fused backend not available"); return MON_ERR_STATE; }
             HIPCHECK(use_device(m.device)); HIPCHECK(hipMemsetAsync(m.d_frag_render, 0, 64 * 512 * 2, m.train_stream));

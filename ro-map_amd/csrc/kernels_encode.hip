@@ -45,14 +45,21 @@ bool encode_tiles_supported(const LevelTable& lt, const NetDims& nd) {
 // One thread per sample.  Training ray j is valid candidate number (j mod n_valid) in candidate order; every block finds its rays' candidates
 // from the candidates' ballot words (<= 256 words, prefix in LDS).  The position arithmetic is ray_sample's of k_fused_train, which recomputes
 // t (it needs the distances for the composite) and stores the same x for the gradient scatter.
-__global__ void __launch_bounds__(256) k_sample_points(BatchPtrs b, ObjectConst oc, DevState* __restrict__ st, float4_t* __restrict__ x_all) {
+__global__ void __launch_bounds__(256) k_sample_points(BatchPtrs b, ObjectConst oc, DevState* __restrict__ st, float4_t* __restrict__ x_all, LiveArgs live) {
     __shared__ PointsLds lds;
     const uint32_t R = oc.R, nwords = R >> 6, iter = st->iter;
     const uint32_t nvalid = points_prefix(lds, b.mask, nwords);
     if (blockIdx.x == 0u && threadIdx.x == 0u) st->n_valid_pre = nvalid;
     if (nvalid == 0u) return;
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < R * 32u) points_sample(lds, b, oc, iter, nvalid, nwords, s, x_all);
+    if (s >= R * 32u) return;                                            // (uniform per block: the batch is a multiple of 256 samples)
+    if (live.occ_bits) points_sample<true>(lds, b, oc, iter, nvalid, nwords, s, x_all, live);
+    else points_sample<false>(lds, b, oc, iter, nvalid, nwords, s, x_all);
+}
+// the stand-alone position pass counts into the live-sample counters of its iteration like k_optimizer's position blocks do, but nothing has cleared them
+// for it (k_encode_tiles clears the set of the iteration AFTER its own): one tiny launch in front
+__global__ void __launch_bounds__(64) k_live_reset(const DevState* __restrict__ st, uint32_t* __restrict__ cnt) {
+    if (threadIdx.x < kLiveMaxParts) cnt[((size_t)(st->iter & 1u) * kLiveMaxParts + threadIdx.x) * kLiveCntStride] = 0u;
 }
 
 // ------------------------------------------------------------------ level-tile encode
@@ -67,6 +74,7 @@ struct EncodeArgs {
     // shortest of the grid): workgroup p of level 0 generates candidates [256 p, 256 p + 256) into the OTHER candidate set; k_optimizer's position blocks
     // then turn them into next iteration's positions (gen_next = 0: nothing to prepare)
     uint32_t gen_next; BatchPtrs b_next; DatasetPtrs ds;  ObjectConst oc;
+    LiveArgs live;                 // occupancy-grid skipping: walk each partition's list of live samples instead of all of its samples (idx == nullptr: all)
 };
 
 // the chain of encode_interp: corners in order k = x + 2y + 4z, c0[j] / c1[j] = x-corner 0 / 1 of pair j, weight ((wx * wy) * wz); the two x-corners of a pair
@@ -86,45 +94,61 @@ __device__ __forceinline__ half2_t enc_chain(const uint32_t (&c0)[4], const uint
     return half2_t{ (half_t)a.x, (half_t)a.y };
 }
 
-// a thread's kEncSpt positions, requested together (one load per loop trip put a global round trip in front of every sample)
-__device__ __forceinline__ void load_positions(float4_t (&xs)[kEncSpt], const float4_t* __restrict__ x_all, uint32_t s0, uint32_t s_end) {
+// A thread's kEncSpt sample slots and their positions, requested together (one load per loop trip put a global round trip in front of every sample).
+// LIVE (occupancy-grid skipping): the slots come from the partition's list of live samples -- entry threadIdx.x + k * kEncThreads of `count` -- and a wave whose
+// entries of round k all lie beyond the list skips that round altogether (wave-uniform: the unrolled rounds keep their static register arrays).
+template <bool LIVE>
+__device__ __forceinline__ void load_positions(float4_t (&xs)[kEncSpt], uint32_t (&slot)[kEncSpt], const EncodeArgs& a, uint32_t s_base, uint32_t s_end,
+        uint32_t count) {
+    if constexpr (LIVE) {
 #pragma unroll
-    for (uint32_t k = 0; k < kEncSpt; ++k) { const uint32_t s = s0 + k * kEncThreads; xs[k] = x_all[min(s, s_end - 1u)]; }
+        for (uint32_t k = 0; k < kEncSpt; ++k) { const uint32_t j = threadIdx.x + k * kEncThreads; slot[k] = (j < count) ? a.live.idx[s_base + j] : 0xffffffffu; }
+#pragma unroll
+        for (uint32_t k = 0; k < kEncSpt; ++k) xs[k] = a.x_all[slot[k] != 0xffffffffu ? slot[k] : s_base];
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < kEncSpt; ++k) { const uint32_t s = s_base + threadIdx.x + k * kEncThreads; slot[k] = s < s_end ? s : 0xffffffffu;
+            xs[k] = a.x_all[min(s, s_end - 1u)]; }
+    }
 }
+// round k has work for this wave (uniform)
+template <bool LIVE> __device__ __forceinline__ bool round_on(uint32_t k, uint32_t count) {
+    return !LIVE || k * kEncThreads + (threadIdx.x & ~63u) < count; }
 
-template <bool HASHED, bool POW2>
-__device__ __forceinline__ void encode_whole(const uint32_t* tile, const EncodeArgs& a, uint32_t s0, uint32_t s_end, half2_t* __restrict__ out, float scale,
-        uint32_t size, uint32_t my, uint32_t mz, uint32_t mask) {
-    if (s0 >= s_end) return;
-    float4_t xs[kEncSpt]; load_positions(xs, a.x_all, s0, s_end);
+template <bool HASHED, bool POW2, bool LIVE>
+__device__ __forceinline__ void encode_whole(const uint32_t* tile, const EncodeArgs& a, uint32_t s_base, uint32_t s_end, uint32_t count,
+        half2_t* __restrict__ out, float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask) {
+    if (s_base + threadIdx.x >= s_end && !LIVE) return;
+    float4_t xs[kEncSpt]; uint32_t slot[kEncSpt]; load_positions<LIVE>(xs, slot, a, s_base, s_end, count);
 #pragma unroll
     for (uint32_t k = 0; k < kEncSpt; ++k) {
-        const uint32_t s = s0 + k * kEncThreads;
+        if (!round_on<LIVE>(k, count)) continue;
         uint32_t i0[4], i1[4], c0[4], c1[4]; float pos[3];
         enc_indices<HASHED, POW2>(xs[k], scale, size, my, mz, mask, i0, i1, pos);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { c0[j] = tile[i0[j]]; c1[j] = tile[i1[j]]; }
         const half2_t e = enc_chain(c0, c1, pos);
-        if (s < s_end) out[s] = e;
+        if (slot[k] != 0xffffffffu) out[slot[k]] = e;
     }
 }
 
-template <bool HASHED, bool POW2>
+template <bool HASHED, bool POW2, bool LIVE>
 // (src: the level in the tile image, evens then odds)
-__device__ __forceinline__ void encode_parity(uint32_t* tile, const uint4* __restrict__ src, const EncodeArgs& a, uint32_t s0, uint32_t s_end,
+__device__ __forceinline__ void encode_parity(uint32_t* tile, const uint4* __restrict__ src, const EncodeArgs& a, uint32_t s_base, uint32_t s_end, uint32_t count,
                                               half2_t* __restrict__ out, float scale, uint32_t size, uint32_t my, uint32_t mz, uint32_t mask) {
     // pass 0: the even entries.  Per pair the even one of (i0, i1) is read now; the odd one is kept for pass 1 as 16 bits whose (always set) lowest bit is
     // replaced by "the odd one is x-corner 0"
     // (the position inside the cell is kept too: 24 registers against a second load + 9 instructions per sample)
     uint32_t veven[kEncSpt][4], cache[kEncSpt][2]; float pos[kEncSpt][3];
-    const bool walk = s0 < s_end;
-    float4_t xs[kEncSpt];
-    if (walk) load_positions(xs, a.x_all, s0, s_end);          // (the copy of the even half is under way: k_encode_tiles requested it at its entry)
+    const bool walk = LIVE ? (threadIdx.x & ~63u) < count : s_base + threadIdx.x < s_end;
+    float4_t xs[kEncSpt]; uint32_t slot[kEncSpt];
+    if (walk) load_positions<LIVE>(xs, slot, a, s_base, s_end, count);          // (the copy of the even half is under way: k_encode_tiles requested it at its entry)
     __builtin_amdgcn_s_waitcnt(0x0f70);                                   // vmcnt(0): the LDS writes of the copy are counted there
     __syncthreads();
     if (walk) {
 #pragma unroll
         for (uint32_t k = 0; k < kEncSpt; ++k) {
+            if (!round_on<LIVE>(k, count)) continue;
             uint32_t i0[4], i1[4], c[4];
             enc_indices<HASHED, POW2>(xs[k], scale, size, my, mz, mask, i0, i1, pos[k]);
 #pragma unroll
@@ -144,7 +168,7 @@ __device__ __forceinline__ void encode_parity(uint32_t* tile, const uint4* __res
     if (walk) {
 #pragma unroll
         for (uint32_t k = 0; k < kEncSpt; ++k) {
-            const uint32_t s = s0 + k * kEncThreads;
+            if (!round_on<LIVE>(k, count)) continue;
             uint32_t c0[4], c1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -154,7 +178,7 @@ __device__ __forceinline__ void encode_parity(uint32_t* tile, const uint4* __res
                 c0[j] = odd0 ? vodd : veven[k][j]; c1[j] = odd0 ? veven[k][j] : vodd;
             }
             const half2_t e = enc_chain(c0, c1, pos[k]);
-            if (s < s_end) out[s] = e;
+            if (slot[k] != 0xffffffffu) out[slot[k]] = e;
         }
     }
 }
@@ -167,7 +191,7 @@ __global__ void __launch_bounds__(kEncThreads) k_encode_tiles(EncodeArgs a) {
         for (uint32_t c0 = part * 256u; c0 < a.oc.R; c0 += kEncWgPerLevel * 256u) gen_candidate(a.b_next, a.ds, a.oc, a.st->n_boxes, a.st->iter + 1u,
                 c0 + threadIdx.x);
     const uint32_t w = blockIdx.y * kEncWgPerLevel + part;             // sample partition of the batch
-    const uint32_t s_base = w * a.spw, s_end = min(s_base + a.spw, a.B), s0 = s_base + threadIdx.x;
+    const uint32_t s_base = w * a.spw, s_end = min(s_base + a.spw, a.B);
     if (s_base >= a.B) return;
     const uint32_t off = a.lt.offset[level], size = a.lt.size[level], my = a.lt.my[level], mz = a.lt.mz[level], mask = a.lt.mask[level];
     const bool hashed = a.lt.hashed[level] != 0u, pow2 = mask != 0xffffffffu;
@@ -177,18 +201,28 @@ __global__ void __launch_bounds__(kEncThreads) k_encode_tiles(EncodeArgs a) {
     // the first tile is requested BEFORE the state is looked at (everything above comes from the argument segment): the round trip for n_valid_pre runs under
     // the copy
     tile_copy(tile, src, size <= kEncWholeMax ? size / 4u : size / 8u);
+    // occupancy-grid skipping: this partition's live-sample count -- both parity sets requested with the state, the iteration's one picked afterwards
+    const bool live = a.live.idx != nullptr;
+    uint32_t cnt0 = 0u, cnt1 = 0u;
+    if (live) { cnt0 = a.live.cnt[(size_t)w * kLiveCntStride]; cnt1 = a.live.cnt[((size_t)kLiveMaxParts + w) * kLiveCntStride]; }
+    const uint32_t iter = a.st->iter;
+    if (live && blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x < kLiveMaxParts)      // (the set the next iteration's position pass counts in: nobody reads it now)
+        a.live.cnt[((size_t)((iter + 1u) & 1u) * kLiveMaxParts + threadIdx.x) * kLiveCntStride] = 0u;
     if (a.st->n_valid_pre == 0u) return;                               // batch skipped (the position pass wrote the count)
+    const uint32_t count = min((iter & 1u) ? cnt1 : cnt0, s_end - s_base);
+#define MON_ENC_CALL(FN, H, P2, ...) do { if (live) FN<H, P2, true>(__VA_ARGS__); else FN<H, P2, false>(__VA_ARGS__); } while (0)
     if (size <= kEncWholeMax) {
         __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
-        if (hashed) { if (pow2) encode_whole<true, true>(tile, a, s0, s_end, out, scale, size, my, mz, mask);
-            else encode_whole<true, false>(tile, a, s0, s_end, out, scale, size, my, mz, mask); }
-        else encode_whole<false, false>(tile, a, s0, s_end, out, scale, size, my, mz, mask);
+        if (hashed) { if (pow2) MON_ENC_CALL(encode_whole, true, true, tile, a, s_base, s_end, count, out, scale, size, my, mz, mask);
+            else MON_ENC_CALL(encode_whole, true, false, tile, a, s_base, s_end, count, out, scale, size, my, mz, mask); }
+        else MON_ENC_CALL(encode_whole, false, false, tile, a, s_base, s_end, count, out, scale, size, my, mz, mask);
     } else {
-        if (hashed) { if (pow2) encode_parity<true, true>(tile, src, a, s0, s_end, out, scale, size, my, mz, mask);
-            else encode_parity<true, false>(tile, src, a, s0, s_end, out, scale, size, my, mz, mask); }
-        else encode_parity<false, false>(tile, src, a, s0, s_end, out, scale, size, my, mz, mask);
+        if (hashed) { if (pow2) MON_ENC_CALL(encode_parity, true, true, tile, src, a, s_base, s_end, count, out, scale, size, my, mz, mask);
+            else MON_ENC_CALL(encode_parity, true, false, tile, src, a, s_base, s_end, count, out, scale, size, my, mz, mask); }
+        else MON_ENC_CALL(encode_parity, false, false, tile, src, a, s_base, s_end, count, out, scale, size, my, mz, mask);
     }
+#undef MON_ENC_CALL
 }
 
 // the tile image from the fp16 working copy (object creation, set_params, backend switch: whenever the weights changed outside k_optimizer, which keeps it
@@ -233,21 +267,26 @@ void launch_xorwow_fill(hipStream_t s, void* lane_states, uint32_t lanes, int fl
             n0, out1, n1, out2, n2);
 }
 
+uint32_t encode_tiles_spw(uint32_t B) {
+    const uint32_t per_chunk = kEncWgPerLevel * kEncThreads * kEncSpt, chunks = (B + per_chunk - 1u) / per_chunk;
+    return (B + kEncWgPerLevel * chunks - 1u) / (kEncWgPerLevel * chunks);
+}
 void encode_tiles_setup_device() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsBytes); }
 
-void launch_sample_points(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* x_all) {
+void launch_sample_points(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* x_all, const LiveArgs& live) {
     const uint32_t B = oc.R * 32u;
-    hipLaunchKernelGGL(k_sample_points, dim3((B + 255u) / 256u), dim3(256), 0, s, b, oc, st, reinterpret_cast<float4_t*>(x_all));
+    if (live.occ_bits) hipLaunchKernelGGL(k_live_reset, dim3(1), dim3(64), 0, s, st, live.cnt);
+    hipLaunchKernelGGL(k_sample_points, dim3((B + 255u) / 256u), dim3(256), 0, s, b, oc, st, reinterpret_cast<float4_t*>(x_all), live);
 }
 
 void launch_encode_tiles(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* half_tiles, const float* x_all, uint16_t* e_soa, uint32_t B,
         const DevState* st,
-                         const BatchPtrs* b_next, const DatasetPtrs& ds, const ObjectConst& oc, uint32_t lds_bytes) {
+                         const BatchPtrs* b_next, const DatasetPtrs& ds, const ObjectConst& oc, uint32_t lds_bytes, const LiveArgs& live) {
     const uint32_t per_chunk = kEncWgPerLevel * kEncThreads * kEncSpt, chunks = (B + per_chunk - 1u) / per_chunk;
-    const uint32_t spw = (B + kEncWgPerLevel * chunks - 1u) / (kEncWgPerLevel * chunks);
+    const uint32_t spw = encode_tiles_spw(B);
     EncodeArgs a{ lf, nd.L, nd.n_mlp, half_tiles, reinterpret_cast<const float4_t*>(x_all), reinterpret_cast<half2_t*>(e_soa), B, spw, st,
-            b_next ? 1u : 0u, b_next ? *b_next : BatchPtrs{}, ds, oc };
+            b_next ? 1u : 0u, b_next ? *b_next : BatchPtrs{}, ds, oc, live };
 #ifdef MON_OVERLAP_PROBE
     // (lds_bytes bit 0 = launch without the AQL barrier bit, hipExtAnyOrderLaunch: ignored on gfx950)
     if (lds_bytes & 1u) { hipExtLaunchKernelGGL(k_encode_tiles, dim3((uint32_t)nd.L * kEncWgPerLevel, chunks), dim3(kEncThreads), (lds_bytes & ~1u) ? (lds_bytes & ~1u)

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256, (((NH == 2 && W == 64) || W == 128) ? 1 :
         if (lane < 10) v = *reinterpret_cast<const uint32_t*>(rec_base + 4u * (size_t)(cand * rec_mul)); return v; };
     // (PRE with records: lane l < 10 takes field l of ray `r`'s 12-float record -- one coalesced 40-byte load, requested a ray ahead like the candidate record)
     const auto load_ray_rec = [&](uint32_t r) -> uint32_t { uint32_t v = 0u;
-        if (lane < 11) v = reinterpret_cast<const uint32_t*>(a.b.ray_rec)[12u * (size_t)r + (uint32_t)lane]; return v; };
+        if (lane < 12) v = reinterpret_cast<const uint32_t*>(a.b.ray_rec)[12u * (size_t)r + (uint32_t)lane]; return v; };
     const uint32_t ray0 = blockIdx.x * S::WAVES + wave;
     uint32_t cand = 0u, rec = 0u;
     if (have_rec) { if (nvalid != 0u && ray0 < R) rec = load_ray_rec(ray0); }
@@ -144,7 +144,10 @@ __global__ void __launch_bounds__(256, (((NH == 2 && W == 64) || W == 128) ? 1 :
         for (int d = 0; d < 3; ++d) { const float p = fmaf(q.t, rd[d], ro[d]); q.x[d] = (p - a.oc.aabb.mn[d]) / (a.oc.aabb.mx[d] - a.oc.aabb.mn[d]); }
         // occupancy-grid skipping (default off): a sample whose cell the grid marks empty is not evaluated -- no gathers, alpha = 0, no gradient
         q.live = true;
-        if constexpr (OCC) {
+        // (level-tile chain: the position pass looked the cells up and left the ray's 32 live bits in word 11 of its record -- k_encode_tiles encoded exactly
+        // those samples, and a grid refreshed since then takes effect with the next position pass)
+        if constexpr (OCC && PRE) q.live = ((lane_u(recv, 11) >> (uint32_t)n) & 1u) != 0u;
+        else if constexpr (OCC) {
             const uint32_t cx = (uint32_t)min(max((int)(q.x[0] * (float)kOccRes), 0), kOccRes - 1),
                     cy = (uint32_t)min(max((int)(q.x[1] * (float)kOccRes), 0), kOccRes - 1),
                     cz = (uint32_t)min(max((int)(q.x[2] * (float)kOccRes), 0), kOccRes - 1);
@@ -175,7 +178,9 @@ __global__ void __launch_bounds__(256, (((NH == 2 && W == 64) || W == 128) ? 1 :
         TileState<EPAD, W, NH> ts;
         if constexpr (PRE) {
 #pragma unroll
-            for (int il = 0; il < S::LLV; ++il) { const half2_t v = __builtin_bit_cast(half2_t, epre[il]); ts.ef[2 * il] = v.x; ts.ef[2 * il + 1] = v.y; }
+            for (int il = 0; il < S::LLV; ++il) {
+                // (a dead sample's slot was not encoded: zero features, like the gather chain's masked loads)
+                const half2_t v = __builtin_bit_cast(half2_t, (!OCC || live) ? epre[il] : 0u); ts.ef[2 * il] = v.x; ts.ef[2 * il + 1] = v.y; }
         } else if (cur.any) { GatherWindow<EPAD, W, NH> gw; encode_begin<EPAD, W, NH, OCC>(gw, lregs, rsrc, x, lane, live);
             encode_finish<EPAD, W, NH, OCC>(ts, gw, lregs, rsrc, x, lane, L, live); }
         tstamp(tc, 2);

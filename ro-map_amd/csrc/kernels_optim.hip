@@ -115,8 +115,10 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
 #else
         if (nv != 0u)
 #endif
-            for (uint32_t s = vblock * blockDim.x + threadIdx.x; s < nx.oc.R * 32u; s += nx.pos_blocks * blockDim.x) points_sample(plds, nx.b, nx.oc,
-                    st->iter + 1u, nv, nwords, s, reinterpret_cast<float4_t*>(nx.x_all));
+            for (uint32_t s = vblock * blockDim.x + threadIdx.x; s < nx.oc.R * 32u; s += nx.pos_blocks * blockDim.x) {
+                if (nx.live.occ_bits) points_sample<true>(plds, nx.b, nx.oc, st->iter + 1u, nv, nwords, s, reinterpret_cast<float4_t*>(nx.x_all), nx.live);
+                else points_sample<false>(plds, nx.b, nx.oc, st->iter + 1u, nv, nwords, s, reinterpret_cast<float4_t*>(nx.x_all));
+            }
     }
     const uint32_t bid = vblock - extra, nblk = gridDim.x - extra;
     const float lr0 = st->lr;

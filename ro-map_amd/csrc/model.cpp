@@ -596,6 +596,13 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         float diag2 = 0.f; for (int a = 0; a < 3; ++a) diag2 += (amax[a] - amin[a]) * (amax[a] - amin[a]);
         const float dt = std::sqrt(diag2) / (float)S;
         m.occ_raw_threshold = std::log(1e-3f / std::max(dt, 1e-6f));
+        // the level-tile chain with the grid in use: live-sample lists for k_encode_tiles (LiveArgs, model.h) -- a position block's 256 samples must lie in
+        // one of the encode's sample partitions
+        // (a list holds at most ceil(blocks / n_parts) * 256 entries: it must fit the partition's spw slots)
+        const uint32_t spw_l = encode_tiles_spw(Btrain), parts_l = (Btrain + spw_l - 1u) / spw_l, blocks_l = (Btrain + 255u) / 256u;
+        if (m.d_e_soa && Btrain % 256u == 0u && parts_l <= kLiveMaxParts && ((blocks_l + parts_l - 1u) / parts_l) * 256u <= spw_l) {
+            if ((rc = dev_alloc(m, m.d_live_idx, Btrain)) || (rc = dev_alloc(m, m.d_live_cnt, 2u * kLiveMaxParts * kLiveCntStride))) return rc;
+        }
     }
     m.boxes_cap = 1024;
     if ((rc = dev_alloc(m, m.d_boxes, m.boxes_cap))) return rc;
@@ -777,6 +784,13 @@ static void collect_profile(Model& m) {
     m.ev_pending.clear();
 }
 
+// occupancy-grid skipping on the level-tile chain: what the position pass, k_encode_tiles and k_fused_train<PRE, OCC> share once the grid is in use
+static LiveArgs live_args(const Model& m) {
+    if (!(m.d_occ && m.occ_refreshed_iter && m.d_live_idx)) return LiveArgs{};
+    const uint32_t B = m.oc.R * m.oc.S, spw = encode_tiles_spw(B);
+    return LiveArgs{ m.d_occ, m.d_live_idx, m.d_live_cnt, spw, (B + spw - 1u) / spw };
+}
+
 // One iteration of Train_Step's loop body (nerf_model.cu:1637-1646), enqueued without host syncs.
 static void enqueue_iteration(Model& m, int stages) {
     hipStream_t s = m.train_stream; const uint32_t B = m.oc.R * m.oc.S;
@@ -843,20 +857,24 @@ static void enqueue_iteration(Model& m, int stages) {
             // stage-wise debugging: a forward/backward without an optimizer step after it
             if (m.scatter_pending) hipMemsetAsync(m.d_state->n_scatter, 0, sizeof(m.d_state->n_scatter), s);
             // the encode as LDS reads of level tiles; the fused kernel then loads the features
-            const bool pre = m.d_e_soa && m.fused_dump != 1 && options().lds_encode && !m.gathers_preferred;
+            // (the grid in use without live-sample lists -- a batch size whose partitions do not hold whole position blocks --: the gather chain masks its loads)
+            const bool pre = m.d_e_soa && m.fused_dump != 1 && options().lds_encode && !m.gathers_preferred && !(m.d_occ && m.occ_refreshed_iter && !m.d_live_idx);
             m.pre_active = pre;
+            const LiveArgs live = live_args(m);
             if (pre) {
                 // positions of this batch: normally the last k_optimizer's position blocks already wrote them (and k_encode_tiles of the last iteration the
                 // candidates)
-                if (!(m.next_ready && m.points_ready)) { ProfScope pp(m, MON_K_POINTS); launch_sample_points(s, m.B, m.oc, m.d_state, m.d_x_all); }
+                if (!(m.next_ready && m.points_ready)) { ProfScope pp(m, MON_K_POINTS); launch_sample_points(s, m.B, m.oc, m.d_state, m.d_x_all, live); }
                 // (the next iteration is always prepared ahead: the stand-alone kernels run after an invalidation only)
                 const bool gen_next = true;
                 { ProfScope pe(m, MON_K_ENCODE); launch_encode_tiles(s, m.lf, m.nd, m.d_half_tiles, m.d_x_all, m.d_e_soa, B, m.d_state, gen_next ? &m.B_alt
-                        : nullptr, m.ds->ptrs(), m.oc
+                        : nullptr, m.ds->ptrs(), m.oc,
 #ifdef MON_OVERLAP_PROBE
-                        , (uint32_t)options().enc_lds_kb * 1024u
+                        (uint32_t)options().enc_lds_kb * 1024u,
+#else
+                        0u,
 #endif
-                        ); }
+                        live); }
             }
             ProfScope ps(m, MON_K_FWDBWD);
             // (no grid look-ups before the first refresh: every cell is live during the warm-up)
@@ -902,7 +920,7 @@ static void enqueue_iteration(Model& m, int stages) {
             // one sample per thread up to 131 072 samples (two beyond: as many position blocks as optimizer blocks made the kernel 10 us longer at R = 8192): a
             // thread's chain is select -> candidate loads -> store, ~5 us of latency that several samples per thread put in series (64 blocks of 8 samples per
             // thread made these blocks the kernel's tail)
-            if (pos_mode) { nx.pos_blocks = std::min((B + 255u) / 256u, 512u); nx.x_all = m.d_x_all; }
+            if (pos_mode) { nx.pos_blocks = std::min((B + 255u) / 256u, 512u); nx.x_all = m.d_x_all; nx.live = live_args(m); }
         }
 #ifdef MON_OVERLAP_PROBE
         // PROBE (option overlap): a second, throw-away k_encode_tiles of the CURRENT batch next to k_optimizer -- what would the pair cost side by side?
@@ -941,6 +959,8 @@ static void maybe_refresh_occupancy(Model& m, uint32_t iter) {
     // early rate -- more than the skipping saves once the level-tile chain has taken the gathers out of the forward pass; tools/occ_timing.py)
     const uint32_t every = (uint32_t)kOccInterval * (iter < 512u ? 1u : iter < 2048u ? 4u : 16u);
     m.occ_refreshed_iter = iter; m.occ_next_refresh = (iter / every + 1u) * every;
+    // the positions already sampled for this iteration carry the OLD grid's live bits and lists (or none: the first refresh): sample them again
+    if (m.d_live_idx) m.points_ready = false;
 }
 
 static int sync_state(Model& m) {
@@ -974,6 +994,10 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     // samples in empty cells, k_encode_tiles encodes every sample (kernel_times, late window: 63.3 against 65.4 us per step; early, 99.6 against 92.1).  Both
     // chains leave bit-identical parameters, so the choice is free per call; the host knows the regime from the last call's read-back.
     m.gathers_preferred = m.d_occ && m.occ_refreshed_iter && m.h_state.n_scatter_last != 0u && 8u * m.h_state.n_scatter_last < m.oc.R * m.oc.S;
+#ifndef MON_OCC_PREFER_GATHERS      // (variant build for the A/B)
+    // round 6: with the live-sample lists k_encode_tiles walks the live samples only and the level tiles win in every regime
+    if (m.d_live_idx) m.gathers_preferred = false;
+#endif
     const bool use_graph_env = options().use_graph != 0;
     if (iters > 0) m.weights_epoch = next_weights_epoch();
     // (nothing of this object is in flight between calls: the read-back at the end of the last one is current)

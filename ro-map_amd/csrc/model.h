@@ -126,11 +126,23 @@ struct OptimConst {
     uint32_t n_mlp, n_params;
 };
 
+// Occupancy-grid skipping on the level-tile chain (north_star N1; cfg.occupancy_skip): the position pass looks every sample's cell up in the bit grid, leaves
+// the ray's 32 live bits in word 11 of its record (k_fused_train<PRE, OCC> takes them from there: both kernels see the grid as the position pass saw it) and
+// compacts the LIVE samples of each of k_encode_tiles' sample partitions into an index list, so that the encode walks the live samples only.
+//   idx [B]: partition w's list at [w * spw, w * spw + count_w), in arrival order (irrelevant: a sample's features go to its own slot).  WHICH list a sample
+//     is on is free for the same reason: position block b (256 consecutive samples) appends to list b mod n_parts, so the lists come out equally long
+//     whatever part of the batch is live (by sample range the longest list of the bench scene's late batches had 2355 entries against a mean of 2010: three
+//     rounds of the encode's 1024 threads instead of two)
+//   cnt [2][kLiveMaxParts][kLiveCntStride]: count_w of the iteration with parity p at [p][w][0] -- a 64-byte line each (one returning atomic per position
+//     block lands there); the position pass of iteration j counts in set j & 1, k_encode_tiles(j) reads it and clears the other one for iteration j + 1
+constexpr uint32_t kLiveMaxParts = 64, kLiveCntStride = 16;
+struct LiveArgs { const uint32_t* occ_bits; uint32_t* idx; uint32_t* cnt; uint32_t spw, n_parts; };      // occ_bits == nullptr: every sample is evaluated, no lists
+
 // What k_optimizer prepares for the next iteration of the fused backend (all zero = nothing): candidate rays and the A-fragment image.
 struct OptimNext { uint32_t cand_blocks; uint16_t* frag_image; FragDims fd; BatchPtrs b; DatasetPtrs ds; ObjectConst oc;
                    // pos_blocks > 0 (level-tile encode): `b` holds the NEXT iteration's candidates already (k_encode_tiles generated them), these blocks sample
                    // its positions
-                   uint32_t pos_blocks; float* x_all; };
+                   uint32_t pos_blocks; float* x_all; LiveArgs live; };
 
 // debug buffer ids for mon_object_debug_read (stable numbering, see binding.py BUF)
 enum {
@@ -145,6 +157,7 @@ enum {
     MON_BUF_X_ALL = 36,         // level-tile encode: positions float4 [B] of the batch the next / last iteration uses
     MON_BUF_E_SOA = 37,         // level-tile encode: encoded features half2 [L][B] of the last iteration
     MON_BUF_HALF_TILES = 38,    // level-tile encode: the fp16 grid in tile order (ParamPtrs::half_tiles)
+    MON_BUF_LIVE_CNT = 40,      // occupancy-grid skipping on the level tiles: the live-sample counters [2][kLiveMaxParts][kLiveCntStride] (LiveArgs)
     MON_BUF_GGRID_F32 = 39      // the grid gradient the next k_optimizer will form, fp32: gradient table + the partial tables summed in the kernel's order
 };
 
@@ -223,11 +236,12 @@ void launch_fused_train(hipStream_t s, const LevelFast& lt, const NetDims& nd, c
 // level-tile encode (kernels_encode.hip): the forward gathers as LDS reads of a level tile, one workgroup per (level, sample partition)
 bool encode_tiles_supported(const LevelTable& lt, const NetDims& nd);
 void encode_tiles_setup_device();
-void launch_sample_points(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* x_all);
+void launch_sample_points(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st, float* x_all, const LiveArgs& live = LiveArgs{});
 void launch_encode_tiles(hipStream_t s, const LevelFast& lf, const NetDims& nd, const uint16_t* half_tiles, const float* x_all, uint16_t* e_soa, uint32_t B,
         const DevState* st,
                          // b_next: the candidate set GenerateRays of the next iteration goes to
-                         const BatchPtrs* b_next_or_null, const DatasetPtrs& ds, const ObjectConst& oc, uint32_t lds_bytes = 0);
+                         const BatchPtrs* b_next_or_null, const DatasetPtrs& ds, const ObjectConst& oc, uint32_t lds_bytes = 0, const LiveArgs& live = LiveArgs{});
+uint32_t encode_tiles_spw(uint32_t B);          // samples per sample partition of k_encode_tiles (a partition's live list starts at w * spw)
 // XORWOW sample stream (kernels_encode.hip k_xorwow_fill): one thread per lane, the generate calls of one iteration / one Render in the reference's order
 void launch_xorwow_fill(hipStream_t s, void* lane_states, uint32_t lanes, int flavour, uint32_t start_lane, float* out0, uint32_t n0, float* out1, uint32_t n1,
         float* out2, uint32_t n2);
@@ -317,6 +331,7 @@ struct Model {
     // occupancy grid (cfg.occupancy_skip)
     uint32_t *d_occ = nullptr, *d_occ_tmp = nullptr; uint16_t* d_frag_occ = nullptr; float occ_raw_threshold = 0.f;
     uint32_t occ_refreshed_iter = 0, occ_next_refresh = 0;
+    uint32_t *d_live_idx = nullptr, *d_live_cnt = nullptr;      // live-sample lists of the level-tile chain (LiveArgs)
     // whole-crop render outputs: ONE grow-only buffer, rgb | depth | mask of the current crop back to back
     float *d_out_all = nullptr, *d_out_rgb = nullptr, *d_out_depth = nullptr, *d_out_mask = nullptr; size_t out_cap = 0;
     // pinned staging of a crop on its way to the caller's (pageable) buffers

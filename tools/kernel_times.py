@@ -18,12 +18,18 @@ def window(pkg, sc, extra, kw):
     obj.train(extra + 5); pkg.lib().mon_device_synchronize(0)
     t0 = time.perf_counter(); obj.train(20); pkg.lib().mon_device_synchronize(0); plain = (time.perf_counter() - t0) / 20
     crc = zlib.crc32(obj.get_params(0).tobytes()); n_grad = int(obj.buffer("state")[24])      # gradient-carrying samples of the window's last iteration
+    live = None
+    if kw.get("occupancy_skip"):
+        try:
+            c = obj.buffer("live_cnt").reshape(2, 64, 16)[:, :, 0]; live = [int(c[0].sum()), int(c[1].sum()), int(c.max())]      # per parity set; largest partition
+        except Exception:
+            live = None
     obj.close()
     _, obj = ge.make_problem(pkg, sc, kw, dataset=ds)
     obj.train(extra + 5); obj.set_profiling(True); obj.profile(reset=True); obj.train(20); p = obj.profile(reset=True)
     obj.close(); ds.close()
     avg = lambda k: round(1e3 * p["ms"][k] / max(1, p["launches"][k]), 2)
-    return dict(step_us=round(1e6 * plain, 2), points_us=avg(7), encode_us=avg(6), fused_us=avg(1), scatter_us=avg(4), optim_us=avg(2), crc="%08x" % crc, n_grad=n_grad)
+    return dict(step_us=round(1e6 * plain, 2), points_us=avg(7), encode_us=avg(6), fused_us=avg(1), scatter_us=avg(4), optim_us=avg(2), crc="%08x" % crc, n_grad=n_grad, live=live)
 
 
 def main():

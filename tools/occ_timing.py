@@ -18,6 +18,6 @@ def run(tag, cfg_kw, opts):
     o.close()
     for k in opts: pkg.set_option(k, {"lds_encode": 1}[k])
 run("default (no occupancy grid)", {}, {})
-run("occupancy skipping (chain picked per train call)", dict(occupancy_skip=1), {})
+run("occupancy skipping (level tiles, live-sample lists)", dict(occupancy_skip=1), {})
 run("occupancy skipping, gather chain only", dict(occupancy_skip=1), dict(lds_encode=0))
 run("default again", {}, {})
