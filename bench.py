@@ -148,10 +148,10 @@ def main():
     dt = median(reps)
     cfg = obj.cfg; L = cfg.n_levels; B = cfg.rays_per_batch * cfg.n_samples
     value = world * args.steps * B / dt
-    per_rank = None
-    if dist is not None:                   # every rank's own last-repeat time (the headline uses the max over ranks)
-        t = torch.tensor([own_last], dtype=torch.float64, device=coll_dev); outs = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(outs, t); per_rank = [round(args.steps * B / float(o.item()), 1) for o in outs]
+    per_rank = None; rank_devices = [device]
+    if dist is not None:                   # every rank's own last-repeat time (the headline uses the max over ranks) and the device it trained on
+        t = torch.tensor([own_last, float(device)], dtype=torch.float64, device=coll_dev); outs = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outs, t); per_rank = [round(args.steps * B / float(o[0].item()), 1) for o in outs]; rank_devices = [int(o[1].item()) for o in outs]
 
     # ---- roofline of the dominant kernel: HIP events on the kernel's own stream (the object's train stream) around every launch of
     # the SAME window (a fresh object, steps W..W+K from init), un-timed because the events cost ~37 us per step between the launches.
@@ -171,12 +171,22 @@ def main():
     regime = "dense" if scattered > 0.5 * B else "sparse"          # which committed PMC pass matches this window
     pmc = {}
     base_cfg = not args.log2_hashmap_size            # the committed PMC numbers were collected on the base.json workload only
+    # the committed profile belongs to the kernel sources it was measured on: their fingerprint is stored with it (tools/fingerprint.py) and recomputed here.
+    # A kernel change without a re-profile makes every profile-derived number STALE: it stays in the line (labelled), but `frac` falls back to the live one.
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from fingerprint import kernel_sources_sha16
+        sources_now = kernel_sources_sha16()
+    except Exception:
+        sources_now = None
     try:
         if base_cfg:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             pmc = dict(pj.get(regime, {}), source=pj.get(regime, {}).get("source"))
     except Exception:
         pmc = {}
+    profile_sources = pmc.get("kernel_sources_sha16")
+    traffic_stale = bool(pmc) and not (sources_now and profile_sources == sources_now)
     # Algorithmic bytes per launch, SURVEY 8(d) split over the kernels of a step: per ray-sample position 12 + table gathers 32*L (encode),
     # distance 4 + network output w+r 16 + dL/dO w+r 16 + distance re-read 4 (forward/backward), gradient scatter read-modify-write 64*L of the samples that
     # carry a gradient (scatter); per step 40 B per parameter (optimizer: fp16 gradient, fp32 Adam moments + master r/w, step counter r/w, fp16 copy, EMA r/w).
@@ -209,9 +219,19 @@ def main():
     rp_sum = sum(r["rocprof_launch_ms"] for r in table) if all(r["rocprof_launch_ms"] for r in table) else None
     # "bound" names the roof the contract prices the path against (SURVEY 8(d) accounts it in bytes); what the counters name as the kernel's limiter is
     # `limited_by`
+    # achieved / frac: from the kernel's rocprofv3 duration in the committed window when that profile was measured on THESE kernel sources (the event pair
+    # inflates the launch it brackets; the rocprofv3 durations are the ones that fit the timed step) -- otherwise from the live HIP-event time, flagged
+    use_rp = bool(dom["rocprof_launch_ms"]) and not traffic_stale
+    rp_ach = round(dom["algorithmic_bytes_per_launch"] / (dom["rocprof_launch_ms"] * 1e-3) / 1e9, 2) if dom["rocprof_launch_ms"] else None
     roofline = {"bound": "hbm", "bound_note": "priced against HBM bytes as SURVEY 8(d) prescribes; the dominant kernel's measured limiter is in limited_by "
                                                 "(it is not HBM-bound at base.json size: tables live in L2 / LDS)",
-                "achieved": dom["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
+                "achieved": rp_ach if use_rp else dom["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": dom["frac_rocprof"] if use_rp else dom["frac"],
+                "frac_is": "algorithmic bytes / the kernel's rocprofv3 duration in the committed window of these kernel sources" if use_rp
+                           else "algorithmic bytes / the live HIP-event time (inflated by ~2 us per launch)" + (
+                               ": the committed profile was measured on OTHER kernel sources" if traffic_stale else ""),
+                "frac_hip_events": dom["frac"], "achieved_hip_events": dom["achieved"],
+                "traffic": dom["traffic"], "traffic_stale": traffic_stale,
+                "kernel_sources_sha16": sources_now, "profile_kernel_sources_sha16": profile_sources,
                 "traffic_regime": regime if dom["traffic"] else None, "traffic_source": pmc.get("source"),
                 "kernel": dom["kernel"], "avg_launch_ms": dom["avg_launch_ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                         "limited_by": dom["limited_by"],
@@ -499,6 +519,7 @@ def main():
                       "late": {"steps": "800..840", "ms_per_step": round(1e3 * ts_late, 4), "value": round(B / ts_late, 1),
                                "frac_of_hbm_from_counters": hbm_frac("step_bytes_beyond_l2_steps_800_820", 1e3 * ts_late)},
                       "unit": "ray-samples/s", "traffic_source": sp.get("source"),
+                      "traffic_stale": bool(sp) and not (sources_now and sp.get("kernel_sources_sha16") == sources_now),
                       "note": "frac_of_hbm = committed counter traffic of the step's kernels ((2 FETCH_SIZE + WRITE_SIZE) KB summed over the kernels of a "
                               "step, profiles/r05_window_T22.md) / measured step time / 8 TB/s"}
             so.close()
@@ -518,7 +539,11 @@ def main():
                           "parallelism": "object-per-GPU (no training collective; %s gather-to-root of the final render%s)" % (
                               {"nccl": "RCCL", None: "RCCL"}.get(coll_backend, coll_backend), ", device-resident crops" if coll_backend == "nccl" else ""),
                           "launcher": "self-spawned ranks" if os.environ.get("MON_BENCH_SPAWNED")
-                                       else ("torch.distributed.run" if world > 1 else "single process")},
+                                       else ("torch.distributed.run" if world > 1 else "single process"),
+                          # what the collective itself says: ranks in the process group, its backend, devices visible to this rank
+                          "ranks_in_collective": (dist.get_world_size() if dist is not None else 1),
+                          "collective_backend": (dist.get_backend() if dist is not None else None), "visible_devices": ndev,
+                          "rank_devices": rank_devices},
                "timed_region": "median of %d independent repeats; each repeat: fresh object, %d warm-up steps, %d timed steps from init, barrier + device sync "
                                "on both sides, max over ranks" % (len(reps), args.warmup, args.steps),
                "ms_per_step_repeats": [round(1e3 * r / args.steps, 4) for r in reps], "per_rank_ray_samples_per_s": per_rank,

@@ -94,6 +94,13 @@ int mon_gather_create(int root_device, mon_gather** out) {
     ncclResult_t r = ncclCommInitAll(g->comms.data(), n_phys, ids.data());
     if (r != ncclSuccess) { for (auto& c : g->comms) c = nullptr; mon_gather_destroy(g);
         return fail(MON_ERR_HIP, "ncclCommInitAll over %d devices: %s", n_phys, ncclGetErrorString(r)); }
+    // once per communicator set: what RCCL itself says it built (rank count, device of every communicator) -- the line an 8-GPU run's log should carry
+    {   std::string desc; int cnt = 0;
+        for (int d = 0; d < n_phys; ++d) { int c = 0, dev = -1, rk = -1; (void)ncclCommCount(g->comms[d], &c); (void)ncclCommCuDevice(g->comms[d], &dev);
+            (void)ncclCommUserRank(g->comms[d], &rk); cnt = c; char b[48]; snprintf(b, sizeof b, "%s%d@gpu%d", d ? " " : "", rk, dev); desc += b; }
+        fprintf(stderr, "[mon_gather] RCCL communicators over %d GPU(s): ncclCommCount %d, rank@device %s; %d logical rank(s), root rank %d on GPU %d\n", n_phys, cnt,
+                desc.c_str(), n_ranks, root_device, g->root_phys);
+    }
     for (int d = 0; d < n_ranks; ++d) {
         hipError_t e = hipSetDevice(g->rk[d].phys); if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->rk[d].stream, hipStreamNonBlocking);
         if (e != hipSuccess) { mon_gather_destroy(g); return fail(MON_ERR_HIP, "gather_create: stream of rank %d: %s", d, hipGetErrorString(e)); }
@@ -192,7 +199,7 @@ int mon_gather_renders(mon_gather* g, mon_object* const* objects, const mon_fram
                 if (!any) { r = grp.start(); any = true; if (r != ncclSuccess) break; }
                 r = ncclSend(g->rk[d].msg, len[d], ncclFloat, g->root_phys, g->comms[g->rk[d].phys], g->rk[first_rank_of[g->rk[d].phys]].stream);
                 if (r == ncclSuccess) r = ncclRecv(g->recv + recv_off[d], len[d], ncclFloat, g->rk[d].phys, g->comms[g->root_phys], g->rk[g->root].stream);
-                g->bytes_rccl += len[d] * 4; ++g->msgs_rccl;
+                if (r == ncclSuccess) { g->bytes_rccl += len[d] * 4; ++g->msgs_rccl; }      // (counted once both calls were accepted: ADVICE r05)
             }
             if (r == ncclSuccess && any) r = grp.end();
             if (r != ncclSuccess) return fail(MON_ERR_HIP, "gather_renders: RCCL send / receive: %s", ncclGetErrorString(r));

@@ -52,6 +52,27 @@ def test_two_self_spawned_ranks_report_two_gpus_and_gather_both_crops(pkg):
         assert rf["bound"] in ("l2-requests", "hbm") and 0 < rf["frac"] < 1 and rf["avg_launch_ms"] > 0
 
 
+@pytest.mark.gpu
+def test_eight_self_spawned_ranks_run_the_drivers_n8_command_end_to_end(pkg):
+    """The command the driver runs on the 8-GPU node, `python bench.py --gpus 8 ...`, end to end on whatever this box has: eight ranks (one process each;
+    rank r -> device r mod the visible ones, gloo when they have to share a GPU), eight objects trained, eight crops gathered to rank 0, one JSON line
+    whose config says what the collective itself reported -- its world size and backend, and the device every rank trained on."""
+    assert pkg.device_count() >= 1
+    r = _run(["--gpus", "8", "--steps", "4", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline", "--objects-per-gpu", "0", "--views", "8",
+              "--no-sustained", "--no-stress"], timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 8 and j["config"]["objects"] == 8 and j["config"]["ranks_in_collective"] == 8
+    ndev = pkg.device_count()
+    assert j["config"]["collective_backend"] == ("nccl" if ndev >= 8 else "gloo") and j["config"]["visible_devices"] == ndev
+    assert j["config"]["rank_devices"] == [k % ndev for k in range(8)]                      # object k -> rank k -> device k mod nGPU (nerf.cu:27-33)
+    assert len(j["per_rank_ray_samples_per_s"]) == 8 and all(v > 0 for v in j["per_rank_ray_samples_per_s"])
+    assert j["render_gather"] == "ok" and len(j["psnr_db"]) == 8 and all(p > 5.0 for p in j["psnr_db"])
+    B = 4096 * 32
+    assert abs(j["value"] - 8 * B / (1e-3 * j["ms_per_step"])) < 2e-3 * j["value"]
+    assert j["scaling"] == "weak"
+
+
 def test_gpus_flag_without_a_device_fails_loudly():
     """No CPU fallback: without a HIP device the spawner stops with a message instead of printing a line."""
     import __graft_entry__ as ge

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--extra", type=int, default=0)
     ap.add_argument("--log2-hashmap-size", type=int, default=0)
     ap.add_argument("--views", type=int, default=40)
+    ap.add_argument("--occupancy", action="store_true", help="mon_config::occupancy_skip = 1 (opt-in occupancy-grid skipping)")
     ap.add_argument("--objects", type=int, default=1,
             help="K objects trained concurrently, one host thread each (dispatch numbers [K W, K (W + K_steps)) of a kernel are then the window)")
     a = ap.parse_args()
@@ -30,6 +31,8 @@ def main():
     kw = dict(sample_seed=2024)
     if a.log2_hashmap_size:
         kw["log2_hashmap_size"] = a.log2_hashmap_size
+    if a.occupancy:
+        kw["occupancy_skip"] = 1
     import threading
     ds, obj = ge.make_problem(pkg, sc, kw)
     objs = [obj] + [ge.make_problem(pkg, sc, dict(kw, sample_seed=2024 + k), dataset=ds)[1] for k in range(1, a.objects)]

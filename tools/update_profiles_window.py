@@ -13,7 +13,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = ("k_encode_tiles", "k_fused_train", "k_grid_scatter", "k_optimizer")
-WHAT = {"dense": "steps 5..25 from init -- the window `bench.py --gpus 1 --steps 20 --warmup 5` times; every one of the 131 072 samples carries a gradient",
+WHAT = {"sparse_occ": "steps 805..825 from init with occupancy-grid skipping switched on (mon_config::occupancy_skip; opt-in, DESIGN.md 3.4)",
+        "dense": "steps 5..25 from init -- the window `bench.py --gpus 1 --steps 20 --warmup 5` times; every one of the 131 072 samples carries a gradient",
         "sparse": "steps 805..825 from init -- late training; a few per cent of the samples still carry a gradient (DESIGN.md 3.2b)"}
 
 
@@ -49,13 +50,15 @@ def main():
                    "`python tools/profile_window.py` (base.json object, bench scene); hbm bytes = (2*FETCH_SIZE + WRITE_SIZE) KB per MI355X_MICROARCH.md (the FETCH_SIZE correction is "
                    "calibrated for wide streams only; 4-byte gathers are uncalibrated). l2_line_request_rate: distinct-line gather rate measured by tools/run_gatherbench.py "
                    "(266-272 G lines/s chip-wide with every lane on its own line = 128 L2 channels x ~2.1 GHz; profiles/r02_gatherbench.md). SQ_* cycle counters are in quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES."})
-    for k in ("dense", "sparse"):
+    for k in ("dense", "sparse", "sparse_occ"):
         if k in old and isinstance(old[k], dict):
             out[k] = old[k]
     for arg in sys.argv[2:]:
         regime, src = arg.split("=", 1); tag = os.path.basename(src.rstrip("/"))
         kw = open(os.path.join(src, "kernel_window.md")).read(); pw = open(os.path.join(src, "pmc_window.md")).read()
-        v = parse(pw); du = durations(kw); d = {"source": "profiles/%s_window_%s.md (gpurun %s)" % (rnd, regime, tag)}
+        # the sources these numbers were measured on: bench.py recomputes the fingerprint and flags the numbers as stale when it differs (tools/fingerprint.py)
+        sys.path.insert(0, os.path.join(ROOT, "tools")); from fingerprint import kernel_sources_sha16
+        v = parse(pw); du = durations(kw); d = {"source": "profiles/%s_window_%s.md (gpurun %s)" % (rnd, regime, tag), "kernel_sources_sha16": kernel_sources_sha16()}
         for k in KERNELS:
             if (k, "FETCH_SIZE") not in v:
                 continue
@@ -86,7 +89,7 @@ def main():
                      "(tools/rocpd_window.py). The trace's VGPR column counts register pairs (x2 = the compiler's .vgpr_count).\n\n## Durations\n\n%s\n## Counters\n\nFETCH_SIZE / WRITE_SIZE in KB; TCC_* / TCP_* in requests; "
                      "SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* in quad-cycles summed over waves; SQ_BUSY_CYCLES summed over the 32 shader engines; SQ_LDS_* in LDS-array cycles summed over CUs; GRBM_GUI_ACTIVE summed over the 8 XCDs.\n\n%s\n"
                      "## Derived (also in profiles/pmc_traffic.json)\n\n```\n%s\n```\n" % (rnd, regime, WHAT.get(regime, regime),
-                             " --extra 800" if regime == "sparse" else "", tag,
+                             (" --extra 800" if regime.startswith("sparse") else "") + (" --occupancy" if regime.endswith("_occ") else ""), tag,
                                                                                            kw.split("\n\n", 1)[-1], pw.split("\n\n", 1)[-1], json.dumps(d,
                                                                                                    indent=1)))
     json.dump(out, open(pj_path, "w"), indent=1)
