@@ -191,7 +191,7 @@ def main():
     # distance 4 + network output w+r 16 + dL/dO w+r 16 + distance re-read 4 (forward/backward), gradient scatter read-modify-write 64*L of the samples that
     # carry a gradient (scatter); per step 40 B per parameter (optimizer: fp16 gradient, fp32 Adam moments + master r/w, step counter r/w, fp16 copy, EMA r/w).
     step_ms = 1e3 * dt / args.steps
-    opt_bpp = 38 if pkg.get_option("steps16") else 40      # 16-bit saturating step counters (exact for base.json's betas) read + write 2 B instead of 4 B each
+    opt_bpp = 38      # 16-bit saturating step counters (exact for base.json's betas; 32-bit ones are a variant build) read + write 2 B instead of 4 B each
     if fused:
         enc_ms = avg(6) + avg(7)
         kern = [("k_encode_tiles", enc_ms, (12 + 32 * L) * B,

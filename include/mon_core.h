@@ -195,6 +195,9 @@ int mon_object_destroy(mon_object* obj);
 typedef struct mon_offline mon_offline;
 int mon_offline_create(const char* dataset_path, const char* network_config_file, int use_dense_depth, mon_offline** out);
 int mon_offline_init(mon_offline* mgr);                                   /* Init()            */
+/* The offline training schedule, process-wide, read by mon_offline_init: `outer` Train_Step calls of `inner` iterations per object (the reference hard-codes
+ * 10 x 500: nerf_manager.cu:89, nerf_model.cu:1635; a mesh every 2nd outer step).  Both >= 1. */
+int mon_offline_set_schedule(int outer, int inner);
 int mon_offline_read_dataset(mon_offline* mgr);                           /* ReadDataset()     */
 int mon_offline_create_nerf(mon_offline* mgr, const char* object_file);   /* CreateNeRF(file): starts the object's training thread */
 int mon_offline_wait_threads_end(mon_offline* mgr);                       /* WaitThreadsEnd()  */
@@ -259,18 +262,19 @@ int mon_write_render_pngs(const char* img_path, const char* depth_path, const ch
         const float* mask);
 
 /* Process-wide test and tuning switches (none is needed for normal operation; defaults are the product behaviour).  Read when an object is
- * created or a training call is enqueued -- set them before.  Names: "backend" (-1 auto, 0 layer-at-a-time kernels, 1 fused), "use_graph" (replay
- * an iteration as a hipGraph), "lazy_ema" (-1 auto: tables above 8 M parameters), "big_switch" (gradient-carrying samples below which the
- * large-table levels scatter with global atomics; 0 = always), "touched_flags" (1 = on: the lazy optimizer's chunk flags), "lds_encode" (1 = on: the forward
- * hash-grid encode from LDS-resident level tiles, kernels_encode.hip; 0 = gathers inside k_fused_train -- both give bit-identical parameters),
- * "step_variant" (1: NeRF_Model::Step's sample-compaction schedule, nerf_model.cu:1504-1550, on the layer-at-a-time kernels -- the reference's own
- * "unavailable, for
- * reference only" path, kept checkable; 0 = Step_No_Compacted, what both drivers train with), "roctx" (1: roctx ranges per phase), "tile_render"
- * (inference on feature-planar level tiles: 0 never, 1 crops of 4096 rays and more + point queries, 2 always), "state_records" (1 = on: tables above
- * 8 M parameters keep their optimizer state as 128-byte chunk records), "steps16" (1 = on: 16-bit per-chunk step counters of the lazy optimizer),
- * "keep_zero_samples" (1: zero-gradient samples are scattered too -- the exactness test's A/B), "train_lanes" / "lane_chunk" (per-device training lanes),
- * "online_slice_min" (shortest training slice of the online manager), "offline_outer" / "offline_inner" (NerfManagerOffline's 10 x 500 iterations,
- * nerf_manager.cu:89).
+ * created or a training call is enqueued -- set them before.  Nine names (round 6; the A/B switches whose losing setting only a measurement wanted --
+ * record / array optimizer state, 16- / 32-bit step counters, chunk flags, lane chunk, slice length -- are variant builds now, model.h):
+ *   "backend"            -1 auto, 0 layer-at-a-time kernels, 1 fused
+ *   "use_graph"          1: replay an iteration pair as a hipGraph
+ *   "big_switch"         gradient-carrying samples below which the large-table levels scatter with global atomics (0 = always atomics, 1 = always binned)
+ *   "lds_encode"         forward hash-grid encode from LDS-resident level tiles (kernels_encode.hip): 1 = from 3072 rays per batch (default), 2 = always,
+ *                        0 = never (gathers inside k_fused_train) -- bit-identical parameters either way
+ *   "tile_render"        inference on feature-planar level tiles: 0 never, 1 crops of 4096 rays and more + point queries, 2 always -- bit-identical images
+ *   "step_variant"       1: NeRF_Model::Step's sample-compaction schedule (nerf_model.cu:1504-1550) on the layer-at-a-time kernels -- the reference's own
+ *                        "unavailable, for reference only" path, kept checkable; 0 = Step_No_Compacted, what both drivers train with
+ *   "keep_zero_samples"  1: zero-gradient samples are scattered too -- the exactness test's A/B
+ *   "train_lanes"        per-device training lanes (0 = every object on its own stream)
+ *   "roctx"              1: roctx ranges per phase
  * Unknown names return MON_ERR_ARG. */
 int mon_set_option(const char* name, long value);
 int mon_get_option(const char* name, long* value);

@@ -45,6 +45,7 @@ _SIGS = {
     "mon_version": (C.c_int, []),
     "mon_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "mon_set_logical_devices": (C.c_int, [C.c_int]),
+    "mon_offline_set_schedule": (C.c_int, [C.c_int, C.c_int]),
     "mon_set_option": (C.c_int, [C.c_char_p, C.c_long]),
     "mon_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_long)]),
     "mon_config_default": (C.c_int, [C.POINTER(MonConfig)]),
@@ -260,7 +261,11 @@ def lib():
         _lib = L
         # harness convenience (tools / tests that run in a subprocess): MON_OPTIONS="name=value,..." -> mon_set_option calls
         for kv in filter(None, os.environ.get("MON_OPTIONS", "").split(",")):
-            k, v = kv.split("="); rc = L.mon_set_option(k.strip().encode(), int(v))
+            k, v = kv.split("=")
+            if k.strip() == "offline_schedule":          # "offline_schedule=OUTERxINNER"
+                o, i = v.lower().split("x"); rc = L.mon_offline_set_schedule(int(o), int(i))
+            else:
+                rc = L.mon_set_option(k.strip().encode(), int(v))
             if rc != 0:
                 raise MonError(rc, L.mon_last_error().decode("utf-8", "replace"))
     return _lib
@@ -314,6 +319,11 @@ def device_count():
     n = C.c_int(0)
     rc = lib().mon_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+def set_offline_schedule(outer=10, inner=500):
+    """NerfManagerOffline's outer x inner training iterations per object (reference: 10 x 500), read by Offline.init."""
+    _check(lib().mon_offline_set_schedule(int(outer), int(inner)))
 
 
 def set_logical_devices(n):

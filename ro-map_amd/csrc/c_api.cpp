@@ -46,6 +46,10 @@ const char* mon_last_error(void) { return last_error(); }
 int mon_version(void) { return 100; }
 int mon_device_count(int* n) { REQUIRE(n, "n_devices"); return device_count(n); }
 int mon_set_logical_devices(int n) { return set_logical_devices(n); }
+int mon_offline_set_schedule(int outer, int inner) {
+    if (outer < 1 || inner < 1) { set_error("offline_set_schedule: %d x %d", outer, inner); return MON_ERR_ARG; }
+    options().offline_outer = outer; options().offline_inner = inner; return MON_OK;
+}
 int mon_set_option(const char* name, long value) { return option_set(name, value); }
 int mon_get_option(const char* name, long* value) { return option_get(name, value); }
 int mon_config_default(mon_config* cfg) { REQUIRE(cfg, "cfg"); config_default(*cfg); return MON_OK; }

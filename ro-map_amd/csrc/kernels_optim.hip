@@ -61,19 +61,21 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
     const uint32_t n_extra = nx.cand_blocks + nx.pos_blocks, n_opt = gridDim.x - n_extra, vblock = blockIdx.x < n_opt ? blockIdx.x + n_extra
             : blockIdx.x - n_opt;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const uint32_t step_cap = (p.steps16 || p.rec) ? 65535u : 0xffffffffu;
+    // (chunk records exist for the lazy optimizer of large tables only: compile-time null in the dense instantiations, whose record branches fold away)
+    float* const prec = LAZY ? p.rec : nullptr;
+    const uint32_t step_cap = (p.steps16 || prec) ? 65535u : 0xffffffffu;
     // where a chunk's optimizer state lives: the four SoA arrays, or (large tables, ParamPtrs::rec) ONE 128-byte record per chunk -- master | m1 | m2 | step
     // counters -- so that a touched chunk among untouched ones costs one full line instead of four half-used 64-byte sectors
-    auto st_master = [&](uint32_t c) -> float* { return p.rec ? p.rec + 32u * (size_t)c : p.master + 8u * (size_t)c; };
-    auto st_m1 = [&](uint32_t c) -> float* { return p.rec ? p.rec + 32u * (size_t)c + 8u : p.m1 + 8u * (size_t)c; };
-    auto st_m2 = [&](uint32_t c) -> float* { return p.rec ? p.rec + 32u * (size_t)c + 16u : p.m2 + 8u * (size_t)c; };
-    auto st_steps16 = [&](uint32_t c) -> uint16_t* { return p.rec ? reinterpret_cast<uint16_t*>(p.rec + 32u * (size_t)c + 24u) : p.steps16 + 8u * (size_t)c; };
+    auto st_master = [&](uint32_t c) -> float* { return prec ? prec + 32u * (size_t)c : p.master + 8u * (size_t)c; };
+    auto st_m1 = [&](uint32_t c) -> float* { return prec ? prec + 32u * (size_t)c + 8u : p.m1 + 8u * (size_t)c; };
+    auto st_m2 = [&](uint32_t c) -> float* { return prec ? prec + 32u * (size_t)c + 16u : p.m2 + 8u * (size_t)c; };
+    auto st_steps16 = [&](uint32_t c) -> uint16_t* { return prec ? reinterpret_cast<uint16_t*>(prec + 32u * (size_t)c + 24u) : p.steps16 + 8u * (size_t)c; };
     // lazy EMA: the optimizer step a chunk's EMA is current for -- in the chunk record's pad word (the same 128-byte line as the state: late in training a touched
     // chunk's own 64-byte line of a separate array was a seventh of what the kernel moved), or in the array
-    auto ema_step_of = [&](uint32_t c) -> uint32_t* { return p.rec ? reinterpret_cast<uint32_t*>(p.rec + 32u * (size_t)c + 28u) : p.ema_step + c; };
+    auto ema_step_of = [&](uint32_t c) -> uint32_t* { return prec ? reinterpret_cast<uint32_t*>(prec + 32u * (size_t)c + 28u) : p.ema_step + c; };
     // a chunk's eight step counters: two 16-byte loads of uint32, or ONE of eight uint16 (4 B per parameter less to read and to write back)
     auto load_steps = [&](uint32_t i0, u32x4& s0, u32x4& s1) __attribute__((always_inline)) {
-        if (p.steps16 || p.rec) { const u32x4 v = *reinterpret_cast<const u32x4*>(st_steps16(i0 >> 3));
+        if (p.steps16 || prec) { const u32x4 v = *reinterpret_cast<const u32x4*>(st_steps16(i0 >> 3));
             s0 = u32x4{ v[0] & 0xffffu, v[0] >> 16, v[1] & 0xffffu, v[1] >> 16 }; s1 = u32x4{ v[2] & 0xffffu, v[2] >> 16, v[3] & 0xffffu, v[3] >> 16 }; }
         else { s0 = *reinterpret_cast<const u32x4*>(p.steps + i0); s1 = *reinterpret_cast<const u32x4*>(p.steps + i0 + 4); }
     };
@@ -292,7 +294,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                 state_store<!LAZY>(float4_t{ m2[0], m2[1], m2[2], m2[3] }, reinterpret_cast<float4_t*>(st_m2(c)));
                 state_store<!LAZY>(float4_t{ m2[4], m2[5], m2[6], m2[7] }, reinterpret_cast<float4_t*>(st_m2(c) + 4));
                 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-                if (p.steps16 || p.rec) state_store<!LAZY>(u4v{ sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16), sc[4] | (sc[5] << 16), sc[6] | (sc[7] << 16) },
+                if (p.steps16 || prec) state_store<!LAZY>(u4v{ sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16), sc[4] | (sc[5] << 16), sc[6] | (sc[7] << 16) },
                         reinterpret_cast<u4v*>(st_steps16(c)));
                 else { state_store<!LAZY>(u4v{ sc[0], sc[1], sc[2], sc[3] }, reinterpret_cast<u4v*>(p.steps + i0));
                     state_store<!LAZY>(u4v{ sc[4], sc[5], sc[6], sc[7] }, reinterpret_cast<u4v*>(p.steps + i0 + 4)); }
@@ -441,7 +443,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
                 state_store<false>(float4_t{ m2[0], m2[1], m2[2], m2[3] }, reinterpret_cast<float4_t*>(st_m2(c)));
                 state_store<false>(float4_t{ m2[4], m2[5], m2[6], m2[7] }, reinterpret_cast<float4_t*>(st_m2(c) + 4));
                 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-                if (p.steps16 || p.rec) state_store<false>(u4v{ sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16), sc[4] | (sc[5] << 16), sc[6] | (sc[7] << 16) },
+                if (p.steps16 || prec) state_store<false>(u4v{ sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16), sc[4] | (sc[5] << 16), sc[6] | (sc[7] << 16) },
                         reinterpret_cast<u4v*>(st_steps16(c)));
                 else { state_store<false>(u4v{ sc[0], sc[1], sc[2], sc[3] }, reinterpret_cast<u4v*>(p.steps + i0));
                     state_store<false>(u4v{ sc[4], sc[5], sc[6], sc[7] }, reinterpret_cast<u4v*>(p.steps + i0 + 4)); }

@@ -405,7 +405,7 @@ static int train_sliced(OnlineObject* o) {
     for (int done = 0; done < o->iterations && rc == MON_OK; ) {
         while (o->waiters.load() > 0) std::this_thread::yield();
         const int sharing = o->device_objects ? o->device_objects->load() : 1;
-        int n = kOnlineSlice / (sharing > 0 ? sharing : 1); const long slice_min = options().online_slice_min;
+        int n = kOnlineSlice / (sharing > 0 ? sharing : 1); const long slice_min = kOnlineSliceMin;
         const int n_min = slice_min > 0 ? (int)slice_min : 2; if (n < n_min) n = n_min; if (n > o->iterations - done) n = o->iterations - done;
         std::unique_lock<std::mutex> dl(*o->dataset_mutex); std::lock_guard<std::mutex> lm(o->mu_model);
         rc = model_train(*o->model, n, &o->last_loss, 7); done += n;

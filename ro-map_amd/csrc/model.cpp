@@ -37,12 +37,9 @@ static Options g_options;
 Options& options() { return g_options; }
 static std::atomic<long>* option_slot(const char* name) {
     static const struct { const char* n; std::atomic<long> Options::*f; } tab[] = {
-        { "backend", &Options::backend }, { "use_graph", &Options::use_graph }, { "lazy_ema", &Options::lazy_ema }, { "big_switch", &Options::big_switch },
-        { "touched_flags", &Options::touched_flags }, { "lds_encode", &Options::lds_encode }, { "roctx", &Options::roctx },
-        { "step_variant", &Options::step_variant }, { "steps16", &Options::steps16 }, { "keep_zero_samples", &Options::keep_zero_samples },
-        { "train_lanes", &Options::train_lanes }, { "lane_chunk", &Options::lane_chunk }, { "online_slice_min", &Options::online_slice_min },
-        { "offline_outer", &Options::offline_outer }, { "offline_inner", &Options::offline_inner },
-        { "tile_render", &Options::tile_render }, { "state_records", &Options::state_records },
+        { "backend", &Options::backend }, { "use_graph", &Options::use_graph }, { "big_switch", &Options::big_switch }, { "lds_encode", &Options::lds_encode },
+        { "roctx", &Options::roctx }, { "step_variant", &Options::step_variant }, { "keep_zero_samples", &Options::keep_zero_samples },
+        { "train_lanes", &Options::train_lanes }, { "tile_render", &Options::tile_render },
 #ifdef MON_OVERLAP_PROBE
         { "overlap", &Options::overlap }, { "enc_lds_kb", &Options::enc_lds_kb },
 #endif
@@ -481,15 +478,14 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     // ---- parameters (ResetNetwork :1286-1342; Trainer init)
     const size_t n = m.n_params;
     // per-parameter step counters in 16 bits, saturating, where that is EXACT: 1 - beta^t == 1.0f (beta^t < 2^-25) for every t >= 65535 and both betas
-    // (option steps16 = 0: always 32 bits).  The device evaluates 1 - exp2f(t * log2(beta)) in fp32; the host test runs in double, so it keeps a
+    // (variant build MON_VARIANT_STEPS32: always 32 bits).  The device evaluates 1 - exp2f(t * log2(beta)) in fp32; the host test runs in double, so it keeps a
     // margin of four binades (beta^65535 < 2^-29, i.e. beta <= 0.99969) instead of sitting on the rounding boundary.
     const double kSteps16Bound = std::ldexp(1.0, -29);
-    const bool steps16 = options().steps16 != 0 && std::pow((double)cfg.beta1, 65535.0) < kSteps16Bound && std::pow((double)cfg.beta2, 65535.0) < kSteps16Bound;
-    // lazy EMA: only where the optimizer is not the dense variant anyway and the table is large (> 8 M parameters); option lazy_ema = 0 / 1 overrides
+    const bool steps16 = kSteps16 && std::pow((double)cfg.beta1, 65535.0) < kSteps16Bound && std::pow((double)cfg.beta2, 65535.0) < kSteps16Bound;
+    // lazy EMA: only where the optimizer is not the dense variant anyway and the table is large (> 8 M parameters)
     m.lazy_ema = m.n_grid > (8u << 20);
-    if (options().lazy_ema >= 0) m.lazy_ema = options().lazy_ema != 0;
     // large tables (lazy EMA, 16-bit step counters): the optimizer state as one 128-byte record per chunk (ParamPtrs::rec) instead of four arrays
-    const bool records = m.lazy_ema && steps16 && options().state_records != 0 && (n & 7u) == 0u;
+    const bool records = m.lazy_ema && steps16 && kStateRecords && (n & 7u) == 0u;
     if (records) { if ((rc = dev_alloc(m, m.P.rec, 4 * n))) return rc; }
     else if ((rc = dev_alloc(m, m.P.master, n, false)) || (rc = dev_alloc(m, m.P.m1, n)) || (rc = dev_alloc(m, m.P.m2, n)) ||
              (rc = steps16 ? dev_alloc(m, m.P.steps16, n + 8) : dev_alloc(m, m.P.steps, n))) return rc;
@@ -572,7 +568,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
             encode_tiles_setup_device();
         }
         // chunk flags for the lazy optimizer (tables above 8 M parameters with levels outside the LDS plan); MON_TOUCHED_FLAGS=0: scan the gradient table
-        const bool flags_on = options().touched_flags != 0;
+        const bool flags_on = kTouchedFlags;
         if (flags_on && m.lazy_ema && m.lds_mask && m.lds_mask != ((m.nd.L >= 32) ? 0xffffffffu : ((1u << m.nd.L) - 1u))
                 && (rc = dev_alloc(m, m.d_touched, (m.n_params >> 3) + 16))) return rc;
     }
@@ -1006,7 +1002,7 @@ int model_train(Model& m, int iters, float* loss, int stages) {
     const bool use_graph = use_graph_env && !m.profiling && stages == 7 && iters >= 2 && !(m.d_occ && !m.occ_refreshed_iter) && !m.d_xw;
     // chunks of iterations go through the device's training lanes (whole steps only; big-table objects are HBM-bound in their optimizer and gain from more
     // overlap, not less)
-    const bool lanes_on = stages == 7 && m.big_switch == 0u; const int chunk = options().lane_chunk >= 2 ? (options().lane_chunk & ~1) : 2;
+    const bool lanes_on = stages == 7 && m.big_switch == 0u; const int chunk = kLaneChunk;
     if (use_graph) {
         // (the last bit: which forward chain the captured pair runs)
         const int graph_key = m.backend | (m.big_active ? 256 : 0) | (m.occ_refreshed_iter ? 512 : 0)

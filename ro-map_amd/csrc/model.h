@@ -163,15 +163,37 @@ enum {
 
 // Process-wide test and tuning switches (mon_set_option, include/mon_core.h); defaults are the product behaviour.
 struct Options {      // (atomics: tests and tools flip options while object threads read them)
-    std::atomic<long> backend{ -1 }, use_graph{ 0 }, lazy_ema{ -1 }, big_switch{ 16384 }, touched_flags{ 1 }, lds_encode{ 1 }, offline_outer{ 10 },
-         offline_inner{ 500 }, train_lanes{ 2 }, lane_chunk{ 16 }, online_slice_min{ 2 }, roctx{ 0 }, step_variant{ 0 }, steps16{ 1 },
+    std::atomic<long> backend{ -1 }, use_graph{ 0 }, big_switch{ 16384 }, lds_encode{ 1 }, train_lanes{ 2 }, roctx{ 0 }, step_variant{ 0 },
          keep_zero_samples{ 0 },   // 1: k_fused_train hands zero-gradient samples to the scatter too (the exactness test's A/B; same parameters, slower)
-         state_records{ 1 },    // tables above 8 M parameters keep their optimizer state as 128-byte chunk records (ParamPtrs::rec); 0: the four arrays
          tile_render{ 1 };      // inference on feature-planar level tiles: 0 never (gathers), 1 crops of 4096 rays and more + point queries, 2 always
+    // NerfManagerOffline's 10 x 500 iterations (nerf_manager.cu:89): mon_offline_set_schedule, read by mon_offline_init
+    std::atomic<long> offline_outer{ 10 }, offline_inner{ 500 };
 #ifdef MON_OVERLAP_PROBE        // variant build only (tools/variant_build.sh ovl -DMON_OVERLAP_PROBE): k_optimizer(i) next to a throw-away k_encode_tiles
     std::atomic<long> overlap{ 0 }, enc_lds_kb{ 0 };
 #endif
 };
+// Round 6: the A/B switches whose losing setting only a measurement ever wanted are VARIANT BUILDS now (tools/variant_build.sh <tag> -DMON_VARIANT_...; the
+// oracle tests of the large-table optimizer run against each, tools/gpu_variants_large.sh), not runtime options of the shipping library:
+//   MON_VARIANT_STEPS32   per-parameter step counters always 32 bits (shipping: saturating 16-bit ones where that is exact)
+//   MON_VARIANT_ARRAYS    tables above 8 M parameters keep master / m1 / m2 / steps as four arrays (shipping: 128-byte chunk records)
+//   MON_VARIANT_NO_FLAGS  the lazy optimizer finds touched chunks by scanning the gradient table (shipping: byte flags next to it)
+#ifdef MON_VARIANT_STEPS32
+constexpr bool kSteps16 = false;
+#else
+constexpr bool kSteps16 = true;
+#endif
+#ifdef MON_VARIANT_ARRAYS
+constexpr bool kStateRecords = false;
+#else
+constexpr bool kStateRecords = true;
+#endif
+#ifdef MON_VARIANT_NO_FLAGS
+constexpr bool kTouchedFlags = false;
+#else
+constexpr bool kTouchedFlags = true;
+#endif
+constexpr int kLaneChunk = 16;          // iterations an object enqueues per turn on a training lane (measured best)
+constexpr long kOnlineSliceMin = 2;     // shortest training slice of the online manager (iterations)
 Options& options();
 int option_set(const char* name, long value);
 int option_get(const char* name, long* value);

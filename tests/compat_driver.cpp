@@ -142,8 +142,11 @@ static void apply_options_from_env() {
     const char* e = std::getenv("MON_OPTIONS"); if (!e) return;
     std::stringstream ss(e); std::string kv;
     while (std::getline(ss, kv, ',')) { const size_t q = kv.find('=');
-        if (q != std::string::npos && mon_set_option(kv.substr(0, q).c_str(), std::atol(kv.c_str() + q + 1))) { std::cerr << mon_last_error() << std::endl;
-            exit(6); } }
+        if (q == std::string::npos) continue;
+        int rc;
+        if (kv.substr(0, q) == "offline_schedule") { int o = 0, i = 0; rc = std::sscanf(kv.c_str() + q + 1, "%dx%d", &o, &i) == 2 ? mon_offline_set_schedule(o, i) : 1; }
+        else rc = mon_set_option(kv.substr(0, q).c_str(), std::atol(kv.c_str() + q + 1));
+        if (rc) { std::cerr << mon_last_error() << std::endl; exit(6); } }
 }
 
 int main(int argc, char** argv) {

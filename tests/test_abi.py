@@ -199,9 +199,19 @@ def test_diagnostics_live_in_their_own_library(pkg):
 
 def test_options_are_an_explicit_interface(pkg):
     """Test and tuning switches go through mon_set_option / mon_get_option; the product library reads no environment variables."""
-    assert pkg.get_option("big_switch") == 16384 and pkg.get_option("backend") == -1 and pkg.get_option("offline_inner") == 500
-    # the per-device scheduler's defaults
-    assert pkg.get_option("train_lanes") == 2 and pkg.get_option("lane_chunk") == 16 and pkg.get_option("online_slice_min") == 2
+    assert pkg.get_option("big_switch") == 16384 and pkg.get_option("backend") == -1 and pkg.get_option("train_lanes") == 2
     pkg.set_option("keep_zero_samples", 1); assert pkg.get_option("keep_zero_samples") == 1; pkg.set_option("keep_zero_samples", 0)
     with pytest.raises(pkg.MonError):
         pkg.set_option("no_such_switch", 1)
+    # round 6: nine names, each documented in include/mon_core.h; the A/B switches whose losing setting only a measurement wanted are variant builds
+    names = ("backend", "use_graph", "big_switch", "lds_encode", "tile_render", "step_variant", "keep_zero_samples", "train_lanes", "roctx")
+    hdr = open(os.path.join(ROOT, "include", "mon_core.h")).read()
+    for n in names:
+        pkg.get_option(n); assert '"%s"' % n in hdr, n
+    for retired in ("steps16", "state_records", "touched_flags", "lazy_ema", "lane_chunk", "online_slice_min", "offline_outer", "offline_inner"):
+        with pytest.raises(pkg.MonError):
+            pkg.get_option(retired)
+    # the offline schedule is an API call of its own (reference: 10 x 500, nerf_manager.cu:89)
+    pkg.set_offline_schedule(3, 40); pkg.set_offline_schedule(10, 500)
+    with pytest.raises(pkg.MonError):
+        pkg.set_offline_schedule(0, 500)

@@ -192,7 +192,7 @@ def test_object_placement_over_logical_devices(pkg, ss, tmp_path):
     assert pkg.device_count() >= 1
     sc = ss.make_scene(n_views=10, H=120, W=160, f=130.0, n_objects=3, seed=4)
     seq = str(tmp_path / "seq"); ss.write_sequence(sc, seq)
-    pkg.set_option("offline_outer", 2); pkg.set_option("offline_inner", 60)
+    pkg.set_offline_schedule(2, 60)
     pkg.set_logical_devices(2)
     try:
         assert pkg.device_count() == 2
@@ -209,7 +209,7 @@ def test_object_placement_over_logical_devices(pkg, ss, tmp_path):
             assert os.path.exists(os.path.join(str(tmp_path / "out"), "%d.ply" % k))
         m.close()
     finally:
-        pkg.set_logical_devices(0); pkg.set_option("offline_outer", 10); pkg.set_option("offline_inner", 500)
+        pkg.set_logical_devices(0); pkg.set_offline_schedule(10, 500)
     assert pkg.device_count() >= 1
 
 
@@ -220,7 +220,7 @@ def test_configs2_shape_eight_objects_on_eight_logical_devices_with_the_gathered
     assert pkg.device_count() >= 1
     sc = ss.make_scene(n_views=16, H=240, W=320, f=260.0, n_objects=8, seed=21)
     seq = str(tmp_path / "seq"); ss.write_sequence(sc, seq)
-    pkg.set_option("offline_outer", 2); pkg.set_option("offline_inner", 100); pkg.set_logical_devices(8)
+    pkg.set_offline_schedule(2, 100); pkg.set_logical_devices(8)
     try:
         assert pkg.device_count() == 8
         m = pkg.OfflineManager(seq, os.path.join(ROOT, "ro-map_amd", "configs", "base.json")); m.set_output_dir(str(tmp_path / "out")); m.init(); m.read_dataset()
@@ -244,7 +244,7 @@ def test_configs2_shape_eight_objects_on_eight_logical_devices_with_the_gathered
         assert n == 8 * (3 * 2 + 1)                                                  # two views x (img, depth, mask) + obj.ply per object
         m.close()
     finally:
-        pkg.set_logical_devices(0); pkg.set_option("offline_outer", 10); pkg.set_option("offline_inner", 500)
+        pkg.set_logical_devices(0); pkg.set_offline_schedule(10, 500)
 
 
 def test_objects_come_and_go_while_others_train(pkg):

@@ -53,7 +53,7 @@ def test_shim_runs_the_offline_and_online_call_sequences(pkg, ss, tmp_path):
     sc = ss.make_scene(n_views=24, H=120, W=160, f=130.0, n_objects=2, seed=9)
     seq = str(tmp_path / "seq"); ss.write_sequence(sc, seq)
     cfg = os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json")
-    env = dict(os.environ, MON_OPTIONS="offline_outer=4,offline_inner=150")
+    env = dict(os.environ, MON_OPTIONS="offline_schedule=4x150")
     out = str(tmp_path / "out_offline")
     r = subprocess.run([exe, "offline", seq, cfg, out], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr

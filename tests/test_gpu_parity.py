@@ -680,10 +680,6 @@ def test_binned_large_level_scatter_is_exact_and_deterministic(pkg, orc, small_s
         return [ln.split()[2] for ln in r.stdout.strip().split("\n") if ln.startswith("steps+")]
     a = run({"MON_OPTIONS": "big_switch=1"}); b = run({"MON_OPTIONS": "big_switch=1"})
     assert a == b and len(a) == 2, (a, b)
-    # the lazy optimizer finds the touched chunks through the byte flags written next to the gradient table; scanning the table itself
-    # (option touched_flags = 0) must train the same parameters bit for bit
-    c = run({"MON_OPTIONS": "big_switch=1,touched_flags=0"})
-    assert a == c, (a, c)
 
 
 def test_atomic_path_marks_every_touched_chunk(pkg, small_scene, monkeypatch):
@@ -776,31 +772,6 @@ def test_lazy_ema_matches_eager_on_large_tables(pkg, small_scene):
     obj.close(); ds.close()
 
 
-def test_optimizer_state_records_train_exactly_like_the_arrays(pkg, small_scene):
-    """Tables above 8 M parameters keep master / m1 / m2 / step counters as one 128-byte record per 8-parameter chunk (ParamPtrs::rec) instead of four arrays
-    (option state_records = 0): a layout change only.  With the binned large-level scatter (deterministic) both must leave bit-identical weights, Adam
-    moments, step counters and EMA, also through set_params / get_params, which translate between the records and the flat arrays of the boundary."""
-    _need_gpu(pkg)
-    import zlib
-    kw = dict(rays_per_batch=1024, log2_hashmap_size=20, n_levels=8, per_level_scale=2.0, n_neurons=32, n_hidden_layers=2)
-    res = []
-    old_bs = pkg.get_option("big_switch"); pkg.set_option("big_switch", 1)        # always binned: no global-atomic arrival order in the comparison
-    try:
-        for rec in (1, 0):
-            pkg.set_option("state_records", rec)
-            ds, obj = ge.make_problem(pkg, small_scene, kw); obj.set_backend(1)
-            assert obj.info().n_grid_params > (8 << 20)
-            p0 = obj.get_params(0); p0[obj.info().n_mlp_params::7] *= 1.5; obj.set_params(p0)      # through the boundary once
-            assert np.array_equal(obj.get_params(0), p0)
-            obj.train(12)
-            res.append([zlib.crc32(obj.get_params(w).tobytes()) for w in (0, 1, 2)] + [zlib.crc32(obj.buffer(b).tobytes()) for b in ("m1", "m2", "steps")])
-            assert np.array_equal(obj.buffer("master"), obj.get_params(0)) and int(obj.buffer("steps").max()) >= 1
-            obj.close(); ds.close()
-    finally:
-        pkg.set_option("state_records", 1); pkg.set_option("big_switch", old_bs)
-    assert res[0] == res[1], res
-
-
 LARGE = {"T19": dict(rays_per_batch=256, log2_hashmap_size=19, n_neurons=64, n_hidden_layers=1),
          "T20L8": dict(rays_per_batch=256, log2_hashmap_size=20, n_levels=8, per_level_scale=2.0, n_neurons=32, n_hidden_layers=2)}
 
@@ -814,23 +785,21 @@ def _ulp16(x):
 def test_large_table_optimizer_matches_oracle(pkg, orc, small_scene, name):
     """Tables above 8 M parameters (BASELINE configs[4]'s regime) run k_optimizer<false, true>: untouched chunks are skipped altogether (lazy EMA, closed-form
     catch-up), the state sits in 128-byte chunk records, touched chunks are found through byte flags, step counters are 16-bit.  Three WHOLE steps on both
-    sides from the pattern parameters, binned scatter (deterministic), in every records / flags / 16-bit-counter combination -- against the ORACLE's
+    sides from the pattern parameters, binned scatter (deterministic) -- the shipping build here; the variant builds that keep the four state arrays, 32-bit
+    counters or scan the gradient table instead of flags run the same test through tools/gpu_variants_large.sh (profiles/r06_variants.md) -- against the ORACLE's
     Trainer::optimizer_step (tcnn's rule, nerf_model.cu:1644: zero-gradient grid entries untouched, per-parameter bias correction, debiased EMA of every
     parameter every step), with the bars of the base-size step tests.  Entries that never saw a gradient must still hold the pattern bit for bit, with empty
     Adam state, and their lazily caught-up EMA must equal the oracle's eager step-by-step one."""
-    import itertools
     _need_gpu(pkg)
     kw = LARGE[name]
     ref = ge.make_oracle(orc, small_scene, kw); p = pattern_params(ref); ref.set_params(p)
     for _ in range(3):
         ref.train(1)
     nm = ref.n_mlp; want = {b: ref.buffer(b) for b in ("master", "half", "ema", "m1", "m2", "steps")}; loss_ref = ref.loss; ref.close()
-    names = ("state_records", "touched_flags", "steps16", "big_switch"); old = {n: pkg.get_option(n) for n in names}
+    old = {"big_switch": pkg.get_option("big_switch")}
     try:
         pkg.set_option("big_switch", 1)
-        for combo in itertools.product((1, 0), (1, 0), (1, 0)):
-            for n, v in zip(names, combo):
-                pkg.set_option(n, v)
+        for combo in (("shipping",),):
             ds, obj = ge.make_problem(pkg, small_scene, kw); obj.set_backend(1)
             assert obj.info().n_grid_params > (8 << 20)
             obj.set_params(p)
@@ -866,18 +835,19 @@ def test_large_table_optimizer_matches_oracle(pkg, orc, small_scene, name):
             pkg.set_option(n, v)
 
 
-@pytest.mark.parametrize("variant", ["default", "binned-arrays"])
+@pytest.mark.parametrize("variant", ["default", "binned"])
 def test_large_table_optimizer_follows_the_oracle_over_30_steps_on_its_own_gradients(pkg, orc, small_scene, variant):
     """The large-table optimizer over a 30-step run, judged by the ORACLE's optimizer instead of a NumPy recurrence: every step the device's own gradients
     (fp32 MLP gradient; grid gradient = gradient table + partial tables as k_optimizer sums them) are handed to the oracle's Trainer::optimizer_step, so both
     sides integrate the SAME gradient sequence and the comparison is free of the training trajectory's chaos and of the arrival order of the fine levels'
     atomics: master weights, both Adam moments and the per-parameter step counters must agree to fp32 rounding after 1, 2, 5 and 30 steps, the fp16 copy up to
     rounding-boundary flips, and the LAZILY maintained EMA (chunks catch up in closed form when they are touched again or the inference weights are read)
-    must equal the oracle's eager every-parameter-every-step EMA.  `default`: the shipping options (records, flags, 16-bit counters, binned -> atomic switch);
-    `binned-arrays`: every switch the other way, with the inference weights also read in the middle of the run (finalize, then train on)."""
+    must equal the oracle's eager every-parameter-every-step EMA.  `default`: the shipping library (records, flags, 16-bit counters, binned -> atomic switch);
+    `binned`: the binned scatter throughout, with the inference weights also read in the middle of the run (finalize, then train on).  The variant builds
+    (arrays / 32-bit counters / no flags) run both through tools/gpu_variants_large.sh."""
     _need_gpu(pkg)
     kw = dict(rays_per_batch=512, log2_hashmap_size=19)
-    opts = {} if variant == "default" else dict(state_records=0, touched_flags=0, steps16=0, big_switch=1)
+    opts = {} if variant == "default" else dict(big_switch=1)
     old = {n: pkg.get_option(n) for n in opts}
     try:
         for n, v in opts.items():
@@ -965,9 +935,9 @@ def test_stress_configuration_t22_matches_oracle(pkg, orc, small_scene):
 @pytest.mark.parametrize("group", ["base", "large"])
 def test_every_combination_of_the_equivalence_switches_trains_the_same_parameters(pkg, small_scene, group):
     """The A/B switches of mon_set_option that claim "same parameters either way" are flipped in EVERY combination, not one at a time: level-tile encode or
-    gathers, hipGraph replay, zero-gradient samples kept, training lanes (base.json-sized tables); chunk records or arrays, touched flags, 16-bit step
-    counters, level-tile encode, zero-gradient samples kept (tables above 8 M parameters, binned scatter).  Master weights, fp16 weights and EMA must have
-    one CRC over all combinations of a group."""
+    gathers, hipGraph replay, zero-gradient samples kept, training lanes (base.json-sized tables); level-tile encode, zero-gradient samples kept, hipGraph
+    replay (tables above 8 M parameters, binned scatter; the record / flag / counter switches of rounds 4-5 are variant builds since round 6, checked against
+    the oracle instead: tools/gpu_variants_large.sh).  Master weights, fp16 weights and EMA must have one CRC over all combinations of a group."""
     _need_gpu(pkg)
     import itertools, zlib
     if group == "base":
@@ -976,7 +946,7 @@ def test_every_combination_of_the_equivalence_switches_trains_the_same_parameter
         fixed = {}
     else:
         kw, steps = dict(rays_per_batch=1024, log2_hashmap_size=20, n_levels=8, per_level_scale=2.0, n_neurons=32, n_hidden_layers=2), 10
-        switches = {"state_records": (1, 0), "touched_flags": (1, 0), "steps16": (1, 0), "lds_encode": (1, 0), "keep_zero_samples": (0, 1)}
+        switches = {"lds_encode": (1, 0), "keep_zero_samples": (0, 1), "use_graph": (0, 1)}
         fixed = {"big_switch": 1}                                                   # always binned: no global-atomic arrival order in the comparison
     names = list(switches) + list(fixed)
     old = {n: pkg.get_option(n) for n in names}

@@ -85,11 +85,11 @@ def test_offline_test_images_through_the_gather_are_the_same_files(pkg, ss, tmp_
     assert pkg.device_count() >= 1
     sc = ss.make_scene(n_views=8, H=120, W=160, f=130.0, n_objects=3, seed=6)
     seq = str(tmp_path / "seq"); ss.write_sequence(sc, seq)
-    pkg.set_option("offline_outer", 2); pkg.set_option("offline_inner", 50)       # (a mesh exists from the 2nd outer step on, nerf.cu:138-145)
+    pkg.set_offline_schedule(2, 50)       # (a mesh exists from the 2nd outer step on, nerf.cu:138-145)
     try:
         m = pkg.OfflineManager(seq, os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json")); m.init(); m.read_dataset()
     finally:
-        pkg.set_option("offline_outer", 10); pkg.set_option("offline_inner", 500)
+        pkg.set_offline_schedule(10, 500)
     m.set_output_dir("")
     for k in range(3):
         m.create_nerf(os.path.join(seq, "obj_offline", "%d.txt" % k))
@@ -183,7 +183,7 @@ def test_offline_output_tree_through_the_gather_on_logical_devices(pkg, ss, tmp_
     assert pkg.device_count() >= 1
     sc = ss.make_scene(n_views=8, H=120, W=160, f=130.0, n_objects=3, seed=6)
     seq = str(tmp_path / "seq"); ss.write_sequence(sc, seq)
-    pkg.set_option("offline_outer", 2); pkg.set_option("offline_inner", 60); pkg.set_logical_devices(2)
+    pkg.set_offline_schedule(2, 60); pkg.set_logical_devices(2)
     try:
         m = pkg.OfflineManager(seq, os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json")); m.init(); m.read_dataset(); m.set_output_dir("")
         for k in range(3):
@@ -200,4 +200,4 @@ def test_offline_output_tree_through_the_gather_on_logical_devices(pkg, ss, tmp_
         assert all(ta[f] == tb[f] for f in ta), [f for f in ta if ta[f] != tb[f]]
         m.close()
     finally:
-        pkg.set_logical_devices(0); pkg.set_option("offline_outer", 10); pkg.set_option("offline_inner", 500)
+        pkg.set_logical_devices(0); pkg.set_offline_schedule(10, 500)

@@ -123,10 +123,10 @@ def test_offline_nerf_flow_on_disk_sequence(pkg, ss, tmp_path):
     assert pkg.device_count() >= 1
     sc = ss.make_scene(n_views=10, H=120, W=160, f=130.0, n_objects=3, seed=5)
     seq = str(tmp_path / "seq"); ss.write_sequence(sc, seq)
-    pkg.set_option("offline_outer", 2); pkg.set_option("offline_inner", 150)
+    pkg.set_offline_schedule(2, 150)
     m = pkg.OfflineManager(seq, os.path.join(ROOT, "ro-map_amd", "configs", "c1_small.json"), use_dense_depth=True)
     m.init(); m.read_dataset()
-    pkg.set_option("offline_outer", 10); pkg.set_option("offline_inner", 500)      # (read by init)
+    pkg.set_offline_schedule(10, 500)      # (read by init)
     out = str(tmp_path / "out"); os.makedirs(out); m.set_output_dir(out)
     for k in range(3):
         m.create_nerf(os.path.join(seq, "obj_offline", "%d.txt" % k))

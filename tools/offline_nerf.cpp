@@ -32,7 +32,11 @@ int main(int argc, char** argv) {
             const size_t p1 = all.find(',', p0); kv = all.substr(p0, p1 == std::string::npos ? std::string::npos : p1 - p0);
             p0 = p1 == std::string::npos ? all.size() + 1 : p1 + 1;
             const size_t q = kv.find('=');
-            if (q != std::string::npos && mon_set_option(kv.substr(0, q).c_str(), std::atol(kv.c_str() + q + 1))) return fail("MON_OPTIONS");
+            if (q == std::string::npos) continue;
+            int orc;
+            if (kv.substr(0, q) == "offline_schedule") { int o = 0, i = 0; orc = std::sscanf(kv.c_str() + q + 1, "%dx%d", &o, &i) == 2 ? mon_offline_set_schedule(o, i) : 1; }
+            else orc = mon_set_option(kv.substr(0, q).c_str(), std::atol(kv.c_str() + q + 1));
+            if (orc) return fail("MON_OPTIONS");
         }
     }
     // wall clock per phase (like the reference's steady_clock around Train_Step, nerf_model.cu:1632,1659)
