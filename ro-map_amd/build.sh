@@ -5,7 +5,7 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 OBJ="$HERE/build"; mkdir -p "$OBJ"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -ffp-contract=off -fno-math-errno -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result)
-SRCS=(config.cpp model.cpp c_api.cpp manager.cpp png_io.cpp mesh.cpp kernels_batch.hip kernels_net.hip kernels_net_wide.hip kernels_net_deep.hip kernels_composite.hip kernels_optim.hip kernels_fused.hip kernels_scatter.hip kernels_render.hip kernels_tilerender.hip kernels_encode.hip kernels_step.hip kernels_bigscatter.hip kernels_mesh.hip)
+SRCS=(config.cpp model.cpp c_api.cpp manager.cpp png_io.cpp mesh.cpp kernels_batch.hip kernels_net.hip kernels_net_wide.hip kernels_net_deep.hip kernels_layers.hip kernels_composite.hip kernels_optim.hip kernels_fused.hip kernels_scatter.hip kernels_render.hip kernels_tilerender.hip kernels_encode.hip kernels_step.hip kernels_bigscatter.hip kernels_mesh.hip)
 DIAG_SRCS=(diag.cpp diag_kernels.hip microbench.hip)      # libmon_core_diag.so: test scaffolding and micro-benchmarks, not the product
 pids=()
 # every object depends on every header (frag_layout.h is the MFMA weight image shared by k_optimizer and k_fused_train: a partial rebuild must not mix layouts)

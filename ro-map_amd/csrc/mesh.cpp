@@ -185,7 +185,7 @@ int model_generate_mesh(Model& m, int res, float thresh, uint32_t* n_verts, uint
             }
             launch_grid_points(s, m.B.pts, res, res, res, (uint32_t)p0, n);
             launch_encode(s, m.lt, m.nd, prm, m.B.pts, m.B.E, n, nullptr);
-            launch_mlp_forward(s, m.nd, prm, m.B.E, nullptr, m.B.O, n, nullptr);
+            mlp_forward_inference(m, s, prm, m.B.E, m.B.O, n);
             launch_extract_density(s, m.B.O, ms.d_density + p0, n);
         }
     }
@@ -202,7 +202,7 @@ int model_generate_mesh(Model& m, int res, float thresh, uint32_t* n_verts, uint
             }
             launch_mesh_warp(s, ms.d_verts, m.B.pts, v0, n, m.oc.aabb);
             launch_encode(s, m.lt, m.nd, prm, m.B.pts, m.B.E, n, nullptr);
-            launch_mlp_forward(s, m.nd, prm, m.B.E, nullptr, m.B.O, n, nullptr);
+            mlp_forward_inference(m, s, prm, m.B.E, m.B.O, n);
             launch_mesh_colors(s, m.B.O, ms.d_colf, ms.d_col8, v0, n);
         }
     }

@@ -299,6 +299,53 @@ __global__ void __launch_bounds__(1024) k_ub_grid_barrier_xcd(uint32_t n_barrier
     }
     if (acc == 0x12345678u) scratch[0] = acc;
 }
+// mode 73 (VERDICT r05 item 4's probe): a per-LEVEL barrier.  The resident grid of 256 x 1024 threads with the CU's whole LDS, its workgroups grouped by XCD
+// (HW_REG_XCC_ID) into groups of 16 in arrival order -- a "level" whose scatter -> optimizer -> encode tail would stay inside one XCD's L2.  Per phase every
+// workgroup writes 64 KB (a partial table's worth), the 16 of a group meet at the group's counter, then each reads ANOTHER member's 64 KB and checks it.
+//   variant 0: everything at agent scope (acq_rel arrive, acquire spin): the flat barrier's semantics on 16 arrivals
+//   variant 1: same-XCD semantics -- the stores are in this XCD's L2 once vmcnt is 0, the arrive is a relaxed atomic, the spin relaxed, the reader invalidates its
+//              L1 only (buffer_inv sc0): no L2 write-back, no L2 invalidate
+// ctr (256-byte spacing): [0] start census barrier, [64 (1 + x)] census of XCD x, [64 (16 + g)] arrivals of group g, [64 * 60] mismatches seen by readers.
+__global__ void __launch_bounds__(1024) k_ub_level_barrier(uint32_t n_barriers, uint32_t* __restrict__ ctr, uint32_t* __restrict__ scratch, int variant) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    reinterpret_cast<uint32_t*>(smem)[threadIdx.x] = threadIdx.x;
+    __shared__ uint32_t s_group, s_member;
+    uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc)); xcc &= 7u;
+    if (threadIdx.x == 0) {
+        const uint32_t r = __hip_atomic_fetch_add(ctr + 64u * (1u + xcc), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // rank inside the XCD
+        s_group = xcc * 2u + ((r >> 4) & 1u); s_member = r & 15u;
+        const uint32_t a = __hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (a < gridDim.x) while (__hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    const uint32_t g = s_group, m = s_member;
+    uint32_t* const arrive = ctr + 64u * (16u + g);
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4* const mine = reinterpret_cast<u4*>(scratch) + ((size_t)(g * 16u + m) * 4096u);                    // 64 KB = 4096 x 16 B per workgroup
+    const u4* const theirs = reinterpret_cast<const u4*>(scratch) + ((size_t)(g * 16u + ((m + 1u) & 15u)) * 4096u);
+    uint32_t bad = 0u;
+    for (uint32_t b = 0; b < n_barriers; ++b) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) mine[threadIdx.x + 1024u * k] = u4{ b + 1u, m, g, threadIdx.x };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (variant == 0) {
+                __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (b + 1u) * 16u) __builtin_amdgcn_s_sleep(1);
+            } else {
+                __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (b + 1u) * 16u) __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        if (variant != 0) asm volatile("buffer_inv sc0" ::: "memory");                                    // this CU's L1 only
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) { const u4 v = theirs[threadIdx.x + 1024u * k]; bad += (v[0] != b + 1u || v[1] != ((m + 1u) & 15u)) ? 1u : 0u; }
+        __syncthreads();                                                                                  // (nobody overwrites before its reader is done: next arrive)
+    }
+    if (bad) atomicAdd(ctr + 64u * 60u, bad);
+}
 __global__ void __launch_bounds__(1024) k_ub_phase(uint32_t b, uint32_t* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     reinterpret_cast<uint32_t*>(smem)[threadIdx.x] = threadIdx.x;
@@ -417,7 +464,7 @@ int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n
         *ms_out = best * 1e6f / (float)(list.size() ? list.size() : 1);      // NANOSECONDS per 1000 touched records (the caller knows the percentage, not the count)
         return hipGetLastError() == hipSuccess ? MON_OK : MON_ERR_HIP;
     }
-    const size_t bytes = stream ? np * (12 + 8 + 2 * 8) + 4096 : mode == 30 ? 2 * (size_t)n_ops : (mode >= 70 && mode <= 72) ? (size_t)16 << 20 : (mode >= 80 && mode <= 82) ? (size_t)n_entries * 4
+    const size_t bytes = stream ? np * (12 + 8 + 2 * 8) + 4096 : mode == 30 ? 2 * (size_t)n_ops : (mode >= 70 && mode <= 72) ? (size_t)16 << 20 : (mode == 73 || mode == 74) ? (size_t)20 << 20 : (mode >= 80 && mode <= 82) ? (size_t)n_entries * 4
             : (size_t)n_entries * 4 * 8;
     if (hipMalloc((void**)&table, bytes) != hipSuccess || hipMalloc((void**)&sink, 64) != hipSuccess) { set_error("microbench: hipMalloc failed");
         return MON_ERR_HIP; }
@@ -436,6 +483,11 @@ int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n
                           reinterpret_cast<uint16_t*>(b + 16 * np), reinterpret_cast<uint16_t*>(b + 18 * np), reinterpret_cast<const uint16_t*>(b + 20 * np),
                                   (uint32_t)np, (n_entries >> 8) & 15u, n_entries & 1u };
             launch_stream(mode, pattern > 0 ? pattern : 512, (int)((n_entries >> 4) & 15u), a);
+        }
+        else if (mode == 73 || mode == 74) {      // per-level (16 workgroups of one XCD) barrier + 64 KB exchange; 73 agent-scope semantics, 74 same-XCD semantics
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ub_level_barrier), hipFuncAttributeMaxDynamicSharedMemorySize, 163840 - 64);
+            hipMemsetAsync(table, 0, 65536, 0);
+            hipLaunchKernelGGL(k_ub_level_barrier, dim3(256), dim3(1024), 163840 - 64, 0, n_ops, table, table + 16384, mode == 73 ? 0 : 1);
         }
         else if (mode >= 70 && mode <= 72) {
             const uint32_t wgs = pattern > 0 ? (uint32_t)pattern : 256u;
@@ -464,6 +516,12 @@ int microbench(int device, int mode, int pattern, uint32_t n_entries, uint32_t n
         else hipLaunchKernelGGL(k_ub, dim3(blocks), dim3(256), 0, 0, mode, pattern, n_entries, ops_per_thread, table, sink);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms = 0.f; hipEventElapsedTime(&ms, e0, e1); if (rep > 0 && ms < best) best = ms;
+    }
+    if (mode == 73 || mode == 74) {      // a reader that saw stale data invalidates the timing: reported as a negative time
+        uint32_t bad = 0, census[8] = { 0 }; hipMemcpy(&bad, table + 64 * 60, 4, hipMemcpyDeviceToHost);
+        for (int x = 0; x < 8; ++x) hipMemcpy(&census[x], table + 64 * (1 + x), 4, hipMemcpyDeviceToHost);
+        bool even = true; for (int x = 0; x < 8; ++x) even = even && census[x] == 32u;
+        if (bad || !even) best = -(bad ? 1.f : 2.f);
     }
     hipEventDestroy(e0); hipEventDestroy(e1); hipFree(table); hipFree(sink);
     *ms_out = best;

@@ -572,6 +572,12 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
         if (flags_on && m.lazy_ema && m.lds_mask && m.lds_mask != ((m.nd.L >= 32) ? 0xffffffffu : ((1u << m.nd.L) - 1u))
                 && (rc = dev_alloc(m, m.d_touched, (m.n_params >> 3) + 16))) return rc;
     }
+    if (!fused_supported(m.nd, S, m.oc.R) && (Btrain & 31u) == 0u) {
+        // shapes outside the fused kernels: the T-layout workspace of the MFMA layer kernels (kernels_layers.hip); without it kernels_net.hip's one-sample-per-
+        // thread kernels run
+        if ((rc = dev_alloc(m, m.d_layers_T, layers_workspace_halves(m.nd, Btrain), false))) return rc;
+    }
+    if (fused_supported(m.nd, S, m.oc.R)) { }
     else if (S == 32u && !m.lazy_ema) {
         // Shapes the fused kernels do not take (16 neurons, 2 x 128, three / four hidden layers): the layer-at-a-time kernels, but their grid backward through
         // k_grid_scatter when the plan covers every level (tables up to 2^18 entries per level) -- see k_rows_to_bins
@@ -780,6 +786,16 @@ static void collect_profile(Model& m) {
     m.ev_pending.clear();
 }
 
+void mlp_forward_inference(Model& m, hipStream_t s, const uint16_t* params, const uint16_t* E, uint16_t* O, uint32_t n) {
+    const uint32_t piece = (m.oc.R * m.oc.S) & ~31u; uint32_t done = 0;
+    if (m.d_layers_T && m.B.Hid && piece) {
+        for (; done + 32u <= n; ) { const uint32_t cnt = std::min(piece, (n - done) & ~31u);
+            if (!launch_mlp_forward_layers(s, m.nd, params, E + (size_t)done * m.nd.Epad, m.B.Hid, O + (size_t)done * kOut, cnt, nullptr, nullptr)) break;
+            done += cnt; }
+    }
+    if (done < n) launch_mlp_forward(s, m.nd, params, E + (size_t)done * m.nd.Epad, nullptr, O + (size_t)done * kOut, n - done, nullptr);
+}
+
 // occupancy-grid skipping on the level-tile chain: what the position pass, k_encode_tiles and k_fused_train<PRE, OCC> share once the grid is in use
 static LiveArgs live_args(const Model& m) {
     if (!(m.d_occ && m.occ_refreshed_iter && m.d_live_idx)) return LiveArgs{};
@@ -827,18 +843,29 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_step_compaction(s, m.B, m.oc, m.d_state, m.d_step_counts, m.d_step_pts);
             hipMemcpyAsync(m.B.pts, m.d_step_pts, 12 * (size_t)B, hipMemcpyDeviceToDevice, s);
             launch_encode(s, m.lt, m.nd, m.P.half, m.B.pts, m.B.E, B, m.d_state);                             // :1545 forward of the compacted batch
-            launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);
-            launch_mlp_backward(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state);          // :1547
-            launch_weight_grads(s, m.nd, m.B.E, m.B.Hid, m.B.dHid, m.B.dO, m.P.gmlp, B, m.d_state);
+            if (!(m.d_layers_T && launch_mlp_forward_layers(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state, m.d_layers_T)))
+                launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);
+            if (m.d_layers_T && launch_mlp_backward_layers(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state, m.d_layers_T))
+                launch_weight_grads_layers(s, m.nd, m.P.gmlp, B, m.d_state, m.d_layers_T);
+            else {
+                launch_mlp_backward(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state);          // :1547
+                launch_weight_grads(s, m.nd, m.B.E, m.B.Hid, m.B.dHid, m.B.dO, m.P.gmlp, B, m.d_state);
+            }
             if (m.hybrid_scatter) hipMemsetAsync(m.P.ggrid, 0, (size_t)m.n_grid * 2, s);           // (a whole step of the other schedule may have left partial sums)
             launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
         } else if (m.backend == 0) {
             ProfScope ps(m, MON_K_FWDBWD);
             launch_encode(s, m.lt, m.nd, m.P.half, m.B.pts, m.B.E, B, m.d_state);
-            launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);
+            // (shapes outside the fused kernels: one MFMA launch per layer, kernels_layers.hip)
+            if (!(m.d_layers_T && launch_mlp_forward_layers(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state, m.d_layers_T)))
+                launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);
             launch_composite_grad(s, m.B, m.oc, m.d_state);
-            launch_mlp_backward(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state);
-            launch_weight_grads(s, m.nd, m.B.E, m.B.Hid, m.B.dHid, m.B.dO, m.P.gmlp, B, m.d_state);
+            if (m.d_layers_T && launch_mlp_backward_layers(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state, m.d_layers_T))
+                launch_weight_grads_layers(s, m.nd, m.P.gmlp, B, m.d_state, m.d_layers_T);
+            else {
+                launch_mlp_backward(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state);
+                launch_weight_grads(s, m.nd, m.B.E, m.B.Hid, m.B.dHid, m.B.dO, m.P.gmlp, B, m.d_state);
+            }
             // whole steps of a shape outside the fused kernels: the exact LDS scatter (partial tables, summed by the optimizer).  Stage-wise calls (the debugging
             // entry that stops before the optimizer) keep tcnn's global atomics into ggrid, which only the non-dense optimizer clears: start from zeros there
             if (hybrid) {
@@ -1178,7 +1205,7 @@ int model_render(Model& m, mon_frame_bbox box, const float* pose16, int pose_is_
         if (m.backend == 0) {
             launch_gen_samples(s, m.B, m.oc, m.d_state, S2, n * S2, kStreamRender, p0 * S2, 1);
             launch_encode(s, m.lt, m.nd, prm, m.B.pts, m.B.E, n * S2, nullptr);
-            launch_mlp_forward(s, m.nd, prm, m.B.E, nullptr, m.B.O, n * S2, nullptr);
+            mlp_forward_inference(m, s, prm, m.B.E, m.B.O, n * S2);
             launch_composite_render(s, m.B, S2, n, m.d_out_rgb + 3 * (size_t)p0, m.d_out_depth + p0, m.d_out_mask + p0);
         } else {
             launch_fused_render(s, m.lf, m.nd, prm, m.B, m.oc, n, p0 * S2, m.d_out_rgb + 3 * (size_t)p0, m.d_out_depth + p0, m.d_out_mask + p0,
@@ -1234,7 +1261,7 @@ int model_density_grid(Model& m, int rx, int ry, int rz, float* out_host) {
         const uint32_t n = (total - p0) < chunk ? (total - p0) : chunk;
         launch_grid_points(s, m.B.pts, rx, ry, rz, p0, n);
         launch_encode(s, m.lt, m.nd, prm, m.B.pts, m.B.E, n, nullptr);
-        launch_mlp_forward(s, m.nd, prm, m.B.E, nullptr, m.B.O, n, nullptr);
+        mlp_forward_inference(m, s, prm, m.B.E, m.B.O, n);
         launch_extract_density(s, m.B.O, m.B.tdist, n);
         HIPCHECK(hipMemcpyAsync(out_host + p0, m.B.tdist, 4 * (size_t)n, hipMemcpyDeviceToHost, s));
         HIPCHECK(hipStreamSynchronize(s));

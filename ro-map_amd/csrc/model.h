@@ -222,6 +222,18 @@ void launch_weight_grads(hipStream_t s, const NetDims& nd, const uint16_t* E, co
 void launch_grid_backward(hipStream_t s, const LevelTable& lt, const NetDims& nd, const float* pts, const uint16_t* dE, uint16_t* ggrid, uint32_t n,
         const DevState* st);
 
+// MFMA layer-at-a-time kernels (kernels_layers.hip): the shapes the fused kernels do not take.  ws_T: the T-layout copies the weight gradients read
+// (layers_workspace_halves(nd, n) halves; nullptr = forward only, nothing is kept).  false: shape / batch not covered, nothing was launched
+size_t layers_workspace_halves(const NetDims& nd, uint32_t n);
+bool launch_mlp_forward_layers(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n,
+        const DevState* st_or_null, uint16_t* ws_T_or_null);
+bool launch_mlp_backward_layers(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE,
+        uint32_t n, const DevState* st, uint16_t* ws_T);
+void launch_weight_grads_layers(hipStream_t s, const NetDims& nd, float* gmlp, uint32_t n, const DevState* st, uint16_t* ws_T);
+struct Model;
+// inference forward of n samples E -> O with the layer kernels where the object has them (Hid of the training batch as scratch, piece by piece), else k_mlp_forward
+void mlp_forward_inference(Model& m, hipStream_t s, const uint16_t* params, const uint16_t* E, uint16_t* O, uint32_t n);
+
 // composite / loss gradient (kernels_composite.hip)
 void launch_composite_grad(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st);
 void launch_composite_render(hipStream_t s, const BatchPtrs& b, uint32_t S, uint32_t n_rays, float* rgb, float* depth, float* mask);
@@ -342,6 +354,7 @@ struct Model {
     float* d_x_all = nullptr; uint16_t* d_e_soa = nullptr; uint16_t* d_half_tiles = nullptr;
     // network shapes outside the fused kernels (backend 0 by necessity) whose levels all fit the LDS scatter plan: whole training steps scatter through k_grid_scatter
     bool hybrid_scatter = false;
+    uint16_t* d_layers_T = nullptr;          // T-layout workspace of the MFMA layer kernels (shapes outside the fused kernels)
     uint16_t* d_gpart = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0;   // k_grid_scatter: partial tables, plan, levels it covers
     // halves of ONE partial table: the grid parameters of the LDS-scattered levels (a prefix of the levels), not of the whole table
     uint32_t part_halves = 0;

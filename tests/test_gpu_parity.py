@@ -313,8 +313,14 @@ def test_the_other_fully_fused_mlp_widths_match_oracle(pkg, orc, small_scene, W,
         obj.train_stages(1 | 2); ref.generate_batch(); ref.forward_backward()
         assert int(obj.buffer("state")[2]) == ref.n_valid > 0
         assert np.array_equal(obj.buffer("E"), ref.buffer("E")), "hash-grid encode must be bit-exact"
-        close_half(obj.buffer("O"), ref.buffer("O"), "network output", frac_ok=1.0 if backend == 0 else 0.999)
+        # (MFMA summation order -- the fused kernels, and since round 6 the layer-at-a-time kernels of the shapes outside them: a hidden activation on a
+        # rounding boundary lands one fp16 ulp away now and then, and the layers behind it carry that on)
+        close_half(obj.buffer("O"), ref.buffer("O"), "network output", frac_ok=0.999)
+        close_half(obj.buffer("Hid"), ref.buffer("Hid"), "hidden activations", frac_ok=0.999)
         close_half(obj.buffer("dO"), ref.buffer("dO"), "dL/dO", ulps=4, frac_ok=0.999)
+        close_half(obj.buffer("dHid"), ref.buffer("dHid"), "dL/dh", ulps=4, frac_ok=0.999)
+        nf = 2 * L; B_, Ep_ = ref.R * ref.S, ref.Epad
+        close_half(obj.buffer("dE").reshape(B_, Ep_)[:, :nf], ref.buffer("dE").reshape(B_, Ep_)[:, :nf], "dL/dE", ulps=4, frac_ok=0.999)
         gm, rm = obj.buffer("gmlp").astype(np.float64), ref.buffer("gmlp").astype(np.float64)
         assert gm.shape == rm.shape and np.abs(gm - rm).max() < 5e-3 * np.abs(rm).max()
         gg = h2f(obj.buffer("ggrid_h")).astype(np.float64); rg = ref.buffer("ggrid").astype(np.float64); ra = ref.buffer("ggrid_abs").astype(np.float64)
@@ -337,7 +343,7 @@ def test_the_other_fully_fused_mlp_widths_match_oracle(pkg, orc, small_scene, W,
         ref.set_params(obj.get_params(0)); ref.set_ema(obj.get_params(2))
         rgb, dep, msk = obj.render(ob, pose); r2, d2, m2 = ref.render(ob, pose)
         same = msk == m2
-        assert same.mean() > 0.99 and np.abs(rgb - r2)[same].max() < 2e-2 and np.abs(rgb - r2)[same].mean() < 2e-3
+        d = np.abs(rgb - r2)[same]; print("render diff max %.2e mean %.2e" % (d.max(), d.mean())); assert same.mean() > 0.99 and d.max() < 2e-2 and d.mean() < 2e-3
         obj.close(); ds.close(); ref.close()
 
 

@@ -6,7 +6,7 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"; REPO="$HERE/../.."
 OUT="${1:-/tmp/mon_tsan}"; mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-host-only -fsanitize=thread -g -O1 -std=c++17 -fPIC -x hip -ffp-contract=off -fno-math-errno -w)
-SRCS=(config.cpp model.cpp c_api.cpp manager.cpp png_io.cpp mesh.cpp kernels_batch.hip kernels_net.hip kernels_net_wide.hip kernels_net_deep.hip kernels_composite.hip kernels_optim.hip kernels_fused.hip kernels_scatter.hip kernels_render.hip kernels_tilerender.hip kernels_encode.hip kernels_step.hip kernels_bigscatter.hip kernels_mesh.hip)
+SRCS=(config.cpp model.cpp c_api.cpp manager.cpp png_io.cpp mesh.cpp kernels_batch.hip kernels_net.hip kernels_net_wide.hip kernels_net_deep.hip kernels_layers.hip kernels_composite.hip kernels_optim.hip kernels_fused.hip kernels_scatter.hip kernels_render.hip kernels_tilerender.hip kernels_encode.hip kernels_step.hip kernels_bigscatter.hip kernels_mesh.hip)
 pids=()
 for s in "${SRCS[@]}"; do "$HIPCC" "${FLAGS[@]}" -c "$REPO/ro-map_amd/csrc/$s" -o "$OUT/${s%.*}.o" & pids+=($!); done
 "$HIPCC" "${FLAGS[@]}" -c "$HERE/hip_stub.cpp" -o "$OUT/hip_stub.o" & pids+=($!)

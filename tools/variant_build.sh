@@ -6,7 +6,7 @@ TAG="$1"; shift
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/../ro-map_amd" && pwd)"
 OBJ="$HERE/build_$TAG"; mkdir -p "$OBJ"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -ffp-contract=off -fno-math-errno -w "$@")
-SRCS=(config.cpp model.cpp c_api.cpp manager.cpp png_io.cpp mesh.cpp kernels_batch.hip kernels_net.hip kernels_net_wide.hip kernels_net_deep.hip kernels_composite.hip kernels_optim.hip kernels_fused.hip kernels_scatter.hip kernels_render.hip kernels_tilerender.hip kernels_encode.hip kernels_step.hip kernels_bigscatter.hip kernels_mesh.hip)
+SRCS=(config.cpp model.cpp c_api.cpp manager.cpp png_io.cpp mesh.cpp kernels_batch.hip kernels_net.hip kernels_net_wide.hip kernels_net_deep.hip kernels_layers.hip kernels_composite.hip kernels_optim.hip kernels_fused.hip kernels_scatter.hip kernels_render.hip kernels_tilerender.hip kernels_encode.hip kernels_step.hip kernels_bigscatter.hip kernels_mesh.hip)
 DIAG_SRCS=(diag.cpp diag_kernels.hip microbench.hip)
 pids=()
 for s in "${SRCS[@]}" "${DIAG_SRCS[@]}"; do /opt/rocm/bin/hipcc "${FLAGS[@]}" -I"$HERE/../include" -c "$HERE/csrc/$s" -o "$OBJ/${s%.*}.o" & pids+=($!); done
