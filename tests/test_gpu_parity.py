@@ -343,7 +343,7 @@ def test_the_other_fully_fused_mlp_widths_match_oracle(pkg, orc, small_scene, W,
         ref.set_params(obj.get_params(0)); ref.set_ema(obj.get_params(2))
         rgb, dep, msk = obj.render(ob, pose); r2, d2, m2 = ref.render(ob, pose)
         same = msk == m2
-        d = np.abs(rgb - r2)[same]; print("render diff max %.2e mean %.2e" % (d.max(), d.mean())); assert same.mean() > 0.99 and d.max() < 2e-2 and d.mean() < 2e-3
+        d = np.abs(rgb - r2)[same]; assert same.mean() > 0.99 and d.max() < 4e-3 and d.mean() < 1e-4          # (measured: max 5e-5 over the eight shapes)
         obj.close(); ds.close(); ref.close()
 
 
