@@ -73,6 +73,27 @@ def test_eight_self_spawned_ranks_run_the_drivers_n8_command_end_to_end(pkg):
     assert j["scaling"] == "weak"
 
 
+@pytest.mark.gpu
+def test_the_drivers_launcher_command_runs_two_ranks(pkg):
+    """The driver's own N > 1 command -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
+    --steps K --warmup W` -- with N = 2 on this box: the ranks come from the launcher's environment (no self-spawn), rank 0 prints the one JSON line."""
+    assert pkg.device_count() >= 1
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MON_BENCH_DIST_BACKEND", "MON_BENCH_SPAWNED")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline", "--objects-per-gpu", "0",
+           "--views", "8", "--no-sustained", "--no-stress"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    ndev = pkg.device_count()
+    assert j["n_gpus"] == 2 and j["config"]["launcher"] == "torch.distributed.run" and j["config"]["ranks_in_collective"] == 2
+    assert j["config"]["collective_backend"] == ("nccl" if ndev >= 2 else "gloo") and j["config"]["rank_devices"] == [0, 1 % ndev]
+    assert j["render_gather"] == "ok" and len(j["psnr_db"]) == 2 and len(j["per_rank_ray_samples_per_s"]) == 2
+    assert j["steps"] == 4 and j["warmup"] == 2 and j["value"] > 0
+
+
 def test_gpus_flag_without_a_device_fails_loudly():
     """No CPU fallback: without a HIP device the spawner stops with a message instead of printing a line."""
     import __graft_entry__ as ge
