@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
-mkdir -p gpurun_out
-python -m pytest tests/test_gpu_parity.py tests/test_step_variant.py tests/test_gpu_mesh.py tests/test_tile_render.py -m gpu -q -x -k "other_fully_fused or trains_the_grid or mesh or render" 2>&1 | tail -5 | tee gpurun_out/layers_test.log
-for sh in "16 1" "64 3" "128 2" "32 4" "16 4"; do python tools/shape_times.py $sh; done 2>&1 | grep "^{" | tee gpurun_out/shape_times.log
+mkdir -p gpurun_out; export TMPDIR=/tmp
+for sh in "16 1" "64 3"; do python tools/shape_times.py $sh; MON_OPTIONS=use_graph=1 python tools/shape_times.py $sh; done 2>&1 | grep "^{"
+(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_a -o t -- python $GRAFT_REPO_ROOT/tools/shape_times.py 16 1 > /dev/null 2>&1)
+db=$(find /tmp/prof_a -name "*.db" | head -1); python tools/rocpd_stats.py "$db" gpurun_out/shape_16x1_stats.md > /dev/null 2>&1; head -18 gpurun_out/shape_16x1_stats.md | cut -c1-110
