@@ -162,7 +162,7 @@ def main():
     pobj.set_profiling(True); pobj.profile(reset=True)
     sc0 = int(pobj.buffer("state")[25])
     pobj.train(args.steps); prof = pobj.profile(reset=True); pobj.set_profiling(False)
-    # samples with a non-zero gradient per step in this window
+    # samples with a non-zero gradient per step in this window (DESIGN.md 3.1 (HISTORY 3.2b))
     scattered = ((int(pobj.buffer("state")[25]) - sc0) % (1 << 32)) / float(args.steps)
     pobj.close()
     avg = lambda k: prof["ms"][k] / max(1, prof["launches"][k])
@@ -252,7 +252,7 @@ def main():
     roofline["contract"] = {"bytes_per_step": int(contract_bytes), "bytes_per_ray_sample": train_bytes_per_sample(L), "optimizer_bytes_per_step": 40 * n_params,
                             "ms_per_step": round(step_ms, 4), "achieved": round(contract_bytes / (step_ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                             "frac_of_hbm": round(contract_bytes / (step_ms * 1e-3) / 1e9 / 8000.0, 4),
-                            "note": "nominal bytes: every sample counts its scatter bytes whether or not its gradient underflowed to zero (DESIGN.md 3.2b)"}
+                            "note": "nominal bytes: every sample counts its scatter bytes whether or not its gradient underflowed to zero (DESIGN.md 3.1 (HISTORY 3.2b))"}
     # MFMA side (the tiny GEMMs of the MLP are the only matrix work): algorithmic flops = 2 * MACs of forward, input gradients and weight gradients
     W_, NH_, F_in = cfg.n_neurons, cfg.n_hidden_layers, 2 * L
     macs = F_in * W_ + (NH_ - 1) * W_ * W_ + W_ * 4
@@ -266,7 +266,7 @@ def main():
                                 "the path is not priced against this roof"}
 
     # ---- extra, not the headline: the same measurement late in training (the scatter handles only the samples that still carry a
-    #      gradient; an OfflineNeRF job runs 5000 iterations)
+    #      gradient, DESIGN.md 3.1 (HISTORY 3.2b); an OfflineNeRF job runs 5000 iterations)
     late = None
     if fused:
         done = args.warmup + args.steps; extra = max(0, 800 - done)
@@ -492,7 +492,7 @@ def main():
             multi = {"objects": K, "value": round(K * msteps * B / tm, 1), "unit": "ray-samples/s (all objects)",
                     "ms_per_step_per_object": round(1e3 * tm / msteps / K, 4),
                      "values_of_the_repeats": [round(K * msteps * B / t, 1) for t in tms],
-                     "note": "K independent objects, one host thread each, their training work on the device's two training lanes (DESIGN 7.2), same GPU, "
+                     "note": "K independent objects, one host thread each, their training work on the device's two training lanes (HISTORY 7.2), same GPU, "
                              "each over steps %d..%d from init; median of 3 fresh sets" % (args.warmup, args.warmup + msteps)}
         except Exception as e:
             multi = {"objects": args.objects_per_gpu, "value": None, "note": "failed: %s" % e}

@@ -288,7 +288,7 @@ void launch_encode_tiles(hipStream_t s, const LevelFast& lf, const NetDims& nd, 
     EncodeArgs a{ lf, nd.L, nd.n_mlp, half_tiles, reinterpret_cast<const float4_t*>(x_all), reinterpret_cast<half2_t*>(e_soa), B, spw, st,
             b_next ? 1u : 0u, b_next ? *b_next : BatchPtrs{}, ds, oc, live };
 #ifdef MON_OVERLAP_PROBE
-    // (lds_bytes bit 0 = launch without the AQL barrier bit, hipExtAnyOrderLaunch: ignored on gfx950)
+    // (lds_bytes bit 0 = launch without the AQL barrier bit, hipExtAnyOrderLaunch: ignored on gfx950, HISTORY 7.9)
     if (lds_bytes & 1u) { hipExtLaunchKernelGGL(k_encode_tiles, dim3((uint32_t)nd.L * kEncWgPerLevel, chunks), dim3(kEncThreads), (lds_bytes & ~1u) ? (lds_bytes & ~1u)
             : kEncLdsBytes, s, nullptr, nullptr, hipExtAnyOrderLaunch, a); return; }
 #endif

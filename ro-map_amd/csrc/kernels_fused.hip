@@ -488,7 +488,7 @@ bool fused_supported(const NetDims& nd, uint32_t S, uint32_t R) {
 uint32_t fused_train_grid(const NetDims&, uint32_t R) {
     const uint32_t want = (R + 3) / 4;            // one ray per wavefront when it fits
     // (two workgroups per CU; the dW partial rows are allocated for kMaxFusedGrid of them.  One ray per wave -- 768 / 1024 workgroups -- measured slower,
-    // DESIGN 7.6)
+    // HISTORY 7.6)
     return want < kMaxFusedGrid ? want : kMaxFusedGrid;
 }
 

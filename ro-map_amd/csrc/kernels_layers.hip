@@ -9,7 +9,7 @@
 //   dW[units x K] = sum over samples dAct[s][unit] In[s][k]: SAMPLES ON K -- both operands then want eight consecutive samples of one feature in 16 bytes,
 //     which the row-major activations do not have.  The producers therefore write every tensor a weight gradient reads a second time in "T layout"
 //     XT[s / 8][feature][s % 8] (2-byte stores from the registers they hold anyway); k_weight_grad_mfma then feeds the MFMA straight from global memory with
-//     one 16-byte load per operand -- no LDS, no transposition pass (the LDS-staged kernel was bound by its 2-byte LDS reads).
+//     one 16-byte load per operand -- no LDS, no transposition pass (the LDS-staged kernel was bound by its 2-byte LDS reads, HISTORY 0, r05 row 7).
 // Numerics are kernels_net.hip's: fp16 operands, fp32 accumulation (in MFMA order instead of k-ascending fmaf order), one rounding to fp16 per activation.
 #include "device_common.h"
 #include "model.h"

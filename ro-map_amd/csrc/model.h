@@ -168,7 +168,7 @@ struct Options {      // (atomics: tests and tools flip options while object thr
          tile_render{ 1 };      // inference on feature-planar level tiles: 0 never (gathers), 1 crops of 4096 rays and more + point queries, 2 always
     // NerfManagerOffline's 10 x 500 iterations (nerf_manager.cu:89): mon_offline_set_schedule, read by mon_offline_init
     std::atomic<long> offline_outer{ 10 }, offline_inner{ 500 };
-#ifdef MON_OVERLAP_PROBE        // variant build only (tools/variant_build.sh ovl -DMON_OVERLAP_PROBE): k_optimizer(i) next to a throw-away k_encode_tiles
+#ifdef MON_OVERLAP_PROBE        // variant build only (tools/variant_build.sh ovl -DMON_OVERLAP_PROBE; HISTORY 7.9): k_optimizer(i) next to a throw-away k_encode_tiles
     std::atomic<long> overlap{ 0 }, enc_lds_kb{ 0 };
 #endif
 };
@@ -192,7 +192,7 @@ constexpr bool kTouchedFlags = false;
 #else
 constexpr bool kTouchedFlags = true;
 #endif
-constexpr int kLaneChunk = 16;          // iterations an object enqueues per turn on a training lane (measured best)
+constexpr int kLaneChunk = 16;          // iterations an object enqueues per turn on a training lane (measured best, HISTORY 7.2)
 constexpr long kOnlineSliceMin = 2;     // shortest training slice of the online manager (iterations)
 Options& options();
 int option_set(const char* name, long value);

@@ -2,7 +2,7 @@
 # Round 5 probe: k_optimizer(i) next to a throw-away k_encode_tiles (option overlap: side stream / no barrier bit), step times + a kernel trace.
 # The options exist in a VARIANT build only (the product library carries none of it): build it first, in the container,
 #   tools/variant_build.sh ovl -DMON_OVERLAP_PROBE
-# then on the GPU box:  gpurun -- 'bash tools/gpu_overlap_probe.sh'      (results: profiles/r05_probes.md section 1)
+# then on the GPU box:  gpurun -- 'bash tools/gpu_overlap_probe.sh'      (results: profiles/r05_probes.md section 1, HISTORY 7.9)
 #   PROBE_SET / TRACE_SET: space-separated option strings ("-" = no options)
 set -u
 export MON_CORE_LIB="${MON_CORE_LIB:-${GRAFT_REPO_ROOT:-/root/repo}/ro-map_amd/build_ovl/libmon_core.so}"

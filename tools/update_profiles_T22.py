@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from update_profiles_render import counters, table  # noqa: E402
 
 
+STEP_BYTES = {}      # tag -> counter traffic of one step's kernels, bytes (sum over kernels of MB per launch x launches per step of the 20-step window)
+
+
 def section(tag, title, L):
     d = os.path.join(ROOT, "gpurun_out", tag)
     if not os.path.exists(os.path.join(d, "kernel_window.md")):
@@ -28,6 +31,8 @@ def section(tag, title, L):
                 ("%.2f" % (mb / r["avg"])) if cc and r["avg"] else "-",
                                                                  ("%.2f M" % (g("TCC_REQ_sum") / 1e6)) if cc else "-", ("%.2f" % hit) if cc else "-"))
         tot += r["total"] / max(1, r["n"])
+        if cc:
+            STEP_BYTES[tag] = STEP_BYTES.get(tag, 0.0) + mb * 1e6 * r["n"] / 20.0
     L.append("\nsum of the kernels' average durations per step: %.0f us\n" % tot)
 
 
@@ -46,6 +51,14 @@ def main():
     if os.path.exists(notes):
         L.append(open(notes).read())
     open(os.path.join(ROOT, "profiles", rnd + "_window_T22.md"), "w").write("\n".join(L) + "\n")
+    # the step's counter traffic for bench.py's stress_T22 line, with the fingerprint of the kernel sources it was measured on (tools/fingerprint.py)
+    if (rnd + "_T22_init") in STEP_BYTES and (rnd + "_T22_late") in STEP_BYTES:
+        import json
+        from fingerprint import kernel_sources_sha16
+        pj_path = os.path.join(ROOT, "profiles", "pmc_traffic.json"); pj = json.load(open(pj_path))
+        pj["stress_T22"] = {"source": "profiles/%s_window_T22.md (gpurun %s_T22_init / %s_T22_late)" % (rnd, rnd, rnd), "kernel_sources_sha16": kernel_sources_sha16(),
+                            "step_bytes_beyond_l2_steps_20_40": int(STEP_BYTES[rnd + "_T22_init"]), "step_bytes_beyond_l2_steps_800_820": int(STEP_BYTES[rnd + "_T22_late"])}
+        json.dump(pj, open(pj_path, "w"), indent=1)
     print("\n".join(L))
 
 

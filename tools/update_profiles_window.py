@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = ("k_encode_tiles", "k_fused_train", "k_grid_scatter", "k_optimizer")
 WHAT = {"sparse_occ": "steps 805..825 from init with occupancy-grid skipping switched on (mon_config::occupancy_skip; opt-in, DESIGN.md 3.4)",
         "dense": "steps 5..25 from init -- the window `bench.py --gpus 1 --steps 20 --warmup 5` times; every one of the 131 072 samples carries a gradient",
-        "sparse": "steps 805..825 from init -- late training; a few per cent of the samples still carry a gradient (DESIGN.md 3.2b)"}
+        "sparse": "steps 805..825 from init -- late training; a few per cent of the samples still carry a gradient (DESIGN.md 3.1 (HISTORY 3.2b))"}
 
 
 def parse(md):
