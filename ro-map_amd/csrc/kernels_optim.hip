@@ -53,7 +53,10 @@ __device__ __forceinline__ void ema_catch_up(half8_t& e, const half8_t& w, uint3
 // remembers the optimizer step its EMA is current for, and the missing steps are applied in closed form when the chunk next receives a
 // gradient or when the inference weights are needed (k_ema_finalize).  The weights and Adam state are exactly those of the eager
 // schedule; the EMA differs from the step-by-step fp16 recurrence by rounding only.
-template <bool DENSE, bool LAZY, bool ONE = false /* the grid covers every chunk with one thread: no second chunk's state to hold (44 registers less) */>
+// (LIVE: the position blocks also look the samples' occupancy cells up and compact the live ones -- a template parameter because the kernel's register count is the
+// maximum over its paths: compiled into the default instantiation it cost a wave per SIMD, 96 -> 104 registers, and 1.4 us of the dense step)
+template <bool DENSE, bool LAZY, bool ONE = false /* the grid covers every chunk with one thread: no second chunk's state to hold (44 registers less) */,
+          bool LIVE = false>
 __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, const DevState* __restrict__ st, DevState* __restrict__ st_next, OptimNext nx,
         uint32_t lazy_below) {
     // block roles by VIRTUAL index: [0, extra) prepare the next iteration, the rest update parameters.  Physically the parameter blocks come first (they are
@@ -118,7 +121,7 @@ __global__ void __launch_bounds__(256) k_optimizer(ParamPtrs p, OptimConst oc, c
         if (nv != 0u)
 #endif
             for (uint32_t s = vblock * blockDim.x + threadIdx.x; s < nx.oc.R * 32u; s += nx.pos_blocks * blockDim.x) {
-                if (nx.live.occ_bits) points_sample<true>(plds, nx.b, nx.oc, st->iter + 1u, nv, nwords, s, reinterpret_cast<float4_t*>(nx.x_all), nx.live);
+                if constexpr (LIVE) points_sample<true>(plds, nx.b, nx.oc, st->iter + 1u, nv, nwords, s, reinterpret_cast<float4_t*>(nx.x_all), nx.live);
                 else points_sample<false>(plds, nx.b, nx.oc, st->iter + 1u, nv, nwords, s, reinterpret_cast<float4_t*>(nx.x_all));
             }
     }
@@ -575,14 +578,16 @@ void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, c
     uint32_t cap = chunks / (256u * 8u); if (cap < 1024u) cap = 1024u; if (cap > 2048u) cap = 2048u;
     uint32_t blocks = (chunks + 255) / 256; if (blocks > cap) blocks = cap; if (blocks < 1u) blocks = 1u;
     // dense = every level goes through the LDS scatter, i.e. tables of at most 2^18 entries that a 131 072-sample batch covers
+    const dim3 grid(blocks + nx.cand_blocks + nx.pos_blocks); const bool live = nx.pos_blocks && nx.live.occ_bits;
+#define MON_OPT_LAUNCH(D, L, O) do { if (live) hipLaunchKernelGGL((k_optimizer<D, L, O, true>), grid, dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below); \
+        else hipLaunchKernelGGL((k_optimizer<D, L, O, false>), grid, dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below); } while (0)
     if (p.gpart && p.all_levels_dense) {
-        if ((size_t)blocks * 256u >= chunks) hipLaunchKernelGGL((k_optimizer<true, false, true>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0,
-                s, p, oc, st, st_next, nx, lazy_below);
-        else hipLaunchKernelGGL((k_optimizer<true, false>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
+        if ((size_t)blocks * 256u >= chunks) MON_OPT_LAUNCH(true, false, true);
+        else MON_OPT_LAUNCH(true, false, false);
     }
-    else if (p.ema_step) hipLaunchKernelGGL((k_optimizer<false, true>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx,
-            lazy_below);
-    else hipLaunchKernelGGL((k_optimizer<false, false>), dim3(blocks + nx.cand_blocks + nx.pos_blocks), dim3(256), 0, s, p, oc, st, st_next, nx, lazy_below);
+    else if (p.ema_step) MON_OPT_LAUNCH(false, true, false);
+    else MON_OPT_LAUNCH(false, false, false);
+#undef MON_OPT_LAUNCH
 }
 
 }  // namespace mon

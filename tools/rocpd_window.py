@@ -22,6 +22,10 @@ def short(name):
     # one dispatch sequence, so that window [skip, skip + take) means the same iterations as for the other kernels
     if s.startswith("k_fused_train"):
         s = "k_fused_train"
+    # (likewise k_optimizer<.., LIVE>: the position blocks compact live samples once the grid is in use)
+    m = re.match(r"k_optimizer<(true|false), (true|false), (true|false), (true|false)>", s)
+    if m:
+        s = "k_optimizer<%s, %s, %s>" % m.group(1, 2, 3)
     return s
 
 
