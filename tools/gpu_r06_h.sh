@@ -1,5 +1,8 @@
 #!/usr/bin/env bash
-mkdir -p gpurun_out; export TMPDIR=/tmp
-for sh in "16 1" "64 3"; do python tools/shape_times.py $sh; MON_OPTIONS=use_graph=1 python tools/shape_times.py $sh; done 2>&1 | grep "^{"
-(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_a -o t -- python $GRAFT_REPO_ROOT/tools/shape_times.py 16 1 > /dev/null 2>&1)
-db=$(find /tmp/prof_a -name "*.db" | head -1); python tools/rocpd_stats.py "$db" gpurun_out/shape_16x1_stats.md > /dev/null 2>&1; head -18 gpurun_out/shape_16x1_stats.md | cut -c1-110
+mkdir -p gpurun_out
+( time python -m pytest tests -m gpu -q -x ) > gpurun_out/gpu_suite.log 2>&1; grep -E "passed|failed|error|^real" gpurun_out/gpu_suite.log | tail -5
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_r06.json 2> gpurun_out/bench_r06.err; python - <<'PY'
+import json
+j=json.load(open('gpurun_out/bench_r06.json'))
+print(j['value'], j['ms_per_step'], j['ms_per_step_repeats'], j['roofline']['frac'], j['roofline']['traffic_stale'], j['late_training']['ms_per_step'], j['late_training_with_occupancy_skipping']['ms_per_step'], j['offline_job']['ms_per_step'])
+PY
