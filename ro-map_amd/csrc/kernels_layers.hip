@@ -3,7 +3,8 @@
 // round 5 those shapes ran kernels_net.hip's one-sample-per-thread MLP and its LDS-staged weight-gradient kernel: 0.24 / 0.74 / 1.28 ms per base.json-sized
 // step for 16 neurons / 3 x 64 / 2 x 128, of which k_weight_grad alone was 29-54 % and the two MLP kernels 7-40 %.
 //
-// One launch per layer, one wave per 32 samples, v_mfma_f32_32x32x16_f16 with SAMPLES ON N:
+// One launch for the whole forward pass and one for the backward pass, one wave per 32 samples, v_mfma_f32_32x32x16_f16 with SAMPLES ON N (a layer's C/D
+// fragment is the next product's B fragment: activations stay in registers between layers):
 //   forward   Out^T[units x 32]  = W[units x K]   . In^T[K x 32]        A = rows of W (16-byte LDS reads), B = a sample's K features (16-byte global loads)
 //   backward  dIn^T[K x 32]      = W^T[K x units] . dAct^T[units x 32]  A = rows of W^T (transposed once per workgroup into LDS), masked by the ReLU of In
 //   dW[units x K] = sum over samples dAct[s][unit] In[s][k]: SAMPLES ON K -- both operands then want eight consecutive samples of one feature in 16 bytes,
@@ -25,109 +26,186 @@ __device__ __forceinline__ int frag_row(int r, int h) { return (r & 3) + 8 * (r 
 // XT[s / 8][f][s % 8]
 __device__ __forceinline__ size_t t_index(uint32_t s, int f, int F) { return ((size_t)(s >> 3) * (size_t)F + (size_t)f) * 8u + (s & 7u); }
 
-// ------------------------------------------------------------------ forward: Out[s][u] = act(sum_k W[u][k] In[s][k])
-template <int KB /* K / 16 */, int MB /* ceil(units / 32) */>
-__global__ void __launch_bounds__(256) k_layer_fwd(const half_t* __restrict__ Wg, int nout, const half_t* __restrict__ In, int ld_in, half_t* __restrict__ Out,
-                                                   int ld_out, half_t* __restrict__ OutT, half_t* __restrict__ InT, int relu, uint32_t n,
-                                                   const DevState* __restrict__ st) {
-    __shared__ __attribute__((aligned(16))) half_t w[kLayerMaxW * kLayerMaxW];
+// ------------------------------------------------------------------ the hand-over between two layers
+// A layer's C/D fragment holds, on half-wave h, register r = the unit frag_row(r, h) of its 32-unit block.  Taken as they are, registers 0..7 / 8..15 of block mb
+// are the B fragments of K blocks 2 mb / 2 mb + 1 of the NEXT product if that product's K slots are numbered to match: slot (kb, h, j) = unit
+// 32 (kb >> 1) + 16 (kb & 1) + 8 (j >> 2) + 4 h + (j & 3).  The A fragment of such a K block is then two 8-byte pieces of a weight row -- units U0 .. U0 + 3 and
+// U0 + 8 .. U0 + 11 with U0 = 32 (kb >> 1) + 16 (kb & 1) + 4 h -- so activations never move across lanes or through LDS between layers (the fused kernels' trick,
+// fused_device.h, without a pre-permuted fragment image: the permutation is in the LDS read addresses).
+__device__ __forceinline__ half8_t frag_a_perm(const half_t* row, int kb, int h) {
+    const int u0 = 32 * (kb >> 1) + 16 * (kb & 1) + 4 * h;
+    const half4_t lo = *reinterpret_cast<const half4_t*>(row + u0), hi = *reinterpret_cast<const half4_t*>(row + u0 + 8);
+    return half8_t{ lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
+}
+
+// A 32-unit x 32-sample block (C/D fragment: lo = registers 0..7, hi = 8..15) into T layout: through a per-wave LDS tile [unit][sample] (row stride 40 halves:
+// 16-byte aligned rows, the two half-waves' rows on different banks), read back as 16-byte pieces of eight samples -- lanes 0..31 take consecutive units of one
+// sample block, so a store instruction writes 512 contiguous bytes (2-byte stores straight from the registers wrote eight 16-byte pieces per instruction and
+// were a third of the two kernels' time).  DS operations of a wave execute in order: no barrier between the writes and the reads.
+constexpr int kTRow = 40;
+__device__ __forceinline__ void store_t_block(half_t* scr, const half8_t& lo, const half8_t& hi, half_t* __restrict__ XT, uint32_t s0, int ubase, int F, int lane) {
+    const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scr[frag_row(r, h) * kTRow + n] = r < 8 ? lo[r] : hi[r - 8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = lane + 64 * i, unit = p & 31, sb = p >> 5;
+        const half8_t v = *reinterpret_cast<const half8_t*>(scr + unit * kTRow + 8 * sb);
+        if (ubase + unit < F) *reinterpret_cast<half8_t*>(XT + (((size_t)(s0 >> 3) + (size_t)sb) * (size_t)F + (size_t)(ubase + unit)) * 8u) = v;
+    }
+}
+
+// ------------------------------------------------------------------ forward of the whole network: one launch, one wave per 32 samples
+// O = W_out relu(W_{NH-1} ... relu(W_0 E)); every layer's activations also go out row-major (Hid: the backward pass masks with them) and in T layout (HidT, ET:
+// the weight gradients).  Hid == nullptr: inference, nothing but O is written.
+template <int EPAD, int W>
+__global__ void __launch_bounds__(256) k_mlp_fwd_all(const half_t* __restrict__ params, int NH, const half_t* __restrict__ E, half_t* __restrict__ Hid,
+                                                     half_t* __restrict__ O, half_t* __restrict__ ET, half_t* __restrict__ HidT, uint32_t n,
+                                                     const DevState* __restrict__ st) {
+    constexpr int KB0 = EPAD / 16, MB = (W + 31) / 32, KBW = W / 16, kMaxHid = W == 128 ? 1 : 3, kLds = W * EPAD + kMaxHid * W * W + kOut * W;
+    __shared__ __attribute__((aligned(16))) half_t w[kLds];
+    __shared__ __attribute__((aligned(16))) half_t tscr[4][32 * kTRow];
     if (st && st->n_valid == 0u) return;
-    constexpr int nin = 16 * KB;
-    for (int i = threadIdx.x * 8; i < nout * nin; i += 256 * 8) *reinterpret_cast<half8_t*>(w + i) = *reinterpret_cast<const half8_t*>(Wg + i);
+    const int n_mlp = W * EPAD + (NH - 1) * W * W + kOut * W;
+    for (int i = threadIdx.x * 8; i < n_mlp; i += 256 * 8) *reinterpret_cast<half8_t*>(w + i) = *reinterpret_cast<const half8_t*>(params + i);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, h = lane >> 5, ld = NH * W;
     const uint32_t tiles = n >> 5;
     for (uint32_t t = blockIdx.x * 4u + (uint32_t)wave; t < tiles; t += gridDim.x * 4u) {
         const uint32_t s = t * 32u + (uint32_t)m;
-        half8_t bf[KB];
+        half8_t bf[KB0];
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) bf[kb] = *reinterpret_cast<const half8_t*>(In + (size_t)s * ld_in + 16 * kb + 8 * h);
-        if (InT) {
+        for (int kb = 0; kb < KB0; ++kb) bf[kb] = *reinterpret_cast<const half8_t*>(E + (size_t)s * EPAD + 16 * kb + 8 * h);
+        if (ET) {
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
+            for (int kb = 0; kb < KB0; ++kb)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) InT[t_index(s, 16 * kb + 8 * h + j, nin)] = bf[kb][j];
+                for (int j = 0; j < 8; ++j) ET[t_index(s, 16 * kb + 8 * h + j, EPAD)] = bf[kb][j];
         }
+        half8_t hb[2 * MB];                                   // the current layer's activations as the next product's B fragments
+        // relu + rounding of a block's accumulators; stores; the block's two B fragments
+        const auto finish = [&](const f16acc& acc, int mb, int layer, half8_t& lo, half8_t& hi) {
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            f16acc acc = { 0 };
-            const int row = 32 * mb + m;
+            for (int r = 0; r < 16; ++r) { const half_t v = (half_t)fmaxf(acc[r], 0.f); if (r < 8) lo[r] = v; else hi[r - 8] = v; }
+            if (Hid) {
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                half8_t a = {};
-                if (row < nout) a = *reinterpret_cast<const half8_t*>(w + row * nin + 16 * kb + 8 * h);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kb], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int u0 = 32 * mb + 4 * h + 8 * q;
-                if (u0 >= nout) continue;
-                half4_t o;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { const float v = acc[4 * q + c]; o[c] = (half_t)(relu ? fmaxf(v, 0.f) : v); }
-                *reinterpret_cast<half4_t*>(Out + (size_t)s * ld_out + u0) = o;
-                if (OutT) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) OutT[t_index(s, u0 + c, nout)] = o[c];
+                for (int q = 0; q < 4; ++q) {
+                    const int u0 = 32 * mb + 4 * h + 8 * q; if (u0 >= W) continue;
+                    const half4_t o = q < 2 ? half4_t{ lo[4 * q], lo[4 * q + 1], lo[4 * q + 2], lo[4 * q + 3] }
+                                            : half4_t{ hi[4 * q - 8], hi[4 * q - 7], hi[4 * q - 6], hi[4 * q - 5] };
+                    *reinterpret_cast<half4_t*>(Hid + (size_t)s * ld + (size_t)layer * W + u0) = o;
                 }
+                if (HidT) store_t_block(tscr[wave], lo, hi, HidT + (size_t)layer * n * W, t * 32u, 32 * mb, W, lane);
             }
+        };
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {                     // layer 0: K = the encoded features in their natural order
+            f16acc acc = { 0 }; const int row = 32 * mb + m;
+#pragma unroll
+            for (int kb = 0; kb < KB0; ++kb) { half8_t a = {}; if (row < W) a = *reinterpret_cast<const half8_t*>(w + row * EPAD + 16 * kb + 8 * h);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kb], acc, 0, 0, 0); }
+            finish(acc, mb, 0, hb[2 * mb], hb[2 * mb + 1]);
+        }
+        for (int l = 1; l < NH; ++l) {                        // hidden -> hidden
+            const half_t* wl = w + W * EPAD + (l - 1) * W * W;
+            half8_t nb[2 * MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                f16acc acc = { 0 }; const int row = 32 * mb + m;
+#pragma unroll
+                for (int kb = 0; kb < KBW; ++kb) { half8_t a = {}; if (row < W) a = frag_a_perm(wl + row * W, kb, h);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, hb[kb], acc, 0, 0, 0); }
+                finish(acc, mb, l, nb[2 * mb], nb[2 * mb + 1]);
+            }
+#pragma unroll
+            for (int k = 0; k < 2 * MB; ++k) hb[k] = nb[k];
+        }
+        {   // output layer: four rows, no activation
+            const half_t* wo = w + W * EPAD + (NH - 1) * W * W;
+            f16acc acc = { 0 };
+#pragma unroll
+            for (int kb = 0; kb < KBW; ++kb) { half8_t a = {}; if (m < kOut) a = frag_a_perm(wo + m * W, kb, h);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, hb[kb], acc, 0, 0, 0); }
+            if (h == 0) *reinterpret_cast<half4_t*>(O + (size_t)s * kOut) = half4_t{ (half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3] };
         }
     }
 }
 
-// ------------------------------------------------------------------ backward: dIn[s][k] = relu'(InAct[s][k]) * sum_u W[u][k] dAct[s][u]
-template <int KB /* ceil(units / 16): the K of this product */, int MB /* ceil(nin / 32) */>
-__global__ void __launch_bounds__(256) k_layer_bwd(const half_t* __restrict__ Wg, int nout, int nin, const half_t* __restrict__ dAct, int ld_d, int d_valid,
-                                                   const half_t* __restrict__ InAct, int ld_a, half_t* __restrict__ dIn, int ld_o, half_t* __restrict__ dInT,
-                                                   half_t* __restrict__ dActT, uint32_t n, const DevState* __restrict__ st) {
-    __shared__ __attribute__((aligned(16))) half_t wt[kLayerMaxW * kLayerMaxW];      // W^T [nin][16 KB], units beyond nout zero
+// ------------------------------------------------------------------ backward of the whole network (dh, dE): one launch
+// dh_{NH-1} = relu'(h_{NH-1}) * W_out^T dO;  dh_{l-1} = relu'(h_{l-1}) * W_l^T dh_l;  dE = W_0^T dh_0.  The transposed matrices are built once per workgroup in LDS;
+// every dh also goes out in T layout (dHidT, dOT) for the weight gradients.
+template <int EPAD, int W>
+__global__ void __launch_bounds__(256) k_mlp_bwd_all(const half_t* __restrict__ params, int NH, const half_t* __restrict__ Hid, const half_t* __restrict__ dO,
+                                                     half_t* __restrict__ dHid, half_t* __restrict__ dE, half_t* __restrict__ dOT, half_t* __restrict__ dHidT,
+                                                     uint32_t n, const DevState* __restrict__ st) {
+    constexpr int MB = (W + 31) / 32, KBW = W / 16, kMaxHid = W == 128 ? 1 : 3, kOffHid = W * 16, kOff0 = kOffHid + kMaxHid * W * W, kLds = kOff0 + EPAD * W;
+    __shared__ __attribute__((aligned(16))) half_t wt[kLds];      // W_out^T [W][16] (columns 4..15 zero) | W_l^T [W][W], l = 1 .. NH-1 | W_0^T [EPAD][W]
+    __shared__ __attribute__((aligned(16))) half_t tscr[4][32 * kTRow];
     if (st->n_valid == 0u) return;
-    constexpr int kp = 16 * KB;
-    for (int i = threadIdx.x; i < nin * kp; i += 256) { const int k = i / kp, u = i - k * kp; wt[i] = u < nout ? Wg[u * nin + k] : (half_t)0.f; }
+    {
+        const half_t* wo = params + W * EPAD + (NH - 1) * W * W;
+        for (int i = threadIdx.x; i < W * 16; i += 256) { const int u = i >> 4, c = i & 15; wt[i] = c < kOut ? wo[c * W + u] : (half_t)0.f; }
+        for (int l = 1; l < NH; ++l) { const half_t* wl = params + W * EPAD + (l - 1) * W * W; half_t* d = wt + kOffHid + (l - 1) * W * W;
+            for (int i = threadIdx.x; i < W * W; i += 256) { const int k = i / W, u = i - k * W; d[i] = wl[u * W + k]; } }
+        for (int i = threadIdx.x; i < EPAD * W; i += 256) { const int k = i / W, u = i - k * W; wt[kOff0 + i] = params[u * EPAD + k]; }
+    }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, h = lane >> 5, ld = NH * W;
     const uint32_t tiles = n >> 5;
     for (uint32_t t = blockIdx.x * 4u + (uint32_t)wave; t < tiles; t += gridDim.x * 4u) {
         const uint32_t s = t * 32u + (uint32_t)m;
-        half8_t bf[KB];
+        half8_t bo = {};
+        if (h == 0) { const half4_t v = *reinterpret_cast<const half4_t*>(dO + (size_t)s * kOut); bo[0] = v[0]; bo[1] = v[1]; bo[2] = v[2]; bo[3] = v[3];
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const int f0 = 16 * kb + 8 * h; bf[kb] = half8_t{};
-            if (f0 + 8 <= d_valid) bf[kb] = *reinterpret_cast<const half8_t*>(dAct + (size_t)s * ld_d + f0);
-            else if (f0 + 4 <= d_valid) { const half4_t v = *reinterpret_cast<const half4_t*>(dAct + (size_t)s * ld_d + f0);      // dL/dO: four values per sample
-                bf[kb][0] = v[0]; bf[kb][1] = v[1]; bf[kb][2] = v[2]; bf[kb][3] = v[3]; }
-        }
-        if (dActT) {
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const int f = 16 * kb + 8 * h + j; if (f < d_valid) dActT[t_index(s, f, d_valid)] = bf[kb][j]; }
-        }
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            f16acc acc = { 0 };
-            const int row = 32 * mb + m;
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                half8_t a = {};
-                if (row < nin) a = *reinterpret_cast<const half8_t*>(wt + row * kp + 16 * kb + 8 * h);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[kb], acc, 0, 0, 0);
-            }
+            for (int c = 0; c < kOut; ++c) dOT[t_index(s, c, kOut)] = v[c]; }
+        half8_t db[2 * MB];
+        // mask with the layer's activations, round, store row-major + T layout, hand the block over as two B fragments
+        const auto finish = [&](const f16acc& acc, int mb, int layer, half8_t& lo, half8_t& hi) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int k0 = 32 * mb + 4 * h + 8 * q;
-                if (k0 >= nin) continue;
-                half4_t act = { (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f };
-                if (InAct) act = *reinterpret_cast<const half4_t*>(InAct + (size_t)s * ld_a + k0);
-                half4_t o;
+                half4_t o = { (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f };
+                if (k0 < W) {
+                    const half4_t act = *reinterpret_cast<const half4_t*>(Hid + (size_t)s * ld + (size_t)layer * W + k0);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] = (half_t)(((float)act[c] > 0.f) ? acc[4 * q + c] : 0.f);
-                *reinterpret_cast<half4_t*>(dIn + (size_t)s * ld_o + k0) = o;
-                if (dInT) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) dInT[t_index(s, k0 + c, nin)] = o[c];
+                    for (int c = 0; c < 4; ++c) o[c] = (half_t)(((float)act[c] > 0.f) ? acc[4 * q + c] : 0.f);
+                    *reinterpret_cast<half4_t*>(dHid + (size_t)s * ld + (size_t)layer * W + k0) = o;
                 }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { if (q < 2) lo[4 * q + c] = o[c]; else hi[4 * q - 8 + c] = o[c]; }
             }
+            store_t_block(tscr[wave], lo, hi, dHidT + (size_t)layer * n * W, t * 32u, 32 * mb, W, lane);
+        };
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {                     // dh of the last hidden layer: K = the four outputs (one K block, natural order)
+            f16acc acc = { 0 }; const int row = 32 * mb + m;
+            half8_t a = {}; if (row < W) a = *reinterpret_cast<const half8_t*>(wt + row * 16 + 8 * h);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bo, acc, 0, 0, 0);
+            finish(acc, mb, NH - 1, db[2 * mb], db[2 * mb + 1]);
+        }
+        for (int l = NH - 1; l >= 1; --l) {
+            const half_t* wl = wt + kOffHid + (l - 1) * W * W;
+            half8_t nb[2 * MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                f16acc acc = { 0 }; const int row = 32 * mb + m;
+#pragma unroll
+                for (int kb = 0; kb < KBW; ++kb) { half8_t a = {}; if (row < W) a = frag_a_perm(wl + row * W, kb, h);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, db[kb], acc, 0, 0, 0); }
+                finish(acc, mb, l - 1, nb[2 * mb], nb[2 * mb + 1]);
+            }
+#pragma unroll
+            for (int k = 0; k < 2 * MB; ++k) db[k] = nb[k];
+        }
+        {   // dE: EPAD <= 32 rows, no mask
+            f16acc acc = { 0 };
+#pragma unroll
+            for (int kb = 0; kb < KBW; ++kb) { half8_t a = {}; if (m < EPAD) a = frag_a_perm(wt + kOff0 + m * W, kb, h);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, db[kb], acc, 0, 0, 0); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int k0 = 4 * h + 8 * q; if (k0 >= EPAD) continue;
+                *reinterpret_cast<half4_t*>(dE + (size_t)s * EPAD + k0) = half4_t{ (half_t)acc[4 * q], (half_t)acc[4 * q + 1], (half_t)acc[4 * q + 2],
+                        (half_t)acc[4 * q + 3] }; }
         }
     }
 }
@@ -215,28 +293,6 @@ __global__ void __launch_bounds__(1024) k_wgrad_reduce(const float* __restrict__
 // ------------------------------------------------------------------ launchers
 static uint32_t layer_grid(uint32_t n) { const uint32_t tiles = n >> 5, wgs = (tiles + 3u) / 4u; return wgs < 1u ? 1u : (wgs > 1024u ? 1024u : wgs); }
 
-static bool launch_layer_fwd(hipStream_t s, const uint16_t* W, int nout, int nin, const uint16_t* In, int ld_in, uint16_t* Out, int ld_out, uint16_t* OutT,
-        uint16_t* InT, int relu, uint32_t n, const DevState* st) {
-    const int KB = nin / 16, MB = (nout + 31) / 32;
-#define MON_FWD(K_, M_) if (KB == K_ && MB == M_) { hipLaunchKernelGGL((k_layer_fwd<K_, M_>), dim3(layer_grid(n)), dim3(256), 0, s, \
-        reinterpret_cast<const half_t*>(W), nout, reinterpret_cast<const half_t*>(In), ld_in, reinterpret_cast<half_t*>(Out), ld_out, \
-        reinterpret_cast<half_t*>(OutT), reinterpret_cast<half_t*>(InT), relu, n, st); return true; }
-    MON_FWD(1, 1) MON_FWD(2, 1) MON_FWD(4, 1) MON_FWD(8, 1) MON_FWD(1, 2) MON_FWD(2, 2) MON_FWD(4, 2) MON_FWD(8, 2) MON_FWD(1, 4) MON_FWD(2, 4) MON_FWD(4, 4)
-    MON_FWD(8, 4)
-#undef MON_FWD
-    return false;
-}
-static bool launch_layer_bwd(hipStream_t s, const uint16_t* W, int nout, int nin, const uint16_t* dAct, int ld_d, int d_valid, const uint16_t* InAct, int ld_a,
-        uint16_t* dIn, int ld_o, uint16_t* dInT, uint16_t* dActT, uint32_t n, const DevState* st) {
-    const int KB = (nout + 15) / 16, MB = (nin + 31) / 32;
-#define MON_BWD(K_, M_) if (KB == K_ && MB == M_) { hipLaunchKernelGGL((k_layer_bwd<K_, M_>), dim3(layer_grid(n)), dim3(256), 0, s, \
-        reinterpret_cast<const half_t*>(W), nout, nin, reinterpret_cast<const half_t*>(dAct), ld_d, d_valid, reinterpret_cast<const half_t*>(InAct), ld_a, \
-        reinterpret_cast<half_t*>(dIn), ld_o, reinterpret_cast<half_t*>(dInT), reinterpret_cast<half_t*>(dActT), n, st); return true; }
-    MON_BWD(1, 1) MON_BWD(2, 1) MON_BWD(4, 1) MON_BWD(8, 1) MON_BWD(1, 2) MON_BWD(2, 2) MON_BWD(4, 2) MON_BWD(8, 2) MON_BWD(1, 4) MON_BWD(2, 4) MON_BWD(4, 4)
-    MON_BWD(8, 4)
-#undef MON_BWD
-    return false;
-}
 constexpr uint32_t kWgradChunk = 512;          // samples per workgroup of k_weight_grad_mfma: 256 workgroups per layer at base.json's batch
 static uint32_t wgrad_rows(uint32_t n) { return (n + kWgradChunk - 1u) / kWgradChunk; }
 
@@ -252,28 +308,31 @@ static LayerT layer_t(const NetDims& nd, uint16_t* ws, uint32_t n) {
 // parameter offsets: W0 [W][Epad] | W_1 .. W_{NH-1} [W][W] | W_out [4][W]  (kernels_net.hip / frag_layout.h)
 static size_t w_off(const NetDims& nd, int layer) { return layer == 0 ? 0 : (size_t)nd.W * nd.Epad + (size_t)(layer - 1) * nd.W * nd.W; }
 
+#define MON_LAYERS_DISPATCH(CALL) do { switch (nd.Epad * 1000 + nd.W) { \
+        case 16016: { CALL(16, 16); return true; } case 16032: { CALL(16, 32); return true; } case 16064: { CALL(16, 64); return true; } \
+        case 16128: { CALL(16, 128); return true; } case 32016: { CALL(32, 16); return true; } case 32032: { CALL(32, 32); return true; } \
+        case 32064: { CALL(32, 64); return true; } case 32128: { CALL(32, 128); return true; } default: return false; } } while (0)
+static bool layers_shape_ok(const NetDims& nd, uint32_t n) { return nd.W <= kLayerMaxW && (n & 31u) == 0u && nd.NH >= 1 && nd.NH <= (nd.W == 128 ? 2 : 4); }
+
 bool launch_mlp_forward_layers(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n,
         const DevState* st, uint16_t* ws_T) {
-    if (nd.W > kLayerMaxW || (n & 31u) || !Hid) return false;
-    const int W = nd.W, NH = nd.NH, ld = NH * W; LayerT t{}; if (ws_T) t = layer_t(nd, ws_T, n);
-    bool ok = launch_layer_fwd(s, params, W, nd.Epad, E, nd.Epad, Hid, ld, ws_T ? t.HidT : nullptr, ws_T ? t.ET : nullptr, 1, n, st);
-    for (int l = 1; l < NH && ok; ++l)
-        ok = launch_layer_fwd(s, params + w_off(nd, l), W, W, Hid + (size_t)(l - 1) * W, ld, Hid + (size_t)l * W, ld, ws_T ? t.HidT + (size_t)l * n * W : nullptr, nullptr, 1, n, st);
-    if (ok) ok = launch_layer_fwd(s, params + w_off(nd, NH), kOut, W, Hid + (size_t)(NH - 1) * W, ld, O, kOut, nullptr, nullptr, 0, n, st);
-    return ok;
+    if (!layers_shape_ok(nd, n)) return false;
+    LayerT t{}; if (ws_T && Hid) t = layer_t(nd, ws_T, n);
+    auto H = [](const uint16_t* p) { return reinterpret_cast<const half_t*>(p); }; auto Hm = [](uint16_t* p) { return reinterpret_cast<half_t*>(p); };
+#define MON_FWD_ALL(E_, W_) hipLaunchKernelGGL((k_mlp_fwd_all<E_, W_>), dim3(layer_grid(n)), dim3(256), 0, s, H(params), nd.NH, H(E), Hm(Hid), Hm(O), Hm(t.ET), \
+        Hm(t.HidT), n, st)
+    MON_LAYERS_DISPATCH(MON_FWD_ALL);
+#undef MON_FWD_ALL
 }
 bool launch_mlp_backward_layers(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE,
         uint32_t n, const DevState* st, uint16_t* ws_T) {
-    if (nd.W > kLayerMaxW || (n & 31u) || !ws_T) return false;
-    const int W = nd.W, NH = nd.NH, ld = NH * W; const LayerT t = layer_t(nd, ws_T, n);
-    // dh_last = relu'(h_last) * W_out^T dO
-    bool ok = launch_layer_bwd(s, params + w_off(nd, NH), kOut, W, dO, kOut, kOut, Hid + (size_t)(NH - 1) * W, ld, dHid + (size_t)(NH - 1) * W, ld,
-            t.dHidT + (size_t)(NH - 1) * n * W, t.dOT, n, st);
-    for (int l = NH - 1; l >= 1 && ok; --l)
-        ok = launch_layer_bwd(s, params + w_off(nd, l), W, W, dHid + (size_t)l * W, ld, W, Hid + (size_t)(l - 1) * W, ld, dHid + (size_t)(l - 1) * W, ld,
-                t.dHidT + (size_t)(l - 1) * n * W, nullptr, n, st);
-    if (ok) ok = launch_layer_bwd(s, params, W, nd.Epad, dHid, ld, W, nullptr, 0, dE, nd.Epad, nullptr, nullptr, n, st);
-    return ok;
+    if (!layers_shape_ok(nd, n) || !ws_T) return false;
+    const LayerT t = layer_t(nd, ws_T, n);
+    auto H = [](const uint16_t* p) { return reinterpret_cast<const half_t*>(p); }; auto Hm = [](uint16_t* p) { return reinterpret_cast<half_t*>(p); };
+#define MON_BWD_ALL(E_, W_) hipLaunchKernelGGL((k_mlp_bwd_all<E_, W_>), dim3(layer_grid(n)), dim3(256), 0, s, H(params), nd.NH, H(Hid), H(dO), Hm(dHid), Hm(dE), \
+        Hm(t.dOT), Hm(t.dHidT), n, st)
+    MON_LAYERS_DISPATCH(MON_BWD_ALL);
+#undef MON_BWD_ALL
 }
 void launch_weight_grads_layers(hipStream_t s, const NetDims& nd, float* gmlp, uint32_t n, const DevState* st, uint16_t* ws_T) {
     const int W = nd.W, NH = nd.NH; const LayerT t = layer_t(nd, ws_T, n);

@@ -278,6 +278,7 @@ void launch_weight_grads(hipStream_t s, const NetDims& nd, const uint16_t* E, co
         uint32_t n, const DevState* st) {
     const dim3 grid((n + kChunk - 1) / kChunk), block(256);
     const int W = nd.W, NH = nd.NH, ld = NH * W;
+    if (W > kMaxWidth || nd.Epad > kMaxWidth) return;          // (k_weight_grad stages kChunk x kMaxWidth halves per operand; config.cpp admits no wider network)
     // layer 0: dW0[u][k] = sum dh0[u] * E[k]
     hipLaunchKernelGGL(k_weight_grad, grid, block, 0, s, dHid, ld, W, E, nd.Epad, nd.Epad, gmlp, n, st);
     for (int layer = 1; layer < NH; ++layer)

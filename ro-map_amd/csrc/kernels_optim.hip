@@ -585,7 +585,7 @@ void launch_optimizer(hipStream_t s, const ParamPtrs& p, const OptimConst& oc, c
         if ((size_t)blocks * 256u >= chunks) MON_OPT_LAUNCH(true, false, true);
         else MON_OPT_LAUNCH(true, false, false);
     }
-    else if (p.ema_step) MON_OPT_LAUNCH(false, true, false);
+    else if (p.lazy) MON_OPT_LAUNCH(false, true, false);
     else MON_OPT_LAUNCH(false, false, false);
 #undef MON_OPT_LAUNCH
 }

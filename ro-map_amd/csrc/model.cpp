@@ -489,7 +489,7 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
     if (records) { if ((rc = dev_alloc(m, m.P.rec, 4 * n))) return rc; }
     else if ((rc = dev_alloc(m, m.P.master, n, false)) || (rc = dev_alloc(m, m.P.m1, n)) || (rc = dev_alloc(m, m.P.m2, n)) ||
              (rc = steps16 ? dev_alloc(m, m.P.steps16, n + 8) : dev_alloc(m, m.P.steps, n))) return rc;
-    if ((rc = dev_alloc(m, m.P.half, n, false)) || (rc = dev_alloc(m, m.P.ema, n)) || (rc = dev_alloc(m, m.d_ema_step, records ? 16 : n / 8 + 1)) ||      // (chunk records keep the EMA step in their pad word; the pointer still says "lazy")
+    if ((rc = dev_alloc(m, m.P.half, n, false)) || (rc = dev_alloc(m, m.P.ema, n)) || (rc = records ? MON_OK : dev_alloc(m, m.d_ema_step, n / 8 + 1)) ||      // (chunk records keep the EMA step in their pad word: no array, ParamPtrs::lazy says "lazy")
         
         (rc = dev_alloc(m, m.P.gmlp, m.nd.n_mlp)) || (rc = dev_alloc(m, m.P.ggrid, m.n_grid))) return rc;
     {
@@ -787,12 +787,9 @@ static void collect_profile(Model& m) {
 }
 
 void mlp_forward_inference(Model& m, hipStream_t s, const uint16_t* params, const uint16_t* E, uint16_t* O, uint32_t n) {
-    const uint32_t piece = (m.oc.R * m.oc.S) & ~31u; uint32_t done = 0;
-    if (m.d_layers_T && m.B.Hid && piece) {
-        for (; done + 32u <= n; ) { const uint32_t cnt = std::min(piece, (n - done) & ~31u);
-            if (!launch_mlp_forward_layers(s, m.nd, params, E + (size_t)done * m.nd.Epad, m.B.Hid, O + (size_t)done * kOut, cnt, nullptr, nullptr)) break;
-            done += cnt; }
-    }
+    // (shapes outside the fused kernels: the whole-network MFMA forward, nothing but O written; a tail of fewer than 32 samples on the per-sample kernel)
+    const uint32_t body = m.d_layers_T ? (n & ~31u) : 0u; uint32_t done = 0;
+    if (body && launch_mlp_forward_layers(s, m.nd, params, E, nullptr, O, body, nullptr, nullptr)) done = body;
     if (done < n) launch_mlp_forward(s, m.nd, params, E + (size_t)done * m.nd.Epad, nullptr, O + (size_t)done * kOut, n - done, nullptr);
 }
 
@@ -925,7 +922,7 @@ static void enqueue_iteration(Model& m, int stages) {
         if (hybrid) { P.gpart = m.d_gpart; P.part_stride = m.part_halves; P.sl = m.scatter; P.all_levels_dense = 1; }
         P.half_tiles = (m.backend == 1 && P.gpart && P.all_levels_dense) ? m.d_half_tiles : nullptr;
         const bool lazy = m.lazy_ema && !(P.gpart && P.all_levels_dense);
-        P.ema_step = lazy ? m.d_ema_step : nullptr; if (lazy) m.ema_pending = true;
+        P.ema_step = lazy ? m.d_ema_step : nullptr; P.lazy = lazy ? 1 : 0; if (lazy) m.ema_pending = true;
         // (the LDS-scattered levels are a prefix: sizes grow with the level)              // every writer of ggrid on the fused path sets the chunk flags; the
         // unfused grid backward does not
         if (lazy && m.backend == 1 && m.d_touched && (m.lds_mask & (m.lds_mask + 1u)) == 0u) {
@@ -1148,7 +1145,7 @@ int model_render_snapshot(Model& m, mon_frame_bbox box, const float* pose16, int
 int ensure_ema_current(Model& m) {
     if (!m.ema_pending) return MON_OK;
     HIPCHECK(use_device(m.device)); model_leave_lane(m);
-    ParamPtrs P = m.P; P.ema_step = m.d_ema_step;
+    ParamPtrs P = m.P; P.ema_step = m.d_ema_step; P.lazy = 1;
     launch_ema_finalize(m.train_stream, P, m.opt, m.d_state);
     HIPCHECK(hipGetLastError()); m.ema_pending = false; m.weights_epoch = next_weights_epoch(); return MON_OK;
 }

@@ -103,8 +103,10 @@ struct ParamPtrs {
     // fused backend: dense fp16 partial gradient tables from k_grid_scatter (stride in halves); nullptr = unused
     const uint16_t* gpart; uint32_t part_stride;
     ScatterLevels sl;                                               // per-level partial-table counts
-    // lazy EMA (large tables): per 8-parameter chunk, the optimizer step its EMA is current for; nullptr = eager EMA
-    uint32_t* ema_step;
+    // lazy EMA (large tables; `lazy` set by the launcher's caller): per 8-parameter chunk, the optimizer step its EMA is current for -- in word 28 (the pad) of the
+    // chunk's record when `rec` is set (ema_step is nullptr then: nothing may index it), in this array otherwise.  set_params / upload_master leave the steps
+    // alone: new weights enter the average from the next step on, chunks that sat steps out catch up with the weights they find (as the arrays always did)
+    uint32_t* ema_step; int lazy;
     // lazy EMA + fused backend: one byte per 8-parameter chunk, set by whoever adds into ggrid (k_fused_train's atomics, k_big_accum),
     uint8_t* touched; uint32_t first_flag_chunk;
                                                                     // read and cleared by k_optimizer instead of scanning ggrid; chunks below first_flag_chunk

@@ -1,8 +1,4 @@
 #!/usr/bin/env bash
 mkdir -p gpurun_out
-( time python -m pytest tests -m gpu -q -x ) > gpurun_out/gpu_suite.log 2>&1; grep -E "passed|failed|error|^real" gpurun_out/gpu_suite.log | tail -5
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_r06.json 2> gpurun_out/bench_r06.err; python - <<'PY'
-import json
-j=json.load(open('gpurun_out/bench_r06.json'))
-print(j['value'], j['ms_per_step'], j['ms_per_step_repeats'], j['roofline']['frac'], j['roofline']['traffic_stale'], j['late_training']['ms_per_step'], j['late_training_with_occupancy_skipping']['ms_per_step'], j['offline_job']['ms_per_step'])
-PY
+python -m pytest tests/test_gpu_parity.py tests/test_step_variant.py tests/test_gpu_mesh.py tests/test_tile_render.py -m gpu -q -x -k "other_fully_fused or trains_the_grid or mesh or render" 2>&1 | tail -5 | tee gpurun_out/layers_test.log
+for sh in "16 1" "64 3" "128 2" "32 4" "16 4"; do python tools/shape_times.py $sh; done 2>&1 | grep "^{" | tee gpurun_out/shape_times.log
