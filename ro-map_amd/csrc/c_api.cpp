@@ -122,7 +122,7 @@ int mon_object_set_backend(mon_object* o, int backend) {
     if (backend == 1 && !fused_supported(o->m->nd, o->m->oc.S, o->m->oc.R)) { set_error("fused backend does not support this network shape");
         return MON_ERR_ARG; }
     if (backend != 0 && backend != 1) { set_error("backend must be 0 or 1"); return MON_ERR_ARG; }
-    o->m->backend = backend; o->m->next_ready = false; return MON_OK;
+    o->m->backend = backend; o->m->next_ready = false; o->m->b0_tiles_current = false; return MON_OK;
 }
 int mon_object_set_debug_dump(mon_object* o, int enable) { REQUIRE(o, "object"); o->m->fused_dump = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     o->m->graph_backend = -1; return MON_OK; }

@@ -58,10 +58,12 @@ __device__ __forceinline__ void store_t_block(half_t* scr, const half8_t& lo, co
 // ------------------------------------------------------------------ forward of the whole network: one launch, one wave per 32 samples
 // O = W_out relu(W_{NH-1} ... relu(W_0 E)); every layer's activations also go out row-major (Hid: the backward pass masks with them) and in T layout (HidT, ET:
 // the weight gradients).  Hid == nullptr: inference, nothing but O is written.
+// e_soa != nullptr: the encoded features come from k_encode_tiles' [L][n] half2 layout (four 4-byte loads per 16-wide K block instead of one 16-byte load)
+// and are ALSO written row-major to E_out (what the debug read-back and the tests see).
 template <int EPAD, int W>
 __global__ void __launch_bounds__(256) k_mlp_fwd_all(const half_t* __restrict__ params, int NH, const half_t* __restrict__ E, half_t* __restrict__ Hid,
                                                      half_t* __restrict__ O, half_t* __restrict__ ET, half_t* __restrict__ HidT, uint32_t n,
-                                                     const DevState* __restrict__ st) {
+                                                     const DevState* __restrict__ st, const half2_t* __restrict__ e_soa, int L, half_t* __restrict__ E_out) {
     constexpr int KB0 = EPAD / 16, MB = (W + 31) / 32, KBW = W / 16, kMaxHid = W == 128 ? 1 : 3, kLds = W * EPAD + kMaxHid * W * W + kOut * W;
     __shared__ __attribute__((aligned(16))) half_t w[kLds];
     __shared__ __attribute__((aligned(16))) half_t tscr[4][32 * kTRow];
@@ -74,8 +76,19 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_all(const half_t* __restrict__ 
     for (uint32_t t = blockIdx.x * 4u + (uint32_t)wave; t < tiles; t += gridDim.x * 4u) {
         const uint32_t s = t * 32u + (uint32_t)m;
         half8_t bf[KB0];
+        if (e_soa) {
 #pragma unroll
-        for (int kb = 0; kb < KB0; ++kb) bf[kb] = *reinterpret_cast<const half8_t*>(E + (size_t)s * EPAD + 16 * kb + 8 * h);
+            for (int kb = 0; kb < KB0; ++kb) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int level = 8 * kb + 4 * h + i; half2_t v = { (half_t)0.f, (half_t)0.f };       // (zero padding beyond L levels)
+                    if (level < L) v = e_soa[(size_t)level * n + s];
+                    bf[kb][2 * i] = v.x; bf[kb][2 * i + 1] = v.y; }
+                *reinterpret_cast<half8_t*>(E_out + (size_t)s * EPAD + 16 * kb + 8 * h) = bf[kb];
+            }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < KB0; ++kb) bf[kb] = *reinterpret_cast<const half8_t*>(E + (size_t)s * EPAD + 16 * kb + 8 * h);
+        }
         if (ET) {
 #pragma unroll
             for (int kb = 0; kb < KB0; ++kb)
@@ -314,13 +327,23 @@ static size_t w_off(const NetDims& nd, int layer) { return layer == 0 ? 0 : (siz
         case 32064: { CALL(32, 64); return true; } case 32128: { CALL(32, 128); return true; } default: return false; } } while (0)
 static bool layers_shape_ok(const NetDims& nd, uint32_t n) { return nd.W <= kLayerMaxW && (n & 31u) == 0u && nd.NH >= 1 && nd.NH <= (nd.W == 128 ? 2 : 4); }
 
+// backend 0's positions float [n][3] -> k_encode_tiles' float4 x_all, and the batch's ray count where k_encode_tiles looks for it
+__global__ void __launch_bounds__(256) k_pts_to_x4(const float* __restrict__ pts, float4_t* __restrict__ x4, uint32_t n, DevState* __restrict__ st) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0u) st->n_valid_pre = st->n_valid;
+    if (i < n) x4[i] = float4_t{ pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], 0.f };
+}
+void launch_pts_to_x4(hipStream_t s, const float* pts, float* x_all, uint32_t n, DevState* st) {
+    hipLaunchKernelGGL(k_pts_to_x4, dim3((n + 255u) / 256u), dim3(256), 0, s, pts, reinterpret_cast<float4_t*>(x_all), n, st);
+}
+
 bool launch_mlp_forward_layers(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n,
-        const DevState* st, uint16_t* ws_T) {
+        const DevState* st, uint16_t* ws_T, const uint16_t* e_soa, uint16_t* E_out) {
     if (!layers_shape_ok(nd, n)) return false;
     LayerT t{}; if (ws_T && Hid) t = layer_t(nd, ws_T, n);
     auto H = [](const uint16_t* p) { return reinterpret_cast<const half_t*>(p); }; auto Hm = [](uint16_t* p) { return reinterpret_cast<half_t*>(p); };
 #define MON_FWD_ALL(E_, W_) hipLaunchKernelGGL((k_mlp_fwd_all<E_, W_>), dim3(layer_grid(n)), dim3(256), 0, s, H(params), nd.NH, H(E), Hm(Hid), Hm(O), Hm(t.ET), \
-        Hm(t.HidT), n, st)
+        Hm(t.HidT), n, st, reinterpret_cast<const half2_t*>(e_soa), nd.L, Hm(E_out))
     MON_LAYERS_DISPATCH(MON_FWD_ALL);
 #undef MON_FWD_ALL
 }

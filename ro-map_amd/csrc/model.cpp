@@ -587,6 +587,13 @@ static int model_init(Model& m, Dataset* ds, const mon_config& cfg, int class_id
             if ((rc = dev_alloc(m, m.d_de_soa, (size_t)m.nd.L * Btrain * 2)) || (rc = dev_alloc(m, m.d_x_soa, 4 * (size_t)Btrain)) ||
                 (rc = dev_alloc(m, m.d_gpart, (size_t)m.scatter.max_P * m.part_halves))) return rc;
             m.hybrid_scatter = true;
+            // ... and their forward encode from LDS level tiles like the fused chain's (k_encode_tiles; same batch-size rule, option lds_encode)
+            const bool tiles_pay_b0 = options().lds_encode >= 2 || Btrain >= 98304u;
+            if (m.d_layers_T && options().lds_encode && tiles_pay_b0 && encode_tiles_supported(m.lt, m.nd)) {
+                if ((rc = dev_alloc(m, m.d_x_all, 4 * (size_t)Btrain)) || (rc = dev_alloc(m, m.d_e_soa, (size_t)m.nd.L * Btrain * 2))
+                        || (rc = dev_alloc(m, m.d_half_tiles, (size_t)m.n_grid + 64))) return rc;
+                encode_tiles_setup_device();
+            }
         }
     }
     if (cfg.occupancy_skip && fused_supported(m.nd, S, m.oc.R)) {
@@ -852,9 +859,21 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_grid_backward(s, m.lt, m.nd, m.B.pts, m.B.dE, m.P.ggrid, B, m.d_state);
         } else if (m.backend == 0) {
             ProfScope ps(m, MON_K_FWDBWD);
+            // the layer-kernel shapes at base.json-sized batches: the encode from LDS level tiles (k_encode_tiles, bit-identical to the gathers) -- the tile image
+            // is kept current by k_optimizer in whole steps and rebuilt here after anything else touched the weights
+            const bool tiles_b0 = m.d_layers_T && m.d_e_soa && m.d_half_tiles && options().lds_encode != 0;
+            if (tiles_b0) {
+                if (!m.b0_tiles_current) { launch_build_tiles_image(s, m.lf, m.nd, m.P.half, m.d_half_tiles); m.b0_tiles_current = true; }
+                launch_pts_to_x4(s, m.B.pts, m.d_x_all, B, m.d_state);
+                launch_encode_tiles(s, m.lf, m.nd, m.d_half_tiles, m.d_x_all, m.d_e_soa, B, m.d_state, nullptr, m.ds->ptrs(), m.oc);
+            } else
             launch_encode(s, m.lt, m.nd, m.P.half, m.B.pts, m.B.E, B, m.d_state);
-            // (shapes outside the fused kernels: one MFMA launch per layer, kernels_layers.hip)
-            if (!(m.d_layers_T && launch_mlp_forward_layers(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state, m.d_layers_T)))
+            // (shapes outside the fused kernels: whole-network MFMA kernels, kernels_layers.hip)
+            if (tiles_b0) {
+                if (!launch_mlp_forward_layers(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state, m.d_layers_T, m.d_e_soa, m.B.E))
+                    launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);         // (not reached: the shapes with a T workspace are the kernels' shapes)
+            }
+            else if (!(m.d_layers_T && launch_mlp_forward_layers(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state, m.d_layers_T)))
                 launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);
             launch_composite_grad(s, m.B, m.oc, m.d_state);
             if (m.d_layers_T && launch_mlp_backward_layers(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state, m.d_layers_T))
@@ -920,7 +939,8 @@ static void enqueue_iteration(Model& m, int stages) {
         if (m.backend == 1 && m.lds_mask) { P.gpart = m.d_gpart; P.part_stride = m.part_halves; P.sl = m.scatter;
             P.all_levels_dense = (m.lds_mask == ((1u << m.nd.L) - 1u)) ? 1 : 0; }
         if (hybrid) { P.gpart = m.d_gpart; P.part_stride = m.part_halves; P.sl = m.scatter; P.all_levels_dense = 1; }
-        P.half_tiles = (m.backend == 1 && P.gpart && P.all_levels_dense) ? m.d_half_tiles : nullptr;
+        P.half_tiles = ((m.backend == 1 || hybrid) && P.gpart && P.all_levels_dense) ? m.d_half_tiles : nullptr;
+        if (m.backend == 0) m.b0_tiles_current = hybrid && P.half_tiles != nullptr;        // (any other optimizer leaves the tile image behind the weights)
         const bool lazy = m.lazy_ema && !(P.gpart && P.all_levels_dense);
         P.ema_step = lazy ? m.d_ema_step : nullptr; P.lazy = lazy ? 1 : 0; if (lazy) m.ema_pending = true;
         // (the LDS-scattered levels are a prefix: sizes grow with the level)              // every writer of ggrid on the fused path sets the chunk flags; the
@@ -1290,6 +1310,7 @@ int model_set_params(Model& m, const float* master, size_t n) {
     { const int urc = upload_master(m, master); if (urc) return urc; }
     HIPCHECK(hipStreamSynchronize(m.train_stream));
     m.next_ready = false;                                   // the fragment image no longer matches the weights
+    m.b0_tiles_current = false;
     m.weights_epoch = next_weights_epoch();
     { const int rc = publish_snapshot(m); if (rc) return rc; }   // (viewers of an untrained object see the weights just set:
     // the snapshot is complete before the call returns, so no render prefers the one before it)

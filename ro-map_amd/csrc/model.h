@@ -228,7 +228,10 @@ void launch_grid_backward(hipStream_t s, const LevelTable& lt, const NetDims& nd
 // (layers_workspace_halves(nd, n) halves; nullptr = forward only, nothing is kept).  false: shape / batch not covered, nothing was launched
 size_t layers_workspace_halves(const NetDims& nd, uint32_t n);
 bool launch_mlp_forward_layers(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n,
-        const DevState* st_or_null, uint16_t* ws_T_or_null);
+        const DevState* st_or_null, uint16_t* ws_T_or_null,
+        // the features as k_encode_tiles wrote them ([L][n] half2) instead of row-major E; E_out: where the row-major copy goes
+        const uint16_t* e_soa_or_null = nullptr, uint16_t* E_out = nullptr);
+void launch_pts_to_x4(hipStream_t s, const float* pts, float* x_all, uint32_t n, DevState* st);
 bool launch_mlp_backward_layers(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE,
         uint32_t n, const DevState* st, uint16_t* ws_T);
 void launch_weight_grads_layers(hipStream_t s, const NetDims& nd, float* gmlp, uint32_t n, const DevState* st, uint16_t* ws_T);
@@ -356,6 +359,7 @@ struct Model {
     float* d_x_all = nullptr; uint16_t* d_e_soa = nullptr; uint16_t* d_half_tiles = nullptr;
     // network shapes outside the fused kernels (backend 0 by necessity) whose levels all fit the LDS scatter plan: whole training steps scatter through k_grid_scatter
     bool hybrid_scatter = false;
+    bool b0_tiles_current = false;            // layer-kernel shapes on the level-tile encode: the tile image matches the fp16 weights (k_optimizer keeps it so in whole steps)
     uint16_t* d_layers_T = nullptr;          // T-layout workspace of the MFMA layer kernels (shapes outside the fused kernels)
     uint16_t* d_gpart = nullptr; ScatterLevels scatter{}; uint32_t lds_mask = 0;   // k_grid_scatter: partial tables, plan, levels it covers
     // halves of ONE partial table: the grid parameters of the LDS-scattered levels (a prefix of the levels), not of the whole table

@@ -300,19 +300,35 @@ def test_nondefault_hyperparameters_match_oracle(pkg, orc, small_scene, backend)
 @pytest.mark.parametrize("W,NH,L,backends", [(128, 1, 16, (0, 1)), (128, 1, 6, (1,)), (128, 2, 8, (0,)), (16, 1, 16, (0,)), (16, 2, 4, (0,)), (64, 3, 16, (0,)),
                                              (32, 4, 8, (0,)), (16, 4, 12, (0,)), (128, 2, 16, (0,)), (64, 4, 6, (0,)), (32, 3, 16, (0,))],
                          ids=["1x128", "1x128-L6", "2x128", "1x16", "2x16", "3x64", "4x32", "4x16", "2x128-L16", "4x64-L6", "3x32-L16"])
-def test_the_other_fully_fused_mlp_widths_match_oracle(pkg, orc, small_scene, W, NH, L, backends):
+@pytest.mark.parametrize("lds", [1, 2], ids=["gather-encode", "tile-encode"])
+def test_the_other_fully_fused_mlp_widths_match_oracle(pkg, orc, small_scene, W, NH, L, backends, lds):
     """tcnn's FullyFusedMLP takes 16 / 32 / 64 / 128 neurons and base.json:30-36 is the user's to edit: one hidden layer of 128 runs on the fused MFMA kernels
     (the default backend for it), 2 x 128, 16 neurons (half an MFMA tile) and three / four hidden layers on the layer-at-a-time kernels.  Forward / backward and three optimizer steps
     against the oracle, a render against the oracle's, both encoder paddings."""
     _need_gpu(pkg)
     kw = dict(rays_per_batch=256, n_levels=L, log2_hashmap_size=15, n_neurons=W, n_hidden_layers=NH)
     ds, o = ge.make_problem(pkg, small_scene, kw); assert int(o.info().backend) == (1 if (W == 128 and NH == 1) else 0); o.close(); ds.close()
+    # lds = 2: the layer-kernel shapes' encode from LDS level tiles (what they use from 3072 rays per batch on), forced at this small batch -- same bars: the
+    # features are bit-exact either way, three whole steps exercise k_optimizer keeping the tile image current, the stage-wise call its rebuild
+    if lds == 2 and (W == 128 and NH == 1):
+        pytest.skip("a fused shape: its tile chain has tests of its own")
+    old_lds = pkg.get_option("lds_encode"); pkg.set_option("lds_encode", lds)
+    try:
+        _other_widths_body(pkg, orc, small_scene, W, NH, L, backends, kw, lds)
+    finally:
+        pkg.set_option("lds_encode", old_lds)
+
+
+def _other_widths_body(pkg, orc, small_scene, W, NH, L, backends, kw, lds):
     for backend in backends:
         ds, obj, ref = _pair(pkg, orc, small_scene, kw, backend)
         p = pattern_params(ref); obj.set_params(p); ref.set_params(p)
         obj.train_stages(1 | 2); ref.generate_batch(); ref.forward_backward()
         assert int(obj.buffer("state")[2]) == ref.n_valid > 0
         assert np.array_equal(obj.buffer("E"), ref.buffer("E")), "hash-grid encode must be bit-exact"
+        if lds == 2 and backend == 0:                       # ... and it did come from the tiles: k_encode_tiles' output holds the same features
+            B_, Ep_ = ref.R * ref.S, ref.Epad
+            assert np.array_equal(obj.buffer("e_soa").reshape(L, B_, 2).transpose(1, 0, 2).reshape(B_, 2 * L), ref.buffer("E").reshape(B_, Ep_)[:, :2 * L])
         # (MFMA summation order -- the fused kernels, and since round 6 the layer-at-a-time kernels of the shapes outside them: a hidden activation on a
         # rounding boundary lands one fp16 ulp away now and then, and the layers behind it carry that on)
         close_half(obj.buffer("O"), ref.buffer("O"), "network output", frac_ok=0.999)
