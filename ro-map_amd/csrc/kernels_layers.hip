@@ -234,7 +234,9 @@ struct WgradJobs { WgradJob j[5]; int n; };
 constexpr int kWgUnroll = 4;
 __global__ void __launch_bounds__(256) k_weight_grad_mfma(WgradJobs jobs, float* __restrict__ partials, uint32_t n_mlp, uint32_t n, uint32_t chunk,
                                                           const DevState* __restrict__ st) {
-    __shared__ float red[2 * 1024];                         // the cross-wave sum of the (at most two) blocks of a job whose waves split the samples
+    // the cross-wave sum of the (at most two) blocks of a job whose waves split the samples: a slice per sample share, summed after a barrier (LDS float
+    // atomics run at ~0.35 per clock and CU: 4096 of them per workgroup were 5-6 us of the small shapes' launch)
+    __shared__ float red[4][2 * 1024];
     if (st->n_valid == 0u) return;
     const WgradJob jb = jobs.j[blockIdx.y];
     const half_t* __restrict__ AT = jb.AT; const half_t* __restrict__ BT = jb.BT; const int rows = jb.rows, cols = jb.cols;
@@ -243,7 +245,6 @@ __global__ void __launch_bounds__(256) k_weight_grad_mfma(WgradJobs jobs, float*
     const int nsub = TB >= 4 ? 1 : 4 / TB, sub = TB >= 4 ? 0 : wave / TB, b0 = TB >= 4 ? wave : wave % TB;
     const uint32_t c0 = blockIdx.x * chunk, c1 = min(c0 + chunk, n), per = ((c1 - c0) / 16u + (uint32_t)nsub - 1u) / (uint32_t)nsub * 16u;
     const uint32_t s_lo = c0 + (uint32_t)sub * per, s_hi = min(s_lo + per, c1);
-    if (nsub > 1) { for (int i = threadIdx.x; i < TB * 1024; i += 256) red[i] = 0.f; __syncthreads(); }
     f16acc acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = f16acc{ 0 };
@@ -267,10 +268,12 @@ __global__ void __launch_bounds__(256) k_weight_grad_mfma(WgradJobs jobs, float*
     if (nsub > 1) {
         const int bi = b0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(&red[bi * 1024 + frag_row(r, h) * 32 + m], acc[0][r]);
+        for (int r = 0; r < 16; ++r) red[sub][bi * 1024 + frag_row(r, h) * 32 + m] = acc[0][r];
         __syncthreads();
         for (int i = threadIdx.x; i < TB * 1024; i += 256) { const int bq = i >> 10, rr = (i >> 5) & 31, cc = i & 31, mb = bq / NBt, nb = bq - mb * NBt;
-            const int u = 32 * mb + rr, k = 32 * nb + cc; if (u < rows && k < cols) out[u * cols + k] = red[i]; }
+            const int u = 32 * mb + rr, k = 32 * nb + cc;
+            float v = red[0][i]; for (int q = 1; q < nsub; ++q) v += red[q][i];
+            if (u < rows && k < cols) out[u * cols + k] = v; }
         return;
     }
 #pragma unroll
