@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_all(const half_t* __restrict__ 
 template <int EPAD, int W>
 __global__ void __launch_bounds__(256) k_mlp_bwd_all(const half_t* __restrict__ params, int NH, const half_t* __restrict__ Hid, const half_t* __restrict__ dO,
                                                      half_t* __restrict__ dHid, half_t* __restrict__ dE, half_t* __restrict__ dOT, half_t* __restrict__ dHidT,
-                                                     uint32_t n, const DevState* __restrict__ st) {
+                                                     uint32_t n, const DevState* __restrict__ st, int keep_rowmajor /* 0: nobody reads dHid row-major (whole steps) */) {
     constexpr int MB = (W + 31) / 32, KBW = W / 16, kMaxHid = W == 128 ? 1 : 3, kOffHid = W * 16, kOff0 = kOffHid + kMaxHid * W * W, kLds = kOff0 + EPAD * W;
     __shared__ __attribute__((aligned(16))) half_t wt[kLds];      // W_out^T [W][16] (columns 4..15 zero) | W_l^T [W][W], l = 1 .. NH-1 | W_0^T [EPAD][W]
     __shared__ __attribute__((aligned(16))) half_t tscr[4][32 * kTRow];
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_all(const half_t* __restrict__ 
                     const half4_t act = *reinterpret_cast<const half4_t*>(Hid + (size_t)s * ld + (size_t)layer * W + k0);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) o[c] = (half_t)(((float)act[c] > 0.f) ? acc[4 * q + c] : 0.f);
-                    *reinterpret_cast<half4_t*>(dHid + (size_t)s * ld + (size_t)layer * W + k0) = o;
+                    if (keep_rowmajor) *reinterpret_cast<half4_t*>(dHid + (size_t)s * ld + (size_t)layer * W + k0) = o;
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { if (q < 2) lo[4 * q + c] = o[c]; else hi[4 * q - 8 + c] = o[c]; }
@@ -351,12 +351,12 @@ bool launch_mlp_forward_layers(hipStream_t s, const NetDims& nd, const uint16_t*
 #undef MON_FWD_ALL
 }
 bool launch_mlp_backward_layers(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE,
-        uint32_t n, const DevState* st, uint16_t* ws_T) {
+        uint32_t n, const DevState* st, uint16_t* ws_T, bool keep_rowmajor) {
     if (!layers_shape_ok(nd, n) || !ws_T) return false;
     const LayerT t = layer_t(nd, ws_T, n);
     auto H = [](const uint16_t* p) { return reinterpret_cast<const half_t*>(p); }; auto Hm = [](uint16_t* p) { return reinterpret_cast<half_t*>(p); };
 #define MON_BWD_ALL(E_, W_) hipLaunchKernelGGL((k_mlp_bwd_all<E_, W_>), dim3(layer_grid(n)), dim3(256), 0, s, H(params), nd.NH, H(Hid), H(dO), Hm(dHid), Hm(dE), \
-        Hm(t.dOT), Hm(t.dHidT), n, st)
+        Hm(t.dOT), Hm(t.dHidT), n, st, keep_rowmajor ? 1 : 0)
     MON_LAYERS_DISPATCH(MON_BWD_ALL);
 #undef MON_BWD_ALL
 }

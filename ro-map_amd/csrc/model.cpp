@@ -849,7 +849,7 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_encode(s, m.lt, m.nd, m.P.half, m.B.pts, m.B.E, B, m.d_state);                             // :1545 forward of the compacted batch
             if (!(m.d_layers_T && launch_mlp_forward_layers(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state, m.d_layers_T)))
                 launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);
-            if (m.d_layers_T && launch_mlp_backward_layers(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state, m.d_layers_T))
+            if (m.d_layers_T && launch_mlp_backward_layers(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state, m.d_layers_T, stages != 7))
                 launch_weight_grads_layers(s, m.nd, m.P.gmlp, B, m.d_state, m.d_layers_T);
             else {
                 launch_mlp_backward(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state);          // :1547
@@ -876,7 +876,7 @@ static void enqueue_iteration(Model& m, int stages) {
             else if (!(m.d_layers_T && launch_mlp_forward_layers(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state, m.d_layers_T)))
                 launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);
             launch_composite_grad(s, m.B, m.oc, m.d_state);
-            if (m.d_layers_T && launch_mlp_backward_layers(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state, m.d_layers_T))
+            if (m.d_layers_T && launch_mlp_backward_layers(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state, m.d_layers_T, stages != 7))
                 launch_weight_grads_layers(s, m.nd, m.P.gmlp, B, m.d_state, m.d_layers_T);
             else {
                 launch_mlp_backward(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state);

@@ -233,7 +233,8 @@ bool launch_mlp_forward_layers(hipStream_t s, const NetDims& nd, const uint16_t*
         const uint16_t* e_soa_or_null = nullptr, uint16_t* E_out = nullptr);
 void launch_pts_to_x4(hipStream_t s, const float* pts, float* x_all, uint32_t n, DevState* st);
 bool launch_mlp_backward_layers(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE,
-        uint32_t n, const DevState* st, uint16_t* ws_T);
+        uint32_t n, const DevState* st, uint16_t* ws_T,
+        bool keep_rowmajor = true /* false: dHid is written in T layout only -- the weight gradients' copy; the debug read-back then sees stale rows */);
 void launch_weight_grads_layers(hipStream_t s, const NetDims& nd, float* gmlp, uint32_t n, const DevState* st, uint16_t* ws_T);
 struct Model;
 // inference forward of n samples E -> O with the layer kernels where the object has them (Hid of the training batch as scratch, piece by piece), else k_mlp_forward
