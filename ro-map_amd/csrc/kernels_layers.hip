@@ -63,7 +63,8 @@ __device__ __forceinline__ void store_t_block(half_t* scr, const half8_t& lo, co
 template <int EPAD, int W>
 __global__ void __launch_bounds__(256) k_mlp_fwd_all(const half_t* __restrict__ params, int NH, const half_t* __restrict__ E, half_t* __restrict__ Hid,
                                                      half_t* __restrict__ O, half_t* __restrict__ ET, half_t* __restrict__ HidT, uint32_t n,
-                                                     const DevState* __restrict__ st, const half2_t* __restrict__ e_soa, int L, half_t* __restrict__ E_out) {
+                                                     const DevState* __restrict__ st, const half2_t* __restrict__ e_soa, int L, half_t* __restrict__ E_out,
+                                                     uint16_t* __restrict__ relu_bits /* whole steps: the ReLU masks as bits instead of the row-major activations */) {
     constexpr int KB0 = EPAD / 16, MB = (W + 31) / 32, KBW = W / 16, kMaxHid = W == 128 ? 1 : 3, kLds = W * EPAD + kMaxHid * W * W + kOut * W;
     __shared__ __attribute__((aligned(16))) half_t w[kLds];
     __shared__ __attribute__((aligned(16))) half_t tscr[4][32 * kTRow];
@@ -100,9 +101,15 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_all(const half_t* __restrict__ 
         const auto finish = [&](const f16acc& acc, int mb, int layer, half8_t& lo, half8_t& hi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const half_t v = (half_t)fmaxf(acc[r], 0.f); if (r < 8) lo[r] = v; else hi[r - 8] = v; }
+            if (relu_bits) {          // bit r: the ROUNDED activation of register r is positive (what the backward pass masks with), one 16-bit word per lane
+                uint32_t bits = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bits |= ((float)(r < 8 ? lo[r] : hi[r - 8]) > 0.f) ? (1u << r) : 0u;
+                relu_bits[((size_t)(layer * MB + mb) * tiles + t) * 64u + (uint32_t)lane] = (uint16_t)bits;
+            }
             if (Hid) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < 4 && !relu_bits; ++q) {
                     const int u0 = 32 * mb + 4 * h + 8 * q; if (u0 >= W) continue;
                     const half4_t o = q < 2 ? half4_t{ lo[4 * q], lo[4 * q + 1], lo[4 * q + 2], lo[4 * q + 3] }
                                             : half4_t{ hi[4 * q - 8], hi[4 * q - 7], hi[4 * q - 6], hi[4 * q - 5] };
@@ -150,7 +157,8 @@ __global__ void __launch_bounds__(256) k_mlp_fwd_all(const half_t* __restrict__ 
 template <int EPAD, int W>
 __global__ void __launch_bounds__(256) k_mlp_bwd_all(const half_t* __restrict__ params, int NH, const half_t* __restrict__ Hid, const half_t* __restrict__ dO,
                                                      half_t* __restrict__ dHid, half_t* __restrict__ dE, half_t* __restrict__ dOT, half_t* __restrict__ dHidT,
-                                                     uint32_t n, const DevState* __restrict__ st, int keep_rowmajor /* 0: nobody reads dHid row-major (whole steps) */) {
+                                                     uint32_t n, const DevState* __restrict__ st, int keep_rowmajor /* 0: nobody reads dHid row-major (whole steps) */,
+                                                     const uint16_t* __restrict__ relu_bits /* the forward pass's mask bits; nullptr: masks from row-major Hid */) {
     constexpr int MB = (W + 31) / 32, KBW = W / 16, kMaxHid = W == 128 ? 1 : 3, kOffHid = W * 16, kOff0 = kOffHid + kMaxHid * W * W, kLds = kOff0 + EPAD * W;
     __shared__ __attribute__((aligned(16))) half_t wt[kLds];      // W_out^T [W][16] (columns 4..15 zero) | W_l^T [W][W], l = 1 .. NH-1 | W_0^T [EPAD][W]
     __shared__ __attribute__((aligned(16))) half_t tscr[4][32 * kTRow];
@@ -174,14 +182,21 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_all(const half_t* __restrict__ 
         half8_t db[2 * MB];
         // mask with the layer's activations, round, store row-major + T layout, hand the block over as two B fragments
         const auto finish = [&](const f16acc& acc, int mb, int layer, half8_t& lo, half8_t& hi) {
+            uint32_t bits = 0u;
+            if (relu_bits) bits = relu_bits[((size_t)(layer * MB + mb) * tiles + t) * 64u + (uint32_t)lane];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int k0 = 32 * mb + 4 * h + 8 * q;
                 half4_t o = { (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f };
                 if (k0 < W) {
-                    const half4_t act = *reinterpret_cast<const half4_t*>(Hid + (size_t)s * ld + (size_t)layer * W + k0);
+                    if (relu_bits) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = (half_t)(((float)act[c] > 0.f) ? acc[4 * q + c] : 0.f);
+                        for (int c = 0; c < 4; ++c) o[c] = (half_t)(((bits >> (4 * q + c)) & 1u) ? acc[4 * q + c] : 0.f);
+                    } else {
+                        const half4_t act = *reinterpret_cast<const half4_t*>(Hid + (size_t)s * ld + (size_t)layer * W + k0);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = (half_t)(((float)act[c] > 0.f) ? acc[4 * q + c] : 0.f);
+                    }
                     if (keep_rowmajor) *reinterpret_cast<half4_t*>(dHid + (size_t)s * ld + (size_t)layer * W + k0) = o;
                 }
 #pragma unroll
@@ -315,11 +330,14 @@ static uint32_t wgrad_rows(uint32_t n) { return (n + kWgradChunk - 1u) / kWgradC
 // T-layout workspace of a batch of n samples: ET [Epad] | dOT [4] | HidT [NH][W] | dHidT [NH][W], each n halfs per feature
 // followed by the weight-gradient partials, fp32 [chunks][n_mlp]
 static size_t layers_t_halves(const NetDims& nd, uint32_t n) { return (((size_t)n * (size_t)(nd.Epad + kOut + 2 * nd.NH * nd.W)) + 7u) & ~(size_t)7u; }
-size_t layers_workspace_halves(const NetDims& nd, uint32_t n) { return layers_t_halves(nd, n) + 2u * (size_t)wgrad_rows(n) * nd.n_mlp; }
-struct LayerT { uint16_t *ET, *dOT, *HidT, *dHidT; float* partials; };
+// ... the weight-gradient partials, fp32 [chunks][n_mlp], and the ReLU mask bits, uint16 [layer][unit block][tile][64 lanes]
+static size_t layers_part_halves(const NetDims& nd, uint32_t n) { return 2u * (size_t)wgrad_rows(n) * nd.n_mlp; }
+static size_t layers_bits_halves(const NetDims& nd, uint32_t n) { return (size_t)nd.NH * (size_t)((nd.W + 31) / 32) * 2u * (size_t)n; }
+size_t layers_workspace_halves(const NetDims& nd, uint32_t n) { return layers_t_halves(nd, n) + layers_part_halves(nd, n) + layers_bits_halves(nd, n); }
+struct LayerT { uint16_t *ET, *dOT, *HidT, *dHidT; float* partials; uint16_t* bits; };
 static LayerT layer_t(const NetDims& nd, uint16_t* ws, uint32_t n) {
     LayerT t; t.ET = ws; t.dOT = t.ET + (size_t)n * nd.Epad; t.HidT = t.dOT + (size_t)n * kOut; t.dHidT = t.HidT + (size_t)n * nd.NH * nd.W;
-    t.partials = reinterpret_cast<float*>(ws + layers_t_halves(nd, n)); return t; }
+    t.partials = reinterpret_cast<float*>(ws + layers_t_halves(nd, n)); t.bits = ws + layers_t_halves(nd, n) + layers_part_halves(nd, n); return t; }
 
 // parameter offsets: W0 [W][Epad] | W_1 .. W_{NH-1} [W][W] | W_out [4][W]  (kernels_net.hip / frag_layout.h)
 static size_t w_off(const NetDims& nd, int layer) { return layer == 0 ? 0 : (size_t)nd.W * nd.Epad + (size_t)(layer - 1) * nd.W * nd.W; }
@@ -341,12 +359,12 @@ void launch_pts_to_x4(hipStream_t s, const float* pts, float* x_all, uint32_t n,
 }
 
 bool launch_mlp_forward_layers(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n,
-        const DevState* st, uint16_t* ws_T, const uint16_t* e_soa, uint16_t* E_out) {
+        const DevState* st, uint16_t* ws_T, const uint16_t* e_soa, uint16_t* E_out, bool keep_rowmajor) {
     if (!layers_shape_ok(nd, n)) return false;
     LayerT t{}; if (ws_T && Hid) t = layer_t(nd, ws_T, n);
     auto H = [](const uint16_t* p) { return reinterpret_cast<const half_t*>(p); }; auto Hm = [](uint16_t* p) { return reinterpret_cast<half_t*>(p); };
 #define MON_FWD_ALL(E_, W_) hipLaunchKernelGGL((k_mlp_fwd_all<E_, W_>), dim3(layer_grid(n)), dim3(256), 0, s, H(params), nd.NH, H(E), Hm(Hid), Hm(O), Hm(t.ET), \
-        Hm(t.HidT), n, st, reinterpret_cast<const half2_t*>(e_soa), nd.L, Hm(E_out))
+        Hm(t.HidT), n, st, reinterpret_cast<const half2_t*>(e_soa), nd.L, Hm(E_out), (ws_T && Hid && !keep_rowmajor) ? t.bits : nullptr)
     MON_LAYERS_DISPATCH(MON_FWD_ALL);
 #undef MON_FWD_ALL
 }
@@ -356,7 +374,7 @@ bool launch_mlp_backward_layers(hipStream_t s, const NetDims& nd, const uint16_t
     const LayerT t = layer_t(nd, ws_T, n);
     auto H = [](const uint16_t* p) { return reinterpret_cast<const half_t*>(p); }; auto Hm = [](uint16_t* p) { return reinterpret_cast<half_t*>(p); };
 #define MON_BWD_ALL(E_, W_) hipLaunchKernelGGL((k_mlp_bwd_all<E_, W_>), dim3(layer_grid(n)), dim3(256), 0, s, H(params), nd.NH, H(Hid), H(dO), Hm(dHid), Hm(dE), \
-        Hm(t.dOT), Hm(t.dHidT), n, st, keep_rowmajor ? 1 : 0)
+        Hm(t.dOT), Hm(t.dHidT), n, st, keep_rowmajor ? 1 : 0, keep_rowmajor ? nullptr : t.bits)
     MON_LAYERS_DISPATCH(MON_BWD_ALL);
 #undef MON_BWD_ALL
 }

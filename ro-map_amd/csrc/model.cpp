@@ -847,9 +847,10 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_step_compaction(s, m.B, m.oc, m.d_state, m.d_step_counts, m.d_step_pts);
             hipMemcpyAsync(m.B.pts, m.d_step_pts, 12 * (size_t)B, hipMemcpyDeviceToDevice, s);
             launch_encode(s, m.lt, m.nd, m.P.half, m.B.pts, m.B.E, B, m.d_state);                             // :1545 forward of the compacted batch
+            // (this schedule's gradient scatter reads dE / dO row-major through tcnn-style atomics and is a checkable curiosity, not a fast path: row-major throughout)
             if (!(m.d_layers_T && launch_mlp_forward_layers(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state, m.d_layers_T)))
                 launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);
-            if (m.d_layers_T && launch_mlp_backward_layers(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state, m.d_layers_T, stages != 7))
+            if (m.d_layers_T && launch_mlp_backward_layers(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state, m.d_layers_T, true))
                 launch_weight_grads_layers(s, m.nd, m.P.gmlp, B, m.d_state, m.d_layers_T);
             else {
                 launch_mlp_backward(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state);          // :1547
@@ -870,10 +871,10 @@ static void enqueue_iteration(Model& m, int stages) {
             launch_encode(s, m.lt, m.nd, m.P.half, m.B.pts, m.B.E, B, m.d_state);
             // (shapes outside the fused kernels: whole-network MFMA kernels, kernels_layers.hip)
             if (tiles_b0) {
-                if (!launch_mlp_forward_layers(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state, m.d_layers_T, m.d_e_soa, m.B.E))
+                if (!launch_mlp_forward_layers(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state, m.d_layers_T, m.d_e_soa, m.B.E, stages != 7))
                     launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);         // (not reached: the shapes with a T workspace are the kernels' shapes)
             }
-            else if (!(m.d_layers_T && launch_mlp_forward_layers(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state, m.d_layers_T)))
+            else if (!(m.d_layers_T && launch_mlp_forward_layers(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state, m.d_layers_T, nullptr, nullptr, stages != 7)))
                 launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);
             launch_composite_grad(s, m.B, m.oc, m.d_state);
             if (m.d_layers_T && launch_mlp_backward_layers(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state, m.d_layers_T, stages != 7))

@@ -230,7 +230,10 @@ size_t layers_workspace_halves(const NetDims& nd, uint32_t n);
 bool launch_mlp_forward_layers(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n,
         const DevState* st_or_null, uint16_t* ws_T_or_null,
         // the features as k_encode_tiles wrote them ([L][n] half2) instead of row-major E; E_out: where the row-major copy goes
-        const uint16_t* e_soa_or_null = nullptr, uint16_t* E_out = nullptr);
+        const uint16_t* e_soa_or_null = nullptr, uint16_t* E_out = nullptr,
+        // false (whole steps): the activations go out in T layout + one ReLU mask bit each; row-major Hid is not written and launch_mlp_backward_layers must be
+        // called with keep_rowmajor = false too
+        bool keep_rowmajor = true);
 void launch_pts_to_x4(hipStream_t s, const float* pts, float* x_all, uint32_t n, DevState* st);
 bool launch_mlp_backward_layers(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE,
         uint32_t n, const DevState* st, uint16_t* ws_T,
