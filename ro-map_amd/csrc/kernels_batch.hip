@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) k_build_rays(BatchPtrs b, ObjectConst oc,
         total += prefix[64];
         __syncthreads();
     }
-    if (j == 0) { st->n_valid = total; st->loss_sum = 0.0f; }
+    if (j == 0) { st->n_valid = total; st->n_valid_pre = total; st->loss_sum = 0.0f; }      // (n_valid_pre: where k_encode_tiles looks for a skipped batch)
     if (total == 0u) return;                  // uniform across the grid
     const bool active = j < R;
     const uint32_t iter = st->iter;
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_build_rays(BatchPtrs b, ObjectConst oc,
 
 // One thread per sample (ray-major: sample s belongs to ray s / S).  :553-566
 __global__ void __launch_bounds__(256) k_gen_samples(BatchPtrs b, ObjectConst oc, const DevState* __restrict__ st, uint32_t S, uint32_t n_samples,
-                                                     uint32_t rng_stream, uint32_t idx_base, int render) {
+                                                     uint32_t rng_stream, uint32_t idx_base, int render, float4_t* __restrict__ x4 /* also as k_encode_tiles' float4 */) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_samples) return;
     if (!render && st->n_valid == 0u) return;
@@ -112,11 +112,13 @@ __global__ void __launch_bounds__(256) k_gen_samples(BatchPtrs b, ObjectConst oc
     const float t0 = b.ray_t0[j], t1 = b.ray_t1[j];
     const float dt = (t1 - t0) / (float)S;
     const float t = fmaf(dt, (float)n + (render ? render_rand(oc, idx_base + s) : batch_rand(oc, rng_stream, iter, idx_base + s)), t0);
+    float x[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float p = fmaf(t, b.ray_d[3 * j + a], b.ray_o[3 * j + a]);
-        b.pts[3 * s + a] = (p - oc.aabb.mn[a]) / (oc.aabb.mx[a] - oc.aabb.mn[a]);      // WarpPoint :140-144
+        x[a] = (p - oc.aabb.mn[a]) / (oc.aabb.mx[a] - oc.aabb.mn[a]); b.pts[3 * s + a] = x[a];      // WarpPoint :140-144
     }
+    if (x4) x4[s] = float4_t{ x[0], x[1], x[2], 0.f };
     b.tdist[s] = t;
 }
 
@@ -155,8 +157,9 @@ void launch_build_rays(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc,
     hipLaunchKernelGGL(k_build_rays, dim3((oc.R + 255) / 256), dim3(256), 0, s, b, oc, st);
 }
 void launch_gen_samples(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, const DevState* st, uint32_t S, uint32_t n_samples, uint32_t stream_id,
-        uint32_t idx_base, int render) {
-    hipLaunchKernelGGL(k_gen_samples, dim3((n_samples + 255) / 256), dim3(256), 0, s, b, oc, st, S, n_samples, stream_id, idx_base, render);
+        uint32_t idx_base, int render, float* x4) {
+    hipLaunchKernelGGL(k_gen_samples, dim3((n_samples + 255) / 256), dim3(256), 0, s, b, oc, st, S, n_samples, stream_id, idx_base, render,
+            reinterpret_cast<float4_t*>(x4));
 }
 void launch_render_rays(hipStream_t s, const BatchPtrs& b, const Intrinsics& K, const ObjectConst& oc, mon_frame_bbox box, const Mat4& pose, int pose_is_Toc,
         uint32_t pix0, uint32_t n) {

@@ -158,7 +158,8 @@ template <int EPAD, int W>
 __global__ void __launch_bounds__(256) k_mlp_bwd_all(const half_t* __restrict__ params, int NH, const half_t* __restrict__ Hid, const half_t* __restrict__ dO,
                                                      half_t* __restrict__ dHid, half_t* __restrict__ dE, half_t* __restrict__ dOT, half_t* __restrict__ dHidT,
                                                      uint32_t n, const DevState* __restrict__ st, int keep_rowmajor /* 0: nobody reads dHid row-major (whole steps) */,
-                                                     const uint16_t* __restrict__ relu_bits /* the forward pass's mask bits; nullptr: masks from row-major Hid */) {
+                                                     const uint16_t* __restrict__ relu_bits /* the forward pass's mask bits; nullptr: masks from row-major Hid */,
+                                                     BinsOut bins, int L) {
     constexpr int MB = (W + 31) / 32, KBW = W / 16, kMaxHid = W == 128 ? 1 : 3, kOffHid = W * 16, kOff0 = kOffHid + kMaxHid * W * W, kLds = kOff0 + EPAD * W;
     __shared__ __attribute__((aligned(16))) half_t wt[kLds];      // W_out^T [W][16] (columns 4..15 zero) | W_l^T [W][W], l = 1 .. NH-1 | W_0^T [EPAD][W]
     __shared__ __attribute__((aligned(16))) half_t tscr[4][32 * kTRow];
@@ -171,6 +172,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_all(const half_t* __restrict__ 
         for (int i = threadIdx.x; i < EPAD * W; i += 256) { const int k = i / W, u = i - k * W; wt[kOff0 + i] = params[u * EPAD + k]; }
     }
     __syncthreads();
+    if (bins.de_soa && blockIdx.x == 0u && threadIdx.x < bins.n_bins) bins.st->n_scatter[scatter_counter(bins.st->iter, threadIdx.x)] = n / bins.n_bins;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, h = lane >> 5, ld = NH * W;
     const uint32_t tiles = n >> 5;
     for (uint32_t t = blockIdx.x * 4u + (uint32_t)wave; t < tiles; t += gridDim.x * 4u) {
@@ -230,10 +232,23 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_all(const half_t* __restrict__ 
 #pragma unroll
             for (int kb = 0; kb < KBW; ++kb) { half8_t a = {}; if (m < EPAD) a = frag_a_perm(wt + kOff0 + m * W, kb, h);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, db[kb], acc, 0, 0, 0); }
+            if (bins.de_soa) {
+                // k_rows_to_bins folded in (S = 32: tile t is ray t): the ray's bin is t & (bins - 1), the sample's slot (t / bins) * 32 + its number in the ray;
+                // the half4 at features 4 h + 8 q holds levels 2 h + 4 q and 2 h + 4 q + 1
+                const uint32_t slot = (t & (bins.n_bins - 1u)) * (n / bins.n_bins) + (t / bins.n_bins) * 32u + (uint32_t)m;
+                half2_t* de = reinterpret_cast<half2_t*>(bins.de_soa);
+                const auto cl = [&](float v) { return (half_t)clamp_f((float)(half_t)v, -bins.clampv, bins.clampv); };
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int l0 = 2 * h + 4 * q;
+                    if (l0 < L) de[(size_t)l0 * n + slot] = half2_t{ cl(acc[4 * q]), cl(acc[4 * q + 1]) };
+                    if (l0 + 1 < L) de[(size_t)(l0 + 1) * n + slot] = half2_t{ cl(acc[4 * q + 2]), cl(acc[4 * q + 3]) }; }
+                if (h == 0) reinterpret_cast<float4_t*>(bins.x_soa)[slot] = float4_t{ bins.pts[3 * (size_t)s], bins.pts[3 * (size_t)s + 1], bins.pts[3 * (size_t)s + 2], 0.f };
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { const int k0 = 4 * h + 8 * q; if (k0 >= EPAD) continue;
                 *reinterpret_cast<half4_t*>(dE + (size_t)s * EPAD + k0) = half4_t{ (half_t)acc[4 * q], (half_t)acc[4 * q + 1], (half_t)acc[4 * q + 2],
                         (half_t)acc[4 * q + 3] }; }
+            }
         }
     }
 }
@@ -348,16 +363,6 @@ static size_t w_off(const NetDims& nd, int layer) { return layer == 0 ? 0 : (siz
         case 32064: { CALL(32, 64); return true; } case 32128: { CALL(32, 128); return true; } default: return false; } } while (0)
 static bool layers_shape_ok(const NetDims& nd, uint32_t n) { return nd.W <= kLayerMaxW && (n & 31u) == 0u && nd.NH >= 1 && nd.NH <= (nd.W == 128 ? 2 : 4); }
 
-// backend 0's positions float [n][3] -> k_encode_tiles' float4 x_all, and the batch's ray count where k_encode_tiles looks for it
-__global__ void __launch_bounds__(256) k_pts_to_x4(const float* __restrict__ pts, float4_t* __restrict__ x4, uint32_t n, DevState* __restrict__ st) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0u) st->n_valid_pre = st->n_valid;
-    if (i < n) x4[i] = float4_t{ pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], 0.f };
-}
-void launch_pts_to_x4(hipStream_t s, const float* pts, float* x_all, uint32_t n, DevState* st) {
-    hipLaunchKernelGGL(k_pts_to_x4, dim3((n + 255u) / 256u), dim3(256), 0, s, pts, reinterpret_cast<float4_t*>(x_all), n, st);
-}
-
 bool launch_mlp_forward_layers(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* E, uint16_t* Hid, uint16_t* O, uint32_t n,
         const DevState* st, uint16_t* ws_T, const uint16_t* e_soa, uint16_t* E_out, bool keep_rowmajor) {
     if (!layers_shape_ok(nd, n)) return false;
@@ -369,12 +374,13 @@ bool launch_mlp_forward_layers(hipStream_t s, const NetDims& nd, const uint16_t*
 #undef MON_FWD_ALL
 }
 bool launch_mlp_backward_layers(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE,
-        uint32_t n, const DevState* st, uint16_t* ws_T, bool keep_rowmajor) {
+        uint32_t n, const DevState* st, uint16_t* ws_T, bool keep_rowmajor, const BinsOut* bins) {
     if (!layers_shape_ok(nd, n) || !ws_T) return false;
+    const BinsOut bo = bins ? *bins : BinsOut{};
     const LayerT t = layer_t(nd, ws_T, n);
     auto H = [](const uint16_t* p) { return reinterpret_cast<const half_t*>(p); }; auto Hm = [](uint16_t* p) { return reinterpret_cast<half_t*>(p); };
 #define MON_BWD_ALL(E_, W_) hipLaunchKernelGGL((k_mlp_bwd_all<E_, W_>), dim3(layer_grid(n)), dim3(256), 0, s, H(params), nd.NH, H(Hid), H(dO), Hm(dHid), Hm(dE), \
-        Hm(t.dOT), Hm(t.dHidT), n, st, keep_rowmajor ? 1 : 0, keep_rowmajor ? nullptr : t.bits)
+        Hm(t.dOT), Hm(t.dHidT), n, st, keep_rowmajor ? 1 : 0, keep_rowmajor ? nullptr : t.bits, bo, nd.L)
     MON_LAYERS_DISPATCH(MON_BWD_ALL);
 #undef MON_BWD_ALL
 }

@@ -829,7 +829,8 @@ static void enqueue_iteration(Model& m, int stages) {
         else launch_gen_candidates(s, m.B, m.ds->ptrs(), m.oc, m.d_state);
         if (m.backend == 0) {                       // the fused kernel compacts the rays itself
             launch_build_rays(s, m.B, m.oc, m.d_state);
-            launch_gen_samples(s, m.B, m.oc, m.d_state, m.oc.S, B, kStreamDt, 0u, 0);
+            // (the layer-kernel shapes on the level-tile encode: the positions also as k_encode_tiles' float4)
+            launch_gen_samples(s, m.B, m.oc, m.d_state, m.oc.S, B, kStreamDt, 0u, 0, (m.d_layers_T && m.d_e_soa && m.d_half_tiles) ? m.d_x_all : nullptr);
         }
     }
     // whole steps of a shape outside the fused kernels scatter through k_rows_to_bins -> k_grid_scatter into partial tables that the DENSE optimizer sums; the
@@ -865,7 +866,6 @@ static void enqueue_iteration(Model& m, int stages) {
             const bool tiles_b0 = m.d_layers_T && m.d_e_soa && m.d_half_tiles && options().lds_encode != 0;
             if (tiles_b0) {
                 if (!m.b0_tiles_current) { launch_build_tiles_image(s, m.lf, m.nd, m.P.half, m.d_half_tiles); m.b0_tiles_current = true; }
-                launch_pts_to_x4(s, m.B.pts, m.d_x_all, B, m.d_state);
                 launch_encode_tiles(s, m.lf, m.nd, m.d_half_tiles, m.d_x_all, m.d_e_soa, B, m.d_state, nullptr, m.ds->ptrs(), m.oc);
             } else
             launch_encode(s, m.lt, m.nd, m.P.half, m.B.pts, m.B.E, B, m.d_state);
@@ -877,8 +877,13 @@ static void enqueue_iteration(Model& m, int stages) {
             else if (!(m.d_layers_T && launch_mlp_forward_layers(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state, m.d_layers_T, nullptr, nullptr, stages != 7)))
                 launch_mlp_forward(s, m.nd, m.P.half, m.B.E, m.B.Hid, m.B.O, B, m.d_state);
             launch_composite_grad(s, m.B, m.oc, m.d_state);
-            if (m.d_layers_T && launch_mlp_backward_layers(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state, m.d_layers_T, stages != 7))
-                launch_weight_grads_layers(s, m.nd, m.P.gmlp, B, m.d_state, m.d_layers_T);
+            // (whole steps of the hybrid scatter with S = 32: the backward kernel writes k_grid_scatter's hand-over itself)
+            const bool fold_bins = hybrid && m.d_layers_T && m.oc.S == 32u;
+            const BinsOut bins{ m.d_de_soa, m.d_x_soa, m.B.pts, m.n_bins, m.lf.fix_clamp, m.d_state };
+            bool bins_done = false;
+            if (m.d_layers_T && launch_mlp_backward_layers(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state, m.d_layers_T, stages != 7,
+                    fold_bins ? &bins : nullptr)) {
+                launch_weight_grads_layers(s, m.nd, m.P.gmlp, B, m.d_state, m.d_layers_T); bins_done = fold_bins; }
             else {
                 launch_mlp_backward(s, m.nd, m.P.half, m.B.Hid, m.B.dO, m.B.dHid, m.B.dE, B, m.d_state);
                 launch_weight_grads(s, m.nd, m.B.E, m.B.Hid, m.B.dHid, m.B.dO, m.P.gmlp, B, m.d_state);
@@ -886,7 +891,7 @@ static void enqueue_iteration(Model& m, int stages) {
             // whole steps of a shape outside the fused kernels: the exact LDS scatter (partial tables, summed by the optimizer).  Stage-wise calls (the debugging
             // entry that stops before the optimizer) keep tcnn's global atomics into ggrid, which only the non-dense optimizer clears: start from zeros there
             if (hybrid) {
-                launch_rows_to_bins(s, m.lf, m.nd, m.B.dE, m.B.pts, m.oc.R, m.oc.S, m.n_bins, m.d_de_soa, m.d_x_soa, m.d_state);
+                if (!bins_done) launch_rows_to_bins(s, m.lf, m.nd, m.B.dE, m.B.pts, m.oc.R, m.oc.S, m.n_bins, m.d_de_soa, m.d_x_soa, m.d_state);
                 launch_grid_scatter(s, m.lt, m.lf, m.nd, m.d_de_soa, m.d_x_soa, B, m.n_bins, m.d_gpart, m.part_halves / 2, m.d_state, nullptr, 0u, m.P.gmlp,
                         m.d_state_next);
             } else {

@@ -207,7 +207,7 @@ int set_logical_devices(int n);
 void launch_gen_candidates(hipStream_t s, const BatchPtrs& b, const DatasetPtrs& ds, const ObjectConst& oc, const DevState* st);
 void launch_build_rays(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, DevState* st);
 void launch_gen_samples(hipStream_t s, const BatchPtrs& b, const ObjectConst& oc, const DevState* st, uint32_t S, uint32_t n_samples, uint32_t stream_id,
-        uint32_t idx_base, int render);
+        uint32_t idx_base, int render, float* x4_or_null = nullptr);
 void launch_render_rays(hipStream_t s, const BatchPtrs& b, const Intrinsics& K, const ObjectConst& oc, mon_frame_bbox box, const Mat4& pose, int pose_is_Toc,
         uint32_t pix0, uint32_t n);
 void launch_grid_points(hipStream_t s, float* pts, int rx, int ry, int rz, uint32_t p0, uint32_t n);
@@ -234,10 +234,13 @@ bool launch_mlp_forward_layers(hipStream_t s, const NetDims& nd, const uint16_t*
         // false (whole steps): the activations go out in T layout + one ReLU mask bit each; row-major Hid is not written and launch_mlp_backward_layers must be
         // called with keep_rowmajor = false too
         bool keep_rowmajor = true);
-void launch_pts_to_x4(hipStream_t s, const float* pts, float* x_all, uint32_t n, DevState* st);
 bool launch_mlp_backward_layers(hipStream_t s, const NetDims& nd, const uint16_t* params, const uint16_t* Hid, const uint16_t* dO, uint16_t* dHid, uint16_t* dE,
         uint32_t n, const DevState* st, uint16_t* ws_T,
-        bool keep_rowmajor = true /* false: dHid is written in T layout only -- the weight gradients' copy; the debug read-back then sees stale rows */);
+        bool keep_rowmajor = true /* false: dHid is written in T layout only -- the weight gradients' copy; the debug read-back then sees stale rows */,
+        // != nullptr (whole steps of the hybrid scatter): dL/dE and the positions go straight into k_grid_scatter's hand-over layout (what k_rows_to_bins writes:
+        // every sample at its natural slot of its ray's bin, every bin counter = its capacity) instead of row-major dE
+        const struct BinsOut* bins = nullptr);
+struct BinsOut { uint16_t* de_soa; float* x_soa; const float* pts; uint32_t n_bins; float clampv; DevState* st; };
 void launch_weight_grads_layers(hipStream_t s, const NetDims& nd, float* gmlp, uint32_t n, const DevState* st, uint16_t* ws_T);
 struct Model;
 // inference forward of n samples E -> O with the layer kernels where the object has them (Hid of the training batch as scratch, piece by piece), else k_mlp_forward
